@@ -1,0 +1,149 @@
+/* msde_hip.h — C ABI of libmsde_hip.so, the MI355X (gfx950) kernels behind the MoleculeSDE
+ * pretrain hot path.
+ *
+ * The reference (chao1224/MoleculeSDE) has NO FFI/plugin layer of its own: its hot path reaches
+ * native code only through third-party wheels (PyG / torch-scatter / torch-cluster).  Each entry
+ * point below therefore cites the *reference call site* (path relative to the reference root) whose
+ * native work it replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a positive hipError_t on a HIP failure, or a negative
+ *     MSDE_E* code on an argument error; nothing throws, nothing synchronises, nothing allocates;
+ *   - the caller owns every buffer (device pointers), all fp32 row-major contiguous, indices int32;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*), safe for hipGraph capture;
+ *   - graphs are CSR sorted by TARGET node: rowptr[N+1], src[E] ("canonical edge order"); the
+ *     transposed view is rowptr_s[N+1] + perm_s[E] (by-source slot -> canonical edge id);
+ *   - E may be an upper bound: kernels that walk rowptr never touch the padded tail.
+ */
+#ifndef MSDE_HIP_H
+#define MSDE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSDE_EINVAL (-1) /* bad size / null pointer */
+#define MSDE_EUNSUP (-2) /* unsupported shape for this kernel */
+
+/* library identification: returns the ABI version (monotonic integer) */
+int msde_abi_version(void);
+/* name of the code-object target the library was built for ("gfx950") */
+const char* msde_target_arch(void);
+
+/* ------------------------------------------------------------------ graph construction ----- */
+/* torch_cluster.radius via PyG radius_graph — Geom3D/models/schnet.py:91.
+ * count: deg[i] = #{j in molecule(i), j != i, |p_i-p_j|^2 < r2}, capped at max_nbr (index order). */
+int msde_radius_count(const float* pos, const int* batch, const int* mol_ptr, int N, float r2,
+                      int max_nbr, int* deg, void* stream);
+/* exclusive scan: out[0]=0, out[i+1]=out[i]+in[i]  (n <= 2^24; single workgroup, LDS scan) */
+int msde_exclusive_scan_i32(const int* in, int* out, int n, void* stream);
+/* fill: src[rowptr[i]+k] = k-th neighbour of i (index order), dst[..]=i, dist[..]=|p_i-p_j|
+ * (schnet.py:92-93).  Slots in [rowptr[N], E_cap) get src=dst=N_sentinel(-1), dist=0. */
+int msde_radius_fill(const float* pos, const int* batch, const int* mol_ptr, int N, float r2,
+                     int max_nbr, const int* rowptr, int* src, int* dst, float* dist, int E_cap,
+                     void* stream);
+
+/* ------------------------------------------------------------------ generic row ops -------- */
+/* torch_scatter.scatter(reduce=sum) over CSR rows: out[i] = sum_{s in [rowptr[i],rowptr[i+1])}
+ * rows[perm ? perm[s] : s]; used for every backward "gather by source/target".  D % 4 == 0 or any. */
+int msde_segment_sum_rows(const float* rows, const int* rowptr, const int* perm, int N, int D,
+                          float scale_by_inv_count, float* out, void* stream);
+/* out[e] = A[src[e]] + B[dst[e]] (+ bias) for e < E; rows with src<0 are zero-filled.
+ * SDE_model_2D_to_3D.py:346-347 (factored cat+Linear), equivariant_scorenetwork.py:154-155 */
+int msde_pair_gather_add(const float* A, const float* B, const int* src, const int* dst, int E,
+                         int D, float* out, void* stream);
+/* out[e] = X[idx[e]] (row gather), idx<0 -> zeros */
+int msde_gather_rows(const float* X, const int* idx, int E, int D, float* out, void* stream);
+
+/* ------------------------------------------------------------------ embeddings ------------- */
+/* ogb AtomEncoder/BondEncoder, nn.Embedding — molecule_gnn_model.py:171, schnet.py:89.
+ * codes[i*K+k] already offset into the concatenated table tab[R,D]. */
+int msde_embedding_sum_fwd(const float* tab, const int* codes, int N, int K, int D, float* out,
+                           void* stream);
+/* g_tab[r] += sum over list(r) of g[node]; lists given as CSR (list_ptr[R+1], list_nodes[..]);
+ * g_tab must be zero-initialised by the caller; SPLIT partial sums are combined with atomics. */
+int msde_embedding_sum_bwd(const float* g, const int* list_ptr, const int* list_nodes, int R,
+                           int D, int split, float* g_tab, void* stream);
+
+/* ------------------------------------------------------------------ GIN -------------------- */
+/* GINConv.forward/message — molecule_gnn_model.py:22-29:
+ * out[i] = (1+eps)*x[i] + sum_{e in in(i)} relu(x[src[e]] + sum_k tab[codes[e*3+k]]) */
+int msde_gin_aggregate_fwd(const float* x, const float* tab, const int* codes, const float* eps,
+                           const int* rowptr, const int* src, int N, int D, float* out,
+                           void* stream);
+/* g_x[j] = (1+eps)*g[j] + sum_{e in out(j)} g[dst[e]] * [x[j]+emb_e > 0]   (by-source CSR) */
+int msde_gin_aggregate_bwd_x(const float* g, const float* x, const float* tab, const int* codes,
+                             const float* eps, const int* rowptr_s, const int* perm_s,
+                             const int* dst, int N, int D, float* g_x, void* stream);
+/* g_tab[code] += g[dst]*mask (LDS-privatised, atomics on flush); g_eps += sum g*x.
+ * g_tab [R,D] and g_eps[1] zero-initialised by the caller. R*D*4 must fit LDS (<= 64 KiB). */
+int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab, const int* codes,
+                               const int* rowptr, const int* src, int N, int D, int R,
+                               float* g_tab, float* g_eps, void* stream);
+
+/* ------------------------------------------------------------------ SchNet ----------------- */
+/* GaussianSmearing + cosine cutoff — schnet.py:186,205-207: rbf[e,g]=exp(coeff*(d-offset[g])^2),
+ * C[e]=0.5(cos(d*pi/cutoff)+1); padded rows (e >= E_dev[0]) are zero. */
+int msde_rbf_cutoff_fwd(const float* dist, const int* E_dev, int E_cap, int G,
+                        const float* offset, float coeff, float cutoff, float* rbf, float* C,
+                        void* stream);
+/* CFConv.message + aggregate — schnet.py:190,194-195: agg[i] = sum_e x1[src[e]] * Wf[e] * C[e] */
+int msde_cfconv_aggregate_fwd(const float* x1, const float* Wf, const float* C, const int* rowptr,
+                              const int* src, int N, int F, float* agg, void* stream);
+/* g_Wf[e] = g_agg[dst[e]] * x1[src[e]] * C[e]   (rows e >= rowptr[N] zero-filled up to E_cap) */
+int msde_cfconv_aggregate_bwd_w(const float* g_agg, const float* x1, const float* C,
+                                const int* rowptr, const int* src, int N, int F, int E_cap,
+                                float* g_Wf, void* stream);
+/* g_x1[j] = sum_{e in out(j)} g_agg[dst[e]] * Wf[e] * C[e] */
+int msde_cfconv_aggregate_bwd_x(const float* g_agg, const float* Wf, const float* C,
+                                const int* rowptr_s, const int* perm_s, const int* dst, int N,
+                                int F, float* g_x1, void* stream);
+/* Fused CFConv forward (inference / no-grad and the roofline kernel): RBF + filter MLP
+ * (Linear(G,F) -> ShiftedSoftplus -> Linear(F,F)) + cutoff + gather + segmented sum, fp32 MFMA.
+ * schnet.py:141-145,185-195.  F must be 128, G <= 64.  W1 [F,G], b1 [F], W2 [F,F], b2 [F]. */
+int msde_cfconv_fused_fwd(const float* x1, const float* dist, const int* rowptr, const int* src,
+                          const int* dst, const float* W1, const float* b1, const float* W2,
+                          const float* b2, const float* offset, int N, int F, int G, float coeff,
+                          float cutoff, int nodes_per_wg, float* agg, void* stream);
+
+/* ------------------------------------------------------------------ 2D->3D score net ------- */
+/* coord2basis / get_perturb_distance / GaussianFourierProjection / pseudo-angle —
+ * SDE_model_2D_to_3D.py:35-66,342-369.  Outputs per edge (canonical order):
+ * feat_d [E,2C] = [sin,cos](2pi d Wd); feat_i/feat_j [E,4C] = Fourier of frame coords 0 and 2 of
+ * r_i (source) / r_j (target); angle [E,2] = (pseudo_sin, pseudo_cos); basis [E,9]. */
+int msde_edge_geometry_fwd(const float* pos, const int* src, const int* dst, int E,
+                           const float* Wd, const float* Wc, int C, float* feat_d, float* feat_i,
+                           float* feat_j, float* angle, float* basis, void* stream);
+/* PyG TransformerConv message+softmax+aggregate — equivariant_scorenetwork.py:18-24,35:
+ * s[e,h] = q[dst]·(k[src]+ee[e]) / sqrt(Ch); alpha = softmax over in-edges of dst;
+ * out[i] = sum_e dropout(alpha)[e,h] * (v[src]+ee[e]).  H*Ch == D <= 64.  alpha [E,H] is saved. */
+int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* ee,
+                            const int* rowptr, const int* src, int N, int H, int Ch,
+                            float p_drop, unsigned long long seed, float* alpha, float* out,
+                            void* stream);
+/* backward of the above: writes g_q [N,D], g_ee [E,D] and the per-edge grads g_kpe/g_vpe [E,D]
+ * (to be segment-summed by source into g_k / g_v with msde_segment_sum_rows). */
+int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v,
+                            const float* ee, const float* alpha, const int* rowptr,
+                            const int* src, int N, int H, int Ch, float p_drop,
+                            unsigned long long seed, float* g_q, float* g_ee, float* g_kpe,
+                            float* g_vpe, void* stream);
+/* basis mix + EquiLayer mean — equivariant_scorenetwork.py:159-164:
+ * out[i] = mean_{e in in(i)} (c0*b_diff + c1*b_cross + c2*b_vert) */
+int msde_frame_mix_mean_fwd(const float* coff, const float* basis, const int* rowptr, int N,
+                            float* out, void* stream);
+int msde_frame_mix_mean_bwd(const float* g_out, const float* basis, const int* rowptr, int N,
+                            int E_cap, float* g_coff, void* stream);
+
+/* ------------------------------------------------------------------ optimiser -------------- */
+/* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —
+ * examples/pretrain_MoleculeSDE.py:331-337,156.  seg_end[S] (exclusive ends), seg_lr[S].
+ * step_dev[0] holds the 1-based step count (device int, incremented by the kernel's caller). */
+int msde_adam_flat(float* p, const float* g, float* m, float* v, long long n, const int* step_dev,
+                   const long long* seg_end, const float* seg_lr, int S, float beta1, float beta2,
+                   float eps, float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSDE_HIP_H */

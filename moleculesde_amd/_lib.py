@@ -1,0 +1,78 @@
+"""ctypes binding of libmsde_hip.so (include/msde_hip.h).  No torch types cross this boundary: only
+raw device pointers, sizes and the HIP stream handle.  Fails loudly if the library is missing --
+there is no CPU fallback anywhere in moleculesde_amd."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmsde_hip.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+F = ctypes.c_float
+LL = ctypes.c_longlong
+ULL = ctypes.c_ulonglong
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "msde_abi_version": [],
+    "msde_target_arch": [],
+    "msde_radius_count": [P, P, P, I, F, I, P, P],
+    "msde_exclusive_scan_i32": [P, P, I, P],
+    "msde_radius_fill": [P, P, P, I, F, I, P, P, P, P, I, P],
+    "msde_segment_sum_rows": [P, P, P, I, I, F, P, P],
+    "msde_pair_gather_add": [P, P, P, P, I, I, P, P],
+    "msde_gather_rows": [P, P, I, I, P, P],
+    "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
+    "msde_embedding_sum_bwd": [P, P, P, I, I, I, P, P],
+    "msde_gin_aggregate_fwd": [P, P, P, P, P, P, I, I, P, P],
+    "msde_gin_aggregate_bwd_x": [P, P, P, P, P, P, P, P, I, I, P, P],
+    "msde_gin_aggregate_bwd_tab": [P, P, P, P, P, P, I, I, I, P, P, P],
+    "msde_rbf_cutoff_fwd": [P, P, I, I, P, F, F, P, P, P],
+    "msde_cfconv_aggregate_fwd": [P, P, P, P, P, I, I, P, P],
+    "msde_cfconv_aggregate_bwd_w": [P, P, P, P, P, I, I, I, P, P],
+    "msde_cfconv_aggregate_bwd_x": [P, P, P, P, P, P, I, I, P, P],
+    "msde_cfconv_fused_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, P],
+    "msde_edge_geometry_fwd": [P, P, P, I, P, P, I, P, P, P, P, P, P],
+    "msde_edge_attention_fwd": [P, P, P, P, P, P, I, I, I, F, ULL, P, P, P],
+    "msde_edge_attention_bwd": [P, P, P, P, P, P, P, P, I, I, I, F, ULL, P, P, P, P, P],
+    "msde_frame_mix_mean_fwd": [P, P, P, I, P, P],
+    "msde_frame_mix_mean_bwd": [P, P, P, I, I, P, P],
+    "msde_adam_flat": [P, P, P, P, LL, P, P, P, I, F, F, F, F, F, P],
+}
+_RESTYPE = {"msde_target_arch": ctypes.c_char_p}
+
+_lib = None
+
+
+class MsdeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsdeHipError(
+            f"{LIB_PATH} not found: build it with `python -m moleculesde_amd.build` "
+            "(hipcc --offload-arch=gfx950).  moleculesde_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def check(code, name):
+    if code != 0:
+        kind = "argument error" if code < 0 else "hipError_t"
+        raise MsdeHipError(f"{name} failed: {kind} {code}")
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

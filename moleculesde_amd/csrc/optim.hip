@@ -1,0 +1,42 @@
+// optim.hip — Adam over one flat fp32 parameter buffer (examples/pretrain_MoleculeSDE.py:331-337,156).
+// torch.optim.Adam (no amsgrad) semantics:
+//   g += wd * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+#include "msde_common.h"
+
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, long long n, const int* __restrict__ step_dev,
+                                 const long long* __restrict__ seg_end, const float* __restrict__ seg_lr, int S,
+                                 float beta1, float beta2, float eps, float wd, float grad_scale) {
+  int t = step_dev[0];
+  float bc1 = 1.f - powf(beta1, (float)t);
+  float bc2 = 1.f - powf(beta2, (float)t);
+  float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    int s = 0;
+    while (s < S - 1 && i >= seg_end[s]) ++s;
+    float lr = seg_lr[s];
+    float pi = p[i];
+    float gi = g[i] * grad_scale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+extern "C" int msde_adam_flat(float* p, const float* g, float* m, float* v, long long n, const int* step_dev,
+                              const long long* seg_end, const float* seg_lr, int S, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, void* stream) {
+  if (n < 0 || S <= 0 || !p || !g || !m || !v || !step_dev || !seg_end || !seg_lr) return MSDE_EINVAL;
+  if (n == 0) return 0;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, step_dev,
+                     seg_end, seg_lr, S, beta1, beta2, eps, weight_decay, grad_scale);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,289 @@
+// sde2d3d.hip — kernels of the 2D->3D equivariant score network (SDE_model_2D_to_3D.py,
+// equivariant_scorenetwork.py): per-edge SE(3) frame + Fourier features, edge-featured multi-head
+// attention with per-target softmax (PyG TransformerConv), frame mix + mean scatter.
+#include "msde_common.h"
+
+#define MSDE_EPS 1e-6f
+
+// one thread per (edge, fourier channel c); every thread rebuilds the (cheap) frame in registers
+__global__ void edge_geometry_fwd_kernel(const float* __restrict__ pos, const int* __restrict__ src,
+                                         const int* __restrict__ dst, int E, const float* __restrict__ Wd,
+                                         const float* __restrict__ Wc, int C, float* __restrict__ feat_d,
+                                         float* __restrict__ feat_i, float* __restrict__ feat_j,
+                                         float* __restrict__ angle, float* __restrict__ basis) {
+  const float PI_F = 3.14159265358979323846f;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)E * C) return;
+  int e = (int)(t / C), c = (int)(t % C);
+  int r = src[e], q = dst[e];  // row = edge_index[0] (source), col = edge_index[1] (target)
+  float prx = pos[3 * r], pry = pos[3 * r + 1], prz = pos[3 * r + 2];
+  float pcx = pos[3 * q], pcy = pos[3 * q + 1], pcz = pos[3 * q + 2];
+  // coord2basis (SDE_model_2D_to_3D.py:35-47)
+  float dx = prx - pcx, dy = pry - pcy, dz = prz - pcz;
+  float radial = dx * dx + dy * dy + dz * dz;
+  float cx = pry * pcz - prz * pcy, cy = prz * pcx - prx * pcz, cz = prx * pcy - pry * pcx;
+  float dist = sqrtf(radial);
+  float norm = dist + MSDE_EPS;
+  dx /= norm; dy /= norm; dz /= norm;
+  float cnorm = sqrtf(cx * cx + cy * cy + cz * cz) + MSDE_EPS;
+  cx /= cnorm; cy /= cnorm; cz /= cnorm;
+  float vx = dy * cz - dz * cy, vy = dz * cx - dx * cz, vz = dx * cy - dy * cx;
+  // frame coordinates of both endpoints (:357-360)
+  float ci0 = dx * prx + dy * pry + dz * prz;
+  float ci1 = fabsf(cx * prx + cy * pry + cz * prz);
+  float ci2 = vx * prx + vy * pry + vz * prz;
+  float cj0 = dx * pcx + dy * pcy + dz * pcz;
+  float cj1 = fabsf(cx * pcx + cy * pcy + cz * pcz);
+  float cj2 = vx * pcx + vy * pcy + vz * pcz;
+  if (c == 0) {
+    float mul = ci0 * cj0 + ci1 * cj1 + ci2 * cj2;
+    float ni = sqrtf(ci0 * ci0 + ci1 * ci1 + ci2 * ci2);
+    float nj = sqrtf(cj0 * cj0 + cj1 * cj1 + cj2 * cj2);
+    float pcos = mul / (ni + MSDE_EPS) / (nj + MSDE_EPS);
+    float psin = sqrtf(1.f - pcos * pcos);
+    angle[2 * (size_t)e] = psin;
+    angle[2 * (size_t)e + 1] = pcos;
+    float* b = basis + 9 * (size_t)e;
+    b[0] = dx; b[1] = dy; b[2] = dz; b[3] = cx; b[4] = cy; b[5] = cz; b[6] = vx; b[7] = vy; b[8] = vz;
+  }
+  // GaussianFourierProjection (:57-66): x * W * 2 * pi, in that order
+  float wd = Wd[c], wc = Wc[c];
+  float a = ((dist * wd) * 2.f) * PI_F;
+  float* fd = feat_d + (size_t)e * 2 * C;
+  fd[c] = sinf(a);
+  fd[C + c] = cosf(a);
+  float* fi = feat_i + (size_t)e * 4 * C;
+  float* fj = feat_j + (size_t)e * 4 * C;
+  float a0 = ((ci0 * wc) * 2.f) * PI_F, a2 = ((ci2 * wc) * 2.f) * PI_F;
+  fi[c] = sinf(a0); fi[C + c] = cosf(a0); fi[2 * C + c] = sinf(a2); fi[3 * C + c] = cosf(a2);
+  float b0 = ((cj0 * wc) * 2.f) * PI_F, b2 = ((cj2 * wc) * 2.f) * PI_F;
+  fj[c] = sinf(b0); fj[C + c] = cosf(b0); fj[2 * C + c] = sinf(b2); fj[3 * C + c] = cosf(b2);
+}
+
+extern "C" int msde_edge_geometry_fwd(const float* pos, const int* src, const int* dst, int E, const float* Wd,
+                                      const float* Wc, int C, float* feat_d, float* feat_i, float* feat_j,
+                                      float* angle, float* basis, void* stream) {
+  if (E < 0 || C <= 0 || !pos || !src || !dst || !Wd || !Wc || !feat_d || !feat_i || !feat_j || !angle || !basis)
+    return MSDE_EINVAL;
+  if (E == 0) return 0;
+  size_t total = (size_t)E * C;
+  hipLaunchKernelGGL(edge_geometry_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     pos, src, dst, E, Wd, Wc, C, feat_d, feat_i, feat_j, angle, basis);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge attention: one thread per (target node, head); CH channels per head kept in registers.
+// ------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                          const float* __restrict__ v, const float* __restrict__ ee,
+                                          const int* __restrict__ rowptr, const int* __restrict__ src, int N, int H,
+                                          float p_drop, unsigned long long seed, float* __restrict__ alpha,
+                                          float* __restrict__ out) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * H) return;
+  int i = t / H, h = t % H;
+  const int D = H * CH;
+  float qv[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) qv[c] = q[(size_t)i * D + h * CH + c];
+  const float scale = 1.f / sqrtf((float)CH);
+  int s0 = rowptr[i], s1 = rowptr[i + 1];
+  float m = -INFINITY;
+  for (int e = s0; e < s1; ++e) {
+    const float* kr = k + (size_t)src[e] * D + h * CH;
+    const float* er = ee + (size_t)e * D + h * CH;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) s += qv[c] * (kr[c] + er[c]);
+    s *= scale;
+    alpha[(size_t)e * H + h] = s;
+    m = fmaxf(m, s);
+  }
+  float sum = 0.f;
+  for (int e = s0; e < s1; ++e) {
+    float p = expf(alpha[(size_t)e * H + h] - m);
+    alpha[(size_t)e * H + h] = p;
+    sum += p;
+  }
+  float inv = 1.f / (sum + 1e-16f);
+  float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  float acc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+  for (int e = s0; e < s1; ++e) {
+    float a = alpha[(size_t)e * H + h] * inv;
+    alpha[(size_t)e * H + h] = a;
+    if (p_drop > 0.f) a = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? a * keep_scale : 0.f;
+    const float* vr = v + (size_t)src[e] * D + h * CH;
+    const float* er = ee + (size_t)e * D + h * CH;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = fmaf(a, vr[c] + er[c], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < CH; ++c) out[(size_t)i * D + h * CH + c] = acc[c];
+}
+
+template <int CH>
+__global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ q,
+                                          const float* __restrict__ k, const float* __restrict__ v,
+                                          const float* __restrict__ ee, const float* __restrict__ alpha,
+                                          const int* __restrict__ rowptr, const int* __restrict__ src, int N, int H,
+                                          float p_drop, unsigned long long seed, float* __restrict__ g_q,
+                                          float* __restrict__ g_ee, float* __restrict__ g_kpe,
+                                          float* __restrict__ g_vpe) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * H) return;
+  int i = t / H, h = t % H;
+  const int D = H * CH;
+  float qv[CH], go[CH], gq[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    qv[c] = q[(size_t)i * D + h * CH + c];
+    go[c] = g_out[(size_t)i * D + h * CH + c];
+    gq[c] = 0.f;
+  }
+  const float scale = 1.f / sqrtf((float)CH);
+  float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  int s0 = rowptr[i], s1 = rowptr[i + 1];
+  // pass 1: g_vpe, and dsum = sum_e alpha_e * g_alpha_e
+  float dsum = 0.f;
+  for (int e = s0; e < s1; ++e) {
+    float a = alpha[(size_t)e * H + h];
+    float ms = 1.f;
+    if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
+    const float* vr = v + (size_t)src[e] * D + h * CH;
+    const float* er = ee + (size_t)e * D + h * CH;
+    float ga = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      ga = fmaf(go[c], vr[c] + er[c], ga);
+      g_vpe[(size_t)e * D + h * CH + c] = go[c] * (a * ms);
+    }
+    dsum = fmaf(a, ga * ms, dsum);
+  }
+  // pass 2: softmax backward, g_q, g_kpe, g_ee
+  for (int e = s0; e < s1; ++e) {
+    float a = alpha[(size_t)e * H + h];
+    float ms = 1.f;
+    if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
+    const float* vr = v + (size_t)src[e] * D + h * CH;
+    const float* kr = k + (size_t)src[e] * D + h * CH;
+    const float* er = ee + (size_t)e * D + h * CH;
+    float ga = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) ga = fmaf(go[c], vr[c] + er[c], ga);
+    float gs = a * (ga * ms - dsum) * scale;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      gq[c] = fmaf(gs, kr[c] + er[c], gq[c]);
+      float gk = gs * qv[c];
+      g_kpe[(size_t)e * D + h * CH + c] = gk;
+      g_ee[(size_t)e * D + h * CH + c] = gk + go[c] * (a * ms);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CH; ++c) g_q[(size_t)i * D + h * CH + c] = gq[c];
+}
+
+extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* ee,
+                                       const int* rowptr, const int* src, int N, int H, int Ch, float p_drop,
+                                       unsigned long long seed, float* alpha, float* out, void* stream) {
+  if (N < 0 || H <= 0 || Ch <= 0 || !q || !k || !v || !ee || !rowptr || !src || !alpha || !out) return MSDE_EINVAL;
+  if (p_drop < 0.f || p_drop >= 1.f) return MSDE_EINVAL;
+  if (N == 0) return 0;
+  dim3 grid((N * H + 255) / 256), block(256);
+  switch (Ch) {
+    case 1: hipLaunchKernelGGL(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    case 2: hipLaunchKernelGGL(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    case 4: hipLaunchKernelGGL(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    case 8: hipLaunchKernelGGL(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    default: return MSDE_EUNSUP;
+  }
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v,
+                                       const float* ee, const float* alpha, const int* rowptr, const int* src, int N,
+                                       int H, int Ch, float p_drop, unsigned long long seed, float* g_q, float* g_ee,
+                                       float* g_kpe, float* g_vpe, void* stream) {
+  if (N < 0 || H <= 0 || Ch <= 0 || !g_out || !q || !k || !v || !ee || !alpha || !rowptr || !src || !g_q || !g_ee ||
+      !g_kpe || !g_vpe)
+    return MSDE_EINVAL;
+  if (p_drop < 0.f || p_drop >= 1.f) return MSDE_EINVAL;
+  if (N == 0) return 0;
+  dim3 grid((N * H + 255) / 256), block(256);
+  switch (Ch) {
+    case 1: hipLaunchKernelGGL(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    case 2: hipLaunchKernelGGL(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    case 4: hipLaunchKernelGGL(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    case 8: hipLaunchKernelGGL(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    default: return MSDE_EUNSUP;
+  }
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame mix + mean scatter (equivariant_scorenetwork.py:159-164)
+// ------------------------------------------------------------------------------------------------
+__global__ void frame_mix_mean_fwd_kernel(const float* __restrict__ coff, const float* __restrict__ basis,
+                                          const int* __restrict__ rowptr, int N, float* __restrict__ out) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * 3) return;
+  int i = t / 3, m = t % 3;
+  int s0 = rowptr[i], s1 = rowptr[i + 1];
+  float acc = 0.f;
+  for (int e = s0; e < s1; ++e) {
+    const float* c = coff + 3 * (size_t)e;
+    const float* b = basis + 9 * (size_t)e;
+    // (c0*diff + c1*cross) + c2*vert, as written in the reference
+    acc += (c[0] * b[m] + c[1] * b[3 + m]) + c[2] * b[6 + m];
+  }
+  out[t] = acc / (float)max(s1 - s0, 1);
+}
+
+__global__ void frame_mix_mean_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ basis,
+                                          const int* __restrict__ rowptr, int N, int E_cap,
+                                          float* __restrict__ g_coff) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    int s0 = rowptr[i], s1 = rowptr[i + 1];
+    float inv = 1.f / (float)max(s1 - s0, 1);
+    float gx = g_out[3 * i] * inv, gy = g_out[3 * i + 1] * inv, gz = g_out[3 * i + 2] * inv;
+    for (int e = s0; e < s1; ++e) {
+      const float* b = basis + 9 * (size_t)e;
+      float* g = g_coff + 3 * (size_t)e;
+      g[0] = gx * b[0] + gy * b[1] + gz * b[2];
+      g[1] = gx * b[3] + gy * b[4] + gz * b[5];
+      g[2] = gx * b[6] + gy * b[7] + gz * b[8];
+    }
+  }
+  int E = rowptr[N];
+  for (int e = E + blockIdx.x * blockDim.x + threadIdx.x; e < E_cap; e += gridDim.x * blockDim.x) {
+    g_coff[3 * (size_t)e] = 0.f; g_coff[3 * (size_t)e + 1] = 0.f; g_coff[3 * (size_t)e + 2] = 0.f;
+  }
+}
+
+extern "C" int msde_frame_mix_mean_fwd(const float* coff, const float* basis, const int* rowptr, int N, float* out,
+                                       void* stream) {
+  if (N < 0 || !coff || !basis || !rowptr || !out) return MSDE_EINVAL;
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(frame_mix_mean_fwd_kernel, dim3((N * 3 + 255) / 256), dim3(256), 0, as_stream(stream), coff,
+                     basis, rowptr, N, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_frame_mix_mean_bwd(const float* g_out, const float* basis, const int* rowptr, int N, int E_cap,
+                                       float* g_coff, void* stream) {
+  if (N < 0 || !g_out || !basis || !rowptr || !g_coff) return MSDE_EINVAL;
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(frame_mix_mean_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), g_out, basis,
+                     rowptr, N, E_cap, g_coff);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

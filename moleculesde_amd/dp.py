@@ -1,0 +1,58 @@
+"""Data parallelism: one process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm, over
+xGMI), molecules sharded across ranks, ONE all-reduce of the flat fp32 gradient buffer per step
+(4.67 M elements = 18.7 MB).  The reference has no distributed code; semantics chosen
+here: BatchNorm statistics are per replica, contrastive negatives are permuted within a replica,
+losses are averaged over ranks for logging.  Works on CPU tensors with the gloo backend, which is
+how the N>1 path is tested without GPUs."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type="cuda"):
+    """Initialise the process group from torchrun's environment; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def broadcast_flat(flat, src=0):
+    """Make every replica start from rank `src`'s parameters."""
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+def allreduce_mean_(flat):
+    """Sum the flat gradient buffer over ranks (in place); returns the scale (1/world) that the
+    optimiser kernel applies, so no extra pass over the buffer is spent on the division."""
+    w = world_size()
+    if w > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return 1.0 / w
+
+
+def shard_seed(base_seed, rank):
+    """Rank-distinct seed for synthetic shards / shuffling."""
+    return int(base_seed) * 1000003 + int(rank)
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,130 @@
+"""Small host-side building blocks shared by the model classes (state_dict-compatible with the
+reference's modules).  Dense node/edge-level Linear layers are plain library GEMMs (rocBLAS via
+torch); everything graph-shaped goes through moleculesde_amd.hip."""
+import weakref
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import plan as _plan
+
+_LN2 = float(torch.log(torch.tensor(2.0)).item())
+
+
+def shifted_softplus(x):
+    """softplus(x) - ln 2 (reference ShiftedSoftplus, schnet.py:210-216)."""
+    return F.softplus(x) - _LN2
+
+
+class ShiftedSoftplus(nn.Module):
+    def forward(self, x):
+        return shifted_softplus(x)
+
+
+class MultiLayerPerceptron(nn.Module):
+    """Same parameters/keys as layers/common.py:5-40 (`layers.{i}.weight|bias`, Xavier / zero init)."""
+
+    def __init__(self, input_dim, hidden_dims, activation="relu", dropout=0):
+        super().__init__()
+        self.dims = [input_dim] + list(hidden_dims)
+        self.activation = getattr(F, activation) if isinstance(activation, str) else None
+        self.dropout = nn.Dropout(dropout) if dropout else None
+        self.layers = nn.ModuleList([nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(len(self.dims) - 1)])
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for layer in self.layers:
+            nn.init.xavier_uniform_(layer.weight)
+            nn.init.constant_(layer.bias, 0.0)
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < len(self.layers) - 1:
+                if self.activation:
+                    x = self.activation(x)
+                if self.dropout:
+                    x = self.dropout(x)
+        return x
+
+
+class EmbeddingList(nn.Module):
+    """ogb AtomEncoder / BondEncoder parameters (`<name>.{k}.weight`, Xavier-uniform)."""
+
+    def __init__(self, dims, emb_dim, list_name):
+        super().__init__()
+        lst = nn.ModuleList()
+        for d in dims:
+            e = nn.Embedding(d, emb_dim)
+            nn.init.xavier_uniform_(e.weight.data)
+            lst.append(e)
+        setattr(self, list_name, lst)
+        self._list_name = list_name
+
+    def table(self):
+        """Concatenated [sum(dims), D] table, the layout the kernels index with pre-offset codes."""
+        return torch.cat([e.weight for e in getattr(self, self._list_name)], dim=0)
+
+
+# ---- plan registry: lets the reference-style call signatures (tensors, not a Batch) find the plan --
+_REGISTRY = {}
+
+
+def register_plan(data, pl):
+    for name in ("x", "batch", "edge_index"):
+        t = getattr(data, name, None)
+        if isinstance(t, torch.Tensor):
+            _REGISTRY[id(t)] = (weakref.ref(t), pl)
+    if len(_REGISTRY) > 64:
+        for k in [k for k, (r, _) in _REGISTRY.items() if r() is None]:
+            _REGISTRY.pop(k, None)
+
+
+def lookup_plan(t):
+    ent = _REGISTRY.get(id(t))
+    if ent is not None and ent[0]() is t:
+        return ent[1]
+    return None
+
+
+def prepare_batch(data, device=None, **kw):
+    """Collation-time hook of the drivers: build the index plan on the host, move everything to the
+    device, and register the plan so `GNN(batch.x, batch.edge_index, batch.edge_attr)` and
+    `SchNet(batch.x[:, 0], batch.positions, batch.batch)` (the reference's call forms,
+    pretrain_MoleculeSDE.py:128-131) find it."""
+    _plan.prepare_batch(data, device=device, **kw)
+    register_plan(data, data._msde_plan)
+    return data
+
+
+class DeviceNoise:
+    """Default noise source: device RNG (torch's HIP generator)."""
+
+    def randn_like(self, x):
+        return torch.randn_like(x)
+
+    def randint(self, high, size, device):
+        return torch.randint(0, high, size=size, device=device)
+
+    def randperm(self, n, device):
+        return torch.randperm(n, device=device)
+
+
+class CpuReplayNoise:
+    """Parity noise source: draws from a torch CPU generator in the reference's program order
+     and uploads, so a reference/oracle run under torch.manual_seed(seed)
+    sees the same numbers."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator(device="cpu")
+        self.g.manual_seed(int(seed))
+
+    def randn_like(self, x):
+        return torch.randn(x.shape, generator=self.g, dtype=x.dtype).to(x.device)
+
+    def randint(self, high, size, device):
+        return torch.randint(0, high, size=size, generator=self.g).to(device)
+
+    def randperm(self, n, device):
+        return torch.randperm(n, generator=self.g).to(device)

@@ -1,0 +1,134 @@
+"""SchNet 3D encoder on HIP kernels.  Mirrors Geom3D/models/schnet.py:16-125: same constructor,
+`forward(z, pos, batch=None, return_latent=False)` and state_dict keys (including the duplicated
+`interactions.i.mlp.*` / `interactions.i.conv.nn.*` entries and the float64 `atomic_mass` buffer).
+
+Device pipeline per forward:
+  radius-graph CSR (count -> scan -> fill, no host sync)  ->  Gaussian smearing + cosine cutoff
+  -> 6 x [ filter MLP, lin1, CFConv gather*filter segmented sum, lin2, ssp, lin, residual ]
+  -> head -> per-molecule readout.
+Under torch.no_grad() with num_filters == 128 the whole CFConv (smearing, filter MLP, cutoff,
+gather, segmented sum) is ONE fp32-MFMA kernel (csrc/cfconv_fused.hip).
+"""
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip, plan as _plan
+from . import nn as _nn
+
+
+class GaussianSmearing(nn.Module):
+    """Parameters of schnet.py:198-207; the expansion itself is fused into the edge kernels."""
+
+    def __init__(self, start=0.0, stop=5.0, num_gaussians=50):
+        super().__init__()
+        offset = torch.linspace(start, stop, num_gaussians)
+        self.coeff = -0.5 / (offset[1] - offset[0]).item() ** 2
+        self.num_gaussians = num_gaussians
+        self.register_buffer("offset", offset)
+
+
+class CFConv(nn.Module):
+    def __init__(self, in_channels, out_channels, num_filters, nn_, cutoff):
+        super().__init__()
+        self.lin1 = nn.Linear(in_channels, num_filters, bias=False)
+        self.lin2 = nn.Linear(num_filters, out_channels)
+        self.nn = nn_
+        self.cutoff = cutoff
+        nn.init.xavier_uniform_(self.lin1.weight)
+        nn.init.xavier_uniform_(self.lin2.weight)
+        self.lin2.bias.data.fill_(0)
+
+
+class InteractionBlock(nn.Module):
+    def __init__(self, hidden_channels, num_gaussians, num_filters, cutoff):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(num_gaussians, num_filters), _nn.ShiftedSoftplus(),
+                                 nn.Linear(num_filters, num_filters))
+        self.conv = CFConv(hidden_channels, hidden_channels, num_filters, self.mlp, cutoff)
+        self.act = _nn.ShiftedSoftplus()
+        self.lin = nn.Linear(hidden_channels, hidden_channels)
+        nn.init.xavier_uniform_(self.mlp[0].weight)
+        self.mlp[0].bias.data.fill_(0)
+        nn.init.xavier_uniform_(self.mlp[2].weight)   # mlp[2].bias keeps nn.Linear's default (App. B.1)
+        nn.init.xavier_uniform_(self.lin.weight)
+        self.lin.bias.data.fill_(0)
+
+
+class SchNet(nn.Module):
+    def __init__(self, hidden_channels=128, num_filters=128, num_interactions=6, num_gaussians=50, cutoff=10.0,
+                 node_class=None, readout="mean", dipole=False, mean=None, std=None, atomref=None):
+        super().__init__()
+        assert readout in ["add", "sum", "mean"]
+        if dipole or mean is not None or std is not None or atomref is not None:
+            raise NotImplementedError("dipole / mean-std / atomref branches are never enabled on the MoleculeSDE path")
+        self.hidden_channels, self.num_filters = hidden_channels, num_filters
+        self.num_interactions, self.num_gaussians, self.cutoff = num_interactions, num_gaussians, cutoff
+        self.readout, self.dipole, self.mean, self.std, self.scale = readout, False, None, None, None
+        self.node_class = node_class
+        self.max_num_neighbors = 32
+        # ase.data.atomic_masses placeholder: only ever stored (schnet.py:47-48), real values come
+        # from a loaded checkpoint
+        self.register_buffer("atomic_mass", torch.zeros(119, dtype=torch.float64))
+        self.embedding = nn.Embedding(node_class, hidden_channels)
+        self.distance_expansion = GaussianSmearing(0.0, cutoff, num_gaussians)
+        self.interactions = nn.ModuleList(
+            [InteractionBlock(hidden_channels, num_gaussians, num_filters, cutoff) for _ in range(num_interactions)])
+        self.lin1 = nn.Linear(hidden_channels, hidden_channels)
+        self.act = _nn.ShiftedSoftplus()
+        self.lin2 = nn.Linear(hidden_channels, hidden_channels)
+        self.register_buffer("initial_atomref", None)
+        self.atomref = None
+        nn.init.xavier_uniform_(self.lin1.weight)
+        self.lin1.bias.data.fill_(0)
+        nn.init.xavier_uniform_(self.lin2.weight)
+        self.lin2.bias.data.fill_(0)
+        self.fused_nodes_per_wg = 16
+
+    def _find_plan(self, z, batch):
+        pl = _nn.lookup_plan(batch) if batch is not None else None
+        if pl is None:
+            b = torch.zeros(z.size(0), dtype=torch.long, device=z.device) if batch is None else batch
+            d = types.SimpleNamespace(x=z, batch=b, num_graphs=int(b.max()) + 1 if b.numel() else 0,
+                                      edge_index=None, edge_attr=None)
+            pl = _plan.build_plan(d, max_nbr=self.max_num_neighbors, with_ext=False)
+        return pl
+
+    def forward(self, z, pos, batch=None, return_latent=False):
+        assert z.dim() == 1 and z.dtype == torch.long
+        if pos.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("gradients w.r.t. positions (MD17 force path) are not wired in this build")
+        pl = self._find_plan(z, batch)
+        ptr, nodes = _plan.z_lists(pl, self.node_class)
+        h = hip.embedding_sum(self.embedding.weight, pl.z_codes, ptr, nodes)
+
+        rplan, dist = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors)
+        de = self.distance_expansion
+        fused = (not torch.is_grad_enabled()) and self.num_filters == 128 and self.num_gaussians <= 64
+        if not fused:
+            rbf, C = hip.rbf_cutoff(dist, rplan.E_dev, de.offset, de.coeff, self.cutoff)
+
+        for blk in self.interactions:
+            x1 = F.linear(h, blk.conv.lin1.weight)
+            if fused:
+                agg = hip.cfconv_fused_forward(x1, dist, rplan, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
+                                               blk.mlp[2].bias, de.offset, de.coeff, self.cutoff,
+                                               self.fused_nodes_per_wg)
+            else:
+                Wf = blk.mlp(rbf)
+                agg = hip.cfconv_aggregate(x1, Wf, C, rplan)
+            x = blk.conv.lin2(agg)
+            x = blk.lin(_nn.shifted_softplus(x))
+            h = h + x
+
+        h = self.lin2(_nn.shifted_softplus(self.lin1(h)))
+        out = hip.segment_reduce(h, pl.mol_ptr, pl.batch_i32, mean=(self.readout == "mean"))
+        if return_latent:
+            return out, h
+        return out
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(hidden_channels={self.hidden_channels}, num_filters={self.num_filters}, "
+                f"num_interactions={self.num_interactions}, num_gaussians={self.num_gaussians}, cutoff={self.cutoff})")

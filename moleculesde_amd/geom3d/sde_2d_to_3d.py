@@ -1,0 +1,198 @@
+"""SDEModel2Dto3D_02 + EquivariantScoreNetwork on HIP kernels.
+
+API, constructor arguments, `forward(node_2D_repr, data, anneal_power) -> {"position": loss}`,
+`get_score(...)`, `.sde_pos` and state_dict keys mirror SDE_model_2D_to_3D.py:252-445 and
+equivariant_scorenetwork.py:13-169.
+
+What runs where:
+  * per-edge SE(3) frame, distance, pseudo-angle and all Gaussian-Fourier features: one kernel
+    (hip.edge_geometry); no gradient flows to coordinates;
+  * `edge_2D_emb`'s Linear(cat(h_row, h_col)) is factored into two node-level GEMMs plus a
+    gather-add kernel (12.3 -> 1.3 GFLOP at bs 256);
+  * TransformerConv = q/k/v/skip/edge Linear (library GEMMs) + hip.edge_attention (scores,
+    per-target softmax, dropout, weighted sum in one kernel);
+  * basis mixing + mean scatter: hip.frame_mix_mean.
+Edge tensors live in the plan's canonical (by-target) order; nothing per-edge is returned to the
+caller, so the order is internal.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip, plan as _plan
+from . import nn as _nn
+from .sde import VESDE, VPSDE
+
+EPSILON = 1e-6
+
+
+class GaussianFourierProjection(nn.Module):
+    """Frozen random features W (in the state dict, excluded from the optimiser; App. B.10)."""
+
+    def __init__(self, embedding_size, scale=1.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embedding_size) * scale, requires_grad=False)
+
+
+class TransformerConv(nn.Module):
+    """PyG TransformerConv(in, out, heads, dropout, edge_dim) parameters (App. A.4 / C.2)."""
+
+    def __init__(self, in_channels, out_channels, heads, dropout, edge_dim):
+        super().__init__()
+        self.heads, self.out_channels, self.dropout = heads, out_channels, dropout
+        self.lin_key = nn.Linear(in_channels, heads * out_channels)
+        self.lin_query = nn.Linear(in_channels, heads * out_channels)
+        self.lin_value = nn.Linear(in_channels, heads * out_channels)
+        self.lin_edge = nn.Linear(edge_dim, heads * out_channels, bias=False)
+        self.lin_skip = nn.Linear(in_channels, heads * out_channels, bias=True)
+
+    def forward(self, x, edge_attr, plan, seed):
+        q, k, v = self.lin_query(x), self.lin_key(x), self.lin_value(x)
+        ee = self.lin_edge(edge_attr)
+        p = self.dropout if self.training else 0.0
+        out = hip.edge_attention(q, k, v, ee, plan, self.heads, p, seed)
+        return out + self.lin_skip(x)
+
+
+class GATLayer(nn.Module):
+    def __init__(self, n_head, hidden_dim, dropout=0.2):
+        super().__init__()
+        assert hidden_dim % n_head == 0
+        self.MHA = TransformerConv(hidden_dim, hidden_dim // n_head, n_head, dropout, hidden_dim)
+        self.FFN = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.SiLU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, hidden_dim))
+        self.norm1 = nn.LayerNorm(hidden_dim)
+        self.norm2 = nn.LayerNorm(hidden_dim)
+
+    def forward(self, plan, node_attr, edge_attr, seed):
+        x = self.MHA(node_attr, edge_attr, plan, seed)
+        node_attr = node_attr + self.norm1(x)
+        x = self.FFN(node_attr)
+        return node_attr + self.norm2(x)
+
+
+class _EquiLayer(nn.Module):
+    """Holds the `eps` buffer of the reference's EquiLayer (state-dict key only)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("eps", torch.Tensor([0.0]))
+
+
+class EquivariantScoreNetwork(nn.Module):
+    def __init__(self, hidden_dim, hidden_coff_dim=64, activation="silu", short_cut=False, concat_hidden=False):
+        super().__init__()
+        if short_cut or concat_hidden:
+            raise NotImplementedError("short_cut / concat_hidden are never enabled on the MoleculeSDE path")
+        self.hidden_dim, self.num_layers, self.num_convs = hidden_dim, 2, 2
+        self.num_head, self.dropout, self.hidden_coff_dim = 8, 0.1, hidden_coff_dim
+        self.gnn_layers = nn.ModuleList()
+        self.equi_modules = nn.ModuleList()
+        self.basis_mlp_modules = nn.ModuleList()
+        for _ in range(self.num_layers):
+            self.gnn_layers.append(nn.ModuleList(
+                [GATLayer(self.num_head, hidden_dim, dropout=self.dropout) for _ in range(self.num_convs)]))
+            self.equi_modules.append(_EquiLayer())
+            self.basis_mlp_modules.append(nn.Sequential(
+                nn.Linear(2 * hidden_dim, hidden_coff_dim), nn.SiLU(), nn.Linear(hidden_coff_dim, 3)))
+        self._seed_base = 0x5DE2D3D
+        self._calls = 0
+
+    def forward(self, plan, node_attr, edge_attr, basis):
+        conv_input = node_attr
+        gradient = None
+        self._calls += 1
+        for module_idx, gnn_layers in enumerate(self.gnn_layers):
+            for conv_idx, gnn in enumerate(gnn_layers):
+                seed = (self._seed_base + self._calls) * 16 + module_idx * 4 + conv_idx
+                hidden = gnn(plan, conv_input, edge_attr, seed)
+                if conv_idx < len(gnn_layers) - 1:
+                    hidden = F.silu(hidden)
+                conv_input = hidden
+            node_feature = hidden
+            pair = hip.pair_gather_add(node_feature, node_feature, plan)        # h_row + h_col
+            edge_feature = torch.cat([pair, edge_attr], dim=-1)
+            coff = self.basis_mlp_modules[module_idx](edge_feature)             # [E, 3]
+            g = hip.frame_mix_mean(coff, basis, plan)
+            gradient = g if gradient is None else gradient + g
+        return {"node_feature": node_feature, "gradient": gradient}
+
+
+class SDEModel2Dto3D_02(nn.Module):
+    def __init__(self, emb_dim, hidden_dim, beta_schedule, beta_min, beta_max, num_diffusion_timesteps,
+                 SDE_type="VE", short_cut=False, concat_hidden=False, use_extend_graph=False):
+        super().__init__()
+        self.emb_dim, self.hidden_dim = emb_dim, hidden_dim
+        self.SDE_type, self.use_extend_graph = SDE_type, use_extend_graph
+        self.node_emb = _nn.MultiLayerPerceptron(emb_dim, [hidden_dim], activation="silu")
+        self.edge_2D_emb = nn.Sequential(nn.Linear(emb_dim * 2, emb_dim), nn.BatchNorm1d(emb_dim), nn.ReLU(),
+                                         nn.Linear(emb_dim, hidden_dim))
+        self.dist_gaussian_fourier = GaussianFourierProjection(hidden_dim, scale=1)
+        self.input_mlp = _nn.MultiLayerPerceptron(2 * hidden_dim, [hidden_dim], activation="silu")
+        self.coff_gaussian_fourier = GaussianFourierProjection(hidden_dim, scale=1)
+        self.coff_mlp = nn.Linear(4 * hidden_dim, hidden_dim)
+        self.project = _nn.MultiLayerPerceptron(2 * hidden_dim + 2, [hidden_dim, hidden_dim], activation="silu")
+        self.score_network = EquivariantScoreNetwork(hidden_dim, hidden_coff_dim=128, activation="silu",
+                                                     short_cut=short_cut, concat_hidden=concat_hidden)
+        if SDE_type in ("VE", "VE_test"):
+            self.sde_pos = VESDE(sigma_min=beta_min, sigma_max=beta_max, N=num_diffusion_timesteps)
+        elif SDE_type in ("VP", "VP_test"):
+            self.sde_pos = VPSDE(beta_min=beta_min, beta_max=beta_max, N=num_diffusion_timesteps)
+        else:
+            raise NotImplementedError(f"SDE_type={SDE_type!r}")
+        self.num_diffusion_timesteps = num_diffusion_timesteps
+        self.noise = _nn.DeviceNoise()     # set to nn.CpuReplayNoise(seed) for replayable parity runs
+
+    def _plan(self, data):
+        pl = _plan.get_plan(data)
+        return pl, (pl.ext if self.use_extend_graph else pl.bond)
+
+    def _edge_and_node_features(self, node_2D_repr, pos_perturbed, ep):
+        D = self.emb_dim
+        feat_d, feat_i, feat_j, angle, basis = hip.edge_geometry(
+            pos_perturbed, ep, self.dist_gaussian_fourier.W, self.coff_gaussian_fourier.W)
+        # edge_2D_emb[0](cat(h[row], h[col])) == h[row] W[:, :D]^T + h[col] W[:, D:]^T + b
+        lin0 = self.edge_2D_emb[0]
+        A = F.linear(node_2D_repr, lin0.weight[:, :D])
+        Bm = F.linear(node_2D_repr, lin0.weight[:, D:], lin0.bias)
+        pre = hip.pair_gather_add(A, Bm, ep)
+        edge_attr_2D = self.edge_2D_emb[3](self.edge_2D_emb[2](self.edge_2D_emb[1](pre)))
+        edge_attr_3D_invariant = self.input_mlp(feat_d)
+        embed_i = self.coff_mlp(feat_i)
+        embed_j = self.coff_mlp(feat_j)
+        edge_attr_3D_frame_invariant = self.project(torch.cat([angle, embed_i, embed_j], dim=-1))
+        edge_attr = edge_attr_3D_invariant * edge_attr_2D + edge_attr_3D_frame_invariant
+        node_attr = self.node_emb(node_2D_repr)
+        return node_attr, edge_attr, basis
+
+    def forward(self, node_2D_repr, data, anneal_power):
+        pos = data.positions
+        node2graph = data.batch
+        pl, ep = self._plan(data)
+        B = data.num_graphs
+        T = self.num_diffusion_timesteps
+        pos_noise = self.noise.randn_like(pos)
+        time_step = self.noise.randint(T, (B // 2 + 1,), pos.device)
+        time_step = torch.cat([time_step, T - time_step - 1], dim=0)[:B]
+        if self.SDE_type in ("VE", "VP"):
+            time_step = time_step / T * (1 - EPSILON) + EPSILON
+        t_pos = time_step.index_select(0, node2graph)
+        mean_pos, std_pos = self.sde_pos.marGINal_prob(pos.detach(), t_pos)
+        pos_perturbed = mean_pos + std_pos[:, None] * pos_noise
+
+        node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep)
+        scores = self.score_network(ep, node_attr, edge_attr, basis)["gradient"]
+        if anneal_power == 0:
+            loss_pos = torch.sum((scores - pos_noise) ** 2, -1)
+        else:
+            loss_pos = torch.sum((scores - pos_noise) ** 2 * (std_pos ** anneal_power).unsqueeze(1), -1)
+        loss_pos = hip.segment_reduce(loss_pos.unsqueeze(1), pl.mol_ptr, pl.batch_i32, mean=True)   # scatter_mean
+        return {"position": loss_pos.mean()}
+
+    @torch.no_grad()
+    def get_score(self, node_2D_repr, data, pos_perturbed, sigma, t_pos):
+        pl, ep = self._plan(data)
+        node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep)
+        output = self.score_network(ep, node_attr, edge_attr, basis)["gradient"]
+        _, std_pos = self.sde_pos.marGINal_prob(pos_perturbed, t_pos)
+        return -output / std_pos[:, None]

@@ -1,0 +1,387 @@
+"""torch-facing wrappers over the C ABI (include/msde_hip.h).
+
+PyTorch is used here as plumbing only: device buffers, the current HIP stream and the autograd
+tape.  Every function launches hand-written gfx950 kernels from libmsde_hip.so on torch's current
+stream; tensors must live on a HIP device -- there is no CPU path (a CPU tensor raises).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    if not t.is_cuda:
+        raise _lib.MsdeHipError("moleculesde_amd kernels need tensors on the HIP device (no CPU fallback)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _i32(t):
+    if not t.is_cuda:
+        raise _lib.MsdeHipError("moleculesde_amd kernels need tensors on the HIP device (no CPU fallback)")
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# graph plans
+# ------------------------------------------------------------------------------------------------
+class CsrPlan:
+    """CSR by target (canonical edge order) + transposed view by source.
+
+    rowptr [N+1], src [E], dst [E]  : canonical order (sorted by target, ties in input order)
+    rowptr_s [N+1], perm_s [E]      : by-source slot -> canonical edge id
+    perm_t [E] (int64)              : canonical edge id -> position in the caller's edge_index
+    E may be an upper bound (radius graph): slots >= rowptr[N] are padding (src = dst = -1).
+    """
+
+    __slots__ = ("N", "E", "rowptr", "src", "dst", "rowptr_s", "perm_s", "perm_t", "E_dev")
+
+    def to(self, device):
+        for k in ("rowptr", "src", "dst", "rowptr_s", "perm_s", "perm_t", "E_dev"):
+            v = getattr(self, k, None)
+            if isinstance(v, torch.Tensor):
+                setattr(self, k, v.to(device))
+        return self
+
+
+def build_csr(edge_index, num_nodes):
+    """Plan for a static edge set (bonds / extended edges).  Device agnostic torch ops: runs on the
+    host at batch-collation time (preferred) or on the device if handed a device batch."""
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    N = int(num_nodes)
+    dev = edge_index.device
+    perm_t = torch.argsort(dst, stable=True)
+    src_c, dst_c = src[perm_t], dst[perm_t]
+    ar = torch.arange(N + 1, device=dev)
+    rowptr = torch.searchsorted(dst_c, ar).to(torch.int32)
+    perm_s = torch.argsort(src_c, stable=True)
+    rowptr_s = torch.searchsorted(src_c[perm_s], ar).to(torch.int32)
+    p = CsrPlan()
+    p.N, p.E = N, int(src.numel())
+    p.rowptr, p.src, p.dst = rowptr, src_c.to(torch.int32), dst_c.to(torch.int32)
+    p.rowptr_s, p.perm_s, p.perm_t = rowptr_s, perm_s.to(torch.int32), perm_t
+    p.E_dev = None
+    return p
+
+
+def radius_plan(pos, batch_i32, mol_ptr_i32, cutoff, E_cap, max_nbr=32):
+    """Radius graph as a by-target CSR emitted directly on the device (schnet.py:91-93).
+    Returns (plan, dist[E_cap]).  No host synchronisation: E_cap is the host-side upper bound
+    sum_m n_m * min(n_m - 1, max_nbr); the true edge count stays on the device (plan.E_dev)."""
+    pos = _f32(pos.detach())
+    N = pos.size(0)
+    dev = pos.device
+    deg = torch.empty(N, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(E_cap, dtype=torch.int32, device=dev)
+    dst = torch.empty(E_cap, dtype=torch.int32, device=dev)
+    dist = torch.empty(E_cap, dtype=torch.float32, device=dev)
+    st = _stream()
+    r2 = float(cutoff) * float(cutoff)
+    _lib.call("msde_radius_count", _p(pos), _p(batch_i32), _p(mol_ptr_i32), N, r2, max_nbr, _p(deg), st)
+    _lib.call("msde_exclusive_scan_i32", _p(deg), _p(rowptr), N, st)
+    _lib.call("msde_radius_fill", _p(pos), _p(batch_i32), _p(mol_ptr_i32), N, r2, max_nbr, _p(rowptr), _p(src),
+              _p(dst), _p(dist), E_cap, st)
+    # transposed view (by source): padding (src = -1) sorts to the end under key N
+    key = torch.where(src < 0, torch.full_like(src, N), src)
+    skey, perm_s = torch.sort(key.long(), stable=True)
+    rowptr_s = torch.searchsorted(skey, torch.arange(N + 1, device=dev)).to(torch.int32)
+    p = CsrPlan()
+    p.N, p.E = N, E_cap
+    p.rowptr, p.src, p.dst = rowptr, src, dst
+    p.rowptr_s, p.perm_s, p.perm_t = rowptr_s, perm_s.to(torch.int32), None
+    p.E_dev = rowptr[N:]
+    return p, dist
+
+
+# ------------------------------------------------------------------------------------------------
+# plain (non-differentiable) launches
+# ------------------------------------------------------------------------------------------------
+def segment_sum_rows(rows, rowptr, perm, N, mean=False):
+    rows = _f32(rows)
+    D = rows.size(1)
+    out = torch.empty(N, D, dtype=torch.float32, device=rows.device)
+    _lib.call("msde_segment_sum_rows", _p(rows), _p(rowptr), _p(perm), N, D, 1.0 if mean else 0.0, _p(out), _stream())
+    return out
+
+
+def gather_rows(X, idx):
+    X = _f32(X)
+    E, D = idx.numel(), X.size(1)
+    out = torch.empty(E, D, dtype=torch.float32, device=X.device)
+    _lib.call("msde_gather_rows", _p(X), _p(idx), E, D, _p(out), _stream())
+    return out
+
+
+def rbf_cutoff(dist, E_dev, offset, coeff, cutoff):
+    """GaussianSmearing + cosine cutoff (schnet.py:186,205-207) -> rbf [E,G], C [E]."""
+    dist = _f32(dist)
+    E = dist.numel()
+    G = offset.numel()
+    rbf = torch.empty(E, G, dtype=torch.float32, device=dist.device)
+    C = torch.empty(E, dtype=torch.float32, device=dist.device)
+    _lib.call("msde_rbf_cutoff_fwd", _p(dist), _p(E_dev), E, G, _p(_f32(offset)), float(coeff),
+              float(cutoff), _p(rbf), _p(C), _stream())
+    return rbf, C
+
+
+def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, nodes_per_wg=16):
+    """Fused CFConv forward (no autograd): see csrc/cfconv_fused.hip."""
+    x1 = _f32(x1)
+    N, Fd = x1.shape
+    G = W1.size(1)
+    agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
+    _lib.call("msde_cfconv_fused_fwd", _p(x1), _p(_f32(dist)), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
+              _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)), _p(_f32(offset)), N, Fd, G,
+              float(coeff), float(cutoff), int(nodes_per_wg), _p(agg), _stream())
+    return agg
+
+
+def edge_geometry(pos, plan, Wd, Wc):
+    """Per-edge frame + Fourier features (SDE_model_2D_to_3D.py:35-66,342-369); no gradient: the
+    perturbed coordinates do not depend on any parameter."""
+    pos = _f32(pos.detach())
+    E, C = plan.E, Wd.numel()
+    dev = pos.device
+    feat_d = torch.empty(E, 2 * C, dtype=torch.float32, device=dev)
+    feat_i = torch.empty(E, 4 * C, dtype=torch.float32, device=dev)
+    feat_j = torch.empty(E, 4 * C, dtype=torch.float32, device=dev)
+    angle = torch.empty(E, 2, dtype=torch.float32, device=dev)
+    basis = torch.empty(E, 9, dtype=torch.float32, device=dev)
+    _lib.call("msde_edge_geometry_fwd", _p(pos), _p(plan.src), _p(plan.dst), E, _p(_f32(Wd.detach())),
+              _p(_f32(Wc.detach())), C, _p(feat_d), _p(feat_i), _p(feat_j), _p(angle), _p(basis), _stream())
+    return feat_d, feat_i, feat_j, angle, basis
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable ops
+# ------------------------------------------------------------------------------------------------
+class _EmbeddingSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tab, codes, list_ptr, list_nodes):
+        tab = _f32(tab)
+        N, K = codes.shape
+        D = tab.size(1)
+        out = torch.empty(N, D, dtype=torch.float32, device=tab.device)
+        _lib.call("msde_embedding_sum_fwd", _p(tab), _p(codes), N, K, D, _p(out), _stream())
+        ctx.save_for_backward(list_ptr, list_nodes)
+        ctx.R, ctx.D = tab.size(0), D
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        list_ptr, list_nodes = ctx.saved_tensors
+        g = _f32(g)
+        g_tab = torch.zeros(ctx.R, ctx.D, dtype=torch.float32, device=g.device)
+        _lib.call("msde_embedding_sum_bwd", _p(g), _p(list_ptr), _p(list_nodes), ctx.R, ctx.D, 16, _p(g_tab), _stream())
+        return g_tab, None, None, None
+
+
+def embedding_sum(tab, codes, list_ptr, list_nodes):
+    """out[i] = sum_k tab[codes[i,k]]; lists = CSR of nodes per table row (for the backward)."""
+    return _EmbeddingSum.apply(tab, codes, list_ptr, list_nodes)
+
+
+class _GinAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tab, eps, plan, codes):
+        x, tab, eps = _f32(x), _f32(tab), _f32(eps)
+        N, D = x.shape
+        out = torch.empty_like(x)
+        _lib.call("msde_gin_aggregate_fwd", _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr), _p(plan.src), N, D,
+                  _p(out), _stream())
+        ctx.save_for_backward(x, tab, eps, codes)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, tab, eps, codes = ctx.saved_tensors
+        plan = ctx.plan
+        g = _f32(g)
+        N, D = x.shape
+        R = tab.size(0)
+        st = _stream()
+        g_x = torch.empty_like(x)
+        _lib.call("msde_gin_aggregate_bwd_x", _p(g), _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr_s),
+                  _p(plan.perm_s), _p(plan.dst), N, D, _p(g_x), st)
+        g_tab = torch.zeros_like(tab)
+        g_eps = torch.zeros(1, dtype=torch.float32, device=x.device)
+        _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.rowptr), _p(plan.src), N, D,
+                  R, _p(g_tab), _p(g_eps), st)
+        return g_x, g_tab, g_eps, None, None
+
+
+def gin_aggregate(x, tab, eps, plan, codes):
+    """(1+eps) x_i + sum_j relu(x_j + bond_emb(e_ji))  (molecule_gnn_model.py:22-29)."""
+    return _GinAggregate.apply(x, tab, eps, plan, codes)
+
+
+class _CFConvAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, Wf, C, plan):
+        x1, Wf = _f32(x1), _f32(Wf)
+        N, Fd = x1.shape
+        agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
+        _lib.call("msde_cfconv_aggregate_fwd", _p(x1), _p(Wf), _p(C), _p(plan.rowptr), _p(plan.src), N, Fd, _p(agg),
+                  _stream())
+        ctx.save_for_backward(x1, Wf, C)
+        ctx.plan = plan
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, Wf, C = ctx.saved_tensors
+        plan = ctx.plan
+        g = _f32(g)
+        N, Fd = x1.shape
+        st = _stream()
+        g_x1 = g_Wf = None
+        if ctx.needs_input_grad[0]:
+            g_x1 = torch.empty_like(x1)
+            _lib.call("msde_cfconv_aggregate_bwd_x", _p(g), _p(Wf), _p(C), _p(plan.rowptr_s), _p(plan.perm_s),
+                      _p(plan.dst), N, Fd, _p(g_x1), st)
+        if ctx.needs_input_grad[1]:
+            g_Wf = torch.empty_like(Wf)
+            _lib.call("msde_cfconv_aggregate_bwd_w", _p(g), _p(x1), _p(C), _p(plan.rowptr), _p(plan.src), N, Fd,
+                      Wf.size(0), _p(g_Wf), st)
+        return g_x1, g_Wf, None, None
+
+
+def cfconv_aggregate(x1, Wf, C, plan):
+    """agg_i = sum_j x1_j * (Wf_ij * C_ij)  (schnet.py:187,190,194-195); C carries no gradient here."""
+    return _CFConvAggregate.apply(x1, Wf, C, plan)
+
+
+class _PairGatherAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, plan):
+        A, B = _f32(A), _f32(B)
+        E, D = plan.E, A.size(1)
+        out = torch.empty(E, D, dtype=torch.float32, device=A.device)
+        _lib.call("msde_pair_gather_add", _p(A), _p(B), _p(plan.src), _p(plan.dst), E, D, _p(out), _stream())
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        g = _f32(g)
+        g_A = segment_sum_rows(g, plan.rowptr_s, plan.perm_s, plan.N) if ctx.needs_input_grad[0] else None
+        g_B = segment_sum_rows(g, plan.rowptr, None, plan.N) if ctx.needs_input_grad[1] else None
+        return g_A, g_B, None
+
+
+def pair_gather_add(A, B, plan):
+    """out[e] = A[row_e] + B[col_e]  (row = source, col = target)."""
+    return _PairGatherAdd.apply(A, B, plan)
+
+
+class _EdgeAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, ee, plan, heads, p_drop, seed):
+        q, k, v, ee = _f32(q), _f32(k), _f32(v), _f32(ee)
+        N, D = q.shape
+        Ch = D // heads
+        alpha = torch.empty(plan.E, heads, dtype=torch.float32, device=q.device)
+        out = torch.empty_like(q)
+        _lib.call("msde_edge_attention_fwd", _p(q), _p(k), _p(v), _p(ee), _p(plan.rowptr), _p(plan.src), N, heads, Ch,
+                  float(p_drop), int(seed), _p(alpha), _p(out), _stream())
+        ctx.save_for_backward(q, k, v, ee, alpha)
+        ctx.plan, ctx.heads, ctx.p_drop, ctx.seed = plan, heads, float(p_drop), int(seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, ee, alpha = ctx.saved_tensors
+        plan, H = ctx.plan, ctx.heads
+        g = _f32(g)
+        N, D = q.shape
+        g_q = torch.empty_like(q)
+        g_ee = torch.empty_like(ee)
+        g_kpe = torch.empty_like(ee)
+        g_vpe = torch.empty_like(ee)
+        _lib.call("msde_edge_attention_bwd", _p(g), _p(q), _p(k), _p(v), _p(ee), _p(alpha), _p(plan.rowptr),
+                  _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(g_q), _p(g_ee), _p(g_kpe), _p(g_vpe), _stream())
+        g_k = segment_sum_rows(g_kpe, plan.rowptr_s, plan.perm_s, N)
+        g_v = segment_sum_rows(g_vpe, plan.rowptr_s, plan.perm_s, N)
+        return g_q, g_k, g_v, g_ee, None, None, None, None
+
+
+def edge_attention(q, k, v, ee, plan, heads, p_drop=0.0, seed=0):
+    """TransformerConv message + per-target softmax + aggregate (App. A.4)."""
+    return _EdgeAttention.apply(q, k, v, ee, plan, heads, p_drop, seed)
+
+
+class _FrameMixMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coff, basis, plan):
+        coff = _f32(coff)
+        out = torch.empty(plan.N, 3, dtype=torch.float32, device=coff.device)
+        _lib.call("msde_frame_mix_mean_fwd", _p(coff), _p(basis), _p(plan.rowptr), plan.N, _p(out), _stream())
+        ctx.save_for_backward(basis)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (basis,) = ctx.saved_tensors
+        plan = ctx.plan
+        g = _f32(g)
+        g_coff = torch.empty(plan.E, 3, dtype=torch.float32, device=g.device)
+        _lib.call("msde_frame_mix_mean_bwd", _p(g), _p(basis), _p(plan.rowptr), plan.N, plan.E, _p(g_coff), _stream())
+        return g_coff, None, None
+
+
+def frame_mix_mean(coff, basis, plan):
+    """mean_{e -> i} (c0 b_diff + c1 b_cross + c2 b_vert)  (equivariant_scorenetwork.py:159-164)."""
+    return _FrameMixMean.apply(coff, basis, plan)
+
+
+class _SegmentMean(torch.autograd.Function):
+    """Per-molecule mean/sum of node rows (torch_scatter.scatter over the sorted `batch` vector)."""
+
+    @staticmethod
+    def forward(ctx, x, mol_ptr, batch_i32, mean):
+        x = _f32(x)
+        B = mol_ptr.numel() - 1
+        out = segment_sum_rows(x, mol_ptr, None, B, mean=mean)
+        ctx.save_for_backward(mol_ptr, batch_i32)
+        ctx.mean = mean
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mol_ptr, batch_i32 = ctx.saved_tensors
+        g = _f32(g)
+        if ctx.mean:
+            cnt = (mol_ptr[1:] - mol_ptr[:-1]).clamp(min=1).to(torch.float32)
+            g = g / cnt.unsqueeze(1)
+        return gather_rows(g, batch_i32), None, None, None
+
+
+def segment_reduce(x, mol_ptr, batch_i32, mean=True):
+    return _SegmentMean.apply(x, mol_ptr, batch_i32, mean)
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+def adam_flat(p, g, m, v, step_dev, seg_end, seg_lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    _lib.call("msde_adam_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(step_dev), _p(seg_end), _p(seg_lr),
+              seg_lr.numel(), float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _stream())

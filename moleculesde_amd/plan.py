@@ -1,0 +1,116 @@
+"""Per-batch graph plans: everything index-shaped that the kernels need, built ONCE per mini-batch
+(at collation time on the host, next to PyG-style collate, or lazily from a device batch).
+
+The reference rebuilds nothing but the radius graph per step (schnet.py:91); its bond and extended
+edge lists come from the data loader (dataset_3D.py:12-35).  Accordingly the bond / extended CSR
+plans and embedding row lists live here, while the radius CSR is produced on the device in every
+SchNet forward (hip.radius_plan).
+"""
+import types
+
+import torch
+
+from . import hip
+
+ATOM_FEATURE_DIMS = [119, 4, 12, 12, 10, 6, 6, 2, 2]   # ogb 1.2.1; configurable in GNN
+BOND_FEATURE_DIMS = [5, 6, 2]
+
+
+def _offsets(dims):
+    off = [0]
+    for d in dims[:-1]:
+        off.append(off[-1] + d)
+    return off
+
+
+def _row_lists(codes, R):
+    """CSR of item ids per table row: codes [M,K] (already offset) -> (list_ptr [R+1], list_items)."""
+    M, K = codes.shape
+    flat = codes.reshape(-1).long()
+    item = torch.arange(M, device=codes.device).repeat_interleave(K)
+    srow, order = torch.sort(flat, stable=True)
+    list_ptr = torch.searchsorted(srow, torch.arange(R + 1, device=codes.device)).to(torch.int32)
+    return list_ptr, item[order].to(torch.int32)
+
+
+def build_plan(data, atom_dims=None, bond_dims=None, max_nbr=32, with_ext=True):
+    """Build the plan from the batch tensors wherever they live (host preferred)."""
+    atom_dims = atom_dims or ATOM_FEATURE_DIMS
+    bond_dims = bond_dims or BOND_FEATURE_DIMS
+    pl = types.SimpleNamespace()
+    x = data.x
+    N = x.size(0)
+    dev = x.device
+    pl.N = N
+    batch = data.batch
+    B = int(data.num_graphs) if hasattr(data, "num_graphs") else int(batch.max()) + 1
+    pl.B = B
+    counts = torch.bincount(batch, minlength=B)
+    pl.mol_ptr = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+    pl.batch_i32 = batch.to(torch.int32)
+    c = counts.cpu()
+    pl.E_r_cap = int((c * torch.clamp(c - 1, max=max_nbr)).sum())
+    pl.N_max = int(c.max()) if B > 0 else 0
+    pl.max_nbr = max_nbr
+    # 2D atom codes (9 OGB columns) or 1-D z
+    if x.dim() == 2:
+        aoff = torch.tensor(_offsets(atom_dims), device=dev)
+        pl.atom_codes = (x.long() + aoff[None, : x.size(1)]).to(torch.int32).contiguous()
+        pl.atom_R = sum(atom_dims)
+        pl.atom_list_ptr, pl.atom_list_nodes = _row_lists(pl.atom_codes, pl.atom_R)
+        z = x[:, 0]
+    else:
+        z = x
+    pl.z_codes = z.to(torch.int32).view(-1, 1).contiguous()
+    pl.z_list = None  # built lazily per node_class (SchNet.embedding rows)
+    # bond graph
+    if hasattr(data, "edge_index") and data.edge_index is not None:
+        pl.bond = hip.build_csr(data.edge_index, N)
+        if hasattr(data, "edge_attr") and data.edge_attr is not None and data.edge_attr.dim() == 2:
+            boff = torch.tensor(_offsets(bond_dims), device=dev)
+            ea = data.edge_attr.long()[pl.bond.perm_t]
+            pl.bond_codes = (ea + boff[None, : ea.size(1)]).to(torch.int32).contiguous()
+            pl.bond_R = sum(bond_dims)
+            pl.bond_type = ea[:, 0].to(torch.float32)  # canonical order; 3D->2D adjacency values
+    if with_ext and hasattr(data, "extended_edge_index") and data.extended_edge_index is not None:
+        pl.ext = hip.build_csr(data.extended_edge_index, N)
+    return pl
+
+
+def plan_to(pl, device):
+    for k, v in list(vars(pl).items()):
+        if isinstance(v, torch.Tensor):
+            setattr(pl, k, v.to(device))
+        elif isinstance(v, hip.CsrPlan):
+            v.to(device)
+    return pl
+
+
+def prepare_batch(data, device=None, **kw):
+    """Collate-time entry point: build the plan on the host, then move batch + plan to the device."""
+    pl = build_plan(data, **kw)
+    if device is not None:
+        data.to(device)
+        plan_to(pl, device)
+    data._msde_plan = pl
+    return data
+
+
+def get_plan(data):
+    """Plan of a batch, built lazily (one host sync) when the driver did not call prepare_batch."""
+    pl = getattr(data, "_msde_plan", None)
+    if pl is None or pl.mol_ptr.device != data.x.device:
+        pl = build_plan(data)
+        try:
+            data._msde_plan = pl
+        except Exception:
+            pass
+    return pl
+
+
+def z_lists(pl, node_class):
+    """Row lists for SchNet's nn.Embedding(node_class, H) backward."""
+    if pl.z_list is None or pl.z_list[0] != node_class:
+        ptr, nodes = _row_lists(pl.z_codes, node_class)
+        pl.z_list = (node_class, ptr, nodes)
+    return pl.z_list[1], pl.z_list[2]

@@ -1,0 +1,241 @@
+"""Counterpart of examples/pretrain_MoleculeSDE.py:106-175,178-348 on the HIP-backed models.
+
+Same flag names and defaults for everything that shapes the hot path (examples/config.py), same
+loss composition  CL*c1 + L_2Dto3D*c2 + 0.5(L_x + L_adj)*c3  (:135-152), same optimiser grouping
+(:331-337), same checkpoint dictionary (:78-88).  Differences, all deliberate:
+  * per-step loss logging accumulates on the device (the reference forces 3 D2H syncs per step);
+  * Adam is one flat HIP kernel; under DP one RCCL all-reduce precedes it;
+  * the data here is the synthetic PCQM4Mv2-shaped generator (no dataset exists in the containers).
+"""
+import argparse
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+
+from . import dp
+from .geom3d import GNN, SchNet, SDEModel2Dto3D_02, prepare_batch
+from .geom3d import nn as _nn
+from .optim import FlatAdam
+
+
+def add_hot_path_flags(parser):
+    """Subset of examples/config.py that shapes the pretrain step (same names and defaults)."""
+    a = parser.add_argument
+    a("--seed", type=int, default=42)
+    a("--device", type=int, default=0)
+    a("--epochs", type=int, default=100)
+    a("--batch_size", type=int, default=128)
+    a("--lr", type=float, default=1e-4)
+    a("--decay", type=float, default=0)
+    a("--gnn_type", type=str, default="GIN")
+    a("--num_layer", type=int, default=5)
+    a("--emb_dim", type=int, default=300)
+    a("--dropout_ratio", type=float, default=0.5)
+    a("--JK", type=str, default="last")
+    a("--gnn_2d_lr_scale", type=float, default=1)
+    a("--gnn_3d_lr_scale", type=float, default=1)
+    a("--model_3d", type=str, default="SchNet")
+    a("--SchNet_num_filters", type=int, default=128)
+    a("--SchNet_num_interactions", type=int, default=6)
+    a("--SchNet_num_gaussians", type=int, default=51)
+    a("--SchNet_cutoff", type=float, default=10)
+    a("--SchNet_readout", type=str, default="mean", choices=["mean", "add"])
+    a("--CL_similarity_metric", type=str, default="InfoNCE_dot_prod")
+    a("--T", type=float, default=0.1)
+    a("--normalize", dest="normalize", action="store_true")
+    a("--no_normalize", dest="normalize", action="store_false")
+    a("--SDE_type_2Dto3D", type=str, default="VE")
+    a("--SDE_type_3Dto2D", type=str, default="VE")
+    a("--SDE_2Dto3D_model", type=str, default="SDEModel2Dto3D_01")
+    a("--SDE_3Dto2D_model", type=str, default="SDEModel3Dto2D_node_adj_dense")
+    a("--SDE_coeff_contrastive", type=float, default=1)
+    a("--SDE_coeff_contrastive_skip_epochs", type=int, default=0)
+    a("--SDE_coeff_generative_2Dto3D", type=float, default=1)
+    a("--SDE_coeff_generative_3Dto2D", type=float, default=1)
+    a("--use_extend_graph", dest="use_extend_graph", action="store_true")
+    a("--no_extend_graph", dest="use_extend_graph", action="store_false")
+    parser.set_defaults(use_extend_graph=True)
+    a("--noise_on_one_hot", dest="noise_on_one_hot", action="store_true")
+    a("--no_noise_on_one_hot", dest="noise_on_one_hot", action="store_false")
+    parser.set_defaults(noise_on_one_hot=True)
+    a("--SDE_anneal_power", type=float, default=0)
+    a("--output_model_dir", type=str, default="")
+    a("--verbose", dest="verbose", action="store_true")
+    return parser
+
+
+def readme_args(**over):
+    """The README pre-training command (README.md:86-93) as a namespace."""
+    p = add_hot_path_flags(argparse.ArgumentParser())
+    args = p.parse_args([
+        "--model_3d=SchNet", "--lr=1e-4", "--batch_size=256", "--gnn_3d_lr_scale=0.1", "--dropout_ratio=0",
+        "--emb_dim=300", "--epochs=1", "--SDE_coeff_contrastive=1", "--CL_similarity_metric=EBM_node_dot_prod",
+        "--T=0.1", "--normalize", "--SDE_coeff_contrastive_skip_epochs=0", "--SDE_coeff_generative_2Dto3D=1",
+        "--SDE_2Dto3D_model=SDEModel2Dto3D_02", "--SDE_type_2Dto3D=VE", "--use_extend_graph",
+        "--SDE_coeff_generative_3Dto2D=1", "--SDE_3Dto2D_model=SDEModel3Dto2D_node_adj_dense",
+        "--SDE_type_3Dto2D=VE", "--noise_on_one_hot"])
+    for k, v in over.items():
+        setattr(args, k, v)
+    return args
+
+
+_SDE_RANGES_2D3D = {"VE": ("VE", 0.2, 1.0), "VP": ("VP", 0.2, 1.0), "VE02": ("VE", 0.1, 10.0), "VP02": ("VP", 0.2, 30.0),
+                    "VE03": ("VE", 0.1, 1000.0), "VP03": ("VP", 0.2, 1000.0)}
+
+
+def build_models(args, device):
+    """pretrain_MoleculeSDE.py:197-315 (SchNet / SDEModel2Dto3D_02 / SDEModel3Dto2D_node_adj_dense)."""
+    node_class = 119
+    models = {}
+    models["model_2D"] = GNN(args.num_layer, args.emb_dim, JK=args.JK, drop_ratio=args.dropout_ratio,
+                             gnn_type=args.gnn_type).to(device)
+    if args.model_3d != "SchNet":
+        raise NotImplementedError("only SchNet is on the MoleculeSDE hot path")
+    models["model_3D"] = SchNet(hidden_channels=args.emb_dim, num_filters=args.SchNet_num_filters,
+                                num_interactions=args.SchNet_num_interactions,
+                                num_gaussians=args.SchNet_num_gaussians, cutoff=args.SchNet_cutoff,
+                                readout=args.SchNet_readout, node_class=node_class).to(device)
+    if args.SDE_2Dto3D_model != "SDEModel2Dto3D_02":
+        raise NotImplementedError(args.SDE_2Dto3D_model)
+    sde_type, bmin, bmax = _SDE_RANGES_2D3D[args.SDE_type_2Dto3D]
+    models["SDE_2Dto3D_model"] = SDEModel2Dto3D_02(
+        emb_dim=args.emb_dim, hidden_dim=32, beta_min=bmin, beta_max=bmax, num_diffusion_timesteps=1000,
+        beta_schedule=None, SDE_type=sde_type, use_extend_graph=args.use_extend_graph).to(device)
+    if args.SDE_coeff_generative_3Dto2D > 0:
+        from .geom3d import sde_3d_to_2d  # noqa: F401  (built in a later milestone)
+        models["SDE_3Dto2D_model"] = sde_3d_to_2d.build_from_args(args, node_class).to(device)
+    return models
+
+
+def make_optimizer(args, models):
+    """pretrain_MoleculeSDE.py:331-337."""
+    groups = [{"params": list(models["model_2D"].parameters()), "lr": args.lr * args.gnn_2d_lr_scale},
+              {"params": list(models["model_3D"].parameters()), "lr": args.lr * args.gnn_3d_lr_scale},
+              {"params": list(models["SDE_2Dto3D_model"].parameters()), "lr": args.lr * args.gnn_2d_lr_scale}]
+    if "SDE_3Dto2D_model" in models:
+        groups.append({"params": list(models["SDE_3Dto2D_model"].parameters()),
+                       "lr": args.lr * args.gnn_3d_lr_scale})
+    return FlatAdam(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=args.decay)
+
+
+def do_CL(X, Y, args, noise):
+    """'EBM_node_dot_prod' branch of examples/util.py:52-68 (the metric of the README command)."""
+    if args.CL_similarity_metric != "EBM_node_dot_prod":
+        raise NotImplementedError(args.CL_similarity_metric)
+    neg_index = noise.randperm(len(Y), Y.device)
+    neg_Y = Y[neg_index]
+    pred_pos = torch.sum(X * Y, dim=1) / args.T
+    pred_neg = torch.sum(X * neg_Y, dim=1) / args.T
+    loss_pos = F.binary_cross_entropy_with_logits(pred_pos, torch.ones_like(pred_pos))
+    loss_neg = F.binary_cross_entropy_with_logits(pred_neg, torch.zeros_like(pred_neg))
+    acc = (torch.sum(pred_pos > 0).float() + torch.sum(pred_neg < 0).float()) / (len(pred_pos) + len(pred_neg))
+    return loss_pos + loss_neg, acc.detach()
+
+
+def dual_CL(X, Y, args, noise):
+    """examples/util.py:76-79; the accuracy stays a device scalar (no sync)."""
+    l1, a1 = do_CL(X, Y, args, noise)
+    l2, a2 = do_CL(Y, X, args, noise)
+    return (l1 + l2) / 2, (a1 + a2) / 2
+
+
+class Trainer:
+    """One object per rank: models, flat Adam, the step function of pretrain_MoleculeSDE.py:125-156."""
+
+    def __init__(self, args, device, noise=None):
+        self.args, self.device = args, device
+        self.models = build_models(args, device)
+        self.opt = make_optimizer(args, self.models)
+        dp.broadcast_flat(self.opt.flat_p)
+        self.noise = noise or _nn.DeviceNoise()
+        self.models["SDE_2Dto3D_model"].noise = self.noise
+        if "SDE_3Dto2D_model" in self.models:
+            self.models["SDE_3Dto2D_model"].noise = self.noise
+        self.coeff_cl = args.SDE_coeff_contrastive
+        self.log = {k: torch.zeros((), device=device) for k in ("CL", "CL_acc", "2Dto3D", "3Dto2D")}
+        self.steps = 0
+        for m in self.models.values():
+            m.train()
+
+    def losses(self, batch):
+        a, m = self.args, self.models
+        node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
+        _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+        loss = 0
+        parts = {}
+        if self.coeff_cl > 0:
+            cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise)
+            loss = loss + cl * self.coeff_cl
+            parts["CL"], parts["CL_acc"] = cl.detach(), acc
+        if a.SDE_coeff_generative_2Dto3D > 0:
+            l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
+            loss = loss + l23 * a.SDE_coeff_generative_2Dto3D
+            parts["2Dto3D"] = l23.detach()
+        if a.SDE_coeff_generative_3Dto2D > 0:
+            lx, la = m["SDE_3Dto2D_model"](node_3D_repr, batch, reduce_mean=a.noise_on_one_hot, continuous=True,
+                                           train=True, anneal_power=a.SDE_anneal_power)
+            l32 = (lx + la) * 0.5
+            loss = loss + l32 * a.SDE_coeff_generative_3Dto2D
+            parts["3Dto2D"] = l32.detach()
+        return loss, parts
+
+    def step(self, batch):
+        loss, parts = self.losses(batch)
+        self.opt.zero_grad()
+        loss.backward()
+        flat_g = self.opt.gather_grads()
+        scale = dp.allreduce_mean_(flat_g)
+        self.opt.step(grad_scale=scale)
+        for k, v in parts.items():
+            self.log[k] += v
+        self.steps += 1
+        return loss.detach(), parts
+
+    def state_dicts(self):
+        """Checkpoint dictionary of pretrain_MoleculeSDE.py:78-88."""
+        return {k: m.state_dict() for k, m in self.models.items()}
+
+    def save(self, path):
+        torch.save(self.state_dicts(), path)
+
+
+def main(argv=None):
+    from .synthetic import make_batch
+    p = add_hot_path_flags(argparse.ArgumentParser(description=__doc__))
+    p.add_argument("--steps_per_epoch", type=int, default=20)
+    args = p.parse_args(argv)
+    rank, world, local = dp.init_from_env("cuda")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.manual_seed(0)
+    trainer = Trainer(args, device)
+    pool = [prepare_batch(make_batch(args.batch_size, seed=dp.shard_seed(s, rank)), device) for s in range(4)]
+    original = args.SDE_coeff_contrastive
+    optimal = 1e10
+    for epoch in range(1, args.epochs + 1):
+        trainer.coeff_cl = original if epoch > args.SDE_coeff_contrastive_skip_epochs else 0
+        for k in trainer.log:
+            trainer.log[k].zero_()
+        t0 = time.time()
+        for s in range(args.steps_per_epoch):
+            trainer.step(pool[s % len(pool)])
+        torch.cuda.synchronize()
+        n = args.steps_per_epoch
+        cl, acc, l23, l32 = (float(trainer.log[k]) / n for k in ("CL", "CL_acc", "2Dto3D", "3Dto2D"))
+        if rank == 0:
+            print("epoch: {}".format(epoch))
+            print("CL Loss: {:.5f}\tCL Acc: {:.5f}\t\tSDE 2Dto3D Loss: {:.5f}\tSDE 3Dto2D Loss: {:.5f}".format(cl, acc, l23, l32))
+            print("Time: {:.5f}\n".format(time.time() - t0))
+            temp = args.SDE_coeff_contrastive * cl + args.SDE_coeff_generative_2Dto3D * l23 + \
+                args.SDE_coeff_generative_3Dto2D * l32
+            if temp < optimal and args.output_model_dir:
+                optimal = temp
+                trainer.save(os.path.join(args.output_model_dir, "model_complete.pth"))
+    if rank == 0 and args.output_model_dir:
+        trainer.save(os.path.join(args.output_model_dir, "model_complete_final.pth"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,49 @@
+"""2D->3D reverse-SDE predictor-corrector sampler (BASELINE.json config 4), as INTENDED by
+examples/pretrain_MoleculeSDE_inference_2D_to_3D_VE_VP.py:92-212.  The script itself is broken as
+shipped (missing import, undefined args, hard-coded `break` after 11 steps); this
+restates the algorithm:  for t in linspace(T, eps, N):  Langevin corrector -> reverse-diffusion
+predictor, each calling SDEModel2Dto3D_02.get_score on the replicated molecule batch."""
+import torch
+
+
+def predictor_update(sde, score_model, representation, data, pos, t, noise=None):
+    """ReverseDiffusionPredictor.update_fn (:163-168)."""
+    f, G = sde.reverse_discretize(score_model, pos, representation, data, t)
+    noise = torch.randn_like(pos) if noise is None else noise
+    x_mean = pos - f
+    return x_mean + G[:, None] * noise, x_mean
+
+
+def corrector_update(sde, score_model, representation, data, pos, t, snr, scale_eps, n_steps, noises=None):
+    """LangevinCorrector.update_fn (:191-212), VE branch (alpha = 1).  As in the script, the inner
+    iterations do not feed `pos` back (App. B.2), so the score is evaluated once per call when
+    n_steps == 1 and only the last pass matters otherwise."""
+    alpha = torch.ones_like(t)
+    x = x_mean = pos
+    for i in range(n_steps):
+        grad = score_model.get_score(representation, data, pos, None, t)
+        noise = torch.randn_like(pos) if noises is None else noises[i]
+        grad_norm = torch.norm(grad.reshape(grad.shape[0], -1), dim=-1).mean()
+        noise_norm = torch.norm(noise.reshape(noise.shape[0], -1), dim=-1).mean()
+        step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+        x_mean = pos + step_size[:, None] * grad
+        x = x_mean + torch.sqrt(step_size * 2)[:, None] * noise * scale_eps
+    return x, x_mean
+
+
+@torch.no_grad()
+def position_PC_generation(score_model, representation, data, num_steps=1000, snr=0.16, scale_eps=0.7,
+                           n_corrector_steps=1, eps=1e-4, denoise=True, pos_init=None):
+    """position_PC_generation (:92-138): returns the final coordinates [N, 3]."""
+    sde = score_model.sde_pos
+    n = representation.size(0)
+    dev = representation.device
+    pos = torch.randn(n, 3, device=dev) if pos_init is None else pos_init
+    timesteps = torch.linspace(sde.T, eps, num_steps, device=dev)
+    x_mean = pos
+    for i in range(num_steps):
+        vec_t = torch.ones(n, device=dev) * timesteps[i]
+        pos, x_mean = corrector_update(sde, score_model, representation, data, pos, vec_t, snr, scale_eps,
+                                       n_corrector_steps)
+        pos, x_mean = predictor_update(sde, score_model, representation, data, pos, vec_t)
+    return x_mean if denoise else pos

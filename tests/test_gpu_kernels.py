@@ -1,0 +1,390 @@
+"""Kernel-level parity (GPU box): every C-ABI entry point, called through moleculesde_amd.hip, against
+the oracle's CPU restatement of the same op on seeded inputs.  Integer/index outputs are bit-exact;
+floating point is fp32 with the tolerance written at each assert."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restate as R  # noqa: E402
+from helpers import assert_close  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from moleculesde_amd import _lib
+    _lib.load()  # fails loudly if libmsde_hip.so is missing
+    return torch.device("cuda", 0)
+
+
+def _toy_graph(seed=0, B=6):
+    from moleculesde_amd.synthetic import make_batch
+    return make_batch(B, seed)
+
+
+def _plan_for(edge_index, N, dev):
+    from moleculesde_amd import hip
+    return hip.build_csr(edge_index, N).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_abi_identity(dev):
+    from moleculesde_amd import _lib
+    lib = _lib.load()
+    assert lib.msde_abi_version() == 1
+    assert lib.msde_target_arch() == b"gfx950"
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 1023, 1024, 1025, 5000])
+def test_exclusive_scan(dev, n):
+    from moleculesde_amd import _lib, hip
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 33, (n,), generator=g, dtype=torch.int32)
+    xd = x.to(dev)
+    out = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    _lib.call("msde_exclusive_scan_i32", hip._p(xd), hip._p(out), n, hip._stream())
+    ref = torch.cat([torch.zeros(1, dtype=torch.int64), x.long().cumsum(0)])
+    assert torch.equal(out.cpu().long(), ref)
+
+
+def _radius_check(dev, pos, batch, cutoff, max_nbr=32):
+    from moleculesde_amd import hip, plan as P
+    import types
+    d = types.SimpleNamespace(x=torch.zeros(pos.size(0), dtype=torch.long), batch=batch, num_graphs=int(batch.max()) + 1,
+                              edge_index=None, edge_attr=None)
+    pl = P.plan_to(P.build_plan(d, max_nbr=max_nbr, with_ext=False), dev)
+    rp, dist = hip.radius_plan(pos.to(dev), pl.batch_i32, pl.mol_ptr, cutoff, pl.E_r_cap, max_nbr)
+    ei = R.radius_graph(pos, cutoff, batch, max_nbr)
+    E = ei.size(1)
+    assert int(rp.rowptr[-1]) == E
+    assert torch.equal(rp.src[:E].cpu().long(), ei[0])          # grouped by target, index order
+    assert torch.equal(rp.dst[:E].cpu().long(), ei[1])
+    assert bool((rp.src[E:] == -1).all()) and bool((dist[E:] == 0).all())
+    dref = (pos[ei[0]] - pos[ei[1]]).norm(dim=-1)
+    assert_close(dist[:E], dref, 1e-6, 1e-7, "edge distance")
+    # transposed view is a permutation of the real edges, grouped by source
+    perm = rp.perm_s[:E].cpu().long()
+    assert torch.equal(torch.sort(perm)[0], torch.arange(E))
+    s_sorted = ei[0][perm]
+    assert torch.equal(s_sorted, torch.sort(ei[0], stable=True)[0])
+    N = pos.size(0)
+    assert torch.equal(rp.rowptr_s.cpu().long(), torch.searchsorted(s_sorted, torch.arange(N + 1)))
+    return rp, dist
+
+
+def test_radius_graph_synthetic(dev):
+    b = _toy_graph(3, 16)
+    _radius_check(dev, b.positions, b.batch, 10.0)
+    _radius_check(dev, b.positions, b.batch, 2.0)      # sparse: most pairs outside
+
+
+def test_radius_graph_strict_and_cap(dev):
+    pos = torch.tensor([[0.0, 0, 0], [1.0, 0, 0], [0.0, 0, 0], [11.0, 0, 0], [10.0, 0, 0]])
+    batch = torch.tensor([0, 0, 1, 1, 1])
+    _radius_check(dev, pos, batch, 10.0)
+    line = torch.zeros(40, 3)
+    line[:, 0] = torch.arange(40) * 0.01
+    rp, _ = _radius_check(dev, line, torch.zeros(40, dtype=torch.long), 10.0, 32)   # cap binds: asymmetric graph
+    assert int((rp.rowptr[1:] - rp.rowptr[:-1]).max()) == 32
+
+
+@pytest.mark.parametrize("D", [300, 128, 32, 3])
+def test_segment_sum_and_gathers(dev, D):
+    from moleculesde_amd import hip
+    torch.manual_seed(D)
+    b = _toy_graph(1, 8)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    E = pl.E
+    rows = torch.randn(E, D)
+    rd = rows.to(dev)
+    dst = pl.dst.cpu().long()
+    src = pl.src.cpu().long()
+    out_t = hip.segment_sum_rows(rd, pl.rowptr, None, N)
+    assert_close(out_t, R.scatter_sum(rows, dst, N), 1e-5, 1e-5, "segment sum by target")
+    out_s = hip.segment_sum_rows(rd, pl.rowptr_s, pl.perm_s, N)
+    assert_close(out_s, R.scatter_sum(rows, src, N), 1e-5, 1e-5, "segment sum by source")
+    out_m = hip.segment_sum_rows(rd, pl.rowptr, None, N, mean=True)
+    assert_close(out_m, R.scatter_mean(rows, dst, N), 1e-5, 1e-5, "segment mean")
+    A, Bm = torch.randn(N, D), torch.randn(N, D)
+    pg = hip.pair_gather_add(A.to(dev), Bm.to(dev), pl)
+    assert_close(pg, A[src] + Bm[dst], 0, 0, "pair gather add")     # exact: one add
+    assert_close(hip.gather_rows(A.to(dev), pl.src), A[src], 0, 0, "gather rows")
+
+
+def test_pair_gather_add_backward(dev):
+    from moleculesde_amd import hip
+    torch.manual_seed(5)
+    b = _toy_graph(2, 8)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    src, dst = pl.src.cpu().long(), pl.dst.cpu().long()
+    A = torch.randn(N, 32, requires_grad=True)
+    Bm = torch.randn(N, 32, requires_grad=True)
+    w = torch.randn(pl.E, 32)
+    ((A[src] + Bm[dst]) * w).sum().backward()
+    Ad, Bd = A.detach().to(dev).requires_grad_(True), Bm.detach().to(dev).requires_grad_(True)
+    (hip.pair_gather_add(Ad, Bd, pl) * w.to(dev)).sum().backward()
+    assert_close(Ad.grad, A.grad, 1e-5, 1e-5, "gA")
+    assert_close(Bd.grad, Bm.grad, 1e-5, 1e-5, "gB")
+
+
+@pytest.mark.parametrize("D", [300, 16])
+def test_embedding_sum(dev, D):
+    from moleculesde_amd import hip, plan as P
+    torch.manual_seed(1)
+    b = _toy_graph(4, 32)
+    pl = P.plan_to(P.build_plan(b), dev)
+    enc = R._EmbeddingSum(R.ATOM_FEATURE_DIMS, D, "atom_embedding_list")
+    ref = enc(b.x)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    tab = torch.cat([e.weight.detach() for e in enc.atom_embedding_list]).to(dev).requires_grad_(True)
+    out = hip.embedding_sum(tab, pl.atom_codes, pl.atom_list_ptr, pl.atom_list_nodes)
+    assert_close(out, ref, 1e-6, 1e-6, "atom encoder fwd")
+    (out * w.to(dev)).sum().backward()
+    gref = torch.cat([e.weight.grad for e in enc.atom_embedding_list])
+    assert_close(tab.grad, gref, 1e-4, 1e-4, "atom encoder table grad")
+
+
+@pytest.mark.parametrize("D", [300, 16, 6])
+def test_gin_aggregate(dev, D):
+    from moleculesde_amd import hip, plan as P
+    torch.manual_seed(2)
+    b = _toy_graph(5, 32)
+    pl = P.plan_to(P.build_plan(b), dev)
+    conv = R.GINConv(D)
+    conv.mlp = torch.nn.Identity()
+    with torch.no_grad():
+        conv.eps.fill_(0.3)
+    x = torch.randn(b.x.size(0), D, requires_grad=True)
+    ref = conv(x, b.edge_index, b.edge_attr)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    tab = torch.cat([e.weight.detach() for e in conv.bond_encoder.bond_embedding_list]).to(dev).requires_grad_(True)
+    xd = x.detach().to(dev).requires_grad_(True)
+    eps = conv.eps.detach().to(dev).requires_grad_(True)
+    out = hip.gin_aggregate(xd, tab, eps, pl.bond, pl.bond_codes)
+    assert_close(out, ref, 1e-5, 1e-5, "gin fwd")
+    (out * w.to(dev)).sum().backward()
+    assert_close(xd.grad, x.grad, 1e-5, 1e-5, "gin g_x")
+    gtab = torch.cat([e.weight.grad for e in conv.bond_encoder.bond_embedding_list])
+    assert_close(tab.grad, gtab, 1e-4, 1e-4, "gin g_tab")
+    assert_close(eps.grad, conv.eps.grad, 1e-4, 1e-4, "gin g_eps")
+
+
+def _radius_setup(dev, B=24, seed=7):
+    from moleculesde_amd import hip, plan as P
+    b = _toy_graph(seed, B)
+    pl = P.plan_to(P.build_plan(b), dev)
+    rp, dist = hip.radius_plan(b.positions.to(dev), pl.batch_i32, pl.mol_ptr, 10.0, pl.E_r_cap, 32)
+    E = int(rp.rowptr[-1])
+    ei = torch.stack([rp.src[:E].cpu().long(), rp.dst[:E].cpu().long()])
+    return b, pl, rp, dist, E, ei
+
+
+def test_rbf_cutoff(dev):
+    from moleculesde_amd import hip
+    b, pl, rp, dist, E, ei = _radius_setup(dev)
+    gs = R.GaussianSmearing(0.0, 10.0, 51)
+    rbf, C = hip.rbf_cutoff(dist, rp.E_dev, gs.offset.to(dev), gs.coeff, 10.0)
+    d = dist[:E].cpu()
+    assert_close(rbf[:E], gs(d), 1e-5, 1e-6, "rbf")
+    assert_close(C[:E], 0.5 * (torch.cos(d * math.pi / 10.0) + 1.0), 1e-5, 1e-6, "cutoff")
+    assert bool((rbf[E:] == 0).all()) and bool((C[E:] == 0).all())
+
+
+@pytest.mark.parametrize("Fd", [128, 16])
+def test_cfconv_aggregate(dev, Fd):
+    from moleculesde_amd import hip
+    torch.manual_seed(3)
+    b, pl, rp, dist, E, ei = _radius_setup(dev)
+    N = b.x.size(0)
+    x1 = torch.randn(N, Fd, requires_grad=True)
+    Wf = torch.randn(rp.E, Fd, requires_grad=True)
+    C = torch.rand(rp.E)
+    ref = R.scatter_sum(x1[ei[0]] * (Wf[:E] * C[:E, None]), ei[1], N)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    x1d = x1.detach().to(dev).requires_grad_(True)
+    Wfd = Wf.detach().to(dev).requires_grad_(True)
+    out = hip.cfconv_aggregate(x1d, Wfd, C.to(dev), rp)
+    assert_close(out, ref, 1e-5, 1e-5, "cfconv fwd")
+    (out * w.to(dev)).sum().backward()
+    assert_close(x1d.grad, x1.grad, 1e-5, 1e-5, "cfconv g_x1")
+    assert_close(Wfd.grad, Wf.grad, 1e-5, 1e-5, "cfconv g_Wf (padded rows zero)")
+
+
+@pytest.mark.parametrize("G,npw", [(51, 16), (50, 7), (20, 32)])
+def test_cfconv_fused_forward(dev, G, npw):
+    """Fused fp32-MFMA CFConv vs the oracle's CFConv interior (schnet.py:185-195)."""
+    from moleculesde_amd import hip
+    torch.manual_seed(4)
+    b, pl, rp, dist, E, ei = _radius_setup(dev, B=40, seed=9)
+    N = b.x.size(0)
+    blk = R.InteractionBlock(hidden_channels=64, num_gaussians=G, num_filters=128, cutoff=10.0)
+    with torch.no_grad():
+        blk.mlp[0].bias.normal_(0, 0.1)
+        blk.mlp[2].bias.normal_(0, 0.1)
+    gs = R.GaussianSmearing(0.0, 10.0, G)
+    x1 = torch.randn(N, 128)
+    d = dist[:E].cpu()
+    Cc = 0.5 * (torch.cos(d * math.pi / 10.0) + 1.0)
+    with torch.no_grad():
+        Wf = blk.mlp(gs(d)) * Cc.view(-1, 1)
+        ref = R.scatter_sum(x1[ei[0]] * Wf, ei[1], N)
+    out = hip.cfconv_fused_forward(x1.to(dev), dist, rp, blk.mlp[0].weight.detach().to(dev),
+                                   blk.mlp[0].bias.detach().to(dev), blk.mlp[2].weight.detach().to(dev),
+                                   blk.mlp[2].bias.detach().to(dev), gs.offset.to(dev), gs.coeff, 10.0, npw)
+    assert_close(out, ref, 1e-4, 1e-4 * float(ref.abs().max()), "fused cfconv")
+
+
+def test_edge_geometry(dev):
+    from moleculesde_amd import hip
+    torch.manual_seed(6)
+    b = _toy_graph(8, 16)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    pos = b.positions + 0.3 * torch.randn_like(b.positions)
+    Wd, Wc = torch.randn(32), torch.randn(32)
+    fd, fi, fj, ang, basis = hip.edge_geometry(pos.to(dev), pl, Wd.to(dev), Wc.to(dev))
+    row, col = pl.src.cpu().long(), pl.dst.cpu().long()
+    cd, cc, cv = R.coord2basis(pos, row, col)
+    assert_close(basis, torch.cat([cd, cc, cv], dim=1), 1e-4, 1e-5, "basis")
+    dist = (pos[row] - pos[col]).norm(dim=-1, keepdim=True)
+    gf = R.GaussianFourierProjection(32)
+    gf.W.data = Wd
+    # sin/cos of arguments up to ~1e2 rad: absolute tolerance = |arg| * 2^-23 * few
+    assert_close(fd, gf(dist), 0, 5e-5, "distance fourier")
+    eb = torch.stack([cd, cc, cv], dim=1)
+    ci = torch.matmul(eb, pos[row].unsqueeze(-1)).squeeze(-1)
+    cj = torch.matmul(eb, pos[col].unsqueeze(-1)).squeeze(-1)
+    ci[:, 1] = ci[:, 1].abs()
+    cj[:, 1] = cj[:, 1].abs()
+    gc = R.GaussianFourierProjection(32)
+    gc.W.data = Wc
+    emb = lambda c: torch.cat([gc(c[:, 0:1]), gc(c[:, 2:3])], dim=-1)
+    assert_close(fi, emb(ci), 0, 2e-4, "frame fourier i")
+    assert_close(fj, emb(cj), 0, 2e-4, "frame fourier j")
+    pcos = (ci * cj).sum(-1, keepdim=True) / (ci.norm(dim=-1, keepdim=True) + 1e-6) / (cj.norm(dim=-1, keepdim=True) + 1e-6)
+    assert_close(ang[:, 1:2], pcos, 1e-4, 1e-5, "pseudo cos")
+    good = (pcos.abs() < 0.999).flatten()          # sqrt(1-c^2) is ill-conditioned near |c| = 1
+    assert_close(ang[good, 0:1], torch.sqrt(1 - pcos[good] ** 2), 1e-3, 1e-4, "pseudo sin")
+
+
+@pytest.mark.parametrize("H,Ch", [(8, 4), (4, 8), (2, 2)])
+def test_edge_attention(dev, H, Ch):
+    from moleculesde_amd import hip
+    torch.manual_seed(10 + H)
+    b = _toy_graph(11, 16)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    D = H * Ch
+    src, dst = pl.src.cpu().long(), pl.dst.cpu().long()
+    q, k, v = (torch.randn(N, D, requires_grad=True) for _ in range(3))
+    ee = torch.randn(pl.E, D, requires_grad=True)
+    qe = q[dst].view(-1, H, Ch)
+    ke = k[src].view(-1, H, Ch) + ee.view(-1, H, Ch)
+    alpha = R.segment_softmax((qe * ke).sum(-1) / math.sqrt(Ch), dst, N)
+    ref = R.scatter_sum((v[src].view(-1, H, Ch) + ee.view(-1, H, Ch)) * alpha.unsqueeze(-1), dst, N).view(N, D)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    ds = [t.detach().to(dev).requires_grad_(True) for t in (q, k, v, ee)]
+    out = hip.edge_attention(*ds, pl, H, 0.0, 0)
+    assert_close(out, ref, 1e-4, 1e-5, "attention fwd")
+    (out * w.to(dev)).sum().backward()
+    for name, a, r in zip("qkve", ds, (q, k, v, ee)):
+        assert_close(a.grad, r.grad, 1e-3, 2e-5, f"attention g_{name}")
+
+
+def test_edge_attention_dropout(dev):
+    """Dropout on alpha (hard-wired p = 0.1 in the reference): mask is a pure function of (seed, edge,
+    head) -> forward is reproducible, backward uses the same mask, and E[out] is preserved."""
+    from moleculesde_amd import hip
+    torch.manual_seed(12)
+    b = _toy_graph(13, 64)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    q, k, v = (torch.randn(N, 32, device=dev) for _ in range(3))
+    ee = torch.randn(pl.E, 32, device=dev)
+    o0 = hip.edge_attention(q, k, v, ee, pl, 8, 0.0, 0)
+    o1 = hip.edge_attention(q, k, v, ee, pl, 8, 0.1, 1234)
+    o1b = hip.edge_attention(q, k, v, ee, pl, 8, 0.1, 1234)
+    o2 = hip.edge_attention(q, k, v, ee, pl, 8, 0.1, 99)
+    assert torch.equal(o1, o1b) and not torch.equal(o1, o2) and not torch.equal(o1, o0)
+    acc = torch.zeros_like(o0)
+    for s in range(200):
+        acc += hip.edge_attention(q, k, v, ee, pl, 8, 0.1, 5000 + s)
+    assert float((acc / 200 - o0).abs().mean()) < 0.05 * float(o0.abs().mean()) + 0.02
+    # backward consistency under a fixed mask: directional finite difference on v
+    vv = v.clone().requires_grad_(True)
+    out = hip.edge_attention(q, k, vv, ee, pl, 8, 0.1, 77)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    dv = torch.randn_like(v)
+    eps = 1e-2
+    fp = (hip.edge_attention(q, k, v + eps * dv, ee, pl, 8, 0.1, 77) * w).sum()
+    fm = (hip.edge_attention(q, k, v - eps * dv, ee, pl, 8, 0.1, 77) * w).sum()
+    fd = float((fp - fm) / (2 * eps))
+    an = float((vv.grad * dv).sum())
+    assert abs(fd - an) <= 2e-3 * max(1.0, abs(an))     # out is linear in v: FD is exact up to rounding
+
+
+def test_frame_mix_mean(dev):
+    from moleculesde_amd import hip
+    torch.manual_seed(14)
+    b = _toy_graph(15, 16)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    dst = pl.dst.cpu().long()
+    coff = torch.randn(pl.E, 3, requires_grad=True)
+    basis = torch.randn(pl.E, 9)
+    mix = coff[:, :1] * basis[:, 0:3] + coff[:, 1:2] * basis[:, 3:6] + coff[:, 2:3] * basis[:, 6:9]
+    ref = R.scatter_mean(mix, dst, N)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    cd = coff.detach().to(dev).requires_grad_(True)
+    out = hip.frame_mix_mean(cd, basis.to(dev), pl)
+    assert_close(out, ref, 1e-5, 1e-6, "frame mix fwd")
+    (out * w.to(dev)).sum().backward()
+    assert_close(cd.grad, coff.grad, 1e-5, 1e-6, "frame mix g_coff")
+
+
+def test_segment_reduce_molecule(dev):
+    from moleculesde_amd import hip, plan as P
+    torch.manual_seed(16)
+    b = _toy_graph(17, 12)
+    pl = P.plan_to(P.build_plan(b), dev)
+    x = torch.randn(b.x.size(0), 20, requires_grad=True)
+    ref = R.scatter_mean(x, b.batch, b.num_graphs)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    xd = x.detach().to(dev).requires_grad_(True)
+    out = hip.segment_reduce(xd, pl.mol_ptr, pl.batch_i32, mean=True)
+    assert_close(out, ref, 1e-5, 1e-6, "readout mean")
+    (out * w.to(dev)).sum().backward()
+    assert_close(xd.grad, x.grad, 1e-5, 1e-6, "readout grad")
+
+
+def test_adam_flat_matches_torch_adam(dev):
+    from moleculesde_amd.optim import FlatAdam
+    torch.manual_seed(18)
+    ps = [torch.nn.Parameter(torch.randn(37, 5)), torch.nn.Parameter(torch.randn(11)), torch.nn.Parameter(torch.randn(64, 3))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt_ref = torch.optim.Adam([{"params": ref[:2], "lr": 1e-2}, {"params": ref[2:], "lr": 3e-3}], lr=1e-2, weight_decay=0.01)
+    pd = [torch.nn.Parameter(p.detach().to(dev)) for p in ps]
+    opt = FlatAdam([{"params": pd[:2], "lr": 1e-2}, {"params": pd[2:], "lr": 3e-3}], weight_decay=0.01)
+    for step in range(25):
+        gs = [torch.randn_like(p) for p in ps]
+        for p, g in zip(ref, gs):
+            p.grad = g.clone()
+        opt_ref.step()
+        for p, g in zip(pd, gs):
+            p.grad = g.to(dev)
+        opt.gather_grads()
+        opt.step()
+    for a, r in zip(pd, ref):
+        assert_close(a, r, 1e-5, 1e-6, "adam params after 25 steps")

@@ -1,0 +1,304 @@
+"""Model-level parity (GPU box): the HIP-backed classes of moleculesde_amd.geom3d against
+(a) the committed golden vectors produced by the reference's own files and (b) the oracle
+(oracle/restate.py) on seeded inputs at the BASELINE.json sizes, plus size-independent properties
+(rotation equivariance, molecule-permutation invariance) at full size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restate as R  # noqa: E402
+from helpers import assert_close, batch_from, disable_dropout, load_golden, sub  # noqa: E402
+
+TOY = dict(emb=16, filters=16, interactions=2, gaussians=51)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from moleculesde_amd import _lib
+    _lib.load()
+    return torch.device("cuda", 0)
+
+
+def _grads_close(model, ggrads, rtol, atol_scale, what):
+    scale = max(float(v.abs().max()) for v in ggrads.values())
+    for n, p in model.named_parameters():
+        if n in ggrads:
+            assert p.grad is not None, f"{what}: no grad for {n}"
+            assert_close(p.grad, ggrads[n], rtol, atol_scale * scale, f"{what}:{n}")
+
+
+def _s23(mod, E):
+    return disable_dropout(mod.SDEModel2Dto3D_02(emb_dim=E, hidden_dim=32, beta_min=0.2, beta_max=1.0,
+                                                 num_diffusion_timesteps=1000, beta_schedule=None, SDE_type="VE",
+                                                 use_extend_graph=True))
+
+
+# ---------------------------------------------------------------------------- golden fixtures ---
+def test_golden_toy_gnn(dev):
+    import moleculesde_amd.geom3d as G
+    g = load_golden("toy_gnn.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    m = G.GNN(3, TOY["emb"], JK="last", drop_ratio=0, gnn_type="GIN")
+    m.load_state_dict(sub(g, "sd."))
+    m.to(dev).train()
+    out = m(b.x, b.edge_index, b.edge_attr)
+    assert_close(out, g["out"], 1e-4, 1e-5, "gnn out")
+    out.pow(2).sum().backward()
+    _grads_close(m, sub(g, "grad."), 1e-3, 1e-4, "gnn")
+    for k, v in sub(g, "sd_after.").items():
+        assert_close(m.state_dict()[k], v, 1e-4, 1e-5, "sd_after." + k)
+    # the reference's other call form: forward(data)
+    m.zero_grad()
+    assert_close(m(b), out, 1e-6, 1e-6, "forward(data) form")
+
+
+def test_golden_toy_schnet(dev):
+    import moleculesde_amd.geom3d as G
+    g = load_golden("toy_schnet.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    m = G.SchNet(hidden_channels=TOY["emb"], num_filters=TOY["filters"], num_interactions=TOY["interactions"],
+                 num_gaussians=TOY["gaussians"], cutoff=10, readout="mean", node_class=119)
+    m.load_state_dict(sub(g, "sd."))
+    m.to(dev)
+    out, h = m(b.x[:, 0], b.positions, b.batch, return_latent=True)
+    assert_close(out, g["out"], 1e-4, 1e-5, "schnet out")
+    assert_close(h, g["h"], 1e-4, 1e-5, "schnet h")
+    (h.pow(2).sum() + out.sum()).backward()
+    _grads_close(m, sub(g, "grad."), 1e-3, 1e-4, "schnet")
+
+
+def test_golden_toy_sde2d3d(dev):
+    import moleculesde_amd.geom3d as G
+    g = load_golden("toy_sde2d3d.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    m = _s23(G, TOY["emb"])
+    m.load_state_dict(sub(g, "sd."))
+    m.to(dev).train()
+    m.noise = G.CpuReplayNoise(int(g["seed"]))
+    h2 = torch.from_numpy(g["h2"]).to(dev).requires_grad_(True)
+    loss = m(h2, b, anneal_power=0)["position"]
+    assert_close(loss, g["loss"], 1e-4, 1e-5, "loss 2d3d")
+    loss.backward()
+    assert_close(h2.grad, g["grad_h2"], 1e-3, 1e-4 * float(np.abs(g["grad_h2"]).max()), "grad h2")
+    _grads_close(m, sub(g, "grad."), 1e-3, 2e-4, "sde2d3d")
+    for k, v in sub(g, "sd_after.").items():
+        assert_close(m.state_dict()[k], v, 1e-4, 1e-5, "sd_after." + k)
+    m.eval()
+    score = m.get_score(torch.from_numpy(g["h2"]).to(dev), b, torch.from_numpy(g["gs_pos"]).to(dev), None,
+                        torch.from_numpy(g["gs_t_pos"]).to(dev))
+    assert_close(score, g["gs_score"], 1e-3, 1e-4, "get_score")
+
+
+def test_golden_qm9_schnet_config1(dev):
+    """BASELINE.json configs[0] shape on the GPU: both the decomposed and (F=128 only) fused paths."""
+    import moleculesde_amd.geom3d as G
+    g = load_golden("qm9_schnet.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    m = G.SchNet(hidden_channels=32, num_filters=32, num_interactions=3, num_gaussians=51, cutoff=10,
+                 readout="mean", node_class=119)
+    m.load_state_dict(sub(g, "sd."))
+    m.to(dev)
+    out, h = m(b.x, b.positions, b.batch, return_latent=True)
+    assert_close(out, g["out"], 1e-4, 1e-5, "qm9 out")
+    assert_close(h, g["h"], 1e-4, 1e-5, "qm9 h")
+    with torch.no_grad():
+        out2, _ = m(b.x, b.positions, b.batch, return_latent=True)
+    assert_close(out2, g["out"], 1e-4, 1e-5, "qm9 out no_grad")
+
+
+def test_golden_sampler(dev):
+    """5 predictor-corrector steps of the intended 2D->3D sampler with replayed noise."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import sampler
+    g = load_golden("sampler.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    m = _s23(G, TOY["emb"])
+    m.load_state_dict(sub(g, "sd."))
+    m.to(dev).eval()
+    rep = torch.from_numpy(g["rep"]).to(dev)
+    pos = torch.from_numpy(g["pos0"]).to(dev)
+    n = pos.size(0)
+    for i, tval in enumerate(torch.from_numpy(g["ts"])):
+        vec_t = torch.ones(n, device=dev) * float(tval)
+        pos, _ = sampler.corrector_update(m.sde_pos, m, rep, b, pos, vec_t, float(g["snr"]), float(g["scale_eps"]), 1,
+                                          noises=[torch.from_numpy(g["noise_corr"][i]).to(dev)])
+        pos, _ = sampler.predictor_update(m.sde_pos, m, rep, b, pos, vec_t, noise=torch.from_numpy(g["noise_pred"][i]).to(dev))
+        assert_close(pos, g["traj"][i], 1e-3, 1e-4, f"sampler step {i}")
+
+
+# ------------------------------------------------------------- oracle at BASELINE sizes (bs 256) ---
+def _pair_models(dev, seed=0):
+    """Oracle (CPU) and product (GPU) models at the README configuration with identical weights."""
+    import moleculesde_amd.geom3d as G
+    torch.manual_seed(seed)
+    om = R.build_models(use_3d2d=False)
+    disable_dropout(om["SDE_2Dto3D_model"])
+    pm = {
+        "model_2D": G.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="GIN"),
+        "model_3D": G.SchNet(hidden_channels=300, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10,
+                             readout="mean", node_class=119),
+        "SDE_2Dto3D_model": _s23(G, 300),
+    }
+    for k in pm:
+        pm[k].load_state_dict(om[k].state_dict())
+        pm[k].to(dev).train()
+        om[k].train()
+    return om, pm
+
+
+def test_bs256_forward_backward_vs_oracle(dev):
+    """configs[1]: GIN + SchNet + contrastive + SDE2Dto3D_02 VE, emb 300, bs 256 -- node representations,
+    the three loss terms and every parameter gradient against the oracle (fp32: 2e-4 on activations,
+    1e-3 relative on losses, 2e-3 of the model's largest gradient on gradients)."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_batch
+    from moleculesde_amd import pretrain
+    om, pm = _pair_models(dev)
+    cpu_b = make_batch(256, seed=0)
+    dev_b = G.prepare_batch(cpu_b.clone(), dev)
+    # oracle
+    torch.manual_seed(123)
+    h2o = om["model_2D"](cpu_b.x, cpu_b.edge_index, cpu_b.edge_attr)
+    _, h3o = om["model_3D"](cpu_b.x[:, 0], cpu_b.positions, cpu_b.batch, return_latent=True)
+    clo, _ = R.dual_CL(h2o, h3o, 0.1)
+    l23o = om["SDE_2Dto3D_model"](h2o, cpu_b, anneal_power=0)["position"]
+    (clo + l23o).backward()
+    # product, same draws in the same program order
+    noise = G.CpuReplayNoise(123)
+    pm["SDE_2Dto3D_model"].noise = noise
+    args = pretrain.readme_args()
+    h2 = pm["model_2D"](dev_b.x, dev_b.edge_index, dev_b.edge_attr)
+    _, h3 = pm["model_3D"](dev_b.x[:, 0], dev_b.positions, dev_b.batch, return_latent=True)
+    cl, _ = pretrain.dual_CL(h2, h3, args, noise)
+    l23 = pm["SDE_2Dto3D_model"](h2, dev_b, anneal_power=0)["position"]
+    (cl + l23).backward()
+    assert_close(h2, h2o.detach(), 2e-4, 2e-4 * float(h2o.abs().max()), "GIN node repr")
+    assert_close(h3, h3o.detach(), 2e-4, 2e-4 * float(h3o.abs().max()), "SchNet node repr")
+    assert_close(cl, clo.detach(), 1e-3, 0, "contrastive loss")
+    assert_close(l23, l23o.detach(), 1e-3, 0, "2D->3D loss")
+    for k in pm:
+        gs = {n: p.grad for n, p in om[k].named_parameters() if p.grad is not None}
+        _grads_close(pm[k], gs, 2e-3, 2e-3, k)
+
+
+def test_bs256_loss_curve_vs_oracle(dev):
+    """10 Adam steps at bs 64 (oracle finishes in seconds) with replayed noise: loss curve within
+    1e-3 relative (BASELINE.json target), product Trainer (flat HIP Adam) vs oracle torch.optim.Adam."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_batch
+    from moleculesde_amd import pretrain
+    args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=0, lr=1e-3)
+    torch.manual_seed(1)
+    tr = pretrain.Trainer(args, dev)
+    disable_dropout(tr.models["SDE_2Dto3D_model"])
+    om = R.build_models(use_3d2d=False)
+    disable_dropout(om["SDE_2Dto3D_model"])
+    for k in om:
+        om[k].load_state_dict(tr.models[k].state_dict())
+        om[k].train()
+    opt = R.make_optimizer(om, lr=1e-3, gnn_2d_lr_scale=1.0, gnn_3d_lr_scale=0.1)
+    cpu_b = make_batch(64, seed=2)
+    dev_b = G.prepare_batch(cpu_b.clone(), dev)
+    ref, got = [], []
+    for step in range(10):
+        torch.manual_seed(500 + step)
+        loss, _ = R.pretrain_losses(om, cpu_b, T=0.1, coeff_3d2d=0.0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref.append(loss.item())
+        tr.noise = G.CpuReplayNoise(500 + step)
+        tr.models["SDE_2Dto3D_model"].noise = tr.noise
+        l, _ = tr.step(dev_b)
+        got.append(float(l))
+    rel = np.abs(np.array(got) - np.array(ref)) / np.abs(np.array(ref))
+    assert rel.max() < 1e-3, (rel, got, ref)
+
+
+# ------------------------------------------------------------------ properties at full size ------
+def test_fullsize_properties(dev):
+    """bs 256, emb 300: (1) the 2D->3D score rotates with the input (SE(3) frame), translation of a
+    whole molecule is NOT an invariance of this model (frames use absolute positions) so only rotation
+    about the origin is checked; (2) SchNet is invariant to rotation+translation; (3) permuting the
+    molecules of the batch permutes the outputs; (4) two launches are bitwise identical."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.batch import Batch
+    from moleculesde_amd.synthetic import make_batch, make_molecule
+    torch.manual_seed(3)
+    sch = G.SchNet(hidden_channels=300, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10,
+                   readout="mean", node_class=119).to(dev)
+    gnn = G.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="GIN").to(dev).eval()
+    s23 = _s23(G, 300).to(dev).eval()
+    b = G.prepare_batch(make_batch(256, seed=4), dev)
+    with torch.no_grad():
+        h2 = gnn(b.x, b.edge_index, b.edge_attr)
+        out, h = sch(b.x[:, 0], b.positions, b.batch, return_latent=True)
+        out_b, h_b = sch(b.x[:, 0], b.positions, b.batch, return_latent=True)
+        assert torch.equal(h, h_b) and torch.equal(out, out_b)               # (4) deterministic
+        Q, _ = torch.linalg.qr(torch.randn(3, 3, device=dev))
+        if torch.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        shift = torch.randn(256, 3, device=dev)[b.batch]
+        _, h_rt = sch(b.x[:, 0], b.positions @ Q.T + shift, b.batch, return_latent=True)
+        assert_close(h_rt, h, 1e-3, 1e-3 * float(h.abs().max()), "SchNet SE(3) invariance")       # (2)
+        t_pos = torch.full((b.x.size(0),), 0.5, device=dev)
+        pos_p = b.positions + 0.2 * torch.randn_like(b.positions)
+        sc = s23.get_score(h2, b, pos_p, None, t_pos)
+        sc_r = s23.get_score(h2, b, pos_p @ Q.T, None, t_pos)
+        assert_close(sc_r, sc @ Q.T, 5e-3, 5e-3 * float(sc.abs().max()), "score rotation equivariance")  # (1)
+    # (3) molecule permutation
+    rng = np.random.default_rng(7)
+    mols = [make_molecule(rng) for _ in range(64)]
+    perm = rng.permutation(64)
+    b1 = G.prepare_batch(Batch.from_data_list(mols), dev)
+    b2 = G.prepare_batch(Batch.from_data_list([mols[i] for i in perm]), dev)
+    with torch.no_grad():
+        o1 = sch(b1.x[:, 0], b1.positions, b1.batch)
+        o2 = sch(b2.x[:, 0], b2.positions, b2.batch)
+    assert_close(o2, o1[torch.from_numpy(perm).to(dev)], 1e-5, 1e-5, "molecule permutation")
+
+
+def test_fused_vs_decomposed_fullsize(dev):
+    """SchNet forward at bs 256 / emb 300: fused MFMA CFConv path (no_grad) == decomposed path."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_batch
+    torch.manual_seed(5)
+    sch = G.SchNet(hidden_channels=300, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10,
+                   readout="mean", node_class=119).to(dev)
+    b = G.prepare_batch(make_batch(256, seed=6), dev)
+    _, h_dec = sch(b.x[:, 0], b.positions, b.batch, return_latent=True)
+    with torch.no_grad():
+        _, h_fused = sch(b.x[:, 0], b.positions, b.batch, return_latent=True)
+    assert_close(h_fused, h_dec.detach(), 1e-4, 1e-4 * float(h_dec.abs().max()), "fused vs decomposed SchNet")
+
+
+def test_empty_and_ragged_inputs(dev):
+    """Edge cases: single-atom molecules (no radius/bond edges), 2-atom molecules, one big molecule."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.batch import Batch, MolData, extend_graph_index
+    from moleculesde_amd.synthetic import make_molecule
+    rng = np.random.default_rng(9)
+    lone = MolData(x=torch.tensor([[5, 0, 0, 0, 0, 0, 0, 0, 0]]), edge_index=torch.zeros(2, 0, dtype=torch.long),
+                   edge_attr=torch.zeros(0, 3, dtype=torch.long), positions=torch.zeros(1, 3))
+    lone.extended_edge_index = extend_graph_index(lone.edge_index, 1)
+    mols = [lone, make_molecule(rng, 2), make_molecule(rng, 20), lone, make_molecule(rng, 7)]
+    cpu_b = Batch.from_data_list(mols)
+    b = G.prepare_batch(cpu_b.clone(), dev)
+    torch.manual_seed(0)
+    osch = R.SchNet(hidden_channels=32, num_filters=128, num_interactions=2, num_gaussians=51, cutoff=10, readout="mean", node_class=119)
+    ognn = R.GNN(2, 32)
+    sch = G.SchNet(hidden_channels=32, num_filters=128, num_interactions=2, num_gaussians=51, cutoff=10, readout="mean", node_class=119)
+    gnn = G.GNN(2, 32, gnn_type="GIN")
+    sch.load_state_dict(osch.state_dict()); gnn.load_state_dict(ognn.state_dict())
+    sch.to(dev); gnn.to(dev)
+    o_ref, h_ref = osch(cpu_b.x[:, 0], cpu_b.positions, cpu_b.batch, return_latent=True)
+    o, h = sch(b.x[:, 0], b.positions, b.batch, return_latent=True)
+    assert_close(h, h_ref.detach(), 1e-4, 1e-5, "ragged schnet h")
+    assert_close(o, o_ref.detach(), 1e-4, 1e-5, "ragged schnet out")
+    with torch.no_grad():
+        _, hf = sch(b.x[:, 0], b.positions, b.batch, return_latent=True)
+    assert_close(hf, h_ref.detach(), 1e-4, 1e-5, "ragged schnet fused")
+    assert_close(gnn(b.x, b.edge_index, b.edge_attr), ognn(cpu_b.x, cpu_b.edge_index, cpu_b.edge_attr).detach(), 1e-4, 1e-5, "ragged gnn")
