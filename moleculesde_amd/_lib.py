@@ -54,6 +54,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one already mapped
+    # when our library's NEEDED libamdhip64.so.7 is resolved, or two runtimes end up in one process
+    # (symptom: hipErrorNoDevice / hangs).  Importing torch first guarantees a single runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MsdeHipError(
             f"{LIB_PATH} not found: build it with `python -m moleculesde_amd.build` "

@@ -172,7 +172,7 @@ extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const i
       attr_done = true;                                                                                            \
     }                                                                                                              \
   }                                                                                                                \
-  hipLaunchKernelGGL(cfconv_fused_fwd_kernel<KK>, dim3(grid), dim3(256), lds_bytes(KK), as_stream(stream), x1, dist, \
+  MSDE_LAUNCH(cfconv_fused_fwd_kernel<KK>, dim3(grid), dim3(256), lds_bytes(KK), as_stream(stream), x1, dist, \
                      rowptr, src, dst, W1, b1, W2, b2, offset, N, G, coeff, cutoff, nodes_per_wg, agg)
   if (kk1 == 26) { CF_LAUNCH(26); }
   else if (kk1 == 25) { CF_LAUNCH(25); }

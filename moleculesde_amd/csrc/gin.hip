@@ -140,7 +140,7 @@ extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const 
   if (lds > 64 * 1024) return MSDE_EUNSUP;
   if (N == 0) return 0;
   int npb = 16;
-  hipLaunchKernelGGL(gin_aggregate_bwd_tab_kernel, dim3((N + npb - 1) / npb), dim3(256), lds, as_stream(stream), g, x,
+  MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3((N + npb - 1) / npb), dim3(256), lds, as_stream(stream), g, x,
                      tab, codes, rowptr, src, N, D, R, npb, g_tab, g_eps);
   MSDE_CHECK_LAUNCH();
   return 0;

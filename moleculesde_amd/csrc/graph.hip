@@ -94,7 +94,7 @@ extern "C" int msde_radius_count(const float* pos, const int* batch, const int* 
                                  int max_nbr, int* deg, void* stream) {
   if (N < 0 || (N > 0 && (!pos || !batch || !mol_ptr || !deg))) return MSDE_EINVAL;
   if (N == 0) return 0;
-  hipLaunchKernelGGL(radius_count_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), pos, batch,
+  MSDE_LAUNCH(radius_count_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), pos, batch,
                      mol_ptr, N, r2, max_nbr, deg);
   MSDE_CHECK_LAUNCH();
   return 0;
@@ -102,7 +102,7 @@ extern "C" int msde_radius_count(const float* pos, const int* batch, const int* 
 
 extern "C" int msde_exclusive_scan_i32(const int* in, int* out, int n, void* stream) {
   if (n < 0 || !out || (n > 0 && !in)) return MSDE_EINVAL;
-  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), in, out, n);
+  MSDE_LAUNCH(exclusive_scan_kernel, dim3(1), dim3(1024), 0, as_stream(stream), in, out, n);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -113,7 +113,7 @@ extern "C" int msde_radius_fill(const float* pos, const int* batch, const int* m
   if (N < 0 || E_cap < 0 || !rowptr) return MSDE_EINVAL;
   if (N == 0 && E_cap == 0) return 0;
   int work = N > 0 ? N : 1;
-  hipLaunchKernelGGL(radius_fill_kernel, dim3((work + 255) / 256), dim3(256), 0, as_stream(stream), pos, batch,
+  MSDE_LAUNCH(radius_fill_kernel, dim3((work + 255) / 256), dim3(256), 0, as_stream(stream), pos, batch,
                      mol_ptr, N, r2, max_nbr, rowptr, src, dst, dist, E_cap);
   MSDE_CHECK_LAUNCH();
   return 0;
@@ -154,11 +154,11 @@ extern "C" int msde_segment_sum_rows(const float* rows, const int* rowptr, const
   if (N == 0) return 0;
   if (D % 4 == 0) {
     int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
-    hipLaunchKernelGGL(segment_sum_rows_kernel<4>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
+    MSDE_LAUNCH(segment_sum_rows_kernel<4>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
                        rowptr, perm, N, cols, tpr, scale_by_inv_count, out);
   } else {
     int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
-    hipLaunchKernelGGL(segment_sum_rows_kernel<1>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
+    MSDE_LAUNCH(segment_sum_rows_kernel<1>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
                        rowptr, perm, N, cols, tpr, scale_by_inv_count, out);
   }
   MSDE_CHECK_LAUNCH();
@@ -195,11 +195,11 @@ extern "C" int msde_pair_gather_add(const float* A, const float* B, const int* s
   if (E == 0) return 0;
   if (D % 4 == 0) {
     int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
-    hipLaunchKernelGGL(pair_gather_add_kernel<4>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), A, B,
+    MSDE_LAUNCH(pair_gather_add_kernel<4>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), A, B,
                        src, dst, E, cols, tpr, out);
   } else {
     int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
-    hipLaunchKernelGGL(pair_gather_add_kernel<1>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), A, B,
+    MSDE_LAUNCH(pair_gather_add_kernel<1>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), A, B,
                        src, dst, E, cols, tpr, out);
   }
   MSDE_CHECK_LAUNCH();
@@ -211,11 +211,11 @@ extern "C" int msde_gather_rows(const float* X, const int* idx, int E, int D, fl
   if (E == 0) return 0;
   if (D % 4 == 0) {
     int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
-    hipLaunchKernelGGL(pair_gather_add_kernel<4>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), X,
+    MSDE_LAUNCH(pair_gather_add_kernel<4>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), X,
                        (const float*)nullptr, idx, (const int*)nullptr, E, cols, tpr, out);
   } else {
     int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
-    hipLaunchKernelGGL(pair_gather_add_kernel<1>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), X,
+    MSDE_LAUNCH(pair_gather_add_kernel<1>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), X,
                        (const float*)nullptr, idx, (const int*)nullptr, E, cols, tpr, out);
   }
   MSDE_CHECK_LAUNCH();
@@ -249,11 +249,11 @@ extern "C" int msde_embedding_sum_fwd(const float* tab, const int* codes, int N,
   if (N == 0) return 0;
   if (D % 4 == 0) {
     int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
-    hipLaunchKernelGGL(embedding_sum_fwd_kernel<4>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), tab,
+    MSDE_LAUNCH(embedding_sum_fwd_kernel<4>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), tab,
                        codes, N, K, cols, tpr, out);
   } else {
     int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
-    hipLaunchKernelGGL(embedding_sum_fwd_kernel<1>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), tab,
+    MSDE_LAUNCH(embedding_sum_fwd_kernel<1>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), tab,
                        codes, N, K, cols, tpr, out);
   }
   MSDE_CHECK_LAUNCH();
@@ -286,7 +286,7 @@ extern "C" int msde_embedding_sum_bwd(const float* g, const int* list_ptr, const
                                       int split, float* g_tab, void* stream) {
   if (R <= 0 || D <= 0 || split <= 0 || !g || !list_ptr || !list_nodes || !g_tab) return MSDE_EINVAL;
   int threads = D >= 256 ? 256 : ((D + 63) / 64) * 64;
-  hipLaunchKernelGGL(embedding_sum_bwd_kernel, dim3(R, split), dim3(threads), 0, as_stream(stream), g, list_ptr,
+  MSDE_LAUNCH(embedding_sum_bwd_kernel, dim3(R, split), dim3(threads), 0, as_stream(stream), g, list_ptr,
                      list_nodes, D, split, g_tab);
   MSDE_CHECK_LAUNCH();
   return 0;

@@ -13,6 +13,14 @@
     if (_e != hipSuccess) return (int)_e;        \
   } while (0)
 
+// hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
+// (torch included): clear it right before our launch so MSDE_CHECK_LAUNCH reports only our error.
+#define MSDE_LAUNCH(...)            \
+  do {                              \
+    (void)hipGetLastError();        \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- tiny vector abstraction: V = 4 (float4, 16 B/lane) or V = 1 (scalar fallback) -------------
@@ -76,9 +84,9 @@ __device__ __forceinline__ float msde_uniform(unsigned long long seed, unsigned 
 #define LAUNCH_ROWS(KERNEL, ROWS, D, ...)                                                                          \
   if ((D) % 4 == 0) {                                                                                              \
     int cols = (D) / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;                                                     \
-    hipLaunchKernelGGL(KERNEL<4>, dim3(((ROWS) + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), __VA_ARGS__);    \
+    MSDE_LAUNCH(KERNEL<4>, dim3(((ROWS) + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), __VA_ARGS__);    \
   } else {                                                                                                         \
     int cols = (D), tpr = pick_tpr(cols), rpb = 256 / tpr;                                                         \
-    hipLaunchKernelGGL(KERNEL<1>, dim3(((ROWS) + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), __VA_ARGS__);    \
+    MSDE_LAUNCH(KERNEL<1>, dim3(((ROWS) + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), __VA_ARGS__);    \
   }
 

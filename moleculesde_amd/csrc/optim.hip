@@ -35,7 +35,7 @@ extern "C" int msde_adam_flat(float* p, const float* g, float* m, float* v, long
   if (n == 0) return 0;
   long long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, step_dev,
+  MSDE_LAUNCH(adam_flat_kernel, dim3((int)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n, step_dev,
                      seg_end, seg_lr, S, beta1, beta2, eps, weight_decay, grad_scale);
   MSDE_CHECK_LAUNCH();
   return 0;

@@ -32,7 +32,7 @@ extern "C" int msde_rbf_cutoff_fwd(const float* dist, const int* E_dev, int E_ca
   size_t total = (size_t)E_cap * G;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(rbf_cutoff_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dist, E_dev, E_cap, G,
+  MSDE_LAUNCH(rbf_cutoff_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dist, E_dev, E_cap, G,
                      offset, coeff, cutoff, rbf, C);
   MSDE_CHECK_LAUNCH();
   return 0;

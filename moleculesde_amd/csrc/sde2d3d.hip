@@ -67,7 +67,7 @@ extern "C" int msde_edge_geometry_fwd(const float* pos, const int* src, const in
     return MSDE_EINVAL;
   if (E == 0) return 0;
   size_t total = (size_t)E * C;
-  hipLaunchKernelGGL(edge_geometry_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+  MSDE_LAUNCH(edge_geometry_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                      pos, src, dst, E, Wd, Wc, C, feat_d, feat_i, feat_j, angle, basis);
   MSDE_CHECK_LAUNCH();
   return 0;
@@ -196,10 +196,10 @@ extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const flo
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: hipLaunchKernelGGL(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
-    case 2: hipLaunchKernelGGL(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
-    case 4: hipLaunchKernelGGL(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
-    case 8: hipLaunchKernelGGL(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    case 1: MSDE_LAUNCH(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    case 2: MSDE_LAUNCH(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    case 4: MSDE_LAUNCH(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    case 8: MSDE_LAUNCH(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();
@@ -217,10 +217,10 @@ extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: hipLaunchKernelGGL(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
-    case 2: hipLaunchKernelGGL(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
-    case 4: hipLaunchKernelGGL(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
-    case 8: hipLaunchKernelGGL(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();
@@ -272,7 +272,7 @@ extern "C" int msde_frame_mix_mean_fwd(const float* coff, const float* basis, co
                                        void* stream) {
   if (N < 0 || !coff || !basis || !rowptr || !out) return MSDE_EINVAL;
   if (N == 0) return 0;
-  hipLaunchKernelGGL(frame_mix_mean_fwd_kernel, dim3((N * 3 + 255) / 256), dim3(256), 0, as_stream(stream), coff,
+  MSDE_LAUNCH(frame_mix_mean_fwd_kernel, dim3((N * 3 + 255) / 256), dim3(256), 0, as_stream(stream), coff,
                      basis, rowptr, N, out);
   MSDE_CHECK_LAUNCH();
   return 0;
@@ -282,7 +282,7 @@ extern "C" int msde_frame_mix_mean_bwd(const float* g_out, const float* basis, c
                                        float* g_coff, void* stream) {
   if (N < 0 || !g_out || !basis || !rowptr || !g_coff) return MSDE_EINVAL;
   if (N == 0) return 0;
-  hipLaunchKernelGGL(frame_mix_mean_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), g_out, basis,
+  MSDE_LAUNCH(frame_mix_mean_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), g_out, basis,
                      rowptr, N, E_cap, g_coff);
   MSDE_CHECK_LAUNCH();
   return 0;
