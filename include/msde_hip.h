@@ -135,6 +135,21 @@ int msde_frame_mix_mean_fwd(const float* coff, const float* basis, const int* ro
 int msde_frame_mix_mean_bwd(const float* g_out, const float* basis, const int* rowptr, int N,
                             int E_cap, float* g_coff, void* stream);
 
+/* ------------------------------------------------------------------ dense layers ----------- */
+/* torch.nn.functional.linear on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) — every
+ * nn.Linear on the path (schnet.py:141-150,173-174; molecule_gnn_model.py:17; layers/common.py:21).
+ * Y[M,N] = X[M,K] . W[N,K]^T + bias[N] (bias may be NULL). */
+int msde_linear_fwd(const float* X, const float* W, const float* bias, int M, int N, int K, float* Y,
+                    void* stream);
+/* gX[M,K] = gY[M,N] . W[N,K] */
+int msde_linear_bwd_x(const float* gY, const float* W, int M, int N, int K, float* gX,
+                      void* stream);
+/* gW[N,K] = gY^T . X and gb[N] = column sums of gY (gb may be NULL); split over M into slabs in
+ * `workspace` (msde_linear_bwd_w_workspace_bytes) that are summed in a fixed order: reproducible. */
+long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K);
+int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, float* gW, float* gb,
+                      float* workspace, void* stream);
+
 /* ------------------------------------------------------------------ optimiser -------------- */
 /* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —
  * examples/pretrain_MoleculeSDE.py:331-337,156.  seg_end[S] (exclusive ends), seg_lr[S].

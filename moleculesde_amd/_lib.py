@@ -38,9 +38,13 @@ SIGNATURES = {
     "msde_edge_attention_bwd": [P, P, P, P, P, P, P, P, I, I, I, F, ULL, P, P, P, P, P],
     "msde_frame_mix_mean_fwd": [P, P, P, I, P, P],
     "msde_frame_mix_mean_bwd": [P, P, P, I, I, P, P],
+    "msde_linear_fwd": [P, P, P, I, I, I, P, P],
+    "msde_linear_bwd_x": [P, P, I, I, I, P, P],
+    "msde_linear_bwd_w_workspace_bytes": [I, I, I],
+    "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
     "msde_adam_flat": [P, P, P, P, LL, P, P, P, I, F, F, F, F, F, P],
 }
-_RESTYPE = {"msde_target_arch": ctypes.c_char_p}
+_RESTYPE = {"msde_target_arch": ctypes.c_char_p, "msde_linear_bwd_w_workspace_bytes": ctypes.c_longlong}
 
 _lib = None
 

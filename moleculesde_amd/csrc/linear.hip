@@ -1,0 +1,292 @@
+// linear.hip — fp32 Linear layer (forward, input gradient, weight/bias gradient) on the gfx950
+// matrix cores.  Uses v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-for-bit an fmaf chain in k
+// order -- no reduced-precision shortcut, so results match an fp32 CPU GEMM to rounding.
+//
+// Why not the vendor GEMM: the shapes on the MoleculeSDE path are skinny (M = 3.6 k nodes or 35-49 k
+// edges, N and K in 3..600).  One kernel template covers the three products of a Linear layer:
+//     forward   Y[M,N]  = X[M,K]  . W[N,K]^T (+ bias)         A row-major,  B "n-major"  (NT)
+//     grad-in   gX[M,K] = gY[M,N] . W[N,K]                    A row-major,  B k-major    (NN)
+//     grad-w    gW[N,K] = gY[M,N]^T . X[M,K]  (+ column sums) A k-major,    B k-major    (TN, split over M)
+// Tiling: 256 threads = 4 waves as 2 x 2; each wave owns TM x TN MFMA tiles of 32 x 32; block tile
+// (64 TM) x (64 TN); K step 32.  LDS images are k-major with row stride BM+1 / BN+1 (== 1 mod 32):
+// the MFMA operand reads (32 consecutive rows per half-wave at one k) and the transposing staging
+// writes are both bank-conflict free.  Next tile's global loads are issued before the current tile's
+// MFMAs (register prefetch).  The split-M weight gradient writes per-split slabs that a second
+// kernel sums in a fixed order: bitwise reproducible, no float atomics.
+#include "msde_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LG_BK 32
+
+template <int TM, int TN, bool A_KM, bool B_KM>
+__global__ void __launch_bounds__(256)
+gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                     float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
+                     int ldc, int k_per_split, int vecA, int vecB) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+  __shared__ float As[LG_BK * LDA_S];
+  __shared__ float Bs[LG_BK * LDB_S];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 31, lhalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kb = blockIdx.z * k_per_split;
+  const int ke = min(K, kb + k_per_split);
+
+  // staging registers: each thread moves (BM*BK/4)/256 = 2*TM float4 of A and 2*TN of B per tile
+  constexpr int NA = 2 * TM, NB = 2 * TN;
+  float4 ra[NA], rb[NB];
+
+  auto load_tile = [&](int k0) {
+    // ---- A
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      int idx = p * 256 + tid;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!A_KM) {                       // A[m][k], k contiguous: 8 float4 per row
+        int r = idx >> 3, kq = (idx & 7) * 4;
+        int gm = m0 + r, gk = k0 + kq;
+        if (gm < M) {
+          const float* src = A + (size_t)gm * lda + gk;
+          if (vecA && gk + 3 < ke) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gk < ke) v.x = src[0];
+            if (gk + 1 < ke) v.y = src[1];
+            if (gk + 2 < ke) v.z = src[2];
+            if (gk + 3 < ke) v.w = src[3];
+          }
+        }
+      } else {                           // A[k][m], m contiguous: BM/4 float4 per k-row
+        int kr = idx / (BM / 4), mq = (idx % (BM / 4)) * 4;
+        int gk = k0 + kr, gm = m0 + mq;
+        if (gk < ke) {
+          const float* src = A + (size_t)gk * lda + gm;
+          if (vecA && gm + 3 < M) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gm < M) v.x = src[0];
+            if (gm + 1 < M) v.y = src[1];
+            if (gm + 2 < M) v.z = src[2];
+            if (gm + 3 < M) v.w = src[3];
+          }
+        }
+      }
+      ra[p] = v;
+    }
+    // ---- B
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      int idx = p * 256 + tid;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!B_KM) {                       // B[n][k], k contiguous
+        int r = idx >> 3, kq = (idx & 7) * 4;
+        int gn = n0 + r, gk = k0 + kq;
+        if (gn < N) {
+          const float* src = B + (size_t)gn * ldb + gk;
+          if (vecB && gk + 3 < ke) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gk < ke) v.x = src[0];
+            if (gk + 1 < ke) v.y = src[1];
+            if (gk + 2 < ke) v.z = src[2];
+            if (gk + 3 < ke) v.w = src[3];
+          }
+        }
+      } else {                           // B[k][n], n contiguous
+        int kr = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
+        int gk = k0 + kr, gn = n0 + nq;
+        if (gk < ke) {
+          const float* src = B + (size_t)gk * ldb + gn;
+          if (vecB && gn + 3 < N) v = *reinterpret_cast<const float4*>(src);
+          else {
+            if (gn < N) v.x = src[0];
+            if (gn + 1 < N) v.y = src[1];
+            if (gn + 2 < N) v.z = src[2];
+            if (gn + 3 < N) v.w = src[3];
+          }
+        }
+      }
+      rb[p] = v;
+    }
+  };
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      int idx = p * 256 + tid;
+      if (!A_KM) {
+        int r = idx >> 3, kq = (idx & 7) * 4;
+        As[(kq + 0) * LDA_S + r] = ra[p].x;
+        As[(kq + 1) * LDA_S + r] = ra[p].y;
+        As[(kq + 2) * LDA_S + r] = ra[p].z;
+        As[(kq + 3) * LDA_S + r] = ra[p].w;
+      } else {
+        int kr = idx / (BM / 4), mq = (idx % (BM / 4)) * 4;
+        As[kr * LDA_S + mq + 0] = ra[p].x;
+        As[kr * LDA_S + mq + 1] = ra[p].y;
+        As[kr * LDA_S + mq + 2] = ra[p].z;
+        As[kr * LDA_S + mq + 3] = ra[p].w;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      int idx = p * 256 + tid;
+      if (!B_KM) {
+        int r = idx >> 3, kq = (idx & 7) * 4;
+        Bs[(kq + 0) * LDB_S + r] = rb[p].x;
+        Bs[(kq + 1) * LDB_S + r] = rb[p].y;
+        Bs[(kq + 2) * LDB_S + r] = rb[p].z;
+        Bs[(kq + 3) * LDB_S + r] = rb[p].w;
+      } else {
+        int kr = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
+        Bs[kr * LDB_S + nq + 0] = rb[p].x;
+        Bs[kr * LDB_S + nq + 1] = rb[p].y;
+        Bs[kr * LDB_S + nq + 2] = rb[p].z;
+        Bs[kr * LDB_S + nq + 3] = rb[p].w;
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float csum = 0.f;  // column sum of A over k (weight-gradient mode: bias gradient), thread tid < BM
+
+  if (kb < ke) {
+    load_tile(kb);
+    for (int k0 = kb; k0 < ke; k0 += LG_BK) {
+      __syncthreads();  // previous tile fully consumed
+      store_tile();
+      __syncthreads();
+      if (k0 + LG_BK < ke) load_tile(k0 + LG_BK);  // in flight during the MFMAs below
+#pragma unroll
+      for (int kk = 0; kk < LG_BK / 2; ++kk) {
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = As[(2 * kk + lhalf) * LDA_S + (wm * TM + i) * 32 + lcol];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kk + lhalf) * LDB_S + (wn * TN + j) * 32 + lcol];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      if (colsum_ws != nullptr && blockIdx.x == 0 && tid < BM) {
+#pragma unroll 8
+        for (int kr = 0; kr < LG_BK; ++kr) csum += As[kr * LDA_S + tid];
+      }
+    }
+  }
+
+  // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* Cz = C + (size_t)blockIdx.z * (size_t)M * ldc;  // split slabs (blockIdx.z == 0 when unsplit)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int gn = n0 + (wn * TN + j) * 32 + lcol;
+      float bv = (bias != nullptr && gn < N) ? bias[gn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        if (gm < M && gn < N) Cz[(size_t)gm * ldc + gn] = acc[i][j][r] + bv;
+      }
+    }
+  if (colsum_ws != nullptr && blockIdx.x == 0 && tid < BM && m0 + tid < M)
+    colsum_ws[(size_t)blockIdx.z * M + m0 + tid] = csum;
+}
+
+// out[i] = sum_z slabs[z][i] (fixed order), i < n
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int z = 0; z < splits; ++z) acc += slabs[(size_t)z * n + i];
+    out[i] = acc;
+  }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool A_KM, bool B_KM>
+static int launch_gemm(const float* A, const float* B, const float* bias, float* C, float* colsum_ws, int M, int N,
+                       int K, int lda, int ldb, int ldc, int splits, int k_per_split, hipStream_t st) {
+  int vecA = aligned16(A) && (lda % 4 == 0);
+  int vecB = aligned16(B) && (ldb % 4 == 0);
+  // pick the tile so that the grid has a few hundred workgroups
+  long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
+  long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64) * splits;
+  if (t128 >= 384) {
+    dim3 grid((N + 127) / 128, (M + 127) / 128, splits);
+    MSDE_LAUNCH((gemm_f32_mfma_kernel<2, 2, A_KM, B_KM>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N, K, lda,
+                ldb, ldc, k_per_split, vecA, vecB);
+  } else if (t12864 >= 256) {
+    dim3 grid((N + 63) / 64, (M + 127) / 128, splits);
+    MSDE_LAUNCH((gemm_f32_mfma_kernel<2, 1, A_KM, B_KM>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N, K, lda,
+                ldb, ldc, k_per_split, vecA, vecB);
+  } else {
+    dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
+    MSDE_LAUNCH((gemm_f32_mfma_kernel<1, 1, A_KM, B_KM>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N, K, lda,
+                ldb, ldc, k_per_split, vecA, vecB);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int msde_linear_fwd(const float* X, const float* W, const float* bias, int M, int N, int K, float* Y,
+                               void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || !X || !W || !Y) return MSDE_EINVAL;
+  if (M == 0) return 0;
+  return launch_gemm<false, false>(X, W, bias, Y, nullptr, M, N, K, K, K, N, 1, K, as_stream(stream));
+}
+
+extern "C" int msde_linear_bwd_x(const float* gY, const float* W, int M, int N, int K, float* gX, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || !gY || !W || !gX) return MSDE_EINVAL;
+  if (M == 0) return 0;
+  // gX[M,K] = gY[M,N] . W[N,K]: reduce over N; B = W is k-major ([N][K], K contiguous)
+  return launch_gemm<false, true>(gY, W, nullptr, gX, nullptr, M, K, N, N, K, K, 1, N, as_stream(stream));
+}
+
+extern "C" long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K) {
+  int splits = (M + 511) / 512;
+  if (splits < 1) splits = 1;
+  if (splits > 128) splits = 128;
+  return (long long)splits * ((long long)N * K + N) * (long long)sizeof(float);
+}
+
+extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, float* gW, float* gb,
+                                 float* workspace, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || !gY || !X || !gW || !workspace) return MSDE_EINVAL;
+  hipStream_t st = as_stream(stream);
+  int splits = (M + 511) / 512;
+  if (splits < 1) splits = 1;
+  if (splits > 128) splits = 128;
+  int k_per_split = ((M + splits - 1) / splits + LG_BK - 1) / LG_BK * LG_BK;
+  splits = M > 0 ? (M + k_per_split - 1) / k_per_split : 1;
+  float* slabs = workspace;
+  float* cs = gb ? workspace + (size_t)splits * N * K : nullptr;
+  if (M == 0) {
+    hipError_t e = hipMemsetAsync(gW, 0, (size_t)N * K * sizeof(float), st);
+    if (e == hipSuccess && gb) e = hipMemsetAsync(gb, 0, (size_t)N * sizeof(float), st);
+    return (int)e;
+  }
+  // C[N,K] = A^T B with A = gY [M][N] (k-major, "M" of the product = N), B = X [M][K] (k-major)
+  int rc = launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, st);
+  if (rc != 0) return rc;
+  size_t n = (size_t)N * K;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  MSDE_LAUNCH(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, n, gW);
+  MSDE_CHECK_LAUNCH();
+  if (gb) {
+    MSDE_LAUNCH(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cs, splits, (size_t)N, gb);
+    MSDE_CHECK_LAUNCH();
+  }
+  return 0;
+}

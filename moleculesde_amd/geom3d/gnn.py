@@ -15,8 +15,8 @@ class GINConv(nn.Module):
 
     def __init__(self, emb_dim, bond_dims):
         super().__init__()
-        self.mlp = nn.Sequential(nn.Linear(emb_dim, 2 * emb_dim), nn.BatchNorm1d(2 * emb_dim), nn.ReLU(),
-                                 nn.Linear(2 * emb_dim, emb_dim))
+        self.mlp = nn.Sequential(_nn.Linear(emb_dim, 2 * emb_dim), nn.BatchNorm1d(2 * emb_dim), nn.ReLU(),
+                                 _nn.Linear(2 * emb_dim, emb_dim))
         self.eps = nn.Parameter(torch.Tensor([0]))
         self.bond_encoder = _nn.EmbeddingList(bond_dims, emb_dim, "bond_embedding_list")
 

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import plan as _plan
+from .. import hip, plan as _plan
 
 _LN2 = float(torch.log(torch.tensor(2.0)).item())
 
@@ -15,6 +15,25 @@ _LN2 = float(torch.log(torch.tensor(2.0)).item())
 def shifted_softplus(x):
     """softplus(x) - ln 2 (reference ShiftedSoftplus, schnet.py:210-216)."""
     return F.softplus(x) - _LN2
+
+
+USE_HIP_LINEAR = True   # False routes dense layers to the vendor GEMM (A/B measurements only)
+
+
+class Linear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose forward, input gradient and weight/bias
+    gradient run on the fp32 MFMA GEMM of csrc/linear.hip."""
+
+    def forward(self, x):
+        if USE_HIP_LINEAR and x.is_cuda:
+            return hip.linear(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+
+def linear(x, weight, bias=None):
+    if USE_HIP_LINEAR and x.is_cuda:
+        return hip.linear(x, weight, bias)
+    return F.linear(x, weight, bias)
 
 
 class ShiftedSoftplus(nn.Module):
@@ -30,7 +49,7 @@ class MultiLayerPerceptron(nn.Module):
         self.dims = [input_dim] + list(hidden_dims)
         self.activation = getattr(F, activation) if isinstance(activation, str) else None
         self.dropout = nn.Dropout(dropout) if dropout else None
-        self.layers = nn.ModuleList([nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(len(self.dims) - 1)])
+        self.layers = nn.ModuleList([Linear(self.dims[i], self.dims[i + 1]) for i in range(len(self.dims) - 1)])
         self.reset_parameters()
 
     def reset_parameters(self):

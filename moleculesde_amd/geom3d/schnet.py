@@ -33,8 +33,8 @@ class GaussianSmearing(nn.Module):
 class CFConv(nn.Module):
     def __init__(self, in_channels, out_channels, num_filters, nn_, cutoff):
         super().__init__()
-        self.lin1 = nn.Linear(in_channels, num_filters, bias=False)
-        self.lin2 = nn.Linear(num_filters, out_channels)
+        self.lin1 = _nn.Linear(in_channels, num_filters, bias=False)
+        self.lin2 = _nn.Linear(num_filters, out_channels)
         self.nn = nn_
         self.cutoff = cutoff
         nn.init.xavier_uniform_(self.lin1.weight)
@@ -45,11 +45,11 @@ class CFConv(nn.Module):
 class InteractionBlock(nn.Module):
     def __init__(self, hidden_channels, num_gaussians, num_filters, cutoff):
         super().__init__()
-        self.mlp = nn.Sequential(nn.Linear(num_gaussians, num_filters), _nn.ShiftedSoftplus(),
-                                 nn.Linear(num_filters, num_filters))
+        self.mlp = nn.Sequential(_nn.Linear(num_gaussians, num_filters), _nn.ShiftedSoftplus(),
+                                 _nn.Linear(num_filters, num_filters))
         self.conv = CFConv(hidden_channels, hidden_channels, num_filters, self.mlp, cutoff)
         self.act = _nn.ShiftedSoftplus()
-        self.lin = nn.Linear(hidden_channels, hidden_channels)
+        self.lin = _nn.Linear(hidden_channels, hidden_channels)
         nn.init.xavier_uniform_(self.mlp[0].weight)
         self.mlp[0].bias.data.fill_(0)
         nn.init.xavier_uniform_(self.mlp[2].weight)   # mlp[2].bias keeps nn.Linear's default (App. B.1)
@@ -76,9 +76,9 @@ class SchNet(nn.Module):
         self.distance_expansion = GaussianSmearing(0.0, cutoff, num_gaussians)
         self.interactions = nn.ModuleList(
             [InteractionBlock(hidden_channels, num_gaussians, num_filters, cutoff) for _ in range(num_interactions)])
-        self.lin1 = nn.Linear(hidden_channels, hidden_channels)
+        self.lin1 = _nn.Linear(hidden_channels, hidden_channels)
         self.act = _nn.ShiftedSoftplus()
-        self.lin2 = nn.Linear(hidden_channels, hidden_channels)
+        self.lin2 = _nn.Linear(hidden_channels, hidden_channels)
         self.register_buffer("initial_atomref", None)
         self.atomref = None
         nn.init.xavier_uniform_(self.lin1.weight)
@@ -111,7 +111,7 @@ class SchNet(nn.Module):
             rbf, C = hip.rbf_cutoff(dist, rplan.E_dev, de.offset, de.coeff, self.cutoff)
 
         for blk in self.interactions:
-            x1 = F.linear(h, blk.conv.lin1.weight)
+            x1 = _nn.linear(h, blk.conv.lin1.weight)
             if fused:
                 agg = hip.cfconv_fused_forward(x1, dist, rplan, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
                                                blk.mlp[2].bias, de.offset, de.coeff, self.cutoff,

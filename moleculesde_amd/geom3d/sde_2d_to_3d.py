@@ -40,11 +40,11 @@ class TransformerConv(nn.Module):
     def __init__(self, in_channels, out_channels, heads, dropout, edge_dim):
         super().__init__()
         self.heads, self.out_channels, self.dropout = heads, out_channels, dropout
-        self.lin_key = nn.Linear(in_channels, heads * out_channels)
-        self.lin_query = nn.Linear(in_channels, heads * out_channels)
-        self.lin_value = nn.Linear(in_channels, heads * out_channels)
-        self.lin_edge = nn.Linear(edge_dim, heads * out_channels, bias=False)
-        self.lin_skip = nn.Linear(in_channels, heads * out_channels, bias=True)
+        self.lin_key = _nn.Linear(in_channels, heads * out_channels)
+        self.lin_query = _nn.Linear(in_channels, heads * out_channels)
+        self.lin_value = _nn.Linear(in_channels, heads * out_channels)
+        self.lin_edge = _nn.Linear(edge_dim, heads * out_channels, bias=False)
+        self.lin_skip = _nn.Linear(in_channels, heads * out_channels, bias=True)
 
     def forward(self, x, edge_attr, plan, seed):
         q, k, v = self.lin_query(x), self.lin_key(x), self.lin_value(x)
@@ -59,8 +59,8 @@ class GATLayer(nn.Module):
         super().__init__()
         assert hidden_dim % n_head == 0
         self.MHA = TransformerConv(hidden_dim, hidden_dim // n_head, n_head, dropout, hidden_dim)
-        self.FFN = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.SiLU(), nn.Dropout(dropout),
-                                 nn.Linear(hidden_dim, hidden_dim))
+        self.FFN = nn.Sequential(_nn.Linear(hidden_dim, hidden_dim), nn.SiLU(), nn.Dropout(dropout),
+                                 _nn.Linear(hidden_dim, hidden_dim))
         self.norm1 = nn.LayerNorm(hidden_dim)
         self.norm2 = nn.LayerNorm(hidden_dim)
 
@@ -94,7 +94,7 @@ class EquivariantScoreNetwork(nn.Module):
                 [GATLayer(self.num_head, hidden_dim, dropout=self.dropout) for _ in range(self.num_convs)]))
             self.equi_modules.append(_EquiLayer())
             self.basis_mlp_modules.append(nn.Sequential(
-                nn.Linear(2 * hidden_dim, hidden_coff_dim), nn.SiLU(), nn.Linear(hidden_coff_dim, 3)))
+                _nn.Linear(2 * hidden_dim, hidden_coff_dim), nn.SiLU(), _nn.Linear(hidden_coff_dim, 3)))
         self._seed_base = 0x5DE2D3D
         self._calls = 0
 
@@ -125,12 +125,12 @@ class SDEModel2Dto3D_02(nn.Module):
         self.emb_dim, self.hidden_dim = emb_dim, hidden_dim
         self.SDE_type, self.use_extend_graph = SDE_type, use_extend_graph
         self.node_emb = _nn.MultiLayerPerceptron(emb_dim, [hidden_dim], activation="silu")
-        self.edge_2D_emb = nn.Sequential(nn.Linear(emb_dim * 2, emb_dim), nn.BatchNorm1d(emb_dim), nn.ReLU(),
-                                         nn.Linear(emb_dim, hidden_dim))
+        self.edge_2D_emb = nn.Sequential(_nn.Linear(emb_dim * 2, emb_dim), nn.BatchNorm1d(emb_dim), nn.ReLU(),
+                                         _nn.Linear(emb_dim, hidden_dim))
         self.dist_gaussian_fourier = GaussianFourierProjection(hidden_dim, scale=1)
         self.input_mlp = _nn.MultiLayerPerceptron(2 * hidden_dim, [hidden_dim], activation="silu")
         self.coff_gaussian_fourier = GaussianFourierProjection(hidden_dim, scale=1)
-        self.coff_mlp = nn.Linear(4 * hidden_dim, hidden_dim)
+        self.coff_mlp = _nn.Linear(4 * hidden_dim, hidden_dim)
         self.project = _nn.MultiLayerPerceptron(2 * hidden_dim + 2, [hidden_dim, hidden_dim], activation="silu")
         self.score_network = EquivariantScoreNetwork(hidden_dim, hidden_coff_dim=128, activation="silu",
                                                      short_cut=short_cut, concat_hidden=concat_hidden)
@@ -153,8 +153,8 @@ class SDEModel2Dto3D_02(nn.Module):
             pos_perturbed, ep, self.dist_gaussian_fourier.W, self.coff_gaussian_fourier.W)
         # edge_2D_emb[0](cat(h[row], h[col])) == h[row] W[:, :D]^T + h[col] W[:, D:]^T + b
         lin0 = self.edge_2D_emb[0]
-        A = F.linear(node_2D_repr, lin0.weight[:, :D])
-        Bm = F.linear(node_2D_repr, lin0.weight[:, D:], lin0.bias)
+        A = _nn.linear(node_2D_repr, lin0.weight[:, :D])
+        Bm = _nn.linear(node_2D_repr, lin0.weight[:, D:], lin0.bias)
         pre = hip.pair_gather_add(A, Bm, ep)
         edge_attr_2D = self.edge_2D_emb[3](self.edge_2D_emb[2](self.edge_2D_emb[1](pre)))
         edge_attr_3D_invariant = self.input_mlp(feat_d)

@@ -380,6 +380,51 @@ def segment_reduce(x, mol_ptr, batch_i32, mean=True):
 
 
 # ------------------------------------------------------------------------------------------------
+# dense layers
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shape = x.shape
+        x2 = _f32(x.reshape(-1, shape[-1]))
+        w = _f32(weight)
+        M, K = x2.shape
+        N = w.size(0)
+        y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+        _lib.call("msde_linear_fwd", _p(x2), _p(w), _p(_f32(bias) if bias is not None else None), M, N, K, _p(y),
+                  _stream())
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = shape
+        return y.view(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.size(0)
+        g2 = _f32(g.reshape(-1, N))
+        st = _stream()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, dtype=torch.float32, device=g2.device)
+            _lib.call("msde_linear_bwd_x", _p(g2), _p(w), M, N, K, _p(gx), st)
+            gx = gx.view(ctx.in_shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
+            gb = torch.empty(N, dtype=torch.float32, device=g2.device) if ctx.has_bias else None
+            nbytes = _lib.load().msde_linear_bwd_w_workspace_bytes(M, N, K)
+            ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=g2.device)
+            _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """F.linear on the fp32 MFMA GEMM of csrc/linear.hip (forward, dgrad and wgrad+bias-grad)."""
+    return _Linear.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------
 def adam_flat(p, g, m, v, step_dev, seg_end, seg_lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):

@@ -25,7 +25,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/msde_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     # argument counts in the ctypes table match the header prototypes
-    protos = re.findall(r"(?:int|const char\*)\s+(msde_[a-z0-9_]+)\s*\(([^;]*?)\);", header, flags=re.S)
+    protos = re.findall(r"(?:long long|int|const char\*)\s+(msde_[a-z0-9_]+)\s*\(([^;]*?)\);", header, flags=re.S)
     assert len(protos) == len(declared)
     for name, args in protos:
         args = args.strip()
