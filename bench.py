@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--batch_size", type=int, default=256)
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host (no hipGraph replay)")
     a = ap.parse_args()
 
     from moleculesde_amd import _lib, dp, pretrain
@@ -155,13 +156,29 @@ def main():
     stats = batch_stats(cpu_pool[0])
     pool = [prepare_batch(b, device) for b in cpu_pool]
 
-    for s in range(a.warmup):
+    # warm-up: W eager steps (every batch shape at least once), then -- unless --eager -- each batch shape
+    # is captured into a hipGraph (fwd + bwd + grad flattening + Adam) that the timed steps replay
+    for s in range(max(a.warmup, len(pool))):
         trainer.step(pool[s % len(pool)])
+    use_graph = not a.eager
+    eager_ms = None
+    if use_graph:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(len(pool)):
+            trainer.step(pool[s])
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / len(pool) * 1e3
+        for b in pool:
+            trainer.capture(b)
+        for b in pool:
+            trainer.step_graph(b)
+    step_fn = trainer.step_graph if use_graph else trainer.step
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(a.steps):
-        trainer.step(pool[s % len(pool)])
+        step_fn(pool[s % len(pool)])
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -185,6 +202,8 @@ def main():
                                    "EBM_node_dot_prod contrastive + SDEModel2Dto3D_02 VE; fwd+bwd+Adam",
                        "molecules_per_gpu": a.batch_size, "global_batch": world * a.batch_size,
                        "parallelism": f"dp{world}", "batch_shape": stats, "dropout_p_2Dto3D": 0.1,
+                       "launch": ("hipGraph replay, one graph per batch shape (pool of %d shapes)" % len(pool))
+                       if use_graph else "eager", "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                        "loss_scalar": float(trainer.log["2Dto3D"]) / max(trainer.steps, 1)},
             "roofline": roof,
             "roofline_fused_cfconv_fwd": fused,

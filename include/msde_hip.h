@@ -116,18 +116,21 @@ int msde_edge_geometry_fwd(const float* pos, const int* src, const int* dst, int
                            float* feat_j, float* angle, float* basis, void* stream);
 /* PyG TransformerConv message+softmax+aggregate — equivariant_scorenetwork.py:18-24,35:
  * s[e,h] = q[dst]·(k[src]+ee[e]) / sqrt(Ch); alpha = softmax over in-edges of dst;
- * out[i] = sum_e dropout(alpha)[e,h] * (v[src]+ee[e]).  H*Ch == D <= 64.  alpha [E,H] is saved. */
+ * out[i] = sum_e dropout(alpha)[e,h] * (v[src]+ee[e]).  H*Ch == D <= 64.  alpha [E,H] is saved.
+ * The dropout mask is a pure function of (seed + seed_dev[0]*prime, edge, head); seed_dev (may be
+ * NULL) lets a captured hipGraph draw a fresh mask on every replay. */
 int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* ee,
                             const int* rowptr, const int* src, int N, int H, int Ch,
-                            float p_drop, unsigned long long seed, float* alpha, float* out,
+                            float p_drop, unsigned long long seed,
+                            const unsigned long long* seed_dev, float* alpha, float* out,
                             void* stream);
 /* backward of the above: writes g_q [N,D], g_ee [E,D] and the per-edge grads g_kpe/g_vpe [E,D]
  * (to be segment-summed by source into g_k / g_v with msde_segment_sum_rows). */
 int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v,
                             const float* ee, const float* alpha, const int* rowptr,
                             const int* src, int N, int H, int Ch, float p_drop,
-                            unsigned long long seed, float* g_q, float* g_ee, float* g_kpe,
-                            float* g_vpe, void* stream);
+                            unsigned long long seed, const unsigned long long* seed_dev,
+                            float* g_q, float* g_ee, float* g_kpe, float* g_vpe, void* stream);
 /* basis mix + EquiLayer mean — equivariant_scorenetwork.py:159-164:
  * out[i] = mean_{e in in(i)} (c0*b_diff + c1*b_cross + c2*b_vert) */
 int msde_frame_mix_mean_fwd(const float* coff, const float* basis, const int* rowptr, int N,

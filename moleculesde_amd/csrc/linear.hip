@@ -38,9 +38,10 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
 
   // staging registers: each thread moves (BM*BK/4)/256 = 2*TM float4 of A and 2*TN of B per tile
   constexpr int NA = 2 * TM, NB = 2 * TN;
-  float4 ra[NA], rb[NB];
+  constexpr int ST = 3;  // register prefetch depth: loads are issued ST tiles ahead of their MFMAs
+  float4 rsa[ST][NA], rsb[ST][NB];
 
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](float4 (&ra)[NA], float4 (&rb)[NB], int k0) {
     // ---- A
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
@@ -111,7 +112,7 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
     }
   };
 
-  auto store_tile = [&]() {
+  auto store_tile = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       int idx = p * 256 + tid;
@@ -158,29 +159,41 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
 
   float csum = 0.f;  // column sum of A over k (weight-gradient mode: bias gradient), thread tid < BM
 
-  if (kb < ke) {
-    load_tile(kb);
-    for (int k0 = kb; k0 < ke; k0 += LG_BK) {
-      __syncthreads();  // previous tile fully consumed
-      store_tile();
-      __syncthreads();
-      if (k0 + LG_BK < ke) load_tile(k0 + LG_BK);  // in flight during the MFMAs below
+  auto compute_tile = [&]() {
 #pragma unroll
-      for (int kk = 0; kk < LG_BK / 2; ++kk) {
-        float af[TM], bf[TN];
+    for (int kk = 0; kk < LG_BK / 2; ++kk) {
+      float af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = As[(2 * kk + lhalf) * LDA_S + (wm * TM + i) * 32 + lcol];
+      for (int i = 0; i < TM; ++i) af[i] = As[(2 * kk + lhalf) * LDA_S + (wm * TM + i) * 32 + lcol];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kk + lhalf) * LDB_S + (wn * TN + j) * 32 + lcol];
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[(2 * kk + lhalf) * LDB_S + (wn * TN + j) * 32 + lcol];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
-      if (colsum_ws != nullptr && blockIdx.x == 0 && tid < BM) {
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (colsum_ws != nullptr && blockIdx.x == 0 && tid < BM) {
 #pragma unroll 8
-        for (int kr = 0; kr < LG_BK; ++kr) csum += As[kr * LDA_S + tid];
+      for (int kr = 0; kr < LG_BK; ++kr) csum += As[kr * LDA_S + tid];
+    }
+  };
+
+  if (kb < ke) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s)
+      if (kb + s * LG_BK < ke) load_tile(rsa[s], rsb[s], kb + s * LG_BK);
+    for (int k0 = kb; k0 < ke; k0 += ST * LG_BK) {
+#pragma unroll
+      for (int s = 0; s < ST; ++s) {          // static stage index: the staging arrays stay in VGPRs
+        int kt = k0 + s * LG_BK;
+        if (kt < ke) {
+          __syncthreads();                    // previous tile fully consumed
+          store_tile(rsa[s], rsb[s]);
+          __syncthreads();
+          if (kt + ST * LG_BK < ke) load_tile(rsa[s], rsb[s], kt + ST * LG_BK);   // ST tiles ahead
+          compute_tile();
+        }
       }
     }
   }
@@ -203,12 +216,21 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
     colsum_ws[(size_t)blockIdx.z * M + m0 + tid] = csum;
 }
 
-// out[i] = sum_z slabs[z][i] (fixed order), i < n
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, size_t n, float* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+// out[i] = sum_z slabs[z][i] (fixed order) for the weight slabs (n entries) and, in the same launch,
+// the bias-gradient column sums (nb entries; cs == nullptr when the layer has no bias)
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, size_t n, float* __restrict__ out,
+                                    const float* __restrict__ cs, size_t nb, float* __restrict__ outb) {
+  size_t total = n + (cs ? nb : 0);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
-    for (int z = 0; z < splits; ++z) acc += slabs[(size_t)z * n + i];
-    out[i] = acc;
+    if (i < n) {
+      for (int z = 0; z < splits; ++z) acc += slabs[(size_t)z * n + i];
+      out[i] = acc;
+    } else {
+      size_t j = i - n;
+      for (int z = 0; z < splits; ++z) acc += cs[(size_t)z * nb + j];
+      outb[j] = acc;
+    }
   }
 }
 
@@ -253,10 +275,24 @@ extern "C" int msde_linear_bwd_x(const float* gY, const float* W, int M, int N, 
   return launch_gemm<false, true>(gY, W, nullptr, gX, nullptr, M, K, N, N, K, K, 1, N, as_stream(stream));
 }
 
+// split policy of the weight gradient: enough (tile x split) workgroups to put ~4 on every CU, at
+// least 64 rows of M per split, at most 512 splits
+static inline void wgrad_split(int M, int N, int K, int* splits, int* k_per_split) {
+  long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+  long want = (1024 + tiles - 1) / tiles;
+  long maxs = (M + 63) / 64;
+  if (want > maxs) want = maxs;
+  if (want > 512) want = 512;
+  if (want < 1) want = 1;
+  int kps = (int)(((M + want - 1) / want + LG_BK - 1) / LG_BK * LG_BK);
+  if (kps < LG_BK) kps = LG_BK;
+  *k_per_split = kps;
+  *splits = M > 0 ? (M + kps - 1) / kps : 1;
+}
+
 extern "C" long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K) {
-  int splits = (M + 511) / 512;
-  if (splits < 1) splits = 1;
-  if (splits > 128) splits = 128;
+  int splits, kps;
+  wgrad_split(M, N, K, &splits, &kps);
   return (long long)splits * ((long long)N * K + N) * (long long)sizeof(float);
 }
 
@@ -264,11 +300,8 @@ extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, 
                                  float* workspace, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !gY || !X || !gW || !workspace) return MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
-  int splits = (M + 511) / 512;
-  if (splits < 1) splits = 1;
-  if (splits > 128) splits = 128;
-  int k_per_split = ((M + splits - 1) / splits + LG_BK - 1) / LG_BK * LG_BK;
-  splits = M > 0 ? (M + k_per_split - 1) / k_per_split : 1;
+  int splits, k_per_split;
+  wgrad_split(M, N, K, &splits, &k_per_split);
   float* slabs = workspace;
   float* cs = gb ? workspace + (size_t)splits * N * K : nullptr;
   if (M == 0) {
@@ -282,11 +315,8 @@ extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, 
   size_t n = (size_t)N * K;
   int blocks = (int)((n + 255) / 256);
   if (blocks > 1024) blocks = 1024;
-  MSDE_LAUNCH(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, n, gW);
+  MSDE_LAUNCH(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, n, gW, (const float*)cs, (size_t)N,
+              gb);
   MSDE_CHECK_LAUNCH();
-  if (gb) {
-    MSDE_LAUNCH(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cs, splits, (size_t)N, gb);
-    MSDE_CHECK_LAUNCH();
-  }
   return 0;
 }

@@ -80,10 +80,12 @@ template <int CH>
 __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                           const float* __restrict__ v, const float* __restrict__ ee,
                                           const int* __restrict__ rowptr, const int* __restrict__ src, int N, int H,
-                                          float p_drop, unsigned long long seed, float* __restrict__ alpha,
-                                          float* __restrict__ out) {
+                                          float p_drop, unsigned long long seed,
+                                          const unsigned long long* __restrict__ seed_dev,
+                                          float* __restrict__ alpha, float* __restrict__ out) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N * H) return;
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
   int i = t / H, h = t % H;
   const int D = H * CH;
   float qv[CH];
@@ -131,11 +133,13 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
                                           const float* __restrict__ k, const float* __restrict__ v,
                                           const float* __restrict__ ee, const float* __restrict__ alpha,
                                           const int* __restrict__ rowptr, const int* __restrict__ src, int N, int H,
-                                          float p_drop, unsigned long long seed, float* __restrict__ g_q,
+                                          float p_drop, unsigned long long seed,
+                                          const unsigned long long* __restrict__ seed_dev, float* __restrict__ g_q,
                                           float* __restrict__ g_ee, float* __restrict__ g_kpe,
                                           float* __restrict__ g_vpe) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N * H) return;
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
   int i = t / H, h = t % H;
   const int D = H * CH;
   float qv[CH], go[CH], gq[CH];
@@ -190,16 +194,17 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
 
 extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* ee,
                                        const int* rowptr, const int* src, int N, int H, int Ch, float p_drop,
-                                       unsigned long long seed, float* alpha, float* out, void* stream) {
+                                       unsigned long long seed, const unsigned long long* seed_dev, float* alpha,
+                                       float* out, void* stream) {
   if (N < 0 || H <= 0 || Ch <= 0 || !q || !k || !v || !ee || !rowptr || !src || !alpha || !out) return MSDE_EINVAL;
   if (p_drop < 0.f || p_drop >= 1.f) return MSDE_EINVAL;
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: MSDE_LAUNCH(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
-    case 2: MSDE_LAUNCH(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
-    case 4: MSDE_LAUNCH(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
-    case 8: MSDE_LAUNCH(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, alpha, out); break;
+    case 1: MSDE_LAUNCH(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 2: MSDE_LAUNCH(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 4: MSDE_LAUNCH(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 8: MSDE_LAUNCH(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();
@@ -208,8 +213,9 @@ extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const flo
 
 extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v,
                                        const float* ee, const float* alpha, const int* rowptr, const int* src, int N,
-                                       int H, int Ch, float p_drop, unsigned long long seed, float* g_q, float* g_ee,
-                                       float* g_kpe, float* g_vpe, void* stream) {
+                                       int H, int Ch, float p_drop, unsigned long long seed,
+                                       const unsigned long long* seed_dev, float* g_q, float* g_ee, float* g_kpe,
+                                       float* g_vpe, void* stream) {
   if (N < 0 || H <= 0 || Ch <= 0 || !g_out || !q || !k || !v || !ee || !alpha || !rowptr || !src || !g_q || !g_ee ||
       !g_kpe || !g_vpe)
     return MSDE_EINVAL;
@@ -217,10 +223,10 @@ extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
-    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
-    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
-    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, g_q, g_ee, g_kpe, g_vpe); break;
+    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();

@@ -46,11 +46,11 @@ class TransformerConv(nn.Module):
         self.lin_edge = _nn.Linear(edge_dim, heads * out_channels, bias=False)
         self.lin_skip = _nn.Linear(in_channels, heads * out_channels, bias=True)
 
-    def forward(self, x, edge_attr, plan, seed):
+    def forward(self, x, edge_attr, plan, seed, seed_dev=None):
         q, k, v = self.lin_query(x), self.lin_key(x), self.lin_value(x)
         ee = self.lin_edge(edge_attr)
         p = self.dropout if self.training else 0.0
-        out = hip.edge_attention(q, k, v, ee, plan, self.heads, p, seed)
+        out = hip.edge_attention(q, k, v, ee, plan, self.heads, p, seed, seed_dev)
         return out + self.lin_skip(x)
 
 
@@ -64,8 +64,8 @@ class GATLayer(nn.Module):
         self.norm1 = nn.LayerNorm(hidden_dim)
         self.norm2 = nn.LayerNorm(hidden_dim)
 
-    def forward(self, plan, node_attr, edge_attr, seed):
-        x = self.MHA(node_attr, edge_attr, plan, seed)
+    def forward(self, plan, node_attr, edge_attr, seed, seed_dev=None):
+        x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev)
         node_attr = node_attr + self.norm1(x)
         x = self.FFN(node_attr)
         return node_attr + self.norm2(x)
@@ -97,15 +97,17 @@ class EquivariantScoreNetwork(nn.Module):
                 _nn.Linear(2 * hidden_dim, hidden_coff_dim), nn.SiLU(), _nn.Linear(hidden_coff_dim, 3)))
         self._seed_base = 0x5DE2D3D
         self._calls = 0
+        self.seed_dev = None   # device uint64 step counter (set by the trainer for hipGraph replay)
 
     def forward(self, plan, node_attr, edge_attr, basis):
         conv_input = node_attr
         gradient = None
-        self._calls += 1
+        if self.seed_dev is None:
+            self._calls += 1     # eager: host-side call counter; graph mode: the device counter varies the mask
         for module_idx, gnn_layers in enumerate(self.gnn_layers):
             for conv_idx, gnn in enumerate(gnn_layers):
                 seed = (self._seed_base + self._calls) * 16 + module_idx * 4 + conv_idx
-                hidden = gnn(plan, conv_input, edge_attr, seed)
+                hidden = gnn(plan, conv_input, edge_attr, seed, self.seed_dev)
                 if conv_idx < len(gnn_layers) - 1:
                     hidden = F.silu(hidden)
                 conv_input = hidden

@@ -294,16 +294,16 @@ def pair_gather_add(A, B, plan):
 
 class _EdgeAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, ee, plan, heads, p_drop, seed):
+    def forward(ctx, q, k, v, ee, plan, heads, p_drop, seed, seed_dev):
         q, k, v, ee = _f32(q), _f32(k), _f32(v), _f32(ee)
         N, D = q.shape
         Ch = D // heads
         alpha = torch.empty(plan.E, heads, dtype=torch.float32, device=q.device)
         out = torch.empty_like(q)
         _lib.call("msde_edge_attention_fwd", _p(q), _p(k), _p(v), _p(ee), _p(plan.rowptr), _p(plan.src), N, heads, Ch,
-                  float(p_drop), int(seed), _p(alpha), _p(out), _stream())
+                  float(p_drop), int(seed), _p(seed_dev), _p(alpha), _p(out), _stream())
         ctx.save_for_backward(q, k, v, ee, alpha)
-        ctx.plan, ctx.heads, ctx.p_drop, ctx.seed = plan, heads, float(p_drop), int(seed)
+        ctx.plan, ctx.heads, ctx.p_drop, ctx.seed, ctx.seed_dev = plan, heads, float(p_drop), int(seed), seed_dev
         return out
 
     @staticmethod
@@ -317,15 +317,17 @@ class _EdgeAttention(torch.autograd.Function):
         g_kpe = torch.empty_like(ee)
         g_vpe = torch.empty_like(ee)
         _lib.call("msde_edge_attention_bwd", _p(g), _p(q), _p(k), _p(v), _p(ee), _p(alpha), _p(plan.rowptr),
-                  _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(g_q), _p(g_ee), _p(g_kpe), _p(g_vpe), _stream())
+                  _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), _p(g_q), _p(g_ee), _p(g_kpe),
+                  _p(g_vpe), _stream())
         g_k = segment_sum_rows(g_kpe, plan.rowptr_s, plan.perm_s, N)
         g_v = segment_sum_rows(g_vpe, plan.rowptr_s, plan.perm_s, N)
-        return g_q, g_k, g_v, g_ee, None, None, None, None
+        return g_q, g_k, g_v, g_ee, None, None, None, None, None
 
 
-def edge_attention(q, k, v, ee, plan, heads, p_drop=0.0, seed=0):
-    """TransformerConv message + per-target softmax + aggregate (App. A.4)."""
-    return _EdgeAttention.apply(q, k, v, ee, plan, heads, p_drop, seed)
+def edge_attention(q, k, v, ee, plan, heads, p_drop=0.0, seed=0, seed_dev=None):
+    """TransformerConv message + per-target softmax + aggregate (App. A.4).  seed_dev: optional
+    device uint64 added to the seed inside the kernel (fresh masks under hipGraph replay)."""
+    return _EdgeAttention.apply(q, k, v, ee, plan, heads, p_drop, seed, seed_dev)
 
 
 class _FrameMixMean(torch.autograd.Function):
@@ -382,6 +384,25 @@ def segment_reduce(x, mol_ptr, batch_i32, mean=True):
 # ------------------------------------------------------------------------------------------------
 # dense layers
 # ------------------------------------------------------------------------------------------------
+_WS = {}          # per-device wgrad slab workspace, grown on demand (stream-ordered reuse)
+_WS_BYTES = {}    # (M, N, K) -> workspace bytes
+
+
+def _wgrad_workspace(M, N, K, device):
+    key = (M, N, K)
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = int(_lib.load().msde_linear_bwd_w_workspace_bytes(M, N, K))
+        _WS_BYTES[key] = nbytes
+    ws = _WS.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.MsdeHipError("wgrad workspace must be sized by an eager warm-up step before graph capture")
+        ws = torch.empty(max(nbytes // 4, 1 << 20), dtype=torch.float32, device=device)
+        _WS[device] = ws
+    return ws
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -413,8 +434,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
             gb = torch.empty(N, dtype=torch.float32, device=g2.device) if ctx.has_bias else None
-            nbytes = _lib.load().msde_linear_bwd_w_workspace_bytes(M, N, K)
-            ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=g2.device)
+            ws = _wgrad_workspace(M, N, K, g2.device)
             _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
         return gx, gw, gb
 

@@ -158,6 +158,12 @@ class Trainer:
         self.steps = 0
         for m in self.models.values():
             m.train()
+        # hipGraph mode: one captured graph per batch shape (forward + backward + gradient flattening
+        # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
+        self._graphs = {}
+        self._graph_pool = None
+        self._graph_loss = {}
+        self.step_counter = torch.zeros(1, dtype=torch.int64, device=device)
 
     def losses(self, batch):
         a, m = self.args, self.models
@@ -192,6 +198,48 @@ class Trainer:
             self.log[k] += v
         self.steps += 1
         return loss.detach(), parts
+
+    # ---- hipGraph path ---------------------------------------------------------------------------
+    def _graph_body(self, batch, with_adam):
+        self.step_counter.add_(1)
+        loss, parts = self.losses(batch)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.gather_grads()
+        if with_adam:
+            self.opt.step(grad_scale=1.0)
+        for k, v in parts.items():
+            self.log[k] += v
+        return loss.detach()
+
+    def capture(self, batch):
+        """Capture one step on `batch` (static shapes / addresses) into a hipGraph.  Call after at least
+        one eager step on a batch of the same shape (sizes workspaces, sets kernel attributes)."""
+        key = id(batch)
+        if key in self._graphs:
+            return self._graphs[key]
+        with_adam = dp.world_size() == 1
+        sd = self.step_counter.view(torch.int64)
+        self.models["SDE_2Dto3D_model"].score_network.seed_dev = sd
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            loss = self._graph_body(batch, with_adam)
+        self._graphs[key] = g
+        self._graph_loss[key] = loss
+        return g
+
+    def step_graph(self, batch):
+        """Replay the captured step; under DP the all-reduce and Adam run after the replay."""
+        g = self._graphs[id(batch)]
+        g.replay()
+        if dp.world_size() > 1:
+            scale = dp.allreduce_mean_(self.opt.flat_g)
+            self.opt.step(grad_scale=scale)
+        self.steps += 1
+        return self._graph_loss[id(batch)]
 
     def state_dicts(self):
         """Checkpoint dictionary of pretrain_MoleculeSDE.py:78-88."""
