@@ -19,11 +19,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LG_BK 32
 
-template <int TM, int TN, bool A_KM, bool B_KM>
+template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>
 __global__ void __launch_bounds__(256)
 gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                      float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
-                     int ldc, int k_per_split, int vecA, int vecB) {
+                     int ldc, int k_per_split) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
   __shared__ float As[LG_BK * LDA_S];
@@ -41,74 +41,51 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
   constexpr int ST = 3;  // register prefetch depth: loads are issued ST tiles ahead of their MFMAs
   float4 rsa[ST][NA], rsb[ST][NB];
 
+  // Branch-free tile loads: out-of-range rows / k are redirected to a valid address and zeroed by a
+  // select, so the compiler emits back-to-back loads with ONE counted wait (a per-element branch makes
+  // hipcc wait vmcnt(0) after every load: 6 serialized L2 round trips per tile).
+  auto ld4 = [&](const float* __restrict__ base, int row, int nrows, int ld, int col, int ncols, bool vec) -> float4 {
+    bool rv = row < nrows;
+    int rc = rv ? row : 0;
+    const float* src = base + (size_t)rc * ld;
+    float4 v;
+    if (vec) {                                   // ncols % 4 == 0: a float4 is all-in or all-out
+      bool cv = col < ncols;
+      v = *reinterpret_cast<const float4*>(src + (cv ? col : 0));
+      if (!(rv && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      float x0 = src[col < ncols ? col : 0], x1 = src[col + 1 < ncols ? col + 1 : 0];
+      float x2 = src[col + 2 < ncols ? col + 2 : 0], x3 = src[col + 3 < ncols ? col + 3 : 0];
+      v.x = (rv && col < ncols) ? x0 : 0.f;
+      v.y = (rv && col + 1 < ncols) ? x1 : 0.f;
+      v.z = (rv && col + 2 < ncols) ? x2 : 0.f;
+      v.w = (rv && col + 3 < ncols) ? x3 : 0.f;
+    }
+    return v;
+  };
+
   auto load_tile = [&](float4 (&ra)[NA], float4 (&rb)[NB], int k0) {
-    // ---- A
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       int idx = p * 256 + tid;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!A_KM) {                       // A[m][k], k contiguous: 8 float4 per row
+      if (!A_KM) {                       // A[m][k], k contiguous: 8 float4 per row of the tile
         int r = idx >> 3, kq = (idx & 7) * 4;
-        int gm = m0 + r, gk = k0 + kq;
-        if (gm < M) {
-          const float* src = A + (size_t)gm * lda + gk;
-          if (vecA && gk + 3 < ke) v = *reinterpret_cast<const float4*>(src);
-          else {
-            if (gk < ke) v.x = src[0];
-            if (gk + 1 < ke) v.y = src[1];
-            if (gk + 2 < ke) v.z = src[2];
-            if (gk + 3 < ke) v.w = src[3];
-          }
-        }
+        ra[p] = ld4(A, m0 + r, M, lda, k0 + kq, ke, VEC);
       } else {                           // A[k][m], m contiguous: BM/4 float4 per k-row
         int kr = idx / (BM / 4), mq = (idx % (BM / 4)) * 4;
-        int gk = k0 + kr, gm = m0 + mq;
-        if (gk < ke) {
-          const float* src = A + (size_t)gk * lda + gm;
-          if (vecA && gm + 3 < M) v = *reinterpret_cast<const float4*>(src);
-          else {
-            if (gm < M) v.x = src[0];
-            if (gm + 1 < M) v.y = src[1];
-            if (gm + 2 < M) v.z = src[2];
-            if (gm + 3 < M) v.w = src[3];
-          }
-        }
+        ra[p] = ld4(A, k0 + kr, ke, lda, m0 + mq, M, VEC);
       }
-      ra[p] = v;
     }
-    // ---- B
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       int idx = p * 256 + tid;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!B_KM) {                       // B[n][k], k contiguous
         int r = idx >> 3, kq = (idx & 7) * 4;
-        int gn = n0 + r, gk = k0 + kq;
-        if (gn < N) {
-          const float* src = B + (size_t)gn * ldb + gk;
-          if (vecB && gk + 3 < ke) v = *reinterpret_cast<const float4*>(src);
-          else {
-            if (gk < ke) v.x = src[0];
-            if (gk + 1 < ke) v.y = src[1];
-            if (gk + 2 < ke) v.z = src[2];
-            if (gk + 3 < ke) v.w = src[3];
-          }
-        }
+        rb[p] = ld4(B, n0 + r, N, ldb, k0 + kq, ke, VEC);
       } else {                           // B[k][n], n contiguous
         int kr = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
-        int gk = k0 + kr, gn = n0 + nq;
-        if (gk < ke) {
-          const float* src = B + (size_t)gk * ldb + gn;
-          if (vecB && gn + 3 < N) v = *reinterpret_cast<const float4*>(src);
-          else {
-            if (gn < N) v.x = src[0];
-            if (gn + 1 < N) v.y = src[1];
-            if (gn + 2 < N) v.z = src[2];
-            if (gn + 3 < N) v.w = src[3];
-          }
-        }
+        rb[p] = ld4(B, k0 + kr, ke, ldb, n0 + nq, N, VEC);
       }
-      rb[p] = v;
     }
   };
 
@@ -179,21 +156,32 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
     }
   };
 
-  if (kb < ke) {
+  // Software pipeline: the loads of tile t+ST are issued while tile t is multiplied.  Every load is
+  // unconditional (tiles past the end are masked to zero by ld4), so the steady-state loop is branch
+  // free and the compiler can retire each stage with a counted vmcnt instead of vmcnt(0).
+  const int ntiles = (ke - kb + LG_BK - 1) / LG_BK;
+  if (ntiles > 0) {
 #pragma unroll
-    for (int s = 0; s < ST; ++s)
-      if (kb + s * LG_BK < ke) load_tile(rsa[s], rsb[s], kb + s * LG_BK);
-    for (int k0 = kb; k0 < ke; k0 += ST * LG_BK) {
+    for (int s = 0; s < ST; ++s) load_tile(rsa[s], rsb[s], kb + s * LG_BK);
+    int t = 0;
+    for (; t + ST <= ntiles; t += ST) {
 #pragma unroll
       for (int s = 0; s < ST; ++s) {          // static stage index: the staging arrays stay in VGPRs
-        int kt = k0 + s * LG_BK;
-        if (kt < ke) {
-          __syncthreads();                    // previous tile fully consumed
-          store_tile(rsa[s], rsb[s]);
-          __syncthreads();
-          if (kt + ST * LG_BK < ke) load_tile(rsa[s], rsb[s], kt + ST * LG_BK);   // ST tiles ahead
-          compute_tile();
-        }
+        __syncthreads();                      // previous tile fully consumed
+        store_tile(rsa[s], rsb[s]);
+        __syncthreads();
+        load_tile(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
+        compute_tile();
+      }
+    }
+    const int rem = ntiles - t;               // 0 .. ST-1 tiles left, already in flight
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s) {
+      if (s < rem) {
+        __syncthreads();
+        store_tile(rsa[s], rsb[s]);
+        __syncthreads();
+        compute_tile();
       }
     }
   }
@@ -224,7 +212,13 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int splits,
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
     if (i < n) {
-      for (int z = 0; z < splits; ++z) acc += slabs[(size_t)z * n + i];
+      int z = 0;
+      for (; z + 4 <= splits; z += 4) {      // four independent loads in flight, fixed summation order
+        float a0 = slabs[(size_t)z * n + i], a1 = slabs[(size_t)(z + 1) * n + i];
+        float a2 = slabs[(size_t)(z + 2) * n + i], a3 = slabs[(size_t)(z + 3) * n + i];
+        acc = (((acc + a0) + a1) + a2) + a3;
+      }
+      for (; z < splits; ++z) acc += slabs[(size_t)z * n + i];
       out[i] = acc;
     } else {
       size_t j = i - n;
@@ -236,27 +230,43 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int splits,
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <int TM, int TN, bool A_KM, bool B_KM>
+static void launch_cfg(bool vec, dim3 grid, hipStream_t st, const float* A, const float* B, const float* bias, float* C,
+                       float* colsum_ws, int M, int N, int K, int lda, int ldb, int ldc, int k_per_split) {
+  if (vec)
+    MSDE_LAUNCH((gemm_f32_mfma_kernel<TM, TN, A_KM, B_KM, true>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N,
+                K, lda, ldb, ldc, k_per_split);
+  else
+    MSDE_LAUNCH((gemm_f32_mfma_kernel<TM, TN, A_KM, B_KM, false>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M,
+                N, K, lda, ldb, ldc, k_per_split);
+}
+
+// tile: rows (product M) and columns (product N) each 64 or 128 wide; `big` prefers 128-wide tiles
+// whenever the dimension exceeds 64 (weight gradient: parallelism comes from the M split instead).
 template <bool A_KM, bool B_KM>
 static int launch_gemm(const float* A, const float* B, const float* bias, float* C, float* colsum_ws, int M, int N,
-                       int K, int lda, int ldb, int ldc, int splits, int k_per_split, hipStream_t st) {
-  int vecA = aligned16(A) && (lda % 4 == 0);
-  int vecB = aligned16(B) && (ldb % 4 == 0);
-  // pick the tile so that the grid has a few hundred workgroups
-  long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * splits;
-  long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64) * splits;
-  if (t128 >= 384) {
-    dim3 grid((N + 127) / 128, (M + 127) / 128, splits);
-    MSDE_LAUNCH((gemm_f32_mfma_kernel<2, 2, A_KM, B_KM>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N, K, lda,
-                ldb, ldc, k_per_split, vecA, vecB);
-  } else if (t12864 >= 256) {
-    dim3 grid((N + 63) / 64, (M + 127) / 128, splits);
-    MSDE_LAUNCH((gemm_f32_mfma_kernel<2, 1, A_KM, B_KM>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N, K, lda,
-                ldb, ldc, k_per_split, vecA, vecB);
+                       int K, int lda, int ldb, int ldc, int splits, int k_per_split, bool big, hipStream_t st) {
+  // vector path: 16-B aligned bases, leading dimensions % 4, and the contiguous extent of each operand % 4
+  bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (k_per_split % 4 == 0);
+  vec = vec && ((A_KM ? M : K) % 4 == 0) && ((B_KM ? N : K) % 4 == 0);
+  int tm, tn;
+  if (big) {
+    tm = M > 64 ? 2 : 1;
+    tn = N > 64 ? 2 : 1;
   } else {
-    dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
-    MSDE_LAUNCH((gemm_f32_mfma_kernel<1, 1, A_KM, B_KM>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N, K, lda,
-                ldb, ldc, k_per_split, vecA, vecB);
+    long t22 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    long t21 = (long)((M + 127) / 128) * ((N + 63) / 64);
+    if (t22 >= 384) { tm = 2; tn = 2; }
+    else if (t21 >= 256) { tm = 2; tn = 1; }
+    else { tm = 1; tn = 1; }
   }
+  dim3 grid((N + 64 * tn - 1) / (64 * tn), (M + 64 * tm - 1) / (64 * tm), splits);
+#define LG_ARGS vec, grid, st, A, B, bias, C, colsum_ws, M, N, K, lda, ldb, ldc, k_per_split
+  if (tm == 2 && tn == 2) launch_cfg<2, 2, A_KM, B_KM>(LG_ARGS);
+  else if (tm == 2 && tn == 1) launch_cfg<2, 1, A_KM, B_KM>(LG_ARGS);
+  else if (tm == 1 && tn == 2) launch_cfg<1, 2, A_KM, B_KM>(LG_ARGS);
+  else launch_cfg<1, 1, A_KM, B_KM>(LG_ARGS);
+#undef LG_ARGS
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -265,24 +275,26 @@ extern "C" int msde_linear_fwd(const float* X, const float* W, const float* bias
                                void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !X || !W || !Y) return MSDE_EINVAL;
   if (M == 0) return 0;
-  return launch_gemm<false, false>(X, W, bias, Y, nullptr, M, N, K, K, K, N, 1, K, as_stream(stream));
+  return launch_gemm<false, false>(X, W, bias, Y, nullptr, M, N, K, K, K, N, 1, (K + 31) / 32 * 32, false,
+                                    as_stream(stream));
 }
 
 extern "C" int msde_linear_bwd_x(const float* gY, const float* W, int M, int N, int K, float* gX, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !gY || !W || !gX) return MSDE_EINVAL;
   if (M == 0) return 0;
   // gX[M,K] = gY[M,N] . W[N,K]: reduce over N; B = W is k-major ([N][K], K contiguous)
-  return launch_gemm<false, true>(gY, W, nullptr, gX, nullptr, M, K, N, N, K, K, 1, N, as_stream(stream));
+  return launch_gemm<false, true>(gY, W, nullptr, gX, nullptr, M, K, N, N, K, K, 1, (N + 31) / 32 * 32, false,
+                                   as_stream(stream));
 }
 
-// split policy of the weight gradient: enough (tile x split) workgroups to put ~4 on every CU, at
-// least 64 rows of M per split, at most 512 splits
+// split policy of the weight gradient: 128-wide tiles where the output allows, then enough splits of
+// the reduction (M) to put ~2 workgroups on every CU; at most 64 splits so the slab reduce stays short
 static inline void wgrad_split(int M, int N, int K, int* splits, int* k_per_split) {
-  long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
-  long want = (1024 + tiles - 1) / tiles;
-  long maxs = (M + 63) / 64;
+  long tiles = (long)((N + (N > 64 ? 127 : 63)) / (N > 64 ? 128 : 64)) * ((K + (K > 64 ? 127 : 63)) / (K > 64 ? 128 : 64));
+  long want = (512 + tiles - 1) / tiles;
+  long maxs = (M + 127) / 128;
   if (want > maxs) want = maxs;
-  if (want > 512) want = 512;
+  if (want > 64) want = 64;
   if (want < 1) want = 1;
   int kps = (int)(((M + want - 1) / want + LG_BK - 1) / LG_BK * LG_BK);
   if (kps < LG_BK) kps = LG_BK;
@@ -310,11 +322,11 @@ extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, 
     return (int)e;
   }
   // C[N,K] = A^T B with A = gY [M][N] (k-major, "M" of the product = N), B = X [M][K] (k-major)
-  int rc = launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, st);
+  int rc = launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, true, st);
   if (rc != 0) return rc;
   size_t n = (size_t)N * K;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
+  int blocks = (int)((n + (size_t)N + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
   MSDE_LAUNCH(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, n, gW, (const float*)cs, (size_t)N,
               gb);
   MSDE_CHECK_LAUNCH();
