@@ -403,6 +403,25 @@ def _wgrad_workspace(M, N, K, device):
     return ws
 
 
+# Dispatch policy of the dense layers, from per-shape rocprofv3 timings on MI355X (profiles/):
+#   * forward / input gradient: the vendor fp32 GEMM is ~1.7x faster than csrc/linear.hip on these
+#     skinny shapes (22 vs 41 us at 49090x128x128), so plain library GEMMs are used there;
+#   * weight + bias gradient at edge level (M >= 8192 rows reduced into a <=128x300 output): the vendor
+#     kernel takes 110-190 us; the split-M MFMA kernel + fixed-order slab reduce takes 40-95 us and is
+#     bitwise reproducible -> hand-written kernel.
+# MSDE_LINEAR=hip forces the hand-written kernel everywhere (parity tests do), =lib the vendor GEMM.
+import os as _os
+
+_LINEAR_MODE = _os.environ.get("MSDE_LINEAR", "auto")
+WGRAD_HIP_MIN_ROWS = 8192
+
+
+def set_linear_mode(mode):
+    global _LINEAR_MODE
+    assert mode in ("auto", "hip", "lib")
+    _LINEAR_MODE = mode
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -411,9 +430,12 @@ class _Linear(torch.autograd.Function):
         w = _f32(weight)
         M, K = x2.shape
         N = w.size(0)
-        y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
-        _lib.call("msde_linear_fwd", _p(x2), _p(w), _p(_f32(bias) if bias is not None else None), M, N, K, _p(y),
-                  _stream())
+        if _LINEAR_MODE == "hip":
+            y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+            _lib.call("msde_linear_fwd", _p(x2), _p(w), _p(_f32(bias) if bias is not None else None), M, N, K, _p(y),
+                      _stream())
+        else:
+            y = torch.addmm(bias, x2, w.t()) if bias is not None else torch.mm(x2, w.t())
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.in_shape = shape
@@ -428,19 +450,27 @@ class _Linear(torch.autograd.Function):
         st = _stream()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.empty(M, K, dtype=torch.float32, device=g2.device)
-            _lib.call("msde_linear_bwd_x", _p(g2), _p(w), M, N, K, _p(gx), st)
+            if _LINEAR_MODE == "hip":
+                gx = torch.empty(M, K, dtype=torch.float32, device=g2.device)
+                _lib.call("msde_linear_bwd_x", _p(g2), _p(w), M, N, K, _p(gx), st)
+            else:
+                gx = torch.mm(g2, w)
             gx = gx.view(ctx.in_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
-            gb = torch.empty(N, dtype=torch.float32, device=g2.device) if ctx.has_bias else None
-            ws = _wgrad_workspace(M, N, K, g2.device)
-            _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
+            use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
+            if use_hip:
+                gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
+                gb = torch.empty(N, dtype=torch.float32, device=g2.device) if ctx.has_bias else None
+                ws = _wgrad_workspace(M, N, K, g2.device)
+                _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
+            else:
+                gw = torch.mm(g2.t(), x2)
+                gb = g2.sum(0) if ctx.has_bias else None
         return gx, gw, gb
 
 
 def linear(x, weight, bias=None):
-    """F.linear on the fp32 MFMA GEMM of csrc/linear.hip (forward, dgrad and wgrad+bias-grad)."""
+    """F.linear with the dispatch policy above (library GEMM / csrc/linear.hip MFMA kernels)."""
     return _Linear.apply(x, weight, bias)
 
 

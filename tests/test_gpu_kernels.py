@@ -398,6 +398,7 @@ def test_linear_mfma_gemm(dev, M, N, K, bias):
     """fp32 MFMA Linear (fwd, dgrad, wgrad + bias grad, all three tile configs, ragged edges, the
     scalar-load path for K % 4 != 0) vs torch CPU fp64 accumulation of the same fp32 inputs."""
     from moleculesde_amd import hip
+    hip.set_linear_mode("hip")           # exercise the hand-written kernels for all three products
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -422,3 +423,10 @@ def test_linear_mfma_gemm(dev, M, N, K, bias):
     wd2 = w.to(dev).requires_grad_(True)
     hip.linear(xd2, wd2, bd.detach() if bias else None).backward(gy.to(dev))
     assert torch.equal(wd2.grad, wd.grad) and torch.equal(xd2.grad, xd.grad)
+    hip.set_linear_mode("auto")
+    xd3 = x.to(dev).requires_grad_(True)
+    wd3 = w.to(dev).requires_grad_(True)
+    y3 = hip.linear(xd3, wd3, bd.detach() if bias else None)
+    y3.backward(gy.to(dev))
+    assert_close(y3, yr, 1e-4, 1e-4, "auto-dispatch fwd")
+    assert_close(wd3.grad, gwr, 1e-4, 2e-6 * math.sqrt(M) * 8, "auto-dispatch wgrad")
