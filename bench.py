@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host (no hipGraph replay)")
+    ap.add_argument("--full", action="store_true",
+                    help="configs[2] per-GPU work: add the 3D->2D dense head loss (default: configs[1])")
     a = ap.parse_args()
 
     from moleculesde_amd import _lib, dp, pretrain
@@ -150,7 +152,7 @@ def main():
     torch.cuda.set_device(device)
     torch.manual_seed(0)
 
-    args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=0, batch_size=a.batch_size)
+    args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=1 if a.full else 0, batch_size=a.batch_size)
     trainer = pretrain.Trainer(args, device)
     cpu_pool = [make_batch(a.batch_size, seed=dp.shard_seed(s, rank)) for s in range(a.pool)]
     stats = batch_stats(cpu_pool[0])
@@ -199,7 +201,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PCQM4Mv2-shaped pretrain step: GIN5x300 + SchNet(6x128f,51g,rc10) + "
-                                   "EBM_node_dot_prod contrastive + SDEModel2Dto3D_02 VE; fwd+bwd+Adam",
+                                   "EBM_node_dot_prod contrastive + SDEModel2Dto3D_02 VE" + (" + SDEModel3Dto2D_node_adj_dense VE" if a.full else "") + "; fwd+bwd+Adam",
                        "molecules_per_gpu": a.batch_size, "global_batch": world * a.batch_size,
                        "parallelism": f"dp{world}", "batch_shape": stats, "dropout_p_2Dto3D": 0.1,
                        "launch": ("hipGraph replay, one graph per batch shape (pool of %d shapes)" % len(pool))

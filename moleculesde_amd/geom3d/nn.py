@@ -129,6 +129,9 @@ class DeviceNoise:
     def randperm(self, n, device):
         return torch.randperm(n, device=device)
 
+    def rand(self, n, device):
+        return torch.rand(n, device=device)
+
 
 class CpuReplayNoise:
     """Parity noise source: draws from a torch CPU generator in the reference's program order
@@ -147,3 +150,6 @@ class CpuReplayNoise:
 
     def randperm(self, n, device):
         return torch.randperm(n, generator=self.g).to(device)
+
+    def rand(self, n, device):
+        return torch.rand(n, generator=self.g).to(device)

@@ -377,6 +377,25 @@ class _SegmentMean(torch.autograd.Function):
         return gather_rows(g, batch_i32), None, None, None
 
 
+class _GatherRowsGrad(torch.autograd.Function):
+    """out[s] = x[idx[s]] (idx < 0 -> zero row) where every row of x appears at most once: the backward is
+    the inverse gather g_x[i] = g_out[inv[i]] (ragged -> padded packing, PyG to_dense_batch)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, inv):
+        ctx.save_for_backward(inv)
+        return gather_rows(x, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return gather_rows(_f32(g), inv), None, None
+
+
+def gather_rows_grad(x, idx, inv):
+    return _GatherRowsGrad.apply(x, idx, inv)
+
+
 def segment_reduce(x, mol_ptr, batch_i32, mean=True):
     return _SegmentMean.apply(x, mol_ptr, batch_i32, mean)
 

@@ -83,12 +83,18 @@ def plan_to(pl, device):
             setattr(pl, k, v.to(device))
         elif isinstance(v, hip.CsrPlan):
             v.to(device)
+        elif isinstance(v, types.SimpleNamespace):
+            for kk, vv in list(vars(v).items()):
+                if isinstance(vv, torch.Tensor):
+                    setattr(v, kk, vv.to(device))
     return pl
 
 
 def prepare_batch(data, device=None, **kw):
     """Collate-time entry point: build the plan on the host, then move batch + plan to the device."""
     pl = build_plan(data, **kw)
+    if getattr(data, "edge_attr", None) is not None and data.edge_attr.dim() == 2:
+        dense_plan(pl, data)
     if device is not None:
         data.to(device)
         plan_to(pl, device)
@@ -106,6 +112,37 @@ def get_plan(data):
         except Exception:
             pass
     return pl
+
+
+def dense_plan(pl, data):
+    """Padded (dense) layout of the batch for the 3D->2D head, built once per batch from data only
+    (SDE_model_3D_to_2D_node_adj_dense.py:121-134): N_max, slot maps, adj [B,Nm,Nm] with bond type + 1,
+    flags (atoms with a non-zero adjacency row), padded atom classes z."""
+    dn = getattr(pl, "dense", None)
+    if dn is not None:
+        return dn
+    dn = types.SimpleNamespace()
+    dev = data.x.device
+    B, N, Nm = pl.B, pl.N, pl.N_max
+    batch = data.batch
+    mol_ptr = pl.mol_ptr.long()
+    local = torch.arange(N, device=dev) - mol_ptr[batch]
+    slot = batch * Nm + local
+    pad_idx = torch.full((B * Nm,), -1, dtype=torch.int32, device=dev)
+    pad_idx[slot] = torch.arange(N, device=dev, dtype=torch.int32)
+    dn.N_max, dn.pad_idx, dn.node_slot = Nm, pad_idx, slot.to(torch.int32)
+    ei = data.edge_index
+    val = data.edge_attr[:, 0].float() + 1                               # bond type + 1 (:121)
+    b = batch[ei[0]]
+    flat = b * Nm * Nm + (ei[0] - mol_ptr[b]) * Nm + (ei[1] - mol_ptr[b])
+    adj = torch.zeros(B * Nm * Nm, dtype=torch.float32, device=dev).index_add_(0, flat, val)
+    dn.adj = adj.view(B, Nm, Nm)
+    dn.flags = torch.abs(dn.adj).sum(-1).gt(1e-5).to(torch.float32)      # node_flags (:523-529)
+    z = torch.zeros(B * Nm, dtype=torch.long, device=dev)
+    z[slot] = data.x[:, 0].long() if data.x.dim() == 2 else data.x.long()
+    dn.z = z.view(B, Nm)
+    pl.dense = dn
+    return dn
 
 
 def z_lists(pl, node_class):

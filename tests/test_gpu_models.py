@@ -416,3 +416,90 @@ def test_hipgraph_step_matches_eager(dev):
     # pure rounding noise that Adam normalises to +-lr, so agreement is judged on the whole vector
     d = float((tr_g.opt.flat_p - tr_e.opt.flat_p).norm() / tr_e.opt.flat_p.norm())
     assert d < 1e-4, d
+
+
+# ------------------------------------------------------------------ 3D -> 2D dense head (a12-a14) ---
+def _s32(mod, E):
+    return mod.SDEModel3Dto2D_node_adj_dense(dim3D=E, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=16, nhid=16,
+                                             num_layers=4, emb_dim=E, num_linears=3, beta_min=0.1, beta_max=1.0,
+                                             num_diffusion_timesteps=1000, SDE_type="VE", num_class_X=119,
+                                             noise_on_one_hot=True)
+
+
+@pytest.mark.parametrize("mode", ["hip", "auto"])
+def test_golden_dense_head_genuine(dev, mode):
+    """Edge / node score networks vs the golden produced by the GENUINE reference import (no stand-ins);
+    mode 'hip' runs every Linear (incl. the node MLP chain) on the hand-written MFMA kernels."""
+    from moleculesde_amd import hip
+    from moleculesde_amd.geom3d import sde_3d_to_2d as S
+    hip.set_linear_mode(mode)
+    try:
+        g = load_golden("dense_head.npz")
+        edge = S.EdgeScoreNetwork_dense(dim3D=12, nhid=8, num_layers=3, num_linears=3, c_init=2, c_hid=4, c_final=2,
+                                        adim=8, num_heads=4, conv="MLP")
+        node = S.NodeScoreNetwork_dense(nfeat=12, depth=3, nhid=8, nout=7)
+        edge.load_state_dict(sub(g, "edge.sd."))
+        node.load_state_dict(sub(g, "node.sd."))
+        edge.to(dev); node.to(dev)
+        x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+        a = torch.from_numpy(g["adj"]).to(dev).requires_grad_(True)
+        flags = torch.from_numpy(g["flags"]).to(dev)
+        se, sn = edge(x, a, flags), node(x, a, flags)
+        assert_close(se, g["score_edge"], 1e-4, 1e-5, "edge score")
+        assert_close(sn, g["score_node"], 1e-4, 1e-5, "node score")
+        (se.pow(2).sum() + sn.pow(2).sum()).backward()
+        assert_close(x.grad, g["grad_x"], 1e-3, 1e-4, "grad x")
+        assert_close(a.grad, g["grad_adj"], 1e-3, 1e-4, "grad adj")
+        _grads_close(edge, sub(g, "edge.grad."), 1e-3, 1e-4, "edge net")
+        _grads_close(node, sub(g, "node.grad."), 1e-3, 1e-4, "node net")
+    finally:
+        hip.set_linear_mode("auto")
+
+
+def test_golden_toy_sde3d2d(dev):
+    import moleculesde_amd.geom3d as G
+    g = load_golden("toy_sde3d2d.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    m = _s32(G, TOY["emb"])
+    m.load_state_dict(sub(g, "sd."))
+    m.to(dev).train()
+    m.noise = G.CpuReplayNoise(int(g["seed"]))
+    h3 = torch.from_numpy(g["h3"]).to(dev).requires_grad_(True)
+    lx, la = m(h3, b, reduce_mean=True, continuous=True, train=True, anneal_power=0)
+    assert_close(lx, g["loss_x"], 1e-4, 1e-6, "loss_x")
+    assert_close(la, g["loss_adj"], 1e-4, 1e-6, "loss_adj")
+    (lx + la).backward()
+    assert_close(h3.grad, g["grad_h3"], 1e-3, 1e-4 * float(np.abs(g["grad_h3"]).max()), "grad h3")
+    _grads_close(m, sub(g, "grad."), 1e-3, 2e-4, "sde3d2d")
+
+
+def test_bs256_full_pretrain_losses_vs_oracle(dev):
+    """BASELINE.json configs[2] per-GPU work: all three losses (contrastive + 2D->3D + 3D->2D VE) at bs 256,
+    emb 300, against the oracle with replayed noise: each loss term within 1e-3 relative."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_batch
+    from moleculesde_amd import pretrain
+    args = pretrain.readme_args()
+    torch.manual_seed(4)
+    tr = pretrain.Trainer(args, dev)
+    disable_dropout(tr.models["SDE_2Dto3D_model"])
+    om = R.build_models(use_3d2d=True)
+    disable_dropout(om["SDE_2Dto3D_model"])
+    for k in om:
+        om[k].load_state_dict(tr.models[k].state_dict())
+        om[k].train()
+    cpu_b = make_batch(256, seed=3)
+    dev_b = G.prepare_batch(cpu_b.clone(), dev)
+    torch.manual_seed(77)
+    loss_o, parts_o = R.pretrain_losses(om, cpu_b, T=0.1)
+    tr.noise = G.CpuReplayNoise(77)
+    tr.models["SDE_2Dto3D_model"].noise = tr.noise
+    tr.models["SDE_3Dto2D_model"].noise = tr.noise
+    loss, parts = tr.losses(dev_b)
+    for k in ("CL", "2Dto3D", "3Dto2D"):
+        assert_close(parts[k], parts_o[k].detach(), 1e-3, 0, f"loss term {k}")
+    assert_close(loss, loss_o.detach(), 1e-3, 0, "total loss")
+    loss.backward()
+    loss_o.backward()
+    g64n = {n: p.grad for n, p in om["SDE_3Dto2D_model"].named_parameters() if p.grad is not None}
+    _grads_close_l2(tr.models["SDE_3Dto2D_model"], g64n, 5e-3, 2e-2, "3D->2D grads")
