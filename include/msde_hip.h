@@ -153,6 +153,19 @@ long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K);
 int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, float* gW, float* gb,
                       float* workspace, void* stream);
 
+/* ------------------------------------------------------------------ normalisation ---------- */
+/* nn.BatchNorm1d in training mode over the rows of X[M,C], optional fused ReLU —
+ * molecule_gnn_model.py:17,176-182; SDE_model_2D_to_3D.py:265.  Batch statistics by Welford partials
+ * combined in a fixed order; running_mean/var (may be NULL) are updated with `momentum` (unbiased
+ * variance), save_mean/save_rstd [C] feed the backward.  workspace: msde_bn_workspace_floats floats. */
+int msde_bn_workspace_floats(int M, int C);
+int msde_bn_fwd(const float* X, int M, int C, const float* gamma, const float* beta, float eps,
+                float momentum, float* running_mean, float* running_var, int relu, float* Y,
+                float* save_mean, float* save_rstd, float* workspace, void* stream);
+int msde_bn_bwd(const float* dY, const float* X, const float* save_mean, const float* save_rstd,
+                const float* gamma, const float* beta, int relu, int M, int C, float* dX,
+                float* dgamma, float* dbeta, float* workspace, void* stream);
+
 /* ------------------------------------------------------------------ optimiser -------------- */
 /* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —
  * examples/pretrain_MoleculeSDE.py:331-337,156.  seg_end[S] (exclusive ends), seg_lr[S].

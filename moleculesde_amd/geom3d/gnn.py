@@ -15,8 +15,9 @@ class GINConv(nn.Module):
 
     def __init__(self, emb_dim, bond_dims):
         super().__init__()
-        self.mlp = nn.Sequential(_nn.Linear(emb_dim, 2 * emb_dim), nn.BatchNorm1d(2 * emb_dim), nn.ReLU(),
-                                 _nn.Linear(2 * emb_dim, emb_dim))
+        bn = _nn.BatchNorm1d(2 * emb_dim)
+        bn.fuse_relu = True                      # mlp[2] (ReLU) is fused into the BatchNorm kernel
+        self.mlp = nn.Sequential(_nn.Linear(emb_dim, 2 * emb_dim), bn, nn.Identity(), _nn.Linear(2 * emb_dim, emb_dim))
         self.eps = nn.Parameter(torch.Tensor([0]))
         self.bond_encoder = _nn.EmbeddingList(bond_dims, emb_dim, "bond_embedding_list")
 
@@ -38,7 +39,9 @@ class GNN(nn.Module):
         self.bond_dims = list(bond_feature_dims or _plan.BOND_FEATURE_DIMS)
         self.atom_encoder = _nn.EmbeddingList(self.atom_dims, emb_dim, "atom_embedding_list")
         self.gnns = nn.ModuleList([GINConv(emb_dim, self.bond_dims) for _ in range(num_layer)])
-        self.batch_norms = nn.ModuleList([nn.BatchNorm1d(emb_dim) for _ in range(num_layer)])
+        self.batch_norms = nn.ModuleList([_nn.BatchNorm1d(emb_dim) for _ in range(num_layer)])
+        for layer in range(num_layer - 1):
+            self.batch_norms[layer].fuse_relu = True     # ReLU after every layer but the last (:178-182)
 
     def _find_plan(self, x, edge_index, edge_attr, data=None):
         pl = None
@@ -69,11 +72,8 @@ class GNN(nn.Module):
         h_list = [h]
         for layer in range(self.num_layer):
             h = self.gnns[layer](h_list[layer], pl.bond, pl.bond_codes)
-            h = self.batch_norms[layer](h)
-            if layer == self.num_layer - 1:
-                h = F.dropout(h, self.drop_ratio, training=self.training)
-            else:
-                h = F.dropout(F.relu(h), self.drop_ratio, training=self.training)
+            h = self.batch_norms[layer](h)             # ReLU fused for all but the last layer
+            h = F.dropout(h, self.drop_ratio, training=self.training)
             h_list.append(h)
 
         if self.JK == "concat":

@@ -30,6 +30,29 @@ class Linear(nn.Linear):
         return F.linear(x, self.weight, self.bias)
 
 
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters / buffers / state_dict keys).  Training mode runs the two-launch
+    HIP kernels of csrc/norm.hip, optionally with the following ReLU fused (`fuse_relu`); eval mode is
+    the affine map on the running statistics."""
+
+    fuse_relu = False
+
+    def forward(self, x):
+        if not (USE_HIP_LINEAR and x.is_cuda and x.dim() == 2):
+            y = super().forward(x)
+            return F.relu(y) if self.fuse_relu else y
+        if self.training or not self.track_running_stats:
+            if self.track_running_stats and self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            momentum = 0.1 if self.momentum is None else self.momentum
+            return hip.batch_norm_train(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                        self.running_var if self.track_running_stats else None, self.eps, momentum,
+                                        self.fuse_relu)
+        scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+        y = x * scale + (self.bias - self.running_mean * scale)
+        return F.relu(y) if self.fuse_relu else y
+
+
 def linear(x, weight, bias=None):
     if USE_HIP_LINEAR and x.is_cuda:
         return hip.linear(x, weight, bias)

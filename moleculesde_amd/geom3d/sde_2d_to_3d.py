@@ -127,7 +127,9 @@ class SDEModel2Dto3D_02(nn.Module):
         self.emb_dim, self.hidden_dim = emb_dim, hidden_dim
         self.SDE_type, self.use_extend_graph = SDE_type, use_extend_graph
         self.node_emb = _nn.MultiLayerPerceptron(emb_dim, [hidden_dim], activation="silu")
-        self.edge_2D_emb = nn.Sequential(_nn.Linear(emb_dim * 2, emb_dim), nn.BatchNorm1d(emb_dim), nn.ReLU(),
+        bn = _nn.BatchNorm1d(emb_dim)
+        bn.fuse_relu = True                      # edge_2D_emb[2] (ReLU) is fused into the BatchNorm kernel
+        self.edge_2D_emb = nn.Sequential(_nn.Linear(emb_dim * 2, emb_dim), bn, nn.Identity(),
                                          _nn.Linear(emb_dim, hidden_dim))
         self.dist_gaussian_fourier = GaussianFourierProjection(hidden_dim, scale=1)
         self.input_mlp = _nn.MultiLayerPerceptron(2 * hidden_dim, [hidden_dim], activation="silu")

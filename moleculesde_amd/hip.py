@@ -494,6 +494,57 @@ def linear(x, weight, bias=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# normalisation
+# ------------------------------------------------------------------------------------------------
+_BN_WS = {}
+
+
+def _bn_workspace(M, C, device):
+    n = int(_lib.load().msde_bn_workspace_floats(M, C))
+    ws = _BN_WS.get(device)
+    if ws is None or ws.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.MsdeHipError("BatchNorm workspace must be sized by an eager warm-up step before graph capture")
+        ws = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=device)
+        _BN_WS[device] = ws
+    return ws
+
+
+class _BatchNormTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = _f32(x)
+        M, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _bn_workspace(M, C, x.device)
+        _lib.call("msde_bn_fwd", _p(x), M, C, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+                  _p(running_var), int(relu), _p(y), _p(mean), _p(rstd), _p(ws), _stream())
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.relu = int(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        g = _f32(g)
+        M, C = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if beta is not None else None
+        ws = _bn_workspace(M, C, x.device)
+        _lib.call("msde_bn_bwd", _p(g), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), ctx.relu, M, C, _p(dx), _p(dgamma),
+                  _p(dbeta), _p(ws), _stream())
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, eps, momentum, relu=False):
+    """Training-mode BatchNorm1d over rows (+ optional fused ReLU); updates the running buffers in place."""
+    return _BatchNormTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum, relu)
+
+
+# ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------
 def adam_flat(p, g, m, v, step_dev, seg_end, seg_lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):

@@ -430,3 +430,34 @@ def test_linear_mfma_gemm(dev, M, N, K, bias):
     y3.backward(gy.to(dev))
     assert_close(y3, yr, 1e-4, 1e-4, "auto-dispatch fwd")
     assert_close(wd3.grad, gwr, 1e-4, 2e-6 * math.sqrt(M) * 8, "auto-dispatch wgrad")
+
+
+@pytest.mark.parametrize("M,C,relu", [(3588, 600, True), (3588, 300, False), (35186, 300, True), (7, 5, True), (1, 3, False),
+                                      (300, 64, True)])
+def test_batchnorm_train_kernels(dev, M, C, relu):
+    """csrc/norm.hip vs torch CPU BatchNorm1d (training mode) + ReLU: output, input/affine gradients and
+    the running-statistics update."""
+    from moleculesde_amd import hip
+    torch.manual_seed(M + C)
+    x = (torch.randn(M, C) * 2 + 0.5).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.3); bn.bias.normal_(0, 0.3)
+    if M == 1:
+        pytest.skip("torch refuses a single row in training mode")
+    y = bn(x)
+    y = torch.relu(y) if relu else y
+    w = torch.randn(M, C)
+    (y * w).sum().backward()
+    xd = x.detach().to(dev).requires_grad_(True)
+    gd = bn.weight.detach().clone().to(dev).requires_grad_(True)
+    bd = bn.bias.detach().clone().to(dev).requires_grad_(True)
+    rm = torch.zeros(C, device=dev); rv = torch.ones(C, device=dev)
+    yd = hip.batch_norm_train(xd, gd, bd, rm, rv, 1e-5, 0.1, relu)
+    assert_close(yd, y.detach(), 1e-4, 1e-5, "bn fwd")
+    (yd * w.to(dev)).sum().backward()
+    assert_close(xd.grad, x.grad, 1e-3, 1e-5 * float(x.grad.abs().max()) + 1e-6, "bn dx")
+    assert_close(gd.grad, bn.weight.grad, 1e-4, 1e-4 * float(bn.weight.grad.abs().max()) + 1e-6, "bn dgamma")
+    assert_close(bd.grad, bn.bias.grad, 1e-4, 1e-4 * float(bn.bias.grad.abs().max()) + 1e-6, "bn dbeta")
+    assert_close(rm, bn.running_mean, 1e-5, 1e-6, "running mean")
+    assert_close(rv, bn.running_var, 1e-4, 1e-6, "running var")
