@@ -94,17 +94,28 @@ int msde_cfconv_aggregate_fwd(const float* x1, const float* Wf, const float* C, 
 int msde_cfconv_aggregate_bwd_w(const float* g_agg, const float* x1, const float* C,
                                 const int* rowptr, const int* src, int N, int F, int E_cap,
                                 float* g_Wf, void* stream);
-/* g_x1[j] = sum_{e in out(j)} g_agg[dst[e]] * Wf[e] * C[e] */
+/* g_x1[j] = sum_{e in out(j)} g_agg[dst[e]] * Wf[e] * C[e]   (C may be NULL: Wf already holds Wf*C) */
 int msde_cfconv_aggregate_bwd_x(const float* g_agg, const float* Wf, const float* C,
                                 const int* rowptr_s, const int* perm_s, const int* dst, int N,
                                 int F, float* g_x1, void* stream);
-/* Fused CFConv forward (inference / no-grad and the roofline kernel): RBF + filter MLP
- * (Linear(G,F) -> ShiftedSoftplus -> Linear(F,F)) + cutoff + gather + segmented sum, fp32 MFMA.
- * schnet.py:141-145,185-195.  F must be 128, G <= 64.  W1 [F,G], b1 [F], W2 [F,F], b2 [F]. */
+/* Fused CFConv forward: RBF + filter MLP (Linear(G,F) -> ShiftedSoftplus -> Linear(F,F)) + cutoff +
+ * gather + segmented sum in one fp32-MFMA kernel — schnet.py:141-145,185-195.  F must be 128, G <= 64.
+ * W1 [F,G], b1 [F], W2 [F,F], b2 [F].  E_cap bounds the edge count (true count = rowptr[N]).
+ * Wf_out (may be NULL) receives the filter rows (W2 h1 + b2) * C(d) [E_cap,F] for the backward. */
 int msde_cfconv_fused_fwd(const float* x1, const float* dist, const int* rowptr, const int* src,
                           const int* dst, const float* W1, const float* b1, const float* W2,
-                          const float* b2, const float* offset, int N, int F, int G, float coeff,
-                          float cutoff, int nodes_per_wg, float* agg, void* stream);
+                          const float* b2, const float* offset, int N, int F, int G, int E_cap,
+                          float coeff, float cutoff, int chunks_per_wg, float* agg, float* Wf_out,
+                          void* stream);
+/* Weight gradients of the filter network for the fused CFConv, recomputing rbf/h1 on chip:
+ * gW1 [F,G], gb1 [F], gW2 [F,F], gb2 [F] from g_agg [N,F], x1 [N,F], dist.  Per-workgroup slabs in
+ * `workspace` (msde_cfconv_fused_bwd_w_workspace_floats floats) are summed in a fixed order. */
+long long msde_cfconv_fused_bwd_w_workspace_floats(int E_cap, int G);
+int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, const float* dist,
+                            const int* rowptr, const int* src, const int* dst, const float* W1,
+                            const float* b1, const float* W2, const float* offset, int N, int F,
+                            int G, int E_cap, float coeff, float cutoff, float* gW1, float* gb1,
+                            float* gW2, float* gb2, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------ 2D->3D score net ------- */
 /* coord2basis / get_perturb_distance / GaussianFourierProjection / pseudo-angle —

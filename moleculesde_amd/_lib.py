@@ -32,7 +32,9 @@ SIGNATURES = {
     "msde_cfconv_aggregate_fwd": [P, P, P, P, P, I, I, P, P],
     "msde_cfconv_aggregate_bwd_w": [P, P, P, P, P, I, I, I, P, P],
     "msde_cfconv_aggregate_bwd_x": [P, P, P, P, P, P, I, I, P, P],
-    "msde_cfconv_fused_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, I, P, P],
+    "msde_cfconv_fused_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P, P],
+    "msde_cfconv_fused_bwd_w_workspace_floats": [I, I],
+    "msde_cfconv_fused_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, P, P, P],
     "msde_edge_geometry_fwd": [P, P, P, I, P, P, I, P, P, P, P, P, P],
     "msde_edge_attention_fwd": [P, P, P, P, P, P, I, I, I, F, ULL, P, P, P, P],
     "msde_edge_attention_bwd": [P, P, P, P, P, P, P, P, I, I, I, F, ULL, P, P, P, P, P, P],
@@ -47,7 +49,8 @@ SIGNATURES = {
     "msde_bn_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P],
     "msde_adam_flat": [P, P, P, P, LL, P, P, P, I, F, F, F, F, F, P],
 }
-_RESTYPE = {"msde_target_arch": ctypes.c_char_p, "msde_linear_bwd_w_workspace_bytes": ctypes.c_longlong}
+_RESTYPE = {"msde_target_arch": ctypes.c_char_p, "msde_linear_bwd_w_workspace_bytes": ctypes.c_longlong,
+            "msde_cfconv_fused_bwd_w_workspace_floats": ctypes.c_longlong}
 
 _lib = None
 

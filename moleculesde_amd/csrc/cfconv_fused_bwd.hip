@@ -1,0 +1,289 @@
+// cfconv_fused_bwd.hip — weight gradients of the CFConv filter network in ONE kernel (gfx950).
+//
+// For every radius edge e = (j -> i), with rbf = smearing(d_e), pre1 = W1 rbf + b1, h1 = ssp(pre1),
+// filter = (W2 h1 + b2) * C(d_e) and agg_i = sum_e x1_j * filter (schnet.py:141-145,185-195):
+//     g_pre2[e] = g_agg[i] * x1[j] * C(d_e)                      (needs NO recomputation of W2 h1)
+//     g_W2     += g_pre2[e] (x) h1[e]        g_b2 += g_pre2[e]
+//     g_h1[e]   = W2^T g_pre2[e]             g_pre1[e] = g_h1[e] * sigmoid(pre1[e])
+//     g_W1     += g_pre1[e] (x) rbf[e]       g_b1 += g_pre1[e]
+// The [E,128] intermediates never exist in HBM: each persistent workgroup (one per CU, 4 waves) walks
+// its share of 64-edge chunks, recomputes rbf / h1 with fp32 MFMA, and keeps its partial g_W2 (128x128),
+// g_W1 (128xG) and bias sums in MFMA accumulators; partial slabs are then summed over workgroups in a
+// fixed order by a second kernel (bitwise reproducible, no float atomics).
+//
+// MFMA operand tricks (v_mfma_f32_32x32x2_f32; C/D map: col = lane&31, row = (r&3)+8(r>>2)+4(lane>>5)):
+//   * a tile held in accumulator layout (column on the lane, 16 rows in registers) is used directly as
+//     the A operand of a product that sums over its ROW index (edges): k-step s takes register s, and
+//     the B operand is read from LDS at the SAME permuted edge row -> no LDS round trip for g_pre2/g_pre1;
+//   * W2 sits once in LDS as [128][129]: the odd stride makes both its row-per-lane (W2 h1) and
+//     column-per-lane (W2^T g) operand reads bank-conflict free.
+#include "msde_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CB_F 128
+#define CB_TE 64
+#define CB_HS 129
+
+__device__ __forceinline__ int cb_row(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+template <int KK1>
+__global__ void __launch_bounds__(256, 1)
+cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
+                          const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ dst,
+                          const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                          const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
+                          float* __restrict__ slabs) {
+  constexpr int RS = 2 * KK1 + 1;
+  extern __shared__ float lds[];
+  float* W2s = lds;                            // [128][129]
+  float* rbf_t = W2s + CB_F * CB_HS;           // [64][RS]  (+ slack: reads up to column 63 of the last row)
+  float* hid_t = rbf_t + CB_TE * RS + 64;      // [64][129] h1
+  float* gp_t = hid_t + CB_TE * CB_HS;         // [64][129] g_pre2
+  float* c_s = gp_t + CB_TE * CB_HS;           // [64]
+  float* d_s = c_s + CB_TE;                    // [64]
+  int* src_s = reinterpret_cast<int*>(d_s + CB_TE);
+  int* dst_s = src_s + CB_TE;
+
+  const float PI_F = 3.14159265358979323846f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 31, lhalf = lane >> 5;
+  const int col = wave * 32 + lcol;
+
+  const int E = rowptr[N];
+  const int e_begin = min(blockIdx.x * cpw * CB_TE, E);
+  const int e_end = min(e_begin + cpw * CB_TE, E);
+
+  // W2 -> LDS (coalesced), W1 slice -> registers
+  for (int t = tid; t < CB_F * CB_F; t += 256) W2s[(t >> 7) * CB_HS + (t & 127)] = W2[t];
+  float w1r[KK1];
+#pragma unroll
+  for (int kk = 0; kk < KK1; ++kk) {
+    int g = 2 * kk + lhalf;
+    w1r[kk] = g < G ? W1[(size_t)col * G + g] : 0.f;
+  }
+  const float b1c = b1[col];
+
+  f32x16 aW2[4], aW1[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW2[j][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW1[j][r] = 0.f;
+  float sb1 = 0.f, sb2 = 0.f;
+
+  for (int ec = e_begin; ec < e_end; ec += CB_TE) {
+    __syncthreads();
+    if (tid < CB_TE) {
+      int e = ec + tid;
+      bool ok = e < e_end;
+      float d = ok ? dist[e] : 0.f;
+      d_s[tid] = d;
+      c_s[tid] = ok ? 0.5f * (cosf(d * PI_F / cutoff) + 1.0f) : 0.f;
+      src_s[tid] = ok ? src[e] : -1;
+      dst_s[tid] = ok ? dst[e] : -1;
+    }
+    __syncthreads();
+    // g_pre2 in accumulator layout straight from the gathers: gp[rb][s] = g_agg[dst] * x1[src] * C
+    float gp0[16], gp1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int row = cb_row(s, lhalf);
+      int s0 = src_s[row], s1 = src_s[32 + row], t0 = dst_s[row], t1 = dst_s[32 + row];
+      float xa = x1[(size_t)(s0 >= 0 ? s0 : 0) * CB_F + col], ga = g_agg[(size_t)(t0 >= 0 ? t0 : 0) * CB_F + col];
+      float xb = x1[(size_t)(s1 >= 0 ? s1 : 0) * CB_F + col], gb = g_agg[(size_t)(t1 >= 0 ? t1 : 0) * CB_F + col];
+      gp0[s] = ga * xa * c_s[row];          // padding rows: c_s = 0
+      gp1[s] = gb * xb * c_s[32 + row];
+    }
+    // rbf tile
+    for (int idx = tid; idx < CB_TE * 2 * KK1; idx += 256) {
+      int r = idx / (2 * KK1), g = idx % (2 * KK1);
+      float v = 0.f;
+      if (ec + r < e_end && g < G) {
+        float diff = d_s[r] - offset[g];
+        v = __expf(coeff * (diff * diff));
+      }
+      rbf_t[r * RS + g] = v;
+    }
+    __syncthreads();
+
+    // ---- recompute pre1 = rbf W1^T (+ b1): h1 -> LDS, sigmoid(pre1) stays in registers
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < KK1; ++kk) {
+      float a0 = rbf_t[lcol * RS + 2 * kk + lhalf];
+      float a1 = rbf_t[(32 + lcol) * RS + 2 * kk + lhalf];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w1r[kk], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1r[kk], acc1, 0, 0, 0);
+    }
+    float sg0[16], sg1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int row = cb_row(i, lhalf);
+      float p0 = acc0[i] + b1c, p1 = acc1[i] + b1c;
+      float e0 = __expf(-fabsf(p0)), e1 = __expf(-fabsf(p1));
+      hid_t[row * CB_HS + col] = fmaxf(p0, 0.f) + __logf(1.f + e0) - 0.69314718246459961f;
+      hid_t[(32 + row) * CB_HS + col] = fmaxf(p1, 0.f) + __logf(1.f + e1) - 0.69314718246459961f;
+      float r0 = 1.f / (1.f + e0), r1 = 1.f / (1.f + e1);
+      sg0[i] = p0 >= 0.f ? r0 : e0 * r0;       // sigmoid = d softplus / dx
+      sg1[i] = p1 >= 0.f ? r1 : e1 * r1;
+      gp_t[row * CB_HS + col] = gp0[i];        // g_pre2 tile for the W2^T product (row-per-lane reads)
+      gp_t[(32 + row) * CB_HS + col] = gp1[i];
+      sb2 += gp0[i] + gp1[i];
+    }
+    __syncthreads();
+
+    // ---- g_W2[f][k] += sum_e g_pre2[e][f] h1[e][k]: A = g_pre2 registers, B = h1 rows (same permuted e)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int row = cb_row(s, lhalf);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float bA = hid_t[row * CB_HS + 32 * j + lcol];
+        float bB = hid_t[(32 + row) * CB_HS + 32 * j + lcol];
+        aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp0[s], bA, aW2[j], 0, 0, 0);
+        aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp1[s], bB, aW2[j], 0, 0, 0);
+      }
+    }
+
+    // ---- g_h1[e][k] = sum_f g_pre2[e][f] W2[f][k]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < CB_F / 2; ++kk) {
+      float a0 = gp_t[lcol * CB_HS + 2 * kk + lhalf];
+      float a1 = gp_t[(32 + lcol) * CB_HS + 2 * kk + lhalf];
+      float b = W2s[(2 * kk + lhalf) * CB_HS + col];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+    }
+    // g_pre1 = g_h1 * sigmoid(pre1)  (same lanes / registers as pre1)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sg0[i] *= acc0[i];
+      sg1[i] *= acc1[i];
+      sb1 += sg0[i] + sg1[i];
+    }
+    // ---- g_W1[k][g] += sum_e g_pre1[e][k] rbf[e][g]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int row = cb_row(s, lhalf);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float bA = rbf_t[row * RS + 32 * j + lcol];            // g >= 2*KK1 reads slack: columns discarded
+        float bB = rbf_t[(32 + row) * RS + 32 * j + lcol];
+        aW1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sg0[s], bA, aW1[j], 0, 0, 0);
+        aW1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sg1[s], bB, aW1[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- write this workgroup's slab: [128*128 gW2][128*G gW1][128 gb1][128 gb2]
+  const size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
+  float* slab = slabs + (size_t)blockIdx.x * slab_sz;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int f = wave * 32 + cb_row(r, lhalf);
+      slab[(size_t)f * CB_F + 32 * j + lcol] = aW2[j][r];
+    }
+  float* sW1 = slab + (size_t)CB_F * CB_F;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int k = wave * 32 + cb_row(r, lhalf);
+      int g = 32 * j + lcol;
+      if (g < G) sW1[(size_t)k * G + g] = aW1[j][r];
+    }
+  // bias sums: combine the two lane halves (rows) of each column
+  sb1 += __shfl_xor(sb1, 32, 64);
+  sb2 += __shfl_xor(sb2, 32, 64);
+  if (lhalf == 0) {
+    slab[(size_t)CB_F * CB_F + (size_t)CB_F * G + col] = sb1;
+    slab[(size_t)CB_F * CB_F + (size_t)CB_F * G + CB_F + col] = sb2;
+  }
+}
+
+__global__ void cfconv_reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_sz, int G,
+                                           float* __restrict__ gW2, float* __restrict__ gW1, float* __restrict__ gb1,
+                                           float* __restrict__ gb2) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slab_sz; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    int z = 0;
+    for (; z + 4 <= nslab; z += 4) {
+      float a0 = slabs[(size_t)z * slab_sz + i], a1 = slabs[(size_t)(z + 1) * slab_sz + i];
+      float a2 = slabs[(size_t)(z + 2) * slab_sz + i], a3 = slabs[(size_t)(z + 3) * slab_sz + i];
+      acc = (((acc + a0) + a1) + a2) + a3;
+    }
+    for (; z < nslab; ++z) acc += slabs[(size_t)z * slab_sz + i];
+    size_t n2 = (size_t)CB_F * CB_F, n1 = (size_t)CB_F * G;
+    if (i < n2) gW2[i] = acc;
+    else if (i < n2 + n1) gW1[i - n2] = acc;
+    else if (i < n2 + n1 + CB_F) gb1[i - n2 - n1] = acc;
+    else gb2[i - n2 - n1 - CB_F] = acc;
+  }
+}
+
+static inline void cb_geometry(int E_cap, int* nwg, int* cpw) {
+  int chunks = (E_cap + CB_TE - 1) / CB_TE;
+  int w = chunks < 256 ? chunks : 256;     // one persistent workgroup per CU
+  if (w < 1) w = 1;
+  *cpw = (chunks + w - 1) / w;
+  if (*cpw < 1) *cpw = 1;
+  *nwg = (chunks + *cpw - 1) / *cpw;
+  if (*nwg < 1) *nwg = 1;
+}
+
+extern "C" long long msde_cfconv_fused_bwd_w_workspace_floats(int E_cap, int G) {
+  int nwg, cpw;
+  cb_geometry(E_cap, &nwg, &cpw);
+  return (long long)nwg * ((long long)CB_F * CB_F + (long long)CB_F * G + 2 * CB_F);
+}
+
+extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, const float* dist, const int* rowptr,
+                                       const int* src, const int* dst, const float* W1, const float* b1,
+                                       const float* W2, const float* offset, int N, int F, int G, int E_cap,
+                                       float coeff, float cutoff, float* gW1, float* gb1, float* gW2, float* gb2,
+                                       float* workspace, void* stream) {
+  if (N < 0 || E_cap < 0 || !g_agg || !x1 || !dist || !rowptr || !src || !dst || !W1 || !b1 || !W2 || !offset || !gW1 ||
+      !gb1 || !gW2 || !gb2 || !workspace)
+    return MSDE_EINVAL;
+  if (F != CB_F || G <= 0 || G > 64) return MSDE_EUNSUP;
+  hipStream_t st = as_stream(stream);
+  int nwg, cpw;
+  cb_geometry(E_cap, &nwg, &cpw);
+  int kk1 = (G + 1) / 2;
+  auto lds_bytes = [](int KK1) {
+    return (size_t)(CB_F * CB_HS + CB_TE * (2 * KK1 + 1) + 64 + 2 * CB_TE * CB_HS + 4 * CB_TE) * sizeof(float);
+  };
+#define CB_LAUNCH(KK)                                                                                                 \
+  {                                                                                                                   \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_bwd_w_kernel<KK>),              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(KK));            \
+      if (ae != hipSuccess) return (int)ae;                                                                           \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+  }                                                                                                                   \
+  MSDE_LAUNCH(cfconv_fused_bwd_w_kernel<KK>, dim3(nwg), dim3(256), lds_bytes(KK), st, g_agg, x1, dist, rowptr, src, dst, \
+              W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
+  if (kk1 == 26) { CB_LAUNCH(26); }
+  else if (kk1 == 25) { CB_LAUNCH(25); }
+  else { CB_LAUNCH(32); }
+#undef CB_LAUNCH
+  MSDE_CHECK_LAUNCH();
+  size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
+  int blocks = (int)((slab_sz + 255) / 256);
+  MSDE_LAUNCH(cfconv_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, nwg, slab_sz, G, gW2,
+              gW1, gb1, gb2);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

@@ -107,7 +107,7 @@ __global__ void cfconv_aggregate_bwd_x_kernel(const float* __restrict__ g_agg, c
     T acc = vzero<V>();
     for (int s = s0; s < s1; ++s) {
       int e = perm_s[s];
-      T w = vscale(W[(size_t)e * cols + c], C[e]);
+      T w = C ? vscale(W[(size_t)e * cols + c], C[e]) : W[(size_t)e * cols + c];
       acc = vadd(acc, vmul(G[(size_t)dst[e] * cols + c], w));
     }
     O[(size_t)j * cols + c] = acc;
@@ -135,7 +135,7 @@ extern "C" int msde_cfconv_aggregate_bwd_w(const float* g_agg, const float* x1, 
 extern "C" int msde_cfconv_aggregate_bwd_x(const float* g_agg, const float* Wf, const float* C, const int* rowptr_s,
                                            const int* perm_s, const int* dst, int N, int F, float* g_x1,
                                            void* stream) {
-  if (N < 0 || F <= 0 || !g_agg || !Wf || !C || !rowptr_s || !perm_s || !dst || !g_x1) return MSDE_EINVAL;
+  if (N < 0 || F <= 0 || !g_agg || !Wf || !rowptr_s || !perm_s || !dst || !g_x1) return MSDE_EINVAL;
   if (N == 0) return 0;
   LAUNCH_ROWS(cfconv_aggregate_bwd_x_kernel, N, F, g_agg, Wf, C, rowptr_s, perm_s, dst, N, cols, tpr, g_x1);
   MSDE_CHECK_LAUNCH();

@@ -85,7 +85,7 @@ class SchNet(nn.Module):
         self.lin1.bias.data.fill_(0)
         nn.init.xavier_uniform_(self.lin2.weight)
         self.lin2.bias.data.fill_(0)
-        self.fused_nodes_per_wg = 16
+        self.use_fused = True      # False: decomposed path (rbf kernel + library GEMMs + aggregate kernels)
 
     def _find_plan(self, z, batch):
         pl = _nn.lookup_plan(batch) if batch is not None else None
@@ -106,16 +106,19 @@ class SchNet(nn.Module):
 
         rplan, dist = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors)
         de = self.distance_expansion
-        fused = (not torch.is_grad_enabled()) and self.num_filters == 128 and self.num_gaussians <= 64
-        if not fused:
+        fusable = self.use_fused and self.num_filters == 128 and self.num_gaussians <= 64
+        grad = torch.is_grad_enabled()
+        if not fusable:
             rbf, C = hip.rbf_cutoff(dist, rplan.E_dev, de.offset, de.coeff, self.cutoff)
 
         for blk in self.interactions:
             x1 = _nn.linear(h, blk.conv.lin1.weight)
-            if fused:
+            if fusable and grad:
+                agg = hip.cfconv_fused(x1, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias,
+                                       dist, rplan, de.offset, de.coeff, self.cutoff)
+            elif fusable:
                 agg = hip.cfconv_fused_forward(x1, dist, rplan, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
-                                               blk.mlp[2].bias, de.offset, de.coeff, self.cutoff,
-                                               self.fused_nodes_per_wg)
+                                               blk.mlp[2].bias, de.offset, de.coeff, self.cutoff)
             else:
                 Wf = blk.mlp(rbf)
                 agg = hip.cfconv_aggregate(x1, Wf, C, rplan)

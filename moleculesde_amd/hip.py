@@ -140,16 +140,77 @@ def rbf_cutoff(dist, E_dev, offset, coeff, cutoff):
     return rbf, C
 
 
-def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, nodes_per_wg=16):
-    """Fused CFConv forward (no autograd): see csrc/cfconv_fused.hip."""
+FUSED_CHUNKS_PER_WG = 1
+
+
+def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, chunks_per_wg=None, want_filter=False):
+    """Fused CFConv forward (no autograd): see csrc/cfconv_fused.hip.  Returns agg (and the filter rows
+    Wf = (W2 h1 + b2) * C when want_filter)."""
     x1 = _f32(x1)
     N, Fd = x1.shape
     G = W1.size(1)
     agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
+    Wf = torch.empty(plan.E, Fd, dtype=torch.float32, device=x1.device) if want_filter else None
+    cpw = FUSED_CHUNKS_PER_WG if chunks_per_wg is None else chunks_per_wg
     _lib.call("msde_cfconv_fused_fwd", _p(x1), _p(_f32(dist)), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
-              _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)), _p(_f32(offset)), N, Fd, G,
-              float(coeff), float(cutoff), int(nodes_per_wg), _p(agg), _stream())
-    return agg
+              _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)), _p(_f32(offset)), N, Fd, G, plan.E,
+              float(coeff), float(cutoff), int(cpw), _p(agg), _p(Wf), _stream())
+    return (agg, Wf) if want_filter else agg
+
+
+_CF_WS = {}
+
+
+def _cf_workspace(E_cap, G, device):
+    n = int(_lib.load().msde_cfconv_fused_bwd_w_workspace_floats(E_cap, G))
+    ws = _CF_WS.get(device)
+    if ws is None or ws.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.MsdeHipError("fused CFConv workspace must be sized by an eager warm-up step before graph capture")
+        ws = torch.empty(n, dtype=torch.float32, device=device)
+        _CF_WS[device] = ws
+    return ws
+
+
+class _CFConvFused(torch.autograd.Function):
+    """Whole CFConv (smearing, filter MLP, cutoff, gather, segmented sum) as one forward kernel; the
+    backward is two kernels (+ one slab reduce): g_x1 by a by-source gather over the saved filter rows,
+    and all four filter-network weight gradients by the recomputing MFMA kernel of cfconv_fused_bwd.hip."""
+
+    @staticmethod
+    def forward(ctx, x1, W1, b1, W2, b2, dist, plan, offset, coeff, cutoff):
+        x1, W1, b1, W2, b2 = _f32(x1), _f32(W1), _f32(b1), _f32(W2), _f32(b2)
+        agg, Wf = cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, want_filter=True)
+        ctx.save_for_backward(x1, W1, b1, W2, Wf, dist, offset)
+        ctx.plan, ctx.coeff, ctx.cutoff = plan, float(coeff), float(cutoff)
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, W1, b1, W2, Wf, dist, offset = ctx.saved_tensors
+        plan = ctx.plan
+        g = _f32(g)
+        N, Fd = x1.shape
+        G = W1.size(1)
+        st = _stream()
+        g_x1 = None
+        if ctx.needs_input_grad[0]:
+            g_x1 = torch.empty_like(x1)
+            _lib.call("msde_cfconv_aggregate_bwd_x", _p(g), _p(Wf), _p(None), _p(plan.rowptr_s), _p(plan.perm_s),
+                      _p(plan.dst), N, Fd, _p(g_x1), st)
+        gW1 = torch.empty_like(W1)
+        gb1 = torch.empty_like(b1)
+        gW2 = torch.empty_like(W2)
+        gb2 = torch.empty_like(b1)
+        ws = _cf_workspace(plan.E, G, x1.device)
+        _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
+                  _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, _p(gW1), _p(gb1),
+                  _p(gW2), _p(gb2), _p(ws), st)
+        return g_x1, gW1, gb1, gW2, gb2, None, None, None, None, None
+
+
+def cfconv_fused(x1, W1, b1, W2, b2, dist, plan, offset, coeff, cutoff):
+    return _CFConvFused.apply(x1, W1, b1, W2, b2, dist, plan, offset, coeff, cutoff)
 
 
 def edge_geometry(pos, plan, Wd, Wc):

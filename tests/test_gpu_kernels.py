@@ -218,9 +218,10 @@ def test_cfconv_aggregate(dev, Fd):
     assert_close(Wfd.grad, Wf.grad, 1e-5, 1e-5, "cfconv g_Wf (padded rows zero)")
 
 
-@pytest.mark.parametrize("G,npw", [(51, 16), (50, 7), (20, 32)])
-def test_cfconv_fused_forward(dev, G, npw):
-    """Fused fp32-MFMA CFConv vs the oracle's CFConv interior (schnet.py:185-195)."""
+@pytest.mark.parametrize("G,cpw", [(51, 1), (50, 3), (20, 2)])
+def test_cfconv_fused_forward_and_backward(dev, G, cpw):
+    """Fused fp32-MFMA CFConv (forward, filter rows, g_x1, and the four filter-network weight gradients
+    recomputed on chip) vs autograd through the oracle's CFConv interior (schnet.py:141-145,185-195)."""
     from moleculesde_amd import hip
     torch.manual_seed(4)
     b, pl, rp, dist, E, ei = _radius_setup(dev, B=40, seed=9)
@@ -230,16 +231,32 @@ def test_cfconv_fused_forward(dev, G, npw):
         blk.mlp[0].bias.normal_(0, 0.1)
         blk.mlp[2].bias.normal_(0, 0.1)
     gs = R.GaussianSmearing(0.0, 10.0, G)
-    x1 = torch.randn(N, 128)
+    x1 = torch.randn(N, 128, requires_grad=True)
     d = dist[:E].cpu()
     Cc = 0.5 * (torch.cos(d * math.pi / 10.0) + 1.0)
-    with torch.no_grad():
-        Wf = blk.mlp(gs(d)) * Cc.view(-1, 1)
-        ref = R.scatter_sum(x1[ei[0]] * Wf, ei[1], N)
-    out = hip.cfconv_fused_forward(x1.to(dev), dist, rp, blk.mlp[0].weight.detach().to(dev),
-                                   blk.mlp[0].bias.detach().to(dev), blk.mlp[2].weight.detach().to(dev),
-                                   blk.mlp[2].bias.detach().to(dev), gs.offset.to(dev), gs.coeff, 10.0, npw)
-    assert_close(out, ref, 1e-4, 1e-4 * float(ref.abs().max()), "fused cfconv")
+    Wf_ref = blk.mlp(gs(d)) * Cc.view(-1, 1)
+    ref = R.scatter_sum(x1[ei[0]] * Wf_ref, ei[1], N)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    ps = [blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias]
+    pd = [p.detach().to(dev).requires_grad_(True) for p in ps]
+    x1d = x1.detach().to(dev).requires_grad_(True)
+    old = hip.FUSED_CHUNKS_PER_WG
+    hip.FUSED_CHUNKS_PER_WG = cpw
+    try:
+        out = hip.cfconv_fused(x1d, pd[0], pd[1], pd[2], pd[3], dist, rp, gs.offset.to(dev), gs.coeff, 10.0)
+        out2, Wf = hip.cfconv_fused_forward(x1d.detach(), dist, rp, pd[0].detach(), pd[1].detach(), pd[2].detach(),
+                                            pd[3].detach(), gs.offset.to(dev), gs.coeff, 10.0, want_filter=True)
+    finally:
+        hip.FUSED_CHUNKS_PER_WG = old
+    scale = float(ref.abs().max())
+    assert_close(out, ref.detach(), 1e-4, 1e-4 * scale, "fused cfconv fwd")
+    assert torch.equal(out, out2)                                     # bitwise reproducible (2-addend atomics)
+    assert_close(Wf[:E], Wf_ref.detach(), 1e-4, 1e-5, "filter rows")
+    (out * w.to(dev)).sum().backward()
+    assert_close(x1d.grad, x1.grad, 1e-4, 1e-4 * float(x1.grad.abs().max()), "fused g_x1")
+    for name, a, r in zip(("gW1", "gb1", "gW2", "gb2"), pd, ps):
+        assert_close(a.grad, r.grad, 1e-3, 2e-4 * float(r.grad.abs().max()), f"fused {name}")
 
 
 def test_edge_geometry(dev):
