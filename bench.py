@@ -86,7 +86,7 @@ def roofline_fused(trainer, batch, iters=50):
         x1 = torch.randn(N, 128, device=batch.x.device)
         stream = torch.cuda.current_stream()
         fn = lambda: hip.cfconv_fused_forward(x1, dist, rplan, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
-                                              blk.mlp[2].bias, de.offset, de.coeff, sch.cutoff, sch.fused_nodes_per_wg)
+                                              blk.mlp[2].bias, de.offset, de.coeff, sch.cutoff)
         ms = _event_time_ms(fn, iters, stream)
     G = sch.num_gaussians
     flops = E * 2.0 * (G * 128 + 128 * 128)

@@ -37,8 +37,8 @@ __device__ __forceinline__ float ssp_fast(float x) {
 template <int KK1>
 __global__ void __launch_bounds__(256, 2)
 cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ dist, const int* __restrict__ rowptr,
-                        const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ W1,
-                        const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                        const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ W1T,
+                        const float* __restrict__ b1, const float* __restrict__ W2T, const float* __restrict__ b2,
                         const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
                         float* __restrict__ agg, float* __restrict__ Wf_out) {
   constexpr int RS = 2 * KK1 + 1;  // rbf tile row stride (odd)
@@ -49,6 +49,7 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
   float* d_s = c_s + CF_TE;                    // [64] distance per edge row
   int* src_s = reinterpret_cast<int*>(d_s + CF_TE);  // [64]
   int* dst_s = src_s + CF_TE;                  // [64] target node, -1 for padding rows
+  float* off_s = reinterpret_cast<float*>(dst_s + CF_TE);  // [64] Gaussian centres
 
   const float PI_F = 3.14159265358979323846f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,16 +61,27 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
   if (e_begin >= E) return;
   const int e_end = min(e_begin + cpw * CF_TE, E);
 
-  // weights -> registers (B operands).  torch Linear weight is [out, in].
+  // weights -> registers (B operands), from the TRANSPOSED copies ([in][out]) so that each half-wave
+  // reads 128 contiguous bytes per k (the [out][in] layout costs 64 cache lines per load instruction)
   float w1r[KK1], w2r[CF_F / 2];
 #pragma unroll
   for (int kk = 0; kk < KK1; ++kk) {
     int g = 2 * kk + lhalf;
-    w1r[kk] = g < G ? W1[(size_t)col * G + g] : 0.f;
+    w1r[kk] = g < G ? W1T[(size_t)g * CF_F + col] : 0.f;
   }
 #pragma unroll
-  for (int kk = 0; kk < CF_F / 2; ++kk) w2r[kk] = W2[(size_t)col * CF_F + 2 * kk + lhalf];
+  for (int kk = 0; kk < CF_F / 2; ++kk) w2r[kk] = W2T[(size_t)(2 * kk + lhalf) * CF_F + col];
   const float b1c = b1[col], b2c = b2[col];
+  if (tid < 64) off_s[tid] = tid < G ? offset[tid] : 0.f;
+
+  // per-edge metadata of the first chunk; later chunks are prefetched one chunk ahead (registers of
+  // the first wave) so their global-load latency hides under the MFMAs
+  float m_d = 0.f;
+  int m_s = -1, m_t = -1;
+  if (tid < CF_TE) {
+    int e = e_begin + tid;
+    if (e < e_end) { m_d = dist[e]; m_s = src[e]; m_t = dst[e]; }
+  }
 
   // running segmented sum of this thread: column rc, targets of parity rpar
   const int rc = tid & 127, rpar = tid >> 7;
@@ -86,13 +98,14 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
   for (int ec = e_begin; ec < e_end; ec += CF_TE) {
     __syncthreads();  // previous chunk's reduction is done with hid_t / meta
     if (tid < CF_TE) {
-      int e = ec + tid;
-      bool ok = e < e_end;
-      float d = ok ? dist[e] : 0.f;
-      d_s[tid] = d;
-      c_s[tid] = ok ? 0.5f * (cosf(d * PI_F / cutoff) + 1.0f) : 0.f;
-      src_s[tid] = ok ? src[e] : -1;
-      dst_s[tid] = ok ? dst[e] : -1;
+      bool ok = ec + tid < e_end;
+      d_s[tid] = m_d;
+      c_s[tid] = ok ? 0.5f * (cosf(m_d * PI_F / cutoff) + 1.0f) : 0.f;
+      src_s[tid] = m_s;
+      dst_s[tid] = m_t;
+      int en = ec + CF_TE + tid;             // prefetch the next chunk's metadata
+      m_d = 0.f; m_s = -1; m_t = -1;
+      if (en < e_end) { m_d = dist[en]; m_s = src[en]; m_t = dst[en]; }
     }
     __syncthreads();
     // gathered x1 rows for the epilogue: request now, consume after the GEMMs
@@ -109,7 +122,7 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
       int r = idx / (2 * KK1), g = idx % (2 * KK1);
       float v = 0.f;
       if (ec + r < e_end && g < G) {
-        float diff = d_s[r] - offset[g];
+        float diff = d_s[r] - off_s[g];
         v = __expf(coeff * (diff * diff));
       }
       rbf_t[r * RS + g] = v;
@@ -180,11 +193,11 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
 }
 
 extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const int* rowptr, const int* src,
-                                     const int* dst, const float* W1, const float* b1, const float* W2,
+                                     const int* dst, const float* W1T, const float* b1, const float* W2T,
                                      const float* b2, const float* offset, int N, int F, int G, int E_cap,
                                      float coeff, float cutoff, int chunks_per_wg, float* agg, float* Wf_out,
                                      void* stream) {
-  if (N < 0 || E_cap < 0 || !x1 || !dist || !rowptr || !src || !dst || !W1 || !b1 || !W2 || !b2 || !offset || !agg)
+  if (N < 0 || E_cap < 0 || !x1 || !dist || !rowptr || !src || !dst || !W1T || !b1 || !W2T || !b2 || !offset || !agg)
     return MSDE_EINVAL;
   if (F != CF_F || G <= 0 || G > 64) return MSDE_EUNSUP;
   if (chunks_per_wg <= 0) chunks_per_wg = 1;
@@ -197,7 +210,7 @@ extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const i
   int chunks = (E_cap + CF_TE - 1) / CF_TE;
   int grid = (chunks + chunks_per_wg - 1) / chunks_per_wg;
   auto lds_bytes = [](int KK1) {
-    return (size_t)(CF_TE * (2 * KK1 + 1) + CF_TE * CF_HS + 4 * CF_TE) * sizeof(float);
+    return (size_t)(CF_TE * (2 * KK1 + 1) + CF_TE * CF_HS + 5 * CF_TE) * sizeof(float);
   };
 #define CF_LAUNCH(KK)                                                                                              \
   {                                                                                                                \
@@ -209,8 +222,8 @@ extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const i
       attr_done = true;                                                                                            \
     }                                                                                                              \
   }                                                                                                                \
-  MSDE_LAUNCH(cfconv_fused_fwd_kernel<KK>, dim3(grid), dim3(256), lds_bytes(KK), st, x1, dist, rowptr, src, dst, W1, \
-              b1, W2, b2, offset, N, G, coeff, cutoff, chunks_per_wg, agg, Wf_out)
+  MSDE_LAUNCH(cfconv_fused_fwd_kernel<KK>, dim3(grid), dim3(256), lds_bytes(KK), st, x1, dist, rowptr, src, dst, W1T, \
+              b1, W2T, b2, offset, N, G, coeff, cutoff, chunks_per_wg, agg, Wf_out)
   if (kk1 == 26) { CF_LAUNCH(26); }
   else if (kk1 == 25) { CF_LAUNCH(25); }
   else { CF_LAUNCH(32); }

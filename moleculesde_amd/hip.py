@@ -140,7 +140,7 @@ def rbf_cutoff(dist, E_dev, offset, coeff, cutoff):
     return rbf, C
 
 
-FUSED_CHUNKS_PER_WG = 1
+FUSED_CHUNKS_PER_WG = 1   # measured on MI355X (tools/tune_fused.py): 1 -> 54 us, 2 -> 56, 3 -> 59, 6 -> 106
 
 
 def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, chunks_per_wg=None, want_filter=False):
@@ -152,8 +152,10 @@ def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, 
     agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
     Wf = torch.empty(plan.E, Fd, dtype=torch.float32, device=x1.device) if want_filter else None
     cpw = FUSED_CHUNKS_PER_WG if chunks_per_wg is None else chunks_per_wg
+    W1T = _f32(W1).t().contiguous()      # [G, F]: coalesced operand loads in the kernel
+    W2T = _f32(W2).t().contiguous()      # [F_in, F_out]
     _lib.call("msde_cfconv_fused_fwd", _p(x1), _p(_f32(dist)), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
-              _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)), _p(_f32(offset)), N, Fd, G, plan.E,
+              _p(W1T), _p(_f32(b1)), _p(W2T), _p(_f32(b2)), _p(_f32(offset)), N, Fd, G, plan.E,
               float(coeff), float(cutoff), int(cpw), _p(agg), _p(Wf), _stream())
     return (agg, Wf) if want_filter else agg
 

@@ -161,6 +161,7 @@ class Trainer:
         # hipGraph mode: one captured graph per batch shape (forward + backward + gradient flattening
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self._graphs = {}
+        self.adam_outside_graph = False   # True reproduces the multi-GPU structure (graph; all-reduce; Adam) on 1 GPU
         self._graph_pool = None
         self._graph_loss = {}
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=device)
@@ -218,7 +219,7 @@ class Trainer:
         key = id(batch)
         if key in self._graphs:
             return self._graphs[key]
-        with_adam = dp.world_size() == 1
+        with_adam = dp.world_size() == 1 and not self.adam_outside_graph
         sd = self.step_counter.view(torch.int64)
         self.models["SDE_2Dto3D_model"].score_network.seed_dev = sd
         torch.cuda.synchronize()
@@ -235,7 +236,7 @@ class Trainer:
         """Replay the captured step; under DP the all-reduce and Adam run after the replay."""
         g = self._graphs[id(batch)]
         g.replay()
-        if dp.world_size() > 1:
+        if dp.world_size() > 1 or self.adam_outside_graph:
             scale = dp.allreduce_mean_(self.opt.flat_g)
             self.opt.step(grad_scale=scale)
         self.steps += 1

@@ -378,7 +378,8 @@ def test_empty_and_ragged_inputs(dev):
     assert_close(gnn(b.x, b.edge_index, b.edge_attr), ognn(cpu_b.x, cpu_b.edge_index, cpu_b.edge_attr).detach(), 1e-4, 1e-5, "ragged gnn")
 
 
-def test_hipgraph_step_matches_eager(dev):
+@pytest.mark.parametrize("adam_outside", [False, True])
+def test_hipgraph_step_matches_eager(dev, adam_outside):
     """The captured hipGraph step (fwd + bwd + grad flattening + flat Adam) replays the same arithmetic
     as the eager step: same loss on the same weights with dropout off, and parameters move identically."""
     import copy
@@ -389,6 +390,7 @@ def test_hipgraph_step_matches_eager(dev):
     torch.manual_seed(3)
     tr_e = pretrain.Trainer(args, dev)
     tr_g = pretrain.Trainer(args, dev)
+    tr_g.adam_outside_graph = adam_outside      # True = the multi-GPU structure: graph, all-reduce, Adam
     for k in tr_e.models:
         tr_g.models[k].load_state_dict(tr_e.models[k].state_dict())
         disable_dropout(tr_e.models[k]); disable_dropout(tr_g.models[k])

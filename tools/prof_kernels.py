@@ -21,6 +21,6 @@ with torch.no_grad():
     torch.cuda.synchronize()
     for _ in range(20):
         hip.cfconv_fused_forward(x1, dist, rplan, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias,
-                                 de.offset, de.coeff, sch.cutoff, sch.fused_nodes_per_wg)
+                                 de.offset, de.coeff, sch.cutoff)
     torch.cuda.synchronize()
 print("E", int(rplan.rowptr[-1]), "N", N)
