@@ -178,6 +178,10 @@ int msde_bn_bwd(const float* dY, const float* X, const float* save_mean, const f
                 const float* gamma, const float* beta, int relu, int M, int C, float* dX,
                 float* dgamma, float* dbeta, float* workspace, void* stream);
 
+/* out[c] = sum_m X[m,c] (bias gradient of an nn.Linear when the vendor GEMM computes the weight
+ * gradient); workspace: msde_bn_workspace_floats(M, C) floats; fixed summation order. */
+int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void* stream);
+
 /* ------------------------------------------------------------------ optimiser -------------- */
 /* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —
  * examples/pretrain_MoleculeSDE.py:331-337,156.  seg_end[S] (exclusive ends), seg_lr[S].

@@ -45,6 +45,7 @@ SIGNATURES = {
     "msde_linear_bwd_w_workspace_bytes": [I, I, I],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
     "msde_bn_workspace_floats": [I, I],
+    "msde_colsum": [P, I, I, P, P, P],
     "msde_bn_fwd": [P, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
     "msde_bn_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P],
     "msde_adam_flat": [P, P, P, P, LL, P, P, P, I, F, F, F, F, F, P],

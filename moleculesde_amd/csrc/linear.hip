@@ -25,9 +25,13 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
                      float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
                      int ldc, int k_per_split) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
-  __shared__ float As[LG_BK * LDA_S];
-  __shared__ float Bs[LG_BK * LDB_S];
+  // k-major LDS images.  An operand that is k-major in memory is copied with aligned 16-B stores (row
+  // stride BM+4); one that is row-major is transposed on the way in with scalar stores, for which the
+  // stride BM+1 (== 1 mod 32) is the conflict-free one.  The MFMA operand reads (32 consecutive floats
+  // of one k row per half-wave) are conflict free for any stride.
+  constexpr int LDA_S = A_KM ? BM + 4 : BM + 1, LDB_S = B_KM ? BN + 4 : BN + 1;
+  __shared__ __attribute__((aligned(16))) float As[LG_BK * LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[LG_BK * LDB_S];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 31, lhalf = lane >> 5;
@@ -101,10 +105,7 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
         As[(kq + 3) * LDA_S + r] = ra[p].w;
       } else {
         int kr = idx / (BM / 4), mq = (idx % (BM / 4)) * 4;
-        As[kr * LDA_S + mq + 0] = ra[p].x;
-        As[kr * LDA_S + mq + 1] = ra[p].y;
-        As[kr * LDA_S + mq + 2] = ra[p].z;
-        As[kr * LDA_S + mq + 3] = ra[p].w;
+        *reinterpret_cast<float4*>(&As[kr * LDA_S + mq]) = ra[p];
       }
     }
 #pragma unroll
@@ -118,10 +119,7 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
         Bs[(kq + 3) * LDB_S + r] = rb[p].w;
       } else {
         int kr = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
-        Bs[kr * LDB_S + nq + 0] = rb[p].x;
-        Bs[kr * LDB_S + nq + 1] = rb[p].y;
-        Bs[kr * LDB_S + nq + 2] = rb[p].z;
-        Bs[kr * LDB_S + nq + 3] = rb[p].w;
+        *reinterpret_cast<float4*>(&Bs[kr * LDB_S + nq]) = rb[p];
       }
     }
   };

@@ -162,11 +162,51 @@ bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, c
 }
 
 static inline void bn_geometry(int M, int* splits, int* rows) {
-  int s = (M + 255) / 256;          // >= 256 rows per split
-  if (s > 64) s = 64;
+  int s = (M + 63) / 64;            // >= 64 rows per split: (C/64) x splits workgroups fill the chip
+  if (s > 128) s = 128;
   if (s < 1) s = 1;
   *rows = (M + s - 1) / s;
   *splits = (M + *rows - 1) / *rows;
+}
+
+// ---- column sums (bias gradients of the library-GEMM weight-gradient path): two launches, fixed order
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const float* __restrict__ X, int M, int C, int rows_per_split, float* __restrict__ ws) {
+  __shared__ float s_a[BN_RL][BN_COLS];
+  const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
+  const int c = blockIdx.x * BN_COLS + tx;
+  const int r0 = blockIdx.y * rows_per_split, r1 = min(r0 + rows_per_split, M);
+  float sa = 0.f;
+  if (c < C)
+    for (int r = r0 + ty; r < r1; r += BN_RL) sa += X[(size_t)r * C + c];
+  s_a[ty][tx] = sa;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+#pragma unroll
+    for (int l = 1; l < BN_RL; ++l) sa += s_a[l][tx];
+    ws[(size_t)blockIdx.y * C + c] = sa;
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ ws, int splits, int C, float* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) acc += ws[(size_t)s * C + c];
+  out[c] = acc;
+}
+
+extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void* stream) {
+  if (M < 0 || C <= 0 || !X || !out || !workspace) return MSDE_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (M == 0) return (int)hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
+  int splits, rows;
+  bn_geometry(M, &splits, &rows);
+  MSDE_LAUNCH(colsum_partial_kernel, dim3((C + BN_COLS - 1) / BN_COLS, splits), dim3(256), 0, st, X, M, C, rows, workspace);
+  MSDE_CHECK_LAUNCH();
+  MSDE_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, splits, C, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int msde_bn_workspace_floats(int M, int C) {

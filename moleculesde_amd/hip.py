@@ -547,7 +547,10 @@ class _Linear(torch.autograd.Function):
                 _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
             else:
                 gw = torch.mm(g2.t(), x2)
-                gb = g2.sum(0) if ctx.has_bias else None
+                gb = None
+                if ctx.has_bias:
+                    gb = torch.empty(N, dtype=torch.float32, device=g2.device)
+                    _lib.call("msde_colsum", _p(g2), M, N, _p(gb), _p(_bn_workspace(M, N, g2.device)), st)
         return gx, gw, gb
 
 
