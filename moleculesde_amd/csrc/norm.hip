@@ -66,11 +66,38 @@ bn_fwd_apply_kernel(const float* __restrict__ X, const float* __restrict__ ws, i
                     float momentum, float* __restrict__ running_mean, float* __restrict__ running_var, int relu,
                     float* __restrict__ Y, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
   __shared__ float s_scale[BN_COLS], s_shift[BN_COLS];
+  __shared__ float s_n[BN_RL][BN_COLS], s_mean[BN_RL][BN_COLS], s_m2[BN_RL][BN_COLS];
   const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
   const int c = blockIdx.x * BN_COLS + tx;
+  {  // each row lane merges the splits s = ty, ty+4, ...; the four partials are then merged in lane order
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C) {
+      for (int sidx = ty; sidx < splits; sidx += BN_RL) {
+        const float* p = ws + ((size_t)sidx * C + c) * 3;
+        float nb = p[0], mb = p[1], m2b = p[2];
+        if (nb > 0.f) {
+          float nn = n + nb, d = mb - mean;
+          mean += d * (nb / nn);
+          m2 += m2b + d * d * (n * nb / nn);
+          n = nn;
+        }
+      }
+    }
+    s_n[ty][tx] = n; s_mean[ty][tx] = mean; s_m2[ty][tx] = m2;
+  }
+  __syncthreads();
   if (ty == 0 && c < C) {
-    float n, mean, m2;
-    bn_combine(ws, splits, C, c, n, mean, m2);
+    float n = s_n[0][tx], mean = s_mean[0][tx], m2 = s_m2[0][tx];
+#pragma unroll
+    for (int l = 1; l < BN_RL; ++l) {
+      float nb = s_n[l][tx], mb = s_mean[l][tx], m2b = s_m2[l][tx];
+      if (nb > 0.f) {
+        float nn = n + nb, d = mb - mean;
+        mean += d * (nb / nn);
+        m2 += m2b + d * d * (n * nb / nn);
+        n = nn;
+      }
+    }
     float var = m2 / n;
     float rstd = rsqrtf(var + eps);
     float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -133,14 +160,22 @@ bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, c
                     int relu, const float* __restrict__ ws, int M, int C, int splits, int rows_per_block,
                     float* __restrict__ dX, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float s_db[BN_COLS], s_dg[BN_COLS];
+  __shared__ float s_pa[BN_RL][BN_COLS], s_pb[BN_RL][BN_COLS];
   const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
   const int c = blockIdx.x * BN_COLS + tx;
+  {
+    float pa = 0.f, pb = 0.f;
+    if (c < C)
+      for (int sidx = ty; sidx < splits; sidx += BN_RL) {
+        const float* p = ws + ((size_t)sidx * C + c) * 2;
+        pa += p[0]; pb += p[1];
+      }
+    s_pa[ty][tx] = pa; s_pb[ty][tx] = pb;
+  }
+  __syncthreads();
   if (ty == 0 && c < C) {
-    float sa = 0.f, sb = 0.f;
-    for (int s = 0; s < splits; ++s) {
-      const float* p = ws + ((size_t)s * C + c) * 2;
-      sa += p[0]; sb += p[1];
-    }
+    float sa = ((s_pa[0][tx] + s_pa[1][tx]) + s_pa[2][tx]) + s_pa[3][tx];
+    float sb = ((s_pb[0][tx] + s_pb[1][tx]) + s_pb[2][tx]) + s_pb[3][tx];
     s_db[tx] = sa; s_dg[tx] = sb;
     if (blockIdx.y == 0) {
       if (dbeta) dbeta[c] = sa;
@@ -162,8 +197,8 @@ bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, c
 }
 
 static inline void bn_geometry(int M, int* splits, int* rows) {
-  int s = (M + 63) / 64;            // >= 64 rows per split: (C/64) x splits workgroups fill the chip
-  if (s > 128) s = 128;
+  int s = (M + 127) / 128;          // >= 128 rows per split: (C/64) x splits workgroups fill the chip
+  if (s > 64) s = 64;
   if (s < 1) s = 1;
   *rows = (M + s - 1) / s;
   *splits = (M + *rows - 1) / *rows;
@@ -188,12 +223,17 @@ colsum_partial_kernel(const float* __restrict__ X, int M, int C, int rows_per_sp
   }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ ws, int splits, int C, float* __restrict__ out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const float* __restrict__ ws, int splits, int C, float* __restrict__ out) {
+  __shared__ float s_p[BN_RL][BN_COLS];
+  const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
+  const int c = blockIdx.x * BN_COLS + tx;
   float acc = 0.f;
-  for (int s = 0; s < splits; ++s) acc += ws[(size_t)s * C + c];
-  out[c] = acc;
+  if (c < C)
+    for (int s = ty; s < splits; s += BN_RL) acc += ws[(size_t)s * C + c];
+  s_p[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < C) out[c] = ((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx];
 }
 
 extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void* stream) {
@@ -204,7 +244,8 @@ extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* work
   bn_geometry(M, &splits, &rows);
   MSDE_LAUNCH(colsum_partial_kernel, dim3((C + BN_COLS - 1) / BN_COLS, splits), dim3(256), 0, st, X, M, C, rows, workspace);
   MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, splits, C, out);
+  MSDE_LAUNCH(colsum_final_kernel, dim3((C + BN_COLS - 1) / BN_COLS), dim3(256), 0, st, (const float*)workspace, splits, C,
+              out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
