@@ -43,56 +43,110 @@ def _event_time_ms(fn, iters, stream):
     return start.elapsed_time(end) / iters
 
 
-def roofline_cfconv(trainer, batch, iters=50):
-    """Roofline of the dominant hand-written kernel of the step: the CFConv message-passing kernel
-    (gather x1[src] * filter, segmented sum per target; schnet.py:190,194-195), one launch per
-    interaction.  Algorithmic bytes per launch (SURVEY §8d convention: each distinct input once, a
-    gather counts E*row_bytes):  E*F*4 (filter rows) + E*F*4 (gathered x1 rows) + E*4 (cutoff) +
-    E*4 (src) + (N+1)*4 (rowptr) + N*F*4 (output)."""
+def _radius(trainer, batch):
     from moleculesde_amd import hip, plan as P
     sch = trainer.models["model_3D"]
     pl = P.get_plan(batch)
     with torch.no_grad():
         rplan, dist = hip.radius_plan(batch.positions, pl.batch_i32, pl.mol_ptr, sch.cutoff, pl.E_r_cap, 32)
-        E = int(rplan.rowptr[-1])
-        N, Fd = batch.x.size(0), sch.num_filters
+    return sch, rplan, dist, int(rplan.rowptr[-1]), batch.x.size(0)
+
+
+def _pmc_traffic(kernel, E, N):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json),
+    valid only for the batch shape they were collected on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            d = json.load(f)
+        ent = d.get(kernel)
+        if ent and d.get("shape", {}).get("E_r") == E and d.get("shape", {}).get("N") == N:
+            return ent["traffic_bytes"]
+    except Exception:
+        pass
+    return None
+
+
+def roofline_fused_fwd(trainer, batch, iters=50):
+    """Roofline of the dominant hand-written kernel of the step: the fused CFConv forward
+    (csrc/cfconv_fused.hip; 6 launches per step forward).  It is matrix-core bound in fp32 (83 FLOP/B):
+    algorithmic FLOPs per launch = E * 2 * (G*F + F*F) for the filter network (SURVEY §8d row 'SchNet
+    CFConv fused'); algorithmic bytes = E*8 + E*F*4 (gather) + weights + N*F*4 (+ E*F*4 filter rows out).
+    Timed on the raw C-ABI call (weights pre-transposed, output zeroing included) with HIP events."""
+    from moleculesde_amd import hip, _lib
+    sch, rplan, dist, E, N = _radius(trainer, batch)
+    if sch.num_filters != 128:
+        return None
+    blk, de = sch.interactions[0], sch.distance_expansion
+    G = sch.num_gaussians
+    with torch.no_grad():
+        x1 = torch.randn(N, 128, device=batch.x.device)
+        W1T = blk.mlp[0].weight.detach().t().contiguous()
+        W2T = blk.mlp[2].weight.detach().t().contiguous()
+        b1, b2 = blk.mlp[0].bias.detach(), blk.mlp[2].bias.detach()
+        agg = torch.empty(N, 128, device=batch.x.device)
+        Wf = torch.empty(rplan.E, 128, device=batch.x.device)
+        stream = torch.cuda.current_stream()
+        p, st = hip._p, hip._stream()
+        fn = lambda: _lib.call("msde_cfconv_fused_fwd", p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst), p(W1T),
+                               p(b1), p(W2T), p(b2), p(de.offset), N, 128, G, rplan.E, float(de.coeff), float(sch.cutoff),
+                               hip.FUSED_CHUNKS_PER_WG, p(agg), p(Wf), st)
+        ms = _event_time_ms(fn, iters, stream)
+    flops = E * 2.0 * (G * 128 + 128 * 128)
+    nbytes = E * 8 + E * 128 * 4 * 2 + (G * 128 + 128 * 128 + 256) * 4 + N * 128 * 4 + (N + 1) * 4
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "cfconv_fused_fwd_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+            "traffic": _pmc_traffic("cfconv_fused_fwd_kernel", E, N), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": nbytes, "hbm_frac_at_this_time": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N}
+
+
+def roofline_fused_bwd(trainer, batch, iters=30):
+    """Second line: the recomputing weight-gradient kernel of the fused CFConv (cfconv_fused_bwd.hip),
+    FLOPs per launch = E * 2 * (G*F [recompute pre1] + F*F [g_W2] + F*F [W2^T g] + F*G [g_W1])."""
+    from moleculesde_amd import hip, _lib
+    sch, rplan, dist, E, N = _radius(trainer, batch)
+    if sch.num_filters != 128:
+        return None
+    blk, de = sch.interactions[0], sch.distance_expansion
+    G = sch.num_gaussians
+    with torch.no_grad():
+        dev = batch.x.device
+        x1 = torch.randn(N, 128, device=dev)
+        g = torch.randn(N, 128, device=dev)
+        W1, b1, W2 = blk.mlp[0].weight.detach(), blk.mlp[0].bias.detach(), blk.mlp[2].weight.detach()
+        gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b1)
+        ws = hip._cf_workspace(rplan.E, G, dev)
+        p, st = hip._p, hip._stream()
+        fn = lambda: _lib.call("msde_cfconv_fused_bwd_w", p(g), p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst),
+                               p(W1), p(b1), p(W2), p(de.offset), N, 128, G, rplan.E, float(de.coeff), float(sch.cutoff),
+                               p(gW1), p(gb1), p(gW2), p(gb2), p(ws), st)
+        ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
+    flops = E * 2.0 * (2 * G * 128 + 2 * 128 * 128)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "cfconv_fused_bwd_w_kernel (+ slab reduce)", "bound": "mfma", "achieved": round(tf, 2),
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6}
+
+
+def roofline_cfconv_aggregate(trainer, batch, iters=50):
+    """HBM-bound message-passing kernel of the decomposed path (gather x1[src] * filter, segmented sum;
+    schnet.py:190,194-195).  Algorithmic bytes per launch (SURVEY §8d convention):
+    E*F*4 (filter rows) + E*F*4 (gathered x1 rows) + E*8 + (N+1)*4 + N*F*4 (output)."""
+    from moleculesde_amd import hip
+    sch, rplan, dist, E, N = _radius(trainer, batch)
+    Fd = sch.num_filters
+    with torch.no_grad():
         x1 = torch.randn(N, Fd, device=batch.x.device)
         Wf = torch.randn(rplan.E, Fd, device=batch.x.device)
         C = torch.rand(rplan.E, device=batch.x.device)
-        stream = torch.cuda.current_stream()
-        ms = _event_time_ms(lambda: hip.cfconv_aggregate(x1, Wf, C, rplan), iters, stream)
+        ms = _event_time_ms(lambda: hip.cfconv_aggregate(x1, Wf, C, rplan), iters, torch.cuda.current_stream())
     nbytes = E * Fd * 4 * 2 + E * 8 + (N + 1) * 4 + N * Fd * 4
     achieved = nbytes / (ms * 1e-3) / 1e9
     return {"kernel": "cfconv_aggregate_fwd_kernel", "bound": "hbm", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "bytes_per_launch": nbytes, "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6,
-            "edges": E, "nodes": N}
-
-
-def roofline_fused(trainer, batch, iters=50):
-    """Secondary line: the fused fp32-MFMA CFConv forward (inference path).  FLOPs per launch:
-    E * 2 * (G*F + F*F) (filter MLP) ; bound by the fp32 matrix peak."""
-    from moleculesde_amd import hip, plan as P
-    sch = trainer.models["model_3D"]
-    if sch.num_filters != 128:
-        return None
-    pl = P.get_plan(batch)
-    blk = sch.interactions[0]
-    de = sch.distance_expansion
-    with torch.no_grad():
-        rplan, dist = hip.radius_plan(batch.positions, pl.batch_i32, pl.mol_ptr, sch.cutoff, pl.E_r_cap, 32)
-        E = int(rplan.rowptr[-1])
-        N = batch.x.size(0)
-        x1 = torch.randn(N, 128, device=batch.x.device)
-        stream = torch.cuda.current_stream()
-        fn = lambda: hip.cfconv_fused_forward(x1, dist, rplan, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
-                                              blk.mlp[2].bias, de.offset, de.coeff, sch.cutoff)
-        ms = _event_time_ms(fn, iters, stream)
-    G = sch.num_gaussians
-    flops = E * 2.0 * (G * 128 + 128 * 128)
-    tf = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "cfconv_fused_fwd_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF,
-            "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "avg_launch_us": round(ms * 1e3, 2)}
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": _pmc_traffic("cfconv_aggregate_fwd_kernel", E, N), "bytes_per_launch": nbytes,
+            "avg_launch_us": round(ms * 1e3, 2)}
 
 
 def cpu_baseline(bs=256, warm=1, timed=3):
@@ -171,10 +225,14 @@ def main():
             trainer.step(pool[s])
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t0) / len(pool) * 1e3
-        for b in pool:
-            trainer.capture(b)
-        for b in pool:
-            trainer.step_graph(b)
+        try:
+            for b in pool:
+                trainer.capture(b)
+            for b in pool:
+                trainer.step_graph(b)
+        except Exception as exc:      # never lose the measurement to a capture problem: fall back to eager
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr)
+            use_graph = False
     step_fn = trainer.step_graph if use_graph else trainer.step
     dp.barrier()
     torch.cuda.synchronize()
@@ -193,8 +251,9 @@ def main():
     if rank == 0:
         print(f"[bench] {a.steps} steps in {dt:.3f}s", file=sys.stderr, flush=True)
         mols = world * a.batch_size * a.steps
-        roof = roofline_cfconv(trainer, pool[0])
-        fused = roofline_fused(trainer, pool[0])
+        roof = roofline_fused_fwd(trainer, pool[0])
+        roof_bwd = roofline_fused_bwd(trainer, pool[0])
+        roof_agg = roofline_cfconv_aggregate(trainer, pool[0])
         out = {
             "metric": "molecules/sec pretrain step (SchNet+SDE VE, bs256)",
             "value": round(mols / dt, 1), "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
@@ -208,7 +267,8 @@ def main():
                        if use_graph else "eager", "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                        "loss_scalar": float(trainer.log["2Dto3D"]) / max(trainer.steps, 1)},
             "roofline": roof,
-            "roofline_fused_cfconv_fwd": fused,
+            "roofline_cfconv_fused_bwd_w": roof_bwd,
+            "roofline_cfconv_aggregate_hbm": roof_agg,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch_size)
