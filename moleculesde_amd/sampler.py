@@ -33,17 +33,37 @@ def corrector_update(sde, score_model, representation, data, pos, t, snr, scale_
 
 @torch.no_grad()
 def position_PC_generation(score_model, representation, data, num_steps=1000, snr=0.16, scale_eps=0.7,
-                           n_corrector_steps=1, eps=1e-4, denoise=True, pos_init=None):
-    """position_PC_generation (:92-138): returns the final coordinates [N, 3]."""
+                           n_corrector_steps=1, eps=1e-4, denoise=True, pos_init=None, use_graph=True):
+    """position_PC_generation (:92-138): returns the final coordinates [N, 3].
+
+    The loop is latency bound (every iteration = 1 + n_corrector_steps score-network calls on a graph of
+    ~10 x 14 atoms, ~150 small launches), so by default one iteration (corrector + predictor, noise drawn
+    inside) is captured into a hipGraph after two eager warm-up iterations and replayed; only the
+    per-atom time vector is refreshed from the host between replays."""
     sde = score_model.sde_pos
     n = representation.size(0)
     dev = representation.device
-    pos = torch.randn(n, 3, device=dev) if pos_init is None else pos_init
+    pos = (torch.randn(n, 3, device=dev) if pos_init is None else pos_init.clone()).contiguous()
     timesteps = torch.linspace(sde.T, eps, num_steps, device=dev)
-    x_mean = pos
+    vec_t = torch.ones(n, device=dev)
+    x_mean = pos.clone()
+
+    def one_step():
+        p, _ = corrector_update(sde, score_model, representation, data, pos, vec_t, snr, scale_eps, n_corrector_steps)
+        p, m = predictor_update(sde, score_model, representation, data, p, vec_t)
+        pos.copy_(p)
+        x_mean.copy_(m)
+
+    graph = None
     for i in range(num_steps):
-        vec_t = torch.ones(n, device=dev) * timesteps[i]
-        pos, x_mean = corrector_update(sde, score_model, representation, data, pos, vec_t, snr, scale_eps,
-                                       n_corrector_steps)
-        pos, x_mean = predictor_update(sde, score_model, representation, data, pos, vec_t)
-    return x_mean if denoise else pos
+        vec_t.fill_(1.0).mul_(timesteps[i])
+        if use_graph and dev.type == "cuda" and graph is None and i == 2:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one_step()                 # capture only records; the replay below executes iteration i
+        if graph is not None:
+            graph.replay()
+        else:
+            one_step()
+    return (x_mean if denoise else pos).clone()
