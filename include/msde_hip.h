@@ -87,7 +87,8 @@ int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab,
 int msde_rbf_cutoff_fwd(const float* dist, const int* E_dev, int E_cap, int G,
                         const float* offset, float coeff, float cutoff, float* rbf, float* C,
                         void* stream);
-/* CFConv.message + aggregate — schnet.py:190,194-195: agg[i] = sum_e x1[src[e]] * Wf[e] * C[e] */
+/* CFConv.message + aggregate — schnet.py:190,194-195: agg[i] = sum_e x1[src[e]] * Wf[e] * C[e]
+ * (C may be NULL = 1 in all three aggregate kernels) */
 int msde_cfconv_aggregate_fwd(const float* x1, const float* Wf, const float* C, const int* rowptr,
                               const int* src, int N, int F, float* agg, void* stream);
 /* g_Wf[e] = g_agg[dst[e]] * x1[src[e]] * C[e]   (rows e >= rowptr[N] zero-filled up to E_cap) */

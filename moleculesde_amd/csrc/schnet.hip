@@ -56,7 +56,7 @@ __global__ void cfconv_aggregate_fwd_kernel(const float* __restrict__ x1, const 
     T acc = vzero<V>();
     for (int e = s0; e < s1; ++e) {
       // message = x_j * (nn(edge_attr) * C): keep the reference's rounding order (W*C first)
-      T w = vscale(W[(size_t)e * cols + c], C[e]);
+      T w = C ? vscale(W[(size_t)e * cols + c], C[e]) : W[(size_t)e * cols + c];
       acc = vadd(acc, vmul(X[(size_t)src[e] * cols + c], w));
     }
     O[(size_t)i * cols + c] = acc;
@@ -79,7 +79,10 @@ __global__ void cfconv_aggregate_bwd_w_kernel(const float* __restrict__ g_agg, c
     int s0 = rowptr[i], s1 = rowptr[i + 1];
     for (int c = lane; c < cols; c += tpr) {
       T gi = G[(size_t)i * cols + c];
-      for (int e = s0; e < s1; ++e) O[(size_t)e * cols + c] = vscale(vmul(gi, X[(size_t)src[e] * cols + c]), C[e]);
+      for (int e = s0; e < s1; ++e) {
+        T v = vmul(gi, X[(size_t)src[e] * cols + c]);
+        O[(size_t)e * cols + c] = C ? vscale(v, C[e]) : v;
+      }
     }
   }
   // zero the padded tail rows [rowptr[N], E_cap): they feed the weight-gradient GEMMs
@@ -116,7 +119,7 @@ __global__ void cfconv_aggregate_bwd_x_kernel(const float* __restrict__ g_agg, c
 
 extern "C" int msde_cfconv_aggregate_fwd(const float* x1, const float* Wf, const float* C, const int* rowptr,
                                          const int* src, int N, int F, float* agg, void* stream) {
-  if (N < 0 || F <= 0 || !x1 || !Wf || !C || !rowptr || !src || !agg) return MSDE_EINVAL;
+  if (N < 0 || F <= 0 || !x1 || !Wf || !rowptr || !src || !agg) return MSDE_EINVAL;
   if (N == 0) return 0;
   LAUNCH_ROWS(cfconv_aggregate_fwd_kernel, N, F, x1, Wf, C, rowptr, src, N, cols, tpr, agg);
   MSDE_CHECK_LAUNCH();
@@ -125,7 +128,7 @@ extern "C" int msde_cfconv_aggregate_fwd(const float* x1, const float* Wf, const
 
 extern "C" int msde_cfconv_aggregate_bwd_w(const float* g_agg, const float* x1, const float* C, const int* rowptr,
                                            const int* src, int N, int F, int E_cap, float* g_Wf, void* stream) {
-  if (N < 0 || F <= 0 || !g_agg || !x1 || !C || !rowptr || !src || !g_Wf) return MSDE_EINVAL;
+  if (N < 0 || F <= 0 || !g_agg || !x1 || !rowptr || !src || !g_Wf) return MSDE_EINVAL;
   if (N == 0) return 0;
   LAUNCH_ROWS(cfconv_aggregate_bwd_w_kernel, N, F, g_agg, x1, C, rowptr, src, N, cols, tpr, E_cap, g_Wf);
   MSDE_CHECK_LAUNCH();

@@ -98,9 +98,9 @@ class SchNet(nn.Module):
 
     def forward(self, z, pos, batch=None, return_latent=False):
         assert z.dim() == 1 and z.dtype == torch.long
-        if pos.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("gradients w.r.t. positions (MD17 force path) are not wired in this build")
         pl = self._find_plan(z, batch)
+        if pos.requires_grad and torch.is_grad_enabled():
+            return self._forward_force_path(z, pos, pl, return_latent)
         ptr, nodes = _plan.z_lists(pl, self.node_class)
         h = hip.embedding_sum(self.embedding.weight, pl.z_codes, ptr, nodes)
 
@@ -128,6 +128,42 @@ class SchNet(nn.Module):
 
         h = self.lin2(_nn.shifted_softplus(self.lin1(h)))
         out = hip.segment_reduce(h, pl.mol_ptr, pl.batch_i32, mean=(self.readout == "mean"))
+        if return_latent:
+            return out, h
+        return out
+
+    def _forward_force_path(self, z, pos, pl, return_latent):
+        """Energy path that is differentiable w.r.t. positions, twice (finetune_MD17.py:47-78: forces by
+        autograd.grad(create_graph=True), then backward through them).  The radius CSR still comes from
+        the HIP kernels (indices carry no gradient); distances, smearing, cutoff and the dense layers use
+        library ops that autograd can differentiate twice; the message passing uses the closed family of
+        bilinear edge kernels (hip.edge_aggregate_dd)."""
+        import math
+        rplan, _ = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors)
+        valid = (rplan.src >= 0)
+        src = rplan.src.clamp(min=0).long()
+        dst = rplan.dst.clamp(min=0).long()
+        diff = pos[src] - pos[dst]
+        d2 = (diff * diff).sum(-1)
+        # padded slots: distance of an atom to itself would be sqrt(0) (infinite slope); give them d = 1
+        dist = torch.sqrt(torch.where(valid, d2, torch.ones_like(d2)))
+        de = self.distance_expansion
+        rbf = torch.exp(de.coeff * (dist.unsqueeze(1) - de.offset.unsqueeze(0)) ** 2)
+        C = 0.5 * (torch.cos(dist * math.pi / self.cutoff) + 1.0) * valid.to(dist.dtype)
+        h = F.embedding(z, self.embedding.weight)
+        for blk in self.interactions:
+            m0, m2 = blk.mlp[0], blk.mlp[2]
+            Wf = F.linear(_nn.shifted_softplus(F.linear(rbf, m0.weight, m0.bias)), m2.weight, m2.bias) * C.unsqueeze(1)
+            x1 = F.linear(h, blk.conv.lin1.weight)
+            agg = hip.edge_aggregate_dd(x1, Wf, rplan)
+            x = F.linear(agg, blk.conv.lin2.weight, blk.conv.lin2.bias)
+            h = h + F.linear(_nn.shifted_softplus(x), blk.lin.weight, blk.lin.bias)
+        h = F.linear(_nn.shifted_softplus(F.linear(h, self.lin1.weight, self.lin1.bias)), self.lin2.weight, self.lin2.bias)
+        bidx = pl.batch_i32.long()
+        out = torch.zeros(pl.B, h.size(1), dtype=h.dtype, device=h.device).index_add(0, bidx, h)
+        if self.readout == "mean":
+            cnt = (pl.mol_ptr[1:] - pl.mol_ptr[:-1]).clamp(min=1).to(h.dtype)
+            out = out / cnt.unsqueeze(1)
         if return_latent:
             return out, h
         return out

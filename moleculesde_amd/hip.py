@@ -331,6 +331,75 @@ def cfconv_aggregate(x1, Wf, C, plan):
     return _CFConvAggregate.apply(x1, Wf, C, plan)
 
 
+# ---- twice-differentiable edge primitives (MD17 force path: F = -dE/dpos with create_graph=True, then
+# loss(F).backward(); finetune_MD17.py:47-78).  The three bilinear maps below are closed under
+# differentiation -- each backward is expressed with the other two -- so autograd can differentiate the
+# backward graph again.
+class _EdgeAgg(torch.autograd.Function):
+    """agg(x, W)[i] = sum_{e: dst_e = i} x[src_e] * W[e]"""
+
+    @staticmethod
+    def forward(ctx, x, W, plan):
+        x, W = _f32(x), _f32(W)
+        N, Fd = x.shape
+        out = torch.empty(N, Fd, dtype=torch.float32, device=x.device)
+        _lib.call("msde_cfconv_aggregate_fwd", _p(x), _p(W), _p(None), _p(plan.rowptr), _p(plan.src), N, Fd, _p(out),
+                  _stream())
+        ctx.save_for_backward(x, W)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        return _EdgeAggT.apply(g, W, ctx.plan), _EdgeProd.apply(g, x, ctx.plan), None
+
+
+class _EdgeAggT(torch.autograd.Function):
+    """aggT(g, W)[j] = sum_{e: src_e = j} g[dst_e] * W[e]"""
+
+    @staticmethod
+    def forward(ctx, g, W, plan):
+        g, W = _f32(g), _f32(W)
+        N, Fd = g.shape
+        out = torch.empty(N, Fd, dtype=torch.float32, device=g.device)
+        _lib.call("msde_cfconv_aggregate_bwd_x", _p(g), _p(W), _p(None), _p(plan.rowptr_s), _p(plan.perm_s), _p(plan.dst),
+                  N, Fd, _p(out), _stream())
+        ctx.save_for_backward(g, W)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, u):
+        g, W = ctx.saved_tensors
+        return _EdgeAgg.apply(u, W, ctx.plan), _EdgeProd.apply(g, u, ctx.plan), None
+
+
+class _EdgeProd(torch.autograd.Function):
+    """prod(g, x)[e] = g[dst_e] * x[src_e]   (padded rows zero)"""
+
+    @staticmethod
+    def forward(ctx, g, x, plan):
+        g, x = _f32(g), _f32(x)
+        N, Fd = x.shape
+        out = torch.empty(plan.E, Fd, dtype=torch.float32, device=x.device)
+        _lib.call("msde_cfconv_aggregate_bwd_w", _p(g), _p(x), _p(None), _p(plan.rowptr), _p(plan.src), N, Fd, plan.E,
+                  _p(out), _stream())
+        ctx.save_for_backward(g, x)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, U):
+        g, x = ctx.saved_tensors
+        return _EdgeAgg.apply(x, U, ctx.plan), _EdgeAggT.apply(g, U, ctx.plan), None
+
+
+def edge_aggregate_dd(x, W, plan):
+    """Twice-differentiable  agg_i = sum_{e -> i} x[src_e] * W[e]  (W must already include the cutoff)."""
+    return _EdgeAgg.apply(x, W, plan)
+
+
 class _PairGatherAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, B, plan):

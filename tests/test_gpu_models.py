@@ -532,3 +532,43 @@ def test_sampler_graph_matches_eager(dev):
     assert torch.isfinite(outs[0]).all()
     # identical kernels and (Philox) noise sequence; graph-mode RNG offsets advance identically
     assert_close(outs[1], outs[0], 1e-4, 1e-4, "graph vs eager sampler")
+
+
+@pytest.mark.parametrize("bs", [1, 4])
+def test_md17_force_path_double_backward(dev, bs):
+    """BASELINE.json config 5 (finetune_MD17.py:47-78): energy = Linear(SchNet(z, pos)), force =
+    -d(energy)/d(pos) with create_graph=True, loss = L1(energy) + L1(force), backward through the forces.
+    Energy, forces and every parameter gradient against the oracle's autograd on the CPU."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_md17_batch
+    torch.manual_seed(7)
+    kw = dict(hidden_channels=64, num_filters=32, num_interactions=3, num_gaussians=51, cutoff=10, readout="mean", node_class=119)
+    osch = R.SchNet(**kw)
+    ohead = torch.nn.Linear(64, 1)
+    sch = G.SchNet(**kw)
+    sch.load_state_dict(osch.state_dict())
+    head = torch.nn.Linear(64, 1)
+    head.load_state_dict(ohead.state_dict())
+    sch.to(dev); head.to(dev)
+    cpu_b = make_md17_batch(bs, seed=3, n_atoms=21)
+    e_t = torch.randn(bs, 1)
+    f_t = torch.randn(cpu_b.x.size(0), 3)
+
+    def run(model, hd, b, et, ft):
+        pos = b.positions.clone().requires_grad_(True)
+        energy = hd(model(b.x, pos, b.batch))
+        force = -torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=True,
+                                     retain_graph=True)[0]
+        loss = (energy - et).abs().mean() + (force - ft).abs().mean()
+        loss.backward()
+        return energy.detach(), force.detach(), loss.detach()
+
+    eo, fo, lo = run(osch, ohead, cpu_b, e_t, f_t)
+    dev_b = G.prepare_batch(cpu_b.clone(), dev)
+    e, f, l = run(sch, head, dev_b, e_t.to(dev), f_t.to(dev))
+    assert_close(e, eo, 1e-4, 1e-5, "energy")
+    assert_close(f, fo, 1e-3, 1e-4 * float(fo.abs().max()), "force")
+    assert_close(l, lo, 1e-4, 1e-6, "loss")
+    gs = {n: p.grad for n, p in osch.named_parameters() if p.grad is not None}
+    _grads_close(sch, gs, 2e-3, 2e-4, "SchNet double-backward grads")
+    assert_close(head.weight.grad, ohead.weight.grad, 1e-3, 1e-5, "head grad")
