@@ -165,11 +165,12 @@ _CF_WS = {}
 
 def _cf_workspace(E_cap, G, device):
     n = int(_lib.load().msde_cfconv_fused_bwd_w_workspace_floats(E_cap, G))
+    device = _ws_key(device)
     ws = _CF_WS.get(device)
     if ws is None or ws.numel() < n:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.MsdeHipError("fused CFConv workspace must be sized by an eager warm-up step before graph capture")
-        ws = torch.empty(n, dtype=torch.float32, device=device)
+        ws = torch.empty(n, dtype=torch.float32, device=device[0])
         _CF_WS[device] = ws
     return ws
 
@@ -539,17 +540,23 @@ _WS = {}          # per-device wgrad slab workspace, grown on demand (stream-ord
 _WS_BYTES = {}    # (M, N, K) -> workspace bytes
 
 
+def _ws_key(device):
+    """Workspaces are per (device, stream): kernels on concurrent streams must not share scratch."""
+    return (device, torch.cuda.current_stream().cuda_stream)
+
+
 def _wgrad_workspace(M, N, K, device):
     key = (M, N, K)
     nbytes = _WS_BYTES.get(key)
     if nbytes is None:
         nbytes = int(_lib.load().msde_linear_bwd_w_workspace_bytes(M, N, K))
         _WS_BYTES[key] = nbytes
+    device = _ws_key(device)
     ws = _WS.get(device)
     if ws is None or ws.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.MsdeHipError("wgrad workspace must be sized by an eager warm-up step before graph capture")
-        ws = torch.empty(max(nbytes // 4, 1 << 20), dtype=torch.float32, device=device)
+        ws = torch.empty(max(nbytes // 4, 1 << 20), dtype=torch.float32, device=device[0])
         _WS[device] = ws
     return ws
 
@@ -636,11 +643,12 @@ _BN_WS = {}
 
 def _bn_workspace(M, C, device):
     n = int(_lib.load().msde_bn_workspace_floats(M, C))
+    device = _ws_key(device)
     ws = _BN_WS.get(device)
     if ws is None or ws.numel() < n:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.MsdeHipError("BatchNorm workspace must be sized by an eager warm-up step before graph capture")
-        ws = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=device)
+        ws = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=device[0])
         _BN_WS[device] = ws
     return ws
 

@@ -160,6 +160,8 @@ class Trainer:
             m.train()
         # hipGraph mode: one captured graph per batch shape (forward + backward + gradient flattening
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
+        self.overlap_streams = True
+        self._side_stream = torch.cuda.Stream(device=device)
         self._graphs = {}
         self.adam_outside_graph = False   # True reproduces the multi-GPU structure (graph; all-reduce; Adam) on 1 GPU
         self._graph_pool = None
@@ -167,19 +169,33 @@ class Trainer:
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=device)
 
     def losses(self, batch):
+        """Loss composition of pretrain_MoleculeSDE.py:128-152.  The 3D encoder does not depend on the 2D
+        branch (GIN -> 2D->3D score model) until the contrastive term, and most kernels of this 256-molecule
+        step fill only part of the chip, so SchNet runs on a second HIP stream beside the 2D branch; autograd
+        replays each op's backward on the stream of its forward, so the backward overlaps the same way."""
         a, m = self.args, self.models
-        node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
-        _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
         loss = 0
         parts = {}
-        if self.coeff_cl > 0:
-            cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise)
-            loss = loss + cl * self.coeff_cl
-            parts["CL"], parts["CL_acc"] = cl.detach(), acc
+        main = torch.cuda.current_stream()
+        if self.overlap_streams:
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+        else:
+            _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+        node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
         if a.SDE_coeff_generative_2Dto3D > 0:
             l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
             loss = loss + l23 * a.SDE_coeff_generative_2Dto3D
             parts["2Dto3D"] = l23.detach()
+        if self.overlap_streams:
+            main.wait_stream(side)
+            node_3D_repr.record_stream(main)
+        if self.coeff_cl > 0:
+            cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise)
+            loss = loss + cl * self.coeff_cl
+            parts["CL"], parts["CL_acc"] = cl.detach(), acc
         if a.SDE_coeff_generative_3Dto2D > 0:
             lx, la = m["SDE_3Dto2D_model"](node_3D_repr, batch, reduce_mean=a.noise_on_one_hot, continuous=True,
                                            train=True, anneal_power=a.SDE_anneal_power)
