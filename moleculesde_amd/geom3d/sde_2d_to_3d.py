@@ -146,25 +146,44 @@ class SDEModel2Dto3D_02(nn.Module):
             raise NotImplementedError(f"SDE_type={SDE_type!r}")
         self.num_diffusion_timesteps = num_diffusion_timesteps
         self.noise = _nn.DeviceNoise()     # set to nn.CpuReplayNoise(seed) for replayable parity runs
+        self.side_stream = None            # optional second HIP stream for the coordinate-only branch
 
     def _plan(self, data):
         pl = _plan.get_plan(data)
         return pl, (pl.ext if self.use_extend_graph else pl.bond)
 
-    def _edge_and_node_features(self, node_2D_repr, pos_perturbed, ep):
-        D = self.emb_dim
+    def _geometry_branch(self, pos_perturbed, ep):
+        """Everything that depends on coordinates only (frame, Fourier features, their MLPs)."""
         feat_d, feat_i, feat_j, angle, basis = hip.edge_geometry(
             pos_perturbed, ep, self.dist_gaussian_fourier.W, self.coff_gaussian_fourier.W)
+        edge_attr_3D_invariant = self.input_mlp(feat_d)
+        embed_i = self.coff_mlp(feat_i)
+        embed_j = self.coff_mlp(feat_j)
+        edge_attr_3D_frame_invariant = self.project(torch.cat([angle, embed_i, embed_j], dim=-1))
+        return edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis
+
+    def _edge_and_node_features(self, node_2D_repr, pos_perturbed, ep):
+        D = self.emb_dim
+        # the coordinate branch is independent of the 2D representation: run it on the side stream (if the
+        # trainer gave us one) beside the 2D-embedding branch; autograd mirrors the overlap in the backward
+        side = self.side_stream if (self.side_stream is not None and node_2D_repr.is_cuda) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis = self._geometry_branch(pos_perturbed, ep)
+        else:
+            edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis = self._geometry_branch(pos_perturbed, ep)
         # edge_2D_emb[0](cat(h[row], h[col])) == h[row] W[:, :D]^T + h[col] W[:, D:]^T + b
         lin0 = self.edge_2D_emb[0]
         A = _nn.linear(node_2D_repr, lin0.weight[:, :D])
         Bm = _nn.linear(node_2D_repr, lin0.weight[:, D:], lin0.bias)
         pre = hip.pair_gather_add(A, Bm, ep)
         edge_attr_2D = self.edge_2D_emb[3](self.edge_2D_emb[2](self.edge_2D_emb[1](pre)))
-        edge_attr_3D_invariant = self.input_mlp(feat_d)
-        embed_i = self.coff_mlp(feat_i)
-        embed_j = self.coff_mlp(feat_j)
-        edge_attr_3D_frame_invariant = self.project(torch.cat([angle, embed_i, embed_j], dim=-1))
+        if side is not None:
+            main.wait_stream(side)
+            for t in (edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis):
+                t.record_stream(main)
         edge_attr = edge_attr_3D_invariant * edge_attr_2D + edge_attr_3D_frame_invariant
         node_attr = self.node_emb(node_2D_repr)
         return node_attr, edge_attr, basis

@@ -168,8 +168,6 @@ def _cf_workspace(E_cap, G, device):
     device = _ws_key(device)
     ws = _CF_WS.get(device)
     if ws is None or ws.numel() < n:
-        if torch.cuda.is_current_stream_capturing():
-            raise _lib.MsdeHipError("fused CFConv workspace must be sized by an eager warm-up step before graph capture")
         ws = torch.empty(n, dtype=torch.float32, device=device[0])
         _CF_WS[device] = ws
     return ws
@@ -554,8 +552,6 @@ def _wgrad_workspace(M, N, K, device):
     device = _ws_key(device)
     ws = _WS.get(device)
     if ws is None or ws.numel() * 4 < nbytes:
-        if torch.cuda.is_current_stream_capturing():
-            raise _lib.MsdeHipError("wgrad workspace must be sized by an eager warm-up step before graph capture")
         ws = torch.empty(max(nbytes // 4, 1 << 20), dtype=torch.float32, device=device[0])
         _WS[device] = ws
     return ws
@@ -646,8 +642,6 @@ def _bn_workspace(M, C, device):
     device = _ws_key(device)
     ws = _BN_WS.get(device)
     if ws is None or ws.numel() < n:
-        if torch.cuda.is_current_stream_capturing():
-            raise _lib.MsdeHipError("BatchNorm workspace must be sized by an eager warm-up step before graph capture")
         ws = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=device[0])
         _BN_WS[device] = ws
     return ws

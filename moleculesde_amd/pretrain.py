@@ -120,11 +120,12 @@ def make_optimizer(args, models):
     return FlatAdam(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=args.decay)
 
 
-def do_CL(X, Y, args, noise):
+def do_CL(X, Y, args, noise, neg_index=None):
     """'EBM_node_dot_prod' branch of examples/util.py:52-68 (the metric of the README command)."""
     if args.CL_similarity_metric != "EBM_node_dot_prod":
         raise NotImplementedError(args.CL_similarity_metric)
-    neg_index = noise.randperm(len(Y), Y.device)
+    if neg_index is None:
+        neg_index = noise.randperm(len(Y), Y.device)
     neg_Y = Y[neg_index]
     pred_pos = torch.sum(X * Y, dim=1) / args.T
     pred_neg = torch.sum(X * neg_Y, dim=1) / args.T
@@ -134,10 +135,10 @@ def do_CL(X, Y, args, noise):
     return loss_pos + loss_neg, acc.detach()
 
 
-def dual_CL(X, Y, args, noise):
+def dual_CL(X, Y, args, noise, neg_indices=(None, None)):
     """examples/util.py:76-79; the accuracy stays a device scalar (no sync)."""
-    l1, a1 = do_CL(X, Y, args, noise)
-    l2, a2 = do_CL(Y, X, args, noise)
+    l1, a1 = do_CL(X, Y, args, noise, neg_indices[0])
+    l2, a2 = do_CL(Y, X, args, noise, neg_indices[1])
     return (l1 + l2) / 2, (a1 + a2) / 2
 
 
@@ -162,6 +163,7 @@ class Trainer:
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self.overlap_streams = True
         self._side_stream = torch.cuda.Stream(device=device)
+        self.models["SDE_2Dto3D_model"].side_stream = torch.cuda.Stream(device=device)
         self._graphs = {}
         self.adam_outside_graph = False   # True reproduces the multi-GPU structure (graph; all-reduce; Adam) on 1 GPU
         self._graph_pool = None
@@ -185,6 +187,11 @@ class Trainer:
         else:
             _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
         node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
+        # random draws keep the reference's program order (contrastive permutations, then the 2D->3D noise)
+        negs = (None, None)
+        if self.coeff_cl > 0:
+            n = node_2D_repr.size(0)
+            negs = (self.noise.randperm(n, node_2D_repr.device), self.noise.randperm(n, node_2D_repr.device))
         if a.SDE_coeff_generative_2Dto3D > 0:
             l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
             loss = loss + l23 * a.SDE_coeff_generative_2Dto3D
@@ -193,7 +200,7 @@ class Trainer:
             main.wait_stream(side)
             node_3D_repr.record_stream(main)
         if self.coeff_cl > 0:
-            cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise)
+            cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
             loss = loss + cl * self.coeff_cl
             parts["CL"], parts["CL_acc"] = cl.detach(), acc
         if a.SDE_coeff_generative_3Dto2D > 0:
