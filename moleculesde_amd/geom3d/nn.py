@@ -143,6 +143,8 @@ def prepare_batch(data, device=None, **kw):
 class DeviceNoise:
     """Default noise source: device RNG (torch's HIP generator)."""
 
+    replay = False     # draws are not tied to a program order: independent branches may run concurrently
+
     def randn_like(self, x):
         return torch.randn_like(x)
 
@@ -160,6 +162,8 @@ class CpuReplayNoise:
     """Parity noise source: draws from a torch CPU generator in the reference's program order
      and uploads, so a reference/oracle run under torch.manual_seed(seed)
     sees the same numbers."""
+
+    replay = True      # draws must happen in the reference's program order
 
     def __init__(self, seed):
         self.g = torch.Generator(device="cpu")

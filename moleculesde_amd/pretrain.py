@@ -179,11 +179,24 @@ class Trainer:
         loss = 0
         parts = {}
         main = torch.cuda.current_stream()
+        want_32 = a.SDE_coeff_generative_3Dto2D > 0
+        # the 3D->2D head depends only on the SchNet output: it follows SchNet on the side stream unless the
+        # noise source replays the reference's program order (its draws come last there)
+        head_on_side = want_32 and self.overlap_streams and not getattr(self.noise, "replay", False)
+
+        def head_32(rep):
+            lx, la = m["SDE_3Dto2D_model"](rep, batch, reduce_mean=a.noise_on_one_hot, continuous=True, train=True,
+                                           anneal_power=a.SDE_anneal_power)
+            return (lx + la) * 0.5
+
+        l32 = None
         if self.overlap_streams:
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+                if head_on_side:
+                    l32 = head_32(node_3D_repr)
         else:
             _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
         node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
@@ -199,14 +212,15 @@ class Trainer:
         if self.overlap_streams:
             main.wait_stream(side)
             node_3D_repr.record_stream(main)
+            if l32 is not None:
+                l32.record_stream(main)
         if self.coeff_cl > 0:
             cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
             loss = loss + cl * self.coeff_cl
             parts["CL"], parts["CL_acc"] = cl.detach(), acc
-        if a.SDE_coeff_generative_3Dto2D > 0:
-            lx, la = m["SDE_3Dto2D_model"](node_3D_repr, batch, reduce_mean=a.noise_on_one_hot, continuous=True,
-                                           train=True, anneal_power=a.SDE_anneal_power)
-            l32 = (lx + la) * 0.5
+        if want_32:
+            if l32 is None:
+                l32 = head_32(node_3D_repr)
             loss = loss + l32 * a.SDE_coeff_generative_3Dto2D
             parts["3Dto2D"] = l32.detach()
         return loss, parts
