@@ -202,27 +202,33 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
     colsum_ws[(size_t)blockIdx.z * M + m0 + tid] = csum;
 }
 
-// out[i] = sum_z slabs[z][i] (fixed order) for the weight slabs (n entries) and, in the same launch,
-// the bias-gradient column sums (nb entries; cs == nullptr when the layer has no bias)
-__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, size_t n, float* __restrict__ out,
-                                    const float* __restrict__ cs, size_t nb, float* __restrict__ outb) {
+// out[i] = sum_z slabs[z][i] for the weight slabs (n entries) and, in the same launch, the bias-gradient
+// column sums (nb entries; cs == nullptr when the layer has no bias).  16 split lanes per output: lane l
+// sums the splits z = l, l+16, ... and the 16 partials are added in lane order -> fixed summation order.
+#define RS_LANES 16
+__global__ void __launch_bounds__(256)
+reduce_slabs_kernel(const float* __restrict__ slabs, int splits, size_t n, float* __restrict__ out,
+                    const float* __restrict__ cs, size_t nb, float* __restrict__ outb) {
+  __shared__ float part[RS_LANES][16];
+  const int ox = threadIdx.x & 15, ly = threadIdx.x >> 4;
   size_t total = n + (cs ? nb : 0);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t base = (size_t)blockIdx.x * 16; base < total; base += (size_t)gridDim.x * 16) {
+    size_t i = base + ox;
     float acc = 0.f;
-    if (i < n) {
-      int z = 0;
-      for (; z + 4 <= splits; z += 4) {      // four independent loads in flight, fixed summation order
-        float a0 = slabs[(size_t)z * n + i], a1 = slabs[(size_t)(z + 1) * n + i];
-        float a2 = slabs[(size_t)(z + 2) * n + i], a3 = slabs[(size_t)(z + 3) * n + i];
-        acc = (((acc + a0) + a1) + a2) + a3;
-      }
-      for (; z < splits; ++z) acc += slabs[(size_t)z * n + i];
-      out[i] = acc;
-    } else {
-      size_t j = i - n;
-      for (int z = 0; z < splits; ++z) acc += cs[(size_t)z * nb + j];
-      outb[j] = acc;
+    if (i < total) {
+      const float* src = i < n ? slabs + i : cs + (i - n);
+      size_t stride = i < n ? n : nb;
+      for (int z = ly; z < splits; z += RS_LANES) acc += src[(size_t)z * stride];
     }
+    part[ly][ox] = acc;
+    __syncthreads();
+    if (ly == 0 && i < total) {
+      float r = part[0][ox];
+#pragma unroll
+      for (int l = 1; l < RS_LANES; ++l) r += part[l][ox];
+      if (i < n) out[i] = r; else outb[i - n] = r;
+    }
+    __syncthreads();
   }
 }
 
@@ -286,13 +292,14 @@ extern "C" int msde_linear_bwd_x(const float* gY, const float* W, int M, int N, 
 }
 
 // split policy of the weight gradient: 128-wide tiles where the output allows, then enough splits of
-// the reduction (M) to put ~2 workgroups on every CU; at most 64 splits so the slab reduce stays short
+// the reduction (M) that ~1024 workgroups are in flight (each then loops over only a few 32-row tiles:
+// the loop is latency bound per tile), at least 64 rows per split, at most 512 splits
 static inline void wgrad_split(int M, int N, int K, int* splits, int* k_per_split) {
   long tiles = (long)((N + (N > 64 ? 127 : 63)) / (N > 64 ? 128 : 64)) * ((K + (K > 64 ? 127 : 63)) / (K > 64 ? 128 : 64));
-  long want = (512 + tiles - 1) / tiles;
-  long maxs = (M + 127) / 128;
+  long want = (1024 + tiles - 1) / tiles;
+  long maxs = (M + 63) / 64;
   if (want > maxs) want = maxs;
-  if (want > 64) want = 64;
+  if (want > 512) want = 512;
   if (want < 1) want = 1;
   int kps = (int)(((M + want - 1) / want + LG_BK - 1) / LG_BK * LG_BK);
   if (kps < LG_BK) kps = LG_BK;
@@ -323,8 +330,8 @@ extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, 
   int rc = launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, true, st);
   if (rc != 0) return rc;
   size_t n = (size_t)N * K;
-  int blocks = (int)((n + (size_t)N + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  int blocks = (int)((n + (size_t)N + 15) / 16);
+  if (blocks > 4096) blocks = 4096;
   MSDE_LAUNCH(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, n, gW, (const float*)cs, (size_t)N,
               gb);
   MSDE_CHECK_LAUNCH();
