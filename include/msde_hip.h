@@ -47,7 +47,8 @@ int msde_radius_fill(const float* pos, const int* batch, const int* mol_ptr, int
 /* torch_scatter.scatter(reduce=sum) over CSR rows: out[i] = sum_{s in [rowptr[i],rowptr[i+1])}
  * rows[perm ? perm[s] : s]; used for every backward "gather by source/target".  D % 4 == 0 or any. */
 int msde_segment_sum_rows(const float* rows, const int* rowptr, const int* perm, int N, int D,
-                          float scale_by_inv_count, float* out, void* stream);
+                          float scale_by_inv_count, float* out, int ldo /* row stride of out, 0 = D */,
+                          void* stream);
 /* out[e] = A[src[e]] + B[dst[e]] (+ bias) for e < E; rows with src<0 are zero-filled.
  * SDE_model_2D_to_3D.py:346-347 (factored cat+Linear), equivariant_scorenetwork.py:154-155 */
 int msde_pair_gather_add(const float* A, const float* B, const int* src, const int* dst, int E,
@@ -132,14 +133,19 @@ int msde_edge_geometry_fwd(const float* pos, const int* src, const int* dst, int
  * out[i] = sum_e dropout(alpha)[e,h] * (v[src]+ee[e]).  H*Ch == D <= 64.  alpha [E,H] is saved.
  * The dropout mask is a pure function of (seed + seed_dev[0]*prime, edge, head); seed_dev (may be
  * NULL) lets a captured hipGraph draw a fresh mask on every replay. */
-int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* ee,
-                            const int* rowptr, const int* src, int N, int H, int Ch,
+int msde_edge_attention_fwd(const float* q, const float* k, const float* v,
+                            const float* skip /* may be NULL, else out += skip (lin_skip(x_i)) */,
+                            int ld /* row stride of q,k,v,skip: they may be column blocks of one
+                                      fused projection [N, 4D] */,
+                            const float* ee, const int* rowptr, const int* src, int N, int H, int Ch,
                             float p_drop, unsigned long long seed,
                             const unsigned long long* seed_dev, float* alpha, float* out,
                             void* stream);
 /* backward of the above: writes g_q [N,D], g_ee [E,D] and the per-edge grads g_kpe/g_vpe [E,D]
  * (to be segment-summed by source into g_k / g_v with msde_segment_sum_rows). */
 int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v,
+                            int ld, float* g_skip /* may be NULL, else receives g_out */,
+                            int ldg /* row stride of g_q and g_skip */,
                             const float* ee, const float* alpha, const int* rowptr,
                             const int* src, int N, int H, int Ch, float p_drop,
                             unsigned long long seed, const unsigned long long* seed_dev,

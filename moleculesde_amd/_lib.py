@@ -20,7 +20,7 @@ SIGNATURES = {
     "msde_radius_count": [P, P, P, I, F, I, P, P],
     "msde_exclusive_scan_i32": [P, P, I, P],
     "msde_radius_fill": [P, P, P, I, F, I, P, P, P, P, I, P],
-    "msde_segment_sum_rows": [P, P, P, I, I, F, P, P],
+    "msde_segment_sum_rows": [P, P, P, I, I, F, P, I, P],
     "msde_pair_gather_add": [P, P, P, P, I, I, P, P],
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
@@ -36,8 +36,8 @@ SIGNATURES = {
     "msde_cfconv_fused_bwd_w_workspace_floats": [I, I],
     "msde_cfconv_fused_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, P, P, P],
     "msde_edge_geometry_fwd": [P, P, P, I, P, P, I, P, P, P, P, P, P],
-    "msde_edge_attention_fwd": [P, P, P, P, P, P, I, I, I, F, ULL, P, P, P, P],
-    "msde_edge_attention_bwd": [P, P, P, P, P, P, P, P, I, I, I, F, ULL, P, P, P, P, P, P],
+    "msde_edge_attention_fwd": [P, P, P, P, I, P, P, P, I, I, I, F, ULL, P, P, P, P],
+    "msde_edge_attention_bwd": [P, P, P, P, I, P, I, P, P, P, P, I, I, I, F, ULL, P, P, P, P, P, P],
     "msde_frame_mix_mean_fwd": [P, P, P, I, P, P],
     "msde_frame_mix_mean_bwd": [P, P, P, I, I, P, P],
     "msde_linear_fwd": [P, P, P, I, I, I, P, P],

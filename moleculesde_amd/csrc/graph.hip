@@ -127,7 +127,7 @@ extern "C" int msde_radius_fill(const float* pos, const int* batch, const int* m
 template <int V>
 __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const int* __restrict__ rowptr,
                                         const int* __restrict__ perm, int N, int cols, int tpr, float mean,
-                                        float* __restrict__ out) {
+                                        float* __restrict__ out, int ldo_cols) {
   using T = typename VecT<V>::type;
   int rpb = blockDim.x / tpr;
   int i = blockIdx.x * rpb + threadIdx.x / tpr;
@@ -144,22 +144,24 @@ __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const in
       int e = perm ? perm[s] : s;
       acc = vadd(acc, R[(size_t)e * cols + c]);
     }
-    O[(size_t)i * cols + c] = vscale(acc, scale);
+    O[(size_t)i * ldo_cols + c] = vscale(acc, scale);
   }
 }
 
 extern "C" int msde_segment_sum_rows(const float* rows, const int* rowptr, const int* perm, int N, int D,
-                                     float scale_by_inv_count, float* out, void* stream) {
+                                     float scale_by_inv_count, float* out, int ldo, void* stream) {
   if (N < 0 || D <= 0 || !rowptr || !out) return MSDE_EINVAL;
+  if (ldo <= 0) ldo = D;
+  if (ldo < D) return MSDE_EINVAL;
   if (N == 0) return 0;
-  if (D % 4 == 0) {
+  if (D % 4 == 0 && ldo % 4 == 0) {
     int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
     MSDE_LAUNCH(segment_sum_rows_kernel<4>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
-                       rowptr, perm, N, cols, tpr, scale_by_inv_count, out);
+                       rowptr, perm, N, cols, tpr, scale_by_inv_count, out, ldo / 4);
   } else {
     int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
     MSDE_LAUNCH(segment_sum_rows_kernel<1>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
-                       rowptr, perm, N, cols, tpr, scale_by_inv_count, out);
+                       rowptr, perm, N, cols, tpr, scale_by_inv_count, out, ldo);
   }
   MSDE_CHECK_LAUNCH();
   return 0;

@@ -78,7 +78,8 @@ extern "C" int msde_edge_geometry_fwd(const float* pos, const int* src, const in
 // ------------------------------------------------------------------------------------------------
 template <int CH>
 __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                          const float* __restrict__ v, const float* __restrict__ ee,
+                                          const float* __restrict__ v, const float* __restrict__ skip, int ld,
+                                          const float* __restrict__ ee,
                                           const int* __restrict__ rowptr, const int* __restrict__ src, int N, int H,
                                           float p_drop, unsigned long long seed,
                                           const unsigned long long* __restrict__ seed_dev,
@@ -90,12 +91,12 @@ __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const flo
   const int D = H * CH;
   float qv[CH];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) qv[c] = q[(size_t)i * D + h * CH + c];
+  for (int c = 0; c < CH; ++c) qv[c] = q[(size_t)i * ld + h * CH + c];
   const float scale = 1.f / sqrtf((float)CH);
   int s0 = rowptr[i], s1 = rowptr[i + 1];
   float m = -INFINITY;
   for (int e = s0; e < s1; ++e) {
-    const float* kr = k + (size_t)src[e] * D + h * CH;
+    const float* kr = k + (size_t)src[e] * ld + h * CH;
     const float* er = ee + (size_t)e * D + h * CH;
     float s = 0.f;
 #pragma unroll
@@ -119,18 +120,20 @@ __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const flo
     float a = alpha[(size_t)e * H + h] * inv;
     alpha[(size_t)e * H + h] = a;
     if (p_drop > 0.f) a = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? a * keep_scale : 0.f;
-    const float* vr = v + (size_t)src[e] * D + h * CH;
+    const float* vr = v + (size_t)src[e] * ld + h * CH;
     const float* er = ee + (size_t)e * D + h * CH;
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = fmaf(a, vr[c] + er[c], acc[c]);
   }
 #pragma unroll
-  for (int c = 0; c < CH; ++c) out[(size_t)i * D + h * CH + c] = acc[c];
+  for (int c = 0; c < CH; ++c)
+    out[(size_t)i * D + h * CH + c] = acc[c] + (skip ? skip[(size_t)i * ld + h * CH + c] : 0.f);   // + lin_skip(x_i)
 }
 
 template <int CH>
 __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ q,
-                                          const float* __restrict__ k, const float* __restrict__ v,
+                                          const float* __restrict__ k, const float* __restrict__ v, int ld,
+                                          float* __restrict__ g_skip, int ldg,
                                           const float* __restrict__ ee, const float* __restrict__ alpha,
                                           const int* __restrict__ rowptr, const int* __restrict__ src, int N, int H,
                                           float p_drop, unsigned long long seed,
@@ -145,9 +148,10 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
   float qv[CH], go[CH], gq[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    qv[c] = q[(size_t)i * D + h * CH + c];
+    qv[c] = q[(size_t)i * ld + h * CH + c];
     go[c] = g_out[(size_t)i * D + h * CH + c];
     gq[c] = 0.f;
+    if (g_skip) g_skip[(size_t)i * ldg + h * CH + c] = go[c];      // d(out)/d(skip) = 1
   }
   const float scale = 1.f / sqrtf((float)CH);
   float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
@@ -158,7 +162,7 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
     float a = alpha[(size_t)e * H + h];
     float ms = 1.f;
     if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
-    const float* vr = v + (size_t)src[e] * D + h * CH;
+    const float* vr = v + (size_t)src[e] * ld + h * CH;
     const float* er = ee + (size_t)e * D + h * CH;
     float ga = 0.f;
 #pragma unroll
@@ -173,8 +177,8 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
     float a = alpha[(size_t)e * H + h];
     float ms = 1.f;
     if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
-    const float* vr = v + (size_t)src[e] * D + h * CH;
-    const float* kr = k + (size_t)src[e] * D + h * CH;
+    const float* vr = v + (size_t)src[e] * ld + h * CH;
+    const float* kr = k + (size_t)src[e] * ld + h * CH;
     const float* er = ee + (size_t)e * D + h * CH;
     float ga = 0.f;
 #pragma unroll
@@ -189,29 +193,31 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
     }
   }
 #pragma unroll
-  for (int c = 0; c < CH; ++c) g_q[(size_t)i * D + h * CH + c] = gq[c];
+  for (int c = 0; c < CH; ++c) g_q[(size_t)i * ldg + h * CH + c] = gq[c];
 }
 
-extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* ee,
+extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
+                                       const float* ee,
                                        const int* rowptr, const int* src, int N, int H, int Ch, float p_drop,
                                        unsigned long long seed, const unsigned long long* seed_dev, float* alpha,
                                        float* out, void* stream) {
   if (N < 0 || H <= 0 || Ch <= 0 || !q || !k || !v || !ee || !rowptr || !src || !alpha || !out) return MSDE_EINVAL;
-  if (p_drop < 0.f || p_drop >= 1.f) return MSDE_EINVAL;
+  if (p_drop < 0.f || p_drop >= 1.f || ld < H * Ch) return MSDE_EINVAL;
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: MSDE_LAUNCH(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
-    case 2: MSDE_LAUNCH(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
-    case 4: MSDE_LAUNCH(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
-    case 8: MSDE_LAUNCH(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 1: MSDE_LAUNCH(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 2: MSDE_LAUNCH(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 4: MSDE_LAUNCH(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 8: MSDE_LAUNCH(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v,
+extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v, int ld,
+                                       float* g_skip, int ldg,
                                        const float* ee, const float* alpha, const int* rowptr, const int* src, int N,
                                        int H, int Ch, float p_drop, unsigned long long seed,
                                        const unsigned long long* seed_dev, float* g_q, float* g_ee, float* g_kpe,
@@ -223,10 +229,10 @@ extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();

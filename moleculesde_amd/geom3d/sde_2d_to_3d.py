@@ -47,11 +47,13 @@ class TransformerConv(nn.Module):
         self.lin_skip = _nn.Linear(in_channels, heads * out_channels, bias=True)
 
     def forward(self, x, edge_attr, plan, seed, seed_dev=None):
-        q, k, v = self.lin_query(x), self.lin_key(x), self.lin_value(x)
+        # one projection GEMM for query | key | value | skip (they share the input x)
+        W = torch.cat([self.lin_query.weight, self.lin_key.weight, self.lin_value.weight, self.lin_skip.weight], dim=0)
+        b = torch.cat([self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias], dim=0)
+        qkvs = _nn.linear(x, W, b)
         ee = self.lin_edge(edge_attr)
         p = self.dropout if self.training else 0.0
-        out = hip.edge_attention(q, k, v, ee, plan, self.heads, p, seed, seed_dev)
-        return out + self.lin_skip(x)
+        return hip.edge_attention_fused(qkvs, ee, plan, self.heads, p, seed, seed_dev)
 
 
 class GATLayer(nn.Module):

@@ -112,11 +112,15 @@ def radius_plan(pos, batch_i32, mol_ptr_i32, cutoff, E_cap, max_nbr=32):
 # ------------------------------------------------------------------------------------------------
 # plain (non-differentiable) launches
 # ------------------------------------------------------------------------------------------------
-def segment_sum_rows(rows, rowptr, perm, N, mean=False):
+def segment_sum_rows(rows, rowptr, perm, N, mean=False, out=None, ldo=0):
+    """out[i] = sum of rows over CSR row i; `out`/`ldo` let the result land in a column block of a wider
+    buffer (row stride ldo floats)."""
     rows = _f32(rows)
     D = rows.size(1)
-    out = torch.empty(N, D, dtype=torch.float32, device=rows.device)
-    _lib.call("msde_segment_sum_rows", _p(rows), _p(rowptr), _p(perm), N, D, 1.0 if mean else 0.0, _p(out), _stream())
+    if out is None:
+        out = torch.empty(N, D, dtype=torch.float32, device=rows.device)
+    _lib.call("msde_segment_sum_rows", _p(rows), _p(rowptr), _p(perm), N, D, 1.0 if mean else 0.0, _p(out), int(ldo),
+              _stream())
     return out
 
 
@@ -431,8 +435,8 @@ class _EdgeAttention(torch.autograd.Function):
         Ch = D // heads
         alpha = torch.empty(plan.E, heads, dtype=torch.float32, device=q.device)
         out = torch.empty_like(q)
-        _lib.call("msde_edge_attention_fwd", _p(q), _p(k), _p(v), _p(ee), _p(plan.rowptr), _p(plan.src), N, heads, Ch,
-                  float(p_drop), int(seed), _p(seed_dev), _p(alpha), _p(out), _stream())
+        _lib.call("msde_edge_attention_fwd", _p(q), _p(k), _p(v), _p(None), D, _p(ee), _p(plan.rowptr), _p(plan.src), N,
+                  heads, Ch, float(p_drop), int(seed), _p(seed_dev), _p(alpha), _p(out), _stream())
         ctx.save_for_backward(q, k, v, ee, alpha)
         ctx.plan, ctx.heads, ctx.p_drop, ctx.seed, ctx.seed_dev = plan, heads, float(p_drop), int(seed), seed_dev
         return out
@@ -447,12 +451,62 @@ class _EdgeAttention(torch.autograd.Function):
         g_ee = torch.empty_like(ee)
         g_kpe = torch.empty_like(ee)
         g_vpe = torch.empty_like(ee)
-        _lib.call("msde_edge_attention_bwd", _p(g), _p(q), _p(k), _p(v), _p(ee), _p(alpha), _p(plan.rowptr),
-                  _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), _p(g_q), _p(g_ee), _p(g_kpe),
-                  _p(g_vpe), _stream())
+        _lib.call("msde_edge_attention_bwd", _p(g), _p(q), _p(k), _p(v), D, _p(None), D, _p(ee), _p(alpha),
+                  _p(plan.rowptr), _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), _p(g_q), _p(g_ee),
+                  _p(g_kpe), _p(g_vpe), _stream())
         g_k = segment_sum_rows(g_kpe, plan.rowptr_s, plan.perm_s, N)
         g_v = segment_sum_rows(g_vpe, plan.rowptr_s, plan.perm_s, N)
         return g_q, g_k, g_v, g_ee, None, None, None, None, None
+
+
+class _EdgeAttentionFused(torch.autograd.Function):
+    """TransformerConv with ONE fused projection: qkvs = [q | k | v | skip] as column blocks of a [N, 4D]
+    buffer (one GEMM instead of four); out = attention(q, k, v, ee) + skip.  The backward writes g_q and
+    g_skip straight into their column blocks of g_qkvs and lets the two by-source segment sums land in
+    the k and v blocks, so the projection needs one dgrad + one wgrad."""
+
+    @staticmethod
+    def forward(ctx, qkvs, ee, plan, heads, p_drop, seed, seed_dev):
+        qkvs, ee = _f32(qkvs), _f32(ee)
+        N, D4 = qkvs.shape
+        D = D4 // 4
+        Ch = D // heads
+        alpha = torch.empty(plan.E, heads, dtype=torch.float32, device=qkvs.device)
+        out = torch.empty(N, D, dtype=torch.float32, device=qkvs.device)
+        base = qkvs.data_ptr()
+        pq, pk, pv, ps = (ctypes.c_void_p(base + 4 * D * j) for j in range(4))
+        _lib.call("msde_edge_attention_fwd", pq, pk, pv, ps, D4, _p(ee), _p(plan.rowptr), _p(plan.src), N, heads, Ch,
+                  float(p_drop), int(seed), _p(seed_dev), _p(alpha), _p(out), _stream())
+        ctx.save_for_backward(qkvs, ee, alpha)
+        ctx.plan, ctx.heads, ctx.p_drop, ctx.seed, ctx.seed_dev = plan, heads, float(p_drop), int(seed), seed_dev
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkvs, ee, alpha = ctx.saved_tensors
+        plan, H = ctx.plan, ctx.heads
+        g = _f32(g)
+        N, D4 = qkvs.shape
+        D = D4 // 4
+        g_qkvs = torch.empty_like(qkvs)
+        g_ee = torch.empty_like(ee)
+        g_kpe = torch.empty_like(ee)
+        g_vpe = torch.empty_like(ee)
+        base, gbase = qkvs.data_ptr(), g_qkvs.data_ptr()
+        pq, pk, pv = (ctypes.c_void_p(base + 4 * D * j) for j in range(3))
+        gq, gk, gv, gs = (ctypes.c_void_p(gbase + 4 * D * j) for j in range(4))
+        _lib.call("msde_edge_attention_bwd", _p(g), pq, pk, pv, D4, gs, D4, _p(ee), _p(alpha), _p(plan.rowptr),
+                  _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), gq, _p(g_ee), _p(g_kpe), _p(g_vpe),
+                  _stream())
+        st = _stream()
+        _lib.call("msde_segment_sum_rows", _p(g_kpe), _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gk, D4, st)
+        _lib.call("msde_segment_sum_rows", _p(g_vpe), _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gv, D4, st)
+        return g_qkvs, g_ee, None, None, None, None, None
+
+
+def edge_attention_fused(qkvs, ee, plan, heads, p_drop=0.0, seed=0, seed_dev=None):
+    """attention(q, k, v, ee) + skip with q, k, v, skip = column blocks of qkvs [N, 4D]."""
+    return _EdgeAttentionFused.apply(qkvs, ee, plan, heads, p_drop, seed, seed_dev)
 
 
 def edge_attention(q, k, v, ee, plan, heads, p_drop=0.0, seed=0, seed_dev=None):
