@@ -47,7 +47,7 @@ int msde_radius_fill(const float* pos, const int* batch, const int* mol_ptr, int
 /* torch_scatter.scatter(reduce=sum) over CSR rows: out[i] = sum_{s in [rowptr[i],rowptr[i+1])}
  * rows[perm ? perm[s] : s]; used for every backward "gather by source/target".  D % 4 == 0 or any. */
 int msde_segment_sum_rows(const float* rows, const int* rowptr, const int* perm, int N, int D,
-                          float scale_by_inv_count, float* out, int ldo /* row stride of out, 0 = D */,
+                          float scale_by_inv_count, float* out, int ldo /* row stride of out (0 = D) */,
                           void* stream);
 /* out[e] = A[src[e]] + B[dst[e]] (+ bias) for e < E; rows with src<0 are zero-filled.
  * SDE_model_2D_to_3D.py:346-347 (factored cat+Linear), equivariant_scorenetwork.py:154-155 */
