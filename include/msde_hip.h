@@ -172,6 +172,16 @@ long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K);
 int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, float* gW, float* gb,
                       float* workspace, void* stream);
 
+/* ------------------------------------------------------------------ contrastive loss ------- */
+/* do_CL('EBM_node_dot_prod') in both directions + dual_CL — examples/util.py:52-68,76-79.
+ * perm1/perm2: the two negative-sample permutations (torch.randperm).  out[0] = loss, out[1] = accuracy.
+ * rows [N,3] (p, n1, n2 logits) and inv1/inv2 [N] (inverse permutations) feed the backward. */
+int msde_cl_ebm_fwd(const float* X, const float* Y, const int* perm1, const int* perm2, int N, int D,
+                    float invT, float* rows, int* inv1, int* inv2, float* out, void* stream);
+int msde_cl_ebm_bwd(const float* X, const float* Y, const int* perm1, const int* perm2,
+                    const int* inv1, const int* inv2, const float* rows, const float* g_loss, int N,
+                    int D, float invT, float* gX, float* gY, void* stream);
+
 /* ------------------------------------------------------------------ normalisation ---------- */
 /* nn.BatchNorm1d in training mode over the rows of X[M,C], optional fused ReLU —
  * molecule_gnn_model.py:17,176-182; SDE_model_2D_to_3D.py:265.  Batch statistics by Welford partials

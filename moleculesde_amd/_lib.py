@@ -44,6 +44,8 @@ SIGNATURES = {
     "msde_linear_bwd_x": [P, P, I, I, I, P, P],
     "msde_linear_bwd_w_workspace_bytes": [I, I, I],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
+    "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],
+    "msde_cl_ebm_bwd": [P, P, P, P, P, P, P, P, I, I, F, P, P, P],
     "msde_bn_workspace_floats": [I, I],
     "msde_colsum": [P, I, I, P, P, P],
     "msde_bn_fwd": [P, I, I, P, P, F, F, P, P, I, P, P, P, P, P],

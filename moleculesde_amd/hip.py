@@ -686,6 +686,42 @@ def linear(x, weight, bias=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# contrastive loss
+# ------------------------------------------------------------------------------------------------
+class _ContrastiveEBM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, Y, perm1, perm2, T):
+        X, Y = _f32(X), _f32(Y)
+        N, D = X.shape
+        p1, p2 = _i32(perm1), _i32(perm2)
+        rows = torch.empty(N, 3, dtype=torch.float32, device=X.device)
+        inv1 = torch.empty(N, dtype=torch.int32, device=X.device)
+        inv2 = torch.empty(N, dtype=torch.int32, device=X.device)
+        out = torch.empty(2, dtype=torch.float32, device=X.device)
+        _lib.call("msde_cl_ebm_fwd", _p(X), _p(Y), _p(p1), _p(p2), N, D, 1.0 / float(T), _p(rows), _p(inv1), _p(inv2),
+                  _p(out), _stream())
+        ctx.save_for_backward(X, Y, p1, p2, inv1, inv2, rows)
+        ctx.invT = 1.0 / float(T)
+        ctx.mark_non_differentiable(out[1:])
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_acc):
+        X, Y, p1, p2, inv1, inv2, rows = ctx.saved_tensors
+        N, D = X.shape
+        gX, gY = torch.empty_like(X), torch.empty_like(Y)
+        g = _f32(g_loss).reshape(1)
+        _lib.call("msde_cl_ebm_bwd", _p(X), _p(Y), _p(p1), _p(p2), _p(inv1), _p(inv2), _p(rows), _p(g), N, D, ctx.invT,
+                  _p(gX), _p(gY), _stream())
+        return gX, gY, None, None, None
+
+
+def contrastive_ebm(X, Y, perm1, perm2, T):
+    """dual_CL with 'EBM_node_dot_prod' (examples/util.py:52-68,76-79): returns (loss, accuracy)."""
+    return _ContrastiveEBM.apply(X, Y, perm1, perm2, T)
+
+
+# ------------------------------------------------------------------------------------------------
 # normalisation
 # ------------------------------------------------------------------------------------------------
 _BN_WS = {}

@@ -81,6 +81,8 @@ def readme_args(**over):
     return args
 
 
+USE_FUSED_CL = True
+
 _SDE_RANGES_2D3D = {"VE": ("VE", 0.2, 1.0), "VP": ("VP", 0.2, 1.0), "VE02": ("VE", 0.1, 10.0), "VP02": ("VP", 0.2, 30.0),
                     "VE03": ("VE", 0.1, 1000.0), "VP03": ("VP", 0.2, 1000.0)}
 
@@ -136,7 +138,13 @@ def do_CL(X, Y, args, noise, neg_index=None):
 
 
 def dual_CL(X, Y, args, noise, neg_indices=(None, None)):
-    """examples/util.py:76-79; the accuracy stays a device scalar (no sync)."""
+    """examples/util.py:76-79; the accuracy stays a device scalar (no sync).  On the HIP device both
+    directions run as one fused kernel pair (csrc/contrastive.hip)."""
+    if X.is_cuda and args.CL_similarity_metric == "EBM_node_dot_prod" and USE_FUSED_CL:
+        n1 = neg_indices[0] if neg_indices[0] is not None else noise.randperm(len(Y), Y.device)
+        n2 = neg_indices[1] if neg_indices[1] is not None else noise.randperm(len(X), X.device)
+        from . import hip
+        return hip.contrastive_ebm(X, Y, n1, n2, args.T)
     l1, a1 = do_CL(X, Y, args, noise, neg_indices[0])
     l2, a2 = do_CL(Y, X, args, noise, neg_indices[1])
     return (l1 + l2) / 2, (a1 + a2) / 2

@@ -478,3 +478,23 @@ def test_batchnorm_train_kernels(dev, M, C, relu):
     assert_close(bd.grad, bn.bias.grad, 1e-4, 1e-4 * float(bn.bias.grad.abs().max()) + 1e-6, "bn dbeta")
     assert_close(rm, bn.running_mean, 1e-5, 1e-6, "running mean")
     assert_close(rv, bn.running_var, 1e-4, 1e-6, "running var")
+
+
+@pytest.mark.parametrize("N,D", [(3588, 300), (50, 16), (7, 5)])
+def test_contrastive_ebm_kernels(dev, N, D):
+    """Fused dual EBM-NCE loss (csrc/contrastive.hip) vs the oracle's dual_CL with the same permutations."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(N + D)
+    X = (torch.randn(N, D, generator=g) * 0.3).requires_grad_(True)
+    Y = (torch.randn(N, D, generator=g) * 0.3).requires_grad_(True)
+    p1, p2 = torch.randperm(N, generator=g), torch.randperm(N, generator=g)
+    ref, acc_ref = R.dual_CL(X, Y, 0.1, p1, p2)
+    (ref * 1.7).backward()
+    Xd = X.detach().to(dev).requires_grad_(True)
+    Yd = Y.detach().to(dev).requires_grad_(True)
+    loss, acc = hip.contrastive_ebm(Xd, Yd, p1.to(dev), p2.to(dev), 0.1)
+    assert_close(loss, ref.detach(), 1e-5, 1e-6, "CL loss")
+    assert abs(float(acc) - acc_ref) < 1e-6
+    (loss * 1.7).backward()
+    assert_close(Xd.grad, X.grad, 1e-4, 1e-5 * float(X.grad.abs().max()), "CL gX")
+    assert_close(Yd.grad, Y.grad, 1e-4, 1e-5 * float(Y.grad.abs().max()), "CL gY")
