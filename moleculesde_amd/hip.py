@@ -702,15 +702,14 @@ class _ContrastiveEBM(torch.autograd.Function):
                   _p(out), _stream())
         ctx.save_for_backward(X, Y, p1, p2, inv1, inv2, rows)
         ctx.invT = 1.0 / float(T)
-        ctx.mark_non_differentiable(out[1:])
-        return out[0], out[1]
+        return out                         # [loss, accuracy]; split by the caller (plain autograd views)
 
     @staticmethod
-    def backward(ctx, g_loss, g_acc):
+    def backward(ctx, g_out):
         X, Y, p1, p2, inv1, inv2, rows = ctx.saved_tensors
         N, D = X.shape
         gX, gY = torch.empty_like(X), torch.empty_like(Y)
-        g = _f32(g_loss).reshape(1)
+        g = _f32(g_out)                    # g[0] = d/d(loss); the accuracy carries no gradient
         _lib.call("msde_cl_ebm_bwd", _p(X), _p(Y), _p(p1), _p(p2), _p(inv1), _p(inv2), _p(rows), _p(g), N, D, ctx.invT,
                   _p(gX), _p(gY), _stream())
         return gX, gY, None, None, None
@@ -718,7 +717,8 @@ class _ContrastiveEBM(torch.autograd.Function):
 
 def contrastive_ebm(X, Y, perm1, perm2, T):
     """dual_CL with 'EBM_node_dot_prod' (examples/util.py:52-68,76-79): returns (loss, accuracy)."""
-    return _ContrastiveEBM.apply(X, Y, perm1, perm2, T)
+    out = _ContrastiveEBM.apply(X, Y, perm1, perm2, T)
+    return out[0], out[1].detach()
 
 
 # ------------------------------------------------------------------------------------------------
