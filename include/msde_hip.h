@@ -195,6 +195,17 @@ int msde_bn_bwd(const float* dY, const float* X, const float* save_mean, const f
                 const float* gamma, const float* beta, int relu, int M, int C, float* dX,
                 float* dgamma, float* dbeta, float* workspace, void* stream);
 
+/* y = res + LayerNorm(x) over rows of D floats (res may be NULL) — GATLayer, equivariant_scorenetwork.py:36,38.
+ * mean/rstd [N] are saved for the backward.  D % 4 == 0, D <= 1024. */
+int msde_res_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                           int N, int D, float eps, float* y, float* mean, float* rstd,
+                           void* stream);
+/* gx (the residual branch's gradient is g itself), and [ggamma | gbeta] which must be one contiguous
+ * buffer of 2*D floats (gbeta == ggamma + D).  workspace: 64 * 2 * D floats. */
+int msde_res_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean,
+                           const float* rstd, int N, int D, float* gx, float* ggamma, float* gbeta,
+                           float* workspace, void* stream);
+
 /* out[c] = sum_m X[m,c] (bias gradient of an nn.Linear when the vendor GEMM computes the weight
  * gradient); workspace: msde_bn_workspace_floats(M, C) floats; fixed summation order. */
 int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void* stream);

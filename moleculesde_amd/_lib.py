@@ -48,6 +48,8 @@ SIGNATURES = {
     "msde_cl_ebm_bwd": [P, P, P, P, P, P, P, P, I, I, F, P, P, P],
     "msde_bn_workspace_floats": [I, I],
     "msde_colsum": [P, I, I, P, P, P],
+    "msde_res_layernorm_fwd": [P, P, P, P, I, I, F, P, P, P, P],
+    "msde_res_layernorm_bwd": [P, P, P, P, P, I, I, P, P, P, P, P],
     "msde_bn_fwd": [P, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
     "msde_bn_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P],
     "msde_adam_flat": [P, P, P, P, LL, P, P, P, I, F, F, F, F, F, P],

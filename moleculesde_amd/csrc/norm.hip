@@ -286,3 +286,151 @@ extern "C" int msde_bn_bwd(const float* dY, const float* X, const float* save_me
   MSDE_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// y = res + LayerNorm(x)  (GATLayer: node_attr + norm(x), equivariant_scorenetwork.py:36,38), rows of D
+// floats; one group of TPR lanes per row, the row lives in registers (D <= 4*TPR*LN_MAXV).
+// ------------------------------------------------------------------------------------------------
+#define LN_MAXV 4
+#define LN_BLOCKS 64
+
+__global__ void __launch_bounds__(256)
+res_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, int N, int cols, int tpr, float eps, float* __restrict__ y,
+                         float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  const int gpb = 256 / tpr;
+  const int lane = threadIdx.x % tpr;
+  const float invD = 1.f / (float)(cols * 4);
+  for (int i = blockIdx.x * gpb + threadIdx.x / tpr; i < N; i += gridDim.x * gpb) {
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+      int c = lane + u * tpr;
+      v[u] = c < cols ? reinterpret_cast<const float4*>(x)[(size_t)i * cols + c] : vzero4();
+      s += vhsum(v[u]);
+    }
+    float mu = group_sum(s, tpr) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+      int c = lane + u * tpr;
+      if (c < cols) {
+        float4 d = make_float4(v[u].x - mu, v[u].y - mu, v[u].z - mu, v[u].w - mu);
+        q += vhsum(vmul(d, d));
+      }
+    }
+    float rs = rsqrtf(group_sum(q, tpr) * invD + eps);
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+      int c = lane + u * tpr;
+      if (c < cols) {
+        float4 g = reinterpret_cast<const float4*>(gamma)[c], b = reinterpret_cast<const float4*>(beta)[c];
+        float4 o = make_float4(fmaf((v[u].x - mu) * rs, g.x, b.x), fmaf((v[u].y - mu) * rs, g.y, b.y),
+                               fmaf((v[u].z - mu) * rs, g.z, b.z), fmaf((v[u].w - mu) * rs, g.w, b.w));
+        if (res) o = vadd(o, reinterpret_cast<const float4*>(res)[(size_t)i * cols + c]);
+        reinterpret_cast<float4*>(y)[(size_t)i * cols + c] = o;
+      }
+    }
+    if (lane == 0) { mean_o[i] = mu; rstd_o[i] = rs; }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+res_layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ gamma,
+                         const float* __restrict__ mean, const float* __restrict__ rstd, int N, int cols, int tpr,
+                         float* __restrict__ gx, float* __restrict__ ws) {
+  extern __shared__ float lds[];      // [gpb][2 * D] partial gamma/beta sums of the block's groups
+  const int gpb = 256 / tpr;
+  const int lane = threadIdx.x % tpr, grp = threadIdx.x / tpr;
+  const int D = cols * 4;
+  const float invD = 1.f / (float)D;
+  float4 sg[LN_MAXV], sb[LN_MAXV];
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) { sg[u] = vzero4(); sb[u] = vzero4(); }
+  for (int i = blockIdx.x * gpb + grp; i < N; i += gridDim.x * gpb) {
+    float mu = mean[i], rs = rstd[i];
+    float4 gg[LN_MAXV], xh[LN_MAXV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+      int c = lane + u * tpr;
+      gg[u] = vzero4(); xh[u] = vzero4();
+      if (c < cols) {
+        float4 gv = reinterpret_cast<const float4*>(g)[(size_t)i * cols + c];
+        float4 xv = reinterpret_cast<const float4*>(x)[(size_t)i * cols + c];
+        float4 gm = reinterpret_cast<const float4*>(gamma)[c];
+        xh[u] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        sb[u] = vadd(sb[u], gv);
+        sg[u] = vfma(gv, xh[u], sg[u]);
+        gg[u] = vmul(gv, gm);
+        c1 += vhsum(gg[u]);
+        c2 += vhsum(vmul(gg[u], xh[u]));
+      }
+    }
+    c1 = group_sum(c1, tpr) * invD;
+    c2 = group_sum(c2, tpr) * invD;
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+      int c = lane + u * tpr;
+      if (c < cols)
+        reinterpret_cast<float4*>(gx)[(size_t)i * cols + c] =
+            make_float4(rs * (gg[u].x - c1 - xh[u].x * c2), rs * (gg[u].y - c1 - xh[u].y * c2),
+                        rs * (gg[u].z - c1 - xh[u].z * c2), rs * (gg[u].w - c1 - xh[u].w * c2));
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < LN_MAXV; ++u) {
+    int c = lane + u * tpr;
+    if (c < cols) {
+      reinterpret_cast<float4*>(lds + (size_t)grp * 2 * D)[c] = sg[u];
+      reinterpret_cast<float4*>(lds + (size_t)grp * 2 * D + D)[c] = sb[u];
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * D; t += 256) {
+    float acc = 0.f;
+    for (int q = 0; q < gpb; ++q) acc += lds[(size_t)q * 2 * D + t];
+    ws[(size_t)blockIdx.x * 2 * D + t] = acc;      // [block][gamma D | beta D]
+  }
+}
+
+extern "C" int msde_res_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int N,
+                                      int D, float eps, float* y, float* mean, float* rstd, void* stream) {
+  if (N < 0 || D <= 0 || !x || !gamma || !beta || !y || !mean || !rstd) return MSDE_EINVAL;
+  if (D % 4 != 0) return MSDE_EUNSUP;
+  int cols = D / 4, tpr = pick_tpr(cols);
+  if (cols > tpr * LN_MAXV) return MSDE_EUNSUP;
+  if (N == 0) return 0;
+  int gpb = 256 / tpr;
+  int blocks = (N + gpb - 1) / gpb;
+  if (blocks > 1024) blocks = 1024;
+  MSDE_LAUNCH(res_layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, res, gamma, beta, N, cols, tpr,
+              eps, y, mean, rstd);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_res_layernorm_bwd(const float* g, const float* x, const float* gamma, const float* mean,
+                                      const float* rstd, int N, int D, float* gx, float* ggamma, float* gbeta,
+                                      float* workspace /* LN_BLOCKS * 2 * D floats */, void* stream) {
+  if (N <= 0 || D <= 0 || !g || !x || !gamma || !mean || !rstd || !gx || !ggamma || !gbeta || !workspace) return MSDE_EINVAL;
+  if (D % 4 != 0) return MSDE_EUNSUP;
+  int cols = D / 4, tpr = pick_tpr(cols);
+  if (cols > tpr * LN_MAXV) return MSDE_EUNSUP;
+  int gpb = 256 / tpr;
+  hipStream_t st = as_stream(stream);
+  MSDE_LAUNCH(res_layernorm_bwd_kernel, dim3(LN_BLOCKS), dim3(256), (size_t)gpb * 2 * D * sizeof(float), st, g, x, gamma,
+              mean, rstd, N, cols, tpr, gx, workspace);
+  MSDE_CHECK_LAUNCH();
+  // workspace is [LN_BLOCKS][2D]: the column-sum finaliser produces [ggamma | gbeta] when they are contiguous,
+  // otherwise two launches on the two halves
+  if (gbeta == ggamma + D) {
+    MSDE_LAUNCH(colsum_final_kernel, dim3((2 * D + BN_COLS - 1) / BN_COLS), dim3(256), 0, st, (const float*)workspace,
+                LN_BLOCKS, 2 * D, ggamma);
+    MSDE_CHECK_LAUNCH();
+  } else {
+    return MSDE_EINVAL;
+  }
+  return 0;
+}

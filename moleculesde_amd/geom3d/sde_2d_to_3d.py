@@ -68,6 +68,10 @@ class GATLayer(nn.Module):
 
     def forward(self, plan, node_attr, edge_attr, seed, seed_dev=None):
         x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev)
+        if x.is_cuda and x.size(-1) % 4 == 0:
+            node_attr = hip.res_layernorm(x, node_attr, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x = self.FFN(node_attr)
+            return hip.res_layernorm(x, node_attr, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         node_attr = node_attr + self.norm1(x)
         x = self.FFN(node_attr)
         return node_attr + self.norm2(x)

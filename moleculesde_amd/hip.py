@@ -771,6 +771,38 @@ def batch_norm_train(x, gamma, beta, running_mean, running_var, eps, momentum, r
     return _BatchNormTrain.apply(x, gamma, beta, running_mean, running_var, eps, momentum, relu)
 
 
+class _ResLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps):
+        x = _f32(x)
+        N, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(N, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(N, dtype=torch.float32, device=x.device)
+        _lib.call("msde_res_layernorm_fwd", _p(x), _p(_f32(res) if res is not None else None), _p(gamma), _p(beta), N, D,
+                  float(eps), _p(y), _p(mean), _p(rstd), _stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        g = _f32(g)
+        N, D = x.shape
+        gx = torch.empty_like(x)
+        gab = torch.empty(2 * D, dtype=torch.float32, device=x.device)
+        ws = _bn_workspace(64 * 2, D, x.device)           # >= 64 * 2 * D floats
+        _lib.call("msde_res_layernorm_bwd", _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), N, D, _p(gx), _p(gab),
+                  ctypes.c_void_p(gab.data_ptr() + 4 * D), _p(ws), _stream())
+        return gx, (g if ctx.has_res else None), gab[:D], gab[D:], None
+
+
+def res_layernorm(x, res, gamma, beta, eps=1e-5):
+    """res + LayerNorm(x) in one kernel (backward: one kernel + a column-sum finaliser)."""
+    return _ResLayerNorm.apply(x, res, gamma, beta, eps)
+
+
 # ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------

@@ -498,3 +498,29 @@ def test_contrastive_ebm_kernels(dev, N, D):
     (loss * 1.7).backward()
     assert_close(Xd.grad, X.grad, 1e-4, 1e-5 * float(X.grad.abs().max()), "CL gX")
     assert_close(Yd.grad, Y.grad, 1e-4, 1e-5 * float(Y.grad.abs().max()), "CL gY")
+
+
+@pytest.mark.parametrize("N,D,with_res", [(3588, 32, True), (100, 300, True), (5, 8, False), (777, 64, True)])
+def test_res_layernorm_kernels(dev, N, D, with_res):
+    from moleculesde_amd import hip
+    torch.manual_seed(N + D)
+    x = torch.randn(N, D, requires_grad=True)
+    res = torch.randn(N, D, requires_grad=True) if with_res else None
+    ln = torch.nn.LayerNorm(D)
+    with torch.no_grad():
+        ln.weight.normal_(1, 0.3); ln.bias.normal_(0, 0.3)
+    y = ln(x) + (res if with_res else 0)
+    w = torch.randn(N, D)
+    (y * w).sum().backward()
+    xd = x.detach().to(dev).requires_grad_(True)
+    rd = res.detach().to(dev).requires_grad_(True) if with_res else None
+    gd = ln.weight.detach().to(dev).requires_grad_(True)
+    bd = ln.bias.detach().to(dev).requires_grad_(True)
+    yd = hip.res_layernorm(xd, rd, gd, bd, ln.eps)
+    assert_close(yd, y.detach(), 1e-4, 1e-5, "res+LN fwd")
+    (yd * w.to(dev)).sum().backward()
+    assert_close(xd.grad, x.grad, 1e-3, 1e-5, "LN gx")
+    if with_res:
+        assert_close(rd.grad, res.grad, 0, 0, "LN g_res")
+    assert_close(gd.grad, ln.weight.grad, 1e-4, 1e-4 * float(ln.weight.grad.abs().max()), "LN ggamma")
+    assert_close(bd.grad, ln.bias.grad, 1e-4, 1e-4 * float(ln.bias.grad.abs().max()), "LN gbeta")
