@@ -17,15 +17,30 @@ bn_stats_partial_kernel(const float* __restrict__ X, int M, int C, int rows_per_
   const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
   const int c = blockIdx.x * BN_COLS + tx;
   const int r0 = blockIdx.y * rows_per_split, r1 = min(r0 + rows_per_split, M);
+  // shifted sums s1 = sum(x - x0), s2 = sum((x - x0)^2) with x0 = the lane's first row (close to the mean,
+  // so no catastrophic cancellation): independent accumulators, four loads in flight per thread
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (c < C) {
-    for (int r = r0 + ty; r < r1; r += BN_RL) {
-      float x = X[(size_t)r * C + c];
-      n += 1.f;
-      float d = x - mean;
-      mean += d / n;
-      m2 = fmaf(d, x - mean, m2);
+  if (c < C && r0 + ty < r1) {
+    const float x0 = X[(size_t)(r0 + ty) * C + c];
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f, d1 = 0.f, d2 = 0.f;
+    int r = r0 + ty;
+    for (; r + 3 * BN_RL < r1; r += 4 * BN_RL) {
+      float xa = X[(size_t)r * C + c] - x0, xb = X[(size_t)(r + BN_RL) * C + c] - x0;
+      float xc = X[(size_t)(r + 2 * BN_RL) * C + c] - x0, xd = X[(size_t)(r + 3 * BN_RL) * C + c] - x0;
+      a1 += xa; a2 = fmaf(xa, xa, a2);
+      b1 += xb; b2 = fmaf(xb, xb, b2);
+      c1 += xc; c2 = fmaf(xc, xc, c2);
+      d1 += xd; d2 = fmaf(xd, xd, d2);
+      n += 4.f;
     }
+    for (; r < r1; r += BN_RL) {
+      float xa = X[(size_t)r * C + c] - x0;
+      a1 += xa; a2 = fmaf(xa, xa, a2);
+      n += 1.f;
+    }
+    float s1 = (a1 + b1) + (c1 + d1), s2 = (a2 + b2) + (c2 + d2);
+    mean = x0 + s1 / n;
+    m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
   }
   s_n[ty][tx] = n; s_mean[ty][tx] = mean; s_m2[ty][tx] = m2;
   __syncthreads();
@@ -136,13 +151,25 @@ bn_bwd_partial_kernel(const float* __restrict__ dY, const float* __restrict__ X,
   float sa = 0.f, sb = 0.f;
   if (c < C) {
     float mu = mean[c], rs = rstd[c], g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    for (int r = r0 + ty; r < r1; r += BN_RL) {
+    float sa2 = 0.f, sb2 = 0.f;
+    int r = r0 + ty;
+    for (; r + BN_RL < r1; r += 2 * BN_RL) {       // two independent rows in flight
+      float x0 = X[(size_t)r * C + c], x1 = X[(size_t)(r + BN_RL) * C + c];
+      float d0 = dY[(size_t)r * C + c], d1 = dY[(size_t)(r + BN_RL) * C + c];
+      float h0 = (x0 - mu) * rs, h1 = (x1 - mu) * rs;
+      if (relu && !(fmaf(h0, g, b) > 0.f)) d0 = 0.f;
+      if (relu && !(fmaf(h1, g, b) > 0.f)) d1 = 0.f;
+      sa += d0; sb = fmaf(d0, h0, sb);
+      sa2 += d1; sb2 = fmaf(d1, h1, sb2);
+    }
+    for (; r < r1; r += BN_RL) {
       float xh = (X[(size_t)r * C + c] - mu) * rs;
       float dz = dY[(size_t)r * C + c];
       if (relu && !(fmaf(xh, g, b) > 0.f)) dz = 0.f;
       sa += dz;
       sb = fmaf(dz, xh, sb);
     }
+    sa += sa2; sb += sb2;
   }
   s_a[ty][tx] = sa; s_b[ty][tx] = sb;
   __syncthreads();

@@ -622,6 +622,7 @@ import os as _os
 
 _LINEAR_MODE = _os.environ.get("MSDE_LINEAR", "auto")
 WGRAD_HIP_MIN_ROWS = 8192
+WGRAD_HIP_MAX_SMALL = 40000      # node-level layers with N*K below this: split-M kernel (bias grad fused) wins
 
 
 def set_linear_mode(mode):
@@ -665,7 +666,8 @@ class _Linear(torch.autograd.Function):
                 gx = torch.mm(g2, w)
             gx = gx.view(ctx.in_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
+            use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and
+                                                (M >= WGRAD_HIP_MIN_ROWS or (N * K <= WGRAD_HIP_MAX_SMALL and M >= 256)))
             if use_hip:
                 gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
                 gb = torch.empty(N, dtype=torch.float32, device=g2.device) if ctx.has_bias else None
