@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct synthetic batches cycled through")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host (no hipGraph replay)")
+    ap.add_argument("--debug_dp_path", action="store_true",
+                    help="one GPU: initialise a 1-rank RCCL group and run the multi-GPU step structure "
+                         "(graph without Adam; all-reduce; Adam kernel)")
     ap.add_argument("--full", action="store_true",
                     help="configs[2] per-GPU work: add the 3D->2D dense head loss (default: configs[1])")
     a = ap.parse_args()
@@ -198,7 +201,7 @@ def main():
     from moleculesde_amd.geom3d import prepare_batch
     from moleculesde_amd.synthetic import make_batch, batch_stats
     _lib.load()
-    rank, world, local = dp.init_from_env("cuda")
+    rank, world, local = dp.init_from_env("cuda", force=a.debug_dp_path)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
@@ -208,6 +211,7 @@ def main():
 
     args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=1 if a.full else 0, batch_size=a.batch_size)
     trainer = pretrain.Trainer(args, device)
+    trainer.adam_outside_graph = a.debug_dp_path
     cpu_pool = [make_batch(a.batch_size, seed=dp.shard_seed(s, rank)) for s in range(a.pool)]
     stats = batch_stats(cpu_pool[0])
     pool = [prepare_batch(b, device) for b in cpu_pool]
@@ -274,7 +278,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.batch_size)
         print(json.dumps(out), flush=True)
     dp.barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -10,12 +10,18 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(device_type="cuda"):
+FORCE_COLLECTIVES = False    # debug: run the collectives even at world size 1 (exercises RCCL on one GPU)
+
+
+def init_from_env(device_type="cuda", force=False):
     """Initialise the process group from torchrun's environment; returns (rank, world, local_rank)."""
+    global FORCE_COLLECTIVES
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force:
+        FORCE_COLLECTIVES = True
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = "nccl" if device_type == "cuda" else "gloo"
@@ -34,7 +40,7 @@ def world_size():
 
 def broadcast_flat(flat, src=0):
     """Make every replica start from rank `src`'s parameters."""
-    if world_size() > 1:
+    if world_size() > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
         dist.broadcast(flat, src=src)
     return flat
 
@@ -43,7 +49,7 @@ def allreduce_mean_(flat):
     """Sum the flat gradient buffer over ranks (in place); returns the scale (1/world) that the
     optimiser kernel applies, so no extra pass over the buffer is spent on the division."""
     w = world_size()
-    if w > 1:
+    if w > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return 1.0 / w
 

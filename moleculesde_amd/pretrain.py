@@ -271,7 +271,9 @@ class Trainer:
         g = torch.cuda.CUDAGraph()
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=self._graph_pool):
+        # thread_local: other threads of the process (the RCCL watchdog under DP) may issue HIP calls
+        # while this thread captures; they must not invalidate the capture
+        with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             loss = self._graph_body(batch, with_adam)
         self._graphs[key] = g
         self._graph_loss[key] = loss
