@@ -3,28 +3,37 @@
 // in ONE kernel with fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 fma chain in k order).
 //
 // Mapping (F = 128):
-//   * the by-target CSR edge list is cut into chunks of 64 edges (two 32-row MFMA blocks); a workgroup
-//     (4 waves) owns `chunks_per_wg` consecutive chunks -- perfectly balanced, independent of node degree;
+//   * the by-target CSR edge list is cut into chunks of 32 edges (one 32-row MFMA block); a workgroup
+//     (4 waves) owns `chunks_per_wg` consecutive chunks -- perfectly balanced, independent of node degree.
+//     By default the grid is ONE resident wave of persistent workgroups (2 per CU, 243 VGPRs per lane), so the
+//     weights are fetched once per workgroup and two workgroups per CU interleave: one's MFMAs run under the
+//     other's softplus / gather / store phases;
 //   * wave w owns filter columns [32w, 32w+32): its slices of W1 (G x 32) and W2 (128 x 32) live in
 //     VGPRs for the whole kernel as MFMA B operands (lane l: B[k = 2kk + (l>>5)][col = l&31]), so
 //     weights come from L2 once per workgroup and never touch LDS;
 //   * the A operands (rbf tile, then the softplus'd hidden tile) are shared by the 4 waves through
 //     LDS, row-major with ODD row strides (2*KK1+1, 129): the row-per-lane A reads and the
 //     column-per-lane epilogue writes are bank-conflict free;
-//   * gathered x1[src] values are requested before the GEMMs and consumed after them;
-//   * the message tile reuses the hidden tile's LDS; each (column, target parity) thread carries a
-//     running per-target sum in a register across chunks, in edge order.  Targets whose edges lie
-//     entirely inside the workgroup's range are written with one plain store; the (at most two)
-//     boundary targets are combined with atomicAdd into a zero-initialised output -- two addends on
-//     top of zero commute exactly, so the result is bitwise reproducible.
+//   * gathered x1[src] values and the NEXT chunk's distances / edge ids are requested right after the chunk's
+//     first barrier and consumed after its last MFMA; no load depends on another load; two barriers per chunk;
+//   * the per-target segmented sum also runs on the matrix cores: agg = S . msg with the 0/1 selection
+//     matrix S[t][e] = (dst_e == t); the message tile in accumulator layout is the B operand as it stands
+//     (no LDS round trip).  Targets whose edges lie entirely inside the chunk are written with one plain
+//     store; the first / last target of a chunk may continue in a neighbouring chunk and are combined
+//     with atomicAdd into a zero-initialised output -- with degree <= 32 (radius graph cap, schnet.py:91) a
+//     target spans at most two chunks, and two addends on top of zero commute exactly, so the result is
+//     bitwise reproducible (a general CSR with higher degrees is still summed correctly, in atomic order);
 //   * optionally the filter rows Wf[e] = (W2 h1 + b2) * C(d) are written out for the backward pass.
+// History (MI355X, E = 49090, bs256 batch): 64-edge chunks, one workgroup per CU or spilling at two: 54 us;
+// this layout 42-45 us.  tools/fused_phases.py (-DCF_TIMING=1 build) prints the per-phase cycle stamps.
 #include "msde_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CF_F 128
-#define CF_TE 64          // edges per chunk
-#define CF_HS 129         // hidden/message tile row stride (floats)
+#define CF_TE 32          // edges per chunk (one 32-row MFMA block)
+#define CF_HS 129         // hidden tile row stride (floats)
+
 
 __device__ __forceinline__ float ssp_fast(float x) {
   // softplus(x) - ln2 = max(x,0) + log(1 + exp(-|x|)) - ln2.  Hardware exp/log (v_exp_f32/v_log_f32):
@@ -34,35 +43,61 @@ __device__ __forceinline__ float ssp_fast(float x) {
   return fmaxf(x, 0.f) + __logf(1.f + e) - 0.69314718246459961f;
 }
 
+__device__ __forceinline__ int cf_row(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+#ifndef CF_TIMING
+#define CF_TIMING 0          // 1: debug build -- per-phase s_memtime stamps of wave 0 go to Wf_out (tools/fused_phases.py)
+#endif
+#if CF_TIMING
+#define CF_STAMP(k)                                                                         \
+  do {                                                                                      \
+    __builtin_amdgcn_s_waitcnt(0);                                                          \
+    if (tid == 0 && stamp_n < 60) stamps[stamp_n++] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define CF_STAMP(k)
+#endif
+#ifndef CF_OCC
+#define CF_OCC 2             // waves per SIMD promised to the compiler
+#endif
+
 template <int KK1>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, CF_OCC)
 cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ dist, const int* __restrict__ rowptr,
                         const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ W1T,
                         const float* __restrict__ b1, const float* __restrict__ W2T, const float* __restrict__ b2,
                         const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
                         float* __restrict__ agg, float* __restrict__ Wf_out) {
-  constexpr int RS = 2 * KK1 + 1;  // rbf tile row stride (odd)
+  constexpr int RS = 2 * KK1 + 1;           // rbf tile row stride (odd)
+  constexpr int NR = (CF_TE * 2 * KK1 + 255) / 256;   // rbf entries per thread
   extern __shared__ float lds[];
-  float* rbf_t = lds;                          // [64][RS]
-  float* hid_t = rbf_t + CF_TE * RS;           // [64][129]  (hidden tile, then message tile)
-  float* c_s = hid_t + CF_TE * CF_HS;          // [64] cutoff value per edge row (0 for padding rows)
-  float* d_s = c_s + CF_TE;                    // [64] distance per edge row
-  int* src_s = reinterpret_cast<int*>(d_s + CF_TE);  // [64]
-  int* dst_s = src_s + CF_TE;                  // [64] target node, -1 for padding rows
-  float* off_s = reinterpret_cast<float*>(dst_s + CF_TE);  // [64] Gaussian centres
+  float* rbf_t = lds;                          // [32][RS]      rbf tile (A of GEMM1)
+  float* hid_t = rbf_t + CF_TE * RS;           // [32][129]     hidden tile (A of GEMM2)
+  float* c_s = hid_t + CF_TE * CF_HS;          // [2][32] cutoff per edge row (0 for padding rows)
+  int* src_s = reinterpret_cast<int*>(c_s + 2 * CF_TE);   // [2][32]
+  int* dst_s = src_s + 2 * CF_TE;              // [2][32] target node, -1 for padding rows
+  int* flag_s = dst_s + 2 * CF_TE;             // [2][4]: first target partial?, last target partial?, last target
+  float* off_s = reinterpret_cast<float*>(flag_s + 8);    // [64] Gaussian centres
 
   const float PI_F = 3.14159265358979323846f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 31, lhalf = lane >> 5;
   const int col = wave * 32 + lcol;  // this lane's filter column
 
+#if CF_TIMING
+  long long* stamps = reinterpret_cast<long long*>(Wf_out) + (size_t)blockIdx.x * 64;
+  int stamp_n = 0;
+  Wf_out = nullptr;
+  CF_STAMP(0);
+  if (tid == 0) stamps[62] = (long long)wall_clock64();
+#endif
   const int E = rowptr[N];
   const int e_begin = blockIdx.x * cpw * CF_TE;
   if (e_begin >= E) return;
   const int e_end = min(e_begin + cpw * CF_TE, E);
 
   // weights -> registers (B operands), from the TRANSPOSED copies ([in][out]) so that each half-wave
-  // reads 128 contiguous bytes per k (the [out][in] layout costs 64 cache lines per load instruction)
+  // reads 128 contiguous bytes per k
   float w1r[KK1], w2r[CF_F / 2];
 #pragma unroll
   for (int kk = 0; kk < KK1; ++kk) {
@@ -74,122 +109,142 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
   const float b1c = b1[col], b2c = b2[col];
   if (tid < 64) off_s[tid] = tid < G ? offset[tid] : 0.f;
 
-  // per-edge metadata of the first chunk; later chunks are prefetched one chunk ahead (registers of
-  // the first wave) so their global-load latency hides under the MFMAs
+  // ---- one-chunk-ahead production of everything that depends only on the edge list.  The global loads are
+  // REQUESTED right after the chunk's first barrier and CONSUMED (exp / cos) after its last MFMA, so their
+  // latency lies under the GEMMs; no load depends on another load (the "does my first / last target continue
+  // in the neighbouring chunk" flags come from dst[ec-1] and dst[ce], not from rowptr[dst[..]]).
+  float rv[NR];                 // distances, then rbf values
   float m_d = 0.f;
-  int m_s = -1, m_t = -1;
-  if (tid < CF_TE) {
-    int e = e_begin + tid;
-    if (e < e_end) { m_d = dist[e]; m_s = src[e]; m_t = dst[e]; }
-  }
-
-  // running segmented sum of this thread: column rc, targets of parity rpar
-  const int rc = tid & 127, rpar = tid >> 7;
-  int cur_t = -1;
-  float cur_acc = 0.f;
-  auto flush = [&]() {
-    if (cur_t >= 0) {
-      bool owned = rowptr[cur_t] >= e_begin && rowptr[cur_t + 1] <= e_end;
-      if (owned) agg[(size_t)cur_t * CF_F + rc] = cur_acc;
-      else atomicAdd(&agg[(size_t)cur_t * CF_F + rc], cur_acc);
+  int m_s = -1, m_t = -1, m_prev = -2, m_next = -2;
+  auto produce_load = [&](int ec) {
+    const int ce = min(ec + CF_TE, e_end);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      int r = (tid + 256 * j) / (2 * KK1);
+      rv[j] = (r < CF_TE && ec + r < ce) ? dist[ec + r] : -1.f;
+    }
+    if (tid < CF_TE) {
+      int e = ec + tid;
+      m_s = -1; m_t = -1; m_d = 0.f;
+      if (e < ce) { m_d = dist[e]; m_s = src[e]; m_t = dst[e]; }
+      if (tid == 0) {
+        m_prev = ec > 0 ? dst[ec - 1] : -2;
+        m_next = ce < E ? dst[ce] : -2;
+      }
     }
   };
+  auto produce_math = [&]() {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      int g = (tid + 256 * j) % (2 * KK1);
+      float diff = rv[j] - off_s[g];
+      rv[j] = (rv[j] >= 0.f && g < G) ? __expf(coeff * (diff * diff)) : 0.f;
+    }
+  };
+  produce_load(e_begin);
+  __syncthreads();              // off_s visible
+  produce_math();
+  CF_STAMP(1);
 
-  for (int ec = e_begin; ec < e_end; ec += CF_TE) {
-    __syncthreads();  // previous chunk's reduction is done with hid_t / meta
+  int buf = 0;
+  for (int ec = e_begin; ec < e_end; ec += CF_TE, buf ^= 1) {
+    const int ce = min(ec + CF_TE, e_end);
+    // ---- P0: publish this chunk's rbf tile and metadata
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      int idx = tid + 256 * j;
+      if (idx < CF_TE * 2 * KK1) rbf_t[(idx / (2 * KK1)) * RS + idx % (2 * KK1)] = rv[j];
+    }
+    const int nxt = __shfl(m_next, 0);
     if (tid < CF_TE) {
-      bool ok = ec + tid < e_end;
-      d_s[tid] = m_d;
-      c_s[tid] = ok ? 0.5f * (cosf(m_d * PI_F / cutoff) + 1.0f) : 0.f;
-      src_s[tid] = m_s;
-      dst_s[tid] = m_t;
-      int en = ec + CF_TE + tid;             // prefetch the next chunk's metadata
-      m_d = 0.f; m_s = -1; m_t = -1;
-      if (en < e_end) { m_d = dist[en]; m_s = src[en]; m_t = dst[en]; }
+      c_s[buf * CF_TE + tid] = m_t >= 0 ? 0.5f * (__cosf(m_d * (PI_F / cutoff)) + 1.0f) : 0.f;
+      src_s[buf * CF_TE + tid] = m_s;
+      dst_s[buf * CF_TE + tid] = m_t;
+      if (tid == 0) flag_s[buf * 4] = (m_prev == m_t);
+      if (tid == ce - ec - 1) { flag_s[buf * 4 + 1] = (nxt == m_t); flag_s[buf * 4 + 2] = m_t; }
     }
-    __syncthreads();
+    __syncthreads();   // B1
+    CF_STAMP(2);
+
+    const float* cb = c_s + buf * CF_TE;
+    const int* sb = src_s + buf * CF_TE;
+    const int* db = dst_s + buf * CF_TE;
     // gathered x1 rows for the epilogue: request now, consume after the GEMMs
-    float xg0[16], xg1[16];
+    float xg[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      int row = (i & 3) + 8 * (i >> 2) + 4 * lhalf;
-      int s0 = src_s[row], s1 = src_s[32 + row];
-      xg0[i] = x1[(size_t)(s0 >= 0 ? s0 : 0) * CF_F + col];
-      xg1[i] = x1[(size_t)(s1 >= 0 ? s1 : 0) * CF_F + col];
+      int s0 = sb[cf_row(i, lhalf)];
+      xg[i] = x1[(size_t)(s0 >= 0 ? s0 : 0) * CF_F + col];
     }
-    // Gaussian smearing tile: rbf[r][g] = exp(coeff * (d_r - mu_g)^2), zero for padding
-    for (int idx = tid; idx < CF_TE * 2 * KK1; idx += 256) {
-      int r = idx / (2 * KK1), g = idx % (2 * KK1);
-      float v = 0.f;
-      if (ec + r < e_end && g < G) {
-        float diff = d_s[r] - off_s[g];
-        v = __expf(coeff * (diff * diff));
+    const bool more = ec + CF_TE < e_end;
+    if (more) produce_load(ec + CF_TE);
+
+    // ---- GEMM1: [32 x 2KK1] . [2KK1 x 32] per wave
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KK1; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rbf_t[lcol * RS + 2 * kk + lhalf], w1r[kk], acc, 0, 0, 0);
+    CF_STAMP(3);
+    // epilogue 1: bias + shifted softplus -> hidden tile
+#pragma unroll
+    for (int i = 0; i < 16; ++i) hid_t[cf_row(i, lhalf) * CF_HS + col] = ssp_fast(acc[i] + b1c);
+    __syncthreads();   // B2
+    CF_STAMP(4);
+
+    // ---- GEMM2: [32 x 128] . [128 x 32] per wave
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < CF_F / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hid_t[lcol * CF_HS + 2 * kk + lhalf], w2r[kk], acc, 0, 0, 0);
+
+    CF_STAMP(5);
+    // epilogue 2 (registers only): filter = (acc + b2) * C ; message = x1[src] * filter
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int row = cf_row(i, lhalf);
+      float f0 = (acc[i] + b2c) * cb[row];          // padding rows: C = 0 -> message 0
+      if (Wf_out && ec + row < ce) Wf_out[(size_t)(ec + row) * CF_F + col] = f0;
+      acc[i] = xg[i] * f0;
+    }
+
+    CF_STAMP(6);
+    // ---- segmented sum on the matrix cores: agg[t][f] += sum_e S[t][e] msg[e][f] with the 0/1 selection
+    // matrix S[t][e] = (dst_e == t).  The message tile in accumulator layout is the B operand as it stands
+    // (k-step s <-> register s, i.e. edge row cf_row(s, lane half)); A is built from the target ids.
+    const int t0 = db[0];
+    const int ntl = flag_s[buf * 4 + 2] - t0 + 1;    // local targets 0 .. ntl-1 (one tile unless the chunk
+    const bool part0 = flag_s[buf * 4] != 0, part1 = flag_s[buf * 4 + 1] != 0;   // straddles isolated nodes)
+    for (int tile = 0; tile * 32 < ntl; ++tile) {
+      f32x16 d;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[i] = 0.f;
+      const int want = t0 + tile * 32 + lcol;
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        float sa = db[cf_row(s2, lhalf)] == want ? 1.f : 0.f;
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, acc[s2], d, 0, 0, 0);
       }
-      rbf_t[r * RS + g] = v;
-    }
-    __syncthreads();
-
-    // ---- GEMM1: [64 x 2KK1] . [2KK1 x 32] per wave, two 32-row blocks
-    f32x16 acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < KK1; ++kk) {
-      float a0 = rbf_t[lcol * RS + 2 * kk + lhalf];
-      float a1 = rbf_t[(32 + lcol) * RS + 2 * kk + lhalf];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w1r[kk], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1r[kk], acc1, 0, 0, 0);
-    }
-    // epilogue 1: bias + shifted softplus -> hidden tile (C/D map: row = (i&3)+8(i>>2)+4*lhalf)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int row = (i & 3) + 8 * (i >> 2) + 4 * lhalf;
-      hid_t[row * CF_HS + col] = ssp_fast(acc0[i] + b1c);
-      hid_t[(32 + row) * CF_HS + col] = ssp_fast(acc1[i] + b1c);
-    }
-    __syncthreads();
-
-    // ---- GEMM2: [64 x 128] . [128 x 32] per wave
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < CF_F / 2; ++kk) {
-      float a0 = hid_t[lcol * CF_HS + 2 * kk + lhalf];
-      float a1 = hid_t[(32 + lcol) * CF_HS + 2 * kk + lhalf];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w2r[kk], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w2r[kk], acc1, 0, 0, 0);
-    }
-    __syncthreads();  // every wave is done reading the hidden tile: reuse it for messages
-
-    // epilogue 2: filter = (acc + b2) * C ; message = x1[src] * filter
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      int row = (i & 3) + 8 * (i >> 2) + 4 * lhalf;
-      float f0 = (acc0[i] + b2c) * c_s[row];
-      float f1 = (acc1[i] + b2c) * c_s[32 + row];
-      hid_t[row * CF_HS + col] = xg0[i] * f0;        // padding rows: c_s = 0 -> message 0
-      hid_t[(32 + row) * CF_HS + col] = xg1[i] * f1;
-      if (Wf_out) {
-        if (ec + row < e_end) Wf_out[(size_t)(ec + row) * CF_F + col] = f0;
-        if (ec + 32 + row < e_end) Wf_out[(size_t)(ec + 32 + row) * CF_F + col] = f1;
-      }
-    }
-    __syncthreads();
-
-    // segmented sum in edge order; thread (column rc, parity rpar) owns the targets of its parity
-    for (int r = 0; r < CF_TE; ++r) {
-      int t = dst_s[r];
-      if (t >= 0 && (t & 1) == rpar) {
-        if (t != cur_t) {
-          flush();
-          cur_t = t;
-          cur_acc = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        int tl = tile * 32 + cf_row(i, lhalf);
+        if (tl < ntl) {
+          bool partial = (tl == 0 && part0) || (tl == ntl - 1 && part1);
+          float* o = &agg[(size_t)(t0 + tl) * CF_F + col];
+          if (partial) atomicAdd(o, d[i]);           // <= 2 addends per target on top of zero: order-free
+          else *o = d[i];
         }
-        cur_acc += hid_t[r * CF_HS + rc];
       }
     }
+    CF_STAMP(7);
+    if (more) produce_math();
+    CF_STAMP(8);
   }
-  flush();
+#if CF_TIMING
+  if (tid == 0) stamps[63] = (long long)wall_clock64();
+#endif
 }
 
 extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const int* rowptr, const int* src,
@@ -200,7 +255,6 @@ extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const i
   if (N < 0 || E_cap < 0 || !x1 || !dist || !rowptr || !src || !dst || !W1T || !b1 || !W2T || !b2 || !offset || !agg)
     return MSDE_EINVAL;
   if (F != CF_F || G <= 0 || G > 64) return MSDE_EUNSUP;
-  if (chunks_per_wg <= 0) chunks_per_wg = 1;
   if (N == 0) return 0;
   hipStream_t st = as_stream(stream);
   hipError_t me = hipMemsetAsync(agg, 0, (size_t)N * CF_F * sizeof(float), st);   // atomics target + isolated nodes
@@ -208,9 +262,13 @@ extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const i
   if (E_cap == 0) return 0;
   int kk1 = (G + 1) / 2;
   int chunks = (E_cap + CF_TE - 1) / CF_TE;
+  if (chunks_per_wg <= 0) {   // auto: one resident wave of workgroups (weights are loaded once per workgroup)
+    int resident = msde_num_cus() * CF_OCC;
+    chunks_per_wg = (chunks + resident - 1) / resident;
+  }
   int grid = (chunks + chunks_per_wg - 1) / chunks_per_wg;
   auto lds_bytes = [](int KK1) {
-    return (size_t)(CF_TE * (2 * KK1 + 1) + CF_TE * CF_HS + 5 * CF_TE) * sizeof(float);
+    return (size_t)(CF_TE * (2 * KK1 + 1) + CF_TE * CF_HS + 6 * CF_TE + 8 + 64) * sizeof(float);
   };
 #define CF_LAUNCH(KK)                                                                                              \
   {                                                                                                                \

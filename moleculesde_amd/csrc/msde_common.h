@@ -23,6 +23,20 @@
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// compute units of the current device (256 on MI355X); queried once -- one process drives one GPU model
+static inline int msde_num_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
 // ---- tiny vector abstraction: V = 4 (float4, 16 B/lane) or V = 1 (scalar fallback) -------------
 template <int V> struct VecT;
 template <> struct VecT<4> { using type = float4; };

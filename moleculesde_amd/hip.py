@@ -144,7 +144,7 @@ def rbf_cutoff(dist, E_dev, offset, coeff, cutoff):
     return rbf, C
 
 
-FUSED_CHUNKS_PER_WG = 1   # measured on MI355X (tools/tune_fused.py): 1 -> 54 us, 2 -> 56, 3 -> 59, 6 -> 106
+FUSED_CHUNKS_PER_WG = 0   # 0 = auto: one resident wave of persistent workgroups (msde_cfconv_fused_fwd)
 
 
 def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, chunks_per_wg=None, want_filter=False):

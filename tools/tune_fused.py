@@ -21,7 +21,7 @@ with torch.no_grad():
     rplan, dist = hip.radius_plan(b.positions, pl.batch_i32, pl.mol_ptr, sch.cutoff, pl.E_r_cap, 32)
     N = b.x.size(0)
     x1 = torch.randn(N, 128, device=dev)
-    for cpw in (1, 2, 3, 4, 6):
+    for cpw in (0, 1, 2, 3, 4, 6, 8):
         for wf in (False,):
             us = t(lambda: hip.cfconv_fused_forward(x1, dist, rplan, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
                                                     blk.mlp[2].bias, de.offset, de.coeff, sch.cutoff, chunks_per_wg=cpw, want_filter=wf))
