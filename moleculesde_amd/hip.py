@@ -614,15 +614,15 @@ def _wgrad_workspace(M, N, K, device):
 # Dispatch policy of the dense layers, from per-shape rocprofv3 timings on MI355X (profiles/):
 #   * forward / input gradient: the vendor fp32 GEMM is ~1.7x faster than csrc/linear.hip on these
 #     skinny shapes (22 vs 41 us at 49090x128x128), so plain library GEMMs are used there;
-#   * weight + bias gradient at edge level (M >= 8192 rows reduced into a <=128x300 output): the vendor
-#     kernel takes 110-190 us; the split-M MFMA kernel + fixed-order slab reduce takes 40-95 us and is
-#     bitwise reproducible -> hand-written kernel.
+#   * weight + bias gradient: the vendor kernel runs ~100 output tiles over the whole M loop (31-39 us at
+#     M = 3588 whatever the layer size, 110-225 us at edge level); the split-M MFMA kernel + fixed-order
+#     slab reduce takes 9-33 us (tools/bench_wgrad.py, hipGraph-timed), fuses the bias gradient and is
+#     bitwise reproducible -> hand-written kernel for every layer.
 # MSDE_LINEAR=hip forces the hand-written kernel everywhere (parity tests do), =lib the vendor GEMM.
 import os as _os
 
 _LINEAR_MODE = _os.environ.get("MSDE_LINEAR", "auto")
-WGRAD_HIP_MIN_ROWS = 8192
-WGRAD_HIP_MAX_SMALL = 40000      # node-level layers with N*K below this: split-M kernel (bias grad fused) wins
+WGRAD_HIP_MIN_ROWS = 64          # below this a split over M has nothing to split
 
 
 def set_linear_mode(mode):
@@ -666,8 +666,7 @@ class _Linear(torch.autograd.Function):
                 gx = torch.mm(g2, w)
             gx = gx.view(ctx.in_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and
-                                                (M >= WGRAD_HIP_MIN_ROWS or (N * K <= WGRAD_HIP_MAX_SMALL and M >= 256)))
+            use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
             if use_hip:
                 gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
                 gb = torch.empty(N, dtype=torch.float32, device=g2.device) if ctx.has_bias else None

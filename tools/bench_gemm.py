@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from moleculesde_amd import hip  # noqa: E402
 
 SHAPES = [(3588, 600, 300), (3588, 300, 600), (3588, 128, 300), (3588, 300, 128), (3588, 300, 300),
-          (49090, 128, 51), (49090, 128, 128), (35186, 32, 300), (35186, 32, 128), (35186, 128, 64), (35186, 32, 32)]
+          (49090, 128, 51), (49090, 128, 128), (35186, 32, 300), (35186, 32, 128), (35186, 128, 64), (35186, 32, 32), (3588, 32, 32), (3588, 128, 32), (3588, 32, 300), (35186, 3, 128), (35186, 66, 32)]
 
 
 def t(fn, it=30):
@@ -25,6 +25,7 @@ def t(fn, it=30):
 
 def main():
     dev = torch.device("cuda", 0)
+    hip.set_linear_mode("hip")   # the "hip" columns time csrc/linear.hip regardless of the dispatch policy
     print(f"{'M':>6} {'N':>4} {'K':>4} | {'fwd hip':>8} {'fwd lib':>8} | {'dgrad hip':>9} {'lib':>7} | {'wgrad hip':>9} {'lib':>7} | TF(hip fwd)")
     for M, N, K in SHAPES:
         x = torch.randn(M, K, device=dev)
