@@ -2,235 +2,301 @@
 // molecule_gnn_model.py:17,159,176-182 (10 BatchNorms of the GIN stack) and
 // SDE_model_2D_to_3D.py:265 (BatchNorm over ~35 k edges inside edge_2D_emb).
 //
-// Forward  = 2 launches: per-(row split, column) Welford partials, then combine (fixed order, Chan's
+// Forward  = 2 launches: per-(row split, column) shifted-sum partials, then combine (fixed order, Chan's
 //            formula) + normalise + affine (+ ReLU) + running-stat update.
 // Backward = 2 launches: per-split column sums of dz and dz*xhat, then combine + input gradient.
-// Threads run along columns (64 consecutive floats per wave row = 256 B), 4 row lanes per block.
+// Threads hold float4 column groups (16 per 64-column block) by 16 row lanes; 64-row splits put 300-600
+// workgroups in flight for the 3.6 k-atom batch, with four 16-B loads per thread outstanding.
 #include "msde_common.h"
 
-#define BN_COLS 64
-#define BN_RL 4   // row lanes per block
+#define BN_COLS 64   // columns per block
+// Thread layout, templated on the vector width V (4 when C % 4 == 0, else 1): CG = 64 / V column groups by
+// RL = 256 / CG row lanes (16 x 16 for float4, 64 x 4 scalar).  A wave covers 4 (or 1) rows of 256 B each.
+template <int V> struct BnGeo {
+  static constexpr int CG = BN_COLS / V, RL = 256 / CG;
+};
+#define BN_MAXRL 16
 
+template <int V> __device__ __forceinline__ typename VecT<V>::type bn_ld(const float* p) {
+  return *reinterpret_cast<const typename VecT<V>::type*>(p);
+}
+template <int V> __device__ __forceinline__ void bn_st(float* p, typename VecT<V>::type v) {
+  *reinterpret_cast<typename VecT<V>::type*>(p) = v;
+}
+__device__ __forceinline__ float& vref(float4& v, int k) { return reinterpret_cast<float*>(&v)[k]; }
+__device__ __forceinline__ float& vref(float& v, int) { return v; }
+__device__ __forceinline__ float vget(const float4& v, int k) { return reinterpret_cast<const float*>(&v)[k]; }
+__device__ __forceinline__ float vget(const float& v, int) { return v; }
+__device__ __forceinline__ float4 vsub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float vsub(float a, float b) { return a - b; }
+
+// merge (nb, mb, m2b) into (n, mean, m2): Chan's parallel-variance update
+__device__ __forceinline__ void bn_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+  if (nb > 0.f) {
+    float nn = n + nb, d = mb - mean;
+    mean += d * (nb / nn);
+    m2 += m2b + d * d * (n * nb / nn);
+    n = nn;
+  }
+}
+
+// Per-(row split, column) partials (n, mean, M2).  Shifted sums s1 = sum(x - x0), s2 = sum((x - x0)^2) with
+// x0 = the split's first row (close to the mean: no catastrophic cancellation); every row lane of the block
+// uses the SAME shift, so lane partials add directly, in lane order.
+template <int V>
 __global__ void __launch_bounds__(256)
 bn_stats_partial_kernel(const float* __restrict__ X, int M, int C, int rows_per_split, float* __restrict__ ws) {
-  __shared__ float s_n[BN_RL][BN_COLS], s_mean[BN_RL][BN_COLS], s_m2[BN_RL][BN_COLS];
-  const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
-  const int c = blockIdx.x * BN_COLS + tx;
+  using T = typename VecT<V>::type;
+  constexpr int CG = BnGeo<V>::CG, RL = BnGeo<V>::RL;
+  __shared__ float s_1[BN_MAXRL][BN_COLS], s_2[BN_MAXRL][BN_COLS];
+  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
+  const int c = blockIdx.x * BN_COLS + tx * V;
   const int r0 = blockIdx.y * rows_per_split, r1 = min(r0 + rows_per_split, M);
-  // shifted sums s1 = sum(x - x0), s2 = sum((x - x0)^2) with x0 = the lane's first row (close to the mean,
-  // so no catastrophic cancellation): independent accumulators, four loads in flight per thread
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (c < C && r0 + ty < r1) {
-    const float x0 = X[(size_t)(r0 + ty) * C + c];
-    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f, d1 = 0.f, d2 = 0.f;
+  T a1 = vzero<V>(), a2 = vzero<V>(), b1 = vzero<V>(), b2 = vzero<V>();
+  T x0 = vzero<V>();
+  if (c < C) {
+    x0 = bn_ld<V>(X + (size_t)r0 * C + c);
     int r = r0 + ty;
-    for (; r + 3 * BN_RL < r1; r += 4 * BN_RL) {
-      float xa = X[(size_t)r * C + c] - x0, xb = X[(size_t)(r + BN_RL) * C + c] - x0;
-      float xc = X[(size_t)(r + 2 * BN_RL) * C + c] - x0, xd = X[(size_t)(r + 3 * BN_RL) * C + c] - x0;
-      a1 += xa; a2 = fmaf(xa, xa, a2);
-      b1 += xb; b2 = fmaf(xb, xb, b2);
-      c1 += xc; c2 = fmaf(xc, xc, c2);
-      d1 += xd; d2 = fmaf(xd, xd, d2);
-      n += 4.f;
+    for (; r + 3 * RL < r1; r += 4 * RL) {           // four independent rows in flight
+      T xa = vsub(bn_ld<V>(X + (size_t)r * C + c), x0), xb = vsub(bn_ld<V>(X + (size_t)(r + RL) * C + c), x0);
+      T xc = vsub(bn_ld<V>(X + (size_t)(r + 2 * RL) * C + c), x0), xd = vsub(bn_ld<V>(X + (size_t)(r + 3 * RL) * C + c), x0);
+      a1 = vadd(a1, xa); a2 = vfma(xa, xa, a2);
+      b1 = vadd(b1, xb); b2 = vfma(xb, xb, b2);
+      a1 = vadd(a1, xc); a2 = vfma(xc, xc, a2);
+      b1 = vadd(b1, xd); b2 = vfma(xd, xd, b2);
     }
-    for (; r < r1; r += BN_RL) {
-      float xa = X[(size_t)r * C + c] - x0;
-      a1 += xa; a2 = fmaf(xa, xa, a2);
-      n += 1.f;
+    for (; r < r1; r += RL) {
+      T xa = vsub(bn_ld<V>(X + (size_t)r * C + c), x0);
+      a1 = vadd(a1, xa); a2 = vfma(xa, xa, a2);
     }
-    float s1 = (a1 + b1) + (c1 + d1), s2 = (a2 + b2) + (c2 + d2);
-    mean = x0 + s1 / n;
-    m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
+    a1 = vadd(a1, b1); a2 = vadd(a2, b2);
   }
-  s_n[ty][tx] = n; s_mean[ty][tx] = mean; s_m2[ty][tx] = m2;
-  __syncthreads();
-  if (ty == 0 && c < C) {
 #pragma unroll
-    for (int l = 1; l < BN_RL; ++l) {
-      float nb = s_n[l][tx], mb = s_mean[l][tx], m2b = s_m2[l][tx];
-      if (nb > 0.f) {
-        float nn = n + nb, d = mb - mean;
-        mean += d * (nb / nn);
-        m2 += m2b + d * d * (n * nb / nn);
-        n = nn;
-      }
-    }
-    float* o = ws + ((size_t)blockIdx.y * C + c) * 3;
-    o[0] = n; o[1] = mean; o[2] = m2;
-  }
-}
-
-__device__ __forceinline__ void bn_combine(const float* __restrict__ ws, int splits, int C, int c, float& n, float& mean,
-                                           float& m2) {
-  n = 0.f; mean = 0.f; m2 = 0.f;
-  for (int s = 0; s < splits; ++s) {
-    const float* p = ws + ((size_t)s * C + c) * 3;
-    float nb = p[0], mb = p[1], m2b = p[2];
-    if (nb > 0.f) {
-      float nn = n + nb, d = mb - mean;
-      mean += d * (nb / nn);
-      m2 += m2b + d * d * (n * nb / nn);
-      n = nn;
+  for (int k = 0; k < V; ++k) { s_1[ty][tx * V + k] = vget(a1, k); s_2[ty][tx * V + k] = vget(a2, k); }
+  __syncthreads();
+  if (threadIdx.x < BN_COLS) {
+    const int cc = blockIdx.x * BN_COLS + threadIdx.x;
+    if (cc < C) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int l = 0; l < RL; ++l) { s1 += s_1[l][threadIdx.x]; s2 += s_2[l][threadIdx.x]; }
+      const float n = (float)(r1 - r0);
+      const float xs = X[(size_t)r0 * C + cc];
+      float* o = ws + ((size_t)blockIdx.y * C + cc) * 3;
+      o[0] = n; o[1] = xs + s1 / n; o[2] = fmaxf(s2 - s1 * s1 / n, 0.f);
     }
   }
 }
 
+template <int V>
 __global__ void __launch_bounds__(256)
 bn_fwd_apply_kernel(const float* __restrict__ X, const float* __restrict__ ws, int M, int C, int splits,
                     int rows_per_block, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                     float momentum, float* __restrict__ running_mean, float* __restrict__ running_var, int relu,
                     float* __restrict__ Y, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  using T = typename VecT<V>::type;
+  constexpr int CG = BnGeo<V>::CG, RL = BnGeo<V>::RL;
   __shared__ float s_scale[BN_COLS], s_shift[BN_COLS];
-  __shared__ float s_n[BN_RL][BN_COLS], s_mean[BN_RL][BN_COLS], s_m2[BN_RL][BN_COLS];
-  const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
-  const int c = blockIdx.x * BN_COLS + tx;
-  {  // each row lane merges the splits s = ty, ty+4, ...; the four partials are then merged in lane order
+  __shared__ float s_n[4][BN_COLS], s_mean[4][BN_COLS], s_m2[4][BN_COLS];
+  {  // 4 lanes per column merge the splits s = l, l+4, ...; the four partials are then merged in lane order
+    const int cx = threadIdx.x & (BN_COLS - 1), l = threadIdx.x / BN_COLS;
+    const int cc = blockIdx.x * BN_COLS + cx;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (c < C) {
-      for (int sidx = ty; sidx < splits; sidx += BN_RL) {
-        const float* p = ws + ((size_t)sidx * C + c) * 3;
-        float nb = p[0], mb = p[1], m2b = p[2];
-        if (nb > 0.f) {
-          float nn = n + nb, d = mb - mean;
-          mean += d * (nb / nn);
-          m2 += m2b + d * d * (n * nb / nn);
-          n = nn;
+    if (cc < C)
+      for (int sidx = l; sidx < splits; sidx += 4) {
+        const float* p = ws + ((size_t)sidx * C + cc) * 3;
+        bn_merge(n, mean, m2, p[0], p[1], p[2]);
+      }
+    s_n[l][cx] = n; s_mean[l][cx] = mean; s_m2[l][cx] = m2;
+    __syncthreads();
+    if (l == 0 && cc < C) {
+#pragma unroll
+      for (int k = 1; k < 4; ++k) bn_merge(n, mean, m2, s_n[k][cx], s_mean[k][cx], s_m2[k][cx]);
+      float var = m2 / n;
+      float rstd = rsqrtf(var + eps);
+      float g = gamma ? gamma[cc] : 1.f, b = beta ? beta[cc] : 0.f;
+      s_scale[cx] = g * rstd;
+      s_shift[cx] = b - mean * g * rstd;
+      if (blockIdx.y == 0) {
+        save_mean[cc] = mean;
+        save_rstd[cc] = rstd;
+        if (running_mean) {
+          float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
+          running_mean[cc] = (1.f - momentum) * running_mean[cc] + momentum * mean;
+          running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * unbiased;
         }
       }
     }
-    s_n[ty][tx] = n; s_mean[ty][tx] = mean; s_m2[ty][tx] = m2;
+    __syncthreads();
   }
-  __syncthreads();
-  if (ty == 0 && c < C) {
-    float n = s_n[0][tx], mean = s_mean[0][tx], m2 = s_m2[0][tx];
-#pragma unroll
-    for (int l = 1; l < BN_RL; ++l) {
-      float nb = s_n[l][tx], mb = s_mean[l][tx], m2b = s_m2[l][tx];
-      if (nb > 0.f) {
-        float nn = n + nb, d = mb - mean;
-        mean += d * (nb / nn);
-        m2 += m2b + d * d * (n * nb / nn);
-        n = nn;
-      }
-    }
-    float var = m2 / n;
-    float rstd = rsqrtf(var + eps);
-    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    s_scale[tx] = g * rstd;
-    s_shift[tx] = b - mean * g * rstd;
-    if (blockIdx.y == 0) {
-      save_mean[c] = mean;
-      save_rstd[c] = rstd;
-      if (running_mean) {
-        float unbiased = n > 1.f ? m2 / (n - 1.f) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-      }
-    }
-  }
-  __syncthreads();
+  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
+  const int c = blockIdx.x * BN_COLS + tx * V;
   if (c >= C) return;
-  const float sc = s_scale[tx], sh = s_shift[tx];
+  T sc, sh;
+#pragma unroll
+  for (int k = 0; k < V; ++k) { vref(sc, k) = s_scale[tx * V + k]; vref(sh, k) = s_shift[tx * V + k]; }
   const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, M);
-  for (int r = r0 + ty; r < r1; r += BN_RL) {
-    float y = fmaf(X[(size_t)r * C + c], sc, sh);
-    if (relu) y = fmaxf(y, 0.f);
-    Y[(size_t)r * C + c] = y;
+  int r = r0 + ty;
+  for (; r + 3 * RL < r1; r += 4 * RL) {
+    T xa = bn_ld<V>(X + (size_t)r * C + c), xb = bn_ld<V>(X + (size_t)(r + RL) * C + c);
+    T xc = bn_ld<V>(X + (size_t)(r + 2 * RL) * C + c), xd = bn_ld<V>(X + (size_t)(r + 3 * RL) * C + c);
+    xa = vfma(xa, sc, sh); xb = vfma(xb, sc, sh); xc = vfma(xc, sc, sh); xd = vfma(xd, sc, sh);
+    if (relu) { xa = vrelu(xa); xb = vrelu(xb); xc = vrelu(xc); xd = vrelu(xd); }
+    bn_st<V>(Y + (size_t)r * C + c, xa); bn_st<V>(Y + (size_t)(r + RL) * C + c, xb);
+    bn_st<V>(Y + (size_t)(r + 2 * RL) * C + c, xc); bn_st<V>(Y + (size_t)(r + 3 * RL) * C + c, xd);
+  }
+  for (; r < r1; r += RL) {
+    T y = vfma(bn_ld<V>(X + (size_t)r * C + c), sc, sh);
+    if (relu) y = vrelu(y);
+    bn_st<V>(Y + (size_t)r * C + c, y);
   }
 }
 
-// partial column sums of dz and dz*xhat (dz = dY gated by the fused ReLU)
+// dz = dY gated by the fused ReLU (y = gamma*xhat + beta > 0), xhat = (x - mean) * rstd
+template <int V>
+__device__ __forceinline__ void bn_dz_xhat(typename VecT<V>::type x, typename VecT<V>::type& d, typename VecT<V>::type mu,
+                                           typename VecT<V>::type rs, typename VecT<V>::type g,
+                                           typename VecT<V>::type b, int relu, typename VecT<V>::type& xh) {
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    float h = (vget(x, k) - vget(mu, k)) * vget(rs, k);
+    vref(xh, k) = h;
+    if (relu && !(fmaf(h, vget(g, k), vget(b, k)) > 0.f)) vref(d, k) = 0.f;
+  }
+}
+
+template <int V>
+__device__ __forceinline__ void bn_col_params(const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                              int c, typename VecT<V>::type& mu, typename VecT<V>::type& rs,
+                                              typename VecT<V>::type& g, typename VecT<V>::type& b) {
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    vref(mu, k) = mean[c + k]; vref(rs, k) = rstd[c + k];
+    vref(g, k) = gamma ? gamma[c + k] : 1.f; vref(b, k) = beta ? beta[c + k] : 0.f;
+  }
+}
+
+// partial column sums of dz and dz*xhat
+template <int V>
 __global__ void __launch_bounds__(256)
 bn_bwd_partial_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                       const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                       int relu, int M, int C, int rows_per_split, float* __restrict__ ws) {
-  __shared__ float s_a[BN_RL][BN_COLS], s_b[BN_RL][BN_COLS];
-  const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
-  const int c = blockIdx.x * BN_COLS + tx;
+  using T = typename VecT<V>::type;
+  constexpr int CG = BnGeo<V>::CG, RL = BnGeo<V>::RL;
+  __shared__ float s_a[BN_MAXRL][BN_COLS], s_b[BN_MAXRL][BN_COLS];
+  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
+  const int c = blockIdx.x * BN_COLS + tx * V;
   const int r0 = blockIdx.y * rows_per_split, r1 = min(r0 + rows_per_split, M);
-  float sa = 0.f, sb = 0.f;
+  T sa = vzero<V>(), sb = vzero<V>(), sa2 = vzero<V>(), sb2 = vzero<V>();
   if (c < C) {
-    float mu = mean[c], rs = rstd[c], g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    float sa2 = 0.f, sb2 = 0.f;
+    T mu, rs, g, b;
+    bn_col_params<V>(mean, rstd, gamma, beta, c, mu, rs, g, b);
     int r = r0 + ty;
-    for (; r + BN_RL < r1; r += 2 * BN_RL) {       // two independent rows in flight
-      float x0 = X[(size_t)r * C + c], x1 = X[(size_t)(r + BN_RL) * C + c];
-      float d0 = dY[(size_t)r * C + c], d1 = dY[(size_t)(r + BN_RL) * C + c];
-      float h0 = (x0 - mu) * rs, h1 = (x1 - mu) * rs;
-      if (relu && !(fmaf(h0, g, b) > 0.f)) d0 = 0.f;
-      if (relu && !(fmaf(h1, g, b) > 0.f)) d1 = 0.f;
-      sa += d0; sb = fmaf(d0, h0, sb);
-      sa2 += d1; sb2 = fmaf(d1, h1, sb2);
+    for (; r + 3 * RL < r1; r += 4 * RL) {       // four independent rows in flight
+      T x0 = bn_ld<V>(X + (size_t)r * C + c), x1 = bn_ld<V>(X + (size_t)(r + RL) * C + c);
+      T x2 = bn_ld<V>(X + (size_t)(r + 2 * RL) * C + c), x3 = bn_ld<V>(X + (size_t)(r + 3 * RL) * C + c);
+      T d0 = bn_ld<V>(dY + (size_t)r * C + c), d1 = bn_ld<V>(dY + (size_t)(r + RL) * C + c);
+      T d2 = bn_ld<V>(dY + (size_t)(r + 2 * RL) * C + c), d3 = bn_ld<V>(dY + (size_t)(r + 3 * RL) * C + c);
+      T h0, h1, h2, h3;
+      bn_dz_xhat<V>(x0, d0, mu, rs, g, b, relu, h0); bn_dz_xhat<V>(x1, d1, mu, rs, g, b, relu, h1);
+      bn_dz_xhat<V>(x2, d2, mu, rs, g, b, relu, h2); bn_dz_xhat<V>(x3, d3, mu, rs, g, b, relu, h3);
+      sa = vadd(sa, d0); sb = vfma(d0, h0, sb);
+      sa2 = vadd(sa2, d1); sb2 = vfma(d1, h1, sb2);
+      sa = vadd(sa, d2); sb = vfma(d2, h2, sb);
+      sa2 = vadd(sa2, d3); sb2 = vfma(d3, h3, sb2);
     }
-    for (; r < r1; r += BN_RL) {
-      float xh = (X[(size_t)r * C + c] - mu) * rs;
-      float dz = dY[(size_t)r * C + c];
-      if (relu && !(fmaf(xh, g, b) > 0.f)) dz = 0.f;
-      sa += dz;
-      sb = fmaf(dz, xh, sb);
+    for (; r < r1; r += RL) {
+      T x0 = bn_ld<V>(X + (size_t)r * C + c), d0 = bn_ld<V>(dY + (size_t)r * C + c), h0;
+      bn_dz_xhat<V>(x0, d0, mu, rs, g, b, relu, h0);
+      sa = vadd(sa, d0); sb = vfma(d0, h0, sb);
     }
-    sa += sa2; sb += sb2;
+    sa = vadd(sa, sa2); sb = vadd(sb, sb2);
   }
-  s_a[ty][tx] = sa; s_b[ty][tx] = sb;
-  __syncthreads();
-  if (ty == 0 && c < C) {
 #pragma unroll
-    for (int l = 1; l < BN_RL; ++l) { sa += s_a[l][tx]; sb += s_b[l][tx]; }
-    float* o = ws + ((size_t)blockIdx.y * C + c) * 2;
-    o[0] = sa; o[1] = sb;
+  for (int k = 0; k < V; ++k) { s_a[ty][tx * V + k] = vget(sa, k); s_b[ty][tx * V + k] = vget(sb, k); }
+  __syncthreads();
+  if (threadIdx.x < BN_COLS) {
+    const int cc = blockIdx.x * BN_COLS + threadIdx.x;
+    if (cc < C) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int l = 0; l < RL; ++l) { a += s_a[l][threadIdx.x]; b += s_b[l][threadIdx.x]; }
+      float* o = ws + ((size_t)blockIdx.y * C + cc) * 2;
+      o[0] = a; o[1] = b;
+    }
   }
 }
 
+template <int V>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
                     int relu, const float* __restrict__ ws, int M, int C, int splits, int rows_per_block,
                     float* __restrict__ dX, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  using T = typename VecT<V>::type;
+  constexpr int CG = BnGeo<V>::CG, RL = BnGeo<V>::RL;
   __shared__ float s_db[BN_COLS], s_dg[BN_COLS];
-  __shared__ float s_pa[BN_RL][BN_COLS], s_pb[BN_RL][BN_COLS];
-  const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
-  const int c = blockIdx.x * BN_COLS + tx;
+  __shared__ float s_pa[4][BN_COLS], s_pb[4][BN_COLS];
   {
+    const int cx = threadIdx.x & (BN_COLS - 1), l = threadIdx.x / BN_COLS;
+    const int cc = blockIdx.x * BN_COLS + cx;
     float pa = 0.f, pb = 0.f;
-    if (c < C)
-      for (int sidx = ty; sidx < splits; sidx += BN_RL) {
-        const float* p = ws + ((size_t)sidx * C + c) * 2;
+    if (cc < C)
+      for (int sidx = l; sidx < splits; sidx += 4) {
+        const float* p = ws + ((size_t)sidx * C + cc) * 2;
         pa += p[0]; pb += p[1];
       }
-    s_pa[ty][tx] = pa; s_pb[ty][tx] = pb;
-  }
-  __syncthreads();
-  if (ty == 0 && c < C) {
-    float sa = ((s_pa[0][tx] + s_pa[1][tx]) + s_pa[2][tx]) + s_pa[3][tx];
-    float sb = ((s_pb[0][tx] + s_pb[1][tx]) + s_pb[2][tx]) + s_pb[3][tx];
-    s_db[tx] = sa; s_dg[tx] = sb;
-    if (blockIdx.y == 0) {
-      if (dbeta) dbeta[c] = sa;
-      if (dgamma) dgamma[c] = sb;
+    s_pa[l][cx] = pa; s_pb[l][cx] = pb;
+    __syncthreads();
+    if (l == 0 && cc < C) {
+      float sa = ((s_pa[0][cx] + s_pa[1][cx]) + s_pa[2][cx]) + s_pa[3][cx];
+      float sb = ((s_pb[0][cx] + s_pb[1][cx]) + s_pb[2][cx]) + s_pb[3][cx];
+      s_db[cx] = sa; s_dg[cx] = sb;
+      if (blockIdx.y == 0) {
+        if (dbeta) dbeta[cc] = sa;
+        if (dgamma) dgamma[cc] = sb;
+      }
     }
+    __syncthreads();
   }
-  __syncthreads();
+  const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
+  const int c = blockIdx.x * BN_COLS + tx * V;
   if (c >= C) return;
-  const float mu = mean[c], rs = rstd[c], g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  T mu, rs, g, b;
+  bn_col_params<V>(mean, rstd, gamma, beta, c, mu, rs, g, b);
   const float invM = 1.f / (float)M;
-  const float kb = s_db[tx] * invM, kg = s_dg[tx] * invM;
+  T kb, kg, grs = vmul(g, rs);
+#pragma unroll
+  for (int k = 0; k < V; ++k) { vref(kb, k) = s_db[tx * V + k] * invM; vref(kg, k) = s_dg[tx * V + k] * invM; }
   const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, M);
-  for (int r = r0 + ty; r < r1; r += BN_RL) {
-    float xh = (X[(size_t)r * C + c] - mu) * rs;
-    float dz = dY[(size_t)r * C + c];
-    if (relu && !(fmaf(xh, g, b) > 0.f)) dz = 0.f;
-    dX[(size_t)r * C + c] = g * rs * (dz - kb - xh * kg);
+  auto one = [&](T x, T d) -> T {
+    T h;
+    bn_dz_xhat<V>(x, d, mu, rs, g, b, relu, h);
+    T o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) vref(o, k) = vget(grs, k) * (vget(d, k) - vget(kb, k) - vget(h, k) * vget(kg, k));
+    return o;
+  };
+  int r = r0 + ty;
+  for (; r + RL < r1; r += 2 * RL) {
+    T x0 = bn_ld<V>(X + (size_t)r * C + c), x1 = bn_ld<V>(X + (size_t)(r + RL) * C + c);
+    T d0 = bn_ld<V>(dY + (size_t)r * C + c), d1 = bn_ld<V>(dY + (size_t)(r + RL) * C + c);
+    bn_st<V>(dX + (size_t)r * C + c, one(x0, d0));
+    bn_st<V>(dX + (size_t)(r + RL) * C + c, one(x1, d1));
   }
+  for (; r < r1; r += RL) bn_st<V>(dX + (size_t)r * C + c, one(bn_ld<V>(X + (size_t)r * C + c), bn_ld<V>(dY + (size_t)r * C + c)));
 }
 
 static inline void bn_geometry(int M, int* splits, int* rows) {
-  int s = (M + 127) / 128;          // >= 128 rows per split: (C/64) x splits workgroups fill the chip
+  int s = (M + 63) / 64;            // >= 64 rows per split: (C/64) x splits workgroups fill the chip
   if (s > 64) s = 64;
   if (s < 1) s = 1;
   *rows = (M + s - 1) / s;
   *splits = (M + *rows - 1) / *rows;
 }
 
+#define BN_RL 4   // row lanes of the scalar column-sum kernels
 // ---- column sums (bias gradients of the library-GEMM weight-gradient path): two launches, fixed order
 __global__ void __launch_bounds__(256)
 colsum_partial_kernel(const float* __restrict__ X, int M, int C, int rows_per_split, float* __restrict__ ws) {
@@ -277,6 +343,8 @@ extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* work
   return 0;
 }
 
+static inline bool bn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 extern "C" int msde_bn_workspace_floats(int M, int C) {
   int splits, rows;
   bn_geometry(M, &splits, &rows);
@@ -290,10 +358,18 @@ extern "C" int msde_bn_fwd(const float* X, int M, int C, const float* gamma, con
   int splits, rows;
   bn_geometry(M, &splits, &rows);
   dim3 grid((C + BN_COLS - 1) / BN_COLS, splits);
-  MSDE_LAUNCH(bn_stats_partial_kernel, grid, dim3(256), 0, as_stream(stream), X, M, C, rows, workspace);
-  MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(bn_fwd_apply_kernel, grid, dim3(256), 0, as_stream(stream), X, (const float*)workspace, M, C, splits, rows,
-              gamma, beta, eps, momentum, running_mean, running_var, relu, Y, save_mean, save_rstd);
+  const bool vec = (C % 4 == 0) && bn_aligned16(X) && bn_aligned16(Y);
+  if (vec) {
+    MSDE_LAUNCH(bn_stats_partial_kernel<4>, grid, dim3(256), 0, as_stream(stream), X, M, C, rows, workspace);
+    MSDE_CHECK_LAUNCH();
+    MSDE_LAUNCH(bn_fwd_apply_kernel<4>, grid, dim3(256), 0, as_stream(stream), X, (const float*)workspace, M, C, splits,
+                rows, gamma, beta, eps, momentum, running_mean, running_var, relu, Y, save_mean, save_rstd);
+  } else {
+    MSDE_LAUNCH(bn_stats_partial_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, M, C, rows, workspace);
+    MSDE_CHECK_LAUNCH();
+    MSDE_LAUNCH(bn_fwd_apply_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, (const float*)workspace, M, C, splits,
+                rows, gamma, beta, eps, momentum, running_mean, running_var, relu, Y, save_mean, save_rstd);
+  }
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -305,11 +381,20 @@ extern "C" int msde_bn_bwd(const float* dY, const float* X, const float* save_me
   int splits, rows;
   bn_geometry(M, &splits, &rows);
   dim3 grid((C + BN_COLS - 1) / BN_COLS, splits);
-  MSDE_LAUNCH(bn_bwd_partial_kernel, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta, relu,
-              M, C, rows, workspace);
-  MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta, relu,
-              (const float*)workspace, M, C, splits, rows, dX, dgamma, dbeta);
+  const bool vec = (C % 4 == 0) && bn_aligned16(X) && bn_aligned16(dY) && bn_aligned16(dX);
+  if (vec) {
+    MSDE_LAUNCH(bn_bwd_partial_kernel<4>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
+                relu, M, C, rows, workspace);
+    MSDE_CHECK_LAUNCH();
+    MSDE_LAUNCH(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
+                relu, (const float*)workspace, M, C, splits, rows, dX, dgamma, dbeta);
+  } else {
+    MSDE_LAUNCH(bn_bwd_partial_kernel<1>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
+                relu, M, C, rows, workspace);
+    MSDE_CHECK_LAUNCH();
+    MSDE_LAUNCH(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
+                relu, (const float*)workspace, M, C, splits, rows, dX, dgamma, dbeta);
+  }
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -462,8 +462,8 @@ def test_batchnorm_train_kernels(dev, M, C, relu):
         bn.weight.normal_(1, 0.3); bn.bias.normal_(0, 0.3)
     if M == 1:
         pytest.skip("torch refuses a single row in training mode")
-    y = bn(x)
-    y = torch.relu(y) if relu else y
+    y_pre = bn(x)
+    y = torch.relu(y_pre) if relu else y_pre
     w = torch.randn(M, C)
     (y * w).sum().backward()
     xd = x.detach().to(dev).requires_grad_(True)
@@ -473,9 +473,20 @@ def test_batchnorm_train_kernels(dev, M, C, relu):
     yd = hip.batch_norm_train(xd, gd, bd, rm, rv, 1e-5, 0.1, relu)
     assert_close(yd, y.detach(), 1e-4, 1e-5, "bn fwd")
     (yd * w.to(dev)).sum().backward()
-    assert_close(xd.grad, x.grad, 1e-3, 1e-5 * float(x.grad.abs().max()) + 1e-6, "bn dx")
-    assert_close(gd.grad, bn.weight.grad, 1e-4, 1e-4 * float(bn.weight.grad.abs().max()) + 1e-6, "bn dgamma")
-    assert_close(bd.grad, bn.bias.grad, 1e-4, 1e-4 * float(bn.bias.grad.abs().max()) + 1e-6, "bn dbeta")
+    # a pre-activation within rounding of 0 may fall on either side of the fused ReLU gate: those few
+    # elements are excluded from the element-wise input-gradient check (the column sums below keep them)
+    sure = (y_pre.detach().abs() > 1e-5) if relu else torch.ones_like(y_pre, dtype=torch.bool)
+    assert int((~sure).sum()) <= 1e-4 * sure.numel() + 2
+    assert_close(torch.where(sure.to(dev), xd.grad, torch.zeros_like(xd.grad)), torch.where(sure, x.grad, torch.zeros_like(x.grad)),
+                 1e-3, 1e-5 * float(x.grad.abs().max()) + 1e-6, "bn dx")
+    # column sums: an element on the gate boundary contributes |w| (dbeta) / |w xhat| (dgamma) or nothing
+    unsure = (~sure).float()
+    xhat = (y_pre.detach() - bn.bias.detach()) / bn.weight.detach()
+    for got, ref, allow, what in ((gd.grad, bn.weight.grad, (unsure * (w * xhat).abs()).sum(0), "bn dgamma"),
+                                  (bd.grad, bn.bias.grad, (unsure * w.abs()).sum(0), "bn dbeta")):
+        err = (got.cpu() - ref).abs()
+        bound = 1e-4 * ref.abs() + 1e-4 * float(ref.abs().max()) + 1e-6 + 1.01 * allow
+        assert bool((err <= bound).all()), f"{what}: max excess {(err - bound).max().item():.3e}"
     assert_close(rm, bn.running_mean, 1e-5, 1e-6, "running mean")
     assert_close(rv, bn.running_var, 1e-4, 1e-6, "running var")
 
