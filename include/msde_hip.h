@@ -61,10 +61,13 @@ int msde_gather_rows(const float* X, const int* idx, int E, int D, float* out, v
  * codes[i*K+k] already offset into the concatenated table tab[R,D]. */
 int msde_embedding_sum_fwd(const float* tab, const int* codes, int N, int K, int D, float* out,
                            void* stream);
-/* g_tab[r] += sum over list(r) of g[node]; lists given as CSR (list_ptr[R+1], list_nodes[..]);
- * g_tab must be zero-initialised by the caller; SPLIT partial sums are combined with atomics. */
+/* g_tab[r] = sum over list(r) of g[node]; lists given as CSR (list_ptr[R+1], list_nodes[..]).
+ * Every element of g_tab is written (no zero-init needed).  A row's list is cut into at most SPLIT slices
+ * whose partial sums are combined in slice order: deterministic, no atomics.  workspace:
+ * msde_embedding_sum_bwd_workspace_floats(R, D, split) floats. */
+long long msde_embedding_sum_bwd_workspace_floats(int R, int D, int split);
 int msde_embedding_sum_bwd(const float* g, const int* list_ptr, const int* list_nodes, int R,
-                           int D, int split, float* g_tab, void* stream);
+                           int D, int split, float* g_tab, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------ GIN -------------------- */
 /* GINConv.forward/message — molecule_gnn_model.py:22-29:
@@ -76,11 +79,14 @@ int msde_gin_aggregate_fwd(const float* x, const float* tab, const int* codes, c
 int msde_gin_aggregate_bwd_x(const float* g, const float* x, const float* tab, const int* codes,
                              const float* eps, const int* rowptr_s, const int* perm_s,
                              const int* dst, int N, int D, float* g_x, void* stream);
-/* g_tab[code] += g[dst]*mask (LDS-privatised, atomics on flush); g_eps += sum g*x.
- * g_tab [R,D] and g_eps[1] zero-initialised by the caller. R*D*4 must fit LDS (<= 64 KiB). */
+/* g_tab[code] = sum_e g[dst[e]] * [x[src[e]] + emb_e > 0] over the E edges (canonical by-target order, codes
+ * [E,3]); g_eps[0] = sum_i g[i].x[i].  Both outputs are fully written (no zero-init); per-workgroup partial
+ * tables are summed in a fixed order (deterministic, no atomics).  2*R*D*4 bytes must fit LDS (<= 64 KiB).
+ * workspace: msde_gin_aggregate_bwd_tab_workspace_floats(N, E, D, R) floats. */
+long long msde_gin_aggregate_bwd_tab_workspace_floats(int N, int E, int D, int R);
 int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab, const int* codes,
-                               const int* rowptr, const int* src, int N, int D, int R,
-                               float* g_tab, float* g_eps, void* stream);
+                               const int* src, const int* dst, int N, int E, int D, int R,
+                               float* g_tab, float* g_eps, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------ SchNet ----------------- */
 /* GaussianSmearing + cosine cutoff — schnet.py:186,205-207: rbf[e,g]=exp(coeff*(d-offset[g])^2),
@@ -217,6 +223,17 @@ int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void
 int msde_adam_flat(float* p, const float* g, float* m, float* v, long long n, const int* step_dev,
                    const long long* seg_end, const float* seg_lr, int S, float beta1, float beta2,
                    float eps, float weight_decay, float grad_scale, void* stream);
+
+/* Chunk-table variants (no flattening copy): table[c] = {gradient chunk address (0 = no gradient: zeros),
+ * chunk offset in the flat buffers, element count <= msde_chunk_elems()} as three int64 per chunk; chunks never
+ * straddle tensors.  msde_gather_chunks copies the gradients into the flat buffer (the message of the
+ * data-parallel all-reduce); msde_adam_chunks is msde_adam_flat reading the gradients through the table. */
+int msde_chunk_elems(void);
+int msde_gather_chunks(const long long* table, int n_chunks, float* flat, void* stream);
+int msde_adam_chunks(float* p, const long long* table, int n_chunks, float* m, float* v,
+                     const int* step_dev, const long long* seg_end, const float* seg_lr, int S,
+                     float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,10 +24,12 @@ SIGNATURES = {
     "msde_pair_gather_add": [P, P, P, P, I, I, P, P],
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
-    "msde_embedding_sum_bwd": [P, P, P, I, I, I, P, P],
+    "msde_embedding_sum_bwd_workspace_floats": [I, I, I],
+    "msde_embedding_sum_bwd": [P, P, P, I, I, I, P, P, P],
     "msde_gin_aggregate_fwd": [P, P, P, P, P, P, I, I, P, P],
     "msde_gin_aggregate_bwd_x": [P, P, P, P, P, P, P, P, I, I, P, P],
-    "msde_gin_aggregate_bwd_tab": [P, P, P, P, P, P, I, I, I, P, P, P],
+    "msde_gin_aggregate_bwd_tab_workspace_floats": [I, I, I, I],
+    "msde_gin_aggregate_bwd_tab": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],
     "msde_rbf_cutoff_fwd": [P, P, I, I, P, F, F, P, P, P],
     "msde_cfconv_aggregate_fwd": [P, P, P, P, P, I, I, P, P],
     "msde_cfconv_aggregate_bwd_w": [P, P, P, P, P, I, I, I, P, P],
@@ -53,9 +55,14 @@ SIGNATURES = {
     "msde_bn_fwd": [P, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
     "msde_bn_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P],
     "msde_adam_flat": [P, P, P, P, LL, P, P, P, I, F, F, F, F, F, P],
+    "msde_chunk_elems": [],
+    "msde_gather_chunks": [P, I, P, P],
+    "msde_adam_chunks": [P, P, I, P, P, P, P, P, I, F, F, F, F, F, P],
 }
 _RESTYPE = {"msde_target_arch": ctypes.c_char_p, "msde_linear_bwd_w_workspace_bytes": ctypes.c_longlong,
-            "msde_cfconv_fused_bwd_w_workspace_floats": ctypes.c_longlong}
+            "msde_cfconv_fused_bwd_w_workspace_floats": ctypes.c_longlong,
+            "msde_embedding_sum_bwd_workspace_floats": ctypes.c_longlong,
+            "msde_gin_aggregate_bwd_tab_workspace_floats": ctypes.c_longlong}
 
 _lib = None
 

@@ -65,52 +65,69 @@ __global__ void gin_aggregate_bwd_x_kernel(const float* __restrict__ g, const fl
   }
 }
 
-// by-target pass: table gradient accumulated in LDS (R*D floats), flushed with global atomics;
-// g_eps = sum_i g[i].x[i] reduced per block then one atomic.
+// Bond-table and eps gradients, deterministic and free of global atomics.  Block b owns GT_EC consecutive
+// edges (canonical by-target order) and a slice of the nodes; thread t owns column t (+ blockDim, ...) of the
+// LDS copies of the table (for the ReLU gate x[src] + emb > 0) and of the block's partial gradient table, so
+// the read-modify-writes never race.  Four edges' row loads are in flight per thread.  The partial tables
+// (R*D floats per block) and eps partials are summed over blocks in index order by reduce_slabs.
+#define GT_EC 16
 __global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                              const float* __restrict__ tab, const int* __restrict__ codes,
-                                             const int* __restrict__ rowptr, const int* __restrict__ src, int N, int D,
-                                             int R, int nodes_per_block, float* __restrict__ g_tab,
-                                             float* __restrict__ g_eps) {
-  extern __shared__ float lds[];  // [R*D] + [blockDim/64]
-  float* ltab = lds;
-  float* red = lds + (size_t)R * D;
-  for (int t = threadIdx.x; t < R * D; t += blockDim.x) ltab[t] = 0.f;
+                                             const int* __restrict__ src, const int* __restrict__ dst, int N, int E,
+                                             int D, int R, int nodes_per_block, float* __restrict__ slabs,
+                                             float* __restrict__ eps_part) {
+  extern __shared__ float lds[];  // [R*D] table copy, [R*D] partial gradient, [blockDim/64] reduction scratch
+  float* stab = lds;
+  float* ltab = lds + (size_t)R * D;
+  float* red = ltab + (size_t)R * D;
+  for (int t = threadIdx.x; t < R * D; t += blockDim.x) { stab[t] = tab[t]; ltab[t] = 0.f; }
   __syncthreads();
-  int n0 = blockIdx.x * nodes_per_block, n1 = min(n0 + nodes_per_block, N);
-  float eacc = 0.f;
-  for (int i = n0; i < n1; ++i) {
-    int s0 = rowptr[i], s1 = rowptr[i + 1];
-    for (int c = threadIdx.x; c < D; c += blockDim.x) {
-      float gi = g[(size_t)i * D + c];
-      eacc = fmaf(gi, x[(size_t)i * D + c], eacc);
-      for (int e = s0; e < s1; ++e) {
-        int c0 = codes[3 * e], c1 = codes[3 * e + 1], c2 = codes[3 * e + 2];
-        float emb = (tab[(size_t)c0 * D + c] + tab[(size_t)c1 * D + c]) + tab[(size_t)c2 * D + c];
-        float m = x[(size_t)src[e] * D + c] + emb;
-        if (m > 0.f) {
-          // column c is owned by this thread within the block: no LDS race, plain read-modify-write
-          ltab[c0 * D + c] += gi;
-          ltab[c1 * D + c] += gi;
-          ltab[c2 * D + c] += gi;
+  const int e0 = blockIdx.x * GT_EC, e1 = min(e0 + GT_EC, E);
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    for (int eb = e0; eb < e1; eb += 4) {
+      float xv[4], gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int e = min(eb + u, e1 - 1);
+        xv[u] = x[(size_t)src[e] * D + c];
+        gv[u] = g[(size_t)dst[e] * D + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int e = eb + u;
+        if (e < e1) {
+          int c0 = codes[3 * e], c1 = codes[3 * e + 1], c2 = codes[3 * e + 2];
+          float emb = (stab[c0 * D + c] + stab[c1 * D + c]) + stab[c2 * D + c];
+          if (xv[u] + emb > 0.f) {
+            ltab[c0 * D + c] += gv[u];
+            ltab[c1 * D + c] += gv[u];
+            ltab[c2 * D + c] += gv[u];
+          }
         }
       }
     }
   }
+  // eps partial: sum_i g[i].x[i] over this block's node slice
+  float eacc = 0.f;
+  const int n0 = blockIdx.x * nodes_per_block, n1 = min(n0 + nodes_per_block, N);
+  for (int i = n0; i < n1; ++i)
+    for (int c = threadIdx.x; c < D; c += blockDim.x) eacc = fmaf(g[(size_t)i * D + c], x[(size_t)i * D + c], eacc);
   __syncthreads();
-  for (int t = threadIdx.x; t < R * D; t += blockDim.x) {
-    float v = ltab[t];
-    if (v != 0.f) atomicAdd(&g_tab[t], v);
-  }
-  // block reduce eacc
+  float* slab = slabs + (size_t)blockIdx.x * R * D;
+  for (int t = threadIdx.x; t < R * D; t += blockDim.x) slab[t] = ltab[t];
   eacc = group_sum(eacc, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = eacc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
-    atomicAdd(g_eps, s);
+    float sum = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += red[w];
+    eps_part[blockIdx.x] = sum;
   }
+}
+
+static inline int gt_blocks(int N, int E) {
+  int nb = (E + GT_EC - 1) / GT_EC;
+  return nb < 1 ? 1 : nb;
 }
 
 extern "C" int msde_gin_aggregate_fwd(const float* x, const float* tab, const int* codes, const float* eps,
@@ -132,16 +149,26 @@ extern "C" int msde_gin_aggregate_bwd_x(const float* g, const float* x, const fl
   return 0;
 }
 
+extern "C" long long msde_gin_aggregate_bwd_tab_workspace_floats(int N, int E, int D, int R) {
+  return (long long)gt_blocks(N, E) * ((long long)R * D + 1);
+}
+
 extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab, const int* codes,
-                                          const int* rowptr, const int* src, int N, int D, int R, float* g_tab,
-                                          float* g_eps, void* stream) {
-  if (N < 0 || D <= 0 || R <= 0 || !g || !x || !tab || !rowptr || !g_tab || !g_eps) return MSDE_EINVAL;
-  size_t lds = ((size_t)R * D + 8) * sizeof(float);
+                                          const int* src, const int* dst, int N, int E, int D, int R, float* g_tab,
+                                          float* g_eps, float* workspace, void* stream) {
+  if (N < 0 || E < 0 || D <= 0 || R <= 0 || !g || !x || !tab || !g_tab || !g_eps || !workspace) return MSDE_EINVAL;
+  if (E > 0 && (!codes || !src || !dst)) return MSDE_EINVAL;
+  hipStream_t st = as_stream(stream);
+  int threads = ((D + 63) / 64) * 64;
+  if (threads > 512) threads = 512;
+  size_t lds = (2 * (size_t)R * D + 8) * sizeof(float);
   if (lds > 64 * 1024) return MSDE_EUNSUP;
-  if (N == 0) return 0;
-  int npb = 16;
-  MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3((N + npb - 1) / npb), dim3(256), lds, as_stream(stream), g, x,
-                     tab, codes, rowptr, src, N, D, R, npb, g_tab, g_eps);
+  int nb = gt_blocks(N, E);
+  int npb = (N + nb - 1) / nb;
+  float* slabs = workspace;
+  float* eps_part = workspace + (size_t)nb * R * D;
+  MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3(nb), dim3(threads), lds, st, g, x, tab, codes, src, dst, N, E, D, R, npb,
+              slabs, eps_part);
   MSDE_CHECK_LAUNCH();
-  return 0;
+  return msde_reduce_slabs(slabs, nb, (size_t)R * D, g_tab, eps_part, 1, g_eps, st);
 }

@@ -262,34 +262,87 @@ extern "C" int msde_embedding_sum_fwd(const float* tab, const int* codes, int N,
   return 0;
 }
 
-// block (r, s): table row r, slice s of its node list; one wave-wide pass over D per slice.
-__global__ void embedding_sum_bwd_kernel(const float* __restrict__ g, const int* __restrict__ list_ptr,
-                                         const int* __restrict__ list_nodes, int D, int split,
-                                         float* __restrict__ g_tab) {
-  int r = blockIdx.x, s = blockIdx.y;
-  int p0 = list_ptr[r], p1 = list_ptr[r + 1];
-  int len = p1 - p0;
-  if (len == 0) return;
-  // lists shorter than 32 rows stay in one slice (plain store, bitwise deterministic)
-  int chunk = max((len + split - 1) / split, 32);
-  int a = p0 + s * chunk, b = min(a + chunk, p1);
-  if (a >= b) return;
-  for (int c = threadIdx.x; c < D; c += blockDim.x) {
-    float acc = 0.f;
-    for (int p = a; p < b; ++p) acc += g[(size_t)list_nodes[p] * D + c];
-    if (len <= chunk)
-      g_tab[(size_t)r * D + c] = acc;  // single slice owns the row: plain store, deterministic
-    else
-      atomicAdd(&g_tab[(size_t)r * D + c], acc);
+// Table gradient g_tab[r] = sum over list(r) of g[node], deterministic and atomic-free:
+//   pass 1, block (r, s, column tile): slice s of row r's node list, 4 item lanes x 64 column lanes, four row
+//           loads in flight per thread; the 4 item lanes are combined in lane order and the partial row goes to
+//           slab[s][r][:].  Row r is cut into slices(r) = clamp(ceil(len/32), 1, split) slices.
+//   pass 2, one thread per table element: sums its row's slices in index order (zero for an empty list).
+#define ES_ITEMS_PER_SLICE 32
+__device__ __forceinline__ int es_slices(int len, int split) {
+  int s = (len + ES_ITEMS_PER_SLICE - 1) / ES_ITEMS_PER_SLICE;
+  return s < 1 ? 1 : (s > split ? split : s);
+}
+
+template <int V>
+__global__ void __launch_bounds__(256)
+embedding_sum_bwd_partial_kernel(const float* __restrict__ g, const int* __restrict__ list_ptr,
+                                 const int* __restrict__ list_nodes, int R, int D, int split, float* __restrict__ slab) {
+  using T = typename VecT<V>::type;
+  __shared__ T part[4][64];
+  const int r = blockIdx.x, s = blockIdx.y;
+  const int p0 = list_ptr[r], len = list_ptr[r + 1] - p0;
+  const int ns = es_slices(len, split);
+  if (len == 0 || s >= ns) return;
+  const int chunk = (len + ns - 1) / ns;
+  const int a = p0 + s * chunk, b = min(a + chunk, p0 + len);
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int c = (blockIdx.z * 64 + lx) * V;
+  T acc = vzero<V>(), acc2 = vzero<V>();
+  if (c < D) {
+    int p = a + ly;
+    for (; p + 12 < b; p += 16) {
+      int n0 = list_nodes[p], n1 = list_nodes[p + 4], n2 = list_nodes[p + 8], n3 = list_nodes[p + 12];
+      T v0 = *reinterpret_cast<const T*>(g + (size_t)n0 * D + c), v1 = *reinterpret_cast<const T*>(g + (size_t)n1 * D + c);
+      T v2 = *reinterpret_cast<const T*>(g + (size_t)n2 * D + c), v3 = *reinterpret_cast<const T*>(g + (size_t)n3 * D + c);
+      acc = vadd(acc, v0); acc2 = vadd(acc2, v1); acc = vadd(acc, v2); acc2 = vadd(acc2, v3);
+    }
+    for (; p < b; p += 4) acc = vadd(acc, *reinterpret_cast<const T*>(g + (size_t)list_nodes[p] * D + c));
+    acc = vadd(acc, acc2);
+  }
+  part[ly][lx] = acc;
+  __syncthreads();
+  if (ly == 0 && c < D) {
+    T t = vadd(vadd(vadd(part[0][lx], part[1][lx]), part[2][lx]), part[3][lx]);
+    *reinterpret_cast<T*>(slab + ((size_t)s * R + r) * D + c) = t;
   }
 }
 
+__global__ void __launch_bounds__(256)
+embedding_sum_bwd_reduce_kernel(const float* __restrict__ slab, const int* __restrict__ list_ptr, int R, int D, int split,
+                                float* __restrict__ g_tab) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * D) return;
+  int r = (int)(i / D);
+  int len = list_ptr[r + 1] - list_ptr[r];
+  float acc = 0.f;
+  if (len > 0) {
+    int ns = es_slices(len, split);
+    for (int s = 0; s < ns; ++s) acc += slab[(size_t)s * R * D + i];
+  }
+  g_tab[i] = acc;
+}
+
+extern "C" long long msde_embedding_sum_bwd_workspace_floats(int R, int D, int split) {
+  if (split < 1) split = 1;
+  return (long long)split * R * D;
+}
+
 extern "C" int msde_embedding_sum_bwd(const float* g, const int* list_ptr, const int* list_nodes, int R, int D,
-                                      int split, float* g_tab, void* stream) {
-  if (R <= 0 || D <= 0 || split <= 0 || !g || !list_ptr || !list_nodes || !g_tab) return MSDE_EINVAL;
-  int threads = D >= 256 ? 256 : ((D + 63) / 64) * 64;
-  MSDE_LAUNCH(embedding_sum_bwd_kernel, dim3(R, split), dim3(threads), 0, as_stream(stream), g, list_ptr,
-                     list_nodes, D, split, g_tab);
+                                      int split, float* g_tab, float* workspace, void* stream) {
+  if (R <= 0 || D <= 0 || split <= 0 || !g || !list_ptr || !list_nodes || !g_tab || !workspace) return MSDE_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const bool vec = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(g) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+  if (vec)
+    MSDE_LAUNCH(embedding_sum_bwd_partial_kernel<4>, dim3(R, split, (D / 4 + 63) / 64), dim3(256), 0, st, g, list_ptr,
+                list_nodes, R, D, split, workspace);
+  else
+    MSDE_LAUNCH(embedding_sum_bwd_partial_kernel<1>, dim3(R, split, (D + 63) / 64), dim3(256), 0, st, g, list_ptr,
+                list_nodes, R, D, split, workspace);
+  MSDE_CHECK_LAUNCH();
+  size_t n = (size_t)R * D;
+  MSDE_LAUNCH(embedding_sum_bwd_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+              (const float*)workspace, list_ptr, R, D, split, g_tab);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

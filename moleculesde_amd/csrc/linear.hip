@@ -232,6 +232,19 @@ reduce_slabs_kernel(const float* __restrict__ slabs, int splits, size_t n, float
   }
 }
 
+// out[i] = sum_z slabs[z*n + i] (z in index order, 16 interleaved lanes) and, when cs != nullptr, the same
+// for a second family outb[j] = sum_z cs[z*nb + j].  Shared by the other translation units (msde_common.h).
+int msde_reduce_slabs(const float* slabs, int splits, size_t n, float* out, const float* cs, size_t nb, float* outb,
+                      hipStream_t st) {
+  size_t total = n + (cs ? nb : 0);
+  int blocks = (int)((total + 15) / 16);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  MSDE_LAUNCH(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, n, out, cs, nb, outb);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int TM, int TN, bool A_KM, bool B_KM>
@@ -342,11 +355,5 @@ extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, 
   // C[N,K] = A^T B with A = gY [M][N] (k-major, "M" of the product = N), B = X [M][K] (k-major)
   int rc = launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, wgrad_big(M, N, K), st);
   if (rc != 0) return rc;
-  size_t n = (size_t)N * K;
-  int blocks = (int)((n + (size_t)N + 15) / 16);
-  if (blocks > 4096) blocks = 4096;
-  MSDE_LAUNCH(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, slabs, splits, n, gW, (const float*)cs, (size_t)N,
-              gb);
-  MSDE_CHECK_LAUNCH();
-  return 0;
+  return msde_reduce_slabs(slabs, splits, (size_t)N * K, gW, cs, (size_t)N, gb, st);
 }

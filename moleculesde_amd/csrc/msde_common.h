@@ -23,6 +23,10 @@
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// fixed-order sum of per-workgroup partial slabs (defined in linear.hip)
+int msde_reduce_slabs(const float* slabs, int splits, size_t n, float* out, const float* cs, size_t nb, float* outb,
+                      hipStream_t st);
+
 // compute units of the current device (256 on MI355X); queried once -- one process drives one GPU model
 static inline int msde_num_cus() {
   static int cus = 0;

@@ -16,6 +16,7 @@ template <int V> struct BnGeo {
   static constexpr int CG = BN_COLS / V, RL = 256 / CG;
 };
 #define BN_MAXRL 16
+#define BN_MAXSPLIT 64   // bn_geometry never makes more row splits than this
 
 template <int V> __device__ __forceinline__ typename VecT<V>::type bn_ld(const float* p) {
   return *reinterpret_cast<const typename VecT<V>::type*>(p);
@@ -102,11 +103,19 @@ bn_fwd_apply_kernel(const float* __restrict__ X, const float* __restrict__ ws, i
     const int cx = threadIdx.x & (BN_COLS - 1), l = threadIdx.x / BN_COLS;
     const int cc = blockIdx.x * BN_COLS + cx;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (cc < C)
-      for (int sidx = l; sidx < splits; sidx += 4) {
-        const float* p = ws + ((size_t)sidx * C + cc) * 3;
-        bn_merge(n, mean, m2, p[0], p[1], p[2]);
+    if (cc < C) {
+      // all of this lane's partials are requested first (independent loads), then merged in split order
+      float pn[BN_MAXSPLIT / 4], pm[BN_MAXSPLIT / 4], pq[BN_MAXSPLIT / 4];
+#pragma unroll
+      for (int k = 0; k < BN_MAXSPLIT / 4; ++k) {
+        int sidx = l + 4 * k;
+        bool ok = sidx < splits;
+        const float* p = ws + ((size_t)(ok ? sidx : 0) * C + cc) * 3;
+        pn[k] = ok ? p[0] : 0.f; pm[k] = p[1]; pq[k] = p[2];
       }
+#pragma unroll
+      for (int k = 0; k < BN_MAXSPLIT / 4; ++k) bn_merge(n, mean, m2, pn[k], pm[k], pq[k]);
+    }
     s_n[l][cx] = n; s_mean[l][cx] = mean; s_m2[l][cx] = m2;
     __syncthreads();
     if (l == 0 && cc < C) {
@@ -242,11 +251,18 @@ bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, c
     const int cx = threadIdx.x & (BN_COLS - 1), l = threadIdx.x / BN_COLS;
     const int cc = blockIdx.x * BN_COLS + cx;
     float pa = 0.f, pb = 0.f;
-    if (cc < C)
-      for (int sidx = l; sidx < splits; sidx += 4) {
-        const float* p = ws + ((size_t)sidx * C + cc) * 2;
-        pa += p[0]; pb += p[1];
+    if (cc < C) {
+      float qa[BN_MAXSPLIT / 4], qb[BN_MAXSPLIT / 4];
+#pragma unroll
+      for (int k = 0; k < BN_MAXSPLIT / 4; ++k) {
+        int sidx = l + 4 * k;
+        bool ok = sidx < splits;
+        const float* p = ws + ((size_t)(ok ? sidx : 0) * C + cc) * 2;
+        qa[k] = ok ? p[0] : 0.f; qb[k] = ok ? p[1] : 0.f;
       }
+#pragma unroll
+      for (int k = 0; k < BN_MAXSPLIT / 4; ++k) { pa += qa[k]; pb += qb[k]; }
+    }
     s_pa[l][cx] = pa; s_pb[l][cx] = pb;
     __syncthreads();
     if (l == 0 && cc < C) {
@@ -290,7 +306,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, c
 
 static inline void bn_geometry(int M, int* splits, int* rows) {
   int s = (M + 63) / 64;            // >= 64 rows per split: (C/64) x splits workgroups fill the chip
-  if (s > 64) s = 64;
+  if (s > BN_MAXSPLIT) s = BN_MAXSPLIT;
   if (s < 1) s = 1;
   *rows = (M + s - 1) / s;
   *splits = (M + *rows - 1) / *rows;

@@ -40,3 +40,69 @@ extern "C" int msde_adam_flat(float* p, const float* g, float* m, float* v, long
   MSDE_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- chunk-table variants: the gradients stay where autograd left them -------------------------------------
+// table[c] = {address of the chunk's first gradient element (0: the parameter received no gradient -> zeros),
+//             offset of the chunk in the flat buffers, element count (<= MSDE_CHUNK)}, three int64 per chunk.
+// One workgroup per chunk; chunks never straddle tensors.
+#define MSDE_CHUNK 2048
+
+__global__ void __launch_bounds__(256)
+gather_chunks_kernel(const long long* __restrict__ table, float* __restrict__ flat) {
+  const long long* e = table + (size_t)blockIdx.x * 3;
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  float* dst = flat + e[1];
+  const int cnt = (int)e[2];
+  for (int i = threadIdx.x; i < cnt; i += 256) dst[i] = src ? src[i] : 0.f;
+}
+
+__global__ void __launch_bounds__(256)
+adam_chunks_kernel(float* __restrict__ p, const long long* __restrict__ table, float* __restrict__ m,
+                   float* __restrict__ v, const int* __restrict__ step_dev, const long long* __restrict__ seg_end,
+                   const float* __restrict__ seg_lr, int S, float beta1, float beta2, float eps, float wd,
+                   float grad_scale) {
+  const long long* e = table + (size_t)blockIdx.x * 3;
+  const float* g = reinterpret_cast<const float*>(e[0]);
+  const long long off = e[1];
+  const int cnt = (int)e[2];
+  const int t = step_dev[0];
+  const float bc1 = 1.f - powf(beta1, (float)t);
+  const float bc2 = 1.f - powf(beta2, (float)t);
+  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  int s = 0;
+  while (s < S - 1 && off >= seg_end[s]) ++s;       // a chunk lies inside one tensor, hence inside one group
+  const float lr = seg_lr[s];
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const long long k = off + i;
+    float pi = p[k];
+    float gi = (g ? g[i] : 0.f) * grad_scale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float mi = beta1 * m[k] + (1.f - beta1) * gi;
+    float vi = beta2 * v[k] + (1.f - beta2) * gi * gi;
+    m[k] = mi;
+    v[k] = vi;
+    float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[k] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+extern "C" int msde_chunk_elems(void) { return MSDE_CHUNK; }
+
+extern "C" int msde_gather_chunks(const long long* table, int n_chunks, float* flat, void* stream) {
+  if (n_chunks < 0 || !table || !flat) return MSDE_EINVAL;
+  if (n_chunks == 0) return 0;
+  MSDE_LAUNCH(gather_chunks_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), table, flat);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_adam_chunks(float* p, const long long* table, int n_chunks, float* m, float* v, const int* step_dev,
+                                const long long* seg_end, const float* seg_lr, int S, float beta1, float beta2,
+                                float eps, float weight_decay, float grad_scale, void* stream) {
+  if (n_chunks < 0 || S <= 0 || !p || !table || !m || !v || !step_dev || !seg_end || !seg_lr) return MSDE_EINVAL;
+  if (n_chunks == 0) return 0;
+  MSDE_LAUNCH(adam_chunks_kernel, dim3(n_chunks), dim3(256), 0, as_stream(stream), p, table, m, v, step_dev, seg_end,
+              seg_lr, S, beta1, beta2, eps, weight_decay, grad_scale);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

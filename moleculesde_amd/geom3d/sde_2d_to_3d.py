@@ -153,6 +153,7 @@ class SDEModel2Dto3D_02(nn.Module):
         self.num_diffusion_timesteps = num_diffusion_timesteps
         self.noise = _nn.DeviceNoise()     # set to nn.CpuReplayNoise(seed) for replayable parity runs
         self.side_stream = None            # optional second HIP stream for the coordinate-only branch
+        self._pending = None               # results of begin() waiting for forward()
 
     def _plan(self, data):
         pl = _plan.get_plan(data)
@@ -168,35 +169,24 @@ class SDEModel2Dto3D_02(nn.Module):
         edge_attr_3D_frame_invariant = self.project(torch.cat([angle, embed_i, embed_j], dim=-1))
         return edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis
 
-    def _edge_and_node_features(self, node_2D_repr, pos_perturbed, ep):
-        D = self.emb_dim
-        # the coordinate branch is independent of the 2D representation: run it on the side stream (if the
-        # trainer gave us one) beside the 2D-embedding branch; autograd mirrors the overlap in the backward
-        side = self.side_stream if (self.side_stream is not None and node_2D_repr.is_cuda) else None
+    def _launch_geometry(self, pos_perturbed, ep):
+        """Start the coordinate-only branch: on the side stream if the trainer gave us one (it is independent of
+        the 2D representation, so it runs beside the GIN encoder / the 2D-embedding branch; autograd mirrors the
+        overlap in the backward), else inline.  Returns (tensors, side stream used or None)."""
+        side = self.side_stream if (self.side_stream is not None and pos_perturbed.is_cuda) else None
         if side is not None:
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
+            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis = self._geometry_branch(pos_perturbed, ep)
+                geo = self._geometry_branch(pos_perturbed, ep)
         else:
-            edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis = self._geometry_branch(pos_perturbed, ep)
-        # edge_2D_emb[0](cat(h[row], h[col])) == h[row] W[:, :D]^T + h[col] W[:, D:]^T + b
-        lin0 = self.edge_2D_emb[0]
-        A = _nn.linear(node_2D_repr, lin0.weight[:, :D])
-        Bm = _nn.linear(node_2D_repr, lin0.weight[:, D:], lin0.bias)
-        pre = hip.pair_gather_add(A, Bm, ep)
-        edge_attr_2D = self.edge_2D_emb[3](self.edge_2D_emb[2](self.edge_2D_emb[1](pre)))
-        if side is not None:
-            main.wait_stream(side)
-            for t in (edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis):
-                t.record_stream(main)
-        edge_attr = edge_attr_3D_invariant * edge_attr_2D + edge_attr_3D_frame_invariant
-        node_attr = self.node_emb(node_2D_repr)
-        return node_attr, edge_attr, basis
+            geo = self._geometry_branch(pos_perturbed, ep)
+        return geo, side
 
-    def forward(self, node_2D_repr, data, anneal_power):
+    def begin(self, data):
+        """Optional early start (the trainer calls it BEFORE the 2D encoder runs): draws this step's noise --
+        same draws, same order as forward() -- perturbs the coordinates and launches the coordinate-only branch,
+        which then overlaps the GIN forward.  forward(node_2D_repr, data, ...) picks the results up."""
         pos = data.positions
-        node2graph = data.batch
         pl, ep = self._plan(data)
         B = data.num_graphs
         T = self.num_diffusion_timesteps
@@ -205,11 +195,39 @@ class SDEModel2Dto3D_02(nn.Module):
         time_step = torch.cat([time_step, T - time_step - 1], dim=0)[:B]
         if self.SDE_type in ("VE", "VP"):
             time_step = time_step / T * (1 - EPSILON) + EPSILON
-        t_pos = time_step.index_select(0, node2graph)
+        t_pos = time_step.index_select(0, data.batch)
         mean_pos, std_pos = self.sde_pos.marGINal_prob(pos.detach(), t_pos)
         pos_perturbed = mean_pos + std_pos[:, None] * pos_noise
+        geo, side = self._launch_geometry(pos_perturbed, ep)
+        self._pending = (data, pos_noise, std_pos, pos_perturbed, geo, side)
 
-        node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep)
+    def _edge_and_node_features(self, node_2D_repr, pos_perturbed, ep, started=None):
+        D = self.emb_dim
+        geo, side = started if started is not None else self._launch_geometry(pos_perturbed, ep)
+        edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis = geo
+        # edge_2D_emb[0](cat(h[row], h[col])) == h[row] W[:, :D]^T + h[col] W[:, D:]^T + b
+        lin0 = self.edge_2D_emb[0]
+        A = _nn.linear(node_2D_repr, lin0.weight[:, :D])
+        Bm = _nn.linear(node_2D_repr, lin0.weight[:, D:], lin0.bias)
+        pre = hip.pair_gather_add(A, Bm, ep)
+        edge_attr_2D = self.edge_2D_emb[3](self.edge_2D_emb[2](self.edge_2D_emb[1](pre)))
+        if side is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            for t in (edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis):
+                t.record_stream(main)
+        edge_attr = edge_attr_3D_invariant * edge_attr_2D + edge_attr_3D_frame_invariant
+        node_attr = self.node_emb(node_2D_repr)
+        return node_attr, edge_attr, basis
+
+    def forward(self, node_2D_repr, data, anneal_power):
+        pl, ep = self._plan(data)
+        if self._pending is None or self._pending[0] is not data:
+            self.begin(data)
+        _, pos_noise, std_pos, pos_perturbed, geo, side = self._pending
+        self._pending = None
+
+        node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep, (geo, side))
         scores = self.score_network(ep, node_attr, edge_attr, basis)["gradient"]
         if anneal_power == 0:
             loss_pos = torch.sum((scores - pos_noise) ** 2, -1)

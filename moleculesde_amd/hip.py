@@ -253,8 +253,10 @@ class _EmbeddingSum(torch.autograd.Function):
     def backward(ctx, g):
         list_ptr, list_nodes = ctx.saved_tensors
         g = _f32(g)
-        g_tab = torch.zeros(ctx.R, ctx.D, dtype=torch.float32, device=g.device)
-        _lib.call("msde_embedding_sum_bwd", _p(g), _p(list_ptr), _p(list_nodes), ctx.R, ctx.D, 16, _p(g_tab), _stream())
+        g_tab = torch.empty(ctx.R, ctx.D, dtype=torch.float32, device=g.device)
+        ws = _scratch(int(_lib.load().msde_embedding_sum_bwd_workspace_floats(ctx.R, ctx.D, EMB_BWD_SPLIT)), g.device)
+        _lib.call("msde_embedding_sum_bwd", _p(g), _p(list_ptr), _p(list_nodes), ctx.R, ctx.D, EMB_BWD_SPLIT, _p(g_tab),
+                  _p(ws), _stream())
         return g_tab, None, None, None
 
 
@@ -286,10 +288,11 @@ class _GinAggregate(torch.autograd.Function):
         g_x = torch.empty_like(x)
         _lib.call("msde_gin_aggregate_bwd_x", _p(g), _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr_s),
                   _p(plan.perm_s), _p(plan.dst), N, D, _p(g_x), st)
-        g_tab = torch.zeros_like(tab)
-        g_eps = torch.zeros(1, dtype=torch.float32, device=x.device)
-        _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.rowptr), _p(plan.src), N, D,
-                  R, _p(g_tab), _p(g_eps), st)
+        g_tab = torch.empty_like(tab)
+        g_eps = torch.empty(1, dtype=torch.float32, device=x.device)
+        ws = _scratch(int(_lib.load().msde_gin_aggregate_bwd_tab_workspace_floats(N, plan.E, D, R)), x.device)
+        _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N, plan.E,
+                  D, R, _p(g_tab), _p(g_eps), _p(ws), st)
         return g_x, g_tab, g_eps, None, None
 
 
@@ -592,6 +595,19 @@ _WS = {}          # per-device wgrad slab workspace, grown on demand (stream-ord
 _WS_BYTES = {}    # (M, N, K) -> workspace bytes
 
 
+_SCRATCH = {}     # per-(device, stream) scratch of the table-gradient kernels
+EMB_BWD_SPLIT = 32   # max slices per table row in msde_embedding_sum_bwd
+
+
+def _scratch(nfloats, device):
+    key = _ws_key(device)
+    ws = _SCRATCH.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=key[0])
+        _SCRATCH[key] = ws
+    return ws
+
+
 def _ws_key(device):
     """Workspaces are per (device, stream): kernels on concurrent streams must not share scratch."""
     return (device, torch.cuda.current_stream().cuda_stream)
@@ -807,6 +823,19 @@ def res_layernorm(x, res, gamma, beta, eps=1e-5):
 # ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------
+def chunk_elems():
+    return int(_lib.load().msde_chunk_elems())
+
+
+def gather_chunks(table, n_chunks, flat):
+    _lib.call("msde_gather_chunks", _p(table), n_chunks, _p(flat), _stream())
+
+
+def adam_chunks(p, table, n_chunks, m, v, step_dev, seg_end, seg_lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    _lib.call("msde_adam_chunks", _p(p), _p(table), n_chunks, _p(m), _p(v), _p(step_dev), _p(seg_end), _p(seg_lr),
+              int(seg_end.numel()), float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _stream())
+
+
 def adam_flat(p, g, m, v, step_dev, seg_end, seg_lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
     _lib.call("msde_adam_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(step_dev), _p(seg_end), _p(seg_lr),
               seg_lr.numel(), float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _stream())

@@ -37,7 +37,9 @@ class FlatAdam:
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.grad_views = []
+        self.offsets, self.sizes = [], []
+        self._chunk = hip.chunk_elems()
+        self._grad_keep = []
         off = 0
         with torch.no_grad():
             for p in self.params:
@@ -45,8 +47,20 @@ class FlatAdam:
                 view = self.flat_p[off:off + n].view_as(p)
                 view.copy_(p.data)
                 p.data = view                       # parameters now alias the flat buffer
-                self.grad_views.append(self.flat_g[off:off + n].view_as(p))
+                self.offsets.append(off)
+                self.sizes.append(n)
                 off += n
+        import numpy as np
+        ch = self._chunk
+        self._chunks_per_param = [(n + ch - 1) // ch for n in self.sizes]
+        self.n_chunks = sum(self._chunks_per_param)
+        self._chunk_bytes = np.arange(max(self._chunks_per_param), dtype=np.int64) * (4 * ch)
+        self._chunk_off = torch.tensor([o + c * ch for o, nc in zip(self.offsets, self._chunks_per_param) for c in range(nc)],
+                                       dtype=torch.int64)
+        self._chunk_cnt = torch.tensor([min(ch, n - c * ch) for n, nc in zip(self.sizes, self._chunks_per_param)
+                                        for c in range(nc)], dtype=torch.int64)
+        self._slots = []
+        self.new_table_slot()
         self.seg_end = torch.tensor(seg_end, dtype=torch.int64, device=dev)
         self.seg_lr = torch.tensor(seg_lr, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -55,23 +69,53 @@ class FlatAdam:
         for p in self.params:
             p.grad = None
 
-    def gather_grads(self):
-        """Copy the per-parameter .grad tensors into the flat gradient buffer (multi-tensor copy)."""
-        have_v, have_g, missing = [], [], []
-        for p, gv in zip(self.params, self.grad_views):
-            if p.grad is None:
-                missing.append(gv)
+    def new_table_slot(self):
+        """Fresh pinned host image + device copy of the chunk table.  A captured hipGraph re-reads ITS host
+        image at every replay (the upload is a memcpy node), so each capture gets its own slot; call this
+        before entering the capture (no allocation happens inside it)."""
+        host = torch.empty(self.n_chunks, 3, dtype=torch.int64).pin_memory()
+        host[:, 0] = 0
+        host[:, 1] = self._chunk_off
+        host[:, 2] = self._chunk_cnt
+        self._slot = (host, torch.empty(self.n_chunks, 3, dtype=torch.int64, device=self.flat_p.device))
+        self._slots.append(self._slot)
+
+    def _chunk_table(self):
+        """Device table of (gradient chunk address, flat offset, count) for the current .grad tensors."""
+        host, dev = self._slot
+        col = host[:, 0].numpy()
+        self._grad_keep = []
+        r = 0
+        for p, n, nc in zip(self.params, self.sizes, self._chunks_per_param):
+            g = p.grad
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                g = g.contiguous().float()
+                self._grad_keep.append(g)
+            if g is None:
+                col[r:r + nc] = 0
             else:
-                have_v.append(gv)
-                have_g.append(p.grad)
-        if have_v:
-            torch._foreach_copy_(have_v, have_g)
-        if missing:
-            torch._foreach_zero_(missing)
+                col[r:r + nc] = g.data_ptr() + self._chunk_bytes[:nc]
+            r += nc
+        dev.copy_(host, non_blocking=True)
+        return dev, self.n_chunks
+
+    def gather_grads(self):
+        """Copy the per-parameter .grad tensors into the flat gradient buffer (one kernel, chunk table);
+        parameters without a gradient contribute zeros.  Only the data-parallel path needs the flat copy."""
+        table, n = self._chunk_table()
+        hip.gather_chunks(table, n, self.flat_g)
         return self.flat_g
 
     def step(self, grad_scale=1.0):
-        """Assumes gather_grads() (and, under DP, the all-reduce of flat_g) already happened."""
+        """Adam on the flat gradient buffer: assumes gather_grads() (and, under DP, the all-reduce of
+        flat_g) already happened."""
         self.step_dev.add_(1)
         hip.adam_flat(self.flat_p, self.flat_g, self.m, self.v, self.step_dev, self.seg_end, self.seg_lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)
+
+    def step_from_grads(self, grad_scale=1.0):
+        """Single-GPU step: Adam reads each parameter's .grad in place through the chunk table (no flattening)."""
+        table, n = self._chunk_table()
+        self.step_dev.add_(1)
+        hip.adam_chunks(self.flat_p, table, n, self.m, self.v, self.step_dev, self.seg_end, self.seg_lr,
+                        self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)

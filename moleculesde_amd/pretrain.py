@@ -82,6 +82,7 @@ def readme_args(**over):
 
 
 USE_FUSED_CL = True
+EARLY_GEOMETRY = os.environ.get("MSDE_EARLY_GEO", "0") != "0"   # start the 2D->3D coordinate branch before the encoders (measured: 2% slower at bs256, so off)
 
 _SDE_RANGES_2D3D = {"VE": ("VE", 0.2, 1.0), "VP": ("VP", 0.2, 1.0), "VE02": ("VE", 0.1, 10.0), "VP02": ("VP", 0.2, 30.0),
                     "VE03": ("VE", 0.1, 1000.0), "VP03": ("VP", 0.2, 1000.0)}
@@ -197,6 +198,15 @@ class Trainer:
                                            anneal_power=a.SDE_anneal_power)
             return (lx + la) * 0.5
 
+        # random draws keep the reference's program order (contrastive permutations, then the 2D->3D noise);
+        # both happen before any encoder runs so that the coordinate-only branch of the 2D->3D model can start
+        # right away on its own stream (neither encoder draws random numbers on this path)
+        negs = (None, None)
+        if self.coeff_cl > 0:
+            n = batch.x.size(0)
+            negs = (self.noise.randperm(n, batch.x.device), self.noise.randperm(n, batch.x.device))
+        if a.SDE_coeff_generative_2Dto3D > 0 and EARLY_GEOMETRY:
+            m["SDE_2Dto3D_model"].begin(batch)
         l32 = None
         if self.overlap_streams:
             side = self._side_stream
@@ -208,11 +218,6 @@ class Trainer:
         else:
             _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
         node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
-        # random draws keep the reference's program order (contrastive permutations, then the 2D->3D noise)
-        negs = (None, None)
-        if self.coeff_cl > 0:
-            n = node_2D_repr.size(0)
-            negs = (self.noise.randperm(n, node_2D_repr.device), self.noise.randperm(n, node_2D_repr.device))
         if a.SDE_coeff_generative_2Dto3D > 0:
             l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
             loss = loss + l23 * a.SDE_coeff_generative_2Dto3D
@@ -237,9 +242,12 @@ class Trainer:
         loss, parts = self.losses(batch)
         self.opt.zero_grad()
         loss.backward()
-        flat_g = self.opt.gather_grads()
-        scale = dp.allreduce_mean_(flat_g)
-        self.opt.step(grad_scale=scale)
+        if dp.world_size() > 1 or dp.FORCE_COLLECTIVES:
+            flat_g = self.opt.gather_grads()
+            scale = dp.allreduce_mean_(flat_g)
+            self.opt.step(grad_scale=scale)
+        else:
+            self.opt.step_from_grads()
         for k, v in parts.items():
             self.log[k] += v
         self.steps += 1
@@ -251,9 +259,10 @@ class Trainer:
         loss, parts = self.losses(batch)
         self.opt.zero_grad()
         loss.backward()
-        self.opt.gather_grads()
         if with_adam:
-            self.opt.step(grad_scale=1.0)
+            self.opt.step_from_grads()
+        else:
+            self.opt.gather_grads()
         for k, v in parts.items():
             self.log[k] += v
         return loss.detach()
@@ -267,6 +276,7 @@ class Trainer:
         with_adam = dp.world_size() == 1 and not self.adam_outside_graph
         sd = self.step_counter.view(torch.int64)
         self.models["SDE_2Dto3D_model"].score_network.seed_dev = sd
+        self.opt.new_table_slot()       # this graph's own (pinned) gradient chunk table
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         if self._graph_pool is None:

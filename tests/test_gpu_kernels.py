@@ -386,10 +386,15 @@ def test_segment_reduce_molecule(dev):
     assert_close(xd.grad, x.grad, 1e-5, 1e-6, "readout grad")
 
 
-def test_adam_flat_matches_torch_adam(dev):
+@pytest.mark.parametrize("in_place", [False, True])
+def test_adam_flat_matches_torch_adam(dev, in_place):
+    """FlatAdam vs torch.optim.Adam over 25 steps, two lr groups, weight decay: the flat path (gather kernel +
+    msde_adam_flat, used under data parallelism) and the chunk-table path that reads .grad in place.  One tensor
+    spans several chunks, one is skipped by autograd in some steps (zero gradient by our definition)."""
     from moleculesde_amd.optim import FlatAdam
     torch.manual_seed(18)
-    ps = [torch.nn.Parameter(torch.randn(37, 5)), torch.nn.Parameter(torch.randn(11)), torch.nn.Parameter(torch.randn(64, 3))]
+    ps = [torch.nn.Parameter(torch.randn(37, 5)), torch.nn.Parameter(torch.randn(11)), torch.nn.Parameter(torch.randn(64, 3)),
+          torch.nn.Parameter(torch.randn(70, 77))]
     ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
     opt_ref = torch.optim.Adam([{"params": ref[:2], "lr": 1e-2}, {"params": ref[2:], "lr": 3e-3}], lr=1e-2, weight_decay=0.01)
     pd = [torch.nn.Parameter(p.detach().to(dev)) for p in ps]
@@ -398,11 +403,18 @@ def test_adam_flat_matches_torch_adam(dev):
         gs = [torch.randn_like(p) for p in ps]
         for p, g in zip(ref, gs):
             p.grad = g.clone()
+        if step % 5 == 4:
+            ref[1].grad = torch.zeros_like(ref[1])
         opt_ref.step()
         for p, g in zip(pd, gs):
             p.grad = g.to(dev)
-        opt.gather_grads()
-        opt.step()
+        if step % 5 == 4:                 # a parameter without a gradient this step == zero gradient
+            pd[1].grad = None
+        if in_place:
+            opt.step_from_grads()
+        else:
+            opt.gather_grads()
+            opt.step()
     for a, r in zip(pd, ref):
         assert_close(a, r, 1e-5, 1e-6, "adam params after 25 steps")
 

@@ -29,7 +29,7 @@ def part_cl():
     l, _ = pretrain.dual_CL(h2d, h3d, args, tr.noise)
     l.backward()
 def part_adam():
-    tr.opt.gather_grads(); tr.opt.step()
+    tr.opt.step_from_grads()
 
 for name, fn in (("GIN", part_gin), ("SchNet", part_schnet), ("2D->3D", part_2d3d), ("3D->2D head", part_3d2d), ("CL", part_cl), ("grad flatten + Adam", part_adam)):
     for _ in range(3):
