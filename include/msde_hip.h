@@ -56,6 +56,13 @@ int msde_pair_gather_add(const float* A, const float* B, const int* src, const i
 /* out[e] = X[idx[e]] (row gather), idx<0 -> zeros */
 int msde_gather_rows(const float* X, const int* idx, int E, int D, float* out, void* stream);
 
+/* By-source (transposed) view of the radius graph for the atomic-free input gradient of CFConv
+ * (the adjoint of schnet.py:141-145's scatter): rowptr_s[N+1], perm_s[E_cap] = edge positions grouped by
+ * source, canonical order inside a group (a stable counting sort; padded slots keep their own index).
+ * Uses that edges stay inside a molecule and rows list sources in ascending order.  deg_s: N ints scratch. */
+int msde_radius_transpose(const int* batch, const int* mol_ptr, const int* rowptr, const int* src, int N,
+                          int E_cap, int* deg_s, int* rowptr_s, int* perm_s, void* stream);
+
 /* ------------------------------------------------------------------ embeddings ------------- */
 /* ogb AtomEncoder/BondEncoder, nn.Embedding — molecule_gnn_model.py:171, schnet.py:89.
  * codes[i*K+k] already offset into the concatenated table tab[R,D]. */
@@ -215,6 +222,30 @@ int msde_res_layernorm_bwd(const float* g, const float* x, const float* gamma, c
 /* out[c] = sum_m X[m,c] (bias gradient of an nn.Linear when the vendor GEMM computes the weight
  * gradient); workspace: msde_bn_workspace_floats(M, C) floats; fixed summation order. */
 int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------ pointwise stages ------- */
+/* ShiftedSoftplus (schnet.py:199-206): y = softplus(x) - log 2 (threshold 20); g_x = g * sigmoid(x).
+ * 16-byte aligned buffers. */
+int msde_ssp_fwd(const float* x, long long n, float* y, void* stream);
+int msde_ssp_bwd(const float* g, const float* x, long long n, float* gx, void* stream);
+/* nn.SiLU -> nn.Dropout(p) of the GAT feed-forward block (equivariant_scorenetwork.py:27-31), p = 0 for the
+ * plain F.silu between layers (:142).  keep = uniform(seed [+ seed_dev[0]*FNV], element index) >= p, kept
+ * values scaled by 1/(1-p); the backward regenerates the mask. */
+int msde_silu_dropout_fwd(const float* x, long long n, float p, unsigned long long seed,
+                          const unsigned long long* seed_dev, float* y, void* stream);
+int msde_silu_dropout_bwd(const float* g, const float* x, long long n, float p, unsigned long long seed,
+                          const unsigned long long* seed_dev, float* gx, void* stream);
+/* out = a*b + c (SDE_model_2D_to_3D.py:393); ga = g*b, gb = g*a (either may be NULL); gc = g. */
+int msde_mul_add_fwd(const float* a, const float* b, const float* c, long long n, float* out, void* stream);
+int msde_mul_add_bwd(const float* g, const float* a, const float* b, long long n, float* ga, float* gb,
+                     void* stream);
+/* VE position loss (SDE_model_2D_to_3D.py:425-432): loss[0] = mean_b mean_{i in b} sum_k (scores-noise)^2
+ * [* std_i^anneal_power when anneal_power != 0]; mol_ws: B floats.  bwd: g_scores [N,3] from g_loss[0]. */
+int msde_ve_pos_loss_fwd(const float* scores, const float* noise, const float* std, float anneal_power,
+                         const int* mol_ptr, int N, int B, float* mol_ws, float* loss, void* stream);
+int msde_ve_pos_loss_bwd(const float* scores, const float* noise, const float* std, float anneal_power,
+                         const int* mol_ptr, const int* batch, int N, int B, const float* g_loss,
+                         float* g_scores, void* stream);
 
 /* ------------------------------------------------------------------ optimiser -------------- */
 /* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —

@@ -24,6 +24,7 @@ SIGNATURES = {
     "msde_pair_gather_add": [P, P, P, P, I, I, P, P],
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
+    "msde_radius_transpose": [P, P, P, P, I, I, P, P, P, P],
     "msde_embedding_sum_bwd_workspace_floats": [I, I, I],
     "msde_embedding_sum_bwd": [P, P, P, I, I, I, P, P, P],
     "msde_gin_aggregate_fwd": [P, P, P, P, P, P, I, I, P, P],
@@ -55,6 +56,14 @@ SIGNATURES = {
     "msde_bn_fwd": [P, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
     "msde_bn_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P],
     "msde_adam_flat": [P, P, P, P, LL, P, P, P, I, F, F, F, F, F, P],
+    "msde_ssp_fwd": [P, LL, P, P],
+    "msde_ssp_bwd": [P, P, LL, P, P],
+    "msde_silu_dropout_fwd": [P, LL, F, ULL, P, P, P],
+    "msde_silu_dropout_bwd": [P, P, LL, F, ULL, P, P, P],
+    "msde_mul_add_fwd": [P, P, P, LL, P, P],
+    "msde_mul_add_bwd": [P, P, P, LL, P, P, P],
+    "msde_ve_pos_loss_fwd": [P, P, P, F, P, I, I, P, P, P],
+    "msde_ve_pos_loss_bwd": [P, P, P, F, P, P, I, I, P, P, P],
     "msde_chunk_elems": [],
     "msde_gather_chunks": [P, I, P, P],
     "msde_adam_chunks": [P, P, I, P, P, P, P, P, I, F, F, F, F, F, P],

@@ -119,6 +119,57 @@ extern "C" int msde_radius_fill(const float* pos, const int* batch, const int* m
   return 0;
 }
 
+// ---- transposed (by-source) view of the radius graph, without a sort ---------------------------------------
+// Edges never leave a molecule and every target row lists its sources in ascending order (radius_fill), so the
+// edges of source j, in canonical order, are found by walking the molecule's target rows and binary-searching j
+// in each: a stable counting sort with one thread per source, no atomics.  Pass 0 counts, pass 1 writes perm_s.
+template <bool FILL>
+__global__ void radius_transpose_kernel(const int* __restrict__ batch, const int* __restrict__ mol_ptr,
+                                        const int* __restrict__ rowptr, const int* __restrict__ src, int N, int E_cap,
+                                        int* __restrict__ deg_s, const int* __restrict__ rowptr_s,
+                                        int* __restrict__ perm_s) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (FILL) {   // padded slots keep their own index (never read through rowptr_s)
+    int E = rowptr[N];
+    for (int e = E + j; e < E_cap; e += gridDim.x * blockDim.x) perm_s[e] = e;
+  }
+  if (j >= N) return;
+  int m = batch[j];
+  int i0 = mol_ptr[m], i1 = mol_ptr[m + 1];
+  int cnt = 0;
+  int base = FILL ? rowptr_s[j] : 0;
+  for (int i = i0; i < i1; ++i) {
+    int lo = rowptr[i], hi = rowptr[i + 1];
+    while (lo < hi) {                       // first position with src >= j
+      int mid = (lo + hi) >> 1;
+      if (src[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    if (lo < rowptr[i + 1] && src[lo] == j) {
+      if (FILL) perm_s[base + cnt] = lo;
+      ++cnt;
+    }
+  }
+  if (!FILL) deg_s[j] = cnt;
+}
+
+extern "C" int msde_radius_transpose(const int* batch, const int* mol_ptr, const int* rowptr, const int* src, int N,
+                                     int E_cap, int* deg_s, int* rowptr_s, int* perm_s, void* stream) {
+  if (N < 0 || E_cap < 0 || !rowptr || !rowptr_s || (N > 0 && (!batch || !mol_ptr || !deg_s))) return MSDE_EINVAL;
+  if (E_cap > 0 && (!src || !perm_s)) return MSDE_EINVAL;
+  hipStream_t st = as_stream(stream);
+  int work = N > 0 ? N : 1;
+  dim3 grid((work + 255) / 256);
+  MSDE_LAUNCH(radius_transpose_kernel<false>, grid, dim3(256), 0, st, batch, mol_ptr, rowptr, src, N, E_cap, deg_s,
+              (const int*)nullptr, (int*)nullptr);
+  MSDE_CHECK_LAUNCH();
+  int rc = msde_exclusive_scan_i32(deg_s, rowptr_s, N, stream);
+  if (rc != 0) return rc;
+  MSDE_LAUNCH(radius_transpose_kernel<true>, grid, dim3(256), 0, st, batch, mol_ptr, rowptr, src, N, E_cap, deg_s,
+              (const int*)rowptr_s, perm_s);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic CSR row ops.  Thread layout for every "row" kernel in this library: a group of TPR
 // consecutive lanes (power of two <= 64) owns one row and walks its float4 columns with stride TPR,

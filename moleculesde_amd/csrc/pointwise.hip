@@ -1,0 +1,215 @@
+// pointwise.hip — the small element-wise stages of the pretrain step that are not worth a GEMM epilogue but,
+// left to the framework, cost one launch per arithmetic operator (the step is launch/latency bound at
+// 3.6 k atoms): ShiftedSoftplus, SiLU(+dropout), a*b+c, and the VE position loss with its two reductions.
+#include "msde_common.h"
+
+#define PW_LOG2 0.69314718246459961f
+
+// y = softplus(x) - log 2 with torch's threshold-20 rule (schnet.py:199-206 ShiftedSoftplus); fp32 like the
+// reference: log1p(exp(x)) evaluated as max(x,0) + log1p(exp(-|x|)) (same value, no overflow)
+__device__ __forceinline__ float pw_ssp(float x) {
+  float sp = x > 20.f ? x : fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+  return sp - PW_LOG2;
+}
+__device__ __forceinline__ float pw_sigmoid(float x) {
+  float e = expf(-fabsf(x));
+  float r = 1.f / (1.f + e);
+  return x >= 0.f ? r : e * r;
+}
+
+__global__ void __launch_bounds__(256) ssp_fwd_kernel(const float* __restrict__ x, long long n, float* __restrict__ y) {
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    *reinterpret_cast<float4*>(y + i) = make_float4(pw_ssp(v.x), pw_ssp(v.y), pw_ssp(v.z), pw_ssp(v.w));
+  } else {
+    for (; i < n; ++i) y[i] = pw_ssp(x[i]);
+  }
+}
+
+// g_x = g * sigmoid(x)   (softplus_backward with beta 1; x > 20 -> 1 to fp32 rounding either way)
+__global__ void __launch_bounds__(256)
+ssp_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, long long n, float* __restrict__ gx) {
+  long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 v = *reinterpret_cast<const float4*>(x + i), d = *reinterpret_cast<const float4*>(g + i);
+    *reinterpret_cast<float4*>(gx + i) = make_float4(d.x * (v.x > 20.f ? 1.f : pw_sigmoid(v.x)), d.y * (v.y > 20.f ? 1.f : pw_sigmoid(v.y)),
+                                                     d.z * (v.z > 20.f ? 1.f : pw_sigmoid(v.z)), d.w * (v.w > 20.f ? 1.f : pw_sigmoid(v.w)));
+  } else {
+    for (; i < n; ++i) gx[i] = g[i] * (x[i] > 20.f ? 1.f : pw_sigmoid(x[i]));
+  }
+}
+
+// y = silu(x) * keep / (1 - p): nn.SiLU followed by nn.Dropout(p) (equivariant_scorenetwork.py:27-31); the keep
+// mask is a counter-based function of (seed, element index) and is regenerated in the backward.
+__global__ void __launch_bounds__(256)
+silu_dropout_fwd_kernel(const float* __restrict__ x, long long n, float p, unsigned long long seed,
+                        const unsigned long long* __restrict__ seed_dev, float* __restrict__ y) {
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
+  const float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = x[i];
+    float s = v * pw_sigmoid(v);
+    if (p > 0.f) s = msde_uniform(seed, (unsigned long long)i) >= p ? s * scale : 0.f;
+    y[i] = s;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+silu_dropout_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, long long n, float p,
+                        unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                        float* __restrict__ gx) {
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
+  const float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = x[i], d = g[i];
+    float sg = pw_sigmoid(v);
+    float ds = sg * (1.f + v * (1.f - sg));          // d silu / dx
+    if (p > 0.f) d = msde_uniform(seed, (unsigned long long)i) >= p ? d * scale : 0.f;
+    gx[i] = d * ds;
+  }
+}
+
+// out = a * b + c   (edge_attr = invariant * edge_2D + frame_invariant, SDE_model_2D_to_3D.py:393)
+__global__ void __launch_bounds__(256)
+mul_add_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, long long n,
+                   float* __restrict__ out) {
+#pragma clang fp contract(off)   // separate roundings for the product and the sum, like the reference's two operators
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = a[i] * b[i] + c[i];
+}
+__global__ void __launch_bounds__(256)
+mul_add_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b, long long n,
+                   float* __restrict__ ga, float* __restrict__ gb) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float d = g[i];
+    if (ga) ga[i] = d * b[i];
+    if (gb) gb[i] = d * a[i];
+  }
+}
+
+// VE position loss (SDE_model_2D_to_3D.py:425-432): per atom l_i = sum_k (score - noise)^2 [* std_i^power],
+// scatter_mean over molecules, mean over molecules.  One wave per molecule, then one block over molecules; both
+// reductions run in a fixed order.
+__global__ void __launch_bounds__(256)
+ve_pos_loss_mol_kernel(const float* __restrict__ scores, const float* __restrict__ noise, const float* __restrict__ std,
+                       float power, const int* __restrict__ mol_ptr, int B, float* __restrict__ mol_val) {
+  int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (b >= B) return;
+  int i0 = mol_ptr[b], i1 = mol_ptr[b + 1];
+  float acc = 0.f;
+  for (int i = i0 + lane; i < i1; i += 64) {
+    float dx = scores[3 * i] - noise[3 * i], dy = scores[3 * i + 1] - noise[3 * i + 1], dz = scores[3 * i + 2] - noise[3 * i + 2];
+    float w = std ? powf(std[i], power) : 1.f;
+    acc += (dx * dx * w + dy * dy * w) + dz * dz * w;
+  }
+  acc = group_sum(acc, 64);
+  if (lane == 0) mol_val[b] = i1 > i0 ? acc / (float)(i1 - i0) : 0.f;
+}
+
+__global__ void __launch_bounds__(256) ve_pos_loss_final_kernel(const float* __restrict__ mol_val, int B, float* __restrict__ loss) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) acc += mol_val[b];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] / (float)B;
+}
+
+__global__ void __launch_bounds__(256)
+ve_pos_loss_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ noise, const float* __restrict__ std,
+                       float power, const int* __restrict__ mol_ptr, const int* __restrict__ batch, int N, int B,
+                       const float* __restrict__ g_loss, float* __restrict__ g_scores) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int b = batch[i];
+  float cnt = (float)(mol_ptr[b + 1] - mol_ptr[b]);
+  float w = std ? powf(std[i], power) : 1.f;
+  float k = g_loss[0] * 2.f * w / (cnt * (float)B);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) g_scores[3 * i + c] = k * (scores[3 * i + c] - noise[3 * i + c]);
+}
+
+static inline int pw_blocks(long long n, int per_thread) {
+  long long b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+  if (b > 4096 && per_thread == 1) b = 4096;
+  return b < 1 ? 1 : (int)b;
+}
+
+extern "C" int msde_ssp_fwd(const float* x, long long n, float* y, void* stream) {
+  if (n < 0 || !x || !y) return MSDE_EINVAL;
+  if (n == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return MSDE_EINVAL;
+  MSDE_LAUNCH(ssp_fwd_kernel, dim3(pw_blocks(n, 4)), dim3(256), 0, as_stream(stream), x, n, y);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_ssp_bwd(const float* g, const float* x, long long n, float* gx, void* stream) {
+  if (n < 0 || !g || !x || !gx) return MSDE_EINVAL;
+  if (n == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(gx)) & 15) return MSDE_EINVAL;
+  MSDE_LAUNCH(ssp_bwd_kernel, dim3(pw_blocks(n, 4)), dim3(256), 0, as_stream(stream), g, x, n, gx);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_silu_dropout_fwd(const float* x, long long n, float p, unsigned long long seed,
+                                     const unsigned long long* seed_dev, float* y, void* stream) {
+  if (n < 0 || !x || !y || p < 0.f || p >= 1.f) return MSDE_EINVAL;
+  if (n == 0) return 0;
+  MSDE_LAUNCH(silu_dropout_fwd_kernel, dim3(pw_blocks(n, 1)), dim3(256), 0, as_stream(stream), x, n, p, seed, seed_dev, y);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_silu_dropout_bwd(const float* g, const float* x, long long n, float p, unsigned long long seed,
+                                     const unsigned long long* seed_dev, float* gx, void* stream) {
+  if (n < 0 || !g || !x || !gx || p < 0.f || p >= 1.f) return MSDE_EINVAL;
+  if (n == 0) return 0;
+  MSDE_LAUNCH(silu_dropout_bwd_kernel, dim3(pw_blocks(n, 1)), dim3(256), 0, as_stream(stream), g, x, n, p, seed, seed_dev,
+              gx);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_mul_add_fwd(const float* a, const float* b, const float* c, long long n, float* out, void* stream) {
+  if (n < 0 || !a || !b || !c || !out) return MSDE_EINVAL;
+  if (n == 0) return 0;
+  MSDE_LAUNCH(mul_add_fwd_kernel, dim3(pw_blocks(n, 1)), dim3(256), 0, as_stream(stream), a, b, c, n, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_mul_add_bwd(const float* g, const float* a, const float* b, long long n, float* ga, float* gb,
+                                void* stream) {
+  if (n < 0 || !g || !a || !b) return MSDE_EINVAL;
+  if (n == 0 || (!ga && !gb)) return 0;
+  MSDE_LAUNCH(mul_add_bwd_kernel, dim3(pw_blocks(n, 1)), dim3(256), 0, as_stream(stream), g, a, b, n, ga, gb);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_ve_pos_loss_fwd(const float* scores, const float* noise, const float* std, float anneal_power,
+                                    const int* mol_ptr, int N, int B, float* mol_ws, float* loss, void* stream) {
+  if (N < 0 || B <= 0 || !scores || !noise || !mol_ptr || !mol_ws || !loss) return MSDE_EINVAL;
+  const float* sd = anneal_power != 0.f ? std : nullptr;
+  if (anneal_power != 0.f && !std) return MSDE_EINVAL;
+  MSDE_LAUNCH(ve_pos_loss_mol_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), scores, noise, sd, anneal_power,
+              mol_ptr, B, mol_ws);
+  MSDE_CHECK_LAUNCH();
+  MSDE_LAUNCH(ve_pos_loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)mol_ws, B, loss);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_ve_pos_loss_bwd(const float* scores, const float* noise, const float* std, float anneal_power,
+                                    const int* mol_ptr, const int* batch, int N, int B, const float* g_loss,
+                                    float* g_scores, void* stream) {
+  if (N < 0 || B <= 0 || !scores || !noise || !mol_ptr || !batch || !g_loss || !g_scores) return MSDE_EINVAL;
+  if (N == 0) return 0;
+  const float* sd = anneal_power != 0.f ? std : nullptr;
+  if (anneal_power != 0.f && !std) return MSDE_EINVAL;
+  MSDE_LAUNCH(ve_pos_loss_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), scores, noise, sd,
+              anneal_power, mol_ptr, batch, N, B, g_loss, g_scores);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

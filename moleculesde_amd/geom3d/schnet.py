@@ -123,10 +123,10 @@ class SchNet(nn.Module):
                 Wf = blk.mlp(rbf)
                 agg = hip.cfconv_aggregate(x1, Wf, C, rplan)
             x = blk.conv.lin2(agg)
-            x = blk.lin(_nn.shifted_softplus(x))
+            x = blk.lin(hip.shifted_softplus(x))
             h = h + x
 
-        h = self.lin2(_nn.shifted_softplus(self.lin1(h)))
+        h = self.lin2(hip.shifted_softplus(self.lin1(h)))
         out = hip.segment_reduce(h, pl.mol_ptr, pl.batch_i32, mean=(self.readout == "mean"))
         if return_latent:
             return out, h

@@ -70,7 +70,9 @@ class GATLayer(nn.Module):
         x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev)
         if x.is_cuda and x.size(-1) % 4 == 0:
             node_attr = hip.res_layernorm(x, node_attr, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-            x = self.FFN(node_attr)
+            # FFN = Linear -> SiLU -> Dropout -> Linear with the two pointwise stages in one kernel
+            p = self.FFN[2].p if self.training else 0.0
+            x = self.FFN[3](hip.silu_dropout(self.FFN[0](node_attr), p, seed ^ 0x46464E, seed_dev))
             return hip.res_layernorm(x, node_attr, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         node_attr = node_attr + self.norm1(x)
         x = self.FFN(node_attr)
@@ -115,7 +117,7 @@ class EquivariantScoreNetwork(nn.Module):
                 seed = (self._seed_base + self._calls) * 16 + module_idx * 4 + conv_idx
                 hidden = gnn(plan, conv_input, edge_attr, seed, self.seed_dev)
                 if conv_idx < len(gnn_layers) - 1:
-                    hidden = F.silu(hidden)
+                    hidden = hip.silu_dropout(hidden) if hidden.is_cuda else F.silu(hidden)
                 conv_input = hidden
             node_feature = hidden
             pair = hip.pair_gather_add(node_feature, node_feature, plan)        # h_row + h_col
@@ -216,7 +218,7 @@ class SDEModel2Dto3D_02(nn.Module):
             main.wait_stream(side)
             for t in (edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis):
                 t.record_stream(main)
-        edge_attr = edge_attr_3D_invariant * edge_attr_2D + edge_attr_3D_frame_invariant
+        edge_attr = hip.mul_add(edge_attr_3D_invariant, edge_attr_2D, edge_attr_3D_frame_invariant)
         node_attr = self.node_emb(node_2D_repr)
         return node_attr, edge_attr, basis
 
@@ -229,12 +231,8 @@ class SDEModel2Dto3D_02(nn.Module):
 
         node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep, (geo, side))
         scores = self.score_network(ep, node_attr, edge_attr, basis)["gradient"]
-        if anneal_power == 0:
-            loss_pos = torch.sum((scores - pos_noise) ** 2, -1)
-        else:
-            loss_pos = torch.sum((scores - pos_noise) ** 2 * (std_pos ** anneal_power).unsqueeze(1), -1)
-        loss_pos = hip.segment_reduce(loss_pos.unsqueeze(1), pl.mol_ptr, pl.batch_i32, mean=True)   # scatter_mean
-        return {"position": loss_pos.mean()}
+        # sum_k (score - noise)^2 [* std^anneal_power] -> scatter_mean over molecules -> mean: one kernel pair
+        return {"position": hip.ve_position_loss(scores, pos_noise, std_pos, anneal_power, pl.mol_ptr, pl.batch_i32)}
 
     @torch.no_grad()
     def get_score(self, node_2D_repr, data, pos_perturbed, sigma, t_pos):

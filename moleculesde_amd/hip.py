@@ -97,14 +97,15 @@ def radius_plan(pos, batch_i32, mol_ptr_i32, cutoff, E_cap, max_nbr=32):
     _lib.call("msde_exclusive_scan_i32", _p(deg), _p(rowptr), N, st)
     _lib.call("msde_radius_fill", _p(pos), _p(batch_i32), _p(mol_ptr_i32), N, r2, max_nbr, _p(rowptr), _p(src),
               _p(dst), _p(dist), E_cap, st)
-    # transposed view (by source): padding (src = -1) sorts to the end under key N
-    key = torch.where(src < 0, torch.full_like(src, N), src)
-    skey, perm_s = torch.sort(key.long(), stable=True)
-    rowptr_s = torch.searchsorted(skey, torch.arange(N + 1, device=dev)).to(torch.int32)
+    # transposed view (by source): stable counting sort on the device, no torch.sort
+    rowptr_s = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    perm_s = torch.empty(E_cap, dtype=torch.int32, device=dev)
+    _lib.call("msde_radius_transpose", _p(batch_i32), _p(mol_ptr_i32), _p(rowptr), _p(src), N, E_cap, _p(deg),
+              _p(rowptr_s), _p(perm_s), st)
     p = CsrPlan()
     p.N, p.E = N, E_cap
     p.rowptr, p.src, p.dst = rowptr, src, dst
-    p.rowptr_s, p.perm_s, p.perm_t = rowptr_s, perm_s.to(torch.int32), None
+    p.rowptr_s, p.perm_s, p.perm_t = rowptr_s, perm_s, None
     p.E_dev = rowptr[N:]
     return p, dist
 
@@ -823,6 +824,114 @@ def res_layernorm(x, res, gamma, beta, eps=1e-5):
 # ------------------------------------------------------------------------------------------------
 # optimiser
 # ------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# pointwise stages (csrc/pointwise.hip)
+# ------------------------------------------------------------------------------------------------
+class _ShiftedSoftplus(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        y = torch.empty_like(x)
+        _lib.call("msde_ssp_fwd", _p(x), x.numel(), _p(y), _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _f32(g)
+        gx = torch.empty_like(x)
+        _lib.call("msde_ssp_bwd", _p(g), _p(x), x.numel(), _p(gx), _stream())
+        return gx
+
+
+def shifted_softplus(x):
+    """F.softplus(x) - log 2 (schnet.py:199-206) as one kernel."""
+    return _ShiftedSoftplus.apply(x)
+
+
+class _SiluDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, seed_dev):
+        x = _f32(x)
+        y = torch.empty_like(x)
+        _lib.call("msde_silu_dropout_fwd", _p(x), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(seed_dev), _p(y),
+                  _stream())
+        ctx.save_for_backward(x)
+        ctx.p, ctx.seed, ctx.seed_dev = float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, seed_dev
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _f32(g)
+        gx = torch.empty_like(x)
+        _lib.call("msde_silu_dropout_bwd", _p(g), _p(x), x.numel(), ctx.p, ctx.seed, _p(ctx.seed_dev), _p(gx), _stream())
+        return gx, None, None, None
+
+
+def silu_dropout(x, p=0.0, seed=0, seed_dev=None):
+    """nn.SiLU followed by nn.Dropout(p) (p = 0: plain SiLU) as one kernel; the mask is a function of
+    (seed [+ device counter], element index) and is regenerated in the backward."""
+    return _SiluDropout.apply(x, p, seed, seed_dev)
+
+
+class _MulAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, c):
+        a, b, c = _f32(a), _f32(b), _f32(c)
+        assert a.shape == b.shape == c.shape
+        out = torch.empty_like(a)
+        _lib.call("msde_mul_add_fwd", _p(a), _p(b), _p(c), a.numel(), _p(out), _stream())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _f32(g)
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        _lib.call("msde_mul_add_bwd", _p(g), _p(a), _p(b), a.numel(), _p(ga), _p(gb), _stream())
+        return ga, gb, (g if ctx.needs_input_grad[2] else None)
+
+
+def mul_add(a, b, c):
+    """a * b + c for same-shape tensors, one kernel each way."""
+    return _MulAdd.apply(a, b, c)
+
+
+class _VEPosLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, noise, std, anneal_power, mol_ptr, batch_i32):
+        scores, noise = _f32(scores), _f32(noise)
+        std = _f32(std) if std is not None else None
+        N, B = scores.size(0), mol_ptr.numel() - 1
+        ws = torch.empty(B, dtype=torch.float32, device=scores.device)
+        loss = torch.empty(1, dtype=torch.float32, device=scores.device)
+        _lib.call("msde_ve_pos_loss_fwd", _p(scores), _p(noise), _p(std), float(anneal_power), _p(mol_ptr), N, B, _p(ws),
+                  _p(loss), _stream())
+        ctx.save_for_backward(scores, noise, std if std is not None else scores, mol_ptr, batch_i32)
+        ctx.power, ctx.has_std = float(anneal_power), std is not None
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        scores, noise, std, mol_ptr, batch_i32 = ctx.saved_tensors
+        N, B = scores.size(0), mol_ptr.numel() - 1
+        g = _f32(g).reshape(1)
+        gs = torch.empty_like(scores)
+        _lib.call("msde_ve_pos_loss_bwd", _p(scores), _p(noise), _p(std if ctx.has_std else None), ctx.power, _p(mol_ptr),
+                  _p(batch_i32), N, B, _p(g), _p(gs), _stream())
+        return gs, None, None, None, None, None
+
+
+def ve_position_loss(scores, noise, std, anneal_power, mol_ptr, batch_i32):
+    """mean over molecules of the per-molecule mean of sum_k (scores - noise)^2 [* std^anneal_power]
+    (SDE_model_2D_to_3D.py:425-432); gradient flows to `scores` only."""
+    return _VEPosLoss.apply(scores, noise, std, anneal_power, mol_ptr, batch_i32)
+
+
 def chunk_elems():
     return int(_lib.load().msde_chunk_elems())
 

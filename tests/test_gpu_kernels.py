@@ -547,3 +547,95 @@ def test_res_layernorm_kernels(dev, N, D, with_res):
         assert_close(rd.grad, res.grad, 0, 0, "LN g_res")
     assert_close(gd.grad, ln.weight.grad, 1e-4, 1e-4 * float(ln.weight.grad.abs().max()), "LN ggamma")
     assert_close(bd.grad, ln.bias.grad, 1e-4, 1e-4 * float(ln.bias.grad.abs().max()), "LN gbeta")
+
+
+# ------------------------------------------------------------------------------------------------
+# pointwise stages (csrc/pointwise.hip)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 7, 1024, 3588 * 300])
+def test_shifted_softplus_kernel(dev, n):
+    from moleculesde_amd import hip
+    torch.manual_seed(n)
+    x = (torch.randn(n) * 6).requires_grad_(True)
+    with torch.no_grad():
+        x[: min(n, 3)] = torch.tensor([25.0, -30.0, 0.0])[: min(n, 3)]     # threshold branch, deep negative, zero
+    ref = torch.nn.functional.softplus(x) - math.log(2.0)
+    w = torch.randn(n)
+    (ref * w).sum().backward()
+    xd = x.detach().to(dev).requires_grad_(True)
+    y = hip.shifted_softplus(xd)
+    assert_close(y, ref.detach(), 1e-6, 1e-6, "ssp fwd")
+    (y * w.to(dev)).sum().backward()
+    assert_close(xd.grad, x.grad, 1e-5, 1e-6, "ssp bwd")
+
+
+def test_silu_dropout_kernel(dev):
+    from moleculesde_amd import hip
+    torch.manual_seed(3)
+    x = (torch.randn(3588, 32) * 2).requires_grad_(True)
+    w = torch.randn(3588, 32)
+    ref = torch.nn.functional.silu(x)
+    (ref * w).sum().backward()
+    xd = x.detach().to(dev).requires_grad_(True)
+    y = hip.silu_dropout(xd)                                   # p = 0: plain SiLU
+    assert_close(y, ref.detach(), 1e-6, 1e-6, "silu fwd")
+    (y * w.to(dev)).sum().backward()
+    assert_close(xd.grad, x.grad, 1e-5, 1e-6, "silu bwd")
+    # p = 0.1: kept entries are silu/(1-p), dropped are 0, the backward uses the same mask, a new seed (or a new
+    # device counter value) gives a new mask, the drop rate is right
+    p = 0.1
+    xd2 = x.detach().to(dev).requires_grad_(True)
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    y1 = hip.silu_dropout(xd2, p, 1234, ctr)
+    keep = y1 != 0
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - p) < 0.01, rate
+    assert_close(torch.where(keep, y1, torch.zeros_like(y1)), torch.where(keep.cpu(), ref.detach() / (1 - p), torch.zeros_like(ref)),
+                 1e-5, 1e-6, "dropout kept values")
+    (y1 * w.to(dev)).sum().backward()
+    gref = torch.where(keep.cpu(), x.grad / (1 - p), torch.zeros_like(x.grad))
+    assert_close(xd2.grad, gref, 1e-5, 1e-6, "dropout bwd mask")
+    y2 = hip.silu_dropout(xd2, p, 1234, ctr)
+    assert torch.equal(y1, y2)                                # same (seed, counter) -> same mask
+    ctr.add_(1)
+    y3 = hip.silu_dropout(xd2, p, 1234, ctr)
+    assert not torch.equal(y1 != 0, y3 != 0)                  # replay with an advanced counter -> fresh mask
+    assert not torch.equal(y1 != 0, hip.silu_dropout(xd2, p, 99, None) != 0)
+
+
+def test_mul_add_kernel(dev):
+    from moleculesde_amd import hip
+    torch.manual_seed(4)
+    a, b, c = (torch.randn(35186, 32).requires_grad_(True) for _ in range(3))
+    w = torch.randn(35186, 32)
+    ((a * b + c) * w).sum().backward()
+    ad, bd, cd = (t.detach().to(dev).requires_grad_(True) for t in (a, b, c))
+    out = hip.mul_add(ad, bd, cd)
+    assert_close(out, (a * b + c).detach(), 0, 0, "mul_add fwd")          # same two roundings as the reference
+    (out * w.to(dev)).sum().backward()
+    for got, ref, what in ((ad.grad, a.grad, "ga"), (bd.grad, b.grad, "gb"), (cd.grad, c.grad, "gc")):
+        assert_close(got, ref, 0, 0, what)
+
+
+@pytest.mark.parametrize("power", [0.0, 2.0])
+def test_ve_position_loss_kernel(dev, power):
+    """Fused VE position loss vs the reference's operator chain (SDE_model_2D_to_3D.py:425-432)."""
+    from moleculesde_amd import hip, plan as P
+    b = _toy_graph(9, 37)
+    pl = P.plan_to(P.build_plan(b), dev)
+    N = b.x.size(0)
+    torch.manual_seed(11)
+    scores = torch.randn(N, 3, requires_grad=True)
+    noise = torch.randn(N, 3)
+    std = torch.rand(N) + 0.3
+    if power == 0:
+        lp = torch.sum((scores - noise) ** 2, -1)
+    else:
+        lp = torch.sum((scores - noise) ** 2 * (std ** power).unsqueeze(1), -1)
+    ref = R.scatter_mean(lp.unsqueeze(1), b.batch, int(b.num_graphs)).mean()
+    (ref * 1.3).backward()
+    sd = scores.detach().to(dev).requires_grad_(True)
+    loss = hip.ve_position_loss(sd, noise.to(dev), std.to(dev), power, pl.mol_ptr, pl.batch_i32)
+    assert_close(loss, ref.detach(), 1e-5, 1e-6, "VE position loss")
+    (loss * 1.3).backward()
+    assert_close(sd.grad, scores.grad, 1e-5, 1e-7, "VE position loss grad")
