@@ -49,9 +49,10 @@ int msde_radius_fill(const float* pos, const int* batch, const int* mol_ptr, int
 int msde_segment_sum_rows(const float* rows, const int* rowptr, const int* perm, int N, int D,
                           float scale_by_inv_count, float* out, int ldo /* row stride of out (0 = D) */,
                           void* stream);
-/* out[e] = A[src[e]] + B[dst[e]] (+ bias) for e < E; rows with src<0 are zero-filled.
+/* out[e] = A[src[e]] + B[dst[e]] for e < E; rows with src<0 are zero-filled.  A and B have row stride ld
+ * floats (0 = D): they may be column blocks of one [N, 2D] GEMM result.
  * SDE_model_2D_to_3D.py:346-347 (factored cat+Linear), equivariant_scorenetwork.py:154-155 */
-int msde_pair_gather_add(const float* A, const float* B, const int* src, const int* dst, int E,
+int msde_pair_gather_add(const float* A, const float* B, int ld, const int* src, const int* dst, int E,
                          int D, float* out, void* stream);
 /* out[e] = X[idx[e]] (row gather), idx<0 -> zeros */
 int msde_gather_rows(const float* X, const int* idx, int E, int D, float* out, void* stream);

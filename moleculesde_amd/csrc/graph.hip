@@ -221,7 +221,7 @@ extern "C" int msde_segment_sum_rows(const float* rows, const int* rowptr, const
 template <int V>
 __global__ void pair_gather_add_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                        const int* __restrict__ src, const int* __restrict__ dst, int E, int cols,
-                                       int tpr, float* __restrict__ out) {
+                                       int ld_cols, int tpr, float* __restrict__ out) {
   using T = typename VecT<V>::type;
   int rpb = blockDim.x / tpr;
   int e = blockIdx.x * rpb + threadIdx.x / tpr;
@@ -233,27 +233,31 @@ __global__ void pair_gather_add_kernel(const float* __restrict__ A, const float*
     for (int c = lane; c < cols; c += tpr) O[c] = vzero<V>();
     return;
   }
-  const T* a = reinterpret_cast<const T*>(A) + (size_t)j * cols;
+  const T* a = reinterpret_cast<const T*>(A) + (size_t)j * ld_cols;
   if (B) {
-    const T* b = reinterpret_cast<const T*>(B) + (size_t)i * cols;
+    const T* b = reinterpret_cast<const T*>(B) + (size_t)i * ld_cols;
     for (int c = lane; c < cols; c += tpr) O[c] = vadd(a[c], b[c]);
   } else {
     for (int c = lane; c < cols; c += tpr) O[c] = a[c];
   }
 }
 
-extern "C" int msde_pair_gather_add(const float* A, const float* B, const int* src, const int* dst, int E, int D,
-                                    float* out, void* stream) {
+extern "C" int msde_pair_gather_add(const float* A, const float* B, int ld, const int* src, const int* dst, int E,
+                                    int D, float* out, void* stream) {
   if (E < 0 || D <= 0 || !A || !B || !src || !dst || !out) return MSDE_EINVAL;
+  if (ld == 0) ld = D;
+  if (ld < D) return MSDE_EINVAL;
   if (E == 0) return 0;
-  if (D % 4 == 0) {
+  const bool vec = D % 4 == 0 && ld % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (vec) {
     int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
     MSDE_LAUNCH(pair_gather_add_kernel<4>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), A, B,
-                       src, dst, E, cols, tpr, out);
+                       src, dst, E, cols, ld / 4, tpr, out);
   } else {
     int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
     MSDE_LAUNCH(pair_gather_add_kernel<1>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), A, B,
-                       src, dst, E, cols, tpr, out);
+                       src, dst, E, cols, ld, tpr, out);
   }
   MSDE_CHECK_LAUNCH();
   return 0;
@@ -265,11 +269,11 @@ extern "C" int msde_gather_rows(const float* X, const int* idx, int E, int D, fl
   if (D % 4 == 0) {
     int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
     MSDE_LAUNCH(pair_gather_add_kernel<4>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), X,
-                       (const float*)nullptr, idx, (const int*)nullptr, E, cols, tpr, out);
+                       (const float*)nullptr, idx, (const int*)nullptr, E, cols, cols, tpr, out);
   } else {
     int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
     MSDE_LAUNCH(pair_gather_add_kernel<1>, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), X,
-                       (const float*)nullptr, idx, (const int*)nullptr, E, cols, tpr, out);
+                       (const float*)nullptr, idx, (const int*)nullptr, E, cols, cols, tpr, out);
   }
   MSDE_CHECK_LAUNCH();
   return 0;

@@ -106,7 +106,12 @@ class EmbeddingList(nn.Module):
 
     def table(self):
         """Concatenated [sum(dims), D] table, the layout the kernels index with pre-offset codes."""
-        return torch.cat([e.weight for e in getattr(self, self._list_name)], dim=0)
+        ws = [e.weight for e in getattr(self, self._list_name)]
+        return hip.cat_params(ws) if ws[0].is_cuda else torch.cat(ws, dim=0)
+
+    def fusion_sets(self):
+        """Parameters that want to be adjacent in the optimiser's flat buffer (then table() is a free view)."""
+        return [[e.weight for e in getattr(self, self._list_name)]]
 
 
 # ---- plan registry: lets the reference-style call signatures (tensors, not a Batch) find the plan --

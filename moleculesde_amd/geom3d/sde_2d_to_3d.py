@@ -46,10 +46,17 @@ class TransformerConv(nn.Module):
         self.lin_edge = _nn.Linear(edge_dim, heads * out_channels, bias=False)
         self.lin_skip = _nn.Linear(in_channels, heads * out_channels, bias=True)
 
+    def fusion_sets(self):
+        return [[self.lin_query.weight, self.lin_key.weight, self.lin_value.weight, self.lin_skip.weight],
+                [self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias]]
+
     def forward(self, x, edge_attr, plan, seed, seed_dev=None):
         # one projection GEMM for query | key | value | skip (they share the input x)
-        W = torch.cat([self.lin_query.weight, self.lin_key.weight, self.lin_value.weight, self.lin_skip.weight], dim=0)
-        b = torch.cat([self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias], dim=0)
+        Ws, bs = self.fusion_sets()
+        if x.is_cuda:
+            W, b = hip.cat_params(Ws), hip.cat_params(bs)     # free views once FlatAdam has laid them out back to back
+        else:
+            W, b = torch.cat(Ws, dim=0), torch.cat(bs, dim=0)
         qkvs = _nn.linear(x, W, b)
         ee = self.lin_edge(edge_attr)
         p = self.dropout if self.training else 0.0
@@ -154,6 +161,7 @@ class SDEModel2Dto3D_02(nn.Module):
             raise NotImplementedError(f"SDE_type={SDE_type!r}")
         self.num_diffusion_timesteps = num_diffusion_timesteps
         self.noise = _nn.DeviceNoise()     # set to nn.CpuReplayNoise(seed) for replayable parity runs
+        self.register_buffer("_zero_bias", torch.zeros(emb_dim), persistent=False)
         self.side_stream = None            # optional second HIP stream for the coordinate-only branch
         self._pending = None               # results of begin() waiting for forward()
 
@@ -208,10 +216,12 @@ class SDEModel2Dto3D_02(nn.Module):
         geo, side = started if started is not None else self._launch_geometry(pos_perturbed, ep)
         edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis = geo
         # edge_2D_emb[0](cat(h[row], h[col])) == h[row] W[:, :D]^T + h[col] W[:, D:]^T + b
+        # as ONE node-level GEMM with the two weight halves stacked ([W_row; W_col], one re-layout copy per step)
         lin0 = self.edge_2D_emb[0]
-        A = _nn.linear(node_2D_repr, lin0.weight[:, :D])
-        Bm = _nn.linear(node_2D_repr, lin0.weight[:, D:], lin0.bias)
-        pre = hip.pair_gather_add(A, Bm, ep)
+        Wst = lin0.weight.view(D, 2, D).transpose(0, 1).reshape(2 * D, D)
+        bst = torch.cat([self._zero_bias, lin0.bias])          # the row half carries no bias
+        AB = _nn.linear(node_2D_repr, Wst, bst)
+        pre = hip.pair_gather_add_cols(AB, ep)
         edge_attr_2D = self.edge_2D_emb[3](self.edge_2D_emb[2](self.edge_2D_emb[1](pre)))
         if side is not None:
             main = torch.cuda.current_stream()

@@ -413,7 +413,7 @@ class _PairGatherAdd(torch.autograd.Function):
         A, B = _f32(A), _f32(B)
         E, D = plan.E, A.size(1)
         out = torch.empty(E, D, dtype=torch.float32, device=A.device)
-        _lib.call("msde_pair_gather_add", _p(A), _p(B), _p(plan.src), _p(plan.dst), E, D, _p(out), _stream())
+        _lib.call("msde_pair_gather_add", _p(A), _p(B), 0, _p(plan.src), _p(plan.dst), E, D, _p(out), _stream())
         ctx.plan = plan
         return out
 
@@ -429,6 +429,72 @@ class _PairGatherAdd(torch.autograd.Function):
 def pair_gather_add(A, B, plan):
     """out[e] = A[row_e] + B[col_e]  (row = source, col = target)."""
     return _PairGatherAdd.apply(A, B, plan)
+
+
+class _PairGatherAddCols(torch.autograd.Function):
+    """out[e] = AB[src_e, :D] + AB[dst_e, D:] for AB = [A | B] of one GEMM; the backward writes the two segment
+    sums straight into the column blocks of g_AB."""
+
+    @staticmethod
+    def forward(ctx, AB, plan):
+        AB = _f32(AB)
+        E, D = plan.E, AB.size(1) // 2
+        out = torch.empty(E, D, dtype=torch.float32, device=AB.device)
+        _lib.call("msde_pair_gather_add", _p(AB), AB.data_ptr() + 4 * D, 2 * D, _p(plan.src), _p(plan.dst), E, D, _p(out),
+                  _stream())
+        ctx.plan, ctx.D = plan, D
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, D = ctx.plan, ctx.D
+        g = _f32(g)
+        g_AB = torch.empty(plan.N, 2 * D, dtype=torch.float32, device=g.device)
+        segment_sum_rows(g, plan.rowptr_s, plan.perm_s, plan.N, out=g_AB, ldo=2 * D)
+        segment_sum_rows(g, plan.rowptr, None, plan.N, out=g_AB[:, D:], ldo=2 * D)
+        return g_AB, None
+
+
+def pair_gather_add_cols(AB, plan):
+    return _PairGatherAddCols.apply(AB, plan)
+
+
+class _CatParams(torch.autograd.Function):
+    """torch.cat(params, 0) that costs nothing when the parameters already lie back to back in memory (FlatAdam
+    lays fusion sets out that way): the result aliases them.  Falls back to a real concatenation otherwise."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.rows = [w.size(0) for w in ws]
+        w0 = ws[0]
+        tail = tuple(w0.shape[1:])
+        adjacent = all(w.is_contiguous() and w.dtype == torch.float32 for w in ws)
+        if adjacent:
+            base = w0.untyped_storage().data_ptr()
+            nxt = w0.data_ptr()
+            for w in ws:
+                if w.untyped_storage().data_ptr() != base or w.data_ptr() != nxt:
+                    adjacent = False
+                    break
+                nxt += 4 * w.numel()
+        if not adjacent:
+            return torch.cat([w.detach() for w in ws], 0)
+        total = sum(ctx.rows)
+        size = (total,) + tail
+        stride, acc = [], 1
+        for d in reversed(size):
+            stride.append(acc)
+            acc *= d
+        return torch.as_strided(w0.detach(), size, tuple(reversed(stride)), w0.storage_offset())
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.rows, 0))
+
+
+def cat_params(ws):
+    ws = list(ws)
+    return ws[0] if len(ws) == 1 else _CatParams.apply(*ws)
 
 
 class _EdgeAttention(torch.autograd.Function):

@@ -22,34 +22,36 @@ class FlatAdam:
         self.params, seg_end, seg_lr = [], [], []
         seen = set()
         total = 0
+        offsets = []
         for g in groups:
             for p in g["params"]:
                 if not p.requires_grad or id(p) in seen:
                     continue
                 seen.add(id(p))
                 self.params.append(p)
+                total = (total + 3) & ~3           # 16-byte aligned start: kernels read parameters with float4 loads
+                offsets.append(total)
                 total += p.numel()
+            total = (total + 3) & ~3
             seg_end.append(total)
             seg_lr.append(float(g["lr"]))
         dev = self.params[0].device
         self.n = total
-        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)   # alignment gaps stay zero
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets, self.sizes = [], []
         self._chunk = hip.chunk_elems()
         self._grad_keep = []
-        off = 0
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, offsets):
                 n = p.numel()
                 view = self.flat_p[off:off + n].view_as(p)
                 view.copy_(p.data)
                 p.data = view                       # parameters now alias the flat buffer
                 self.offsets.append(off)
                 self.sizes.append(n)
-                off += n
         import numpy as np
         ch = self._chunk
         self._chunks_per_param = [(n + ch - 1) // ch for n in self.sizes]

@@ -112,13 +112,31 @@ def build_models(args, device):
     return models
 
 
+def ordered_parameters(model):
+    """model.parameters() with every fusion set (module.fusion_sets(): parameters the kernels consume as one
+    concatenated operand) moved together, so that FlatAdam lays them out back to back and hip.cat_params is a
+    free view.  Adam is element-wise: the order inside a param group changes nothing else."""
+    params = list(model.parameters())
+    for mod in model.modules():
+        sets = getattr(mod, "fusion_sets", None)
+        if sets is None:
+            continue
+        for group in sets():
+            ids = {id(p) for p in group}
+            first = next(i for i, p in enumerate(params) if id(p) in ids)
+            rest = [p for p in params if id(p) not in ids]
+            n_before = sum(1 for p in params[:first] if id(p) not in ids)
+            params = rest[:n_before] + list(group) + rest[n_before:]
+    return params
+
+
 def make_optimizer(args, models):
     """pretrain_MoleculeSDE.py:331-337."""
-    groups = [{"params": list(models["model_2D"].parameters()), "lr": args.lr * args.gnn_2d_lr_scale},
-              {"params": list(models["model_3D"].parameters()), "lr": args.lr * args.gnn_3d_lr_scale},
-              {"params": list(models["SDE_2Dto3D_model"].parameters()), "lr": args.lr * args.gnn_2d_lr_scale}]
+    groups = [{"params": ordered_parameters(models["model_2D"]), "lr": args.lr * args.gnn_2d_lr_scale},
+              {"params": ordered_parameters(models["model_3D"]), "lr": args.lr * args.gnn_3d_lr_scale},
+              {"params": ordered_parameters(models["SDE_2Dto3D_model"]), "lr": args.lr * args.gnn_2d_lr_scale}]
     if "SDE_3Dto2D_model" in models:
-        groups.append({"params": list(models["SDE_3Dto2D_model"].parameters()),
+        groups.append({"params": ordered_parameters(models["SDE_3Dto2D_model"]),
                        "lr": args.lr * args.gnn_3d_lr_scale})
     return FlatAdam(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=args.decay)
 

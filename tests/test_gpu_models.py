@@ -572,3 +572,32 @@ def test_md17_force_path_double_backward(dev, bs):
     gs = {n: p.grad for n, p in osch.named_parameters() if p.grad is not None}
     _grads_close(sch, gs, 2e-3, 2e-4, "SchNet double-backward grads")
     assert_close(head.weight.grad, ohead.weight.grad, 1e-3, 1e-5, "head grad")
+
+
+def test_fusion_sets_alias_flat_parameters(dev):
+    """The trainer's optimiser lays every fusion set (embedding tables of one encoder; query/key/value/skip
+    projections of one TransformerConv) out back to back, so hip.cat_params returns a VIEW of the parameters
+    (no concatenation kernel), the view tracks optimiser updates, gradients still reach every member, and
+    state-dict keys are untouched."""
+    from moleculesde_amd import hip, pretrain
+    args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=0)
+    tr = pretrain.Trainer(args, dev)
+    n_sets = 0
+    for model in tr.models.values():
+        for mod in model.modules():
+            if not hasattr(mod, "fusion_sets"):
+                continue
+            for group in mod.fusion_sets():
+                n_sets += 1
+                cat = hip.cat_params(group)
+                assert cat.data_ptr() == group[0].data_ptr(), "fusion set not contiguous in the flat buffer"
+                assert cat.data_ptr() % 16 == 0
+                assert torch.equal(cat, torch.cat([p.detach() for p in group], 0))
+                (cat * 2.0).sum().backward()
+                for p in group:
+                    assert p.grad is not None and bool((p.grad == 2.0).all())
+                    p.grad = None
+    assert n_sets >= 6 + 2 * 4          # 6 embedding encoders (atom + 5 bond), 4 TransformerConv x (weights, biases)
+    keys = set(tr.models["SDE_2Dto3D_model"].state_dict().keys())
+    assert "score_network.gnn_layers.0.0.MHA.lin_query.weight" in keys and "edge_2D_emb.0.weight" in keys
+    assert not any(k.startswith("_zero_bias") for k in keys)
