@@ -80,8 +80,8 @@ def roofline_fused_fwd(trainer, batch, iters=50):
     G = sch.num_gaussians
     with torch.no_grad():
         x1 = torch.randn(N, 128, device=batch.x.device)
-        W1T = blk.mlp[0].weight.detach().t().contiguous()
-        W2T = blk.mlp[2].weight.detach().t().contiguous()
+        W1T = blk.mlp[0].weight.detach()          # nn.Linear layouts, as the C ABI takes them
+        W2T = blk.mlp[2].weight.detach()
         b1, b2 = blk.mlp[0].bias.detach(), blk.mlp[2].bias.detach()
         agg = torch.empty(N, 128, device=batch.x.device)
         Wf = torch.empty(rplan.E, 128, device=batch.x.device)

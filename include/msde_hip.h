@@ -116,11 +116,11 @@ int msde_cfconv_aggregate_bwd_x(const float* g_agg, const float* Wf, const float
                                 int F, float* g_x1, void* stream);
 /* Fused CFConv forward: RBF + filter MLP (Linear(G,F) -> ShiftedSoftplus -> Linear(F,F)) + cutoff +
  * gather + segmented sum in one fp32-MFMA kernel — schnet.py:141-145,185-195.  F must be 128, G <= 64.
- * Weights are passed TRANSPOSED ([in][out]: W1T [G,F], W2T [F,F]) so the per-lane operand loads
- * coalesce; b1 [F], b2 [F].  E_cap bounds the edge count (true count = rowptr[N]).
+ * Weights in the nn.Linear layout of the reference's `mlp` (W1 [F,G], W2 [F,F], b1 [F], b2 [F]): no
+ * transposed copies.  E_cap bounds the edge count (true count = rowptr[N]).
  * Wf_out (may be NULL) receives the filter rows (W2 h1 + b2) * C(d) [E_cap,F] for the backward. */
 int msde_cfconv_fused_fwd(const float* x1, const float* dist, const int* rowptr, const int* src,
-                          const int* dst, const float* W1T, const float* b1, const float* W2T,
+                          const int* dst, const float* W1, const float* b1, const float* W2,
                           const float* b2, const float* offset, int N, int F, int G, int E_cap,
                           float coeff, float cutoff, int chunks_per_wg, float* agg, float* Wf_out,
                           void* stream);

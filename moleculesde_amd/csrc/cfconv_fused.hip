@@ -64,8 +64,8 @@ __device__ __forceinline__ int cf_row(int s, int h) { return (s & 3) + 8 * (s >>
 template <int KK1>
 __global__ void __launch_bounds__(256, CF_OCC)
 cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ dist, const int* __restrict__ rowptr,
-                        const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ W1T,
-                        const float* __restrict__ b1, const float* __restrict__ W2T, const float* __restrict__ b2,
+                        const int* __restrict__ src, const int* __restrict__ dst, const float* __restrict__ W1,
+                        const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
                         const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
                         float* __restrict__ agg, float* __restrict__ Wf_out) {
   constexpr int RS = 2 * KK1 + 1;           // rbf tile row stride (odd)
@@ -96,16 +96,68 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
   if (e_begin >= E) return;
   const int e_end = min(e_begin + cpw * CF_TE, E);
 
-  // weights -> registers (B operands), from the TRANSPOSED copies ([in][out]) so that each half-wave
-  // reads 128 contiguous bytes per k
+  // weights -> registers (B operands) from the nn.Linear layouts W1 [F][G], W2 [F][F] (row = output column), with
+  // no transposed copy per step: the workgroup reads them with coalesced loads, stages 32 (W2) / 64 (W1) rows at
+  // a time in the still unused tile region of LDS (odd row strides), and the owning waves pick their operands
+  // lane (col, half) <- W[col][2kk + half].  All global loads are requested before the first staging round.
   float w1r[KK1], w2r[CF_F / 2];
+  {
+    float* stage = hid_t;                         // [32][129] floats (>= 64 x G for W1's two rounds)
+    const bool vec = (reinterpret_cast<uintptr_t>(W2) & 15) == 0;
+    float4 v2[4][4];
 #pragma unroll
-  for (int kk = 0; kk < KK1; ++kk) {
-    int g = 2 * kk + lhalf;
-    w1r[kk] = g < G ? W1T[(size_t)g * CF_F + col] : 0.f;
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int i4 = tid + 256 * j;                   // float4 index inside the 32-row slab: row i4/32, column 4*(i4%32)
+        const float* srcp = W2 + (size_t)(32 * r + (i4 >> 5)) * CF_F + 4 * (i4 & 31);
+        v2[r][j] = vec ? *reinterpret_cast<const float4*>(srcp) : make_float4(srcp[0], srcp[1], srcp[2], srcp[3]);
+      }
+    constexpr int W1N = 64 * 64;                  // upper bound of one W1 half (64 rows x G <= 64)
+    constexpr int W1J = W1N / 256;
+    float v1[2][W1J];
+    const int half_n = 64 * G;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < W1J; ++j) {
+        int i = tid + 256 * j;
+        v1[r][j] = i < half_n ? W1[(size_t)r * half_n + i] : 0.f;
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int i4 = tid + 256 * j;
+        float* d = stage + (i4 >> 5) * CF_HS + 4 * (i4 & 31);
+        d[0] = v2[r][j].x; d[1] = v2[r][j].y; d[2] = v2[r][j].z; d[3] = v2[r][j].w;
+      }
+      __syncthreads();
+      if (wave == r) {
+#pragma unroll
+        for (int kk = 0; kk < CF_F / 2; ++kk) w2r[kk] = stage[lcol * CF_HS + 2 * kk + lhalf];
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int j = 0; j < W1J; ++j) {
+        int i = tid + 256 * j;
+        if (i < half_n) stage[i] = v1[r][j];      // rows of G floats, natural layout (G odd: conflict-free reads)
+      }
+      __syncthreads();
+      if ((wave >> 1) == r) {
+        const int lrow = (wave & 1) * 32 + lcol;
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk) {
+          int g = 2 * kk + lhalf;
+          w1r[kk] = g < G ? stage[lrow * G + g] : 0.f;
+        }
+      }
+      __syncthreads();
+    }
   }
-#pragma unroll
-  for (int kk = 0; kk < CF_F / 2; ++kk) w2r[kk] = W2T[(size_t)(2 * kk + lhalf) * CF_F + col];
   const float b1c = b1[col], b2c = b2[col];
   if (tid < 64) off_s[tid] = tid < G ? offset[tid] : 0.f;
 
@@ -248,11 +300,11 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
 }
 
 extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const int* rowptr, const int* src,
-                                     const int* dst, const float* W1T, const float* b1, const float* W2T,
+                                     const int* dst, const float* W1, const float* b1, const float* W2,
                                      const float* b2, const float* offset, int N, int F, int G, int E_cap,
                                      float coeff, float cutoff, int chunks_per_wg, float* agg, float* Wf_out,
                                      void* stream) {
-  if (N < 0 || E_cap < 0 || !x1 || !dist || !rowptr || !src || !dst || !W1T || !b1 || !W2T || !b2 || !offset || !agg)
+  if (N < 0 || E_cap < 0 || !x1 || !dist || !rowptr || !src || !dst || !W1 || !b1 || !W2 || !b2 || !offset || !agg)
     return MSDE_EINVAL;
   if (F != CF_F || G <= 0 || G > 64) return MSDE_EUNSUP;
   if (N == 0) return 0;
@@ -280,8 +332,8 @@ extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const i
       attr_done = true;                                                                                            \
     }                                                                                                              \
   }                                                                                                                \
-  MSDE_LAUNCH(cfconv_fused_fwd_kernel<KK>, dim3(grid), dim3(256), lds_bytes(KK), st, x1, dist, rowptr, src, dst, W1T, \
-              b1, W2T, b2, offset, N, G, coeff, cutoff, chunks_per_wg, agg, Wf_out)
+  MSDE_LAUNCH(cfconv_fused_fwd_kernel<KK>, dim3(grid), dim3(256), lds_bytes(KK), st, x1, dist, rowptr, src, dst, W1, \
+              b1, W2, b2, offset, N, G, coeff, cutoff, chunks_per_wg, agg, Wf_out)
   if (kk1 == 26) { CF_LAUNCH(26); }
   else if (kk1 == 25) { CF_LAUNCH(25); }
   else { CF_LAUNCH(32); }

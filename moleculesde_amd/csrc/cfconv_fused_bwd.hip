@@ -281,6 +281,9 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
 #undef CB_LAUNCH
   MSDE_CHECK_LAUNCH();
   size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
+  // outputs laid out like a slab ([gW2 | gW1 | gb1 | gb2] in one buffer): generic 16-lane parallel reduction
+  if (gW1 == gW2 + (size_t)CB_F * CB_F && gb1 == gW1 + (size_t)CB_F * G && gb2 == gb1 + CB_F)
+    return msde_reduce_slabs(workspace, nwg, slab_sz, gW2, nullptr, 0, nullptr, st);
   int blocks = (int)((slab_sz + 255) / 256);
   MSDE_LAUNCH(cfconv_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, nwg, slab_sz, G, gW2,
               gW1, gb1, gb2);

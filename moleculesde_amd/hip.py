@@ -157,10 +157,8 @@ def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, 
     agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
     Wf = torch.empty(plan.E, Fd, dtype=torch.float32, device=x1.device) if want_filter else None
     cpw = FUSED_CHUNKS_PER_WG if chunks_per_wg is None else chunks_per_wg
-    W1T = _f32(W1).t().contiguous()      # [G, F]: coalesced operand loads in the kernel
-    W2T = _f32(W2).t().contiguous()      # [F_in, F_out]
     _lib.call("msde_cfconv_fused_fwd", _p(x1), _p(_f32(dist)), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
-              _p(W1T), _p(_f32(b1)), _p(W2T), _p(_f32(b2)), _p(_f32(offset)), N, Fd, G, plan.E,
+              _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)), _p(_f32(offset)), N, Fd, G, plan.E,
               float(coeff), float(cutoff), int(cpw), _p(agg), _p(Wf), _stream())
     return (agg, Wf) if want_filter else agg
 
@@ -204,10 +202,13 @@ class _CFConvFused(torch.autograd.Function):
             g_x1 = torch.empty_like(x1)
             _lib.call("msde_cfconv_aggregate_bwd_x", _p(g), _p(Wf), _p(None), _p(plan.rowptr_s), _p(plan.perm_s),
                       _p(plan.dst), N, Fd, _p(g_x1), st)
-        gW1 = torch.empty_like(W1)
-        gb1 = torch.empty_like(b1)
-        gW2 = torch.empty_like(W2)
-        gb2 = torch.empty_like(b1)
+        # one buffer in the slab order [gW2 | gW1 | gb1 | gb2]: the kernel then sums the slabs with the generic
+        # parallel reduction
+        gall = torch.empty(Fd * Fd + Fd * G + 2 * Fd, dtype=torch.float32, device=g.device)
+        gW2 = gall[:Fd * Fd].view(Fd, Fd)
+        gW1 = gall[Fd * Fd:Fd * Fd + Fd * G].view(Fd, G)
+        gb1 = gall[Fd * Fd + Fd * G:Fd * Fd + Fd * G + Fd]
+        gb2 = gall[Fd * Fd + Fd * G + Fd:]
         ws = _cf_workspace(plan.E, G, x1.device)
         _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
                   _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, _p(gW1), _p(gb1),
