@@ -82,6 +82,7 @@ def readme_args(**over):
 
 
 USE_FUSED_CL = True
+GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
 EARLY_GEOMETRY = os.environ.get("MSDE_EARLY_GEO", "0") != "0"   # start the 2D->3D coordinate branch before the encoders (measured: 2% slower at bs256, so off)
 
 _SDE_RANGES_2D3D = {"VE": ("VE", 0.2, 1.0), "VP": ("VP", 0.2, 1.0), "VE02": ("VE", 0.1, 10.0), "VP02": ("VP", 0.2, 30.0),
@@ -190,7 +191,12 @@ class Trainer:
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self.overlap_streams = True
         self._side_stream = torch.cuda.Stream(device=device)
-        self.models["SDE_2Dto3D_model"].side_stream = torch.cuda.Stream(device=device)
+        # Measured on MI355X (tools/marginal_cost.py, hipGraph replay, bs 256): 1 stream 5.26 ms, SchNet beside the
+        # 2D branch 4.55 ms, a third stream for the 2D->3D coordinate branch 4.73 ms, weight gradients on a fourth
+        # 5.4 ms -- the step is a chain of small kernels and every extra queue / cross-stream event costs more
+        # dispatch latency than it hides.  Two streams it is.
+        if GEOMETRY_STREAM:
+            self.models["SDE_2Dto3D_model"].side_stream = torch.cuda.Stream(device=device)
         self._graphs = {}
         self.adam_outside_graph = False   # True reproduces the multi-GPU structure (graph; all-reduce; Adam) on 1 GPU
         self._graph_pool = None
