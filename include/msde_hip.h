@@ -224,6 +224,18 @@ int msde_res_layernorm_bwd(const float* g, const float* x, const float* gamma, c
  * gradient); workspace: msde_bn_workspace_floats(M, C) floats; fixed summation order. */
 int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void* stream);
 
+/* Batched weight gradients: msde_linear_bwd_w_partial runs only the split-M GEMM of msde_linear_bwd_w and
+ * leaves slabs [splits][N*K] (+ bias partials [splits][N] when want_bias) in `slabs`
+ * (msde_linear_bwd_w_workspace_bytes); splits = msde_linear_bwd_w_splits(M,N,K).  msde_reduce_slabs_multi then
+ * sums the slabs of MANY layers in one launch: rows[r] = {slab address, splits, entries n (= stride between
+ * splits), output address} as four int64; prefix[r] = 256-entry chunks before row r, prefix[count] =
+ * total_chunks.  Fixed summation order (16 interleaved lanes over the splits), like msde_linear_bwd_w. */
+int msde_linear_bwd_w_splits(int M, int N, int K);
+int msde_linear_bwd_w_partial(const float* gY, const float* X, int M, int N, int K, int want_bias,
+                              float* slabs, void* stream);
+int msde_reduce_slabs_multi(const long long* rows, const int* prefix, int count, int total_chunks,
+                            void* stream);
+
 /* ------------------------------------------------------------------ pointwise stages ------- */
 /* ShiftedSoftplus (schnet.py:199-206): y = softplus(x) - log 2 (threshold 20); g_x = g * sigmoid(x).
  * 16-byte aligned buffers. */

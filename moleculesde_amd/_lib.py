@@ -46,6 +46,9 @@ SIGNATURES = {
     "msde_linear_fwd": [P, P, P, I, I, I, P, P],
     "msde_linear_bwd_x": [P, P, I, I, I, P, P],
     "msde_linear_bwd_w_workspace_bytes": [I, I, I],
+    "msde_linear_bwd_w_splits": [I, I, I],
+    "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P],
+    "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
     "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],
     "msde_cl_ebm_bwd": [P, P, P, P, P, P, P, P, I, I, F, P, P, P],

@@ -339,6 +339,69 @@ extern "C" long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K) {
   return (long long)splits * ((long long)N * K + N) * (long long)sizeof(float);
 }
 
+// Batched form of the slab reduction: the weight-gradient GEMMs of a whole backward pass only write their
+// slabs (msde_linear_bwd_w_partial) and ONE launch sums them all.  rows[r] = {slab address, splits, stride
+// between splits (= entries n), output address} as four int64; prefix[r] = number of 256-entry chunks before
+// row r (prefix[count] = grid size).  Same 16-lane fixed-order summation as reduce_slabs_kernel.
+__global__ void __launch_bounds__(256)
+reduce_slabs_multi_kernel(const long long* __restrict__ rows, const int* __restrict__ prefix, int count) {
+  __shared__ float part[RS_LANES][16];
+  int lo = 0, hi = count;                  // last row with prefix[row] <= blockIdx.x
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const long long* e = rows + (size_t)lo * 4;
+  const float* slabs = reinterpret_cast<const float*>(e[0]);
+  const int splits = (int)e[1];
+  const size_t n = (size_t)e[2];
+  float* out = reinterpret_cast<float*>(e[3]);
+  const size_t c0 = (size_t)(blockIdx.x - prefix[lo]) * 256;
+  const int ox = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  for (int it = 0; it < 16; ++it) {
+    size_t i = c0 + it * 16 + ox;
+    float acc = 0.f;
+    if (i < n)
+      for (int z = ly; z < splits; z += RS_LANES) acc += slabs[(size_t)z * n + i];
+    part[ly][ox] = acc;
+    __syncthreads();
+    if (ly == 0 && i < n) {
+      float r = part[0][ox];
+#pragma unroll
+      for (int l = 1; l < RS_LANES; ++l) r += part[l][ox];
+      out[i] = r;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int msde_reduce_slabs_multi(const long long* rows, const int* prefix, int count, int total_chunks,
+                                       void* stream) {
+  if (count < 0 || total_chunks < 0 || (count > 0 && (!rows || !prefix))) return MSDE_EINVAL;
+  if (count == 0 || total_chunks == 0) return 0;
+  MSDE_LAUNCH(reduce_slabs_multi_kernel, dim3(total_chunks), dim3(256), 0, as_stream(stream), rows, prefix, count);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_linear_bwd_w_splits(int M, int N, int K) {
+  int splits, kps;
+  wgrad_split(M, N, K, &splits, &kps);
+  return splits;
+}
+
+// GEMM half of msde_linear_bwd_w: slabs [splits][N*K] followed (when want_bias) by the bias partials
+// [splits][N]; sum them with msde_reduce_slabs_multi (or msde_linear_bwd_w does both).
+extern "C" int msde_linear_bwd_w_partial(const float* gY, const float* X, int M, int N, int K, int want_bias,
+                                         float* slabs, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs) return MSDE_EINVAL;
+  int splits, k_per_split;
+  wgrad_split(M, N, K, &splits, &k_per_split);
+  float* cs = want_bias ? slabs + (size_t)splits * N * K : nullptr;
+  return launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, wgrad_big(M, N, K),
+                                 as_stream(stream));
+}
+
 extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, float* gW, float* gb,
                                  float* workspace, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !gY || !X || !gW || !workspace) return MSDE_EINVAL;

@@ -22,11 +22,14 @@ USE_HIP_LINEAR = True   # False routes dense layers to the vendor GEMM (A/B meas
 
 class Linear(nn.Linear):
     """nn.Linear (same parameters / state_dict keys) whose forward, input gradient and weight/bias
-    gradient run on the fp32 MFMA GEMM of csrc/linear.hip."""
+    gradient run on the fp32 MFMA GEMM of csrc/linear.hip.  `shared`: the module is applied more than once per
+    forward, so autograd adds its weight gradients (they are then reduced on the spot, not in the batch)."""
+
+    shared = False
 
     def forward(self, x):
         if USE_HIP_LINEAR and x.is_cuda:
-            return hip.linear(x, self.weight, self.bias)
+            return hip.linear(x, self.weight, self.bias, offload=not self.shared)
         return F.linear(x, self.weight, self.bias)
 
 

@@ -150,6 +150,7 @@ class SDEModel2Dto3D_02(nn.Module):
         self.input_mlp = _nn.MultiLayerPerceptron(2 * hidden_dim, [hidden_dim], activation="silu")
         self.coff_gaussian_fourier = GaussianFourierProjection(hidden_dim, scale=1)
         self.coff_mlp = _nn.Linear(4 * hidden_dim, hidden_dim)
+        self.coff_mlp.shared = True            # applied to both frame features of an edge
         self.project = _nn.MultiLayerPerceptron(2 * hidden_dim + 2, [hidden_dim, hidden_dim], activation="silu")
         self.score_network = EquivariantScoreNetwork(hidden_dim, hidden_coff_dim=128, activation="silu",
                                                      short_cut=short_cut, concat_hidden=concat_hidden)

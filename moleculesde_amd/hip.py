@@ -495,7 +495,11 @@ class _CatParams(torch.autograd.Function):
 
 def cat_params(ws):
     ws = list(ws)
-    return ws[0] if len(ws) == 1 else _CatParams.apply(*ws)
+    if len(ws) == 1:
+        return ws[0]
+    out = _CatParams.apply(*ws)
+    out._msde_leaf_like = all(w.is_leaf for w in ws)     # its gradient only gets split into views for the leaves
+    return out
 
 
 class _EdgeAttention(torch.autograd.Function):
@@ -715,9 +719,112 @@ def set_linear_mode(mode):
     _LINEAR_MODE = mode
 
 
+# ---- batched slab reduction -----------------------------------------------------------------------------------
+# Every split-M weight gradient is a GEMM that writes per-split slabs plus a reduction over the splits.  The
+# reductions are leaves of the backward graph (only the optimiser reads their results), and the step is bound
+# by the number of dependent launches: between begin_param_grad_batch() and finish_param_grad_batch() the GEMMs
+# write their slabs into one arena and ONE kernel (msde_reduce_slabs_multi) sums the slabs of all layers at the
+# end.  Until then the returned gradient tensors are allocated but not yet filled, which is safe exactly when
+# nothing but autograd's leaf bookkeeping touches them: parameters used once per forward (`offload`) that are
+# leaves or concatenation views of leaves.  Everything else keeps the immediate two-kernel path.
+class _SlabBatch:
+    MAX_ROWS = 4096
+
+    def __init__(self):
+        self.active = False
+        self.arena = None
+        self.used = 0
+        self.rows = []           # (slab address, splits, n, out tensor)
+        self.retired = []        # outgrown arenas still referenced by queued rows
+        self.slot = None
+        self.slots = []
+
+    def new_slot(self, device):
+        """Pinned host image + device copy of the row / prefix tables (one per captured graph: the upload is a
+        memcpy node that re-reads its host image at every replay)."""
+        host_rows = torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64).pin_memory()
+        host_pre = torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32).pin_memory()
+        self.slot = (host_rows, host_pre, torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64, device=device),
+                     torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device))
+        self.slots.append(self.slot)
+
+    def begin(self):
+        assert not self.rows, "finish_param_grad_batch() was not called after the previous backward"
+        self.active = True
+        self.used = 0
+
+    def alloc(self, nfloats, device):
+        nfloats = (nfloats + 3) & ~3
+        if self.arena is None or self.arena.device != device or self.used + nfloats > self.arena.numel():
+            if self.arena is not None:
+                self.retired.append(self.arena)
+            size = max(1 << 26, 2 * (self.used + nfloats))
+            self.arena = torch.empty(size, dtype=torch.float32, device=device)
+            self.used = 0
+        view = self.arena[self.used:self.used + nfloats]
+        self.used += nfloats
+        return view
+
+    def add(self, slab_ptr, splits, n, out):
+        # only the ADDRESS of the output is kept: an extra reference to the gradient tensor would make autograd's
+        # AccumulateGrad clone it (it steals the buffer only when it holds the sole reference) -- a copy of the
+        # not yet reduced buffer.  The leaf's .grad keeps the memory alive until the optimiser has used it.
+        self.rows.append((slab_ptr, splits, n, out.data_ptr(), out.device))
+
+    def finish(self):
+        self.active = False
+        rows = self.rows
+        if not rows:
+            return
+        assert len(rows) <= self.MAX_ROWS
+        dev = rows[0][4]
+        if self.slot is None or self.slot[2].device != dev:
+            self.new_slot(dev)
+        host_rows, host_pre, dev_rows, dev_pre = self.slot
+        hr, hp = host_rows.numpy(), host_pre.numpy()
+        total = 0
+        for r, (ptr, splits, n, out_ptr, _) in enumerate(rows):
+            hr[r, 0], hr[r, 1], hr[r, 2], hr[r, 3] = ptr, splits, n, out_ptr
+            hp[r] = total
+            total += (n + 255) // 256
+        hp[len(rows)] = total
+        dev_rows.copy_(host_rows, non_blocking=True)
+        dev_pre.copy_(host_pre, non_blocking=True)
+        _lib.call("msde_reduce_slabs_multi", _p(dev_rows), _p(dev_pre), len(rows), total, _stream())
+        self.rows = []
+        self.retired = []
+
+
+_SLABS = _SlabBatch()
+_SPLITS = {}
+
+
+def begin_param_grad_batch():
+    _SLABS.begin()
+
+
+def finish_param_grad_batch():
+    """Sum all queued slabs (one launch on the current stream, which must already be ordered after every stream
+    that ran part of the backward -- loss.backward() returns in that state)."""
+    _SLABS.finish()
+
+
+def new_param_grad_slot(device):
+    """Before a hipGraph capture: give the graph its own table slot (see _SlabBatch.new_slot)."""
+    if not _SLABS.slots:
+        _SLABS.new_slot(device)          # slot 0 stays the eager slot
+    _SLABS.new_slot(device)
+
+
+def use_eager_param_grad_slot():
+    """After a capture: eager steps must not overwrite the host tables a captured graph re-reads."""
+    if _SLABS.slots:
+        _SLABS.slot = _SLABS.slots[0]
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, offload=True):
         shape = x.shape
         x2 = _f32(x.reshape(-1, shape[-1]))
         w = _f32(weight)
@@ -732,6 +839,9 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.in_shape = shape
+        # deferred slab reduction (see _SlabBatch) only for gradients nothing reads before the optimiser
+        ctx.deferrable = offload and all(t is None or t.is_leaf or getattr(t, "_msde_leaf_like", False)
+                                         for t in (weight, bias))
         return y.view(*shape[:-1], N)
 
     @staticmethod
@@ -754,20 +864,32 @@ class _Linear(torch.autograd.Function):
             if use_hip:
                 gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
                 gb = torch.empty(N, dtype=torch.float32, device=g2.device) if ctx.has_bias else None
-                ws = _wgrad_workspace(M, N, K, g2.device)
-                _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
+                if _SLABS.active and ctx.deferrable:
+                    splits = _SPLITS.get((M, N, K))
+                    if splits is None:
+                        splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
+                    slab = _SLABS.alloc(splits * (N * K + (N if ctx.has_bias else 0)), g2.device)
+                    _lib.call("msde_linear_bwd_w_partial", _p(g2), _p(x2), M, N, K, int(ctx.has_bias), _p(slab), st)
+                    _SLABS.add(slab.data_ptr(), splits, N * K, gw)
+                    if ctx.has_bias:
+                        _SLABS.add(slab.data_ptr() + 4 * splits * N * K, splits, N, gb)
+                else:
+                    ws = _wgrad_workspace(M, N, K, g2.device)
+                    _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
             else:
                 gw = torch.mm(g2.t(), x2)
                 gb = None
                 if ctx.has_bias:
                     gb = torch.empty(N, dtype=torch.float32, device=g2.device)
                     _lib.call("msde_colsum", _p(g2), M, N, _p(gb), _p(_bn_workspace(M, N, g2.device)), st)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def linear(x, weight, bias=None):
-    """F.linear with the dispatch policy above (library GEMM / csrc/linear.hip MFMA kernels)."""
-    return _Linear.apply(x, weight, bias)
+def linear(x, weight, bias=None, offload=True):
+    """F.linear with the dispatch policy above (library GEMM / csrc/linear.hip MFMA kernels).  offload=False:
+    the parameters are used more than once per forward, so autograd adds their gradients and the weight-gradient
+    slabs are reduced on the spot instead of in the batched reduction."""
+    return _Linear.apply(x, weight, bias, offload)
 
 
 # ------------------------------------------------------------------------------------------------

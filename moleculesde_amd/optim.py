@@ -82,6 +82,11 @@ class FlatAdam:
         self._slot = (host, torch.empty(self.n_chunks, 3, dtype=torch.int64, device=self.flat_p.device))
         self._slots.append(self._slot)
 
+    def use_eager_slot(self):
+        """After a capture: eager steps go back to slot 0 so that they never overwrite the host image a captured
+        graph re-reads at every replay."""
+        self._slot = self._slots[0]
+
     def _chunk_table(self):
         """Device table of (gradient chunk address, flat offset, count) for the current .grad tensors."""
         host, dev = self._slot

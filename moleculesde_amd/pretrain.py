@@ -82,6 +82,7 @@ def readme_args(**over):
 
 
 USE_FUSED_CL = True
+BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
 GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
 EARLY_GEOMETRY = os.environ.get("MSDE_EARLY_GEO", "0") != "0"   # start the 2D->3D coordinate branch before the encoders (measured: 2% slower at bs256, so off)
 
@@ -262,10 +263,22 @@ class Trainer:
             parts["3Dto2D"] = l32.detach()
         return loss, parts
 
+    def _backward(self, loss):
+        """loss.backward() with the weight-gradient slab reductions of all layers batched into one launch."""
+        from . import hip
+        if not BATCH_SLAB_REDUCE:
+            loss.backward()
+            return
+        hip.begin_param_grad_batch()
+        try:
+            loss.backward()
+        finally:
+            hip.finish_param_grad_batch()
+
     def step(self, batch):
         loss, parts = self.losses(batch)
         self.opt.zero_grad()
-        loss.backward()
+        self._backward(loss)
         if dp.world_size() > 1 or dp.FORCE_COLLECTIVES:
             flat_g = self.opt.gather_grads()
             scale = dp.allreduce_mean_(flat_g)
@@ -282,7 +295,7 @@ class Trainer:
         self.step_counter.add_(1)
         loss, parts = self.losses(batch)
         self.opt.zero_grad()
-        loss.backward()
+        self._backward(loss)
         if with_adam:
             self.opt.step_from_grads()
         else:
@@ -301,6 +314,8 @@ class Trainer:
         sd = self.step_counter.view(torch.int64)
         self.models["SDE_2Dto3D_model"].score_network.seed_dev = sd
         self.opt.new_table_slot()       # this graph's own (pinned) gradient chunk table
+        from . import hip as _hip
+        _hip.new_param_grad_slot(batch.x.device)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         if self._graph_pool is None:
@@ -309,6 +324,8 @@ class Trainer:
         # while this thread captures; they must not invalidate the capture
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             loss = self._graph_body(batch, with_adam)
+        self.opt.use_eager_slot()
+        _hip.use_eager_param_grad_slot()
         self._graphs[key] = g
         self._graph_loss[key] = loss
         return g
