@@ -252,6 +252,12 @@ int msde_silu_dropout_bwd(const float* g, const float* x, long long n, float p, 
 int msde_mul_add_fwd(const float* a, const float* b, const float* c, long long n, float* out, void* stream);
 int msde_mul_add_bwd(const float* g, const float* a, const float* b, long long n, float* ga, float* gb,
                      void* stream);
+/* VE perturbation (SDE_model_2D_to_3D.py:401-412, SDE_sparse.py VESDE.marginal_prob): draws [B/2+1] int64 in
+ * [0,T); molecule b uses ts = draws[b] (b < B/2+1) or T - draws[b-(B/2+1)] - 1; t = ts/T*(1-eps)+eps;
+ * std_out[i] = sigma_min (sigma_max/sigma_min)^t of atom i's molecule; pos_out = pos + std * noise. */
+int msde_ve_perturb(const float* pos, const float* noise, const long long* draws, const int* batch, int N,
+                    int B, int T, float eps, float sigma_min, float sigma_max, float* pos_out,
+                    float* std_out, void* stream);
 /* VE position loss (SDE_model_2D_to_3D.py:425-432): loss[0] = mean_b mean_{i in b} sum_k (scores-noise)^2
  * [* std_i^anneal_power when anneal_power != 0]; mol_ws: B floats.  bwd: g_scores [N,3] from g_loss[0]. */
 int msde_ve_pos_loss_fwd(const float* scores, const float* noise, const float* std, float anneal_power,

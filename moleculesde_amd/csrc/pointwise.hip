@@ -135,6 +135,38 @@ ve_pos_loss_bwd_kernel(const float* __restrict__ scores, const float* __restrict
   for (int c = 0; c < 3; ++c) g_scores[3 * i + c] = k * (scores[3 * i + c] - noise[3 * i + c]);
 }
 
+// VE perturbation of the coordinates (SDE_model_2D_to_3D.py:401-412): per molecule b the time step is
+// ts = draws[b] for b < H = B/2+1 and T - draws[b-H] - 1 after that (the antithetic half), t = ts/T*(1-eps)+eps,
+// std = sigma_min (sigma_max/sigma_min)^t, pos_perturbed = pos + std * noise.  One thread per atom.
+__global__ void __launch_bounds__(256)
+ve_perturb_kernel(const float* __restrict__ pos, const float* __restrict__ noise, const long long* __restrict__ draws,
+                  const int* __restrict__ batch, int N, int B, int T, float eps, float sigma_min, float sigma_ratio,
+                  float* __restrict__ pos_out, float* __restrict__ std_out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int b = batch[i];
+  int H = B / 2 + 1;
+  long long ts = b < H ? draws[b] : (long long)T - draws[b - H] - 1;
+  float t = (float)ts / (float)T;
+  t = t * (1.0f - eps) + eps;
+  float sd = sigma_min * powf(sigma_ratio, t);
+  std_out[i] = sd;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pos_out[3 * i + c] = pos[3 * i + c] + sd * noise[3 * i + c];
+}
+
+extern "C" int msde_ve_perturb(const float* pos, const float* noise, const long long* draws, const int* batch, int N,
+                               int B, int T, float eps, float sigma_min, float sigma_max, float* pos_out,
+                               float* std_out, void* stream) {
+  if (N < 0 || B <= 0 || T <= 0 || !pos || !noise || !draws || !batch || !pos_out || !std_out || sigma_min <= 0.f)
+    return MSDE_EINVAL;
+  if (N == 0) return 0;
+  MSDE_LAUNCH(ve_perturb_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), pos, noise, draws, batch, N, B,
+              T, eps, sigma_min, sigma_max / sigma_min, pos_out, std_out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 static inline int pw_blocks(long long n, int per_thread) {
   long long b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
   if (b > 4096 && per_thread == 1) b = 4096;

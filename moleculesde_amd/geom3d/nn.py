@@ -39,6 +39,20 @@ class BatchNorm1d(nn.BatchNorm1d):
     the affine map on the running statistics."""
 
     fuse_relu = False
+    # num_batches_tracked only feeds the momentum=None (cumulative average) mode; with a fixed momentum its per-call
+    # increment is a kernel launch that changes no result.  The increments are counted on the host instead
+    # (`pending_batches`; a trainer replaying a captured graph adds its replays) and folded into the buffer
+    # whenever a state dict is taken, so checkpoints are identical to the reference's.
+    pending_batches = 0
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_batches_tracked())
+
+    def flush_batches_tracked(self):
+        if self.pending_batches and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(int(self.pending_batches))
+        self.pending_batches = 0
 
     def forward(self, x):
         if not (USE_HIP_LINEAR and x.is_cuda and x.dim() == 2):
@@ -46,7 +60,11 @@ class BatchNorm1d(nn.BatchNorm1d):
             return F.relu(y) if self.fuse_relu else y
         if self.training or not self.track_running_stats:
             if self.track_running_stats and self.num_batches_tracked is not None:
-                self.num_batches_tracked.add_(1)
+                if self.momentum is None:
+                    self.flush_batches_tracked()
+                    self.num_batches_tracked.add_(1)
+                elif not torch.cuda.is_current_stream_capturing():
+                    self.pending_batches += 1          # replays of a captured step are counted by the trainer
             momentum = 0.1 if self.momentum is None else self.momentum
             return hip.batch_norm_train(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                         self.running_var if self.track_running_stats else None, self.eps, momentum,

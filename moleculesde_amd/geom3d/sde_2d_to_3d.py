@@ -202,13 +202,17 @@ class SDEModel2Dto3D_02(nn.Module):
         B = data.num_graphs
         T = self.num_diffusion_timesteps
         pos_noise = self.noise.randn_like(pos)
-        time_step = self.noise.randint(T, (B // 2 + 1,), pos.device)
-        time_step = torch.cat([time_step, T - time_step - 1], dim=0)[:B]
-        if self.SDE_type in ("VE", "VP"):
-            time_step = time_step / T * (1 - EPSILON) + EPSILON
-        t_pos = time_step.index_select(0, data.batch)
-        mean_pos, std_pos = self.sde_pos.marGINal_prob(pos.detach(), t_pos)
-        pos_perturbed = mean_pos + std_pos[:, None] * pos_noise
+        draws = self.noise.randint(T, (B // 2 + 1,), pos.device)
+        if pos.is_cuda and self.SDE_type == "VE" and draws.dtype == torch.int64:
+            pos_perturbed, std_pos = hip.ve_perturb(pos, pos_noise, draws, pl.batch_i32, B, T, EPSILON,
+                                                    self.sde_pos.sigma_min, self.sde_pos.sigma_max)
+        else:
+            time_step = torch.cat([draws, T - draws - 1], dim=0)[:B]
+            if self.SDE_type in ("VE", "VP"):
+                time_step = time_step / T * (1 - EPSILON) + EPSILON
+            t_pos = time_step.index_select(0, data.batch)
+            mean_pos, std_pos = self.sde_pos.marGINal_prob(pos.detach(), t_pos)
+            pos_perturbed = mean_pos + std_pos[:, None] * pos_noise
         geo, side = self._launch_geometry(pos_perturbed, ep)
         self._pending = (data, pos_noise, std_pos, pos_perturbed, geo, side)
 

@@ -1090,6 +1090,18 @@ def mul_add(a, b, c):
     return _MulAdd.apply(a, b, c)
 
 
+def ve_perturb(pos, noise, draws, batch_i32, B, T, eps, sigma_min, sigma_max):
+    """pos + std(t_mol) * noise and std per atom for the VE SDE, from the integer time-step draws (one kernel for
+    the ~9 pointwise operators of SDE_model_2D_to_3D.py:401-412).  No gradient (coordinates carry none)."""
+    pos, noise = _f32(pos.detach()), _f32(noise)
+    N = pos.size(0)
+    out = torch.empty_like(pos)
+    std = torch.empty(N, dtype=torch.float32, device=pos.device)
+    _lib.call("msde_ve_perturb", _p(pos), _p(noise), _p(draws.contiguous()), _p(batch_i32), N, int(B), int(T), float(eps),
+              float(sigma_min), float(sigma_max), _p(out), _p(std), _stream())
+    return out, std
+
+
 class _VEPosLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scores, noise, std, anneal_power, mol_ptr, batch_i32):

@@ -192,6 +192,7 @@ class Trainer:
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self.overlap_streams = True
         self._side_stream = torch.cuda.Stream(device=device)
+        self._bn_modules = [mod for m_ in self.models.values() for mod in m_.modules() if isinstance(mod, _nn.BatchNorm1d)]
         # Measured on MI355X (tools/marginal_cost.py, hipGraph replay, bs 256): 1 stream 5.26 ms, SchNet beside the
         # 2D branch 4.55 ms, a third stream for the 2D->3D coordinate branch 4.73 ms, weight gradients on a fourth
         # 5.4 ms -- the step is a chain of small kernels and every extra queue / cross-stream event costs more
@@ -263,6 +264,10 @@ class Trainer:
             parts["3Dto2D"] = l32.detach()
         return loss, parts
 
+    def _log_parts(self, parts):
+        keys = list(parts.keys())
+        torch._foreach_add_([self.log[k] for k in keys], [parts[k].to(torch.float32) for k in keys])   # one launch
+
     def _backward(self, loss):
         """loss.backward() with the weight-gradient slab reductions of all layers batched into one launch."""
         from . import hip
@@ -285,8 +290,7 @@ class Trainer:
             self.opt.step(grad_scale=scale)
         else:
             self.opt.step_from_grads()
-        for k, v in parts.items():
-            self.log[k] += v
+        self._log_parts(parts)
         self.steps += 1
         return loss.detach(), parts
 
@@ -300,8 +304,7 @@ class Trainer:
             self.opt.step_from_grads()
         else:
             self.opt.gather_grads()
-        for k, v in parts.items():
-            self.log[k] += v
+        self._log_parts(parts)
         return loss.detach()
 
     def capture(self, batch):
@@ -334,6 +337,8 @@ class Trainer:
         """Replay the captured step; under DP the all-reduce and Adam run after the replay."""
         g = self._graphs[id(batch)]
         g.replay()
+        for bn in self._bn_modules:
+            bn.pending_batches += 1        # the captured forward does not run Python: count its BatchNorm calls here
         if dp.world_size() > 1 or self.adam_outside_graph:
             scale = dp.allreduce_mean_(self.opt.flat_g)
             self.opt.step(grad_scale=scale)

@@ -639,3 +639,24 @@ def test_ve_position_loss_kernel(dev, power):
     assert_close(loss, ref.detach(), 1e-5, 1e-6, "VE position loss")
     (loss * 1.3).backward()
     assert_close(sd.grad, scores.grad, 1e-5, 1e-7, "VE position loss grad")
+
+
+def test_ve_perturb_kernel(dev):
+    """Fused VE perturbation vs the reference's operator chain (SDE_model_2D_to_3D.py:401-412)."""
+    from moleculesde_amd import hip, plan as P
+    from moleculesde_amd.geom3d.sde import VESDE
+    b = _toy_graph(13, 37)
+    pl = P.plan_to(P.build_plan(b), dev)
+    B, T, eps = int(b.num_graphs), 1000, 1e-6
+    g = torch.Generator().manual_seed(5)
+    noise = torch.randn(b.positions.shape, generator=g)
+    draws = torch.randint(0, T, (B // 2 + 1,), generator=g)
+    sde = VESDE(sigma_min=0.2, sigma_max=1.0, N=T)
+    time_step = torch.cat([draws, T - draws - 1], dim=0)[:B]
+    t = time_step / T * (1 - eps) + eps
+    t_pos = t.index_select(0, b.batch)
+    mean, std = sde.marGINal_prob(b.positions, t_pos)
+    ref = mean + std[:, None] * noise
+    out, sd = hip.ve_perturb(b.positions.to(dev), noise.to(dev), draws.to(dev), pl.batch_i32, B, T, eps, 0.2, 1.0)
+    assert_close(sd, std, 1e-6, 1e-7, "std per atom")
+    assert_close(out, ref, 1e-6, 1e-6, "perturbed positions")
