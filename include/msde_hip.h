@@ -151,16 +151,18 @@ int msde_edge_attention_fwd(const float* q, const float* k, const float* v,
                             const float* skip /* may be NULL, else out += skip (lin_skip(x_i)) */,
                             int ld /* row stride of q,k,v,skip: they may be column blocks of one
                                       fused projection [N, 4D] */,
-                            const float* ee, const int* rowptr, const int* src, int N, int H, int Ch,
+                            const float* ee, int ld_ee /* row stride of ee (0 = D): it may be a column block
+                                                          of one projection shared by several layers */,
+                            const int* rowptr, const int* src, int N, int H, int Ch,
                             float p_drop, unsigned long long seed,
                             const unsigned long long* seed_dev, float* alpha, float* out,
                             void* stream);
-/* backward of the above: writes g_q [N,D], g_ee [E,D] and the per-edge grads g_kpe/g_vpe [E,D]
- * (to be segment-summed by source into g_k / g_v with msde_segment_sum_rows). */
+/* backward of the above: writes g_q [N,D], g_ee [E,D] (row stride ld_ee, like ee) and the per-edge grads
+ * g_kpe/g_vpe [E,D] (to be segment-summed by source into g_k / g_v with msde_segment_sum_rows). */
 int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v,
                             int ld, float* g_skip /* may be NULL, else receives g_out */,
                             int ldg /* row stride of g_q and g_skip */,
-                            const float* ee, const float* alpha, const int* rowptr,
+                            const float* ee, int ld_ee, const float* alpha, const int* rowptr,
                             const int* src, int N, int H, int Ch, float p_drop,
                             unsigned long long seed, const unsigned long long* seed_dev,
                             float* g_q, float* g_ee, float* g_kpe, float* g_vpe, void* stream);

@@ -79,7 +79,7 @@ extern "C" int msde_edge_geometry_fwd(const float* pos, const int* src, const in
 template <int CH>
 __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                           const float* __restrict__ v, const float* __restrict__ skip, int ld,
-                                          const float* __restrict__ ee,
+                                          const float* __restrict__ ee, int ld_ee,
                                           const int* __restrict__ rowptr, const int* __restrict__ src, int N, int H,
                                           float p_drop, unsigned long long seed,
                                           const unsigned long long* __restrict__ seed_dev,
@@ -97,7 +97,7 @@ __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const flo
   float m = -INFINITY;
   for (int e = s0; e < s1; ++e) {
     const float* kr = k + (size_t)src[e] * ld + h * CH;
-    const float* er = ee + (size_t)e * D + h * CH;
+    const float* er = ee + (size_t)e * ld_ee + h * CH;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) s += qv[c] * (kr[c] + er[c]);
@@ -121,7 +121,7 @@ __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const flo
     alpha[(size_t)e * H + h] = a;
     if (p_drop > 0.f) a = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? a * keep_scale : 0.f;
     const float* vr = v + (size_t)src[e] * ld + h * CH;
-    const float* er = ee + (size_t)e * D + h * CH;
+    const float* er = ee + (size_t)e * ld_ee + h * CH;
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[c] = fmaf(a, vr[c] + er[c], acc[c]);
   }
@@ -134,7 +134,7 @@ template <int CH>
 __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ q,
                                           const float* __restrict__ k, const float* __restrict__ v, int ld,
                                           float* __restrict__ g_skip, int ldg,
-                                          const float* __restrict__ ee, const float* __restrict__ alpha,
+                                          const float* __restrict__ ee, int ld_ee, const float* __restrict__ alpha,
                                           const int* __restrict__ rowptr, const int* __restrict__ src, int N, int H,
                                           float p_drop, unsigned long long seed,
                                           const unsigned long long* __restrict__ seed_dev, float* __restrict__ g_q,
@@ -163,7 +163,7 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
     float ms = 1.f;
     if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
     const float* vr = v + (size_t)src[e] * ld + h * CH;
-    const float* er = ee + (size_t)e * D + h * CH;
+    const float* er = ee + (size_t)e * ld_ee + h * CH;
     float ga = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -179,7 +179,7 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
     if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
     const float* vr = v + (size_t)src[e] * ld + h * CH;
     const float* kr = k + (size_t)src[e] * ld + h * CH;
-    const float* er = ee + (size_t)e * D + h * CH;
+    const float* er = ee + (size_t)e * ld_ee + h * CH;
     float ga = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) ga = fmaf(go[c], vr[c] + er[c], ga);
@@ -189,7 +189,7 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
       gq[c] = fmaf(gs, kr[c] + er[c], gq[c]);
       float gk = gs * qv[c];
       g_kpe[(size_t)e * D + h * CH + c] = gk;
-      g_ee[(size_t)e * D + h * CH + c] = gk + go[c] * (a * ms);
+      g_ee[(size_t)e * ld_ee + h * CH + c] = gk + go[c] * (a * ms);
     }
   }
 #pragma unroll
@@ -197,19 +197,20 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
 }
 
 extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
-                                       const float* ee,
+                                       const float* ee, int ld_ee,
                                        const int* rowptr, const int* src, int N, int H, int Ch, float p_drop,
                                        unsigned long long seed, const unsigned long long* seed_dev, float* alpha,
                                        float* out, void* stream) {
   if (N < 0 || H <= 0 || Ch <= 0 || !q || !k || !v || !ee || !rowptr || !src || !alpha || !out) return MSDE_EINVAL;
-  if (p_drop < 0.f || p_drop >= 1.f || ld < H * Ch) return MSDE_EINVAL;
+  if (ld_ee == 0) ld_ee = H * Ch;
+  if (p_drop < 0.f || p_drop >= 1.f || ld < H * Ch || ld_ee < H * Ch) return MSDE_EINVAL;
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: MSDE_LAUNCH(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
-    case 2: MSDE_LAUNCH(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
-    case 4: MSDE_LAUNCH(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
-    case 8: MSDE_LAUNCH(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 1: MSDE_LAUNCH(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, ld_ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 2: MSDE_LAUNCH(edge_attention_fwd_kernel<2>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, ld_ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 4: MSDE_LAUNCH(edge_attention_fwd_kernel<4>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, ld_ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
+    case 8: MSDE_LAUNCH(edge_attention_fwd_kernel<8>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, ld_ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();
@@ -218,21 +219,22 @@ extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const flo
 
 extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, const float* v, int ld,
                                        float* g_skip, int ldg,
-                                       const float* ee, const float* alpha, const int* rowptr, const int* src, int N,
-                                       int H, int Ch, float p_drop, unsigned long long seed,
+                                       const float* ee, int ld_ee, const float* alpha, const int* rowptr, const int* src,
+                                       int N, int H, int Ch, float p_drop, unsigned long long seed,
                                        const unsigned long long* seed_dev, float* g_q, float* g_ee, float* g_kpe,
                                        float* g_vpe, void* stream) {
   if (N < 0 || H <= 0 || Ch <= 0 || !g_out || !q || !k || !v || !ee || !alpha || !rowptr || !src || !g_q || !g_ee ||
       !g_kpe || !g_vpe)
     return MSDE_EINVAL;
-  if (p_drop < 0.f || p_drop >= 1.f) return MSDE_EINVAL;
+  if (ld_ee == 0) ld_ee = H * Ch;
+  if (p_drop < 0.f || p_drop >= 1.f || ld_ee < H * Ch) return MSDE_EINVAL;
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();

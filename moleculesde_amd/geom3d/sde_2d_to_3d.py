@@ -50,7 +50,7 @@ class TransformerConv(nn.Module):
         return [[self.lin_query.weight, self.lin_key.weight, self.lin_value.weight, self.lin_skip.weight],
                 [self.lin_query.bias, self.lin_key.bias, self.lin_value.bias, self.lin_skip.bias]]
 
-    def forward(self, x, edge_attr, plan, seed, seed_dev=None):
+    def forward(self, x, edge_attr, plan, seed, seed_dev=None, ee_all=None, col=0, shared=None):
         # one projection GEMM for query | key | value | skip (they share the input x)
         Ws, bs = self.fusion_sets()
         if x.is_cuda:
@@ -58,8 +58,10 @@ class TransformerConv(nn.Module):
         else:
             W, b = torch.cat(Ws, dim=0), torch.cat(bs, dim=0)
         qkvs = _nn.linear(x, W, b)
-        ee = self.lin_edge(edge_attr)
         p = self.dropout if self.training else 0.0
+        if ee_all is not None:           # lin_edge of all layers evaluated as one GEMM by the caller
+            return hip.edge_attention_fused(qkvs, ee_all, plan, self.heads, p, seed, seed_dev, col, shared)
+        ee = self.lin_edge(edge_attr)
         return hip.edge_attention_fused(qkvs, ee, plan, self.heads, p, seed, seed_dev)
 
 
@@ -73,8 +75,8 @@ class GATLayer(nn.Module):
         self.norm1 = nn.LayerNorm(hidden_dim)
         self.norm2 = nn.LayerNorm(hidden_dim)
 
-    def forward(self, plan, node_attr, edge_attr, seed, seed_dev=None):
-        x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev)
+    def forward(self, plan, node_attr, edge_attr, seed, seed_dev=None, ee_all=None, col=0, shared=None):
+        x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev, ee_all, col, shared)
         if x.is_cuda and x.size(-1) % 4 == 0:
             node_attr = hip.res_layernorm(x, node_attr, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             # FFN = Linear -> SiLU -> Dropout -> Linear with the two pointwise stages in one kernel
@@ -114,15 +116,25 @@ class EquivariantScoreNetwork(nn.Module):
         self._calls = 0
         self.seed_dev = None   # device uint64 step counter (set by the trainer for hipGraph replay)
 
+    def fusion_sets(self):
+        # lin_edge of every GAT layer consumes the same edge features: one stacked weight, one GEMM
+        return [[gnn.MHA.lin_edge.weight for layers in self.gnn_layers for gnn in layers]]
+
     def forward(self, plan, node_attr, edge_attr, basis):
         conv_input = node_attr
         gradient = None
+        ee_all, shared, D = None, None, self.hidden_dim
+        if edge_attr.is_cuda:
+            ee_all = _nn.linear(edge_attr, hip.cat_params(self.fusion_sets()[0]))       # [E, layers*D]
+            shared = {}
+        layer_no = 0
         if self.seed_dev is None:
             self._calls += 1     # eager: host-side call counter; graph mode: the device counter varies the mask
         for module_idx, gnn_layers in enumerate(self.gnn_layers):
             for conv_idx, gnn in enumerate(gnn_layers):
                 seed = (self._seed_base + self._calls) * 16 + module_idx * 4 + conv_idx
-                hidden = gnn(plan, conv_input, edge_attr, seed, self.seed_dev)
+                hidden = gnn(plan, conv_input, edge_attr, seed, self.seed_dev, ee_all, layer_no * D, shared)
+                layer_no += 1
                 if conv_idx < len(gnn_layers) - 1:
                     hidden = hip.silu_dropout(hidden) if hidden.is_cuda else F.silu(hidden)
                 conv_input = hidden

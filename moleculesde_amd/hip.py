@@ -510,7 +510,7 @@ class _EdgeAttention(torch.autograd.Function):
         Ch = D // heads
         alpha = torch.empty(plan.E, heads, dtype=torch.float32, device=q.device)
         out = torch.empty_like(q)
-        _lib.call("msde_edge_attention_fwd", _p(q), _p(k), _p(v), _p(None), D, _p(ee), _p(plan.rowptr), _p(plan.src), N,
+        _lib.call("msde_edge_attention_fwd", _p(q), _p(k), _p(v), _p(None), D, _p(ee), 0, _p(plan.rowptr), _p(plan.src), N,
                   heads, Ch, float(p_drop), int(seed), _p(seed_dev), _p(alpha), _p(out), _stream())
         ctx.save_for_backward(q, k, v, ee, alpha)
         ctx.plan, ctx.heads, ctx.p_drop, ctx.seed, ctx.seed_dev = plan, heads, float(p_drop), int(seed), seed_dev
@@ -526,7 +526,7 @@ class _EdgeAttention(torch.autograd.Function):
         g_ee = torch.empty_like(ee)
         g_kpe = torch.empty_like(ee)
         g_vpe = torch.empty_like(ee)
-        _lib.call("msde_edge_attention_bwd", _p(g), _p(q), _p(k), _p(v), D, _p(None), D, _p(ee), _p(alpha),
+        _lib.call("msde_edge_attention_bwd", _p(g), _p(q), _p(k), _p(v), D, _p(None), D, _p(ee), 0, _p(alpha),
                   _p(plan.rowptr), _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), _p(g_q), _p(g_ee),
                   _p(g_kpe), _p(g_vpe), _stream())
         g_k = segment_sum_rows(g_kpe, plan.rowptr_s, plan.perm_s, N)
@@ -538,22 +538,31 @@ class _EdgeAttentionFused(torch.autograd.Function):
     """TransformerConv with ONE fused projection: qkvs = [q | k | v | skip] as column blocks of a [N, 4D]
     buffer (one GEMM instead of four); out = attention(q, k, v, ee) + skip.  The backward writes g_q and
     g_skip straight into their column blocks of g_qkvs and lets the two by-source segment sums land in
-    the k and v blocks, so the projection needs one dgrad + one wgrad."""
+    the k and v blocks, so the projection needs one dgrad + one wgrad.
+
+    `ee` may itself be a column block of a wider projection shared by several layers (all GAT layers project
+    the SAME edge features): ee_all [E, L*D], this layer's block starting at column `col`.  The layers' backward
+    passes then fill their blocks of ONE gradient buffer (`shared`, a dict owned by the caller); the first to run
+    allocates and returns it, the others return None, and autograd hands the completed buffer to the shared
+    projection's backward."""
 
     @staticmethod
-    def forward(ctx, qkvs, ee, plan, heads, p_drop, seed, seed_dev):
+    def forward(ctx, qkvs, ee, plan, heads, p_drop, seed, seed_dev, col=0, shared=None):
         qkvs, ee = _f32(qkvs), _f32(ee)
         N, D4 = qkvs.shape
         D = D4 // 4
         Ch = D // heads
+        ld_ee = ee.size(1)
         alpha = torch.empty(plan.E, heads, dtype=torch.float32, device=qkvs.device)
         out = torch.empty(N, D, dtype=torch.float32, device=qkvs.device)
         base = qkvs.data_ptr()
         pq, pk, pv, ps = (ctypes.c_void_p(base + 4 * D * j) for j in range(4))
-        _lib.call("msde_edge_attention_fwd", pq, pk, pv, ps, D4, _p(ee), _p(plan.rowptr), _p(plan.src), N, heads, Ch,
-                  float(p_drop), int(seed), _p(seed_dev), _p(alpha), _p(out), _stream())
+        _lib.call("msde_edge_attention_fwd", pq, pk, pv, ps, D4, ctypes.c_void_p(ee.data_ptr() + 4 * col), ld_ee,
+                  _p(plan.rowptr), _p(plan.src), N, heads, Ch, float(p_drop), int(seed), _p(seed_dev), _p(alpha), _p(out),
+                  _stream())
         ctx.save_for_backward(qkvs, ee, alpha)
         ctx.plan, ctx.heads, ctx.p_drop, ctx.seed, ctx.seed_dev = plan, heads, float(p_drop), int(seed), seed_dev
+        ctx.col, ctx.shared = col, shared
         return out
 
     @staticmethod
@@ -563,25 +572,37 @@ class _EdgeAttentionFused(torch.autograd.Function):
         g = _f32(g)
         N, D4 = qkvs.shape
         D = D4 // 4
+        E, ld_ee = ee.shape
         g_qkvs = torch.empty_like(qkvs)
-        g_ee = torch.empty_like(ee)
-        g_kpe = torch.empty_like(ee)
-        g_vpe = torch.empty_like(ee)
+        first = True
+        if ctx.shared is None or ld_ee == D:
+            g_ee = torch.empty_like(ee)
+        else:
+            g_ee = ctx.shared.get("g_ee")
+            first = g_ee is None
+            if first:
+                g_ee = ctx.shared["g_ee"] = torch.empty_like(ee)
+                ctx.shared["left"] = ld_ee // D
+            ctx.shared["left"] -= 1
+            if ctx.shared["left"] == 0:
+                del ctx.shared["g_ee"]          # the buffer now lives in the autograd graph only
+        g_kpe = torch.empty(E, D, dtype=torch.float32, device=g.device)
+        g_vpe = torch.empty(E, D, dtype=torch.float32, device=g.device)
         base, gbase = qkvs.data_ptr(), g_qkvs.data_ptr()
         pq, pk, pv = (ctypes.c_void_p(base + 4 * D * j) for j in range(3))
         gq, gk, gv, gs = (ctypes.c_void_p(gbase + 4 * D * j) for j in range(4))
-        _lib.call("msde_edge_attention_bwd", _p(g), pq, pk, pv, D4, gs, D4, _p(ee), _p(alpha), _p(plan.rowptr),
-                  _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), gq, _p(g_ee), _p(g_kpe), _p(g_vpe),
-                  _stream())
+        _lib.call("msde_edge_attention_bwd", _p(g), pq, pk, pv, D4, gs, D4, ctypes.c_void_p(ee.data_ptr() + 4 * ctx.col),
+                  ld_ee, _p(alpha), _p(plan.rowptr), _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), gq,
+                  ctypes.c_void_p(g_ee.data_ptr() + 4 * ctx.col), _p(g_kpe), _p(g_vpe), _stream())
         st = _stream()
         _lib.call("msde_segment_sum_rows", _p(g_kpe), _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gk, D4, st)
         _lib.call("msde_segment_sum_rows", _p(g_vpe), _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gv, D4, st)
-        return g_qkvs, g_ee, None, None, None, None, None
+        return g_qkvs, (g_ee if first else None), None, None, None, None, None, None, None
 
 
-def edge_attention_fused(qkvs, ee, plan, heads, p_drop=0.0, seed=0, seed_dev=None):
-    """attention(q, k, v, ee) + skip with q, k, v, skip = column blocks of qkvs [N, 4D]."""
-    return _EdgeAttentionFused.apply(qkvs, ee, plan, heads, p_drop, seed, seed_dev)
+def edge_attention_fused(qkvs, ee, plan, heads, p_drop=0.0, seed=0, seed_dev=None, col=0, shared=None):
+    """attention(q, k, v, ee[:, col:col+D]) + skip with q, k, v, skip = column blocks of qkvs [N, 4D]."""
+    return _EdgeAttentionFused.apply(qkvs, ee, plan, heads, p_drop, seed, seed_dev, col, shared)
 
 
 def edge_attention(q, k, v, ee, plan, heads, p_drop=0.0, seed=0, seed_dev=None):
