@@ -32,6 +32,12 @@ class Linear(nn.Linear):
             return hip.linear(x, self.weight, self.bias, offload=not self.shared)
         return F.linear(x, self.weight, self.bias)
 
+    def fork(self, x):
+        """(x, self(x)) for blocks that also feed x to a residual: see hip.linear_fork."""
+        if USE_HIP_LINEAR and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+            return hip.linear_fork(x, self.weight, self.bias, not self.shared)
+        return x, self.forward(x)
+
 
 class BatchNorm1d(nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters / buffers / state_dict keys).  Training mode runs the two-launch
@@ -78,6 +84,12 @@ def linear(x, weight, bias=None):
     if USE_HIP_LINEAR and x.is_cuda:
         return hip.linear(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+def linear_fork(x, weight, bias=None):
+    if USE_HIP_LINEAR and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+        return hip.linear_fork(x, weight, bias)
+    return x, linear(x, weight, bias)
 
 
 class ShiftedSoftplus(nn.Module):

@@ -112,7 +112,9 @@ class SchNet(nn.Module):
             rbf, C = hip.rbf_cutoff(dist, rplan.E_dev, de.offset, de.coeff, self.cutoff)
 
         for blk in self.interactions:
-            x1 = _nn.linear(h, blk.conv.lin1.weight)
+            # h feeds the block and the residual: the fork lets the block's input-gradient GEMM accumulate the
+            # residual's gradient (no separate add in the backward)
+            h_res, x1 = _nn.linear_fork(h, blk.conv.lin1.weight)
             if fusable and grad:
                 agg = hip.cfconv_fused(x1, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias,
                                        dist, rplan, de.offset, de.coeff, self.cutoff)
@@ -124,7 +126,7 @@ class SchNet(nn.Module):
                 agg = hip.cfconv_aggregate(x1, Wf, C, rplan)
             x = blk.conv.lin2(agg)
             x = blk.lin(hip.shifted_softplus(x))
-            h = h + x
+            h = h_res + x
 
         h = self.lin2(hip.shifted_softplus(self.lin1(h)))
         out = hip.segment_reduce(h, pl.mol_ptr, pl.batch_i32, mean=(self.readout == "mean"))

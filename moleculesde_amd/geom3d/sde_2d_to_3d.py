@@ -57,12 +57,12 @@ class TransformerConv(nn.Module):
             W, b = hip.cat_params(Ws), hip.cat_params(bs)     # free views once FlatAdam has laid them out back to back
         else:
             W, b = torch.cat(Ws, dim=0), torch.cat(bs, dim=0)
-        qkvs = _nn.linear(x, W, b)
+        x_res, qkvs = _nn.linear_fork(x, W, b)      # x also feeds the caller's residual
         p = self.dropout if self.training else 0.0
         if ee_all is not None:           # lin_edge of all layers evaluated as one GEMM by the caller
-            return hip.edge_attention_fused(qkvs, ee_all, plan, self.heads, p, seed, seed_dev, col, shared)
+            return x_res, hip.edge_attention_fused(qkvs, ee_all, plan, self.heads, p, seed, seed_dev, col, shared)
         ee = self.lin_edge(edge_attr)
-        return hip.edge_attention_fused(qkvs, ee, plan, self.heads, p, seed, seed_dev)
+        return x_res, hip.edge_attention_fused(qkvs, ee, plan, self.heads, p, seed, seed_dev)
 
 
 class GATLayer(nn.Module):
@@ -76,12 +76,13 @@ class GATLayer(nn.Module):
         self.norm2 = nn.LayerNorm(hidden_dim)
 
     def forward(self, plan, node_attr, edge_attr, seed, seed_dev=None, ee_all=None, col=0, shared=None):
-        x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev, ee_all, col, shared)
+        node_attr, x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev, ee_all, col, shared)
         if x.is_cuda and x.size(-1) % 4 == 0:
             node_attr = hip.res_layernorm(x, node_attr, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             # FFN = Linear -> SiLU -> Dropout -> Linear with the two pointwise stages in one kernel
             p = self.FFN[2].p if self.training else 0.0
-            x = self.FFN[3](hip.silu_dropout(self.FFN[0](node_attr), p, seed ^ 0x46464E, seed_dev))
+            node_attr, f0 = self.FFN[0].fork(node_attr)
+            x = self.FFN[3](hip.silu_dropout(f0, p, seed ^ 0x46464E, seed_dev))
             return hip.res_layernorm(x, node_attr, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         node_attr = node_attr + self.norm1(x)
         x = self.FFN(node_attr)

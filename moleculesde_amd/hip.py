@@ -866,7 +866,7 @@ class _Linear(torch.autograd.Function):
         return y.view(*shape[:-1], N)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_res=None):
         x2, w = ctx.saved_tensors
         M, K = x2.shape
         N = w.size(0)
@@ -877,6 +877,10 @@ class _Linear(torch.autograd.Function):
             if _LINEAR_MODE == "hip":
                 gx = torch.empty(M, K, dtype=torch.float32, device=g2.device)
                 _lib.call("msde_linear_bwd_x", _p(g2), _p(w), M, N, K, _p(gx), st)
+                if g_res is not None:
+                    gx = gx + g_res.reshape(M, K)
+            elif g_res is not None:          # residual gradient folded into the GEMM (beta = 1): no separate add
+                gx = torch.addmm(_f32(g_res.reshape(M, K)), g2, w)
             else:
                 gx = torch.mm(g2, w)
             gx = gx.view(ctx.in_shape)
@@ -904,6 +908,29 @@ class _Linear(torch.autograd.Function):
                     gb = torch.empty(N, dtype=torch.float32, device=g2.device)
                     _lib.call("msde_colsum", _p(g2), M, N, _p(gb), _p(_bn_workspace(M, N, g2.device)), st)
         return gx, gw, gb, None
+
+
+class _LinearFork(torch.autograd.Function):
+    """(x, Linear(x)): the input comes back as a second output for a residual / second consumer, so that in the
+    backward the gradient arriving on that branch is ACCUMULATED BY THE INPUT-GRADIENT GEMM (C = g_res + g W)
+    instead of by a separate element-wise add launched by autograd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, offload=True):
+        y = _Linear.forward(ctx, x, weight, bias, offload)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, g_res, g):
+        if g is None:
+            return g_res, None, None, None
+        gx, gw, gb, _ = _Linear.backward(ctx, g, g_res)
+        return gx, gw, gb, None
+
+
+def linear_fork(x, weight, bias=None, offload=True):
+    """Returns (x_again, F.linear(x, weight, bias)); use x_again for the residual branch."""
+    return _LinearFork.apply(x, weight, bias, offload)
 
 
 def linear(x, weight, bias=None, offload=True):
