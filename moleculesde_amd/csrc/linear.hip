@@ -342,10 +342,10 @@ extern "C" long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K) {
 // Batched form of the slab reduction: the weight-gradient GEMMs of a whole backward pass only write their
 // slabs (msde_linear_bwd_w_partial) and ONE launch sums them all.  rows[r] = {slab address, splits, stride
 // between splits (= entries n), output address} as four int64; prefix[r] = number of 256-entry chunks before
-// row r (prefix[count] = grid size).  Same 16-lane fixed-order summation as reduce_slabs_kernel.
+// row r (prefix[count] = grid size).  Fixed summation order (4 interleaved split lanes, combined in lane order).
 __global__ void __launch_bounds__(256)
 reduce_slabs_multi_kernel(const long long* __restrict__ rows, const int* __restrict__ prefix, int count) {
-  __shared__ float part[RS_LANES][16];
+  __shared__ float4 part[4][64];
   int lo = 0, hi = count;                  // last row with prefix[row] <= blockIdx.x
   while (hi - lo > 1) {
     int mid = (lo + hi) >> 1;
@@ -356,22 +356,45 @@ reduce_slabs_multi_kernel(const long long* __restrict__ rows, const int* __restr
   const int splits = (int)e[1];
   const size_t n = (size_t)e[2];
   float* out = reinterpret_cast<float*>(e[3]);
-  const size_t c0 = (size_t)(blockIdx.x - prefix[lo]) * 256;
-  const int ox = threadIdx.x & 15, ly = threadIdx.x >> 4;
-  for (int it = 0; it < 16; ++it) {
-    size_t i = c0 + it * 16 + ox;
-    float acc = 0.f;
-    if (i < n)
-      for (int z = ly; z < splits; z += RS_LANES) acc += slabs[(size_t)z * n + i];
-    part[ly][ox] = acc;
-    __syncthreads();
-    if (ly == 0 && i < n) {
-      float r = part[0][ox];
-#pragma unroll
-      for (int l = 1; l < RS_LANES; ++l) r += part[l][ox];
-      out[i] = r;
+  // 64 lanes x 4 consecutive outputs (1 KiB of one split row per wave), 4 split lanes: lane ly sums the splits
+  // z = ly, ly+4, ...; the four partials are added in lane order
+  const int ox = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const size_t i = (size_t)(blockIdx.x - prefix[lo]) * 256 + 4 * ox;
+  const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+    if (vec) {
+      int z = ly;
+      for (; z + 12 < splits; z += 16) {       // four independent 16-byte loads in flight
+        float4 a = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i);
+        float4 b = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 4) * n + i);
+        float4 c = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 8) * n + i);
+        float4 d = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 12) * n + i);
+        acc = vadd(vadd(vadd(vadd(acc, a), b), c), d);
+      }
+      for (; z < splits; z += 4) acc = vadd(acc, *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i));
+    } else {
+      for (int z = ly; z < splits; z += 4) {
+        const float* p = slabs + (size_t)z * n + i;
+        acc.x += p[0];
+        if (i + 1 < n) acc.y += p[1];
+        if (i + 2 < n) acc.z += p[2];
+        if (i + 3 < n) acc.w += p[3];
+      }
     }
-    __syncthreads();
+  }
+  part[ly][ox] = acc;
+  __syncthreads();
+  if (ly == 0 && i < n) {
+    float4 r = vadd(vadd(vadd(part[0][ox], part[1][ox]), part[2][ox]), part[3][ox]);
+    if (vec) {
+      *reinterpret_cast<float4*>(out + i) = r;
+    } else {
+      out[i] = r.x;
+      if (i + 1 < n) out[i + 1] = r.y;
+      if (i + 2 < n) out[i + 2] = r.z;
+      if (i + 3 < n) out[i + 3] = r.w;
+    }
   }
 }
 

@@ -660,3 +660,45 @@ def test_ve_perturb_kernel(dev):
     out, sd = hip.ve_perturb(b.positions.to(dev), noise.to(dev), draws.to(dev), pl.batch_i32, B, T, eps, 0.2, 1.0)
     assert_close(sd, std, 1e-6, 1e-7, "std per atom")
     assert_close(out, ref, 1e-6, 1e-6, "perturbed positions")
+
+
+def test_batched_slab_reduction_matches_immediate(dev):
+    """Weight/bias gradients with the slab reductions of several layers batched into one launch
+    (hip.begin/finish_param_grad_batch) are bit-identical to the per-layer reduction... up to the different
+    (but fixed) lane interleave of the two reduction kernels: compared at fp32 tolerance, and exactly against a
+    second batched run (determinism)."""
+    from moleculesde_amd import hip
+    torch.manual_seed(21)
+    shapes = [(3588, 300, 300, True), (35186, 32, 32, True), (3588, 3, 128, True), (35186, 128, 64, False), (300, 7, 5, True)]
+    layers = []
+    for M, N, K, bias in shapes:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev, requires_grad=True)
+        b = torch.randn(N, device=dev, requires_grad=True) if bias else None
+        g = torch.randn(M, N, device=dev)
+        layers.append((x, w, b, g))
+
+    def run(batched):
+        for x, w, b, g in layers:
+            w.grad = None
+            if b is not None:
+                b.grad = None
+        if batched:
+            hip.begin_param_grad_batch()
+        for x, w, b, g in layers:
+            hip.linear(x, w, b).backward(g)
+        if batched:
+            hip.finish_param_grad_batch()
+        torch.cuda.synchronize()
+        return [(w.grad.clone(), None if b is None else b.grad.clone()) for x, w, b, g in layers]
+
+    ref = run(False)
+    got = run(True)
+    again = run(True)
+    for (M, N, K, bias), (gw0, gb0), (gw1, gb1), (gw2, gb2) in zip(shapes, ref, got, again):
+        tol = 2e-6 * math.sqrt(M) * 8
+        assert_close(gw1, gw0.cpu(), 1e-4, tol, f"batched wgrad {M}x{N}x{K}")
+        assert torch.equal(gw1, gw2)
+        if bias:
+            assert_close(gb1, gb0.cpu(), 1e-4, tol, f"batched bias grad {M}x{N}x{K}")
+            assert torch.equal(gb1, gb2)
