@@ -46,7 +46,9 @@ int msde_radius_fill(const float* pos, const int* batch, const int* mol_ptr, int
 /* ------------------------------------------------------------------ generic row ops -------- */
 /* torch_scatter.scatter(reduce=sum) over CSR rows: out[i] = sum_{s in [rowptr[i],rowptr[i+1])}
  * rows[perm ? perm[s] : s]; used for every backward "gather by source/target".  D % 4 == 0 or any. */
-int msde_segment_sum_rows(const float* rows, const int* rowptr, const int* perm, int N, int D,
+int msde_segment_sum_rows(const float* rows, int ldi /* row stride of rows (0 = D): a column block of a
+                                                          wider gradient can be summed without a copy */,
+                          const int* rowptr, const int* perm, int N, int D,
                           float scale_by_inv_count, float* out, int ldo /* row stride of out (0 = D) */,
                           void* stream);
 /* out[e] = A[src[e]] + B[dst[e]] for e < E; rows with src<0 are zero-filled.  A and B have row stride ld
@@ -254,6 +256,9 @@ int msde_silu_dropout_bwd(const float* g, const float* x, long long n, float p, 
 int msde_mul_add_fwd(const float* a, const float* b, const float* c, long long n, float* out, void* stream);
 int msde_mul_add_bwd(const float* g, const float* a, const float* b, long long n, float* ga, float* gb,
                      void* stream);
+/* torch.randperm(n) for the contrastive negatives (examples/util.py:55), n <= 4096 (else MSDE_EUNSUP): out[n]
+ * int32, a uniform shuffle drawn from the counter-based generator (seed [+ seed_dev[0]*FNV], index). */
+int msde_randperm(int n, unsigned long long seed, const unsigned long long* seed_dev, int* out, void* stream);
 /* VE perturbation (SDE_model_2D_to_3D.py:401-412, SDE_sparse.py VESDE.marginal_prob): draws [B/2+1] int64 in
  * [0,T); molecule b uses ts = draws[b] (b < B/2+1) or T - draws[b-(B/2+1)] - 1; t = ts/T*(1-eps)+eps;
  * std_out[i] = sigma_min (sigma_max/sigma_min)^t of atom i's molecule; pos_out = pos + std * noise. */

@@ -20,7 +20,7 @@ SIGNATURES = {
     "msde_radius_count": [P, P, P, I, F, I, P, P],
     "msde_exclusive_scan_i32": [P, P, I, P],
     "msde_radius_fill": [P, P, P, I, F, I, P, P, P, P, I, P],
-    "msde_segment_sum_rows": [P, P, P, I, I, F, P, I, P],
+    "msde_segment_sum_rows": [P, I, P, P, I, I, F, P, I, P],
     "msde_pair_gather_add": [P, P, I, P, P, I, I, P, P],
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
@@ -65,6 +65,7 @@ SIGNATURES = {
     "msde_silu_dropout_bwd": [P, P, LL, F, ULL, P, P, P],
     "msde_mul_add_fwd": [P, P, P, LL, P, P],
     "msde_mul_add_bwd": [P, P, P, LL, P, P, P],
+    "msde_randperm": [I, ULL, P, P, P],
     "msde_ve_perturb": [P, P, P, P, I, I, I, F, F, F, P, P, P],
     "msde_ve_pos_loss_fwd": [P, P, P, F, P, I, I, P, P, P],
     "msde_ve_pos_loss_bwd": [P, P, P, F, P, P, I, I, P, P, P],

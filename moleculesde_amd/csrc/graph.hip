@@ -177,8 +177,8 @@ extern "C" int msde_radius_transpose(const int* batch, const int* mol_ptr, const
 // ------------------------------------------------------------------------------------------------
 template <int V>
 __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const int* __restrict__ rowptr,
-                                        const int* __restrict__ perm, int N, int cols, int tpr, float mean,
-                                        float* __restrict__ out, int ldo_cols) {
+                                        const int* __restrict__ perm, int N, int cols, int ldi_cols, int tpr,
+                                        float mean, float* __restrict__ out, int ldo_cols) {
   using T = typename VecT<V>::type;
   int rpb = blockDim.x / tpr;
   int i = blockIdx.x * rpb + threadIdx.x / tpr;
@@ -193,26 +193,29 @@ __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const in
     T acc = vzero<V>();
     for (int s = s0; s < s1; ++s) {
       int e = perm ? perm[s] : s;
-      acc = vadd(acc, R[(size_t)e * cols + c]);
+      acc = vadd(acc, R[(size_t)e * ldi_cols + c]);
     }
     O[(size_t)i * ldo_cols + c] = vscale(acc, scale);
   }
 }
 
-extern "C" int msde_segment_sum_rows(const float* rows, const int* rowptr, const int* perm, int N, int D,
+extern "C" int msde_segment_sum_rows(const float* rows, int ldi, const int* rowptr, const int* perm, int N, int D,
                                      float scale_by_inv_count, float* out, int ldo, void* stream) {
   if (N < 0 || D <= 0 || !rowptr || !out) return MSDE_EINVAL;
   if (ldo <= 0) ldo = D;
-  if (ldo < D) return MSDE_EINVAL;
+  if (ldi <= 0) ldi = D;
+  if (ldo < D || ldi < D) return MSDE_EINVAL;
   if (N == 0) return 0;
-  if (D % 4 == 0 && ldo % 4 == 0) {
+  const bool vec = D % 4 == 0 && ldo % 4 == 0 && ldi % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (vec) {
     int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
     MSDE_LAUNCH(segment_sum_rows_kernel<4>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
-                       rowptr, perm, N, cols, tpr, scale_by_inv_count, out, ldo / 4);
+                       rowptr, perm, N, cols, ldi / 4, tpr, scale_by_inv_count, out, ldo / 4);
   } else {
     int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
     MSDE_LAUNCH(segment_sum_rows_kernel<1>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
-                       rowptr, perm, N, cols, tpr, scale_by_inv_count, out, ldo);
+                       rowptr, perm, N, cols, ldi, tpr, scale_by_inv_count, out, ldo);
   }
   MSDE_CHECK_LAUNCH();
   return 0;

@@ -167,6 +167,51 @@ extern "C" int msde_ve_perturb(const float* pos, const float* noise, const long 
   return 0;
 }
 
+// Random permutation of 0..n-1 (torch.randperm for the contrastive negatives, examples/util.py:55) for n <= 4096:
+// one workgroup sorts 64-bit keys = 52 random bits (counter-based: seed, device step counter, index) | 12 index
+// bits with a bitonic network in LDS.  Sorting i.i.d. keys is a uniform shuffle; ties (p ~ n^2 / 2^53) fall back
+// to index order.  One launch instead of the library's key generation + multi-pass sort.
+#define RP_MAX 4096
+__global__ void __launch_bounds__(1024)
+randperm_kernel(int n, unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int* __restrict__ out) {
+  __shared__ unsigned long long key[RP_MAX];
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
+  for (int i = threadIdx.x; i < RP_MAX; i += 1024) {
+    unsigned long long k = ~0ull;                        // padding sorts to the end
+    if (i < n) {
+      unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)i + 1ull);
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      z = z ^ (z >> 31);
+      k = (z & ~0xFFFull) | (unsigned long long)i;
+      if (k == ~0ull) k -= 0x1000ull;
+    }
+    key[i] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= RP_MAX; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < RP_MAX / 2; t += 1024) {
+        int lo = 2 * t - (t & (stride - 1));             // partner pairs (lo, lo + stride)
+        int hi = lo + stride;
+        bool up = (lo & size) == 0;
+        unsigned long long a = key[lo], b = key[hi];
+        if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < n; i += 1024) out[i] = (int)(key[i] & 0xFFFull);
+}
+
+extern "C" int msde_randperm(int n, unsigned long long seed, const unsigned long long* seed_dev, int* out, void* stream) {
+  if (n < 0 || !out) return MSDE_EINVAL;
+  if (n > RP_MAX) return MSDE_EUNSUP;
+  if (n == 0) return 0;
+  MSDE_LAUNCH(randperm_kernel, dim3(1), dim3(1024), 0, as_stream(stream), n, seed, seed_dev, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 static inline int pw_blocks(long long n, int per_thread) {
   long long b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
   if (b > 4096 && per_thread == 1) b = 4096;

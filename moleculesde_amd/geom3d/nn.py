@@ -183,6 +183,11 @@ class DeviceNoise:
 
     replay = False     # draws are not tied to a program order: independent branches may run concurrently
 
+    def __init__(self, seed=0x5EED):
+        self.seed = int(seed)
+        self.calls = 0          # host-side draw counter (eager); under hipGraph replay `seed_dev` varies the draws
+        self.seed_dev = None    # device uint64 step counter, set by the trainer
+
     def randn_like(self, x):
         return torch.randn_like(x)
 
@@ -190,6 +195,9 @@ class DeviceNoise:
         return torch.randint(0, high, size=size, device=device)
 
     def randperm(self, n, device):
+        if torch.device(device).type == "cuda" and n <= hip.RANDPERM_MAX:
+            self.calls += 1
+            return hip.randperm(n, device, self.seed + 0x9E3779B1 * self.calls, self.seed_dev)
         return torch.randperm(n, device=device)
 
     def rand(self, n, device):

@@ -116,12 +116,16 @@ def radius_plan(pos, batch_i32, mol_ptr_i32, cutoff, E_cap, max_nbr=32):
 def segment_sum_rows(rows, rowptr, perm, N, mean=False, out=None, ldo=0):
     """out[i] = sum of rows over CSR row i; `out`/`ldo` let the result land in a column block of a wider
     buffer (row stride ldo floats)."""
-    rows = _f32(rows)
+    ldi = 0
+    if rows.dtype == torch.float32 and rows.dim() == 2 and rows.stride(1) == 1 and rows.stride(0) > rows.size(1):
+        ldi = rows.stride(0)            # a column block of a wider tensor (e.g. a slice of a concat's gradient)
+    else:
+        rows = _f32(rows)
     D = rows.size(1)
     if out is None:
         out = torch.empty(N, D, dtype=torch.float32, device=rows.device)
-    _lib.call("msde_segment_sum_rows", _p(rows), _p(rowptr), _p(perm), N, D, 1.0 if mean else 0.0, _p(out), int(ldo),
-              _stream())
+    _lib.call("msde_segment_sum_rows", _p(rows), ldi, _p(rowptr), _p(perm), N, D, 1.0 if mean else 0.0, _p(out),
+              int(ldo), _stream())
     return out
 
 
@@ -420,8 +424,7 @@ class _PairGatherAdd(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        plan = ctx.plan
-        g = _f32(g)
+        plan = ctx.plan                 # g may be a column block of a concat's gradient: summed without a copy
         g_A = segment_sum_rows(g, plan.rowptr_s, plan.perm_s, plan.N) if ctx.needs_input_grad[0] else None
         g_B = segment_sum_rows(g, plan.rowptr, None, plan.N) if ctx.needs_input_grad[1] else None
         return g_A, g_B, None
@@ -595,8 +598,8 @@ class _EdgeAttentionFused(torch.autograd.Function):
                   ld_ee, _p(alpha), _p(plan.rowptr), _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), gq,
                   ctypes.c_void_p(g_ee.data_ptr() + 4 * ctx.col), _p(g_kpe), _p(g_vpe), _stream())
         st = _stream()
-        _lib.call("msde_segment_sum_rows", _p(g_kpe), _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gk, D4, st)
-        _lib.call("msde_segment_sum_rows", _p(g_vpe), _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gv, D4, st)
+        _lib.call("msde_segment_sum_rows", _p(g_kpe), 0, _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gk, D4, st)
+        _lib.call("msde_segment_sum_rows", _p(g_vpe), 0, _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gv, D4, st)
         return g_qkvs, (g_ee if first else None), None, None, None, None, None, None, None
 
 
@@ -1136,6 +1139,16 @@ class _MulAdd(torch.autograd.Function):
 def mul_add(a, b, c):
     """a * b + c for same-shape tensors, one kernel each way."""
     return _MulAdd.apply(a, b, c)
+
+
+RANDPERM_MAX = 4096
+
+
+def randperm(n, device, seed, seed_dev=None):
+    """Uniform random permutation of range(n) as int32 (n <= RANDPERM_MAX), one kernel."""
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    _lib.call("msde_randperm", int(n), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(seed_dev), _p(out), _stream())
+    return out
 
 
 def ve_perturb(pos, noise, draws, batch_i32, B, T, eps, sigma_min, sigma_max):

@@ -316,6 +316,8 @@ class Trainer:
         with_adam = dp.world_size() == 1 and not self.adam_outside_graph
         sd = self.step_counter.view(torch.int64)
         self.models["SDE_2Dto3D_model"].score_network.seed_dev = sd
+        if hasattr(self.noise, "seed_dev"):
+            self.noise.seed_dev = sd        # fresh contrastive negatives on every replay
         self.opt.new_table_slot()       # this graph's own (pinned) gradient chunk table
         from . import hip as _hip
         _hip.new_param_grad_slot(batch.x.device)

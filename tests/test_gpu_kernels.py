@@ -702,3 +702,28 @@ def test_batched_slab_reduction_matches_immediate(dev):
         if bias:
             assert_close(gb1, gb0.cpu(), 1e-4, tol, f"batched bias grad {M}x{N}x{K}")
             assert torch.equal(gb1, gb2)
+
+
+@pytest.mark.parametrize("n", [1, 2, 37, 3588, 4096])
+def test_randperm_kernel(dev, n):
+    """msde_randperm: always a permutation; reproducible for a (seed, counter); a new seed or counter value gives
+    another permutation; no position bias (mean image of every quarter of the range stays near the centre)."""
+    from moleculesde_amd import hip
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    p1 = hip.randperm(n, dev, 123, ctr)
+    assert p1.dtype == torch.int32
+    assert torch.equal(torch.sort(p1.long())[0].cpu(), torch.arange(n))
+    assert torch.equal(p1, hip.randperm(n, dev, 123, ctr))
+    if n >= 37:
+        assert not torch.equal(p1, hip.randperm(n, dev, 124, ctr))
+        ctr.add_(1)
+        assert not torch.equal(p1, hip.randperm(n, dev, 123, ctr))
+    if n >= 3588:
+        acc = torch.zeros(4, dtype=torch.float64)
+        reps = 64
+        for r in range(reps):
+            p = hip.randperm(n, dev, 1000 + r, None).double().cpu()
+            acc += p.view(4, -1).mean(1) if n % 4 == 0 else torch.stack([c.mean() for c in p.chunk(4)])
+        acc /= reps
+        sigma = n / math.sqrt(12.0) / math.sqrt(reps * (n // 4))
+        assert bool(((acc - (n - 1) / 2).abs() < 6 * sigma).all()), acc
