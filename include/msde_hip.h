@@ -235,6 +235,13 @@ int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void
  * splits), output address} as four int64; prefix[r] = 256-entry chunks before row r, prefix[count] =
  * total_chunks.  Fixed summation order (16 interleaved lanes over the splits), like msde_linear_bwd_w. */
 int msde_linear_bwd_w_splits(int M, int N, int K);
+/* Grouped form: the split-M GEMMs of many layers in ONE launch (same tile code, bit-identical slabs).
+ * msde_linear_bwd_w_describe fills one HOST row (12 int64) of the problem table for a layer and returns the
+ * number of workgroups it needs; prefix[p] = workgroups before problem p, prefix[count] = total_blocks. */
+int msde_linear_bwd_w_describe(const float* gY, const float* X, int M, int N, int K, int want_bias,
+                               float* slabs, long long* host_row);
+int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
+                              void* stream);
 int msde_linear_bwd_w_partial(const float* gY, const float* X, int M, int N, int K, int want_bias,
                               float* slabs, void* stream);
 int msde_reduce_slabs_multi(const long long* rows, const int* prefix, int count, int total_chunks,

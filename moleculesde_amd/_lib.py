@@ -47,6 +47,8 @@ SIGNATURES = {
     "msde_linear_bwd_x": [P, P, I, I, I, P, P],
     "msde_linear_bwd_w_workspace_bytes": [I, I, I],
     "msde_linear_bwd_w_splits": [I, I, I],
+    "msde_linear_bwd_w_describe": [P, P, I, I, I, I, P, P],
+    "msde_linear_bwd_w_grouped": [P, P, I, I, P],
     "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],

@@ -20,10 +20,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LG_BK 32
 
 template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>
-__global__ void __launch_bounds__(256)
-gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
-                     float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
-                     int ldc, int k_per_split) {
+__device__ __forceinline__ void
+gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                   float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
+                   int ldc, int k_per_split, const int bid_x, const int bid_y, const int bid_z) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   // k-major LDS images.  An operand that is k-major in memory is copied with aligned 16-B stores (row
   // stride BM+4); one that is row-major is transposed on the way in with scalar stores, for which the
@@ -36,8 +36,8 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 31, lhalf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kb = blockIdx.z * k_per_split;
+  const int m0 = bid_y * BM, n0 = bid_x * BN;
+  const int kb = bid_z * k_per_split;
   const int ke = min(K, kb + k_per_split);
 
   // staging registers: each thread moves (BM*BK/4)/256 = 2*TM float4 of A and 2*TN of B per tile
@@ -148,7 +148,7 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (colsum_ws != nullptr && blockIdx.x == 0 && tid < BM) {
+    if (colsum_ws != nullptr && bid_x == 0 && tid < BM) {
 #pragma unroll 8
       for (int kr = 0; kr < LG_BK; ++kr) csum += As[kr * LDA_S + tid];
     }
@@ -185,7 +185,7 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
   }
 
   // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  float* Cz = C + (size_t)blockIdx.z * (size_t)M * ldc;  // split slabs (blockIdx.z == 0 when unsplit)
+  float* Cz = C + (size_t)bid_z * (size_t)M * ldc;  // split slabs (bid_z == 0 when unsplit)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -198,8 +198,43 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
         if (gm < M && gn < N) Cz[(size_t)gm * ldc + gn] = acc[i][j][r] + bv;
       }
     }
-  if (colsum_ws != nullptr && blockIdx.x == 0 && tid < BM && m0 + tid < M)
-    colsum_ws[(size_t)blockIdx.z * M + m0 + tid] = csum;
+  if (colsum_ws != nullptr && bid_x == 0 && tid < BM && m0 + tid < M)
+    colsum_ws[(size_t)bid_z * M + m0 + tid] = csum;
+}
+
+template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                     float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
+                     int ldc, int k_per_split) {
+  gemm_f32_mfma_body<TM, TN, A_KM, B_KM, VEC>(A, B, bias, C, colsum_ws, M, N, K, lda, ldb, ldc, k_per_split, blockIdx.x,
+                                              blockIdx.y, blockIdx.z);
+}
+
+// Grouped weight gradients: ONE launch runs the split-M GEMMs of many layers.  probs[p] = 12 int64:
+// {gY, X, slabs, colsum partials (0: no bias), M, N, K, splits, k_per_split, tiles_x, tiles_y, vec};
+// prefix[p] = workgroups before problem p.  A workgroup finds its problem by binary search and then runs the very
+// same tile body as the per-layer kernel (64 x 64 tiles), so results are bit-identical to it.
+__global__ void __launch_bounds__(256)
+gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count) {
+  int lo = 0, hi = count;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const long long* e = probs + (size_t)lo * 12;
+  const float* gY = reinterpret_cast<const float*>(e[0]);
+  const float* X = reinterpret_cast<const float*>(e[1]);
+  float* slabs = reinterpret_cast<float*>(e[2]);
+  float* cs = reinterpret_cast<float*>(e[3]);
+  const int M = (int)e[4], N = (int)e[5], K = (int)e[6], kps = (int)e[8], tx = (int)e[9], ty = (int)e[10];
+  const int local = (int)blockIdx.x - prefix[lo];
+  const int bx = local % tx, by = (local / tx) % ty, bz = local / (tx * ty);
+  // product C[N][K] = gY^T X: "M" of the product = N, "N" = K, reduction = M (see msde_linear_bwd_w)
+  if (e[11])
+    gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, kps, bx, by, bz);
+  else
+    gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, kps, bx, by, bz);
 }
 
 // out[i] = sum_z slabs[z][i] for the weight slabs (n entries) and, in the same launch, the bias-gradient
@@ -403,6 +438,33 @@ extern "C" int msde_reduce_slabs_multi(const long long* rows, const int* prefix,
   if (count < 0 || total_chunks < 0 || (count > 0 && (!rows || !prefix))) return MSDE_EINVAL;
   if (count == 0 || total_chunks == 0) return 0;
   MSDE_LAUNCH(reduce_slabs_multi_kernel, dim3(total_chunks), dim3(256), 0, as_stream(stream), rows, prefix, count);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Fills one row of the grouped-GEMM problem table (host memory, 12 int64) and returns the number of workgroups
+// the problem needs (<= 0: error).  want_bias: the bias partials follow the weight slabs in `slabs`.
+extern "C" int msde_linear_bwd_w_describe(const float* gY, const float* X, int M, int N, int K, int want_bias,
+                                          float* slabs, long long* row) {
+  if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs || !row) return MSDE_EINVAL;
+  if (wgrad_big(M, N, K)) return MSDE_EUNSUP;        // the grouped kernel is built for 64 x 64 tiles
+  int splits, kps;
+  wgrad_split(M, N, K, &splits, &kps);
+  int tx = (K + 63) / 64, ty = (N + 63) / 64;
+  bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (kps % 4 == 0);
+  row[0] = reinterpret_cast<long long>(gY);
+  row[1] = reinterpret_cast<long long>(X);
+  row[2] = reinterpret_cast<long long>(slabs);
+  row[3] = want_bias ? reinterpret_cast<long long>(slabs + (size_t)splits * N * K) : 0;
+  row[4] = M; row[5] = N; row[6] = K; row[7] = splits; row[8] = kps; row[9] = tx; row[10] = ty; row[11] = vec ? 1 : 0;
+  return tx * ty * splits;
+}
+
+extern "C" int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
+                                         void* stream) {
+  if (count < 0 || total_blocks < 0 || (count > 0 && (!probs || !prefix))) return MSDE_EINVAL;
+  if (count == 0 || total_blocks == 0) return 0;
+  MSDE_LAUNCH(gemm_grouped_wgrad_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), probs, prefix, count);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -758,7 +758,8 @@ class _SlabBatch:
         self.active = False
         self.arena = None
         self.used = 0
-        self.rows = []           # (slab address, splits, n, out tensor)
+        self.rows = []           # (slab address, splits, n, out address, device)
+        self.gemms = []          # queued weight-gradient GEMMs: (gY, X, M, N, K, has_bias, slab) -- inputs kept alive
         self.retired = []        # outgrown arenas still referenced by queued rows
         self.slot = None
         self.slots = []
@@ -768,7 +769,11 @@ class _SlabBatch:
         memcpy node that re-reads its host image at every replay)."""
         host_rows = torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64).pin_memory()
         host_pre = torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32).pin_memory()
+        host_prob = torch.zeros(self.MAX_ROWS, 12, dtype=torch.int64).pin_memory()
+        host_ppre = torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32).pin_memory()
         self.slot = (host_rows, host_pre, torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64, device=device),
+                     torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device),
+                     host_prob, host_ppre, torch.zeros(self.MAX_ROWS, 12, dtype=torch.int64, device=device),
                      torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device))
         self.slots.append(self.slot)
 
@@ -795,6 +800,9 @@ class _SlabBatch:
         # not yet reduced buffer.  The leaf's .grad keeps the memory alive until the optimiser has used it.
         self.rows.append((slab_ptr, splits, n, out.data_ptr(), out.device))
 
+    def queue_gemm(self, gY, X, M, N, K, has_bias, slab):
+        self.gemms.append((gY, X, M, N, K, has_bias, slab))
+
     def finish(self):
         self.active = False
         rows = self.rows
@@ -804,7 +812,23 @@ class _SlabBatch:
         dev = rows[0][4]
         if self.slot is None or self.slot[2].device != dev:
             self.new_slot(dev)
-        host_rows, host_pre, dev_rows, dev_pre = self.slot
+        host_rows, host_pre, dev_rows, dev_pre, host_prob, host_ppre, dev_prob, dev_ppre = self.slot
+        if self.gemms:           # all queued weight-gradient GEMMs as one grouped launch
+            lib = _lib.load()
+            hp2 = host_ppre.numpy()
+            total_b = 0
+            for r, (gY, X, M, N, K, hb, slab) in enumerate(self.gemms):
+                nb = lib.msde_linear_bwd_w_describe(_p(gY), _p(X), M, N, K, hb, _p(slab),
+                                                    ctypes.c_void_p(host_prob[r].data_ptr()))
+                if nb <= 0:
+                    raise _lib.MsdeHipError(f"msde_linear_bwd_w_describe failed ({nb}) for {M}x{N}x{K}")
+                hp2[r] = total_b
+                total_b += nb
+            hp2[len(self.gemms)] = total_b
+            dev_prob.copy_(host_prob, non_blocking=True)
+            dev_ppre.copy_(host_ppre, non_blocking=True)
+            _lib.call("msde_linear_bwd_w_grouped", _p(dev_prob), _p(dev_ppre), len(self.gemms), total_b, _stream())
+            self.gemms = []
         hr, hp = host_rows.numpy(), host_pre.numpy()
         total = 0
         for r, (ptr, splits, n, out_ptr, _) in enumerate(rows):
@@ -819,6 +843,7 @@ class _SlabBatch:
         self.retired = []
 
 
+GROUPED_WGRAD = _os.environ.get("MSDE_GROUPED_WGRAD", "1") != "0"   # queued GEMMs -> one grouped launch at finish()
 _SLABS = _SlabBatch()
 _SPLITS = {}
 
@@ -897,7 +922,10 @@ class _Linear(torch.autograd.Function):
                     if splits is None:
                         splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
                     slab = _SLABS.alloc(splits * (N * K + (N if ctx.has_bias else 0)), g2.device)
-                    _lib.call("msde_linear_bwd_w_partial", _p(g2), _p(x2), M, N, K, int(ctx.has_bias), _p(slab), st)
+                    if GROUPED_WGRAD:
+                        _SLABS.queue_gemm(g2, x2, M, N, K, int(ctx.has_bias), slab)
+                    else:
+                        _lib.call("msde_linear_bwd_w_partial", _p(g2), _p(x2), M, N, K, int(ctx.has_bias), _p(slab), st)
                     _SLABS.add(slab.data_ptr(), splits, N * K, gw)
                     if ctx.has_bias:
                         _SLABS.add(slab.data_ptr() + 4 * splits * N * K, splits, N, gb)
