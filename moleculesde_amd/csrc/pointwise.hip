@@ -168,46 +168,40 @@ extern "C" int msde_ve_perturb(const float* pos, const float* noise, const long 
 }
 
 // Random permutation of 0..n-1 (torch.randperm for the contrastive negatives, examples/util.py:55) for n <= 4096:
-// one workgroup sorts 64-bit keys = 52 random bits (counter-based: seed, device step counter, index) | 12 index
-// bits with a bitonic network in LDS.  Sorting i.i.d. keys is a uniform shuffle; ties (p ~ n^2 / 2^53) fall back
-// to index order.  One launch instead of the library's key generation + multi-pass sort.
+// out[i] = rank of key_i among n i.i.d. 64-bit keys (52 counter-based random bits: seed, device step counter,
+// index | 12 index bits, so keys are distinct).  The ranks of i.i.d. keys are a uniform random permutation.
+// Every workgroup keeps all keys in LDS and ranks 256 of them by counting (broadcast LDS reads): n^2 compares
+// spread over n/256 workgroups -- one short launch instead of key generation + a multi-pass sort.
 #define RP_MAX 4096
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(256)
 randperm_kernel(int n, unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int* __restrict__ out) {
   __shared__ unsigned long long key[RP_MAX];
   if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
-  for (int i = threadIdx.x; i < RP_MAX; i += 1024) {
-    unsigned long long k = ~0ull;                        // padding sorts to the end
-    if (i < n) {
-      unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)i + 1ull);
-      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-      z = z ^ (z >> 31);
-      k = (z & ~0xFFFull) | (unsigned long long)i;
-      if (k == ~0ull) k -= 0x1000ull;
-    }
-    key[i] = k;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)i + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    key[i] = (z & ~0xFFFull) | (unsigned long long)i;
   }
   __syncthreads();
-  for (int size = 2; size <= RP_MAX; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = threadIdx.x; t < RP_MAX / 2; t += 1024) {
-        int lo = 2 * t - (t & (stride - 1));             // partner pairs (lo, lo + stride)
-        int hi = lo + stride;
-        bool up = (lo & size) == 0;
-        unsigned long long a = key[lo], b = key[hi];
-        if ((a > b) == up) { key[lo] = b; key[hi] = a; }
-      }
-      __syncthreads();
-    }
-  for (int i = threadIdx.x; i < n; i += 1024) out[i] = (int)(key[i] & 0xFFFull);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long mine = key[i];
+  int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  int j = 0;
+  for (; j + 3 < n; j += 4) {
+    r0 += key[j] < mine; r1 += key[j + 1] < mine; r2 += key[j + 2] < mine; r3 += key[j + 3] < mine;
+  }
+  for (; j < n; ++j) r0 += key[j] < mine;
+  out[i] = (r0 + r1) + (r2 + r3);
 }
 
 extern "C" int msde_randperm(int n, unsigned long long seed, const unsigned long long* seed_dev, int* out, void* stream) {
   if (n < 0 || !out) return MSDE_EINVAL;
   if (n > RP_MAX) return MSDE_EUNSUP;
   if (n == 0) return 0;
-  MSDE_LAUNCH(randperm_kernel, dim3(1), dim3(1024), 0, as_stream(stream), n, seed, seed_dev, out);
+  MSDE_LAUNCH(randperm_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), n, seed, seed_dev, out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -751,6 +751,28 @@ def set_linear_mode(mode):
 # end.  Until then the returned gradient tensors are allocated but not yet filled, which is safe exactly when
 # nothing but autograd's leaf bookkeeping touches them: parameters used once per forward (`offload`) that are
 # leaves or concatenation views of leaves.  Everything else keeps the immediate two-kernel path.
+# Pointer tables (slab rows, grouped-GEMM problems, Adam chunks) are built on the host and uploaded.  Under hipGraph
+# capture the addresses in them are static, so re-uploading them at every replay (a memcpy node each) is wasted
+# work at the tail of the step: while capturing, uploads are only RECORDED here and the trainer performs them once
+# after the capture (`flush_table_uploads`); the captured kernels just read the device tables.
+_PENDING_UPLOADS = []
+
+
+def upload_table(dev, host):
+    if torch.cuda.is_current_stream_capturing():
+        _PENDING_UPLOADS.append((dev, host))
+    else:
+        dev.copy_(host, non_blocking=True)
+
+
+def flush_table_uploads():
+    """After a capture ends: upload the tables its kernels read (their host images stay untouched afterwards)."""
+    for dev, host in _PENDING_UPLOADS:
+        dev.copy_(host, non_blocking=True)
+    _PENDING_UPLOADS.clear()
+    torch.cuda.synchronize()
+
+
 class _SlabBatch:
     MAX_ROWS = 4096
 
@@ -825,8 +847,9 @@ class _SlabBatch:
                 hp2[r] = total_b
                 total_b += nb
             hp2[len(self.gemms)] = total_b
-            dev_prob.copy_(host_prob, non_blocking=True)
-            dev_ppre.copy_(host_ppre, non_blocking=True)
+            ng = len(self.gemms)
+            upload_table(dev_prob[:ng], host_prob[:ng])
+            upload_table(dev_ppre[:ng + 1], host_ppre[:ng + 1])
             _lib.call("msde_linear_bwd_w_grouped", _p(dev_prob), _p(dev_ppre), len(self.gemms), total_b, _stream())
             self.gemms = []
         hr, hp = host_rows.numpy(), host_pre.numpy()
@@ -836,8 +859,8 @@ class _SlabBatch:
             hp[r] = total
             total += (n + 255) // 256
         hp[len(rows)] = total
-        dev_rows.copy_(host_rows, non_blocking=True)
-        dev_pre.copy_(host_pre, non_blocking=True)
+        upload_table(dev_rows[:len(rows)], host_rows[:len(rows)])
+        upload_table(dev_pre[:len(rows) + 1], host_pre[:len(rows) + 1])
         _lib.call("msde_reduce_slabs_multi", _p(dev_rows), _p(dev_pre), len(rows), total, _stream())
         self.rows = []
         self.retired = []

@@ -103,7 +103,7 @@ class FlatAdam:
             else:
                 col[r:r + nc] = g.data_ptr() + self._chunk_bytes[:nc]
             r += nc
-        dev.copy_(host, non_blocking=True)
+        hip.upload_table(dev, host)        # recorded (not captured) while a hipGraph is being captured
         return dev, self.n_chunks
 
     def gather_grads(self):

@@ -329,6 +329,7 @@ class Trainer:
         # while this thread captures; they must not invalidate the capture
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             loss = self._graph_body(batch, with_adam)
+        _hip.flush_table_uploads()      # the graph's pointer tables: uploaded once, not at every replay
         self.opt.use_eager_slot()
         _hip.use_eager_param_grad_slot()
         self._graphs[key] = g
