@@ -94,6 +94,9 @@ int msde_gin_aggregate_bwd_x(const float* g, const float* x, const float* tab, c
  * tables are summed in a fixed order (deterministic, no atomics).  2*R*D*4 bytes must fit LDS (<= 64 KiB).
  * workspace: msde_gin_aggregate_bwd_tab_workspace_floats(N, E, D, R) floats. */
 long long msde_gin_aggregate_bwd_tab_workspace_floats(int N, int E, int D, int R);
+/* With g_tab == g_eps == NULL the call only leaves msde_gin_aggregate_bwd_tab_slabs(N,E) partial tables
+ * [slabs][R*D] followed by [slabs] eps partials in `workspace` (for msde_reduce_slabs_multi). */
+int msde_gin_aggregate_bwd_tab_slabs(int N, int E);
 int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab, const int* codes,
                                const int* src, const int* dst, int N, int E, int D, int R,
                                float* g_tab, float* g_eps, float* workspace, void* stream);
@@ -135,6 +138,9 @@ int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, const float* di
                             const float* b1, const float* W2, const float* offset, int N, int F,
                             int G, int E_cap, float coeff, float cutoff, float* gW1, float* gb1,
                             float* gW2, float* gb2, float* workspace, void* stream);
+/* With gW1 == gb1 == gW2 == gb2 == NULL the call only leaves msde_cfconv_fused_bwd_w_slabs(E_cap) slabs of
+ * F*F + F*G + 2F floats ([gW2 | gW1 | gb1 | gb2]) in `workspace` (for msde_reduce_slabs_multi). */
+int msde_cfconv_fused_bwd_w_slabs(int E_cap);
 
 /* ------------------------------------------------------------------ 2D->3D score net ------- */
 /* coord2basis / get_perturb_distance / GaussianFourierProjection / pseudo-angle —

@@ -241,6 +241,12 @@ static inline void cb_geometry(int E_cap, int* nwg, int* cpw) {
   if (*nwg < 1) *nwg = 1;
 }
 
+extern "C" int msde_cfconv_fused_bwd_w_slabs(int E_cap) {
+  int nwg, cpw;
+  cb_geometry(E_cap, &nwg, &cpw);
+  return nwg;
+}
+
 extern "C" long long msde_cfconv_fused_bwd_w_workspace_floats(int E_cap, int G) {
   int nwg, cpw;
   cb_geometry(E_cap, &nwg, &cpw);
@@ -252,8 +258,10 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
                                        const float* W2, const float* offset, int N, int F, int G, int E_cap,
                                        float coeff, float cutoff, float* gW1, float* gb1, float* gW2, float* gb2,
                                        float* workspace, void* stream) {
-  if (N < 0 || E_cap < 0 || !g_agg || !x1 || !dist || !rowptr || !src || !dst || !W1 || !b1 || !W2 || !offset || !gW1 ||
-      !gb1 || !gW2 || !gb2 || !workspace)
+  // gW1 == gb1 == gW2 == gb2 == NULL: leave the per-workgroup slabs in `workspace` for a batched reduction
+  const bool no_reduce = !gW1 && !gb1 && !gW2 && !gb2;
+  if (N < 0 || E_cap < 0 || !g_agg || !x1 || !dist || !rowptr || !src || !dst || !W1 || !b1 || !W2 || !offset ||
+      !workspace || (!no_reduce && (!gW1 || !gb1 || !gW2 || !gb2)))
     return MSDE_EINVAL;
   if (F != CB_F || G <= 0 || G > 64) return MSDE_EUNSUP;
   hipStream_t st = as_stream(stream);
@@ -280,6 +288,7 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   else { CB_LAUNCH(32); }
 #undef CB_LAUNCH
   MSDE_CHECK_LAUNCH();
+  if (no_reduce) return 0;
   size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
   // outputs laid out like a slab ([gW2 | gW1 | gb1 | gb2] in one buffer): generic 16-lane parallel reduction
   if (gW1 == gW2 + (size_t)CB_F * CB_F && gb1 == gW1 + (size_t)CB_F * G && gb2 == gb1 + CB_F)

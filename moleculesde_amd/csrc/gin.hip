@@ -149,6 +149,8 @@ extern "C" int msde_gin_aggregate_bwd_x(const float* g, const float* x, const fl
   return 0;
 }
 
+extern "C" int msde_gin_aggregate_bwd_tab_slabs(int N, int E) { return gt_blocks(N, E); }
+
 extern "C" long long msde_gin_aggregate_bwd_tab_workspace_floats(int N, int E, int D, int R) {
   return (long long)gt_blocks(N, E) * ((long long)R * D + 1);
 }
@@ -156,7 +158,10 @@ extern "C" long long msde_gin_aggregate_bwd_tab_workspace_floats(int N, int E, i
 extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab, const int* codes,
                                           const int* src, const int* dst, int N, int E, int D, int R, float* g_tab,
                                           float* g_eps, float* workspace, void* stream) {
-  if (N < 0 || E < 0 || D <= 0 || R <= 0 || !g || !x || !tab || !g_tab || !g_eps || !workspace) return MSDE_EINVAL;
+  // g_tab == g_eps == NULL: leave the per-workgroup partial tables in `workspace` for a batched reduction
+  const bool no_reduce = !g_tab && !g_eps;
+  if (N < 0 || E < 0 || D <= 0 || R <= 0 || !g || !x || !tab || !workspace || (!no_reduce && (!g_tab || !g_eps)))
+    return MSDE_EINVAL;
   if (E > 0 && (!codes || !src || !dst)) return MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
   int threads = ((D + 63) / 64) * 64;
@@ -170,5 +175,6 @@ extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const 
   MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3(nb), dim3(threads), lds, st, g, x, tab, codes, src, dst, N, E, D, R, npb,
               slabs, eps_part);
   MSDE_CHECK_LAUNCH();
+  if (no_reduce) return 0;
   return msde_reduce_slabs(slabs, nb, (size_t)R * D, g_tab, eps_part, 1, g_eps, st);
 }

@@ -213,10 +213,18 @@ class _CFConvFused(torch.autograd.Function):
         gW1 = gall[Fd * Fd:Fd * Fd + Fd * G].view(Fd, G)
         gb1 = gall[Fd * Fd + Fd * G:Fd * Fd + Fd * G + Fd]
         gb2 = gall[Fd * Fd + Fd * G + Fd:]
-        ws = _cf_workspace(plan.E, G, x1.device)
-        _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
-                  _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, _p(gW1), _p(gb1),
-                  _p(gW2), _p(gb2), _p(ws), st)
+        if _SLABS.active:            # slabs into the arena, summed by the batched reduction of the backward pass
+            nslab = int(_lib.load().msde_cfconv_fused_bwd_w_slabs(plan.E))
+            ws = _SLABS.alloc(nslab * gall.numel(), g.device)
+            _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
+                      _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, _p(None), _p(None),
+                      _p(None), _p(None), _p(ws), st)
+            _SLABS.add(ws.data_ptr(), nslab, gall.numel(), gall)
+        else:
+            ws = _cf_workspace(plan.E, G, x1.device)
+            _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
+                      _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, _p(gW1), _p(gb1),
+                      _p(gW2), _p(gb2), _p(ws), st)
         return g_x1, gW1, gb1, gW2, gb2, None, None, None, None, None
 
 
@@ -296,9 +304,18 @@ class _GinAggregate(torch.autograd.Function):
                   _p(plan.perm_s), _p(plan.dst), N, D, _p(g_x), st)
         g_tab = torch.empty_like(tab)
         g_eps = torch.empty(1, dtype=torch.float32, device=x.device)
-        ws = _scratch(int(_lib.load().msde_gin_aggregate_bwd_tab_workspace_floats(N, plan.E, D, R)), x.device)
-        _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N, plan.E,
-                  D, R, _p(g_tab), _p(g_eps), _p(ws), st)
+        nfl = int(_lib.load().msde_gin_aggregate_bwd_tab_workspace_floats(N, plan.E, D, R))
+        if _SLABS.active:            # partial tables into the arena, summed by the batched reduction
+            nslab = int(_lib.load().msde_gin_aggregate_bwd_tab_slabs(N, plan.E))
+            ws = _SLABS.alloc(nfl, x.device)
+            _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N,
+                      plan.E, D, R, _p(None), _p(None), _p(ws), st)
+            _SLABS.add(ws.data_ptr(), nslab, R * D, g_tab)
+            _SLABS.add(ws.data_ptr() + 4 * nslab * R * D, nslab, 1, g_eps)
+        else:
+            ws = _scratch(nfl, x.device)
+            _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N,
+                      plan.E, D, R, _p(g_tab), _p(g_eps), _p(ws), st)
         return g_x, g_tab, g_eps, None, None
 
 
