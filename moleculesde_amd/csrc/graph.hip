@@ -296,10 +296,25 @@ __global__ void embedding_sum_fwd_kernel(const float* __restrict__ tab, const in
   const T* Tb = reinterpret_cast<const T*>(tab);
   T* O = reinterpret_cast<T*>(out) + (size_t)i * cols;
   for (int c = lane; c < cols; c += tpr) {
-    // same left-to-right order as the reference's  x_embedding += emb_k(x[:,k])  (starts from 0)
-    T acc = Tb[(size_t)codes[(size_t)i * K] * cols + c];
-    for (int k = 1; k < K; ++k) acc = vadd(acc, Tb[(size_t)codes[(size_t)i * K + k] * cols + c]);
-    O[c] = acc;
+    // same left-to-right order as the reference's  x_embedding += emb_k(x[:,k])  (starts from 0); codes first,
+    // then all table rows in flight (no code -> row chain per feature)
+    if (K <= 16) {
+      int cd[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) cd[k] = k < K ? codes[(size_t)i * K + k] : 0;
+      T v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = k < K ? Tb[(size_t)cd[k] * cols + c] : vzero<V>();
+      T acc = v[0];
+#pragma unroll
+      for (int k = 1; k < 16; ++k)
+        if (k < K) acc = vadd(acc, v[k]);
+      O[c] = acc;
+    } else {
+      T acc = Tb[(size_t)codes[(size_t)i * K] * cols + c];
+      for (int k = 1; k < K; ++k) acc = vadd(acc, Tb[(size_t)codes[(size_t)i * K + k] * cols + c]);
+      O[c] = acc;
+    }
   }
 }
 
@@ -347,14 +362,22 @@ embedding_sum_bwd_partial_kernel(const float* __restrict__ g, const int* __restr
   const int c = (blockIdx.z * 64 + lx) * V;
   T acc = vzero<V>(), acc2 = vzero<V>();
   if (c < D) {
-    int p = a + ly;
-    for (; p + 12 < b; p += 16) {
-      int n0 = list_nodes[p], n1 = list_nodes[p + 4], n2 = list_nodes[p + 8], n3 = list_nodes[p + 12];
-      T v0 = *reinterpret_cast<const T*>(g + (size_t)n0 * D + c), v1 = *reinterpret_cast<const T*>(g + (size_t)n1 * D + c);
-      T v2 = *reinterpret_cast<const T*>(g + (size_t)n2 * D + c), v3 = *reinterpret_cast<const T*>(g + (size_t)n3 * D + c);
-      acc = vadd(acc, v0); acc2 = vadd(acc2, v1); acc = vadd(acc, v2); acc2 = vadd(acc2, v3);
+    // 16 items per pass and item lane: all node ids first, then all 16 row loads in flight (a dependent
+    // id -> row chain per item would make the block latency bound), summed in list order
+    for (int p0 = a + ly; p0 < b; p0 += 64) {
+      int ids[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        int p = p0 + 4 * k;
+        ids[k] = p < b ? list_nodes[p] : -1;
+      }
+      T v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        v[k] = ids[k] >= 0 ? *reinterpret_cast<const T*>(g + (size_t)ids[k] * D + c) : vzero<V>();
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) { acc = vadd(acc, v[k]); acc2 = vadd(acc2, v[k + 1]); }
     }
-    for (; p < b; p += 4) acc = vadd(acc, *reinterpret_cast<const T*>(g + (size_t)list_nodes[p] * D + c));
     acc = vadd(acc, acc2);
   }
   part[ly][lx] = acc;
@@ -374,8 +397,16 @@ embedding_sum_bwd_reduce_kernel(const float* __restrict__ slab, const int* __res
   int len = list_ptr[r + 1] - list_ptr[r];
   float acc = 0.f;
   if (len > 0) {
-    int ns = es_slices(len, split);
-    for (int s = 0; s < ns; ++s) acc += slab[(size_t)s * R * D + i];
+    const int ns = es_slices(len, split);
+    const size_t st = (size_t)R * D;
+    int s = 0;
+    for (; s + 8 <= ns; s += 8) {          // eight slices in flight, added in slice order
+      float v0 = slab[(size_t)s * st + i], v1 = slab[(size_t)(s + 1) * st + i], v2 = slab[(size_t)(s + 2) * st + i];
+      float v3 = slab[(size_t)(s + 3) * st + i], v4 = slab[(size_t)(s + 4) * st + i], v5 = slab[(size_t)(s + 5) * st + i];
+      float v6 = slab[(size_t)(s + 6) * st + i], v7 = slab[(size_t)(s + 7) * st + i];
+      acc = (((((((acc + v0) + v1) + v2) + v3) + v4) + v5) + v6) + v7;
+    }
+    for (; s < ns; ++s) acc += slab[(size_t)s * st + i];
   }
   g_tab[i] = acc;
 }

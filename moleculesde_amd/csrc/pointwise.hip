@@ -170,14 +170,15 @@ extern "C" int msde_ve_perturb(const float* pos, const float* noise, const long 
 // Random permutation of 0..n-1 (torch.randperm for the contrastive negatives, examples/util.py:55) for n <= 4096:
 // out[i] = rank of key_i among n i.i.d. 64-bit keys (52 counter-based random bits: seed, device step counter,
 // index | 12 index bits, so keys are distinct).  The ranks of i.i.d. keys are a uniform random permutation.
-// Every workgroup keeps all keys in LDS and ranks 256 of them by counting (broadcast LDS reads): n^2 compares
-// spread over n/256 workgroups -- one short launch instead of key generation + a multi-pass sort.
+// Every workgroup (one wave) keeps all keys in LDS and ranks 64 of them by counting (broadcast LDS reads): n^2
+// compares spread over n/64 workgroups -- one short launch instead of key generation + a multi-pass sort.
 #define RP_MAX 4096
-__global__ void __launch_bounds__(256)
+#define RP_BLOCK 64     // one wave per workgroup: the counting loop is bound by LDS broadcast reads per wave
+__global__ void __launch_bounds__(RP_BLOCK)
 randperm_kernel(int n, unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int* __restrict__ out) {
   __shared__ unsigned long long key[RP_MAX];
   if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += RP_BLOCK) {
     unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)i + 1ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -185,7 +186,7 @@ randperm_kernel(int n, unsigned long long seed, const unsigned long long* __rest
     key[i] = (z & ~0xFFFull) | (unsigned long long)i;
   }
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * RP_BLOCK + threadIdx.x;
   if (i >= n) return;
   const unsigned long long mine = key[i];
   int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -201,7 +202,8 @@ extern "C" int msde_randperm(int n, unsigned long long seed, const unsigned long
   if (n < 0 || !out) return MSDE_EINVAL;
   if (n > RP_MAX) return MSDE_EUNSUP;
   if (n == 0) return 0;
-  MSDE_LAUNCH(randperm_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), n, seed, seed_dev, out);
+  MSDE_LAUNCH(randperm_kernel, dim3((n + RP_BLOCK - 1) / RP_BLOCK), dim3(RP_BLOCK), 0, as_stream(stream), n, seed, seed_dev,
+              out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

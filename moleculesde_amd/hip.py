@@ -709,7 +709,7 @@ _WS_BYTES = {}    # (M, N, K) -> workspace bytes
 
 
 _SCRATCH = {}     # per-(device, stream) scratch of the table-gradient kernels
-EMB_BWD_SPLIT = 32   # max slices per table row in msde_embedding_sum_bwd
+EMB_BWD_SPLIT = 64   # max slices per table row in msde_embedding_sum_bwd
 
 
 def _scratch(nfloats, device):
@@ -989,7 +989,9 @@ class _LinearFork(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, offload=True):
         y = _Linear.forward(ctx, x, weight, bias, offload)
-        return x.view_as(x), y
+        # an alias of x WITHOUT autograd's view relation to it (a tracked view of an input returned from a custom
+        # Function makes the engine copy its gradient); as an output of this node it is differentiable all the same
+        return x.detach(), y
 
     @staticmethod
     def backward(ctx, g_res, g):
