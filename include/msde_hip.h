@@ -173,7 +173,10 @@ int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, 
                             const float* ee, int ld_ee, const float* alpha, const int* rowptr,
                             const int* src, int N, int H, int Ch, float p_drop,
                             unsigned long long seed, const unsigned long long* seed_dev,
-                            float* g_q, float* g_ee, float* g_kpe, float* g_vpe, void* stream);
+                            float* g_q, float* g_ee, float* g_kpe, float* g_vpe,
+                            int ld_kv /* row stride of g_kpe and g_vpe (0 = D): as the two halves of one
+                                         [E, 2D] buffer they are segment-summed by ONE launch */,
+                            void* stream);
 /* basis mix + EquiLayer mean — equivariant_scorenetwork.py:159-164:
  * out[i] = mean_{e in in(i)} (c0*b_diff + c1*b_cross + c2*b_vert) */
 int msde_frame_mix_mean_fwd(const float* coff, const float* basis, const int* rowptr, int N,

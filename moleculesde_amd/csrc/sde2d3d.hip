@@ -139,7 +139,7 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
                                           float p_drop, unsigned long long seed,
                                           const unsigned long long* __restrict__ seed_dev, float* __restrict__ g_q,
                                           float* __restrict__ g_ee, float* __restrict__ g_kpe,
-                                          float* __restrict__ g_vpe) {
+                                          float* __restrict__ g_vpe, int ld_kv) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= N * H) return;
   if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
@@ -168,7 +168,7 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       ga = fmaf(go[c], vr[c] + er[c], ga);
-      g_vpe[(size_t)e * D + h * CH + c] = go[c] * (a * ms);
+      g_vpe[(size_t)e * ld_kv + h * CH + c] = go[c] * (a * ms);
     }
     dsum = fmaf(a, ga * ms, dsum);
   }
@@ -188,7 +188,7 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
     for (int c = 0; c < CH; ++c) {
       gq[c] = fmaf(gs, kr[c] + er[c], gq[c]);
       float gk = gs * qv[c];
-      g_kpe[(size_t)e * D + h * CH + c] = gk;
+      g_kpe[(size_t)e * ld_kv + h * CH + c] = gk;
       g_ee[(size_t)e * ld_ee + h * CH + c] = gk + go[c] * (a * ms);
     }
   }
@@ -222,19 +222,20 @@ extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const
                                        const float* ee, int ld_ee, const float* alpha, const int* rowptr, const int* src,
                                        int N, int H, int Ch, float p_drop, unsigned long long seed,
                                        const unsigned long long* seed_dev, float* g_q, float* g_ee, float* g_kpe,
-                                       float* g_vpe, void* stream) {
+                                       float* g_vpe, int ld_kv, void* stream) {
   if (N < 0 || H <= 0 || Ch <= 0 || !g_out || !q || !k || !v || !ee || !alpha || !rowptr || !src || !g_q || !g_ee ||
       !g_kpe || !g_vpe)
     return MSDE_EINVAL;
   if (ld_ee == 0) ld_ee = H * Ch;
-  if (p_drop < 0.f || p_drop >= 1.f || ld_ee < H * Ch) return MSDE_EINVAL;
+  if (ld_kv == 0) ld_kv = H * Ch;
+  if (p_drop < 0.f || p_drop >= 1.f || ld_ee < H * Ch || ld_kv < H * Ch) return MSDE_EINVAL;
   if (N == 0) return 0;
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
-    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
-    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe); break;
+    case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe, ld_kv); break;
+    case 2: MSDE_LAUNCH(edge_attention_bwd_kernel<2>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe, ld_kv); break;
+    case 4: MSDE_LAUNCH(edge_attention_bwd_kernel<4>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe, ld_kv); break;
+    case 8: MSDE_LAUNCH(edge_attention_bwd_kernel<8>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe, ld_kv); break;
     default: return MSDE_EUNSUP;
   }
   MSDE_CHECK_LAUNCH();

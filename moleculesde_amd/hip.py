@@ -548,7 +548,7 @@ class _EdgeAttention(torch.autograd.Function):
         g_vpe = torch.empty_like(ee)
         _lib.call("msde_edge_attention_bwd", _p(g), _p(q), _p(k), _p(v), D, _p(None), D, _p(ee), 0, _p(alpha),
                   _p(plan.rowptr), _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), _p(g_q), _p(g_ee),
-                  _p(g_kpe), _p(g_vpe), _stream())
+                  _p(g_kpe), _p(g_vpe), 0, _stream())
         g_k = segment_sum_rows(g_kpe, plan.rowptr_s, plan.perm_s, N)
         g_v = segment_sum_rows(g_vpe, plan.rowptr_s, plan.perm_s, N)
         return g_q, g_k, g_v, g_ee, None, None, None, None, None
@@ -606,17 +606,16 @@ class _EdgeAttentionFused(torch.autograd.Function):
             ctx.shared["left"] -= 1
             if ctx.shared["left"] == 0:
                 del ctx.shared["g_ee"]          # the buffer now lives in the autograd graph only
-        g_kpe = torch.empty(E, D, dtype=torch.float32, device=g.device)
-        g_vpe = torch.empty(E, D, dtype=torch.float32, device=g.device)
+        g_kv = torch.empty(E, 2 * D, dtype=torch.float32, device=g.device)     # [g_kpe | g_vpe] per edge
         base, gbase = qkvs.data_ptr(), g_qkvs.data_ptr()
         pq, pk, pv = (ctypes.c_void_p(base + 4 * D * j) for j in range(3))
         gq, gk, gv, gs = (ctypes.c_void_p(gbase + 4 * D * j) for j in range(4))
         _lib.call("msde_edge_attention_bwd", _p(g), pq, pk, pv, D4, gs, D4, ctypes.c_void_p(ee.data_ptr() + 4 * ctx.col),
                   ld_ee, _p(alpha), _p(plan.rowptr), _p(plan.src), N, H, D // H, ctx.p_drop, ctx.seed, _p(ctx.seed_dev), gq,
-                  ctypes.c_void_p(g_ee.data_ptr() + 4 * ctx.col), _p(g_kpe), _p(g_vpe), _stream())
-        st = _stream()
-        _lib.call("msde_segment_sum_rows", _p(g_kpe), 0, _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gk, D4, st)
-        _lib.call("msde_segment_sum_rows", _p(g_vpe), 0, _p(plan.rowptr_s), _p(plan.perm_s), N, D, 0.0, gv, D4, st)
+                  ctypes.c_void_p(g_ee.data_ptr() + 4 * ctx.col), _p(g_kv), ctypes.c_void_p(g_kv.data_ptr() + 4 * D), 2 * D,
+                  _stream())
+        # one by-source segment sum over the 2D columns lands in the adjacent k | v blocks of g_qkvs
+        _lib.call("msde_segment_sum_rows", _p(g_kv), 0, _p(plan.rowptr_s), _p(plan.perm_s), N, 2 * D, 0.0, gk, D4, _stream())
         return g_qkvs, (g_ee if first else None), None, None, None, None, None, None, None
 
 
