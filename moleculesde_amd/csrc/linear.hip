@@ -352,8 +352,18 @@ static inline bool wgrad_big(int M, int N, int K) {
   if (force == 128) return true;
   return false;   // measured (tools/bench_wgrad.py): 64-wide tiles + ~512 workgroups win on every step shape
 }
+static inline void wgrad_split_for(int M, int N, int K, int target, int* splits, int* k_per_split);
 static inline void wgrad_split(int M, int N, int K, int* splits, int* k_per_split) {
   static int target = env_int("MSDE_WGRAD_WGS", 512);
+  wgrad_split_for(M, N, K, target, splits, k_per_split);
+}
+// the batched paths (msde_linear_bwd_w_partial / _describe + _grouped) share one launch among all layers, so a
+// layer needs far fewer workgroups of its own: fewer, longer splits = less prologue / slab traffic per FLOP
+static inline void wgrad_split_batched(int M, int N, int K, int* splits, int* k_per_split) {
+  static int target = env_int("MSDE_WGRAD_WGS_GROUPED", 64);
+  wgrad_split_for(M, N, K, target, splits, k_per_split);
+}
+static inline void wgrad_split_for(int M, int N, int K, int target, int* splits, int* k_per_split) {
   bool big = wgrad_big(M, N, K);
   int tw_n = (big && N > 64) ? 128 : 64, tw_k = (big && K > 64) ? 128 : 64;
   long tiles = (long)((N + tw_n - 1) / tw_n) * ((K + tw_k - 1) / tw_k);
@@ -449,7 +459,7 @@ extern "C" int msde_linear_bwd_w_describe(const float* gY, const float* X, int M
   if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs || !row) return MSDE_EINVAL;
   if (wgrad_big(M, N, K)) return MSDE_EUNSUP;        // the grouped kernel is built for 64 x 64 tiles
   int splits, kps;
-  wgrad_split(M, N, K, &splits, &kps);
+  wgrad_split_batched(M, N, K, &splits, &kps);
   int tx = (K + 63) / 64, ty = (N + 63) / 64;
   bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (kps % 4 == 0);
   row[0] = reinterpret_cast<long long>(gY);
@@ -471,7 +481,7 @@ extern "C" int msde_linear_bwd_w_grouped(const long long* probs, const int* pref
 
 extern "C" int msde_linear_bwd_w_splits(int M, int N, int K) {
   int splits, kps;
-  wgrad_split(M, N, K, &splits, &kps);
+  wgrad_split_batched(M, N, K, &splits, &kps);
   return splits;
 }
 
@@ -481,7 +491,7 @@ extern "C" int msde_linear_bwd_w_partial(const float* gY, const float* X, int M,
                                          float* slabs, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs) return MSDE_EINVAL;
   int splits, k_per_split;
-  wgrad_split(M, N, K, &splits, &k_per_split);
+  wgrad_split_batched(M, N, K, &splits, &k_per_split);
   float* cs = want_bias ? slabs + (size_t)splits * N * K : nullptr;
   return launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, wgrad_big(M, N, K),
                                  as_stream(stream));
