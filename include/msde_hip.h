@@ -289,6 +289,26 @@ int msde_ve_pos_loss_bwd(const float* scores, const float* noise, const float* s
                          const int* mol_ptr, const int* batch, int N, int B, const float* g_loss,
                          float* g_scores, void* stream);
 
+/* ------------------------------------------------------------------ GAT layer tail --------- */
+/* GATLayer after the attention (equivariant_scorenetwork.py:27-38,142), D = 32:
+ *   y1 = res + LayerNorm1(x); a = Dropout_p(SiLU(W0 y1 + b0)); x2 = W3 a + b3; out = y1 + LayerNorm2(x2)
+ *   [out = SiLU(out) when silu_out].  Saves y1, h0 = W0 y1 + b0 and x2 ([N,D] each) for the backward.
+ * bwd: g_x (to the attention output), g_res (to the layer input), the two (gradient, input) pairs of the
+ * feed-forward weight gradients -- (g_x2, a) for W3/b3 and (g_h0, y1) for W0/b0 -- and per-workgroup partial sums
+ * ln_part [msde_gat_tail_blocks(N)][4D] = [d ln2_g | d ln2_b | d ln1_g | d ln1_b] to be summed over workgroups. */
+int msde_gat_tail_blocks(int N);
+int msde_gat_tail_fwd(const float* x, const float* res, const float* ln1_g, const float* ln1_b,
+                      const float* W0, const float* b0, const float* W3, const float* b3,
+                      const float* ln2_g, const float* ln2_b, int N, int D, float eps1, float eps2,
+                      float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                      int silu_out, float* out, float* y1, float* h0, float* x2, void* stream);
+int msde_gat_tail_bwd(const float* g_out, const float* x, const float* y1, const float* h0,
+                      const float* x2, const float* ln1_g, const float* W0, const float* W3,
+                      const float* ln2_g, const float* ln2_b, int N, int D, float eps1, float eps2,
+                      float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                      int silu_out, float* g_x, float* g_res, float* g_x2, float* a, float* g_h0,
+                      float* ln_part, void* stream);
+
 /* ------------------------------------------------------------------ optimiser -------------- */
 /* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —
  * examples/pretrain_MoleculeSDE.py:331-337,156.  seg_end[S] (exclusive ends), seg_lr[S].

@@ -73,6 +73,9 @@ SIGNATURES = {
     "msde_ve_perturb": [P, P, P, P, I, I, I, F, F, F, P, P, P],
     "msde_ve_pos_loss_fwd": [P, P, P, F, P, I, I, P, P, P],
     "msde_ve_pos_loss_bwd": [P, P, P, F, P, P, I, I, P, P, P],
+    "msde_gat_tail_blocks": [I],
+    "msde_gat_tail_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P],
+    "msde_gat_tail_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P, P, P],
     "msde_chunk_elems": [],
     "msde_gather_chunks": [P, I, P, P],
     "msde_adam_chunks": [P, P, I, P, P, P, P, P, I, F, F, F, F, F, P],

@@ -24,6 +24,7 @@ from . import nn as _nn
 from .sde import VESDE, VPSDE
 
 EPSILON = 1e-6
+FUSE_GAT_TAIL = True     # csrc/gat_tail.hip for hidden size 32 (False: the kernel-per-stage path, used as a cross-check)
 
 
 class GaussianFourierProjection(nn.Module):
@@ -75,18 +76,26 @@ class GATLayer(nn.Module):
         self.norm1 = nn.LayerNorm(hidden_dim)
         self.norm2 = nn.LayerNorm(hidden_dim)
 
-    def forward(self, plan, node_attr, edge_attr, seed, seed_dev=None, ee_all=None, col=0, shared=None):
+    def forward(self, plan, node_attr, edge_attr, seed, seed_dev=None, ee_all=None, col=0, shared=None, silu_out=False):
+        """silu_out: apply the SiLU that follows every convolution but the last of a block
+        (equivariant_scorenetwork.py:142) inside the layer, so it can ride in the fused kernel."""
         node_attr, x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev, ee_all, col, shared)
+        p = self.FFN[2].p if self.training else 0.0
+        if x.is_cuda and x.size(-1) == 32 and FUSE_GAT_TAIL:
+            # LayerNorm + residual, feed-forward, LayerNorm + residual (+ SiLU): one kernel each way
+            return hip.gat_tail(x, node_attr, self.norm1, self.FFN[0], self.FFN[3], self.norm2, p, seed ^ 0x46464E,
+                                seed_dev, silu_out)
         if x.is_cuda and x.size(-1) % 4 == 0:
             node_attr = hip.res_layernorm(x, node_attr, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             # FFN = Linear -> SiLU -> Dropout -> Linear with the two pointwise stages in one kernel
-            p = self.FFN[2].p if self.training else 0.0
             node_attr, f0 = self.FFN[0].fork(node_attr)
             x = self.FFN[3](hip.silu_dropout(f0, p, seed ^ 0x46464E, seed_dev))
-            return hip.res_layernorm(x, node_attr, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            out = hip.res_layernorm(x, node_attr, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return hip.silu_dropout(out) if silu_out else out
         node_attr = node_attr + self.norm1(x)
         x = self.FFN(node_attr)
-        return node_attr + self.norm2(x)
+        out = node_attr + self.norm2(x)
+        return F.silu(out) if silu_out else out
 
 
 class _EquiLayer(nn.Module):
@@ -134,10 +143,9 @@ class EquivariantScoreNetwork(nn.Module):
         for module_idx, gnn_layers in enumerate(self.gnn_layers):
             for conv_idx, gnn in enumerate(gnn_layers):
                 seed = (self._seed_base + self._calls) * 16 + module_idx * 4 + conv_idx
-                hidden = gnn(plan, conv_input, edge_attr, seed, self.seed_dev, ee_all, layer_no * D, shared)
+                hidden = gnn(plan, conv_input, edge_attr, seed, self.seed_dev, ee_all, layer_no * D, shared,
+                             silu_out=conv_idx < len(gnn_layers) - 1)
                 layer_no += 1
-                if conv_idx < len(gnn_layers) - 1:
-                    hidden = hip.silu_dropout(hidden) if hidden.is_cuda else F.silu(hidden)
                 conv_input = hidden
             node_feature = hidden
             pair = hip.pair_gather_add(node_feature, node_feature, plan)        # h_row + h_col

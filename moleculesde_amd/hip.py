@@ -910,6 +910,41 @@ def use_eager_param_grad_slot():
         _SLABS.slot = _SLABS.slots[0]
 
 
+def weight_grad(g2, x2, has_bias, deferrable=True):
+    """gW [N,K] = g2^T x2 and (has_bias) gb [N] = column sums of g2 for g2 [M,N], x2 [M,K]: the hand-written
+    split-M kernel -- queued for the grouped launch + batched slab reduction when a parameter-gradient batch is
+    open and the results are `deferrable` -- or the vendor GEMM + column-sum kernels (MSDE_LINEAR=lib, tiny M)."""
+    M, N = g2.shape
+    K = x2.size(1)
+    st = _stream()
+    use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
+    if use_hip:
+        gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
+        gb = torch.empty(N, dtype=torch.float32, device=g2.device) if has_bias else None
+        if _SLABS.active and deferrable:
+            splits = _SPLITS.get((M, N, K))
+            if splits is None:
+                splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
+            slab = _SLABS.alloc(splits * (N * K + (N if has_bias else 0)), g2.device)
+            if GROUPED_WGRAD:
+                _SLABS.queue_gemm(g2, x2, M, N, K, int(has_bias), slab)
+            else:
+                _lib.call("msde_linear_bwd_w_partial", _p(g2), _p(x2), M, N, K, int(has_bias), _p(slab), st)
+            _SLABS.add(slab.data_ptr(), splits, N * K, gw)
+            if has_bias:
+                _SLABS.add(slab.data_ptr() + 4 * splits * N * K, splits, N, gb)
+        else:
+            ws = _wgrad_workspace(M, N, K, g2.device)
+            _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
+    else:
+        gw = torch.mm(g2.t(), x2)
+        gb = None
+        if has_bias:
+            gb = torch.empty(N, dtype=torch.float32, device=g2.device)
+            _lib.call("msde_colsum", _p(g2), M, N, _p(gb), _p(_bn_workspace(M, N, g2.device)), st)
+    return gw, gb
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, offload=True):
@@ -952,31 +987,7 @@ class _Linear(torch.autograd.Function):
                 gx = torch.mm(g2, w)
             gx = gx.view(ctx.in_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
-            if use_hip:
-                gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
-                gb = torch.empty(N, dtype=torch.float32, device=g2.device) if ctx.has_bias else None
-                if _SLABS.active and ctx.deferrable:
-                    splits = _SPLITS.get((M, N, K))
-                    if splits is None:
-                        splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
-                    slab = _SLABS.alloc(splits * (N * K + (N if ctx.has_bias else 0)), g2.device)
-                    if GROUPED_WGRAD:
-                        _SLABS.queue_gemm(g2, x2, M, N, K, int(ctx.has_bias), slab)
-                    else:
-                        _lib.call("msde_linear_bwd_w_partial", _p(g2), _p(x2), M, N, K, int(ctx.has_bias), _p(slab), st)
-                    _SLABS.add(slab.data_ptr(), splits, N * K, gw)
-                    if ctx.has_bias:
-                        _SLABS.add(slab.data_ptr() + 4 * splits * N * K, splits, N, gb)
-                else:
-                    ws = _wgrad_workspace(M, N, K, g2.device)
-                    _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
-            else:
-                gw = torch.mm(g2.t(), x2)
-                gb = None
-                if ctx.has_bias:
-                    gb = torch.empty(N, dtype=torch.float32, device=g2.device)
-                    _lib.call("msde_colsum", _p(g2), M, N, _p(gb), _p(_bn_workspace(M, N, g2.device)), st)
+            gw, gb = weight_grad(g2, x2, ctx.has_bias, ctx.deferrable)
         return gx, gw, gb, None
 
 
@@ -1261,6 +1272,54 @@ def ve_position_loss(scores, noise, std, anneal_power, mol_ptr, batch_i32):
     """mean over molecules of the per-molecule mean of sum_k (scores - noise)^2 [* std^anneal_power]
     (SDE_model_2D_to_3D.py:425-432); gradient flows to `scores` only."""
     return _VEPosLoss.apply(scores, noise, std, anneal_power, mol_ptr, batch_i32)
+
+
+class _GatTail(torch.autograd.Function):
+    """GATLayer after the attention (LayerNorm + residual, feed-forward with SiLU and dropout, LayerNorm +
+    residual, optional SiLU) as one kernel each way -- csrc/gat_tail.hip."""
+
+    @staticmethod
+    def forward(ctx, x, res, g1, b1, W0, b0, W3, b3, g2, b2, eps1, eps2, p, seed, seed_dev, silu_out):
+        x, res = _f32(x), _f32(res)
+        N, D = x.shape
+        out, y1, h0, x2 = (torch.empty_like(x) for _ in range(4))
+        seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        _lib.call("msde_gat_tail_fwd", _p(x), _p(res), _p(g1), _p(b1), _p(W0), _p(b0), _p(W3), _p(b3), _p(g2), _p(b2), N, D,
+                  float(eps1), float(eps2), float(p), seed, _p(seed_dev), int(silu_out), _p(out), _p(y1), _p(h0), _p(x2),
+                  _stream())
+        ctx.save_for_backward(x, y1, h0, x2, g1, W0, W3, g2, b2)
+        ctx.cfg = (float(eps1), float(eps2), float(p), seed, seed_dev, int(silu_out))
+        ctx.deferrable = all(t.is_leaf for t in (g1, b1, W0, b0, W3, b3, g2, b2))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y1, h0, x2, g1, W0, W3, g2, b2 = ctx.saved_tensors
+        eps1, eps2, p, seed, seed_dev, silu_out = ctx.cfg
+        g = _f32(g)
+        N, D = x.shape
+        g_x, g_res, g_x2, a, g_h0 = (torch.empty_like(x) for _ in range(5))
+        nblk = int(_lib.load().msde_gat_tail_blocks(N))
+        defer = _SLABS.active and ctx.deferrable
+        part = _SLABS.alloc(nblk * 4 * D, x.device) if defer else torch.empty(nblk * 4 * D, dtype=torch.float32, device=x.device)
+        _lib.call("msde_gat_tail_bwd", _p(g), _p(x), _p(y1), _p(h0), _p(x2), _p(g1), _p(W0), _p(W3), _p(g2), _p(b2), N, D,
+                  eps1, eps2, p, seed, _p(seed_dev), silu_out, _p(g_x), _p(g_res), _p(g_x2), _p(a), _p(g_h0), _p(part),
+                  _stream())
+        ln = torch.empty(4 * D, dtype=torch.float32, device=x.device)      # [d ln2_g | d ln2_b | d ln1_g | d ln1_b]
+        if defer:
+            _SLABS.add(part.data_ptr(), nblk, 4 * D, ln)
+        else:
+            torch.sum(part.view(nblk, 4 * D), dim=0, out=ln)
+        gW3, gb3 = weight_grad(g_x2, a, True, ctx.deferrable)
+        gW0, gb0 = weight_grad(g_h0, y1, True, ctx.deferrable)
+        return (g_x, g_res, ln[2 * D:3 * D], ln[3 * D:], gW0, gb0, gW3, gb3, ln[:D], ln[D:2 * D],
+                None, None, None, None, None, None)
+
+
+def gat_tail(x, res, norm1, ffn0, ffn3, norm2, p, seed, seed_dev=None, silu_out=False):
+    """out = y1 + LN2(FFN(y1)), y1 = res + LN1(x), optionally followed by SiLU; modules give the parameters."""
+    return _GatTail.apply(x, res, norm1.weight, norm1.bias, ffn0.weight, ffn0.bias, ffn3.weight, ffn3.bias, norm2.weight,
+                          norm2.bias, norm1.eps, norm2.eps, p, seed, seed_dev, silu_out)
 
 
 def chunk_elems():

@@ -727,3 +727,64 @@ def test_randperm_kernel(dev, n):
         acc /= reps
         sigma = n / math.sqrt(12.0) / math.sqrt(reps * (n // 4))
         assert bool(((acc - (n - 1) / 2).abs() < 6 * sigma).all()), acc
+
+
+@pytest.mark.parametrize("silu_out", [False, True])
+def test_gat_tail_kernel(dev, silu_out):
+    """Fused GATLayer tail (csrc/gat_tail.hip) vs the reference's operator chain on the CPU (p = 0), all ten
+    gradients; with p = 0.1 vs the kernel-per-stage HIP path, which draws the identical dropout mask."""
+    from moleculesde_amd import hip
+    from moleculesde_amd.geom3d import nn as _nn
+    torch.manual_seed(31)
+    N, D = 3588, 32
+    n1, n2 = torch.nn.LayerNorm(D), torch.nn.LayerNorm(D)
+    f0, f3 = torch.nn.Linear(D, D), torch.nn.Linear(D, D)
+    with torch.no_grad():
+        for m in (n1, n2):
+            m.weight.normal_(1, 0.3); m.bias.normal_(0, 0.3)
+    x = torch.randn(N, D, requires_grad=True)
+    res = torch.randn(N, D, requires_grad=True)
+    w = torch.randn(N, D)
+    y1 = res + n1(x)
+    out = y1 + n2(f3(torch.nn.functional.silu(f0(y1))))
+    out = torch.nn.functional.silu(out) if silu_out else out
+    (out * w).sum().backward()
+    params = [n1.weight, n1.bias, f0.weight, f0.bias, f3.weight, f3.bias, n2.weight, n2.bias]
+    ref_grads = [x.grad, res.grad] + [p.grad for p in params]
+
+    def dev_modules():
+        m1, m2 = torch.nn.LayerNorm(D).to(dev), torch.nn.LayerNorm(D).to(dev)
+        g0, g3 = _nn.Linear(D, D).to(dev), _nn.Linear(D, D).to(dev)
+        with torch.no_grad():
+            for a, b in ((m1, n1), (m2, n2), (g0, f0), (g3, f3)):
+                a.weight.copy_(b.weight); a.bias.copy_(b.bias)
+        return m1, g0, g3, m2
+
+    m1, g0, g3, m2 = dev_modules()
+    xd, rd = x.detach().to(dev).requires_grad_(True), res.detach().to(dev).requires_grad_(True)
+    od = hip.gat_tail(xd, rd, m1, g0, g3, m2, 0.0, 7, None, silu_out)
+    assert_close(od, out.detach(), 1e-4, 1e-5, "gat tail fwd")
+    (od * w.to(dev)).sum().backward()
+    got = [xd.grad, rd.grad, m1.weight.grad, m1.bias.grad, g0.weight.grad, g0.bias.grad, g3.weight.grad, g3.bias.grad,
+           m2.weight.grad, m2.bias.grad]
+    names = ["g_x", "g_res", "ln1_g", "ln1_b", "W0", "b0", "W3", "b3", "ln2_g", "ln2_b"]
+    for a, b, nme in zip(got, ref_grads, names):
+        assert_close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-6, f"gat tail grad {nme}")
+
+    # dropout: same (seed, index) mask as the staged path
+    p, seed = 0.1, 1234
+    ctr = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    outs = []
+    for fused in (True, False):
+        m1, g0, g3, m2 = dev_modules()
+        xd, rd = x.detach().to(dev).requires_grad_(True), res.detach().to(dev).requires_grad_(True)
+        if fused:
+            o = hip.gat_tail(xd, rd, m1, g0, g3, m2, p, seed, ctr, silu_out)
+        else:
+            y1d = hip.res_layernorm(xd, rd, m1.weight, m1.bias, m1.eps)
+            o = hip.res_layernorm(g3(hip.silu_dropout(g0(y1d), p, seed, ctr)), y1d, m2.weight, m2.bias, m2.eps)
+            o = hip.silu_dropout(o) if silu_out else o
+        (o * w.to(dev)).sum().backward()
+        outs.append([o.detach(), xd.grad, rd.grad, g0.weight.grad, g3.bias.grad, m2.weight.grad])
+    for a, b, nme in zip(outs[0], outs[1], ["out", "g_x", "g_res", "W0", "b3", "ln2_g"]):
+        assert_close(a, b.cpu(), 2e-4, 2e-5 * float(b.abs().max()) + 1e-6, f"gat tail with dropout: {nme}")
