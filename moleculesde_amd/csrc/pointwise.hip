@@ -186,23 +186,28 @@ randperm_kernel(int n, unsigned long long seed, const unsigned long long* __rest
     key[i] = (z & ~0xFFFull) | (unsigned long long)i;
   }
   __syncthreads();
-  const int i = blockIdx.x * RP_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const unsigned long long mine = key[i];
+  // four lanes per key, each counting a quarter of the keys; 16 keys per (one-wave) workgroup
+  const int i = blockIdx.x * (RP_BLOCK / 4) + (threadIdx.x >> 2), part = threadIdx.x & 3;
+  const int quarter = (n + 3) / 4;
+  const int j0 = part * quarter, j1 = min(j0 + quarter, n);
+  const unsigned long long mine = key[min(i, n - 1)];
   int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-  int j = 0;
-  for (; j + 3 < n; j += 4) {
+  int j = j0;
+  for (; j + 3 < j1; j += 4) {
     r0 += key[j] < mine; r1 += key[j + 1] < mine; r2 += key[j + 2] < mine; r3 += key[j + 3] < mine;
   }
-  for (; j < n; ++j) r0 += key[j] < mine;
-  out[i] = (r0 + r1) + (r2 + r3);
+  for (; j < j1; ++j) r0 += key[j] < mine;
+  int r = (r0 + r1) + (r2 + r3);
+  r += __shfl_xor(r, 1);
+  r += __shfl_xor(r, 2);
+  if (part == 0 && i < n) out[i] = r;
 }
 
 extern "C" int msde_randperm(int n, unsigned long long seed, const unsigned long long* seed_dev, int* out, void* stream) {
   if (n < 0 || !out) return MSDE_EINVAL;
   if (n > RP_MAX) return MSDE_EUNSUP;
   if (n == 0) return 0;
-  MSDE_LAUNCH(randperm_kernel, dim3((n + RP_BLOCK - 1) / RP_BLOCK), dim3(RP_BLOCK), 0, as_stream(stream), n, seed, seed_dev,
+  MSDE_LAUNCH(randperm_kernel, dim3((n + RP_BLOCK / 4 - 1) / (RP_BLOCK / 4)), dim3(RP_BLOCK), 0, as_stream(stream), n, seed, seed_dev,
               out);
   MSDE_CHECK_LAUNCH();
   return 0;
