@@ -28,7 +28,18 @@ __global__ void gin_aggregate_fwd_kernel(const float* __restrict__ x, const floa
   int s0 = rowptr[i], s1 = rowptr[i + 1];
   for (int c = lane; c < cols; c += tpr) {
     T acc = vzero<V>();
-    for (int e = s0; e < s1; ++e) {
+    int e = s0;
+    for (; e + 1 < s1; e += 2) {      // two edges (2 neighbour rows + 6 table rows) in flight, added in edge order
+      int j0 = src[e], j1 = src[e + 1];
+      int a0 = codes[3 * e], a1 = codes[3 * e + 1], a2 = codes[3 * e + 2];
+      int b0 = codes[3 * e + 3], b1 = codes[3 * e + 4], b2 = codes[3 * e + 5];
+      T x0 = X[(size_t)j0 * cols + c], x1 = X[(size_t)j1 * cols + c];
+      T t0 = Tb[(size_t)a0 * cols + c], t1 = Tb[(size_t)a1 * cols + c], t2 = Tb[(size_t)a2 * cols + c];
+      T u0 = Tb[(size_t)b0 * cols + c], u1 = Tb[(size_t)b1 * cols + c], u2 = Tb[(size_t)b2 * cols + c];
+      acc = vadd(acc, vrelu(vadd(x0, vadd(vadd(t0, t1), t2))));
+      acc = vadd(acc, vrelu(vadd(x1, vadd(vadd(u0, u1), u2))));
+    }
+    for (; e < s1; ++e) {
       T m = vadd(X[(size_t)src[e] * cols + c], bond_emb<V>(Tb, codes, e, cols, c));
       acc = vadd(acc, vrelu(m));
     }
@@ -56,7 +67,19 @@ __global__ void gin_aggregate_bwd_x_kernel(const float* __restrict__ g, const fl
   for (int c = lane; c < cols; c += tpr) {
     T xj = X[(size_t)j * cols + c];
     T acc = vscale(G[(size_t)j * cols + c], ope);
-    for (int s = s0; s < s1; ++s) {
+    int s = s0;
+    for (; s + 1 < s1; s += 2) {      // two edges in flight (indices, then 2 gradient rows + 6 table rows)
+      int e0 = perm_s[s], e1 = perm_s[s + 1];
+      int d0 = dst[e0], d1 = dst[e1];
+      int a0 = codes[3 * e0], a1 = codes[3 * e0 + 1], a2 = codes[3 * e0 + 2];
+      int b0 = codes[3 * e1], b1 = codes[3 * e1 + 1], b2 = codes[3 * e1 + 2];
+      T g0 = G[(size_t)d0 * cols + c], g1 = G[(size_t)d1 * cols + c];
+      T t0 = Tb[(size_t)a0 * cols + c], t1 = Tb[(size_t)a1 * cols + c], t2 = Tb[(size_t)a2 * cols + c];
+      T u0 = Tb[(size_t)b0 * cols + c], u1 = Tb[(size_t)b1 * cols + c], u2 = Tb[(size_t)b2 * cols + c];
+      acc = vadd(acc, vgate(g0, vadd(xj, vadd(vadd(t0, t1), t2))));
+      acc = vadd(acc, vgate(g1, vadd(xj, vadd(vadd(u0, u1), u2))));
+    }
+    for (; s < s1; ++s) {
       int e = perm_s[s];
       T m = vadd(xj, bond_emb<V>(Tb, codes, e, cols, c));
       acc = vadd(acc, vgate(G[(size_t)dst[e] * cols + c], m));

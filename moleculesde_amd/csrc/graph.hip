@@ -191,7 +191,15 @@ __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const in
   T* O = reinterpret_cast<T*>(out);
   for (int c = lane; c < cols; c += tpr) {
     T acc = vzero<V>();
-    for (int s = s0; s < s1; ++s) {
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {      // four rows in flight (no index -> row chain per edge); summed in edge order
+      int e0 = perm ? perm[s] : s, e1 = perm ? perm[s + 1] : s + 1;
+      int e2 = perm ? perm[s + 2] : s + 2, e3 = perm ? perm[s + 3] : s + 3;
+      T v0 = R[(size_t)e0 * ldi_cols + c], v1 = R[(size_t)e1 * ldi_cols + c];
+      T v2 = R[(size_t)e2 * ldi_cols + c], v3 = R[(size_t)e3 * ldi_cols + c];
+      acc = vadd(vadd(vadd(vadd(acc, v0), v1), v2), v3);
+    }
+    for (; s < s1; ++s) {
       int e = perm ? perm[s] : s;
       acc = vadd(acc, R[(size_t)e * ldi_cols + c]);
     }

@@ -108,7 +108,17 @@ __global__ void cfconv_aggregate_bwd_x_kernel(const float* __restrict__ g_agg, c
   int s0 = rowptr_s[j], s1 = rowptr_s[j + 1];
   for (int c = lane; c < cols; c += tpr) {
     T acc = vzero<V>();
-    for (int s = s0; s < s1; ++s) {
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {      // indices first, then the eight row loads in flight; accumulated in edge order
+      int e0 = perm_s[s], e1 = perm_s[s + 1], e2 = perm_s[s + 2], e3 = perm_s[s + 3];
+      int d0 = dst[e0], d1 = dst[e1], d2 = dst[e2], d3 = dst[e3];
+      T w0 = W[(size_t)e0 * cols + c], w1 = W[(size_t)e1 * cols + c], w2 = W[(size_t)e2 * cols + c], w3 = W[(size_t)e3 * cols + c];
+      T g0 = G[(size_t)d0 * cols + c], g1 = G[(size_t)d1 * cols + c], g2 = G[(size_t)d2 * cols + c], g3 = G[(size_t)d3 * cols + c];
+      if (C) { w0 = vscale(w0, C[e0]); w1 = vscale(w1, C[e1]); w2 = vscale(w2, C[e2]); w3 = vscale(w3, C[e3]); }
+      acc = vadd(acc, vmul(g0, w0)); acc = vadd(acc, vmul(g1, w1));
+      acc = vadd(acc, vmul(g2, w2)); acc = vadd(acc, vmul(g3, w3));
+    }
+    for (; s < s1; ++s) {
       int e = perm_s[s];
       T w = C ? vscale(W[(size_t)e * cols + c], C[e]) : W[(size_t)e * cols + c];
       acc = vadd(acc, vmul(G[(size_t)dst[e] * cols + c], w));
