@@ -76,6 +76,8 @@ extern "C" int msde_edge_geometry_fwd(const float* pos, const int* src, const in
 // ------------------------------------------------------------------------------------------------
 // edge attention: one thread per (target node, head); CH channels per head kept in registers.
 // ------------------------------------------------------------------------------------------------
+#define EA_UB 4     // edges per batch
+
 template <int CH>
 __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                           const float* __restrict__ v, const float* __restrict__ skip, int ld,
@@ -94,36 +96,72 @@ __global__ void edge_attention_fwd_kernel(const float* __restrict__ q, const flo
   for (int c = 0; c < CH; ++c) qv[c] = q[(size_t)i * ld + h * CH + c];
   const float scale = 1.f / sqrtf((float)CH);
   int s0 = rowptr[i], s1 = rowptr[i + 1];
+  // Every pass walks the in-edges in batches of EA_UB: indices, then all rows of the batch in flight (the
+  // index -> row -> arithmetic chain per edge is what bounds this kernel), arithmetic in edge order.
   float m = -INFINITY;
-  for (int e = s0; e < s1; ++e) {
-    const float* kr = k + (size_t)src[e] * ld + h * CH;
-    const float* er = ee + (size_t)e * ld_ee + h * CH;
-    float s = 0.f;
+  for (int e = s0; e < s1; e += EA_UB) {
+    float kv[EA_UB][CH], ev[EA_UB][CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) s += qv[c] * (kr[c] + er[c]);
-    s *= scale;
-    alpha[(size_t)e * H + h] = s;
-    m = fmaxf(m, s);
+    for (int u = 0; u < EA_UB; ++u) {
+      const int eu = min(e + u, s1 - 1);
+      const float* kr = k + (size_t)src[eu] * ld + h * CH;
+      const float* er = ee + (size_t)eu * ld_ee + h * CH;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { kv[u][c] = kr[c]; ev[u][c] = er[c]; }
+    }
+#pragma unroll
+    for (int u = 0; u < EA_UB; ++u) {
+      if (e + u < s1) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) s += qv[c] * (kv[u][c] + ev[u][c]);
+        s *= scale;
+        alpha[(size_t)(e + u) * H + h] = s;
+        m = fmaxf(m, s);
+      }
+    }
   }
   float sum = 0.f;
-  for (int e = s0; e < s1; ++e) {
-    float p = expf(alpha[(size_t)e * H + h] - m);
-    alpha[(size_t)e * H + h] = p;
-    sum += p;
+  for (int e = s0; e < s1; e += EA_UB) {
+    float sv[EA_UB];
+#pragma unroll
+    for (int u = 0; u < EA_UB; ++u) sv[u] = alpha[(size_t)min(e + u, s1 - 1) * H + h];
+#pragma unroll
+    for (int u = 0; u < EA_UB; ++u) {
+      if (e + u < s1) {
+        float p = expf(sv[u] - m);
+        alpha[(size_t)(e + u) * H + h] = p;
+        sum += p;
+      }
+    }
   }
   float inv = 1.f / (sum + 1e-16f);
   float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   float acc[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) acc[c] = 0.f;
-  for (int e = s0; e < s1; ++e) {
-    float a = alpha[(size_t)e * H + h] * inv;
-    alpha[(size_t)e * H + h] = a;
-    if (p_drop > 0.f) a = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? a * keep_scale : 0.f;
-    const float* vr = v + (size_t)src[e] * ld + h * CH;
-    const float* er = ee + (size_t)e * ld_ee + h * CH;
+  for (int e = s0; e < s1; e += EA_UB) {
+    float vv[EA_UB][CH], ev[EA_UB][CH], av[EA_UB];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc[c] = fmaf(a, vr[c] + er[c], acc[c]);
+    for (int u = 0; u < EA_UB; ++u) {
+      const int eu = min(e + u, s1 - 1);
+      const float* vr = v + (size_t)src[eu] * ld + h * CH;
+      const float* er = ee + (size_t)eu * ld_ee + h * CH;
+      av[u] = alpha[(size_t)eu * H + h];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { vv[u][c] = vr[c]; ev[u][c] = er[c]; }
+    }
+#pragma unroll
+    for (int u = 0; u < EA_UB; ++u) {
+      if (e + u < s1) {
+        float a = av[u] * inv;
+        alpha[(size_t)(e + u) * H + h] = a;
+        if (p_drop > 0.f)
+          a = (msde_uniform(seed, (unsigned long long)(e + u) * H + h) >= p_drop) ? a * keep_scale : 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = fmaf(a, vv[u][c] + ev[u][c], acc[c]);
+      }
+    }
   }
 #pragma unroll
   for (int c = 0; c < CH; ++c)
@@ -156,40 +194,67 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
   const float scale = 1.f / sqrtf((float)CH);
   float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   int s0 = rowptr[i], s1 = rowptr[i + 1];
-  // pass 1: g_vpe, and dsum = sum_e alpha_e * g_alpha_e
+  // pass 1: g_vpe, and dsum = sum_e alpha_e * g_alpha_e   (batches of EA_UB edges, see the forward kernel)
   float dsum = 0.f;
-  for (int e = s0; e < s1; ++e) {
-    float a = alpha[(size_t)e * H + h];
-    float ms = 1.f;
-    if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
-    const float* vr = v + (size_t)src[e] * ld + h * CH;
-    const float* er = ee + (size_t)e * ld_ee + h * CH;
-    float ga = 0.f;
+  for (int e = s0; e < s1; e += EA_UB) {
+    float vv[EA_UB][CH], ev[EA_UB][CH], av[EA_UB];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      ga = fmaf(go[c], vr[c] + er[c], ga);
-      g_vpe[(size_t)e * ld_kv + h * CH + c] = go[c] * (a * ms);
+    for (int u = 0; u < EA_UB; ++u) {
+      const int eu = min(e + u, s1 - 1);
+      const float* vr = v + (size_t)src[eu] * ld + h * CH;
+      const float* er = ee + (size_t)eu * ld_ee + h * CH;
+      av[u] = alpha[(size_t)eu * H + h];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { vv[u][c] = vr[c]; ev[u][c] = er[c]; }
     }
-    dsum = fmaf(a, ga * ms, dsum);
+#pragma unroll
+    for (int u = 0; u < EA_UB; ++u) {
+      if (e + u < s1) {
+        const float a = av[u];
+        float ms = 1.f;
+        if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)(e + u) * H + h) >= p_drop) ? keep_scale : 0.f;
+        float ga = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          ga = fmaf(go[c], vv[u][c] + ev[u][c], ga);
+          g_vpe[(size_t)(e + u) * ld_kv + h * CH + c] = go[c] * (a * ms);
+        }
+        dsum = fmaf(a, ga * ms, dsum);
+      }
+    }
   }
   // pass 2: softmax backward, g_q, g_kpe, g_ee
-  for (int e = s0; e < s1; ++e) {
-    float a = alpha[(size_t)e * H + h];
-    float ms = 1.f;
-    if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
-    const float* vr = v + (size_t)src[e] * ld + h * CH;
-    const float* kr = k + (size_t)src[e] * ld + h * CH;
-    const float* er = ee + (size_t)e * ld_ee + h * CH;
-    float ga = 0.f;
+  for (int e = s0; e < s1; e += EA_UB) {
+    float vv[EA_UB][CH], kv[EA_UB][CH], ev[EA_UB][CH], av[EA_UB];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) ga = fmaf(go[c], vr[c] + er[c], ga);
-    float gs = a * (ga * ms - dsum) * scale;
+    for (int u = 0; u < EA_UB; ++u) {
+      const int eu = min(e + u, s1 - 1);
+      const int j = src[eu];
+      const float* vr = v + (size_t)j * ld + h * CH;
+      const float* kr = k + (size_t)j * ld + h * CH;
+      const float* er = ee + (size_t)eu * ld_ee + h * CH;
+      av[u] = alpha[(size_t)eu * H + h];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      gq[c] = fmaf(gs, kr[c] + er[c], gq[c]);
-      float gk = gs * qv[c];
-      g_kpe[(size_t)e * ld_kv + h * CH + c] = gk;
-      g_ee[(size_t)e * ld_ee + h * CH + c] = gk + go[c] * (a * ms);
+      for (int c = 0; c < CH; ++c) { vv[u][c] = vr[c]; kv[u][c] = kr[c]; ev[u][c] = er[c]; }
+    }
+#pragma unroll
+    for (int u = 0; u < EA_UB; ++u) {
+      if (e + u < s1) {
+        const float a = av[u];
+        float ms = 1.f;
+        if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)(e + u) * H + h) >= p_drop) ? keep_scale : 0.f;
+        float ga = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) ga = fmaf(go[c], vv[u][c] + ev[u][c], ga);
+        float gs = a * (ga * ms - dsum) * scale;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          gq[c] = fmaf(gs, kv[u][c] + ev[u][c], gq[c]);
+          float gk = gs * qv[c];
+          g_kpe[(size_t)(e + u) * ld_kv + h * CH + c] = gk;
+          g_ee[(size_t)(e + u) * ld_ee + h * CH + c] = gk + go[c] * (a * ms);
+        }
+      }
     }
   }
 #pragma unroll
