@@ -170,10 +170,11 @@ extern "C" int msde_ve_perturb(const float* pos, const float* noise, const long 
 // Random permutation of 0..n-1 (torch.randperm for the contrastive negatives, examples/util.py:55) for n <= 4096:
 // out[i] = rank of key_i among n i.i.d. 64-bit keys (52 counter-based random bits: seed, device step counter,
 // index | 12 index bits, so keys are distinct).  The ranks of i.i.d. keys are a uniform random permutation.
-// Every workgroup (one wave) keeps all keys in LDS and ranks 64 of them by counting (broadcast LDS reads): n^2
-// compares spread over n/64 workgroups -- one short launch instead of key generation + a multi-pass sort.
+// Every workgroup keeps all keys in LDS and ranks 64 of them by counting (four lanes per key, broadcast LDS
+// reads): n^2 compares spread over n/64 workgroups -- one short launch instead of key generation + a multi-pass sort.
 #define RP_MAX 4096
-#define RP_BLOCK 64     // one wave per workgroup: the counting loop is bound by LDS broadcast reads per wave
+#define RP_BLOCK 256    // 64 keys per workgroup (four lanes each): every workgroup regenerates all n keys, so fewer,
+                        // larger workgroups keep that redundant hashing small
 __global__ void __launch_bounds__(RP_BLOCK)
 randperm_kernel(int n, unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int* __restrict__ out) {
   __shared__ unsigned long long key[RP_MAX];
@@ -186,7 +187,7 @@ randperm_kernel(int n, unsigned long long seed, const unsigned long long* __rest
     key[i] = (z & ~0xFFFull) | (unsigned long long)i;
   }
   __syncthreads();
-  // four lanes per key, each counting a quarter of the keys; 16 keys per (one-wave) workgroup
+  // four lanes per key, each counting a quarter of the keys
   const int i = blockIdx.x * (RP_BLOCK / 4) + (threadIdx.x >> 2), part = threadIdx.x & 3;
   const int quarter = (n + 3) / 4;
   const int j0 = part * quarter, j1 = min(j0 + quarter, n);
