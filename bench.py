@@ -149,6 +149,29 @@ def roofline_cfconv_aggregate(trainer, batch, iters=50):
             "avg_launch_us": round(ms * 1e3, 2)}
 
 
+def roofline_dense_head_gemm(batch, iters=30):
+    """Dense node-adjacency score head (SDEModel3Dto2D_node_adj_dense, --full): its largest product is the node
+    head's Linear(728, 728) over the B*N_max padded atom slots.  Timed: the hand-written fp32-MFMA GEMM
+    (msde_linear_fwd, csrc/linear.hip) on that shape, against the fp32 matrix-core peak."""
+    from moleculesde_amd import hip, _lib
+    dev = batch.x.device
+    pl = getattr(batch, "_msde_plan", None)
+    M = int(pl.B * pl.N_max) if pl is not None else 5120
+    N = K = 728
+    with torch.no_grad():
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev)
+        b = torch.randn(N, device=dev)
+        y = torch.empty(M, N, device=dev)
+        p, st = hip._p, hip._stream()
+        fn = lambda: _lib.call("msde_linear_fwd", p(x), p(w), p(b), M, N, K, p(y), st)
+        ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_f32_mfma_kernel (Linear 728x728 of the dense head)", "bound": "mfma", "achieved": round(tf, 2),
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+            "avg_launch_us": round(ms * 1e3, 2), "shape": [M, N, K]}
+
+
 def cpu_baseline(bs=256, warm=1, timed=3):
     """The oracle port of the same step (oracle/restate.py, plain PyTorch fp32 on the host cores) on a
     bounded sample: `timed` steps of one bs-256 synthetic batch after `warm` warm-up steps."""
@@ -258,6 +281,7 @@ def main():
         roof = roofline_fused_fwd(trainer, pool[0])
         roof_bwd = roofline_fused_bwd(trainer, pool[0])
         roof_agg = roofline_cfconv_aggregate(trainer, pool[0])
+        roof_head = roofline_dense_head_gemm(pool[0])
         out = {
             "metric": "molecules/sec pretrain step (SchNet+SDE VE, bs256)",
             "value": round(mols / dt, 1), "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
@@ -273,6 +297,7 @@ def main():
             "roofline": roof,
             "roofline_cfconv_fused_bwd_w": roof_bwd,
             "roofline_cfconv_aggregate_hbm": roof_agg,
+            "roofline_dense_head_gemm": roof_head,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch_size)
