@@ -120,7 +120,7 @@ def roofline_fused_bwd(trainer, batch, iters=30):
         p, st = hip._p, hip._stream()
         fn = lambda: _lib.call("msde_cfconv_fused_bwd_w", p(g), p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst),
                                p(W1), p(b1), p(W2), p(de.offset), N, 128, G, rplan.E, float(de.coeff), float(sch.cutoff),
-                               p(gW1), p(gb1), p(gW2), p(gb2), p(ws), st)
+                               0, p(gW1), p(gb1), p(gW2), p(gb2), p(ws), st)
         ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
     flops = E * 2.0 * (2 * G * 128 + 2 * 128 * 128)
     tf = flops / (ms * 1e-3) / 1e12

@@ -127,20 +127,26 @@ int msde_cfconv_aggregate_bwd_x(const float* g_agg, const float* Wf, const float
 int msde_cfconv_fused_fwd(const float* x1, const float* dist, const int* rowptr, const int* src,
                           const int* dst, const float* W1, const float* b1, const float* W2,
                           const float* b2, const float* offset, int N, int F, int G, int E_cap,
-                          float coeff, float cutoff, int chunks_per_wg, float* agg, float* Wf_out,
-                          void* stream);
+                          float coeff, float cutoff,
+                          int chunks_per_wg /* 32-edge chunks per persistent workgroup; <= 0: two workgroups
+                                               per CU.  A caller running this kernel beside latency-critical
+                                               work on another stream asks for fewer, longer workgroups. */,
+                          float* agg, float* Wf_out, void* stream);
 /* Weight gradients of the filter network for the fused CFConv, recomputing rbf/h1 on chip:
  * gW1 [F,G], gb1 [F], gW2 [F,F], gb2 [F] from g_agg [N,F], x1 [N,F], dist.  Per-workgroup slabs in
- * `workspace` (msde_cfconv_fused_bwd_w_workspace_floats floats) are summed in a fixed order. */
-long long msde_cfconv_fused_bwd_w_workspace_floats(int E_cap, int G);
+ * `workspace` (msde_cfconv_fused_bwd_w_workspace_floats floats) are summed in a fixed order.
+ * max_workgroups <= 0: one persistent workgroup per CU (each holds 147 KB of LDS); smaller values leave whole
+ * CUs to work running concurrently on other streams (the kernel itself then takes longer). */
+long long msde_cfconv_fused_bwd_w_workspace_floats(int E_cap, int G, int max_workgroups);
 int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, const float* dist,
                             const int* rowptr, const int* src, const int* dst, const float* W1,
                             const float* b1, const float* W2, const float* offset, int N, int F,
-                            int G, int E_cap, float coeff, float cutoff, float* gW1, float* gb1,
-                            float* gW2, float* gb2, float* workspace, void* stream);
-/* With gW1 == gb1 == gW2 == gb2 == NULL the call only leaves msde_cfconv_fused_bwd_w_slabs(E_cap) slabs of
+                            int G, int E_cap, float coeff, float cutoff, int max_workgroups,
+                            float* gW1, float* gb1, float* gW2, float* gb2, float* workspace,
+                            void* stream);
+/* With gW1 == gb1 == gW2 == gb2 == NULL the call only leaves msde_cfconv_fused_bwd_w_slabs(E_cap, max_workgroups) slabs of
  * F*F + F*G + 2F floats ([gW2 | gW1 | gb1 | gb2]) in `workspace` (for msde_reduce_slabs_multi). */
-int msde_cfconv_fused_bwd_w_slabs(int E_cap);
+int msde_cfconv_fused_bwd_w_slabs(int E_cap, int max_workgroups);
 
 /* ------------------------------------------------------------------ 2D->3D score net ------- */
 /* coord2basis / get_perturb_distance / GaussianFourierProjection / pseudo-angle —

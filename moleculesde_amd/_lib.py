@@ -36,10 +36,10 @@ SIGNATURES = {
     "msde_cfconv_aggregate_bwd_w": [P, P, P, P, P, I, I, I, P, P],
     "msde_cfconv_aggregate_bwd_x": [P, P, P, P, P, P, I, I, P, P],
     "msde_cfconv_fused_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P, P],
-    "msde_cfconv_fused_bwd_w_workspace_floats": [I, I],
-    "msde_cfconv_fused_bwd_w_slabs": [I],
+    "msde_cfconv_fused_bwd_w_workspace_floats": [I, I, I],
+    "msde_cfconv_fused_bwd_w_slabs": [I, I],
     "msde_gin_aggregate_bwd_tab_slabs": [I, I],
-    "msde_cfconv_fused_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P, P, P, P],
+    "msde_cfconv_fused_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P, P, P, P, P],
     "msde_edge_geometry_fwd": [P, P, P, I, P, P, I, P, P, P, P, P, P],
     "msde_edge_attention_fwd": [P, P, P, P, I, P, I, P, P, I, I, I, F, ULL, P, P, P, P],
     "msde_edge_attention_bwd": [P, P, P, P, I, P, I, P, I, P, P, P, I, I, I, F, ULL, P, P, P, P, P, I, P],

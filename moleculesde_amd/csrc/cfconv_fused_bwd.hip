@@ -231,9 +231,14 @@ __global__ void cfconv_reduce_slabs_kernel(const float* __restrict__ slabs, int 
   }
 }
 
-static inline void cb_geometry(int E_cap, int* nwg, int* cpw) {
+// max_wgs <= 0: one persistent workgroup per CU (each takes 147 KB of LDS, i.e. the whole CU as far as other
+// LDS-using kernels are concerned).  A caller that runs this kernel BESIDE latency-critical work on another stream
+// passes a smaller number: the kernel takes longer but leaves whole CUs to the other stream (measured on the
+// pretrain step: 128 workgroups instead of 256 = +6 % step throughput).
+static inline void cb_geometry(int E_cap, int max_wgs, int* nwg, int* cpw) {
   int chunks = (E_cap + CB_TE - 1) / CB_TE;
-  int w = chunks < 256 ? chunks : 256;     // one persistent workgroup per CU
+  int cap = max_wgs > 0 ? max_wgs : msde_num_cus();
+  int w = chunks < cap ? chunks : cap;
   if (w < 1) w = 1;
   *cpw = (chunks + w - 1) / w;
   if (*cpw < 1) *cpw = 1;
@@ -241,23 +246,23 @@ static inline void cb_geometry(int E_cap, int* nwg, int* cpw) {
   if (*nwg < 1) *nwg = 1;
 }
 
-extern "C" int msde_cfconv_fused_bwd_w_slabs(int E_cap) {
+extern "C" int msde_cfconv_fused_bwd_w_slabs(int E_cap, int max_workgroups) {
   int nwg, cpw;
-  cb_geometry(E_cap, &nwg, &cpw);
+  cb_geometry(E_cap, max_workgroups, &nwg, &cpw);
   return nwg;
 }
 
-extern "C" long long msde_cfconv_fused_bwd_w_workspace_floats(int E_cap, int G) {
+extern "C" long long msde_cfconv_fused_bwd_w_workspace_floats(int E_cap, int G, int max_workgroups) {
   int nwg, cpw;
-  cb_geometry(E_cap, &nwg, &cpw);
+  cb_geometry(E_cap, max_workgroups, &nwg, &cpw);
   return (long long)nwg * ((long long)CB_F * CB_F + (long long)CB_F * G + 2 * CB_F);
 }
 
 extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, const float* dist, const int* rowptr,
                                        const int* src, const int* dst, const float* W1, const float* b1,
                                        const float* W2, const float* offset, int N, int F, int G, int E_cap,
-                                       float coeff, float cutoff, float* gW1, float* gb1, float* gW2, float* gb2,
-                                       float* workspace, void* stream) {
+                                       float coeff, float cutoff, int max_workgroups, float* gW1, float* gb1, float* gW2,
+                                       float* gb2, float* workspace, void* stream) {
   // gW1 == gb1 == gW2 == gb2 == NULL: leave the per-workgroup slabs in `workspace` for a batched reduction
   const bool no_reduce = !gW1 && !gb1 && !gW2 && !gb2;
   if (N < 0 || E_cap < 0 || !g_agg || !x1 || !dist || !rowptr || !src || !dst || !W1 || !b1 || !W2 || !offset ||
@@ -266,7 +271,7 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   if (F != CB_F || G <= 0 || G > 64) return MSDE_EUNSUP;
   hipStream_t st = as_stream(stream);
   int nwg, cpw;
-  cb_geometry(E_cap, &nwg, &cpw);
+  cb_geometry(E_cap, max_workgroups, &nwg, &cpw);
   int kk1 = (G + 1) / 2;
   auto lds_bytes = [](int KK1) {
     return (size_t)(CB_F * CB_HS + CB_TE * (2 * KK1 + 1) + 64 + 2 * CB_TE * CB_HS + 4 * CB_TE) * sizeof(float);

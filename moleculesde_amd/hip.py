@@ -150,6 +150,19 @@ def rbf_cutoff(dist, E_dev, offset, coeff, cutoff):
 
 
 FUSED_CHUNKS_PER_WG = 0   # 0 = auto: one resident wave of persistent workgroups (msde_cfconv_fused_fwd)
+# Geometry of the two wide CFConv kernels when they run BESIDE latency-critical work on another stream (the trainer
+# runs SchNet next to the GIN -> 2D->3D chain): at full width they hold most of every CU's LDS / registers and the
+# other stream's kernels wait for a free CU.  Fewer, longer workgroups make the kernels themselves slower but the
+# step faster (MI355X, bs 256: 71.8k -> 78.7k molecules/s).  None = full width (standalone use, the roofline runs).
+CFCONV_FWD_WGS = None     # workgroups of the fused forward (full width: 2 per CU)
+CFCONV_BWD_WGS = None     # workgroups of the fused weight-gradient kernel (full width: 1 per CU)
+
+
+def _fwd_chunks_per_wg(E_cap):
+    if CFCONV_FWD_WGS is None:
+        return FUSED_CHUNKS_PER_WG
+    chunks = (E_cap + 31) // 32
+    return max(1, -(-chunks // int(CFCONV_FWD_WGS)))
 
 
 def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, chunks_per_wg=None, want_filter=False):
@@ -160,7 +173,7 @@ def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, 
     G = W1.size(1)
     agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
     Wf = torch.empty(plan.E, Fd, dtype=torch.float32, device=x1.device) if want_filter else None
-    cpw = FUSED_CHUNKS_PER_WG if chunks_per_wg is None else chunks_per_wg
+    cpw = _fwd_chunks_per_wg(plan.E) if chunks_per_wg is None else chunks_per_wg
     _lib.call("msde_cfconv_fused_fwd", _p(x1), _p(_f32(dist)), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
               _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)), _p(_f32(offset)), N, Fd, G, plan.E,
               float(coeff), float(cutoff), int(cpw), _p(agg), _p(Wf), _stream())
@@ -170,8 +183,8 @@ def cfconv_fused_forward(x1, dist, plan, W1, b1, W2, b2, offset, coeff, cutoff, 
 _CF_WS = {}
 
 
-def _cf_workspace(E_cap, G, device):
-    n = int(_lib.load().msde_cfconv_fused_bwd_w_workspace_floats(E_cap, G))
+def _cf_workspace(E_cap, G, device, max_wgs=0):
+    n = int(_lib.load().msde_cfconv_fused_bwd_w_workspace_floats(E_cap, G, max_wgs))
     device = _ws_key(device)
     ws = _CF_WS.get(device)
     if ws is None or ws.numel() < n:
@@ -213,17 +226,18 @@ class _CFConvFused(torch.autograd.Function):
         gW1 = gall[Fd * Fd:Fd * Fd + Fd * G].view(Fd, G)
         gb1 = gall[Fd * Fd + Fd * G:Fd * Fd + Fd * G + Fd]
         gb2 = gall[Fd * Fd + Fd * G + Fd:]
+        mw = int(CFCONV_BWD_WGS or 0)
         if _SLABS.active:            # slabs into the arena, summed by the batched reduction of the backward pass
-            nslab = int(_lib.load().msde_cfconv_fused_bwd_w_slabs(plan.E))
+            nslab = int(_lib.load().msde_cfconv_fused_bwd_w_slabs(plan.E, mw))
             ws = _SLABS.alloc(nslab * gall.numel(), g.device)
             _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
-                      _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, _p(None), _p(None),
+                      _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, mw, _p(None), _p(None),
                       _p(None), _p(None), _p(ws), st)
             _SLABS.add(ws.data_ptr(), nslab, gall.numel(), gall)
         else:
-            ws = _cf_workspace(plan.E, G, x1.device)
+            ws = _cf_workspace(plan.E, G, x1.device, mw)
             _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
-                      _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, _p(gW1), _p(gb1),
+                      _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, mw, _p(gW1), _p(gb1),
                       _p(gW2), _p(gb2), _p(ws), st)
         return g_x1, gW1, gb1, gW2, gb2, None, None, None, None, None
 

@@ -82,6 +82,8 @@ def readme_args(**over):
 
 
 USE_FUSED_CL = True
+SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
+SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "128"))   # measured best (full width 512 / 256: -9 %)
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
 GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
 EARLY_GEOMETRY = os.environ.get("MSDE_EARLY_GEO", "0") != "0"   # start the 2D->3D coordinate branch before the encoders (measured: 2% slower at bs256, so off)
@@ -205,6 +207,13 @@ class Trainer:
         self._graph_loss = {}
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=device)
 
+    def _side_geometry(self, on):
+        """While SchNet runs beside the GIN -> 2D->3D chain its two wide CFConv kernels take only part of the chip
+        (see hip.CFCONV_FWD_WGS); restored afterwards so that standalone users get the full-width kernels."""
+        from . import hip
+        hip.CFCONV_FWD_WGS = SIDE_CFCONV_FWD_WGS if on else None
+        hip.CFCONV_BWD_WGS = SIDE_CFCONV_BWD_WGS if on else None
+
     def losses(self, batch):
         """Loss composition of pretrain_MoleculeSDE.py:128-152.  The 3D encoder does not depend on the 2D
         branch (GIN -> 2D->3D score model) until the contrastive term, and most kernels of this 256-molecule
@@ -213,6 +222,8 @@ class Trainer:
         a, m = self.args, self.models
         loss = 0
         parts = {}
+        if self.overlap_streams:
+            self._side_geometry(True)          # until the end of this step's backward pass
         main = torch.cuda.current_stream()
         want_32 = a.SDE_coeff_generative_3Dto2D > 0
         # the 3D->2D head depends only on the SchNet output: it follows SchNet on the side stream unless the
@@ -271,14 +282,17 @@ class Trainer:
     def _backward(self, loss):
         """loss.backward() with the weight-gradient slab reductions of all layers batched into one launch."""
         from . import hip
-        if not BATCH_SLAB_REDUCE:
-            loss.backward()
-            return
-        hip.begin_param_grad_batch()
         try:
-            loss.backward()
+            if not BATCH_SLAB_REDUCE:
+                loss.backward()
+                return
+            hip.begin_param_grad_batch()
+            try:
+                loss.backward()
+            finally:
+                hip.finish_param_grad_batch()
         finally:
-            hip.finish_param_grad_batch()
+            self._side_geometry(False)
 
     def step(self, batch):
         loss, parts = self.losses(batch)
