@@ -42,6 +42,7 @@ class GNN(nn.Module):
         self.batch_norms = nn.ModuleList([_nn.BatchNorm1d(emb_dim) for _ in range(num_layer)])
         for layer in range(num_layer - 1):
             self.batch_norms[layer].fuse_relu = True     # ReLU after every layer but the last (:178-182)
+        self.on_input_grad = None
 
     def _find_plan(self, x, edge_index, edge_attr, data=None):
         pl = None
@@ -69,6 +70,11 @@ class GNN(nn.Module):
             raise ValueError("unmatched number of arguments.")
 
         h = hip.embedding_sum(self.atom_encoder.table(), pl.atom_codes, pl.atom_list_ptr, pl.atom_list_nodes)
+        if self.on_input_grad is not None and h.requires_grad:
+            # trainer hook: fires when the gradient of the first activation is ready, i.e. every Linear / BatchNorm
+            # of the encoder has run its backward (only the embedding tables' own gradient is still to come)
+            cb = self.on_input_grad
+            h.register_hook(lambda g_: (cb(), None)[1])
         h_list = [h]
         for layer in range(self.num_layer):
             h = self.gnns[layer](h_list[layer], pl.bond, pl.bond_codes)

@@ -833,6 +833,7 @@ class _SlabBatch:
         assert not self.rows, "finish_param_grad_batch() was not called after the previous backward"
         self.active = True
         self.used = 0
+        self.prob_used = self.pre_used = 0
 
     def alloc(self, nfloats, device):
         nfloats = (nfloats + 3) & ~3
@@ -855,6 +856,35 @@ class _SlabBatch:
     def queue_gemm(self, gY, X, M, N, K, has_bias, slab):
         self.gemms.append((gY, X, M, N, K, has_bias, slab))
 
+    def launch_gemms(self):
+        """One grouped launch, on the current stream, for the weight-gradient GEMMs queued so far.  May be called
+        several times per backward pass (each call takes the next rows of the problem table)."""
+        if not self.gemms:
+            return
+        dev = self.gemms[0][0].device
+        if self.slot is None or self.slot[2].device != dev:
+            self.new_slot(dev)
+        host_prob, host_ppre, dev_prob, dev_ppre = self.slot[4:]
+        lib = _lib.load()
+        r0, q0, ng = self.prob_used, self.pre_used, len(self.gemms)
+        assert r0 + ng <= self.MAX_ROWS
+        hp2 = host_ppre.numpy()
+        total_b = 0
+        for r, (gY, X, M, N, K, hb, slab) in enumerate(self.gemms):
+            nb = lib.msde_linear_bwd_w_describe(_p(gY), _p(X), M, N, K, hb, _p(slab),
+                                                ctypes.c_void_p(host_prob[r0 + r].data_ptr()))
+            if nb <= 0:
+                raise _lib.MsdeHipError(f"msde_linear_bwd_w_describe failed ({nb}) for {M}x{N}x{K}")
+            hp2[q0 + r] = total_b
+            total_b += nb
+        hp2[q0 + ng] = total_b
+        upload_table(dev_prob[r0:r0 + ng], host_prob[r0:r0 + ng])
+        upload_table(dev_ppre[q0:q0 + ng + 1], host_ppre[q0:q0 + ng + 1])
+        self.prob_used, self.pre_used = r0 + ng, q0 + ng + 1
+        _lib.call("msde_linear_bwd_w_grouped", ctypes.c_void_p(dev_prob[r0].data_ptr()),
+                  ctypes.c_void_p(dev_ppre[q0:].data_ptr()), ng, total_b, _stream())
+        self.gemms = []
+
     def finish(self):
         self.active = False
         rows = self.rows
@@ -864,24 +894,8 @@ class _SlabBatch:
         dev = rows[0][4]
         if self.slot is None or self.slot[2].device != dev:
             self.new_slot(dev)
-        host_rows, host_pre, dev_rows, dev_pre, host_prob, host_ppre, dev_prob, dev_ppre = self.slot
-        if self.gemms:           # all queued weight-gradient GEMMs as one grouped launch
-            lib = _lib.load()
-            hp2 = host_ppre.numpy()
-            total_b = 0
-            for r, (gY, X, M, N, K, hb, slab) in enumerate(self.gemms):
-                nb = lib.msde_linear_bwd_w_describe(_p(gY), _p(X), M, N, K, hb, _p(slab),
-                                                    ctypes.c_void_p(host_prob[r].data_ptr()))
-                if nb <= 0:
-                    raise _lib.MsdeHipError(f"msde_linear_bwd_w_describe failed ({nb}) for {M}x{N}x{K}")
-                hp2[r] = total_b
-                total_b += nb
-            hp2[len(self.gemms)] = total_b
-            ng = len(self.gemms)
-            upload_table(dev_prob[:ng], host_prob[:ng])
-            upload_table(dev_ppre[:ng + 1], host_ppre[:ng + 1])
-            _lib.call("msde_linear_bwd_w_grouped", _p(dev_prob), _p(dev_ppre), len(self.gemms), total_b, _stream())
-            self.gemms = []
+        self.launch_gemms()          # the (still) queued weight-gradient GEMMs as one grouped launch
+        host_rows, host_pre, dev_rows, dev_pre = self.slot[:4]
         hr, hp = host_rows.numpy(), host_pre.numpy()
         total = 0
         for r, (ptr, splits, n, out_ptr, _) in enumerate(rows):
@@ -903,6 +917,13 @@ _SPLITS = {}
 
 def begin_param_grad_batch():
     _SLABS.begin()
+
+
+def flush_wgrad_gemms():
+    """Launch the weight-gradient GEMMs queued so far as one grouped kernel on the current stream (their slabs are
+    still summed by finish_param_grad_batch)."""
+    if _SLABS.active:
+        _SLABS.launch_gemms()
 
 
 def finish_param_grad_batch():

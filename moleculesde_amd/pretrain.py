@@ -84,6 +84,7 @@ def readme_args(**over):
 USE_FUSED_CL = True
 SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
 SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "128"))   # measured best (full width 512 / 256: -9 %)
+EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
 GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
 EARLY_GEOMETRY = os.environ.get("MSDE_EARLY_GEO", "0") != "0"   # start the 2D->3D coordinate branch before the encoders (measured: 2% slower at bs256, so off)
@@ -194,6 +195,12 @@ class Trainer:
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self.overlap_streams = True
         self._side_stream = torch.cuda.Stream(device=device)
+        if EARLY_WGRAD_FLUSH:
+            # when the 2D encoder's backward is through, launch the weight gradients queued so far (2D->3D model and
+            # GIN) on the same stream: they run while the second stream still finishes SchNet's backward, and only
+            # SchNet's own weight gradients are left for the tail of the step
+            from . import hip as _hip4
+            self.models["model_2D"].on_input_grad = _hip4.flush_wgrad_gemms
         self._bn_modules = [mod for m_ in self.models.values() for mod in m_.modules() if isinstance(mod, _nn.BatchNorm1d)]
         # Measured on MI355X (tools/marginal_cost.py, hipGraph replay, bs 256): 1 stream 5.26 ms, SchNet beside the
         # 2D branch 4.55 ms, a third stream for the 2D->3D coordinate branch 4.73 ms, weight gradients on a fourth
