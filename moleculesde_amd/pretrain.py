@@ -229,13 +229,15 @@ class Trainer:
         a, m = self.args, self.models
         loss = 0
         parts = {}
-        if self.overlap_streams:
-            self._side_geometry(True)          # until the end of this step's backward pass
         main = torch.cuda.current_stream()
         want_32 = a.SDE_coeff_generative_3Dto2D > 0
         # the 3D->2D head depends only on the SchNet output: it follows SchNet on the side stream unless the
         # noise source replays the reference's program order (its draws come last there)
         head_on_side = want_32 and self.overlap_streams and not getattr(self.noise, "replay", False)
+        if self.overlap_streams and not head_on_side:
+            # SchNet alone on the second stream is the shorter chain: its wide kernels give way to the main chain
+            # (with the 3D->2D head behind it the second stream is the critical one and keeps the full width)
+            self._side_geometry(True)          # until the end of this step's backward pass
 
         def head_32(rep):
             lx, la = m["SDE_3Dto2D_model"](rep, batch, reduce_mean=a.noise_on_one_hot, continuous=True, train=True,
