@@ -211,6 +211,191 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
   }
 }
 
+// ---- light variant: 32-edge chunks, W2 in registers -----------------------------------------------------------
+// The kernel above keeps W2 (66 KB) and two 64-row tiles in LDS: 147 KB per workgroup, i.e. the whole CU as far as
+// any other LDS-using kernel is concerned.  In the training step this kernel runs on the second stream beside the
+// latency-critical GIN / 2D->3D chain, and those kernels then wait for a free CU.  Here a wave's W2 slice is the
+// B operand of the W2^T product straight from registers (lane (col, half) <- W2[2kk + half][col]: rows of W2 are
+// read coalesced, no transpose), chunks are one 32-row MFMA block, and a workgroup needs 41 KB of LDS and <= 256
+// VGPRs: it can sit on every CU and still leave room for the other stream's workgroups.
+// Measured (MI355X, bs 256): correct, but without the forward kernel's prefetching its 32-edge chunks cost 112 us
+// standalone against 89 us, and the step is slower with it (75.5k molecules/s at full width, 72.4k at 128
+// workgroups) than with the 147 KB kernel confined to 128 CUs (78.5k).  Kept selectable (MSDE_CFBWD_LIGHT=1) as the
+// starting point for a prefetching two-workgroup version.
+#define CB2_TE 32
+template <int KK1>
+__global__ void __launch_bounds__(256, 2)
+cfconv_fused_bwd_w32_kernel(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
+                            const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ dst,
+                            const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                            const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
+                            float* __restrict__ slabs) {
+  constexpr int RS = 2 * KK1 + 1;
+  extern __shared__ float lds[];
+  float* rbf_t = lds;                          // [32][RS] (+ slack: gW1 reads up to column 63 of the last row)
+  float* hid_t = rbf_t + CB2_TE * RS + 64;     // [32][129] h1
+  float* gp_t = hid_t + CB2_TE * CB_HS;        // [32][129] g_pre2
+  float* c_s = gp_t + CB2_TE * CB_HS;          // [32]
+  float* d_s = c_s + CB2_TE;                   // [32]
+  int* src_s = reinterpret_cast<int*>(d_s + CB2_TE);
+  int* dst_s = src_s + CB2_TE;
+  float* off_s = reinterpret_cast<float*>(dst_s + CB2_TE);   // [64]
+
+  const float PI_F = 3.14159265358979323846f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 31, lhalf = lane >> 5;
+  const int col = wave * 32 + lcol;
+
+  const int E = rowptr[N];
+  const int e_begin = min(blockIdx.x * cpw * CB2_TE, E);
+  const int e_end = min(e_begin + cpw * CB2_TE, E);
+
+  // W2 slice -> registers (coalesced: lanes read consecutive columns of one W2 row); W1 slice through LDS
+  float w1r[KK1], w2r[CB_F / 2];
+#pragma unroll
+  for (int kk = 0; kk < CB_F / 2; ++kk) w2r[kk] = W2[(size_t)(2 * kk + lhalf) * CB_F + col];
+  if (tid < 64) off_s[tid] = tid < G ? offset[tid] : 0.f;
+  {
+    float* stage = hid_t;                        // 64 x G floats fit in hid_t + gp_t
+    const int half_n = 64 * G;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      for (int i = tid; i < half_n; i += 256) stage[i] = W1[(size_t)r * half_n + i];
+      __syncthreads();
+      if ((wave >> 1) == r) {
+        const int lrow = (wave & 1) * 32 + lcol;
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk) {
+          int g = 2 * kk + lhalf;
+          w1r[kk] = g < G ? stage[lrow * G + g] : 0.f;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const float b1c = b1[col];
+
+  f32x16 aW2[4], aW1[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW2[j][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW1[j][r] = 0.f;
+  float sb1 = 0.f, sb2 = 0.f;
+
+  for (int ec = e_begin; ec < e_end; ec += CB2_TE) {
+    __syncthreads();
+    if (tid < CB2_TE) {
+      int e = ec + tid;
+      bool ok = e < e_end;
+      float d = ok ? dist[e] : 0.f;
+      d_s[tid] = d;
+      c_s[tid] = ok ? 0.5f * (cosf(d * PI_F / cutoff) + 1.0f) : 0.f;
+      src_s[tid] = ok ? src[e] : -1;
+      dst_s[tid] = ok ? dst[e] : -1;
+    }
+    __syncthreads();
+    // g_pre2 in accumulator layout straight from the gathers: gp[s] = g_agg[dst] * x1[src] * C
+    float gp[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int row = cb_row(s, lhalf);
+      int s0 = src_s[row], t0 = dst_s[row];
+      float xa = x1[(size_t)(s0 >= 0 ? s0 : 0) * CB_F + col], ga = g_agg[(size_t)(t0 >= 0 ? t0 : 0) * CB_F + col];
+      gp[s] = ga * xa * c_s[row];               // padding rows: c_s = 0
+    }
+    for (int idx = tid; idx < CB2_TE * 2 * KK1; idx += 256) {
+      int r = idx / (2 * KK1), g = idx % (2 * KK1);
+      float v = 0.f;
+      if (ec + r < e_end && g < G) {
+        float diff = d_s[r] - off_s[g];
+        v = __expf(coeff * (diff * diff));
+      }
+      rbf_t[r * RS + g] = v;
+    }
+    __syncthreads();
+
+    // ---- recompute pre1 = rbf W1^T (+ b1): h1 -> LDS, sigmoid(pre1) stays in registers
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KK1; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rbf_t[lcol * RS + 2 * kk + lhalf], w1r[kk], acc, 0, 0, 0);
+    float sg[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int row = cb_row(i, lhalf);
+      float p0 = acc[i] + b1c;
+      float e0 = __expf(-fabsf(p0));
+      hid_t[row * CB_HS + col] = fmaxf(p0, 0.f) + __logf(1.f + e0) - 0.69314718246459961f;
+      float r0 = 1.f / (1.f + e0);
+      sg[i] = p0 >= 0.f ? r0 : e0 * r0;          // sigmoid = d softplus / dx
+      gp_t[row * CB_HS + col] = gp[i];           // g_pre2 tile for the W2^T product (row-per-lane reads)
+      sb2 += gp[i];
+    }
+    __syncthreads();
+
+    // ---- g_W2[f][k] += sum_e g_pre2[e][f] h1[e][k]: A = g_pre2 registers, B = h1 rows (same permuted e)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int row = cb_row(s, lhalf);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[s], hid_t[row * CB_HS + 32 * j + lcol], aW2[j], 0, 0, 0);
+    }
+    // ---- g_h1[e][k] = sum_f g_pre2[e][f] W2[f][k]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < CB_F / 2; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp_t[lcol * CB_HS + 2 * kk + lhalf], w2r[kk], acc, 0, 0, 0);
+    // g_pre1 = g_h1 * sigmoid(pre1)  (same lanes / registers as pre1)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sg[i] *= acc[i];
+      sb1 += sg[i];
+    }
+    // ---- g_W1[k][g] += sum_e g_pre1[e][k] rbf[e][g]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      int row = cb_row(s, lhalf);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        aW1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sg[s], rbf_t[row * RS + 32 * j + lcol], aW1[j], 0, 0, 0);
+    }
+  }
+
+  // ---- write this workgroup's slab: [128*128 gW2][128*G gW1][128 gb1][128 gb2]
+  const size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
+  float* slab = slabs + (size_t)blockIdx.x * slab_sz;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int f = wave * 32 + cb_row(r, lhalf);
+      slab[(size_t)f * CB_F + 32 * j + lcol] = aW2[j][r];
+    }
+  float* sW1 = slab + (size_t)CB_F * CB_F;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int k = wave * 32 + cb_row(r, lhalf);
+      int g = 32 * j + lcol;
+      if (g < G) sW1[(size_t)k * G + g] = aW1[j][r];
+    }
+  sb1 += __shfl_xor(sb1, 32, 64);
+  sb2 += __shfl_xor(sb2, 32, 64);
+  if (lhalf == 0) {
+    slab[(size_t)CB_F * CB_F + (size_t)CB_F * G + col] = sb1;
+    slab[(size_t)CB_F * CB_F + (size_t)CB_F * G + CB_F + col] = sb2;
+  }
+}
+
 __global__ void cfconv_reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_sz, int G,
                                            float* __restrict__ gW2, float* __restrict__ gW1, float* __restrict__ gb1,
                                            float* __restrict__ gb2) {
@@ -235,8 +420,13 @@ __global__ void cfconv_reduce_slabs_kernel(const float* __restrict__ slabs, int 
 // LDS-using kernels are concerned).  A caller that runs this kernel BESIDE latency-critical work on another stream
 // passes a smaller number: the kernel takes longer but leaves whole CUs to the other stream (measured on the
 // pretrain step: 128 workgroups instead of 256 = +6 % step throughput).
+static inline bool cb_light() {
+  static int v = [] { const char* e = getenv("MSDE_CFBWD_LIGHT"); return e ? atoi(e) : 0; }();   // off: see below
+  return v != 0;
+}
 static inline void cb_geometry(int E_cap, int max_wgs, int* nwg, int* cpw) {
-  int chunks = (E_cap + CB_TE - 1) / CB_TE;
+  const int te = cb_light() ? CB2_TE : CB_TE;
+  int chunks = (E_cap + te - 1) / te;
   int cap = max_wgs > 0 ? max_wgs : msde_num_cus();
   int w = chunks < cap ? chunks : cap;
   if (w < 1) w = 1;
@@ -288,10 +478,23 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   }                                                                                                                   \
   MSDE_LAUNCH(cfconv_fused_bwd_w_kernel<KK>, dim3(nwg), dim3(256), lds_bytes(KK), st, g_agg, x1, dist, rowptr, src, dst, \
               W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
-  if (kk1 == 26) { CB_LAUNCH(26); }
-  else if (kk1 == 25) { CB_LAUNCH(25); }
-  else { CB_LAUNCH(32); }
+  auto lds2_bytes = [](int KK1) {
+    return (size_t)(CB2_TE * (2 * KK1 + 1) + 64 + 2 * CB2_TE * CB_HS + 4 * CB2_TE + 64) * sizeof(float);
+  };
+#define CB2_LAUNCH(KK)                                                                                                \
+  MSDE_LAUNCH(cfconv_fused_bwd_w32_kernel<KK>, dim3(nwg), dim3(256), lds2_bytes(KK), st, g_agg, x1, dist, rowptr, src,   \
+              dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
+  if (cb_light()) {
+    if (kk1 == 26) { CB2_LAUNCH(26); }
+    else if (kk1 == 25) { CB2_LAUNCH(25); }
+    else { CB2_LAUNCH(32); }
+  } else {
+    if (kk1 == 26) { CB_LAUNCH(26); }
+    else if (kk1 == 25) { CB_LAUNCH(25); }
+    else { CB_LAUNCH(32); }
+  }
 #undef CB_LAUNCH
+#undef CB2_LAUNCH
   MSDE_CHECK_LAUNCH();
   if (no_reduce) return 0;
   size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
