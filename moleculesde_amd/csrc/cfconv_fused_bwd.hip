@@ -75,18 +75,31 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
     for (int r = 0; r < 16; ++r) aW1[j][r] = 0.f;
   float sb1 = 0.f, sb2 = 0.f;
 
-  for (int ec = e_begin; ec < e_end; ec += CB_TE) {
-    __syncthreads();
+  // per-edge metadata is requested one chunk ahead (the gathers below depend on it: without the prefetch every
+  // chunk starts with two back-to-back global round trips)
+  float m_d = 0.f;
+  int m_s = -1, m_t = -1;
+  auto fetch_meta = [&](int ec) {
     if (tid < CB_TE) {
       int e = ec + tid;
       bool ok = e < e_end;
-      float d = ok ? dist[e] : 0.f;
-      d_s[tid] = d;
-      c_s[tid] = ok ? 0.5f * (cosf(d * PI_F / cutoff) + 1.0f) : 0.f;
-      src_s[tid] = ok ? src[e] : -1;
-      dst_s[tid] = ok ? dst[e] : -1;
+      m_d = ok ? dist[e] : -1.f;
+      m_s = ok ? src[e] : -1;
+      m_t = ok ? dst[e] : -1;
+    }
+  };
+  fetch_meta(e_begin);
+  for (int ec = e_begin; ec < e_end; ec += CB_TE) {
+    __syncthreads();
+    if (tid < CB_TE) {
+      bool ok = m_t >= 0;
+      d_s[tid] = ok ? m_d : 0.f;
+      c_s[tid] = ok ? 0.5f * (cosf(m_d * PI_F / cutoff) + 1.0f) : 0.f;
+      src_s[tid] = m_s;
+      dst_s[tid] = m_t;
     }
     __syncthreads();
+    if (ec + CB_TE < e_end) fetch_meta(ec + CB_TE);
     // g_pre2 in accumulator layout straight from the gathers: gp[rb][s] = g_agg[dst] * x1[src] * C
     float gp0[16], gp1[16];
 #pragma unroll
