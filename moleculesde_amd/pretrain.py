@@ -194,6 +194,8 @@ class Trainer:
         # hipGraph mode: one captured graph per batch shape (forward + backward + gradient flattening
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self.overlap_streams = True
+        from . import tuned_gemm
+        tuned_gemm.enable()           # per-signature library-GEMM algorithm lookup (read-only; see tuned_gemm.py)
         self._side_stream = torch.cuda.Stream(device=device)
         if EARLY_WGRAD_FLUSH:
             # when the 2D encoder's backward is through, launch the weight gradients queued so far (2D->3D model and
