@@ -278,9 +278,11 @@ int msde_silu_dropout_bwd(const float* g, const float* x, long long n, float p, 
 int msde_mul_add_fwd(const float* a, const float* b, const float* c, long long n, float* out, void* stream);
 int msde_mul_add_bwd(const float* g, const float* a, const float* b, long long n, float* ga, float* gb,
                      void* stream);
-/* torch.randperm(n) for the contrastive negatives (examples/util.py:55), n <= 4096 (else MSDE_EUNSUP): out[n]
- * int32, a uniform shuffle drawn from the counter-based generator (seed [+ seed_dev[0]*FNV], index). */
-int msde_randperm(int n, unsigned long long seed, const unsigned long long* seed_dev, int* out, void* stream);
+/* torch.randperm(n) for the contrastive negatives (examples/util.py:55), n <= 4096 (else MSDE_EUNSUP):
+ * out[count][n] int32, `count` independent uniform shuffles in one launch (dual_CL draws two) from the
+ * counter-based generator (seed [+ seed_dev[0]*FNV], permutation number, index). */
+int msde_randperm(int n, int count, unsigned long long seed, const unsigned long long* seed_dev, int* out,
+                  void* stream);
 /* VE perturbation (SDE_model_2D_to_3D.py:401-412, SDE_sparse.py VESDE.marginal_prob): draws [B/2+1] int64 in
  * [0,T); molecule b uses ts = draws[b] (b < B/2+1) or T - draws[b-(B/2+1)] - 1; t = ts/T*(1-eps)+eps;
  * std_out[i] = sigma_min (sigma_max/sigma_min)^t of atom i's molecule; pos_out = pos + std * noise. */

@@ -179,6 +179,8 @@ __global__ void __launch_bounds__(RP_BLOCK)
 randperm_kernel(int n, unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int* __restrict__ out) {
   __shared__ unsigned long long key[RP_MAX];
   if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
+  seed += 0xD1B54A32D192ED03ull * blockIdx.y;       // blockIdx.y: which of the `count` independent permutations
+  out += (size_t)blockIdx.y * n;
   for (int i = threadIdx.x; i < n; i += RP_BLOCK) {
     unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)i + 1ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -204,12 +206,13 @@ randperm_kernel(int n, unsigned long long seed, const unsigned long long* __rest
   if (part == 0 && i < n) out[i] = r;
 }
 
-extern "C" int msde_randperm(int n, unsigned long long seed, const unsigned long long* seed_dev, int* out, void* stream) {
-  if (n < 0 || !out) return MSDE_EINVAL;
+extern "C" int msde_randperm(int n, int count, unsigned long long seed, const unsigned long long* seed_dev, int* out,
+                             void* stream) {
+  if (n < 0 || count < 0 || !out) return MSDE_EINVAL;
   if (n > RP_MAX) return MSDE_EUNSUP;
-  if (n == 0) return 0;
-  MSDE_LAUNCH(randperm_kernel, dim3((n + RP_BLOCK / 4 - 1) / (RP_BLOCK / 4)), dim3(RP_BLOCK), 0, as_stream(stream), n, seed, seed_dev,
-              out);
+  if (n == 0 || count == 0) return 0;
+  MSDE_LAUNCH(randperm_kernel, dim3((n + RP_BLOCK / 4 - 1) / (RP_BLOCK / 4), count), dim3(RP_BLOCK), 0, as_stream(stream), n,
+              seed, seed_dev, out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -182,6 +182,7 @@ class DeviceNoise:
     """Default noise source: device RNG (torch's HIP generator)."""
 
     replay = False     # draws are not tied to a program order: independent branches may run concurrently
+    seed, calls, seed_dev = 0x5EED, 0, None     # class defaults: subclasses need not call __init__
 
     def __init__(self, seed=0x5EED):
         self.seed = int(seed)
@@ -203,6 +204,16 @@ class DeviceNoise:
     def rand(self, n, device):
         return torch.rand(n, device=device)
 
+    def randperm_pair(self, n, device):
+        """The two permutations of dual_CL from one launch (a subclass that overrides randperm is asked twice)."""
+        if type(self).randperm is not DeviceNoise.randperm:
+            return self.randperm(n, device), self.randperm(n, device)
+        if torch.device(device).type == "cuda" and n <= hip.RANDPERM_MAX:
+            self.calls += 1
+            p = hip.randperm(n, device, self.seed + 0x9E3779B1 * self.calls, self.seed_dev, count=2)
+            return p[0], p[1]
+        return self.randperm(n, device), self.randperm(n, device)
+
 
 class CpuReplayNoise:
     """Parity noise source: draws from a torch CPU generator in the reference's program order
@@ -214,6 +225,9 @@ class CpuReplayNoise:
     def __init__(self, seed):
         self.g = torch.Generator(device="cpu")
         self.g.manual_seed(int(seed))
+
+    def randperm_pair(self, n, device):
+        return self.randperm(n, device), self.randperm(n, device)     # the reference's two consecutive draws
 
     def randn_like(self, x):
         return torch.randn(x.shape, generator=self.g, dtype=x.dtype).to(x.device)

@@ -1259,10 +1259,12 @@ def mul_add(a, b, c):
 RANDPERM_MAX = 4096
 
 
-def randperm(n, device, seed, seed_dev=None):
-    """Uniform random permutation of range(n) as int32 (n <= RANDPERM_MAX), one kernel."""
-    out = torch.empty(n, dtype=torch.int32, device=device)
-    _lib.call("msde_randperm", int(n), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(seed_dev), _p(out), _stream())
+def randperm(n, device, seed, seed_dev=None, count=None):
+    """Uniform random permutation(s) of range(n) as int32 (n <= RANDPERM_MAX), one kernel: [n], or [count, n]
+    independent ones when `count` is given."""
+    out = torch.empty((n,) if count is None else (count, n), dtype=torch.int32, device=device)
+    _lib.call("msde_randperm", int(n), 1 if count is None else int(count), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(seed_dev),
+              _p(out), _stream())
     return out
 
 

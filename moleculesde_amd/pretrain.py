@@ -252,7 +252,7 @@ class Trainer:
         negs = (None, None)
         if self.coeff_cl > 0:
             n = batch.x.size(0)
-            negs = (self.noise.randperm(n, batch.x.device), self.noise.randperm(n, batch.x.device))
+            negs = self.noise.randperm_pair(n, batch.x.device)
         if a.SDE_coeff_generative_2Dto3D > 0 and EARLY_GEOMETRY:
             m["SDE_2Dto3D_model"].begin(batch)
         l32 = None

@@ -718,6 +718,12 @@ def test_randperm_kernel(dev, n):
         assert not torch.equal(p1, hip.randperm(n, dev, 124, ctr))
         ctr.add_(1)
         assert not torch.equal(p1, hip.randperm(n, dev, 123, ctr))
+    pair = hip.randperm(n, dev, 77, None, count=2)            # two independent permutations from one launch
+    assert pair.shape == (2, n)
+    for r in range(2):
+        assert torch.equal(torch.sort(pair[r].long())[0].cpu(), torch.arange(n))
+    if n >= 37:
+        assert not torch.equal(pair[0], pair[1])
     if n >= 3588:
         acc = torch.zeros(4, dtype=torch.float64)
         reps = 64
