@@ -66,12 +66,20 @@ def _pmc_traffic(kernel, E, N):
     return None
 
 
-def roofline_fused_fwd(trainer, batch, iters=50):
-    """Roofline of the dominant hand-written kernel of the step: the fused CFConv forward
-    (csrc/cfconv_fused.hip; 6 launches per step forward).  It is matrix-core bound in fp32 (83 FLOP/B):
-    algorithmic FLOPs per launch = E * 2 * (G*F + F*F) for the filter network (SURVEY §8d row 'SchNet
+def _step_widths(trainer):
+    """Workgroup counts the trainer gives the two wide CFConv kernels inside the step (pretrain.Trainer.losses:
+    narrowed while SchNet runs beside the GIN -> 2D->3D chain, full width with the 3D->2D head behind it)."""
+    from moleculesde_amd import pretrain
+    side = trainer.overlap_streams and not (trainer.args.SDE_coeff_generative_3Dto2D > 0)
+    return (pretrain.SIDE_CFCONV_FWD_WGS, pretrain.SIDE_CFCONV_BWD_WGS) if side else (None, None)
+
+
+def roofline_fused_fwd(trainer, batch, iters=50, wgs=None):
+    """The fused CFConv forward (csrc/cfconv_fused.hip; 6 launches per step forward), fp32 matrix-core bound
+    (83 FLOP/B): algorithmic FLOPs per launch = E * 2 * (G*F + F*F) for the filter network (SURVEY §8d row 'SchNet
     CFConv fused'); algorithmic bytes = E*8 + E*F*4 (gather) + weights + N*F*4 (+ E*F*4 filter rows out).
-    Timed on the raw C-ABI call (weights pre-transposed, output zeroing included) with HIP events."""
+    Timed on the raw C-ABI call with HIP events at the SAME workgroup count the step launches it with (`wgs`; None
+    = full width), so the figure is the kernel as the step runs it, minus cross-stream contention."""
     from moleculesde_amd import hip, _lib
     sch, rplan, dist, E, N = _radius(trainer, batch)
     if sch.num_filters != 128:
@@ -87,9 +95,10 @@ def roofline_fused_fwd(trainer, batch, iters=50):
         Wf = torch.empty(rplan.E, 128, device=batch.x.device)
         stream = torch.cuda.current_stream()
         p, st = hip._p, hip._stream()
+        cpw = hip.FUSED_CHUNKS_PER_WG if wgs is None else max(1, -(-((rplan.E + 31) // 32) // int(wgs)))
         fn = lambda: _lib.call("msde_cfconv_fused_fwd", p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst), p(W1T),
                                p(b1), p(W2T), p(b2), p(de.offset), N, 128, G, rplan.E, float(de.coeff), float(sch.cutoff),
-                               hip.FUSED_CHUNKS_PER_WG, p(agg), p(Wf), st)
+                               cpw, p(agg), p(Wf), st)
         ms = _event_time_ms(fn, iters, stream)
     flops = E * 2.0 * (G * 128 + 128 * 128)
     nbytes = E * 8 + E * 128 * 4 * 2 + (G * 128 + 128 * 128 + 256) * 4 + N * 128 * 4 + (N + 1) * 4
@@ -98,10 +107,11 @@ def roofline_fused_fwd(trainer, batch, iters=50):
             "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
             "traffic": _pmc_traffic("cfconv_fused_fwd_kernel", E, N), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": nbytes, "hbm_frac_at_this_time": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N}
+            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N,
+            "workgroups": "full width" if wgs is None else int(wgs)}
 
 
-def roofline_fused_bwd(trainer, batch, iters=30):
+def roofline_fused_bwd(trainer, batch, iters=30, wgs=None):
     """Second line: the recomputing weight-gradient kernel of the fused CFConv (cfconv_fused_bwd.hip),
     FLOPs per launch = E * 2 * (G*F [recompute pre1] + F*F [g_W2] + F*F [W2^T g] + F*G [g_W1])."""
     from moleculesde_amd import hip, _lib
@@ -116,37 +126,120 @@ def roofline_fused_bwd(trainer, batch, iters=30):
         g = torch.randn(N, 128, device=dev)
         W1, b1, W2 = blk.mlp[0].weight.detach(), blk.mlp[0].bias.detach(), blk.mlp[2].weight.detach()
         gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b1)
-        ws = hip._cf_workspace(rplan.E, G, dev)
+        mw = int(wgs or 0)
+        ws = hip._cf_workspace(rplan.E, G, dev, mw)
         p, st = hip._p, hip._stream()
         fn = lambda: _lib.call("msde_cfconv_fused_bwd_w", p(g), p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst),
                                p(W1), p(b1), p(W2), p(de.offset), N, 128, G, rplan.E, float(de.coeff), float(sch.cutoff),
-                               0, p(gW1), p(gb1), p(gW2), p(gb2), p(ws), st)
+                               mw, p(gW1), p(gb1), p(gW2), p(gb2), p(ws), st)
         ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
     flops = E * 2.0 * (2 * G * 128 + 2 * 128 * 128)
     tf = flops / (ms * 1e-3) / 1e12
     return {"kernel": "cfconv_fused_bwd_w_kernel (+ slab reduce)", "bound": "mfma", "achieved": round(tf, 2),
             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6}
+            "traffic": _pmc_traffic("cfconv_fused_bwd_w_kernel", E, N), "flops_per_launch": flops,
+            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N,
+            "workgroups": "full width" if wgs is None else int(wgs)}
 
 
-def roofline_cfconv_aggregate(trainer, batch, iters=50):
-    """HBM-bound message-passing kernel of the decomposed path (gather x1[src] * filter, segmented sum;
-    schnet.py:190,194-195).  Algorithmic bytes per launch (SURVEY §8d convention):
-    E*F*4 (filter rows) + E*F*4 (gathered x1 rows) + E*8 + (N+1)*4 + N*F*4 (output)."""
-    from moleculesde_amd import hip
+def roofline_hbm_kernel(trainer, batch, iters=50):
+    """HBM-bound message-passing kernel that the step really launches (6 x per backward pass): the input gradient
+    of the CFConv aggregation, g_x1[j] = sum_{e: src_e = j} g_agg[dst_e] * Wf[e]  (schnet.py:190,194-195 transposed;
+    `cfconv_aggregate_bwd_x_kernel`).  Algorithmic bytes per launch (SURVEY §8d convention): E*F*4 (filter rows) +
+    E*F*4 (gathered gradient rows) + E*8 (slot -> edge, edge -> target) + (N+1)*4 + N*F*4 (output)."""
+    from moleculesde_amd import hip, _lib
     sch, rplan, dist, E, N = _radius(trainer, batch)
     Fd = sch.num_filters
     with torch.no_grad():
-        x1 = torch.randn(N, Fd, device=batch.x.device)
-        Wf = torch.randn(rplan.E, Fd, device=batch.x.device)
-        C = torch.rand(rplan.E, device=batch.x.device)
-        ms = _event_time_ms(lambda: hip.cfconv_aggregate(x1, Wf, C, rplan), iters, torch.cuda.current_stream())
+        dev = batch.x.device
+        g = torch.randn(N, Fd, device=dev)
+        Wf = torch.randn(rplan.E, Fd, device=dev)
+        out = torch.empty(N, Fd, device=dev)
+        p, st = hip._p, hip._stream()
+        fn = lambda: _lib.call("msde_cfconv_aggregate_bwd_x", p(g), p(Wf), p(None), p(rplan.rowptr_s), p(rplan.perm_s),
+                               p(rplan.dst), N, Fd, p(out), st)
+        ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
     nbytes = E * Fd * 4 * 2 + E * 8 + (N + 1) * 4 + N * Fd * 4
     achieved = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "cfconv_aggregate_fwd_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+    return {"kernel": "cfconv_aggregate_bwd_x_kernel", "bound": "hbm", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": _pmc_traffic("cfconv_aggregate_fwd_kernel", E, N), "bytes_per_launch": nbytes,
-            "avg_launch_us": round(ms * 1e3, 2)}
+            "traffic": _pmc_traffic("cfconv_aggregate_bwd_x_kernel", E, N), "bytes_per_launch": nbytes,
+            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6}
+
+
+def forward_algorithmic(st, H=300, F=128, G=51, D=300, C=32, L3=6):
+    """Algorithmic bytes and FLOPs of the SchNet + SDEModel2Dto3D_02 FORWARD for a batch with the counts `st`
+    (formulas not constants: fp32 = 4 B, index = 4 B, each logical op reads each distinct input
+    once and writes its output once, a gather counts E x row bytes, temporaries inside one logical op are free)."""
+    N, E_e, E_r = st["N"], st["E_e"], st["E_r"]
+    b, f = {}, {}
+    b["schnet_embedding"] = N * 4 + N * H * 4
+    b["schnet_radius"] = N * 16 + E_r * 12
+    b["schnet_lin1"] = L3 * (N * H + H * F + N * F) * 4
+    b["schnet_cfconv"] = L3 * (E_r * 8 + E_r * F * 4 + (G * F + F + F * F + F) * 4 + N * F * 4 + (N + 1) * 4)
+    b["schnet_lin2_ssp_lin_res"] = L3 * (N * F * 4 + 2 * N * H * 4 + (F * H + H + H * H + H) * 4)
+    b["schnet_head"] = 2 * N * H * 4 + 2 * (H * H + H) * 4
+    b["sde_edge_2D_emb"] = 3 * N * D * 4 + 2 * D * D * 4 + E_e * 8 + 2 * E_e * D * 4 + E_e * C * 4 + D * C * 4
+    b["sde_edge_geometry"] = E_e * (8 + 24 + 2 * C * 4 + 36)
+    b["sde_node_emb"] = N * D * 4 + N * C * 4 + D * C * 4
+    b["sde_gat_layers"] = 4 * (8 * N * C * 4 + E_e * 8 + 3 * E_e * C * 4)
+    b["sde_basis_mlp_mean"] = 2 * (E_e * 8 + 3 * E_e * C * 4 + E_e * 36 + N * 12)
+    f["schnet_lin1"] = L3 * 2 * N * H * F
+    f["schnet_cfconv"] = L3 * E_r * (2 * (G * F + F * F) + 5 * F + 5 * G)
+    f["schnet_lin2_ssp_lin_res"] = L3 * (2 * N * F * H + 2 * N * H * H + 4 * N * H)
+    f["schnet_head"] = 2 * 2 * N * H * H
+    f["sde_edge_2D_emb"] = 2 * N * D * 2 * D + 4 * E_e * D + 2 * E_e * D * C
+    f["sde_edge_geometry"] = E_e * (2 * 2 * C * C + 2 * 2 * 4 * C * C + 2 * (2 * C + 2) * C + 2 * C * C + 400)
+    f["sde_node_emb"] = 2 * N * D * C
+    f["sde_gat_layers"] = 4 * (N * (2 * C * 4 * C + 2 * 2 * C * C) + E_e * (2 * C * C + 8 * C))
+    f["sde_basis_mlp_mean"] = 2 * E_e * (2 * 2 * C * 128 + 2 * 128 * 3 + 50)
+    return b, f
+
+
+def roofline_forward(trainer, batch, stats, iters=30):
+    """The north-star figure (BASELINE.json; SURVEY §8d 'SchNet + 2D->3D fwd'): the training-mode FORWARD of SchNet
+    and SDEModel2Dto3D_02 at this batch, captured as ONE hipGraph (both models back to back on one stream, tape
+    built as in a training step, 2D representation = a resident [N, emb] tensor) and replayed `iters` times between
+    HIP events.  Reported against both bounds: algorithmic bytes / 8 TB/s and algorithmic FLOPs / 157.3 TFLOP/s."""
+    m = trainer.models
+    sch, sde = m["model_3D"], m["SDE_2Dto3D_model"]
+    dev = batch.x.device
+    h2 = torch.randn(batch.x.size(0), trainer.args.emb_dim, device=dev, requires_grad=True)
+    keep = []
+
+    def fwd():
+        _, h3 = sch(batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+        l23 = sde(h2, batch, anneal_power=0)["position"]
+        keep[:] = [h3, l23]
+
+    for _ in range(2):
+        fwd()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            fwd()
+        run = g.replay
+        how = "hipGraph replay"
+    except Exception as exc:
+        print(f"[bench] forward capture failed ({type(exc).__name__}: {exc}); timing eager", file=sys.stderr)
+        run, how = fwd, "eager"
+    torch.cuda.synchronize()
+    ms = _event_time_ms(run, iters, torch.cuda.current_stream())
+    by, fl = forward_algorithmic(stats, H=trainer.args.emb_dim, D=trainer.args.emb_dim)
+    nbytes, flops = float(sum(by.values())), float(sum(fl.values()))
+    B = stats["B"]
+    t = ms * 1e-3
+    gbs, tf = nbytes / t / 1e9, flops / t / 1e12
+    return {"what": "SchNet + SDEModel2Dto3D_02 forward, training mode, bs %d (%s)" % (B, how), "ms": round(ms, 4),
+            "molecules_per_s_forward_only": round(B / t, 1),
+            "algorithmic_MB": round(nbytes / 1e6, 2), "algorithmic_MB_per_molecule": round(nbytes / 1e6 / B, 4),
+            "algorithmic_GFLOP": round(flops / 1e9, 3), "algorithmic_MFLOP_per_molecule": round(flops / 1e6 / B, 2),
+            "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)},
+            "fp32_flop_floor": {"achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                "frac": round(tf / FP32_MFMA_PEAK_TF, 4)},
+            "us_at_100pct_hbm": round(nbytes / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
+            "us_at_fp32_peak": round(flops / (FP32_MFMA_PEAK_TF * 1e12) * 1e6, 1)}
 
 
 def roofline_dense_head_gemm(batch, iters=30):
@@ -172,36 +265,65 @@ def roofline_dense_head_gemm(batch, iters=30):
             "avg_launch_us": round(ms * 1e3, 2), "shape": [M, N, K]}
 
 
-def cpu_baseline(bs=256, warm=1, timed=3):
-    """The oracle port of the same step (oracle/restate.py, plain PyTorch fp32 on the host cores) on a
-    bounded sample: `timed` steps of one bs-256 synthetic batch after `warm` warm-up steps."""
+def cpu_baseline(bs=256, warm=3, timed=10, budget_s=45.0):
+    """The oracle port of the same step (oracle/restate.py, plain PyTorch fp32 on the host cores):
+    `warm` warm-up + `timed` timed steps of one bs-256 synthetic batch on ALL physical cores, median, with the
+    per-stage split (GIN / SchNet / contrastive / 2D->3D forward, backward, Adam).  Bounded: stops early once
+    `budget_s` of timed work is spent (the number of steps actually timed is reported)."""
     from oracle import restate as R
     from moleculesde_amd.synthetic import make_batch
-    # thousands of small eager ops per step: beyond ~16 threads the per-op barrier dominates, so the
-    # port is timed on min(host cores, 16) threads (the count actually used is what `cores` reports)
-    cores = min(os.cpu_count() or 1, 16)
+    logical = os.cpu_count() or 1
+    try:          # physical cores = distinct (package, core) pairs
+        phys = set()
+        pk = co = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pk = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                co = line.split(":")[1].strip()
+            elif not line.strip():
+                if pk is not None and co is not None:
+                    phys.add((pk, co))
+                pk = co = None
+        cores = len(phys) or logical
+        model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
+    except Exception:
+        cores, model = logical, "?"
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     models = R.build_models(use_3d2d=False)
     opt = R.make_optimizer(models, lr=1e-4, gnn_2d_lr_scale=1.0, gnn_3d_lr_scale=0.1)
     b = make_batch(bs, seed=0)
-    times = []
+    times, stages = [], []
+    spent = 0.0
     for i in range(warm + timed):
-        t0 = time.perf_counter()
-        loss, _ = R.pretrain_losses(models, b, T=0.1, coeff_3d2d=0.0)
+        t = [time.perf_counter()]
+        h2 = models["model_2D"](b.x, b.edge_index, b.edge_attr); t.append(time.perf_counter())
+        _, h3 = models["model_3D"](b.x[:, 0], b.positions, b.batch, return_latent=True); t.append(time.perf_counter())
+        cl, _ = R.dual_CL(h2, h3, 0.1); t.append(time.perf_counter())
+        l23 = models["SDE_2Dto3D_model"](h2, b, anneal_power=0)["position"]; t.append(time.perf_counter())
+        loss = cl + l23
         opt.zero_grad()
-        loss.backward()
-        opt.step()
-        dt = time.perf_counter() - t0
+        loss.backward(); t.append(time.perf_counter())
+        opt.step(); t.append(time.perf_counter())
+        dt = t[-1] - t[0]
         print(f"[cpu_baseline] step {i}: {dt:.2f}s", file=sys.stderr, flush=True)
         if i >= warm:
             times.append(dt)
-        if dt > 15.0 and times:      # keep the default run bounded on slow hosts
-            break
-    med = sorted(times)[len(times) // 2]
+            stages.append([t[k + 1] - t[k] for k in range(6)])
+            spent += dt
+            if spent > budget_s:
+                break
+    order = sorted(range(len(times)), key=lambda k: times[k])
+    mid = order[len(order) // 2]
+    med = times[mid]
+    names = ["GIN_fwd", "SchNet_fwd", "contrastive_fwd", "SDE2Dto3D_fwd", "backward", "Adam"]
     return {"value": round(bs / med, 1), "unit": "molecules/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} timed steps (median) of one bs-{bs} synthetic batch after {warm} warm-up, "
-                      f"oracle/restate.py on torch CPU fp32, {cores} threads", "ms_per_step": round(med * 1e3, 1)}
+                      f"oracle/restate.py on torch CPU fp32, {cores} threads = all physical cores "
+                      f"({logical} logical) of {model}",
+            "ms_per_step": round(med * 1e3, 1),
+            "stage_ms_median_step": {n: round(v * 1e3, 1) for n, v in zip(names, stages[mid])}}
 
 
 def main():
@@ -278,10 +400,17 @@ def main():
     if rank == 0:
         print(f"[bench] {a.steps} steps in {dt:.3f}s", file=sys.stderr, flush=True)
         mols = world * a.batch_size * a.steps
-        roof = roofline_fused_fwd(trainer, pool[0])
-        roof_bwd = roofline_fused_bwd(trainer, pool[0])
-        roof_agg = roofline_cfconv_aggregate(trainer, pool[0])
+        # `roofline` = the kernel with the largest share of the step's GPU time (profiles/*_kernel_stats.csv):
+        # cfconv_fused_bwd_w, timed at the workgroup count the step launches it with; the full-width figures are
+        # kept as separate keys
+        wf, wb = _step_widths(trainer)
+        roof = roofline_fused_bwd(trainer, pool[0], wgs=wb)
+        roof["standalone_full_width"] = roofline_fused_bwd(trainer, pool[0]) if wb else None
+        roof_fwd = roofline_fused_fwd(trainer, pool[0], wgs=wf)
+        roof_fwd["standalone_full_width"] = roofline_fused_fwd(trainer, pool[0]) if wf else None
+        roof_agg = roofline_hbm_kernel(trainer, pool[0])
         roof_head = roofline_dense_head_gemm(pool[0])
+        roof_forward = roofline_forward(trainer, pool[0], stats)
         out = {
             "metric": "molecules/sec pretrain step (SchNet+SDE VE, bs256)",
             "value": round(mols / dt, 1), "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
@@ -295,8 +424,9 @@ def main():
                        if use_graph else "eager", "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                        "loss_scalar": float(trainer.log["2Dto3D"]) / max(trainer.steps, 1)},
             "roofline": roof,
-            "roofline_cfconv_fused_bwd_w": roof_bwd,
-            "roofline_cfconv_aggregate_hbm": roof_agg,
+            "roofline_cfconv_fused_fwd": roof_fwd,
+            "roofline_hbm_message_passing": roof_agg,
+            "roofline_forward_schnet_sde2d3d": roof_forward,
             "roofline_dense_head_gemm": roof_head,
         }
         if world == 1 and not a.no_cpu_baseline:

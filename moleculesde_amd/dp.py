@@ -24,8 +24,10 @@ def init_from_env(device_type="cuda", force=False):
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
-        if device_type == "cuda":
+        # MSDE_DP_BACKEND=gloo on device tensors: how the N>1 trainer step is tested with several ranks sharing ONE
+        # GPU (RCCL refuses two ranks on one device)
+        backend = os.environ.get("MSDE_DP_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
+        if device_type == "cuda" and backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
@@ -52,6 +54,27 @@ def allreduce_mean_(flat):
     if w > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return 1.0 / w
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_buckets_async(flat, ranges, order=None):
+    """One asynchronous all-reduce (sum) per bucket of the flat gradient buffer, issued in `order` (default: the
+    reverse of the buffer order = the order in which the backward pass completes the models' gradients: heads
+    first, encoders last).  Returns (order, works, scale): wait on works[k] before touching bucket order[k]; the
+    waits are stream waits (RCCL) -- the host does not block -- so the optimiser kernel of one bucket runs while
+    the next bucket is on the wire.  xGMI ring collectives are per-link bound: 2-4 buckets of >= 1 MB keep each
+    message in the bandwidth regime while hiding all but the first bucket's latency."""
+    w = world_size()
+    order = list(range(len(ranges) - 1, -1, -1)) if order is None else list(order)
+    works = []
+    live = w > 1 or (FORCE_COLLECTIVES and dist.is_initialized())
+    for i in order:
+        a, b = ranges[i]
+        works.append(dist.all_reduce(flat[a:b], op=dist.ReduceOp.SUM, async_op=True) if (live and b > a) else None)
+    return order, works, 1.0 / w
 
 
 def shard_seed(base_seed, rank):

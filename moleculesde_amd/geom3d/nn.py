@@ -17,7 +17,13 @@ def shifted_softplus(x):
     return F.softplus(x) - _LN2
 
 
-USE_HIP_LINEAR = True   # False routes dense layers to the vendor GEMM (A/B measurements only)
+USE_HIP_LINEAR = True   # False routes dense layers to the vendor GEMM ON THE DEVICE (A/B measurements only)
+
+
+def _need_device(x):
+    """The product has no CPU path: a host tensor is an error, not a silent torch fallback."""
+    if not x.is_cuda:
+        raise hip._lib.MsdeHipError("moleculesde_amd modules need tensors on the HIP device (no CPU fallback)")
 
 
 class Linear(nn.Linear):
@@ -28,13 +34,15 @@ class Linear(nn.Linear):
     shared = False
 
     def forward(self, x):
-        if USE_HIP_LINEAR and x.is_cuda:
+        _need_device(x)
+        if USE_HIP_LINEAR:
             return hip.linear(x, self.weight, self.bias, offload=not self.shared)
         return F.linear(x, self.weight, self.bias)
 
     def fork(self, x):
         """(x, self(x)) for blocks that also feed x to a residual: see hip.linear_fork."""
-        if USE_HIP_LINEAR and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+        _need_device(x)
+        if USE_HIP_LINEAR and torch.is_grad_enabled() and x.requires_grad:
             return hip.linear_fork(x, self.weight, self.bias, not self.shared)
         return x, self.forward(x)
 
@@ -61,7 +69,8 @@ class BatchNorm1d(nn.BatchNorm1d):
         self.pending_batches = 0
 
     def forward(self, x):
-        if not (USE_HIP_LINEAR and x.is_cuda and x.dim() == 2):
+        _need_device(x)
+        if not (USE_HIP_LINEAR and x.dim() == 2):
             y = super().forward(x)
             return F.relu(y) if self.fuse_relu else y
         if self.training or not self.track_running_stats:
@@ -81,13 +90,15 @@ class BatchNorm1d(nn.BatchNorm1d):
 
 
 def linear(x, weight, bias=None):
-    if USE_HIP_LINEAR and x.is_cuda:
+    _need_device(x)
+    if USE_HIP_LINEAR:
         return hip.linear(x, weight, bias)
     return F.linear(x, weight, bias)
 
 
 def linear_fork(x, weight, bias=None):
-    if USE_HIP_LINEAR and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+    _need_device(x)
+    if USE_HIP_LINEAR and torch.is_grad_enabled() and x.requires_grad:
         return hip.linear_fork(x, weight, bias)
     return x, linear(x, weight, bias)
 
@@ -140,7 +151,7 @@ class EmbeddingList(nn.Module):
     def table(self):
         """Concatenated [sum(dims), D] table, the layout the kernels index with pre-offset codes."""
         ws = [e.weight for e in getattr(self, self._list_name)]
-        return hip.cat_params(ws) if ws[0].is_cuda else torch.cat(ws, dim=0)
+        return hip.cat_params(ws)
 
     def fusion_sets(self):
         """Parameters that want to be adjacent in the optimiser's flat buffer (then table() is a free view)."""

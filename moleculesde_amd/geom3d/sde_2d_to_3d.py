@@ -54,10 +54,7 @@ class TransformerConv(nn.Module):
     def forward(self, x, edge_attr, plan, seed, seed_dev=None, ee_all=None, col=0, shared=None):
         # one projection GEMM for query | key | value | skip (they share the input x)
         Ws, bs = self.fusion_sets()
-        if x.is_cuda:
-            W, b = hip.cat_params(Ws), hip.cat_params(bs)     # free views once FlatAdam has laid them out back to back
-        else:
-            W, b = torch.cat(Ws, dim=0), torch.cat(bs, dim=0)
+        W, b = hip.cat_params(Ws), hip.cat_params(bs)     # free views once FlatAdam has laid them out back to back
         x_res, qkvs = _nn.linear_fork(x, W, b)      # x also feeds the caller's residual
         p = self.dropout if self.training else 0.0
         if ee_all is not None:           # lin_edge of all layers evaluated as one GEMM by the caller
@@ -81,11 +78,11 @@ class GATLayer(nn.Module):
         (equivariant_scorenetwork.py:142) inside the layer, so it can ride in the fused kernel."""
         node_attr, x = self.MHA(node_attr, edge_attr, plan, seed, seed_dev, ee_all, col, shared)
         p = self.FFN[2].p if self.training else 0.0
-        if x.is_cuda and x.size(-1) == 32 and FUSE_GAT_TAIL:
+        if x.size(-1) == 32 and FUSE_GAT_TAIL:
             # LayerNorm + residual, feed-forward, LayerNorm + residual (+ SiLU): one kernel each way
             return hip.gat_tail(x, node_attr, self.norm1, self.FFN[0], self.FFN[3], self.norm2, p, seed ^ 0x46464E,
                                 seed_dev, silu_out)
-        if x.is_cuda and x.size(-1) % 4 == 0:
+        if x.size(-1) % 4 == 0:
             node_attr = hip.res_layernorm(x, node_attr, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             # FFN = Linear -> SiLU -> Dropout -> Linear with the two pointwise stages in one kernel
             node_attr, f0 = self.FFN[0].fork(node_attr)
@@ -134,9 +131,8 @@ class EquivariantScoreNetwork(nn.Module):
         conv_input = node_attr
         gradient = None
         ee_all, shared, D = None, None, self.hidden_dim
-        if edge_attr.is_cuda:
-            ee_all = _nn.linear(edge_attr, hip.cat_params(self.fusion_sets()[0]))       # [E, layers*D]
-            shared = {}
+        ee_all = _nn.linear(edge_attr, hip.cat_params(self.fusion_sets()[0]))       # [E, layers*D]
+        shared = {}
         layer_no = 0
         if self.seed_dev is None:
             self._calls += 1     # eager: host-side call counter; graph mode: the device counter varies the mask
@@ -205,7 +201,7 @@ class SDEModel2Dto3D_02(nn.Module):
         """Start the coordinate-only branch: on the side stream if the trainer gave us one (it is independent of
         the 2D representation, so it runs beside the GIN encoder / the 2D-embedding branch; autograd mirrors the
         overlap in the backward), else inline.  Returns (tensors, side stream used or None)."""
-        side = self.side_stream if (self.side_stream is not None and pos_perturbed.is_cuda) else None
+        side = self.side_stream
         if side is not None:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -224,7 +220,7 @@ class SDEModel2Dto3D_02(nn.Module):
         T = self.num_diffusion_timesteps
         pos_noise = self.noise.randn_like(pos)
         draws = self.noise.randint(T, (B // 2 + 1,), pos.device)
-        if pos.is_cuda and self.SDE_type == "VE" and draws.dtype == torch.int64:
+        if self.SDE_type == "VE" and draws.dtype == torch.int64:
             pos_perturbed, std_pos = hip.ve_perturb(pos, pos_noise, draws, pl.batch_i32, B, T, EPSILON,
                                                     self.sde_pos.sigma_min, self.sde_pos.sigma_max)
         else:

@@ -188,6 +188,7 @@ def _cf_workspace(E_cap, G, device, max_wgs=0):
     device = _ws_key(device)
     ws = _CF_WS.get(device)
     if ws is None or ws.numel() < n:
+        _retire([ws])
         ws = torch.empty(n, dtype=torch.float32, device=device[0])
         _CF_WS[device] = ws
     return ws
@@ -597,6 +598,8 @@ class _EdgeAttentionFused(torch.autograd.Function):
         ctx.save_for_backward(qkvs, ee, alpha)
         ctx.plan, ctx.heads, ctx.p_drop, ctx.seed, ctx.seed_dev = plan, heads, float(p_drop), int(seed), seed_dev
         ctx.col, ctx.shared = col, shared
+        if shared is not None and col == 0:
+            shared.clear()       # a backward pass that aborted midway must not leave a stale gradient buffer behind
         return out
 
     @staticmethod
@@ -721,6 +724,24 @@ _WS = {}          # per-device wgrad slab workspace, grown on demand (stream-ord
 _WS_BYTES = {}    # (M, N, K) -> workspace bytes
 
 
+# Grow-on-demand workspaces and captured hipGraphs: a captured graph has the raw addresses of the workspaces it was
+# captured with baked in.  Once any capture has happened (note_capture) an outgrown workspace is therefore never
+# freed -- it is parked in _KEEP_ALIVE for the life of the process -- so a replay can never write into memory the
+# caching allocator has handed to someone else.
+_KEEP_ALIVE = []
+_CAPTURED = False
+
+
+def note_capture():
+    global _CAPTURED
+    _CAPTURED = True
+
+
+def _retire(bufs):
+    if _CAPTURED:
+        _KEEP_ALIVE.extend(b for b in bufs if b is not None)
+
+
 _SCRATCH = {}     # per-(device, stream) scratch of the table-gradient kernels
 EMB_BWD_SPLIT = 64   # max slices per table row in msde_embedding_sum_bwd
 
@@ -729,6 +750,7 @@ def _scratch(nfloats, device):
     key = _ws_key(device)
     ws = _SCRATCH.get(key)
     if ws is None or ws.numel() < nfloats:
+        _retire([ws])
         ws = torch.empty(max(nfloats, 1 << 20), dtype=torch.float32, device=key[0])
         _SCRATCH[key] = ws
     return ws
@@ -748,6 +770,7 @@ def _wgrad_workspace(M, N, K, device):
     device = _ws_key(device)
     ws = _WS.get(device)
     if ws is None or ws.numel() * 4 < nbytes:
+        _retire([ws])
         ws = torch.empty(max(nbytes // 4, 1 << 20), dtype=torch.float32, device=device[0])
         _WS[device] = ws
     return ws
@@ -805,6 +828,7 @@ def flush_table_uploads():
 
 class _SlabBatch:
     MAX_ROWS = 4096
+    EAGER_SLOTS = 3
 
     def __init__(self):
         self.active = False
@@ -814,7 +838,10 @@ class _SlabBatch:
         self.gemms = []          # queued weight-gradient GEMMs: (gY, X, M, N, K, has_bias, slab) -- inputs kept alive
         self.retired = []        # outgrown arenas still referenced by queued rows
         self.slot = None
-        self.slots = []
+        self.slots = []          # slots 0..EAGER_SLOTS-1: the eager ring; one more per captured hipGraph
+        self.events = []         # per slot: event recorded behind the last upload of its pinned host images
+        self.slot_i = -1
+        self.eager_i = 0
 
     def new_slot(self, device):
         """Pinned host image + device copy of the row / prefix tables (one per captured graph: the upload is a
@@ -828,12 +855,41 @@ class _SlabBatch:
                      host_prob, host_ppre, torch.zeros(self.MAX_ROWS, 12, dtype=torch.int64, device=device),
                      torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device))
         self.slots.append(self.slot)
+        self.events.append(None)
+        self.slot_i = len(self.slots) - 1
 
-    def begin(self):
+    def _ensure_eager_ring(self, device):
+        while len(self.slots) < self.EAGER_SLOTS:
+            self.new_slot(device)
+
+    def _rotate_eager(self, device):
+        """Eager backward pass: take the next slot of the ring and wait for the copies that last read its pinned host
+        images (the GPU may be several steps behind the host: rewriting a pinned table it has not fetched yet would
+        hand the earlier step the later step's slab / gradient addresses)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self.slot_i >= self.EAGER_SLOTS and self.slot is not None and self.slot[2].device == device:
+            return                   # a capture slot was selected explicitly (new_param_grad_slot)
+        self._ensure_eager_ring(device)
+        self.eager_i = (self.eager_i + 1) % self.EAGER_SLOTS
+        self.slot, self.slot_i = self.slots[self.eager_i], self.eager_i
+        ev = self.events[self.slot_i]
+        if ev is not None:
+            ev.synchronize()
+
+    def begin(self, check_params=None):
         assert not self.rows, "finish_param_grad_batch() was not called after the previous backward"
+        if check_params is not None:
+            # the deferred reduction hands autograd gradient buffers that are filled only at finish(): that is sound
+            # only when AccumulateGrad STEALS them, i.e. when no .grad exists yet (no gradient accumulation)
+            for p in check_params:
+                if p.grad is not None:
+                    raise _lib.MsdeHipError("begin_param_grad_batch(): a parameter already has a .grad; the batched "
+                                            "slab reduction needs zero_grad(set_to_none=True) before every backward")
         self.active = True
         self.used = 0
         self.prob_used = self.pre_used = 0
+        self.rotated = False
 
     def alloc(self, nfloats, device):
         nfloats = (nfloats + 3) & ~3
@@ -862,8 +918,7 @@ class _SlabBatch:
         if not self.gemms:
             return
         dev = self.gemms[0][0].device
-        if self.slot is None or self.slot[2].device != dev:
-            self.new_slot(dev)
+        self._select_slot(dev)
         host_prob, host_ppre, dev_prob, dev_ppre = self.slot[4:]
         lib = _lib.load()
         r0, q0, ng = self.prob_used, self.pre_used, len(self.gemms)
@@ -892,8 +947,7 @@ class _SlabBatch:
             return
         assert len(rows) <= self.MAX_ROWS
         dev = rows[0][4]
-        if self.slot is None or self.slot[2].device != dev:
-            self.new_slot(dev)
+        self._select_slot(dev)
         self.launch_gemms()          # the (still) queued weight-gradient GEMMs as one grouped launch
         host_rows, host_pre, dev_rows, dev_pre = self.slot[:4]
         hr, hp = host_rows.numpy(), host_pre.numpy()
@@ -906,8 +960,21 @@ class _SlabBatch:
         upload_table(dev_rows[:len(rows)], host_rows[:len(rows)])
         upload_table(dev_pre[:len(rows) + 1], host_pre[:len(rows) + 1])
         _lib.call("msde_reduce_slabs_multi", _p(dev_rows), _p(dev_pre), len(rows), total, _stream())
+        if not torch.cuda.is_current_stream_capturing():
+            ev = self.events[self.slot_i] or torch.cuda.Event()
+            ev.record()
+            self.events[self.slot_i] = ev
         self.rows = []
+        _retire(self.retired)
         self.retired = []
+
+    def _select_slot(self, dev):
+        """Once per backward pass: the table slot its uploads go to (eager ring, or the capture's own slot)."""
+        if not self.rotated:
+            self._rotate_eager(dev)
+            self.rotated = True
+        if self.slot is None or self.slot[2].device != dev:
+            self.new_slot(dev)
 
 
 GROUPED_WGRAD = _os.environ.get("MSDE_GROUPED_WGRAD", "1") != "0"   # queued GEMMs -> one grouped launch at finish()
@@ -915,8 +982,9 @@ _SLABS = _SlabBatch()
 _SPLITS = {}
 
 
-def begin_param_grad_batch():
-    _SLABS.begin()
+def begin_param_grad_batch(params=None):
+    """params: the parameters of the step (optional); each must have .grad None (see _SlabBatch.begin)."""
+    _SLABS.begin(params)
 
 
 def flush_wgrad_gemms():
@@ -934,15 +1002,15 @@ def finish_param_grad_batch():
 
 def new_param_grad_slot(device):
     """Before a hipGraph capture: give the graph its own table slot (see _SlabBatch.new_slot)."""
-    if not _SLABS.slots:
-        _SLABS.new_slot(device)          # slot 0 stays the eager slot
+    _SLABS._ensure_eager_ring(device)    # slots 0..EAGER_SLOTS-1 stay the eager ring
     _SLABS.new_slot(device)
+    note_capture()
 
 
 def use_eager_param_grad_slot():
     """After a capture: eager steps must not overwrite the host tables a captured graph re-reads."""
     if _SLABS.slots:
-        _SLABS.slot = _SLABS.slots[0]
+        _SLABS.slot, _SLABS.slot_i = _SLABS.slots[_SLABS.eager_i], _SLABS.eager_i
 
 
 def weight_grad(g2, x2, has_bias, deferrable=True):
@@ -1105,6 +1173,7 @@ def _bn_workspace(M, C, device):
     device = _ws_key(device)
     ws = _BN_WS.get(device)
     if ws is None or ws.numel() < n:
+        _retire([ws])
         ws = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=device[0])
         _BN_WS[device] = ws
     return ws

@@ -16,6 +16,8 @@ from . import hip
 
 
 class FlatAdam:
+    EAGER_SLOTS = 3
+
     def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         """groups: list of {"params": iterable of Parameters, "lr": float}."""
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
@@ -61,11 +63,21 @@ class FlatAdam:
                                        dtype=torch.int64)
         self._chunk_cnt = torch.tensor([min(ch, n - c * ch) for n, nc in zip(self.sizes, self._chunks_per_param)
                                         for c in range(nc)], dtype=torch.int64)
-        self._slots = []
-        self.new_table_slot()
+        # Slots 0..EAGER_SLOTS-1 form the eager ring (a pinned host image is rewritten only after the event recorded
+        # behind its last upload has completed, so a GPU that runs several steps behind the host never sees the next
+        # step's addresses); every captured hipGraph gets one more slot of its own.
+        self._slots, self._events, self._eager_i = [], [], 0
+        for _ in range(self.EAGER_SLOTS):
+            self.new_table_slot()
+        self._slot, self._slot_i = self._slots[0], 0
         self.seg_end = torch.tensor(seg_end, dtype=torch.int64, device=dev)
         self.seg_lr = torch.tensor(seg_lr, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        # data-parallel buckets = the param groups (one model each), as [begin, end) ranges of the flat buffers
+        self.bucket_ranges = [(0 if i == 0 else seg_end[i - 1], seg_end[i]) for i in range(len(seg_end))]
+        self._bucket_seg = [(torch.tensor([b - a], dtype=torch.int64, device=dev),
+                             torch.tensor([seg_lr[i]], dtype=torch.float32, device=dev))
+                            for i, (a, b) in enumerate(self.bucket_ranges)]
 
     def zero_grad(self):
         for p in self.params:
@@ -81,14 +93,24 @@ class FlatAdam:
         host[:, 2] = self._chunk_cnt
         self._slot = (host, torch.empty(self.n_chunks, 3, dtype=torch.int64, device=self.flat_p.device))
         self._slots.append(self._slot)
+        self._events.append(None)
+        self._slot_i = len(self._slots) - 1
 
     def use_eager_slot(self):
         """After a capture: eager steps go back to slot 0 so that they never overwrite the host image a captured
         graph re-reads at every replay."""
-        self._slot = self._slots[0]
+        self._slot, self._slot_i = self._slots[self._eager_i], self._eager_i
 
     def _chunk_table(self):
         """Device table of (gradient chunk address, flat offset, count) for the current .grad tensors."""
+        capturing = torch.cuda.is_current_stream_capturing() if self.flat_p.is_cuda else False
+        if not capturing and self._slot_i < self.EAGER_SLOTS:
+            # eager: next slot of the ring; wait until the copy that last read its pinned image is done
+            self._eager_i = (self._eager_i + 1) % self.EAGER_SLOTS
+            self._slot, self._slot_i = self._slots[self._eager_i], self._eager_i
+            ev = self._events[self._slot_i]
+            if ev is not None:
+                ev.synchronize()
         host, dev = self._slot
         col = host[:, 0].numpy()
         self._grad_keep = []
@@ -104,6 +126,10 @@ class FlatAdam:
                 col[r:r + nc] = g.data_ptr() + self._chunk_bytes[:nc]
             r += nc
         hip.upload_table(dev, host)        # recorded (not captured) while a hipGraph is being captured
+        if not capturing and self.flat_p.is_cuda:
+            ev = self._events[self._slot_i] or torch.cuda.Event()
+            ev.record()
+            self._events[self._slot_i] = ev
         return dev, self.n_chunks
 
     def gather_grads(self):
@@ -118,6 +144,20 @@ class FlatAdam:
         flat_g) already happened."""
         self.step_dev.add_(1)
         hip.adam_flat(self.flat_p, self.flat_g, self.m, self.v, self.step_dev, self.seg_end, self.seg_lr,
+                      self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)
+
+    def begin_bucket_step(self):
+        """Bucketed form of step(): call once, then step_bucket(i) for every bucket (any order, each once)."""
+        self.step_dev.add_(1)
+
+    def step_bucket(self, i, grad_scale=1.0):
+        """Adam on bucket i (= param group i) of the flat buffers only: lets the optimiser start on a bucket whose
+        all-reduce has finished while the next bucket is still on the wire."""
+        a, b = self.bucket_ranges[i]
+        if b <= a:
+            return
+        seg_end, seg_lr = self._bucket_seg[i]
+        hip.adam_flat(self.flat_p[a:b], self.flat_g[a:b], self.m[a:b], self.v[a:b], self.step_dev, seg_end, seg_lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)
 
     def step_from_grads(self, grad_scale=1.0):

@@ -182,7 +182,16 @@ class Trainer:
         self.models = build_models(args, device)
         self.opt = make_optimizer(args, self.models)
         dp.broadcast_flat(self.opt.flat_p)
-        self.noise = noise or _nn.DeviceNoise()
+        # Replicas start from rank 0's parameters but must draw DIFFERENT noise (position noise, time steps,
+        # contrastive negatives, dropout masks): fold the rank into every random stream, as dp.shard_seed does for
+        # the data.  (Parameters are already broadcast, so reseeding torch here does not desynchronise them.)
+        r = dp.rank()
+        self.dp_enabled = True            # False: ignore the process group (single-replica reference runs in DP tests)
+        self.dp_buckets = int(os.environ.get("MSDE_DP_BUCKETS", "1")) != 0
+        if r:
+            torch.manual_seed(torch.initial_seed() + 7919 * r)
+        self.noise = noise or _nn.DeviceNoise(seed=0x5EED + 7919 * r)
+        self.models["SDE_2Dto3D_model"].score_network._seed_base += 0x10001 * r
         self.models["SDE_2Dto3D_model"].noise = self.noise
         if "SDE_3Dto2D_model" in self.models:
             self.models["SDE_3Dto2D_model"].noise = self.noise
@@ -297,7 +306,7 @@ class Trainer:
             if not BATCH_SLAB_REDUCE:
                 loss.backward()
                 return
-            hip.begin_param_grad_batch()
+            hip.begin_param_grad_batch(self.opt.params)
             try:
                 loss.backward()
             finally:
@@ -305,14 +314,31 @@ class Trainer:
         finally:
             self._side_geometry(False)
 
+    def _use_dp(self):
+        return self.dp_enabled and (dp.world_size() > 1 or dp.FORCE_COLLECTIVES)
+
+    def _allreduce_and_adam(self):
+        """Data-parallel tail of a step: the flat gradient is all-reduced per bucket (= per model, heads first) and
+        each bucket's Adam starts as soon as ITS reduction is done, while the next bucket is still on the wire."""
+        if not self.dp_buckets:
+            scale = dp.allreduce_mean_(self.opt.flat_g)
+            self.opt.step(grad_scale=scale)
+            return
+        order, works, scale = dp.allreduce_buckets_async(self.opt.flat_g, self.opt.bucket_ranges)
+        self.opt.begin_bucket_step()
+        for i, w in zip(order, works):
+            if w is not None:
+                w.wait()                  # stream wait: the host does not block
+            self.opt.step_bucket(i, grad_scale=scale)
+
     def step(self, batch):
+        self.step_counter.add_(1)         # the device step counter re-seeds dropout / negatives once a capture set it
         loss, parts = self.losses(batch)
         self.opt.zero_grad()
         self._backward(loss)
-        if dp.world_size() > 1 or dp.FORCE_COLLECTIVES:
-            flat_g = self.opt.gather_grads()
-            scale = dp.allreduce_mean_(flat_g)
-            self.opt.step(grad_scale=scale)
+        if self._use_dp():
+            self.opt.gather_grads()
+            self._allreduce_and_adam()
         else:
             self.opt.step_from_grads()
         self._log_parts(parts)
@@ -337,8 +363,8 @@ class Trainer:
         one eager step on a batch of the same shape (sizes workspaces, sets kernel attributes)."""
         key = id(batch)
         if key in self._graphs:
-            return self._graphs[key]
-        with_adam = dp.world_size() == 1 and not self.adam_outside_graph
+            return self._graphs[key][0]
+        with_adam = not self._use_dp() and not self.adam_outside_graph
         sd = self.step_counter.view(torch.int64)
         self.models["SDE_2Dto3D_model"].score_network.seed_dev = sd
         if hasattr(self.noise, "seed_dev"):
@@ -357,19 +383,24 @@ class Trainer:
         _hip.flush_table_uploads()      # the graph's pointer tables: uploaded once, not at every replay
         self.opt.use_eager_slot()
         _hip.use_eager_param_grad_slot()
-        self._graphs[key] = g
+        # the captured batch is held strongly: its tensors' addresses are baked into the graph, and a live reference
+        # keeps id(batch) from being recycled for a different batch
+        self._graphs[key] = (g, batch, with_adam)
         self._graph_loss[key] = loss
         return g
 
     def step_graph(self, batch):
         """Replay the captured step; under DP the all-reduce and Adam run after the replay."""
-        g = self._graphs[id(batch)]
+        g, held, with_adam = self._graphs[id(batch)]
+        assert held is batch
         g.replay()
         for bn in self._bn_modules:
             bn.pending_batches += 1        # the captured forward does not run Python: count its BatchNorm calls here
-        if dp.world_size() > 1 or self.adam_outside_graph:
-            scale = dp.allreduce_mean_(self.opt.flat_g)
-            self.opt.step(grad_scale=scale)
+        if not with_adam:
+            if self._use_dp():
+                self._allreduce_and_adam()
+            else:
+                self.opt.step()
         self.steps += 1
         return self._graph_loss[id(batch)]
 

@@ -601,3 +601,83 @@ def test_fusion_sets_alias_flat_parameters(dev):
     keys = set(tr.models["SDE_2Dto3D_model"].state_dict().keys())
     assert "score_network.gnn_layers.0.0.MHA.lin_query.weight" in keys and "edge_2D_emb.0.weight" in keys
     assert not any(k.startswith("_zero_bias") for k in keys)
+
+
+# ------------------------------------------------- reference-generated 20-step curve through the HIP trainer ---
+def test_golden_losscurve_through_hip_trainer(dev):
+    """tests/golden/losscurve.npz was produced by the REFERENCE's own model files (oracle/make_golden.py): 20 Adam
+    steps, bs 8, all three losses, dropout off, noise from torch.manual_seed(seed_base + step).  The product
+    Trainer (HIP kernels, flat HIP Adam) replays it with CpuReplayNoise: every loss term of every step within the
+    north star's 1e-3 relative -- flat, no noise-floor allowance."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import pretrain
+    g = load_golden("losscurve.npz")
+    args = pretrain.readme_args(emb_dim=32, num_layer=3, SchNet_num_filters=32, SchNet_num_interactions=2, lr=1e-3,
+                                gnn_2d_lr_scale=1.0, gnn_3d_lr_scale=0.1)
+    assert [args.lr * s for s in (1.0, 0.1, 1.0, 0.1)] == pytest.approx(list(g["lrs"]))
+    torch.manual_seed(0)
+    tr = pretrain.Trainer(args, dev)
+    for k, m in tr.models.items():
+        m.load_state_dict(sub(g, k + ".sd."))
+        disable_dropout(m)
+    b = G.prepare_batch(batch_from(g), dev)
+    curve = []
+    for step in range(20):
+        tr.noise = G.CpuReplayNoise(int(g["seed_base"]) + step)
+        tr.models["SDE_2Dto3D_model"].noise = tr.noise
+        tr.models["SDE_3Dto2D_model"].noise = tr.noise
+        loss, parts = tr.step(b)
+        curve.append([float(loss), float(parts["CL"]), float(parts["2Dto3D"]), float(parts["3Dto2D"])])
+    curve = np.array(curve)
+    rel = np.abs(curve - g["curve"]) / np.abs(g["curve"])
+    print("reference-generated loss curve through the HIP trainer: max rel err per column", rel.max(axis=0))
+    assert rel.max() < 1e-3, (rel.max(axis=0), rel.argmax())
+
+
+def test_checkpoint_round_trip_reference_layout(dev, tmp_path):
+    """pretrain_MoleculeSDE.py:78-88: `model_complete.pth` = {'model_2D','model_3D','SDE_2Dto3D_model',
+    'SDE_3Dto2D_model'} state dicts with the reference's keys.  Save from a trained-for-two-steps HIP Trainer, load
+    into (a) the oracle classes (= the reference's key layout, strict) and (b) a fresh Trainer: identical tensors,
+    identical next-step loss; finetune-style partial load (finetune_MD17.py:145-164 reads 'model_3D') works."""
+    import json
+    import os
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import pretrain
+    from moleculesde_amd.synthetic import make_batch
+    args = pretrain.readme_args(emb_dim=64)
+    torch.manual_seed(6)
+    tr = pretrain.Trainer(args, dev)
+    b = G.prepare_batch(make_batch(16, seed=21), dev)
+    for _ in range(2):
+        tr.step(b)
+    path = str(tmp_path / "model_complete.pth")
+    tr.save(path)
+    ck = torch.load(path, map_location="cpu")
+    assert list(ck.keys()) == ["model_2D", "model_3D", "SDE_2Dto3D_model", "SDE_3Dto2D_model"]
+    om = R.build_models(emb_dim=64, use_3d2d=True)
+    for k in ck:
+        om[k].load_state_dict(ck[k], strict=True)              # reference key layout, every key, every shape
+    inv = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "inventory.json")))
+    for k in ck:                                                 # same key ORDER as the reference at any width
+        assert list(ck[k].keys()) == list(inv[k]["state_dict"].keys()), k
+    # BatchNorm step counters were folded into the checkpoint (2 training-mode forwards)
+    assert int(ck["model_2D"]["batch_norms.0.num_batches_tracked"]) == 2
+    torch.manual_seed(7)
+    tr2 = pretrain.Trainer(args, dev)
+    for k in ck:
+        tr2.models[k].load_state_dict(ck[k], strict=True)
+    for k in ck:
+        for n, v in tr.models[k].state_dict().items():
+            assert torch.equal(v.cpu(), tr2.models[k].state_dict()[n].cpu()), (k, n)
+    for t in (tr, tr2):
+        for m in t.models.values():
+            disable_dropout(m)
+        t.noise = G.CpuReplayNoise(9)
+        t.models["SDE_2Dto3D_model"].noise = t.noise
+        t.models["SDE_3Dto2D_model"].noise = t.noise
+    l1, _ = tr.losses(b)
+    l2, _ = tr2.losses(b)
+    assert_close(l2, l1.detach(), 1e-6, 0, "loss after reload")
+    sch = G.SchNet(hidden_channels=64, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10, readout="mean",
+                   node_class=119)
+    sch.load_state_dict(ck["model_3D"])                         # finetune_MD17.py:151

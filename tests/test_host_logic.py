@@ -164,7 +164,12 @@ def test_state_dict_surface_matches_reference_inventory():
                               readout="mean", node_class=119),
          "SDE_2Dto3D_model": G.SDEModel2Dto3D_02(emb_dim=300, hidden_dim=32, beta_min=0.2, beta_max=1.0,
                                                  num_diffusion_timesteps=1000, beta_schedule=None, SDE_type="VE",
-                                                 use_extend_graph=True)}
+                                                 use_extend_graph=True),
+         "SDE_3Dto2D_model": G.SDEModel3Dto2D_node_adj_dense(
+             dim3D=300, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=16, nhid=16, num_layers=4, emb_dim=300,
+             num_linears=3, beta_min=0.1, beta_max=1.0, num_diffusion_timesteps=1000, SDE_type="VE", num_class_X=119,
+             noise_on_one_hot=True)}
+    assert set(m) == set(inv)
     for k, mod in m.items():
         sd = mod.state_dict()
         assert list(sd.keys()) == list(inv[k]["state_dict"].keys()), k

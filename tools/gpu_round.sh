@@ -1,0 +1,39 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, bench lines, RCCL 1-rank log, rocprofv3 stats + PMC passes.
+# usage: tools/gpu_round.sh <tag> [tests|bench|prof|pmc|dp ...]   (default: all)
+TAG=${1:-r02}; shift
+WHAT=${@:-tests bench dp prof pmc}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+for w in $WHAT; do
+case $w in
+tests)
+  timeout 1500 python -m pytest tests -m gpu -x -q -s > $O/gputest.log 2>&1; echo "gputest rc=$?" | tee -a $O/gputest.log; tail -5 $O/gputest.log;;
+bench)
+  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cat $O/bench.json
+  timeout 600 python bench.py --full --no_cpu_baseline > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"; cat $O/bench_full.json;;
+dp)
+  timeout 600 python bench.py --debug_dp_path --no_cpu_baseline > $O/bench_dp1.json 2> $O/bench_dp1.err; echo "dp rc=$?"; cat $O/bench_dp1.json; tail -3 $O/bench_dp1.err
+  timeout 600 python bench.py --debug_dp_path --full --no_cpu_baseline > $O/bench_dp1_full.json 2> $O/bench_dp1_full.err; echo "dp full rc=$?"; cat $O/bench_dp1_full.json;;
+prof)
+  cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o run -- python3 $R/bench.py --no_cpu_baseline > $O/prof_bench.json 2> $O/prof.log; echo "prof rc=$?"
+  timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_full -o run -- python3 $R/bench.py --full --no_cpu_baseline > $O/prof_full_bench.json 2> $O/prof_full.log; echo "prof full rc=$?"
+  cd $R;;
+pmc)
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+  done
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $O/pmc_SQ -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_SQ2 -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_SQ2.log 2>&1; echo "pmc SQ2 rc=$?"
+  cd $R
+  find $O -name "*counter_collection.csv" | head
+  # trim the big traces before they are merged back (keep stats + counters)
+  find $O -name "*kernel_trace.csv" -size +8M -delete;;
+esac
+done
+du -sh $O

@@ -1,41 +1,50 @@
-"""Summarise rocprofv3 --pmc counter_collection CSVs (one counter per pass) into
-profiles/r01_pmc_<COUNTER>_cfconv.csv and profiles/r01_pmc_traffic.json.
-Usage: python tools/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv>"""
+"""Summarise rocprofv3 --pmc counter_collection CSVs (any number of passes) into profiles/<tag>_pmc_counters.json:
+per kernel (name substring match), per counter: launches, median / min / max of the per-dispatch value (summed over
+XCDs / instances, as rocprofv3 reports one row per instance).
+
+    python tools/pmc_summary.py <tag> <shape json> <csv> [<csv> ...]
+
+FETCH_SIZE / WRITE_SIZE are in KB; HBM-side bytes per launch follow MI355X_MICROARCH.md: FETCH_SIZE x 2 for kernels
+that read with 16-B-per-lane coalesced loads (gfx950 counts 128-B requests as 64 B), raw for other widths
+(uncalibrated), WRITE_SIZE as is."""
 import csv, json, statistics, sys, collections, os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"cfconv_aggregate_fwd_kernel": "void cfconv_aggregate_fwd_kernel<4>", "cfconv_fused_fwd_kernel": "void cfconv_fused_fwd_kernel<26>"}
-
-
-def per_kernel(path, counter):
-    vals = collections.defaultdict(lambda: collections.defaultdict(float))
-    with open(path) as f:
-        for r in csv.DictReader(f):
-            if r.get("Counter_Name") != counter:
-                continue
-            name = r["Kernel_Name"]
-            for short, full in KERNELS.items():
-                if short in name:
-                    vals[short][r["Dispatch_Id"]] += float(r["Counter_Value"])     # summed over XCDs / instances
-    return {k: sorted(v.values()) for k, v in vals.items()}
+KERNELS = ["cfconv_fused_fwd_kernel", "cfconv_fused_bwd_w_kernel", "cfconv_aggregate_bwd_x_kernel", "dense_edge_layer",
+           "dense_node", "dense_mlp", "dense_pair", "gemm_f32_mfma_kernel", "edge_attention_fwd", "gin_aggregate_fwd"]
+WIDE_READS = {"cfconv_aggregate_bwd_x_kernel", "gin_aggregate_fwd", "edge_attention_fwd"}     # float4 row gathers
 
 
 def main():
-    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-    write = per_kernel(sys.argv[2], "WRITE_SIZE")
-    for counter, data in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-        with open(os.path.join(ROOT, "profiles", f"r01_pmc_{counter}_cfconv.csv"), "w") as f:
-            f.write("kernel,counter,launches,median_value_KB,min,max\n")
-            for k, v in data.items():
-                f.write(f'"{KERNELS[k]}",{counter},{len(v)},{statistics.median(v)},{min(v)},{max(v)}\n')
-    out = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-    fa, wa = statistics.median(fetch["cfconv_aggregate_fwd_kernel"]), statistics.median(write["cfconv_aggregate_fwd_kernel"])
-    ff, wf = statistics.median(fetch["cfconv_fused_fwd_kernel"]), statistics.median(write["cfconv_fused_fwd_kernel"])
-    out["cfconv_aggregate_fwd_kernel"] = {"fetch_kb_raw": fa, "write_kb": wa, "traffic_bytes": int((2 * fa + wa) * 1024)}
-    out["cfconv_fused_fwd_kernel"].update({"fetch_kb_raw": ff, "write_kb": wf, "traffic_bytes": int((ff + wf) * 1024),
-                                           "traffic_bytes_if_doubled": int((2 * ff + wf) * 1024)})
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    tag, shape = sys.argv[1], json.loads(sys.argv[2])
+    vals = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    grid = {}
+    for path in sys.argv[3:]:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name = r["Kernel_Name"]
+                for k in KERNELS:
+                    if k in name:
+                        key = f'{k}[grid={r["Grid_Size"]}]'
+                        vals[key][r["Counter_Name"]][(path, r["Dispatch_Id"])] += float(r["Counter_Value"])
+    out = {"_note": __doc__.split("\n\n")[-1].replace("\n", " "), "shape": shape}
+    for k, counters in sorted(vals.items()):
+        ent = {}
+        for c, d in sorted(counters.items()):
+            v = sorted(d.values())
+            ent[c] = {"launches": len(v), "median": statistics.median(v), "min": v[0], "max": v[-1]}
+        base = k.split("[")[0]
+        if "FETCH_SIZE" in ent and "WRITE_SIZE" in ent:
+            f_kb, w_kb = ent["FETCH_SIZE"]["median"], ent["WRITE_SIZE"]["median"]
+            mult = 2 if base in WIDE_READS else 1
+            ent["traffic_bytes"] = int((mult * f_kb + w_kb) * 1024)
+            ent["traffic_bytes_fetch_doubled"] = int((2 * f_kb + w_kb) * 1024)
+        if "SQ_INSTS_VALU_MFMA_MOPS_F32" in ent and "SQ_BUSY_CYCLES" in ent:
+            ent["mfma_mops_f32_per_busy_cycle"] = ent["SQ_INSTS_VALU_MFMA_MOPS_F32"]["median"] / max(ent["SQ_BUSY_CYCLES"]["median"], 1)
+        out[k] = ent
+    dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1)[:6000])
 
 
 if __name__ == "__main__":
