@@ -205,6 +205,49 @@ long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K);
 int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, float* gW, float* gb,
                       float* workspace, void* stream);
 
+/* ------------------------------------------------------------------ general fused GEMM ------ */
+/* The dense products of the score networks with everything a library GEMM cannot fuse (csrc/gemm_ex.hip):
+ *     C[M,N] (+)= alpha * rowscale[m] * epilogue( A[M,K1] . B + A2[M,K2] . B2 + bias[n] )
+ * Replaces, per call site: nn.Linear on a concatenated input (torch.cat + F.linear:
+ * SDE_model_3D_to_2D_node_adj_dense.py:156 embedding_3D + embedding_X; invariant_scorenetwork_dense.py:123-127
+ * cat(x_list) -> final MLP), Linear + tanh/SiLU/ELU (layers/common.py:26-38), the input gradients of those through
+ * the activation, the `flags` row mask (mask_x, SDE_model_3D_to_2D_node_adj_dense.py:543-548), and the per-channel
+ * (block-diagonal) products of EdgeLayer (edge_network_dense.py:55-64) as `groups` problems in one launch.
+ *   B layout: [N][K] with row stride ldb (nn.Linear weight), or with MSDE_GEMM_B_KMAJOR [K][N] (input gradients;
+ *   NodeNetwork_dense weights, stored [in, out]: node_network_dense.py:32).
+ *   epi = MSDE_EPI_ACT : v = acc + bias; Z (optional) receives v; columns [act_lo, act_hi) get act(v)
+ *   epi = MSDE_EPI_DACT: v = (acc + bias) * act'(R[m,n]) on those columns; R = the forward's saved OUTPUT for
+ *                        tanh / ELU / ReLU and its saved PRE-ACTIVATION for SiLU / shifted softplus
+ *   groups > 1: problem g uses A + g*a_gs (also A2), B + g*b_gs (also B2), bias + g*bias_gs, C + g*c_gs (also Z),
+ *   R + g*r_gs (all in floats); M, N, K, leading dimensions are shared. */
+#define MSDE_ACT_NONE 0
+#define MSDE_ACT_TANH 1
+#define MSDE_ACT_SILU 2
+#define MSDE_ACT_ELU 3
+#define MSDE_ACT_SSP 4  /* shifted softplus, schnet.py:213-216 */
+#define MSDE_ACT_RELU 5
+#define MSDE_EPI_ACT 0
+#define MSDE_EPI_DACT 1
+#define MSDE_GEMM_B_KMAJOR 1
+#define MSDE_GEMM_ACCUMULATE 2
+typedef struct msde_gemm_desc {
+  const float* A;        /* [M, K1], row stride lda */
+  const float* A2;       /* optional second K segment [M, K2], row stride lda2 (NULL: none) */
+  const float* B;        /* weights of segment 1 */
+  const float* B2;       /* weights of segment 2 */
+  const float* bias;     /* [N] or NULL */
+  float* C;              /* [M, N], row stride ldc */
+  float* Z;              /* optional pre-activation output, row stride ldz (MSDE_EPI_ACT only) */
+  const float* R;        /* MSDE_EPI_DACT: saved forward tensor, row stride ldr */
+  const float* rowscale; /* optional [M] multiplier (row mask) */
+  long long a_gs, b_gs, bias_gs, c_gs, r_gs; /* per-group strides in floats */
+  int M, N, K1, K2;
+  int lda, lda2, ldb, ldb2, ldc, ldz, ldr;
+  int act, act_lo, act_hi, epi, flags, groups;
+  float alpha;           /* scales the result (1.0f for none) */
+} msde_gemm_desc;
+int msde_gemm_ex(const msde_gemm_desc* desc, void* stream);
+
 /* ------------------------------------------------------------------ contrastive loss ------- */
 /* do_CL('EBM_node_dot_prod') in both directions + dual_CL — examples/util.py:52-68,76-79.
  * perm1/perm2: the two negative-sample permutations (torch.randperm).  out[0] = loss, out[1] = accuracy.

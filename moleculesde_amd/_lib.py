@@ -54,6 +54,7 @@ SIGNATURES = {
     "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
+    "msde_gemm_ex": [P, P],
     "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],
     "msde_cl_ebm_bwd": [P, P, P, P, P, P, P, P, I, I, F, P, P, P],
     "msde_bn_workspace_floats": [I, I],
@@ -80,6 +81,22 @@ SIGNATURES = {
     "msde_gather_chunks": [P, I, P, P],
     "msde_adam_chunks": [P, P, I, P, P, P, P, P, I, F, F, F, F, F, P],
 }
+
+
+class GemmDesc(ctypes.Structure):
+    """msde_gemm_desc of include/msde_hip.h (field order and types must match)."""
+    _fields_ = [("A", P), ("A2", P), ("B", P), ("B2", P), ("bias", P), ("C", P), ("Z", P), ("R", P), ("rowscale", P),
+                ("a_gs", LL), ("b_gs", LL), ("bias_gs", LL), ("c_gs", LL), ("r_gs", LL),
+                ("M", I), ("N", I), ("K1", I), ("K2", I),
+                ("lda", I), ("lda2", I), ("ldb", I), ("ldb2", I), ("ldc", I), ("ldz", I), ("ldr", I),
+                ("act", I), ("act_lo", I), ("act_hi", I), ("epi", I), ("flags", I), ("groups", I),
+                ("alpha", F)]
+
+
+ACT = {None: 0, "none": 0, "tanh": 1, "silu": 2, "elu": 3, "ssp": 4, "relu": 5}
+EPI_ACT, EPI_DACT = 0, 1
+GEMM_B_KMAJOR, GEMM_ACCUMULATE = 1, 2
+
 _RESTYPE = {"msde_target_arch": ctypes.c_char_p, "msde_linear_bwd_w_workspace_bytes": ctypes.c_longlong,
             "msde_cfconv_fused_bwd_w_workspace_floats": ctypes.c_longlong,
             "msde_embedding_sum_bwd_workspace_floats": ctypes.c_longlong,

@@ -1,0 +1,285 @@
+// gemm_ex.hip — the general fp32 matrix-core GEMM of the library (gfx950, v_mfma_f32_32x32x2_f32).
+//
+//     C[M,N] (+)= epilogue( A1[M,K1] . B1 + A2[M,K2] . B2 + bias )          (optionally `groups` independent problems)
+//
+// One kernel covers every dense product the hot path needs that a library GEMM cannot fuse:
+//   * forward of nn.Linear on a concatenated input without materialising the concat (two K segments), e.g.
+//     embedding_3D(h) + embedding_X(x) of SDE_model_3D_to_2D_node_adj_dense.py:156 as ONE product;
+//   * bias + activation (tanh / SiLU / ELU / shifted softplus / ReLU) in the epilogue, optionally only on a column range
+//     (stacked projections with different activations) and optionally ALSO storing the pre-activation;
+//   * input gradients through an activation: C = (gY . W) * act'(R) with R the saved pre-activation (or output);
+//   * accumulation into C (several consumers of one tensor add their gradients in launch order: deterministic);
+//   * a per-row mask (the `flags` of the dense score networks);
+//   * block-diagonal / per-channel products (`groups`: blockIdx.z with per-group strides).
+// B is either nn.Linear's [N][K] (k contiguous) or [K][N] (n contiguous: input gradients, GCN weights stored [in,out]).
+//
+// Tiling.  256 threads = 4 waves; block tile (32*TM*2) x 64: waves 2 x 2, each TM x 1 MFMA tiles of 32 x 32.  K tile
+// 32.  Both operand tiles are STRAIGHT copies of global memory (16-B loads -> 16-B LDS stores, no transpose):
+//   * a k-contiguous operand lands as [rows][36] (row stride 36 floats keeps 16-B alignment and makes the operand
+//     read -- ONE ds_read_b128 per lane per 4 MFMAs -- conflict free: the 16 lanes the LDS services together start
+//     at 16 distinct multiples of 4 banks).  The MFMA sums over its two k lanes, so lane half h may own the k's
+//     {8q+4h .. 8q+4h+3} as long as both operands agree: four consecutive floats per lane = one b128 read;
+//   * an n-contiguous operand lands as [32 k][68]: its reads are 32 consecutive floats of one k row (conflict free).
+// LDS is double buffered: the global loads of tile t+1 are in flight while tile t is multiplied, and ONE barrier per
+// K tile separates "everyone has finished reading stage s" from "stage s is overwritten".
+// XCD-aware tile order: consecutive tiles of one row strip (same A rows) run on the same XCD, so the strip is fetched
+// into that XCD's L2 once.
+#include "msde_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GX_BK 32
+#define GX_LDK 36   // row stride of a k-contiguous LDS tile
+#define GX_LDN 68   // row stride of an n-contiguous LDS tile (64 columns)
+
+__device__ __forceinline__ float gx_act(float z, int act) {
+  switch (act) {
+    case MSDE_ACT_TANH: return tanhf(z);
+    case MSDE_ACT_SILU: return z / (1.f + __expf(-z));
+    case MSDE_ACT_ELU: return z > 0.f ? z : expm1f(z);
+    case MSDE_ACT_SSP: return (z > 20.f ? z : log1pf(__expf(z))) - 0.6931471805599453f;
+    case MSDE_ACT_RELU: return fmaxf(z, 0.f);
+    default: return z;
+  }
+}
+// derivative of the activation; `r` is what the forward saved: the OUTPUT y for tanh / ELU / ReLU, the
+// PRE-ACTIVATION z for SiLU / shifted softplus
+__device__ __forceinline__ float gx_dact(float r, int act) {
+  switch (act) {
+    case MSDE_ACT_TANH: return 1.f - r * r;
+    case MSDE_ACT_SILU: { float s = 1.f / (1.f + __expf(-r)); return s * (1.f + r * (1.f - s)); }
+    case MSDE_ACT_ELU: return r > 0.f ? 1.f : r + 1.f;
+    case MSDE_ACT_SSP: return 1.f / (1.f + __expf(-r));
+    case MSDE_ACT_RELU: return r > 0.f ? 1.f : 0.f;
+    default: return 1.f;
+  }
+}
+
+// 4 consecutive floats of a row starting at column k (k % 4 == 0).  Out-of-range elements are NOT zeroed here:
+// the load address is clamped into the row and `keep` tells gx_mask4 (applied when the tile goes to LDS, i.e. AFTER
+// the MFMAs of the previous tile) what to keep -- zeroing at load time would make the wave wait for the load
+// before it starts multiplying.  VEC: the row is 16-B aligned and a float4 is entirely inside or outside [0, kend).
+template <bool VEC>
+__device__ __forceinline__ float4 gx_ld4(const float* __restrict__ row, int k, int kend, int& keep) {
+  float4 v;
+  if (VEC) {
+    const bool in = k < kend;
+    keep = in ? 15 : 0;
+    v = *reinterpret_cast<const float4*>(row + (in ? k : 0));
+  } else {
+    const int rem = kend - k;                                 // elements of this float4 inside the row
+    keep = rem >= 4 ? 15 : (rem <= 0 ? 0 : (1 << rem) - 1);
+    v.x = row[rem > 0 ? k : 0];
+    v.y = row[rem > 1 ? k + 1 : 0];
+    v.z = row[rem > 2 ? k + 2 : 0];
+    v.w = row[rem > 3 ? k + 3 : 0];
+  }
+  return v;
+}
+__device__ __forceinline__ float4 gx_mask4(float4 v, int keep) {
+  return make_float4(keep & 1 ? v.x : 0.f, keep & 2 ? v.y : 0.f, keep & 4 ? v.z : 0.f, keep & 8 ? v.w : 0.f);
+}
+
+template <int TM, bool B_KM, bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_ex_kernel(const msde_gemm_desc d) {
+  constexpr int BM = 64 * TM, BN = 64;
+  constexpr int A_FLOATS = BM * GX_LDK;
+  constexpr int B_FLOATS = B_KM ? GX_BK * GX_LDN : BN * GX_LDK;
+  __shared__ __attribute__((aligned(16))) float As[2][A_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][B_FLOATS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lcol = lane & 31, lhalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile order: tiles are numbered row-strip major; block b runs on XCD b % 8, so XCD x takes the
+  // contiguous range of tile numbers [x * per, (x+1) * per)
+  const int tiles_n = (d.N + BN - 1) / BN, tiles_m = (d.M + BM - 1) / BM;
+  const int ntile = tiles_m * tiles_n;
+  int b = blockIdx.x;
+  {
+    const int per = (ntile + 7) >> 3;
+    const int t = (b & 7) * per + (b >> 3);
+    // tiles beyond ntile (last XCD's range may be short) are handled by blocks whose t >= ntile: they take the
+    // leftover slots in natural order
+    b = t;
+  }
+  if (b >= ntile) return;
+  const int m0 = (b / tiles_n) * BM, n0 = (b % tiles_n) * BN;
+  const int g = blockIdx.y;
+
+  const float* __restrict__ A1 = d.A + (size_t)g * d.a_gs;
+  const float* __restrict__ A2 = d.A2 ? d.A2 + (size_t)g * d.a_gs : nullptr;
+  const float* __restrict__ B1 = d.B + (size_t)g * d.b_gs;
+  const float* __restrict__ B2 = d.B2 ? d.B2 + (size_t)g * d.b_gs : nullptr;
+  const int K1 = d.K1, K2 = d.A2 ? d.K2 : 0;
+  const int nt1 = (K1 + GX_BK - 1) / GX_BK, nt2 = (K2 + GX_BK - 1) / GX_BK;
+  const int ntiles = nt1 + nt2;
+
+  // staging: A tile BM x 32 = BM*8 float4 -> 2*TM per thread; B tile 64 x 32 (or 32 x 64) = 512 float4 -> 2
+  constexpr int NA = 2 * TM, NB = 2;
+  float4 ra[NA], rb[NB];
+  int ka[NA], kb_[NB];
+
+  auto load_tile = [&](int t) {
+    const bool s2 = t >= nt1;
+    const float* __restrict__ A = s2 ? A2 : A1;
+    const float* __restrict__ B = s2 ? B2 : B1;
+    const int lda = s2 ? d.lda2 : d.lda, ldb = s2 ? d.ldb2 : d.ldb, K = s2 ? K2 : K1;
+    const int k0 = (s2 ? t - nt1 : t) * GX_BK;
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int idx = p * 256 + tid, r = idx >> 3, kq = (idx & 7) * 4;
+      const int gm = min(m0 + r, d.M - 1);                 // rows past M repeat the last row: never stored
+      ra[p] = gx_ld4<VEC>(A + (size_t)gm * lda, k0 + kq, K, ka[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int idx = p * 256 + tid;
+      if (!B_KM) {                                          // B[n][k]
+        const int r = idx >> 3, kq = (idx & 7) * 4;
+        const int gn = min(n0 + r, d.N - 1);
+        rb[p] = gx_ld4<VEC>(B + (size_t)gn * ldb, k0 + kq, K, kb_[p]);
+      } else {                                              // B[k][n]: 16 float4 per k row
+        const int kr = idx >> 4, nq = (idx & 15) * 4;
+        const int gk = min(k0 + kr, K - 1);
+        rb[p] = gx_ld4<VEC>(B + (size_t)gk * ldb, n0 + nq, d.N, kb_[p]);
+        if (k0 + kr >= K) kb_[p] = 0;
+      }
+    }
+  };
+  auto store_tile = [&](int s) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int idx = p * 256 + tid, r = idx >> 3, kq = (idx & 7) * 4;
+      *reinterpret_cast<float4*>(&As[s][r * GX_LDK + kq]) = gx_mask4(ra[p], ka[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int idx = p * 256 + tid;
+      if (!B_KM) {
+        const int r = idx >> 3, kq = (idx & 7) * 4;
+        *reinterpret_cast<float4*>(&Bs[s][r * GX_LDK + kq]) = gx_mask4(rb[p], kb_[p]);
+      } else {
+        const int kr = idx >> 4, nq = (idx & 15) * 4;
+        *reinterpret_cast<float4*>(&Bs[s][kr * GX_LDN + nq]) = gx_mask4(rb[p], kb_[p]);
+      }
+    }
+  };
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  auto compute_tile = [&](int s) {
+    const float* __restrict__ as = As[s];
+    const float* __restrict__ bs = Bs[s];
+#pragma unroll
+    for (int q = 0; q < GX_BK / 8; ++q) {                   // k's 8q .. 8q+7: lane half h owns 8q+4h .. 8q+4h+3
+      float4 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const float4*>(&as[((wm * TM + i) * 32 + lcol) * GX_LDK + 8 * q + 4 * lhalf]);
+      float4 bf;
+      if (!B_KM) {
+        bf = *reinterpret_cast<const float4*>(&bs[(wn * 32 + lcol) * GX_LDK + 8 * q + 4 * lhalf]);
+      } else {
+        const int kb = 8 * q + 4 * lhalf, c = wn * 32 + lcol;
+        bf = make_float4(bs[kb * GX_LDN + c], bs[(kb + 1) * GX_LDN + c], bs[(kb + 2) * GX_LDN + c],
+                         bs[(kb + 3) * GX_LDN + c]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf.x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf.y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf.z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf.w, acc[i], 0, 0, 0);
+      }
+    }
+  };
+
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      const bool more = t + 1 < ntiles;
+      if (more) load_tile(t + 1);          // in flight during the MFMAs below
+      compute_tile(t & 1);
+      if (more) store_tile((t + 1) & 1);   // stage (t+1)&1 was last read in iteration t-1: everyone is past it
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const float* __restrict__ bias = d.bias ? d.bias + (size_t)g * d.bias_gs : nullptr;
+  float* __restrict__ C = d.C + (size_t)g * d.c_gs;
+  float* __restrict__ Z = d.Z ? d.Z + (size_t)g * d.c_gs : nullptr;
+  const float* __restrict__ R = d.R ? d.R + (size_t)g * d.r_gs : nullptr;
+  const int gn = n0 + wn * 32 + lcol;
+  if (gn < d.N) {
+    const float bv = bias ? bias[gn] : 0.f;
+    const bool act_here = d.act != MSDE_ACT_NONE && gn >= d.act_lo && gn < d.act_hi;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        if (gm < d.M) {
+          float v = acc[i][r] + bv;
+          if (d.epi == MSDE_EPI_ACT) {
+            if (Z) Z[(size_t)gm * d.ldz + gn] = v;
+            if (act_here) v = gx_act(v, d.act);
+          } else if (d.epi == MSDE_EPI_DACT) {
+            if (act_here) v *= gx_dact(R[(size_t)gm * d.ldr + gn], d.act);
+          }
+          if (d.rowscale) v *= d.rowscale[gm];
+          v *= d.alpha;
+          float* dst = C + (size_t)gm * d.ldc + gn;
+          if (d.flags & MSDE_GEMM_ACCUMULATE) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+static inline bool gx_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int msde_gemm_ex(const msde_gemm_desc* desc, void* stream) {
+  if (!desc) return MSDE_EINVAL;
+  msde_gemm_desc d = *desc;
+  if (d.M < 0 || d.N <= 0 || d.K1 <= 0 || !d.A || !d.B || !d.C || d.groups < 1) return MSDE_EINVAL;
+  if (d.A2 && (!d.B2 || d.K2 <= 0)) return MSDE_EINVAL;
+  if (d.epi == MSDE_EPI_DACT && d.act != MSDE_ACT_NONE && !d.R) return MSDE_EINVAL;
+  if (d.M == 0) return 0;
+  if (d.act == MSDE_ACT_NONE || d.act_hi <= d.act_lo) { d.act_lo = 0; d.act_hi = d.act == MSDE_ACT_NONE ? 0 : d.N; }
+  const bool km = (d.flags & MSDE_GEMM_B_KMAJOR) != 0;
+  // vector (16-B) loads per operand: aligned base, group stride and leading dimension, and a contiguous extent % 4
+  auto vec_ok = [&](const float* p, long long gs, int ld, int extent) {
+    return gx_al16(p) && (gs % 4 == 0) && (ld % 4 == 0) && (extent % 4 == 0);
+  };
+  bool vec = vec_ok(d.A, d.a_gs, d.lda, d.K1) && vec_ok(d.B, d.b_gs, d.ldb, km ? d.N : d.K1);
+  if (d.A2) vec = vec && vec_ok(d.A2, d.a_gs, d.lda2, d.K2) && vec_ok(d.B2, d.b_gs, d.ldb2, km ? d.N : d.K2);
+  // tile height: 128 rows when that still gives every CU >= 2 tiles, else 64 (skinny problems need the parallelism)
+  const long t128 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.groups;
+  const int tm = t128 >= 2L * msde_num_cus() ? 2 : 1;
+  const int tiles = ((d.M + 64 * tm - 1) / (64 * tm)) * ((d.N + 63) / 64);
+  const int grid_x = ((tiles + 7) / 8) * 8;       // whole multiples of 8: every XCD gets the same number of slots
+  dim3 grid(grid_x, d.groups);
+  hipStream_t st = as_stream(stream);
+#define GX_GO(TM_, KM_, V_) MSDE_LAUNCH((gemm_ex_kernel<TM_, KM_, V_>), grid, dim3(256), 0, st, d)
+  if (tm == 2) {
+    if (km) { if (vec) GX_GO(2, true, true); else GX_GO(2, true, false); }
+    else { if (vec) GX_GO(2, false, true); else GX_GO(2, false, false); }
+  } else {
+    if (km) { if (vec) GX_GO(1, true, true); else GX_GO(1, true, false); }
+    else { if (vec) GX_GO(1, false, true); else GX_GO(1, false, false); }
+  }
+#undef GX_GO
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

@@ -1444,3 +1444,61 @@ def adam_chunks(p, table, n_chunks, m, v, step_dev, seg_end, seg_lr, beta1, beta
 def adam_flat(p, g, m, v, step_dev, seg_end, seg_lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
     _lib.call("msde_adam_flat", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(step_dev), _p(seg_end), _p(seg_lr),
               seg_lr.numel(), float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# general fused GEMM (csrc/gemm_ex.hip)
+# ------------------------------------------------------------------------------------------------
+def _ld(t):
+    """Row stride of a 2-D fp32 tensor whose rows are contiguous (a column block of a wider buffer is fine)."""
+    assert t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda and (t.size(1) == 1 or t.stride(1) == 1), \
+        (t.shape, t.stride(), t.dtype)
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=None, dact_from=None, rowscale=None,
+            b_kmajor=False, accumulate=False, alpha=1.0, groups=1, group_strides=None, N=None, K=None, K2=None):
+    """out[M,N] (+)= alpha * rowscale * epi(A . B(^T) + A2 . B2(^T) + bias): one launch of msde_gemm_ex, no autograd.
+    A, A2, out, Z, dact_from: 2-D fp32 device tensors with unit column stride (views into wider buffers are fine; their
+    row strides become the leading dimensions).  B: [N, K] (nn.Linear layout) or, with b_kmajor, [K, N].
+    act: None|'tanh'|'silu'|'elu'|'ssp'|'relu' applied on act_cols=(lo, hi) (default: all columns); Z: also store the
+    pre-activation; dact_from: instead of applying `act`, multiply by its derivative evaluated on this saved tensor
+    (the forward OUTPUT for tanh/elu/relu, the PRE-ACTIVATION for silu/ssp).
+    groups > 1: `group_strides` = dict(a=, b=, bias=, c=, r=) in floats; N / K give the per-group problem size (then
+    B may be any tensor starting at group 0's weights)."""
+    d = _lib.GemmDesc()
+    M = A.size(0)
+    d.M = M
+    d.K1 = int(K if K is not None else A.size(1))
+    if N is None:
+        N = B.size(1) if b_kmajor else B.size(0)
+    d.N = int(N)
+    d.A, d.lda = A.data_ptr(), _ld(A)
+    d.B = B.data_ptr()
+    d.ldb = (B.stride(0) if B.dim() == 2 else (d.N if b_kmajor else d.K1))
+    if A2 is not None:
+        d.A2, d.lda2 = A2.data_ptr(), _ld(A2)
+        d.K2 = int(K2 if K2 is not None else A2.size(1))
+        d.B2, d.ldb2 = B2.data_ptr(), (B2.stride(0) if B2.dim() == 2 else (d.N if b_kmajor else d.K2))
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.C, d.ldc = out.data_ptr(), _ld(out)
+    if Z is not None:
+        d.Z, d.ldz = Z.data_ptr(), _ld(Z)
+    d.act = _lib.ACT[act]
+    if act_cols is not None:
+        d.act_lo, d.act_hi = int(act_cols[0]), int(act_cols[1])
+    else:
+        d.act_lo, d.act_hi = 0, d.N
+    d.epi = _lib.EPI_ACT
+    if dact_from is not None:
+        d.epi = _lib.EPI_DACT
+        d.R, d.ldr = dact_from.data_ptr(), _ld(dact_from)
+    d.rowscale = rowscale.data_ptr() if rowscale is not None else None
+    d.flags = (_lib.GEMM_B_KMAJOR if b_kmajor else 0) | (_lib.GEMM_ACCUMULATE if accumulate else 0)
+    d.groups = int(groups)
+    gs = group_strides or {}
+    d.a_gs, d.b_gs, d.bias_gs = int(gs.get("a", 0)), int(gs.get("b", 0)), int(gs.get("bias", 0))
+    d.c_gs, d.r_gs = int(gs.get("c", 0)), int(gs.get("r", 0))
+    d.alpha = float(alpha)
+    _lib.call("msde_gemm_ex", ctypes.byref(d), _stream())
+    return out

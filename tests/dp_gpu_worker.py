@@ -39,7 +39,9 @@ class FixedNoise(G.DeviceNoise):
     def _get(self, key, make, device):
         # device copies are made once (first eager call) and cloned afterwards: no H2D copy inside a graph capture
         if key not in self.cache:
-            self.cache[key] = make(torch.Generator().manual_seed(self.g0 * 1000 + len(self.cache))).to(device)
+            import zlib
+            seed = self.g0 * 1000003 + zlib.crc32(repr(key).encode())     # a function of the KEY, not of call order
+            self.cache[key] = make(torch.Generator().manual_seed(seed)).to(device)
         return self.cache[key].clone()
 
     def randn_like(self, x):

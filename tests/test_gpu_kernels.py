@@ -794,3 +794,94 @@ def test_gat_tail_kernel(dev, silu_out):
         outs.append([o.detach(), xd.grad, rd.grad, g0.weight.grad, g3.bias.grad, m2.weight.grad])
     for a, b, nme in zip(outs[0], outs[1], ["out", "g_x", "g_res", "W0", "b3", "ln2_g"]):
         assert_close(a, b.cpu(), 2e-4, 2e-5 * float(b.abs().max()) + 1e-6, f"gat tail with dropout: {nme}")
+
+
+# ------------------------------------------------------------------ general fused GEMM (gemm_ex.hip) ---
+def _act_ref(name):
+    import torch.nn.functional as F
+    return {None: lambda z: z, "tanh": torch.tanh, "silu": F.silu, "elu": F.elu, "relu": F.relu,
+            "ssp": lambda z: F.softplus(z) - 0.6931471805599453}[name]
+
+
+@pytest.mark.parametrize("M,N,K", [(3588, 728, 364), (777, 119, 728), (100, 30, 30), (52680, 60, 32), (5, 300, 300),
+                                   (1, 1, 7), (300, 176, 300)])
+@pytest.mark.parametrize("km", [False, True])
+def test_gemm_ex_plain_and_kmajor(dev, M, N, K, km):
+    """C = A B^T + bias with SiLU on a column range and the pre-activation stored, against fp64 torch; both B
+    layouts, aligned and unaligned shapes (scalar-load path), M tails, K tails."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    Bop = W.t().contiguous() if km else W
+    out = torch.full((M, N), float("nan"), device=dev)
+    Z = torch.full((M, N), float("nan"), device=dev)
+    lo, hi = N // 4, N
+    hip.gemm_ex(A, Bop, out, bias=b, act="silu", act_cols=(lo, hi), Z=Z, b_kmajor=km)
+    zr = A.double() @ W.double().t() + b.double()
+    ref = zr.clone()
+    ref[:, lo:hi] = torch.nn.functional.silu(zr[:, lo:hi])
+    assert_close(Z, zr, 1e-5, 2e-5, "pre-activation")
+    assert_close(out, ref, 1e-5, 2e-5, "gemm_ex out")
+
+
+@pytest.mark.parametrize("act", [None, "tanh", "silu", "elu", "ssp", "relu"])
+def test_gemm_ex_two_segments_epilogues(dev, act):
+    """Two K segments written into a column block of a wider buffer (ldc > N), row mask, alpha, accumulate; then the
+    matching input-gradient product through the activation (EPI_DACT) against autograd."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(3)
+    M, K1, K2, N = 1000, 300, 119, 300
+    A1 = torch.randn(M, K1, generator=g).to(dev)
+    A2w = torch.randn(M, 120, generator=g).to(dev)          # K2 = 119 inside rows of stride 120
+    A2 = A2w[:, :K2]
+    W1 = (torch.randn(N, K1, generator=g) / 17).to(dev)
+    W2 = (torch.randn(N, K2, generator=g) / 11).to(dev)      # rows of 119 floats: unaligned -> scalar path
+    b = torch.randn(N, generator=g).to(dev)
+    mask = (torch.rand(M, generator=g) > 0.2).float().to(dev)
+    wide = torch.zeros(M, 364, device=dev)
+    base = torch.randn(M, N, generator=g).to(dev)
+    wide[:, 32:32 + N] = base
+    hip.gemm_ex(A1, W1, wide[:, 32:32 + N], bias=b, A2=A2, B2=W2, act=act, rowscale=mask, alpha=0.5, accumulate=True)
+    z = A1.double() @ W1.double().t() + A2.double() @ W2.double().t() + b.double()
+    ref = base.double() + 0.5 * mask.double()[:, None] * _act_ref(act)(z)
+    assert_close(wide[:, 32:32 + N], ref, 1e-5, 3e-5, f"two-segment {act}")
+    assert float(wide[:, :32].abs().max()) == 0 and float(wide[:, 32 + N:].abs().max()) == 0
+    # input gradient through the activation: gA1 = (gY * act'(.)) W1 == (gY W1) only when applied BEFORE the product,
+    # so the library form is  gZ = (gOut . Wnext) * act'(saved)  for the layer whose OUTPUT went through act:
+    # y = act(x Wa^T); o = y Wb^T  =>  g_pre = (gO Wb) * act'(pre)
+    Wa = (torch.randn(64, K1, generator=g) / 17).to(dev)
+    Wb = (torch.randn(40, 64, generator=g) / 8).to(dev)
+    x = A1.clone().requires_grad_(True)
+    pre = x @ Wa.t()
+    y = _act_ref(act)(pre)
+    o = y @ Wb.t()
+    gO = torch.randn(M, 40, generator=g).to(dev)
+    (gpre_ref,) = torch.autograd.grad(o, pre, gO)
+    saved = pre.detach() if act in ("silu", "ssp") else y.detach()
+    gpre = torch.empty(M, 64, device=dev)
+    hip.gemm_ex(gO, Wb, gpre, b_kmajor=True, act=act, dact_from=saved if act else None)
+    assert_close(gpre, gpre_ref, 1e-4, 1e-5, f"dact {act}")
+
+
+def test_gemm_ex_groups(dev):
+    """Block-diagonal product: 16 groups of [M,32] x [32,32] reading column blocks of one wide input and writing column
+    blocks of one wide output (EdgeLayer func_q / func_k second layers of all channels in one launch)."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(5)
+    M, G = 3588, 16
+    H = torch.randn(M, G * 32, generator=g).to(dev)
+    W = (torch.randn(G, 32, 32, generator=g) / 6).to(dev)
+    b = torch.randn(G, 32, generator=g).to(dev)
+    out = torch.empty(M, G * 32, device=dev)
+    hip.gemm_ex(H, W, out, bias=b, groups=G, group_strides=dict(a=32, b=32 * 32, bias=32, c=32), N=32, K=32)
+    ref = torch.einsum("mgk,gnk->mgn", H.view(M, G, 32).double(), W.double()) + b.double()
+    assert_close(out, ref.reshape(M, G * 32), 1e-5, 2e-5, "grouped")
+    # k-major groups: NodeNetwork_dense weights [C, in, out]
+    Wv = (torch.randn(8, 16, 16, generator=g) / 4).to(dev)
+    x = torch.randn(M, 16, generator=g).to(dev)
+    xv = torch.empty(M, 8 * 16, device=dev)
+    hip.gemm_ex(x, Wv, xv, b_kmajor=True, groups=8, group_strides=dict(b=256, c=16), N=16, K=16)
+    ref = torch.einsum("mk,gkn->mgn", x.double(), Wv.double()).reshape(M, 128)
+    assert_close(xv, ref, 1e-5, 2e-5, "grouped k-major")

@@ -11,7 +11,12 @@ cd $R
 for w in $WHAT; do
 case $w in
 tests)
-  timeout 1500 python -m pytest tests -m gpu -x -q -s > $O/gputest.log 2>&1; echo "gputest rc=$?" | tee -a $O/gputest.log; tail -5 $O/gputest.log;;
+  timeout 1500 python -m pytest tests -m gpu -q -x --deselect tests/test_gpu_dp.py > $O/gputest.log 2>&1; echo "gputest rc=$?" | tee -a $O/gputest.log; tail -5 $O/gputest.log;;
+gemm)
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k gemm_ex > $O/gemm_test.log 2>&1; echo "gemm test rc=$?"; tail -15 $O/gemm_test.log
+  timeout 600 python tools/bench_gemm_ex.py > $O/gemm_bench.log 2>&1; cat $O/gemm_bench.log;;
+dptest)
+  timeout 1200 python -m pytest tests/test_gpu_dp.py -q -x > $O/dptest.log 2>&1; echo "dptest rc=$?"; tail -60 $O/dptest.log;;
 bench)
   timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cat $O/bench.json
   timeout 600 python bench.py --full --no_cpu_baseline > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"; cat $O/bench_full.json;;
@@ -31,9 +36,10 @@ pmc)
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $O/pmc_SQ -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"
   timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_SQ2 -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_SQ2.log 2>&1; echo "pmc SQ2 rc=$?"
   cd $R
-  find $O -name "*counter_collection.csv" | head
-  # trim the big traces before they are merged back (keep stats + counters)
-  find $O -name "*kernel_trace.csv" -size +8M -delete;;
+  python tools/pmc_summary.py $O/pmc_counters.json '{"N": 3588, "E_r": 49090, "batch": "make_batch(256, seed=0)"}' $(find $O -name "*counter_collection.csv") > $O/pmc_summary.log 2>&1; tail -3 $O/pmc_summary.log
+  find $O -name "*counter_collection.csv" -delete;;
 esac
 done
+# only summaries travel back: drop per-dispatch traces and rocprof's databases
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O

@@ -2,7 +2,7 @@
 per kernel (name substring match), per counter: launches, median / min / max of the per-dispatch value (summed over
 XCDs / instances, as rocprofv3 reports one row per instance).
 
-    python tools/pmc_summary.py <tag> <shape json> <csv> [<csv> ...]
+    python tools/pmc_summary.py <output json> <shape json> <csv> [<csv> ...]
 
 FETCH_SIZE / WRITE_SIZE are in KB; HBM-side bytes per launch follow MI355X_MICROARCH.md: FETCH_SIZE x 2 for kernels
 that read with 16-B-per-lane coalesced loads (gfx950 counts 128-B requests as 64 B), raw for other widths
@@ -16,7 +16,7 @@ WIDE_READS = {"cfconv_aggregate_bwd_x_kernel", "gin_aggregate_fwd", "edge_attent
 
 
 def main():
-    tag, shape = sys.argv[1], json.loads(sys.argv[2])
+    dst, shape = sys.argv[1], json.loads(sys.argv[2])
     vals = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     grid = {}
     for path in sys.argv[3:]:
@@ -42,7 +42,6 @@ def main():
         if "SQ_INSTS_VALU_MFMA_MOPS_F32" in ent and "SQ_BUSY_CYCLES" in ent:
             ent["mfma_mops_f32_per_busy_cycle"] = ent["SQ_INSTS_VALU_MFMA_MOPS_F32"]["median"] / max(ent["SQ_BUSY_CYCLES"]["median"], 1)
         out[k] = ent
-    dst = os.path.join(ROOT, "profiles", f"{tag}_pmc_counters.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1)[:6000])
 
