@@ -236,17 +236,91 @@ typedef struct msde_gemm_desc {
   const float* B;        /* weights of segment 1 */
   const float* B2;       /* weights of segment 2 */
   const float* bias;     /* [N] or NULL */
+  const float* bias2;    /* optional second bias (two Linear layers summed into one product) */
   float* C;              /* [M, N], row stride ldc */
   float* Z;              /* optional pre-activation output, row stride ldz (MSDE_EPI_ACT only) */
   const float* R;        /* MSDE_EPI_DACT: saved forward tensor, row stride ldr */
   const float* rowscale; /* optional [M] multiplier (row mask) */
   long long a_gs, b_gs, bias_gs, c_gs, r_gs; /* per-group strides in floats */
+  long long b_kblk_stride; /* with b_kblk_log2 > 0 ([N][K] layout only): k is cut into blocks of 2^b_kblk_log2 and block q
+                              of row n starts at B + q * b_kblk_stride + n * ldb */
   int M, N, K1, K2;
   int lda, lda2, ldb, ldb2, ldc, ldz, ldr;
-  int act, act_lo, act_hi, epi, flags, groups;
+  int act, act_lo, act_hi, epi, flags, groups, b_kblk_log2;
   float alpha;           /* scales the result (1.0f for none) */
 } msde_gemm_desc;
 int msde_gemm_ex(const msde_gemm_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------ 3D->2D dense score head -- */
+/* SDEModel3Dto2D_node_adj_dense.forward (SDE_model_3D_to_2D_node_adj_dense.py:101-179) with its
+ * EdgeScoreNetwork_dense / NodeScoreNetwork_dense (invariant_scorenetwork_dense.py:74-93,118-131) on RAGGED data
+ * (csrc/dense_head.hip): atoms in batch order, atom pairs of molecule b at rows pair_ptr[b] + i*n_b + j of every
+ * [P, *] array, P = sum_b n_b^2, n_b <= 32.  The pair channel buffer AC is [P, MSDE_DENSE_AC_LD]: columns 0-1 the
+ * perturbed adjacency and its square (pow_tensor, :28-37), then the outputs of the 4 EdgeNetwork_dense layers
+ * (8, 8, 8, 4 channels) -- exactly the concatenation the final pair MLP reads (:81-84).  Atom-class arrays
+ * ([N, MSDE_DENSE_XP_LD], 119 classes) are padded to a 16-byte row. */
+#define MSDE_DENSE_AC_LD 32
+#define MSDE_DENSE_XP_LD 120
+/* to_dense_adj + node_flags + gen_noise + perturbation of adjacency and one-hot classes (:112-152, 523-548).
+ * Time: t_in[b] if given, else the antithetic integer draws (:112-114; draws == NULL: drawn on the device).  sde_vp = 0: VESDE(p0 = sigma_min, p1 =
+ * sigma_max); 1: VPSDE(p0 = beta_0, p1 = beta_1) (SDE_dense.py).  Noise: noise_adj [B, Nm_pad, Nm_pad] and noise_x
+ * [B, Nm_pad, ncls] (the reference's padded randn draws, replay mode), or both NULL: counter-based N(0,1) from
+ * (seed + *seed_dev).  Outputs: AC columns 0-1 (and zeros in the two pad columns), z_adj [P], flags [N],
+ * mean_std [B][2], px / z_x [N, MSDE_DENSE_XP_LD]. */
+int msde_dense_prepare(const int* rowptr, const int* src, const float* bond_val, const int* z_atom,
+                       const int* mol_ptr, const int* pair_ptr, const long long* draws, const float* t_in,
+                       int B, int T, float eps, int sde_vp, float p0, float p1, const float* noise_adj,
+                       const float* noise_x, int Nm_pad, unsigned long long seed,
+                       const unsigned long long* seed_dev, int ncls, int n_max, float* AC, float* z_adj,
+                       float* flags, float* mean_std, float* px, float* z_x, void* stream);
+/* One EdgeNetwork_dense layer minus its node-level GEMMs (edge_network_dense.py:105-128): inputs QK [N, 64 C]
+ * (func_q outputs of the C channels, then func_k's), XV [N, 16 C] (x W_c of the per-channel GCNs), the C input channels
+ * AC[:, in_off ..]; outputs x_out [N,16], AC[:, out_off .. out_off+CO) and the tensors the backward reuses (IN [P,2C],
+ * H1, H2 [P,16], xcat [N,16C], Hmc [N,16]).  (C, CO) in {(2,8), (8,8), (8,4)}. */
+typedef struct msde_edge_layer_params {
+  const float* bv;                                 /* [C][16]  func_v biases */
+  const float *mW0, *mb0, *mW1, *mb1, *mW2, *mb2;  /* pair MLP: [16][2C], [16][16], [CO][16] */
+  const float *cW0, *cb0, *cW1, *cb1;              /* channel MLP (multi_channel): [16][16C], [16][16] */
+} msde_edge_layer_params;
+int msde_dense_edge_layer_fwd(const float* QK, const float* XV, float* AC, int in_off, int out_off, int C,
+                              int CO, const float* flags, const int* mol_ptr, const int* pair_ptr,
+                              const msde_edge_layer_params* params, int B, int n_max, float* x_out,
+                              float* IN, float* H1, float* H2, float* xcat, float* Hmc, void* stream);
+/* Its backward: reads gAC[:, out block] (and g_xout, NULL when x_out is unused), accumulates into gAC[:, in block]
+ * when need_gadj, writes gQK [N,64C], gXV [N,16C] and the operand pairs of the weight-gradient GEMMs (GO, GH2, GH1
+ * [P, .]; GY, GHm [N,16]; GV [N,16C]). */
+int msde_dense_edge_layer_bwd(const float* QK, const float* XV, const float* AC, float* gAC, int in_off,
+                              int out_off, int C, int CO, const float* flags, const int* mol_ptr,
+                              const int* pair_ptr, const msde_edge_layer_params* params, int B, int n_max,
+                              const float* x_out, const float* g_xout, const float* IN, const float* H1,
+                              const float* H2, const float* xcat, const float* Hmc, int need_gadj, float* gQK,
+                              float* gXV, float* GO, float* GH2, float* GH1, float* GY, float* GHm, float* GV,
+                              void* stream);
+/* The 4 dense-GCN + tanh layers of NodeScoreNetwork_dense (invariant_scorenetwork_dense.py:118-122) after the first
+ * product: XW0 = x W_0 [N,16]; Wl = W_1..3 [3][16 in][16 out]; bl [4][16]; XS [N, ldxs] receives [x_1|x_2|x_3|x_4]. */
+int msde_dense_node_gcn_fwd(const float* XW0, const float* AC, const int* mol_ptr, const int* pair_ptr,
+                            const float* Wl, const float* bl, int B, int n_max, float* XS, int ldxs,
+                            void* stream);
+/* backward: GP [N,64] = gradients of the 4 pre-activations (bias gradients = column sums), MM [N,64] = An^T GP per
+ * layer (block 0 = gradient of XW0; x_l^T MM_l = weight gradients of layers 1..3). */
+int msde_dense_node_gcn_bwd(const float* gXS, int ldg, const float* XS, int ldxs, const float* AC,
+                            const int* mol_ptr, const int* pair_ptr, const float* Wl, int B, int n_max,
+                            float* GP, float* MM, void* stream);
+/* Last Linear(F2, 1) of the pair MLP + diagonal / flag masks + score = -net / std + both losses (:86-94,157-179).
+ * out[0] = loss_x, out[1] = loss_adj; scale_* = 1/(B Nmax ncls), 1/(B Nmax^2) (reduce_mean) or 0.5/B;
+ * residuals res_adj [P], res_x [N, MSDE_DENSE_XP_LD] are kept for the backward; part = [B][2] workspace. */
+int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, const float* b2, const float* OUT,
+                        const float* z_adj, const float* z_x, const float* flags, const float* mean_std,
+                        const int* mol_ptr, const int* pair_ptr, int B, int ncls, float anneal_power,
+                        float scale_x, float scale_adj, float* res_adj, float* res_x, float* part, float* out,
+                        void* stream);
+/* g_out[0..1] = dL/dloss_x, dL/dloss_adj (device).  gS [P] = gradient of the pair MLP's scalar output, gZ2 [P,F2] =
+ * gradient of the pre-activation of its last hidden layer (SiLU), gOUT [N, MSDE_DENSE_XP_LD] = gradient of the node
+ * MLP's output. */
+int msde_dense_loss_bwd(const float* g_out, const float* res_adj, const float* res_x, const float* Z2, int F2,
+                        const float* w2, const float* flags, const float* mean_std, const int* mol_ptr,
+                        const int* pair_ptr, int B, int ncls, float anneal_power, float scale_x,
+                        float scale_adj, float* gS, float* gZ2, float* gOUT, void* stream);
 
 /* ------------------------------------------------------------------ contrastive loss ------- */
 /* do_CL('EBM_node_dot_prod') in both directions + dual_CL — examples/util.py:52-68,76-79.
@@ -298,6 +372,11 @@ int msde_linear_bwd_w_splits(int M, int N, int K);
  * number of workgroups it needs; prefix[p] = workgroups before problem p, prefix[count] = total_blocks. */
 int msde_linear_bwd_w_describe(const float* gY, const float* X, int M, int N, int K, int want_bias,
                                float* slabs, long long* host_row);
+/* the same for operands that are column blocks of wider buffers: ldg / ldx = row strides of gY / X (floats).
+ * Every table row is MSDE_WGRAD_ROW int64 wide. */
+#define MSDE_WGRAD_ROW 16
+int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const float* X, int ldx, int M, int N, int K,
+                                  int want_bias, float* slabs, long long* row);
 int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
                               void* stream);
 int msde_linear_bwd_w_partial(const float* gY, const float* X, int M, int N, int K, int want_bias,

@@ -50,11 +50,20 @@ SIGNATURES = {
     "msde_linear_bwd_w_workspace_bytes": [I, I, I],
     "msde_linear_bwd_w_splits": [I, I, I],
     "msde_linear_bwd_w_describe": [P, P, I, I, I, I, P, P],
+    "msde_linear_bwd_w_describe_ld": [P, I, P, I, I, I, I, I, P, P],
     "msde_linear_bwd_w_grouped": [P, P, I, I, P],
     "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
     "msde_gemm_ex": [P, P],
+    "msde_dense_prepare": [P, P, P, P, P, P, P, P, I, I, F, I, F, F, P, P, I, ULL, P, I, I, P, P, P, P, P, P, P],
+    "msde_dense_edge_layer_fwd": [P, P, P, I, I, I, I, P, P, P, P, I, I, P, P, P, P, P, P, P],
+    "msde_dense_edge_layer_bwd": [P, P, P, P, I, I, I, I, P, P, P, P, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P,
+                                  P],
+    "msde_dense_node_gcn_fwd": [P, P, P, P, P, P, I, I, P, I, P],
+    "msde_dense_node_gcn_bwd": [P, I, P, I, P, P, P, P, I, I, P, P, P],
+    "msde_dense_loss_fwd": [P, I, P, P, P, P, P, P, P, P, P, I, I, F, F, F, P, P, P, P, P],
+    "msde_dense_loss_bwd": [P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, P, P, P, P],
     "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],
     "msde_cl_ebm_bwd": [P, P, P, P, P, P, P, P, I, I, F, P, P, P],
     "msde_bn_workspace_floats": [I, I],
@@ -85,12 +94,18 @@ SIGNATURES = {
 
 class GemmDesc(ctypes.Structure):
     """msde_gemm_desc of include/msde_hip.h (field order and types must match)."""
-    _fields_ = [("A", P), ("A2", P), ("B", P), ("B2", P), ("bias", P), ("C", P), ("Z", P), ("R", P), ("rowscale", P),
-                ("a_gs", LL), ("b_gs", LL), ("bias_gs", LL), ("c_gs", LL), ("r_gs", LL),
+    _fields_ = [("A", P), ("A2", P), ("B", P), ("B2", P), ("bias", P), ("bias2", P), ("C", P), ("Z", P), ("R", P),
+                ("rowscale", P),
+                ("a_gs", LL), ("b_gs", LL), ("bias_gs", LL), ("c_gs", LL), ("r_gs", LL), ("b_kblk_stride", LL),
                 ("M", I), ("N", I), ("K1", I), ("K2", I),
                 ("lda", I), ("lda2", I), ("ldb", I), ("ldb2", I), ("ldc", I), ("ldz", I), ("ldr", I),
                 ("act", I), ("act_lo", I), ("act_hi", I), ("epi", I), ("flags", I), ("groups", I),
-                ("alpha", F)]
+                ("b_kblk_log2", I), ("alpha", F)]
+
+
+class EdgeLayerParams(ctypes.Structure):
+    """msde_edge_layer_params of include/msde_hip.h."""
+    _fields_ = [(n, P) for n in ("bv", "mW0", "mb0", "mW1", "mb1", "mW2", "mb2", "cW0", "cb0", "cW1", "cb1")]
 
 
 ACT = {None: 0, "none": 0, "tanh": 1, "silu": 2, "elu": 3, "ssp": 4, "relu": 5}

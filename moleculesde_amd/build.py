@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmsde_hip.so")
-SOURCES = ["graph.hip", "gin.hip", "schnet.hip", "cfconv_fused.hip", "cfconv_fused_bwd.hip", "sde2d3d.hip", "linear.hip", "gemm_ex.hip", "norm.hip", "contrastive.hip", "optim.hip", "pointwise.hip", "gat_tail.hip"]
+SOURCES = ["graph.hip", "gin.hip", "schnet.hip", "cfconv_fused.hip", "cfconv_fused_bwd.hip", "sde2d3d.hip", "linear.hip", "gemm_ex.hip", "dense_head.hip", "norm.hip", "contrastive.hip", "optim.hip", "pointwise.hip", "gat_tail.hip"]
 
 
 def needs_build():
@@ -24,7 +24,7 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result"] + os.environ.get("MSDE_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+           "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("MSDE_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,0 +1,885 @@
+// dense_head.hip — the 3D->2D dense score head (SDEModel3Dto2D_node_adj_dense, EdgeScoreNetwork_dense,
+// NodeScoreNetwork_dense) on RAGGED data: nothing is padded.
+//
+// The reference densifies every molecule to N_max atoms (to_dense_batch / to_dense_adj,
+// SDE_model_3D_to_2D_node_adj_dense.py:129-131) and runs [B, N_max, ...] tensor ops; padded atoms and atoms without
+// bonds are masked by `flags` after every layer, so no valid atom or pair ever depends on a padded one (adjacency
+// rows of masked atoms are zero, attention is pairwise without a softmax, the GCN self loop only feeds the atom
+// itself).  Here atoms stay in the batch's ragged order ([N, F] rows, molecule b = rows mol_ptr[b]..mol_ptr[b+1]) and
+// atom PAIRS live in a ragged pair list: molecule b owns rows pair_ptr[b] + i*n_b + j of every [P, *] array
+// (P = sum n_b^2).  Results are identical to the reference's on the valid entries; N_max only enters the loss
+// normaliser (the reference's padded mean, App. B.5).
+//
+// Kernels (one workgroup per molecule unless noted; n_b <= 32):
+//   dense_prepare        adjacency from the bond CSR, flags, VE/VP perturbation of adjacency and one-hot atom classes,
+//                        adj^2 channel (pow_tensor, invariant_scorenetwork_dense.py:28-37)
+//   dense_edge_layer_fwd/bwd   everything of EdgeNetwork_dense.forward (edge_network_dense.py:105-128) that is not a
+//                        node-level GEMM: per-channel dense GCN (node_network_dense.py:66-85), tanh attention over
+//                        the 8 effective head chunks (:66-80, App. B.3), symmetrisation, the pair MLP, the channel
+//                        MLP, masks
+//   dense_node_gcn_fwd/bwd     the 4 dense-GCN + tanh layers of NodeScoreNetwork_dense (invariant_scorenetwork_dense.py:118-122)
+//   dense_loss_fwd/bwd   last Linear(60,1) of the pair MLP, diagonal/flag masks, score = -net/std, both losses
+//                        (SDE_model_3D_to_2D_node_adj_dense.py:86-94,157-179) and their gradients
+// The GEMM-shaped parts (embeddings, stacked q/k/v projections, the 364->728->728->119 and 30->60->60 chains, every
+// input/weight gradient) run on msde_gemm_ex / the grouped weight-gradient kernel.
+#include "msde_common.h"
+
+#define DH_NMAX 32
+#define DH_AC MSDE_DENSE_AC_LD     // 32: row stride of the pair channel buffer (30 channels used)
+#define DH_XP MSDE_DENSE_XP_LD     // 120: row stride of the atom-class buffers (119 classes)
+
+__device__ __forceinline__ float dh_elu(float z) { return z > 0.f ? z : expm1f(z); }
+__device__ __forceinline__ float dh_delu_y(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+__device__ __forceinline__ float dh_randn(unsigned long long seed, unsigned long long idx) {
+  float u1 = msde_uniform(seed, 2ull * idx), u2 = msde_uniform(seed, 2ull * idx + 1ull);
+  u1 = fmaxf(u1, 5.9604645e-8f);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// ================================================================================================ prepare
+__global__ void __launch_bounds__(256)
+dense_prepare_kernel(const int* __restrict__ rowptr, const int* __restrict__ src, const float* __restrict__ bond_val,
+                     const int* __restrict__ z_atom, const int* __restrict__ mol_ptr, const int* __restrict__ pair_ptr,
+                     const long long* __restrict__ draws, const float* __restrict__ t_in, int B, int T, float eps,
+                     int sde_vp, float p0, float p1, const float* __restrict__ noise_adj,
+                     const float* __restrict__ noise_x, int Nm_pad, unsigned long long seed,
+                     const unsigned long long* __restrict__ seed_dev, int ncls, float* __restrict__ AC,
+                     float* __restrict__ z_adj, float* __restrict__ flags, float* __restrict__ mean_std,
+                     float* __restrict__ px, float* __restrict__ z_x) {
+  __shared__ float adj[DH_NMAX][DH_NMAX + 1];
+  __shared__ float pa[DH_NMAX][DH_NMAX + 1];
+  __shared__ float fl[DH_NMAX];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
+  // diffusion time of this molecule (antithetic integer draws, :112-114) and the SDE's marginal (SDE_dense.py:200-203)
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
+  float t;
+  if (t_in) {
+    t = t_in[b];
+  } else {
+    const int H = B / 2 + 1;
+    long long ts;
+    if (draws) {
+      ts = b < H ? draws[b] : (long long)T - draws[b - H] - 1;
+    } else {         // device draws: uniform integer in [0, T) per antithetic pair
+      const float u = msde_uniform(seed ^ 0x7157EEDC0FFEEull, (unsigned long long)(b < H ? b : b - H));
+      long long d0 = (long long)(u * (float)T);
+      if (d0 > T - 1) d0 = T - 1;
+      ts = b < H ? d0 : (long long)T - d0 - 1;
+    }
+    t = (float)ts / (float)T;
+    t = t * (1.0f - eps) + eps;
+  }
+  float meanc, sd;
+  if (sde_vp) {      // VPSDE: p0 = beta_0, p1 = beta_1
+    const float lmc = -0.25f * t * t * (p1 - p0) - 0.5f * t * p0;
+    meanc = expf(lmc);
+    sd = sqrtf(1.0f - expf(2.0f * lmc));
+  } else {           // VESDE: p0 = sigma_min, p1 = sigma_max
+    meanc = 1.f;
+    sd = p0 * powf(p1 / p0, t);
+  }
+  if (tid == 0) { mean_std[2 * b] = meanc; mean_std[2 * b + 1] = sd; }
+
+  for (int e = tid; e < DH_NMAX * (DH_NMAX + 1); e += 256) (&adj[0][0])[e] = 0.f;
+  __syncthreads();
+  // to_dense_adj with value bond type + 1 (:121,131): adj[src][dst] += v (duplicates add)
+  const int e0 = rowptr[a0], e1 = rowptr[a0 + n];
+  for (int e = e0 + tid; e < e1; e += 256) {
+    // target of canonical edge e: the row whose [rowptr[i], rowptr[i+1]) contains e (n <= 32: linear scan)
+    int i = 0;
+    while (i + 1 < n && rowptr[a0 + i + 1] <= e) ++i;
+    const int s = src[e] - a0;
+    if (s >= 0 && s < n) atomicAdd(&adj[s][i], bond_val[e] + 1.0f);
+  }
+  __syncthreads();
+  if (tid < n) {     // node_flags (:523-529)
+    float s = 0.f;
+    for (int j = 0; j < n; ++j) s += fabsf(adj[tid][j]);
+    const float f = s > 1e-5f ? 1.f : 0.f;
+    fl[tid] = f;
+    flags[a0 + tid] = f;
+  }
+  __syncthreads();
+  // symmetric masked noise (gen_noise, :532-540) and the perturbed adjacency (:135-138)
+  for (int p = tid; p < n * n; p += 256) {
+    const int i = p / n, j = p - i * n;
+    float z = 0.f;
+    if (i != j) {
+      const int lo = min(i, j), hi = max(i, j);
+      z = noise_adj ? noise_adj[((size_t)b * Nm_pad + lo) * Nm_pad + hi]
+                    : dh_randn(seed, (unsigned long long)(q0 + lo * n + hi));
+    }
+    const float m = fl[i] * fl[j];
+    z *= m;
+    z_adj[q0 + p] = z;
+    pa[i][j] = (meanc * adj[i][j] + sd * z) * m;
+  }
+  __syncthreads();
+  for (int p = tid; p < n * n; p += 256) {
+    const int i = p / n, j = p - i * n;
+    float s2 = 0.f;
+    for (int k = 0; k < n; ++k) s2 = fmaf(pa[i][k], pa[k][j], s2);       // pow_tensor channel 2
+    float* row = AC + (size_t)(q0 + p) * DH_AC;
+    row[0] = pa[i][j];
+    row[1] = s2;
+    row[DH_AC - 2] = 0.f;
+    row[DH_AC - 1] = 0.f;
+  }
+  // one-hot atom classes + noise (:143-152); column ncls .. DH_XP-1 of the padded rows stay zero
+  const unsigned long long seed_x = seed ^ 0xA5A5A5A5DEADBEEFull;
+  for (int e = tid; e < n * DH_XP; e += 256) {
+    const int i = e / DH_XP, c = e - i * DH_XP;
+    float z = 0.f, xp = 0.f;
+    if (c < ncls) {
+      const float f = fl[i];
+      z = noise_x ? noise_x[((size_t)b * Nm_pad + i) * ncls + c]
+                  : dh_randn(seed_x, (unsigned long long)(a0 + i) * ncls + c);
+      z *= f;
+      const float x0 = (z_atom[a0 + i] == c) ? 1.f : 0.f;
+      xp = (meanc * x0 + sd * z) * f;
+    }
+    z_x[(size_t)(a0 + i) * DH_XP + c] = z;
+    px[(size_t)(a0 + i) * DH_XP + c] = xp;
+  }
+}
+
+extern "C" int msde_dense_prepare(const int* rowptr, const int* src, const float* bond_val, const int* z_atom,
+                                  const int* mol_ptr, const int* pair_ptr, const long long* draws, const float* t_in,
+                                  int B, int T, float eps, int sde_vp, float p0, float p1, const float* noise_adj,
+                                  const float* noise_x, int Nm_pad, unsigned long long seed,
+                                  const unsigned long long* seed_dev, int ncls, int n_max, float* AC, float* z_adj,
+                                  float* flags, float* mean_std, float* px, float* z_x, void* stream) {
+  if (B < 0 || !rowptr || !src || !bond_val || !z_atom || !mol_ptr || !pair_ptr || !AC || !z_adj ||
+      !flags || !mean_std || !px || !z_x || ncls <= 0 || ncls > DH_XP)
+    return MSDE_EINVAL;
+  if ((noise_adj == nullptr) != (noise_x == nullptr)) return MSDE_EINVAL;
+  if (n_max > DH_NMAX) return MSDE_EUNSUP;
+  if (B == 0) return 0;
+  MSDE_LAUNCH(dense_prepare_kernel, dim3(B), dim3(256), 0, as_stream(stream), rowptr, src, bond_val, z_atom, mol_ptr,
+              pair_ptr, draws, t_in, B, T, eps, sde_vp, p0, p1, noise_adj, noise_x, Nm_pad, seed, seed_dev, ncls, AC, z_adj,
+              flags, mean_std, px, z_x);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ================================================================================================ edge layer
+// LDS map (floats), C input channels, n atoms (row strides odd -> conflict-free for "lane = pair" access):
+//   Qs, Ks  [n][32C+1]      func_q / func_k outputs
+//   Ad      [n*n][C+1]      input adjacency channels (backward: later overwritten by dL/dA)
+//   Xv      [n][16C+1]      x W_c (forward) -> after the GCN: V = xcat
+//   Wk      weights: pair MLP (W0 [16][2C], b0, W1 [16][16], b1, W2 [CO][16], b2), channel MLP (W0 [16][16C], b0,
+//           W1 [16][16], b1), bv [16C]
+template <int C, int CO>
+struct EdgeLds {
+  static constexpr int LQ = 32 * C + 1, LA = C + 1, LV = 16 * C + 1;
+  static constexpr int W_M0 = 0, B_M0 = W_M0 + 16 * 2 * C, W_M1 = B_M0 + 16, B_M1 = W_M1 + 256, W_M2 = B_M1 + 16,
+                       B_M2 = W_M2 + CO * 16, W_C0 = B_M2 + CO, B_C0 = W_C0 + 16 * 16 * C, W_C1 = B_C0 + 16,
+                       B_C1 = W_C1 + 256, B_V = B_C1 + 16, W_END = B_V + 16 * C;
+  __host__ __device__ static int floats(int nm) {
+    return 2 * nm * LQ + nm * nm * LA + 2 * nm * LV + nm * 17 * 2 + nm * 8 + ((W_END + 3) & ~3) + 8;
+  }
+};
+
+template <int C, int CO>
+__device__ __forceinline__ void edge_load_weights(float* Wk, const msde_edge_layer_params& p, int tid) {
+  using L = EdgeLds<C, CO>;
+  for (int e = tid; e < 16 * 2 * C; e += 256) Wk[L::W_M0 + e] = p.mW0[e];
+  for (int e = tid; e < 256; e += 256) { Wk[L::W_M1 + e] = p.mW1[e]; Wk[L::W_C1 + e] = p.cW1[e]; }
+  for (int e = tid; e < CO * 16; e += 256) Wk[L::W_M2 + e] = p.mW2[e];
+  for (int e = tid; e < 16 * 16 * C; e += 256) Wk[L::W_C0 + e] = p.cW0[e];
+  if (tid < 16) { Wk[L::B_M0 + tid] = p.mb0[tid]; Wk[L::B_M1 + tid] = p.mb1[tid]; Wk[L::B_C0 + tid] = p.cb0[tid]; Wk[L::B_C1 + tid] = p.cb1[tid]; }
+  if (tid < CO) Wk[L::B_M2 + tid] = p.mb2[tid];
+  for (int e = tid; e < 16 * C; e += 256) Wk[L::B_V + e] = p.bv[e];
+}
+
+// stage Q | K, the adjacency channels and x W_c of one molecule; computes r[i] = clamp(deg_i, 1)^-1/2 per channel
+template <int C, int CO>
+__device__ __forceinline__ void edge_stage(float* Qs, float* Ks, float* Ad, float* Xv, float* Rn, const float* QK,
+                                           const float* XV, const float* AC, int in_off, int a0, int n, int q0, int tid) {
+  using L = EdgeLds<C, CO>;
+  constexpr int W = 32 * C;
+  for (int e = tid; e < n * (W / 4); e += 256) {
+    const int i = e / (W / 4), c4 = (e - i * (W / 4)) * 4;
+    const float4 q = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + c4);
+    const float4 k = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + W + c4);
+    float* qd = Qs + i * L::LQ + c4;
+    float* kd = Ks + i * L::LQ + c4;
+    qd[0] = q.x; qd[1] = q.y; qd[2] = q.z; qd[3] = q.w;
+    kd[0] = k.x; kd[1] = k.y; kd[2] = k.z; kd[3] = k.w;
+  }
+  for (int e = tid; e < n * n * C; e += 256) {
+    const int p = e / C, c = e - p * C;
+    Ad[p * L::LA + c] = AC[(size_t)(q0 + p) * DH_AC + in_off + c];
+  }
+  for (int e = tid; e < n * 16 * C; e += 256) {
+    const int i = e / (16 * C), f = e - i * 16 * C;
+    Xv[i * L::LV + f] = XV[(size_t)(a0 + i) * (16 * C) + f];
+  }
+  __syncthreads();
+  // normalised adjacency of node_network_dense.py:66-74: diagonal := 1, deg = row sum clamped at 1
+  for (int e = tid; e < n * C; e += 256) {
+    const int i = e / C, c = e - i * C;
+    float s = 1.f;
+    for (int j = 0; j < n; ++j)
+      if (j != i) s += Ad[(i * n + j) * L::LA + c];
+    Rn[i * C + c] = rsqrtf(fmaxf(s, 1.f));
+  }
+  __syncthreads();
+}
+
+template <int C>
+__device__ __forceinline__ float edge_an(const float* Ad, const float* Rn, int n, int i, int j, int c) {
+  const float a = (i == j) ? 1.f : Ad[(i * n + j) * (C + 1) + c];
+  return Rn[i * C + c] * a * Rn[j * C + c];
+}
+
+// mean over the 8 head chunks of tanh(q_i . k_j / 2) for channel c (edge_network_dense.py:66-80; 8 chunks: App. B.3)
+template <int C>
+__device__ __forceinline__ float edge_att(const float* Qs, const float* Ks, int i, int j, int c) {
+  const float* q = Qs + i * (32 * C + 1) + 32 * c;
+  const float* k = Ks + j * (32 * C + 1) + 32 * c;
+  float acc = 0.f;
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    float s = q[4 * h] * k[4 * h];
+    s = fmaf(q[4 * h + 1], k[4 * h + 1], s);
+    s = fmaf(q[4 * h + 2], k[4 * h + 2], s);
+    s = fmaf(q[4 * h + 3], k[4 * h + 3], s);
+    acc += tanhf(0.5f * s);
+  }
+  return acc * 0.125f;
+}
+
+template <int C, int CO>
+__global__ void __launch_bounds__(256)
+dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restrict__ XV, float* __restrict__ AC, int in_off,
+                            int out_off, const float* __restrict__ flags, const int* __restrict__ mol_ptr,
+                            const int* __restrict__ pair_ptr, const msde_edge_layer_params p, int nm,
+                            float* __restrict__ x_out, float* __restrict__ IN, float* __restrict__ H1,
+                            float* __restrict__ H2, float* __restrict__ xcat, float* __restrict__ Hmc) {
+  using L = EdgeLds<C, CO>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Qs = lds;
+  float* Ks = Qs + nm * L::LQ;
+  float* Ad = Ks + nm * L::LQ;
+  float* Xv = Ad + nm * nm * L::LA;
+  float* Vc = Xv + nm * L::LV;
+  float* Hm = Vc + nm * L::LV;        // [n][17]
+  float* Tm = Hm + nm * 17;           // [n][17] scratch
+  float* Rn = Tm + nm * 17;           // [n][C], C <= 8
+  float* Wk = Rn + nm * 8;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
+  edge_load_weights<C, CO>(Wk, p, tid);
+  edge_stage<C, CO>(Qs, Ks, Ad, Xv, Rn, QK, XV, AC, in_off, a0, n, q0, tid);
+
+  // ---- per-channel dense GCN: V_c = An_c (x W_c) + b_c; xcat[i][16c+f]
+  for (int e = tid; e < n * 16 * C; e += 256) {
+    const int i = e / (16 * C), cf = e - i * 16 * C, c = cf >> 4;
+    float s = Wk[L::B_V + cf];
+    for (int j = 0; j < n; ++j) s = fmaf(edge_an<C>(Ad, Rn, n, i, j, c), Xv[j * L::LV + cf], s);
+    Vc[i * L::LV + cf] = s;
+    xcat[(size_t)(a0 + i) * (16 * C) + cf] = s;
+  }
+  __syncthreads();
+  // ---- channel MLP (multi_channel): 16C -> 16 (elu) -> 16, mask, tanh
+  for (int e = tid; e < n * 16; e += 256) {
+    const int i = e >> 4, o = e & 15;
+    float s = Wk[L::B_C0 + o];
+    const float* w = Wk + L::W_C0 + o * 16 * C;
+    for (int k = 0; k < 16 * C; ++k) s = fmaf(w[k], Vc[i * L::LV + k], s);
+    s = dh_elu(s);
+    Hm[i * 17 + o] = s;
+    Hmc[(size_t)(a0 + i) * 16 + o] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < n * 16; e += 256) {
+    const int i = e >> 4, o = e & 15;
+    float s = Wk[L::B_C1 + o];
+    const float* w = Wk + L::W_C1 + o * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s = fmaf(w[k], Hm[i * 17 + k], s);
+    x_out[(size_t)(a0 + i) * 16 + o] = tanhf(s * flags[a0 + i]);
+  }
+  // ---- pairs: attention, pair MLP, symmetrise (= x2: inputs are symmetric, so mlp(i,j) == mlp(j,i)), mask
+  for (int pp = tid; pp < n * n; pp += 256) {
+    const int i = pp / n, j = pp - i * n;
+    // the weights are loop invariant: without this opaque zero in their address the compiler hoists all ~640 LDS reads
+    // out of the pair loop into registers (and spills)
+    int zofs = 0;
+    asm volatile("" : "+v"(zofs));
+    const float* Wp = Wk + zofs;
+    float in[2 * C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      in[c] = 0.5f * (edge_att<C>(Qs, Ks, i, j, c) + edge_att<C>(Qs, Ks, j, i, c));
+      in[C + c] = Ad[pp * L::LA + c];
+    }
+    float h1[16], h2[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      float s = Wp[L::B_M0 + o];
+#pragma unroll
+      for (int k = 0; k < 2 * C; ++k) s = fmaf(Wp[L::W_M0 + o * 2 * C + k], in[k], s);
+      h1[o] = dh_elu(s);
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      float s = Wp[L::B_M1 + o];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s = fmaf(Wp[L::W_M1 + o * 16 + k], h1[k], s);
+      h2[o] = dh_elu(s);
+    }
+    const float m = 2.f * flags[a0 + i] * flags[a0 + j];
+    float* acrow = AC + (size_t)(q0 + pp) * DH_AC + out_off;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      float s = Wp[L::B_M2 + o];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s = fmaf(Wp[L::W_M2 + o * 16 + k], h2[k], s);
+      acrow[o] = s * m;
+    }
+    float* inrow = IN + (size_t)(q0 + pp) * (2 * C);
+#pragma unroll
+    for (int k = 0; k < 2 * C; ++k) inrow[k] = in[k];
+    float* h1row = H1 + (size_t)(q0 + pp) * 16;
+    float* h2row = H2 + (size_t)(q0 + pp) * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { h1row[k] = h1[k]; h2row[k] = h2[k]; }
+  }
+}
+
+// Backward of the layer.  Inputs: g_xout [N,16] (nullptr: x_out is unused -- last layer), gAC (gradient of the pair
+// buffer: this layer's OUTPUT block is read, its INPUT block is accumulated into when need_gadj), the forward's saved
+// IN / H1 / H2 / xcat / Hmc / x_out.  Outputs: gQK [N, 64C], gXV [N,16C], and the operands of the weight-gradient
+// GEMMs: GO [P,CO], GH2 [P,16], GH1 [P,16] (pair MLP), GY [N,16], GHm [N,16] (channel MLP), GV [N,16C] (bias of V).
+template <int C, int CO>
+__global__ void __launch_bounds__(256)
+dense_edge_layer_bwd_kernel(const float* __restrict__ QK, const float* __restrict__ XV, const float* __restrict__ AC,
+                            float* __restrict__ gAC, int in_off, int out_off, const float* __restrict__ flags,
+                            const int* __restrict__ mol_ptr, const int* __restrict__ pair_ptr,
+                            const msde_edge_layer_params p, int nm, const float* __restrict__ x_out,
+                            const float* __restrict__ g_xout, const float* __restrict__ IN, const float* __restrict__ H1,
+                            const float* __restrict__ H2, const float* __restrict__ xcat, const float* __restrict__ Hmc,
+                            int need_gadj, float* __restrict__ gQK, float* __restrict__ gXV, float* __restrict__ GO,
+                            float* __restrict__ GH2, float* __restrict__ GH1, float* __restrict__ GY,
+                            float* __restrict__ GHm, float* __restrict__ GV) {
+  using L = EdgeLds<C, CO>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Qs = lds;
+  float* Ks = Qs + nm * L::LQ;
+  float* Ad = Ks + nm * L::LQ;
+  float* Xv = Ad + nm * nm * L::LA;
+  float* Vc = Xv + nm * L::LV;        // gV
+  float* Hm = Vc + nm * L::LV;        // g of channel-MLP hidden (pre-activation)
+  float* Tm = Hm + nm * 17;           // g_y
+  float* Rn = Tm + nm * 17;
+  float* Wk = Rn + nm * 8;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
+  edge_load_weights<C, CO>(Wk, p, tid);
+  edge_stage<C, CO>(Qs, Ks, Ad, Xv, Rn, QK, XV, AC, in_off, a0, n, q0, tid);
+
+  // ---- node branch: x_out = tanh(flag * (W1 hm + b1)), hm = elu(W0 xcat + b0), xcat = V
+  const bool node = g_xout != nullptr;
+  if (node) {
+    for (int e = tid; e < n * 16; e += 256) {
+      const int i = e >> 4, o = e & 15;
+      const float y = x_out[(size_t)(a0 + i) * 16 + o];
+      const float g = g_xout[(size_t)(a0 + i) * 16 + o] * (1.f - y * y) * flags[a0 + i];
+      Tm[i * 17 + o] = g;
+      GY[(size_t)(a0 + i) * 16 + o] = g;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * 16; e += 256) {
+      const int i = e >> 4, k = e & 15;
+      float s = 0.f;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) s = fmaf(Wk[L::W_C1 + o * 16 + k], Tm[i * 17 + o], s);
+      s *= dh_delu_y(Hmc[(size_t)(a0 + i) * 16 + k]);
+      Hm[i * 17 + k] = s;
+      GHm[(size_t)(a0 + i) * 16 + k] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * 16 * C; e += 256) {
+      const int i = e / (16 * C), cf = e - i * 16 * C;
+      float s = 0.f;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) s = fmaf(Wk[L::W_C0 + o * 16 * C + cf], Hm[i * 17 + o], s);
+      Vc[i * L::LV + cf] = s;
+      GV[(size_t)(a0 + i) * (16 * C) + cf] = s;
+    }
+    __syncthreads();
+    // g(xW_c)[j][f] = sum_i An_c[i][j] gV_c[i][f]
+    for (int e = tid; e < n * 16 * C; e += 256) {
+      const int j = e / (16 * C), cf = e - j * 16 * C, c = cf >> 4;
+      float s = 0.f;
+      for (int i = 0; i < n; ++i) s = fmaf(edge_an<C>(Ad, Rn, n, i, j, c), Vc[i * L::LV + cf], s);
+      gXV[(size_t)(a0 + j) * (16 * C) + cf] = s;
+    }
+  }
+  // ---- gradient w.r.t. the input adjacency channels through the GCN normalisation (layers >= 1 only)
+  // An_ij = r_i a_ij r_j, r_i = d_i^-1/2, d_i = max(1 + sum_{j != i} a_ij, 1), a_ii := 1
+  //   G_ij = dL/dAn_ij = sum_f gV[i][f] xW[j][f];  dL/da_ij (i != j) = G_ij r_i r_j + gd_i
+  //   gd_i = [d_i unclamped] * (-1/2) d_i^-3/2 * ( sum_j G_ij a_ij r_j + sum_k G_ki a_ki r_k )
+  float gadj[4][C];           // <= 4 pairs per thread (n <= 32)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int c = 0; c < C; ++c) gadj[u][c] = 0.f;
+  if (need_gadj && node) {
+    __syncthreads();
+    float* Gd = Tm;            // [n][C] reuse (n*C <= 17n)
+    for (int e = tid; e < n * C; e += 256) {
+      const int i = e / C, c = e - i * C;
+      float deg = 1.f;
+      for (int j = 0; j < n; ++j)
+        if (j != i) deg += Ad[(i * n + j) * L::LA + c];
+      float acc = 0.f;
+      if (deg >= 1.f) {
+        const float ri = Rn[i * C + c];
+        for (int j = 0; j < n; ++j) {
+          const float aij = (i == j) ? 1.f : Ad[(i * n + j) * L::LA + c];
+          const float aji = (i == j) ? 1.f : Ad[(j * n + i) * L::LA + c];
+          float gij = 0.f, gji = 0.f;
+#pragma unroll
+          for (int f = 0; f < 16; ++f) {
+            gij = fmaf(Vc[i * L::LV + 16 * c + f], Xv[j * L::LV + 16 * c + f], gij);
+            gji = fmaf(Vc[j * L::LV + 16 * c + f], Xv[i * L::LV + 16 * c + f], gji);
+          }
+          acc += (gij * aij + gji * aji) * Rn[j * C + c];
+        }
+        acc *= -0.5f * ri * ri * ri;
+      }
+      Gd[i * C + c] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {          // static u: gadj stays in registers
+      const int pp = tid + 256 * u;
+      if (pp < n * n) {
+        const int i = pp / n, j = pp - i * n;
+        if (i != j) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            float gij = 0.f;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) gij = fmaf(Vc[i * L::LV + 16 * c + f], Xv[j * L::LV + 16 * c + f], gij);
+            gadj[u][c] = gij * Rn[i * C + c] * Rn[j * C + c] + Gd[i * C + c];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pair branch: out(i,j) = f_i f_j (mlp(i,j) + mlp(j,i)), mlp = W2 h2 + b2, h2 = elu(W1 h1 + b1), h1 = elu(W0 in + b0)
+  // => dL/dmlp(i,j) = f_i f_j (g_out(i,j) + g_out(j,i)); the incoming gradient is NOT symmetric in general (the next
+  // layer's GCN normalisation treats rows and columns differently), the result is.
+  {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = tid + 256 * u;
+      if (pp >= n * n) continue;
+      const int i = pp / n, j = pp - i * n;
+      int zofs = 0;
+      asm volatile("" : "+v"(zofs));          // see the forward kernel: keeps the weight reads inside the loop
+      const float* Wp = Wk + zofs;
+      const float m = flags[a0 + i] * flags[a0 + j];
+      const float* grow = gAC + (size_t)(q0 + pp) * DH_AC + out_off;
+      const float* growT = gAC + (size_t)(q0 + j * n + i) * DH_AC + out_off;
+      float go[CO];
+#pragma unroll
+      for (int o = 0; o < CO; ++o) { go[o] = (grow[o] + growT[o]) * m; GO[(size_t)(q0 + pp) * CO + o] = go[o]; }
+      const float* h1row = H1 + (size_t)(q0 + pp) * 16;
+      const float* h2row = H2 + (size_t)(q0 + pp) * 16;
+      float g2[16], g1[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) s = fmaf(Wp[L::W_M2 + o * 16 + k], go[o], s);
+        g2[k] = s * dh_delu_y(h2row[k]);
+        GH2[(size_t)(q0 + pp) * 16 + k] = g2[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) s = fmaf(Wp[L::W_M1 + o * 16 + k], g2[o], s);
+        g1[k] = s * dh_delu_y(h1row[k]);
+        GH1[(size_t)(q0 + pp) * 16 + k] = g1[k];
+      }
+      float gin[2 * C];
+#pragma unroll
+      for (int k = 0; k < 2 * C; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) s = fmaf(Wp[L::W_M0 + o * 2 * C + k], g1[o], s);
+        gin[k] = s;
+      }
+      if (need_gadj) {
+        float* gin_row = gAC + (size_t)(q0 + pp) * DH_AC + in_off;
+#pragma unroll
+        for (int c = 0; c < C; ++c) gin_row[c] += gin[C + c] + gadj[u][c];
+      }
+      // dL/dA (symmetric: pair (j,i) computes the same numbers) replaces the adjacency in LDS: nothing below reads Ad
+#pragma unroll
+      for (int c = 0; c < C; ++c) Ad[pp * L::LA + c] = gin[c];
+    }
+  }
+  __syncthreads();
+  // ---- attention backward.  A = (T + T^T)/2 and dL/dA symmetric => dL/dT = dL/dA.
+  //   T_ij = 1/8 sum_h tanh(s_h), s_h = q_i[h] . k_j[h] / 2  =>  g_s = dL/dT_ij / 8 * (1 - tanh^2)
+  //   g_q[i][h] = sum_j g_s(i,j) k_j[h] / 2,  g_k[j][h] = sum_i g_s(i,j) q_i[h] / 2
+  for (int e = tid; e < n * C * 8 * 2; e += 256) {
+    const int which = e / (n * C * 8);            // 0: g_q, 1: g_k
+    const int r = e - which * n * C * 8;
+    const int i = r / (C * 8), ch = r - i * C * 8, c = ch >> 3, h = ch & 7;
+    const float* mine = (which ? Ks : Qs) + i * L::LQ + 32 * c + 4 * h;
+    const float* oth = (which ? Qs : Ks) + 32 * c + 4 * h;
+    const float m0 = mine[0], m1 = mine[1], m2 = mine[2], m3 = mine[3];
+    float a0_ = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int j = 0; j < n; ++j) {
+      const float* o = oth + j * L::LQ;
+      const float s = 0.5f * (m0 * o[0] + m1 * o[1] + m2 * o[2] + m3 * o[3]);
+      const float th = tanhf(s);
+      const int pp = which ? (j * n + i) : (i * n + j);
+      const float gs = Ad[pp * L::LA + c] * 0.125f * (1.f - th * th) * 0.5f;
+      a0_ = fmaf(gs, o[0], a0_); a1 = fmaf(gs, o[1], a1); a2 = fmaf(gs, o[2], a2); a3 = fmaf(gs, o[3], a3);
+    }
+    float* dst = gQK + (size_t)(a0 + i) * (64 * C) + which * 32 * C + 32 * c + 4 * h;
+    dst[0] = a0_; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+  }
+}
+
+template <int C, int CO>
+static int edge_lds_bytes(int nm) { return EdgeLds<C, CO>::floats(nm) * (int)sizeof(float); }
+
+#define EDGE_DISPATCH(KERNEL, ...)                                                                                  \
+  do {                                                                                                              \
+    int bytes;                                                                                                      \
+    if (edge_lds_bytes<8, 8>(nm) > 160 * 1024) return MSDE_EUNSUP;                                                  \
+    if (C == 2 && CO == 8) {                                                                                        \
+      bytes = edge_lds_bytes<2, 8>(nm);                                                                             \
+      static bool s0 = false;                                                                                       \
+      if (!s0) { hipFuncSetAttribute((const void*)KERNEL<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); s0 = true; } \
+      MSDE_LAUNCH((KERNEL<2, 8>), dim3(B), dim3(256), bytes, st, __VA_ARGS__);                                      \
+    } else if (C == 8 && CO == 8) {                                                                                 \
+      bytes = edge_lds_bytes<8, 8>(nm);                                                                             \
+      static bool s1 = false;                                                                                       \
+      if (!s1) { hipFuncSetAttribute((const void*)KERNEL<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); s1 = true; } \
+      MSDE_LAUNCH((KERNEL<8, 8>), dim3(B), dim3(256), bytes, st, __VA_ARGS__);                                      \
+    } else if (C == 8 && CO == 4) {                                                                                 \
+      bytes = edge_lds_bytes<8, 4>(nm);                                                                             \
+      static bool s2 = false;                                                                                       \
+      if (!s2) { hipFuncSetAttribute((const void*)KERNEL<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); s2 = true; } \
+      MSDE_LAUNCH((KERNEL<8, 4>), dim3(B), dim3(256), bytes, st, __VA_ARGS__);                                      \
+    } else {                                                                                                        \
+      return MSDE_EUNSUP;                                                                                           \
+    }                                                                                                               \
+    (void)bytes;                                                                                                    \
+  } while (0)
+
+extern "C" int msde_dense_edge_layer_fwd(const float* QK, const float* XV, float* AC, int in_off, int out_off, int C,
+                                         int CO, const float* flags, const int* mol_ptr, const int* pair_ptr,
+                                         const msde_edge_layer_params* params, int B, int n_max, float* x_out,
+                                         float* IN, float* H1, float* H2, float* xcat, float* Hmc, void* stream) {
+  if (B < 0 || !QK || !XV || !AC || !flags || !mol_ptr || !pair_ptr || !params || !x_out || !IN || !H1 || !H2 || !xcat ||
+      !Hmc || in_off < 0 || out_off < 0 || in_off + C > DH_AC || out_off + CO > DH_AC)
+    return MSDE_EINVAL;
+  if (n_max > DH_NMAX) return MSDE_EUNSUP;
+  if (B == 0) return 0;
+  const int nm = n_max < 1 ? 1 : n_max;
+  hipStream_t st = as_stream(stream);
+  const msde_edge_layer_params p = *params;
+  EDGE_DISPATCH(dense_edge_layer_fwd_kernel, QK, XV, AC, in_off, out_off, flags, mol_ptr, pair_ptr, p, nm, x_out, IN, H1, H2,
+                xcat, Hmc);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_dense_edge_layer_bwd(const float* QK, const float* XV, const float* AC, float* gAC, int in_off,
+                                         int out_off, int C, int CO, const float* flags, const int* mol_ptr,
+                                         const int* pair_ptr, const msde_edge_layer_params* params, int B, int n_max,
+                                         const float* x_out, const float* g_xout, const float* IN, const float* H1,
+                                         const float* H2, const float* xcat, const float* Hmc, int need_gadj, float* gQK,
+                                         float* gXV, float* GO, float* GH2, float* GH1, float* GY, float* GHm, float* GV,
+                                         void* stream) {
+  if (B < 0 || !QK || !XV || !AC || !gAC || !flags || !mol_ptr || !pair_ptr || !params || !x_out || !IN || !H1 || !H2 ||
+      !xcat || !Hmc || !gQK || !GO || !GH2 || !GH1 || in_off + C > DH_AC || out_off + CO > DH_AC)
+    return MSDE_EINVAL;
+  if (g_xout && (!gXV || !GY || !GHm || !GV)) return MSDE_EINVAL;
+  if (n_max > DH_NMAX) return MSDE_EUNSUP;
+  if (B == 0) return 0;
+  const int nm = n_max < 1 ? 1 : n_max;
+  hipStream_t st = as_stream(stream);
+  const msde_edge_layer_params p = *params;
+  EDGE_DISPATCH(dense_edge_layer_bwd_kernel, QK, XV, AC, gAC, in_off, out_off, flags, mol_ptr, pair_ptr, p, nm, x_out, g_xout,
+                IN, H1, H2, xcat, Hmc, need_gadj, gQK, gXV, GO, GH2, GH1, GY, GHm, GV);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ================================================================================================ node GCN chain
+// x_{l+1} = tanh(An (x_l W_l) + b_l), l = 0..3, An from the perturbed adjacency (channel 0 of the pair buffer);
+// x_0 W_0 comes in as XW0 [N,16] (a GEMM), W_1..3 are [16 in][16 out].  Output: XS = [x_1|x_2|x_3|x_4], row stride ldxs.
+__global__ void __launch_bounds__(256)
+dense_node_gcn_fwd_kernel(const float* __restrict__ XW0, const float* __restrict__ AC, const int* __restrict__ mol_ptr,
+                          const int* __restrict__ pair_ptr, const float* __restrict__ Wl /* [3][16][16] */,
+                          const float* __restrict__ bl /* [4][16] */, float* __restrict__ XS, int ldxs) {
+  __shared__ float An[DH_NMAX][DH_NMAX + 1];
+  __shared__ float xa[DH_NMAX][17], xb[DH_NMAX][17];
+  __shared__ float rn[DH_NMAX];
+  __shared__ float W[3][16][17];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
+  for (int e = tid; e < 3 * 256; e += 256) W[e >> 8][(e >> 4) & 15][e & 15] = Wl[e];
+  for (int p = tid; p < n * n; p += 256) {
+    const int i = p / n, j = p - i * n;
+    An[i][j] = (i == j) ? 1.f : AC[(size_t)(q0 + p) * DH_AC];
+  }
+  for (int e = tid; e < n * 16; e += 256) xa[e >> 4][e & 15] = XW0[(size_t)(a0 + (e >> 4)) * 16 + (e & 15)];
+  __syncthreads();
+  if (tid < n) {
+    float s = 0.f;
+    for (int j = 0; j < n; ++j) s += An[tid][j];
+    rn[tid] = rsqrtf(fmaxf(s, 1.f));
+  }
+  __syncthreads();
+  for (int p = tid; p < n * n; p += 256) {
+    const int i = p / n, j = p - i * n;
+    An[i][j] *= rn[i] * rn[j];
+  }
+  __syncthreads();
+  for (int l = 0; l < 4; ++l) {
+    // xa holds x_l W_l; xb <- tanh(An xa + b_l)
+    for (int e = tid; e < n * 16; e += 256) {
+      const int i = e >> 4, f = e & 15;
+      float s = bl[l * 16 + f];
+      for (int j = 0; j < n; ++j) s = fmaf(An[i][j], xa[j][f], s);
+      s = tanhf(s);
+      xb[i][f] = s;
+      XS[(size_t)(a0 + i) * ldxs + 16 * l + f] = s;
+    }
+    __syncthreads();
+    if (l < 3) {
+      for (int e = tid; e < n * 16; e += 256) {
+        const int i = e >> 4, f = e & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = fmaf(xb[i][k], W[l][k][f], s);
+        xa[i][f] = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// backward of the chain: gXS [N, 64 (ld)] -> GP [N,64] = dL/d(pre-activation of layer l) in block l (bias gradients =
+// column sums), MM [N,64] = An^T GP per block (block 0 = dL/d(x_0 W_0); blocks 1..3: weight gradients x_l^T MM_l)
+__global__ void __launch_bounds__(256)
+dense_node_gcn_bwd_kernel(const float* __restrict__ gXS, int ldg, const float* __restrict__ XS, int ldxs,
+                          const float* __restrict__ AC, const int* __restrict__ mol_ptr,
+                          const int* __restrict__ pair_ptr, const float* __restrict__ Wl, float* __restrict__ GP,
+                          float* __restrict__ MM) {
+  __shared__ float An[DH_NMAX][DH_NMAX + 1];
+  __shared__ float gx[DH_NMAX][17], gp[DH_NMAX][17], mm[DH_NMAX][17];
+  __shared__ float rn[DH_NMAX];
+  __shared__ float W[3][16][17];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
+  for (int e = tid; e < 3 * 256; e += 256) W[e >> 8][(e >> 4) & 15][e & 15] = Wl[e];
+  for (int p = tid; p < n * n; p += 256) {
+    const int i = p / n, j = p - i * n;
+    An[i][j] = (i == j) ? 1.f : AC[(size_t)(q0 + p) * DH_AC];
+  }
+  __syncthreads();
+  if (tid < n) {
+    float s = 0.f;
+    for (int j = 0; j < n; ++j) s += An[tid][j];
+    rn[tid] = rsqrtf(fmaxf(s, 1.f));
+  }
+  __syncthreads();
+  for (int p = tid; p < n * n; p += 256) {
+    const int i = p / n, j = p - i * n;
+    An[i][j] *= rn[i] * rn[j];
+  }
+  for (int e = tid; e < n * 16; e += 256) gx[e >> 4][e & 15] = 0.f;
+  __syncthreads();
+  for (int l = 3; l >= 0; --l) {
+    for (int e = tid; e < n * 16; e += 256) {
+      const int i = e >> 4, f = e & 15;
+      const float y = XS[(size_t)(a0 + i) * ldxs + 16 * l + f];
+      const float g = (gx[i][f] + gXS[(size_t)(a0 + i) * ldg + 16 * l + f]) * (1.f - y * y);
+      gp[i][f] = g;
+      GP[(size_t)(a0 + i) * 64 + 16 * l + f] = g;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * 16; e += 256) {
+      const int j = e >> 4, f = e & 15;
+      float s = 0.f;
+      for (int i = 0; i < n; ++i) s = fmaf(An[i][j], gp[i][f], s);
+      mm[j][f] = s;
+      MM[(size_t)(a0 + j) * 64 + 16 * l + f] = s;
+    }
+    __syncthreads();
+    if (l > 0) {      // g x_l = MM_l W_l^T  (W_l = W[l-1], [in][out])
+      for (int e = tid; e < n * 16; e += 256) {
+        const int i = e >> 4, k = e & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) s = fmaf(mm[i][o], W[l - 1][k][o], s);
+        gx[i][k] = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+extern "C" int msde_dense_node_gcn_fwd(const float* XW0, const float* AC, const int* mol_ptr, const int* pair_ptr,
+                                       const float* Wl, const float* bl, int B, int n_max, float* XS, int ldxs,
+                                       void* stream) {
+  if (B < 0 || !XW0 || !AC || !mol_ptr || !pair_ptr || !Wl || !bl || !XS || ldxs < 64) return MSDE_EINVAL;
+  if (n_max > DH_NMAX) return MSDE_EUNSUP;
+  if (B == 0) return 0;
+  MSDE_LAUNCH(dense_node_gcn_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), XW0, AC, mol_ptr, pair_ptr, Wl, bl, XS,
+              ldxs);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_dense_node_gcn_bwd(const float* gXS, int ldg, const float* XS, int ldxs, const float* AC,
+                                       const int* mol_ptr, const int* pair_ptr, const float* Wl, int B, int n_max,
+                                       float* GP, float* MM, void* stream) {
+  if (B < 0 || !gXS || !XS || !AC || !mol_ptr || !pair_ptr || !Wl || !GP || !MM || ldg < 64 || ldxs < 64) return MSDE_EINVAL;
+  if (n_max > DH_NMAX) return MSDE_EUNSUP;
+  if (B == 0) return 0;
+  MSDE_LAUNCH(dense_node_gcn_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), gXS, ldg, XS, ldxs, AC, mol_ptr, pair_ptr,
+              Wl, GP, MM);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ================================================================================================ losses
+// Per molecule: s_p = G2[p] . w + bias (last Linear(60,1) of the pair MLP), score_adj = -s * [i != j] f_i f_j / std,
+// residual r = score + z; loss_adj_b = sum r^2;  likewise score_x = -OUT * f_i / std over the `ncls` classes.
+// out[0] = scale_x * sum_b w_b sum r_x^2, out[1] = scale_adj * sum_b w_b sum r_adj^2 with w_b = std^anneal_power
+// (scale = 1 / (B Nmax ncls), 1 / (B Nmax^2) for reduce_mean; 0.5 / B otherwise -- :160-179).
+__global__ void __launch_bounds__(256)
+dense_loss_fwd_kernel(const float* __restrict__ G2, int F2, const float* __restrict__ w2, const float* __restrict__ b2,
+                      const float* __restrict__ OUT, const float* __restrict__ z_adj, const float* __restrict__ z_x,
+                      const float* __restrict__ flags, const float* __restrict__ mean_std, const int* __restrict__ mol_ptr,
+                      const int* __restrict__ pair_ptr, int ncls, float anneal, float* __restrict__ res_adj,
+                      float* __restrict__ res_x, float* __restrict__ part /* [B][2] */) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
+  const float sd = mean_std[2 * b + 1], inv = 1.f / sd;
+  const float wb = anneal != 0.f ? powf(sd, anneal) : 1.f;
+  float sx = 0.f, sa = 0.f;
+  for (int p = tid; p < n * n; p += 256) {
+    const int i = p / n, j = p - i * n;
+    const float* g = G2 + (size_t)(q0 + p) * F2;
+    float s = b2[0];
+    for (int k = 0; k < F2; ++k) s = fmaf(g[k], w2[k], s);
+    const float m = (i != j) ? flags[a0 + i] * flags[a0 + j] : 0.f;
+    const float r = -s * m * inv + z_adj[q0 + p];
+    res_adj[q0 + p] = r;
+    sa = fmaf(r, r, sa);
+  }
+  for (int e = tid; e < n * ncls; e += 256) {
+    const int i = e / ncls, c = e - i * ncls;
+    const size_t o = (size_t)(a0 + i) * DH_XP + c;
+    const float r = -OUT[o] * flags[a0 + i] * inv + z_x[o];
+    res_x[o] = r;
+    sx = fmaf(r, r, sx);
+  }
+  // fixed-order block reduction
+  red[tid] = sx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  if (tid == 0) part[2 * b] = red[0] * wb;
+  __syncthreads();
+  red[tid] = sa;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+  if (tid == 0) part[2 * b + 1] = red[0] * wb;
+}
+
+__global__ void __launch_bounds__(256)
+dense_loss_final_kernel(const float* __restrict__ part, int B, float scale_x, float scale_adj, float* __restrict__ out) {
+  __shared__ float red[2][256];
+  float sx = 0.f, sa = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) { sx += part[2 * b]; sa += part[2 * b + 1]; }
+  red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sa;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = red[0][0] * scale_x; out[1] = red[1][0] * scale_adj; }
+}
+
+// gradients: g_s[p] = g_adj * scale_adj * w_b * 2 r * (-m / std); gZ2[p][k] = g_s w2[k] silu'(Z2[p][k]);
+// gOUT[i][c] = g_x * scale_x * w_b * 2 r * (-f_i / std)
+__global__ void __launch_bounds__(256)
+dense_loss_bwd_kernel(const float* __restrict__ g_out /* [2]: dL/dloss_x, dL/dloss_adj */, const float* __restrict__ res_adj,
+                      const float* __restrict__ res_x, const float* __restrict__ Z2, int F2, const float* __restrict__ w2,
+                      const float* __restrict__ flags, const float* __restrict__ mean_std, const int* __restrict__ mol_ptr,
+                      const int* __restrict__ pair_ptr, int ncls, float anneal, float scale_x, float scale_adj,
+                      float* __restrict__ gS, float* __restrict__ gZ2, float* __restrict__ gOUT) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
+  const float sd = mean_std[2 * b + 1], inv = 1.f / sd;
+  const float wb = anneal != 0.f ? powf(sd, anneal) : 1.f;
+  const float cx = g_out[0] * scale_x * wb * 2.f, ca = g_out[1] * scale_adj * wb * 2.f;
+  for (int p = tid; p < n * n; p += 256) {
+    const int i = p / n, j = p - i * n;
+    const float m = (i != j) ? flags[a0 + i] * flags[a0 + j] : 0.f;
+    const float gs = ca * res_adj[q0 + p] * (-m * inv);
+    gS[q0 + p] = gs;
+    const float* z = Z2 + (size_t)(q0 + p) * F2;
+    float* gz = gZ2 + (size_t)(q0 + p) * F2;
+    for (int k = 0; k < F2; ++k) {
+      const float zz = z[k], sg = 1.f / (1.f + __expf(-zz));
+      gz[k] = gs * w2[k] * sg * (1.f + zz * (1.f - sg));
+    }
+  }
+  for (int e = tid; e < n * DH_XP; e += 256) {
+    const int i = e / DH_XP, c = e - i * DH_XP;
+    const size_t o = (size_t)(a0 + i) * DH_XP + c;
+    gOUT[o] = c < ncls ? cx * res_x[o] * (-flags[a0 + i] * inv) : 0.f;
+  }
+}
+
+extern "C" int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, const float* b2, const float* OUT,
+                                   const float* z_adj, const float* z_x, const float* flags, const float* mean_std,
+                                   const int* mol_ptr, const int* pair_ptr, int B, int ncls, float anneal_power,
+                                   float scale_x, float scale_adj, float* res_adj, float* res_x, float* part, float* out,
+                                   void* stream) {
+  if (B <= 0 || !G2 || !w2 || !b2 || !OUT || !z_adj || !z_x || !flags || !mean_std || !mol_ptr || !pair_ptr || !res_adj ||
+      !res_x || !part || !out || F2 <= 0 || ncls <= 0 || ncls > DH_XP)
+    return MSDE_EINVAL;
+  hipStream_t st = as_stream(stream);
+  MSDE_LAUNCH(dense_loss_fwd_kernel, dim3(B), dim3(256), 0, st, G2, F2, w2, b2, OUT, z_adj, z_x, flags, mean_std, mol_ptr,
+              pair_ptr, ncls, anneal_power, res_adj, res_x, part);
+  MSDE_CHECK_LAUNCH();
+  MSDE_LAUNCH(dense_loss_final_kernel, dim3(1), dim3(256), 0, st, part, B, scale_x, scale_adj, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_dense_loss_bwd(const float* g_out, const float* res_adj, const float* res_x, const float* Z2, int F2,
+                                   const float* w2, const float* flags, const float* mean_std, const int* mol_ptr,
+                                   const int* pair_ptr, int B, int ncls, float anneal_power, float scale_x,
+                                   float scale_adj, float* gS, float* gZ2, float* gOUT, void* stream) {
+  if (B <= 0 || !g_out || !res_adj || !res_x || !Z2 || !w2 || !flags || !mean_std || !mol_ptr || !pair_ptr || !gS || !gZ2 ||
+      !gOUT || F2 <= 0 || ncls <= 0 || ncls > DH_XP)
+    return MSDE_EINVAL;
+  MSDE_LAUNCH(dense_loss_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), g_out, res_adj, res_x, Z2, F2, w2, flags,
+              mean_std, mol_ptr, pair_ptr, ncls, anneal_power, scale_x, scale_adj, gS, gZ2, gOUT);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

@@ -140,7 +140,17 @@ gemm_ex_kernel(const msde_gemm_desc d) {
       if (!B_KM) {                                          // B[n][k]
         const int r = idx >> 3, kq = (idx & 7) * 4;
         const int gn = min(n0 + r, d.N - 1);
-        rb[p] = gx_ld4<VEC>(B + (size_t)gn * ldb, k0 + kq, K, kb_[p]);
+        if (d.b_kblk_log2 > 0) {
+          // k is cut into blocks of 2^lg: block q of row n starts at B + q * b_kblk_stride + n * ldb (the stacked
+          // [C][F][16] weights of the per-channel GCNs read as one [F][16 C] operand)
+          const int kk = k0 + kq, q = kk >> d.b_kblk_log2, rem = kk & ((1 << d.b_kblk_log2) - 1);
+          int keep;
+          float4 v = gx_ld4<VEC>(B + (size_t)q * d.b_kblk_stride + (size_t)gn * ldb, kk < K ? rem : 0, 1 << d.b_kblk_log2, keep);
+          kb_[p] = kk < K ? keep : 0;
+          rb[p] = v;
+        } else {
+          rb[p] = gx_ld4<VEC>(B + (size_t)gn * ldb, k0 + kq, K, kb_[p]);
+        }
       } else {                                              // B[k][n]: 16 float4 per k row
         const int kr = idx >> 4, nq = (idx & 15) * 4;
         const int gk = min(k0 + kr, K - 1);
@@ -216,12 +226,13 @@ gemm_ex_kernel(const msde_gemm_desc d) {
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const float* __restrict__ bias = d.bias ? d.bias + (size_t)g * d.bias_gs : nullptr;
+  const float* __restrict__ bias2 = d.bias2 ? d.bias2 + (size_t)g * d.bias_gs : nullptr;
   float* __restrict__ C = d.C + (size_t)g * d.c_gs;
   float* __restrict__ Z = d.Z ? d.Z + (size_t)g * d.c_gs : nullptr;
   const float* __restrict__ R = d.R ? d.R + (size_t)g * d.r_gs : nullptr;
   const int gn = n0 + wn * 32 + lcol;
   if (gn < d.N) {
-    const float bv = bias ? bias[gn] : 0.f;
+    const float bv = (bias ? bias[gn] : 0.f) + (bias2 ? bias2[gn] : 0.f);
     const bool act_here = d.act != MSDE_ACT_NONE && gn >= d.act_lo && gn < d.act_hi;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -262,7 +273,9 @@ extern "C" int msde_gemm_ex(const msde_gemm_desc* desc, void* stream) {
   auto vec_ok = [&](const float* p, long long gs, int ld, int extent) {
     return gx_al16(p) && (gs % 4 == 0) && (ld % 4 == 0) && (extent % 4 == 0);
   };
+  if (d.b_kblk_log2 < 0 || d.b_kblk_log2 > 16 || (d.b_kblk_log2 > 0 && (km || d.A2 || d.b_kblk_log2 < 2))) return MSDE_EINVAL;
   bool vec = vec_ok(d.A, d.a_gs, d.lda, d.K1) && vec_ok(d.B, d.b_gs, d.ldb, km ? d.N : d.K1);
+  if (d.b_kblk_log2 > 0) vec = vec && (d.b_kblk_stride % 4 == 0);
   if (d.A2) vec = vec && vec_ok(d.A2, d.a_gs, d.lda2, d.K2) && vec_ok(d.B2, d.b_gs, d.ldb2, km ? d.N : d.K2);
   // tile height: 128 rows when that still gives every CU >= 2 tiles, else 64 (skinny problems need the parallelism)
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.groups;

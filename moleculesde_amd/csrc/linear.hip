@@ -211,8 +211,9 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
                                               blockIdx.y, blockIdx.z);
 }
 
-// Grouped weight gradients: ONE launch runs the split-M GEMMs of many layers.  probs[p] = 12 int64:
-// {gY, X, slabs, colsum partials (0: no bias), M, N, K, splits, k_per_split, tiles_x, tiles_y, vec};
+// Grouped weight gradients: ONE launch runs the split-M GEMMs of many layers.  probs[p] = 16 int64:
+// {gY, X, slabs, colsum partials (0: no bias), M, N, K, splits, k_per_split, tiles_x, tiles_y, vec, ldg, ldx, 0, 0}
+// (ldg / ldx: row strides of gY / X -- operands may be column blocks of wider buffers);
 // prefix[p] = workgroups before problem p.  A workgroup finds its problem by binary search and then runs the very
 // same tile body as the per-layer kernel (64 x 64 tiles), so results are bit-identical to it.
 __global__ void __launch_bounds__(256)
@@ -222,19 +223,20 @@ gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __rest
     int mid = (lo + hi) >> 1;
     if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
   }
-  const long long* e = probs + (size_t)lo * 12;
+  const long long* e = probs + (size_t)lo * MSDE_WGRAD_ROW;
   const float* gY = reinterpret_cast<const float*>(e[0]);
   const float* X = reinterpret_cast<const float*>(e[1]);
   float* slabs = reinterpret_cast<float*>(e[2]);
   float* cs = reinterpret_cast<float*>(e[3]);
   const int M = (int)e[4], N = (int)e[5], K = (int)e[6], kps = (int)e[8], tx = (int)e[9], ty = (int)e[10];
+  const int ldg = (int)e[12], ldx = (int)e[13];
   const int local = (int)blockIdx.x - prefix[lo];
   const int bx = local % tx, by = (local / tx) % ty, bz = local / (tx * ty);
   // product C[N][K] = gY^T X: "M" of the product = N, "N" = K, reduction = M (see msde_linear_bwd_w)
   if (e[11])
-    gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, kps, bx, by, bz);
+    gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, M, ldg, ldx, K, kps, bx, by, bz);
   else
-    gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, kps, bx, by, bz);
+    gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, M, ldg, ldx, K, kps, bx, by, bz);
 }
 
 // out[i] = sum_z slabs[z][i] for the weight slabs (n entries) and, in the same launch, the bias-gradient
@@ -456,12 +458,19 @@ extern "C" int msde_reduce_slabs_multi(const long long* rows, const int* prefix,
 // the problem needs (<= 0: error).  want_bias: the bias partials follow the weight slabs in `slabs`.
 extern "C" int msde_linear_bwd_w_describe(const float* gY, const float* X, int M, int N, int K, int want_bias,
                                           float* slabs, long long* row) {
-  if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs || !row) return MSDE_EINVAL;
+  return msde_linear_bwd_w_describe_ld(gY, N, X, K, M, N, K, want_bias, slabs, row);
+}
+
+extern "C" int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const float* X, int ldx, int M, int N, int K,
+                                             int want_bias, float* slabs, long long* row) {
+  if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs || !row || ldg < N || ldx < K) return MSDE_EINVAL;
   if (wgrad_big(M, N, K)) return MSDE_EUNSUP;        // the grouped kernel is built for 64 x 64 tiles
   int splits, kps;
   wgrad_split_batched(M, N, K, &splits, &kps);
   int tx = (K + 63) / 64, ty = (N + 63) / 64;
-  bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (kps % 4 == 0);
+  bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (kps % 4 == 0) && (ldg % 4 == 0) &&
+             (ldx % 4 == 0);
+  row[12] = ldg; row[13] = ldx; row[14] = 0; row[15] = 0;
   row[0] = reinterpret_cast<long long>(gY);
   row[1] = reinterpret_cast<long long>(X);
   row[2] = reinterpret_cast<long long>(slabs);

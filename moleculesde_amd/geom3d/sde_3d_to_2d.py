@@ -20,8 +20,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip, plan as _plan
+from . import dense_head as _dh
 from . import nn as _nn
 from .sde import VESDE, VPSDE
+
+USE_FUSED_HEAD = True     # False: the operator-by-operator path below (cross-check; shapes the kernels do not cover)
 
 EPSILON = 1e-6
 
@@ -82,6 +85,16 @@ class EdgeNetwork_dense(nn.Module):
                                             activation="elu")
         self.multi_channel = _nn.MultiLayerPerceptron(input_dim * conv_output_dim, [self.hidden_dim, conv_output_dim],
                                                       activation="elu")
+
+    def fusion_sets(self):
+        """Parameters the fused kernels consume as ONE stacked operand (dense_head.edge_layer_tensors): laid out back
+        to back by FlatAdam so that the stacks are free views."""
+        at = list(self.attn)
+        return [[a.func_q.layers[0].weight for a in at] + [a.func_k.layers[0].weight for a in at],
+                [a.func_q.layers[0].bias for a in at] + [a.func_k.layers[0].bias for a in at],
+                [a.func_q.layers[1].weight for a in at] + [a.func_k.layers[1].weight for a in at],
+                [a.func_q.layers[1].bias for a in at] + [a.func_k.layers[1].bias for a in at],
+                [a.func_v.weight for a in at], [a.func_v.bias for a in at]]
 
     def _stacked_mlp(self, x2, which):
         """func_q / func_k of all C channels at once: x2 [BN, F] -> [C, BN, 2*attn]."""
@@ -169,6 +182,9 @@ class NodeScoreNetwork_dense(nn.Module):
         self.fdim = nfeat + depth * nhid
         self.final = _nn.MultiLayerPerceptron(self.fdim, [2 * self.fdim, 2 * self.fdim, nout], activation="silu")
 
+    def fusion_sets(self):
+        return [[l.weight for l in self.layers[1:]], [l.bias for l in self.layers]]
+
     def forward(self, x, adj, flags):
         B, N, _ = x.shape
         an = _norm_adj(adj)
@@ -208,12 +224,59 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
                                                          nout=num_class_X if noise_on_one_hot else 1)
         self.noise = _nn.DeviceNoise()
 
+    def _forward_fused(self, node_3D_repr, data, reduce_mean, anneal_power, pl, dn):
+        """Product path: one autograd node, only libmsde_hip kernels (geom3d/dense_head.py)."""
+        device = node_3D_repr.device
+        B, Nm, T = pl.B, dn.N_max, self.num_diffusion_timesteps
+        cfg = getattr(dn, "_fused_cfg", None)
+        if cfg is None:
+            import types
+            cfg = types.SimpleNamespace(
+                N=pl.N, P=dn.P, B=B, n_max=Nm, mol_ptr=pl.mol_ptr, pair_ptr=dn.pair_ptr, bond_rowptr=pl.bond.rowptr,
+                bond_src=pl.bond.src, bond_val=pl.bond_type, z_atom=pl.z_codes.view(-1), T=T, eps=EPSILON,
+                ncls=self.num_class_X)
+            cfg.chans, cfg.offs = _dh.edge_net_shape(self.edge_score_network)
+            dn._fused_cfg = cfg
+        cfg.sde_vp = 1 if self.SDE_type == "VP" else 0
+        cfg.p0, cfg.p1 = float(self.beta_min), float(self.beta_max)
+        cfg.draws = cfg.t_in = cfg.noise_adj = cfg.noise_x = None
+        cfg.nm_pad, cfg.seed, cfg.seed_dev = Nm, 0, None
+        noise = self.noise
+        if getattr(noise, "replay", False) or type(noise).randn_like is not _nn.DeviceNoise.randn_like:
+            # replayable noise source: the reference's draws in its program order (:112, :135, :144), padded shapes
+            if self.noise_mode == "discrete":
+                cfg.draws = noise.randint(T, (B // 2 + 1,), device).contiguous()
+            else:
+                cfg.t_in = (noise.rand(B, device) * (1 - EPSILON) + EPSILON).float().contiguous()
+            cfg.noise_adj = noise.randn_like(torch.empty(B, Nm, Nm, device=device)).contiguous()
+            cfg.noise_x = noise.randn_like(torch.empty(B, Nm, self.num_class_X, device=device)).contiguous()
+        else:
+            # device noise: counter-based draws inside the prepare kernel (no operator launches at all)
+            noise.calls += 1
+            cfg.seed = (noise.seed * 0x9E3779B1 + 0x3D2D * noise.calls) & 0xFFFFFFFFFFFFFFFF
+            cfg.seed_dev = noise.seed_dev
+            if self.noise_mode != "discrete":
+                cfg.t_in = (noise.rand(B, device) * (1 - EPSILON) + EPSILON).float().contiguous()
+        cfg.anneal = float(anneal_power)
+        if reduce_mean:
+            cfg.scale_x, cfg.scale_adj = 1.0 / (B * Nm * self.num_class_X), 1.0 / (B * Nm * Nm)
+        else:
+            cfg.scale_x = cfg.scale_adj = 0.5 / B
+        TE = _dh.edge_net_tensors(self.edge_score_network)
+        TN = _dh.node_net_tensors(self.node_score_network)
+        cfg.n_edge_tensors = len(TE)
+        T4 = [self.embedding_3D.weight, self.embedding_3D.bias, self.embedding_X.weight, self.embedding_X.bias]
+        return _dh.dense_head_losses(cfg, node_3D_repr, T4 + TE + TN)
+
     def forward(self, node_3D_repr, data, continuous, train, reduce_mean, anneal_power):
         if not continuous:
             raise NotImplementedError("Discrete not supported")              # as the reference (:82,92)
         device = node_3D_repr.device
         pl = _plan.get_plan(data)
         dn = _plan.dense_plan(pl, data)                                      # padded layout, built once per batch
+        if USE_FUSED_HEAD and self.noise_on_one_hot and hasattr(pl, "bond_type") and \
+                _dh.fused_supported(self.edge_score_network, self.node_score_network, dn.N_max):
+            return self._forward_fused(node_3D_repr, data, reduce_mean, anneal_power, pl, dn)
         B, Nm, T = pl.B, dn.N_max, self.num_diffusion_timesteps
         if self.noise_mode == "discrete":
             t = self.noise.randint(T, (B // 2 + 1,), device)

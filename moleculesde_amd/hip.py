@@ -848,11 +848,11 @@ class _SlabBatch:
         memcpy node that re-reads its host image at every replay)."""
         host_rows = torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64).pin_memory()
         host_pre = torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32).pin_memory()
-        host_prob = torch.zeros(self.MAX_ROWS, 12, dtype=torch.int64).pin_memory()
+        host_prob = torch.zeros(self.MAX_ROWS, 16, dtype=torch.int64).pin_memory()      # MSDE_WGRAD_ROW
         host_ppre = torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32).pin_memory()
         self.slot = (host_rows, host_pre, torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64, device=device),
                      torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device),
-                     host_prob, host_ppre, torch.zeros(self.MAX_ROWS, 12, dtype=torch.int64, device=device),
+                     host_prob, host_ppre, torch.zeros(self.MAX_ROWS, 16, dtype=torch.int64, device=device),
                      torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device))
         self.slots.append(self.slot)
         self.events.append(None)
@@ -926,8 +926,8 @@ class _SlabBatch:
         hp2 = host_ppre.numpy()
         total_b = 0
         for r, (gY, X, M, N, K, hb, slab) in enumerate(self.gemms):
-            nb = lib.msde_linear_bwd_w_describe(_p(gY), _p(X), M, N, K, hb, _p(slab),
-                                                ctypes.c_void_p(host_prob[r0 + r].data_ptr()))
+            nb = lib.msde_linear_bwd_w_describe_ld(_p(gY), _row_stride(gY, N), _p(X), _row_stride(X, K), M, N, K, hb,
+                                                   _p(slab), ctypes.c_void_p(host_prob[r0 + r].data_ptr()))
             if nb <= 0:
                 raise _lib.MsdeHipError(f"msde_linear_bwd_w_describe failed ({nb}) for {M}x{N}x{K}")
             hp2[q0 + r] = total_b
@@ -1013,17 +1013,26 @@ def use_eager_param_grad_slot():
         _SLABS.slot, _SLABS.slot_i = _SLABS.slots[_SLABS.eager_i], _SLABS.eager_i
 
 
-def weight_grad(g2, x2, has_bias, deferrable=True):
+def _row_stride(t, cols):
+    """Row stride of a 2-D operand with unit column stride (a column block of a wider buffer is fine)."""
+    return int(t.stride(0)) if t.size(0) > 1 else max(int(t.stride(0)), cols)
+
+
+def weight_grad(g2, x2, has_bias, deferrable=True, out_w=None, out_b=None):
     """gW [N,K] = g2^T x2 and (has_bias) gb [N] = column sums of g2 for g2 [M,N], x2 [M,K]: the hand-written
     split-M kernel -- queued for the grouped launch + batched slab reduction when a parameter-gradient batch is
-    open and the results are `deferrable` -- or the vendor GEMM + column-sum kernels (MSDE_LINEAR=lib, tiny M)."""
+    open and the results are `deferrable` -- or the vendor GEMM + column-sum kernels (MSDE_LINEAR=lib, tiny M).
+    Under the grouped launch the operands may be column blocks of wider buffers (unit column stride)."""
     M, N = g2.shape
     K = x2.size(1)
+    if not (_SLABS.active and deferrable and GROUPED_WGRAD) or M < WGRAD_HIP_MIN_ROWS:
+        g2, x2 = g2.contiguous(), x2.contiguous()          # only the grouped kernel takes row strides
     st = _stream()
     use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
     if use_hip:
-        gw = torch.empty(N, K, dtype=torch.float32, device=g2.device)
-        gb = torch.empty(N, dtype=torch.float32, device=g2.device) if has_bias else None
+        # out_w / out_b: contiguous slices of a stacked gradient (several layers' weights consumed as one operand)
+        gw = out_w if out_w is not None else torch.empty(N, K, dtype=torch.float32, device=g2.device)
+        gb = (out_b if out_b is not None else torch.empty(N, dtype=torch.float32, device=g2.device)) if has_bias else None
         if _SLABS.active and deferrable:
             splits = _SPLITS.get((M, N, K))
             if splits is None:
@@ -1041,11 +1050,22 @@ def weight_grad(g2, x2, has_bias, deferrable=True):
             _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
     else:
         gw = torch.mm(g2.t(), x2)
+        if out_w is not None:
+            gw = out_w.copy_(gw)
         gb = None
         if has_bias:
-            gb = torch.empty(N, dtype=torch.float32, device=g2.device)
+            gb = out_b if out_b is not None else torch.empty(N, dtype=torch.float32, device=g2.device)
             _lib.call("msde_colsum", _p(g2), M, N, _p(gb), _p(_bn_workspace(M, N, g2.device)), st)
     return gw, gb
+
+
+def colsum(x):
+    """Column sums of a contiguous [M, C] tensor (fixed summation order)."""
+    x = _f32(x)
+    M, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    _lib.call("msde_colsum", _p(x), M, C, _p(out), _p(_bn_workspace(M, C, x.device)), _stream())
+    return out
 
 
 class _Linear(torch.autograd.Function):
@@ -1457,7 +1477,8 @@ def _ld(t):
 
 
 def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=None, dact_from=None, rowscale=None,
-            b_kmajor=False, accumulate=False, alpha=1.0, groups=1, group_strides=None, N=None, K=None, K2=None):
+            b_kmajor=False, accumulate=False, alpha=1.0, groups=1, group_strides=None, N=None, K=None, K2=None, bias2=None,
+            b_kblk=None):
     """out[M,N] (+)= alpha * rowscale * epi(A . B(^T) + A2 . B2(^T) + bias): one launch of msde_gemm_ex, no autograd.
     A, A2, out, Z, dact_from: 2-D fp32 device tensors with unit column stride (views into wider buffers are fine; their
     row strides become the leading dimensions).  B: [N, K] (nn.Linear layout) or, with b_kmajor, [K, N].
@@ -1481,6 +1502,9 @@ def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=N
         d.K2 = int(K2 if K2 is not None else A2.size(1))
         d.B2, d.ldb2 = B2.data_ptr(), (B2.stride(0) if B2.dim() == 2 else (d.N if b_kmajor else d.K2))
     d.bias = bias.data_ptr() if bias is not None else None
+    d.bias2 = bias2.data_ptr() if bias2 is not None else None
+    if b_kblk is not None:          # (block length = power of two, stride between blocks in floats, row stride)
+        d.b_kblk_log2, d.b_kblk_stride, d.ldb = int(b_kblk[0]).bit_length() - 1, int(b_kblk[1]), int(b_kblk[2])
     d.C, d.ldc = out.data_ptr(), _ld(out)
     if Z is not None:
         d.Z, d.ldz = Z.data_ptr(), _ld(Z)

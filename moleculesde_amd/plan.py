@@ -141,6 +141,12 @@ def dense_plan(pl, data):
     z = torch.zeros(B * Nm, dtype=torch.long, device=dev)
     z[slot] = data.x[:, 0].long() if data.x.dim() == 2 else data.x.long()
     dn.z = z.view(B, Nm)
+    # ragged pair layout of the fused head kernels (csrc/dense_head.hip): molecule b owns pair rows
+    # pair_ptr[b] + i * n_b + j
+    cnt = (mol_ptr[1:] - mol_ptr[:-1])
+    sq = (cnt * cnt).cumsum(0)
+    dn.pair_ptr = torch.cat([sq.new_zeros(1), sq]).to(torch.int32)
+    dn.P = int(sq[-1]) if B > 0 else 0
     pl.dense = dn
     return dn
 
