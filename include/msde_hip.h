@@ -314,10 +314,11 @@ int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, const float* b
                         const int* mol_ptr, const int* pair_ptr, int B, int ncls, float anneal_power,
                         float scale_x, float scale_adj, float* res_adj, float* res_x, float* part, float* out,
                         void* stream);
-/* g_out[0..1] = dL/dloss_x, dL/dloss_adj (device).  gS [P] = gradient of the pair MLP's scalar output, gZ2 [P,F2] =
+/* g_lx / g_la: device scalars dL/dloss_x, dL/dloss_adj (NULL = 0).  gS [P] = gradient of the pair MLP's scalar output, gZ2 [P,F2] =
  * gradient of the pre-activation of its last hidden layer (SiLU), gOUT [N, MSDE_DENSE_XP_LD] = gradient of the node
  * MLP's output. */
-int msde_dense_loss_bwd(const float* g_out, const float* res_adj, const float* res_x, const float* Z2, int F2,
+int msde_dense_loss_bwd(const float* g_lx, const float* g_la, const float* res_adj, const float* res_x,
+                        const float* Z2, int F2,
                         const float* w2, const float* flags, const float* mean_std, const int* mol_ptr,
                         const int* pair_ptr, int B, int ncls, float anneal_power, float scale_x,
                         float scale_adj, float* gS, float* gZ2, float* gOUT, void* stream);

@@ -825,7 +825,8 @@ dense_loss_final_kernel(const float* __restrict__ part, int B, float scale_x, fl
 // gradients: g_s[p] = g_adj * scale_adj * w_b * 2 r * (-m / std); gZ2[p][k] = g_s w2[k] silu'(Z2[p][k]);
 // gOUT[i][c] = g_x * scale_x * w_b * 2 r * (-f_i / std)
 __global__ void __launch_bounds__(256)
-dense_loss_bwd_kernel(const float* __restrict__ g_out /* [2]: dL/dloss_x, dL/dloss_adj */, const float* __restrict__ res_adj,
+dense_loss_bwd_kernel(const float* __restrict__ g_lx, const float* __restrict__ g_la /* dL/dloss_x, dL/dloss_adj (NULL: 0) */,
+                      const float* __restrict__ res_adj,
                       const float* __restrict__ res_x, const float* __restrict__ Z2, int F2, const float* __restrict__ w2,
                       const float* __restrict__ flags, const float* __restrict__ mean_std, const int* __restrict__ mol_ptr,
                       const int* __restrict__ pair_ptr, int ncls, float anneal, float scale_x, float scale_adj,
@@ -834,7 +835,7 @@ dense_loss_bwd_kernel(const float* __restrict__ g_out /* [2]: dL/dloss_x, dL/dlo
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
   const float sd = mean_std[2 * b + 1], inv = 1.f / sd;
   const float wb = anneal != 0.f ? powf(sd, anneal) : 1.f;
-  const float cx = g_out[0] * scale_x * wb * 2.f, ca = g_out[1] * scale_adj * wb * 2.f;
+  const float cx = (g_lx ? g_lx[0] : 0.f) * scale_x * wb * 2.f, ca = (g_la ? g_la[0] : 0.f) * scale_adj * wb * 2.f;
   for (int p = tid; p < n * n; p += 256) {
     const int i = p / n, j = p - i * n;
     const float m = (i != j) ? flags[a0 + i] * flags[a0 + j] : 0.f;
@@ -871,14 +872,15 @@ extern "C" int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, con
   return 0;
 }
 
-extern "C" int msde_dense_loss_bwd(const float* g_out, const float* res_adj, const float* res_x, const float* Z2, int F2,
+extern "C" int msde_dense_loss_bwd(const float* g_lx, const float* g_la, const float* res_adj, const float* res_x,
+                                   const float* Z2, int F2,
                                    const float* w2, const float* flags, const float* mean_std, const int* mol_ptr,
                                    const int* pair_ptr, int B, int ncls, float anneal_power, float scale_x,
                                    float scale_adj, float* gS, float* gZ2, float* gOUT, void* stream) {
-  if (B <= 0 || !g_out || !res_adj || !res_x || !Z2 || !w2 || !flags || !mean_std || !mol_ptr || !pair_ptr || !gS || !gZ2 ||
+  if (B <= 0 || !res_adj || !res_x || !Z2 || !w2 || !flags || !mean_std || !mol_ptr || !pair_ptr || !gS || !gZ2 ||
       !gOUT || F2 <= 0 || ncls <= 0 || ncls > DH_XP)
     return MSDE_EINVAL;
-  MSDE_LAUNCH(dense_loss_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), g_out, res_adj, res_x, Z2, F2, w2, flags,
+  MSDE_LAUNCH(dense_loss_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), g_lx, g_la, res_adj, res_x, Z2, F2, w2, flags,
               mean_std, mol_ptr, pair_ptr, ncls, anneal_power, scale_x, scale_adj, gS, gZ2, gOUT);
   MSDE_CHECK_LAUNCH();
   return 0;

@@ -303,10 +303,12 @@ class _DenseHeadLosses(torch.autograd.Function):
         ctx.cfg, ctx.se, ctx.sn = cfg, se, sn
         ctx.keep = (h3, AC, flags, mean_std, px, XC, res_adj, res_x)
         ctx.T = T
-        return out
+        # two 0-d outputs (views of one buffer): the caller's `loss_x, loss_adj = ...` then costs no operator, and the
+        # backward receives the two upstream scalars separately
+        return out[0], out[1]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g_lx, g_la):
         cfg, se, sn, T = ctx.cfg, ctx.se, ctx.sn, ctx.T
         h3, AC, flags, mean_std, px, XC, res_adj, res_x = ctx.keep
         dev = h3.device
@@ -314,10 +316,11 @@ class _DenseHeadLosses(torch.autograd.Function):
         nE = cfg.n_edge_tensors
         W3, b3, WX, bX = T[:4]
         TE, TN = T[4:4 + nE], T[4 + nE:]
-        g = hip._f32(g)
+        g_lx = hip._f32(g_lx) if g_lx is not None else None
+        g_la = hip._f32(g_la) if g_la is not None else None
         gS, gZG2 = _empty(P, device=dev), _empty(P, se.ZG2.size(1), device=dev)
         gOUT = _empty(N, XP_LD, device=dev)
-        _lib.call("msde_dense_loss_bwd", _p(g), _p(res_adj), _p(res_x), _p(se.ZG2), se.ZG2.size(1), _p(TE[-2]), _p(flags),
+        _lib.call("msde_dense_loss_bwd", _p(g_lx), _p(g_la), _p(res_adj), _p(res_x), _p(se.ZG2), se.ZG2.size(1), _p(TE[-2]), _p(flags),
                   _p(mean_std), _p(cfg.mol_ptr), _p(cfg.pair_ptr), B, cfg.ncls, cfg.anneal, cfg.scale_x, cfg.scale_adj, _p(gS),
                   _p(gZG2), _p(gOUT), hip._stream())
         GN, gXC = node_backward(cfg, sn, XC, F, AC, TN, gOUT)
@@ -339,5 +342,59 @@ FUSED_CALLS = 0     # incremented per fused forward: lets tests assert that the 
 def dense_head_losses(cfg, h3, T):
     global FUSED_CALLS
     FUSED_CALLS += 1
-    out = _DenseHeadLosses.apply(cfg, h3, *T)
-    return out[0], out[1]
+    return _DenseHeadLosses.apply(cfg, h3, *T)
+
+
+# ------------------------------------------------------------------------------------------------ stand-alone nets
+class _ScoreNets(torch.autograd.Function):
+    """EdgeScoreNetwork_dense + NodeScoreNetwork_dense on given node features / adjacency channels (the two networks
+    without the SDE wrapper): raw pair scalar S [P] and node outputs [N, nout] before the masks."""
+
+    @staticmethod
+    def forward(ctx, cfg, x2, AC, flags, *T):
+        dev, N, F = x2.device, cfg.N, x2.size(1)
+        TE, TN = T[:cfg.n_edge_tensors], T[cfg.n_edge_tensors:]
+        XC = _empty(N, F + 64, device=dev)
+        XC[:, :F].copy_(x2)
+        se = edge_forward(cfg, XC[:, :F], AC, flags, cfg.chans, cfg.offs, TE)
+        sn = node_forward(cfg, XC, F, AC, TN)
+        S = _empty(cfg.P, 1, device=dev)
+        hip.gemm_ex(se.G2, TE[-2], S, bias=TE[-1])
+        ctx.cfg, ctx.se, ctx.sn, ctx.T, ctx.keep = cfg, se, sn, T, (XC, AC, flags, F)
+        return S.view(-1), sn.OUT[:, :sn.nout].contiguous()
+
+    @staticmethod
+    def backward(ctx, gS, gO):
+        cfg, se, sn, T = ctx.cfg, ctx.se, ctx.sn, ctx.T
+        XC, AC, flags, F = ctx.keep
+        TE, TN = T[:cfg.n_edge_tensors], T[cfg.n_edge_tensors:]
+        gS = gS.contiguous()
+        sg = torch.sigmoid(se.ZG2)
+        gZG2 = (gS[:, None] * TE[-2].detach().view(1, -1) * sg * (1 + se.ZG2 * (1 - sg))).contiguous()
+        gOUT = torch.zeros(cfg.N, XP_LD, device=gO.device)
+        gOUT[:, :sn.nout] = gO
+        GN, gXC = node_backward(cfg, sn, XC, F, AC, TN, gOUT)
+        GE, _ = edge_backward(cfg, se, AC, flags, cfg.chans, cfg.offs, TE, gS, gZG2, gXC[:, :F], True)
+        return (None, gXC[:, :F].contiguous(), None, None) + tuple(GE) + tuple(GN)
+
+
+def score_networks(edge, node, x, adj, flags):
+    """(score_edge [B,N,N], score_node [B,N,nout]) = (edge(x, adj, flags), node(x, adj, flags)) of
+    invariant_scorenetwork_dense.py:74-93,118-131 through the fused kernels, for padded inputs (every molecule is given
+    N rows; `flags` masks).  The adjacency carries no gradient on this path."""
+    B, N, F = x.shape
+    dev = x.device
+    cfg = types.SimpleNamespace(N=B * N, P=B * N * N, B=B, n_max=N)
+    cfg.mol_ptr = (torch.arange(B + 1, device=dev) * N).to(torch.int32)
+    cfg.pair_ptr = (torch.arange(B + 1, device=dev) * N * N).to(torch.int32)
+    cfg.chans, cfg.offs = edge_net_shape(edge)
+    TE, TN = edge_net_tensors(edge), node_net_tensors(node)
+    cfg.n_edge_tensors = len(TE)
+    adj = adj.detach()
+    AC = torch.zeros(B * N * N, AC_LD, device=dev)
+    AC[:, 0] = adj.reshape(-1)
+    AC[:, 1] = torch.bmm(adj, adj).reshape(-1)                      # pow_tensor(adj, 2)
+    S, O = _ScoreNets.apply(cfg, x.reshape(B * N, F).float(), AC, flags.reshape(-1).float().contiguous(), *(TE + TN))
+    eye = torch.eye(N, device=dev)
+    fm = flags[:, :, None] * flags[:, None, :]
+    return S.view(B, N, N) * (1 - eye) * fm, O.view(B, N, -1) * flags[:, :, None]
