@@ -43,6 +43,17 @@ int msde_radius_fill(const float* pos, const int* batch, const int* mol_ptr, int
                      int max_nbr, const int* rowptr, int* src, int* dst, float* dist, int E_cap,
                      void* stream);
 
+/* Row bounds: one captured hipGraph for batches of different sizes.  Tensors are allocated with row CAPACITIES (atoms,
+ * bonds, extended edges, ... each padded to a distinct capacity); msde_set_row_bound(cap, dev_count) declares that every
+ * tensor with exactly `cap` rows has only *dev_count valid leading rows.  Kernels that REDUCE over rows (BatchNorm
+ * statistics, weight / bias gradients, column sums, the contrastive loss and its permutation, LayerNorm-parameter and
+ * embedding-table gradients) then stop at the valid rows; row-wise kernels keep processing all `cap` rows (padded rows
+ * hold finite values and zero gradients) and CSR walks never reach padded edges.  dev_count == NULL removes the bound.
+ * The reference has no counterpart: PyG's collate rebuilds exact-size tensors on the host for every batch
+ * (Geom3D/datasets/dataset_3D.py:114-122, App. A.8). */
+int msde_set_row_bound(int cap, const int* dev_count);
+int msde_clear_row_bounds(void);
+
 /* ------------------------------------------------------------------ generic row ops -------- */
 /* torch_scatter.scatter(reduce=sum) over CSR rows: out[i] = sum_{s in [rowptr[i],rowptr[i+1])}
  * rows[perm ? perm[s] : s]; used for every backward "gather by source/target".  D % 4 == 0 or any. */
@@ -312,8 +323,9 @@ int msde_dense_node_gcn_bwd(const float* gXS, int ldg, const float* XS, int ldxs
 int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, const float* b2, const float* OUT,
                         const float* z_adj, const float* z_x, const float* flags, const float* mean_std,
                         const int* mol_ptr, const int* pair_ptr, int B, int ncls, float anneal_power,
-                        float scale_x, float scale_adj, float* res_adj, float* res_x, float* part, float* out,
-                        void* stream);
+                        float scale_x, float scale_adj, const int* nmax_dev /* non-NULL: reduce_mean scales from this
+                        device-side N_max instead of scale_x / scale_adj */, float* res_adj, float* res_x, float* part,
+                        float* out, void* stream);
 /* g_lx / g_la: device scalars dL/dloss_x, dL/dloss_adj (NULL = 0).  gS [P] = gradient of the pair MLP's scalar output, gZ2 [P,F2] =
  * gradient of the pre-activation of its last hidden layer (SiLU), gOUT [N, MSDE_DENSE_XP_LD] = gradient of the node
  * MLP's output. */
@@ -321,7 +333,7 @@ int msde_dense_loss_bwd(const float* g_lx, const float* g_la, const float* res_a
                         const float* Z2, int F2,
                         const float* w2, const float* flags, const float* mean_std, const int* mol_ptr,
                         const int* pair_ptr, int B, int ncls, float anneal_power, float scale_x,
-                        float scale_adj, float* gS, float* gZ2, float* gOUT, void* stream);
+                        float scale_adj, const int* nmax_dev, float* gS, float* gZ2, float* gOUT, void* stream);
 
 /* ------------------------------------------------------------------ contrastive loss ------- */
 /* do_CL('EBM_node_dot_prod') in both directions + dual_CL — examples/util.py:52-68,76-79.

@@ -16,8 +16,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 template <int V>
 __global__ void cl_rows_kernel(const float* __restrict__ X, const float* __restrict__ Y, const int* __restrict__ perm1,
-                               const int* __restrict__ perm2, int N, int cols, int tpr, float invT,
-                               float* __restrict__ rows, int* __restrict__ inv1, int* __restrict__ inv2) {
+                               const int* __restrict__ perm2, int N, const int* __restrict__ Ndev, int cols, int tpr,
+                               float invT, float* __restrict__ rows, int* __restrict__ inv1, int* __restrict__ inv2) {
+  N = msde_true_rows(N, Ndev);
   using T = typename VecT<V>::type;
   int rpb = blockDim.x / tpr;
   int i = blockIdx.x * rpb + threadIdx.x / tpr;
@@ -45,8 +46,10 @@ __global__ void cl_rows_kernel(const float* __restrict__ X, const float* __restr
   }
 }
 
-__global__ void __launch_bounds__(1024) cl_reduce_kernel(const float* __restrict__ rows, int N, float* __restrict__ out) {
+__global__ void __launch_bounds__(1024) cl_reduce_kernel(const float* __restrict__ rows, int N,
+                                                        const int* __restrict__ Ndev, float* __restrict__ out) {
   __shared__ float s_l[16], s_a[16];
+  N = msde_true_rows(N, Ndev);
   float l = 0.f, a = 0.f;
   for (int i = threadIdx.x; i < N; i += 1024) {
     float p = rows[3 * (size_t)i], n1 = rows[3 * (size_t)i + 1], n2 = rows[3 * (size_t)i + 2];
@@ -67,13 +70,24 @@ __global__ void __launch_bounds__(1024) cl_reduce_kernel(const float* __restrict
 template <int V>
 __global__ void cl_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, const int* __restrict__ perm1,
                               const int* __restrict__ perm2, const int* __restrict__ inv1, const int* __restrict__ inv2,
-                              const float* __restrict__ rows, const float* __restrict__ g_loss, int N, int cols, int tpr,
-                              float invT, float* __restrict__ gX, float* __restrict__ gY) {
+                              const float* __restrict__ rows, const float* __restrict__ g_loss, int N,
+                              const int* __restrict__ Ndev, int cols, int tpr, float invT, float* __restrict__ gX,
+                              float* __restrict__ gY) {
   using T = typename VecT<V>::type;
   int rpb = blockDim.x / tpr;
   int i = blockIdx.x * rpb + threadIdx.x / tpr;
   int lane = threadIdx.x % tpr;
   if (i >= N) return;
+  const int Ncap = N;
+  N = msde_true_rows(N, Ndev);
+  if (i >= N) {                         // rows past the valid ones carry a ZERO gradient (never stale memory)
+    if (i < Ncap) {
+      T* zx = reinterpret_cast<T*>(gX) + (size_t)i * cols;
+      T* zy = reinterpret_cast<T*>(gY) + (size_t)i * cols;
+      for (int c = lane; c < cols; c += tpr) { zx[c] = vzero<V>(); zy[c] = vzero<V>(); }
+    }
+    return;
+  }
   const float g = g_loss[0] * invT / (float)N;
   int j1 = perm1[i], j2 = perm2[i], k1 = inv1[i], k2 = inv2[i];
   float dp = -g * sigmoidf_(-rows[3 * (size_t)i]);                 // d/dp [2 * BCE(p,1)] / 2N
@@ -101,9 +115,10 @@ __global__ void cl_bwd_kernel(const float* __restrict__ X, const float* __restri
 extern "C" int msde_cl_ebm_fwd(const float* X, const float* Y, const int* perm1, const int* perm2, int N, int D,
                                float invT, float* rows, int* inv1, int* inv2, float* out, void* stream) {
   if (N <= 0 || D <= 0 || !X || !Y || !perm1 || !perm2 || !rows || !inv1 || !inv2 || !out) return MSDE_EINVAL;
-  LAUNCH_ROWS(cl_rows_kernel, N, D, X, Y, perm1, perm2, N, cols, tpr, invT, rows, inv1, inv2);
+  const int* ndev = msde_row_bound(N);
+  LAUNCH_ROWS(cl_rows_kernel, N, D, X, Y, perm1, perm2, N, ndev, cols, tpr, invT, rows, inv1, inv2);
   MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(cl_reduce_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (const float*)rows, N, out);
+  MSDE_LAUNCH(cl_reduce_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (const float*)rows, N, ndev, out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -113,7 +128,8 @@ extern "C" int msde_cl_ebm_bwd(const float* X, const float* Y, const int* perm1,
                                float* gX, float* gY, void* stream) {
   if (N <= 0 || D <= 0 || !X || !Y || !perm1 || !perm2 || !inv1 || !inv2 || !rows || !g_loss || !gX || !gY)
     return MSDE_EINVAL;
-  LAUNCH_ROWS(cl_bwd_kernel, N, D, X, Y, perm1, perm2, inv1, inv2, rows, g_loss, N, cols, tpr, invT, gX, gY);
+  LAUNCH_ROWS(cl_bwd_kernel, N, D, X, Y, perm1, perm2, inv1, inv2, rows, g_loss, N, msde_row_bound(N), cols, tpr, invT,
+              gX, gY);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -809,8 +809,14 @@ dense_loss_fwd_kernel(const float* __restrict__ G2, int F2, const float* __restr
 }
 
 __global__ void __launch_bounds__(256)
-dense_loss_final_kernel(const float* __restrict__ part, int B, float scale_x, float scale_adj, float* __restrict__ out) {
+dense_loss_final_kernel(const float* __restrict__ part, int B, float scale_x, float scale_adj,
+                        const int* __restrict__ nmax_dev, int ncls, float* __restrict__ out) {
   __shared__ float red[2][256];
+  if (nmax_dev) {        // reduce_mean with a device-side N_max (one captured graph for every batch): :176-177
+    const float nm = (float)nmax_dev[0];
+    scale_x = 1.f / ((float)B * nm * (float)ncls);
+    scale_adj = 1.f / ((float)B * nm * nm);
+  }
   float sx = 0.f, sa = 0.f;
   for (int b = threadIdx.x; b < B; b += 256) { sx += part[2 * b]; sa += part[2 * b + 1]; }
   red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sa;
@@ -830,8 +836,14 @@ dense_loss_bwd_kernel(const float* __restrict__ g_lx, const float* __restrict__ 
                       const float* __restrict__ res_x, const float* __restrict__ Z2, int F2, const float* __restrict__ w2,
                       const float* __restrict__ flags, const float* __restrict__ mean_std, const int* __restrict__ mol_ptr,
                       const int* __restrict__ pair_ptr, int ncls, float anneal, float scale_x, float scale_adj,
-                      float* __restrict__ gS, float* __restrict__ gZ2, float* __restrict__ gOUT) {
+                      const int* __restrict__ nmax_dev, int B, float* __restrict__ gS, float* __restrict__ gZ2,
+                      float* __restrict__ gOUT) {
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (nmax_dev) {
+    const float nm = (float)nmax_dev[0];
+    scale_x = 1.f / ((float)B * nm * (float)ncls);
+    scale_adj = 1.f / ((float)B * nm * nm);
+  }
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
   const float sd = mean_std[2 * b + 1], inv = 1.f / sd;
   const float wb = anneal != 0.f ? powf(sd, anneal) : 1.f;
@@ -858,8 +870,8 @@ dense_loss_bwd_kernel(const float* __restrict__ g_lx, const float* __restrict__ 
 extern "C" int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, const float* b2, const float* OUT,
                                    const float* z_adj, const float* z_x, const float* flags, const float* mean_std,
                                    const int* mol_ptr, const int* pair_ptr, int B, int ncls, float anneal_power,
-                                   float scale_x, float scale_adj, float* res_adj, float* res_x, float* part, float* out,
-                                   void* stream) {
+                                   float scale_x, float scale_adj, const int* nmax_dev, float* res_adj, float* res_x,
+                                   float* part, float* out, void* stream) {
   if (B <= 0 || !G2 || !w2 || !b2 || !OUT || !z_adj || !z_x || !flags || !mean_std || !mol_ptr || !pair_ptr || !res_adj ||
       !res_x || !part || !out || F2 <= 0 || ncls <= 0 || ncls > DH_XP)
     return MSDE_EINVAL;
@@ -867,7 +879,7 @@ extern "C" int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, con
   MSDE_LAUNCH(dense_loss_fwd_kernel, dim3(B), dim3(256), 0, st, G2, F2, w2, b2, OUT, z_adj, z_x, flags, mean_std, mol_ptr,
               pair_ptr, ncls, anneal_power, res_adj, res_x, part);
   MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(dense_loss_final_kernel, dim3(1), dim3(256), 0, st, part, B, scale_x, scale_adj, out);
+  MSDE_LAUNCH(dense_loss_final_kernel, dim3(1), dim3(256), 0, st, part, B, scale_x, scale_adj, nmax_dev, ncls, out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -876,12 +888,13 @@ extern "C" int msde_dense_loss_bwd(const float* g_lx, const float* g_la, const f
                                    const float* Z2, int F2,
                                    const float* w2, const float* flags, const float* mean_std, const int* mol_ptr,
                                    const int* pair_ptr, int B, int ncls, float anneal_power, float scale_x,
-                                   float scale_adj, float* gS, float* gZ2, float* gOUT, void* stream) {
+                                   float scale_adj, const int* nmax_dev, float* gS, float* gZ2, float* gOUT,
+                                   void* stream) {
   if (B <= 0 || !res_adj || !res_x || !Z2 || !w2 || !flags || !mean_std || !mol_ptr || !pair_ptr || !gS || !gZ2 ||
       !gOUT || F2 <= 0 || ncls <= 0 || ncls > DH_XP)
     return MSDE_EINVAL;
   MSDE_LAUNCH(dense_loss_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), g_lx, g_la, res_adj, res_x, Z2, F2, w2, flags,
-              mean_std, mol_ptr, pair_ptr, ncls, anneal_power, scale_x, scale_adj, gS, gZ2, gOUT);
+              mean_std, mol_ptr, pair_ptr, ncls, anneal_power, scale_x, scale_adj, nmax_dev, B, gS, gZ2, gOUT);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

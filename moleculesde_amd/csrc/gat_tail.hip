@@ -162,8 +162,8 @@ __global__ void __launch_bounds__(GT_THREADS)
 gat_tail_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ x, const float* __restrict__ y1_s,
                     const float* __restrict__ h0_s, const float* __restrict__ x2_s, const float* __restrict__ ln1_g,
                     const float* __restrict__ W0, const float* __restrict__ W3, const float* __restrict__ ln2_g,
-                    const float* __restrict__ ln2_b, int N, float eps1, float eps2, float p_drop,
-                    unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int silu_out,
+                    const float* __restrict__ ln2_b, int N, const int* __restrict__ Ndev, float eps1, float eps2,
+                    float p_drop, unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int silu_out,
                     float* __restrict__ g_x, float* __restrict__ g_res, float* __restrict__ g_x2_o,
                     float* __restrict__ a_o, float* __restrict__ g_h0_o, float* __restrict__ ln_part) {
   constexpr int C = D / GT_LPR;
@@ -178,9 +178,10 @@ gat_tail_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ x
   const int q = threadIdx.x & (GT_LPR - 1), rowl = threadIdx.x / GT_LPR;
   size_t i = (size_t)blockIdx.x * GT_ROWS + rowl;
   const bool live = i < (size_t)N;
+  // rows past the row bound are still computed and stored (finite, never stale) but add nothing to the parameter sums
+  const float lv = i < (size_t)msde_true_rows(N, Ndev) ? 1.f : 0.f;
   if (!live) i = (size_t)N - 1;
   const size_t off = i * D + q * C;
-  const float lv = live ? 1.f : 0.f;
   float g[C], u[C], w[C], t2[C], full[D];
   gt_load<C>(g_out, off, g);
   gt_load<C>(x2_s, off, u);                   // u = x2
@@ -286,7 +287,8 @@ extern "C" int msde_gat_tail_bwd(const float* g_out, const float* x, const float
   if (D != 32) return MSDE_EUNSUP;
   if (N == 0) return 0;
   MSDE_LAUNCH(gat_tail_bwd_kernel<32>, dim3(msde_gat_tail_blocks(N)), dim3(GT_THREADS), 0, as_stream(stream), g_out, x, y1,
-              h0, x2, ln1_g, W0, W3, ln2_g, ln2_b, N, eps1, eps2, p_drop, seed, seed_dev, silu_out, g_x, g_res, g_x2, a, g_h0,
+              h0, x2, ln1_g, W0, W3, ln2_g, ln2_b, N, msde_row_bound(N), eps1, eps2, p_drop, seed, seed_dev, silu_out, g_x, g_res, g_x2,
+              a, g_h0,
               ln_part);
   MSDE_CHECK_LAUNCH();
   return 0;

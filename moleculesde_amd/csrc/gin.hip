@@ -97,8 +97,11 @@ __global__ void gin_aggregate_bwd_x_kernel(const float* __restrict__ g, const fl
 __global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                              const float* __restrict__ tab, const int* __restrict__ codes,
                                              const int* __restrict__ src, const int* __restrict__ dst, int N, int E,
+                                             const int* __restrict__ Ndev, const int* __restrict__ Edev,
                                              int D, int R, int nodes_per_block, float* __restrict__ slabs,
                                              float* __restrict__ eps_part) {
+  N = msde_true_rows(N, Ndev);      // row bounds: padded edges / atoms contribute nothing
+  E = msde_true_rows(E, Edev);
   extern __shared__ float lds[];  // [R*D] table copy, [R*D] partial gradient, [blockDim/64] reduction scratch
   float* stab = lds;
   float* ltab = lds + (size_t)R * D;
@@ -111,7 +114,7 @@ __global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const 
       float xv[4], gv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        int e = min(eb + u, e1 - 1);
+        int e = max(min(eb + u, e1 - 1), 0);
         xv[u] = x[(size_t)src[e] * D + c];
         gv[u] = g[(size_t)dst[e] * D + c];
       }
@@ -195,7 +198,8 @@ extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const 
   int npb = (N + nb - 1) / nb;
   float* slabs = workspace;
   float* eps_part = workspace + (size_t)nb * R * D;
-  MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3(nb), dim3(threads), lds, st, g, x, tab, codes, src, dst, N, E, D, R, npb,
+  MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3(nb), dim3(threads), lds, st, g, x, tab, codes, src, dst, N, E, msde_row_bound(N),
+              msde_row_bound(E), D, R, npb,
               slabs, eps_part);
   MSDE_CHECK_LAUNCH();
   if (no_reduce) return 0;

@@ -38,7 +38,7 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = bid_y * BM, n0 = bid_x * BN;
   const int kb = bid_z * k_per_split;
-  const int ke = min(K, kb + k_per_split);
+  const int ke = max(min(K, kb + k_per_split), kb);      // K may be a device-side row bound below this split: no tiles
 
   // staging registers: each thread moves (BM*BK/4)/256 = 2*TM float4 of A and 2*TN of B per tile
   constexpr int NA = 2 * TM, NB = 2 * TN;
@@ -206,9 +206,9 @@ template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>
 __global__ void __launch_bounds__(256)
 gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                      float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
-                     int ldc, int k_per_split) {
-  gemm_f32_mfma_body<TM, TN, A_KM, B_KM, VEC>(A, B, bias, C, colsum_ws, M, N, K, lda, ldb, ldc, k_per_split, blockIdx.x,
-                                              blockIdx.y, blockIdx.z);
+                     int ldc, int k_per_split, const int* __restrict__ Kdev) {
+  gemm_f32_mfma_body<TM, TN, A_KM, B_KM, VEC>(A, B, bias, C, colsum_ws, M, N, msde_true_rows(K, Kdev), lda, ldb, ldc,
+                                              k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped weight gradients: ONE launch runs the split-M GEMMs of many layers.  probs[p] = 16 int64:
@@ -230,13 +230,14 @@ gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __rest
   float* cs = reinterpret_cast<float*>(e[3]);
   const int M = (int)e[4], N = (int)e[5], K = (int)e[6], kps = (int)e[8], tx = (int)e[9], ty = (int)e[10];
   const int ldg = (int)e[12], ldx = (int)e[13];
+  const int Mt = msde_true_rows(M, reinterpret_cast<const int*>(e[14]));      // valid rows of gY / X (row bound)
   const int local = (int)blockIdx.x - prefix[lo];
   const int bx = local % tx, by = (local / tx) % ty, bz = local / (tx * ty);
   // product C[N][K] = gY^T X: "M" of the product = N, "N" = K, reduction = M (see msde_linear_bwd_w)
   if (e[11])
-    gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, M, ldg, ldx, K, kps, bx, by, bz);
+    gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
   else
-    gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, M, ldg, ldx, K, kps, bx, by, bz);
+    gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
 }
 
 // out[i] = sum_z slabs[z][i] for the weight slabs (n entries) and, in the same launch, the bias-gradient
@@ -287,12 +288,14 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 template <int TM, int TN, bool A_KM, bool B_KM>
 static void launch_cfg(bool vec, dim3 grid, hipStream_t st, const float* A, const float* B, const float* bias, float* C,
                        float* colsum_ws, int M, int N, int K, int lda, int ldb, int ldc, int k_per_split) {
+  // weight gradients reduce over the rows of both operands: honour a row bound on that extent
+  const int* kdev = (A_KM && B_KM) ? msde_row_bound(K) : nullptr;
   if (vec)
     MSDE_LAUNCH((gemm_f32_mfma_kernel<TM, TN, A_KM, B_KM, true>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N,
-                K, lda, ldb, ldc, k_per_split);
+                K, lda, ldb, ldc, k_per_split, kdev);
   else
     MSDE_LAUNCH((gemm_f32_mfma_kernel<TM, TN, A_KM, B_KM, false>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M,
-                N, K, lda, ldb, ldc, k_per_split);
+                N, K, lda, ldb, ldc, k_per_split, kdev);
 }
 
 // tile: rows (product M) and columns (product N) each 64 or 128 wide; `big` prefers 128-wide tiles
@@ -470,7 +473,7 @@ extern "C" int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const flo
   int tx = (K + 63) / 64, ty = (N + 63) / 64;
   bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (kps % 4 == 0) && (ldg % 4 == 0) &&
              (ldx % 4 == 0);
-  row[12] = ldg; row[13] = ldx; row[14] = 0; row[15] = 0;
+  row[12] = ldg; row[13] = ldx; row[14] = reinterpret_cast<long long>(msde_row_bound(M)); row[15] = 0;
   row[0] = reinterpret_cast<long long>(gY);
   row[1] = reinterpret_cast<long long>(X);
   row[2] = reinterpret_cast<long long>(slabs);

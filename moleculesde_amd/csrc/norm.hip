@@ -46,13 +46,15 @@ __device__ __forceinline__ void bn_merge(float& n, float& mean, float& m2, float
 // uses the SAME shift, so lane partials add directly, in lane order.
 template <int V>
 __global__ void __launch_bounds__(256)
-bn_stats_partial_kernel(const float* __restrict__ X, int M, int C, int rows_per_split, float* __restrict__ ws) {
+bn_stats_partial_kernel(const float* __restrict__ X, int M, const int* __restrict__ Mdev, int C, int rows_per_split,
+                        float* __restrict__ ws) {
+  M = msde_true_rows(M, Mdev);          // statistics over the valid rows only (the apply pass still covers all rows)
   using T = typename VecT<V>::type;
   constexpr int CG = BnGeo<V>::CG, RL = BnGeo<V>::RL;
   __shared__ float s_1[BN_MAXRL][BN_COLS], s_2[BN_MAXRL][BN_COLS];
   const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
   const int c = blockIdx.x * BN_COLS + tx * V;
-  const int r0 = blockIdx.y * rows_per_split, r1 = min(r0 + rows_per_split, M);
+  const int r0 = blockIdx.y * rows_per_split, r1 = max(min(r0 + rows_per_split, M), r0);
   T a1 = vzero<V>(), a2 = vzero<V>(), b1 = vzero<V>(), b2 = vzero<V>();
   T x0 = vzero<V>();
   if (c < C) {
@@ -84,7 +86,8 @@ bn_stats_partial_kernel(const float* __restrict__ X, int M, int C, int rows_per_
       const float n = (float)(r1 - r0);
       const float xs = X[(size_t)r0 * C + cc];
       float* o = ws + ((size_t)blockIdx.y * C + cc) * 3;
-      o[0] = n; o[1] = xs + s1 / n; o[2] = fmaxf(s2 - s1 * s1 / n, 0.f);
+      if (n > 0.f) { o[0] = n; o[1] = xs + s1 / n; o[2] = fmaxf(s2 - s1 * s1 / n, 0.f); }
+      else { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }          // a split entirely past the valid rows
     }
   }
 }
@@ -190,10 +193,11 @@ template <int V>
 __global__ void __launch_bounds__(256)
 bn_bwd_partial_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                       const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                      int relu, int M, int C, int rows_per_split, float* __restrict__ ws) {
+                      int relu, int M, const int* __restrict__ Mdev, int C, int rows_per_split, float* __restrict__ ws) {
   using T = typename VecT<V>::type;
   constexpr int CG = BnGeo<V>::CG, RL = BnGeo<V>::RL;
   __shared__ float s_a[BN_MAXRL][BN_COLS], s_b[BN_MAXRL][BN_COLS];
+  M = msde_true_rows(M, Mdev);
   const int tx = threadIdx.x % CG, ty = threadIdx.x / CG;
   const int c = blockIdx.x * BN_COLS + tx * V;
   const int r0 = blockIdx.y * rows_per_split, r1 = min(r0 + rows_per_split, M);
@@ -241,8 +245,8 @@ template <int V>
 __global__ void __launch_bounds__(256)
 bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                    int relu, const float* __restrict__ ws, int M, int C, int splits, int rows_per_block,
-                    float* __restrict__ dX, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                    int relu, const float* __restrict__ ws, int M, const int* __restrict__ Mdev, int C, int splits,
+                    int rows_per_block, float* __restrict__ dX, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   using T = typename VecT<V>::type;
   constexpr int CG = BnGeo<V>::CG, RL = BnGeo<V>::RL;
   __shared__ float s_db[BN_COLS], s_dg[BN_COLS];
@@ -281,7 +285,7 @@ bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, c
   if (c >= C) return;
   T mu, rs, g, b;
   bn_col_params<V>(mean, rstd, gamma, beta, c, mu, rs, g, b);
-  const float invM = 1.f / (float)M;
+  const float invM = 1.f / (float)msde_true_rows(M, Mdev);      // mean over the valid rows; dX is written for all rows
   T kb, kg, grs = vmul(g, rs);
 #pragma unroll
   for (int k = 0; k < V; ++k) { vref(kb, k) = s_db[tx * V + k] * invM; vref(kg, k) = s_dg[tx * V + k] * invM; }
@@ -315,8 +319,10 @@ static inline void bn_geometry(int M, int* splits, int* rows) {
 #define BN_RL 4   // row lanes of the scalar column-sum kernels
 // ---- column sums (bias gradients of the library-GEMM weight-gradient path): two launches, fixed order
 __global__ void __launch_bounds__(256)
-colsum_partial_kernel(const float* __restrict__ X, int M, int C, int rows_per_split, float* __restrict__ ws) {
+colsum_partial_kernel(const float* __restrict__ X, int M, const int* __restrict__ Mdev, int C, int rows_per_split,
+                      float* __restrict__ ws) {
   __shared__ float s_a[BN_RL][BN_COLS];
+  M = msde_true_rows(M, Mdev);
   const int tx = threadIdx.x & (BN_COLS - 1), ty = threadIdx.x / BN_COLS;
   const int c = blockIdx.x * BN_COLS + tx;
   const int r0 = blockIdx.y * rows_per_split, r1 = min(r0 + rows_per_split, M);
@@ -351,7 +357,8 @@ extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* work
   if (M == 0) return (int)hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
   int splits, rows;
   bn_geometry(M, &splits, &rows);
-  MSDE_LAUNCH(colsum_partial_kernel, dim3((C + BN_COLS - 1) / BN_COLS, splits), dim3(256), 0, st, X, M, C, rows, workspace);
+  MSDE_LAUNCH(colsum_partial_kernel, dim3((C + BN_COLS - 1) / BN_COLS, splits), dim3(256), 0, st, X, M, msde_row_bound(M), C, rows,
+              workspace);
   MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(colsum_final_kernel, dim3((C + BN_COLS - 1) / BN_COLS), dim3(256), 0, st, (const float*)workspace, splits, C,
               out);
@@ -376,12 +383,12 @@ extern "C" int msde_bn_fwd(const float* X, int M, int C, const float* gamma, con
   dim3 grid((C + BN_COLS - 1) / BN_COLS, splits);
   const bool vec = (C % 4 == 0) && bn_aligned16(X) && bn_aligned16(Y);
   if (vec) {
-    MSDE_LAUNCH(bn_stats_partial_kernel<4>, grid, dim3(256), 0, as_stream(stream), X, M, C, rows, workspace);
+    MSDE_LAUNCH(bn_stats_partial_kernel<4>, grid, dim3(256), 0, as_stream(stream), X, M, msde_row_bound(M), C, rows, workspace);
     MSDE_CHECK_LAUNCH();
     MSDE_LAUNCH(bn_fwd_apply_kernel<4>, grid, dim3(256), 0, as_stream(stream), X, (const float*)workspace, M, C, splits,
                 rows, gamma, beta, eps, momentum, running_mean, running_var, relu, Y, save_mean, save_rstd);
   } else {
-    MSDE_LAUNCH(bn_stats_partial_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, M, C, rows, workspace);
+    MSDE_LAUNCH(bn_stats_partial_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, M, msde_row_bound(M), C, rows, workspace);
     MSDE_CHECK_LAUNCH();
     MSDE_LAUNCH(bn_fwd_apply_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, (const float*)workspace, M, C, splits,
                 rows, gamma, beta, eps, momentum, running_mean, running_var, relu, Y, save_mean, save_rstd);
@@ -400,16 +407,16 @@ extern "C" int msde_bn_bwd(const float* dY, const float* X, const float* save_me
   const bool vec = (C % 4 == 0) && bn_aligned16(X) && bn_aligned16(dY) && bn_aligned16(dX);
   if (vec) {
     MSDE_LAUNCH(bn_bwd_partial_kernel<4>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
-                relu, M, C, rows, workspace);
+                relu, M, msde_row_bound(M), C, rows, workspace);
     MSDE_CHECK_LAUNCH();
     MSDE_LAUNCH(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
-                relu, (const float*)workspace, M, C, splits, rows, dX, dgamma, dbeta);
+                relu, (const float*)workspace, M, msde_row_bound(M), C, splits, rows, dX, dgamma, dbeta);
   } else {
     MSDE_LAUNCH(bn_bwd_partial_kernel<1>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
-                relu, M, C, rows, workspace);
+                relu, M, msde_row_bound(M), C, rows, workspace);
     MSDE_CHECK_LAUNCH();
     MSDE_LAUNCH(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
-                relu, (const float*)workspace, M, C, splits, rows, dX, dgamma, dbeta);
+                relu, (const float*)workspace, M, msde_row_bound(M), C, splits, rows, dX, dgamma, dbeta);
   }
   MSDE_CHECK_LAUNCH();
   return 0;

@@ -176,8 +176,11 @@ extern "C" int msde_ve_perturb(const float* pos, const float* noise, const long 
 #define RP_BLOCK 256    // 64 keys per workgroup (four lanes each): every workgroup regenerates all n keys, so fewer,
                         // larger workgroups keep that redundant hashing small
 __global__ void __launch_bounds__(RP_BLOCK)
-randperm_kernel(int n, unsigned long long seed, const unsigned long long* __restrict__ seed_dev, int* __restrict__ out) {
+randperm_kernel(int n, const int* __restrict__ ndev, unsigned long long seed,
+                const unsigned long long* __restrict__ seed_dev, int* __restrict__ out) {
   __shared__ unsigned long long key[RP_MAX];
+  const int ncap = n;
+  n = msde_true_rows(n, ndev);          // permutation of the valid rows; entries past them map to themselves
   if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
   seed += 0xD1B54A32D192ED03ull * blockIdx.y;       // blockIdx.y: which of the `count` independent permutations
   out += (size_t)blockIdx.y * n;
@@ -193,7 +196,7 @@ randperm_kernel(int n, unsigned long long seed, const unsigned long long* __rest
   const int i = blockIdx.x * (RP_BLOCK / 4) + (threadIdx.x >> 2), part = threadIdx.x & 3;
   const int quarter = (n + 3) / 4;
   const int j0 = part * quarter, j1 = min(j0 + quarter, n);
-  const unsigned long long mine = key[min(i, n - 1)];
+  const unsigned long long mine = key[max(min(i, n - 1), 0)];
   int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
   int j = j0;
   for (; j + 3 < j1; j += 4) {
@@ -204,6 +207,7 @@ randperm_kernel(int n, unsigned long long seed, const unsigned long long* __rest
   r += __shfl_xor(r, 1);
   r += __shfl_xor(r, 2);
   if (part == 0 && i < n) out[i] = r;
+  else if (part == 0 && i < ncap) out[i] = i;
 }
 
 extern "C" int msde_randperm(int n, int count, unsigned long long seed, const unsigned long long* seed_dev, int* out,
@@ -212,7 +216,7 @@ extern "C" int msde_randperm(int n, int count, unsigned long long seed, const un
   if (n > RP_MAX) return MSDE_EUNSUP;
   if (n == 0 || count == 0) return 0;
   MSDE_LAUNCH(randperm_kernel, dim3((n + RP_BLOCK / 4 - 1) / (RP_BLOCK / 4), count), dim3(RP_BLOCK), 0, as_stream(stream), n,
-              seed, seed_dev, out);
+              msde_row_bound(n), seed, seed_dev, out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

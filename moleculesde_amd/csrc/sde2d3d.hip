@@ -16,6 +16,7 @@ __global__ void edge_geometry_fwd_kernel(const float* __restrict__ pos, const in
   if (t >= (size_t)E * C) return;
   int e = (int)(t / C), c = (int)(t % C);
   int r = src[e], q = dst[e];  // row = edge_index[0] (source), col = edge_index[1] (target)
+  r = max(r, 0); q = max(q, 0); // padded edge slots (src = dst = -1 past the true edge count): any finite geometry
   float prx = pos[3 * r], pry = pos[3 * r + 1], prz = pos[3 * r + 2];
   float pcx = pos[3 * q], pcy = pos[3 * q + 1], pcz = pos[3 * q + 2];
   // coord2basis (SDE_model_2D_to_3D.py:35-47)

@@ -299,7 +299,7 @@ class _DenseHeadLosses(torch.autograd.Function):
         part, out = _empty(B, 2, device=dev), _empty(2, device=dev)
         _lib.call("msde_dense_loss_fwd", _p(se.G2), se.G2.size(1), _p(f2W), _p(f2b), _p(sn.OUT), _p(z_adj), _p(z_x), _p(flags),
                   _p(mean_std), _p(cfg.mol_ptr), _p(cfg.pair_ptr), B, cfg.ncls, cfg.anneal, cfg.scale_x, cfg.scale_adj,
-                  _p(res_adj), _p(res_x), _p(part), _p(out), hip._stream())
+                  _p(getattr(cfg, "nmax_dev", None)), _p(res_adj), _p(res_x), _p(part), _p(out), hip._stream())
         ctx.cfg, ctx.se, ctx.sn = cfg, se, sn
         ctx.keep = (h3, AC, flags, mean_std, px, XC, res_adj, res_x)
         ctx.T = T
@@ -321,8 +321,8 @@ class _DenseHeadLosses(torch.autograd.Function):
         gS, gZG2 = _empty(P, device=dev), _empty(P, se.ZG2.size(1), device=dev)
         gOUT = _empty(N, XP_LD, device=dev)
         _lib.call("msde_dense_loss_bwd", _p(g_lx), _p(g_la), _p(res_adj), _p(res_x), _p(se.ZG2), se.ZG2.size(1), _p(TE[-2]), _p(flags),
-                  _p(mean_std), _p(cfg.mol_ptr), _p(cfg.pair_ptr), B, cfg.ncls, cfg.anneal, cfg.scale_x, cfg.scale_adj, _p(gS),
-                  _p(gZG2), _p(gOUT), hip._stream())
+                  _p(mean_std), _p(cfg.mol_ptr), _p(cfg.pair_ptr), B, cfg.ncls, cfg.anneal, cfg.scale_x, cfg.scale_adj,
+                  _p(getattr(cfg, "nmax_dev", None)), _p(gS), _p(gZG2), _p(gOUT), hip._stream())
         GN, gXC = node_backward(cfg, sn, XC, F, AC, TN, gOUT)
         GE, _ = edge_backward(cfg, se, AC, flags, cfg.chans, cfg.offs, TE, gS, gZG2, gXC[:, :F], True)
         gX = gXC[:, :F]

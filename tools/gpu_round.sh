@@ -27,16 +27,16 @@ dp)
   timeout 600 python bench.py --debug_dp_path --full --no_cpu_baseline > $O/bench_dp1_full.json 2> $O/bench_dp1_full.err; echo "dp full rc=$?"; cat $O/bench_dp1_full.json;;
 prof)
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o run -- python3 $R/bench.py --no_cpu_baseline > $O/prof_bench.json 2> $O/prof.log; echo "prof rc=$?"
-  timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_full -o run -- python3 $R/bench.py --full --no_cpu_baseline > $O/prof_full_bench.json 2> $O/prof_full.log; echo "prof full rc=$?"
+  timeout 900 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof -o run -- python3 $R/bench.py --no_cpu_baseline > $O/prof_bench.json 2> $O/prof.log; echo "prof rc=$?"
+  timeout 900 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_full -o run -- python3 $R/bench.py --full --no_cpu_baseline > $O/prof_full_bench.json 2> $O/prof_full.log; echo "prof full rc=$?"
   cd $R;;
 pmc)
   cd /tmp
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 600 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+    timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc $c -d $O/pmc_$c -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
   done
-  timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $O/pmc_SQ -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"
-  timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_SQ2 -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_SQ2.log 2>&1; echo "pmc SQ2 rc=$?"
+  timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $O/pmc_SQ -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_SQ.log 2>&1; echo "pmc SQ rc=$?"
+  timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_SQ2 -o run -- python3 $R/tools/prof_kernels.py $PMC_ARG > $O/pmc_SQ2.log 2>&1; echo "pmc SQ2 rc=$?"
   cd $R
   python tools/pmc_summary.py $O/pmc_counters.json '{"N": 3588, "E_r": 49090, "batch": "make_batch(256, seed=0)"}' $(find $O -name "*counter_collection.csv") > $O/pmc_summary.log 2>&1; tail -3 $O/pmc_summary.log
   find $O -name "*counter_collection.csv" -delete;;
