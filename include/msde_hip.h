@@ -54,6 +54,33 @@ int msde_radius_fill(const float* pos, const int* batch, const int* mol_ptr, int
 int msde_set_row_bound(int cap, const int* dev_count);
 int msde_clear_row_bounds(void);
 
+/* ------------------------------------------------------------------ batch construction on the GPU --- */
+/* Everything index-shaped a pretrain step needs, from the RAW collated arrays of a mini-batch, into buffers of fixed
+ * capacity (csrc/plan.hip).  Replaces PyG's collate bookkeeping (App. A.8), `extend_graph`
+ * (Geom3D/datasets/dataset_3D.py:12-35: all ordered pairs within <= 4 bonds; a per-sample CPU spspmm in the reference)
+ * and the per-batch host plan.  Inputs (int32, device): x_raw [N_cap][K] atom feature codes, bond_src / bond_dst
+ * [Eb_cap] (batch-global atom indices, loader order), bond_attr [Eb_cap][3], mol_atoms / mol_bonds [B] (per-molecule
+ * counts; a molecule's atoms and bonds are contiguous; <= 32 atoms, <= 1024 directed bonds each; B <= 1024),
+ * atom_off [K] / bond_off [3] (offsets of the concatenated OGB embedding tables).  Outputs: mol_ptr [B+2] (entry B+1
+ * repeats N: padded atoms belong to the empty molecule B), bond_ptr / pair_ptr [B+1], sizes [8] = {N, E_b, E_e,
+ * sum n^2, n_max, radius-edge bound sum n*min(n-1, max_nbr), -, -}, batch_i32 / z_codes [N_cap], atom_codes [N_cap][K],
+ * the bond graph as CSR by target (b_rowptr [N_cap+1], b_src, b_dst [Eb_cap]; canonical order = stable sort by target)
+ * with its by-source view (b_rowptr_s, b_perm_s) and canonical-order bond_codes [Eb_cap][3] / bond_type [Eb_cap], the
+ * extended graph the same way (e_*, Ee_cap), and scratch ext_rows [N_cap] / ext_cnt [B] / ext_ptr [B+1].  Padded tails:
+ * see msde_set_row_bound.  *err is set to 1 if a molecule exceeds the limits. */
+int msde_plan_build(const int* x_raw, int K, const int* atom_off, const int* bond_src, const int* bond_dst,
+                    const int* bond_attr, const int* bond_off, const int* mol_atoms, const int* mol_bonds,
+                    int B, int N_cap, int Eb_cap, int Ee_cap, int max_nbr, int* mol_ptr, int* bond_ptr,
+                    int* pair_ptr, int* sizes, int* batch_i32, int* atom_codes, int* z_codes, int* b_rowptr,
+                    int* b_src, int* b_dst, int* b_rowptr_s, int* b_perm_s, int* bond_codes, float* bond_type,
+                    unsigned* ext_rows, int* ext_cnt, int* ext_ptr, int* e_rowptr, int* e_src, int* e_dst,
+                    int* e_rowptr_s, int* e_perm_s, int* err, void* stream);
+/* Per-table-row atom lists of the embedding backward (msde_embedding_sum_bwd): for codes [*n_dev][K] with values in
+ * [0, R): list_ptr [R+1], items = atom index of every entry with that code, in ascending (atom, column) order; cnt [R]
+ * is scratch. */
+int msde_plan_row_lists(const int* codes, const int* n_dev, int K, int R, int* cnt, int* list_ptr, int* items,
+                        void* stream);
+
 /* ------------------------------------------------------------------ generic row ops -------- */
 /* torch_scatter.scatter(reduce=sum) over CSR rows: out[i] = sum_{s in [rowptr[i],rowptr[i+1])}
  * rows[perm ? perm[s] : s]; used for every backward "gather by source/target".  D % 4 == 0 or any. */

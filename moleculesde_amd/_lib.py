@@ -64,6 +64,8 @@ SIGNATURES = {
     "msde_dense_node_gcn_bwd": [P, I, P, I, P, P, P, P, I, I, P, P, P],
     "msde_dense_loss_fwd": [P, I, P, P, P, P, P, P, P, P, P, I, I, F, F, F, P, P, P, P, P, P],
     "msde_dense_loss_bwd": [P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, P, P, P, P, P],
+    "msde_plan_build": [P, I, P, P, P, P, P, P, P, I, I, I, I, I] + [P] * 23 + [P],
+    "msde_plan_row_lists": [P, P, I, I, P, P, P, P],
     "msde_set_row_bound": [I, P],
     "msde_clear_row_bounds": [],
     "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],

@@ -1,0 +1,192 @@
+"""Capacity buckets: ONE set of static device buffers (and one captured hipGraph) for every mini-batch.
+
+A `Bucket` owns, for fixed row capacities (atoms N, bonds E_b, extended edges E_e, radius edges E_r, atom pairs P):
+  * the RAW input blob of a batch -- what a data loader's collate produces (atom feature codes, coordinates, the bond
+    list with its features, atoms / bonds per molecule) -- as one int32 device buffer, so feeding a batch is ONE copy;
+  * every plan buffer of moleculesde_amd.plan (CSR views, feature codes, embedding row lists, dense-head pair layout),
+    filled ON THE DEVICE from the raw blob by csrc/plan.hip (`build_plan_on_device`), including the extended graph
+    (`extend_graph`, Geom3D/datasets/dataset_3D.py:12-35) the reference computes per sample on the CPU;
+  * a Batch-like object (`bucket.batch`) the model classes accept unchanged.
+True sizes stay on the device (`sizes`): kernels that reduce over rows read them through the row bounds
+(msde_set_row_bound), everything else processes the padded rows too (finite values, zero gradients).
+"""
+import ctypes
+import types
+
+import numpy as np
+import torch
+
+from . import _lib, hip, plan as _plan
+from .batch import Batch
+
+K_ATOM = 9
+MAX_NBR = 32
+
+
+def _round_up(v, q):
+    return ((int(v) + q - 1) // q) * q
+
+
+class Caps:
+    """Row capacities of a bucket.  Pairwise distinct multiples of 8 (the row-bound table is keyed by capacity)."""
+
+    __slots__ = ("B", "N", "E_b", "E_e", "E_r", "P", "n_max")
+
+    def __init__(self, B, N, E_b, E_e, E_r, P, n_max):
+        self.B, self.n_max = int(B), int(n_max)
+        vals = [_round_up(N, 256), _round_up(E_b, 512) + 8, _round_up(E_e, 2048) + 16, _round_up(E_r, 2048) + 24,
+                _round_up(P, 2048) + 40]
+        assert len(set(vals)) == 5
+        self.N, self.E_b, self.E_e, self.E_r, self.P = vals
+
+    def fits(self, need):
+        return (need["B"] == self.B and need["N"] <= self.N and need["E_b"] <= self.E_b and need["E_e"] <= self.E_e and
+                need["E_r"] <= self.E_r and need["P"] <= self.P and need["n_max"] <= self.n_max)
+
+    @staticmethod
+    def covering(needs, n_max=None):
+        """Smallest capacities that hold every entry of `needs` (dicts from raw_sizes)."""
+        mx = lambda k: max(n[k] for n in needs)
+        return Caps(needs[0]["B"], mx("N"), mx("E_b"), mx("E_e"), mx("E_r"), mx("P"), n_max or max(mx("n_max"), 1))
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in self.__slots__}
+
+
+# ------------------------------------------------------------------------------------------------ raw batches
+def raw_layout(caps):
+    """Offsets (in int32 words) of the fields of the raw blob."""
+    o, lay = 0, {}
+    for name, n in (("x", caps.N * K_ATOM), ("pos", caps.N * 3), ("bond_src", caps.E_b), ("bond_dst", caps.E_b),
+                    ("bond_attr", caps.E_b * 3), ("mol_atoms", caps.B), ("mol_bonds", caps.B)):
+        lay[name] = (o, n)
+        o += (n + 3) & ~3
+    lay["_total"] = o
+    return lay
+
+
+def raw_sizes(b):
+    """What a batch needs from a bucket (host side, from the collated Batch)."""
+    cnt = torch.bincount(b.batch, minlength=b.num_graphs)
+    n = cnt.numpy().astype(np.int64)
+    E_e = int(b.extended_edge_index.size(1)) if getattr(b, "extended_edge_index", None) is not None else int((n * (n - 1)).sum())
+    return {"B": int(b.num_graphs), "N": int(b.x.size(0)), "E_b": int(b.edge_index.size(1)), "E_e": E_e,
+            "E_r": int((n * np.minimum(np.maximum(n - 1, 0), MAX_NBR)).sum()), "P": int((n * n).sum()),
+            "n_max": int(n.max()) if len(n) else 0}
+
+
+def pack_raw(b, caps, pin=False):
+    """Raw blob (int32, host) of a collated Batch for a bucket of capacities `caps`: exactly the arrays a loader's
+    collate holds (no plan, no extended edges)."""
+    lay = raw_layout(caps)
+    blob = torch.zeros(lay["_total"], dtype=torch.int32)
+    if pin:
+        blob = blob.pin_memory()
+    N, Eb = b.x.size(0), b.edge_index.size(1)
+    assert b.x.dim() == 2 and b.x.size(1) == K_ATOM
+
+    def put(name, t):
+        o, _ = lay[name]
+        flat = t.reshape(-1)
+        blob[o:o + flat.numel()] = flat
+
+    put("x", b.x.to(torch.int32))
+    o, _ = lay["pos"]
+    blob[o:o + 3 * N] = b.positions.float().contiguous().view(-1).view(torch.int32)
+    put("bond_src", b.edge_index[0].to(torch.int32))
+    put("bond_dst", b.edge_index[1].to(torch.int32))
+    put("bond_attr", b.edge_attr.to(torch.int32))
+    cnt = torch.bincount(b.batch, minlength=b.num_graphs)
+    put("mol_atoms", cnt.to(torch.int32))
+    put("mol_bonds", torch.bincount(b.batch[b.edge_index[0]], minlength=b.num_graphs).to(torch.int32) if Eb else
+        torch.zeros(b.num_graphs, dtype=torch.int32))
+    return blob
+
+
+# ------------------------------------------------------------------------------------------------ the bucket
+class Bucket:
+    def __init__(self, caps, device, atom_dims=None, bond_dims=None, node_class=119):
+        self.caps, self.device = caps, device
+        atom_dims = list(atom_dims or _plan.ATOM_FEATURE_DIMS)
+        bond_dims = list(bond_dims or _plan.BOND_FEATURE_DIMS)
+        c = caps
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        self.layout = raw_layout(c)
+        self.raw = i32(self.layout["_total"])
+        v = lambda name: self.raw[self.layout[name][0]:self.layout[name][0] + self.layout[name][1]]
+        self.x_raw = v("x").view(c.N, K_ATOM)
+        self.positions = v("pos").view(torch.float32).view(c.N, 3)
+        self.bond_src_raw, self.bond_dst_raw, self.bond_attr_raw = v("bond_src"), v("bond_dst"), v("bond_attr").view(c.E_b, 3)
+        self.mol_atoms, self.mol_bonds = v("mol_atoms"), v("mol_bonds")
+        self.atom_off = torch.tensor(_plan._offsets(atom_dims), dtype=torch.int32, device=device)
+        self.bond_off = torch.tensor(_plan._offsets(bond_dims), dtype=torch.int32, device=device)
+        self.sizes, self.err = i32(8), i32(1)
+        self.mol_ptr_full, self.bond_ptr, self.pair_ptr = i32(c.B + 2), i32(c.B + 1), i32(c.B + 1)
+        self.ext_rows, self.ext_cnt, self.ext_ptr = i32(c.N), i32(c.B), i32(c.B + 1)
+        pl = types.SimpleNamespace()
+        pl.N, pl.B, pl.N_max, pl.max_nbr, pl.E_r_cap = c.N, c.B, c.n_max, MAX_NBR, c.E_r
+        pl.mol_ptr = self.mol_ptr_full[:c.B + 1]
+        pl.batch_i32 = i32(c.N)
+        pl.atom_codes, pl.atom_R = i32(c.N, K_ATOM), sum(atom_dims)
+        pl.z_codes, pl.z_list = i32(c.N, 1), None
+        pl.atom_list_ptr, pl.atom_list_nodes = i32(pl.atom_R + 1), i32(c.N * K_ATOM)
+        self._cnt_scratch = i32(max(pl.atom_R, node_class) + 1)
+        self.node_class = node_class
+        pl.z_list = (node_class, i32(node_class + 1), i32(c.N))
+
+        def csr(E):
+            p = hip.CsrPlan()
+            p.N, p.E = c.N, E
+            p.rowptr, p.src, p.dst = i32(c.N + 1), i32(E), i32(E)
+            p.rowptr_s, p.perm_s, p.perm_t, p.E_dev = i32(c.N + 1), i32(E), None, None
+            return p
+        pl.bond, pl.ext = csr(c.E_b), csr(c.E_e)
+        pl.bond.E_dev, pl.ext.E_dev = self.sizes[1:2], self.sizes[2:3]
+        pl.bond_codes, pl.bond_R = i32(c.E_b, 3), sum(bond_dims)
+        pl.bond_type = torch.zeros(c.E_b, dtype=torch.float32, device=device)
+        pl.N_dev = self.sizes[0:1]
+        dn = types.SimpleNamespace(N_max=c.n_max, pair_ptr=self.pair_ptr, P=c.P, nmax_dev=self.sizes[4:5])
+        pl.dense = dn
+        self.plan = pl
+        # the Batch-like object the models see: tensors whose VALUES the kernels never read (identity / dtype only) are
+        # static placeholders; coordinates are the live view of the raw blob
+        z64 = lambda *s: torch.zeros(*s, dtype=torch.int64, device=device)
+        b = Batch(x=z64(c.N, K_ATOM), edge_index=z64(2, c.E_b), edge_attr=z64(c.E_b, 3), positions=self.positions,
+                  extended_edge_index=z64(2, 8), batch=z64(c.N))
+        b.num_graphs = c.B
+        b._msde_plan = pl
+        self.batch = b
+        from .geom3d import nn as _nn
+        _nn.register_plan(b, pl)
+
+    # -- feeding -----------------------------------------------------------------------------------------------
+    def load(self, blob):
+        """Copy a raw blob (host pinned / pageable, or device) into the bucket: the only per-batch transfer."""
+        self.raw.copy_(blob, non_blocking=True)
+
+    def build_plan_on_device(self):
+        """csrc/plan.hip: 8 launches on the current stream, no host synchronisation (capturable)."""
+        c, pl, p, st = self.caps, self.plan, hip._p, hip._stream()
+        _lib.call("msde_plan_build", p(self.x_raw), K_ATOM, p(self.atom_off), p(self.bond_src_raw), p(self.bond_dst_raw),
+                  p(self.bond_attr_raw), p(self.bond_off), p(self.mol_atoms), p(self.mol_bonds), c.B, c.N, c.E_b, c.E_e,
+                  MAX_NBR, p(self.mol_ptr_full), p(self.bond_ptr), p(self.pair_ptr), p(self.sizes), p(pl.batch_i32),
+                  p(pl.atom_codes), p(pl.z_codes), p(pl.bond.rowptr), p(pl.bond.src), p(pl.bond.dst), p(pl.bond.rowptr_s),
+                  p(pl.bond.perm_s), p(pl.bond_codes), p(pl.bond_type), p(self.ext_rows), p(self.ext_cnt), p(self.ext_ptr),
+                  p(pl.ext.rowptr), p(pl.ext.src), p(pl.ext.dst), p(pl.ext.rowptr_s), p(pl.ext.perm_s), p(self.err), st)
+        _lib.call("msde_plan_row_lists", p(pl.atom_codes), p(pl.N_dev), K_ATOM, pl.atom_R, p(self._cnt_scratch),
+                  p(pl.atom_list_ptr), p(pl.atom_list_nodes), st)
+        _lib.call("msde_plan_row_lists", p(pl.z_codes), p(pl.N_dev), 1, self.node_class, p(self._cnt_scratch), p(pl.z_list[1]),
+                  p(pl.z_list[2]), st)
+
+    def activate(self):
+        """Declare the bucket's row bounds (process wide: one bucket is active at a time)."""
+        c = self.caps
+        hip.set_row_bounds({c.N: self.sizes[0:1], c.E_b: self.sizes[1:2], c.E_e: self.sizes[2:3], c.P: self.sizes[3:4]})
+
+    def check(self):
+        """Host-side validation (synchronises): the loaded batch fitted the capacities."""
+        s = self.sizes.cpu().tolist()
+        c = self.caps
+        ok = (int(self.err.cpu()) == 0 and s[0] <= c.N and s[1] <= c.E_b and s[2] <= c.E_e and s[3] <= c.P and
+              s[4] <= c.n_max and s[5] <= c.E_r)
+        return ok, dict(N=s[0], E_b=s[1], E_e=s[2], P=s[3], n_max=s[4], E_r_bound=s[5])

@@ -1,0 +1,304 @@
+// plan.hip — batch construction on the GPU: everything index-shaped that the kernels of a pretrain step
+// need, built from the RAW collated arrays of a mini-batch, into buffers of fixed CAPACITY (so that one captured hipGraph
+// serves every batch; see msde_set_row_bound).
+//
+// Replaces, per batch: PyG's collate bookkeeping (App. A.8), `extend_graph` (Geom3D/datasets/dataset_3D.py:12-35:
+// A ∪ A², then (·) ∪ (·)², self loops removed = all ordered pairs within <= 4 bonds -- a per-sample torch_sparse.spspmm
+// on the CPU in the reference), and the host-side plan of round 1 (moleculesde_amd/plan.py: CSR by target + by-source
+// view for bonds and extended edges, pre-offset OGB feature codes, per-table-row atom lists for the embedding backward).
+// All outputs are bit-identical to plan.py's (tests/test_gpu_plan.py).
+//
+// Input (device, int32): x_raw [N_cap][K] atom feature codes, bond_src / bond_dst [Eb_cap] (batch-global atom indices,
+// loader order, both directions listed), bond_attr [Eb_cap][3], mol_atoms [B], mol_bonds [B] (atoms / directed bonds
+// per molecule; a molecule's atoms and bonds are contiguous).  n <= 32 atoms and <= 1024 directed bonds per molecule.
+#include "msde_common.h"
+
+#define PL_NMAX 32
+#define PL_EMAX 1024
+
+// inclusive block scan of up to 1024 ints held one per thread; returns the exclusive prefix, total in *total
+__device__ __forceinline__ int pl_block_exscan(int v, int* sh /* [1024/64 + 1] */, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) sh[w] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { int t = sh[k]; sh[k] = acc; acc += t; }
+    sh[blockDim.x >> 6] = acc;
+  }
+  __syncthreads();
+  const int ex = sh[w] + x - v;
+  *total = sh[blockDim.x >> 6];
+  __syncthreads();
+  return ex;
+}
+
+// sizes[]: 0 N, 1 E_b, 2 E_e, 3 P = sum n^2, 4 n_max, 5 sum n*min(n-1, max_nbr) (radius-graph edge bound)
+__global__ void __launch_bounds__(1024)
+plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_bonds, int B, int max_nbr,
+                 int* __restrict__ mol_ptr /* [B+2] */, int* __restrict__ bond_ptr /* [B+1] */,
+                 int* __restrict__ pair_ptr /* [B+1] */, int* __restrict__ sizes) {
+  __shared__ int sh[20];
+  __shared__ int smax;
+  const int t = threadIdx.x;
+  const int n = t < B ? mol_atoms[t] : 0, m = t < B ? mol_bonds[t] : 0;
+  if (t == 0) smax = 0;
+  int tot;
+  int ex = pl_block_exscan(n, sh, &tot);
+  if (t < B) mol_ptr[t] = ex;
+  if (t == 0) { mol_ptr[B] = tot; mol_ptr[B + 1] = tot; sizes[0] = tot; }
+  ex = pl_block_exscan(m, sh, &tot);
+  if (t < B) bond_ptr[t] = ex;
+  if (t == 0) { bond_ptr[B] = tot; sizes[1] = tot; }
+  ex = pl_block_exscan(n * n, sh, &tot);
+  if (t < B) pair_ptr[t] = ex;
+  if (t == 0) { pair_ptr[B] = tot; sizes[3] = tot; }
+  ex = pl_block_exscan(n * min(max(n - 1, 0), max_nbr), sh, &tot);
+  if (t == 0) sizes[5] = tot;
+  atomicMax(&smax, n);
+  __syncthreads();
+  if (t == 0) sizes[4] = smax;
+}
+
+// exclusive scan of cnt[0..n) (n <= 1024) -> ptr[0..n], total also to *total_out
+__global__ void __launch_bounds__(1024)
+plan_scan_small_kernel(const int* __restrict__ cnt, int n, int* __restrict__ ptr, int* __restrict__ total_out) {
+  __shared__ int sh[20];
+  const int t = threadIdx.x;
+  int tot;
+  const int ex = pl_block_exscan(t < n ? cnt[t] : 0, sh, &tot);
+  if (t < n) ptr[t] = ex;
+  if (t == 0) { ptr[n] = tot; if (total_out) *total_out = tot; }
+}
+
+// One workgroup per molecule: atom arrays, bond CSR (by target, ties in loader order = torch.argsort(stable)) with its
+// by-source view, bond feature codes, and the <= 4-bond neighbourhood rows (bit masks) + their count.
+__global__ void __launch_bounds__(256)
+plan_molecule_kernel(const int* __restrict__ x_raw, int K, const int* __restrict__ atom_off,
+                     const int* __restrict__ bond_src, const int* __restrict__ bond_dst,
+                     const int* __restrict__ bond_attr, const int* __restrict__ bond_off,
+                     const int* __restrict__ mol_ptr, const int* __restrict__ bond_ptr,
+                     int* __restrict__ batch_i32, int* __restrict__ atom_codes, int* __restrict__ z_codes,
+                     int* __restrict__ rowptr, int* __restrict__ src, int* __restrict__ dst, int* __restrict__ rowptr_s,
+                     int* __restrict__ perm_s, int* __restrict__ bond_codes, float* __restrict__ bond_type,
+                     unsigned* __restrict__ ext_rows, int* __restrict__ ext_cnt, int* __restrict__ err) {
+  __shared__ short ls[PL_EMAX], ld[PL_EMAX];      // local source / target of the loader-order bonds
+  __shared__ short cs[PL_EMAX];                   // local source of the canonical-order bonds
+  __shared__ unsigned A[PL_NMAX], P[PL_NMAX];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0;
+  const int e0 = bond_ptr[b], m = bond_ptr[b + 1] - e0;
+  if (n > PL_NMAX || m > PL_EMAX) {       // unsupported molecule: flag it, leave its rows to the tail fill
+    if (tid == 0) { atomicExch(err, 1); ext_cnt[b] = 0; }
+    return;
+  }
+  for (int e = tid; e < n * K; e += 256) {
+    const int i = e / K, k = e - i * K;
+    atom_codes[(size_t)(a0 + i) * K + k] = x_raw[(size_t)(a0 + i) * K + k] + atom_off[k];
+  }
+  if (tid < n) { batch_i32[a0 + tid] = b; z_codes[a0 + tid] = x_raw[(size_t)(a0 + tid) * K]; A[tid] = 0u; }
+  for (int e = tid; e < m; e += 256) { ls[e] = (short)(bond_src[e0 + e] - a0); ld[e] = (short)(bond_dst[e0 + e] - a0); }
+  __syncthreads();
+  // canonical order: stable sort by target
+  for (int e = tid; e < m; e += 256) {
+    const int d = ld[e];
+    int r = 0;
+    for (int f = 0; f < m; ++f) r += (ld[f] < d) || (ld[f] == d && f < e);
+    const int k = e0 + r;
+    src[k] = a0 + ls[e];
+    dst[k] = a0 + d;
+    cs[r] = ls[e];
+    const int a = bond_attr[3 * (e0 + e)];
+    bond_codes[3 * k] = a + bond_off[0];
+    bond_codes[3 * k + 1] = bond_attr[3 * (e0 + e) + 1] + bond_off[1];
+    bond_codes[3 * k + 2] = bond_attr[3 * (e0 + e) + 2] + bond_off[2];
+    bond_type[k] = (float)a;
+    if (ls[e] >= 0 && ls[e] < n && d >= 0 && d < n) atomicOr(&A[ls[e]], 1u << d);
+  }
+  if (tid < n) {
+    int ct = 0, cs_ = 0;
+    for (int f = 0; f < m; ++f) { ct += ld[f] < tid; cs_ += ls[f] < tid; }
+    rowptr[a0 + tid] = e0 + ct;
+    rowptr_s[a0 + tid] = e0 + cs_;
+  }
+  __syncthreads();
+  // by-source view: slot -> canonical edge, stable in the canonical order
+  for (int r = tid; r < m; r += 256) {
+    const int s = cs[r];
+    int slot = 0;
+    for (int f = 0; f < m; ++f) slot += (cs[f] < s) || (cs[f] == s && f < r);
+    perm_s[e0 + slot] = e0 + r;
+  }
+  // extend_graph: two rounds of  A <- A | (A·A minus the diagonal)   (dataset_3D.py:12-35)
+  for (int round = 0; round < 2; ++round) {
+    if (tid < n) {
+      unsigned row = A[tid], acc = 0u;
+      while (row) { const int k = __ffs(row) - 1; row &= row - 1; acc |= A[k]; }
+      P[tid] = acc & ~(1u << tid);
+    }
+    __syncthreads();
+    if (tid < n) A[tid] |= P[tid];
+    __syncthreads();
+  }
+  if (tid < n) ext_rows[a0 + tid] = A[tid] & ~(1u << tid);       // "no self loops" (a diagonal can only come from A itself)
+  if (tid == 0) {
+    int c = 0;
+    for (int i = 0; i < n; ++i) c += __popc(A[i] & ~(1u << i));
+    ext_cnt[b] = c;
+  }
+}
+
+// extended edges (row = source r, col = target c, loader order = row major): CSR by target + by-source view
+__global__ void __launch_bounds__(64)
+plan_ext_kernel(const unsigned* __restrict__ ext_rows, const int* __restrict__ mol_ptr, const int* __restrict__ ext_ptr,
+                int* __restrict__ rowptr, int* __restrict__ src, int* __restrict__ dst, int* __restrict__ rowptr_s,
+                int* __restrict__ perm_s) {
+  __shared__ unsigned R[PL_NMAX], Cc[PL_NMAX];
+  __shared__ int rp[PL_NMAX + 1], rs[PL_NMAX + 1];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, x0 = ext_ptr[b];
+  if (n > PL_NMAX) return;
+  if (t < n) R[t] = ext_rows[a0 + t];
+  __syncthreads();
+  if (t < n) {
+    unsigned col = 0u;
+    for (int r = 0; r < n; ++r) col |= ((R[r] >> t) & 1u) << r;
+    Cc[t] = col;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int a = x0, s = x0;
+    for (int i = 0; i < n; ++i) { rp[i] = a; rs[i] = s; a += __popc(Cc[i]); s += __popc(R[i]); }
+    rp[n] = a; rs[n] = s;
+  }
+  __syncthreads();
+  if (t < n) {
+    rowptr[a0 + t] = rp[t];
+    rowptr_s[a0 + t] = rs[t];
+    unsigned col = Cc[t];
+    int k = rp[t];
+    while (col) { const int r = __ffs(col) - 1; col &= col - 1; src[k] = a0 + r; dst[k] = a0 + t; ++k; }
+    unsigned row = R[t];
+    int slot = rs[t];
+    while (row) {
+      const int c = __ffs(row) - 1; row &= row - 1;
+      perm_s[slot++] = rp[c] + __popc(Cc[c] & ((1u << t) - 1u));
+    }
+  }
+}
+
+// padded tails: atoms [N, N_cap) belong to the empty molecule B with code 0; row pointers past N hold the edge totals;
+// edge slots past the totals hold src = dst = -1, perm_s = own index
+__global__ void __launch_bounds__(256)
+plan_tail_kernel(const int* __restrict__ sizes, int B, int N_cap, int Eb_cap, int Ee_cap, int K, int* __restrict__ batch_i32,
+                 int* __restrict__ atom_codes, int* __restrict__ z_codes, int* __restrict__ b_rowptr, int* __restrict__ b_src,
+                 int* __restrict__ b_dst, int* __restrict__ b_rowptr_s, int* __restrict__ b_perm_s,
+                 int* __restrict__ bond_codes, float* __restrict__ bond_type, int* __restrict__ e_rowptr,
+                 int* __restrict__ e_src, int* __restrict__ e_dst, int* __restrict__ e_rowptr_s, int* __restrict__ e_perm_s) {
+  const int N = sizes[0], Eb = sizes[1], Ee = sizes[2];
+  const int g = blockIdx.x * 256 + threadIdx.x, G = gridDim.x * 256;
+  for (int i = N + g; i <= N_cap; i += G) {
+    b_rowptr[i] = Eb; b_rowptr_s[i] = Eb; e_rowptr[i] = Ee; e_rowptr_s[i] = Ee;
+    if (i < N_cap) {
+      batch_i32[i] = B;
+      z_codes[i] = 0;
+      for (int k = 0; k < K; ++k) atom_codes[(size_t)i * K + k] = 0;
+    }
+  }
+  for (int e = Eb + g; e < Eb_cap; e += G) {
+    b_src[e] = -1; b_dst[e] = -1; b_perm_s[e] = e; bond_type[e] = 0.f;
+    bond_codes[3 * e] = 0; bond_codes[3 * e + 1] = 0; bond_codes[3 * e + 2] = 0;
+  }
+  for (int e = Ee + g; e < Ee_cap; e += G) { e_src[e] = -1; e_dst[e] = -1; e_perm_s[e] = e; }
+}
+
+// per-table-row item lists of the embedding backward (plan.py::_row_lists): items = flat entries f = i*K + k of
+// codes [N][K] (N from the device), list of row r = items with code r in ascending f, stored as the atom index i.
+__global__ void __launch_bounds__(256)
+plan_lists_count_kernel(const int* __restrict__ codes, const int* __restrict__ n_dev, int K, int* __restrict__ cnt) {
+  __shared__ int red[4];
+  const int r = blockIdx.x, total = n_dev[0] * K;
+  int c = 0;
+  for (int f = threadIdx.x; f < total; f += 256) c += codes[f] == r;
+  c = (int)group_sum((float)c, 64);      // exact: counts < 2^24
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[r] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256)
+plan_lists_fill_kernel(const int* __restrict__ codes, const int* __restrict__ n_dev, int K, const int* __restrict__ ptr,
+                       int* __restrict__ items) {
+  __shared__ int wcnt[4];
+  __shared__ int base;
+  const int r = blockIdx.x, total = n_dev[0] * K;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = ptr[r];
+  __syncthreads();
+  for (int f0 = 0; f0 < total; f0 += 256) {
+    const int f = f0 + threadIdx.x;
+    const bool hit = f < total && codes[f] == r;
+    const unsigned long long mask = __ballot(hit);
+    if (lane == 0) wcnt[w] = __popcll(mask);
+    __syncthreads();
+    int off = base;
+    for (int k = 0; k < w; ++k) off += wcnt[k];
+    if (hit) items[off + __popcll(mask & ((1ull << lane) - 1ull))] = f / K;
+    __syncthreads();
+    if (threadIdx.x == 0) base += (wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]);
+    __syncthreads();
+  }
+}
+
+extern "C" int msde_plan_build(const int* x_raw, int K, const int* atom_off, const int* bond_src, const int* bond_dst,
+                               const int* bond_attr, const int* bond_off, const int* mol_atoms, const int* mol_bonds,
+                               int B, int N_cap, int Eb_cap, int Ee_cap, int max_nbr, int* mol_ptr, int* bond_ptr,
+                               int* pair_ptr, int* sizes, int* batch_i32, int* atom_codes, int* z_codes, int* b_rowptr,
+                               int* b_src, int* b_dst, int* b_rowptr_s, int* b_perm_s, int* bond_codes, float* bond_type,
+                               unsigned* ext_rows, int* ext_cnt, int* ext_ptr, int* e_rowptr, int* e_src, int* e_dst,
+                               int* e_rowptr_s, int* e_perm_s, int* err, void* stream) {
+  if (B <= 0 || B > 1024 || K <= 0 || N_cap <= 0 || !x_raw || !atom_off || !bond_src || !bond_dst || !bond_attr ||
+      !bond_off || !mol_atoms || !mol_bonds || !mol_ptr || !bond_ptr || !pair_ptr || !sizes || !batch_i32 || !atom_codes ||
+      !z_codes || !b_rowptr || !b_src || !b_dst || !b_rowptr_s || !b_perm_s || !bond_codes || !bond_type || !ext_rows ||
+      !ext_cnt || !ext_ptr || !e_rowptr || !e_src || !e_dst || !e_rowptr_s || !e_perm_s || !err)
+    return B > 1024 ? MSDE_EUNSUP : MSDE_EINVAL;
+  hipStream_t st = as_stream(stream);
+  MSDE_LAUNCH(plan_scan_kernel, dim3(1), dim3(1024), 0, st, mol_atoms, mol_bonds, B, max_nbr, mol_ptr, bond_ptr, pair_ptr,
+              sizes);
+  MSDE_CHECK_LAUNCH();
+  MSDE_LAUNCH(plan_molecule_kernel, dim3(B), dim3(256), 0, st, x_raw, K, atom_off, bond_src, bond_dst, bond_attr, bond_off,
+              (const int*)mol_ptr, (const int*)bond_ptr, batch_i32, atom_codes, z_codes, b_rowptr, b_src, b_dst, b_rowptr_s,
+              b_perm_s, bond_codes, bond_type, ext_rows, ext_cnt, err);
+  MSDE_CHECK_LAUNCH();
+  MSDE_LAUNCH(plan_scan_small_kernel, dim3(1), dim3(1024), 0, st, (const int*)ext_cnt, B, ext_ptr, sizes + 2);
+  MSDE_CHECK_LAUNCH();
+  MSDE_LAUNCH(plan_ext_kernel, dim3(B), dim3(64), 0, st, (const unsigned*)ext_rows, (const int*)mol_ptr,
+              (const int*)ext_ptr, e_rowptr, e_src, e_dst, e_rowptr_s, e_perm_s);
+  MSDE_CHECK_LAUNCH();
+  int tail = (N_cap + Eb_cap + Ee_cap + 255) / 256;
+  if (tail > 512) tail = 512;
+  MSDE_LAUNCH(plan_tail_kernel, dim3(tail), dim3(256), 0, st, (const int*)sizes, B, N_cap, Eb_cap, Ee_cap, K, batch_i32,
+              atom_codes, z_codes, b_rowptr, b_src, b_dst, b_rowptr_s, b_perm_s, bond_codes, bond_type, e_rowptr, e_src, e_dst,
+              e_rowptr_s, e_perm_s);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_plan_row_lists(const int* codes, const int* n_dev, int K, int R, int* cnt, int* list_ptr, int* items,
+                                   void* stream) {
+  if (K <= 0 || R <= 0 || R > 1024 || !codes || !n_dev || !cnt || !list_ptr || !items) return R > 1024 ? MSDE_EUNSUP : MSDE_EINVAL;
+  hipStream_t st = as_stream(stream);
+  MSDE_LAUNCH(plan_lists_count_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, cnt);
+  MSDE_CHECK_LAUNCH();
+  MSDE_LAUNCH(plan_scan_small_kernel, dim3(1), dim3(1024), 0, st, (const int*)cnt, R, list_ptr, (int*)nullptr);
+  MSDE_CHECK_LAUNCH();
+  MSDE_LAUNCH(plan_lists_fill_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, (const int*)list_ptr, items);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

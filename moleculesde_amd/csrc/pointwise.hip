@@ -130,7 +130,8 @@ ve_pos_loss_bwd_kernel(const float* __restrict__ scores, const float* __restrict
   int b = batch[i];
   float cnt = (float)(mol_ptr[b + 1] - mol_ptr[b]);
   float w = std ? powf(std[i], power) : 1.f;
-  float k = g_loss[0] * 2.f * w / (cnt * (float)B);
+  // padded atoms (molecule index B, an empty molecule: capacity buckets) take part in no loss: zero gradient
+  float k = (b < B && cnt > 0.f) ? g_loss[0] * 2.f * w / (cnt * (float)B) : 0.f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) g_scores[3 * i + c] = k * (scores[3 * i + c] - noise[3 * i + c]);
 }
@@ -172,7 +173,7 @@ extern "C" int msde_ve_perturb(const float* pos, const float* noise, const long 
 // index | 12 index bits, so keys are distinct).  The ranks of i.i.d. keys are a uniform random permutation.
 // Every workgroup keeps all keys in LDS and ranks 64 of them by counting (four lanes per key, broadcast LDS
 // reads): n^2 compares spread over n/64 workgroups -- one short launch instead of key generation + a multi-pass sort.
-#define RP_MAX 4096
+#define RP_MAX 8192
 #define RP_BLOCK 256    // 64 keys per workgroup (four lanes each): every workgroup regenerates all n keys, so fewer,
                         // larger workgroups keep that redundant hashing small
 __global__ void __launch_bounds__(RP_BLOCK)

@@ -258,6 +258,8 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
             if self.noise_mode != "discrete":
                 cfg.t_in = (noise.rand(B, device) * (1 - EPSILON) + EPSILON).float().contiguous()
         cfg.anneal = float(anneal_power)
+        # capacity buckets (moleculesde_amd.bucket): N_max of the loaded batch lives on the device
+        cfg.nmax_dev = getattr(dn, "nmax_dev", None) if reduce_mean else None
         if reduce_mean:
             cfg.scale_x, cfg.scale_adj = 1.0 / (B * Nm * self.num_class_X), 1.0 / (B * Nm * Nm)
         else:

@@ -38,6 +38,28 @@ def _i32(t):
 
 
 # ------------------------------------------------------------------------------------------------
+# row bounds (include/msde_hip.h: msde_set_row_bound)
+# ------------------------------------------------------------------------------------------------
+_BOUNDS = {}
+
+
+def set_row_bounds(bounds):
+    """bounds: {row capacity: int32 device tensor holding the valid row count}.  Replaces the current set.  Kernels
+    that reduce over rows of a tensor with exactly `capacity` rows then stop at the valid rows (moleculesde_amd.bucket)."""
+    clear_row_bounds()
+    for cap, t in bounds.items():
+        assert t.dtype == torch.int32 and t.is_cuda and t.numel() >= 1
+        _lib.call("msde_set_row_bound", int(cap), _p(t))
+        _BOUNDS[int(cap)] = t          # keeps the device scalar alive
+
+
+def clear_row_bounds():
+    if _BOUNDS:
+        _lib.call("msde_clear_row_bounds")
+        _BOUNDS.clear()
+
+
+# ------------------------------------------------------------------------------------------------
 # graph plans
 # ------------------------------------------------------------------------------------------------
 class CsrPlan:
@@ -1345,7 +1367,7 @@ def mul_add(a, b, c):
     return _MulAdd.apply(a, b, c)
 
 
-RANDPERM_MAX = 4096
+RANDPERM_MAX = 8192
 
 
 def randperm(n, device, seed, seed_dev=None, count=None):
