@@ -34,8 +34,9 @@ class Caps:
 
     def __init__(self, B, N, E_b, E_e, E_r, P, n_max):
         self.B, self.n_max = int(B), int(n_max)
-        vals = [_round_up(N, 256), _round_up(E_b, 512) + 8, _round_up(E_e, 2048) + 16, _round_up(E_r, 2048) + 24,
-                _round_up(P, 2048) + 40]
+        # fine granularity: every padded row is processed by the row-wise kernels, so padding costs time one for one
+        vals = [_round_up(N, 64), _round_up(E_b, 64) + 8, _round_up(E_e, 256) + 16, _round_up(E_r, 256) + 24,
+                _round_up(P, 256) + 40]
         assert len(set(vals)) == 5
         self.N, self.E_b, self.E_e, self.E_r, self.P = vals
 
@@ -155,6 +156,7 @@ class Bucket:
                   extended_edge_index=z64(2, 8), batch=z64(c.N))
         b.num_graphs = c.B
         b._msde_plan = pl
+        b._bucket = self
         self.batch = b
         from .geom3d import nn as _nn
         _nn.register_plan(b, pl)
@@ -181,7 +183,8 @@ class Bucket:
     def activate(self):
         """Declare the bucket's row bounds (process wide: one bucket is active at a time)."""
         c = self.caps
-        hip.set_row_bounds({c.N: self.sizes[0:1], c.E_b: self.sizes[1:2], c.E_e: self.sizes[2:3], c.P: self.sizes[3:4]})
+        hip.set_row_bounds({c.N: self.sizes[0:1], c.E_b: self.sizes[1:2], c.E_e: self.sizes[2:3], c.P: self.sizes[3:4]},
+                           owner=self)
 
     def check(self):
         """Host-side validation (synchronises): the loaded batch fitted the capacities."""

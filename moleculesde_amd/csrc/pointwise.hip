@@ -184,7 +184,7 @@ randperm_kernel(int n, const int* __restrict__ ndev, unsigned long long seed,
   n = msde_true_rows(n, ndev);          // permutation of the valid rows; entries past them map to themselves
   if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
   seed += 0xD1B54A32D192ED03ull * blockIdx.y;       // blockIdx.y: which of the `count` independent permutations
-  out += (size_t)blockIdx.y * n;
+  out += (size_t)blockIdx.y * ncap;
   for (int i = threadIdx.x; i < n; i += RP_BLOCK) {
     unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)i + 1ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

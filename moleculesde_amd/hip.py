@@ -41,9 +41,10 @@ def _i32(t):
 # row bounds (include/msde_hip.h: msde_set_row_bound)
 # ------------------------------------------------------------------------------------------------
 _BOUNDS = {}
+_BOUNDS_OWNER = None      # the bucket whose bounds are set (moleculesde_amd.bucket.Bucket.activate)
 
 
-def set_row_bounds(bounds):
+def set_row_bounds(bounds, owner=None):
     """bounds: {row capacity: int32 device tensor holding the valid row count}.  Replaces the current set.  Kernels
     that reduce over rows of a tensor with exactly `capacity` rows then stop at the valid rows (moleculesde_amd.bucket)."""
     clear_row_bounds()
@@ -51,9 +52,13 @@ def set_row_bounds(bounds):
         assert t.dtype == torch.int32 and t.is_cuda and t.numel() >= 1
         _lib.call("msde_set_row_bound", int(cap), _p(t))
         _BOUNDS[int(cap)] = t          # keeps the device scalar alive
+    global _BOUNDS_OWNER
+    _BOUNDS_OWNER = owner
 
 
 def clear_row_bounds():
+    global _BOUNDS_OWNER
+    _BOUNDS_OWNER = None
     if _BOUNDS:
         _lib.call("msde_clear_row_bounds")
         _BOUNDS.clear()

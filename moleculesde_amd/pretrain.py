@@ -331,7 +331,18 @@ class Trainer:
                 w.wait()                  # stream wait: the host does not block
             self.opt.step_bucket(i, grad_scale=scale)
 
+    def _sync_bounds(self, batch):
+        """Row bounds are process wide: a capacity-bucket batch needs its bucket's bounds, an exact-size batch none."""
+        from . import hip as _hip
+        bk = getattr(batch, "_bucket", None)
+        if bk is not None:
+            if _hip._BOUNDS_OWNER is not bk:
+                bk.activate()
+        elif _hip._BOUNDS:
+            _hip.clear_row_bounds()
+
     def step(self, batch):
+        self._sync_bounds(batch)
         self.step_counter.add_(1)         # the device step counter re-seeds dropout / negatives once a capture set it
         loss, parts = self.losses(batch)
         self.opt.zero_grad()
@@ -358,12 +369,14 @@ class Trainer:
         self._log_parts(parts)
         return loss.detach()
 
-    def capture(self, batch):
+    def capture(self, batch, pre=None):
         """Capture one step on `batch` (static shapes / addresses) into a hipGraph.  Call after at least
-        one eager step on a batch of the same shape (sizes workspaces, sets kernel attributes)."""
+        one eager step on a batch of the same shape (sizes workspaces, sets kernel attributes).  `pre`: launches
+        captured in front of the step (a bucket's device-side plan construction)."""
         key = id(batch)
         if key in self._graphs:
             return self._graphs[key][0]
+        self._sync_bounds(batch)
         with_adam = not self._use_dp() and not self.adam_outside_graph
         sd = self.step_counter.view(torch.int64)
         self.models["SDE_2Dto3D_model"].score_network.seed_dev = sd
@@ -379,6 +392,8 @@ class Trainer:
         # thread_local: other threads of the process (the RCCL watchdog under DP) may issue HIP calls
         # while this thread captures; they must not invalidate the capture
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+            if pre is not None:
+                pre()
             loss = self._graph_body(batch, with_adam)
         _hip.flush_table_uploads()      # the graph's pointer tables: uploaded once, not at every replay
         self.opt.use_eager_slot()
@@ -403,6 +418,29 @@ class Trainer:
                 self.opt.step()
         self.steps += 1
         return self._graph_loss[id(batch)]
+
+    # ---- capacity buckets: ONE captured graph for every batch (moleculesde_amd/bucket.py) ------------------------
+    def make_bucket(self, caps):
+        from .bucket import Bucket
+        return Bucket(caps, self.device)
+
+    def capture_bucket(self, bk, warm_blob, eager_steps=2):
+        """Warm up on one raw batch (sizes the workspaces), then capture {device-side plan construction + step} for
+        the bucket's capacities.  Afterwards every batch that fits the capacities is `step_bucket(bk, blob)`: one
+        copy of its raw blob + one graph replay, no per-batch host work."""
+        bk.activate()
+        bk.load(warm_blob)
+        bk.build_plan_on_device()
+        ok, sizes = bk.check()
+        if not ok:
+            raise RuntimeError(f"batch does not fit the bucket: {sizes} vs {bk.caps.as_dict()}")
+        for _ in range(eager_steps):
+            self.step(bk.batch)
+        return self.capture(bk.batch, pre=bk.build_plan_on_device)
+
+    def step_bucket(self, bk, blob):
+        bk.load(blob)
+        return self.step_graph(bk.batch)
 
     def state_dicts(self):
         """Checkpoint dictionary of pretrain_MoleculeSDE.py:78-88."""

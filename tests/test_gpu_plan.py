@@ -184,3 +184,86 @@ def test_bucket_step_matches_exact_batch(dev, full):
         for n, v in m.state_dict().items():
             if "running_" in n:
                 assert_close(sd_b[k][n], v, 1e-5, 1e-6, f"{k}.{n}")
+
+
+def test_one_graph_serves_different_batches(dev):
+    """ONE captured hipGraph (device-side plan construction + forward + backward + Adam) replayed on three DIFFERENT
+    batches, each compared with the eager step on the exact-size batch from the same parameters / optimiser state /
+    random streams: same loss terms, same updated parameters."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import bucket as BK, hip, pretrain
+    from moleculesde_amd.synthetic import make_batch
+    args = pretrain.readme_args(emb_dim=64)
+    torch.manual_seed(31)
+    tr = pretrain.Trainer(args, dev)
+    tr.overlap_streams = False
+    for m in tr.models.values():
+        disable_dropout(m)
+
+    class Noise(G.DeviceNoise):
+        """Position noise / time steps from fixed device tensors (padding independent, capturable); the contrastive
+        permutation and the dense-head noise stay on the device generators (functions of seed, counter, index)."""
+
+        def __init__(self):
+            super().__init__(seed=77)
+            g = torch.Generator().manual_seed(5)
+            self.big = torch.randn(8192, 3, generator=g).to(dev)
+            self.ints = torch.randint(0, 1000, (4096,), generator=g).to(dev)
+
+        def randn_like(self, x):
+            assert x.dim() == 2 and x.size(1) == 3
+            return self.big[:x.size(0)].clone()
+
+        def randint(self, high, size, device):
+            return self.ints[:size[0]].clone()
+    noise = Noise()
+    # the dense head must see a DeviceNoise (in-kernel draws), the 2D->3D model the fixed tensors
+    tr.noise = noise
+    tr.models["SDE_2Dto3D_model"].noise = noise
+    head_noise = G.DeviceNoise(seed=99)
+    tr.models["SDE_3Dto2D_model"].noise = head_noise
+
+    cpu = [make_batch(40, seed=s) for s in (51, 52, 53)]
+    needs = [BK.raw_sizes(b) for b in cpu]
+    caps = BK.Caps.covering(needs, n_max=24)
+    bk = tr.make_bucket(caps)
+    blobs = [BK.pack_raw(b, caps).to(dev) for b in cpu]
+    tr.capture_bucket(bk, blobs[0])
+    snap = lambda: (tr.opt.flat_p.clone(), tr.opt.m.clone(), tr.opt.v.clone(), tr.opt.step_dev.clone(),
+                    tr.step_counter.clone(), {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in tr.models.items()})
+
+    def restore(s):
+        tr.opt.flat_p.copy_(s[0]); tr.opt.m.copy_(s[1]); tr.opt.v.copy_(s[2]); tr.opt.step_dev.copy_(s[3])
+        tr.step_counter.copy_(s[4])
+        for k, m in tr.models.items():
+            m.load_state_dict(s[5][k])
+    calls = (noise.calls, head_noise.calls)
+    for i in (1, 2, 0, 1):
+        s0 = snap()
+        for k in tr.log:
+            tr.log[k].zero_()
+        tr.step_bucket(bk, blobs[i])
+        torch.cuda.synchronize()
+        ok, sizes = bk.check()
+        assert ok and sizes["N"] == needs[i]["N"] and sizes["E_e"] == needs[i]["E_e"], sizes
+        got_log = {k: float(v) for k, v in tr.log.items()}
+        got_p = tr.opt.flat_p.clone()
+        restore(s0)
+        # eager step on the exact-size batch with the host plan; host-side draw counters as they were at capture time
+        noise.calls, head_noise.calls = calls[0] - 1, calls[1] - 1
+        for k in tr.log:
+            tr.log[k].zero_()
+        exact = G.prepare_batch(cpu[i].clone(), dev)
+        tr.step(exact)
+        torch.cuda.synchronize()
+        for k in got_log:
+            ref = float(tr.log[k])
+            assert abs(got_log[k] - ref) <= 5e-5 * abs(ref) + 1e-7, (i, k, got_log[k], ref)
+        # the two parameter UPDATES point the same way.  (Adam turns every gradient into a step of ~lr: parameters whose
+        # gradient is pure rounding noise -- biases in front of a BatchNorm, key biases under a softmax -- move by +-lr
+        # with a sign that depends on the summation order, so the comparison is a cosine, not an element-wise one; the
+        # gradients themselves are compared element-wise in test_bucket_step_matches_exact_batch.)
+        ua, ub = (got_p - s0[0]).double(), (tr.opt.flat_p - s0[0]).double()
+        cos = float((ua * ub).sum() / (ua.norm() * ub.norm()))
+        assert cos > 0.995, (i, cos)
+        hip.clear_row_bounds()
