@@ -117,12 +117,14 @@ gemm_ex_kernel(const msde_gemm_desc d) {
   const int nt1 = (K1 + GX_BK - 1) / GX_BK, nt2 = (K2 + GX_BK - 1) / GX_BK;
   const int ntiles = nt1 + nt2;
 
-  // staging: A tile BM x 32 = BM*8 float4 -> 2*TM per thread; B tile 64 x 32 (or 32 x 64) = 512 float4 -> 2
+  // staging registers: A tile BM x 32 = BM*8 float4 -> 2*TM per thread; B tile 64 x 32 (or 32 x 64) = 512 float4 -> 2.
+  // TWO register stages: the global loads of tile t+2 are issued while tile t is multiplied, so a load has two K
+  // tiles (~2 x 1024 MFMA cycles) to land -- one is not enough at one workgroup per CU (L2 round trip ~ 1 us under load).
   constexpr int NA = 2 * TM, NB = 2;
-  float4 ra[NA], rb[NB];
-  int ka[NA], kb_[NB];
+  float4 ra[2][NA], rb[2][NB];
+  int ka[2][NA], kb_[2][NB];
 
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t, float4 (&xa)[NA], float4 (&xb)[NB], int (&ma)[NA], int (&mb)[NB]) {
     const bool s2 = t >= nt1;
     const float* __restrict__ A = s2 ? A2 : A1;
     const float* __restrict__ B = s2 ? B2 : B1;
@@ -132,7 +134,7 @@ gemm_ex_kernel(const msde_gemm_desc d) {
     for (int p = 0; p < NA; ++p) {
       const int idx = p * 256 + tid, r = idx >> 3, kq = (idx & 7) * 4;
       const int gm = min(m0 + r, d.M - 1);                 // rows past M repeat the last row: never stored
-      ra[p] = gx_ld4<VEC>(A + (size_t)gm * lda, k0 + kq, K, ka[p]);
+      xa[p] = gx_ld4<VEC>(A + (size_t)gm * lda, k0 + kq, K, ma[p]);
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
@@ -145,35 +147,34 @@ gemm_ex_kernel(const msde_gemm_desc d) {
           // [C][F][16] weights of the per-channel GCNs read as one [F][16 C] operand)
           const int kk = k0 + kq, q = kk >> d.b_kblk_log2, rem = kk & ((1 << d.b_kblk_log2) - 1);
           int keep;
-          float4 v = gx_ld4<VEC>(B + (size_t)q * d.b_kblk_stride + (size_t)gn * ldb, kk < K ? rem : 0, 1 << d.b_kblk_log2, keep);
-          kb_[p] = kk < K ? keep : 0;
-          rb[p] = v;
+          xb[p] = gx_ld4<VEC>(B + (size_t)q * d.b_kblk_stride + (size_t)gn * ldb, kk < K ? rem : 0, 1 << d.b_kblk_log2, keep);
+          mb[p] = kk < K ? keep : 0;
         } else {
-          rb[p] = gx_ld4<VEC>(B + (size_t)gn * ldb, k0 + kq, K, kb_[p]);
+          xb[p] = gx_ld4<VEC>(B + (size_t)gn * ldb, k0 + kq, K, mb[p]);
         }
       } else {                                              // B[k][n]: 16 float4 per k row
         const int kr = idx >> 4, nq = (idx & 15) * 4;
         const int gk = min(k0 + kr, K - 1);
-        rb[p] = gx_ld4<VEC>(B + (size_t)gk * ldb, n0 + nq, d.N, kb_[p]);
-        if (k0 + kr >= K) kb_[p] = 0;
+        xb[p] = gx_ld4<VEC>(B + (size_t)gk * ldb, n0 + nq, d.N, mb[p]);
+        if (k0 + kr >= K) mb[p] = 0;
       }
     }
   };
-  auto store_tile = [&](int s) {
+  auto store_tile = [&](int s, const float4 (&xa)[NA], const float4 (&xb)[NB], const int (&ma)[NA], const int (&mb)[NB]) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       const int idx = p * 256 + tid, r = idx >> 3, kq = (idx & 7) * 4;
-      *reinterpret_cast<float4*>(&As[s][r * GX_LDK + kq]) = gx_mask4(ra[p], ka[p]);
+      *reinterpret_cast<float4*>(&As[s][r * GX_LDK + kq]) = gx_mask4(xa[p], ma[p]);
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = p * 256 + tid;
       if (!B_KM) {
         const int r = idx >> 3, kq = (idx & 7) * 4;
-        *reinterpret_cast<float4*>(&Bs[s][r * GX_LDK + kq]) = gx_mask4(rb[p], kb_[p]);
+        *reinterpret_cast<float4*>(&Bs[s][r * GX_LDK + kq]) = gx_mask4(xb[p], mb[p]);
       } else {
         const int kr = idx >> 4, nq = (idx & 15) * 4;
-        *reinterpret_cast<float4*>(&Bs[s][kr * GX_LDN + nq]) = gx_mask4(rb[p], kb_[p]);
+        *reinterpret_cast<float4*>(&Bs[s][kr * GX_LDN + nq]) = gx_mask4(xb[p], mb[p]);
       }
     }
   };
@@ -212,15 +213,23 @@ gemm_ex_kernel(const msde_gemm_desc d) {
   };
 
   if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
+    load_tile(0, ra[0], rb[0], ka[0], kb_[0]);
+    if (ntiles > 1) load_tile(1, ra[1], rb[1], ka[1], kb_[1]);
+    store_tile(0, ra[0], rb[0], ka[0], kb_[0]);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-      const bool more = t + 1 < ntiles;
-      if (more) load_tile(t + 1);          // in flight during the MFMAs below
-      compute_tile(t & 1);
-      if (more) store_tile((t + 1) & 1);   // stage (t+1)&1 was last read in iteration t-1: everyone is past it
+    // iteration t: register stage t&1 (tile t, already in LDS) is refilled with tile t+2; tile t is multiplied; tile
+    // t+1 (register stage (t+1)&1, requested one iteration ago) moves to LDS stage (t+1)&1, last read in iteration t-1
+    for (int t = 0; t < ntiles; t += 2) {
+      if (t + 2 < ntiles) load_tile(t + 2, ra[0], rb[0], ka[0], kb_[0]);
+      compute_tile(0);
+      if (t + 1 < ntiles) store_tile(1, ra[1], rb[1], ka[1], kb_[1]);
       __syncthreads();
+      if (t + 1 < ntiles) {
+        if (t + 3 < ntiles) load_tile(t + 3, ra[1], rb[1], ka[1], kb_[1]);
+        compute_tile(1);
+        if (t + 2 < ntiles) store_tile(0, ra[0], rb[0], ka[0], kb_[0]);
+        __syncthreads();
+      }
     }
   }
 

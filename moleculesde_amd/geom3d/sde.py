@@ -72,3 +72,15 @@ class VPSDE:
         alpha = self.alphas.to(x.device)[timestep]
         f = torch.sqrt(alpha).view([-1] + [1] * (x.dim() - 1)) * x - x
         return f, torch.sqrt(beta)
+
+    def reverse_discretize(self, score_model, x, representation, data, t, probability_flow=False):
+        """RSDE.discretize (SDE_sparse.py:94-100) on the DDPM discretisation above."""
+        f, G = self.discretize(x, t)
+        score = score_model.get_score(representation, data, x, None, t)
+        rev_f = f - G[:, None] ** 2 * score * (0.5 if probability_flow else 1.0)
+        return rev_f, (torch.zeros_like(G) if probability_flow else G)
+
+    def corrector_alpha(self, t):
+        """alpha of the Langevin corrector for VP SDEs (pretrain_MoleculeSDE_inference_2D_to_3D_VE_VP.py:198-200)."""
+        timestep = (t * (self.N - 1) / self.T).long()
+        return self.alphas.to(t.device)[timestep]

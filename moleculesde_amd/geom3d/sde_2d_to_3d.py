@@ -189,9 +189,11 @@ class SDEModel2Dto3D_02(nn.Module):
 
     def _geometry_branch(self, pos_perturbed, ep):
         """Everything that depends on coordinates only (frame, Fourier features, their MLPs)."""
+        has_dist = hasattr(self, "input_mlp")
         feat_d, feat_i, feat_j, angle, basis = hip.edge_geometry(
-            pos_perturbed, ep, self.dist_gaussian_fourier.W, self.coff_gaussian_fourier.W)
-        edge_attr_3D_invariant = self.input_mlp(feat_d)
+            pos_perturbed, ep, (self.dist_gaussian_fourier if has_dist else self.coff_gaussian_fourier).W,
+            self.coff_gaussian_fourier.W)
+        edge_attr_3D_invariant = self.input_mlp(feat_d) if has_dist else None
         embed_i = self.coff_mlp(feat_i)
         embed_j = self.coff_mlp(feat_j)
         edge_attr_3D_frame_invariant = self.project(torch.cat([angle, embed_i, embed_j], dim=-1))
@@ -249,8 +251,12 @@ class SDEModel2Dto3D_02(nn.Module):
             main = torch.cuda.current_stream()
             main.wait_stream(side)
             for t in (edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis):
-                t.record_stream(main)
-        edge_attr = hip.mul_add(edge_attr_3D_invariant, edge_attr_2D, edge_attr_3D_frame_invariant)
+                if t is not None:
+                    t.record_stream(main)
+        if edge_attr_3D_invariant is None:         # SDEModel2Dto3D_01: no distance branch (:181)
+            edge_attr = edge_attr_2D + edge_attr_3D_frame_invariant
+        else:
+            edge_attr = hip.mul_add(edge_attr_3D_invariant, edge_attr_2D, edge_attr_3D_frame_invariant)
         node_attr = self.node_emb(node_2D_repr)
         return node_attr, edge_attr, basis
 
@@ -273,3 +279,15 @@ class SDEModel2Dto3D_02(nn.Module):
         output = self.score_network(ep, node_attr, edge_attr, basis)["gradient"]
         _, std_pos = self.sde_pos.marGINal_prob(pos_perturbed, t_pos)
         return -output / std_pos[:, None]
+
+
+
+class SDEModel2Dto3D_01(SDEModel2Dto3D_02):
+    """SDE_model_2D_to_3D.py:69-249: `_02` without the distance branch (no `dist_gaussian_fourier` / `input_mlp`,
+    edge_attr = edge_attr_2D + edge_attr_3D_frame_invariant, :181).  Same kernels; state-dict keys and order as the
+    reference's class.  Several published checkpoints use it (README_checkpoints.md)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        del self.dist_gaussian_fourier
+        del self.input_mlp

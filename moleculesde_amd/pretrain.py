@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import dp
-from .geom3d import GNN, SchNet, SDEModel2Dto3D_02, prepare_batch
+from .geom3d import GNN, SchNet, SDEModel2Dto3D_01, SDEModel2Dto3D_02, prepare_batch
 from .geom3d import nn as _nn
 from .optim import FlatAdam
 
@@ -105,10 +105,11 @@ def build_models(args, device):
                                 num_interactions=args.SchNet_num_interactions,
                                 num_gaussians=args.SchNet_num_gaussians, cutoff=args.SchNet_cutoff,
                                 readout=args.SchNet_readout, node_class=node_class).to(device)
-    if args.SDE_2Dto3D_model != "SDEModel2Dto3D_02":
+    cls23 = {"SDEModel2Dto3D_01": SDEModel2Dto3D_01, "SDEModel2Dto3D_02": SDEModel2Dto3D_02}.get(args.SDE_2Dto3D_model)
+    if cls23 is None:
         raise NotImplementedError(args.SDE_2Dto3D_model)
     sde_type, bmin, bmax = _SDE_RANGES_2D3D[args.SDE_type_2Dto3D]
-    models["SDE_2Dto3D_model"] = SDEModel2Dto3D_02(
+    models["SDE_2Dto3D_model"] = cls23(
         emb_dim=args.emb_dim, hidden_dim=32, beta_min=bmin, beta_max=bmax, num_diffusion_timesteps=1000,
         beta_schedule=None, SDE_type=sde_type, use_extend_graph=args.use_extend_graph).to(device)
     if args.SDE_coeff_generative_3Dto2D > 0:

@@ -15,10 +15,10 @@ def predictor_update(sde, score_model, representation, data, pos, t, noise=None)
 
 
 def corrector_update(sde, score_model, representation, data, pos, t, snr, scale_eps, n_steps, noises=None):
-    """LangevinCorrector.update_fn (:191-212), VE branch (alpha = 1).  As in the script, the inner
+    """LangevinCorrector.update_fn (:191-212): alpha = 1 for the VE SDE, alphas[timestep] for VP.  As in the script, the inner
     iterations do not feed `pos` back (App. B.2), so the score is evaluated once per call when
     n_steps == 1 and only the last pass matters otherwise."""
-    alpha = torch.ones_like(t)
+    alpha = sde.corrector_alpha(t) if hasattr(sde, "corrector_alpha") else torch.ones_like(t)     # VP: :198-200
     x = x_mean = pos
     for i in range(n_steps):
         grad = score_model.get_score(representation, data, pos, None, t)

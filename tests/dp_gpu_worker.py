@@ -132,4 +132,5 @@ for use_graph in (False, True):
 
 dp.barrier()
 dist.destroy_process_group()
-print("OK", rank)
+sys.stdout.write(f"RANK{rank}DONE\n")       # ONE write: the two ranks share a pipe, separate writes interleave
+sys.stdout.flush()

@@ -20,4 +20,4 @@ def test_trainer_step_two_ranks_one_gpu(mode):
            os.path.join(ROOT, "tests", "dp_gpu_worker.py"), ROOT] + (["full"] if mode == "full" else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
-    assert r.stdout.count("OK 0") == 1 and r.stdout.count("OK 1") == 1
+    assert r.stdout.count("RANK0DONE") == 1 and r.stdout.count("RANK1DONE") == 1, r.stdout[-2000:]

@@ -831,3 +831,38 @@ def test_dense_head_launches_no_torch_operator(dev):
     foreign = [n for n in foreign if "CatArrayBatchedCopy" not in n and "FillFunctor" not in n and "Memcpy" not in n
                and "Memset" not in n]
     assert not foreign, sorted(set(foreign))
+
+
+# ------------------------------------------------------------------ §8 f3: _01 and the VP SDE on the HIP path ---
+@pytest.mark.parametrize("tag", ["m01", "vp"])
+def test_golden_f3_variants_2d3d(dev, tag):
+    """SDEModel2Dto3D_01 (VE) and SDEModel2Dto3D_02 with the VP SDE on the HIP kernels against the fixture produced by
+    the reference's own files (tests/golden/f3_variants.npz): loss, gradients, get_score, VP predictor steps."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import sampler
+    g = load_golden("f3_variants.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    cls, sde_type = (G.SDEModel2Dto3D_01, "VE") if tag == "m01" else (G.SDEModel2Dto3D_02, "VP")
+    m = disable_dropout(cls(emb_dim=16, hidden_dim=32, beta_schedule=None, beta_min=0.2, beta_max=1.0,
+                            num_diffusion_timesteps=1000, SDE_type=sde_type, use_extend_graph=True))
+    assert list(m.state_dict().keys()) == list(sub(g, f"{tag}.sd.").keys())
+    m.load_state_dict(sub(g, f"{tag}.sd."))
+    m.to(dev).train()
+    m.noise = G.CpuReplayNoise(int(g[f"{tag}.seed"]))
+    h2 = torch.from_numpy(g["h2"]).to(dev).requires_grad_(True)
+    loss = m(h2, b, anneal_power=0)["position"]
+    assert_close(loss, g[f"{tag}.loss"], 1e-4, 1e-6, "loss")
+    loss.backward()
+    assert_close(h2.grad, g[f"{tag}.grad_h2"], 1e-3, 1e-4 * float(np.abs(g[f"{tag}.grad_h2"]).max()), "grad h2")
+    _grads_close(m, sub(g, f"{tag}.grad."), 1e-3, 2e-4, tag)
+    m.eval()
+    pos, t = torch.from_numpy(g[f"{tag}.score_pos"]).to(dev), torch.from_numpy(g[f"{tag}.score_t"]).to(dev)
+    sc = m.get_score(h2.detach(), b, pos, None, t)
+    assert_close(sc, g[f"{tag}.score"], 1e-3, 1e-4 * float(np.abs(g[f"{tag}.score"]).max()), "get_score")
+    if tag == "vp":
+        x = pos.clone()
+        for i, tv in enumerate(g["vp.pred_ts"]):
+            vt = torch.full((x.size(0),), float(tv), device=dev)
+            x, _ = sampler.predictor_update(m.sde_pos, m, h2.detach(), b, x, vt,
+                                            noise=torch.from_numpy(g["vp.pred_noise"][i]).to(dev))
+            assert_close(x, g["vp.pred_traj"][i], 1e-3, 1e-4, f"VP predictor step {i}")

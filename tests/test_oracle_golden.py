@@ -199,3 +199,32 @@ def test_inventory_readme_configuration():
         assert tr == inv[k]["trainable"], k
         total += tr
     assert total == 4668227
+
+
+@pytest.mark.parametrize("tag", ["m01", "vp"])
+def test_f3_variants_2d3d(tag):
+    """SDEModel2Dto3D_01 (VE) and SDEModel2Dto3D_02 with the VP SDE, fixture from the reference's own
+    files (oracle/make_golden_f3.py): loss, gradients, get_score, and (VP) three reverse-diffusion predictor steps."""
+    g = load_golden("f3_variants.npz")
+    b = batch_from(g)
+    cls, sde_type = (R.SDEModel2Dto3D_01, "VE") if tag == "m01" else (R.SDEModel2Dto3D_02, "VP")
+    m = disable_dropout(cls(emb_dim=16, hidden_dim=32, beta_schedule=None, beta_min=0.2, beta_max=1.0,
+                            num_diffusion_timesteps=1000, SDE_type=sde_type, use_extend_graph=True))
+    m.load_state_dict(sub(g, f"{tag}.sd."))
+    h2 = torch.from_numpy(g["h2"]).requires_grad_(True)
+    torch.manual_seed(int(g[f"{tag}.seed"]))
+    loss = m(h2, b.clone(), anneal_power=0)["position"]
+    assert_close(loss, g[f"{tag}.loss"], 1e-5, 1e-6, "loss")
+    loss.backward()
+    assert_close(h2.grad, g[f"{tag}.grad_h2"], 1e-4, 1e-6, "grad h2")
+    grads_close(m, sub(g, f"{tag}.grad."), 1e-4, 1e-5, tag)
+    m.eval()
+    pos, t = torch.from_numpy(g[f"{tag}.score_pos"]), torch.from_numpy(g[f"{tag}.score_t"])
+    assert_close(m.get_score(h2.detach(), b.clone(), pos, None, t), g[f"{tag}.score"], 1e-4, 1e-5, "get_score")
+    if tag == "vp":
+        x = pos.clone()
+        for i, tv in enumerate(g["vp.pred_ts"]):
+            vt = torch.full((x.size(0),), float(tv))
+            f, G = m.sde_pos.reverse_discretize(m, x, h2.detach(), b.clone(), vt)
+            x = (x - f) + G[:, None] * torch.from_numpy(g["vp.pred_noise"][i])
+            assert_close(x, g["vp.pred_traj"][i], 1e-4, 1e-5, f"VP predictor step {i}")
