@@ -52,18 +52,24 @@ def _radius(trainer, batch):
     return sch, rplan, dist, int(rplan.rowptr[-1]), batch.x.size(0)
 
 
-def _pmc_traffic(kernel, E, N):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json),
-    valid only for the batch shape they were collected on."""
+def _pmc_traffic(kernel, E, N, wgs=None):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_counters.json: separate
+    FETCH_SIZE / WRITE_SIZE passes of tools/prof_kernels.py, corrected as MI355X_MICROARCH.md prescribes), valid only for
+    the batch shape they were collected on; `wgs` selects the launch width (grid = workgroups x 256 threads)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_counters.json")) as f:
             d = json.load(f)
-        ent = d.get(kernel)
-        if ent and d.get("shape", {}).get("E_r") == E and d.get("shape", {}).get("N") == N:
-            return ent["traffic_bytes"]
+        if d.get("shape", {}).get("E_r") != E or d.get("shape", {}).get("N") != N:
+            return None
+        cands = {k: v for k, v in d.items() if k.startswith(kernel + "[grid=") and "traffic_bytes" in v}
+        if not cands:
+            return None
+        if wgs:
+            key = f"{kernel}[grid={int(wgs) * 256}]"
+            return cands[key]["traffic_bytes"] if key in cands else None
+        return cands[max(cands, key=lambda k: int(k.split("=")[1].rstrip("]")))]["traffic_bytes"]
     except Exception:
-        pass
-    return None
+        return None
 
 
 def _step_widths(trainer):
@@ -105,7 +111,7 @@ def roofline_fused_fwd(trainer, batch, iters=50, wgs=None):
     tf = flops / (ms * 1e-3) / 1e12
     return {"kernel": "cfconv_fused_fwd_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF,
             "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-            "traffic": _pmc_traffic("cfconv_fused_fwd_kernel", E, N), "flops_per_launch": flops,
+            "traffic": _pmc_traffic("cfconv_fused_fwd_kernel", E, N, wgs), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": nbytes, "hbm_frac_at_this_time": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N,
             "workgroups": "full width" if wgs is None else int(wgs)}
@@ -137,7 +143,7 @@ def roofline_fused_bwd(trainer, batch, iters=30, wgs=None):
     tf = flops / (ms * 1e-3) / 1e12
     return {"kernel": "cfconv_fused_bwd_w_kernel (+ slab reduce)", "bound": "mfma", "achieved": round(tf, 2),
             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-            "traffic": _pmc_traffic("cfconv_fused_bwd_w_kernel", E, N), "flops_per_launch": flops,
+            "traffic": _pmc_traffic("cfconv_fused_bwd_w_kernel", E, N, wgs), "flops_per_launch": flops,
             "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N,
             "workgroups": "full width" if wgs is None else int(wgs)}
 
@@ -242,27 +248,37 @@ def roofline_forward(trainer, batch, stats, iters=30):
             "us_at_fp32_peak": round(flops / (FP32_MFMA_PEAK_TF * 1e12) * 1e6, 1)}
 
 
-def roofline_dense_head_gemm(batch, iters=30):
-    """Dense node-adjacency score head (SDEModel3Dto2D_node_adj_dense, --full): its largest product is the node
-    head's Linear(728, 728) over the B*N_max padded atom slots.  Timed: the hand-written fp32-MFMA GEMM
-    (msde_linear_fwd, csrc/linear.hip) on that shape, against the fp32 matrix-core peak."""
-    from moleculesde_amd import hip, _lib
+def roofline_dense_head_node_mlp(batch, iters=20):
+    """MFMA utilisation of the dense head's node MLP (NodeScoreNetwork_dense.final: 364 -> 728 -> 728 -> 119 with SiLU,
+    invariant_scorenetwork_dense.py:126-127; 2/3 of the head's FLOPs) as the product runs it: three msde_gemm_ex launches
+    (csrc/gemm_ex.hip, bias + SiLU + pre-activation store fused) over the VALID atoms only (no padding to B*N_max).
+    FLOPs = 2 * N * (364*728 + 728*728 + 728*119); timed as a captured hipGraph of the three launches."""
+    from moleculesde_amd import hip
     dev = batch.x.device
-    pl = getattr(batch, "_msde_plan", None)
-    M = int(pl.B * pl.N_max) if pl is not None else 5120
-    N = K = 728
+    N = int(batch.x.size(0))
     with torch.no_grad():
-        x = torch.randn(M, K, device=dev)
-        w = torch.randn(N, K, device=dev)
-        b = torch.randn(N, device=dev)
-        y = torch.empty(M, N, device=dev)
-        p, st = hip._p, hip._stream()
-        fn = lambda: _lib.call("msde_linear_fwd", p(x), p(w), p(b), M, N, K, p(y), st)
-        ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
-    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    return {"kernel": "gemm_f32_mfma_kernel (Linear 728x728 of the dense head)", "bound": "mfma", "achieved": round(tf, 2),
-            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-            "avg_launch_us": round(ms * 1e3, 2), "shape": [M, N, K]}
+        X = torch.randn(N, 364, device=dev)
+        W = [torch.randn(728, 364, device=dev) / 19, torch.randn(728, 728, device=dev) / 27, torch.randn(119, 728, device=dev) / 27]
+        b = [torch.randn(728, device=dev), torch.randn(728, device=dev), torch.randn(119, device=dev)]
+        Z1, F1, Z2, F2 = (torch.empty(N, 728, device=dev) for _ in range(4))
+        OUT = torch.empty(N, 120, device=dev)
+
+        def chain():
+            hip.gemm_ex(X, W[0], F1, bias=b[0], act="silu", Z=Z1)
+            hip.gemm_ex(F1, W[1], F2, bias=b[1], act="silu", Z=Z2)
+            hip.gemm_ex(F2, W[2], OUT[:, :119], bias=b[2])
+        for _ in range(3):
+            chain()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            chain()
+        ms = _event_time_ms(g.replay, iters, torch.cuda.current_stream())
+    flops = 2.0 * N * (364 * 728 + 728 * 728 + 728 * 119)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_ex_kernel x3 (node MLP 364->728->728->119 of the dense head, valid atoms only)", "bound": "mfma",
+            "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+            "us_per_chain": round(ms * 1e3, 2), "rows": N, "flops": flops}
 
 
 def _host_cores():
@@ -474,7 +490,7 @@ def main():
         roof_fwd = roofline_fused_fwd(trainer, pool[0], wgs=wf)
         roof_fwd["standalone_full_width"] = roofline_fused_fwd(trainer, pool[0]) if wf else None
         roof_agg = roofline_hbm_kernel(trainer, pool[0])
-        roof_head = roofline_dense_head_gemm(pool[0])
+        roof_head = roofline_dense_head_node_mlp(pool[0])
         roof_forward = roofline_forward(trainer, pool[0], stats)
         out = {
             "metric": "molecules/sec pretrain step (SchNet+SDE VE, bs256)",
@@ -493,7 +509,7 @@ def main():
             "roofline_cfconv_fused_fwd": roof_fwd,
             "roofline_hbm_message_passing": roof_agg,
             "roofline_forward_schnet_sde2d3d": roof_forward,
-            "roofline_dense_head_gemm": roof_head,
+            "roofline_dense_head_node_mlp": roof_head,
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch_size)

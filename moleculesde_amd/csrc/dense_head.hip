@@ -28,7 +28,9 @@
 #define DH_AC MSDE_DENSE_AC_LD     // 32: row stride of the pair channel buffer (30 channels used)
 #define DH_XP MSDE_DENSE_XP_LD     // 120: row stride of the atom-class buffers (119 classes)
 
-__device__ __forceinline__ float dh_elu(float z) { return z > 0.f ? z : expm1f(z); }
+// fast forms (v_exp_f32 / v_rcp_f32): absolute error ~1e-7, far inside the parity tolerance
+__device__ __forceinline__ float dh_elu(float z) { return z > 0.f ? z : __expf(z) - 1.f; }
+__device__ __forceinline__ float dh_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 __device__ __forceinline__ float dh_delu_y(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
 __device__ __forceinline__ float dh_randn(unsigned long long seed, unsigned long long idx) {
@@ -166,14 +168,16 @@ extern "C" int msde_dense_prepare(const int* rowptr, const int* src, const float
 
 // ================================================================================================ edge layer
 // LDS map (floats), C input channels, n atoms (row strides odd -> conflict-free for "lane = pair" access):
-//   Qs, Ks  [n][32C+1]      func_q / func_k outputs
+//   Wk      weights (first: 16-B aligned for float4 broadcast reads)
+//   Qs, Ks  [n][32C+4]      func_q / func_k outputs (rows 16-B aligned; consecutive rows start 4 banks apart, so the
+//                           float4 reads of 16 consecutive atoms cover all 64 banks)
 //   Ad      [n*n][C+1]      input adjacency channels (backward: later overwritten by dL/dA)
 //   Xv      [n][16C+1]      x W_c (forward) -> after the GCN: V = xcat
 //   Wk      weights: pair MLP (W0 [16][2C], b0, W1 [16][16], b1, W2 [CO][16], b2), channel MLP (W0 [16][16C], b0,
 //           W1 [16][16], b1), bv [16C]
 template <int C, int CO>
 struct EdgeLds {
-  static constexpr int LQ = 32 * C + 1, LA = C + 1, LV = 16 * C + 1;
+  static constexpr int LQ = 32 * C + 4, LA = C + 1, LV = 16 * C + 1;   // LQ: 16-B rows, bank offset 4 per row
   static constexpr int W_M0 = 0, B_M0 = W_M0 + 16 * 2 * C, W_M1 = B_M0 + 16, B_M1 = W_M1 + 256, W_M2 = B_M1 + 16,
                        B_M2 = W_M2 + CO * 16, W_C0 = B_M2 + CO, B_C0 = W_C0 + 16 * 16 * C, W_C1 = B_C0 + 16,
                        B_C1 = W_C1 + 256, B_V = B_C1 + 16, W_END = B_V + 16 * C;
@@ -204,10 +208,8 @@ __device__ __forceinline__ void edge_stage(float* Qs, float* Ks, float* Ad, floa
     const int i = e / (W / 4), c4 = (e - i * (W / 4)) * 4;
     const float4 q = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + c4);
     const float4 k = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + W + c4);
-    float* qd = Qs + i * L::LQ + c4;
-    float* kd = Ks + i * L::LQ + c4;
-    qd[0] = q.x; qd[1] = q.y; qd[2] = q.z; qd[3] = q.w;
-    kd[0] = k.x; kd[1] = k.y; kd[2] = k.z; kd[3] = k.w;
+    *reinterpret_cast<float4*>(Qs + i * L::LQ + c4) = q;
+    *reinterpret_cast<float4*>(Ks + i * L::LQ + c4) = k;
   }
   for (int e = tid; e < n * n * C; e += 256) {
     const int p = e / C, c = e - p * C;
@@ -238,16 +240,14 @@ __device__ __forceinline__ float edge_an(const float* Ad, const float* Rn, int n
 // mean over the 8 head chunks of tanh(q_i . k_j / 2) for channel c (edge_network_dense.py:66-80; 8 chunks: App. B.3)
 template <int C>
 __device__ __forceinline__ float edge_att(const float* Qs, const float* Ks, int i, int j, int c) {
-  const float* q = Qs + i * (32 * C + 1) + 32 * c;
-  const float* k = Ks + j * (32 * C + 1) + 32 * c;
+  const float4* q = reinterpret_cast<const float4*>(Qs + i * (32 * C + 4) + 32 * c);
+  const float4* k = reinterpret_cast<const float4*>(Ks + j * (32 * C + 4) + 32 * c);
   float acc = 0.f;
 #pragma unroll
   for (int h = 0; h < 8; ++h) {
-    float s = q[4 * h] * k[4 * h];
-    s = fmaf(q[4 * h + 1], k[4 * h + 1], s);
-    s = fmaf(q[4 * h + 2], k[4 * h + 2], s);
-    s = fmaf(q[4 * h + 3], k[4 * h + 3], s);
-    acc += tanhf(0.5f * s);
+    const float4 a = q[h], b = k[h];
+    const float s = fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+    acc += dh_tanh(0.5f * s);
   }
   return acc * 0.125f;
 }
@@ -261,7 +261,8 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
                             float* __restrict__ H2, float* __restrict__ xcat, float* __restrict__ Hmc) {
   using L = EdgeLds<C, CO>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Qs = lds;
+  float* Wk = lds;                    // weights first: 16-B aligned for the float4 broadcast reads
+  float* Qs = Wk + ((L::W_END + 3) & ~3);
   float* Ks = Qs + nm * L::LQ;
   float* Ad = Ks + nm * L::LQ;
   float* Xv = Ad + nm * nm * L::LA;
@@ -269,7 +270,6 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
   float* Hm = Vc + nm * L::LV;        // [n][17]
   float* Tm = Hm + nm * 17;           // [n][17] scratch
   float* Rn = Tm + nm * 17;           // [n][C], C <= 8
-  float* Wk = Rn + nm * 8;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
   edge_load_weights<C, CO>(Wk, p, tid);
@@ -301,7 +301,7 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
     const float* w = Wk + L::W_C1 + o * 16;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s = fmaf(w[k], Hm[i * 17 + k], s);
-    x_out[(size_t)(a0 + i) * 16 + o] = tanhf(s * flags[a0 + i]);
+    x_out[(size_t)(a0 + i) * 16 + o] = dh_tanh(s * flags[a0 + i]);
   }
   // ---- pairs: attention, pair MLP, symmetrise (= x2: inputs are symmetric, so mlp(i,j) == mlp(j,i)), mask
   for (int pp = tid; pp < n * n; pp += 256) {
@@ -322,14 +322,20 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
     for (int o = 0; o < 16; ++o) {
       float s = Wp[L::B_M0 + o];
 #pragma unroll
-      for (int k = 0; k < 2 * C; ++k) s = fmaf(Wp[L::W_M0 + o * 2 * C + k], in[k], s);
+      for (int k = 0; k < 2 * C; k += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M0 + o * 2 * C + k]);
+        s = fmaf(w.w, in[k + 3], fmaf(w.z, in[k + 2], fmaf(w.y, in[k + 1], fmaf(w.x, in[k], s))));
+      }
       h1[o] = dh_elu(s);
     }
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
       float s = Wp[L::B_M1 + o];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s = fmaf(Wp[L::W_M1 + o * 16 + k], h1[k], s);
+      for (int k = 0; k < 16; k += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M1 + o * 16 + k]);
+        s = fmaf(w.w, h1[k + 3], fmaf(w.z, h1[k + 2], fmaf(w.y, h1[k + 1], fmaf(w.x, h1[k], s))));
+      }
       h2[o] = dh_elu(s);
     }
     const float m = 2.f * flags[a0 + i] * flags[a0 + j];
@@ -338,7 +344,10 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
     for (int o = 0; o < CO; ++o) {
       float s = Wp[L::B_M2 + o];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s = fmaf(Wp[L::W_M2 + o * 16 + k], h2[k], s);
+      for (int k = 0; k < 16; k += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M2 + o * 16 + k]);
+        s = fmaf(w.w, h2[k + 3], fmaf(w.z, h2[k + 2], fmaf(w.y, h2[k + 1], fmaf(w.x, h2[k], s))));
+      }
       acrow[o] = s * m;
     }
     float* inrow = IN + (size_t)(q0 + pp) * (2 * C);
@@ -368,7 +377,8 @@ dense_edge_layer_bwd_kernel(const float* __restrict__ QK, const float* __restric
                             float* __restrict__ GHm, float* __restrict__ GV) {
   using L = EdgeLds<C, CO>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Qs = lds;
+  float* Wk = lds;
+  float* Qs = Wk + ((L::W_END + 3) & ~3);
   float* Ks = Qs + nm * L::LQ;
   float* Ad = Ks + nm * L::LQ;
   float* Xv = Ad + nm * nm * L::LA;
@@ -376,7 +386,6 @@ dense_edge_layer_bwd_kernel(const float* __restrict__ QK, const float* __restric
   float* Hm = Vc + nm * L::LV;        // g of channel-MLP hidden (pre-activation)
   float* Tm = Hm + nm * 17;           // g_y
   float* Rn = Tm + nm * 17;
-  float* Wk = Rn + nm * 8;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
   edge_load_weights<C, CO>(Wk, p, tid);
@@ -494,31 +503,51 @@ dense_edge_layer_bwd_kernel(const float* __restrict__ QK, const float* __restric
       for (int o = 0; o < CO; ++o) { go[o] = (grow[o] + growT[o]) * m; GO[(size_t)(q0 + pp) * CO + o] = go[o]; }
       const float* h1row = H1 + (size_t)(q0 + pp) * 16;
       const float* h2row = H2 + (size_t)(q0 + pp) * 16;
+      // transposed products W^T g, rows of W read as float4 (broadcast), accumulated over the output index
       float g2[16], g1[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        float s = 0.f;
+      for (int k = 0; k < 16; ++k) g2[k] = 0.f;
 #pragma unroll
-        for (int o = 0; o < CO; ++o) s = fmaf(Wp[L::W_M2 + o * 16 + k], go[o], s);
-        g2[k] = s * dh_delu_y(h2row[k]);
-        GH2[(size_t)(q0 + pp) * 16 + k] = g2[k];
+      for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M2 + o * 16 + k]);
+          g2[k] = fmaf(w.x, go[o], g2[k]); g2[k + 1] = fmaf(w.y, go[o], g2[k + 1]);
+          g2[k + 2] = fmaf(w.z, go[o], g2[k + 2]); g2[k + 3] = fmaf(w.w, go[o], g2[k + 3]);
+        }
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) {
+        const float4 hv = *reinterpret_cast<const float4*>(h2row + k);
+        g2[k] *= dh_delu_y(hv.x); g2[k + 1] *= dh_delu_y(hv.y); g2[k + 2] *= dh_delu_y(hv.z); g2[k + 3] *= dh_delu_y(hv.w);
+        *reinterpret_cast<float4*>(GH2 + (size_t)(q0 + pp) * 16 + k) = make_float4(g2[k], g2[k + 1], g2[k + 2], g2[k + 3]);
       }
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        float s = 0.f;
+      for (int k = 0; k < 16; ++k) g1[k] = 0.f;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) s = fmaf(Wp[L::W_M1 + o * 16 + k], g2[o], s);
-        g1[k] = s * dh_delu_y(h1row[k]);
-        GH1[(size_t)(q0 + pp) * 16 + k] = g1[k];
+      for (int o = 0; o < 16; ++o)
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M1 + o * 16 + k]);
+          g1[k] = fmaf(w.x, g2[o], g1[k]); g1[k + 1] = fmaf(w.y, g2[o], g1[k + 1]);
+          g1[k + 2] = fmaf(w.z, g2[o], g1[k + 2]); g1[k + 3] = fmaf(w.w, g2[o], g1[k + 3]);
+        }
+#pragma unroll
+      for (int k = 0; k < 16; k += 4) {
+        const float4 hv = *reinterpret_cast<const float4*>(h1row + k);
+        g1[k] *= dh_delu_y(hv.x); g1[k + 1] *= dh_delu_y(hv.y); g1[k + 2] *= dh_delu_y(hv.z); g1[k + 3] *= dh_delu_y(hv.w);
+        *reinterpret_cast<float4*>(GH1 + (size_t)(q0 + pp) * 16 + k) = make_float4(g1[k], g1[k + 1], g1[k + 2], g1[k + 3]);
       }
       float gin[2 * C];
 #pragma unroll
-      for (int k = 0; k < 2 * C; ++k) {
-        float s = 0.f;
+      for (int k = 0; k < 2 * C; ++k) gin[k] = 0.f;
 #pragma unroll
-        for (int o = 0; o < 16; ++o) s = fmaf(Wp[L::W_M0 + o * 2 * C + k], g1[o], s);
-        gin[k] = s;
-      }
+      for (int o = 0; o < 16; ++o)
+#pragma unroll
+        for (int k = 0; k < 2 * C; k += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M0 + o * 2 * C + k]);
+          gin[k] = fmaf(w.x, g1[o], gin[k]); gin[k + 1] = fmaf(w.y, g1[o], gin[k + 1]);
+          gin[k + 2] = fmaf(w.z, g1[o], gin[k + 2]); gin[k + 3] = fmaf(w.w, g1[o], gin[k + 3]);
+        }
       if (need_gadj) {
         float* gin_row = gAC + (size_t)(q0 + pp) * DH_AC + in_off;
 #pragma unroll
@@ -537,20 +566,19 @@ dense_edge_layer_bwd_kernel(const float* __restrict__ QK, const float* __restric
     const int which = e / (n * C * 8);            // 0: g_q, 1: g_k
     const int r = e - which * n * C * 8;
     const int i = r / (C * 8), ch = r - i * C * 8, c = ch >> 3, h = ch & 7;
-    const float* mine = (which ? Ks : Qs) + i * L::LQ + 32 * c + 4 * h;
+    const float4 mn = *reinterpret_cast<const float4*>((which ? Ks : Qs) + i * L::LQ + 32 * c + 4 * h);
     const float* oth = (which ? Qs : Ks) + 32 * c + 4 * h;
-    const float m0 = mine[0], m1 = mine[1], m2 = mine[2], m3 = mine[3];
     float a0_ = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int j = 0; j < n; ++j) {
-      const float* o = oth + j * L::LQ;
-      const float s = 0.5f * (m0 * o[0] + m1 * o[1] + m2 * o[2] + m3 * o[3]);
-      const float th = tanhf(s);
+      const float4 o = *reinterpret_cast<const float4*>(oth + j * L::LQ);
+      const float s = 0.5f * fmaf(mn.w, o.w, fmaf(mn.z, o.z, fmaf(mn.y, o.y, mn.x * o.x)));
+      const float th = dh_tanh(s);
       const int pp = which ? (j * n + i) : (i * n + j);
       const float gs = Ad[pp * L::LA + c] * 0.125f * (1.f - th * th) * 0.5f;
-      a0_ = fmaf(gs, o[0], a0_); a1 = fmaf(gs, o[1], a1); a2 = fmaf(gs, o[2], a2); a3 = fmaf(gs, o[3], a3);
+      a0_ = fmaf(gs, o.x, a0_); a1 = fmaf(gs, o.y, a1); a2 = fmaf(gs, o.z, a2); a3 = fmaf(gs, o.w, a3);
     }
-    float* dst = gQK + (size_t)(a0 + i) * (64 * C) + which * 32 * C + 32 * c + 4 * h;
-    dst[0] = a0_; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+    *reinterpret_cast<float4*>(gQK + (size_t)(a0 + i) * (64 * C) + which * 32 * C + 32 * c + 4 * h) =
+        make_float4(a0_, a1, a2, a3);
   }
 }
 
@@ -659,7 +687,7 @@ dense_node_gcn_fwd_kernel(const float* __restrict__ XW0, const float* __restrict
       const int i = e >> 4, f = e & 15;
       float s = bl[l * 16 + f];
       for (int j = 0; j < n; ++j) s = fmaf(An[i][j], xa[j][f], s);
-      s = tanhf(s);
+      s = dh_tanh(s);
       xb[i][f] = s;
       XS[(size_t)(a0 + i) * ldxs + 16 * l + f] = s;
     }
@@ -779,15 +807,23 @@ dense_loss_fwd_kernel(const float* __restrict__ G2, int F2, const float* __restr
   const float sd = mean_std[2 * b + 1], inv = 1.f / sd;
   const float wb = anneal != 0.f ? powf(sd, anneal) : 1.f;
   float sx = 0.f, sa = 0.f;
-  for (int p = tid; p < n * n; p += 256) {
-    const int i = p / n, j = p - i * n;
-    const float* g = G2 + (size_t)(q0 + p) * F2;
-    float s = b2[0];
-    for (int k = 0; k < F2; ++k) s = fmaf(g[k], w2[k], s);
-    const float m = (i != j) ? flags[a0 + i] * flags[a0 + j] : 0.f;
-    const float r = -s * m * inv + z_adj[q0 + p];
-    res_adj[q0 + p] = r;
-    sa = fmaf(r, r, sa);
+  // one wave per pair: the 60 hidden values of a pair are read by consecutive lanes (a thread-per-pair loop reads rows
+  // 240 B apart: 64 cache lines per load instruction)
+  {
+    const int lane = tid & 63, w = tid >> 6;
+    for (int p = w; p < n * n; p += 4) {
+      const int i = p / n, j = p - i * n;
+      float v = 0.f;
+      for (int k = lane; k < F2; k += 64) v = fmaf(G2[(size_t)(q0 + p) * F2 + k], w2[k], v);
+      v = group_sum(v, 64);
+      if (lane == 0) {
+        const float s = v + b2[0];
+        const float m = (i != j) ? flags[a0 + i] * flags[a0 + j] : 0.f;
+        const float r = -s * m * inv + z_adj[q0 + p];
+        res_adj[q0 + p] = r;
+        sa = fmaf(r, r, sa);
+      }
+    }
   }
   for (int e = tid; e < n * ncls; e += 256) {
     const int i = e / ncls, c = e - i * ncls;
@@ -848,17 +884,14 @@ dense_loss_bwd_kernel(const float* __restrict__ g_lx, const float* __restrict__ 
   const float sd = mean_std[2 * b + 1], inv = 1.f / sd;
   const float wb = anneal != 0.f ? powf(sd, anneal) : 1.f;
   const float cx = (g_lx ? g_lx[0] : 0.f) * scale_x * wb * 2.f, ca = (g_la ? g_la[0] : 0.f) * scale_adj * wb * 2.f;
-  for (int p = tid; p < n * n; p += 256) {
+  for (int e = tid; e < n * n * F2; e += 256) {          // flat over (pair, hidden unit): coalesced
+    const int p = e / F2, k = e - p * F2;
     const int i = p / n, j = p - i * n;
     const float m = (i != j) ? flags[a0 + i] * flags[a0 + j] : 0.f;
     const float gs = ca * res_adj[q0 + p] * (-m * inv);
-    gS[q0 + p] = gs;
-    const float* z = Z2 + (size_t)(q0 + p) * F2;
-    float* gz = gZ2 + (size_t)(q0 + p) * F2;
-    for (int k = 0; k < F2; ++k) {
-      const float zz = z[k], sg = 1.f / (1.f + __expf(-zz));
-      gz[k] = gs * w2[k] * sg * (1.f + zz * (1.f - sg));
-    }
+    if (k == 0) gS[q0 + p] = gs;
+    const float zz = Z2[(size_t)(q0 + p) * F2 + k], sg = 1.f / (1.f + __expf(-zz));
+    gZ2[(size_t)(q0 + p) * F2 + k] = gs * w2[k] * sg * (1.f + zz * (1.f - sg));
   }
   for (int e = tid; e < n * DH_XP; e += 256) {
     const int i = e / DH_XP, c = e - i * DH_XP;

@@ -32,26 +32,67 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GX_LDK 36   // row stride of a k-contiguous LDS tile
 #define GX_LDN 68   // row stride of an n-contiguous LDS tile (64 columns)
 
-__device__ __forceinline__ float gx_act(float z, int act) {
-  switch (act) {
-    case MSDE_ACT_TANH: return tanhf(z);
-    case MSDE_ACT_SILU: return z / (1.f + __expf(-z));
-    case MSDE_ACT_ELU: return z > 0.f ? z : expm1f(z);
-    case MSDE_ACT_SSP: return (z > 20.f ? z : log1pf(__expf(z))) - 0.6931471805599453f;
-    case MSDE_ACT_RELU: return fmaxf(z, 0.f);
-    default: return z;
-  }
+// Activations and their derivatives, selected at COMPILE time inside the epilogue (a run-time switch per element
+// turned the epilogue into a chain of scalar branches around every store).  Fast forms: v_exp_f32 / v_rcp_f32 /
+// v_log_f32, absolute error ~1e-7.  `r` of the derivative is what the forward saved: the OUTPUT y for tanh / ELU /
+// ReLU, the PRE-ACTIVATION z for SiLU / shifted softplus.
+template <int ACT> __device__ __forceinline__ float gx_act(float z) {
+  if (ACT == MSDE_ACT_TANH) return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * z));
+  if (ACT == MSDE_ACT_SILU) return z * __frcp_rn(1.f + __expf(-z));
+  if (ACT == MSDE_ACT_ELU) return z > 0.f ? z : __expf(z) - 1.f;
+  if (ACT == MSDE_ACT_SSP) return (z > 20.f ? z : __logf(1.f + __expf(z))) - 0.6931471805599453f;
+  if (ACT == MSDE_ACT_RELU) return fmaxf(z, 0.f);
+  return z;
 }
-// derivative of the activation; `r` is what the forward saved: the OUTPUT y for tanh / ELU / ReLU, the
-// PRE-ACTIVATION z for SiLU / shifted softplus
-__device__ __forceinline__ float gx_dact(float r, int act) {
-  switch (act) {
-    case MSDE_ACT_TANH: return 1.f - r * r;
-    case MSDE_ACT_SILU: { float s = 1.f / (1.f + __expf(-r)); return s * (1.f + r * (1.f - s)); }
-    case MSDE_ACT_ELU: return r > 0.f ? 1.f : r + 1.f;
-    case MSDE_ACT_SSP: return 1.f / (1.f + __expf(-r));
-    case MSDE_ACT_RELU: return r > 0.f ? 1.f : 0.f;
-    default: return 1.f;
+template <int ACT> __device__ __forceinline__ float gx_dact(float r) {
+  if (ACT == MSDE_ACT_TANH) return 1.f - r * r;
+  if (ACT == MSDE_ACT_SILU) { const float s = __frcp_rn(1.f + __expf(-r)); return s * (1.f + r * (1.f - s)); }
+  if (ACT == MSDE_ACT_ELU) return r > 0.f ? 1.f : r + 1.f;
+  if (ACT == MSDE_ACT_SSP) return __frcp_rn(1.f + __expf(-r));
+  if (ACT == MSDE_ACT_RELU) return r > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// Epilogue of one wave: TM accumulator tiles -> C (and Z).  C/D map of the 32x32 MFMA: col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  PLAIN: no derivative / row mask / alpha / accumulation (the forward
+// products): nothing but bias, activation and the stores in the unrolled loop.
+template <int TM, int ACT, bool PLAIN>
+__device__ __forceinline__ void gx_epilogue(const msde_gemm_desc& d, const f32x16 (&acc)[TM], int g, int m_base, int gn,
+                                            int lhalf) {
+  const float* __restrict__ bias = d.bias ? d.bias + (size_t)g * d.bias_gs : nullptr;
+  const float* __restrict__ bias2 = d.bias2 ? d.bias2 + (size_t)g * d.bias_gs : nullptr;
+  float* __restrict__ C = d.C + (size_t)g * d.c_gs + gn;
+  float* __restrict__ Z = d.Z ? d.Z + (size_t)g * d.c_gs + gn : nullptr;
+  const float* __restrict__ R = d.R ? d.R + (size_t)g * d.r_gs + gn : nullptr;
+  const float bv = (bias ? bias[gn] : 0.f) + (bias2 ? bias2[gn] : 0.f);
+  const bool act_here = ACT != MSDE_ACT_NONE && gn >= d.act_lo && gn < d.act_hi;
+  const bool dact = d.epi == MSDE_EPI_DACT, accum = (d.flags & MSDE_GEMM_ACCUMULATE) != 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gm = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+      if (gm < d.M) {
+        float v = acc[i][r] + bv;
+        if (PLAIN) {
+          if (Z) Z[(size_t)gm * d.ldz] = v;
+          if (act_here) v = gx_act<ACT>(v);
+          C[(size_t)gm * d.ldc] = v;
+        } else {
+          if (!dact) {
+            if (Z) Z[(size_t)gm * d.ldz] = v;
+            if (act_here) v = gx_act<ACT>(v);
+          } else if (act_here) {
+            v *= gx_dact<ACT>(R[(size_t)gm * d.ldr]);
+          }
+          if (d.rowscale) v *= d.rowscale[gm];
+          v *= d.alpha;
+          float* dst = C + (size_t)gm * d.ldc;
+          if (accum) v += *dst;
+          *dst = v;
+        }
+      }
+    }
   }
 }
 
@@ -124,38 +165,57 @@ gemm_ex_kernel(const msde_gemm_desc d) {
   float4 ra[2][NA], rb[2][NB];
   int ka[2][NA], kb_[2][NB];
 
+  // per-thread row pointers of both K segments, computed once (the per-tile address is then one 64-bit add)
+  const float* pa1[NA]; const float* pa2[NA]; const float* pb1[NB]; const float* pb2[NB];
+#pragma unroll
+  for (int p = 0; p < NA; ++p) {
+    const int idx = p * 256 + tid, r = idx >> 3;
+    const int gm = min(m0 + r, d.M - 1);                     // rows past M repeat the last row: never stored
+    pa1[p] = A1 + (size_t)gm * d.lda;
+    pa2[p] = A2 ? A2 + (size_t)gm * d.lda2 : pa1[p];
+  }
+#pragma unroll
+  for (int p = 0; p < NB; ++p) {
+    const int idx = p * 256 + tid;
+    if (!B_KM) {
+      const int gn = min(n0 + (idx >> 3), d.N - 1);
+      pb1[p] = B1 + (size_t)gn * d.ldb;
+      pb2[p] = B2 ? B2 + (size_t)gn * d.ldb2 : pb1[p];
+    } else {                                                 // k-major: the row (k) changes per tile; keep the column part
+      pb1[p] = B1;
+      pb2[p] = B2 ? B2 : B1;
+    }
+  }
+
   auto load_tile = [&](int t, float4 (&xa)[NA], float4 (&xb)[NB], int (&ma)[NA], int (&mb)[NB]) {
     const bool s2 = t >= nt1;
-    const float* __restrict__ A = s2 ? A2 : A1;
-    const float* __restrict__ B = s2 ? B2 : B1;
-    const int lda = s2 ? d.lda2 : d.lda, ldb = s2 ? d.ldb2 : d.ldb, K = s2 ? K2 : K1;
+    const int ldb = s2 ? d.ldb2 : d.ldb, K = s2 ? K2 : K1;
     const int k0 = (s2 ? t - nt1 : t) * GX_BK;
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
-      const int idx = p * 256 + tid, r = idx >> 3, kq = (idx & 7) * 4;
-      const int gm = min(m0 + r, d.M - 1);                 // rows past M repeat the last row: never stored
-      xa[p] = gx_ld4<VEC>(A + (size_t)gm * lda, k0 + kq, K, ma[p]);
+      const int kq = ((p * 256 + tid) & 7) * 4;
+      xa[p] = gx_ld4<VEC>(s2 ? pa2[p] : pa1[p], k0 + kq, K, ma[p]);
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = p * 256 + tid;
+      const float* __restrict__ bp = s2 ? pb2[p] : pb1[p];
       if (!B_KM) {                                          // B[n][k]
-        const int r = idx >> 3, kq = (idx & 7) * 4;
-        const int gn = min(n0 + r, d.N - 1);
+        const int kq = (idx & 7) * 4;
         if (d.b_kblk_log2 > 0) {
           // k is cut into blocks of 2^lg: block q of row n starts at B + q * b_kblk_stride + n * ldb (the stacked
           // [C][F][16] weights of the per-channel GCNs read as one [F][16 C] operand)
           const int kk = k0 + kq, q = kk >> d.b_kblk_log2, rem = kk & ((1 << d.b_kblk_log2) - 1);
           int keep;
-          xb[p] = gx_ld4<VEC>(B + (size_t)q * d.b_kblk_stride + (size_t)gn * ldb, kk < K ? rem : 0, 1 << d.b_kblk_log2, keep);
+          xb[p] = gx_ld4<VEC>(bp + (size_t)q * d.b_kblk_stride, kk < K ? rem : 0, 1 << d.b_kblk_log2, keep);
           mb[p] = kk < K ? keep : 0;
         } else {
-          xb[p] = gx_ld4<VEC>(B + (size_t)gn * ldb, k0 + kq, K, mb[p]);
+          xb[p] = gx_ld4<VEC>(bp, k0 + kq, K, mb[p]);
         }
       } else {                                              // B[k][n]: 16 float4 per k row
         const int kr = idx >> 4, nq = (idx & 15) * 4;
         const int gk = min(k0 + kr, K - 1);
-        xb[p] = gx_ld4<VEC>(B + (size_t)gk * ldb, n0 + nq, d.N, mb[p]);
+        xb[p] = gx_ld4<VEC>(bp + (size_t)gk * ldb, n0 + nq, d.N, mb[p]);
         if (k0 + kr >= K) mb[p] = 0;
       }
     }
@@ -185,29 +245,33 @@ gemm_ex_kernel(const msde_gemm_desc d) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // LDS operand reads are software pipelined by hand: the fragment of step q+1 is requested BEFORE the four MFMAs of
+  // step q are issued (the compiler otherwise reuses the fragment registers and exposes one LDS latency per 8 MFMAs)
+  auto read_frag = [&](const float* __restrict__ as, const float* __restrict__ bs, int q, float4 (&af)[TM], float4& bf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      af[i] = *reinterpret_cast<const float4*>(&as[((wm * TM + i) * 32 + lcol) * GX_LDK + 8 * q + 4 * lhalf]);
+    if (!B_KM) {
+      bf = *reinterpret_cast<const float4*>(&bs[(wn * 32 + lcol) * GX_LDK + 8 * q + 4 * lhalf]);
+    } else {
+      const int kb = 8 * q + 4 * lhalf, c = wn * 32 + lcol;
+      bf = make_float4(bs[kb * GX_LDN + c], bs[(kb + 1) * GX_LDN + c], bs[(kb + 2) * GX_LDN + c], bs[(kb + 3) * GX_LDN + c]);
+    }
+  };
   auto compute_tile = [&](int s) {
     const float* __restrict__ as = As[s];
     const float* __restrict__ bs = Bs[s];
+    float4 af[2][TM], bf[2];
+    read_frag(as, bs, 0, af[0], bf[0]);
 #pragma unroll
     for (int q = 0; q < GX_BK / 8; ++q) {                   // k's 8q .. 8q+7: lane half h owns 8q+4h .. 8q+4h+3
-      float4 af[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const float4*>(&as[((wm * TM + i) * 32 + lcol) * GX_LDK + 8 * q + 4 * lhalf]);
-      float4 bf;
-      if (!B_KM) {
-        bf = *reinterpret_cast<const float4*>(&bs[(wn * 32 + lcol) * GX_LDK + 8 * q + 4 * lhalf]);
-      } else {
-        const int kb = 8 * q + 4 * lhalf, c = wn * 32 + lcol;
-        bf = make_float4(bs[kb * GX_LDN + c], bs[(kb + 1) * GX_LDN + c], bs[(kb + 2) * GX_LDN + c],
-                         bs[(kb + 3) * GX_LDN + c]);
-      }
+      if (q + 1 < GX_BK / 8) read_frag(as, bs, q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf.x, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf.y, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf.z, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf.w, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i].x, bf[q & 1].x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i].y, bf[q & 1].y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i].z, bf[q & 1].z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][i].w, bf[q & 1].w, acc[i], 0, 0, 0);
       }
     }
   };
@@ -219,51 +283,42 @@ gemm_ex_kernel(const msde_gemm_desc d) {
     __syncthreads();
     // iteration t: register stage t&1 (tile t, already in LDS) is refilled with tile t+2; tile t is multiplied; tile
     // t+1 (register stage (t+1)&1, requested one iteration ago) moves to LDS stage (t+1)&1, last read in iteration t-1
+    const bool dbg_noload = (d.flags & 256) != 0, dbg_nosync = (d.flags & 512) != 0;   // diagnostics (tools/bench_gemm_ex.py)
     for (int t = 0; t < ntiles; t += 2) {
-      if (t + 2 < ntiles) load_tile(t + 2, ra[0], rb[0], ka[0], kb_[0]);
+      if (t + 2 < ntiles && !dbg_noload) load_tile(t + 2, ra[0], rb[0], ka[0], kb_[0]);
       compute_tile(0);
-      if (t + 1 < ntiles) store_tile(1, ra[1], rb[1], ka[1], kb_[1]);
-      __syncthreads();
+      if (t + 1 < ntiles && !dbg_noload) store_tile(1, ra[1], rb[1], ka[1], kb_[1]);
+      if (!dbg_nosync) __syncthreads();
       if (t + 1 < ntiles) {
-        if (t + 3 < ntiles) load_tile(t + 3, ra[1], rb[1], ka[1], kb_[1]);
+        if (t + 3 < ntiles && !dbg_noload) load_tile(t + 3, ra[1], rb[1], ka[1], kb_[1]);
         compute_tile(1);
-        if (t + 2 < ntiles) store_tile(0, ra[0], rb[0], ka[0], kb_[0]);
-        __syncthreads();
+        if (t + 2 < ntiles && !dbg_noload) store_tile(0, ra[0], rb[0], ka[0], kb_[0]);
+        if (!dbg_nosync) __syncthreads();
       }
     }
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  const float* __restrict__ bias = d.bias ? d.bias + (size_t)g * d.bias_gs : nullptr;
-  const float* __restrict__ bias2 = d.bias2 ? d.bias2 + (size_t)g * d.bias_gs : nullptr;
-  float* __restrict__ C = d.C + (size_t)g * d.c_gs;
-  float* __restrict__ Z = d.Z ? d.Z + (size_t)g * d.c_gs : nullptr;
-  const float* __restrict__ R = d.R ? d.R + (size_t)g * d.r_gs : nullptr;
+  // ---- epilogue: the activation (and the plain / general form) is chosen ONCE, outside the element loop
   const int gn = n0 + wn * 32 + lcol;
-  if (gn < d.N) {
-    const float bv = (bias ? bias[gn] : 0.f) + (bias2 ? bias2[gn] : 0.f);
-    const bool act_here = d.act != MSDE_ACT_NONE && gn >= d.act_lo && gn < d.act_hi;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-        if (gm < d.M) {
-          float v = acc[i][r] + bv;
-          if (d.epi == MSDE_EPI_ACT) {
-            if (Z) Z[(size_t)gm * d.ldz + gn] = v;
-            if (act_here) v = gx_act(v, d.act);
-          } else if (d.epi == MSDE_EPI_DACT) {
-            if (act_here) v *= gx_dact(R[(size_t)gm * d.ldr + gn], d.act);
-          }
-          if (d.rowscale) v *= d.rowscale[gm];
-          v *= d.alpha;
-          float* dst = C + (size_t)gm * d.ldc + gn;
-          if (d.flags & MSDE_GEMM_ACCUMULATE) v += *dst;
-          *dst = v;
-        }
-      }
+  if (gn < d.N && !(d.flags & 1024)) {
+    const int mb = m0 + wm * TM * 32;
+    const bool plain = d.epi == MSDE_EPI_ACT && !d.rowscale && d.alpha == 1.f && !(d.flags & MSDE_GEMM_ACCUMULATE);
+#define GX_EPI(ACT_)                                                        \
+    case ACT_:                                                                \
+      if (plain) gx_epilogue<TM, ACT_, true>(d, acc, g, mb, gn, lhalf);       \
+      else gx_epilogue<TM, ACT_, false>(d, acc, g, mb, gn, lhalf);            \
+      break;
+    switch (d.act) {
+      GX_EPI(MSDE_ACT_TANH)
+      GX_EPI(MSDE_ACT_SILU)
+      GX_EPI(MSDE_ACT_ELU)
+      GX_EPI(MSDE_ACT_SSP)
+      GX_EPI(MSDE_ACT_RELU)
+      default:
+        if (plain) gx_epilogue<TM, MSDE_ACT_NONE, true>(d, acc, g, mb, gn, lhalf);
+        else gx_epilogue<TM, MSDE_ACT_NONE, false>(d, acc, g, mb, gn, lhalf);
     }
+#undef GX_EPI
   }
 }
 
@@ -288,7 +343,8 @@ extern "C" int msde_gemm_ex(const msde_gemm_desc* desc, void* stream) {
   if (d.A2) vec = vec && vec_ok(d.A2, d.a_gs, d.lda2, d.K2) && vec_ok(d.B2, d.b_gs, d.ldb2, km ? d.N : d.K2);
   // tile height: 128 rows when that still gives every CU >= 2 tiles, else 64 (skinny problems need the parallelism)
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.groups;
-  const int tm = t128 >= 2L * msde_num_cus() ? 2 : 1;
+  static const int force_tm = getenv("MSDE_GEMM_TM") ? atoi(getenv("MSDE_GEMM_TM")) : 0;      // tuning knob
+  const int tm = force_tm ? force_tm : (t128 >= 2L * msde_num_cus() ? 2 : 1);
   const int tiles = ((d.M + 64 * tm - 1) / (64 * tm)) * ((d.N + 63) / 64);
   const int grid_x = ((tiles + 7) / 8) * 8;       // whole multiples of 8: every XCD gets the same number of slots
   dim3 grid(grid_x, d.groups);

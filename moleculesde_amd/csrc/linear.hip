@@ -373,7 +373,10 @@ static inline void wgrad_split_for(int M, int N, int K, int target, int* splits,
   int tw_n = (big && N > 64) ? 128 : 64, tw_k = (big && K > 64) ? 128 : 64;
   long tiles = (long)((N + tw_n - 1) / tw_n) * ((K + tw_k - 1) / tw_k);
   long want = (target + tiles - 1) / tiles;
-  long maxs = (M + 63) / 64;
+  // at least 256 rows (8 K tiles) per split: a 64-row split spends its time in the pipeline prologue and the 16 KB
+  // slab write, and the grouped launch has thousands of workgroups anyway (the dense head alone adds ~150 problems)
+  long maxs = (M + 255) / 256;
+  if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want > 512) want = 512;
   if (want < 1) want = 1;

@@ -1505,7 +1505,7 @@ def _ld(t):
 
 def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=None, dact_from=None, rowscale=None,
             b_kmajor=False, accumulate=False, alpha=1.0, groups=1, group_strides=None, N=None, K=None, K2=None, bias2=None,
-            b_kblk=None):
+            b_kblk=None, _debug_flags=0):
     """out[M,N] (+)= alpha * rowscale * epi(A . B(^T) + A2 . B2(^T) + bias): one launch of msde_gemm_ex, no autograd.
     A, A2, out, Z, dact_from: 2-D fp32 device tensors with unit column stride (views into wider buffers are fine; their
     row strides become the leading dimensions).  B: [N, K] (nn.Linear layout) or, with b_kmajor, [K, N].
@@ -1545,7 +1545,7 @@ def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=N
         d.epi = _lib.EPI_DACT
         d.R, d.ldr = dact_from.data_ptr(), _ld(dact_from)
     d.rowscale = rowscale.data_ptr() if rowscale is not None else None
-    d.flags = (_lib.GEMM_B_KMAJOR if b_kmajor else 0) | (_lib.GEMM_ACCUMULATE if accumulate else 0)
+    d.flags = (_lib.GEMM_B_KMAJOR if b_kmajor else 0) | (_lib.GEMM_ACCUMULATE if accumulate else 0) | int(_debug_flags)
     d.groups = int(groups)
     gs = group_strides or {}
     d.a_gs, d.b_gs, d.bias_gs = int(gs.get("a", 0)), int(gs.get("b", 0)), int(gs.get("bias", 0))
