@@ -6,12 +6,18 @@
 
 Workload (BASELINE.json configs[1]): PCQM4Mv2-shaped synthetic batches, 256 molecules per GPU,
 GIN(5x300) + SchNet(6 interactions, 128 filters, 51 Gaussians, cutoff 10) + contrastive
-(EBM_node_dot_prod, so SchNet receives gradient) + SDEModel2Dto3D_02 VE; one "step" = forward,
-backward, (all-reduce), Adam, inputs already resident in HBM.  Weak scaling: every rank owns its own
-shard of molecules; the only collective is one RCCL all-reduce of the flat 3.5 M-element gradient.
+(EBM_node_dot_prod, so SchNet receives gradient) + SDEModel2Dto3D_02 VE; one "step" = device-side batch
+construction, forward, backward, (all-reduce), Adam, inputs already resident in HBM.  `--full` adds the 3D->2D dense
+head (configs[2] per-GPU work).  Weak scaling: every rank owns its own shard of molecules; the only collective is the
+all-reduce of the flat gradient (per-model buckets).
 
-Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events on the launch stream for the
-dominant hand-written kernel, `cpu_baseline` is the oracle port timed on the host cores (N=1 only).
+Headline (`value`): `--stream` (64) DISTINCT batches streamed through ONE captured hipGraph (capacity bucket, raw
+collated arrays in, plans + extended graph built on the device).  Secondary keys under config.stream: the same blobs
+from pinned host memory (PCIe-inclusive) and the round-1 mode (4 resident batches, a graph each).
+
+Rank 0 prints ONE JSON line; `roofline` = the kernel with the largest share of the step's GPU time, timed live with
+HIP events at the step's launch geometry; `roofline_forward_schnet_sde2d3d` = the north-star forward figure;
+`cpu_baseline` = the oracle port timed on the host cores (N=1 only).
 """
 import argparse
 import json
