@@ -165,43 +165,65 @@ gemm_ex_kernel(const msde_gemm_desc d) {
   float4 ra[2][NA], rb[2][NB];
   int ka[2][NA], kb_[2][NB];
 
-  // per-thread row pointers of both K segments, computed once (the per-tile address is then one 64-bit add)
-  const float* pa1[NA]; const float* pa2[NA]; const float* pb1[NB]; const float* pb2[NB];
+  // Staging addresses.  SQ counters showed the staging path issuing ~70 VALU instructions per K tile and wave (64-bit
+  // address arithmetic, segment selects, tail clamps and masks) -- 4.4 per MFMA, a quarter of the kernel's time.  So:
+  // every thread keeps CONSTANT 32-bit byte offsets relative to a UNIFORM tile base (scalar arithmetic; the loads take
+  // the `saddr + voffset` form), and interior tiles (no K tail, no N tail for the k-major layout) take a path without
+  // clamps and masks.  Only tail tiles and unaligned operands use the general gx_ld4 / gx_mask4 path.
+  unsigned oa1[NA], oa2[NA], ob1[NB], ob2[NB];
 #pragma unroll
   for (int p = 0; p < NA; ++p) {
-    const int idx = p * 256 + tid, r = idx >> 3;
+    const int idx = p * 256 + tid, r = idx >> 3, kq = (idx & 7) * 4;
     const int gm = min(m0 + r, d.M - 1);                     // rows past M repeat the last row: never stored
-    pa1[p] = A1 + (size_t)gm * d.lda;
-    pa2[p] = A2 ? A2 + (size_t)gm * d.lda2 : pa1[p];
+    oa1[p] = (unsigned)(((size_t)gm * d.lda + kq) * 4);
+    oa2[p] = (unsigned)(((size_t)gm * d.lda2 + kq) * 4);
   }
 #pragma unroll
   for (int p = 0; p < NB; ++p) {
     const int idx = p * 256 + tid;
     if (!B_KM) {
-      const int gn = min(n0 + (idx >> 3), d.N - 1);
-      pb1[p] = B1 + (size_t)gn * d.ldb;
-      pb2[p] = B2 ? B2 + (size_t)gn * d.ldb2 : pb1[p];
-    } else {                                                 // k-major: the row (k) changes per tile; keep the column part
-      pb1[p] = B1;
-      pb2[p] = B2 ? B2 : B1;
+      const int gn = min(n0 + (idx >> 3), d.N - 1), kq = (idx & 7) * 4;
+      ob1[p] = (unsigned)(((size_t)gn * d.ldb + kq) * 4);
+      ob2[p] = (unsigned)(((size_t)gn * d.ldb2 + kq) * 4);
+    } else {
+      const int kr = idx >> 4, nq = (idx & 15) * 4;
+      ob1[p] = (unsigned)(((size_t)kr * d.ldb + n0 + nq) * 4);
+      ob2[p] = (unsigned)(((size_t)kr * d.ldb2 + n0 + nq) * 4);
     }
   }
+  const bool fast_ok = VEC && d.b_kblk_log2 == 0 && (!B_KM || n0 + BN <= d.N);
+  bool fs[2] = {false, false};                              // register stage holds an interior tile (no masks)
 
-  auto load_tile = [&](int t, float4 (&xa)[NA], float4 (&xb)[NB], int (&ma)[NA], int (&mb)[NB]) {
+  auto load_tile = [&](int t, float4 (&xa)[NA], float4 (&xb)[NB], int (&ma)[NA], int (&mb)[NB], bool& fast) {
     const bool s2 = t >= nt1;
     const int ldb = s2 ? d.ldb2 : d.ldb, K = s2 ? K2 : K1;
     const int k0 = (s2 ? t - nt1 : t) * GX_BK;
+    fast = fast_ok && k0 + GX_BK <= K;
+    if (fast) {
+      const char* __restrict__ ab = reinterpret_cast<const char*>((s2 ? A2 : A1) + k0);
+      const char* __restrict__ bb = reinterpret_cast<const char*>((s2 ? B2 : B1) + (B_KM ? (size_t)k0 * ldb : (size_t)k0));
+#pragma unroll
+      for (int p = 0; p < NA; ++p) xa[p] = *reinterpret_cast<const float4*>(ab + (s2 ? oa2[p] : oa1[p]));
+#pragma unroll
+      for (int p = 0; p < NB; ++p) xb[p] = *reinterpret_cast<const float4*>(bb + (s2 ? ob2[p] : ob1[p]));
+      return;
+    }
+    const float* __restrict__ A = s2 ? A2 : A1;
+    const float* __restrict__ B = s2 ? B2 : B1;
+    const int lda = s2 ? d.lda2 : d.lda;
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
-      const int kq = ((p * 256 + tid) & 7) * 4;
-      xa[p] = gx_ld4<VEC>(s2 ? pa2[p] : pa1[p], k0 + kq, K, ma[p]);
+      const int idx = p * 256 + tid, r = idx >> 3, kq = (idx & 7) * 4;
+      const int gm = min(m0 + r, d.M - 1);
+      xa[p] = gx_ld4<VEC>(A + (size_t)gm * lda, k0 + kq, K, ma[p]);
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = p * 256 + tid;
-      const float* __restrict__ bp = s2 ? pb2[p] : pb1[p];
       if (!B_KM) {                                          // B[n][k]
-        const int kq = (idx & 7) * 4;
+        const int r = idx >> 3, kq = (idx & 7) * 4;
+        const int gn = min(n0 + r, d.N - 1);
+        const float* __restrict__ bp = B + (size_t)gn * ldb;
         if (d.b_kblk_log2 > 0) {
           // k is cut into blocks of 2^lg: block q of row n starts at B + q * b_kblk_stride + n * ldb (the stacked
           // [C][F][16] weights of the per-channel GCNs read as one [F][16 C] operand)
@@ -215,26 +237,27 @@ gemm_ex_kernel(const msde_gemm_desc d) {
       } else {                                              // B[k][n]: 16 float4 per k row
         const int kr = idx >> 4, nq = (idx & 15) * 4;
         const int gk = min(k0 + kr, K - 1);
-        xb[p] = gx_ld4<VEC>(bp + (size_t)gk * ldb, n0 + nq, d.N, mb[p]);
+        xb[p] = gx_ld4<VEC>(B + (size_t)gk * ldb, n0 + nq, d.N, mb[p]);
         if (k0 + kr >= K) mb[p] = 0;
       }
     }
   };
-  auto store_tile = [&](int s, const float4 (&xa)[NA], const float4 (&xb)[NB], const int (&ma)[NA], const int (&mb)[NB]) {
+  auto store_tile = [&](int s, const float4 (&xa)[NA], const float4 (&xb)[NB], const int (&ma)[NA], const int (&mb)[NB],
+                        bool fast) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       const int idx = p * 256 + tid, r = idx >> 3, kq = (idx & 7) * 4;
-      *reinterpret_cast<float4*>(&As[s][r * GX_LDK + kq]) = gx_mask4(xa[p], ma[p]);
+      *reinterpret_cast<float4*>(&As[s][r * GX_LDK + kq]) = fast ? xa[p] : gx_mask4(xa[p], ma[p]);
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       const int idx = p * 256 + tid;
       if (!B_KM) {
         const int r = idx >> 3, kq = (idx & 7) * 4;
-        *reinterpret_cast<float4*>(&Bs[s][r * GX_LDK + kq]) = gx_mask4(xb[p], mb[p]);
+        *reinterpret_cast<float4*>(&Bs[s][r * GX_LDK + kq]) = fast ? xb[p] : gx_mask4(xb[p], mb[p]);
       } else {
         const int kr = idx >> 4, nq = (idx & 15) * 4;
-        *reinterpret_cast<float4*>(&Bs[s][kr * GX_LDN + nq]) = gx_mask4(xb[p], mb[p]);
+        *reinterpret_cast<float4*>(&Bs[s][kr * GX_LDN + nq]) = fast ? xb[p] : gx_mask4(xb[p], mb[p]);
       }
     }
   };
@@ -277,22 +300,22 @@ gemm_ex_kernel(const msde_gemm_desc d) {
   };
 
   if (ntiles > 0) {
-    load_tile(0, ra[0], rb[0], ka[0], kb_[0]);
-    if (ntiles > 1) load_tile(1, ra[1], rb[1], ka[1], kb_[1]);
-    store_tile(0, ra[0], rb[0], ka[0], kb_[0]);
+    load_tile(0, ra[0], rb[0], ka[0], kb_[0], fs[0]);
+    if (ntiles > 1) load_tile(1, ra[1], rb[1], ka[1], kb_[1], fs[1]);
+    store_tile(0, ra[0], rb[0], ka[0], kb_[0], fs[0]);
     __syncthreads();
     // iteration t: register stage t&1 (tile t, already in LDS) is refilled with tile t+2; tile t is multiplied; tile
     // t+1 (register stage (t+1)&1, requested one iteration ago) moves to LDS stage (t+1)&1, last read in iteration t-1
     const bool dbg_noload = (d.flags & 256) != 0, dbg_nosync = (d.flags & 512) != 0;   // diagnostics (tools/bench_gemm_ex.py)
     for (int t = 0; t < ntiles; t += 2) {
-      if (t + 2 < ntiles && !dbg_noload) load_tile(t + 2, ra[0], rb[0], ka[0], kb_[0]);
+      if (t + 2 < ntiles && !dbg_noload) load_tile(t + 2, ra[0], rb[0], ka[0], kb_[0], fs[0]);
       compute_tile(0);
-      if (t + 1 < ntiles && !dbg_noload) store_tile(1, ra[1], rb[1], ka[1], kb_[1]);
+      if (t + 1 < ntiles && !dbg_noload) store_tile(1, ra[1], rb[1], ka[1], kb_[1], fs[1]);
       if (!dbg_nosync) __syncthreads();
       if (t + 1 < ntiles) {
-        if (t + 3 < ntiles && !dbg_noload) load_tile(t + 3, ra[1], rb[1], ka[1], kb_[1]);
+        if (t + 3 < ntiles && !dbg_noload) load_tile(t + 3, ra[1], rb[1], ka[1], kb_[1], fs[1]);
         compute_tile(1);
-        if (t + 2 < ntiles && !dbg_noload) store_tile(0, ra[0], rb[0], ka[0], kb_[0]);
+        if (t + 2 < ntiles && !dbg_noload) store_tile(0, ra[0], rb[0], ka[0], kb_[0], fs[0]);
         if (!dbg_nosync) __syncthreads();
       }
     }
