@@ -428,31 +428,33 @@ def test_linear_mfma_gemm(dev, M, N, K, bias):
     scalar-load path for K % 4 != 0) vs torch CPU fp64 accumulation of the same fp32 inputs."""
     from moleculesde_amd import hip
     hip.set_linear_mode("hip")           # exercise the hand-written kernels for all three products
-    g = torch.Generator().manual_seed(M + N + K)
-    x = torch.randn(M, K, generator=g)
-    w = torch.randn(N, K, generator=g) / math.sqrt(K)
-    b = torch.randn(N, generator=g) if bias else None
-    gy = torch.randn(M, N, generator=g)
-    xd = x.to(dev).requires_grad_(True)
-    wd = w.to(dev).requires_grad_(True)
-    bd = b.to(dev).requires_grad_(True) if bias else None
-    y = hip.linear(xd, wd, bd)
-    y.backward(gy.to(dev))
-    x64, w64 = x.double(), w.double()
-    yr = x64 @ w64.t() + (b.double() if bias else 0)
-    # fp32 fma chain of length K: error ~ sqrt(K) * 2^-24 * |x||w|
-    assert_close(y, yr, 2e-6 * math.sqrt(K) + 1e-6, 1e-5, "linear fwd")
-    assert_close(xd.grad, gy.double() @ w64, 2e-6 * math.sqrt(N) + 1e-6, 1e-5 * math.sqrt(N), "linear dgrad")
-    gwr = gy.double().t() @ x64
-    assert_close(wd.grad, gwr, 1e-5, 2e-6 * math.sqrt(M) * 4, "linear wgrad")
-    if bias:
-        assert_close(bd.grad, gy.double().sum(0), 1e-5, 2e-6 * math.sqrt(M) * 4, "linear bias grad")
-    # reproducible: the split-M slabs are reduced in a fixed order
-    xd2 = x.to(dev).requires_grad_(True)
-    wd2 = w.to(dev).requires_grad_(True)
-    hip.linear(xd2, wd2, bd.detach() if bias else None).backward(gy.to(dev))
-    assert torch.equal(wd2.grad, wd.grad) and torch.equal(xd2.grad, xd.grad)
-    hip.set_linear_mode("auto")
+    try:
+        g = torch.Generator().manual_seed(M + N + K)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g) if bias else None
+        gy = torch.randn(M, N, generator=g)
+        xd = x.to(dev).requires_grad_(True)
+        wd = w.to(dev).requires_grad_(True)
+        bd = b.to(dev).requires_grad_(True) if bias else None
+        y = hip.linear(xd, wd, bd)
+        y.backward(gy.to(dev))
+        x64, w64 = x.double(), w.double()
+        yr = x64 @ w64.t() + (b.double() if bias else 0)
+        # fp32 fma chain of length K: error ~ sqrt(K) * 2^-24 * |x||w|
+        assert_close(y, yr, 2e-6 * math.sqrt(K) + 1e-6, 1e-5, "linear fwd")
+        assert_close(xd.grad, gy.double() @ w64, 2e-6 * math.sqrt(N) + 1e-6, 1e-5 * math.sqrt(N), "linear dgrad")
+        gwr = gy.double().t() @ x64
+        assert_close(wd.grad, gwr, 1e-5, 2e-6 * math.sqrt(M) * 4, "linear wgrad")
+        if bias:
+            assert_close(bd.grad, gy.double().sum(0), 1e-5, 2e-6 * math.sqrt(M) * 4, "linear bias grad")
+        # reproducible: the split-M slabs are reduced in a fixed order
+        xd2 = x.to(dev).requires_grad_(True)
+        wd2 = w.to(dev).requires_grad_(True)
+        hip.linear(xd2, wd2, bd.detach() if bias else None).backward(gy.to(dev))
+        assert torch.equal(wd2.grad, wd.grad) and torch.equal(xd2.grad, xd.grad)
+    finally:
+        hip.set_linear_mode("auto")
     xd3 = x.to(dev).requires_grad_(True)
     wd3 = w.to(dev).requires_grad_(True)
     y3 = hip.linear(xd3, wd3, bd.detach() if bias else None)

@@ -866,3 +866,109 @@ def test_golden_f3_variants_2d3d(dev, tag):
             x, _ = sampler.predictor_update(m.sde_pos, m, h2.detach(), b, x, vt,
                                             noise=torch.from_numpy(g["vp.pred_noise"][i]).to(dev))
             assert_close(x, g["vp.pred_traj"][i], 1e-3, 1e-4, f"VP predictor step {i}")
+
+
+# ------------------------------------------------------------------ robustness of the step machinery ---
+def _quiet_trainer(dev, emb=64, seed=5):
+    from moleculesde_amd import pretrain
+    args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=0, emb_dim=emb)
+    torch.manual_seed(seed)
+    tr = pretrain.Trainer(args, dev)
+    tr.overlap_streams = False
+    return tr
+
+
+def test_eager_steps_with_gpu_far_behind_host(dev):
+    """The eager path uploads pointer tables (Adam chunk table, slab rows, grouped-GEMM problems) from pinned host
+    images.  With the GPU several steps behind the host (a long sleep kernel in front), the images are rotated / guarded
+    by events, so the result equals a run that synchronises after every step."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_batch
+    batches = [G.prepare_batch(make_batch(12, seed=70 + s, sizes=[5 + (s + i) % 9 for i in range(12)]), dev) for s in range(4)]
+    res = []
+    for delayed in (False, True):
+        tr = _quiet_trainer(dev)
+        for m in tr.models.values():
+            disable_dropout(m)
+        tr.noise = G.CpuReplayNoise(123)
+        tr.models["SDE_2Dto3D_model"].noise = tr.noise
+        if delayed:
+            torch.cuda._sleep(int(2.0e9))              # ~1 s of GPU time queued in front of everything
+        for s in range(6):
+            tr.step(batches[s % 4])                    # different shapes -> different gradient / slab addresses per step
+            if not delayed:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        res.append(tr.opt.flat_p.clone())
+    assert torch.equal(res[0], res[1])
+
+
+def test_replay_after_workspaces_grew(dev):
+    """capture on a small batch, eager step on a LARGER one (grow-on-demand workspaces are replaced), replay the small
+    graph: outgrown workspaces stay alive for the graph, so the replay matches an eager step."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_batch
+    small = G.prepare_batch(make_batch(8, seed=81), dev)
+    big = G.prepare_batch(make_batch(96, seed=82), dev)
+
+    class Fixed(G.DeviceNoise):
+        def __init__(self):
+            super().__init__(seed=3)
+            g = torch.Generator().manual_seed(9)
+            self.big, self.ints = torch.randn(4096, 3, generator=g).to(dev), torch.randint(0, 1000, (512,), generator=g).to(dev)
+            self.perm = {}
+
+        def randn_like(self, x): return self.big[:x.size(0)].clone()
+        def randint(self, high, size, device): return self.ints[:size[0]].clone()
+
+        def randperm_pair(self, n, device):
+            if n not in self.perm:
+                self.perm[n] = (torch.randperm(n, generator=torch.Generator().manual_seed(n)).int().to(device),
+                                torch.randperm(n, generator=torch.Generator().manual_seed(n + 1)).int().to(device))
+            return self.perm[n]
+    outs = []
+    for use_graph in (True, False):
+        tr = _quiet_trainer(dev, seed=6)
+        for m in tr.models.values():
+            disable_dropout(m)
+        tr.noise = Fixed()
+        tr.models["SDE_2Dto3D_model"].noise = tr.noise
+        tr.step(small)
+        if use_graph:
+            tr.capture(small)
+        tr.step(big)                                   # larger shape: scratch / slab arena / BN workspace grow
+        for _ in range(2):
+            (tr.step_graph if use_graph else tr.step)(small)
+        torch.cuda.synchronize()
+        outs.append(tr.opt.flat_p.clone())
+    d = float((outs[0] - outs[1]).norm() / outs[1].norm())
+    assert d < 1e-5, d
+
+
+def test_eager_steps_after_capture_draw_fresh_dropout_masks(dev):
+    """After a capture the dropout seeds come from the device step counter; the eager step advances it too, so two
+    eager steps on the same batch with identical other noise still differ through the attention / FFN dropout."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_batch
+    tr = _quiet_trainer(dev, seed=7)
+    b = G.prepare_batch(make_batch(16, seed=83), dev)
+    tr.step(b)
+    tr.capture(b)
+
+    class Fixed(G.DeviceNoise):
+        z, t = torch.randn(4096, 3).to(dev), torch.randint(0, 1000, (64,)).to(dev)
+        def randn_like(self, x): return self.z[:x.size(0)].clone()
+        def randint(self, high, size, device): return self.t[:size[0]].clone()
+        def randperm_pair(self, n, device):
+            p = torch.arange(n - 1, -1, -1, dtype=torch.int32, device=device)
+            return p, p
+    tr.noise = Fixed()
+    tr.models["SDE_2Dto3D_model"].noise = tr.noise
+    sd = {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in tr.models.items()}
+    losses = []
+    for _ in range(2):
+        for k, m in tr.models.items():
+            m.load_state_dict(sd[k])
+        _, parts = tr.step(b)
+        losses.append(float(parts["2Dto3D"]))
+    assert losses[0] != losses[1], losses

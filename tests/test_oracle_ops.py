@@ -118,3 +118,48 @@ def test_vesde_known_answers():
     assert torch.allclose(std, torch.tensor([0.2, 0.2 * 5 ** 0.5, 1.0]), atol=1e-5)
     _, G = ve.discretize(torch.zeros(1, 3), torch.tensor([0.5]))
     assert abs(float(G) - 0.025345) < 1e-5        # SURVEY.md App. C.5 known answer
+
+
+def test_transformer_conv_multi_head_multi_edge_hand_computed():
+    """PyG 2.0.2 TransformerConv semantics (App. A.4) on a case small enough to evaluate by hand with explicit loops:
+    2 heads x 2 channels, node 2 receives THREE edges (two from the same source: duplicate edges are separate
+    messages), node 3 receives none (in-degree 0 -> only lin_skip), the edge term enters BOTH key and value, scores are
+    scaled by 1/sqrt(C) and normalised per (target, head) with the +1e-16 denominator."""
+    torch.manual_seed(0)
+    H, C, Fin, Fe = 2, 2, 3, 2
+    tc = R.TransformerConv(Fin, C, H, 0.0, Fe)
+    x = torch.randn(4, Fin)
+    ei = torch.tensor([[0, 1, 0, 2], [2, 2, 2, 1]])       # edges 0->2, 1->2, 0->2 (duplicate), 2->1
+    ea = torch.randn(4, Fe)
+    out = tc(x, ei, ea)
+    q, k, v, s = tc.lin_query(x), tc.lin_key(x), tc.lin_value(x), tc.lin_skip(x)
+    e = tc.lin_edge(ea)
+    exp = s.clone()
+    for tgt in range(4):
+        inc = [m for m in range(ei.size(1)) if int(ei[1, m]) == tgt]
+        for h in range(H):
+            sl = slice(h * C, (h + 1) * C)
+            scores = [float((q[tgt, sl] * (k[int(ei[0, m]), sl] + e[m, sl])).sum()) / math.sqrt(C) for m in inc]
+            if not inc:
+                continue
+            mx = max(scores)
+            w = [math.exp(sc - mx) for sc in scores]
+            den = sum(w) + 1e-16
+            for m, wm in zip(inc, w):
+                exp[tgt, sl] = exp[tgt, sl] + (v[int(ei[0, m]), sl] + e[m, sl]) * (wm / den)
+    assert torch.allclose(out, exp, atol=1e-6), (out - exp).abs().max()
+    assert torch.allclose(out[3], s[3]) and torch.allclose(out[0], s[0])          # in-degree 0: skip connection only
+    # the two duplicate edges 0->2 are two messages: removing one changes the result
+    out2 = tc(x, ei[:, [0, 1, 3]], ea[[0, 1, 3]])
+    assert not torch.allclose(out2[2], out[2])
+
+
+def test_to_dense_adj_duplicates_and_cross_molecule_offsets():
+    """PyG to_dense_adj (App. A.6): duplicate edges ADD, local indices are relative to each molecule's first atom, and
+    entries of the padded rows / columns stay zero."""
+    batch = torch.tensor([0, 0, 0, 1, 1])
+    ei = torch.tensor([[0, 0, 0, 2, 3, 4, 4], [1, 1, 1, 0, 4, 3, 3]])
+    ea = torch.tensor([1.0, 2.0, 4.0, 8.0, 16.0, 32.0, 64.0])
+    adj = R.to_dense_adj(ei, batch, ea, 3, 2)
+    assert adj[0].tolist() == [[0.0, 7.0, 0.0], [0.0, 0.0, 0.0], [8.0, 0.0, 0.0]]
+    assert adj[1].tolist() == [[0.0, 16.0, 0.0], [96.0, 0.0, 0.0], [0.0, 0.0, 0.0]]
