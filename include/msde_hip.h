@@ -81,6 +81,34 @@ int msde_plan_build(const int* x_raw, int K, const int* atom_off, const int* bon
 int msde_plan_row_lists(const int* codes, const int* n_dev, int K, int R, int* cnt, int* list_ptr, int* items,
                         void* stream);
 
+/* ------------------------------------------------------------------ twice-differentiable force path -------- */
+/* Non-GEMM members of the closed operator set of the MD17 energy/force path (moleculesde_amd/dd.py; replaces the ATen
+ * operators autograd differentiates twice in examples/finetune_MD17.py:47-78 over Geom3D/models/schnet.py:85-125).
+ * kind 0: shifted softplus (schnet.py:213-216), 1: cosine cutoff with p0 = cutoff (schnet.py:186), 2: reciprocal;
+ * order = derivative order 0..2.  mask (may be NULL): entries < 0 give 0. */
+int msde_dd_unary(const float* x, const int* mask, long long n, int kind, int order, float p0, float* y, void* stream);
+/* Gaussian smearing exp(coeff (d - mu_g)^2) (schnet.py:205-207) and its 1st / 2nd derivative in d: y [E][G];
+ * rows with src[e] < 0 (src may be NULL) are zero. */
+int msde_dd_rbf(const float* d, const int* src, const float* mu, int E, int G, float coeff, int order, float* y,
+                void* stream);
+/* op 0: y = alpha a b, 1: y = a + b, 2: y = alpha a (b unused) */
+int msde_dd_binary(const float* a, const float* b, long long n, int op, float alpha, float* y, void* stream);
+/* y[e][k] = M[e][k] s[e]   and   y[e] = sum_k a[e][k] b[e][k] (fixed lane order) */
+int msde_dd_mul_rows(const float* M, const float* s, int E, int K, float* y, void* stream);
+int msde_dd_row_dot(const float* a, const float* b, int E, int K, float* y, void* stream);
+/* y[e] = pos[src_e] - pos[dst_e] (schnet.py:98-99; zero on padded slots) and its adjoint over the by-target CSR
+ * (rowptr) and its by-source view (rowptr_s, perm_s): y[i] = sum_{src_e = i} g[e] - sum_{dst_e = i} g[e]. */
+int msde_dd_edge_diff(const float* pos, const int* src, const int* dst, int E, float* y, void* stream);
+int msde_dd_edge_scatter(const float* g, const int* rowptr, const int* rowptr_s, const int* perm_s, int N, float* y,
+                         void* stream);
+/* y[e] = |v[e]| over 3 coordinates; 1 where src[e] < 0 */
+int msde_dd_row_norm(const float* v, const int* src, int E, float* y, void* stream);
+/* adjoint of the per-molecule readout (schnet.py:122): y[i] = g[batch[i]] (/ atoms of that molecule if mean) */
+int msde_dd_seg_expand(const float* g, const int* batch, const int* mol_ptr, int N, int K, int mean, float* y,
+                       void* stream);
+/* adjoint of msde_colsum: y[m][k] = b[k] */
+int msde_dd_broadcast_rows(const float* b, int M, int K, float* y, void* stream);
+
 /* ------------------------------------------------------------------ generic row ops -------- */
 /* torch_scatter.scatter(reduce=sum) over CSR rows: out[i] = sum_{s in [rowptr[i],rowptr[i+1])}
  * rows[perm ? perm[s] : s]; used for every backward "gather by source/target".  D % 4 == 0 or any. */

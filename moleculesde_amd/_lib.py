@@ -66,6 +66,16 @@ SIGNATURES = {
     "msde_dense_loss_bwd": [P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, P, P, P, P, P],
     "msde_plan_build": [P, I, P, P, P, P, P, P, P, I, I, I, I, I] + [P] * 23 + [P],
     "msde_plan_row_lists": [P, P, I, I, P, P, P, P],
+    "msde_dd_unary": [P, P, LL, I, I, F, P, P],
+    "msde_dd_rbf": [P, P, P, I, I, F, I, P, P],
+    "msde_dd_binary": [P, P, LL, I, F, P, P],
+    "msde_dd_mul_rows": [P, P, I, I, P, P],
+    "msde_dd_row_dot": [P, P, I, I, P, P],
+    "msde_dd_edge_diff": [P, P, P, I, P, P],
+    "msde_dd_edge_scatter": [P, P, P, P, I, P, P],
+    "msde_dd_row_norm": [P, P, I, P, P],
+    "msde_dd_seg_expand": [P, P, P, I, I, I, P, P],
+    "msde_dd_broadcast_rows": [P, I, I, P, P],
     "msde_set_row_bound": [I, P],
     "msde_clear_row_bounds": [],
     "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],

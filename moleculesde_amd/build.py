@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmsde_hip.so")
-SOURCES = ["graph.hip", "gin.hip", "schnet.hip", "cfconv_fused.hip", "cfconv_fused_bwd.hip", "sde2d3d.hip", "linear.hip", "gemm_ex.hip", "dense_head.hip", "plan.hip", "norm.hip", "contrastive.hip", "optim.hip", "pointwise.hip", "gat_tail.hip"]
+SOURCES = ["graph.hip", "gin.hip", "schnet.hip", "cfconv_fused.hip", "cfconv_fused_bwd.hip", "sde2d3d.hip", "linear.hip", "gemm_ex.hip", "dense_head.hip", "plan.hip", "dd.hip", "norm.hip", "contrastive.hip", "optim.hip", "pointwise.hip", "gat_tail.hip"]
 
 
 def needs_build():

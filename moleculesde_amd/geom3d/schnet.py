@@ -136,36 +136,28 @@ class SchNet(nn.Module):
 
     def _forward_force_path(self, z, pos, pl, return_latent):
         """Energy path that is differentiable w.r.t. positions, twice (finetune_MD17.py:47-78: forces by
-        autograd.grad(create_graph=True), then backward through them).  The radius CSR still comes from
-        the HIP kernels (indices carry no gradient); distances, smearing, cutoff and the dense layers use
-        library ops that autograd can differentiate twice; the message passing uses the closed family of
-        bilinear edge kernels (hip.edge_aggregate_dd)."""
-        import math
+        autograd.grad(create_graph=True), then backward through them).  Every operator between the positions and the
+        energy -- coordinate differences, distances, smearing, cutoff, filter MLP, the dense layers, the message passing
+        and the readout -- is a kernel-backed member of the closed operator set of moleculesde_amd.dd, so the first AND
+        the second differentiation only launch library kernels.  The radius CSR comes from the radius kernels (indices
+        carry no gradient) and the atom embedding, which does not depend on the positions, from the embedding kernel."""
+        from .. import dd
         rplan, _ = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors)
-        valid = (rplan.src >= 0)
-        src = rplan.src.clamp(min=0).long()
-        dst = rplan.dst.clamp(min=0).long()
-        diff = pos[src] - pos[dst]
-        d2 = (diff * diff).sum(-1)
-        # padded slots: distance of an atom to itself would be sqrt(0) (infinite slope); give them d = 1
-        dist = torch.sqrt(torch.where(valid, d2, torch.ones_like(d2)))
+        dist = dd.row_norm(dd.edge_diff(pos, rplan), rplan)
         de = self.distance_expansion
-        rbf = torch.exp(de.coeff * (dist.unsqueeze(1) - de.offset.unsqueeze(0)) ** 2)
-        C = 0.5 * (torch.cos(dist * math.pi / self.cutoff) + 1.0) * valid.to(dist.dtype)
-        h = F.embedding(z, self.embedding.weight)
+        rbf = dd.rbf(dist, rplan.src, de.offset, de.coeff)
+        C = dd.cosine_cutoff(dist, self.cutoff, rplan.src)
+        ptr, nodes = _plan.z_lists(pl, self.node_class)
+        h = hip.embedding_sum(self.embedding.weight, pl.z_codes, ptr, nodes)
         for blk in self.interactions:
             m0, m2 = blk.mlp[0], blk.mlp[2]
-            Wf = F.linear(_nn.shifted_softplus(F.linear(rbf, m0.weight, m0.bias)), m2.weight, m2.bias) * C.unsqueeze(1)
-            x1 = F.linear(h, blk.conv.lin1.weight)
-            agg = hip.edge_aggregate_dd(x1, Wf, rplan)
-            x = F.linear(agg, blk.conv.lin2.weight, blk.conv.lin2.bias)
-            h = h + F.linear(_nn.shifted_softplus(x), blk.lin.weight, blk.lin.bias)
-        h = F.linear(_nn.shifted_softplus(F.linear(h, self.lin1.weight, self.lin1.bias)), self.lin2.weight, self.lin2.bias)
-        bidx = pl.batch_i32.long()
-        out = torch.zeros(pl.B, h.size(1), dtype=h.dtype, device=h.device).index_add(0, bidx, h)
-        if self.readout == "mean":
-            cnt = (pl.mol_ptr[1:] - pl.mol_ptr[:-1]).clamp(min=1).to(h.dtype)
-            out = out / cnt.unsqueeze(1)
+            Wf = dd.mul_rows(dd.linear(dd.ssp(dd.linear(rbf, m0.weight, m0.bias)), m2.weight, m2.bias), C)
+            x1 = dd.mm_nt(h, blk.conv.lin1.weight)
+            agg = dd.edge_aggregate(x1, Wf, rplan)
+            x = dd.linear(agg, blk.conv.lin2.weight, blk.conv.lin2.bias)
+            h = dd.add(h, dd.linear(dd.ssp(x), blk.lin.weight, blk.lin.bias))
+        h = dd.linear(dd.ssp(dd.linear(h, self.lin1.weight, self.lin1.bias)), self.lin2.weight, self.lin2.bias)
+        out = dd.seg_reduce(h, pl.mol_ptr, pl.batch_i32, self.readout == "mean")
         if return_latent:
             return out, h
         return out

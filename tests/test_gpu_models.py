@@ -574,6 +574,44 @@ def test_md17_force_path_double_backward(dev, bs):
     assert_close(head.weight.grad, ohead.weight.grad, 1e-3, 1e-5, "head grad")
 
 
+def test_md17_force_path_runs_on_library_kernels(dev):
+    """§8 a18: energy -> forces (create_graph) -> backward through the forces launches the kernels of the closed
+    twice-differentiable operator set (moleculesde_amd.dd) and no torch operator inside SchNet.  What remains on torch is
+    outside the library's boundary: the caller's own head / loss (finetune_MD17.py:50,60-72) and the sums the autograd
+    ENGINE forms where one tensor feeds two operators (plain elementwise adds)."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import dd
+    from moleculesde_amd.synthetic import make_md17_batch
+    from torch.profiler import profile, ProfilerActivity
+    torch.manual_seed(5)
+    sch = G.SchNet(hidden_channels=64, num_filters=32, num_interactions=2, num_gaussians=51, cutoff=10, readout="mean",
+                   node_class=119).to(dev)
+    b = G.prepare_batch(make_md17_batch(4, seed=3, n_atoms=21), dev)
+
+    def run():
+        pos = b.positions.clone().requires_grad_(True)
+        rep = sch(b.x, pos, b.batch)                           # [B, 64]; a linear head would be the caller's operator
+        force = torch.autograd.grad(rep, pos, grad_outputs=torch.ones_like(rep), create_graph=True)[0]
+        torch.autograd.backward([rep, force], [torch.ones_like(rep), torch.ones_like(force)])
+    run()
+    torch.cuda.synchronize()
+    dd.CALLS.clear()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        run()
+        torch.cuda.synchronize()
+    assert dd.CALLS.get("msde_gemm_ex", 0) > 20 and dd.CALLS.get("msde_linear_bwd_w", 0) > 10, dd.CALLS
+    assert dd.CALLS.get("msde_dd_rbf", 0) >= 3 and dd.CALLS.get("msde_dd_edge_scatter", 0) >= 1, dd.CALLS
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    ours = ("dd_", "gemm_ex", "gemm_f32_mfma", "wgrad", "reduce_slabs", "colsum", "cfconv_aggregate", "radius_", "scan",
+            "embedding_sum", "segment_sum", "transpose")
+    foreign = sorted({n for n in names if not any(k in n for k in ours)})
+    # allowed: the test's own clone / ones_like, and the autograd engine's gradient accumulation (a + b)
+    allowed = ("FillFunctor", "Memcpy", "Memset", "CUDAFunctor_add", "direct_copy", "elementwise_kernel_manual_unroll")
+    bad = [n for n in foreign if not any(k in n for k in allowed)]
+    assert not bad, bad
+    assert not any("Cijk" in n for n in names)          # no vendor GEMM
+
+
 def test_fusion_sets_alias_flat_parameters(dev):
     """The trainer's optimiser lays every fusion set (embedding tables of one encoder; query/key/value/skip
     projections of one TransformerConv) out back to back, so hip.cat_params returns a VIEW of the parameters

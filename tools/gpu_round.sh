@@ -19,6 +19,8 @@ head)
   timeout 900 python -m pytest tests/test_gpu_models.py -q -x -k "dense_head or sde3d2d or full_pretrain or losscurve_through" > $O/head_test.log 2>&1; echo "head test rc=$?"; tail -40 $O/head_test.log;;
 plan)
   timeout 900 python -m pytest tests/test_gpu_plan.py -q -x > $O/plan_test.log 2>&1; echo "plan test rc=$?"; tail -40 $O/plan_test.log;;
+md17)
+  timeout 900 python -m pytest tests/test_gpu_models.py -q -x -k "md17" > $O/md17_test.log 2>&1; echo "md17 test rc=$?"; tail -40 $O/md17_test.log;;
 dptest)
   timeout 1200 python -m pytest tests/test_gpu_dp.py -q -x > $O/dptest.log 2>&1; echo "dptest rc=$?"; tail -60 $O/dptest.log;;
 bench)
