@@ -33,7 +33,7 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
                           const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ dst,
                           const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                           const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
-                          float* __restrict__ slabs) {
+                          float* __restrict__ slabs, int dbg) {
   constexpr int RS = 2 * KK1 + 1;
   extern __shared__ float lds[];
   float* W2s = lds;                            // [128][129]
@@ -102,6 +102,10 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
     if (ec + CB_TE < e_end) fetch_meta(ec + CB_TE);
     // g_pre2 in accumulator layout straight from the gathers: gp[rb][s] = g_agg[dst] * x1[src] * C
     float gp0[16], gp1[16];
+    if (dbg & 1) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { gp0[s] = c_s[cb_row(s, lhalf)]; gp1[s] = c_s[32 + cb_row(s, lhalf)]; }
+    } else {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       int row = cb_row(s, lhalf);
@@ -111,7 +115,9 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
       gp0[s] = ga * xa * c_s[row];          // padding rows: c_s = 0
       gp1[s] = gb * xb * c_s[32 + row];
     }
+    }
     // rbf tile
+    if (!(dbg & 2))
     for (int idx = tid; idx < CB_TE * 2 * KK1; idx += 256) {
       int r = idx / (2 * KK1), g = idx % (2 * KK1);
       float v = 0.f;
@@ -127,6 +133,7 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    if (!(dbg & 64)) {
 #pragma unroll
     for (int kk = 0; kk < KK1; ++kk) {
       float a0 = rbf_t[lcol * RS + 2 * kk + lhalf];
@@ -134,7 +141,19 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, w1r[kk], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, w1r[kk], acc1, 0, 0, 0);
     }
+    }
     float sg0[16], sg1[16];
+    if (dbg & 4) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int row = cb_row(i, lhalf);
+        hid_t[row * CB_HS + col] = acc0[i];
+        hid_t[(32 + row) * CB_HS + col] = acc1[i];
+        sg0[i] = acc0[i]; sg1[i] = acc1[i];
+        gp_t[row * CB_HS + col] = gp0[i];
+        gp_t[(32 + row) * CB_HS + col] = gp1[i];
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       int row = cb_row(i, lhalf);
@@ -149,9 +168,11 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
       gp_t[(32 + row) * CB_HS + col] = gp1[i];
       sb2 += gp0[i] + gp1[i];
     }
+    }
     __syncthreads();
 
     // ---- g_W2[f][k] += sum_e g_pre2[e][f] h1[e][k]: A = g_pre2 registers, B = h1 rows (same permuted e)
+    if (!(dbg & 8)) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       int row = cb_row(s, lhalf);
@@ -163,10 +184,12 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
         aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp1[s], bB, aW2[j], 0, 0, 0);
       }
     }
+    }
 
     // ---- g_h1[e][k] = sum_f g_pre2[e][f] W2[f][k]
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    if (!(dbg & 16))
 #pragma unroll
     for (int kk = 0; kk < CB_F / 2; ++kk) {
       float a0 = gp_t[lcol * CB_HS + 2 * kk + lhalf];
@@ -183,6 +206,7 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
       sb1 += sg0[i] + sg1[i];
     }
     // ---- g_W1[k][g] += sum_e g_pre1[e][k] rbf[e][g]
+    if (!(dbg & 32))
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       int row = cb_row(s, lhalf);
@@ -199,6 +223,7 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
   // ---- write this workgroup's slab: [128*128 gW2][128*G gW1][128 gb1][128 gb2]
   const size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
   float* slab = slabs + (size_t)blockIdx.x * slab_sz;
+  if (dbg & 128) { if (aW2[0][0] + aW1[0][0] + sb1 + sb2 == 12345.678f) slab[0] = 1.f; return; }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -224,35 +249,38 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
   }
 }
 
-// ---- light variant: 32-edge chunks, W2 in registers -----------------------------------------------------------
-// The kernel above keeps W2 (66 KB) and two 64-row tiles in LDS: 147 KB per workgroup, i.e. the whole CU as far as
-// any other LDS-using kernel is concerned.  In the training step this kernel runs on the second stream beside the
-// latency-critical GIN / 2D->3D chain, and those kernels then wait for a free CU.  Here a wave's W2 slice is the
-// B operand of the W2^T product straight from registers (lane (col, half) <- W2[2kk + half][col]: rows of W2 are
-// read coalesced, no transpose), chunks are one 32-row MFMA block, and a workgroup needs 41 KB of LDS and <= 256
-// VGPRs: it can sit on every CU and still leave room for the other stream's workgroups.
-// Measured (MI355X, bs 256): correct, but without the forward kernel's prefetching its 32-edge chunks cost 112 us
-// standalone against 89 us, and the step is slower with it (75.5k molecules/s at full width, 72.4k at 128
-// workgroups) than with the 147 KB kernel confined to 128 CUs (78.5k).  Kept selectable (MSDE_CFBWD_LIGHT=1) as the
-// starting point for a prefetching two-workgroup version.
-#define CB2_TE 32
-template <int KK1>
-__global__ void __launch_bounds__(256, 2)
-cfconv_fused_bwd_w32_kernel(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
-                            const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ dst,
-                            const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
-                            const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
-                            float* __restrict__ slabs) {
+// ---- software-pipelined variant -------------------------------------------------------------------------------
+// Phase timing of the kernel above (tools/bench_cfconv_bwd.py, MI355X, E = 49090, 256 workgroups, 75.6 us): the
+// MFMA blocks cost 35 us and everything else 40.6 us (prologue 12.5, gathers 10, smearing 6, softplus/sigmoid 6.5, slab
+// write 4-8), with NO overlap between the two: one wave per SIMD, and every phase separated by a barrier.  This variant
+// keeps the arithmetic and the summation order, but
+//   * W2 reaches LDS by 16-byte loads and W1 is staged through LDS (coalesced) instead of 26 strided loads per lane;
+//   * chunk c+1's gathers are issued, and its smearing tile is computed into a SECOND tile buffer, inside the
+//     g_W2 / g_h1 / g_W1 MFMA block of chunk c (MFMAs execute asynchronously: independent VALU / memory instructions
+//     issue in their shadow); per-edge metadata runs two chunks ahead;
+//   * two barriers per chunk instead of four.
+// The only un-overlapped part of a chunk is recomputing pre1 (52 MFMAs) and the softplus / sigmoid that depends on it.
+template <int KK1, int DBG>
+__global__ void __launch_bounds__(256, 1)
+cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
+                               const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ dst,
+                               const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                               const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
+                               float* __restrict__ slabs) {
+  constexpr int dbg = DBG;                     // phase knock-outs for tools/bench_cfconv_bwd.py (0 in the product)
   constexpr int RS = 2 * KK1 + 1;
+  constexpr int RBF_SZ = CB_TE * RS + 64;      // + slack: the gW1 product reads up to column 63 of the last row
+  constexpr int RBF_IT = (CB_TE * 2 * KK1 + 255) / 256;
   extern __shared__ float lds[];
-  float* rbf_t = lds;                          // [32][RS] (+ slack: gW1 reads up to column 63 of the last row)
-  float* hid_t = rbf_t + CB2_TE * RS + 64;     // [32][129] h1
-  float* gp_t = hid_t + CB2_TE * CB_HS;        // [32][129] g_pre2
-  float* c_s = gp_t + CB2_TE * CB_HS;          // [32]
-  float* d_s = c_s + CB2_TE;                   // [32]
-  int* src_s = reinterpret_cast<int*>(d_s + CB2_TE);
-  int* dst_s = src_s + CB2_TE;
-  float* off_s = reinterpret_cast<float*>(dst_s + CB2_TE);   // [64]
+  float* W2s = lds;                            // [128][129]
+  float* rbf_t = W2s + CB_F * CB_HS;           // [2][64][RS]
+  float* hid_t = rbf_t + 2 * RBF_SZ;           // [64][129] h1
+  float* gp_t = hid_t + CB_TE * CB_HS;         // [64][129] g_pre2
+  float* c_s = gp_t + CB_TE * CB_HS;           // [2][64]
+  float* d_s = c_s + 2 * CB_TE;                // [2][64]
+  int* src_s = reinterpret_cast<int*>(d_s + 2 * CB_TE);   // [2][64]
+  int* dst_s = src_s + 2 * CB_TE;              // [2][64]
+  float* off_s = reinterpret_cast<float*>(dst_s + 2 * CB_TE);   // [64]
 
   const float PI_F = 3.14159265358979323846f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -260,33 +288,64 @@ cfconv_fused_bwd_w32_kernel(const float* __restrict__ g_agg, const float* __rest
   const int col = wave * 32 + lcol;
 
   const int E = rowptr[N];
-  const int e_begin = min(blockIdx.x * cpw * CB2_TE, E);
-  const int e_end = min(e_begin + cpw * CB2_TE, E);
+  const int e_begin = min(blockIdx.x * cpw * CB_TE, E);
+  const int e_end = min(e_begin + cpw * CB_TE, E);
+  const int nchunks = (e_end - e_begin + CB_TE - 1) / CB_TE;
 
-  // W2 slice -> registers (coalesced: lanes read consecutive columns of one W2 row); W1 slice through LDS
-  float w1r[KK1], w2r[CB_F / 2];
-#pragma unroll
-  for (int kk = 0; kk < CB_F / 2; ++kk) w2r[kk] = W2[(size_t)(2 * kk + lhalf) * CB_F + col];
-  if (tid < 64) off_s[tid] = tid < G ? offset[tid] : 0.f;
+  // ---- prologue: metadata of chunk 0, W2 -> LDS (16-byte loads), W1 slice -> registers through LDS
+  float m_d = 0.f;
+  int m_s = -1, m_t = -1;
+  auto fetch_meta = [&](int c) {               // registers of threads 0..63; lands while other work runs
+    if (tid < CB_TE) {
+      const int e = e_begin + c * CB_TE + tid;
+      const bool ok = c < nchunks && e < e_end;
+      m_d = ok ? dist[e] : -1.f;
+      m_s = ok ? src[e] : -1;
+      m_t = ok ? dst[e] : -1;
+    }
+  };
+  auto store_meta = [&](int c) {
+    if (tid < CB_TE) {
+      const int o = (c & 1) * CB_TE + tid;
+      const bool ok = m_t >= 0;
+      d_s[o] = ok ? m_d : 0.f;
+      c_s[o] = ok ? 0.5f * (cosf(m_d * PI_F / cutoff) + 1.0f) : 0.f;
+      src_s[o] = m_s;
+      dst_s[o] = m_t;
+    }
+  };
+  fetch_meta(0);
   {
-    float* stage = hid_t;                        // 64 x G floats fit in hid_t + gp_t
-    const int half_n = 64 * G;
+    const float4* W2v = reinterpret_cast<const float4*>(W2);
+    float4 w[CB_F * CB_F / 4 / 256];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      for (int i = tid; i < half_n; i += 256) stage[i] = W1[(size_t)r * half_n + i];
-      __syncthreads();
-      if ((wave >> 1) == r) {
-        const int lrow = (wave & 1) * 32 + lcol;
+    for (int i = 0; i < CB_F * CB_F / 4 / 256; ++i) w[i] = W2v[tid + 256 * i];
+    float* stage = hid_t;                      // W1 [128][G] (<= 32 KB) fits in hid_t
+    // fixed trip counts: every load is issued before the first store (a run-time bound serialises 26 round trips)
+    float w1v[CB_F * 2 * KK1 / 256];
 #pragma unroll
-        for (int kk = 0; kk < KK1; ++kk) {
-          int g = 2 * kk + lhalf;
-          w1r[kk] = g < G ? stage[lrow * G + g] : 0.f;
-        }
-      }
-      __syncthreads();
+    for (int i = 0; i < CB_F * 2 * KK1 / 256; ++i) w1v[i] = tid + 256 * i < CB_F * G ? W1[tid + 256 * i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < CB_F * 2 * KK1 / 256; ++i)
+      if (tid + 256 * i < CB_F * G) stage[tid + 256 * i] = w1v[i];
+    if (tid < 64) off_s[tid] = tid < G ? offset[tid] : 0.f;
+#pragma unroll
+    for (int i = 0; i < CB_F * CB_F / 4 / 256; ++i) {
+      const int t = (tid + 256 * i) * 4;       // row t >> 7, columns (t & 127) .. +3 (odd row stride: scalar stores)
+      float* q = &W2s[(t >> 7) * CB_HS + (t & 127)];
+      q[0] = w[i].x; q[1] = w[i].y; q[2] = w[i].z; q[3] = w[i].w;
     }
   }
+  store_meta(0);
+  __syncthreads();
+  float w1r[KK1];
+#pragma unroll
+  for (int kk = 0; kk < KK1; ++kk) {
+    const int g = 2 * kk + lhalf;
+    w1r[kk] = g < G ? hid_t[col * G + g] : 0.f;
+  }
   const float b1c = b1[col];
+  fetch_meta(1);
 
   f32x16 aW2[4], aW1[2];
 #pragma unroll
@@ -299,92 +358,213 @@ cfconv_fused_bwd_w32_kernel(const float* __restrict__ g_agg, const float* __rest
     for (int r = 0; r < 16; ++r) aW1[j][r] = 0.f;
   float sb1 = 0.f, sb2 = 0.f;
 
-  for (int ec = e_begin; ec < e_end; ec += CB2_TE) {
-    __syncthreads();
-    if (tid < CB2_TE) {
-      int e = ec + tid;
-      bool ok = e < e_end;
-      float d = ok ? dist[e] : 0.f;
-      d_s[tid] = d;
-      c_s[tid] = ok ? 0.5f * (cosf(d * PI_F / cutoff) + 1.0f) : 0.f;
-      src_s[tid] = ok ? src[e] : -1;
-      dst_s[tid] = ok ? dst[e] : -1;
-    }
-    __syncthreads();
-    // g_pre2 in accumulator layout straight from the gathers: gp[s] = g_agg[dst] * x1[src] * C
-    float gp[16];
+  // gathers of one chunk: x1[src] and g_agg[dst] for this lane's column and its 2 x 16 edge rows
+  float nx[32], ng[32];
+  auto issue_gathers = [&](int c) {
+    if (dbg & 1) return;
+    const int* ss = src_s + (c & 1) * CB_TE;
+    const int* ts = dst_s + (c & 1) * CB_TE;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      int row = cb_row(s, lhalf);
-      int s0 = src_s[row], t0 = dst_s[row];
-      float xa = x1[(size_t)(s0 >= 0 ? s0 : 0) * CB_F + col], ga = g_agg[(size_t)(t0 >= 0 ? t0 : 0) * CB_F + col];
-      gp[s] = ga * xa * c_s[row];               // padding rows: c_s = 0
+      const int row = cb_row(s, lhalf);
+      const int s0 = ss[row], s1 = ss[32 + row], t0 = ts[row], t1 = ts[32 + row];
+      // 32-bit element offsets (N * 128 < 2^31): one VGPR per address, scalar base
+      nx[s] = x1[(unsigned)(max(s0, 0) * CB_F + col)];
+      ng[s] = g_agg[(unsigned)(max(t0, 0) * CB_F + col)];
+      nx[16 + s] = x1[(unsigned)(max(s1, 0) * CB_F + col)];
+      ng[16 + s] = g_agg[(unsigned)(max(t1, 0) * CB_F + col)];
     }
-    for (int idx = tid; idx < CB2_TE * 2 * KK1; idx += 256) {
-      int r = idx / (2 * KK1), g = idx % (2 * KK1);
-      float v = 0.f;
-      if (ec + r < e_end && g < G) {
-        float diff = d_s[r] - off_s[g];
-        v = __expf(coeff * (diff * diff));
+  };
+  // one element (per thread) of chunk c's smearing tile; `it` in [0, RBF_IT).  Branch free (select, clamped index): the
+  // calls sit between MFMAs and must not split the basic block the scheduler interleaves
+  auto rbf_elem = [&](int c, int it) {
+    if (dbg & 2) return;
+    constexpr int TOT = CB_TE * 2 * KK1;
+    int idx = tid + 256 * it;
+    const bool in = (TOT % 256 == 0) || idx < TOT;
+    idx = in ? idx : 0;
+    const int r = idx / (2 * KK1), g = idx - r * (2 * KK1);
+    const float diff = d_s[(c & 1) * CB_TE + r] - off_s[g];
+    const bool live = (e_begin + c * CB_TE + r < e_end) & (g < G);
+    const float v = __expf(live ? coeff * (diff * diff) : -1e30f);      // exp(-1e30) = 0: a select, not a branch
+    float* q = &rbf_t[(c & 1) * RBF_SZ + r * RS + g];
+    if (in) *q = v;
+  };
+  // Per-lane LDS bases: every access below is base + COMPILE-TIME offset (ds_read / ds_write immediates).  Written as
+  // row * stride + col the compiler materialises one address VGPR per access, hoists them all out of the chunk loop and
+  // spills (240 B of scratch, ~40 % of the VALU instructions were address arithmetic).
+  constexpr auto RW = [](int i) constexpr { return (i & 3) + 8 * (i >> 2); };   // cb_row without the lane-half term
+  float* const hw = hid_t + 4 * lhalf * CB_HS + col;         // h1 stores            + RW(i) * HS (+ 32 HS)
+  float* const gw = gp_t + 4 * lhalf * CB_HS + col;          // g_pre2 stores
+  const float* const hr = hid_t + 4 * lhalf * CB_HS + lcol;  // h1 rows, B of gW2    + RW(s) * HS + 32 j (+ 32 HS)
+  const float* const gr = gp_t + lcol * CB_HS + lhalf;       // g_pre2, A of g_h1    + 2 kk (+ 32 HS)
+  const float* const wr = W2s + lhalf * CB_HS + col;         // W2, B of g_h1        + 2 kk * HS
+  const int rb_a = lcol * RS + lhalf;                        // smearing, A of pre1  + 2 kk (+ 32 RS)
+  const int rb_b = 4 * lhalf * RS + lcol;                    // smearing, B of gW1   + RW(s) * RS + 32 j (+ 32 RS)
+  float gp0[16], gp1[16], sg0[16], sg1[16];
+  auto finish_gathers = [&](int c) {           // g_pre2 in accumulator layout: g_agg[dst] * x1[src] * C (padding: C = 0)
+    const float* cs = c_s + (c & 1) * CB_TE;
+    if (dbg & 1) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { gp0[s] = cs[cb_row(s, lhalf)]; gp1[s] = cs[32 + cb_row(s, lhalf)]; }
+      return;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = cb_row(s, lhalf);
+      gp0[s] = ng[s] * nx[s] * cs[row];
+      gp1[s] = ng[16 + s] * nx[16 + s] * cs[32 + row];
+    }
+  };
+  // recompute pre1 = rbf W1^T + b1 of chunk c: h1 and g_pre2 -> LDS, sigmoid(pre1) -> registers
+  auto hidden = [&](int c) {
+    const float* rb = rbf_t + (c & 1) * RBF_SZ + rb_a;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    // LDS operands are requested one k-step ahead of the MFMAs that use them (an MFMA occupies the pipe for 64 cycles, an
+    // LDS read takes longer: read-then-use leaves the pipe idle every step)
+    float pa[2][2];
+    pa[0][0] = rb[0];
+    pa[0][1] = rb[32 * RS];
+    if (!(dbg & 64))
+#pragma unroll
+    for (int kk = 0; kk < KK1; ++kk) {
+      if (kk + 1 < KK1) {
+        pa[(kk + 1) & 1][0] = rb[2 * (kk + 1)];
+        pa[(kk + 1) & 1][1] = rb[32 * RS + 2 * (kk + 1)];
       }
-      rbf_t[r * RS + g] = v;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk & 1][0], w1r[kk], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk & 1][1], w1r[kk], acc1, 0, 0, 0);
     }
-    __syncthreads();
-
-    // ---- recompute pre1 = rbf W1^T (+ b1): h1 -> LDS, sigmoid(pre1) stays in registers
-    f32x16 acc;
+    if (dbg & 4) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < KK1; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rbf_t[lcol * RS + 2 * kk + lhalf], w1r[kk], acc, 0, 0, 0);
-    float sg[16];
+      for (int i = 0; i < 16; ++i) {
+        const int row = cb_row(i, lhalf);
+        hw[RW(i) * CB_HS] = acc0[i];
+        hw[(32 + RW(i)) * CB_HS] = acc1[i];
+        sg0[i] = acc0[i]; sg1[i] = acc1[i];
+        gw[RW(i) * CB_HS] = gp0[i];
+        gw[(32 + RW(i)) * CB_HS] = gp1[i];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      int row = cb_row(i, lhalf);
-      float p0 = acc[i] + b1c;
-      float e0 = __expf(-fabsf(p0));
-      hid_t[row * CB_HS + col] = fmaxf(p0, 0.f) + __logf(1.f + e0) - 0.69314718246459961f;
-      float r0 = 1.f / (1.f + e0);
-      sg[i] = p0 >= 0.f ? r0 : e0 * r0;          // sigmoid = d softplus / dx
-      gp_t[row * CB_HS + col] = gp[i];           // g_pre2 tile for the W2^T product (row-per-lane reads)
-      sb2 += gp[i];
+      const int row = cb_row(i, lhalf);
+      const float p0 = acc0[i] + b1c, p1 = acc1[i] + b1c;
+      const float e0 = __expf(-fabsf(p0)), e1 = __expf(-fabsf(p1));
+      hw[RW(i) * CB_HS] = fmaxf(p0, 0.f) + __logf(1.f + e0) - 0.69314718246459961f;
+      hw[(32 + RW(i)) * CB_HS] = fmaxf(p1, 0.f) + __logf(1.f + e1) - 0.69314718246459961f;
+      const float r0 = 1.f / (1.f + e0), r1 = 1.f / (1.f + e1);
+      sg0[i] = p0 >= 0.f ? r0 : e0 * r0;       // sigmoid = d softplus / dx
+      sg1[i] = p1 >= 0.f ? r1 : e1 * r1;
+      gw[RW(i) * CB_HS] = gp0[i];              // g_pre2 tile for the W2^T product (row-per-lane reads)
+      gw[(32 + RW(i)) * CB_HS] = gp1[i];
+      sb2 += gp0[i] + gp1[i];
     }
-    __syncthreads();
+  };
 
-    // ---- g_W2[f][k] += sum_e g_pre2[e][f] h1[e][k]: A = g_pre2 registers, B = h1 rows (same permuted e)
+  if (nchunks > 0) {
+    issue_gathers(0);
+#pragma unroll
+    for (int it = 0; it < RBF_IT; ++it) rbf_elem(0, it);
+    finish_gathers(0);
+    __syncthreads();                           // smearing tile 0 visible; W1 staging (hid_t) no longer read
+    hidden(0);
+    store_meta(1);
+    fetch_meta(2);
+    __syncthreads();
+  }
+
+  for (int c = 0; c < nchunks; ++c) {
+    const float* rb = rbf_t + (c & 1) * RBF_SZ + rb_b;
+    // past the last chunk the look-ahead work below runs on stale (valid) metadata and its results are never read:
+    // cheaper than branches, which would split the block the MFMA / VALU interleaving lives in
+    issue_gathers(c + 1);
+    // ---- g_W2[f][k] += sum_e g_pre2[e][f] h1[e][k]: A = g_pre2 registers, B = h1 rows (same permuted e);
+    //      the next chunk's smearing tile is computed in the shadow of these MFMAs
+    float hb[2][8];
+    auto read_h = [&](int s, float (&q)[8]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[2 * j] = hr[RW(s) * CB_HS + 32 * j];
+        q[2 * j + 1] = hr[(32 + RW(s)) * CB_HS + 32 * j];
+      }
+    };
+    read_h(0, hb[0]);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      int row = cb_row(s, lhalf);
+      if (s + 1 < 16) read_h(s + 1, hb[(s + 1) & 1]);
+      if (!(dbg & 8))
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[s], hid_t[row * CB_HS + 32 * j + lcol], aW2[j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp0[s], hb[s & 1][2 * j], aW2[j], 0, 0, 0);
+        aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp1[s], hb[s & 1][2 * j + 1], aW2[j], 0, 0, 0);
+      }
+      if (s < RBF_IT) rbf_elem(c + 1, s);
     }
+#pragma unroll
+    for (int it = 16; it < RBF_IT; ++it) rbf_elem(c + 1, it);
+    finish_gathers(c + 1);                     // g_pre2 of chunk c is dead: its registers take chunk c+1's
     // ---- g_h1[e][k] = sum_f g_pre2[e][f] W2[f][k]
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    float ga[2][3];
+    auto read_g = [&](int kk, float (&q)[3]) {
+      q[0] = gr[2 * kk];
+      q[1] = gr[32 * CB_HS + 2 * kk];
+      q[2] = wr[2 * kk * CB_HS];
+    };
+    read_g(0, ga[0]);
+    if (!(dbg & 16))
 #pragma unroll
-    for (int kk = 0; kk < CB_F / 2; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp_t[lcol * CB_HS + 2 * kk + lhalf], w2r[kk], acc, 0, 0, 0);
+    for (int kk = 0; kk < CB_F / 2; ++kk) {
+      if (kk + 1 < CB_F / 2) read_g(kk + 1, ga[(kk + 1) & 1]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[kk & 1][0], ga[kk & 1][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[kk & 1][1], ga[kk & 1][2], acc1, 0, 0, 0);
+    }
     // g_pre1 = g_h1 * sigmoid(pre1)  (same lanes / registers as pre1)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      sg[i] *= acc[i];
-      sb1 += sg[i];
+      sg0[i] *= acc0[i];
+      sg1[i] *= acc1[i];
+      sb1 += sg0[i] + sg1[i];
     }
     // ---- g_W1[k][g] += sum_e g_pre1[e][k] rbf[e][g]
+    float rq[2][4];
+    auto read_r = [&](int s, float (&q)[4]) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        q[2 * j] = rb[RW(s) * RS + 32 * j];                       // g >= 2*KK1 reads slack: columns discarded
+        q[2 * j + 1] = rb[(32 + RW(s)) * RS + 32 * j];
+      }
+    };
+    read_r(0, rq[0]);
+    if (!(dbg & 32))
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      int row = cb_row(s, lhalf);
+      if (s + 1 < 16) read_r(s + 1, rq[(s + 1) & 1]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        aW1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sg[s], rbf_t[row * RS + 32 * j + lcol], aW1[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        aW1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sg0[s], rq[s & 1][2 * j], aW1[j], 0, 0, 0);
+        aW1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sg1[s], rq[s & 1][2 * j + 1], aW1[j], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunks) {
+      __syncthreads();                         // everyone is done with h1 / g_pre2 of chunk c; smearing tile c+1 visible
+      hidden(c + 1);
+      store_meta(c + 2);
+      fetch_meta(c + 3);
+      __syncthreads();
     }
   }
 
   // ---- write this workgroup's slab: [128*128 gW2][128*G gW1][128 gb1][128 gb2]
   const size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
   float* slab = slabs + (size_t)blockIdx.x * slab_sz;
+  if (dbg & 128) { if (aW2[0][0] + aW1[0][0] + sb1 + sb2 == 12345.678f) slab[0] = 1.f; return; }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -433,12 +613,12 @@ __global__ void cfconv_reduce_slabs_kernel(const float* __restrict__ slabs, int 
 // LDS-using kernels are concerned).  A caller that runs this kernel BESIDE latency-critical work on another stream
 // passes a smaller number: the kernel takes longer but leaves whole CUs to the other stream (measured on the
 // pretrain step: 128 workgroups instead of 256 = +6 % step throughput).
-static inline bool cb_light() {
-  static int v = [] { const char* e = getenv("MSDE_CFBWD_LIGHT"); return e ? atoi(e) : 0; }();   // off: see below
+static inline bool cb_pipe() {          // MSDE_CFBWD_PIPE=0: the unpipelined kernel (kept as the cross-check)
+  static int v = [] { const char* e = getenv("MSDE_CFBWD_PIPE"); return e ? atoi(e) : 1; }();
   return v != 0;
 }
 static inline void cb_geometry(int E_cap, int max_wgs, int* nwg, int* cpw) {
-  const int te = cb_light() ? CB2_TE : CB_TE;
+  const int te = CB_TE;
   int chunks = (E_cap + te - 1) / te;
   int cap = max_wgs > 0 ? max_wgs : msde_num_cus();
   int w = chunks < cap ? chunks : cap;
@@ -476,6 +656,7 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   int nwg, cpw;
   cb_geometry(E_cap, max_workgroups, &nwg, &cpw);
   int kk1 = (G + 1) / 2;
+  static const int dbg = getenv("MSDE_CFBWD_DBG") ? atoi(getenv("MSDE_CFBWD_DBG")) : 0;   // diagnostics (tools/bench_cfconv_bwd.py)
   auto lds_bytes = [](int KK1) {
     return (size_t)(CB_F * CB_HS + CB_TE * (2 * KK1 + 1) + 64 + 2 * CB_TE * CB_HS + 4 * CB_TE) * sizeof(float);
   };
@@ -490,24 +671,33 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
     }                                                                                                                 \
   }                                                                                                                   \
   MSDE_LAUNCH(cfconv_fused_bwd_w_kernel<KK>, dim3(nwg), dim3(256), lds_bytes(KK), st, g_agg, x1, dist, rowptr, src, dst, \
-              W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
-  auto lds2_bytes = [](int KK1) {
-    return (size_t)(CB2_TE * (2 * KK1 + 1) + 64 + 2 * CB2_TE * CB_HS + 4 * CB2_TE + 64) * sizeof(float);
+              W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace, dbg)
+  auto ldsp_bytes = [](int KK1) {
+    return (size_t)(CB_F * CB_HS + 2 * (CB_TE * (2 * KK1 + 1) + 64) + 2 * CB_TE * CB_HS + 8 * CB_TE + 64) * sizeof(float);
   };
-#define CB2_LAUNCH(KK)                                                                                                \
-  MSDE_LAUNCH(cfconv_fused_bwd_w32_kernel<KK>, dim3(nwg), dim3(256), lds2_bytes(KK), st, g_agg, x1, dist, rowptr, src,   \
+#define CBP_LAUNCH(KK)                                                                                                \
+  {                                                                                                                   \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_bwd_w_pipe_kernel<KK, 0>),         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp_bytes(KK));           \
+      if (ae != hipSuccess) return (int)ae;                                                                           \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+  }                                                                                                                   \
+  MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, dist, rowptr, src, \
               dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
-  if (cb_light()) {
-    if (kk1 == 26) { CB2_LAUNCH(26); }
-    else if (kk1 == 25) { CB2_LAUNCH(25); }
-    else { CB2_LAUNCH(32); }
+  if (cb_pipe() && kk1 <= 26 && !dbg) {
+    if (kk1 == 26) { CBP_LAUNCH(26); }
+    else if (kk1 == 25) { CBP_LAUNCH(25); }
+    else { CBP_LAUNCH(24); }
   } else {
     if (kk1 == 26) { CB_LAUNCH(26); }
     else if (kk1 == 25) { CB_LAUNCH(25); }
     else { CB_LAUNCH(32); }
   }
 #undef CB_LAUNCH
-#undef CB2_LAUNCH
+#undef CBP_LAUNCH
   MSDE_CHECK_LAUNCH();
   if (no_reduce) return 0;
   size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;

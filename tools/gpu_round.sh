@@ -19,6 +19,11 @@ head)
   timeout 900 python -m pytest tests/test_gpu_models.py -q -x -k "dense_head or sde3d2d or full_pretrain or losscurve_through" > $O/head_test.log 2>&1; echo "head test rc=$?"; tail -40 $O/head_test.log;;
 plan)
   timeout 900 python -m pytest tests/test_gpu_plan.py -q -x > $O/plan_test.log 2>&1; echo "plan test rc=$?"; tail -40 $O/plan_test.log;;
+cfpipe)
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "cfconv" > $O/cf_test.log 2>&1; echo "cf test rc=$?"; tail -8 $O/cf_test.log
+  for d in 1 0; do MSDE_CFBWD_PIPE=$d timeout 300 python tools/bench_cfconv_bwd.py 2>&1 | grep dbg=; done | tee $O/cfpipe.log;;
+cfdbg)
+  for d in 0 1 2 4 7 8 16 32 64 120 127 128 255; do MSDE_CFBWD_DBG=$d timeout 300 python tools/bench_cfconv_bwd.py 2>&1 | grep dbg=; done | tee $O/cfdbg.log;;
 md17)
   timeout 900 python -m pytest tests/test_gpu_models.py -q -x -k "md17" > $O/md17_test.log 2>&1; echo "md17 test rc=$?"; tail -40 $O/md17_test.log;;
 dptest)
