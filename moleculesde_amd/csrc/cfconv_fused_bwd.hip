@@ -270,7 +270,6 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
   constexpr int dbg = DBG;                     // phase knock-outs for tools/bench_cfconv_bwd.py (0 in the product)
   constexpr int RS = 2 * KK1 + 1;
   constexpr int RBF_SZ = CB_TE * RS + 64;      // + slack: the gW1 product reads up to column 63 of the last row
-  constexpr int RBF_IT = (CB_TE * 2 * KK1 + 255) / 256;
   extern __shared__ float lds[];
   float* W2s = lds;                            // [128][129]
   float* rbf_t = W2s + CB_F * CB_HS;           // [2][64][RS]
@@ -280,7 +279,6 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
   float* d_s = c_s + 2 * CB_TE;                // [2][64]
   int* src_s = reinterpret_cast<int*>(d_s + 2 * CB_TE);   // [2][64]
   int* dst_s = src_s + 2 * CB_TE;              // [2][64]
-  float* off_s = reinterpret_cast<float*>(dst_s + 2 * CB_TE);   // [64]
 
   const float PI_F = 3.14159265358979323846f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -310,8 +308,8 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
       const bool ok = m_t >= 0;
       d_s[o] = ok ? m_d : 0.f;
       c_s[o] = ok ? 0.5f * (cosf(m_d * PI_F / cutoff) + 1.0f) : 0.f;
-      src_s[o] = m_s;
-      dst_s[o] = m_t;
+      src_s[o] = max(m_s, 0) * (CB_F * 4);     // BYTE offset of the gathered row: one add per load in the gathers
+      dst_s[o] = max(m_t, 0) * (CB_F * 4);
     }
   };
   fetch_meta(0);
@@ -328,7 +326,6 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
 #pragma unroll
     for (int i = 0; i < CB_F * 2 * KK1 / 256; ++i)
       if (tid + 256 * i < CB_F * G) stage[tid + 256 * i] = w1v[i];
-    if (tid < 64) off_s[tid] = tid < G ? offset[tid] : 0.f;
 #pragma unroll
     for (int i = 0; i < CB_F * CB_F / 4 / 256; ++i) {
       const int t = (tid + 256 * i) * 4;       // row t >> 7, columns (t & 127) .. +3 (odd row stride: scalar stores)
@@ -367,28 +364,29 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int row = cb_row(s, lhalf);
-      const int s0 = ss[row], s1 = ss[32 + row], t0 = ts[row], t1 = ts[32 + row];
-      // 32-bit element offsets (N * 128 < 2^31): one VGPR per address, scalar base
-      nx[s] = x1[(unsigned)(max(s0, 0) * CB_F + col)];
-      ng[s] = g_agg[(unsigned)(max(t0, 0) * CB_F + col)];
-      nx[16 + s] = x1[(unsigned)(max(s1, 0) * CB_F + col)];
-      ng[16 + s] = g_agg[(unsigned)(max(t1, 0) * CB_F + col)];
+      // 32-bit byte offsets (N * 512 < 2^31): scalar base + one VGPR, one v_add per load
+      auto at = [&](const float* base, int row_off) {
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (unsigned)(row_off + 4 * col));
+      };
+      nx[s] = at(x1, ss[row]);
+      ng[s] = at(g_agg, ts[row]);
+      nx[16 + s] = at(x1, ss[32 + row]);
+      ng[16 + s] = at(g_agg, ts[32 + row]);
     }
   };
-  // one element (per thread) of chunk c's smearing tile; `it` in [0, RBF_IT).  Branch free (select, clamped index): the
-  // calls sit between MFMAs and must not split the basic block the scheduler interleaves
+  // Smearing tile of chunk c, 4 rows per call (`it` in [0, 16)): lane = column g, wave + 4 it = row, so the centre is a
+  // register, the distance a broadcast LDS read, and nothing here branches (the calls sit between MFMAs and must not split
+  // the block the scheduler interleaves).  Rows past e_end and column G..2 KK1 - 1 hold finite values that only meet
+  // zeros (g_pre2 = 0 there, W1 columns >= G are zero, gW1 columns >= G are not stored); lanes >= 2 KK1 repeat lane
+  // 2 KK1 - 1 (same value, same address).
+  const float coeff2 = coeff * 1.4426950408889634f;
+  const int rbf_g = min(lane, 2 * KK1 - 1);
+  const float rbf_mu = rbf_g < G ? offset[rbf_g] : 0.f;
   auto rbf_elem = [&](int c, int it) {
     if (dbg & 2) return;
-    constexpr int TOT = CB_TE * 2 * KK1;
-    int idx = tid + 256 * it;
-    const bool in = (TOT % 256 == 0) || idx < TOT;
-    idx = in ? idx : 0;
-    const int r = idx / (2 * KK1), g = idx - r * (2 * KK1);
-    const float diff = d_s[(c & 1) * CB_TE + r] - off_s[g];
-    const bool live = (e_begin + c * CB_TE + r < e_end) & (g < G);
-    const float v = __expf(live ? coeff * (diff * diff) : -1e30f);      // exp(-1e30) = 0: a select, not a branch
-    float* q = &rbf_t[(c & 1) * RBF_SZ + r * RS + g];
-    if (in) *q = v;
+    const int r = wave + 4 * it;
+    const float diff = d_s[(c & 1) * CB_TE + r] - rbf_mu;
+    rbf_t[(c & 1) * RBF_SZ + r * RS + rbf_g] = __builtin_amdgcn_exp2f(coeff2 * (diff * diff));   // raw v_exp_f32
   };
   // Per-lane LDS bases: every access below is base + COMPILE-TIME offset (ds_read / ds_write immediates).  Written as
   // row * stride + col the compiler materialises one address VGPR per access, hoists them all out of the chunk loop and
@@ -452,11 +450,16 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = cb_row(i, lhalf);
+      // raw v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp): the fp32 MFMA leaves NO issue shadow for vector instructions
+      // (profiles/r02_probe_fp32_mfma_fillers.txt), so every VALU instruction here is paid in full: ~12 per element
+      // instead of the ~30 of the range-checked __expf / __logf / division
       const float p0 = acc0[i] + b1c, p1 = acc1[i] + b1c;
-      const float e0 = __expf(-fabsf(p0)), e1 = __expf(-fabsf(p1));
-      hw[RW(i) * CB_HS] = fmaxf(p0, 0.f) + __logf(1.f + e0) - 0.69314718246459961f;
-      hw[(32 + RW(i)) * CB_HS] = fmaxf(p1, 0.f) + __logf(1.f + e1) - 0.69314718246459961f;
-      const float r0 = 1.f / (1.f + e0), r1 = 1.f / (1.f + e1);
+      const float e0 = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(p0));
+      const float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(p1));
+      const float u0 = 1.f + e0, u1 = 1.f + e1;
+      hw[RW(i) * CB_HS] = fmaf(__builtin_amdgcn_logf(u0), 0.69314718055994531f, fmaxf(p0, 0.f) - 0.69314718055994531f);
+      hw[(32 + RW(i)) * CB_HS] = fmaf(__builtin_amdgcn_logf(u1), 0.69314718055994531f, fmaxf(p1, 0.f) - 0.69314718055994531f);
+      const float r0 = __builtin_amdgcn_rcpf(u0), r1 = __builtin_amdgcn_rcpf(u1);
       sg0[i] = p0 >= 0.f ? r0 : e0 * r0;       // sigmoid = d softplus / dx
       sg1[i] = p1 >= 0.f ? r1 : e1 * r1;
       gw[RW(i) * CB_HS] = gp0[i];              // g_pre2 tile for the W2^T product (row-per-lane reads)
@@ -468,7 +471,7 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
   if (nchunks > 0) {
     issue_gathers(0);
 #pragma unroll
-    for (int it = 0; it < RBF_IT; ++it) rbf_elem(0, it);
+    for (int it = 0; it < 16; ++it) rbf_elem(0, it);
     finish_gathers(0);
     __syncthreads();                           // smearing tile 0 visible; W1 staging (hid_t) no longer read
     hidden(0);
@@ -502,10 +505,8 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
         aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp0[s], hb[s & 1][2 * j], aW2[j], 0, 0, 0);
         aW2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gp1[s], hb[s & 1][2 * j + 1], aW2[j], 0, 0, 0);
       }
-      if (s < RBF_IT) rbf_elem(c + 1, s);
+      rbf_elem(c + 1, s);
     }
-#pragma unroll
-    for (int it = 16; it < RBF_IT; ++it) rbf_elem(c + 1, it);
     finish_gathers(c + 1);                     // g_pre2 of chunk c is dead: its registers take chunk c+1's
     // ---- g_h1[e][k] = sum_f g_pre2[e][f] W2[f][k]
     f32x16 acc0, acc1;
@@ -687,6 +688,24 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   }                                                                                                                   \
   MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, dist, rowptr, src, \
               dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
+#ifdef MSDE_CF_DIAG          // phase knock-outs of the pipelined kernel as separate instantiations (no run-time branches)
+#define CBP_DIAG(D_)                                                                                                  \
+  case D_:                                                                                                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_bwd_w_pipe_kernel<26, D_>),                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp_bytes(26));                       \
+    MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<26, D_>), dim3(nwg), dim3(256), ldsp_bytes(26), st, g_agg, x1, dist,    \
+                rowptr, src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace);                           \
+    MSDE_CHECK_LAUNCH();                                                                                              \
+    return 0;
+  if (cb_pipe() && kk1 == 26 && dbg) {
+    switch (dbg) {
+      CBP_DIAG(1) CBP_DIAG(2) CBP_DIAG(4) CBP_DIAG(7) CBP_DIAG(8) CBP_DIAG(16) CBP_DIAG(32) CBP_DIAG(64) CBP_DIAG(120)
+      CBP_DIAG(127) CBP_DIAG(128) CBP_DIAG(255)
+      default: break;
+    }
+  }
+#undef CBP_DIAG
+#endif
   if (cb_pipe() && kk1 <= 26 && !dbg) {
     if (kk1 == 26) { CBP_LAUNCH(26); }
     else if (kk1 == 25) { CBP_LAUNCH(25); }
