@@ -109,6 +109,9 @@ int msde_dd_seg_expand(const float* g, const int* batch, const int* mol_ptr, int
 /* adjoint of msde_colsum: y[m][k] = b[k] */
 int msde_dd_broadcast_rows(const float* b, int M, int K, float* y, void* stream);
 
+/* Diagnostics: store the 100 MHz real-time counter into *slot, in stream order (capturable). */
+int msde_debug_stamp(long long* slot, void* stream);
+
 /* ------------------------------------------------------------------ generic row ops -------- */
 /* torch_scatter.scatter(reduce=sum) over CSR rows: out[i] = sum_{s in [rowptr[i],rowptr[i+1])}
  * rows[perm ? perm[s] : s]; used for every backward "gather by source/target".  D % 4 == 0 or any. */
@@ -447,6 +450,10 @@ int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const float* X, int 
                                   int want_bias, float* slabs, long long* row);
 int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
                               void* stream);
+/* the same launch limited to `max_workgroups` resident workgroups (0 = one per tile): each walks several tiles, so the
+ * GEMMs can run beside a latency-critical kernel chain on another stream without occupying every CU. */
+int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* prefix, int count, int total_blocks,
+                                 int max_workgroups, void* stream);
 int msde_linear_bwd_w_partial(const float* gY, const float* X, int M, int N, int K, int want_bias,
                               float* slabs, void* stream);
 int msde_reduce_slabs_multi(const long long* rows, const int* prefix, int count, int total_chunks,

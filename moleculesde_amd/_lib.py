@@ -52,6 +52,7 @@ SIGNATURES = {
     "msde_linear_bwd_w_describe": [P, P, I, I, I, I, P, P],
     "msde_linear_bwd_w_describe_ld": [P, I, P, I, I, I, I, I, P, P],
     "msde_linear_bwd_w_grouped": [P, P, I, I, P],
+    "msde_linear_bwd_w_grouped_ex": [P, P, I, I, I, P],
     "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
@@ -76,6 +77,7 @@ SIGNATURES = {
     "msde_dd_row_norm": [P, P, I, P, P],
     "msde_dd_seg_expand": [P, P, P, I, I, I, P, P],
     "msde_dd_broadcast_rows": [P, I, I, P, P],
+    "msde_debug_stamp": [P, P],
     "msde_set_row_bound": [I, P],
     "msde_clear_row_bounds": [],
     "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],

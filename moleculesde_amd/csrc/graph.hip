@@ -484,3 +484,14 @@ extern "C" int msde_clear_row_bounds(void) {
   g_bound_n = 0;
   return 0;
 }
+
+// ---- diagnostics: a device timestamp on a stream (tools/probes/step_timeline.py).  One thread stores the 100 MHz
+// real-time counter; captured into the step's hipGraph it gives an undistorted timeline of the replay (rocprofv3's
+// kernel trace slows every dispatch and serialises the two queues of the step).
+__global__ void debug_stamp_kernel(long long* slot) { *slot = (long long)wall_clock64(); }
+extern "C" int msde_debug_stamp(long long* slot, void* stream) {
+  if (!slot) return MSDE_EINVAL;
+  MSDE_LAUNCH(debug_stamp_kernel, dim3(1), dim3(1), 0, as_stream(stream), slot);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

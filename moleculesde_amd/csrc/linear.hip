@@ -217,27 +217,33 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
 // prefix[p] = workgroups before problem p.  A workgroup finds its problem by binary search and then runs the very
 // same tile body as the per-layer kernel (64 x 64 tiles), so results are bit-identical to it.
 __global__ void __launch_bounds__(256)
-gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count) {
-  int lo = 0, hi = count;
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total) {
+  // grid == total: one tile per workgroup.  grid < total (msde_linear_bwd_w_grouped_ex with a width limit): each
+  // workgroup walks tiles blockIdx.x, + gridDim.x, ...: the launch then occupies at most gridDim.x workgroup slots, so it
+  // can run BESIDE a latency-critical chain on another stream without taking every CU (same results, tile by tile).
+  for (int blk = blockIdx.x; blk < total; blk += gridDim.x) {
+    int lo = 0, hi = count;
+    while (hi - lo > 1) {
+      int mid = (lo + hi) >> 1;
+      if (prefix[mid] <= blk) lo = mid; else hi = mid;
+    }
+    const long long* e = probs + (size_t)lo * MSDE_WGRAD_ROW;
+    const float* gY = reinterpret_cast<const float*>(e[0]);
+    const float* X = reinterpret_cast<const float*>(e[1]);
+    float* slabs = reinterpret_cast<float*>(e[2]);
+    float* cs = reinterpret_cast<float*>(e[3]);
+    const int M = (int)e[4], N = (int)e[5], K = (int)e[6], kps = (int)e[8], tx = (int)e[9], ty = (int)e[10];
+    const int ldg = (int)e[12], ldx = (int)e[13];
+    const int Mt = msde_true_rows(M, reinterpret_cast<const int*>(e[14]));      // valid rows of gY / X (row bound)
+    const int local = blk - prefix[lo];
+    const int bx = local % tx, by = (local / tx) % ty, bz = local / (tx * ty);
+    // product C[N][K] = gY^T X: "M" of the product = N, "N" = K, reduction = M (see msde_linear_bwd_w)
+    if (e[11])
+      gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
+    else
+      gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
+    __syncthreads();                 // the next tile reuses the LDS stages
   }
-  const long long* e = probs + (size_t)lo * MSDE_WGRAD_ROW;
-  const float* gY = reinterpret_cast<const float*>(e[0]);
-  const float* X = reinterpret_cast<const float*>(e[1]);
-  float* slabs = reinterpret_cast<float*>(e[2]);
-  float* cs = reinterpret_cast<float*>(e[3]);
-  const int M = (int)e[4], N = (int)e[5], K = (int)e[6], kps = (int)e[8], tx = (int)e[9], ty = (int)e[10];
-  const int ldg = (int)e[12], ldx = (int)e[13];
-  const int Mt = msde_true_rows(M, reinterpret_cast<const int*>(e[14]));      // valid rows of gY / X (row bound)
-  const int local = (int)blockIdx.x - prefix[lo];
-  const int bx = local % tx, by = (local / tx) % ty, bz = local / (tx * ty);
-  // product C[N][K] = gY^T X: "M" of the product = N, "N" = K, reduction = M (see msde_linear_bwd_w)
-  if (e[11])
-    gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
-  else
-    gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
 }
 
 // out[i] = sum_z slabs[z][i] for the weight slabs (n entries) and, in the same launch, the bias-gradient
@@ -485,13 +491,19 @@ extern "C" int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const flo
   return tx * ty * splits;
 }
 
-extern "C" int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
-                                         void* stream) {
+extern "C" int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* prefix, int count, int total_blocks,
+                                            int max_workgroups, void* stream) {
   if (count < 0 || total_blocks < 0 || (count > 0 && (!probs || !prefix))) return MSDE_EINVAL;
   if (count == 0 || total_blocks == 0) return 0;
-  MSDE_LAUNCH(gemm_grouped_wgrad_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), probs, prefix, count);
+  const int grid = max_workgroups > 0 && max_workgroups < total_blocks ? max_workgroups : total_blocks;
+  MSDE_LAUNCH(gemm_grouped_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), probs, prefix, count, total_blocks);
   MSDE_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
+                                         void* stream) {
+  return msde_linear_bwd_w_grouped_ex(probs, prefix, count, total_blocks, 0, stream);
 }
 
 extern "C" int msde_linear_bwd_w_splits(int M, int N, int K) {

@@ -864,6 +864,7 @@ class _SlabBatch:
         self.rows = []           # (slab address, splits, n, out address, device)
         self.gemms = []          # queued weight-gradient GEMMs: (gY, X, M, N, K, has_bias, slab) -- inputs kept alive
         self.retired = []        # outgrown arenas still referenced by queued rows
+        self.launched = []       # operands of GEMMs already launched in this backward pass (kept alive until finish)
         self.slot = None
         self.slots = []          # slots 0..EAGER_SLOTS-1: the eager ring; one more per captured hipGraph
         self.events = []         # per slot: event recorded behind the last upload of its pinned host images
@@ -939,9 +940,10 @@ class _SlabBatch:
     def queue_gemm(self, gY, X, M, N, K, has_bias, slab):
         self.gemms.append((gY, X, M, N, K, has_bias, slab))
 
-    def launch_gemms(self):
+    def launch_gemms(self, max_wgs=0):
         """One grouped launch, on the current stream, for the weight-gradient GEMMs queued so far.  May be called
-        several times per backward pass (each call takes the next rows of the problem table)."""
+        several times per backward pass (each call takes the next rows of the problem table).  max_wgs > 0 limits the
+        launch to that many resident workgroups (a flush that runs beside the backward chain on another stream)."""
         if not self.gemms:
             return
         dev = self.gemms[0][0].device
@@ -963,9 +965,25 @@ class _SlabBatch:
         upload_table(dev_prob[r0:r0 + ng], host_prob[r0:r0 + ng])
         upload_table(dev_ppre[q0:q0 + ng + 1], host_ppre[q0:q0 + ng + 1])
         self.prob_used, self.pre_used = r0 + ng, q0 + ng + 1
-        _lib.call("msde_linear_bwd_w_grouped", ctypes.c_void_p(dev_prob[r0].data_ptr()),
-                  ctypes.c_void_p(dev_ppre[q0:].data_ptr()), ng, total_b, _stream())
+        _lib.call("msde_linear_bwd_w_grouped_ex", ctypes.c_void_p(dev_prob[r0].data_ptr()),
+                  ctypes.c_void_p(dev_ppre[q0:].data_ptr()), ng, total_b, int(max_wgs), _stream())
+        # the operands stay referenced until finish(): a flush may run on ANOTHER stream than the one that allocated
+        # them, and the caching allocator would otherwise hand their memory to the allocating stream's next kernels
+        self.launched.extend(self.gemms)
         self.gemms = []
+
+    def park(self):
+        """Set the GEMMs queued so far aside (returned as an opaque group) instead of launching them: the caller launches
+        the group later with launch_group(), e.g. on another stream once that stream is free."""
+        g, self.gemms = self.gemms, []
+        return g
+
+    def launch_group(self, group, max_wgs=0):
+        rest, self.gemms = self.gemms, group
+        try:
+            self.launch_gemms(max_wgs)
+        finally:
+            self.gemms = rest
 
     def finish(self):
         self.active = False
@@ -992,6 +1010,7 @@ class _SlabBatch:
             ev.record()
             self.events[self.slot_i] = ev
         self.rows = []
+        self.launched = []
         _retire(self.retired)
         self.retired = []
 
@@ -1014,11 +1033,22 @@ def begin_param_grad_batch(params=None):
     _SLABS.begin(params)
 
 
-def flush_wgrad_gemms():
+def flush_wgrad_gemms(max_wgs=0):
     """Launch the weight-gradient GEMMs queued so far as one grouped kernel on the current stream (their slabs are
-    still summed by finish_param_grad_batch)."""
+    still summed by finish_param_grad_batch, whose stream must by then be ordered after this one)."""
     if _SLABS.active:
-        _SLABS.launch_gemms()
+        _SLABS.launch_gemms(max_wgs)
+
+
+def park_wgrad_gemms():
+    """Set the weight-gradient GEMMs queued so far aside; launch them later with launch_wgrad_group (any stream that is
+    ordered after their operands)."""
+    return _SLABS.park() if _SLABS.active else []
+
+
+def launch_wgrad_group(group, max_wgs=0):
+    if group:
+        _SLABS.launch_group(group, max_wgs)
 
 
 def finish_param_grad_batch():
@@ -1553,3 +1583,27 @@ def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=N
     d.alpha = float(alpha)
     _lib.call("msde_gemm_ex", ctypes.byref(d), _stream())
     return out
+
+
+# ---- diagnostics: device timestamps in stream order (tools/probes/step_timeline.py) ---------------------------
+STAMPS = None            # {"buf": int64[256] device tensor, "names": [..]} when enabled
+
+
+def enable_stamps(device):
+    global STAMPS
+    STAMPS = {"buf": torch.zeros(256, dtype=torch.int64, device=device), "names": []}
+
+
+def stamp(name):
+    """No-op unless enable_stamps() was called: one 1-thread launch on the current stream storing the real-time counter."""
+    if STAMPS is None:
+        return
+    if name not in STAMPS["names"]:
+        STAMPS["names"].append(name)
+    i = STAMPS["names"].index(name)
+    _lib.call("msde_debug_stamp", ctypes.c_void_p(STAMPS["buf"].data_ptr() + 8 * i), _stream())
+
+
+def read_stamps():
+    t = STAMPS["buf"].cpu().tolist()
+    return {n: t[i] for i, n in enumerate(STAMPS["names"])}

@@ -83,7 +83,7 @@ def readme_args(**over):
 
 USE_FUSED_CL = True
 SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
-SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "128"))   # measured best (full width 512 / 256: -9 %)
+SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "192"))   # pipelined kernel: 128..192 same step time, 256: -1 %
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
 GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
@@ -266,20 +266,33 @@ class Trainer:
         if a.SDE_coeff_generative_2Dto3D > 0 and EARLY_GEOMETRY:
             m["SDE_2Dto3D_model"].begin(batch)
         l32 = None
+        from . import hip as _hip
+        stamps = _hip.STAMPS is not None
+        _hip.stamp("fwd_start")
         if self.overlap_streams:
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                _hip.stamp("schnet_fwd_start")
                 _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+                _hip.stamp("schnet_fwd_end")
+                if stamps:
+                    node_3D_repr.register_hook(lambda g: _hip.stamp("schnet_bwd_start"))
                 if head_on_side:
                     l32 = head_32(node_3D_repr)
         else:
             _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
         node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
+        _hip.stamp("gin_fwd_end")
+        if stamps:
+            node_2D_repr.register_hook(lambda g: _hip.stamp("gin_bwd_start"))
         if a.SDE_coeff_generative_2Dto3D > 0:
             l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
             loss = loss + l23 * a.SDE_coeff_generative_2Dto3D
             parts["2Dto3D"] = l23.detach()
+            _hip.stamp("2d3d_fwd_end")
+            if stamps:
+                l23.register_hook(lambda g: _hip.stamp("2d3d_bwd_start"))
         if self.overlap_streams:
             main.wait_stream(side)
             node_3D_repr.record_stream(main)
@@ -309,9 +322,16 @@ class Trainer:
                 return
             hip.begin_param_grad_batch(self.opt.params)
             try:
+                hip.stamp("bwd_start")
                 loss.backward()
+                hip.stamp("bwd_main_end")
+                if hip.STAMPS is not None and self.overlap_streams:
+                    with torch.cuda.stream(self._side_stream):
+                        hip.stamp("bwd_side_end")
+                    torch.cuda.current_stream().wait_stream(self._side_stream)
             finally:
                 hip.finish_param_grad_batch()
+                hip.stamp("wgrad_end")
         finally:
             self._side_geometry(False)
 
@@ -359,6 +379,8 @@ class Trainer:
 
     # ---- hipGraph path ---------------------------------------------------------------------------
     def _graph_body(self, batch, with_adam):
+        from . import hip as _hip
+        _hip.stamp("step_start")
         self.step_counter.add_(1)
         loss, parts = self.losses(batch)
         self.opt.zero_grad()
@@ -368,6 +390,8 @@ class Trainer:
         else:
             self.opt.gather_grads()
         self._log_parts(parts)
+        from . import hip as _hip
+        _hip.stamp("step_end")
         return loss.detach()
 
     def capture(self, batch, pre=None):

@@ -19,6 +19,12 @@ head)
   timeout 900 python -m pytest tests/test_gpu_models.py -q -x -k "dense_head or sde3d2d or full_pretrain or losscurve_through" > $O/head_test.log 2>&1; echo "head test rc=$?"; tail -40 $O/head_test.log;;
 plan)
   timeout 900 python -m pytest tests/test_gpu_plan.py -q -x > $O/plan_test.log 2>&1; echo "plan test rc=$?"; tail -40 $O/plan_test.log;;
+trace)
+  cd /tmp
+  timeout 900 rocprofv3 --output-format csv --kernel-trace -d $O/trace -o run -- python3 $R/bench.py --no_cpu_baseline --steps 12 --warmup 6 $TRACE_ARGS > $O/trace_bench.json 2> $O/trace.log; echo "trace rc=$?"
+  cd $R
+  python tools/trace_step.py $O/trace > $O/trace_step.txt 2>&1; head -12 $O/trace_step.txt
+  rm -rf $O/trace;;
 cfpipe)
   timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "cfconv" > $O/cf_test.log 2>&1; echo "cf test rc=$?"; tail -8 $O/cf_test.log
   for d in 1 0; do MSDE_CFBWD_PIPE=$d timeout 300 python tools/bench_cfconv_bwd.py 2>&1 | grep dbg=; done | tee $O/cfpipe.log;;

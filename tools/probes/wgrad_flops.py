@@ -1,0 +1,27 @@
+"""FLOPs of the weight-gradient GEMMs of one pretrain step (the grouped launch at the end of the backward pass)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ["MSDE_WGRAD_OVERLAP"] = "0"
+from moleculesde_amd import pretrain, hip
+from moleculesde_amd.geom3d import prepare_batch
+from moleculesde_amd.synthetic import make_batch
+dev = torch.device("cuda", 0)
+tr = pretrain.Trainer(pretrain.readme_args(SDE_coeff_generative_3Dto2D=0), dev)
+b = prepare_batch(make_batch(256, seed=0), dev)
+tr.step(b)
+orig = hip._SLABS.launch_gemms
+def spy(max_wgs=0):
+    tot = 0
+    rows = []
+    for (gY, X, M, N, K, hb, slab) in hip._SLABS.gemms:
+        tot += 2.0 * M * N * K
+        rows.append((M, N, K))
+    import collections
+    c = collections.Counter(rows)
+    print("queued GEMMs", len(rows), "GFLOP %.2f" % (tot / 1e9))
+    for k, v in sorted(c.items(), key=lambda kv: -2.0 * kv[0][0] * kv[0][1] * kv[0][2] * kv[1])[:25]:
+        print("  M=%6d N=%4d K=%4d x%d  %.2f GFLOP" % (k[0], k[1], k[2], v, 2e-9 * k[0] * k[1] * k[2] * v))
+    return orig(max_wgs)
+hip._SLABS.launch_gemms = spy
+tr.step(b)
+torch.cuda.synchronize()
