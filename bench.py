@@ -143,13 +143,13 @@ def roofline_fused_bwd(trainer, batch, iters=30, wgs=None):
         p, st = hip._p, hip._stream()
         fn = lambda: _lib.call("msde_cfconv_fused_bwd_w", p(g), p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst),
                                p(W1), p(b1), p(W2), p(de.offset), N, 128, G, rplan.E, float(de.coeff), float(sch.cutoff),
-                               mw, p(gW1), p(gb1), p(gW2), p(gb2), p(ws), st)
+                               mw, p(None), p(None), p(None), p(None), p(ws), st)      # slabs only: the kernel alone
         ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
     flops = E * 2.0 * (2 * G * 128 + 2 * 128 * 128)
     tf = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "cfconv_fused_bwd_w_kernel (+ slab reduce)", "bound": "mfma", "achieved": round(tf, 2),
+    return {"kernel": "cfconv_fused_bwd_w_pipe_kernel", "bound": "mfma", "achieved": round(tf, 2),
             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-            "traffic": _pmc_traffic("cfconv_fused_bwd_w_kernel", E, N, wgs), "flops_per_launch": flops,
+            "traffic": _pmc_traffic("cfconv_fused_bwd_w_pipe_kernel", E, N, wgs), "flops_per_launch": flops,
             "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N,
             "workgroups": "full width" if wgs is None else int(wgs)}
 

@@ -3,8 +3,8 @@ hot path (same class names, constructor arguments, forward signatures and state_
 from .gnn import GNN
 from .schnet import SchNet
 from .sde_2d_to_3d import SDEModel2Dto3D_01, SDEModel2Dto3D_02
-from .sde_3d_to_2d import SDEModel3Dto2D_node_adj_dense
+from .sde_3d_to_2d import SDEModel3Dto2D_node_adj_dense, SDEModel3Dto2D_node_adj_dense_02
 from .nn import prepare_batch, CpuReplayNoise, DeviceNoise
 from .sde import VESDE, VPSDE
 
-__all__ = ["GNN", "SchNet", "SDEModel2Dto3D_01", "SDEModel2Dto3D_02", "SDEModel3Dto2D_node_adj_dense", "prepare_batch", "CpuReplayNoise", "DeviceNoise", "VESDE", "VPSDE"]
+__all__ = ["GNN", "SchNet", "SDEModel2Dto3D_01", "SDEModel2Dto3D_02", "SDEModel3Dto2D_node_adj_dense", "SDEModel3Dto2D_node_adj_dense_02", "prepare_batch", "CpuReplayNoise", "DeviceNoise", "VESDE", "VPSDE"]

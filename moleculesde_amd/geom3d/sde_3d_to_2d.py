@@ -198,6 +198,8 @@ class NodeScoreNetwork_dense(nn.Module):
 
 
 class SDEModel3Dto2D_node_adj_dense(nn.Module):
+    CONCAT_EMBEDDINGS = False     # _02 (below): the two embeddings are concatenated instead of added
+
     def __init__(self, dim3D, nhid, num_layers, num_linears, c_hid, c_final, adim, emb_dim, beta_min, beta_max,
                  num_diffusion_timesteps, c_init=1, num_heads=4, conv="MLP", noise_mode="discrete", SDE_type="VE",
                  num_class_X=119, noise_on_one_hot=True):
@@ -217,10 +219,11 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
         self.num_class_X, self.noise_on_one_hot = num_class_X, noise_on_one_hot
         self.embedding_X = _nn.Linear(num_class_X if noise_on_one_hot else 1, dim3D)
         self.embedding_3D = _nn.Linear(dim3D, dim3D)
-        self.edge_score_network = EdgeScoreNetwork_dense(dim3D=dim3D, nhid=nhid, num_layers=num_layers,
+        net_in = 2 * dim3D if self.CONCAT_EMBEDDINGS else dim3D
+        self.edge_score_network = EdgeScoreNetwork_dense(dim3D=net_in, nhid=nhid, num_layers=num_layers,
                                                          num_linears=num_linears, c_init=c_init, c_hid=c_hid,
                                                          c_final=c_final, adim=adim, num_heads=4, conv=conv)
-        self.node_score_network = NodeScoreNetwork_dense(nfeat=dim3D, depth=num_layers, nhid=nhid,
+        self.node_score_network = NodeScoreNetwork_dense(nfeat=net_in, depth=num_layers, nhid=nhid,
                                                          nout=num_class_X if noise_on_one_hot else 1)
         self.noise = _nn.DeviceNoise()
 
@@ -276,7 +279,7 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
         device = node_3D_repr.device
         pl = _plan.get_plan(data)
         dn = _plan.dense_plan(pl, data)                                      # padded layout, built once per batch
-        if USE_FUSED_HEAD and self.noise_on_one_hot and hasattr(pl, "bond_type") and \
+        if USE_FUSED_HEAD and not self.CONCAT_EMBEDDINGS and self.noise_on_one_hot and hasattr(pl, "bond_type") and \
                 _dh.fused_supported(self.edge_score_network, self.node_score_network, dn.N_max):
             return self._forward_fused(node_3D_repr, data, reduce_mean, anneal_power, pl, dn)
         B, Nm, T = pl.B, dn.N_max, self.num_diffusion_timesteps
@@ -301,7 +304,10 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
         z_x = mask_x(self.noise.randn_like(x0), flags)
         mean_x, std_x = self.sde_x.marGINal_prob(x0, t)
         perturbed_x = mask_x(mean_x + std_x[:, None, None] * z_x, flags)
-        perturbed_x = self.embedding_3D(h3) + self.embedding_X(perturbed_x)   # (:156)
+        if self.CONCAT_EMBEDDINGS:
+            perturbed_x = torch.cat([self.embedding_3D(h3), self.embedding_X(perturbed_x)], -1)   # _02 (:326)
+        else:
+            perturbed_x = self.embedding_3D(h3) + self.embedding_X(perturbed_x)   # (:156)
 
         score_adj = -self.edge_score_network(perturbed_x, perturbed_adj, flags) / std_adj[:, None, None]   # (:86-94)
         score_x = -self.node_score_network(perturbed_x, perturbed_adj, flags) / std_x[:, None, None]
@@ -320,14 +326,23 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
         return torch.mean(losses_x), torch.mean(losses_adj)
 
 
+class SDEModel3Dto2D_node_adj_dense_02(SDEModel3Dto2D_node_adj_dense):
+    """SDE_model_3D_to_2D_node_adj_dense.py:182-345: identical to the model above except that embedding_3D(h) and
+    embedding_X(x) are CONCATENATED (:326) and both score networks take 2 * dim3D features (:223,233).  Same state_dict
+    keys.  Runs on the operator-by-operator kernel path (the single-node fused head covers the additive variant)."""
+    CONCAT_EMBEDDINGS = True
+
+
 def build_from_args(args, node_class=119):
-    """pretrain_MoleculeSDE.py:276-315 (SDEModel3Dto2D_node_adj_dense branch)."""
-    if args.SDE_3Dto2D_model != "SDEModel3Dto2D_node_adj_dense":
+    """pretrain_MoleculeSDE.py:276-315 (SDEModel3Dto2D_node_adj_dense branches)."""
+    classes = {"SDEModel3Dto2D_node_adj_dense": SDEModel3Dto2D_node_adj_dense,
+               "SDEModel3Dto2D_node_adj_dense_02": SDEModel3Dto2D_node_adj_dense_02}
+    if args.SDE_3Dto2D_model not in classes:
         raise NotImplementedError(args.SDE_3Dto2D_model)
     ranges = {"VE": ("VE", 0.1, 1.0), "VP": ("VP", 0.2, 1.0), "VE02": ("VE", 0.1, 10.0), "VP02": ("VP", 0.1, 30.0),
               "VE03": ("VE", 0.1, 1000.0), "VP03": ("VP", 0.1, 1000.0)}
     sde_type, bmin, bmax = ranges[args.SDE_type_3Dto2D]
-    return SDEModel3Dto2D_node_adj_dense(
+    return classes[args.SDE_3Dto2D_model](
         dim3D=args.emb_dim, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=16, nhid=16, num_layers=4,
         emb_dim=args.emb_dim, num_linears=3, beta_min=bmin, beta_max=bmax, num_diffusion_timesteps=1000,
         SDE_type=sde_type, num_class_X=node_class, noise_on_one_hot=args.noise_on_one_hot)

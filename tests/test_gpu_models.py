@@ -475,6 +475,31 @@ def test_golden_toy_sde3d2d(dev):
     _grads_close(m, sub(g, "grad."), 1e-3, 2e-4, "sde3d2d")
 
 
+def test_golden_f3_sde3d2d_02(dev):
+    """§8 f3: SDEModel3Dto2D_node_adj_dense_02 (concatenated embeddings, 2 * dim3D score networks) against the fixture
+    produced by the reference's own class (oracle/make_golden_f3_02.py): state-dict keys, both losses under replayed
+    noise, the gradient of the 3D representation and every parameter gradient."""
+    import moleculesde_amd.geom3d as G
+    g = load_golden("f3_sde3d2d_02.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    E = g["h3"].shape[1]
+    m = G.SDEModel3Dto2D_node_adj_dense_02(dim3D=E, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=8, nhid=8,
+                                           num_layers=3, emb_dim=E, num_linears=3, beta_min=0.1, beta_max=1.0,
+                                           num_diffusion_timesteps=1000, SDE_type="VE", num_class_X=119,
+                                           noise_on_one_hot=True)
+    assert [k for k, _ in m.named_parameters()] == list(g["param_names"])
+    _set_parameters_like_generator(m, 4200)
+    m.to(dev).train()
+    m.noise = G.CpuReplayNoise(int(g["seed"]))
+    h3 = torch.from_numpy(g["h3"]).to(dev).requires_grad_(True)
+    lx, la = m(h3, b, reduce_mean=True, continuous=True, train=True, anneal_power=0)
+    assert_close(lx, g["loss_x"], 1e-4, 1e-6, "loss_x")
+    assert_close(la, g["loss_adj"], 1e-4, 1e-6, "loss_adj")
+    (lx + la).backward()
+    assert_close(h3.grad, g["grad_h3"], 1e-3, 1e-4 * float(np.abs(g["grad_h3"]).max()), "grad h3")
+    _grads_close(m, sub(g, "grad."), 1e-3, 2e-4, "sde3d2d_02")
+
+
 def test_bs256_full_pretrain_losses_vs_oracle(dev):
     """BASELINE.json configs[2] per-GPU work: all three losses (contrastive + 2D->3D + 3D->2D VE) at bs 256,
     emb 300, against the oracle with replayed noise: each loss term within 1e-3 relative."""

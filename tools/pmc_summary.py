@@ -10,7 +10,7 @@ that read with 16-B-per-lane coalesced loads (gfx950 counts 128-B requests as 64
 import csv, json, statistics, sys, collections, os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ["cfconv_fused_fwd_kernel", "cfconv_fused_bwd_w_kernel", "cfconv_aggregate_bwd_x_kernel", "dense_edge_layer",
+KERNELS = ["cfconv_fused_fwd_kernel", "cfconv_fused_bwd_w_pipe_kernel", "cfconv_aggregate_bwd_x_kernel", "dense_edge_layer",
            "dense_node", "dense_mlp", "dense_pair", "gemm_f32_mfma_kernel", "edge_attention_fwd", "gin_aggregate_fwd"]
 WIDE_READS = {"cfconv_aggregate_bwd_x_kernel", "gin_aggregate_fwd", "edge_attention_fwd"}     # float4 row gathers
 
