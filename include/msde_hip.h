@@ -109,6 +109,12 @@ int msde_dd_seg_expand(const float* g, const int* batch, const int* mol_ptr, int
 /* adjoint of msde_colsum: y[m][k] = b[k] */
 int msde_dd_broadcast_rows(const float* b, int M, int K, float* y, void* stream);
 
+/* loss = ca *a + cb *b + cc *c + cd *d over device scalars (NULL terms are skipped) and its backward
+ * out4[i] = *g * c_i: the loss composition of examples/pretrain_MoleculeSDE.py:139-152 as one launch each way. */
+int msde_combine_losses(const float* a, const float* b, const float* c, const float* d, float ca, float cb, float cc,
+                        float cd, float* out, void* stream);
+int msde_combine_losses_bwd(const float* g, float ca, float cb, float cc, float cd, float* out4, void* stream);
+
 /* Diagnostics: store the 100 MHz real-time counter into *slot, in stream order (capturable). */
 int msde_debug_stamp(long long* slot, void* stream);
 

@@ -78,6 +78,8 @@ SIGNATURES = {
     "msde_dd_seg_expand": [P, P, P, I, I, I, P, P],
     "msde_dd_broadcast_rows": [P, I, I, P, P],
     "msde_debug_stamp": [P, P],
+    "msde_combine_losses": [P, P, P, P, F, F, F, F, P, P],
+    "msde_combine_losses_bwd": [P, F, F, F, F, P, P],
     "msde_set_row_bound": [I, P],
     "msde_clear_row_bounds": [],
     "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],

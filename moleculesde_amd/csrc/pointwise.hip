@@ -300,3 +300,33 @@ extern "C" int msde_ve_pos_loss_bwd(const float* scores, const float* noise, con
   MSDE_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- the weighted sum of the step's loss terms as ONE launch each way (pretrain_MoleculeSDE.py:139-152: loss =
+// sum_i c_i * l_i over up to four scalar terms).  As torch operators the combination and its backward were 9 launches of
+// one thread each on the critical path between the forward and the backward pass.
+__global__ void combine_losses_kernel(const float* a, const float* b, const float* c, const float* d, float ca, float cb,
+                                      float cc, float cd, float* out) {
+  float s = 0.f;
+  if (a) s = fmaf(ca, *a, s);
+  if (b) s = fmaf(cb, *b, s);
+  if (c) s = fmaf(cc, *c, s);
+  if (d) s = fmaf(cd, *d, s);
+  *out = s;
+}
+__global__ void combine_losses_bwd_kernel(const float* g, float ca, float cb, float cc, float cd, float* out4) {
+  const float v = *g;
+  out4[0] = v * ca; out4[1] = v * cb; out4[2] = v * cc; out4[3] = v * cd;
+}
+extern "C" int msde_combine_losses(const float* a, const float* b, const float* c, const float* d, float ca, float cb,
+                                   float cc, float cd, float* out, void* stream) {
+  if (!out) return MSDE_EINVAL;
+  MSDE_LAUNCH(combine_losses_kernel, dim3(1), dim3(1), 0, as_stream(stream), a, b, c, d, ca, cb, cc, cd, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_combine_losses_bwd(const float* g, float ca, float cb, float cc, float cd, float* out4, void* stream) {
+  if (!g || !out4) return MSDE_EINVAL;
+  MSDE_LAUNCH(combine_losses_bwd_kernel, dim3(1), dim3(1), 0, as_stream(stream), g, ca, cb, cc, cd, out4);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

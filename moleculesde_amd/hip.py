@@ -1220,14 +1220,16 @@ class _ContrastiveEBM(torch.autograd.Function):
                   _p(out), _stream())
         ctx.save_for_backward(X, Y, p1, p2, inv1, inv2, rows)
         ctx.invT = 1.0 / float(T)
-        return out                         # [loss, accuracy]; split by the caller (plain autograd views)
+        loss, acc = out[0], out[1]         # two outputs (a select on ONE output costs a zeros + copy in its backward)
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_loss, g_acc):
         X, Y, p1, p2, inv1, inv2, rows = ctx.saved_tensors
         N, D = X.shape
         gX, gY = torch.empty_like(X), torch.empty_like(Y)
-        g = _f32(g_out)                    # g[0] = d/d(loss); the accuracy carries no gradient
+        g = _f32(g_loss).reshape(1)        # d/d(loss); the accuracy carries no gradient
         _lib.call("msde_cl_ebm_bwd", _p(X), _p(Y), _p(p1), _p(p2), _p(inv1), _p(inv2), _p(rows), _p(g), N, D, ctx.invT,
                   _p(gX), _p(gY), _stream())
         return gX, gY, None, None, None
@@ -1235,8 +1237,8 @@ class _ContrastiveEBM(torch.autograd.Function):
 
 def contrastive_ebm(X, Y, perm1, perm2, T):
     """dual_CL with 'EBM_node_dot_prod' (examples/util.py:52-68,76-79): returns (loss, accuracy)."""
-    out = _ContrastiveEBM.apply(X, Y, perm1, perm2, T)
-    return out[0], out[1].detach()
+    loss, acc = _ContrastiveEBM.apply(X, Y, perm1, perm2, T)
+    return loss, acc
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1449,6 +1451,32 @@ class _VEPosLoss(torch.autograd.Function):
         _lib.call("msde_ve_pos_loss_bwd", _p(scores), _p(noise), _p(std if ctx.has_std else None), ctx.power, _p(mol_ptr),
                   _p(batch_i32), N, B, _p(g), _p(gs), _stream())
         return gs, None, None, None, None, None
+
+
+class _CombineLosses(torch.autograd.Function):
+    """sum_i c_i * l_i over device scalars: one launch forward, one backward (csrc/pointwise.hip)."""
+
+    @staticmethod
+    def forward(ctx, coeffs, *terms):
+        assert 1 <= len(terms) <= 4 and len(coeffs) == len(terms)
+        ts = [_f32(t).reshape(1) for t in terms]
+        c = [float(x) for x in coeffs] + [0.0] * (4 - len(terms))
+        out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        ptrs = [_p(t) for t in ts] + [_p(None)] * (4 - len(ts))
+        _lib.call("msde_combine_losses", *ptrs, *c, _p(out), _stream())
+        ctx.c, ctx.n = c, len(terms)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g).reshape(1)
+        out4 = torch.empty(4, dtype=torch.float32, device=g.device)
+        _lib.call("msde_combine_losses_bwd", _p(g), *ctx.c, _p(out4), _stream())
+        return (None,) + tuple(out4[i] for i in range(ctx.n))
+
+
+def combine_losses(coeffs, terms):
+    return _CombineLosses.apply(tuple(coeffs), *terms)
 
 
 def ve_position_loss(scores, noise, std, anneal_power, mol_ptr, batch_i32):

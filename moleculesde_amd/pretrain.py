@@ -207,6 +207,7 @@ class Trainer:
         from . import tuned_gemm
         tuned_gemm.enable()           # per-signature library-GEMM algorithm lookup (read-only; see tuned_gemm.py)
         self._side_stream = torch.cuda.Stream(device=device)
+        self._one_grad = torch.ones((), dtype=torch.float32, device=device)
         if EARLY_WGRAD_FLUSH:
             # when the 2D encoder's backward is through, launch the weight gradients queued so far (2D->3D model and
             # GIN) on the same stream: they run while the second stream still finishes SchNet's backward, and only
@@ -239,7 +240,7 @@ class Trainer:
         step fill only part of the chip, so SchNet runs on a second HIP stream beside the 2D branch; autograd
         replays each op's backward on the stream of its forward, so the backward overlaps the same way."""
         a, m = self.args, self.models
-        loss = 0
+        terms, coeffs = [], []      # loss = sum_i c_i * term_i, composed by ONE kernel (hip.combine_losses)
         parts = {}
         main = torch.cuda.current_stream()
         want_32 = a.SDE_coeff_generative_3Dto2D > 0
@@ -252,9 +253,8 @@ class Trainer:
             self._side_geometry(True)          # until the end of this step's backward pass
 
         def head_32(rep):
-            lx, la = m["SDE_3Dto2D_model"](rep, batch, reduce_mean=a.noise_on_one_hot, continuous=True, train=True,
-                                           anneal_power=a.SDE_anneal_power)
-            return (lx + la) * 0.5
+            return m["SDE_3Dto2D_model"](rep, batch, reduce_mean=a.noise_on_one_hot, continuous=True, train=True,
+                                         anneal_power=a.SDE_anneal_power)      # (loss_x, loss_adj); their mean below
 
         # random draws keep the reference's program order (contrastive permutations, then the 2D->3D noise);
         # both happen before any encoder runs so that the coordinate-only branch of the 2D->3D model can start
@@ -288,7 +288,7 @@ class Trainer:
             node_2D_repr.register_hook(lambda g: _hip.stamp("gin_bwd_start"))
         if a.SDE_coeff_generative_2Dto3D > 0:
             l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
-            loss = loss + l23 * a.SDE_coeff_generative_2Dto3D
+            terms.append(l23); coeffs.append(a.SDE_coeff_generative_2Dto3D)
             parts["2Dto3D"] = l23.detach()
             _hip.stamp("2d3d_fwd_end")
             if stamps:
@@ -297,16 +297,26 @@ class Trainer:
             main.wait_stream(side)
             node_3D_repr.record_stream(main)
             if l32 is not None:
-                l32.record_stream(main)
+                l32[0].record_stream(main)
+                l32[1].record_stream(main)
         if self.coeff_cl > 0:
             cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
-            loss = loss + cl * self.coeff_cl
+            terms.append(cl); coeffs.append(self.coeff_cl)
             parts["CL"], parts["CL_acc"] = cl.detach(), acc
         if want_32:
             if l32 is None:
                 l32 = head_32(node_3D_repr)
-            loss = loss + l32 * a.SDE_coeff_generative_3Dto2D
-            parts["3Dto2D"] = l32.detach()
+            terms += [l32[0], l32[1]]                      # (loss_x + loss_adj) / 2 (pretrain_MoleculeSDE.py:148)
+            coeffs += [0.5 * a.SDE_coeff_generative_3Dto2D] * 2
+            with torch.no_grad():
+                parts["3Dto2D"] = (_hip.combine_losses([0.5, 0.5], [l32[0].detach(), l32[1].detach()])
+                                   if l32[0].is_cuda else (l32[0].detach() + l32[1].detach()) * 0.5)
+        if terms and all(t.is_cuda for t in terms) and len(terms) <= 4:
+            loss = _hip.combine_losses(coeffs, terms)
+        else:
+            loss = 0
+            for c_, t_ in zip(coeffs, terms):
+                loss = loss + t_ * c_
         return loss, parts
 
     def _log_parts(self, parts):
@@ -317,13 +327,14 @@ class Trainer:
         """loss.backward() with the weight-gradient slab reductions of all layers batched into one launch."""
         from . import hip
         try:
+            one = self._one_grad if loss.is_cuda else None     # preallocated d(loss)/d(loss): no fill launch per step
             if not BATCH_SLAB_REDUCE:
-                loss.backward()
+                loss.backward(one)
                 return
             hip.begin_param_grad_batch(self.opt.params)
             try:
                 hip.stamp("bwd_start")
-                loss.backward()
+                loss.backward(one)
                 hip.stamp("bwd_main_end")
                 if hip.STAMPS is not None and self.overlap_streams:
                     with torch.cuda.stream(self._side_stream):
