@@ -39,8 +39,10 @@ __device__ __forceinline__ float ssp_fast(float x) {
   // softplus(x) - ln2 = max(x,0) + log(1 + exp(-|x|)) - ln2.  Hardware exp/log (v_exp_f32/v_log_f32):
   // absolute error ~1e-7, the same as the fp32 rounding of the reference's result; identical to torch's
   // threshold-20 branch for x > 20 (exp(-20) vanishes against 1).
-  float e = __expf(-fabsf(x));
-  return fmaxf(x, 0.f) + __logf(1.f + e) - 0.69314718246459961f;
+  // raw v_exp_f32 / v_log_f32 (1 ulp): the fp32 MFMA leaves no issue shadow for vector instructions
+  // (profiles/r02_probe_fp32_mfma_fillers.txt), so the range-checked __expf / __logf sequences are paid in full
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));
+  return fmaf(__builtin_amdgcn_logf(1.f + e), 0.69314718055994531f, fmaxf(x, 0.f) - 0.69314718055994531f);
 }
 
 __device__ __forceinline__ int cf_row(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
@@ -69,7 +71,6 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
                         const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
                         float* __restrict__ agg, float* __restrict__ Wf_out) {
   constexpr int RS = 2 * KK1 + 1;           // rbf tile row stride (odd)
-  constexpr int NR = (CF_TE * 2 * KK1 + 255) / 256;   // rbf entries per thread
   extern __shared__ float lds[];
   float* rbf_t = lds;                          // [32][RS]      rbf tile (A of GEMM1)
   float* hid_t = rbf_t + CF_TE * RS;           // [32][129]     hidden tile (A of GEMM2)
@@ -159,21 +160,26 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
     }
   }
   const float b1c = b1[col], b2c = b2[col];
-  if (tid < 64) off_s[tid] = tid < G ? offset[tid] : 0.f;
 
   // ---- one-chunk-ahead production of everything that depends only on the edge list.  The global loads are
   // REQUESTED right after the chunk's first barrier and CONSUMED (exp / cos) after its last MFMA, so their
   // latency lies under the GEMMs; no load depends on another load (the "does my first / last target continue
   // in the neighbouring chunk" flags come from dst[ec-1] and dst[ce], not from rowptr[dst[..]]).
-  float rv[NR];                 // distances, then rbf values
+  // smearing tile: lane = column g (lanes >= 2 KK1 repeat the last column: same value, same address), row = wave + 4 j:
+  // the centre is a register, the distance a wave-uniform load, no index arithmetic
+  constexpr int NRW = CF_TE / 4;
+  float rv[NRW];                // distances, then rbf values
   float m_d = 0.f;
   int m_s = -1, m_t = -1, m_prev = -2, m_next = -2;
+  const int rbf_g = min(lane, 2 * KK1 - 1);
+  const float rbf_mu = rbf_g < G ? offset[rbf_g] : 0.f;
+  const float coeff2 = coeff * 1.4426950408889634f;
   auto produce_load = [&](int ec) {
     const int ce = min(ec + CF_TE, e_end);
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      int r = (tid + 256 * j) / (2 * KK1);
-      rv[j] = (r < CF_TE && ec + r < ce) ? dist[ec + r] : -1.f;
+    for (int j = 0; j < NRW; ++j) {
+      const int r = wave + 4 * j;
+      rv[j] = ec + r < ce ? dist[ec + r] : -1.f;
     }
     if (tid < CF_TE) {
       int e = ec + tid;
@@ -187,15 +193,20 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
   };
   auto produce_math = [&]() {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      int g = (tid + 256 * j) % (2 * KK1);
-      float diff = rv[j] - off_s[g];
-      rv[j] = (rv[j] >= 0.f && g < G) ? __expf(coeff * (diff * diff)) : 0.f;
+    for (int j = 0; j < NRW; ++j) {
+      const float diff = rv[j] - rbf_mu;
+      const float v = __builtin_amdgcn_exp2f(coeff2 * (diff * diff));
+      rv[j] = (rv[j] >= 0.f && rbf_g < G) ? v : 0.f;      // padding rows and columns >= G are zero (A operand of GEMM1)
     }
   };
   produce_load(e_begin);
-  __syncthreads();              // off_s visible
   produce_math();
+  // per-lane LDS bases: every tile access below is base + compile-time offset (ds immediates) instead of one address
+  // VGPR per access (the same change took 240 B of scratch and a third of the VALU work out of the backward kernel)
+  constexpr auto RW = [](int i) constexpr { return (i & 3) + 8 * (i >> 2); };     // cf_row without the lane-half term
+  float* const hw = hid_t + 4 * lhalf * CF_HS + col;          // hidden tile stores     + RW(i) * HS
+  const float* const ra = rbf_t + lcol * RS + lhalf;          // A of GEMM1             + 2 kk
+  const float* const ha = hid_t + lcol * CF_HS + lhalf;       // A of GEMM2             + 2 kk
   CF_STAMP(1);
 
   int buf = 0;
@@ -203,14 +214,11 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
     const int ce = min(ec + CF_TE, e_end);
     // ---- P0: publish this chunk's rbf tile and metadata
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      int idx = tid + 256 * j;
-      if (idx < CF_TE * 2 * KK1) rbf_t[(idx / (2 * KK1)) * RS + idx % (2 * KK1)] = rv[j];
-    }
+    for (int j = 0; j < NRW; ++j) rbf_t[(wave + 4 * j) * RS + rbf_g] = rv[j];
     const int nxt = __shfl(m_next, 0);
     if (tid < CF_TE) {
       c_s[buf * CF_TE + tid] = m_t >= 0 ? 0.5f * (__cosf(m_d * (PI_F / cutoff)) + 1.0f) : 0.f;
-      src_s[buf * CF_TE + tid] = m_s;
+      src_s[buf * CF_TE + tid] = max(m_s, 0) * (CF_F * 4);     // BYTE offset of the gathered x1 row
       dst_s[buf * CF_TE + tid] = m_t;
       if (tid == 0) flag_s[buf * 4] = (m_prev == m_t);
       if (tid == ce - ec - 1) { flag_s[buf * 4 + 1] = (nxt == m_t); flag_s[buf * 4 + 2] = m_t; }
@@ -218,15 +226,15 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
     __syncthreads();   // B1
     CF_STAMP(2);
 
-    const float* cb = c_s + buf * CF_TE;
-    const int* sb = src_s + buf * CF_TE;
+    const float* cb = c_s + buf * CF_TE + 4 * lhalf;            // + RW(i): this lane half's rows
+    const int* sb = src_s + buf * CF_TE + 4 * lhalf;
     const int* db = dst_s + buf * CF_TE;
+    const int* dbh = db + 4 * lhalf;
     // gathered x1 rows for the epilogue: request now, consume after the GEMMs
     float xg[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      int s0 = sb[cf_row(i, lhalf)];
-      xg[i] = x1[(size_t)(s0 >= 0 ? s0 : 0) * CF_F + col];
+      xg[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(x1) + (unsigned)(sb[RW(i)] + 4 * col));
     }
     const bool more = ec + CF_TE < e_end;
     if (more) produce_load(ec + CF_TE);
@@ -237,11 +245,11 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < KK1; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(rbf_t[lcol * RS + 2 * kk + lhalf], w1r[kk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * kk], w1r[kk], acc, 0, 0, 0);
     CF_STAMP(3);
     // epilogue 1: bias + shifted softplus -> hidden tile
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hid_t[cf_row(i, lhalf) * CF_HS + col] = ssp_fast(acc[i] + b1c);
+    for (int i = 0; i < 16; ++i) hw[RW(i) * CF_HS] = ssp_fast(acc[i] + b1c);
     __syncthreads();   // B2
     CF_STAMP(4);
 
@@ -250,14 +258,14 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < CF_F / 2; ++kk)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hid_t[lcol * CF_HS + 2 * kk + lhalf], w2r[kk], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[2 * kk], w2r[kk], acc, 0, 0, 0);
 
     CF_STAMP(5);
     // epilogue 2 (registers only): filter = (acc + b2) * C ; message = x1[src] * filter
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       int row = cf_row(i, lhalf);
-      float f0 = (acc[i] + b2c) * cb[row];          // padding rows: C = 0 -> message 0
+      float f0 = (acc[i] + b2c) * cb[RW(i)];        // padding rows: C = 0 -> message 0
       if (Wf_out && ec + row < ce) Wf_out[(size_t)(ec + row) * CF_F + col] = f0;
       acc[i] = xg[i] * f0;
     }
@@ -276,7 +284,7 @@ cfconv_fused_fwd_kernel(const float* __restrict__ x1, const float* __restrict__ 
       const int want = t0 + tile * 32 + lcol;
 #pragma unroll
       for (int s2 = 0; s2 < 16; ++s2) {
-        float sa = db[cf_row(s2, lhalf)] == want ? 1.f : 0.f;
+        float sa = dbh[RW(s2)] == want ? 1.f : 0.f;
         d = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, acc[s2], d, 0, 0, 0);
       }
 #pragma unroll

@@ -29,3 +29,17 @@ with torch.no_grad():
         t = timeit(fn)
         print(f"dbg={os.environ.get('MSDE_CFBWD_DBG', '0'):>4s} pipe={os.environ.get('MSDE_CFBWD_PIPE', '-')} width={mw or 256:4d}  "
               f"{t:7.1f} us  {flop / t / 1e6:6.1f} TF  frac {flop / t / 1e6 / 157.3:.3f}", flush=True)
+
+    # ---- the fused forward (training mode: filter rows written), full width and the step's width
+    b2 = torch.randn(128, device=dev) * 0.1
+    agg = torch.empty(N, 128, device=dev)
+    Wf = torch.empty(rplan.E, 128, device=dev)
+    fflop = 2.0 * E * (52 * 128 + 128 * 128)
+    for wgs in (None, 256):
+        cpw = hip.FUSED_CHUNKS_PER_WG if wgs is None else max(1, -(-((rplan.E + 31) // 32) // int(wgs)))
+        fn = lambda: _lib.call("msde_cfconv_fused_fwd", p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst), p(W1),
+                               p(b1), p(W2), p(b2), p(offset), N, 128, 51, rplan.E, coeff, 10.0, cpw, p(agg), p(Wf),
+                               hip._stream())
+        agg.zero_()
+        t = timeit(fn)
+        print(f"fwd  width={wgs or 'full':>5}  {t:7.1f} us  {fflop / t / 1e6:6.1f} TF  frac {fflop / t / 1e6 / 157.3:.3f}", flush=True)

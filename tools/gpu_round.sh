@@ -27,7 +27,7 @@ trace)
   rm -rf $O/trace;;
 cfpipe)
   timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "cfconv" > $O/cf_test.log 2>&1; echo "cf test rc=$?"; tail -8 $O/cf_test.log
-  for d in 1 0; do MSDE_CFBWD_PIPE=$d timeout 300 python tools/bench_cfconv_bwd.py 2>&1 | grep dbg=; done | tee $O/cfpipe.log;;
+  for d in 1 0; do MSDE_CFBWD_PIPE=$d timeout 300 python tools/bench_cfconv_bwd.py 2>&1 | grep "dbg=\|fwd "; done | tee $O/cfpipe.log;;
 cfdbg)
   for d in 0 1 2 4 7 8 16 32 64 120 127 128 255; do MSDE_CFBWD_DBG=$d timeout 300 python tools/bench_cfconv_bwd.py 2>&1 | grep dbg=; done | tee $O/cfdbg.log;;
 md17)
