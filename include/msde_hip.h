@@ -84,7 +84,8 @@ int msde_plan_row_lists(const int* codes, const int* n_dev, int K, int R, int* c
 /* ------------------------------------------------------------------ twice-differentiable force path -------- */
 /* Non-GEMM members of the closed operator set of the MD17 energy/force path (moleculesde_amd/dd.py; replaces the ATen
  * operators autograd differentiates twice in examples/finetune_MD17.py:47-78 over Geom3D/models/schnet.py:85-125).
- * kind 0: shifted softplus (schnet.py:213-216), 1: cosine cutoff with p0 = cutoff (schnet.py:186), 2: reciprocal;
+ * kind 0: shifted softplus (schnet.py:213-216), 1: cosine cutoff with p0 = cutoff (schnet.py:186; 0 for x >= p0,
+ * painn_utils.py:150-154), 2: reciprocal, 3: SiLU (painn.py activation), 4: sqrt(x + p0) (painn.py:104);
  * order = derivative order 0..2.  mask (may be NULL): entries < 0 give 0. */
 int msde_dd_unary(const float* x, const int* mask, long long n, int kind, int order, float p0, float* y, void* stream);
 /* Gaussian smearing exp(coeff (d - mu_g)^2) (schnet.py:205-207) and its 1st / 2nd derivative in d: y [E][G];
@@ -106,6 +107,10 @@ int msde_dd_row_norm(const float* v, const int* src, int E, float* y, void* stre
 /* adjoint of the per-molecule readout (schnet.py:122): y[i] = g[batch[i]] (/ atoms of that molecule if mean) */
 int msde_dd_seg_expand(const float* g, const int* batch, const int* mol_ptr, int N, int K, int mean, float* y,
                        void* stream);
+/* per-edge 3-vectors [E][3] -> component-major [3][E] (to_soa = 1) and back (0): adjoint pair */
+int msde_dd_transpose3(const float* x, int E, int to_soa, float* y, void* stream);
+/* y[e] = (a[e], b[e], c[e]); a NULL component reads as zeros */
+int msde_dd_merge3(const float* a, const float* b, const float* c, int E, float* y, void* stream);
 /* adjoint of msde_colsum: y[m][k] = b[k] */
 int msde_dd_broadcast_rows(const float* b, int M, int K, float* y, void* stream);
 

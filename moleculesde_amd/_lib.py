@@ -77,6 +77,8 @@ SIGNATURES = {
     "msde_dd_row_norm": [P, P, I, P, P],
     "msde_dd_seg_expand": [P, P, P, I, I, I, P, P],
     "msde_dd_broadcast_rows": [P, I, I, P, P],
+    "msde_dd_transpose3": [P, I, I, P, P],
+    "msde_dd_merge3": [P, P, P, I, P, P],
     "msde_debug_stamp": [P, P],
     "msde_combine_losses": [P, P, P, P, F, F, F, F, P, P],
     "msde_combine_losses_bwd": [P, F, F, F, F, P, P],

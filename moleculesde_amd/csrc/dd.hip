@@ -16,8 +16,9 @@
 
 __device__ __forceinline__ float dd_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-// kind 0: shifted softplus, order 0..2; kind 1: cosine cutoff 0.5 (cos(pi d / rc) + 1), order 0..2 (p0 = rc);
-// kind 2: reciprocal (order ignored).  mask (optional int array): entries < 0 give 0.
+// kind 0: shifted softplus, order 0..2; kind 1: cosine cutoff 0.5 (cos(pi d / rc) + 1) for d < rc, 0 beyond, order 0..2
+// (p0 = rc); kind 2: reciprocal (order ignored); kind 3: SiLU x sigmoid(x), order 0..2 (painn.py activation);
+// kind 4: sqrt(x + p0), order 0..2 (painn.py:104).  mask (optional int array): entries < 0 give 0.
 __global__ void dd_unary_kernel(const float* __restrict__ x, const int* __restrict__ mask, long long n, int kind, int order,
                                 float p0, float* __restrict__ y) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -29,8 +30,15 @@ __global__ void dd_unary_kernel(const float* __restrict__ x, const int* __restri
     } else if (kind == 1) {
       const float w = 3.14159265358979323846f / p0, a = v * w;
       r = order == 0 ? 0.5f * (cosf(a) + 1.f) : order == 1 ? -0.5f * w * sinf(a) : -0.5f * w * w * cosf(a);
-    } else {
+      if (v >= p0) r = 0.f;                      // painn_utils.py:150-154 (SchNet's radius edges never get here)
+    } else if (kind == 2) {
       r = 1.f / v;
+    } else if (kind == 3) {
+      const float s = dd_sigmoid(v), t = 1.f - s;
+      r = order == 0 ? v * s : order == 1 ? s * (1.f + v * t) : s * t * (2.f + v * (t - s));
+    } else {
+      const float q = sqrtf(v + p0);
+      r = order == 0 ? q : order == 1 ? 0.5f / q : -0.25f / (q * (v + p0));
     }
     if (mask && mask[i] < 0) r = 0.f;
     y[i] = r;
@@ -120,9 +128,37 @@ __global__ void dd_broadcast_rows_kernel(const float* __restrict__ b, int M, int
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = b[i % K];
 }
 
+// [E][3] <-> [3][E] (component-major copies of per-edge 3-vectors: every component is then a contiguous row vector)
+__global__ void dd_transpose3_kernel(const float* __restrict__ x, int E, int to_soa, float* __restrict__ y) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * E; i += gridDim.x * 256) {
+    const int e = i / 3, c = i - 3 * e;
+    if (to_soa) y[(size_t)c * E + e] = x[i]; else y[i] = x[(size_t)c * E + e];
+  }
+}
+__global__ void dd_merge3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int E,
+                                 float* __restrict__ y) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < E; e += gridDim.x * 256) {
+    y[3 * e] = a ? a[e] : 0.f; y[3 * e + 1] = b ? b[e] : 0.f; y[3 * e + 2] = c ? c[e] : 0.f;
+  }
+}
+extern "C" int msde_dd_merge3(const float* a, const float* b, const float* c, int E, float* y, void* stream) {
+  if (E < 0 || !y) return MSDE_EINVAL;
+  if (E == 0) return 0;
+  MSDE_LAUNCH(dd_merge3_kernel, DD_GRID((long long)E), dim3(256), 0, as_stream(stream), a, b, c, E, y);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_dd_transpose3(const float* x, int E, int to_soa, float* y, void* stream) {
+  if (E < 0 || !x || !y) return MSDE_EINVAL;
+  if (E == 0) return 0;
+  MSDE_LAUNCH(dd_transpose3_kernel, DD_GRID(3LL * E), dim3(256), 0, as_stream(stream), x, E, to_soa, y);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int msde_dd_unary(const float* x, const int* mask, long long n, int kind, int order, float p0, float* y,
                              void* stream) {
-  if (n < 0 || !x || !y || kind < 0 || kind > 2 || order < 0 || order > 2) return MSDE_EINVAL;
+  if (n < 0 || !x || !y || kind < 0 || kind > 4 || order < 0 || order > 2) return MSDE_EINVAL;
   if (n == 0) return 0;
   MSDE_LAUNCH(dd_unary_kernel, DD_GRID(n), dim3(256), 0, as_stream(stream), x, mask, n, kind, order, p0, y);
   MSDE_CHECK_LAUNCH();

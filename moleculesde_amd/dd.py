@@ -59,6 +59,15 @@ def ssp(x):
     return _Unary.apply(x, 0, 0, 0.0, None)
 
 
+def silu(x):
+    return _Unary.apply(x, 3, 0, 0.0, None)
+
+
+def sqrt_eps(x, eps):
+    """sqrt(x + eps)"""
+    return _Unary.apply(x, 4, 0, float(eps), None)
+
+
 def cosine_cutoff(d, cutoff, src):
     """0.5 (cos(pi d / cutoff) + 1); padded edge slots (src < 0) -> 0 at every order."""
     return _Unary.apply(d, 1, 0, cutoff, src)
@@ -205,6 +214,44 @@ class _RowDot(torch.autograd.Function):
 
 
 row_dot = _RowDot.apply
+
+
+class _Split3(torch.autograd.Function):
+    """[E, 3] -> three contiguous [E] component vectors (views of one [3, E] buffer, returned as three OUTPUTS)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        E = x.size(0)
+        y = _new(3, E, like=x)
+        _call("msde_dd_transpose3", _p(x), E, 1, _p(y), _stream())
+        return y[0], y[1], y[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        return _Merge3.apply(g0, g1, g2)
+
+
+class _Merge3(torch.autograd.Function):
+    """three [E] vectors (None = zeros) -> [E, 3]"""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ref = next(t for t in (a, b, c) if t is not None)
+        E = ref.numel()
+        a, b, c = (None if t is None else _f32(t) for t in (a, b, c))
+        y = _new(E, 3, like=ref)
+        _call("msde_dd_merge3", _p(a), _p(b), _p(c), E, _p(y), _stream())
+        ctx.has = (a is not None, b is not None, c is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g0, g1, g2 = _Split3.apply(g)
+        return tuple(t if h else None for t, h in zip((g0, g1, g2), ctx.has))
+
+
+components = _Split3.apply
 
 
 class _EdgeDiff(torch.autograd.Function):

@@ -42,6 +42,10 @@ def add_hot_path_flags(parser):
     a("--SchNet_num_gaussians", type=int, default=51)
     a("--SchNet_cutoff", type=float, default=10)
     a("--SchNet_readout", type=str, default="mean", choices=["mean", "add"])
+    a("--PaiNN_radius_cutoff", type=float, default=5.0)      # config.py (PaiNN block)
+    a("--PaiNN_n_interactions", type=int, default=3)
+    a("--PaiNN_n_rbf", type=int, default=20)
+    a("--PaiNN_readout", type=str, default="add", choices=["mean", "add"])
     a("--CL_similarity_metric", type=str, default="InfoNCE_dot_prod")
     a("--T", type=float, default=0.1)
     a("--normalize", dest="normalize", action="store_true")
@@ -99,12 +103,18 @@ def build_models(args, device):
     models = {}
     models["model_2D"] = GNN(args.num_layer, args.emb_dim, JK=args.JK, drop_ratio=args.dropout_ratio,
                              gnn_type=args.gnn_type).to(device)
-    if args.model_3d != "SchNet":
-        raise NotImplementedError("only SchNet is on the MoleculeSDE hot path")
-    models["model_3D"] = SchNet(hidden_channels=args.emb_dim, num_filters=args.SchNet_num_filters,
-                                num_interactions=args.SchNet_num_interactions,
-                                num_gaussians=args.SchNet_num_gaussians, cutoff=args.SchNet_cutoff,
-                                readout=args.SchNet_readout, node_class=node_class).to(device)
+    if args.model_3d == "SchNet":
+        models["model_3D"] = SchNet(hidden_channels=args.emb_dim, num_filters=args.SchNet_num_filters,
+                                    num_interactions=args.SchNet_num_interactions,
+                                    num_gaussians=args.SchNet_num_gaussians, cutoff=args.SchNet_cutoff,
+                                    readout=args.SchNet_readout, node_class=node_class).to(device)
+    elif args.model_3d == "PaiNN":                              # pretrain_MoleculeSDE.py:212-221
+        from .geom3d import PaiNN
+        models["model_3D"] = PaiNN(n_atom_basis=args.emb_dim, n_interactions=args.PaiNN_n_interactions,
+                                   n_rbf=args.PaiNN_n_rbf, cutoff=args.PaiNN_radius_cutoff, max_z=node_class, n_out=1,
+                                   readout=args.PaiNN_readout).to(device)
+    else:
+        raise NotImplementedError(f"Model {args.model_3d} not included.")
     cls23 = {"SDEModel2Dto3D_01": SDEModel2Dto3D_01, "SDEModel2Dto3D_02": SDEModel2Dto3D_02}.get(args.SDE_2Dto3D_model)
     if cls23 is None:
         raise NotImplementedError(args.SDE_2Dto3D_model)
@@ -234,6 +244,22 @@ class Trainer:
         hip.CFCONV_FWD_WGS = SIDE_CFCONV_FWD_WGS if on else None
         hip.CFCONV_BWD_WGS = SIDE_CFCONV_BWD_WGS if on else None
 
+    def _encode_3d(self, batch):
+        """pretrain_MoleculeSDE.py:131-133: SchNet takes (z, pos, batch); PaiNN also the radius graph of the batch
+        (dataset_3D_Radius.py:155; built here with the radius kernels when the loader did not attach one)."""
+        m3 = self.models["model_3D"]
+        if type(m3).__name__ != "PaiNN":
+            return m3(batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+        ei = getattr(batch, "radius_edge_index", None)
+        if ei is None:
+            from . import hip, plan as _pl
+            pl = _pl.get_plan(batch)
+            rp, _ = hip.radius_plan(batch.positions, pl.batch_i32, pl.mol_ptr, m3.cutoff, pl.E_r_cap, 32)
+            keep = rp.src >= 0                                    # host sync: PaiNN batches are not graph-captured
+            ei = torch.stack([rp.dst[keep], rp.src[keep]]).long()
+            batch.radius_edge_index = ei
+        return m3(batch.x[:, 0], batch.positions, ei, batch.batch, return_latent=True)
+
     def losses(self, batch):
         """Loss composition of pretrain_MoleculeSDE.py:128-152.  The 3D encoder does not depend on the 2D
         branch (GIN -> 2D->3D score model) until the contrastive term, and most kernels of this 256-molecule
@@ -274,14 +300,14 @@ class Trainer:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _hip.stamp("schnet_fwd_start")
-                _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+                _, node_3D_repr = self._encode_3d(batch)
                 _hip.stamp("schnet_fwd_end")
                 if stamps:
                     node_3D_repr.register_hook(lambda g: _hip.stamp("schnet_bwd_start"))
                 if head_on_side:
                     l32 = head_32(node_3D_repr)
         else:
-            _, node_3D_repr = m["model_3D"](batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+            _, node_3D_repr = self._encode_3d(batch)
         node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
         _hip.stamp("gin_fwd_end")
         if stamps:

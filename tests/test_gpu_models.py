@@ -500,6 +500,89 @@ def test_golden_f3_sde3d2d_02(dev):
     _grads_close(m, sub(g, "grad."), 1e-3, 2e-4, "sde3d2d_02")
 
 
+def test_golden_f4_painn(dev):
+    """§8 f4: the PaiNN encoder (painn.py:118-269) on the kernel operator set against the fixture produced by the
+    reference's own class (oracle/make_golden_painn.py): readout, latent atom features, the position gradient (force path)
+    and every parameter gradient; the padding row of the embedding stays without gradient."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import dd
+    g = load_golden("f4_painn.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    m = G.PaiNN(n_atom_basis=32, n_interactions=3, n_rbf=20, cutoff=float(g["cutoff"]), max_z=119, n_out=1, readout="mean")
+    assert [k for k, _ in m.named_parameters()] == list(g["param_names"])
+    _set_parameters_like_generator(m, 6100)
+    with torch.no_grad():
+        m.embedding.weight[0].zero_()
+    m.to(dev)
+    ei = torch.from_numpy(g["radius_edge_index"]).to(dev)
+    pos = b.positions.clone().requires_grad_(True)
+    dd.CALLS.clear()
+    h, q = m(b.x[:, 0], pos, ei, b.batch, return_latent=True)
+    assert_close(h, g["h"], 1e-4, 1e-5, "readout")
+    assert_close(q, g["q"], 1e-4, 1e-5, "latent")
+    (h.pow(2).sum() + q.sum()).backward()
+    assert_close(pos.grad, g["grad_pos"], 1e-3, 1e-4 * float(np.abs(g["grad_pos"]).max()), "grad positions")
+    _grads_close(m, sub(g, "grad."), 1e-3, 2e-4, "painn")
+    assert float(m.embedding.weight.grad[0].abs().max()) == 0.0
+    assert dd.CALLS.get("msde_cfconv_aggregate", 0) >= 3 * 7 - 3 and dd.CALLS.get("msde_gemm_ex", 0) > 30, dd.CALLS
+
+
+def test_painn_force_path_double_backward(dev):
+    """PaiNN under the MD17 objective (finetune_MD17.py:47-78): forces by autograd.grad(create_graph=True), then a
+    backward pass through them.  The operator set is closed under differentiation, so this runs on the same kernels;
+    checked against central finite differences of the force-matching loss w.r.t. two parameters."""
+    import moleculesde_amd.geom3d as G
+    g = load_golden("f4_painn.npz")
+    b = G.prepare_batch(batch_from(g), dev)
+    m = G.PaiNN(n_atom_basis=32, n_interactions=2, n_rbf=20, cutoff=float(g["cutoff"]), max_z=119, n_out=1, readout="mean")
+    _set_parameters_like_generator(m, 6100)
+    m.to(dev)
+    ei = torch.from_numpy(g["radius_edge_index"]).to(dev)
+    f_t = torch.randn(b.x.size(0), 3, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+
+    def loss_of():
+        pos = b.positions.clone().requires_grad_(True)
+        e = m(b.x[:, 0], pos, ei, b.batch).sum(dim=1, keepdim=True)
+        force = -torch.autograd.grad(e, pos, grad_outputs=torch.ones_like(e), create_graph=True)[0]
+        return (force - f_t).pow(2).mean()
+    loss = loss_of()
+    loss.backward()
+    for name, idx in (("interactions.0.interatomic_context_net.1.weight", (5, 7)), ("filter_net.weight", (40, 3))):
+        p = dict(m.named_parameters())[name]
+        an = float(p.grad[idx])
+        eps = 2e-3
+        def bump(v):
+            with torch.no_grad():
+                p[idx] += v
+        bump(eps)
+        lp = float(loss_of())
+        bump(-2 * eps)
+        lm = float(loss_of())
+        bump(eps)
+        fd = (lp - lm) / (2 * eps)
+        assert abs(an - fd) <= 5e-2 * max(abs(fd), abs(an)) + 1e-5, (name, an, fd)
+
+
+def test_pretrain_step_with_painn_encoder(dev):
+    """--model_3d PaiNN (pretrain_MoleculeSDE.py:212-221): the trainer builds the radius graph with the radius kernels,
+    runs contrastive + 2D->3D losses over the PaiNN latent and updates every PaiNN parameter."""
+    from moleculesde_amd import pretrain
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_batch
+    args = pretrain.readme_args(model_3d="PaiNN", emb_dim=64, SDE_coeff_generative_3Dto2D=0)
+    tr = pretrain.Trainer(args, dev)
+    assert isinstance(tr.models["model_3D"], G.PaiNN)
+    b = G.prepare_batch(make_batch(16, seed=5), dev)
+    before = {k: v.detach().clone() for k, v in tr.models["model_3D"].named_parameters()}
+    l0, parts = tr.step(b)
+    for _ in range(3):
+        l1, parts = tr.step(b)
+    assert torch.isfinite(l0) and torch.isfinite(l1)
+    assert b.radius_edge_index.size(0) == 2 and b.radius_edge_index.size(1) > 0
+    moved = [k for k, v in tr.models["model_3D"].named_parameters() if not torch.equal(v, before[k])]
+    assert len(moved) == len(before), set(before) - set(moved)
+
+
 def test_bs256_full_pretrain_losses_vs_oracle(dev):
     """BASELINE.json configs[2] per-GPU work: all three losses (contrastive + 2D->3D + 3D->2D VE) at bs 256,
     emb 300, against the oracle with replayed noise: each loss term within 1e-3 relative."""

@@ -202,6 +202,26 @@ def test_sde3d2d_02_surface_and_builder():
     assert isinstance(S.build_from_args(a), G.SDEModel3Dto2D_node_adj_dense_02)
 
 
+def test_painn_surface_and_builder():
+    """§8 f4: PaiNN has the parameter names of the fixture the reference's class produced (tests/golden/f4_painn.npz), the
+    reference's buffers, an output head like painn.py:208-216, and --model_3d PaiNN selects it."""
+    import numpy as np
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import pretrain
+    g = np.load(os.path.join(ROOT, "tests", "golden", "f4_painn.npz"))
+    m = G.PaiNN(n_atom_basis=32, n_interactions=3, n_rbf=20, cutoff=3.5, max_z=119, n_out=1, readout="mean")
+    assert [k for k, _ in m.named_parameters()] == list(g["param_names"])
+    assert {k for k, _ in m.named_buffers()} == {"cutoff_fn.cutoff", "radial_basis.widths", "radial_basis.offsets"}
+    assert float(m.embedding.weight[0].abs().max()) == 0.0                # padding_idx = 0
+    head = m.create_output_layers()
+    assert [tuple(l.weight.shape) for l in head] == [(16, 32), (1, 16)]   # build_mlp: 32 -> 16 -> 1
+    a = pretrain.readme_args(model_3d="PaiNN", emb_dim=16, SDE_coeff_generative_3Dto2D=0)
+    models = pretrain.build_models(a, torch.device("cpu"))
+    assert isinstance(models["model_3D"], G.PaiNN) and models["model_3D"].n_interactions == 3
+    with pytest.raises(RuntimeError):                                     # no CPU fallback
+        m(torch.zeros(3, dtype=torch.long), torch.zeros(3, 3), torch.zeros(2, 0, dtype=torch.long), torch.zeros(3, dtype=torch.long))
+
+
 def test_readme_args_and_flag_defaults():
     from moleculesde_amd import pretrain
     a = pretrain.readme_args()
