@@ -78,6 +78,22 @@ def _pmc_traffic(kernel, E, N, wgs=None):
         return None
 
 
+def _rocprof_avg_us(kernel, full=False):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command
+    (profiles/r02_{default,full}_bench_kernel_stats.csv): launches inside the step (beside the other stream's kernels)
+    and the roofline loop's own, together.  None when the summary does not hold the kernel."""
+    import csv
+    try:
+        path = os.path.join(ROOT, "profiles", "r02_%s_bench_kernel_stats.csv" % ("full" if full else "default"))
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if kernel in r["Name"]:
+                    return round(float(r["AverageNs"]) / 1e3, 2)
+    except Exception:
+        pass
+    return None
+
+
 def _step_widths(trainer):
     """Workgroup counts the trainer gives the two wide CFConv kernels inside the step (pretrain.Trainer.losses:
     narrowed while SchNet runs beside the GIN -> 2D->3D chain, full width with the 3D->2D head behind it)."""
@@ -147,8 +163,12 @@ def roofline_fused_bwd(trainer, batch, iters=30, wgs=None):
         ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
     flops = E * 2.0 * (2 * G * 128 + 2 * 128 * 128)
     tf = flops / (ms * 1e-3) / 1e12
+    full = trainer.args.SDE_coeff_generative_3Dto2D > 0
+    rp = _rocprof_avg_us("cfconv_fused_bwd_w_pipe_kernel", full)
     return {"kernel": "cfconv_fused_bwd_w_pipe_kernel", "bound": "mfma", "achieved": round(tf, 2),
             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
+            "rocprofv3_avg_launch_us_same_command": rp,
+            "frac_at_rocprofv3_avg": None if not rp else round(flops / (rp * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4),
             "traffic": _pmc_traffic("cfconv_fused_bwd_w_pipe_kernel", E, N, wgs), "flops_per_launch": flops,
             "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N,
             "workgroups": "full width" if wgs is None else int(wgs)}

@@ -35,11 +35,11 @@ md17)
 dptest)
   timeout 1200 python -m pytest tests/test_gpu_dp.py -q -x > $O/dptest.log 2>&1; echo "dptest rc=$?"; tail -60 $O/dptest.log;;
 bench)
-  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cat $O/bench.json
-  timeout 600 python bench.py --full --no_cpu_baseline > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"; cat $O/bench_full.json;;
+  timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-330 $O/bench.json
+  timeout 600 python bench.py --full --no_cpu_baseline > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"; cut -c1-330 $O/bench_full.json;;
 dp)
-  timeout 600 python bench.py --debug_dp_path --no_cpu_baseline > $O/bench_dp1.json 2> $O/bench_dp1.err; echo "dp rc=$?"; cat $O/bench_dp1.json; tail -3 $O/bench_dp1.err
-  timeout 600 python bench.py --debug_dp_path --full --no_cpu_baseline > $O/bench_dp1_full.json 2> $O/bench_dp1_full.err; echo "dp full rc=$?"; cat $O/bench_dp1_full.json;;
+  timeout 600 python bench.py --debug_dp_path --no_cpu_baseline > $O/bench_dp1.json 2> $O/bench_dp1.err; echo "dp rc=$?"; cut -c1-330 $O/bench_dp1.json; tail -3 $O/bench_dp1.err
+  timeout 600 python bench.py --debug_dp_path --full --no_cpu_baseline > $O/bench_dp1_full.json 2> $O/bench_dp1_full.err; echo "dp full rc=$?"; cut -c1-330 $O/bench_dp1_full.json;;
 prof)
   cd /tmp
   timeout 900 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof -o run -- python3 $R/bench.py --no_cpu_baseline > $O/prof_bench.json 2> $O/prof.log; echo "prof rc=$?"
