@@ -159,11 +159,15 @@ gemm_ex_kernel(const msde_gemm_desc d) {
   const int ntiles = nt1 + nt2;
 
   // staging registers: A tile BM x 32 = BM*8 float4 -> 2*TM per thread; B tile 64 x 32 (or 32 x 64) = 512 float4 -> 2.
-  // TWO register stages: the global loads of tile t+2 are issued while tile t is multiplied, so a load has two K
-  // tiles (~2 x 1024 MFMA cycles) to land -- one is not enough at one workgroup per CU (L2 round trip ~ 1 us under load).
+  // NS register stages: the global loads of tile t+NS are issued while tile t is multiplied, so a load has NS - 1 K
+  // tiles of MFMA time to land.  Measured with NS = 4 on the encoders' 3588-row problems: no change (3588x300x600 29.7 us
+  // either way) -- those shapes are not latency bound but QUANTISED: 3588 x 300 outputs are 1130 wave tiles of 32 x 32
+  // for 1024 SIMDs, so some SIMDs run two and the launch takes two tile times (0.55 efficiency; the library uses
+  // 16 x 16 MFMA tiles there).  NS = 2 keeps 48 fewer registers.
+  constexpr int NS = 2;
   constexpr int NA = 2 * TM, NB = 2;
-  float4 ra[2][NA], rb[2][NB];
-  int ka[2][NA], kb_[2][NB];
+  float4 ra[NS][NA], rb[NS][NB];
+  int ka[NS][NA], kb_[NS][NB];
 
   // Staging addresses.  SQ counters showed the staging path issuing ~70 VALU instructions per K tile and wave (64-bit
   // address arithmetic, segment selects, tail clamps and masks) -- 4.4 per MFMA, a quarter of the kernel's time.  So:
@@ -192,7 +196,9 @@ gemm_ex_kernel(const msde_gemm_desc d) {
     }
   }
   const bool fast_ok = VEC && d.b_kblk_log2 == 0 && (!B_KM || n0 + BN <= d.N);
-  bool fs[2] = {false, false};                              // register stage holds an interior tile (no masks)
+  bool fs[NS];                                              // register stage holds an interior tile (no masks)
+#pragma unroll
+  for (int i = 0; i < NS; ++i) fs[i] = false;
 
   auto load_tile = [&](int t, float4 (&xa)[NA], float4 (&xb)[NB], int (&ma)[NA], int (&mb)[NB], bool& fast) {
     const bool s2 = t >= nt1;
@@ -300,23 +306,26 @@ gemm_ex_kernel(const msde_gemm_desc d) {
   };
 
   if (ntiles > 0) {
-    load_tile(0, ra[0], rb[0], ka[0], kb_[0], fs[0]);
-    if (ntiles > 1) load_tile(1, ra[1], rb[1], ka[1], kb_[1], fs[1]);
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      if (i < ntiles) load_tile(i, ra[i], rb[i], ka[i], kb_[i], fs[i]);
     store_tile(0, ra[0], rb[0], ka[0], kb_[0], fs[0]);
     __syncthreads();
-    // iteration t: register stage t&1 (tile t, already in LDS) is refilled with tile t+2; tile t is multiplied; tile
-    // t+1 (register stage (t+1)&1, requested one iteration ago) moves to LDS stage (t+1)&1, last read in iteration t-1
+    // step tt (tile tt is in LDS stage tt & 1, its register stage tt % NS is free again): request tile tt + NS into that
+    // register stage, multiply tile tt, move tile tt + 1 (register stage (tt + 1) % NS, requested NS - 1 steps ago) into
+    // the other LDS stage, which was last read in step tt - 1.  One barrier per K tile.
     const bool dbg_noload = (d.flags & 256) != 0, dbg_nosync = (d.flags & 512) != 0;   // diagnostics (tools/bench_gemm_ex.py)
-    for (int t = 0; t < ntiles; t += 2) {
-      if (t + 2 < ntiles && !dbg_noload) load_tile(t + 2, ra[0], rb[0], ka[0], kb_[0], fs[0]);
-      compute_tile(0);
-      if (t + 1 < ntiles && !dbg_noload) store_tile(1, ra[1], rb[1], ka[1], kb_[1], fs[1]);
-      if (!dbg_nosync) __syncthreads();
-      if (t + 1 < ntiles) {
-        if (t + 3 < ntiles && !dbg_noload) load_tile(t + 3, ra[1], rb[1], ka[1], kb_[1], fs[1]);
-        compute_tile(1);
-        if (t + 2 < ntiles && !dbg_noload) store_tile(0, ra[0], rb[0], ka[0], kb_[0], fs[0]);
-        if (!dbg_nosync) __syncthreads();
+    for (int t = 0; t < ntiles; t += NS) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int tt = t + k;
+        if (tt < ntiles) {
+          if (tt + NS < ntiles && !dbg_noload) load_tile(tt + NS, ra[k], rb[k], ka[k], kb_[k], fs[k]);
+          compute_tile(k & 1);
+          const int kn = (k + 1) % NS;                   // compile-time after unrolling
+          if (tt + 1 < ntiles && !dbg_noload) store_tile((k + 1) & 1, ra[kn], rb[kn], ka[kn], kb_[kn], fs[kn]);
+          if (!dbg_nosync) __syncthreads();
+        }
       }
     }
   }

@@ -87,7 +87,7 @@ def readme_args(**over):
 
 USE_FUSED_CL = True
 SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
-SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "192"))   # pipelined kernel: 128..192 same step time, 256: -1 %
+SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "160"))   # step timeline (device stamps): 64: 3.30, 96-128: 3.11, 160: 3.10, 192: 3.13, 256: 3.33 ms
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
 GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
