@@ -262,6 +262,137 @@ __global__ void edge_attention_bwd_kernel(const float* __restrict__ g_out, const
   for (int c = 0; c < CH; ++c) g_q[(size_t)i * ldg + h * CH + c] = gq[c];
 }
 
+// ---- wave-per-target variants for the production shape (8 heads x 4 channels) -----------------------------------
+// The kernels above give one THREAD a (target, head) pair and walk its ~10 in-edges serially: N * H = 28.7 k threads are
+// 448 waves for 1024 SIMDs, and every edge is an index -> row -> arithmetic chain (17 us for 17.4 MB = 0.13 of HBM).
+// Here one WAVE owns a target: lane = 8 * l + h works on head h of in-edge l, l + 8, ...: the 8 head lanes of an edge
+// read one contiguous 128-byte row piece of k / v / edge features as float4, 8 edges are in flight per wave, and the
+// softmax statistics and the weighted sums are combined across the 8 edge lanes with three xor shuffles.  Same three
+// passes, same use of `alpha` as the score scratch; any in-degree.
+__device__ __forceinline__ float ea_red_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float ea_red_sum(float v) {
+  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float ea_dot4(float4 a, float4 b, float4 c) {      // a . (b + c), channel order
+  return ((a.x * (b.x + c.x) + a.y * (b.y + c.y)) + a.z * (b.z + c.z)) + a.w * (b.w + c.w);
+}
+
+__global__ void __launch_bounds__(256)
+edge_attention_fwd_wave_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                               const float* __restrict__ skip, int ld, const float* __restrict__ ee, int ld_ee,
+                               const int* __restrict__ rowptr, const int* __restrict__ src, int N, float p_drop,
+                               unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                               float* __restrict__ alpha, float* __restrict__ out) {
+  constexpr int H = 8, CH = 4, D = 32;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
+  const int lane = threadIdx.x & 63, h = lane & 7, l = lane >> 3;
+  const float4 q4 = *reinterpret_cast<const float4*>(q + (size_t)i * ld + h * CH);
+  const float scale = 0.5f;                                  // 1 / sqrt(CH)
+  const int s0 = rowptr[i], s1 = rowptr[i + 1];
+  float m = -INFINITY;
+  for (int e = s0 + l; e < s1; e += 8) {
+    const float4 k4 = *reinterpret_cast<const float4*>(k + (size_t)src[e] * ld + h * CH);
+    const float4 e4 = *reinterpret_cast<const float4*>(ee + (size_t)e * ld_ee + h * CH);
+    const float sc = ea_dot4(q4, k4, e4) * scale;
+    alpha[(size_t)e * H + h] = sc;
+    m = fmaxf(m, sc);
+  }
+  m = ea_red_max(m);
+  float sum = 0.f;
+  for (int e = s0 + l; e < s1; e += 8) {
+    const float p = expf(alpha[(size_t)e * H + h] - m);
+    alpha[(size_t)e * H + h] = p;
+    sum += p;
+  }
+  sum = ea_red_sum(sum);
+  const float inv = 1.f / (sum + 1e-16f);
+  const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = s0 + l; e < s1; e += 8) {
+    const float4 v4 = *reinterpret_cast<const float4*>(v + (size_t)src[e] * ld + h * CH);
+    const float4 e4 = *reinterpret_cast<const float4*>(ee + (size_t)e * ld_ee + h * CH);
+    float a = alpha[(size_t)e * H + h] * inv;
+    alpha[(size_t)e * H + h] = a;
+    if (p_drop > 0.f) a = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? a * keep_scale : 0.f;
+    acc.x = fmaf(a, v4.x + e4.x, acc.x); acc.y = fmaf(a, v4.y + e4.y, acc.y);
+    acc.z = fmaf(a, v4.z + e4.z, acc.z); acc.w = fmaf(a, v4.w + e4.w, acc.w);
+  }
+  acc.x = ea_red_sum(acc.x); acc.y = ea_red_sum(acc.y); acc.z = ea_red_sum(acc.z); acc.w = ea_red_sum(acc.w);
+  if (l == 0) {
+    if (skip) {
+      const float4 s4 = *reinterpret_cast<const float4*>(skip + (size_t)i * ld + h * CH);   // + lin_skip(x_i)
+      acc.x += s4.x; acc.y += s4.y; acc.z += s4.z; acc.w += s4.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)i * D + h * CH) = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+edge_attention_bwd_wave_kernel(const float* __restrict__ g_out, const float* __restrict__ q, const float* __restrict__ k,
+                               const float* __restrict__ v, int ld, float* __restrict__ g_skip, int ldg,
+                               const float* __restrict__ ee, int ld_ee, const float* __restrict__ alpha,
+                               const int* __restrict__ rowptr, const int* __restrict__ src, int N, float p_drop,
+                               unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                               float* __restrict__ g_q, float* __restrict__ g_ee, float* __restrict__ g_kpe,
+                               float* __restrict__ g_vpe, int ld_kv) {
+  constexpr int H = 8, CH = 4, D = 32;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
+  const int lane = threadIdx.x & 63, h = lane & 7, l = lane >> 3;
+  const float4 q4 = *reinterpret_cast<const float4*>(q + (size_t)i * ld + h * CH);
+  const float4 go = *reinterpret_cast<const float4*>(g_out + (size_t)i * D + h * CH);
+  if (g_skip && l == 0) *reinterpret_cast<float4*>(g_skip + (size_t)i * ldg + h * CH) = go;   // d(out)/d(skip) = 1
+  const float scale = 0.5f;
+  const float keep_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const int s0 = rowptr[i], s1 = rowptr[i + 1];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  // pass 1: g_vpe, and dsum = sum_e alpha_e * g_alpha_e
+  float dsum = 0.f;
+  for (int e = s0 + l; e < s1; e += 8) {
+    const float4 v4 = *reinterpret_cast<const float4*>(v + (size_t)src[e] * ld + h * CH);
+    const float4 e4 = *reinterpret_cast<const float4*>(ee + (size_t)e * ld_ee + h * CH);
+    const float a = alpha[(size_t)e * H + h];
+    float ms = 1.f;
+    if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
+    const float ga = ea_dot4(go, v4, e4), am = a * ms;
+    *reinterpret_cast<float4*>(g_vpe + (size_t)e * ld_kv + h * CH) = make_float4(go.x * am, go.y * am, go.z * am, go.w * am);
+    dsum = fmaf(a, ga * ms, dsum);
+  }
+  dsum = ea_red_sum(dsum);
+  // pass 2: softmax backward, g_q, g_kpe, g_ee
+  float4 gq = zero;
+  for (int e = s0 + l; e < s1; e += 8) {
+    const int j = src[e];
+    const float4 v4 = *reinterpret_cast<const float4*>(v + (size_t)j * ld + h * CH);
+    const float4 k4 = *reinterpret_cast<const float4*>(k + (size_t)j * ld + h * CH);
+    const float4 e4 = *reinterpret_cast<const float4*>(ee + (size_t)e * ld_ee + h * CH);
+    const float a = alpha[(size_t)e * H + h];
+    float ms = 1.f;
+    if (p_drop > 0.f) ms = (msde_uniform(seed, (unsigned long long)e * H + h) >= p_drop) ? keep_scale : 0.f;
+    const float ga = ea_dot4(go, v4, e4);
+    const float gs = a * (ga * ms - dsum) * scale, am = a * ms;
+    gq.x = fmaf(gs, k4.x + e4.x, gq.x); gq.y = fmaf(gs, k4.y + e4.y, gq.y);
+    gq.z = fmaf(gs, k4.z + e4.z, gq.z); gq.w = fmaf(gs, k4.w + e4.w, gq.w);
+    const float4 gk = make_float4(gs * q4.x, gs * q4.y, gs * q4.z, gs * q4.w);
+    *reinterpret_cast<float4*>(g_kpe + (size_t)e * ld_kv + h * CH) = gk;
+    *reinterpret_cast<float4*>(g_ee + (size_t)e * ld_ee + h * CH) =
+        make_float4(gk.x + go.x * am, gk.y + go.y * am, gk.z + go.z * am, gk.w + go.w * am);
+  }
+  gq.x = ea_red_sum(gq.x); gq.y = ea_red_sum(gq.y); gq.z = ea_red_sum(gq.z); gq.w = ea_red_sum(gq.w);
+  if (l == 0) *reinterpret_cast<float4*>(g_q + (size_t)i * ldg + h * CH) = gq;
+}
+
+static inline bool ea_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool ea_wave_path() {           // MSDE_EA_WAVE=0: the thread-per-(target, head) kernels (cross-check)
+  static int v = [] { const char* e = getenv("MSDE_EA_WAVE"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+
 extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                                        const float* ee, int ld_ee,
                                        const int* rowptr, const int* src, int N, int H, int Ch, float p_drop,
@@ -271,6 +402,13 @@ extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const flo
   if (ld_ee == 0) ld_ee = H * Ch;
   if (p_drop < 0.f || p_drop >= 1.f || ld < H * Ch || ld_ee < H * Ch) return MSDE_EINVAL;
   if (N == 0) return 0;
+  if (ea_wave_path() && H == 8 && Ch == 4 && ld % 4 == 0 && ld_ee % 4 == 0 && ea_al16(q) && ea_al16(k) && ea_al16(v) &&
+      ea_al16(ee) && ea_al16(out) && (!skip || ea_al16(skip))) {
+    MSDE_LAUNCH(edge_attention_fwd_wave_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), q, k, v, skip, ld, ee,
+                ld_ee, rowptr, src, N, p_drop, seed, seed_dev, alpha, out);
+    MSDE_CHECK_LAUNCH();
+    return 0;
+  }
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
     case 1: MSDE_LAUNCH(edge_attention_fwd_kernel<1>, grid, block, 0, as_stream(stream), q, k, v, skip, ld, ee, ld_ee, rowptr, src, N, H, p_drop, seed, seed_dev, alpha, out); break;
@@ -296,6 +434,14 @@ extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const
   if (ld_kv == 0) ld_kv = H * Ch;
   if (p_drop < 0.f || p_drop >= 1.f || ld_ee < H * Ch || ld_kv < H * Ch) return MSDE_EINVAL;
   if (N == 0) return 0;
+  if (ea_wave_path() && H == 8 && Ch == 4 && ld % 4 == 0 && ld_ee % 4 == 0 && ld_kv % 4 == 0 && ldg % 4 == 0 &&
+      ea_al16(g_out) && ea_al16(q) && ea_al16(k) && ea_al16(v) && ea_al16(ee) && ea_al16(g_q) && ea_al16(g_ee) &&
+      ea_al16(g_kpe) && ea_al16(g_vpe) && (!g_skip || ea_al16(g_skip))) {
+    MSDE_LAUNCH(edge_attention_bwd_wave_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), g_out, q, k, v, ld,
+                g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe, ld_kv);
+    MSDE_CHECK_LAUNCH();
+    return 0;
+  }
   dim3 grid((N * H + 255) / 256), block(256);
   switch (Ch) {
     case 1: MSDE_LAUNCH(edge_attention_bwd_kernel<1>, grid, block, 0, as_stream(stream), g_out, q, k, v, ld, g_skip, ldg, ee, ld_ee, alpha, rowptr, src, N, H, p_drop, seed, seed_dev, g_q, g_ee, g_kpe, g_vpe, ld_kv); break;
