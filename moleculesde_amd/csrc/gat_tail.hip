@@ -14,7 +14,9 @@
 #include "msde_common.h"
 
 #define GT_THREADS 256
-#define GT_LPR 4                       // lanes per row
+#ifndef GT_LPR
+#define GT_LPR 8                       // lanes per row (4: 58 workgroups at N = 3588, 232 waves for 1024 SIMDs; 8: twice that)
+#endif
 #define GT_ROWS (GT_THREADS / GT_LPR)  // rows per workgroup
 
 __device__ __forceinline__ float gt_sigmoid(float x) {
@@ -29,6 +31,8 @@ template <int C>
 __device__ __forceinline__ float gt_row_sum(float s) {
   s += __shfl_xor(s, 1);
   s += __shfl_xor(s, 2);
+  if (GT_LPR >= 8) s += __shfl_xor(s, 4);
+  if (GT_LPR >= 16) s += __shfl_xor(s, 8);
   return s;
 }
 template <int C>
