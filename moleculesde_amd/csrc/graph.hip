@@ -177,34 +177,53 @@ extern "C" int msde_radius_transpose(const int* batch, const int* mol_ptr, const
 // ------------------------------------------------------------------------------------------------
 template <int V>
 __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const int* __restrict__ rowptr,
-                                        const int* __restrict__ perm, int N, int cols, int ldi_cols, int tpr,
+                                        const int* __restrict__ perm, int N, int cols, int ldi_cols, int tpr, int epl,
                                         float mean, float* __restrict__ out, int ldo_cols) {
+  // a group of tpr * epl lanes owns one output row: tpr column lanes x epl EDGE lanes (edge lane l sums slots l,
+  // l + epl, ...; the epl partial rows meet in log2(epl) xor shuffles, a fixed order).  epl > 1 is chosen for narrow
+  // rows on few nodes, where tpr lanes per row leave most of the chip without a wave (32-float rows at N = 3588: 448
+  // waves for 1024 SIMDs, every wave a serial walk over ~10 in-edges).
   using T = typename VecT<V>::type;
-  int rpb = blockDim.x / tpr;
-  int i = blockIdx.x * rpb + threadIdx.x / tpr;
-  int lane = threadIdx.x % tpr;
-  if (i >= N) return;
-  int s0 = rowptr[i], s1 = rowptr[i + 1];
+  const int group = tpr * epl;
+  int rpb = blockDim.x / group;
+  int i = blockIdx.x * rpb + threadIdx.x / group;
+  int lane = threadIdx.x % tpr, el = (threadIdx.x % group) / tpr;
+  const bool live = i < N;
+  int s0 = 0, s1 = 0;
+  if (live) { s0 = rowptr[i]; s1 = rowptr[i + 1]; }
   float scale = 1.f;
   if (mean != 0.f) scale = 1.f / (float)max(s1 - s0, 1);
   const T* R = reinterpret_cast<const T*>(rows);
   T* O = reinterpret_cast<T*>(out);
   for (int c = lane; c < cols; c += tpr) {
     T acc = vzero<V>();
-    int s = s0;
-    for (; s + 3 < s1; s += 4) {      // four rows in flight (no index -> row chain per edge); summed in edge order
-      int e0 = perm ? perm[s] : s, e1 = perm ? perm[s + 1] : s + 1;
-      int e2 = perm ? perm[s + 2] : s + 2, e3 = perm ? perm[s + 3] : s + 3;
+    int s = s0 + el;
+    for (; s + 3 * epl < s1; s += 4 * epl) {      // four rows in flight (no index -> row chain per edge)
+      int e0 = perm ? perm[s] : s, e1 = perm ? perm[s + epl] : s + epl;
+      int e2 = perm ? perm[s + 2 * epl] : s + 2 * epl, e3 = perm ? perm[s + 3 * epl] : s + 3 * epl;
       T v0 = R[(size_t)e0 * ldi_cols + c], v1 = R[(size_t)e1 * ldi_cols + c];
       T v2 = R[(size_t)e2 * ldi_cols + c], v3 = R[(size_t)e3 * ldi_cols + c];
       acc = vadd(vadd(vadd(vadd(acc, v0), v1), v2), v3);
     }
-    for (; s < s1; ++s) {
+    for (; s < s1; s += epl) {
       int e = perm ? perm[s] : s;
       acc = vadd(acc, R[(size_t)e * ldi_cols + c]);
     }
-    O[(size_t)i * ldo_cols + c] = vscale(acc, scale);
+    for (int o = tpr; o < group; o <<= 1) {
+      float* a = reinterpret_cast<float*>(&acc);
+#pragma unroll
+      for (int k = 0; k < V; ++k) a[k] += __shfl_xor(a[k], o);
+    }
+    if (live && el == 0) O[(size_t)i * ldo_cols + c] = vscale(acc, scale);
   }
+}
+
+static inline int seg_epl(int N, int tpr) {     // edge lanes: fill the chip when N * tpr threads would not
+  static int force = [] { const char* e = getenv("MSDE_SEG_EPL"); return e ? atoi(e) : 0; }();
+  if (force) return force * tpr <= 64 ? force : 1;
+  int epl = 1;
+  while (epl < 4 && tpr * epl * 2 <= 64 && (long)N * tpr * epl < 256L * 1024) epl *= 2;
+  return epl;
 }
 
 extern "C" int msde_segment_sum_rows(const float* rows, int ldi, const int* rowptr, const int* perm, int N, int D,
@@ -217,13 +236,13 @@ extern "C" int msde_segment_sum_rows(const float* rows, int ldi, const int* rowp
   const bool vec = D % 4 == 0 && ldo % 4 == 0 && ldi % 4 == 0 &&
                    ((reinterpret_cast<uintptr_t>(rows) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   if (vec) {
-    int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
+    int cols = D / 4, tpr = pick_tpr(cols), epl = seg_epl(N, tpr), rpb = 256 / (tpr * epl);
     MSDE_LAUNCH(segment_sum_rows_kernel<4>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
-                       rowptr, perm, N, cols, ldi / 4, tpr, scale_by_inv_count, out, ldo / 4);
+                       rowptr, perm, N, cols, ldi / 4, tpr, epl, scale_by_inv_count, out, ldo / 4);
   } else {
-    int cols = D, tpr = pick_tpr(cols), rpb = 256 / tpr;
+    int cols = D, tpr = pick_tpr(cols), epl = seg_epl(N, tpr), rpb = 256 / (tpr * epl);
     MSDE_LAUNCH(segment_sum_rows_kernel<1>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
-                       rowptr, perm, N, cols, ldi, tpr, scale_by_inv_count, out, ldo);
+                       rowptr, perm, N, cols, ldi, tpr, epl, scale_by_inv_count, out, ldo);
   }
   MSDE_CHECK_LAUNCH();
   return 0;

@@ -457,31 +457,45 @@ extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const
 // ------------------------------------------------------------------------------------------------
 // frame mix + mean scatter (equivariant_scorenetwork.py:159-164)
 // ------------------------------------------------------------------------------------------------
+// 8 lanes per target node: lane l takes in-edges l, l + 8, ... (one thread per (node, component) walking its edges one
+// after the other was 44 workgroups of serial index -> row chains); partial sums meet in three xor shuffles.
+#define FM_LPN 8
 __global__ void frame_mix_mean_fwd_kernel(const float* __restrict__ coff, const float* __restrict__ basis,
                                           const int* __restrict__ rowptr, int N, float* __restrict__ out) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= N * 3) return;
-  int i = t / 3, m = t % 3;
-  int s0 = rowptr[i], s1 = rowptr[i + 1];
-  float acc = 0.f;
-  for (int e = s0; e < s1; ++e) {
-    const float* c = coff + 3 * (size_t)e;
-    const float* b = basis + 9 * (size_t)e;
-    // (c0*diff + c1*cross) + c2*vert, as written in the reference
-    acc += (c[0] * b[m] + c[1] * b[3 + m]) + c[2] * b[6 + m];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / FM_LPN, l = t % FM_LPN;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  int s0 = 0, s1 = 0;
+  if (i < N) {
+    s0 = rowptr[i]; s1 = rowptr[i + 1];
+    for (int e = s0 + l; e < s1; e += FM_LPN) {
+      const float* c = coff + 3 * (size_t)e;
+      const float* b = basis + 9 * (size_t)e;
+      const float c0 = c[0], c1 = c[1], c2 = c[2];
+      // (c0*diff + c1*cross) + c2*vert, as written in the reference
+      ax += (c0 * b[0] + c1 * b[3]) + c2 * b[6];
+      ay += (c0 * b[1] + c1 * b[4]) + c2 * b[7];
+      az += (c0 * b[2] + c1 * b[5]) + c2 * b[8];
+    }
   }
-  out[t] = acc / (float)max(s1 - s0, 1);
+#pragma unroll
+  for (int o = 1; o < FM_LPN; o <<= 1) { ax += __shfl_xor(ax, o); ay += __shfl_xor(ay, o); az += __shfl_xor(az, o); }
+  if (i < N && l == 0) {
+    const float inv = 1.f / (float)max(s1 - s0, 1);
+    out[3 * i] = ax * inv; out[3 * i + 1] = ay * inv; out[3 * i + 2] = az * inv;
+  }
 }
 
 __global__ void frame_mix_mean_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ basis,
                                           const int* __restrict__ rowptr, int N, int E_cap,
                                           float* __restrict__ g_coff) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t / FM_LPN, l = t % FM_LPN;
   if (i < N) {
     int s0 = rowptr[i], s1 = rowptr[i + 1];
     float inv = 1.f / (float)max(s1 - s0, 1);
     float gx = g_out[3 * i] * inv, gy = g_out[3 * i + 1] * inv, gz = g_out[3 * i + 2] * inv;
-    for (int e = s0; e < s1; ++e) {
+    for (int e = s0 + l; e < s1; e += FM_LPN) {
       const float* b = basis + 9 * (size_t)e;
       float* g = g_coff + 3 * (size_t)e;
       g[0] = gx * b[0] + gy * b[1] + gz * b[2];
@@ -499,7 +513,7 @@ extern "C" int msde_frame_mix_mean_fwd(const float* coff, const float* basis, co
                                        void* stream) {
   if (N < 0 || !coff || !basis || !rowptr || !out) return MSDE_EINVAL;
   if (N == 0) return 0;
-  MSDE_LAUNCH(frame_mix_mean_fwd_kernel, dim3((N * 3 + 255) / 256), dim3(256), 0, as_stream(stream), coff,
+  MSDE_LAUNCH(frame_mix_mean_fwd_kernel, dim3((N * FM_LPN + 255) / 256), dim3(256), 0, as_stream(stream), coff,
                      basis, rowptr, N, out);
   MSDE_CHECK_LAUNCH();
   return 0;
@@ -509,7 +523,7 @@ extern "C" int msde_frame_mix_mean_bwd(const float* g_out, const float* basis, c
                                        float* g_coff, void* stream) {
   if (N < 0 || !g_out || !basis || !rowptr || !g_coff) return MSDE_EINVAL;
   if (N == 0) return 0;
-  MSDE_LAUNCH(frame_mix_mean_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), g_out, basis,
+  MSDE_LAUNCH(frame_mix_mean_bwd_kernel, dim3((N * FM_LPN + 255) / 256), dim3(256), 0, as_stream(stream), g_out, basis,
                      rowptr, N, E_cap, g_coff);
   MSDE_CHECK_LAUNCH();
   return 0;
