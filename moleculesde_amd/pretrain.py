@@ -89,6 +89,7 @@ USE_FUSED_CL = True
 SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
 SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "160"))   # step timeline (device stamps): 64: 3.30, 96-128: 3.11, 160: 3.10, 192: 3.13, 256: 3.33 ms
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
+PLAN_LISTS_ON_SIDE = os.environ.get("MSDE_PLAN_LISTS_ON_SIDE", "1") != "0"   # bucket mode: embedding row lists off the main chain
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
 GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
 EARLY_GEOMETRY = os.environ.get("MSDE_EARLY_GEO", "0") != "0"   # start the 2D->3D coordinate branch before the encoders (measured: 2% slower at bs256, so off)
@@ -498,7 +499,8 @@ class Trainer:
             raise RuntimeError(f"batch does not fit the bucket: {sizes} vs {bk.caps.as_dict()}")
         for _ in range(eager_steps):
             self.step(bk.batch)
-        return self.capture(bk.batch, pre=bk.build_plan_on_device)
+        side = self._side_stream if (self.overlap_streams and PLAN_LISTS_ON_SIDE) else None
+        return self.capture(bk.batch, pre=lambda: bk.build_plan_on_device(side))
 
     def step_bucket(self, bk, blob):
         bk.load(blob)
