@@ -93,12 +93,15 @@ __global__ void gin_aggregate_bwd_x_kernel(const float* __restrict__ g, const fl
 // LDS copies of the table (for the ReLU gate x[src] + emb > 0) and of the block's partial gradient table, so
 // the read-modify-writes never race.  Four edges' row loads are in flight per thread.  The partial tables
 // (R*D floats per block) and eps partials are summed over blocks in index order by reduce_slabs.
-#define GT_EC 16
+static inline int gt_ec() {           // edges per workgroup (MSDE_GT_EC: tuning knob)
+  static int v = [] { const char* e = getenv("MSDE_GT_EC"); int x = e ? atoi(e) : 16; return x < 4 ? 4 : x; }();
+  return v;
+}
 __global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                              const float* __restrict__ tab, const int* __restrict__ codes,
                                              const int* __restrict__ src, const int* __restrict__ dst, int N, int E,
                                              const int* __restrict__ Ndev, const int* __restrict__ Edev,
-                                             int D, int R, int nodes_per_block, float* __restrict__ slabs,
+                                             int D, int R, int nodes_per_block, int GT_EC, float* __restrict__ slabs,
                                              float* __restrict__ eps_part) {
   N = msde_true_rows(N, Ndev);      // row bounds: padded edges / atoms contribute nothing
   E = msde_true_rows(E, Edev);
@@ -152,7 +155,7 @@ __global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const 
 }
 
 static inline int gt_blocks(int N, int E) {
-  int nb = (E + GT_EC - 1) / GT_EC;
+  int nb = (E + gt_ec() - 1) / gt_ec();
   return nb < 1 ? 1 : nb;
 }
 
@@ -199,7 +202,7 @@ extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const 
   float* slabs = workspace;
   float* eps_part = workspace + (size_t)nb * R * D;
   MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3(nb), dim3(threads), lds, st, g, x, tab, codes, src, dst, N, E, msde_row_bound(N),
-              msde_row_bound(E), D, R, npb,
+              msde_row_bound(E), D, R, npb, gt_ec(),
               slabs, eps_part);
   MSDE_CHECK_LAUNCH();
   if (no_reduce) return 0;

@@ -89,6 +89,7 @@ USE_FUSED_CL = True
 SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
 SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "160"))   # step timeline (device stamps): 64: 3.30, 96-128: 3.11, 160: 3.10, 192: 3.13, 256: 3.33 ms
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
+SCHNET_AFTER_GIN = os.environ.get("MSDE_SCHNET_AFTER_GIN", "0") != "0"   # experiment: start SchNet when GIN's forward is done
 PLAN_LISTS_ON_SIDE = os.environ.get("MSDE_PLAN_LISTS_ON_SIDE", "1") != "0"   # bucket mode: embedding row lists off the main chain
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
 GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
@@ -296,21 +297,24 @@ class Trainer:
         from . import hip as _hip
         stamps = _hip.STAMPS is not None
         _hip.stamp("fwd_start")
-        if self.overlap_streams:
+        def schnet_on_side():
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _hip.stamp("schnet_fwd_start")
-                _, node_3D_repr = self._encode_3d(batch)
+                _, rep = self._encode_3d(batch)
                 _hip.stamp("schnet_fwd_end")
                 if stamps:
-                    node_3D_repr.register_hook(lambda g: _hip.stamp("schnet_bwd_start"))
-                if head_on_side:
-                    l32 = head_32(node_3D_repr)
-        else:
+                    rep.register_hook(lambda g: _hip.stamp("schnet_bwd_start"))
+                return rep, (head_32(rep) if head_on_side else None)
+        if self.overlap_streams and not SCHNET_AFTER_GIN:
+            node_3D_repr, l32 = schnet_on_side()
+        elif not self.overlap_streams:
             _, node_3D_repr = self._encode_3d(batch)
         node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
         _hip.stamp("gin_fwd_end")
+        if self.overlap_streams and SCHNET_AFTER_GIN:
+            node_3D_repr, l32 = schnet_on_side()         # SchNet beside the 2D->3D model instead of beside GIN
         if stamps:
             node_2D_repr.register_hook(lambda g: _hip.stamp("gin_bwd_start"))
         if a.SDE_coeff_generative_2Dto3D > 0:
@@ -321,7 +325,7 @@ class Trainer:
             if stamps:
                 l23.register_hook(lambda g: _hip.stamp("2d3d_bwd_start"))
         if self.overlap_streams:
-            main.wait_stream(side)
+            main.wait_stream(self._side_stream)
             node_3D_repr.record_stream(main)
             if l32 is not None:
                 l32[0].record_stream(main)
