@@ -260,7 +260,7 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
 //     issue in their shadow); per-edge metadata runs two chunks ahead;
 //   * two barriers per chunk instead of four.
 // The only un-overlapped part of a chunk is recomputing pre1 (52 MFMAs) and the softplus / sigmoid that depends on it.
-template <int KK1, int DBG>
+template <int KK1, int DBG, bool W2R = false>
 __global__ void __launch_bounds__(256, 1)
 cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
                                const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ dst,
@@ -271,8 +271,10 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
   constexpr int RS = 2 * KK1 + 1;
   constexpr int RBF_SZ = CB_TE * RS + 64;      // + slack: the gW1 product reads up to column 63 of the last row
   extern __shared__ float lds[];
+  // W2R: W2 as 64 registers per lane (B operand of the W2^T product) instead of a [128][129] LDS image: the workgroup
+  // then needs 96 KB of LDS instead of 158 KB and leaves room on its CU for the other stream's LDS-using kernels
   float* W2s = lds;                            // [128][129]
-  float* rbf_t = W2s + CB_F * CB_HS;           // [2][64][RS]
+  float* rbf_t = W2R ? lds : W2s + CB_F * CB_HS;   // [2][64][RS]
   float* hid_t = rbf_t + 2 * RBF_SZ;           // [64][129] h1
   float* gp_t = hid_t + CB_TE * CB_HS;         // [64][129] g_pre2
   float* c_s = gp_t + CB_TE * CB_HS;           // [2][64]
@@ -313,11 +315,18 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
     }
   };
   fetch_meta(0);
+  float w2r[W2R ? CB_F / 2 : 1];
+  if (W2R) {
+#pragma unroll
+    for (int kk = 0; kk < (W2R ? CB_F / 2 : 1); ++kk) w2r[kk] = W2[(size_t)(2 * kk + lhalf) * CB_F + col];
+  }
   {
     const float4* W2v = reinterpret_cast<const float4*>(W2);
     float4 w[CB_F * CB_F / 4 / 256];
+    if (!W2R) {
 #pragma unroll
-    for (int i = 0; i < CB_F * CB_F / 4 / 256; ++i) w[i] = W2v[tid + 256 * i];
+      for (int i = 0; i < CB_F * CB_F / 4 / 256; ++i) w[i] = W2v[tid + 256 * i];
+    }
     float* stage = hid_t;                      // W1 [128][G] (<= 32 KB) fits in hid_t
     // fixed trip counts: every load is issued before the first store (a run-time bound serialises 26 round trips)
     float w1v[CB_F * 2 * KK1 / 256];
@@ -326,11 +335,13 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
 #pragma unroll
     for (int i = 0; i < CB_F * 2 * KK1 / 256; ++i)
       if (tid + 256 * i < CB_F * G) stage[tid + 256 * i] = w1v[i];
+    if (!W2R) {
 #pragma unroll
-    for (int i = 0; i < CB_F * CB_F / 4 / 256; ++i) {
-      const int t = (tid + 256 * i) * 4;       // row t >> 7, columns (t & 127) .. +3 (odd row stride: scalar stores)
-      float* q = &W2s[(t >> 7) * CB_HS + (t & 127)];
-      q[0] = w[i].x; q[1] = w[i].y; q[2] = w[i].z; q[3] = w[i].w;
+      for (int i = 0; i < CB_F * CB_F / 4 / 256; ++i) {
+        const int t = (tid + 256 * i) * 4;     // row t >> 7, columns (t & 127) .. +3 (odd row stride: scalar stores)
+        float* q = &W2s[(t >> 7) * CB_HS + (t & 127)];
+        q[0] = w[i].x; q[1] = w[i].y; q[2] = w[i].z; q[3] = w[i].w;
+      }
     }
   }
   store_meta(0);
@@ -516,7 +527,7 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
     auto read_g = [&](int kk, float (&q)[3]) {
       q[0] = gr[2 * kk];
       q[1] = gr[32 * CB_HS + 2 * kk];
-      q[2] = wr[2 * kk * CB_HS];
+      q[2] = W2R ? w2r[W2R ? kk : 0] : wr[2 * kk * CB_HS];
     };
     read_g(0, ga[0]);
     if (!(dbg & 16))
@@ -673,8 +684,12 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   }                                                                                                                   \
   MSDE_LAUNCH(cfconv_fused_bwd_w_kernel<KK>, dim3(nwg), dim3(256), lds_bytes(KK), st, g_agg, x1, dist, rowptr, src, dst, \
               W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace, dbg)
+  // W2 in registers (96 KB of LDS per workgroup) by default: the same speed alone (56.6 vs 57.4 us) and the step no longer
+  // loses 1.8 % when the kernel runs at full width beside the main chain (0.7 %); MSDE_CFBWD_W2REG=0: W2 in LDS (158 KB)
+  static const int w2reg = getenv("MSDE_CFBWD_W2REG") ? atoi(getenv("MSDE_CFBWD_W2REG")) : 1;
   auto ldsp_bytes = [](int KK1) {
-    return (size_t)(CB_F * CB_HS + 2 * (CB_TE * (2 * KK1 + 1) + 64) + 2 * CB_TE * CB_HS + 8 * CB_TE + 64) * sizeof(float);
+    return (size_t)((w2reg ? 0 : CB_F * CB_HS) + 2 * (CB_TE * (2 * KK1 + 1) + 64) + 2 * CB_TE * CB_HS + 8 * CB_TE + 64) *
+           sizeof(float);
   };
 #define CBP_LAUNCH(KK)                                                                                                \
   {                                                                                                                   \
@@ -683,11 +698,18 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
       hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_bwd_w_pipe_kernel<KK, 0>),         \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp_bytes(KK));           \
       if (ae != hipSuccess) return (int)ae;                                                                           \
+      ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_bwd_w_pipe_kernel<KK, 0, true>),            \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp_bytes(KK));                      \
+      if (ae != hipSuccess) return (int)ae;                                                                           \
       attr_done = true;                                                                                               \
     }                                                                                                                 \
   }                                                                                                                   \
-  MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, dist, rowptr, src, \
-              dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
+  if (w2reg)                                                                                                          \
+    MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0, true>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, dist,  \
+                rowptr, src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace);                           \
+  else                                                                                                                \
+    MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, dist, rowptr, \
+                src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
 #ifdef MSDE_CF_DIAG          // phase knock-outs of the pipelined kernel as separate instantiations (no run-time branches)
 #define CBP_DIAG(D_)                                                                                                  \
   case D_:                                                                                                            \

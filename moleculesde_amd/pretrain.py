@@ -87,7 +87,7 @@ def readme_args(**over):
 
 USE_FUSED_CL = True
 SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
-SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "192"))   # tools/ab.sh, headline ms/step: 160: 3.178, 192: 3.197, 224: 3.22, 256: 3.236 (192 keeps the kernel at 0.44 of peak)
+SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "256"))   # tools/ab.sh, headline ms/step with W2 in registers: 192: 3.201, 256: 3.22 (W2 in LDS: 160: 3.178, 192: 3.197, 256: 3.236); 256 = full width, 0.51 of peak
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
 SCHNET_AFTER_GIN = os.environ.get("MSDE_SCHNET_AFTER_GIN", "0") != "0"   # experiment: start SchNet when GIN's forward is done
 PLAN_LISTS_ON_SIDE = os.environ.get("MSDE_PLAN_LISTS_ON_SIDE", "1") != "0"   # bucket mode: embedding row lists off the main chain
