@@ -486,9 +486,21 @@ def main():
             # PCIe-inclusive variant: the same blobs from pinned host memory
             pinned = [BK.pack_raw(b, caps, pin=True) for b in stream_cpu[:16]]
             dt_h2d = timed(lambda blob: trainer.step_bucket(bk, blob), pinned, a.steps)
+            # ... and prefetched one step ahead (bucket.BlobFeeder: the blob of step t+1 crosses PCIe while step t runs)
+            feeder = BK.BlobFeeder(bk)
+            feeder.submit(pinned[0])
+            state = {"i": 0}
+
+            def fed_step(_):
+                state["i"] += 1
+                feeder.submit(pinned[state["i"] % len(pinned)])
+                feeder.load_next()
+                return trainer.step_graph(bk.batch)
+            dt_fed = timed(fed_step, pinned, a.steps)
             stream_info = {"distinct_batches": len(blobs), "capacities": caps.as_dict(), "capacity_over_mean_size": pad,
                            "raw_blob_bytes": int(blobs[0].numel() * 4),
                            "ms_per_step_blobs_from_pinned_host": round(dt_h2d / a.steps * 1e3, 3),
+                           "ms_per_step_blobs_from_pinned_host_prefetched": round(dt_fed / a.steps * 1e3, 3),
                            "ms_per_step_4_resident_batches_own_graphs": round(dt_pool / a.steps * 1e3, 3),
                            "host_prep_s_synthetic_generation_and_packing": round(host_prep_s, 2)}
         except Exception as exc:

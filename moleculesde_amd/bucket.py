@@ -203,3 +203,42 @@ class Bucket:
         ok = (int(self.err.cpu()) == 0 and s[0] <= c.N and s[1] <= c.E_b and s[2] <= c.E_e and s[3] <= c.P and
               s[4] <= c.n_max and s[5] <= c.E_r)
         return ok, dict(N=s[0], E_b=s[1], E_e=s[2], P=s[3], n_max=s[4], E_r_bound=s[5])
+
+
+class BlobFeeder:
+    """Pinned-host raw blobs -> the bucket, ONE STEP AHEAD: blob t+1 crosses PCIe on a copy stream into a staging buffer
+    while step t runs; `load_next()` then needs only a device-to-device copy of the staged blob on the compute stream.
+        feeder.submit(blob_0)
+        for t in ...: feeder.submit(blob_{t+1}); feeder.load_next(); trainer.step_graph(bucket.batch)
+    Slots are recycled only after the compute stream has copied out of them (events both ways, no host sync)."""
+
+    def __init__(self, bucket, depth=2):
+        self.bk = bucket
+        self.copy_stream = torch.cuda.Stream(device=bucket.device)
+        self.staging = [torch.empty_like(bucket.raw) for _ in range(depth)]
+        self.ready = [None] * depth           # recorded on the copy stream when slot i holds a blob
+        self.drained = [None] * depth         # recorded on the compute stream when slot i has been copied out
+        self.head = self.tail = 0             # next slot to fill / to consume
+
+    def submit(self, blob):
+        i = self.head % len(self.staging)
+        assert self.head - self.tail < len(self.staging), "BlobFeeder: more submits than slots"
+        with torch.cuda.stream(self.copy_stream):
+            if self.drained[i] is not None:
+                self.copy_stream.wait_event(self.drained[i])
+            self.staging[i].copy_(blob, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            self.ready[i] = ev
+        self.head += 1
+
+    def load_next(self):
+        assert self.tail < self.head, "BlobFeeder: nothing submitted"
+        i = self.tail % len(self.staging)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ready[i])
+        self.bk.raw.copy_(self.staging[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.drained[i] = ev
+        self.tail += 1

@@ -267,3 +267,24 @@ def test_one_graph_serves_different_batches(dev):
         cos = float((ua * ub).sum() / (ua.norm() * ub.norm()))
         assert cos > 0.995, (i, cos)
         hip.clear_row_bounds()
+
+
+def test_blob_feeder_prefetch(dev):
+    """bucket.BlobFeeder: pinned blobs staged one step ahead on a copy stream arrive in the bucket intact and in order."""
+    from moleculesde_amd import bucket as BK
+    from moleculesde_amd.synthetic import make_batch
+    cpu = [make_batch(8, seed=60 + s) for s in range(5)]
+    caps = BK.Caps.covering([BK.raw_sizes(b) for b in cpu])
+    bk = BK.Bucket(caps, dev)
+    pinned = [BK.pack_raw(b, caps, pin=True) for b in cpu]
+    f = BK.BlobFeeder(bk)
+    f.submit(pinned[0])
+    for t in range(5):
+        if t + 1 < 5:
+            f.submit(pinned[t + 1])
+        f.load_next()
+        bk.build_plan_on_device()
+        torch.cuda.synchronize()
+        assert torch.equal(bk.raw.cpu(), pinned[t]), t
+        ok, sizes = bk.check()
+        assert ok and sizes["N"] == cpu[t].x.size(0)
