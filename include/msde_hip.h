@@ -131,6 +131,11 @@ int msde_segment_sum_rows(const float* rows, int ldi /* row stride of rows (0 = 
                           const int* rowptr, const int* perm, int N, int D,
                           float scale_by_inv_count, float* out, int ldo /* row stride of out (0 = D) */,
                           void* stream);
+/* the same with a SECOND CSR view (rowptr2, perm2; NULL = none) of the same rows summed into the same output row: the
+ * gradient of out[e] = x[src_e] + x[dst_e] (by-source plus by-target segments) in one pass. */
+int msde_segment_sum_rows2(const float* rows, int ldi, const int* rowptr, const int* perm, const int* rowptr2,
+                           const int* perm2, int N, int D, float scale_by_inv_count, float* out, int ldo,
+                           void* stream);
 /* out[e] = A[src[e]] + B[dst[e]] for e < E; rows with src<0 are zero-filled.  A and B have row stride ld
  * floats (0 = D): they may be column blocks of one [N, 2D] GEMM result.
  * SDE_model_2D_to_3D.py:346-347 (factored cat+Linear), equivariant_scorenetwork.py:154-155 */

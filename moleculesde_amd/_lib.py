@@ -21,6 +21,7 @@ SIGNATURES = {
     "msde_exclusive_scan_i32": [P, P, I, P],
     "msde_radius_fill": [P, P, P, I, F, I, P, P, P, P, I, P],
     "msde_segment_sum_rows": [P, I, P, P, I, I, F, P, I, P],
+    "msde_segment_sum_rows2": [P, I, P, P, P, P, I, I, F, P, I, P],
     "msde_pair_gather_add": [P, P, I, P, P, I, I, P, P],
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],

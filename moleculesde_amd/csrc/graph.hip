@@ -177,7 +177,8 @@ extern "C" int msde_radius_transpose(const int* batch, const int* mol_ptr, const
 // ------------------------------------------------------------------------------------------------
 template <int V>
 __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const int* __restrict__ rowptr,
-                                        const int* __restrict__ perm, int N, int cols, int ldi_cols, int tpr, int epl,
+                                        const int* __restrict__ perm, const int* __restrict__ rowptr2,
+                                        const int* __restrict__ perm2, int N, int cols, int ldi_cols, int tpr, int epl,
                                         float mean, float* __restrict__ out, int ldo_cols) {
   // a group of tpr * epl lanes owns one output row: tpr column lanes x epl EDGE lanes (edge lane l sums slots l,
   // l + epl, ...; the epl partial rows meet in log2(epl) xor shuffles, a fixed order).  epl > 1 is chosen for narrow
@@ -209,6 +210,13 @@ __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const in
       int e = perm ? perm[s] : s;
       acc = vadd(acc, R[(size_t)e * ldi_cols + c]);
     }
+    if (rowptr2 != nullptr && live) {            // a second CSR view of the same rows summed into the same output row
+      const int q1 = rowptr2[i + 1];             // (gradient of x[src] + x[dst]: by-source and by-target segments)
+      for (int q = rowptr2[i] + el; q < q1; q += epl) {
+        int e = perm2 ? perm2[q] : q;
+        acc = vadd(acc, R[(size_t)e * ldi_cols + c]);
+      }
+    }
     for (int o = tpr; o < group; o <<= 1) {
       float* a = reinterpret_cast<float*>(&acc);
 #pragma unroll
@@ -226,8 +234,9 @@ static inline int seg_epl(int N, int tpr) {     // edge lanes: fill the chip whe
   return epl;
 }
 
-extern "C" int msde_segment_sum_rows(const float* rows, int ldi, const int* rowptr, const int* perm, int N, int D,
-                                     float scale_by_inv_count, float* out, int ldo, void* stream) {
+extern "C" int msde_segment_sum_rows2(const float* rows, int ldi, const int* rowptr, const int* perm, const int* rowptr2,
+                                      const int* perm2, int N, int D, float scale_by_inv_count, float* out, int ldo,
+                                      void* stream) {
   if (N < 0 || D <= 0 || !rowptr || !out) return MSDE_EINVAL;
   if (ldo <= 0) ldo = D;
   if (ldi <= 0) ldi = D;
@@ -238,14 +247,19 @@ extern "C" int msde_segment_sum_rows(const float* rows, int ldi, const int* rowp
   if (vec) {
     int cols = D / 4, tpr = pick_tpr(cols), epl = seg_epl(N, tpr), rpb = 256 / (tpr * epl);
     MSDE_LAUNCH(segment_sum_rows_kernel<4>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
-                       rowptr, perm, N, cols, ldi / 4, tpr, epl, scale_by_inv_count, out, ldo / 4);
+                       rowptr, perm, rowptr2, perm2, N, cols, ldi / 4, tpr, epl, scale_by_inv_count, out, ldo / 4);
   } else {
     int cols = D, tpr = pick_tpr(cols), epl = seg_epl(N, tpr), rpb = 256 / (tpr * epl);
     MSDE_LAUNCH(segment_sum_rows_kernel<1>, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream), rows,
-                       rowptr, perm, N, cols, ldi, tpr, epl, scale_by_inv_count, out, ldo);
+                       rowptr, perm, rowptr2, perm2, N, cols, ldi, tpr, epl, scale_by_inv_count, out, ldo);
   }
   MSDE_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int msde_segment_sum_rows(const float* rows, int ldi, const int* rowptr, const int* perm, int N, int D,
+                                     float scale_by_inv_count, float* out, int ldo, void* stream) {
+  return msde_segment_sum_rows2(rows, ldi, rowptr, perm, nullptr, nullptr, N, D, scale_by_inv_count, out, ldo, stream);
 }
 
 template <int V>

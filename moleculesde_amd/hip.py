@@ -489,8 +489,34 @@ class _PairGatherAdd(torch.autograd.Function):
         return g_A, g_B, None
 
 
+class _PairGatherAddSame(torch.autograd.Function):
+    """out[e] = x[src_e] + x[dst_e]: ONE gradient kernel walks the by-source and the by-target segments of a node
+    (two segment sums and autograd's add of the two gradients otherwise)."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        x = _f32(x)
+        E, D = plan.E, x.size(1)
+        out = torch.empty(E, D, dtype=torch.float32, device=x.device)
+        _lib.call("msde_pair_gather_add", _p(x), _p(x), 0, _p(plan.src), _p(plan.dst), E, D, _p(out), _stream())
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        g = g if (g.is_cuda and g.dtype == torch.float32 and g.stride(-1) == 1) else _f32(g)
+        D = g.size(1)
+        out = torch.empty(plan.N, D, dtype=torch.float32, device=g.device)
+        _lib.call("msde_segment_sum_rows2", _p(g), _row_stride(g, D), _p(plan.rowptr_s), _p(plan.perm_s), _p(plan.rowptr),
+                  _p(None), plan.N, D, 0.0, _p(out), D, _stream())
+        return out, None
+
+
 def pair_gather_add(A, B, plan):
     """out[e] = A[row_e] + B[col_e]  (row = source, col = target)."""
+    if A is B:
+        return _PairGatherAddSame.apply(A, plan)
     return _PairGatherAdd.apply(A, B, plan)
 
 
