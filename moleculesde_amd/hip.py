@@ -350,8 +350,17 @@ class _GinAggregate(torch.autograd.Function):
         if _SLABS.active:            # partial tables into the arena, summed by the batched reduction
             nslab = int(_lib.load().msde_gin_aggregate_bwd_tab_slabs(N, plan.E))
             ws = _SLABS.alloc(nfl, x.device)
-            _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N,
-                      plan.E, D, R, _p(None), _p(None), _p(ws), st)
+            E_ = plan.E
+
+            def launch(st_=None, g=g, x=x, tab=tab, codes=codes, plan=plan, ws=ws):
+                _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N,
+                          E_, D, R, _p(None), _p(None), _p(ws), st_ if st_ is not None else _stream())
+            if DEFER_LEAF_KERNELS:
+                # a parameter gradient nothing in the backward chain reads: queued (operands kept alive) and launched by
+                # run_deferred_leaf_kernels() -- the trainer runs them beside the grouped weight-gradient launch
+                _SLABS.deferred.append(launch)
+            else:
+                launch(st)
             _SLABS.add(ws.data_ptr(), nslab, R * D, g_tab)
             _SLABS.add(ws.data_ptr() + 4 * nslab * R * D, nslab, 1, g_eps)
         else:
@@ -891,6 +900,7 @@ class _SlabBatch:
         self.gemms = []          # queued weight-gradient GEMMs: (gY, X, M, N, K, has_bias, slab) -- inputs kept alive
         self.retired = []        # outgrown arenas still referenced by queued rows
         self.launched = []       # operands of GEMMs already launched in this backward pass (kept alive until finish)
+        self.deferred = []       # leaf-only kernels queued by backward functions (run_deferred_leaf_kernels)
         self.slot = None
         self.slots = []          # slots 0..EAGER_SLOTS-1: the eager ring; one more per captured hipGraph
         self.events = []         # per slot: event recorded behind the last upload of its pinned host images
@@ -998,6 +1008,11 @@ class _SlabBatch:
         self.launched.extend(self.gemms)
         self.gemms = []
 
+    def run_deferred(self):
+        d, self.deferred = self.deferred, []
+        for fn in d:
+            fn(None)
+
     def park(self):
         """Set the GEMMs queued so far aside (returned as an opaque group) instead of launching them: the caller launches
         the group later with launch_group(), e.g. on another stream once that stream is free."""
@@ -1013,6 +1028,7 @@ class _SlabBatch:
 
     def finish(self):
         self.active = False
+        self.run_deferred()          # nobody ran them on another stream: here, before their slabs are summed
         rows = self.rows
         if not rows:
             return
@@ -1049,6 +1065,7 @@ class _SlabBatch:
             self.new_slot(dev)
 
 
+DEFER_LEAF_KERNELS = _os.environ.get("MSDE_DEFER_LEAF", "1") != "0"   # GIN bond-table gradients off the backward chain
 GROUPED_WGRAD = _os.environ.get("MSDE_GROUPED_WGRAD", "1") != "0"   # queued GEMMs -> one grouped launch at finish()
 _SLABS = _SlabBatch()
 _SPLITS = {}
@@ -1064,6 +1081,15 @@ def flush_wgrad_gemms(max_wgs=0):
     still summed by finish_param_grad_batch, whose stream must by then be ordered after this one)."""
     if _SLABS.active:
         _SLABS.launch_gemms(max_wgs)
+
+
+def run_deferred_leaf_kernels():
+    """Launch, on the current stream, the leaf-only kernels the backward functions queued (see DEFER_LEAF_KERNELS)."""
+    _SLABS.run_deferred()
+
+
+def have_deferred_leaf_kernels():
+    return bool(_SLABS.deferred)
 
 
 def park_wgrad_gemms():

@@ -367,6 +367,16 @@ class Trainer:
                 hip.stamp("bwd_start")
                 loss.backward(one)
                 hip.stamp("bwd_main_end")
+                if self.overlap_streams and hip.have_deferred_leaf_kernels():
+                    # leaf-only kernels of the backward pass (GIN bond-table gradients: 5 x 17 us that nothing downstream
+                    # reads) run on the second stream BESIDE the grouped weight-gradient launch instead of inside the
+                    # backward chain.  Host order: everything of SchNet's backward is already queued on that stream.
+                    main_, side_ = torch.cuda.current_stream(), self._side_stream
+                    side_.wait_stream(main_)
+                    with torch.cuda.stream(side_):
+                        hip.run_deferred_leaf_kernels()
+                    hip.flush_wgrad_gemms()
+                    main_.wait_stream(side_)
                 if hip.STAMPS is not None and self.overlap_streams:
                     with torch.cuda.stream(self._side_stream):
                         hip.stamp("bwd_side_end")
