@@ -310,9 +310,22 @@ class _EmbeddingSum(torch.autograd.Function):
         list_ptr, list_nodes = ctx.saved_tensors
         g = _f32(g)
         g_tab = torch.empty(ctx.R, ctx.D, dtype=torch.float32, device=g.device)
-        ws = _scratch(int(_lib.load().msde_embedding_sum_bwd_workspace_floats(ctx.R, ctx.D, EMB_BWD_SPLIT)), g.device)
-        _lib.call("msde_embedding_sum_bwd", _p(g), _p(list_ptr), _p(list_nodes), ctx.R, ctx.D, EMB_BWD_SPLIT, _p(g_tab),
-                  _p(ws), _stream())
+        nfl = int(_lib.load().msde_embedding_sum_bwd_workspace_floats(ctx.R, ctx.D, EMB_BWD_SPLIT))
+        R, D = ctx.R, ctx.D
+        if _SLABS.active and DEFER_LEAF_KERNELS:
+            # the table gradient is a leaf gradient: queued like the GIN bond-table gradients (own workspace in the arena;
+            # only the ADDRESS of g_tab is kept, see _SlabBatch.add)
+            ws = _SLABS.alloc(nfl, g.device)
+            out_ptr = g_tab.data_ptr()
+
+            def launch(st_=None, g=g, list_ptr=list_ptr, list_nodes=list_nodes, ws=ws):
+                _lib.call("msde_embedding_sum_bwd", _p(g), _p(list_ptr), _p(list_nodes), R, D, EMB_BWD_SPLIT,
+                          ctypes.c_void_p(out_ptr), _p(ws), st_ if st_ is not None else _stream())
+            _SLABS.deferred.append(launch)
+        else:
+            ws = _scratch(nfl, g.device)
+            _lib.call("msde_embedding_sum_bwd", _p(g), _p(list_ptr), _p(list_nodes), R, D, EMB_BWD_SPLIT, _p(g_tab),
+                      _p(ws), _stream())
         return g_tab, None, None, None
 
 
