@@ -288,7 +288,11 @@ class Trainer:
         # both happen before any encoder runs so that the coordinate-only branch of the 2D->3D model can start
         # right away on its own stream (neither encoder draws random numbers on this path)
         negs = (None, None)
-        if self.coeff_cl > 0:
+        # device noise: the permutation kernel (20 us, read 1.2 ms later by the contrastive loss) runs at the head of the
+        # SECOND stream instead of at the head of the main chain; host call order (= the reference's draw order) unchanged
+        negs_on_side = (self.coeff_cl > 0 and self.overlap_streams and not SCHNET_AFTER_GIN
+                        and not getattr(self.noise, "replay", False))
+        if self.coeff_cl > 0 and not negs_on_side:
             n = batch.x.size(0)
             negs = self.noise.randperm_pair(n, batch.x.device)
         if a.SDE_coeff_generative_2Dto3D > 0 and EARLY_GEOMETRY:
@@ -301,20 +305,26 @@ class Trainer:
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                ng = self.noise.randperm_pair(batch.x.size(0), batch.x.device) if negs_on_side else None
                 _hip.stamp("schnet_fwd_start")
                 _, rep = self._encode_3d(batch)
                 _hip.stamp("schnet_fwd_end")
                 if stamps:
                     rep.register_hook(lambda g: _hip.stamp("schnet_bwd_start"))
-                return rep, (head_32(rep) if head_on_side else None)
+                return rep, (head_32(rep) if head_on_side else None), ng
         if self.overlap_streams and not SCHNET_AFTER_GIN:
-            node_3D_repr, l32 = schnet_on_side()
+            node_3D_repr, l32, ng = schnet_on_side()
+            if ng is not None:
+                negs = ng
+                for t in negs:
+                    if t is not None:
+                        t.record_stream(main)
         elif not self.overlap_streams:
             _, node_3D_repr = self._encode_3d(batch)
         node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
         _hip.stamp("gin_fwd_end")
         if self.overlap_streams and SCHNET_AFTER_GIN:
-            node_3D_repr, l32 = schnet_on_side()         # SchNet beside the 2D->3D model instead of beside GIN
+            node_3D_repr, l32, _ = schnet_on_side()      # SchNet beside the 2D->3D model instead of beside GIN
         if stamps:
             node_2D_repr.register_hook(lambda g: _hip.stamp("gin_bwd_start"))
         if a.SDE_coeff_generative_2Dto3D > 0:
