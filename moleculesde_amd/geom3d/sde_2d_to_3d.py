@@ -182,6 +182,7 @@ class SDEModel2Dto3D_02(nn.Module):
         self.register_buffer("_zero_bias", torch.zeros(emb_dim), persistent=False)
         self.side_stream = None            # optional second HIP stream for the coordinate-only branch
         self._pending = None               # results of begin() waiting for forward()
+        self._pending_event = None         # recorded by a caller that ran begin() on ANOTHER stream (see forward)
 
     def _plan(self, data):
         pl = _plan.get_plan(data)
@@ -266,6 +267,16 @@ class SDEModel2Dto3D_02(nn.Module):
             self.begin(data)
         _, pos_noise, std_pos, pos_perturbed, geo, side = self._pending
         self._pending = None
+        if self._pending_event is not None:
+            # begin() ran on another stream (the trainer puts the whole coordinate-only branch -- noise, perturbation,
+            # frame / Fourier features and their MLPs -- at the head of its second stream): join by EVENT, so that the
+            # work queued on that stream afterwards (SchNet) is not waited for
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._pending_event)
+            self._pending_event = None
+            for t in (pos_noise, std_pos, pos_perturbed) + tuple(geo):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)
 
         node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep, (geo, side))
         scores = self.score_network(ep, node_attr, edge_attr, basis)["gradient"]

@@ -89,6 +89,7 @@ USE_FUSED_CL = True
 SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
 SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "256"))   # tools/ab.sh, headline ms/step with W2 in registers: 192: 3.201, 256: 3.22 (W2 in LDS: 160: 3.178, 192: 3.197, 256: 3.236); 256 = full width, 0.51 of peak
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
+GEOMETRY_ON_SIDE = os.environ.get("MSDE_GEOMETRY_ON_SIDE", "0") != "0"   # coordinate-only branch of the 2D->3D model at the head of the second stream: measured 3.187 vs 3.151 ms (tools/ab.sh), off
 SCHNET_AFTER_GIN = os.environ.get("MSDE_SCHNET_AFTER_GIN", "0") != "0"   # experiment: start SchNet when GIN's forward is done
 PLAN_LISTS_ON_SIDE = os.environ.get("MSDE_PLAN_LISTS_ON_SIDE", "1") != "0"   # bucket mode: embedding row lists off the main chain
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
@@ -297,6 +298,18 @@ class Trainer:
             negs = self.noise.randperm_pair(n, batch.x.device)
         if a.SDE_coeff_generative_2Dto3D > 0 and EARLY_GEOMETRY:
             m["SDE_2Dto3D_model"].begin(batch)
+        elif (a.SDE_coeff_generative_2Dto3D > 0 and GEOMETRY_ON_SIDE and self.overlap_streams and not SCHNET_AFTER_GIN
+              and not getattr(self.noise, "replay", False)):
+            # the coordinate-only branch of the 2D->3D model (noise, perturbation, frame / Fourier features, their MLPs:
+            # ~10 launches forward, as many backward) depends on nothing the main chain computes: it runs at the head
+            # of the second stream, in the slack SchNet leaves there; the model joins it by event
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                m["SDE_2Dto3D_model"].begin(batch)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            m["SDE_2Dto3D_model"]._pending_event = ev
         l32 = None
         from . import hip as _hip
         stamps = _hip.STAMPS is not None
