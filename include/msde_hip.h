@@ -141,6 +141,11 @@ int msde_segment_sum_rows2(const float* rows, int ldi, const int* rowptr, const 
  * SDE_model_2D_to_3D.py:346-347 (factored cat+Linear), equivariant_scorenetwork.py:154-155 */
 int msde_pair_gather_add(const float* A, const float* B, int ld, const int* src, const int* dst, int E,
                          int D, float* out, void* stream);
+/* out[e] = [X[src[e]] + X[dst[e]] | C[e]] ([E, D + D2], rows with src<0 zero): the gather writes the concatenation
+ * cat([h_row + h_col, edge_attr]) that the basis MLP reads (equivariant_scorenetwork.py:154-157).  Row strides ldx,
+ * ldc in floats; D, D2, ldx, ldc multiples of 4 and 16-byte aligned bases (else MSDE_EUNSUP). */
+int msde_pair_gather_cat(const float* X, int ldx, const float* C, int ldc, const int* src, const int* dst, int E,
+                         int D, int D2, float* out, void* stream);
 /* out[e] = X[idx[e]] (row gather), idx<0 -> zeros */
 int msde_gather_rows(const float* X, const int* idx, int E, int D, float* out, void* stream);
 
@@ -336,6 +341,18 @@ typedef struct msde_gemm_desc {
 } msde_gemm_desc;
 int msde_gemm_ex(const msde_gemm_desc* desc, void* stream);
 
+/* Narrow output layer of an MLP over rows (basis_mlp, equivariant_scorenetwork.py:142-146: Linear -> SiLU -> Linear(H, 3)):
+ * out[e][j] = b[j] + sum_c silu(Z[e][c]) W[j][c] on the PRE-activation Z [E, H] (row stride ldz), J <= 4, H % 4 == 0,
+ * H <= 256, 16-byte aligned Z / W / gZ (else MSDE_EUNSUP).  Backward: gZ [E, H] = d/dZ (SiLU' included; rows past the
+ * row bound of E are zero) and the layer's own gradient [gW (J x H) | gb (J)] = gWb, summed in fixed order from
+ * msde_mlp_head_bwd_slabs(E, H) workgroup slabs in `workspace` (gWb == NULL: the slabs stay there for
+ * msde_reduce_slabs_multi).  Slabs and gWb hold J*H + J floats rounded up to a multiple of 4 (zero padding). */
+int msde_mlp_head_fwd(const float* Z, int ldz, const float* W, const float* b, int E, int H, int J, float* out,
+                      void* stream);
+int msde_mlp_head_bwd_slabs(int E, int H);
+int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const float* g, int E, int H, int J, float* gZ, float* gWb,
+                      float* workspace, void* stream);
+
 /* ------------------------------------------------------------------ 3D->2D dense score head -- */
 /* SDEModel3Dto2D_node_adj_dense.forward (SDE_model_3D_to_2D_node_adj_dense.py:101-179) with its
  * EdgeScoreNetwork_dense / NodeScoreNetwork_dense (invariant_scorenetwork_dense.py:74-93,118-131) on RAGGED data
@@ -474,6 +491,10 @@ int msde_linear_bwd_w_partial(const float* gY, const float* X, int M, int N, int
                               float* slabs, void* stream);
 int msde_reduce_slabs_multi(const long long* rows, const int* prefix, int count, int total_chunks,
                             void* stream);
+/* chunks (= workgroups) a row of n entries x `splits` slabs takes in msde_reduce_slabs_multi's prefix table: 256
+ * entries per chunk, 64 for rows of >= MSDE_REDUCE_LONG splits (16 split lanes instead of 4) */
+#define MSDE_REDUCE_LONG 64
+long long msde_reduce_slabs_chunks(long long n, int splits);
 
 /* ------------------------------------------------------------------ pointwise stages ------- */
 /* ShiftedSoftplus (schnet.py:199-206): y = softplus(x) - log 2 (threshold 20); g_x = g * sigmoid(x).

@@ -23,6 +23,10 @@ SIGNATURES = {
     "msde_segment_sum_rows": [P, I, P, P, I, I, F, P, I, P],
     "msde_segment_sum_rows2": [P, I, P, P, P, P, I, I, F, P, I, P],
     "msde_pair_gather_add": [P, P, I, P, P, I, I, P, P],
+    "msde_pair_gather_cat": [P, I, P, I, P, P, I, I, I, P, P],
+    "msde_mlp_head_fwd": [P, I, P, P, I, I, I, P, P],
+    "msde_mlp_head_bwd_slabs": [I, I],
+    "msde_mlp_head_bwd": [P, I, P, P, I, I, I, P, P, P, P],
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
     "msde_radius_transpose": [P, P, P, P, I, I, P, P, P, P],
@@ -56,6 +60,7 @@ SIGNATURES = {
     "msde_linear_bwd_w_grouped_ex": [P, P, I, I, I, P],
     "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
+    "msde_reduce_slabs_chunks": [LL, I],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
     "msde_gemm_ex": [P, P],
     "msde_dense_prepare": [P, P, P, P, P, P, P, P, I, I, F, I, F, F, P, P, I, ULL, P, I, I, P, P, P, P, P, P, P],
@@ -132,11 +137,13 @@ class EdgeLayerParams(ctypes.Structure):
 ACT = {None: 0, "none": 0, "tanh": 1, "silu": 2, "elu": 3, "ssp": 4, "relu": 5}
 EPI_ACT, EPI_DACT = 0, 1
 GEMM_B_KMAJOR, GEMM_ACCUMULATE = 1, 2
+REDUCE_LONG = 64          # MSDE_REDUCE_LONG of include/msde_hip.h
 
 _RESTYPE = {"msde_target_arch": ctypes.c_char_p, "msde_linear_bwd_w_workspace_bytes": ctypes.c_longlong,
             "msde_cfconv_fused_bwd_w_workspace_floats": ctypes.c_longlong,
             "msde_embedding_sum_bwd_workspace_floats": ctypes.c_longlong,
-            "msde_gin_aggregate_bwd_tab_workspace_floats": ctypes.c_longlong}
+            "msde_gin_aggregate_bwd_tab_workspace_floats": ctypes.c_longlong,
+            "msde_reduce_slabs_chunks": ctypes.c_longlong}
 
 _lib = None
 

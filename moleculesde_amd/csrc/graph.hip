@@ -307,6 +307,50 @@ extern "C" int msde_pair_gather_add(const float* A, const float* B, int ld, cons
   return 0;
 }
 
+// out[e] = [X[src_e] + X[dst_e] | C[e]]: the concatenation the basis MLP of the 2D->3D score network reads
+// (equivariant_scorenetwork.py: cat([h_row + h_col, edge_attr])) written by the gather itself.  D, D2 in float4 units.
+__global__ void pair_gather_cat_kernel(const float4* __restrict__ X, int ldx, const float4* __restrict__ C, int ldc,
+                                       const int* __restrict__ src, const int* __restrict__ dst, int E, int D, int D2,
+                                       int tpr, float4* __restrict__ out) {
+  const int rpb = blockDim.x / tpr;
+  const int e = blockIdx.x * rpb + threadIdx.x / tpr;
+  const int lane = threadIdx.x % tpr;
+  if (e >= E) return;
+  const int j = src[e], i = dst[e];
+  float4* O = out + (size_t)e * (D + D2);
+  if (j < 0) {
+    for (int c = lane; c < D + D2; c += tpr) O[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float4* a = X + (size_t)j * ldx;
+  const float4* b = X + (size_t)i * ldx;
+  const float4* cc = C + (size_t)e * ldc;
+  for (int c = lane; c < D + D2; c += tpr) {
+    float4 v;
+    if (c < D) {
+      const float4 p = a[c], q = b[c];
+      v = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+    } else {
+      v = cc[c - D];
+    }
+    O[c] = v;
+  }
+}
+
+extern "C" int msde_pair_gather_cat(const float* X, int ldx, const float* C, int ldc, const int* src, const int* dst,
+                                    int E, int D, int D2, float* out, void* stream) {
+  if (E < 0 || D <= 0 || D2 <= 0 || !X || !C || !src || !dst || !out || ldx < D || ldc < D2) return MSDE_EINVAL;
+  if ((D | D2 | ldx | ldc) & 3) return MSDE_EUNSUP;
+  if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(out)) & 15) return MSDE_EUNSUP;
+  if (E == 0) return 0;
+  const int cols = (D + D2) / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
+  MSDE_LAUNCH(pair_gather_cat_kernel, dim3((E + rpb - 1) / rpb), dim3(256), 0, as_stream(stream),
+              reinterpret_cast<const float4*>(X), ldx / 4, reinterpret_cast<const float4*>(C), ldc / 4, src, dst, E, D / 4,
+              D2 / 4, tpr, reinterpret_cast<float4*>(out));
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int msde_gather_rows(const float* X, const int* idx, int E, int D, float* out, void* stream) {
   if (E < 0 || D <= 0 || !X || !idx || !out) return MSDE_EINVAL;
   if (E == 0) return 0;

@@ -93,6 +93,39 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
     }
   };
 
+  // Interior tiles of the k-major x k-major product (the weight-gradient shape: both operands are row blocks of
+  // activations): no row / column clamps, no zeroing selects, and every thread's address is a CONSTANT 32-bit byte
+  // offset from a wave-uniform tile base (scalar arithmetic, `saddr + voffset` loads).  The general path costs ~12
+  // vector instructions per float4, and on this chip vector instructions take issue slots from the fp32 MFMAs
+  // (DESIGN 4.17): ~50 per K tile against 16 MFMAs.
+  constexpr bool FAST = A_KM && B_KM && VEC;
+  const bool interior = FAST && m0 + BM <= M && n0 + BN <= N;
+  unsigned oa[NA], ob[NB];
+  if (FAST) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int idx = p * 256 + tid, kr = idx / (BM / 4), mq = (idx % (BM / 4)) * 4;
+      oa[p] = (unsigned)(((size_t)kr * lda + mq) * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int idx = p * 256 + tid, kr = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
+      ob[p] = (unsigned)(((size_t)kr * ldb + nq) * 4);
+    }
+  }
+  auto load_tile_any = [&](float4 (&ra)[NA], float4 (&rb)[NB], int k0) {
+    if (FAST && interior && k0 + LG_BK <= ke) {
+      const char* __restrict__ ab = reinterpret_cast<const char*>(A + (size_t)k0 * lda + m0);
+      const char* __restrict__ bb = reinterpret_cast<const char*>(B + (size_t)k0 * ldb + n0);
+#pragma unroll
+      for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ab + oa[p]);
+#pragma unroll
+      for (int p = 0; p < NB; ++p) rb[p] = *reinterpret_cast<const float4*>(bb + ob[p]);
+    } else {
+      load_tile(ra, rb, k0);
+    }
+  };
+
   auto store_tile = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
@@ -160,7 +193,7 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   const int ntiles = (ke - kb + LG_BK - 1) / LG_BK;
   if (ntiles > 0) {
 #pragma unroll
-    for (int s = 0; s < ST; ++s) load_tile(rsa[s], rsb[s], kb + s * LG_BK);
+    for (int s = 0; s < ST; ++s) load_tile_any(rsa[s], rsb[s], kb + s * LG_BK);
     int t = 0;
     for (; t + ST <= ntiles; t += ST) {
 #pragma unroll
@@ -168,7 +201,7 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
         __syncthreads();                      // previous tile fully consumed
         store_tile(rsa[s], rsb[s]);
         __syncthreads();
-        load_tile(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
+        load_tile_any(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
         compute_tile();
       }
     }
@@ -217,7 +250,8 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
 // prefix[p] = workgroups before problem p.  A workgroup finds its problem by binary search and then runs the very
 // same tile body as the per-layer kernel (64 x 64 tiles), so results are bit-identical to it.
 __global__ void __launch_bounds__(256)
-gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total) {
+gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
+                          int xcd_order) {
   // grid == total: one tile per workgroup.  grid < total (msde_linear_bwd_w_grouped_ex with a width limit): each
   // workgroup walks tiles blockIdx.x, + gridDim.x, ...: the launch then occupies at most gridDim.x workgroup slots, so it
   // can run BESIDE a latency-critical chain on another stream without taking every CU (same results, tile by tile).
@@ -235,7 +269,15 @@ gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __rest
     const int M = (int)e[4], N = (int)e[5], K = (int)e[6], kps = (int)e[8], tx = (int)e[9], ty = (int)e[10];
     const int ldg = (int)e[12], ldx = (int)e[13];
     const int Mt = msde_true_rows(M, reinterpret_cast<const int*>(e[14]));      // valid rows of gY / X (row bound)
-    const int local = blk - prefix[lo];
+    // XCD-aware tile order inside a problem: consecutive workgroups run on different XCDs (b % 8), so in natural order
+    // every XCD streams every operand block of every layer from the fabric.  The problem's n tiles (x fastest, then y,
+    // then split) are cut into 8 contiguous runs and residue class c = local % 8 (one XCD) takes run c: the tiles an
+    // XCD works on share gY / X row blocks in ITS L2.  Every problem is still spread evenly over the 8 XCDs.
+    int local = blk - prefix[lo];
+    if (xcd_order) {
+      const int np = prefix[lo + 1] - prefix[lo], q = np >> 3, r = np & 7, c = local & 7;
+      local = c * q + min(c, r) + (local >> 3);
+    }
     const int bx = local % tx, by = (local / tx) % ty, bz = local / (tx * ty);
     // product C[N][K] = gY^T X: "M" of the product = N, "N" = K, reduction = M (see msde_linear_bwd_w)
     if (e[11])
@@ -400,11 +442,14 @@ extern "C" long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K) {
 
 // Batched form of the slab reduction: the weight-gradient GEMMs of a whole backward pass only write their
 // slabs (msde_linear_bwd_w_partial) and ONE launch sums them all.  rows[r] = {slab address, splits, stride
-// between splits (= entries n), output address} as four int64; prefix[r] = number of 256-entry chunks before
-// row r (prefix[count] = grid size).  Fixed summation order (4 interleaved split lanes, combined in lane order).
+// between splits (= entries n), output address} as four int64; prefix[r] = number of chunks before row r
+// (prefix[count] = grid size).  A chunk is 256 entries summed by 4 split lanes (lane ly takes the splits ly, ly+4, ...),
+// or -- rows with >= MSDE_REDUCE_LONG splits (per-workgroup slabs of the fused kernels: 256-512 of them) -- 64 entries
+// summed by 16 split lanes: the chain of dependent loads per thread is 4x shorter, which is what bounds those rows.
+// Fixed summation order (per lane in split order, lanes combined in lane order).
 __global__ void __launch_bounds__(256)
 reduce_slabs_multi_kernel(const long long* __restrict__ rows, const int* __restrict__ prefix, int count) {
-  __shared__ float4 part[4][64];
+  __shared__ float4 part[256];
   int lo = 0, hi = count;                  // last row with prefix[row] <= blockIdx.x
   while (hi - lo > 1) {
     int mid = (lo + hi) >> 1;
@@ -415,37 +460,53 @@ reduce_slabs_multi_kernel(const long long* __restrict__ rows, const int* __restr
   const int splits = (int)e[1];
   const size_t n = (size_t)e[2];
   float* out = reinterpret_cast<float*>(e[3]);
-  // 64 lanes x 4 consecutive outputs (1 KiB of one split row per wave), 4 split lanes: lane ly sums the splits
-  // z = ly, ly+4, ...; the four partials are added in lane order
-  const int ox = threadIdx.x & 63, ly = threadIdx.x >> 6;
-  const size_t i = (size_t)(blockIdx.x - prefix[lo]) * 256 + 4 * ox;
+  const int LY = splits >= MSDE_REDUCE_LONG ? 16 : 4, OXN = 256 / LY;
+  const int ox = threadIdx.x % OXN, ly = threadIdx.x / OXN;
+  const size_t i = (size_t)(blockIdx.x - prefix[lo]) * (4 * OXN) + 4 * ox;
   const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n) {
     if (vec) {
       int z = ly;
-      for (; z + 12 < splits; z += 16) {       // four independent 16-byte loads in flight
+      for (; z + 3 * LY < splits; z += 4 * LY) {       // four independent 16-byte loads in flight
         float4 a = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i);
-        float4 b = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 4) * n + i);
-        float4 c = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 8) * n + i);
-        float4 d = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 12) * n + i);
+        float4 b = *reinterpret_cast<const float4*>(slabs + (size_t)(z + LY) * n + i);
+        float4 c = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 2 * LY) * n + i);
+        float4 d = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 3 * LY) * n + i);
         acc = vadd(vadd(vadd(vadd(acc, a), b), c), d);
       }
-      for (; z < splits; z += 4) acc = vadd(acc, *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i));
+      for (; z < splits; z += LY) acc = vadd(acc, *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i));
     } else {
-      for (int z = ly; z < splits; z += 4) {
+      const bool h1 = i + 1 < n, h2 = i + 2 < n, h3 = i + 3 < n;
+      int z = ly;
+      for (; z + 3 * LY < splits; z += 4 * LY) {       // same order of additions as the tail loop, 4 rows in flight
+        const float* p0 = slabs + (size_t)z * n + i;
+        const float* p1 = slabs + (size_t)(z + LY) * n + i;
+        const float* p2 = slabs + (size_t)(z + 2 * LY) * n + i;
+        const float* p3 = slabs + (size_t)(z + 3 * LY) * n + i;
+        const float a0 = p0[0], a1 = p1[0], a2 = p2[0], a3 = p3[0];
+        const float b0 = h1 ? p0[1] : 0.f, b1 = h1 ? p1[1] : 0.f, b2 = h1 ? p2[1] : 0.f, b3 = h1 ? p3[1] : 0.f;
+        const float c0 = h2 ? p0[2] : 0.f, c1 = h2 ? p1[2] : 0.f, c2 = h2 ? p2[2] : 0.f, c3 = h2 ? p3[2] : 0.f;
+        const float d0 = h3 ? p0[3] : 0.f, d1 = h3 ? p1[3] : 0.f, d2 = h3 ? p2[3] : 0.f, d3 = h3 ? p3[3] : 0.f;
+        acc.x = (((acc.x + a0) + a1) + a2) + a3;
+        acc.y = (((acc.y + b0) + b1) + b2) + b3;
+        acc.z = (((acc.z + c0) + c1) + c2) + c3;
+        acc.w = (((acc.w + d0) + d1) + d2) + d3;
+      }
+      for (; z < splits; z += LY) {
         const float* p = slabs + (size_t)z * n + i;
         acc.x += p[0];
-        if (i + 1 < n) acc.y += p[1];
-        if (i + 2 < n) acc.z += p[2];
-        if (i + 3 < n) acc.w += p[3];
+        if (h1) acc.y += p[1];
+        if (h2) acc.z += p[2];
+        if (h3) acc.w += p[3];
       }
     }
   }
-  part[ly][ox] = acc;
+  part[ly * OXN + ox] = acc;
   __syncthreads();
   if (ly == 0 && i < n) {
-    float4 r = vadd(vadd(vadd(part[0][ox], part[1][ox]), part[2][ox]), part[3][ox]);
+    float4 r = part[ox];
+    for (int q = 1; q < LY; ++q) r = vadd(r, part[q * OXN + ox]);
     if (vec) {
       *reinterpret_cast<float4*>(out + i) = r;
     } else {
@@ -455,6 +516,11 @@ reduce_slabs_multi_kernel(const long long* __restrict__ rows, const int* __restr
       if (i + 3 < n) out[i + 3] = r.w;
     }
   }
+}
+
+extern "C" long long msde_reduce_slabs_chunks(long long n, int splits) {
+  const long long per = splits >= MSDE_REDUCE_LONG ? 64 : 256;
+  return (n + per - 1) / per;
 }
 
 extern "C" int msde_reduce_slabs_multi(const long long* rows, const int* prefix, int count, int total_chunks,
@@ -495,8 +561,10 @@ extern "C" int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* p
                                             int max_workgroups, void* stream) {
   if (count < 0 || total_blocks < 0 || (count > 0 && (!probs || !prefix))) return MSDE_EINVAL;
   if (count == 0 || total_blocks == 0) return 0;
+  static const int xcd = env_int("MSDE_WGRAD_XCD", 1);
   const int grid = max_workgroups > 0 && max_workgroups < total_blocks ? max_workgroups : total_blocks;
-  MSDE_LAUNCH(gemm_grouped_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), probs, prefix, count, total_blocks);
+  MSDE_LAUNCH(gemm_grouped_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), probs, prefix, count, total_blocks,
+              grid == total_blocks ? xcd : 0);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

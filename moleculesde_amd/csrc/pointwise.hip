@@ -330,3 +330,149 @@ extern "C" int msde_combine_losses_bwd(const float* g, float ca, float cb, float
   MSDE_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- narrow output layer of an MLP over rows: out[e][j] = b[j] + sum_c silu(Z[e][c]) W[j][c] with J <= 4 outputs
+// (basis_mlp of equivariant_scorenetwork.py:142-146: Linear(2D, H) -> SiLU -> Linear(H, 3) on every edge).  As a GEMM the
+// J = 3 product wastes 61 of 64 tile columns forward and runs a K = 3 product backward (12 + 35 us at 35 k edges); here
+// lpr lanes hold one row as float4 pieces: the activation is applied while reading the PRE-activation (the activated
+// tensor is never stored), the backward writes d/dZ (activation derivative included) and accumulates the layer's own
+// weight / bias gradient in registers -> one slab per workgroup (summed by msde_reduce_slabs[_multi], fixed order).
+#define MH_MAXJ 4
+#define MH_MAXWG 256
+// slab of one workgroup: [gW (J x H) | gb (J)] padded to whole float4 (the batched reduction then takes its vector path)
+__host__ __device__ __forceinline__ size_t mh_slab_floats(int J, int H) { return ((size_t)J * H + J + 3) & ~(size_t)3; }
+__device__ __forceinline__ float mh_sigmoid(float z) { return 1.f / (1.f + __expf(-z)); }
+
+__global__ void __launch_bounds__(256)
+mlp_head_fwd_kernel(const float4* __restrict__ Z, int ldz4, const float4* __restrict__ W, const float* __restrict__ b, int E,
+                    int H4, int J, int lpr, float* __restrict__ out) {
+  const int rpb = 256 / lpr, group = threadIdx.x / lpr, lane = threadIdx.x % lpr;
+  for (int e = blockIdx.x * rpb + group; e < E; e += gridDim.x * rpb) {
+    float p[MH_MAXJ] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < H4; c += lpr) {
+      const float4 z = Z[(size_t)e * ldz4 + c];
+      const float4 a = make_float4(z.x * mh_sigmoid(z.x), z.y * mh_sigmoid(z.y), z.z * mh_sigmoid(z.z), z.w * mh_sigmoid(z.w));
+#pragma unroll
+      for (int j = 0; j < MH_MAXJ; ++j)
+        if (j < J) {
+          const float4 w = W[j * H4 + c];
+          p[j] += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MH_MAXJ; ++j)
+      if (j < J) {
+        const float s = group_sum(p[j], lpr);
+        if (lane == 0) out[(size_t)e * J + j] = s + (b ? b[j] : 0.f);
+      }
+  }
+}
+
+// H4 <= lpr here (one float4 column piece per lane): the per-lane weight-gradient accumulators stay in registers
+__global__ void __launch_bounds__(256)
+mlp_head_bwd_kernel(const float4* __restrict__ Z, int ldz4, const float4* __restrict__ W, const float* __restrict__ g, int E,
+                    const int* __restrict__ Edev, int H4, int J, int lpr, float4* __restrict__ gZ, float* __restrict__ slabs) {
+  __shared__ float4 red[256 * MH_MAXJ];
+  __shared__ float redb[64 * MH_MAXJ];
+  const int Et = msde_true_rows(E, Edev);      // padded rows: zero gradient, no contribution to the weight gradient
+  const int rpb = 256 / lpr, group = threadIdx.x / lpr, lane = threadIdx.x % lpr;
+  const bool on = lane < H4;
+  float4 w[MH_MAXJ], dw[MH_MAXJ];
+  float db[MH_MAXJ];
+#pragma unroll
+  for (int j = 0; j < MH_MAXJ; ++j) {
+    w[j] = (j < J && on) ? W[j * H4 + lane] : vzero4();
+    dw[j] = vzero4();
+    db[j] = 0.f;
+  }
+  for (int e = blockIdx.x * rpb + group; e < E; e += gridDim.x * rpb) {
+    if (!on) continue;
+    float4 t = vzero4();
+    if (e < Et) {
+      const float4 z = Z[(size_t)e * ldz4 + lane];
+      const float4 s = make_float4(mh_sigmoid(z.x), mh_sigmoid(z.y), mh_sigmoid(z.z), mh_sigmoid(z.w));
+      const float4 a = make_float4(z.x * s.x, z.y * s.y, z.z * s.z, z.w * s.w);
+#pragma unroll
+      for (int j = 0; j < MH_MAXJ; ++j)
+        if (j < J) {
+          const float gj = g[(size_t)e * J + j];
+          t = make_float4(fmaf(gj, w[j].x, t.x), fmaf(gj, w[j].y, t.y), fmaf(gj, w[j].z, t.z), fmaf(gj, w[j].w, t.w));
+          dw[j] = make_float4(fmaf(gj, a.x, dw[j].x), fmaf(gj, a.y, dw[j].y), fmaf(gj, a.z, dw[j].z), fmaf(gj, a.w, dw[j].w));
+          db[j] += gj;
+        }
+      // d silu(z)/dz = s (1 + z (1 - s))
+      t = make_float4(t.x * s.x * (1.f + z.x * (1.f - s.x)), t.y * s.y * (1.f + z.y * (1.f - s.y)),
+                      t.z * s.z * (1.f + z.z * (1.f - s.z)), t.w * s.w * (1.f + z.w * (1.f - s.w)));
+    }
+    gZ[(size_t)e * H4 + lane] = t;
+  }
+  // row groups of the workgroup, summed in group order
+#pragma unroll
+  for (int j = 0; j < MH_MAXJ; ++j) {
+    red[(group * MH_MAXJ + j) * lpr + lane] = dw[j];
+    if (lane == 0) redb[group * MH_MAXJ + j] = db[j];
+  }
+  __syncthreads();
+  const int H = 4 * H4;
+  float* slab = slabs + (size_t)blockIdx.x * mh_slab_floats(J, H);
+  if (group == 0 && on) {
+    for (int j = 0; j < J; ++j) {
+      float4 s = vzero4();
+      for (int q = 0; q < rpb; ++q) s = vadd(s, red[(q * MH_MAXJ + j) * lpr + lane]);
+      float* o = slab + (size_t)j * H + 4 * lane;          // J * H + J floats per slab: rows need not be 16-B aligned
+      o[0] = s.x; o[1] = s.y; o[2] = s.z; o[3] = s.w;
+    }
+  }
+  if (threadIdx.x < MH_MAXJ && J * H + (int)threadIdx.x < (int)mh_slab_floats(J, H)) {     // bias sums, zeros in the padding
+    float s = 0.f;
+    if ((int)threadIdx.x < J)
+      for (int q = 0; q < rpb; ++q) s += redb[q * MH_MAXJ + threadIdx.x];
+    slab[(size_t)J * H + threadIdx.x] = s;
+  }
+}
+
+static inline bool mh_ok(int H, int J, const void* Z, int ldz, const void* W) {
+  return H > 0 && H % 4 == 0 && H <= 256 && J >= 1 && J <= MH_MAXJ && ldz % 4 == 0 && ldz >= H &&
+         ((reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+}
+static inline int mh_grid(int E, int lpr) {
+  const int rpb = 256 / lpr;
+  int nb = (E + rpb - 1) / rpb;
+  if (nb > MH_MAXWG) nb = MH_MAXWG;
+  return nb < 1 ? 1 : nb;
+}
+
+extern "C" int msde_mlp_head_fwd(const float* Z, int ldz, const float* W, const float* b, int E, int H, int J, float* out,
+                                 void* stream) {
+  if (E < 0 || !Z || !W || !out) return MSDE_EINVAL;
+  if (!mh_ok(H, J, Z, ldz, W)) return MSDE_EUNSUP;
+  if (E == 0) return 0;
+  const int lpr = pick_tpr(H / 4), rpb = 256 / lpr;
+  int nb = (E + rpb - 1) / rpb;
+  if (nb > 8 * MH_MAXWG) nb = 8 * MH_MAXWG;
+  MSDE_LAUNCH(mlp_head_fwd_kernel, dim3(nb), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(Z), ldz / 4,
+              reinterpret_cast<const float4*>(W), b, E, H / 4, J, lpr, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_mlp_head_bwd_slabs(int E, int H) { return mh_grid(E, pick_tpr(H / 4)); }
+
+extern "C" int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const float* g, int E, int H, int J, float* gZ,
+                                 float* gWb, float* workspace, void* stream) {
+  if (E < 0 || !Z || !W || !g || !gZ || !workspace) return MSDE_EINVAL;
+  if (!mh_ok(H, J, Z, ldz, W) || (reinterpret_cast<uintptr_t>(gZ) & 15)) return MSDE_EUNSUP;
+  hipStream_t st = as_stream(stream);
+  const size_t n = mh_slab_floats(J, H);
+  if (E == 0) {
+    if (gWb) { hipError_t e = hipMemsetAsync(gWb, 0, n * sizeof(float), st); if (e != hipSuccess) return (int)e; }
+    return 0;
+  }
+  const int lpr = pick_tpr(H / 4), nb = mh_grid(E, lpr);
+  MSDE_LAUNCH(mlp_head_bwd_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4*>(Z), ldz / 4,
+              reinterpret_cast<const float4*>(W), g, E, msde_row_bound(E), H / 4, J, lpr, reinterpret_cast<float4*>(gZ),
+              workspace);
+  MSDE_CHECK_LAUNCH();
+  if (!gWb) return 0;                 // slabs stay in `workspace` for a batched reduction
+  return msde_reduce_slabs(workspace, nb, n, gWb, nullptr, 0, nullptr, st);
+}

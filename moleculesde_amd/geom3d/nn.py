@@ -17,6 +17,8 @@ def shifted_softplus(x):
     return F.softplus(x) - _LN2
 
 
+import os as _os
+FUSED_MLP = _os.environ.get("MSDE_FUSED_MLP", "1") != "0"     # Linear/SiLU/Linear chains as hip.mlp_fused (A/B switch)
 USE_HIP_LINEAR = True   # False routes dense layers to the vendor GEMM ON THE DEVICE (A/B measurements only)
 
 
@@ -115,6 +117,7 @@ class MultiLayerPerceptron(nn.Module):
         super().__init__()
         self.dims = [input_dim] + list(hidden_dims)
         self.activation = getattr(F, activation) if isinstance(activation, str) else None
+        self.activation_name = activation if isinstance(activation, str) else None
         self.dropout = nn.Dropout(dropout) if dropout else None
         self.layers = nn.ModuleList([Linear(self.dims[i], self.dims[i + 1]) for i in range(len(self.dims) - 1)])
         self.reset_parameters()
@@ -125,6 +128,10 @@ class MultiLayerPerceptron(nn.Module):
             nn.init.constant_(layer.bias, 0.0)
 
     def forward(self, x):
+        if (FUSED_MLP and USE_HIP_LINEAR and len(self.layers) >= 2 and self.activation_name == "silu" and not self.dropout
+                and x.is_cuda and x.dim() == 2 and all(d % 4 == 0 for d in self.dims) and not any(l.shared for l in self.layers)):
+            # bias + SiLU in the GEMM epilogues, SiLU' in the epilogue of the next layer's input-gradient GEMM
+            return hip.mlp_fused(x, [(l.weight, l.bias) for l in self.layers], "silu")
         for i, layer in enumerate(self.layers):
             x = layer(x)
             if i < len(self.layers) - 1:

@@ -144,9 +144,15 @@ class EquivariantScoreNetwork(nn.Module):
                 layer_no += 1
                 conv_input = hidden
             node_feature = hidden
-            pair = hip.pair_gather_add(node_feature, node_feature, plan)        # h_row + h_col
-            edge_feature = torch.cat([pair, edge_attr], dim=-1)
-            coff = self.basis_mlp_modules[module_idx](edge_feature)             # [E, 3]
+            mlp = self.basis_mlp_modules[module_idx]
+            if _nn.FUSED_MLP and node_feature.size(1) % 4 == 0 and edge_attr.size(1) % 4 == 0:
+                # cat([h_row + h_col, edge_attr]) written by the gather; Linear -> SiLU -> Linear on gemm_ex epilogues
+                edge_feature = hip.pair_gather_cat(node_feature, edge_attr, plan)
+                coff = hip.mlp_fused(edge_feature, [(mlp[0].weight, mlp[0].bias), (mlp[2].weight, mlp[2].bias)], "silu")
+            else:
+                pair = hip.pair_gather_add(node_feature, node_feature, plan)        # h_row + h_col
+                edge_feature = torch.cat([pair, edge_attr], dim=-1)
+                coff = mlp(edge_feature)                                           # [E, 3]
             g = hip.frame_mix_mean(coff, basis, plan)
             gradient = g if gradient is None else gradient + g
         return {"node_feature": node_feature, "gradient": gradient}

@@ -261,7 +261,7 @@ class _CFConvFused(torch.autograd.Function):
             _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
                       _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G, plan.E, ctx.coeff, ctx.cutoff, mw, _p(None), _p(None),
                       _p(None), _p(None), _p(ws), st)
-            _SLABS.add(ws.data_ptr(), nslab, gall.numel(), gall)
+            _SLABS.add(ws.data_ptr(), nslab, gall.numel(), gall, written=True)
         else:
             ws = _cf_workspace(plan.E, G, x1.device, mw)
             _lib.call("msde_cfconv_fused_bwd_w", _p(g), _p(x1), _p(dist), _p(plan.rowptr), _p(plan.src), _p(plan.dst),
@@ -568,6 +568,126 @@ class _PairGatherAddCols(torch.autograd.Function):
 
 def pair_gather_add_cols(AB, plan):
     return _PairGatherAddCols.apply(AB, plan)
+
+
+class _PairGatherCat(torch.autograd.Function):
+    """[x[src_e] + x[dst_e] | c[e]]: cat([h_row + h_col, edge_attr]) of equivariant_scorenetwork.py:154-157 written by the
+    gather kernel itself (no separate concatenation); the backward sums the left column block over both CSRs in one
+    kernel and hands the right block on as a view."""
+
+    @staticmethod
+    def forward(ctx, x, c, plan):
+        x, c = _f32(x), _f32(c)
+        E, D, D2 = plan.E, x.size(1), c.size(1)
+        out = torch.empty(E, D + D2, dtype=torch.float32, device=x.device)
+        _lib.call("msde_pair_gather_cat", _p(x), D, _p(c), D2, _p(plan.src), _p(plan.dst), E, D, D2, _p(out), _stream())
+        ctx.plan, ctx.D = plan, D
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, D = ctx.plan, ctx.D
+        g = g if (g.is_cuda and g.dtype == torch.float32 and g.stride(-1) == 1) else _f32(g)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(plan.N, D, dtype=torch.float32, device=g.device)
+            _lib.call("msde_segment_sum_rows2", _p(g), _row_stride(g, g.size(1)), _p(plan.rowptr_s), _p(plan.perm_s),
+                      _p(plan.rowptr), _p(None), plan.N, D, 0.0, _p(gx), D, _stream())
+        return gx, (g[:, D:] if ctx.needs_input_grad[1] else None), None
+
+
+def pair_gather_cat(x, c, plan):
+    """cat([x[row] + x[col], c], -1) for per-edge rows c."""
+    return _PairGatherCat.apply(x, c, plan)
+
+
+class _MlpFused(torch.autograd.Function):
+    """Linear -> act -> Linear (-> act -> Linear ...) on csrc/gemm_ex.hip: bias + activation in the GEMM epilogues (the
+    pre-activation is stored beside the output), the activation's derivative in the epilogue of the input-gradient GEMM
+    of the layer above, weight gradients queued for the grouped split-M launch.  A last layer with <= 4 outputs behind a
+    SiLU runs on the row kernels msde_mlp_head_fwd/_bwd (activation applied while reading the pre-activation, own weight
+    gradient accumulated in the backward kernel).  Replaces the GEMM / activation / GEMM operator chains of
+    layers/common.py:5-40 and equivariant_scorenetwork.py:142-146."""
+
+    @staticmethod
+    def forward(ctx, x, act, offload, *params):
+        x = x if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1) else _f32(x)
+        n = len(params) // 2
+        need = any(ctx.needs_input_grad)
+        M = x.size(0)
+        Wl = params[2 * n - 2]
+        head = (n >= 2 and act == "silu" and Wl.size(0) <= 4 and Wl.size(1) % 4 == 0 and Wl.size(1) <= 256
+                and Wl.is_contiguous() and Wl.data_ptr() % 16 == 0)
+        h, saved = x, []
+        for i in range(n):
+            W, b = params[2 * i], params[2 * i + 1]
+            last = i == n - 1
+            out = torch.empty(M, W.size(0), dtype=torch.float32, device=x.device)
+            if last and head:              # h is the PRE-activation of the layer below
+                _lib.call("msde_mlp_head_fwd", _p(h), _ld(h), _p(W), _p(b), M, W.size(1), W.size(0), _p(out), _stream())
+                saved += [None, None]
+            elif head and i == n - 2:      # only the pre-activation is stored: the head kernels apply the SiLU on load
+                gemm_ex(h, W, out, bias=b)
+                saved += [h, out]
+            else:
+                Z = torch.empty_like(out) if (need and not last) else None
+                gemm_ex(h, W, out, bias=b, act=None if last else act, Z=Z)
+                saved += [h, Z]
+            h = out
+        ctx.save_for_backward(*[t for t in saved if t is not None], *params)
+        ctx.layout = [t is not None for t in saved]
+        ctx.act, ctx.n, ctx.head = act, n, head
+        ctx.deferrable = offload and all(t is None or t.is_leaf or getattr(t, "_msde_leaf_like", False) for t in params)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        n, act = ctx.n, ctx.act
+        it = iter(ctx.saved_tensors)
+        saved = [next(it) if present else None for present in ctx.layout]
+        params = list(it)
+        g = g if (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()) else _f32(g)
+        grads = [None] * (2 * n)
+        top = n - 1
+        if ctx.head:
+            # last layer on the row kernel: d/dZ of the layer below (SiLU' included) + its own [gW | gb] slabs
+            W, b = params[2 * n - 2], params[2 * n - 1]
+            Zp = saved[2 * (n - 2) + 1]
+            E, H, J = Zp.size(0), W.size(1), W.size(0)
+            gz = torch.empty(E, H, dtype=torch.float32, device=g.device)
+            gall = torch.empty((J * H + J + 3) & ~3, dtype=torch.float32, device=g.device)   # slab size: whole float4
+            nslab = int(_lib.load().msde_mlp_head_bwd_slabs(E, H))
+            if _SLABS.active and ctx.deferrable:
+                ws = _SLABS.alloc(nslab * gall.numel(), g.device)
+                _lib.call("msde_mlp_head_bwd", _p(Zp), _ld(Zp), _p(W), _p(g), E, H, J, _p(gz), _p(None), _p(ws), _stream())
+                _SLABS.add(ws.data_ptr(), nslab, gall.numel(), gall, written=True)
+            else:
+                ws = torch.empty(nslab * gall.numel(), dtype=torch.float32, device=g.device)
+                _lib.call("msde_mlp_head_bwd", _p(Zp), _ld(Zp), _p(W), _p(g), E, H, J, _p(gz), _p(gall), _p(ws), _stream())
+            grads[2 * n - 2] = gall[:J * H].view(J, H)
+            grads[2 * n - 1] = gall[J * H:J * H + J] if b is not None else None
+            g, top = gz, n - 2
+        for i in range(top, -1, -1):           # invariant: g = d/d(pre-activation of layer i)
+            W, b = params[2 * i], params[2 * i + 1]
+            h_in = saved[2 * i]
+            if ctx.needs_input_grad[3 + 2 * i] or (b is not None and ctx.needs_input_grad[4 + 2 * i]):
+                grads[2 * i], grads[2 * i + 1] = weight_grad(g, h_in, b is not None, ctx.deferrable)
+            if i == 0 and not ctx.needs_input_grad[0]:
+                g = None
+                break
+            gin = torch.empty(g.size(0), W.size(1), dtype=torch.float32, device=g.device)
+            # d/d(input of layer i) = g W; for i > 0 that input is act(Z_{i-1}): times act'(Z_{i-1}) in the same epilogue
+            gemm_ex(g, W, gin, b_kmajor=True, act=act if i > 0 else None, dact_from=saved[2 * i - 1] if i > 0 else None)
+            g = gin
+        return (g, None, None) + tuple(grads)
+
+
+def mlp_fused(x, layers, act="silu", offload=True):
+    """layers: [(weight, bias), ...] of consecutive nn.Linear; `act` between them (none after the last)."""
+    flat = []
+    for W, b in layers:
+        flat += [W, b]
+    return _MlpFused.apply(x, act, offload, *flat)
 
 
 class _CatParams(torch.autograd.Function):
@@ -924,11 +1044,11 @@ class _SlabBatch:
         """Pinned host image + device copy of the row / prefix tables (one per captured graph: the upload is a
         memcpy node that re-reads its host image at every replay)."""
         host_rows = torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64).pin_memory()
-        host_pre = torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32).pin_memory()
+        host_pre = torch.zeros(self.MAX_ROWS + 64, dtype=torch.int32).pin_memory()
         host_prob = torch.zeros(self.MAX_ROWS, 16, dtype=torch.int64).pin_memory()      # MSDE_WGRAD_ROW
         host_ppre = torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32).pin_memory()
         self.slot = (host_rows, host_pre, torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64, device=device),
-                     torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device),
+                     torch.zeros(self.MAX_ROWS + 64, dtype=torch.int32, device=device),
                      host_prob, host_ppre, torch.zeros(self.MAX_ROWS, 16, dtype=torch.int64, device=device),
                      torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device))
         self.slots.append(self.slot)
@@ -966,6 +1086,7 @@ class _SlabBatch:
         self.active = True
         self.used = 0
         self.prob_used = self.pre_used = 0
+        self.rows_used = self.rpre_used = 0
         self.rotated = False
 
     def alloc(self, nfloats, device):
@@ -980,11 +1101,14 @@ class _SlabBatch:
         self.used += nfloats
         return view
 
-    def add(self, slab_ptr, splits, n, out):
+    def add(self, slab_ptr, splits, n, out, written=False):
         # only the ADDRESS of the output is kept: an extra reference to the gradient tensor would make autograd's
         # AccumulateGrad clone it (it steals the buffer only when it holds the sole reference) -- a copy of the
         # not yet reduced buffer.  The leaf's .grad keeps the memory alive until the optimiser has used it.
-        self.rows.append((slab_ptr, splits, n, out.data_ptr(), out.device))
+        # written: the kernel that fills these slabs is already queued on the CURRENT stream (not a queued GEMM or a
+        # deferred kernel), so reduce_written() may sum them on that stream before the end of the backward pass
+        self.rows.append((slab_ptr, splits, n, out.data_ptr(), out.device,
+                          torch.cuda.current_stream().cuda_stream if written else None))
 
     def queue_gemm(self, gY, X, M, N, K, has_bias, slab):
         self.gemms.append((gY, X, M, N, K, has_bias, slab))
@@ -1043,23 +1167,12 @@ class _SlabBatch:
         self.active = False
         self.run_deferred()          # nobody ran them on another stream: here, before their slabs are summed
         rows = self.rows
-        if not rows:
+        if not rows and not self.rotated:
             return
-        assert len(rows) <= self.MAX_ROWS
-        dev = rows[0][4]
-        self._select_slot(dev)
-        self.launch_gemms()          # the (still) queued weight-gradient GEMMs as one grouped launch
-        host_rows, host_pre, dev_rows, dev_pre = self.slot[:4]
-        hr, hp = host_rows.numpy(), host_pre.numpy()
-        total = 0
-        for r, (ptr, splits, n, out_ptr, _) in enumerate(rows):
-            hr[r, 0], hr[r, 1], hr[r, 2], hr[r, 3] = ptr, splits, n, out_ptr
-            hp[r] = total
-            total += (n + 255) // 256
-        hp[len(rows)] = total
-        upload_table(dev_rows[:len(rows)], host_rows[:len(rows)])
-        upload_table(dev_pre[:len(rows) + 1], host_pre[:len(rows) + 1])
-        _lib.call("msde_reduce_slabs_multi", _p(dev_rows), _p(dev_pre), len(rows), total, _stream())
+        if rows:
+            self._select_slot(rows[0][4])
+            self.launch_gemms()      # the (still) queued weight-gradient GEMMs as one grouped launch
+            self._reduce(rows)
         if not torch.cuda.is_current_stream_capturing():
             ev = self.events[self.slot_i] or torch.cuda.Event()
             ev.record()
@@ -1068,6 +1181,40 @@ class _SlabBatch:
         self.launched = []
         _retire(self.retired)
         self.retired = []
+
+    def _reduce(self, rows):
+        """One msde_reduce_slabs_multi launch on the current stream for `rows` (the next rows of the slot's tables)."""
+        host_rows, host_pre, dev_rows, dev_pre = self.slot[:4]
+        r0, q0, k = self.rows_used, self.rpre_used, len(rows)
+        assert r0 + k <= self.MAX_ROWS
+        hr, hp = host_rows.numpy(), host_pre.numpy()
+        total = 0
+        for r, row in enumerate(rows):
+            hr[r0 + r, 0], hr[r0 + r, 1], hr[r0 + r, 2], hr[r0 + r, 3] = row[0], row[1], row[2], row[3]
+            hp[q0 + r] = total
+            total += (row[2] + 63) // 64 if row[1] >= _lib.REDUCE_LONG else (row[2] + 255) // 256
+        hp[q0 + k] = total
+        upload_table(dev_rows[r0:r0 + k], host_rows[r0:r0 + k])
+        upload_table(dev_pre[q0:q0 + k + 1], host_pre[q0:q0 + k + 1])
+        self.rows_used, self.rpre_used = r0 + k, q0 + k + 1
+        _lib.call("msde_reduce_slabs_multi", ctypes.c_void_p(dev_rows[r0:].data_ptr()),
+                  ctypes.c_void_p(dev_pre[q0:].data_ptr()), k, total, _stream())
+
+    def reduce_written(self):
+        """Sum, on the CURRENT stream, the slabs whose producing kernels are already queued on it (add(written=True)):
+        a stream that finishes its part of the backward early reduces its own slabs while the other stream is still in
+        the backward chain, and the final reduction has that much less to read."""
+        if not self.active or not self.rows:
+            return 0
+        me = torch.cuda.current_stream().cuda_stream
+        mine = [r for r in self.rows if r[5] is not None and r[5] == me]
+        if not mine:
+            return 0
+        self._select_slot(mine[0][4])
+        self._reduce(mine)
+        self.rows = [r for r in self.rows if not (r[5] is not None and r[5] == me)]
+        self.early = True
+        return len(mine)
 
     def _select_slot(self, dev):
         """Once per backward pass: the table slot its uploads go to (eager ring, or the capture's own slot)."""
@@ -1094,6 +1241,12 @@ def flush_wgrad_gemms(max_wgs=0):
     still summed by finish_param_grad_batch, whose stream must by then be ordered after this one)."""
     if _SLABS.active:
         _SLABS.launch_gemms(max_wgs)
+
+
+def reduce_written_slabs():
+    """Sum the slabs written by kernels already queued on the current stream (see _SlabBatch.reduce_written); returns
+    the number of gradient tensors reduced.  finish_param_grad_batch()'s stream must be ordered after this one."""
+    return _SLABS.reduce_written()
 
 
 def run_deferred_leaf_kernels():

@@ -90,6 +90,7 @@ SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFCo
 SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "256"))   # tools/ab.sh, headline ms/step with W2 in registers: 192: 3.201, 256: 3.22 (W2 in LDS: 160: 3.178, 192: 3.197, 256: 3.236); 256 = full width, 0.51 of peak
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
 GEOMETRY_ON_SIDE = os.environ.get("MSDE_GEOMETRY_ON_SIDE", "0") != "0"   # coordinate-only branch of the 2D->3D model at the head of the second stream: measured 3.187 vs 3.151 ms (tools/ab.sh), off
+EARLY_SLAB_REDUCE = os.environ.get("MSDE_EARLY_SLAB_REDUCE", "1") != "0"
 SCHNET_AFTER_GIN = os.environ.get("MSDE_SCHNET_AFTER_GIN", "0") != "0"   # experiment: start SchNet when GIN's forward is done
 PLAN_LISTS_ON_SIDE = os.environ.get("MSDE_PLAN_LISTS_ON_SIDE", "1") != "0"   # bucket mode: embedding row lists off the main chain
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
@@ -390,6 +391,13 @@ class Trainer:
                 hip.stamp("bwd_start")
                 loss.backward(one)
                 hip.stamp("bwd_main_end")
+                if self.overlap_streams and EARLY_SLAB_REDUCE:
+                    # the second stream finished its backward (SchNet) long before the main chain (GIN): it sums the
+                    # CFConv filter-gradient slabs (6 x 256 slabs, ~125 MB) it wrote, in the shadow of the GIN backward
+                    with torch.cuda.stream(self._side_stream):
+                        early = hip.reduce_written_slabs()
+                    if early:
+                        torch.cuda.current_stream().wait_stream(self._side_stream)
                 if self.overlap_streams and hip.have_deferred_leaf_kernels():
                     # leaf-only kernels of the backward pass (GIN bond-table gradients: 5 x 17 us that nothing downstream
                     # reads) run on the second stream BESIDE the grouped weight-gradient launch instead of inside the

@@ -132,6 +132,40 @@ def test_pair_gather_add_backward(dev):
     assert_close(Bd.grad, Bm.grad, 1e-5, 1e-5, "gB")
 
 
+@pytest.mark.parametrize("J", [3, 32])
+def test_pair_gather_cat_and_fused_mlp(dev, J):
+    """cat([h_row + h_col, edge_attr]) -> Linear -> SiLU -> Linear (equivariant_scorenetwork.py:154-157, 142-146): the
+    gather-written concatenation + the gemm_ex MLP against the plain fp32 torch operators (forward and every gradient,
+    immediate and batched weight-gradient paths)."""
+    from moleculesde_amd import hip
+    torch.manual_seed(11)
+    b = _toy_graph(6, 12)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    src, dst = pl.src.cpu().long(), pl.dst.cpu().long()
+    D, H = 32, 128
+    h = torch.randn(N, D, requires_grad=True)
+    ea = torch.randn(pl.E, D, requires_grad=True)
+    l0, l1 = torch.nn.Linear(2 * D, H), torch.nn.Linear(H, J)     # J = 3: the row-kernel head; 32: GEMM epilogues only
+    w = torch.randn(pl.E, J)
+    ref = l1(torch.nn.functional.silu(l0(torch.cat([h[src] + h[dst], ea], -1))))
+    (ref * w).sum().backward()
+    for batched in (False, True):
+        hd, ed = h.detach().to(dev).requires_grad_(True), ea.detach().to(dev).requires_grad_(True)
+        ps = [p.detach().to(dev).requires_grad_(True) for p in (l0.weight, l0.bias, l1.weight, l1.bias)]
+        if batched:
+            hip.begin_param_grad_batch(ps)
+        out = hip.mlp_fused(hip.pair_gather_cat(hd, ed, pl), [(ps[0], ps[1]), (ps[2], ps[3])], "silu")
+        assert_close(out, ref, 2e-5, 2e-5, "fused basis MLP fwd")
+        (out * w.to(dev)).sum().backward()
+        if batched:
+            hip.finish_param_grad_batch()
+        assert_close(hd.grad, h.grad, 1e-4, 1e-4, "g h")
+        assert_close(ed.grad, ea.grad, 1e-4, 1e-4, "g edge_attr")
+        for got, want, name in zip(ps, (l0.weight, l0.bias, l1.weight, l1.bias), ("W0", "b0", "W1", "b1")):
+            assert_close(got.grad, want.grad, 2e-4, 2e-4, "g " + name)
+
+
 @pytest.mark.parametrize("D", [300, 16])
 def test_embedding_sum(dev, D):
     from moleculesde_amd import hip, plan as P

@@ -1,0 +1,57 @@
+"""Basis MLP of the 2D->3D score network (cat([h_row + h_col, edge_attr]) -> Linear(64,128) -> SiLU -> Linear(128,3)) at the
+headline batch's extended-graph size: operator chain vs hip.pair_gather_cat + hip.mlp_fused, forward + backward, timed by
+graph replay.  Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from moleculesde_amd import hip
+from moleculesde_amd.geom3d import prepare_batch, nn as _nn
+from moleculesde_amd.synthetic import make_batch
+
+dev = torch.device("cuda", 0)
+b = prepare_batch(make_batch(256, seed=0), dev)
+pl = b._msde_plan.ext
+N, E, D, H = pl.N, pl.E, 32, 128
+torch.manual_seed(0)
+h = torch.randn(N, D, device=dev, requires_grad=True)
+ea = torch.randn(E, D, device=dev, requires_grad=True)
+l0, l1 = _nn.Linear(2 * D, H).to(dev), _nn.Linear(H, 3).to(dev)
+w = torch.randn(E, 3, device=dev)
+
+
+def chain():
+    pair = hip.pair_gather_add(h, h, pl)
+    return l1(torch.nn.functional.silu(l0(torch.cat([pair, ea], -1))))
+
+
+def fused():
+    return hip.mlp_fused(hip.pair_gather_cat(h, ea, pl), [(l0.weight, l0.bias), (l1.weight, l1.bias)], "silu")
+
+
+def step(fn):
+    for p in (h, ea, l0.weight, l0.bias, l1.weight, l1.bias):
+        p.grad = None
+    hip.begin_param_grad_batch()
+    out = fn()
+    out.backward(w)
+    hip.finish_param_grad_batch()
+
+
+for name, fn in (("operator chain", chain), ("fused", fused)):
+    for _ in range(3):
+        step(fn)
+    torch.cuda.synchronize()
+    hip.new_param_grad_slot(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step(fn)
+    hip.flush_table_uploads()
+    hip.use_eager_param_grad_slot()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        g.replay()
+    torch.cuda.synchronize()
+    print(f"{name:16s} fwd+bwd+wgrad {(time.perf_counter() - t0) / 50 * 1e6:8.1f} us   (N={N}, E={E})")
