@@ -18,6 +18,30 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LG_BK 32
+#ifndef LG_ST
+#define LG_ST 1
+#endif
+
+// Operand loads go through GLOBAL-address-space pointers.  The grouped kernel reads its operand pointers from a table
+// in memory, so to the compiler they are generic pointers and plain dereferences become FLAT loads -- which count on
+// the LDS counter (lgkmcnt) as well as vmcnt: every wait for an LDS operand read then also waits for the global
+// prefetch just issued, and the software pipeline collapses (measured: MFMA time + everything-else time, no overlap).
+__device__ __forceinline__ float4 lg_ldg4(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float lg_v4f __attribute__((ext_vector_type(4)));
+  const lg_v4f v = *(const __attribute__((address_space(1))) lg_v4f*)(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ float lg_ldg1(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *(const __attribute__((address_space(1))) float*)(p);
+#else
+  return *p;
+#endif
+}
 
 template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>
 __device__ __forceinline__ void
@@ -42,7 +66,7 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
 
   // staging registers: each thread moves (BM*BK/4)/256 = 2*TM float4 of A and 2*TN of B per tile
   constexpr int NA = 2 * TM, NB = 2 * TN;
-  constexpr int ST = 3;  // register prefetch depth: loads are issued ST tiles ahead of their MFMAs
+  constexpr int ST = LG_ST;  // register prefetch depth: loads are issued ST tiles ahead of their MFMAs
   float4 rsa[ST][NA], rsb[ST][NB];
 
   // Branch-free tile loads: out-of-range rows / k are redirected to a valid address and zeroed by a
@@ -55,11 +79,11 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
     float4 v;
     if (vec) {                                   // ncols % 4 == 0: a float4 is all-in or all-out
       bool cv = col < ncols;
-      v = *reinterpret_cast<const float4*>(src + (cv ? col : 0));
+      v = lg_ldg4(src + (cv ? col : 0));
       if (!(rv && cv)) v = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      float x0 = src[col < ncols ? col : 0], x1 = src[col + 1 < ncols ? col + 1 : 0];
-      float x2 = src[col + 2 < ncols ? col + 2 : 0], x3 = src[col + 3 < ncols ? col + 3 : 0];
+      float x0 = lg_ldg1(src + (col < ncols ? col : 0)), x1 = lg_ldg1(src + (col + 1 < ncols ? col + 1 : 0));
+      float x2 = lg_ldg1(src + (col + 2 < ncols ? col + 2 : 0)), x3 = lg_ldg1(src + (col + 3 < ncols ? col + 3 : 0));
       v.x = (rv && col < ncols) ? x0 : 0.f;
       v.y = (rv && col + 1 < ncols) ? x1 : 0.f;
       v.z = (rv && col + 2 < ncols) ? x2 : 0.f;
@@ -113,17 +137,13 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
       ob[p] = (unsigned)(((size_t)kr * ldb + nq) * 4);
     }
   }
-  auto load_tile_any = [&](float4 (&ra)[NA], float4 (&rb)[NB], int k0) {
-    if (FAST && interior && k0 + LG_BK <= ke) {
-      const char* __restrict__ ab = reinterpret_cast<const char*>(A + (size_t)k0 * lda + m0);
-      const char* __restrict__ bb = reinterpret_cast<const char*>(B + (size_t)k0 * ldb + n0);
+  auto load_tile_fast = [&](float4 (&ra)[NA], float4 (&rb)[NB], int k0) {
+    const char* __restrict__ ab = reinterpret_cast<const char*>(A + (size_t)k0 * lda + m0);
+    const char* __restrict__ bb = reinterpret_cast<const char*>(B + (size_t)k0 * ldb + n0);
 #pragma unroll
-      for (int p = 0; p < NA; ++p) ra[p] = *reinterpret_cast<const float4*>(ab + oa[p]);
+    for (int p = 0; p < NA; ++p) ra[p] = lg_ldg4(ab + oa[p]);
 #pragma unroll
-      for (int p = 0; p < NB; ++p) rb[p] = *reinterpret_cast<const float4*>(bb + ob[p]);
-    } else {
-      load_tile(ra, rb, k0);
-    }
+    for (int p = 0; p < NB; ++p) rb[p] = lg_ldg4(bb + ob[p]);
   };
 
   auto store_tile = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
@@ -168,6 +188,21 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   float csum = 0.f;  // column sum of A over k (weight-gradient mode: bias gradient), thread tid < BM
 
   auto compute_tile = [&]() {
+    if (TM == 1 && TN == 1) {
+      // all operand reads of the K tile are requested first, then the 16 MFMAs retire them in order behind counted
+      // waits.  Left to itself the compiler emits {2 reads, wait for both, 2 MFMAs} x 8: one LDS round trip exposed
+      // per 128 cycles of MFMA work (the scheduling barrier keeps it from sinking the reads back to their uses).
+      float af[LG_BK / 2], bf[LG_BK / 2];
+#pragma unroll
+      for (int kk = 0; kk < LG_BK / 2; ++kk) {
+        af[kk] = As[(2 * kk + lhalf) * LDA_S + wm * 32 + lcol];
+        bf[kk] = Bs[(2 * kk + lhalf) * LDB_S + wn * 32 + lcol];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < LG_BK / 2; ++kk)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], acc[0][0], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < LG_BK / 2; ++kk) {
       float af[TM], bf[TN];
@@ -181,6 +216,7 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    }
     if (colsum_ws != nullptr && bid_x == 0 && tid < BM) {
 #pragma unroll 8
       for (int kr = 0; kr < LG_BK; ++kr) csum += As[kr * LDA_S + tid];
@@ -193,15 +229,31 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   const int ntiles = (ke - kb + LG_BK - 1) / LG_BK;
   if (ntiles > 0) {
 #pragma unroll
-    for (int s = 0; s < ST; ++s) load_tile_any(rsa[s], rsb[s], kb + s * LG_BK);
+    for (int s = 0; s < ST; ++s) load_tile(rsa[s], rsb[s], kb + s * LG_BK);
     int t = 0;
+    if (FAST && interior) {
+      // steady state of an interior tile: every tile requested here (t + s + ST) lies entirely inside [kb, ke), so the
+      // loop body is straight-line code with clamp-free loads -- with a second (general) path inside the loop the
+      // compiler's wait counters go to vmcnt(0) at the LDS stores, i.e. they wait for the loads just issued
+      const int nfull = (ke - kb) / LG_BK;
+      for (; t + 2 * ST <= nfull; t += ST) {
+#pragma unroll
+        for (int s = 0; s < ST; ++s) {
+          __syncthreads();
+          store_tile(rsa[s], rsb[s]);
+          __syncthreads();
+          load_tile_fast(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
+          compute_tile();
+        }
+      }
+    }
     for (; t + ST <= ntiles; t += ST) {
 #pragma unroll
       for (int s = 0; s < ST; ++s) {          // static stage index: the staging arrays stay in VGPRs
         __syncthreads();                      // previous tile fully consumed
         store_tile(rsa[s], rsb[s]);
         __syncthreads();
-        load_tile_any(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
+        load_tile(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
         compute_tile();
       }
     }
