@@ -53,7 +53,12 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   // stride BM+4); one that is row-major is transposed on the way in with scalar stores, for which the
   // stride BM+1 (== 1 mod 32) is the conflict-free one.  The MFMA operand reads (32 consecutive floats
   // of one k row per half-wave) are conflict free for any stride.
-  constexpr int LDA_S = A_KM ? BM + 4 : BM + 1, LDB_S = B_KM ? BN + 4 : BN + 1;
+  // k-major images of 64-wide tiles use the row stride 64 exactly: rows are whole multiples of 64 dwords apart, so the
+  // operand reads of a K tile become `ds_read2st64_b32 base offset0:k offset1:k+2` off ONE per-lane base register
+  // (with stride 68 every read pair needed a v_add for its address -- 16 vector instructions per K tile that the fp32
+  // MFMAs cannot hide, 4.17).  Conflict-free all the same: a half-wave reads 32 consecutive floats of one row, and a
+  // 16-byte store instruction is served 8 lanes (= 32 consecutive floats) at a time.
+  constexpr int LDA_S = A_KM ? (BM == 64 ? 64 : BM + 4) : BM + 1, LDB_S = B_KM ? (BN == 64 ? 64 : BN + 4) : BN + 1;
   __shared__ __attribute__((aligned(16))) float As[LG_BK * LDA_S];
   __shared__ __attribute__((aligned(16))) float Bs[LG_BK * LDB_S];
 
@@ -217,9 +222,17 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     }
-    if (colsum_ws != nullptr && bid_x == 0 && tid < BM) {
+    if (colsum_ws != nullptr && bid_x == 0) {
+      if (BM == 64) {
+        // all four waves share the column sums (wave q takes k rows 8q .. 8q+7 of column tid & 63): 8 additions per
+        // thread and K tile instead of 32 on wave 0 alone, whose MFMAs they would hold up (4.17)
+        const int c = tid & 63, q = tid >> 6;
+#pragma unroll
+        for (int kr = 0; kr < LG_BK / 4; ++kr) csum += As[(q * (LG_BK / 4) + kr) * LDA_S + c];
+      } else if (tid < BM) {
 #pragma unroll 8
-      for (int kr = 0; kr < LG_BK; ++kr) csum += As[kr * LDA_S + tid];
+        for (int kr = 0; kr < LG_BK; ++kr) csum += As[kr * LDA_S + tid];
+      }
     }
   };
 
@@ -283,8 +296,15 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
         if (gm < M && gn < N) Cz[(size_t)gm * ldc + gn] = acc[i][j][r] + bv;
       }
     }
-  if (colsum_ws != nullptr && bid_x == 0 && tid < BM && m0 + tid < M)
-    colsum_ws[(size_t)bid_z * M + m0 + tid] = csum;
+  if (colsum_ws != nullptr && bid_x == 0) {
+    if (BM == 64) {                      // the four row-quarter partials of a column, added in quarter order
+      __syncthreads();
+      As[tid] = csum;
+      __syncthreads();
+      if (tid < 64) csum = ((As[tid] + As[64 + tid]) + As[128 + tid]) + As[192 + tid];
+    }
+    if (tid < BM && m0 + tid < M) colsum_ws[(size_t)bid_z * M + m0 + tid] = csum;
+  }
 }
 
 template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>

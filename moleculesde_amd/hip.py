@@ -1123,6 +1123,13 @@ class _SlabBatch:
         self._select_slot(dev)
         host_prob, host_ppre, dev_prob, dev_ppre = self.slot[4:]
         lib = _lib.load()
+        if WGRAD_LPT:
+            # longest workgroups first (rows per split = K tiles per workgroup): the launch ends with short workgroups
+            # instead of draining a few 100-us ones at partial occupancy
+            def rows_per_split(t):
+                sp = _SPLITS.get((t[2], t[3], t[4])) or int(lib.msde_linear_bwd_w_splits(t[2], t[3], t[4]))
+                return t[2] / max(sp, 1)
+            self.gemms.sort(key=rows_per_split, reverse=True)
         r0, q0, ng = self.prob_used, self.pre_used, len(self.gemms)
         assert r0 + ng <= self.MAX_ROWS
         hp2 = host_ppre.numpy()
@@ -1226,6 +1233,7 @@ class _SlabBatch:
 
 
 DEFER_LEAF_KERNELS = _os.environ.get("MSDE_DEFER_LEAF", "1") != "0"   # GIN bond-table gradients off the backward chain
+WGRAD_LPT = _os.environ.get("MSDE_WGRAD_LPT", "1") != "0"            # grouped launch: problems with the longest workgroups first
 GROUPED_WGRAD = _os.environ.get("MSDE_GROUPED_WGRAD", "1") != "0"   # queued GEMMs -> one grouped launch at finish()
 _SLABS = _SlabBatch()
 _SPLITS = {}
