@@ -8,7 +8,7 @@ from moleculesde_amd import pretrain, hip
 from moleculesde_amd.geom3d import prepare_batch
 from moleculesde_amd.synthetic import make_batch
 dev = torch.device("cuda", 0)
-tr = pretrain.Trainer(pretrain.readme_args(SDE_coeff_generative_3Dto2D=0), dev)
+tr = pretrain.Trainer(pretrain.readme_args(**({} if "--full" in sys.argv else {"SDE_coeff_generative_3Dto2D": 0})), dev)
 b = prepare_batch(make_batch(256, seed=0), dev)
 tr.step(b)
 orig = hip._SLABS.launch_gemms
@@ -21,7 +21,7 @@ def spy(max_wgs=0):
     import collections
     c = collections.Counter(rows)
     print("queued GEMMs", len(rows), "GFLOP %.2f" % (tot / 1e9))
-    for k, v in sorted(c.items(), key=lambda kv: -2.0 * kv[0][0] * kv[0][1] * kv[0][2] * kv[1])[:25]:
+    for k, v in sorted(c.items(), key=lambda kv: -2.0 * kv[0][0] * kv[0][1] * kv[0][2] * kv[1])[:60]:
         print("  M=%6d N=%4d K=%4d x%d  %.2f GFLOP" % (k[0], k[1], k[2], v, 2e-9 * k[0] * k[1] * k[2] * v))
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
