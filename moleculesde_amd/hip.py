@@ -1193,7 +1193,7 @@ class _SlabBatch:
         """One msde_reduce_slabs_multi launch on the current stream for `rows` (the next rows of the slot's tables)."""
         host_rows, host_pre, dev_rows, dev_pre = self.slot[:4]
         r0, q0, k = self.rows_used, self.rpre_used, len(rows)
-        assert r0 + k <= self.MAX_ROWS
+        assert r0 + k <= self.MAX_ROWS and q0 + k + 1 <= host_pre.numel(), "slab row tables full"
         hr, hp = host_rows.numpy(), host_pre.numpy()
         total = 0
         for r, row in enumerate(rows):
@@ -1220,7 +1220,6 @@ class _SlabBatch:
         self._select_slot(mine[0][4])
         self._reduce(mine)
         self.rows = [r for r in self.rows if not (r[5] is not None and r[5] == me)]
-        self.early = True
         return len(mine)
 
     def _select_slot(self, dev):
