@@ -410,7 +410,9 @@ int msde_dense_node_gcn_bwd(const float* gXS, int ldg, const float* XS, int ldxs
                             float* GP, float* MM, void* stream);
 /* Last Linear(F2, 1) of the pair MLP + diagonal / flag masks + score = -net / std + both losses (:86-94,157-179).
  * out[0] = loss_x, out[1] = loss_adj; scale_* = 1/(B Nmax ncls), 1/(B Nmax^2) (reduce_mean) or 0.5/B;
- * residuals res_adj [P], res_x [N, MSDE_DENSE_XP_LD] are kept for the backward; part = [B][2] workspace. */
+ * residuals res_adj [P], res_x [N, MSDE_DENSE_XP_LD] are kept for the backward; part = [B * MSDE_DENSE_LOSS_SPLITS][2]
+ * workspace (a molecule's pairs / class rows are shared by MSDE_DENSE_LOSS_SPLITS workgroups).  F2 <= 64. */
+#define MSDE_DENSE_LOSS_SPLITS 4
 int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, const float* b2, const float* OUT,
                         const float* z_adj, const float* z_x, const float* flags, const float* mean_std,
                         const int* mol_ptr, const int* pair_ptr, int B, int ncls, float anneal_power,

@@ -791,6 +791,8 @@ extern "C" int msde_dense_node_gcn_bwd(const float* gXS, int ldg, const float* X
 }
 
 // ================================================================================================ losses
+#define DH_LOSS_PAIRS 64
+#define DH_LOSS_F2 64            // widest last hidden layer of the pair MLP the loss kernels stage in LDS (60 on this path)
 // Per molecule: s_p = G2[p] . w + bias (last Linear(60,1) of the pair MLP), score_adj = -s * [i != j] f_i f_j / std,
 // residual r = score + z; loss_adj_b = sum r^2;  likewise score_x = -OUT * f_i / std over the `ncls` classes.
 // out[0] = scale_x * sum_b w_b sum r_x^2, out[1] = scale_adj * sum_b w_b sum r_adj^2 with w_b = std^anneal_power
@@ -802,30 +804,43 @@ dense_loss_fwd_kernel(const float* __restrict__ G2, int F2, const float* __restr
                       const int* __restrict__ pair_ptr, int ncls, float anneal, float* __restrict__ res_adj,
                       float* __restrict__ res_x, float* __restrict__ part /* [B][2] */) {
   __shared__ float red[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ float prod[DH_LOSS_PAIRS * (DH_LOSS_F2 + 1)];
+  // MSDE_DENSE_LOSS_SPLITS workgroups per molecule (blockIdx.y): a molecule alone is 4 waves of latency-bound work
+  const int b = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y, tid = threadIdx.x;
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
   const float sd = mean_std[2 * b + 1], inv = 1.f / sd;
   const float wb = anneal != 0.f ? powf(sd, anneal) : 1.f;
   float sx = 0.f, sa = 0.f;
-  // one wave per pair: the 60 hidden values of a pair are read by consecutive lanes (a thread-per-pair loop reads rows
-  // 240 B apart: 64 cache lines per load instruction)
+  // 64 pairs at a time: the workgroup streams their 64 x F2 hidden values (one contiguous, coalesced block, every load
+  // independent) into LDS as products with w, then thread p adds up row p in k order.  (A wave per pair -- one load, a
+  // shuffle tree and a dependent flag / noise read per pair, ~50 pairs in a row per wave -- was a chain of ~100 memory
+  // round trips: 141 us for a kernel that moves 3 MB.)
   {
-    const int lane = tid & 63, w = tid >> 6;
-    for (int p = w; p < n * n; p += 4) {
-      const int i = p / n, j = p - i * n;
-      float v = 0.f;
-      for (int k = lane; k < F2; k += 64) v = fmaf(G2[(size_t)(q0 + p) * F2 + k], w2[k], v);
-      v = group_sum(v, 64);
-      if (lane == 0) {
-        const float s = v + b2[0];
+    const int ld = F2 | 1;                                  // odd row stride: the row sums are conflict-free
+    for (int c0 = sp * DH_LOSS_PAIRS; c0 < n * n; c0 += nsp * DH_LOSS_PAIRS) {
+      const int np = min(DH_LOSS_PAIRS, n * n - c0), tot = np * F2;
+      const float* __restrict__ g2 = G2 + (size_t)(q0 + c0) * F2;
+#pragma unroll 4
+      for (int e = tid; e < tot; e += 256) {
+        const int p = e / F2, k = e - p * F2;
+        prod[p * ld + k] = g2[e] * w2[k];
+      }
+      __syncthreads();
+      if (tid < np) {
+        float v = 0.f;
+        for (int k = 0; k < F2; ++k) v += prod[tid * ld + k];
+        const int p = c0 + tid, i = p / n, j = p - i * n;
+        const float sc = v + b2[0];
         const float m = (i != j) ? flags[a0 + i] * flags[a0 + j] : 0.f;
-        const float r = -s * m * inv + z_adj[q0 + p];
+        const float r = -sc * m * inv + z_adj[q0 + p];
         res_adj[q0 + p] = r;
         sa = fmaf(r, r, sa);
       }
+      __syncthreads();
     }
   }
-  for (int e = tid; e < n * ncls; e += 256) {
+#pragma unroll 4
+  for (int e = sp * 256 + tid; e < n * ncls; e += nsp * 256) {
     const int i = e / ncls, c = e - i * ncls;
     const size_t o = (size_t)(a0 + i) * DH_XP + c;
     const float r = -OUT[o] * flags[a0 + i] * inv + z_x[o];
@@ -836,16 +851,16 @@ dense_loss_fwd_kernel(const float* __restrict__ G2, int F2, const float* __restr
   red[tid] = sx;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-  if (tid == 0) part[2 * b] = red[0] * wb;
+  if (tid == 0) part[2 * (b * nsp + sp)] = red[0] * wb;
   __syncthreads();
   red[tid] = sa;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-  if (tid == 0) part[2 * b + 1] = red[0] * wb;
+  if (tid == 0) part[2 * (b * nsp + sp) + 1] = red[0] * wb;
 }
 
 __global__ void __launch_bounds__(256)
-dense_loss_final_kernel(const float* __restrict__ part, int B, float scale_x, float scale_adj,
+dense_loss_final_kernel(const float* __restrict__ part, int B, int nparts, float scale_x, float scale_adj,
                         const int* __restrict__ nmax_dev, int ncls, float* __restrict__ out) {
   __shared__ float red[2][256];
   if (nmax_dev) {        // reduce_mean with a device-side N_max (one captured graph for every batch): :176-177
@@ -854,7 +869,7 @@ dense_loss_final_kernel(const float* __restrict__ part, int B, float scale_x, fl
     scale_adj = 1.f / ((float)B * nm * nm);
   }
   float sx = 0.f, sa = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) { sx += part[2 * b]; sa += part[2 * b + 1]; }
+  for (int b = threadIdx.x; b < nparts; b += 256) { sx += part[2 * b]; sa += part[2 * b + 1]; }
   red[0][threadIdx.x] = sx; red[1][threadIdx.x] = sa;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -874,7 +889,7 @@ dense_loss_bwd_kernel(const float* __restrict__ g_lx, const float* __restrict__ 
                       const int* __restrict__ pair_ptr, int ncls, float anneal, float scale_x, float scale_adj,
                       const int* __restrict__ nmax_dev, int B, float* __restrict__ gS, float* __restrict__ gZ2,
                       float* __restrict__ gOUT) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y, tid = threadIdx.x;
   if (nmax_dev) {
     const float nm = (float)nmax_dev[0];
     scale_x = 1.f / ((float)B * nm * (float)ncls);
@@ -884,16 +899,33 @@ dense_loss_bwd_kernel(const float* __restrict__ g_lx, const float* __restrict__ 
   const float sd = mean_std[2 * b + 1], inv = 1.f / sd;
   const float wb = anneal != 0.f ? powf(sd, anneal) : 1.f;
   const float cx = (g_lx ? g_lx[0] : 0.f) * scale_x * wb * 2.f, ca = (g_la ? g_la[0] : 0.f) * scale_adj * wb * 2.f;
-  for (int e = tid; e < n * n * F2; e += 256) {          // flat over (pair, hidden unit): coalesced
-    const int p = e / F2, k = e - p * F2;
+  // per-pair factors first (thread per pair, into LDS), then ONE streaming pass over the (pair, hidden unit) block whose
+  // only global traffic is the coalesced Z2 read and gZ2 write (the flat loop used to re-derive the pair factor -- two
+  // flag reads and a residual read behind two integer divisions -- for every one of its 60 hidden units)
+  __shared__ float gs_l[DH_NMAX * DH_NMAX];
+  __shared__ float w_l[DH_LOSS_F2];
+  for (int p = tid; p < n * n; p += 256) {
     const int i = p / n, j = p - i * n;
     const float m = (i != j) ? flags[a0 + i] * flags[a0 + j] : 0.f;
     const float gs = ca * res_adj[q0 + p] * (-m * inv);
-    if (k == 0) gS[q0 + p] = gs;
-    const float zz = Z2[(size_t)(q0 + p) * F2 + k], sg = 1.f / (1.f + __expf(-zz));
-    gZ2[(size_t)(q0 + p) * F2 + k] = gs * w2[k] * sg * (1.f + zz * (1.f - sg));
+    gs_l[p] = gs;
+    if (sp == 0) gS[q0 + p] = gs;
   }
-  for (int e = tid; e < n * DH_XP; e += 256) {
+  if (tid < F2) w_l[tid] = w2[tid];
+  __syncthreads();
+  {
+    const float* __restrict__ z2 = Z2 + (size_t)q0 * F2;
+    float* __restrict__ gz = gZ2 + (size_t)q0 * F2;
+    const int tot = n * n * F2;
+#pragma unroll 4
+    for (int e = sp * 256 + tid; e < tot; e += nsp * 256) {
+      const int p = e / F2, k = e - p * F2;
+      const float zz = z2[e], sg = 1.f / (1.f + __expf(-zz));
+      gz[e] = gs_l[p] * w_l[k] * sg * (1.f + zz * (1.f - sg));
+    }
+  }
+#pragma unroll 4
+  for (int e = sp * 256 + tid; e < n * DH_XP; e += nsp * 256) {
     const int i = e / DH_XP, c = e - i * DH_XP;
     const size_t o = (size_t)(a0 + i) * DH_XP + c;
     gOUT[o] = c < ncls ? cx * res_x[o] * (-flags[a0 + i] * inv) : 0.f;
@@ -908,11 +940,13 @@ extern "C" int msde_dense_loss_fwd(const float* G2, int F2, const float* w2, con
   if (B <= 0 || !G2 || !w2 || !b2 || !OUT || !z_adj || !z_x || !flags || !mean_std || !mol_ptr || !pair_ptr || !res_adj ||
       !res_x || !part || !out || F2 <= 0 || ncls <= 0 || ncls > DH_XP)
     return MSDE_EINVAL;
+  if (F2 > DH_LOSS_F2) return MSDE_EUNSUP;
   hipStream_t st = as_stream(stream);
-  MSDE_LAUNCH(dense_loss_fwd_kernel, dim3(B), dim3(256), 0, st, G2, F2, w2, b2, OUT, z_adj, z_x, flags, mean_std, mol_ptr,
-              pair_ptr, ncls, anneal_power, res_adj, res_x, part);
+  MSDE_LAUNCH(dense_loss_fwd_kernel, dim3(B, MSDE_DENSE_LOSS_SPLITS), dim3(256), 0, st, G2, F2, w2, b2, OUT, z_adj, z_x, flags,
+              mean_std, mol_ptr, pair_ptr, ncls, anneal_power, res_adj, res_x, part);
   MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(dense_loss_final_kernel, dim3(1), dim3(256), 0, st, part, B, scale_x, scale_adj, nmax_dev, ncls, out);
+  MSDE_LAUNCH(dense_loss_final_kernel, dim3(1), dim3(256), 0, st, part, B, B * MSDE_DENSE_LOSS_SPLITS, scale_x, scale_adj,
+              nmax_dev, ncls, out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -926,7 +960,8 @@ extern "C" int msde_dense_loss_bwd(const float* g_lx, const float* g_la, const f
   if (B <= 0 || !res_adj || !res_x || !Z2 || !w2 || !flags || !mean_std || !mol_ptr || !pair_ptr || !gS || !gZ2 ||
       !gOUT || F2 <= 0 || ncls <= 0 || ncls > DH_XP)
     return MSDE_EINVAL;
-  MSDE_LAUNCH(dense_loss_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), g_lx, g_la, res_adj, res_x, Z2, F2, w2, flags,
+  if (F2 > DH_LOSS_F2) return MSDE_EUNSUP;
+  MSDE_LAUNCH(dense_loss_bwd_kernel, dim3(B, MSDE_DENSE_LOSS_SPLITS), dim3(256), 0, as_stream(stream), g_lx, g_la, res_adj, res_x, Z2, F2, w2, flags,
               mean_std, mol_ptr, pair_ptr, ncls, anneal_power, scale_x, scale_adj, nmax_dev, B, gS, gZ2, gOUT);
   MSDE_CHECK_LAUNCH();
   return 0;

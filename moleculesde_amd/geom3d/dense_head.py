@@ -296,7 +296,7 @@ class _DenseHeadLosses(torch.autograd.Function):
         sn = node_forward(cfg, XC, F, AC, TN)
         f2W, f2b = TE[-2], TE[-1]
         res_adj, res_x = _empty(P, device=dev), _empty(N, XP_LD, device=dev)
-        part, out = _empty(B, 2, device=dev), _empty(2, device=dev)
+        part, out = _empty(B * 4, 2, device=dev), _empty(2, device=dev)      # MSDE_DENSE_LOSS_SPLITS partials per molecule
         _lib.call("msde_dense_loss_fwd", _p(se.G2), se.G2.size(1), _p(f2W), _p(f2b), _p(sn.OUT), _p(z_adj), _p(z_x), _p(flags),
                   _p(mean_std), _p(cfg.mol_ptr), _p(cfg.pair_ptr), B, cfg.ncls, cfg.anneal, cfg.scale_x, cfg.scale_adj,
                   _p(getattr(cfg, "nmax_dev", None)), _p(res_adj), _p(res_x), _p(part), _p(out), hip._stream())
