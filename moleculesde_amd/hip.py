@@ -1447,10 +1447,13 @@ class _ContrastiveEBM(torch.autograd.Function):
         ctx.invT = 1.0 / float(T)
         loss, acc = out[0], out[1]         # two outputs (a select on ONE output costs a zeros + copy in its backward)
         ctx.mark_non_differentiable(acc)
+        ctx.set_materialize_grads(False)   # no zero-filled gradient (one fill launch) for the accuracy output
         return loss, acc
 
     @staticmethod
     def backward(ctx, g_loss, g_acc):
+        if g_loss is None:
+            return None, None, None, None, None
         X, Y, p1, p2, inv1, inv2, rows = ctx.saved_tensors
         N, D = X.shape
         gX, gY = torch.empty_like(X), torch.empty_like(Y)
