@@ -277,6 +277,10 @@ int msde_edge_attention_bwd(const float* g_out, const float* q, const float* k, 
  * out[i] = mean_{e in in(i)} (c0*b_diff + c1*b_cross + c2*b_vert) */
 int msde_frame_mix_mean_fwd(const float* coff, const float* basis, const int* rowptr, int N,
                             float* out, void* stream);
+/* the same with the running sum over score layers folded in (equivariant_scorenetwork.py:166 `gradient += ...`):
+ * out[i] = base[i] + mean(...); base == NULL: plain form */
+int msde_frame_mix_mean_add_fwd(const float* coff, const float* basis, const int* rowptr, int N,
+                                const float* base, float* out, void* stream);
 int msde_frame_mix_mean_bwd(const float* g_out, const float* basis, const int* rowptr, int N,
                             int E_cap, float* g_coff, void* stream);
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "msde_edge_attention_fwd": [P, P, P, P, I, P, I, P, P, I, I, I, F, ULL, P, P, P, P],
     "msde_edge_attention_bwd": [P, P, P, P, I, P, I, P, I, P, P, P, I, I, I, F, ULL, P, P, P, P, P, I, P],
     "msde_frame_mix_mean_fwd": [P, P, P, I, P, P],
+    "msde_frame_mix_mean_add_fwd": [P, P, P, I, P, P, P],
     "msde_frame_mix_mean_bwd": [P, P, P, I, I, P, P],
     "msde_linear_fwd": [P, P, P, I, I, I, P, P],
     "msde_linear_bwd_x": [P, P, I, I, I, P, P],

@@ -461,7 +461,8 @@ extern "C" int msde_edge_attention_bwd(const float* g_out, const float* q, const
 // after the other was 44 workgroups of serial index -> row chains); partial sums meet in three xor shuffles.
 #define FM_LPN 8
 __global__ void frame_mix_mean_fwd_kernel(const float* __restrict__ coff, const float* __restrict__ basis,
-                                          const int* __restrict__ rowptr, int N, float* __restrict__ out) {
+                                          const int* __restrict__ rowptr, int N, const float* __restrict__ base,
+                                          float* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = t / FM_LPN, l = t % FM_LPN;
   float ax = 0.f, ay = 0.f, az = 0.f;
@@ -482,7 +483,9 @@ __global__ void frame_mix_mean_fwd_kernel(const float* __restrict__ coff, const 
   for (int o = 1; o < FM_LPN; o <<= 1) { ax += __shfl_xor(ax, o); ay += __shfl_xor(ay, o); az += __shfl_xor(az, o); }
   if (i < N && l == 0) {
     const float inv = 1.f / (float)max(s1 - s0, 1);
-    out[3 * i] = ax * inv; out[3 * i + 1] = ay * inv; out[3 * i + 2] = az * inv;
+    // base: the running sum of the earlier score layers (equivariant_scorenetwork.py:166 `gradient += ...`)
+    const float bx = base ? base[3 * i] : 0.f, by = base ? base[3 * i + 1] : 0.f, bz = base ? base[3 * i + 2] : 0.f;
+    out[3 * i] = bx + ax * inv; out[3 * i + 1] = by + ay * inv; out[3 * i + 2] = bz + az * inv;
   }
 }
 
@@ -509,14 +512,19 @@ __global__ void frame_mix_mean_bwd_kernel(const float* __restrict__ g_out, const
   }
 }
 
-extern "C" int msde_frame_mix_mean_fwd(const float* coff, const float* basis, const int* rowptr, int N, float* out,
-                                       void* stream) {
+extern "C" int msde_frame_mix_mean_add_fwd(const float* coff, const float* basis, const int* rowptr, int N,
+                                           const float* base, float* out, void* stream) {
   if (N < 0 || !coff || !basis || !rowptr || !out) return MSDE_EINVAL;
   if (N == 0) return 0;
   MSDE_LAUNCH(frame_mix_mean_fwd_kernel, dim3((N * FM_LPN + 255) / 256), dim3(256), 0, as_stream(stream), coff,
-                     basis, rowptr, N, out);
+                     basis, rowptr, N, base, out);
   MSDE_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int msde_frame_mix_mean_fwd(const float* coff, const float* basis, const int* rowptr, int N,
+                                       float* out, void* stream) {
+  return msde_frame_mix_mean_add_fwd(coff, basis, rowptr, N, nullptr, out, stream);
 }
 
 extern "C" int msde_frame_mix_mean_bwd(const float* g_out, const float* basis, const int* rowptr, int N, int E_cap,

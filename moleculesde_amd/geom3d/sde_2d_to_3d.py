@@ -153,8 +153,7 @@ class EquivariantScoreNetwork(nn.Module):
                 pair = hip.pair_gather_add(node_feature, node_feature, plan)        # h_row + h_col
                 edge_feature = torch.cat([pair, edge_attr], dim=-1)
                 coff = mlp(edge_feature)                                           # [E, 3]
-            g = hip.frame_mix_mean(coff, basis, plan)
-            gradient = g if gradient is None else gradient + g
+            gradient = hip.frame_mix_mean(coff, basis, plan, gradient)      # `gradient += ...` folded into the kernel
         return {"node_feature": node_feature, "gradient": gradient}
 
 

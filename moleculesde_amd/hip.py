@@ -844,10 +844,11 @@ def edge_attention(q, k, v, ee, plan, heads, p_drop=0.0, seed=0, seed_dev=None):
 
 class _FrameMixMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, coff, basis, plan):
+    def forward(ctx, coff, basis, plan, base=None):
         coff = _f32(coff)
+        base = _f32(base) if base is not None else None
         out = torch.empty(plan.N, 3, dtype=torch.float32, device=coff.device)
-        _lib.call("msde_frame_mix_mean_fwd", _p(coff), _p(basis), _p(plan.rowptr), plan.N, _p(out), _stream())
+        _lib.call("msde_frame_mix_mean_add_fwd", _p(coff), _p(basis), _p(plan.rowptr), plan.N, _p(base), _p(out), _stream())
         ctx.save_for_backward(basis)
         ctx.plan = plan
         return out
@@ -859,12 +860,13 @@ class _FrameMixMean(torch.autograd.Function):
         g = _f32(g)
         g_coff = torch.empty(plan.E, 3, dtype=torch.float32, device=g.device)
         _lib.call("msde_frame_mix_mean_bwd", _p(g), _p(basis), _p(plan.rowptr), plan.N, plan.E, _p(g_coff), _stream())
-        return g_coff, None, None
+        return g_coff, None, None, (g if ctx.needs_input_grad[3] else None)
 
 
-def frame_mix_mean(coff, basis, plan):
-    """mean_{e -> i} (c0 b_diff + c1 b_cross + c2 b_vert)  (equivariant_scorenetwork.py:159-164)."""
-    return _FrameMixMean.apply(coff, basis, plan)
+def frame_mix_mean(coff, basis, plan, base=None):
+    """base + mean_{e -> i} (c0 b_diff + c1 b_cross + c2 b_vert)  (equivariant_scorenetwork.py:159-166; base: the sum
+    over the earlier score layers, added by the kernel instead of a separate operator)."""
+    return _FrameMixMean.apply(coff, basis, plan, base)
 
 
 class _SegmentMean(torch.autograd.Function):
