@@ -72,17 +72,38 @@ adam_chunks_kernel(float* __restrict__ p, const long long* __restrict__ table, f
   int s = 0;
   while (s < S - 1 && off >= seg_end[s]) ++s;       // a chunk lies inside one tensor, hence inside one group
   const float lr = seg_lr[s];
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    gi *= grad_scale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    mi = beta1 * mi + (1.f - beta1) * gi;
+    vi = beta2 * vi + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi = pi - (lr / bc1) * (mi / denom);
+  };
+  // 16-byte path: chunk start, length and gradient address all float4-aligned (every chunk of a tensor whose element
+  // count and flat offset are multiples of 4 -- all but a few bias / scalar tails); same arithmetic per element
+  const bool vec = ((off | (long long)cnt) & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  if (vec) {
+    float4* p4 = reinterpret_cast<float4*>(p + off);
+    float4* m4 = reinterpret_cast<float4*>(m + off);
+    float4* v4 = reinterpret_cast<float4*>(v + off);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int i = threadIdx.x; i < cnt / 4; i += 256) {
+      float4 pi = p4[i], mi = m4[i], vi = v4[i];
+      const float4 gi = g ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      upd(pi.x, gi.x, mi.x, vi.x); upd(pi.y, gi.y, mi.y, vi.y); upd(pi.z, gi.z, mi.z, vi.z); upd(pi.w, gi.w, mi.w, vi.w);
+      m4[i] = mi; v4[i] = vi; p4[i] = pi;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < cnt; i += 256) {
     const long long k = off + i;
-    float pi = p[k];
-    float gi = (g ? g[i] : 0.f) * grad_scale;
-    if (wd != 0.f) gi = fmaf(wd, pi, gi);
-    float mi = beta1 * m[k] + (1.f - beta1) * gi;
-    float vi = beta2 * v[k] + (1.f - beta2) * gi * gi;
+    float pi = p[k], mi = m[k], vi = v[k];
+    upd(pi, g ? g[i] : 0.f, mi, vi);
     m[k] = mi;
     v[k] = vi;
-    float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[k] = pi - (lr / bc1) * (mi / denom);
+    p[k] = pi;
   }
 }
 
