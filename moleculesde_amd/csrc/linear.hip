@@ -18,6 +18,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LG_BK 32
+#ifndef LG_PRIO
+#define LG_PRIO 2
+#endif
 #ifndef LG_ST
 #define LG_ST 1
 #endif
@@ -204,9 +207,11 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
         bf[kk] = Bs[(2 * kk + lhalf) * LDB_S + wn * 32 + lcol];
       }
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(LG_PRIO);          // the wave in its MFMA phase wins issue slots from waves staging tiles
 #pragma unroll
       for (int kk = 0; kk < LG_BK / 2; ++kk)
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll
     for (int kk = 0; kk < LG_BK / 2; ++kk) {
