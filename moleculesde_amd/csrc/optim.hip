@@ -4,6 +4,21 @@
 //   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 #include "msde_common.h"
 
+// ONE update routine for the flat and the chunk-table kernels (scalar and 16-byte paths): the data-parallel step runs
+// the flat kernel on the all-reduced buffer, the single-GPU step the chunk kernel on the gradients in place, and the two
+// must produce bit-identical parameters from identical gradients (tests/test_gpu_dp.py) -- so no expression here is
+// left to the compiler's context-dependent fma contraction.
+__device__ __forceinline__ void adam_update(float& pi, float gi, float& mi, float& vi, float beta1, float beta2, float eps,
+                                            float wd, float grad_scale, float inv_sqrt_bc2, float step) {
+#pragma clang fp contract(off)
+  gi = gi * grad_scale;
+  if (wd != 0.f) gi = fmaf(wd, pi, gi);
+  mi = beta1 * mi + (1.f - beta1) * gi;
+  vi = beta2 * vi + ((1.f - beta2) * gi) * gi;
+  const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+  pi = pi - step * (mi / denom);
+}
+
 __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, long long n, const int* __restrict__ step_dev,
                                  const long long* __restrict__ seg_end, const float* __restrict__ seg_lr, int S,
@@ -16,15 +31,11 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
     int s = 0;
     while (s < S - 1 && i >= seg_end[s]) ++s;
     float lr = seg_lr[s];
-    float pi = p[i];
-    float gi = g[i] * grad_scale;
-    if (wd != 0.f) gi = fmaf(wd, pi, gi);
-    float mi = beta1 * m[i] + (1.f - beta1) * gi;
-    float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_update(pi, g[i], mi, vi, beta1, beta2, eps, wd, grad_scale, inv_sqrt_bc2, lr / bc1);
     m[i] = mi;
     v[i] = vi;
-    float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[i] = pi - (lr / bc1) * (mi / denom);
+    p[i] = pi;
   }
 }
 
@@ -72,13 +83,9 @@ adam_chunks_kernel(float* __restrict__ p, const long long* __restrict__ table, f
   int s = 0;
   while (s < S - 1 && off >= seg_end[s]) ++s;       // a chunk lies inside one tensor, hence inside one group
   const float lr = seg_lr[s];
+  const float step = lr / bc1;
   auto upd = [&](float& pi, float gi, float& mi, float& vi) {
-    gi *= grad_scale;
-    if (wd != 0.f) gi = fmaf(wd, pi, gi);
-    mi = beta1 * mi + (1.f - beta1) * gi;
-    vi = beta2 * vi + (1.f - beta2) * gi * gi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    pi = pi - (lr / bc1) * (mi / denom);
+    adam_update(pi, gi, mi, vi, beta1, beta2, eps, wd, grad_scale, inv_sqrt_bc2, step);
   };
   // 16-byte path: chunk start, length and gradient address all float4-aligned (every chunk of a tensor whose element
   // count and flat offset are multiples of 4 -- all but a few bias / scalar tails); same arithmetic per element
