@@ -18,6 +18,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LG_BK 32
+#ifndef LG_SKIP_DEAD
+#define LG_SKIP_DEAD 1
+#endif
 #ifndef LG_PRIO
 #define LG_PRIO 2
 #endif
@@ -195,8 +198,12 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
 
   float csum = 0.f;  // column sum of A over k (weight-gradient mode: bias gradient), thread tid < BM
 
+  const bool quadrant_live = !LG_SKIP_DEAD || ((m0 + wm * 32 * TM < M) && (n0 + wn * 32 * TN < N));
   auto compute_tile = [&]() {
     if (TM == 1 && TN == 1) {
+      // a wave whose 32 x 32 quadrant lies entirely outside the product (narrow layers: N or K <= 32 fill one or two
+      // quadrants of the 64 x 64 tile) only helps with the staging: its SIMD is free for other workgroups' MFMAs
+      if (quadrant_live) {
       // all operand reads of the K tile are requested first, then the 16 MFMAs retire them in order behind counted
       // waits.  Left to itself the compiler emits {2 reads, wait for both, 2 MFMAs} x 8: one LDS round trip exposed
       // per 128 cycles of MFMA work (the scheduling barrier keeps it from sinking the reads back to their uses).
@@ -212,6 +219,7 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
       for (int kk = 0; kk < LG_BK / 2; ++kk)
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], acc[0][0], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
+      }
     } else {
 #pragma unroll
     for (int kk = 0; kk < LG_BK / 2; ++kk) {

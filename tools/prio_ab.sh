@@ -7,7 +7,7 @@ cp moleculesde_amd/csrc/libmsde_hip.so /tmp/lib_orig.so
 for i in $(seq 1 ${3:-3}); do
   for v in A B; do
     cp /tmp/lib_$v.so moleculesde_amd/csrc/libmsde_hip.so
-    ms=$(python bench.py --no_cpu_baseline --steps 60 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)
+    ms=$(python bench.py --no_cpu_baseline --steps 60 $BENCH_ARGS 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)
     echo "$v $ms"
   done
 done
