@@ -287,7 +287,11 @@ gemm_ex_kernel(const msde_gemm_desc d) {
       bf = make_float4(bs[kb * GX_LDN + c], bs[(kb + 1) * GX_LDN + c], bs[(kb + 2) * GX_LDN + c], bs[(kb + 3) * GX_LDN + c]);
     }
   };
+  // a wave whose 32-column half of the tile lies outside N (narrow layers) or whose rows lie outside M only helps with
+  // the staging: its SIMD is free for the MFMAs of other workgroups
+  const bool wave_live = (n0 + wn * 32 < d.N) && (m0 + wm * TM * 32 < d.M);
   auto compute_tile = [&](int s) {
+    if (!wave_live) return;
     const float* __restrict__ as = As[s];
     const float* __restrict__ bs = Bs[s];
     float4 af[2][TM], bf[2];
