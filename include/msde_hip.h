@@ -320,6 +320,7 @@ int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, floa
 #define MSDE_ACT_ELU 3
 #define MSDE_ACT_SSP 4  /* shifted softplus, schnet.py:213-216 */
 #define MSDE_ACT_RELU 5
+#define MSDE_ACT_SSPO 6 /* msde_gemm_rs, MSDE_EPI_DACT only: derivative of the shifted softplus from its OUTPUT */
 #define MSDE_EPI_ACT 0
 #define MSDE_EPI_DACT 1
 #define MSDE_GEMM_B_KMAJOR 1
@@ -344,6 +345,85 @@ typedef struct msde_gemm_desc {
   float alpha;           /* scales the result (1.0f for none) */
 } msde_gemm_desc;
 int msde_gemm_ex(const msde_gemm_desc* desc, void* stream);
+
+/* Row-strip fp32 matrix-core GEMM (csrc/gemm_rs.hip): C[M,N] = epilogue( xf(A)[M,K] . B + bias ) for the plain nn.Linear
+ * products of the encoders -- forward and input gradient of Geom3D/models/molecule_gnn_model.py:17 (GIN MLP),
+ * Geom3D/models/schnet.py:141-148,163-167 (lin1 / lin2 / lin), SDE_model_2D_to_3D.py:264-271 (node_emb, edge_2D_emb,
+ * input_mlp, coff_mlp) -- torch.addmm / torch.mm in the reference, with the BatchNorm1d / ReLU around them
+ * (molecule_gnn_model.py:17,176-182; SDE_model_2D_to_3D.py:265) folded into the product:
+ *   B layout     [K][N] with row stride ldb (MSDE_GEMM_B_KMAJOR must be set in flags): an input-gradient product takes
+ *                nn.Linear's weight [out][in] as stored, a forward product its transposed copy (the [N][K] layout with
+ *                per-lane pieces along k is bound by the address path on gfx950; MSDE_EUNSUP);
+ *   axf          transform applied to A while it is loaded:
+ *                MSDE_RS_AXF_AFFINE  a = A[m,k] * xf0[k] + xf1[k], then max(.,0) with MSDE_RS_AXF_RELU (BatchNorm apply);
+ *                MSDE_RS_AXF_BNBWD   a = xf0[k] g + xf1[k] z + xf2[k] with g = A[m,k] (gated to 0 where z xf3[k] + xf4[k] <= 0
+ *                                    when xf3 != NULL) and z = A2[m,k]: the BatchNorm input gradient, vectors from
+ *                                    msde_bn_fin_bwd;
+ *                A_out (optional) receives the transformed A (row stride lda_out): the weight gradient's operand;
+ *   epilogue     v = acc + bias; Z (optional) receives v; epi = MSDE_EPI_ACT: v = act(v); MSDE_EPI_DACT: v = v * act'(R[m,n])
+ *                (R as in msde_gemm_desc); then v += Res[m,n] (optional), v += C[m,n] with MSDE_GEMM_ACCUMULATE; C = v;
+ *   stats        optional [strips][2][N] per-strip column statistics of the stored C over the VALID rows (*m_valid, or M):
+ *                MSDE_RS_STATS_BNFWD  (mean, sum of squared deviations from it) -> msde_bn_fin_fwd;
+ *                MSDE_RS_STATS_BNBWD  (sum v, sum v * (stats_z[m,n] - stats_mean[n]))   -> msde_bn_fin_bwd;
+ *                strips and rows per strip from msde_gemm_rs_geometry(M, N, K).
+ * K % 4 == 0, 16-byte aligned A / A2 / A_out / xf vectors with leading dimensions % 4 == 0, and for N > 64 also N % 4 == 0
+ * with 16-byte aligned weight rows; otherwise MSDE_EUNSUP (callers use msde_gemm_ex).  rt: 0 = chosen by the library. */
+#define MSDE_RS_AXF_NONE 0
+#define MSDE_RS_AXF_AFFINE 1
+#define MSDE_RS_AXF_BNBWD 2
+#define MSDE_RS_AXF_RELU 4 /* flags bit */
+#define MSDE_RS_VEC_STORE 8 /* flags bit, set by the library: C (and Res) rows take 8- / 16-byte stores */
+#define MSDE_RS_STATS_BNFWD 1
+#define MSDE_RS_STATS_BNBWD 2
+typedef struct msde_rs_desc {
+  const float* A;
+  const float* A2;
+  const float* B;
+  const float* bias;
+  float* C;
+  float* Z;
+  const float* R;
+  const float* Res;
+  float* A_out;
+  const float *xf0, *xf1, *xf2, *xf3, *xf4;
+  float* stats;
+  const float* stats_z;
+  const float* stats_mean;
+  const int* m_valid;
+  int M, N, K;
+  int lda, lda2, ldb, ldc, ldz, ldr, ldres, lda_out, ld_sz;
+  int act, epi, flags, axf, stats_mode;
+  int rt, splits;
+} msde_rs_desc;
+int msde_gemm_rs(const msde_rs_desc* desc, void* stream);
+int msde_gemm_rs_geometry(int M, int N, int K, int* strips, int* strip_rows);
+/* Finish the fused BatchNorm statistics (one small launch): forward -> scale = gamma rstd, shift = beta - mean scale (what
+ * MSDE_RS_AXF_AFFINE of the consuming product applies), save_mean / save_rstd for the backward, running buffers updated
+ * with `momentum` (unbiased variance), exactly as msde_bn_fwd.  Backward -> the three vectors of MSDE_RS_AXF_BNBWD and
+ * dgamma / dbeta (may be NULL).  Partials are merged in a fixed order (bitwise reproducible). */
+int msde_bn_fin_fwd(const float* stats, int strips, int strip_rows, int M, const int* m_valid, int C,
+                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                    void* stream);
+int msde_bn_fin_bwd(const float* stats, int strips, int M, const int* m_valid, int C, const float* gamma,
+                    const float* mean, const float* rstd, float* p, float* w, float* u, float* dgamma,
+                    float* dbeta, void* stream);
+
+/* Y = max(X * scale[c] + shift[c], 0 if relu) over rows (the BatchNorm apply for a tensor with several consumers: the GIN
+ * layer output, molecule_gnn_model.py:176-182); C % 4 == 0. */
+int msde_affine_cols(const float* X, int M, int C, const float* scale, const float* shift, int relu, float* Y,
+                     void* stream);
+/* BatchNorm-backward partial sums for msde_bn_fin_bwd of a gradient G [M,C] that is not the result of msde_gemm_rs:
+ * stats [ceil(M/64)][2][C] = per 64-row strip (sum g', sum g' (Z - mean)), g' = G gated by Y > 0 when Y != NULL (the
+ * fused ReLU; Y = the BatchNorm + ReLU output); rows >= *m_valid contribute nothing.  C % 4 == 0. */
+int msde_bn_bwd_colstats(const float* G, const float* Z, const float* Y, const float* mean, int M, const int* m_valid,
+                         int C, float* stats, void* stream);
+/* dst_i [cols_i][rows_i] = src_i [rows_i][cols_i]^T for n contiguous fp32 matrices in one launch: the transposed weight
+ * copies the forward products of msde_gemm_rs read (refreshed once per optimiser step).  table: n rows of 4 x int64
+ * {src, dst, rows, cols} (device); prefix [n+1]: first 32 x 32 tile of each matrix, prefix[n] = total_tiles. */
+int msde_transpose_multi(const long long* table, const int* prefix, int n, int total_tiles, void* stream);
+/* the same for one matrix, no tables: dst [cols][rows] = src [rows][cols]^T */
+int msde_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 
 /* Narrow output layer of an MLP over rows (basis_mlp, equivariant_scorenetwork.py:142-146: Linear -> SiLU -> Linear(H, 3)):
  * out[e][j] = b[j] + sum_c silu(Z[e][c]) W[j][c] on the PRE-activation Z [E, H] (row stride ldz), J <= 4, H % 4 == 0,

@@ -64,6 +64,14 @@ SIGNATURES = {
     "msde_reduce_slabs_chunks": [LL, I],
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
     "msde_gemm_ex": [P, P],
+    "msde_gemm_rs": [P, P],
+    "msde_transpose_multi": [P, P, I, I, P],
+    "msde_transpose": [P, P, I, I, P],
+    "msde_affine_cols": [P, I, I, P, P, I, P, P],
+    "msde_bn_bwd_colstats": [P, P, P, P, I, P, I, P, P],
+    "msde_gemm_rs_geometry": [I, I, I, P, P],
+    "msde_bn_fin_fwd": [P, I, I, I, P, I, P, P, F, F, P, P, P, P, P, P, P],
+    "msde_bn_fin_bwd": [P, I, I, P, I, P, P, P, P, P, P, P, P, P],
     "msde_dense_prepare": [P, P, P, P, P, P, P, P, I, I, F, I, F, F, P, P, I, ULL, P, I, I, P, P, P, P, P, P, P],
     "msde_dense_edge_layer_fwd": [P, P, P, I, I, I, I, P, P, P, P, I, I, P, P, P, P, P, P, P],
     "msde_dense_edge_layer_bwd": [P, P, P, P, I, I, I, I, P, P, P, P, I, I, P, P, P, P, P, P, P, I, P, P, P, P, P, P, P, P,
@@ -130,12 +138,27 @@ class GemmDesc(ctypes.Structure):
                 ("b_kblk_log2", I), ("alpha", F)]
 
 
+class RsDesc(ctypes.Structure):
+    """msde_rs_desc of include/msde_hip.h (field order and types must match)."""
+    _fields_ = [("A", P), ("A2", P), ("B", P), ("bias", P), ("C", P), ("Z", P), ("R", P), ("Res", P), ("A_out", P),
+                ("xf0", P), ("xf1", P), ("xf2", P), ("xf3", P), ("xf4", P), ("stats", P), ("stats_z", P),
+                ("stats_mean", P), ("m_valid", P),
+                ("M", I), ("N", I), ("K", I),
+                ("lda", I), ("lda2", I), ("ldb", I), ("ldc", I), ("ldz", I), ("ldr", I), ("ldres", I), ("lda_out", I),
+                ("ld_sz", I),
+                ("act", I), ("epi", I), ("flags", I), ("axf", I), ("stats_mode", I), ("rt", I), ("splits", I)]
+
+
+RS_AXF_NONE, RS_AXF_AFFINE, RS_AXF_BNBWD, RS_AXF_RELU, RS_VEC_STORE = 0, 1, 2, 4, 8
+RS_STATS_BNFWD, RS_STATS_BNBWD = 1, 2
+
+
 class EdgeLayerParams(ctypes.Structure):
     """msde_edge_layer_params of include/msde_hip.h."""
     _fields_ = [(n, P) for n in ("bv", "mW0", "mb0", "mW1", "mb1", "mW2", "mb2", "cW0", "cb0", "cW1", "cb1")]
 
 
-ACT = {None: 0, "none": 0, "tanh": 1, "silu": 2, "elu": 3, "ssp": 4, "relu": 5}
+ACT = {None: 0, "none": 0, "tanh": 1, "silu": 2, "elu": 3, "ssp": 4, "relu": 5, "sspo": 6}
 EPI_ACT, EPI_DACT = 0, 1
 GEMM_B_KMAJOR, GEMM_ACCUMULATE = 1, 2
 REDUCE_LONG = 64          # MSDE_REDUCE_LONG of include/msde_hip.h

@@ -1,0 +1,638 @@
+// gemm_rs.hip — row-strip fp32 matrix-core GEMMs (gfx950, v_mfma_f32_16x16x4_f32): the forward and input-gradient
+// products of every plain nn.Linear on the hot path, with the normalisation / activation / residual work around them
+// fused in front of and behind the product.  Reference call sites: Geom3D/models/molecule_gnn_model.py:17,28-29 (GIN MLP
+// + BatchNorm), Geom3D/models/schnet.py:141-148,163-167 (lin1 / lin2 / lin), SDE_model_2D_to_3D.py:264-271 (node_emb,
+// edge_2D_emb, input_mlp, coff_mlp, project) -- all torch.addmm / torch.mm (+ F.batch_norm, F.relu) in the reference.
+//
+// gemm_rsa_kernel: "strip of A in LDS, weights streamed per wave" (see gemm_rs.h for the tiling argument).  The weight
+// operand is read as [K][N]: an input-gradient product takes nn.Linear's weight as stored, a forward product its
+// transposed copy (hip.wt_cache: one batched transpose per optimiser step).
+// Fusions (msde_rs_desc): A transform on load (BatchNorm apply + ReLU; the BatchNorm input-gradient formula), the
+// transformed strip optionally written back once (for the weight gradient), bias / activation / activation derivative /
+// residual / accumulate in the epilogue, and per-strip column statistics of the result (BatchNorm forward: mean and
+// centred second moment; BatchNorm backward: sum g and sum g (z - mean)) finished by msde_bn_fin_fwd / _bwd.
+#include "gemm_rs.h"
+
+// ---- activations (same fast forms as gemm_ex.hip) -----------------------------------------------------------------
+__device__ __forceinline__ float rs_act(int act, float z) {
+  switch (act) {
+    case MSDE_ACT_TANH: return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * z));
+    case MSDE_ACT_SILU: return z * __frcp_rn(1.f + __expf(-z));
+    case MSDE_ACT_ELU: return z > 0.f ? z : __expf(z) - 1.f;
+    case MSDE_ACT_SSP: return (z > 20.f ? z : __logf(1.f + __expf(z))) - 0.6931471805599453f;
+    case MSDE_ACT_RELU: return fmaxf(z, 0.f);
+    default: return z;
+  }
+}
+__device__ __forceinline__ float rs_dact(int act, float r) {
+  switch (act) {
+    case MSDE_ACT_TANH: return 1.f - r * r;
+    case MSDE_ACT_SILU: { const float s = __frcp_rn(1.f + __expf(-r)); return s * (1.f + r * (1.f - s)); }
+    case MSDE_ACT_ELU: return r > 0.f ? 1.f : r + 1.f;
+    case MSDE_ACT_SSP: return __frcp_rn(1.f + __expf(-r));
+    case MSDE_ACT_RELU: return r > 0.f ? 1.f : 0.f;
+    case MSDE_ACT_SSPO: return 1.f - __expf(-(r + 0.6931471805599453f));    // sigmoid(x) from a = softplus(x) - ln 2
+    default: return 1.f;
+  }
+}
+
+// Epilogue of one wave: T tiles x RT row tiles of 16 x 16 accumulators.  C/D map of v_mfma_f32_16x16x4_f32: lane-column
+// i = lane & 15, row = 4 (lane >> 4) + e for element e; the column of lane-column i of tile c is rs_col<T>(wcol, c, i)
+// (interleaved inside a segment, gemm_rs.h).  Uniform switches are hoisted out of the element loops.
+template <int RT, int T>
+__device__ __forceinline__ void rs_epilogue(const msde_rs_desc& d, f32x4 (&acc)[T][RT], int wcol, int m0, int strip,
+                                            int strip_rows) {
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  const int M = d.M, N = d.N;
+  // 1. bias, pre-activation store
+#pragma unroll
+  for (int c = 0; c < T; ++c) {
+    const int col = rs_col<T>(wcol, c, n);
+    const float bv = (d.bias && col < N) ? d.bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[c][r][e] += bv;
+  }
+  if (d.Z) {
+#pragma unroll
+    for (int c = 0; c < T; ++c) {
+      const int col = rs_col<T>(wcol, c, n);
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = m0 + r * 16 + 4 * g + e;
+          if (row < M && col < N) d.Z[(size_t)row * d.ldz + col] = acc[c][r][e];
+        }
+    }
+  }
+  // 2. activation / derivative
+  if (d.act != MSDE_ACT_NONE) {
+    if (d.epi == MSDE_EPI_DACT) {
+#define RS_DACT(ACT_)                                                                                        \
+  case ACT_:                                                                                                 \
+    _Pragma("unroll") for (int c = 0; c < T; ++c) {                                                          \
+      const int col = rs_col<T>(wcol, c, n);                                                                 \
+      _Pragma("unroll") for (int r = 0; r < RT; ++r) _Pragma("unroll") for (int e = 0; e < 4; ++e) {         \
+        const int row = m0 + r * 16 + 4 * g + e;                                                             \
+        const float rv = (row < M && col < N) ? d.R[(size_t)row * d.ldr + col] : 0.f;                        \
+        acc[c][r][e] *= rs_dact(ACT_, rv);                                                                   \
+      }                                                                                                      \
+    }                                                                                                        \
+    break;
+      switch (d.act) {
+        RS_DACT(MSDE_ACT_TANH) RS_DACT(MSDE_ACT_SILU) RS_DACT(MSDE_ACT_ELU) RS_DACT(MSDE_ACT_SSP) RS_DACT(MSDE_ACT_RELU)
+        RS_DACT(MSDE_ACT_SSPO)
+        default: break;
+      }
+#undef RS_DACT
+    } else {
+#define RS_ACT(ACT_)                                                                                         \
+  case ACT_:                                                                                                 \
+    _Pragma("unroll") for (int c = 0; c < T; ++c) _Pragma("unroll") for (int r = 0; r < RT; ++r)             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[c][r][e] = rs_act(ACT_, acc[c][r][e]);             \
+    break;
+      switch (d.act) {
+        RS_ACT(MSDE_ACT_TANH) RS_ACT(MSDE_ACT_SILU) RS_ACT(MSDE_ACT_ELU) RS_ACT(MSDE_ACT_SSP) RS_ACT(MSDE_ACT_RELU)
+        default: break;
+      }
+#undef RS_ACT
+    }
+  }
+  // 3. residual, accumulate, store: a lane's W values of a segment are W consecutive floats of the output row
+  const bool accum = (d.flags & MSDE_GEMM_ACCUMULATE) != 0;
+  const bool vec = (d.flags & MSDE_RS_VEC_STORE) != 0;
+  constexpr int NSEG = RsSeg<T>::NSEG;
+#pragma unroll
+  for (int sg = 0; sg < NSEG; ++sg) {
+    constexpr int W0 = RsSeg<T>::W[0];
+    const int W = sg == 0 ? W0 : RsSeg<T>::W[1];
+    const int f = sg == 0 ? 0 : W0;                               // first tile of the segment
+    const int colb = wcol + (sg == 0 ? 0 : 16 * W0) + W * n;       // first of the lane's W columns
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = m0 + r * 16 + 4 * g + e;
+        if (row >= M) continue;
+        if (W == 4 && vec) {
+          if (colb < N) {
+            float4 v = make_float4(acc[f][r][e], acc[f + 1 < T ? f + 1 : f][r][e], acc[f + 2 < T ? f + 2 : f][r][e],
+                                   acc[f + 3 < T ? f + 3 : f][r][e]);
+            if (d.Res) {
+              const float4 q = *reinterpret_cast<const float4*>(d.Res + (size_t)row * d.ldres + colb);
+              v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            float4* dst = reinterpret_cast<float4*>(d.C + (size_t)row * d.ldc + colb);
+            if (accum) { const float4 q = *dst; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+            *dst = v;
+            acc[f][r][e] = v.x;
+            if (f + 1 < T) acc[f + 1][r][e] = v.y;
+            if (f + 2 < T) acc[f + 2][r][e] = v.z;
+            if (f + 3 < T) acc[f + 3][r][e] = v.w;
+          }
+        } else if (W == 2 && vec) {
+          if (colb < N) {
+            float2 v = make_float2(acc[f][r][e], acc[f + 1 < T ? f + 1 : f][r][e]);
+            if (d.Res) {
+              const float2 q = *reinterpret_cast<const float2*>(d.Res + (size_t)row * d.ldres + colb);
+              v.x += q.x; v.y += q.y;
+            }
+            float2* dst = reinterpret_cast<float2*>(d.C + (size_t)row * d.ldc + colb);
+            if (accum) { const float2 q = *dst; v.x += q.x; v.y += q.y; }
+            *dst = v;
+            acc[f][r][e] = v.x;
+            if (f + 1 < T) acc[f + 1][r][e] = v.y;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (t < W && f + t < T && colb + t < N) {
+              float v = acc[f + t][r][e];
+              if (d.Res) v += d.Res[(size_t)row * d.ldres + colb + t];
+              float* dst = d.C + (size_t)row * d.ldc + colb + t;
+              if (accum) v += *dst;
+              *dst = v;
+              acc[f + t][r][e] = v;
+            }
+          }
+        }
+      }
+  }
+  // 4. per-strip column statistics of what was stored, over the VALID rows of the strip
+  if (d.stats) {
+    const int mv = d.m_valid ? min(M, d.m_valid[0]) : M;
+    const int cnt = max(0, min(strip_rows, mv - m0));
+    float* __restrict__ out = d.stats + (size_t)strip * 2 * N;
+#pragma unroll
+    for (int c = 0; c < T; ++c) {
+      const int col = rs_col<T>(wcol, c, n);
+      float s0 = 0.f, s1 = 0.f;
+      if (d.stats_mode == MSDE_RS_STATS_BNFWD) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s0 += (m0 + r * 16 + 4 * g + e < mv) ? acc[c][r][e] : 0.f;
+        s0 += __shfl_xor(s0, 16, 64);
+        s0 += __shfl_xor(s0, 32, 64);
+        const float mean = cnt > 0 ? s0 / (float)cnt : 0.f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dv = acc[c][r][e] - mean;
+            s1 += (m0 + r * 16 + 4 * g + e < mv) ? dv * dv : 0.f;
+          }
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        s0 = mean;
+      } else {                                       // MSDE_RS_STATS_BNBWD: sum g, sum g (z - mean[col])
+        const float mu = col < N ? d.stats_mean[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = m0 + r * 16 + 4 * g + e;
+            if (row < mv && col < N) {
+              const float gv = acc[c][r][e];
+              s0 += gv;
+              s1 = fmaf(gv, d.stats_z[(size_t)row * d.ld_sz + col] - mu, s1);
+            }
+          }
+        s0 += __shfl_xor(s0, 16, 64);
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+      }
+      if (g == 0 && col < N) { out[col] = s0; out[N + col] = s1; }
+    }
+  }
+}
+
+// ---- A transforms on load -----------------------------------------------------------------------------------------
+// MSDE_RS_AXF_AFFINE  BatchNorm apply (+ ReLU): a = max(z s[k] + t[k], 0)
+// MSDE_RS_AXF_BNBWD   BatchNorm input gradient: dz = p[k] g' + w[k] z + u[k] with g' = g gated by the fused ReLU
+//                     (z s[k] + t[k] > 0); p = gamma rstd, w = -p c2 rstd, u = p (c2 rstd mean - c1) come from
+//                     msde_bn_fin_bwd (c1 = mean g', c2 = mean g' xhat)
+// The transformed strip is optionally written back once (A_out, by the workgroup of column split 0): the weight gradient's
+// operand.  All 256 threads, 16-B pieces, coalesced along k; zero beyond M / K.
+template <int MODE>
+__device__ __forceinline__ void rs_stage_mode(const msde_rs_desc& d, bool writer, float* __restrict__ As, int ld, int m0,
+                                              int rows) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int K = d.K, M = d.M, kq = rs_kpad(K) / 4;
+  const bool relu = (d.flags & MSDE_RS_AXF_RELU) != 0;
+  float* __restrict__ out = writer ? d.A_out : nullptr;
+  for (int r = wave; r < rows; r += 4) {
+    const int gm = m0 + r;
+    for (int q = lane; q < kq; q += 64) {
+      const int k = 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gm < M && k < K) {
+        v = *reinterpret_cast<const float4*>(d.A + (size_t)gm * d.lda + k);
+        if (MODE == MSDE_RS_AXF_AFFINE) {
+          const float4 sv = *reinterpret_cast<const float4*>(d.xf0 + k), tv = *reinterpret_cast<const float4*>(d.xf1 + k);
+          v = make_float4(fmaf(v.x, sv.x, tv.x), fmaf(v.y, sv.y, tv.y), fmaf(v.z, sv.z, tv.z), fmaf(v.w, sv.w, tv.w));
+          if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        } else if (MODE == MSDE_RS_AXF_BNBWD) {
+          const float4 z = *reinterpret_cast<const float4*>(d.A2 + (size_t)gm * d.lda2 + k);
+          const float4 pv = *reinterpret_cast<const float4*>(d.xf0 + k), wv = *reinterpret_cast<const float4*>(d.xf1 + k);
+          const float4 uv = *reinterpret_cast<const float4*>(d.xf2 + k);
+          if (d.xf3) {
+            const float4 sv = *reinterpret_cast<const float4*>(d.xf3 + k), tv = *reinterpret_cast<const float4*>(d.xf4 + k);
+            v.x = fmaf(z.x, sv.x, tv.x) > 0.f ? v.x : 0.f;
+            v.y = fmaf(z.y, sv.y, tv.y) > 0.f ? v.y : 0.f;
+            v.z = fmaf(z.z, sv.z, tv.z) > 0.f ? v.z : 0.f;
+            v.w = fmaf(z.w, sv.w, tv.w) > 0.f ? v.w : 0.f;
+          }
+          v = make_float4(fmaf(pv.x, v.x, fmaf(wv.x, z.x, uv.x)), fmaf(pv.y, v.y, fmaf(wv.y, z.y, uv.y)),
+                          fmaf(pv.z, v.z, fmaf(wv.z, z.z, uv.z)), fmaf(pv.w, v.w, fmaf(wv.w, z.w, uv.w)));
+        }
+        if (MODE != MSDE_RS_AXF_NONE && out) *reinterpret_cast<float4*>(out + (size_t)gm * d.lda_out + k) = v;
+      }
+      *reinterpret_cast<float4*>(As + r * ld + k) = v;
+    }
+  }
+}
+
+__device__ __forceinline__ void rs_stage_desc(const msde_rs_desc& d, bool writer, float* __restrict__ As, int ld, int m0,
+                                              int rows) {
+  if (d.axf == MSDE_RS_AXF_AFFINE) rs_stage_mode<MSDE_RS_AXF_AFFINE>(d, writer, As, ld, m0, rows);
+  else if (d.axf == MSDE_RS_AXF_BNBWD) rs_stage_mode<MSDE_RS_AXF_BNBWD>(d, writer, As, ld, m0, rows);
+  else rs_stage_mode<MSDE_RS_AXF_NONE>(d, writer, As, ld, m0, rows);
+}
+
+// ===================================================================================================================
+// RSA: one workgroup = one strip of 16 RT rows x one of `splits` column ranges of 64 T columns; wave w owns the 16 T
+// consecutive columns starting at (split * 4 + w) * 16 T.
+// ===================================================================================================================
+template <int RT, int T>
+__global__ void __launch_bounds__(256, 2)
+gemm_rsa_kernel(const msde_rs_desc d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int S = d.splits;
+  const int strip = blockIdx.x / S, split = blockIdx.x - strip * S;
+  const int m0 = strip * RT * 16;
+  const int ld = rs_lds_ld(d.K);
+  rs_stage_desc(d, split == 0, lds, ld, m0, RT * 16);
+  const int wave = threadIdx.x >> 6;
+  const int wcol = (split * 4 + wave) * 16 * T;       // may lie beyond N (narrow outputs): such a wave computes zeros
+  f32x4 acc[T][RT];
+#pragma unroll
+  for (int c = 0; c < T; ++c)
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (every strip walks k from block 0: starting strip s at block s mod blocks, so that workgroups launched together read
+  // different weight rows, measured no difference on 3588 x {128, 300, 600}^2: the L2 serves the shared rows fine)
+  rsa_mma<RT, T, true>(lds, ld, d.B, d.ldb, d.N, d.K, wcol, acc, 0);
+  if (wcol >= d.N) return;
+  rs_epilogue<RT, T>(d, acc, wcol, m0, strip, RT * 16);
+}
+
+// ===================================================================================================================
+// finishing kernels of the fused BatchNorm: one launch of C / 16 workgroups; 16 lanes per column merge the per-strip
+// partials in a fixed order (lane l takes strips l, l + 16, ...; the 16 lane results are merged in lane order).
+// ===================================================================================================================
+__device__ __forceinline__ void rs_chan(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+  if (nb > 0.f) {
+    const float nn = n + nb, dl = mb - mean;
+    mean += dl * (nb / nn);
+    m2 += m2b + dl * dl * (n * nb / nn);
+    n = nn;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_fin_fwd_kernel(const float* __restrict__ stats, int strips, int strip_rows, int M, const int* __restrict__ m_valid,
+                  int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                  float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ scale,
+                  float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  const int mv = m_valid ? min(M, m_valid[0]) : M;
+  const int l = threadIdx.x & 15, col = blockIdx.x * 16 + (threadIdx.x >> 4);
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  if (col < C) {
+    for (int s = l; s < strips; s += 16) {
+      const float cnt = (float)max(0, min(strip_rows, mv - s * strip_rows));
+      rs_chan(n, mean, m2, cnt, stats[(size_t)s * 2 * C + col], stats[(size_t)s * 2 * C + C + col]);
+    }
+  }
+  // merge the 16 lanes of a column in lane order (all lanes take part in the shuffles)
+  float rn = 0.f, rmean = 0.f, rm2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float nb = __shfl(n, (threadIdx.x & 48) + k, 64), mb = __shfl(mean, (threadIdx.x & 48) + k, 64);
+    const float qb = __shfl(m2, (threadIdx.x & 48) + k, 64);
+    rs_chan(rn, rmean, rm2, nb, mb, qb);
+  }
+  if (col < C && l == 0) {
+    const float var = rn > 0.f ? rm2 / rn : 0.f;
+    const float rstd = rsqrtf(var + eps);
+    const float gv = gamma ? gamma[col] : 1.f, bv = beta ? beta[col] : 0.f;
+    scale[col] = gv * rstd;
+    shift[col] = bv - rmean * gv * rstd;
+    save_mean[col] = rmean;
+    save_rstd[col] = rstd;
+    if (running_mean) {
+      const float unbiased = rn > 1.f ? rm2 / (rn - 1.f) : var;
+      running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * rmean;
+      running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_fin_bwd_kernel(const float* __restrict__ stats, int strips, int M, const int* __restrict__ m_valid, int C,
+                  const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                  float* __restrict__ p, float* __restrict__ w, float* __restrict__ u, float* __restrict__ dgamma,
+                  float* __restrict__ dbeta) {
+  const int mv = m_valid ? min(M, m_valid[0]) : M;
+  const int l = threadIdx.x & 15, col = blockIdx.x * 16 + (threadIdx.x >> 4);
+  float a = 0.f, b = 0.f;
+  if (col < C)
+    for (int s = l; s < strips; s += 16) { a += stats[(size_t)s * 2 * C + col]; b += stats[(size_t)s * 2 * C + C + col]; }
+  float ra = 0.f, rb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    ra += __shfl(a, (threadIdx.x & 48) + k, 64);
+    rb += __shfl(b, (threadIdx.x & 48) + k, 64);
+  }
+  if (col < C && l == 0) {
+    const float rs = rstd[col], mu = mean[col], gv = gamma ? gamma[col] : 1.f;
+    const float sum_g = ra, sum_gx = rb * rs;          // sum g', sum g' xhat
+    if (dbeta) dbeta[col] = sum_g;
+    if (dgamma) dgamma[col] = sum_gx;
+    const float inv = mv > 0 ? 1.f / (float)mv : 0.f;
+    const float c1 = sum_g * inv, c2 = sum_gx * inv;
+    const float pp = gv * rs;
+    p[col] = pp;
+    w[col] = -pp * c2 * rs;
+    u[col] = pp * (c2 * rs * mu - c1);
+  }
+}
+
+// y[m][c] = max(x[m][c] scale[c] + shift[c], 0 if relu): the BatchNorm apply of a tensor that several consumers read
+// (the layer output of the GIN stack); C % 4 == 0.
+__global__ void __launch_bounds__(256)
+affine_cols_kernel(const float* __restrict__ X, int M, int C, const float* __restrict__ scale,
+                   const float* __restrict__ shift, int relu, float* __restrict__ Y) {
+  const int cq = C >> 2;
+  const long total = (long)M * cq;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % cq) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(X + i * 4);
+    const float4 s = *reinterpret_cast<const float4*>(scale + c), t = *reinterpret_cast<const float4*>(shift + c);
+    float4 y = make_float4(fmaf(v.x, s.x, t.x), fmaf(v.y, s.y, t.y), fmaf(v.z, s.z, t.z), fmaf(v.w, s.w, t.w));
+    if (relu) y = make_float4(fmaxf(y.x, 0.f), fmaxf(y.y, 0.f), fmaxf(y.z, 0.f), fmaxf(y.w, 0.f));
+    *reinterpret_cast<float4*>(Y + i * 4) = y;
+  }
+}
+
+// BatchNorm-backward partial sums of a gradient that does NOT come out of one of the products above (the gradient of the
+// GIN layer output): per 64-row strip and column, sum g' and sum g' (z - mean[c]) with g' = g gated by the fused ReLU
+// (y[m][c] > 0, y = the layer output) -- the [strips][2][C] format of MSDE_RS_STATS_BNBWD.  One workgroup per
+// (64 columns, strip); 16 row lanes x 16 float4 column groups; C % 4 == 0.
+__global__ void __launch_bounds__(256)
+bn_bwd_colstats_kernel(const float* __restrict__ G, const float* __restrict__ Z, const float* __restrict__ Y,
+                       const float* __restrict__ mean, int M, const int* __restrict__ m_valid, int C,
+                       float* __restrict__ stats) {
+  __shared__ float sa[16][64], sb[16][64];
+  const int mv = m_valid ? min(M, m_valid[0]) : M;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4, strip = blockIdx.y;
+  const int r0 = strip * 64, r1 = min(r0 + 64, mv);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (c < C) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + ty + 16 * k;
+      if (r < r1) {
+        float4 g = *reinterpret_cast<const float4*>(G + (size_t)r * C + c);
+        const float4 z = *reinterpret_cast<const float4*>(Z + (size_t)r * C + c);
+        if (Y) {
+          const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * C + c);
+          g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f; g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+        }
+        a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+        b.x = fmaf(g.x, z.x - mu.x, b.x); b.y = fmaf(g.y, z.y - mu.y, b.y);
+        b.z = fmaf(g.z, z.z - mu.z, b.z); b.w = fmaf(g.w, z.w - mu.w, b.w);
+      }
+    }
+  }
+  sa[ty][tx * 4] = a.x; sa[ty][tx * 4 + 1] = a.y; sa[ty][tx * 4 + 2] = a.z; sa[ty][tx * 4 + 3] = a.w;
+  sb[ty][tx * 4] = b.x; sb[ty][tx * 4 + 1] = b.y; sb[ty][tx * 4 + 2] = b.z; sb[ty][tx * 4 + 3] = b.w;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < C) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int l = 0; l < 16; ++l) { s0 += sa[l][threadIdx.x]; s1 += sb[l][threadIdx.x]; }
+      stats[(size_t)strip * 2 * C + cc] = s0;
+      stats[(size_t)strip * 2 * C + C + cc] = s1;
+    }
+  }
+}
+
+// ===================================================================================================================
+// host side
+// ===================================================================================================================
+static inline bool rs_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// geometry of the RSA kernel for (M, N, K): row tiles per strip (RT), tiles per wave (T), column splits (S = workgroups per
+// strip, each covering 64 T columns)
+static void rsa_geometry(int M, int N, int K, int* rt, int* tw, int* splits) {
+  const int ntiles = (N + 15) / 16;
+  const int cus = msde_num_cus();
+  int T = (ntiles + 3) / 4;                            // one workgroup per strip if that is <= 5 tiles per wave
+  int S = 1;
+  if (T > 5) { S = (ntiles + 19) / 20; T = (ntiles + 4 * S - 1) / (4 * S); }
+  int RT = 1;
+  // 32-row strips halve the weight traffic per MFMA; taken when they still give every CU a workgroup and two strips fit in
+  // a CU's LDS
+  if ((long)((M + 31) / 32) * S >= (long)(cus * 7) / 8 && (size_t)32 * rs_lds_ld(K) * 4 <= 80 * 1024) RT = 2;
+  static const int f_rt = getenv("MSDE_RS_RT") ? atoi(getenv("MSDE_RS_RT")) : 0;         // tuning knobs
+  static const int f_t = getenv("MSDE_RS_T") ? atoi(getenv("MSDE_RS_T")) : 0;
+  if (f_rt) RT = f_rt;
+  if (f_t >= 1 && f_t <= 5) { T = f_t; S = (ntiles + 4 * T - 1) / (4 * T); }
+  *rt = RT;
+  *tw = T;
+  *splits = S;
+}
+
+extern "C" int msde_gemm_rs_geometry(int M, int N, int K, int* strips, int* strip_rows) {
+  if (M < 0 || N <= 0 || K <= 0 || !strips || !strip_rows) return MSDE_EINVAL;
+  int rt, t, s;
+  rsa_geometry(M, N, K, &rt, &t, &s);
+  *strip_rows = 16 * rt;
+  *strips = (M + 16 * rt - 1) / (16 * rt);
+  return 0;
+}
+
+// dynamic LDS beyond 64 KB must be granted per kernel; remembered per kernel address (the instantiations share one
+// function-pointer type, so a static inside the template would be shared too)
+#include <map>
+#include <mutex>
+template <typename KERN>
+static int rs_launch(KERN kern, dim3 grid, size_t lds, hipStream_t st, const msde_rs_desc& d) {
+  if (lds > 64 * 1024) {
+    static std::map<const void*, size_t> granted;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& gr = granted[reinterpret_cast<const void*>(kern)];
+    if (lds > gr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      gr = lds;
+    }
+  }
+  MSDE_LAUNCH(kern, grid, dim3(256), lds, st, d);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_gemm_rs(const msde_rs_desc* desc, void* stream) {
+  if (!desc) return MSDE_EINVAL;
+  msde_rs_desc d = *desc;
+  if (d.M < 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.B || !d.C) return MSDE_EINVAL;
+  if (d.M == 0) return 0;
+  if (!(d.flags & MSDE_GEMM_B_KMAJOR)) return MSDE_EUNSUP;          // weights are read as [K][N] only (gemm_rs.h)
+  // 16-B pieces: K % 4 and an aligned A for the strip; N % 4 and aligned weight rows for the interleaved column segments
+  if (d.K % 4 || d.lda % 4 || !rs_al16(d.A)) return MSDE_EUNSUP;
+  if ((size_t)d.K * (size_t)d.ldb >= (1u << 30)) return MSDE_EUNSUP;       // 32-bit element offsets of B
+  if (d.epi == MSDE_EPI_DACT && d.act != MSDE_ACT_NONE && !d.R) return MSDE_EINVAL;
+  if (d.axf == MSDE_RS_AXF_AFFINE && (!d.xf0 || !d.xf1 || !rs_al16(d.xf0) || !rs_al16(d.xf1))) return MSDE_EINVAL;
+  if (d.axf == MSDE_RS_AXF_BNBWD && (!d.A2 || !d.xf0 || !d.xf1 || !d.xf2 || d.lda2 % 4 || !rs_al16(d.A2))) return MSDE_EINVAL;
+  if (d.A_out && (d.lda_out % 4 || !rs_al16(d.A_out))) return MSDE_EINVAL;
+  if (d.stats && d.stats_mode == MSDE_RS_STATS_BNBWD && (!d.stats_z || !d.stats_mean)) return MSDE_EINVAL;
+  int rt, T, S;
+  rsa_geometry(d.M, d.N, d.K, &rt, &T, &S);
+  if (d.rt) rt = d.rt;
+  if (T > 1 && (d.N % 4 || d.ldb % 4 || !rs_al16(d.B))) return MSDE_EUNSUP;
+  size_t lds = (size_t)16 * rt * rs_lds_ld(d.K) * 4;
+  if (lds > 160 * 1024 && rt == 2) { rt = 1; lds /= 2; }
+  if (lds > 160 * 1024) return MSDE_EUNSUP;
+  d.splits = S;
+  d.rt = rt;
+  d.flags &= ~MSDE_RS_VEC_STORE;
+  if (d.ldc % 4 == 0 && rs_al16(d.C) && (!d.Res || (d.ldres % 4 == 0 && rs_al16(d.Res)))) d.flags |= MSDE_RS_VEC_STORE;
+  dim3 grid(((d.M + 16 * rt - 1) / (16 * rt)) * S);
+  hipStream_t st = as_stream(stream);
+#define RSA_GO(T_) (rt == 2 ? rs_launch(gemm_rsa_kernel<2, T_>, grid, lds, st, d) : rs_launch(gemm_rsa_kernel<1, T_>, grid, lds, st, d))
+  switch (T) {
+    case 1: return RSA_GO(1);
+    case 2: return RSA_GO(2);
+    case 3: return RSA_GO(3);
+    case 4: return RSA_GO(4);
+    case 5: return RSA_GO(5);
+    default: return MSDE_EUNSUP;
+  }
+#undef RSA_GO
+}
+
+// ---- transposed weight copies (forward products read [K][N], gemm_rs.h): ONE launch for any number of matrices.
+// table rows (long long x 4): {src, dst, rows, cols}; prefix[i] = first 32 x 32 tile of matrix i, prefix[n] = total.
+__global__ void __launch_bounds__(256)
+transpose_multi_kernel(const long long* __restrict__ table, const int* __restrict__ prefix, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;                              // last matrix whose first tile is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const float* __restrict__ src = reinterpret_cast<const float*>(table[4 * lo]);
+  float* __restrict__ dst = reinterpret_cast<float*>(table[4 * lo + 1]);
+  const int rows = (int)table[4 * lo + 2], cols = (int)table[4 * lo + 3];
+  const int t = blockIdx.x - prefix[lo], tc = (cols + 31) >> 5;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + y + 8 * k, c = c0 + x;
+    tile[y + 8 * k][x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + y + 8 * k, r = r0 + x;
+    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[x][y + 8 * k];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+transpose_one_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int tc = (cols + 31) >> 5;
+  const int r0 = ((int)blockIdx.x / tc) * 32, c0 = ((int)blockIdx.x % tc) * 32;
+  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + y + 8 * k, c = c0 + x;
+    tile[y + 8 * k][x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + y + 8 * k, r = r0 + x;
+    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[x][y + 8 * k];
+  }
+}
+
+extern "C" int msde_transpose(const float* src, float* dst, int rows, int cols, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (!src || !dst) return MSDE_EINVAL;
+  MSDE_LAUNCH(transpose_one_kernel, dim3(((rows + 31) / 32) * ((cols + 31) / 32)), dim3(256), 0, as_stream(stream), src, dst,
+              rows, cols);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_transpose_multi(const long long* table, const int* prefix, int n, int total_tiles, void* stream) {
+  if (n <= 0 || total_tiles <= 0) return 0;
+  if (!table || !prefix) return MSDE_EINVAL;
+  MSDE_LAUNCH(transpose_multi_kernel, dim3(total_tiles), dim3(256), 0, as_stream(stream), table, prefix, n);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_bn_fin_fwd(const float* stats, int strips, int strip_rows, int M, const int* m_valid, int C,
+                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* scale, float* shift, float* save_mean, float* save_rstd,
+                               void* stream) {
+  if (!stats || strips <= 0 || strip_rows <= 0 || C <= 0 || !scale || !shift || !save_mean || !save_rstd) return MSDE_EINVAL;
+  MSDE_LAUNCH(bn_fin_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), stats, strips, strip_rows, M, m_valid,
+              C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_bn_fin_bwd(const float* stats, int strips, int M, const int* m_valid, int C, const float* gamma,
+                               const float* mean, const float* rstd, float* p, float* w, float* u, float* dgamma,
+                               float* dbeta, void* stream) {
+  if (!stats || strips <= 0 || C <= 0 || !mean || !rstd || !p || !w || !u) return MSDE_EINVAL;
+  MSDE_LAUNCH(bn_fin_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), stats, strips, M, m_valid, C, gamma,
+              mean, rstd, p, w, u, dgamma, dbeta);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_affine_cols(const float* X, int M, int C, const float* scale, const float* shift, int relu, float* Y,
+                                void* stream) {
+  if (M < 0 || C <= 0 || C % 4 || !X || !Y || !scale || !shift) return MSDE_EINVAL;
+  if (M == 0) return 0;
+  const long total = (long)M * (C / 4);
+  const int blocks = (int)min((total + 255) / 256, (long)msde_num_cus() * 8);
+  MSDE_LAUNCH(affine_cols_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), X, M, C, scale, shift, relu, Y);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_bn_bwd_colstats(const float* G, const float* Z, const float* Y, const float* mean, int M,
+                                    const int* m_valid, int C, float* stats, void* stream) {
+  if (M <= 0 || C <= 0 || C % 4 || !G || !Z || !mean || !stats) return MSDE_EINVAL;
+  MSDE_LAUNCH(bn_bwd_colstats_kernel, dim3((C + 63) / 64, (M + 63) / 64), dim3(256), 0, as_stream(stream), G, Z, Y, mean, M,
+              m_valid, C, stats);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

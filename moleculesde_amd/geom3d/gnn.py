@@ -9,6 +9,10 @@ from .. import hip, plan as _plan
 from . import nn as _nn
 
 
+import os as _os
+FUSE_GIN_LAYER = _os.environ.get("MSDE_FUSE_GIN", "1") != "0"     # A/B switch: BatchNorm folded into the GIN products
+
+
 class GINConv(nn.Module):
     """molecule_gnn_model.py:13-32.  The bond-embedding sum, the gather of x_j, the ReLU and the
     per-target segmented sum run as one kernel (hip.gin_aggregate)."""
@@ -21,9 +25,16 @@ class GINConv(nn.Module):
         self.eps = nn.Parameter(torch.Tensor([0]))
         self.bond_encoder = _nn.EmbeddingList(bond_dims, emb_dim, "bond_embedding_list")
 
-    def forward(self, x, bond_plan, bond_codes):
+    def forward(self, x, bond_plan, bond_codes, outer_bn=None):
+        """outer_bn: the layer's BatchNorm of GNN.batch_norms (molecule_gnn_model.py:176-182).  Given in training mode,
+        the whole Linear -> BatchNorm -> ReLU -> Linear -> BatchNorm (-> ReLU) chain runs as hip.gin_mlp_bn (statistics
+        and normalisation folded into the products) and the result already includes outer_bn."""
         agg = hip.gin_aggregate(x, self.bond_encoder.table(), self.eps, bond_plan, bond_codes)
-        return self.mlp(agg)
+        if outer_bn is None:
+            return self.mlp(agg)
+        for bn in (self.mlp[1], outer_bn):
+            _nn.count_batch(bn)
+        return hip.gin_mlp_bn(agg, self.mlp[0], self.mlp[1], self.mlp[3], outer_bn, outer_bn.fuse_relu)
 
 
 class GNN(nn.Module):
@@ -76,9 +87,13 @@ class GNN(nn.Module):
             cb = self.on_input_grad
             h.register_hook(lambda g_: (cb(), None)[1])
         h_list = [h]
+        fused = FUSE_GIN_LAYER and self.training and h.is_cuda and h.size(1) % 4 == 0 and 0 < h.size(0) <= hip.RS_MAX_ROWS
         for layer in range(self.num_layer):
-            h = self.gnns[layer](h_list[layer], pl.bond, pl.bond_codes)
-            h = self.batch_norms[layer](h)             # ReLU fused for all but the last layer
+            if fused and _nn.bn_fusable(self.gnns[layer].mlp[1]) and _nn.bn_fusable(self.batch_norms[layer]):
+                h = self.gnns[layer](h_list[layer], pl.bond, pl.bond_codes, self.batch_norms[layer])
+            else:
+                h = self.gnns[layer](h_list[layer], pl.bond, pl.bond_codes)
+                h = self.batch_norms[layer](h)             # ReLU fused for all but the last layer
             h = F.dropout(h, self.drop_ratio, training=self.training)
             h_list.append(h)
 

@@ -91,6 +91,23 @@ class BatchNorm1d(nn.BatchNorm1d):
         return F.relu(y) if self.fuse_relu else y
 
 
+def bn_fusable(bn):
+    """Training-mode BatchNorm1d with running statistics and affine parameters: what the fused products implement."""
+    return (isinstance(bn, BatchNorm1d) and bn.training and bn.track_running_stats and bn.affine and USE_HIP_LINEAR
+            and bn.running_mean is not None)
+
+
+def count_batch(bn):
+    """num_batches_tracked bookkeeping of a BatchNorm whose forward ran inside a fused kernel (see BatchNorm1d)."""
+    if bn.num_batches_tracked is None:
+        return
+    if bn.momentum is None:
+        bn.flush_batches_tracked()
+        bn.num_batches_tracked.add_(1)
+    elif not torch.cuda.is_current_stream_capturing():
+        bn.pending_batches += 1
+
+
 def linear(x, weight, bias=None):
     _need_device(x)
     if USE_HIP_LINEAR:

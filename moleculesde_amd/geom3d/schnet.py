@@ -19,6 +19,10 @@ from .. import hip, plan as _plan
 from . import nn as _nn
 
 
+import os as _os
+FUSE_TAIL = _os.environ.get("MSDE_FUSE_SCHNET_TAIL", "1") != "0"   # A/B switch: softplus / residual in GEMM epilogues
+
+
 class GaussianSmearing(nn.Module):
     """Parameters of schnet.py:198-207; the expansion itself is fused into the edge kernels."""
 
@@ -124,11 +128,19 @@ class SchNet(nn.Module):
             else:
                 Wf = blk.mlp(rbf)
                 agg = hip.cfconv_aggregate(x1, Wf, C, rplan)
-            x = blk.conv.lin2(agg)
-            x = blk.lin(hip.shifted_softplus(x))
-            h = h_res + x
+            if FUSE_TAIL and hip.rs_forward_ok(h.size(0), self.hidden_channels, self.num_filters, blk.conv.lin2.weight) \
+                    and self.hidden_channels % 4 == 0 and 0 < h.size(0) <= hip.RS_MAX_ROWS:
+                # lin2 -> ssp -> lin -> + residual: two products with the pointwise stages in their epilogues
+                h = hip.schnet_tail(agg, h_res, blk.conv.lin2, blk.lin)
+            else:
+                x = blk.conv.lin2(agg)
+                x = blk.lin(hip.shifted_softplus(x))
+                h = h_res + x
 
-        h = self.lin2(hip.shifted_softplus(self.lin1(h)))
+        if FUSE_TAIL and self.hidden_channels % 4 == 0 and h.size(0) > 0:
+            h = hip.mlp_fused(h, [(self.lin1.weight, self.lin1.bias), (self.lin2.weight, self.lin2.bias)], "ssp")
+        else:
+            h = self.lin2(hip.shifted_softplus(self.lin1(h)))
         out = hip.segment_reduce(h, pl.mol_ptr, pl.batch_i32, mean=(self.readout == "mean"))
         if return_latent:
             return out, h

@@ -627,11 +627,11 @@ class _MlpFused(torch.autograd.Function):
                 _lib.call("msde_mlp_head_fwd", _p(h), _ld(h), _p(W), _p(b), M, W.size(1), W.size(0), _p(out), _stream())
                 saved += [None, None]
             elif head and i == n - 2:      # only the pre-activation is stored: the head kernels apply the SiLU on load
-                gemm_ex(h, W, out, bias=b)
+                gemm_fwd(h, W, out, bias=b)
                 saved += [h, out]
             else:
                 Z = torch.empty_like(out) if (need and not last) else None
-                gemm_ex(h, W, out, bias=b, act=None if last else act, Z=Z)
+                gemm_fwd(h, W, out, bias=b, act=None if last else act, Z=Z)
                 saved += [h, Z]
             h = out
         ctx.save_for_backward(*[t for t in saved if t is not None], *params)
@@ -677,7 +677,7 @@ class _MlpFused(torch.autograd.Function):
                 break
             gin = torch.empty(g.size(0), W.size(1), dtype=torch.float32, device=g.device)
             # d/d(input of layer i) = g W; for i > 0 that input is act(Z_{i-1}): times act'(Z_{i-1}) in the same epilogue
-            gemm_ex(g, W, gin, b_kmajor=True, act=act if i > 0 else None, dact_from=saved[2 * i - 1] if i > 0 else None)
+            gemm_dgrad(g, W, gin, act=act if i > 0 else None, dact_from=saved[2 * i - 1] if i > 0 else None)
             g = gin
         return (g, None, None) + tuple(grads)
 
@@ -729,6 +729,8 @@ def cat_params(ws):
         return ws[0]
     out = _CatParams.apply(*ws)
     out._msde_leaf_like = all(w.is_leaf for w in ws)     # its gradient only gets split into views for the leaves
+    out._msde_src = tuple(ws)                            # weight_t(): the copy is valid while these are unchanged
+    out._msde_volatile = out.data_ptr() != ws[0].data_ptr()   # a real concatenation: a fresh tensor at every call
     return out
 
 
@@ -974,13 +976,13 @@ def _wgrad_workspace(M, N, K, device):
 
 
 # Dispatch policy of the dense layers, from per-shape rocprofv3 timings on MI355X (profiles/):
-#   * forward / input gradient: the vendor fp32 GEMM is ~1.7x faster than csrc/linear.hip on these
-#     skinny shapes (22 vs 41 us at 49090x128x128), so plain library GEMMs are used there;
+#   * forward / input gradient: the row-strip MFMA kernels of csrc/gemm_rs.hip (round 3; rounds 1-2 used the vendor
+#     fp32 GEMM here, which was faster than csrc/linear.hip and the 64 x 64-tile csrc/gemm_ex.hip on these skinny shapes);
 #   * weight + bias gradient: the vendor kernel runs ~100 output tiles over the whole M loop (31-39 us at
 #     M = 3588 whatever the layer size, 110-225 us at edge level); the split-M MFMA kernel + fixed-order
 #     slab reduce takes 9-33 us (tools/bench_wgrad.py, hipGraph-timed), fuses the bias gradient and is
 #     bitwise reproducible -> hand-written kernel for every layer.
-# MSDE_LINEAR=hip forces the hand-written kernel everywhere (parity tests do), =lib the vendor GEMM.
+# MSDE_LINEAR=hip forces the round-1 kernels of csrc/linear.hip everywhere, =lib the vendor GEMM (A/B measurements only).
 import os as _os
 
 _LINEAR_MODE = _os.environ.get("MSDE_LINEAR", "auto")
@@ -1364,8 +1366,12 @@ class _Linear(torch.autograd.Function):
             y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
             _lib.call("msde_linear_fwd", _p(x2), _p(w), _p(_f32(bias) if bias is not None else None), M, N, K, _p(y),
                       _stream())
-        else:
+        elif _LINEAR_MODE == "lib":
             y = torch.addmm(bias, x2, w.t()) if bias is not None else torch.mm(x2, w.t())
+        else:
+            y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+            if M > 0:
+                gemm_fwd(x2, weight, y, bias=_f32(bias) if bias is not None else None)
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.in_shape = shape
@@ -1388,10 +1394,13 @@ class _Linear(torch.autograd.Function):
                 _lib.call("msde_linear_bwd_x", _p(g2), _p(w), M, N, K, _p(gx), st)
                 if g_res is not None:
                     gx = gx + g_res.reshape(M, K)
-            elif g_res is not None:          # residual gradient folded into the GEMM (beta = 1): no separate add
-                gx = torch.addmm(_f32(g_res.reshape(M, K)), g2, w)
+            elif _LINEAR_MODE == "lib":
+                # residual gradient folded into the GEMM (beta = 1): no separate add
+                gx = torch.addmm(_f32(g_res.reshape(M, K)), g2, w) if g_res is not None else torch.mm(g2, w)
             else:
-                gx = torch.mm(g2, w)
+                gx = torch.empty(M, K, dtype=torch.float32, device=g2.device)
+                if M > 0:
+                    gemm_dgrad(g2, w, gx, res=_f32(g_res.reshape(M, K)) if g_res is not None else None)
             gx = gx.view(ctx.in_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = weight_grad(g2, x2, ctx.has_bias, ctx.deferrable)
@@ -1841,6 +1850,330 @@ def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=N
     d.alpha = float(alpha)
     _lib.call("msde_gemm_ex", ctypes.byref(d), _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# row-strip GEMM family (csrc/gemm_rs.hip): the plain nn.Linear products and the BatchNorm fused around them
+# ------------------------------------------------------------------------------------------------
+# ---- transposed weight copies ------------------------------------------------------------------------------------
+# The row-strip kernels read their weight operand as [K][N] (csrc/gemm_rs.h): an input-gradient product takes nn.Linear's
+# weight [out][in] as stored, a forward product needs its transpose.  One copy per weight is kept here and refreshed
+#   * lazily, when the weight's autograd version counter moved (torch optimisers, load_state_dict, init), or when the
+#     parameter epoch moved (moleculesde_amd.optim.FlatAdam updates parameters through raw pointers and calls
+#     bump_weight_epoch());
+#   * by ONE batched launch for all known weights (refresh_weight_t(), called by the trainer right after the optimiser
+#     step, inside the captured graph) -- then no forward of the next step launches a transpose.
+import weakref as _weakref
+
+_WT = {}                 # key -> entry dict(wt, refs, versions, epoch)
+_WT_EPOCH = 0
+_WT_TABLE = {}           # device -> dict(n, host/dev tables) of the batched refresh
+
+
+def bump_weight_epoch():
+    global _WT_EPOCH
+    _WT_EPOCH += 1
+
+
+def _transpose_into(entries):
+    """One msde_transpose_multi launch for `entries` (same device)."""
+    dev = entries[0]["wt"].device
+    n = len(entries)
+    tab = torch.empty(n, 4, dtype=torch.int64)
+    pre = torch.empty(n + 1, dtype=torch.int32)
+    total = 0
+    for i, e in enumerate(entries):
+        r, c = e["shape"]
+        tab[i, 0], tab[i, 1], tab[i, 2], tab[i, 3] = e["src_ptr"], e["wt"].data_ptr(), r, c
+        pre[i] = total
+        total += ((r + 31) // 32) * ((c + 31) // 32)
+    pre[n] = total
+    return tab, pre, total, dev
+
+
+def weight_t(w):
+    """[K][N] copy of the 2-D fp32 weight w [N][K] (see above); refreshed when stale.  Only leaf tensors (parameters)
+    and free concatenation views of leaves are kept; anything else (a weight computed in the forward) is transposed
+    on the spot."""
+    src = getattr(w, "_msde_src", None) or (w,)
+    stable = not getattr(w, "_msde_volatile", False) and all(p.is_leaf for p in src)
+    if not stable:
+        wc = w if w.is_contiguous() else w.contiguous()
+        wt = torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device)
+        _lib.call("msde_transpose", _p(wc), _p(wt), int(w.size(0)), int(w.size(1)), _stream())
+        return wt
+    key = (tuple(id(p) for p in src), int(w.size(0)), int(w.size(1)), w.data_ptr())
+    ent = _WT.get(key)
+    if ent is None:
+        def drop(_r, key=key):
+            _WT.pop(key, None)
+            _WT_TABLE.clear()
+        ent = {"wt": torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device), "shape": (w.size(0), w.size(1)),
+               "src_ptr": w.data_ptr(), "refs": [_weakref.ref(p, drop) for p in src], "versions": None, "epoch": -1}
+        _WT[key] = ent
+        _WT_TABLE.clear()
+    versions = tuple(p._version for p in src)
+    if ent["versions"] != versions or ent["epoch"] != _WT_EPOCH:
+        _lib.call("msde_transpose", ctypes.c_void_p(ent["src_ptr"]), _p(ent["wt"]), ent["shape"][0], ent["shape"][1], _stream())
+        ent["versions"], ent["epoch"] = versions, _WT_EPOCH
+    return ent["wt"]
+
+
+def refresh_weight_t():
+    """Re-transpose every known weight with one launch per device on the current stream and mark the copies fresh for the
+    current parameter epoch (the trainer calls this right after the optimiser step)."""
+    if not _WT:
+        return
+    by_dev = {}
+    for e in _WT.values():
+        by_dev.setdefault(e["wt"].device, []).append(e)
+    for dev, entries in by_dev.items():
+        t = _WT_TABLE.get(dev)
+        if t is None or t["n"] != len(entries):
+            tab, pre, total, _ = _transpose_into(entries)
+            t = {"n": len(entries), "tab": tab.to(dev), "pre": pre.to(dev), "total": total}
+            _WT_TABLE[dev] = t
+            _retire([])            # tables are tiny and stay referenced from _WT_TABLE
+        _lib.call("msde_transpose_multi", _p(t["tab"]), _p(t["pre"]), t["n"], t["total"], _stream())
+        for e in entries:
+            e["versions"] = tuple(r()._version for r in e["refs"] if r() is not None)
+            e["epoch"] = _WT_EPOCH
+
+
+def rs_forward_ok(M, N, K, w):
+    """Shapes msde_gemm_rs takes for a forward product on weight w [N][K] (the rest goes to msde_gemm_ex)."""
+    return K % 4 == 0 and N % 4 == 0 and w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32
+
+
+def bound_tensor(rows):
+    """Device int32 scalar holding the VALID row count of tensors with `rows` rows (capacity buckets), or None."""
+    return _BOUNDS.get(int(rows))
+
+
+def rs_geometry(M, N, K):
+    """(strips, rows per strip) of the statistics partials msde_gemm_rs writes for this problem."""
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.call("msde_gemm_rs_geometry", int(M), int(N), int(K), ctypes.byref(a), ctypes.byref(b))
+    return a.value, b.value
+
+
+def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_kmajor=False, accumulate=False,
+            axf=None, xf=(), relu=False, A2=None, A_out=None, stats=None, stats_mode=None, stats_z=None,
+            stats_mean=None, m_valid=None, N=None, K=None, rt=0, splits=0, fallback=True):
+    """out[M,N] = epilogue(xf(A) . B(^T) + bias) on msde_gemm_rs (see include/msde_hip.h: msde_rs_desc); no autograd.
+    Returns `out`.  Shapes the row-strip kernels do not take (K % 4, unaligned operands) go to msde_gemm_ex when
+    `fallback` and no fusion beyond bias / activation / derivative / accumulate is asked for; otherwise raises."""
+    d = _lib.RsDesc()
+    M = A.size(0)
+    d.M, d.K = M, int(K if K is not None else A.size(1))
+    if N is None:
+        N = B.size(1) if b_kmajor else B.size(0)
+    d.N = int(N)
+    d.A, d.lda = A.data_ptr(), _ld(A)
+    d.B, d.ldb = B.data_ptr(), (B.stride(0) if B.dim() == 2 else (d.N if b_kmajor else d.K))
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.C, d.ldc = out.data_ptr(), _ld(out)
+    if Z is not None:
+        d.Z, d.ldz = Z.data_ptr(), _ld(Z)
+    d.act = _lib.ACT[act]
+    d.epi = _lib.EPI_ACT
+    if dact_from is not None:
+        d.epi, d.R, d.ldr = _lib.EPI_DACT, dact_from.data_ptr(), _ld(dact_from)
+    if res is not None:
+        d.Res, d.ldres = res.data_ptr(), _ld(res)
+    d.flags = (_lib.GEMM_B_KMAJOR if b_kmajor else 0) | (_lib.GEMM_ACCUMULATE if accumulate else 0) | \
+        (_lib.RS_AXF_RELU if relu else 0)
+    d.axf = {None: _lib.RS_AXF_NONE, "affine": _lib.RS_AXF_AFFINE, "bnbwd": _lib.RS_AXF_BNBWD}[axf]
+    for i, v in enumerate(xf):
+        setattr(d, "xf%d" % i, v.data_ptr() if v is not None else None)
+    if A2 is not None:
+        d.A2, d.lda2 = A2.data_ptr(), _ld(A2)
+    if A_out is not None:
+        d.A_out, d.lda_out = A_out.data_ptr(), _ld(A_out)
+    if stats is not None:
+        d.stats = stats.data_ptr()
+        d.stats_mode = {"bnfwd": _lib.RS_STATS_BNFWD, "bnbwd": _lib.RS_STATS_BNBWD}[stats_mode]
+        if stats_z is not None:
+            d.stats_z, d.ld_sz = stats_z.data_ptr(), _ld(stats_z)
+        if stats_mean is not None:
+            d.stats_mean = stats_mean.data_ptr()
+    if m_valid is None:
+        m_valid = bound_tensor(M)
+    d.m_valid = m_valid.data_ptr() if m_valid is not None else None
+    d.rt, d.splits = int(rt), int(splits)
+    code = _lib.load().msde_gemm_rs(ctypes.byref(d), _stream())
+    if code == -2 and fallback and axf is None and res is None and stats is None and A_out is None:
+        return gemm_ex(A, B, out, bias=bias, act=act, Z=Z, dact_from=dact_from, b_kmajor=b_kmajor, accumulate=accumulate,
+                       N=N, K=K)
+    _lib.check(code, "msde_gemm_rs")
+    return out
+
+
+RS_MAX_ROWS = 8192     # above this (edge-level operands) msde_gemm_ex's 64 x 64 tiles are faster than 16-row strips (tools/bench_gemm_rs.py)
+
+
+def gemm_fwd(x, W, out, bias=None, act=None, Z=None, res=None):
+    """out = act(x W^T + bias) (+ res) for an nn.Linear weight W [N][K]: the row-strip kernel on the transposed copy of
+    W for node-level operands, msde_gemm_ex otherwise.  No autograd."""
+    M, K = x.shape
+    N = W.size(0)
+    if 0 < M <= RS_MAX_ROWS and rs_forward_ok(M, N, K, W) and x.data_ptr() % 16 == 0 and _ld(x) % 4 == 0:
+        return gemm_rs(x, weight_t(W), out, bias=bias, act=act, Z=Z, res=res, b_kmajor=True, N=N, K=K, fallback=False)
+    if res is not None:
+        raise _lib.MsdeHipError("gemm_fwd: a residual needs the row-strip kernel (M <= %d, K %% 4 == N %% 4 == 0)" % RS_MAX_ROWS)
+    return gemm_ex(x, W, out, bias=bias, act=act, Z=Z)
+
+
+def gemm_dgrad(g, W, out, act=None, dact_from=None, res=None):
+    """out = (g W) * act'(dact_from) (+ res) for an nn.Linear weight W [N][K] and g [M][N]: the input gradient."""
+    M, N = g.shape
+    K = W.size(1)
+    if (0 < M <= RS_MAX_ROWS and N % 4 == 0 and K % 4 == 0 and W.is_contiguous() and g.data_ptr() % 16 == 0
+            and _ld(g) % 4 == 0):
+        return gemm_rs(g, W, out, act=act, dact_from=dact_from, res=res, b_kmajor=True, N=K, K=N, fallback=False)
+    if act == "sspo":
+        raise _lib.MsdeHipError("gemm_dgrad: 'sspo' needs the row-strip kernel")
+    if res is not None:
+        if dact_from is not None:
+            raise _lib.MsdeHipError("gemm_dgrad: residual + activation derivative needs the row-strip kernel")
+        out.copy_(res)
+        return gemm_ex(g, W, out, b_kmajor=True, accumulate=True)
+    return gemm_ex(g, W, out, b_kmajor=True, act=act, dact_from=dact_from)
+
+
+def _bn_fin_fwd(stats, strips, srows, M, C, gamma, beta, eps, momentum, rm, rv):
+    dev = stats.device
+    vec = torch.empty(4, C, dtype=torch.float32, device=dev)          # scale | shift | mean | rstd
+    _lib.call("msde_bn_fin_fwd", _p(stats), strips, srows, M, _p(bound_tensor(M)), C, _p(gamma), _p(beta), float(eps),
+              float(momentum), _p(rm), _p(rv), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _stream())
+    return vec
+
+
+def _bn_fin_bwd(stats, strips, M, C, gamma, mean, rstd, need_affine_grads=True):
+    dev = stats.device
+    vec = torch.empty(3, C, dtype=torch.float32, device=dev)          # p | w | u
+    gb = torch.empty(2, C, dtype=torch.float32, device=dev) if need_affine_grads else None
+    _lib.call("msde_bn_fin_bwd", _p(stats), strips, M, _p(bound_tensor(M)), C, _p(gamma), _p(mean), _p(rstd), _p(vec[0]),
+              _p(vec[1]), _p(vec[2]), _p(gb[0] if gb is not None else None), _p(gb[1] if gb is not None else None), _stream())
+    return vec, gb
+
+
+class _GinMlpBN(torch.autograd.Function):
+    """Linear(D, 2D) -> BatchNorm1d -> ReLU -> Linear(2D, D) -> BatchNorm1d (-> ReLU) of a GIN layer in training mode
+    (molecule_gnn_model.py:17,28-29,176-182) on the row-strip GEMMs: batch statistics in the epilogue of the producing
+    product, finished by one small launch; BatchNorm apply + ReLU in the A load of the consuming product; backward:
+    ReLU gate + BatchNorm-backward partial sums in the epilogue of the input-gradient product, the BatchNorm input
+    gradient formed in the A load of the next one.  Forward 5 launches, backward 5 (+ the queued weight gradients)."""
+
+    @staticmethod
+    def forward(ctx, agg, W1, b1, g1, be1, rm1, rv1, W2, b2, g2, be2, rm2, rv2, eps1, mom1, eps2, mom2, relu_out):
+        agg = _f32(agg)
+        M, D = agg.shape
+        H = W1.size(0)
+        dev = agg.device
+        W1t, W2t = weight_t(W1), weight_t(W2)
+        s1, r1 = rs_geometry(M, H, D)
+        st1 = torch.empty(s1, 2, H, dtype=torch.float32, device=dev)
+        z1 = torch.empty(M, H, dtype=torch.float32, device=dev)
+        gemm_rs(agg, W1t, z1, bias=b1, stats=st1, stats_mode="bnfwd", b_kmajor=True, N=H, K=D, fallback=False)
+        v1 = _bn_fin_fwd(st1, s1, r1, M, H, g1, be1, eps1, mom1, rm1, rv1)
+        s2, r2 = rs_geometry(M, D, H)
+        st2 = torch.empty(s2, 2, D, dtype=torch.float32, device=dev)
+        a1 = torch.empty(M, H, dtype=torch.float32, device=dev)
+        z2 = torch.empty(M, D, dtype=torch.float32, device=dev)
+        gemm_rs(z1, W2t, z2, bias=b2, axf="affine", xf=(v1[0], v1[1]), relu=True, A_out=a1, stats=st2, stats_mode="bnfwd",
+                b_kmajor=True, N=D, K=H, fallback=False)
+        v2 = _bn_fin_fwd(st2, s2, r2, M, D, g2, be2, eps2, mom2, rm2, rv2)
+        h = torch.empty(M, D, dtype=torch.float32, device=dev)
+        _lib.call("msde_affine_cols", _p(z2), M, D, _p(v2[0]), _p(v2[1]), int(relu_out), _p(h), _stream())
+        ctx.save_for_backward(agg, z1, a1, z2, h, v1, v2, W1, W2, g1, g2)
+        ctx.relu_out = bool(relu_out)
+        ctx.deferrable = all(t.is_leaf or getattr(t, "_msde_leaf_like", False) for t in (W1, b1, W2, b2))
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        agg, z1, a1, z2, h, v1, v2, W1, W2, g1, g2 = ctx.saved_tensors
+        g = _f32(g)
+        M, D = agg.shape
+        H = W1.size(0)
+        dev = g.device
+        st = _stream()
+        # BatchNorm 2 backward: partial sums of the incoming gradient (gated by the output ReLU), finished, and the input
+        # gradient formed while the next product loads its A strip
+        sb = (M + 63) // 64
+        stb = torch.empty(sb, 2, D, dtype=torch.float32, device=dev)
+        _lib.call("msde_bn_bwd_colstats", _p(g), _p(z2), _p(h if ctx.relu_out else None), _p(v2[2]), M, _p(bound_tensor(M)), D,
+                  _p(stb), st)
+        pw2, gb2 = _bn_fin_bwd(stb, sb, M, D, g2, v2[2], v2[3])
+        # g_a1 = dz2 W2, gated by the ReLU behind BatchNorm 1 (a1 > 0), with BatchNorm 1's partial sums
+        sa, _ = rs_geometry(M, H, D)
+        sta = torch.empty(sa, 2, H, dtype=torch.float32, device=dev)
+        dz2 = torch.empty(M, D, dtype=torch.float32, device=dev)
+        ga1 = torch.empty(M, H, dtype=torch.float32, device=dev)
+        gemm_rs(g, W2, ga1, b_kmajor=True, N=H, K=D, axf="bnbwd",
+                xf=(pw2[0], pw2[1], pw2[2]) + ((v2[0], v2[1]) if ctx.relu_out else (None, None)), A2=z2, A_out=dz2,
+                act="relu", dact_from=a1, stats=sta, stats_mode="bnbwd", stats_z=z1, stats_mean=v1[2], fallback=False)
+        pw1, gb1 = _bn_fin_bwd(sta, sa, M, H, g1, v1[2], v1[3])
+        dz1 = torch.empty(M, H, dtype=torch.float32, device=dev)
+        g_agg = torch.empty(M, D, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        if g_agg is not None:
+            gemm_rs(ga1, W1, g_agg, b_kmajor=True, N=D, K=H, axf="bnbwd", xf=(pw1[0], pw1[1], pw1[2]), A2=z1, A_out=dz1,
+                    fallback=False)
+        else:       # nothing upstream wants a gradient: only dz1 for the weight gradient (product result discarded)
+            scratch = torch.empty(M, D, dtype=torch.float32, device=dev)
+            gemm_rs(ga1, W1, scratch, b_kmajor=True, N=D, K=H, axf="bnbwd", xf=(pw1[0], pw1[1], pw1[2]), A2=z1, A_out=dz1,
+                    fallback=False)
+        gW2, gbias2 = weight_grad(dz2, a1, True, ctx.deferrable)
+        gW1, gbias1 = weight_grad(dz1, agg, True, ctx.deferrable)
+        return (g_agg, gW1, gbias1, gb1[0], gb1[1], None, None, gW2, gbias2, gb2[0], gb2[1], None, None,
+                None, None, None, None, None)
+
+
+def gin_mlp_bn(agg, lin1, bn1, lin2, bn2, relu_out):
+    """mlp(agg) followed by the layer's outer BatchNorm (+ ReLU) -- see _GinMlpBN.  Modules give the parameters."""
+    return _GinMlpBN.apply(agg, lin1.weight, lin1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                           lin2.weight, lin2.bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+                           bn1.eps, 0.1 if bn1.momentum is None else bn1.momentum, bn2.eps,
+                           0.1 if bn2.momentum is None else bn2.momentum, relu_out)
+
+
+class _SchNetTail(torch.autograd.Function):
+    """h + lin(ssp(lin2(agg))) of a SchNet interaction (schnet.py:163-167,97,189; CFConv.lin2, InteractionBlock.act /
+    lin, the residual of SchNet.forward) as two products: bias + shifted softplus in the first epilogue, bias + residual in
+    the second; backward: the softplus derivative (from its saved output) in the epilogue of lin's input-gradient product."""
+
+    @staticmethod
+    def forward(ctx, agg, h, W2, b2, Wl, bl):
+        agg, h = _f32(agg), _f32(h)
+        M = agg.size(0)
+        Hd = W2.size(0)
+        a = torch.empty(M, Hd, dtype=torch.float32, device=agg.device)
+        gemm_fwd(agg, W2, a, bias=b2, act="ssp")
+        out = torch.empty(M, Wl.size(0), dtype=torch.float32, device=agg.device)
+        gemm_fwd(a, Wl, out, bias=bl, res=h)
+        ctx.save_for_backward(agg, a, W2, Wl)
+        ctx.deferrable = all(t.is_leaf for t in (W2, b2, Wl, bl))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        agg, a, W2, Wl = ctx.saved_tensors
+        g = _f32(g)
+        M = g.size(0)
+        gx = torch.empty(M, Wl.size(1), dtype=torch.float32, device=g.device)       # d/d(lin2 output)
+        gemm_dgrad(g, Wl, gx, act="sspo", dact_from=a)
+        g_agg = None
+        if ctx.needs_input_grad[0]:
+            g_agg = torch.empty(M, W2.size(1), dtype=torch.float32, device=g.device)
+            gemm_dgrad(gx, W2, g_agg)
+        gWl, gbl = weight_grad(g, a, True, ctx.deferrable)
+        gW2, gb2 = weight_grad(gx, agg, True, ctx.deferrable)
+        return g_agg, (g if ctx.needs_input_grad[1] else None), gW2, gb2, gWl, gbl
+
+
+def schnet_tail(agg, h, lin2, lin):
+    return _SchNetTail.apply(agg, h, lin2.weight, lin2.bias, lin.weight, lin.bias)
 
 
 # ---- diagnostics: device timestamps in stream order (tools/probes/step_timeline.py) ---------------------------

@@ -218,8 +218,6 @@ class Trainer:
         # hipGraph mode: one captured graph per batch shape (forward + backward + gradient flattening
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self.overlap_streams = True
-        from . import tuned_gemm
-        tuned_gemm.enable()           # per-signature library-GEMM algorithm lookup (read-only; see tuned_gemm.py)
         self._side_stream = torch.cuda.Stream(device=device)
         self._one_grad = torch.ones((), dtype=torch.float32, device=device)
         if EARLY_WGRAD_FLUSH:
@@ -427,6 +425,7 @@ class Trainer:
         if not self.dp_buckets:
             scale = dp.allreduce_mean_(self.opt.flat_g)
             self.opt.step(grad_scale=scale)
+            self._refresh_weights()
             return
         order, works, scale = dp.allreduce_buckets_async(self.opt.flat_g, self.opt.bucket_ranges)
         self.opt.begin_bucket_step()
@@ -434,6 +433,13 @@ class Trainer:
             if w is not None:
                 w.wait()                  # stream wait: the host does not block
             self.opt.step_bucket(i, grad_scale=scale)
+        self._refresh_weights()
+
+    def _refresh_weights(self):
+        """Right after an optimiser step: ONE launch re-transposes every weight the forward products read as [K][N]
+        (hip.weight_t), so that no forward of the next step has to."""
+        from . import hip as _hip
+        _hip.refresh_weight_t()
 
     def _sync_bounds(self, batch):
         """Row bounds are process wide: a capacity-bucket batch needs its bucket's bounds, an exact-size batch none."""
@@ -456,6 +462,7 @@ class Trainer:
             self._allreduce_and_adam()
         else:
             self.opt.step_from_grads()
+            self._refresh_weights()
         self._log_parts(parts)
         self.steps += 1
         return loss.detach(), parts
@@ -470,6 +477,7 @@ class Trainer:
         self._backward(loss)
         if with_adam:
             self.opt.step_from_grads()
+            self._refresh_weights()
         else:
             self.opt.gather_grads()
         self._log_parts(parts)
@@ -524,6 +532,7 @@ class Trainer:
                 self._allreduce_and_adam()
             else:
                 self.opt.step()
+                self._refresh_weights()
         self.steps += 1
         return self._graph_loss[id(batch)]
 

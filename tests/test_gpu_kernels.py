@@ -921,3 +921,152 @@ def test_gemm_ex_groups(dev):
     hip.gemm_ex(x, Wv, xv, b_kmajor=True, groups=8, group_strides=dict(b=256, c=16), N=16, K=16)
     ref = torch.einsum("mk,gkn->mgn", x.double(), Wv.double()).reshape(M, 128)
     assert_close(xv, ref, 1e-5, 2e-5, "grouped k-major")
+
+
+# ---- row-strip GEMM family (csrc/gemm_rs.hip) ----------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(3588, 300, 300), (3588, 600, 300), (3588, 300, 600), (3588, 128, 300), (3588, 300, 128),
+                                   (3588, 32, 300), (3588, 128, 32), (35186, 32, 300), (35186, 128, 32), (35186, 32, 128),
+                                   (35186, 300, 32), (9000, 128, 64), (100, 20, 36), (17, 300, 300), (1, 16, 4),
+                                   (3588, 728, 364), (4096, 364, 120), (777, 80, 64), (500, 176, 32), (3588, 256, 128)])
+def test_gemm_rs_plain(dev, M, N, K):
+    """C = act(A B + bias) with the pre-activation stored, against fp64 torch; [K][N] weights, strips with row tails,
+    16-column tile tails and interleaved column segments (N = 300, 364, 20), K tails (K = 300, 36, 4), every
+    tiles-per-wave variant.  NaN-filled outputs prove every element is written."""
+    from moleculesde_amd import hip
+    km = True
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    Bop = W.t().contiguous() if km else W
+    out = torch.full((M, N), float("nan"), device=dev)
+    Z = torch.full((M, N), float("nan"), device=dev)
+    hip.gemm_rs(A, Bop, out, bias=b, act="ssp", Z=Z, b_kmajor=km, fallback=False)
+    zr = A.double() @ W.double().t() + b.double()
+    assert_close(Z, zr, 1e-5, 2e-5, "gemm_rs pre-activation")
+    assert_close(out, _act_ref("ssp")(zr), 1e-5, 2e-5, "gemm_rs out")
+    out2 = torch.full((M, N), float("nan"), device=dev)
+    hip.gemm_rs(A, Bop, out2, bias=b, act="ssp", b_kmajor=km, fallback=False)
+    assert torch.equal(out, out2), "gemm_rs must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("act", [None, "silu", "ssp", "relu", "tanh"])
+def test_gemm_rs_epilogues(dev, act):
+    """Residual + accumulate into a column block of a wider buffer, and the input-gradient product through an activation
+    (EPI_DACT) with the residual gradient added -- against autograd."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 1000, 300, 300
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / 17).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    wide = torch.zeros(M, 364, device=dev)
+    base = torch.randn(M, N, generator=g).to(dev)
+    wide[:, 32:32 + N] = base
+    hip.gemm_rs(A, W.t().contiguous(), wide[:, 32:32 + N], bias=b, act=act, res=res, accumulate=True, b_kmajor=True,
+                fallback=False)
+    ref = base.double() + res.double() + _act_ref(act)(A.double() @ W.double().t() + b.double())
+    assert_close(wide[:, 32:32 + N], ref, 1e-5, 3e-5, f"rs residual+accumulate {act}")
+    assert float(wide[:, :32].abs().max()) == 0 and float(wide[:, 32 + N:].abs().max()) == 0
+    Wa = (torch.randn(64, K, generator=g) / 17).to(dev)
+    Wb = (torch.randn(40, 64, generator=g) / 8).to(dev)
+    x = A.clone().requires_grad_(True)
+    pre = x @ Wa.t()
+    y = _act_ref(act)(pre)
+    o = y @ Wb.t()
+    gO = torch.randn(M, 40, generator=g).to(dev)
+    (gpre_ref,) = torch.autograd.grad(o, pre, gO)
+    saved = pre.detach() if act in ("silu", "ssp") else y.detach()
+    r2 = torch.randn(M, 64, generator=g).to(dev)
+    gpre = torch.empty(M, 64, device=dev)
+    hip.gemm_rs(gO, Wb, gpre, b_kmajor=True, act=act, dact_from=saved if act else None, res=r2, fallback=False)
+    assert_close(gpre, gpre_ref.double() + r2.double(), 1e-4, 1e-5, f"rs dact {act}")
+
+
+@pytest.mark.parametrize("M,C1,C2,relu,bound", [(3588, 600, 300, True, None), (3588, 300, 600, False, None),
+                                                (35186, 300, 32, True, None), (200, 64, 48, True, 150),
+                                                (3648, 600, 300, True, 3588)])
+def test_gemm_rs_fused_batchnorm_chain(dev, M, C1, C2, relu, bound):
+    """x -> Linear(K0, C1) -> BatchNorm1d (training) -> [ReLU] -> Linear(C1, C2) with the statistics in the first product's
+    epilogue, msde_bn_fin_fwd, and the BatchNorm apply (+ ReLU) in the second product's A load; then the backward:
+    input-gradient product with the ReLU gate and the BatchNorm-backward partial sums in its epilogue, msde_bn_fin_bwd,
+    and the BatchNorm input gradient formed in the A load of the next input-gradient product.  Against torch CPU
+    autograd in fp64 of the same fp32 inputs.  `bound`: only the first `bound` rows are valid (capacity buckets)."""
+    from moleculesde_amd import hip, _lib
+    import ctypes
+    K0 = 128
+    torch.manual_seed(M + C1)
+    Mv = bound or M
+    x = torch.randn(M, K0)
+    W1 = torch.randn(C1, K0) / K0 ** 0.5
+    b1 = torch.randn(C1) * 0.1
+    gamma, beta = torch.randn(C1) * 0.3 + 1, torch.randn(C1) * 0.3
+    W2 = torch.randn(C2, C1) / C1 ** 0.5
+    gy = torch.randn(M, C2)
+    gy[Mv:] = 0
+    # reference (valid rows only)
+    xr = x[:Mv].double().requires_grad_(True)
+    W1r, b1r, gr, br, W2r = (t.double().requires_grad_(True) for t in (W1, b1, gamma, beta, W2))
+    z = xr @ W1r.t() + b1r
+    mu, var = z.mean(0), z.var(0, unbiased=False)
+    xhat = (z - mu) / torch.sqrt(var + 1e-5)
+    a = xhat * gr + br
+    if relu:
+        a = torch.relu(a)
+    y = a @ W2r.t()
+    y.backward(gy[:Mv].double())
+
+    xd, W1d, b1d, gd, bd, W2d, gyd = (t.to(dev) for t in (x, W1, b1, gamma, beta, W2, gy))
+    mvd = torch.tensor([Mv], dtype=torch.int32, device=dev) if bound else None
+    st = hip._stream()
+    p = hip._p
+    # forward
+    strips, srows = hip.rs_geometry(M, C1, K0)
+    stats = torch.full((strips, 2, C1), float("nan"), device=dev)
+    zd = torch.empty(M, C1, device=dev)
+    hip.gemm_rs(xd, W1d.t().contiguous(), zd, bias=b1d, stats=stats, stats_mode="bnfwd", m_valid=mvd, b_kmajor=True,
+                fallback=False)
+    scale, shift, smean, srstd = (torch.empty(C1, device=dev) for _ in range(4))
+    rm, rv = torch.zeros(C1, device=dev), torch.ones(C1, device=dev)
+    _lib.call("msde_bn_fin_fwd", p(stats), strips, srows, M, p(mvd), C1, p(gd), p(bd), 1e-5, 0.1, p(rm), p(rv), p(scale),
+              p(shift), p(smean), p(srstd), st)
+    ad = torch.full((M, C1), float("nan"), device=dev)
+    yd = torch.empty(M, C2, device=dev)
+    hip.gemm_rs(zd, W2d.t().contiguous(), yd, axf="affine", xf=(scale, shift), relu=relu, A_out=ad, m_valid=mvd,
+                b_kmajor=True, fallback=False)
+    assert_close(smean, mu.detach(), 1e-5, 1e-5, "fused bn mean")
+    assert_close(srstd, 1 / torch.sqrt(var.detach() + 1e-5), 1e-4, 1e-5, "fused bn rstd")
+    assert_close(ad[:Mv], a.detach(), 1e-4, 2e-5, "fused bn apply (A_out)")
+    assert_close(yd[:Mv], y.detach(), 1e-4, 5e-5, "fused bn chain out")
+    unb = var.detach() * Mv / max(Mv - 1, 1)
+    assert_close(rm, 0.1 * mu.detach(), 1e-5, 1e-6, "running mean")
+    assert_close(rv, 0.9 + 0.1 * unb, 1e-4, 1e-6, "running var")
+    # backward: g_a = gy W2 gated by the ReLU, with the BatchNorm-backward partial sums
+    strips2, _ = hip.rs_geometry(M, C1, C2)
+    stats2 = torch.full((strips2, 2, C1), float("nan"), device=dev)
+    gad = torch.empty(M, C1, device=dev)
+    hip.gemm_rs(gyd, W2d, gad, b_kmajor=True, act="relu" if relu else None, dact_from=ad if relu else None, stats=stats2,
+                stats_mode="bnbwd", stats_z=zd, stats_mean=smean, m_valid=mvd, fallback=False)
+    pv, wv, uv, dgam, dbet = (torch.empty(C1, device=dev) for _ in range(5))
+    _lib.call("msde_bn_fin_bwd", p(stats2), strips2, M, p(mvd), C1, p(gd), p(smean), p(srstd), p(pv), p(wv), p(uv), p(dgam),
+              p(dbet), st)
+    dzd = torch.full((M, C1), float("nan"), device=dev)
+    gxd = torch.empty(M, K0, device=dev)
+    hip.gemm_rs(gad, W1d, gxd, b_kmajor=True, axf="bnbwd", xf=(pv, wv, uv), A2=zd, A_out=dzd, m_valid=mvd, fallback=False)
+    # a pre-activation within rounding of the ReLU gate may fall on either side: compare away from it
+    apre = (xhat * gr + br).detach()
+    unsure = (apre.abs() <= 2e-5) if relu else torch.zeros_like(apre, dtype=torch.bool)
+    assert int(unsure.sum()) <= 1e-4 * unsure.numel() + 2
+    # an element on the gate boundary contributes its whole upstream gradient or nothing: allow for it column by column
+    ga_ref = (gy[:Mv].double() @ W2.double())
+    allow_b = (unsure * ga_ref.abs()).sum(0)
+    allow_g = (unsure * (ga_ref * xhat.detach()).abs()).sum(0)
+    for got, ref, allow, what in ((dgam, gr.grad, allow_g, "fused dgamma"), (dbet, br.grad, allow_b, "fused dbeta")):
+        err = (got.double().cpu() - ref).abs()
+        bnd = 2e-4 * ref.abs() + 2e-5 * float(ref.abs().max()) + 1e-6 + 1.01 * allow
+        assert bool((err <= bnd).all()), f"{what}: max excess {(err - bnd).max().item():.3e}"
+    if not bool(unsure.any()):
+        assert_close(gxd[:Mv], xr.grad, 2e-3, 2e-5 * float(xr.grad.abs().max()) + 1e-6, "fused bn chain dx")
+        gW1 = dzd[:Mv].double().cpu().t() @ x[:Mv].double()
+        assert_close(gW1, W1r.grad, 2e-3, 2e-5 * float(W1r.grad.abs().max()) + 1e-6, "dz (A_out) -> gW1")
