@@ -437,6 +437,32 @@ int msde_mlp_head_bwd_slabs(int E, int H);
 int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const float* g, int E, int H, int J, float* gZ, float* gWb,
                       float* workspace, void* stream);
 
+/* ------------------------------------------------------------------ CFConv on unordered atom pairs -- */
+/* SchNet's interaction graph (schnet.py:91-93: radius_graph over the molecule, 32-neighbour cap) is symmetric whenever the
+ * cap cannot bind (<= 33 atoms per molecule) and the continuous filter depends on the distance only (schnet.py:141-145,
+ * 185-195): the filter network runs once per UNORDERED pair (csrc/cfconv_pair.hip).  Pairs of molecule m, local atoms
+ * a < b of its n atoms: row pair_ptr[m] + a n - a (a + 1) / 2 + (b - a - 1); pair_ptr[B] = number of pairs.
+ * msde_pair_build: pair_ptr [B+1], pi / pj [P_cap] (batch-global atom indices, pi < pj), pd [P_cap] = |p_i - p_j|, or -1
+ * when d^2 >= r2 (no edge: its filter row is zero).  P_cap >= sum n (n - 1) / 2. */
+int msde_pair_build(const float* pos, const int* mol_ptr, int B, float r2, int* pair_ptr, int* pi, int* pj, float* pd,
+                    int P_cap, void* stream);
+/* Wf [P_cap, F] = (W2 ssp(W1 rbf(pd) + b1) + b2) * C(pd) for the first *count pairs (count = pair_ptr + B); F = 128,
+ * G <= 64; W1 [F][G], W2 [F][F] as nn.Linear stores them.  blocks_per_wg <= 0: chosen by the library. */
+int msde_cfconv_pair_filter(const float* pd, const int* count, const float* W1, const float* b1, const float* W2,
+                            const float* b2, const float* offset, int F, int G, int P_cap, float coeff, float cutoff,
+                            int blocks_per_wg, float* Wf, void* stream);
+/* out[i] = sum_{j != i in i's molecule} x[j] * Wf[pair(i, j)], ascending j (fixed order, no atomics): the CFConv message
+ * aggregation with x = x1, and -- the pair set and Wf being symmetric -- its input gradient with x = g_agg. */
+int msde_cfconv_pair_aggregate(const float* x, const float* Wf, const int* batch, const int* mol_ptr, const int* pair_ptr,
+                               int N, int B, int F, float* out, void* stream);
+/* Filter-network weight gradients over pairs: as msde_cfconv_fused_bwd_w with the rows (pi, pj, pd) and the two directions
+ * of a pair summed before the weight-gradient products; slab / workspace sizes from msde_cfconv_fused_bwd_w_slabs /
+ * _workspace_floats(P_cap, ...). */
+int msde_cfconv_pair_bwd_w(const float* g_agg, const float* x1, const float* pd, const int* count, const int* pi,
+                           const int* pj, const float* W1, const float* b1, const float* W2, const float* offset, int N,
+                           int F, int G, int P_cap, float coeff, float cutoff, int max_workgroups, float* gW1, float* gb1,
+                           float* gW2, float* gb2, float* workspace, void* stream);
+
 /* ------------------------------------------------------------------ 3D->2D dense score head -- */
 /* SDEModel3Dto2D_node_adj_dense.forward (SDE_model_3D_to_2D_node_adj_dense.py:101-179) with its
  * EdgeScoreNetwork_dense / NodeScoreNetwork_dense (invariant_scorenetwork_dense.py:74-93,118-131) on RAGGED data

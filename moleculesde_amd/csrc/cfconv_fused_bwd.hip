@@ -260,10 +260,13 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
 //     issue in their shadow); per-edge metadata runs two chunks ahead;
 //   * two barriers per chunk instead of four.
 // The only un-overlapped part of a chunk is recomputing pre1 (52 MFMAs) and the softplus / sigmoid that depends on it.
-template <int KK1, int DBG, bool W2R = false>
+// SYM (csrc/cfconv_pair.hip): the rows are UNORDERED atom pairs {src, dst}; the filter gradient of a pair is the sum over
+// both directions, g_pre2 = (g_agg[dst] x1[src] + g_agg[src] x1[dst]) C(d), formed before the weight-gradient products --
+// half the rows, half the matrix-core work.  A negative distance marks a pair beyond the cutoff (C = 0).
+template <int KK1, int DBG, bool W2R = false, bool SYM = false>
 __global__ void __launch_bounds__(256, 1)
 cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
-                               const int* __restrict__ rowptr, const int* __restrict__ src, const int* __restrict__ dst,
+                               const int* __restrict__ ecount, const int* __restrict__ src, const int* __restrict__ dst,
                                const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                                const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
                                float* __restrict__ slabs) {
@@ -287,7 +290,7 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
   const int lcol = lane & 31, lhalf = lane >> 5;
   const int col = wave * 32 + lcol;
 
-  const int E = rowptr[N];
+  const int E = ecount[0];                     // rows: radius edges (rowptr[N]) or pairs
   const int e_begin = min(blockIdx.x * cpw * CB_TE, E);
   const int e_end = min(e_begin + cpw * CB_TE, E);
   const int nchunks = (e_end - e_begin + CB_TE - 1) / CB_TE;
@@ -309,7 +312,7 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
       const int o = (c & 1) * CB_TE + tid;
       const bool ok = m_t >= 0;
       d_s[o] = ok ? m_d : 0.f;
-      c_s[o] = ok ? 0.5f * (cosf(m_d * PI_F / cutoff) + 1.0f) : 0.f;
+      c_s[o] = (ok && m_d >= 0.f) ? 0.5f * (cosf(m_d * PI_F / cutoff) + 1.0f) : 0.f;
       src_s[o] = max(m_s, 0) * (CB_F * 4);     // BYTE offset of the gathered row: one add per load in the gathers
       dst_s[o] = max(m_t, 0) * (CB_F * 4);
     }
@@ -368,6 +371,7 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
 
   // gathers of one chunk: x1[src] and g_agg[dst] for this lane's column and its 2 x 16 edge rows
   float nx[32], ng[32];
+  float nx2[SYM ? 32 : 1], ng2[SYM ? 32 : 1];   // SYM: the reverse direction x1[dst], g_agg[src]
   auto issue_gathers = [&](int c) {
     if (dbg & 1) return;
     const int* ss = src_s + (c & 1) * CB_TE;
@@ -383,6 +387,12 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
       ng[s] = at(g_agg, ts[row]);
       nx[16 + s] = at(x1, ss[32 + row]);
       ng[16 + s] = at(g_agg, ts[32 + row]);
+      if (SYM) {
+        nx2[SYM ? s : 0] = at(x1, ts[row]);
+        ng2[SYM ? s : 0] = at(g_agg, ss[row]);
+        nx2[SYM ? 16 + s : 0] = at(x1, ts[32 + row]);
+        ng2[SYM ? 16 + s : 0] = at(g_agg, ss[32 + row]);
+      }
     }
   };
   // Smearing tile of chunk c, 4 rows per call (`it` in [0, 16)): lane = column g, wave + 4 it = row, so the centre is a
@@ -421,8 +431,13 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int row = cb_row(s, lhalf);
-      gp0[s] = ng[s] * nx[s] * cs[row];
-      gp1[s] = ng[16 + s] * nx[16 + s] * cs[32 + row];
+      if (SYM) {
+        gp0[s] = fmaf(ng[s], nx[s], ng2[SYM ? s : 0] * nx2[SYM ? s : 0]) * cs[row];
+        gp1[s] = fmaf(ng[16 + s], nx[16 + s], ng2[SYM ? 16 + s : 0] * nx2[SYM ? 16 + s : 0]) * cs[32 + row];
+      } else {
+        gp0[s] = ng[s] * nx[s] * cs[row];
+        gp1[s] = ng[16 + s] * nx[16 + s] * cs[32 + row];
+      }
     }
   };
   // recompute pre1 = rbf W1^T + b1 of chunk c: h1 and g_pre2 -> LDS, sigmoid(pre1) -> registers
@@ -706,9 +721,9 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   }                                                                                                                   \
   if (w2reg)                                                                                                          \
     MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0, true>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, dist,  \
-                rowptr, src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace);                           \
+                rowptr + N, src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace);                       \
   else                                                                                                                \
-    MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, dist, rowptr, \
+    MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, dist, rowptr + N, \
                 src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
 #ifdef MSDE_CF_DIAG          // phase knock-outs of the pipelined kernel as separate instantiations (no run-time branches)
 #define CBP_DIAG(D_)                                                                                                  \
@@ -716,7 +731,7 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_bwd_w_pipe_kernel<26, D_>),                 \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp_bytes(26));                       \
     MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<26, D_>), dim3(nwg), dim3(256), ldsp_bytes(26), st, g_agg, x1, dist,    \
-                rowptr, src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace);                           \
+                rowptr + N, src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace);                       \
     MSDE_CHECK_LAUNCH();                                                                                              \
     return 0;
   if (cb_pipe() && kk1 == 26 && dbg) {
@@ -746,6 +761,53 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   if (gW1 == gW2 + (size_t)CB_F * CB_F && gb1 == gW1 + (size_t)CB_F * G && gb2 == gb1 + CB_F)
     return msde_reduce_slabs(workspace, nwg, slab_sz, gW2, nullptr, 0, nullptr, st);
   int blocks = (int)((slab_sz + 255) / 256);
+  MSDE_LAUNCH(cfconv_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, nwg, slab_sz, G, gW2,
+              gW1, gb1, gb2);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Pair form (csrc/cfconv_pair.hip): rows = unordered pairs (pi, pj, pd), *count of them valid; slabs / workspace sizes from
+// msde_cfconv_fused_bwd_w_slabs / _workspace_floats with E_cap = P_cap.  W2 as registers, pipelined kernel only.
+extern "C" int msde_cfconv_pair_bwd_w(const float* g_agg, const float* x1, const float* pd, const int* count, const int* pi,
+                                      const int* pj, const float* W1, const float* b1, const float* W2,
+                                      const float* offset, int N, int F, int G, int P_cap, float coeff, float cutoff,
+                                      int max_workgroups, float* gW1, float* gb1, float* gW2, float* gb2,
+                                      float* workspace, void* stream) {
+  const bool no_reduce = !gW1 && !gb1 && !gW2 && !gb2;
+  if (N < 0 || P_cap < 0 || !g_agg || !x1 || !pd || !count || !pi || !pj || !W1 || !b1 || !W2 || !offset || !workspace ||
+      (!no_reduce && (!gW1 || !gb1 || !gW2 || !gb2)))
+    return MSDE_EINVAL;
+  const int kk1 = (G + 1) / 2;
+  if (F != CB_F || G <= 0 || kk1 > 26) return MSDE_EUNSUP;
+  hipStream_t st = as_stream(stream);
+  int nwg, cpw;
+  cb_geometry(P_cap, max_workgroups, &nwg, &cpw);
+  auto ldsp_bytes = [](int KK1) {
+    return (size_t)(2 * (CB_TE * (2 * KK1 + 1) + 64) + 2 * CB_TE * CB_HS + 8 * CB_TE + 64) * sizeof(float);
+  };
+#define CBS_LAUNCH(KK)                                                                                                \
+  {                                                                                                                   \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_fused_bwd_w_pipe_kernel<KK, 0, true, true>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp_bytes(KK));           \
+      if (ae != hipSuccess) return (int)ae;                                                                           \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+  }                                                                                                                   \
+  MSDE_LAUNCH((cfconv_fused_bwd_w_pipe_kernel<KK, 0, true, true>), dim3(nwg), dim3(256), ldsp_bytes(KK), st, g_agg, x1, pd, \
+              count, pj, pi, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace)
+  if (kk1 == 26) { CBS_LAUNCH(26); }
+  else if (kk1 == 25) { CBS_LAUNCH(25); }
+  else { CBS_LAUNCH(24); }
+#undef CBS_LAUNCH
+  MSDE_CHECK_LAUNCH();
+  if (no_reduce) return 0;
+  const size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
+  if (gW1 == gW2 + (size_t)CB_F * CB_F && gb1 == gW1 + (size_t)CB_F * G && gb2 == gb1 + CB_F)
+    return msde_reduce_slabs(workspace, nwg, slab_sz, gW2, nullptr, 0, nullptr, st);
+  const int blocks = (int)((slab_sz + 255) / 256);
   MSDE_LAUNCH(cfconv_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, nwg, slab_sz, G, gW2,
               gW1, gb1, gb2);
   MSDE_CHECK_LAUNCH();

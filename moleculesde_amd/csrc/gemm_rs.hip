@@ -291,18 +291,22 @@ gemm_rsa_kernel(const msde_rs_desc d) {
 }
 
 // ===================================================================================================================
-// finishing kernels of the fused BatchNorm: one launch of C / 16 workgroups; 16 lanes per column merge the per-strip
-// partials in a fixed order (lane l takes strips l, l + 16, ...; the 16 lane results are merged in lane order).
+// finishing kernels of the fused BatchNorm: one launch of C / 16 workgroups; 16 lanes per column combine the per-strip
+// partials in a fixed order.
 // ===================================================================================================================
-__device__ __forceinline__ void rs_chan(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
-  if (nb > 0.f) {
-    const float nn = n + nb, dl = mb - mean;
-    mean += dl * (nb / nn);
-    m2 += m2b + dl * dl * (n * nb / nn);
-    n = nn;
-  }
+// Both kernels: 16 lanes per column; lane l owns strips l, l + 16, ... (up to FIN_PER_LANE kept in registers: all loads are
+// issued before anything is summed), lane partials are combined by a fixed butterfly (bitwise reproducible).
+#define FIN_PER_LANE 16      // strips <= 256 in registers; beyond that the tail is walked in a loop
+__device__ __forceinline__ float fin_lane_sum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
 }
 
+// Forward: strip partials (mean_s, M2_s) with n_s valid rows ->  mean = sum n_s mean_s / n,  M2 = sum M2_s + n_s (mean_s -
+// mean)^2 (two passes over the partials, no division per strip).
 __global__ void __launch_bounds__(256)
 bn_fin_fwd_kernel(const float* __restrict__ stats, int strips, int strip_rows, int M, const int* __restrict__ m_valid,
                   int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
@@ -310,32 +314,47 @@ bn_fin_fwd_kernel(const float* __restrict__ stats, int strips, int strip_rows, i
                   float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
   const int mv = m_valid ? min(M, m_valid[0]) : M;
   const int l = threadIdx.x & 15, col = blockIdx.x * 16 + (threadIdx.x >> 4);
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (col < C) {
-    for (int s = l; s < strips; s += 16) {
-      const float cnt = (float)max(0, min(strip_rows, mv - s * strip_rows));
-      rs_chan(n, mean, m2, cnt, stats[(size_t)s * 2 * C + col], stats[(size_t)s * 2 * C + C + col]);
-    }
-  }
-  // merge the 16 lanes of a column in lane order (all lanes take part in the shuffles)
-  float rn = 0.f, rmean = 0.f, rm2 = 0.f;
+  const int cc = min(col, C - 1);
+  float pm[FIN_PER_LANE], pq[FIN_PER_LANE], pn[FIN_PER_LANE];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const float nb = __shfl(n, (threadIdx.x & 48) + k, 64), mb = __shfl(mean, (threadIdx.x & 48) + k, 64);
-    const float qb = __shfl(m2, (threadIdx.x & 48) + k, 64);
-    rs_chan(rn, rmean, rm2, nb, mb, qb);
+  for (int k = 0; k < FIN_PER_LANE; ++k) {
+    const int s = l + 16 * k;
+    const bool ok = s < strips;
+    const size_t o = (size_t)(ok ? s : 0) * 2 * C + cc;
+    pm[k] = stats[o];
+    pq[k] = stats[o + C];
+    pn[k] = ok ? (float)max(0, min(strip_rows, mv - s * strip_rows)) : 0.f;
   }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < FIN_PER_LANE; ++k) sum = fmaf(pn[k], pn[k] > 0.f ? pm[k] : 0.f, sum);
+  for (int s = l + 16 * FIN_PER_LANE; s < strips; s += 16) {
+    const float n = (float)max(0, min(strip_rows, mv - s * strip_rows));
+    if (n > 0.f) sum = fmaf(n, stats[(size_t)s * 2 * C + cc], sum);
+  }
+  sum = fin_lane_sum16(sum);
+  const float n = (float)mv;
+  const float mean = mv > 0 ? sum / n : 0.f;
+  float m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < FIN_PER_LANE; ++k)
+    if (pn[k] > 0.f) { const float dl = pm[k] - mean; m2 += pq[k] + pn[k] * dl * dl; }
+  for (int s = l + 16 * FIN_PER_LANE; s < strips; s += 16) {
+    const float ns = (float)max(0, min(strip_rows, mv - s * strip_rows));
+    if (ns > 0.f) { const float dl = stats[(size_t)s * 2 * C + cc] - mean; m2 += stats[(size_t)s * 2 * C + C + cc] + ns * dl * dl; }
+  }
+  m2 = fin_lane_sum16(m2);
   if (col < C && l == 0) {
-    const float var = rn > 0.f ? rm2 / rn : 0.f;
+    const float var = mv > 0 ? m2 / n : 0.f;
     const float rstd = rsqrtf(var + eps);
     const float gv = gamma ? gamma[col] : 1.f, bv = beta ? beta[col] : 0.f;
     scale[col] = gv * rstd;
-    shift[col] = bv - rmean * gv * rstd;
-    save_mean[col] = rmean;
+    shift[col] = bv - mean * gv * rstd;
+    save_mean[col] = mean;
     save_rstd[col] = rstd;
     if (running_mean) {
-      const float unbiased = rn > 1.f ? rm2 / (rn - 1.f) : var;
-      running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * rmean;
+      const float unbiased = mv > 1 ? m2 / (n - 1.f) : var;
+      running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean;
       running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
     }
   }
@@ -348,15 +367,21 @@ bn_fin_bwd_kernel(const float* __restrict__ stats, int strips, int M, const int*
                   float* __restrict__ dbeta) {
   const int mv = m_valid ? min(M, m_valid[0]) : M;
   const int l = threadIdx.x & 15, col = blockIdx.x * 16 + (threadIdx.x >> 4);
-  float a = 0.f, b = 0.f;
-  if (col < C)
-    for (int s = l; s < strips; s += 16) { a += stats[(size_t)s * 2 * C + col]; b += stats[(size_t)s * 2 * C + C + col]; }
-  float ra = 0.f, rb = 0.f;
+  const int cc = min(col, C - 1);
+  float pa[FIN_PER_LANE], pb[FIN_PER_LANE];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    ra += __shfl(a, (threadIdx.x & 48) + k, 64);
-    rb += __shfl(b, (threadIdx.x & 48) + k, 64);
+  for (int k = 0; k < FIN_PER_LANE; ++k) {
+    const int s = l + 16 * k;
+    const bool ok = s < strips;
+    const size_t o = (size_t)(ok ? s : 0) * 2 * C + cc;
+    pa[k] = ok ? stats[o] : 0.f;
+    pb[k] = ok ? stats[o + C] : 0.f;
   }
+  float a = 0.f, b = 0.f;
+#pragma unroll
+  for (int k = 0; k < FIN_PER_LANE; ++k) { a += pa[k]; b += pb[k]; }
+  for (int s = l + 16 * FIN_PER_LANE; s < strips; s += 16) { a += stats[(size_t)s * 2 * C + cc]; b += stats[(size_t)s * 2 * C + C + cc]; }
+  const float ra = fin_lane_sum16(a), rb = fin_lane_sum16(b);
   if (col < C && l == 0) {
     const float rs = rstd[col], mu = mean[col], gv = gamma ? gamma[col] : 1.f;
     const float sum_g = ra, sum_gx = rb * rs;          // sum g', sum g' xhat

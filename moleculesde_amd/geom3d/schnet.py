@@ -90,6 +90,7 @@ class SchNet(nn.Module):
         nn.init.xavier_uniform_(self.lin2.weight)
         self.lin2.bias.data.fill_(0)
         self.use_fused = True      # False: decomposed path (rbf kernel + library GEMMs + aggregate kernels)
+        self.use_pairs = True      # False: per-edge fused kernels even where the pair form applies (cross-check)
 
     def _find_plan(self, z, batch):
         pl = _nn.lookup_plan(batch) if batch is not None else None
@@ -108,10 +109,17 @@ class SchNet(nn.Module):
         ptr, nodes = _plan.z_lists(pl, self.node_class)
         h = hip.embedding_sum(self.embedding.weight, pl.z_codes, ptr, nodes)
 
-        rplan, dist = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors)
         de = self.distance_expansion
         fusable = self.use_fused and self.num_filters == 128 and self.num_gaussians <= 64
         grad = torch.is_grad_enabled()
+        # molecules of at most 33 atoms: the 32-neighbour cap cannot bind, the radius graph is symmetric and CFConv runs on
+        # unordered pairs (half the filter-network work, no radius CSR at all); larger molecules keep the per-edge kernels
+        pairwise = (fusable and hip.CFCONV_PAIR and self.use_pairs and self.num_gaussians <= 52
+                    and pl.N_max <= self.max_num_neighbors + 1)
+        if pairwise:
+            pp = hip.pair_plan(pos, pl, self.cutoff)
+        else:
+            rplan, dist = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors)
         if not fusable:
             rbf, C = hip.rbf_cutoff(dist, rplan.E_dev, de.offset, de.coeff, self.cutoff)
 
@@ -119,7 +127,13 @@ class SchNet(nn.Module):
             # h feeds the block and the residual: the fork lets the block's input-gradient GEMM accumulate the
             # residual's gradient (no separate add in the backward)
             h_res, x1 = _nn.linear_fork(h, blk.conv.lin1.weight)
-            if fusable and grad:
+            if pairwise and grad:
+                agg = hip.cfconv_pair(x1, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias, pp,
+                                      de.offset, de.coeff, self.cutoff)
+            elif pairwise:
+                agg, _ = hip.cfconv_pair_forward(x1, pp, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
+                                                 blk.mlp[2].bias, de.offset, de.coeff, self.cutoff)
+            elif fusable and grad:
                 agg = hip.cfconv_fused(x1, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias,
                                        dist, rplan, de.offset, de.coeff, self.cutoff)
             elif fusable:

@@ -274,6 +274,114 @@ def cfconv_fused(x1, W1, b1, W2, b2, dist, plan, offset, coeff, cutoff):
     return _CFConvFused.apply(x1, W1, b1, W2, b2, dist, plan, offset, coeff, cutoff)
 
 
+# ---- CFConv on unordered atom pairs (csrc/cfconv_pair.hip) -----------------------------------------------------
+import os as _os_pair
+CFCONV_PAIR = _os_pair.environ.get("MSDE_CFCONV_PAIR", "1") != "0"     # A/B switch: CFConv on unordered pairs
+
+
+class PairPlan:
+    """Unordered atom pairs of every molecule (all a < b, row-major) with their distances; see msde_pair_build."""
+
+    __slots__ = ("P", "pair_ptr", "pi", "pj", "pd", "count", "B", "N", "mol_ptr", "batch_i32")
+
+
+def pair_capacity(pl):
+    """Host-side bound on the number of pairs of a batch plan: exact when the plan was built on the host, half the
+    radius-edge capacity for a capacity bucket (molecules of <= 33 atoms: every neighbour list is complete)."""
+    p2 = getattr(pl, "P2_cap", None)
+    return int(p2) if p2 is not None else (int(pl.E_r_cap) + 1) // 2
+
+
+def pair_plan(pos, pl, cutoff):
+    """Pair list + distances of the batch on the device, one launch, no host synchronisation (replaces the radius graph of
+    schnet.py:91-93 for molecules the 32-neighbour cap cannot bind on)."""
+    pos = _f32(pos.detach())
+    dev = pos.device
+    pp = PairPlan()
+    pp.P, pp.B, pp.N = pair_capacity(pl), int(pl.B), int(pos.size(0))
+    pp.mol_ptr, pp.batch_i32 = pl.mol_ptr, pl.batch_i32
+    pp.pair_ptr = torch.empty(pp.B + 1, dtype=torch.int32, device=dev)
+    n = max(pp.P, 1)
+    pp.pi = torch.empty(n, dtype=torch.int32, device=dev)
+    pp.pj = torch.empty(n, dtype=torch.int32, device=dev)
+    pp.pd = torch.empty(n, dtype=torch.float32, device=dev)
+    _lib.call("msde_pair_build", _p(pos), _p(pl.mol_ptr), pp.B, float(cutoff) * float(cutoff), _p(pp.pair_ptr), _p(pp.pi),
+              _p(pp.pj), _p(pp.pd), pp.P, _stream())
+    pp.count = pp.pair_ptr[pp.B:]
+    return pp
+
+
+def _pair_blocks_per_wg(P):
+    if CFCONV_FWD_WGS is None:
+        return 0
+    blocks = (P + 31) // 32
+    return max(1, -(-blocks // int(CFCONV_FWD_WGS)))
+
+
+def cfconv_pair_forward(x1, pp, W1, b1, W2, b2, offset, coeff, cutoff):
+    """(agg, Wf): filter rows per unordered pair on the matrix cores, then the fixed-order aggregation."""
+    x1 = _f32(x1)
+    N, Fd = x1.shape
+    G = W1.size(1)
+    st = _stream()
+    Wf = torch.empty(max(pp.P, 1), Fd, dtype=torch.float32, device=x1.device)
+    _lib.call("msde_cfconv_pair_filter", _p(pp.pd), _p(pp.count), _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)),
+              _p(_f32(offset)), Fd, G, pp.P, float(coeff), float(cutoff), _pair_blocks_per_wg(pp.P), _p(Wf), st)
+    agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
+    _lib.call("msde_cfconv_pair_aggregate", _p(x1), _p(Wf), _p(pp.batch_i32), _p(pp.mol_ptr), _p(pp.pair_ptr), N, pp.B, Fd,
+              _p(agg), st)
+    return agg, Wf
+
+
+class _CFConvPair(torch.autograd.Function):
+    """CFConv (schnet.py:141-145,185-195) on unordered pairs: forward = filter kernel + aggregation; backward = the same
+    aggregation applied to the incoming gradient (input gradient) and the pair form of the recomputing weight-gradient
+    kernel (both directions of a pair summed before its products)."""
+
+    @staticmethod
+    def forward(ctx, x1, W1, b1, W2, b2, pp, offset, coeff, cutoff):
+        x1, W1, b1, W2, b2 = _f32(x1), _f32(W1), _f32(b1), _f32(W2), _f32(b2)
+        agg, Wf = cfconv_pair_forward(x1, pp, W1, b1, W2, b2, offset, coeff, cutoff)
+        ctx.save_for_backward(x1, W1, b1, W2, Wf, offset)
+        ctx.pp, ctx.coeff, ctx.cutoff = pp, float(coeff), float(cutoff)
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, W1, b1, W2, Wf, offset = ctx.saved_tensors
+        pp = ctx.pp
+        g = _f32(g)
+        N, Fd = x1.shape
+        G = W1.size(1)
+        st = _stream()
+        g_x1 = None
+        if ctx.needs_input_grad[0]:
+            g_x1 = torch.empty_like(x1)
+            _lib.call("msde_cfconv_pair_aggregate", _p(g), _p(Wf), _p(pp.batch_i32), _p(pp.mol_ptr), _p(pp.pair_ptr), N, pp.B,
+                      Fd, _p(g_x1), st)
+        gall = torch.empty(Fd * Fd + Fd * G + 2 * Fd, dtype=torch.float32, device=g.device)
+        gW2 = gall[:Fd * Fd].view(Fd, Fd)
+        gW1 = gall[Fd * Fd:Fd * Fd + Fd * G].view(Fd, G)
+        gb1 = gall[Fd * Fd + Fd * G:Fd * Fd + Fd * G + Fd]
+        gb2 = gall[Fd * Fd + Fd * G + Fd:]
+        mw = int(CFCONV_BWD_WGS or 0)
+        args = (_p(g), _p(x1), _p(pp.pd), _p(pp.count), _p(pp.pi), _p(pp.pj), _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G,
+                pp.P, ctx.coeff, ctx.cutoff, mw)
+        if _SLABS.active:
+            nslab = int(_lib.load().msde_cfconv_fused_bwd_w_slabs(pp.P, mw))
+            ws = _SLABS.alloc(nslab * gall.numel(), g.device)
+            _lib.call("msde_cfconv_pair_bwd_w", *args, _p(None), _p(None), _p(None), _p(None), _p(ws), st)
+            _SLABS.add(ws.data_ptr(), nslab, gall.numel(), gall, written=True)
+        else:
+            ws = _cf_workspace(pp.P, G, x1.device, mw)
+            _lib.call("msde_cfconv_pair_bwd_w", *args, _p(gW1), _p(gb1), _p(gW2), _p(gb2), _p(ws), st)
+        return g_x1, gW1, gb1, gW2, gb2, None, None, None, None
+
+
+def cfconv_pair(x1, W1, b1, W2, b2, pp, offset, coeff, cutoff):
+    return _CFConvPair.apply(x1, W1, b1, W2, b2, pp, offset, coeff, cutoff)
+
+
 def edge_geometry(pos, plan, Wd, Wc):
     """Per-edge frame + Fourier features (SDE_model_2D_to_3D.py:35-66,342-369); no gradient: the
     perturbed coordinates do not depend on any parameter."""

@@ -51,6 +51,7 @@ def build_plan(data, atom_dims=None, bond_dims=None, max_nbr=32, with_ext=True):
     c = counts.cpu()
     pl.E_r_cap = int((c * torch.clamp(c - 1, max=max_nbr)).sum())
     pl.N_max = int(c.max()) if B > 0 else 0
+    pl.P2_cap = int((c * (c - 1) // 2).sum())      # unordered atom pairs (hip.pair_plan)
     pl.max_nbr = max_nbr
     # 2D atom codes (9 OGB columns) or 1-D z
     if x.dim() == 2:

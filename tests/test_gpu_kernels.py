@@ -293,6 +293,77 @@ def test_cfconv_fused_forward_and_backward(dev, G, cpw):
         assert_close(a.grad, r.grad, 1e-3, 2e-4 * float(r.grad.abs().max()), f"fused {name}")
 
 
+@pytest.mark.parametrize("G,cutoff,stretch,pad", [(51, 10.0, 1.0, 0), (50, 10.0, 1.0, 0), (20, 4.0, 1.0, 0), (51, 10.0, 2.5, 0),
+                                                  (51, 10.0, 1.0, 37)])
+def test_cfconv_pair_forward_and_backward(dev, G, cutoff, stretch, pad):
+    """CFConv on unordered pairs (csrc/cfconv_pair.hip: pair list, filter rows on the matrix cores, fixed-order
+    aggregation; backward = the same aggregation of the gradient + the pair form of the recomputing weight-gradient
+    kernel) vs autograd through the oracle's CFConv interior on the oracle's radius graph (schnet.py:91-93,141-145,
+    185-195).  A short cutoff / stretched coordinates put many pairs BEYOND the cutoff (their rows must contribute
+    nothing); `pad` appends atoms of the empty padding molecule as a capacity bucket does."""
+    from moleculesde_amd import hip, plan as P
+    torch.manual_seed(4)
+    b = _toy_graph(9, 40)
+    b.positions = b.positions * stretch
+    pl = P.plan_to(P.build_plan(b), dev)
+    N = b.x.size(0)
+    ei = R.radius_graph(b.positions, cutoff, b.batch)                    # oracle stand-in: [source; target], strict <
+    dvec = (b.positions[ei[0]] - b.positions[ei[1]]).norm(dim=-1)
+    full = int((torch.bincount(b.batch) * (torch.bincount(b.batch) - 1)).sum())
+    if cutoff < 10.0 or stretch > 1.0:
+        assert ei.size(1) < full, "this case is meant to have pairs beyond the cutoff"
+    blk = R.InteractionBlock(hidden_channels=64, num_gaussians=G, num_filters=128, cutoff=cutoff)
+    with torch.no_grad():
+        blk.mlp[0].bias.normal_(0, 0.1)
+        blk.mlp[2].bias.normal_(0, 0.1)
+    gs = R.GaussianSmearing(0.0, cutoff, G)
+    x1 = torch.randn(N, 128, requires_grad=True)
+    Cc = 0.5 * (torch.cos(dvec * math.pi / cutoff) + 1.0)
+    Wf_ref = blk.mlp(gs(dvec)) * Cc.view(-1, 1)
+    ref = R.scatter_sum(x1[ei[0]] * Wf_ref, ei[1], N)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    ps = [blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias]
+    pd = [q.detach().to(dev).requires_grad_(True) for q in ps]
+    pos_d = b.positions.to(dev)
+    x1_full = x1.detach()
+    w_full = w
+    if pad:      # capacity padding: extra atoms owned by molecule B (no pairs), larger pair capacity
+        pl.batch_i32 = torch.cat([pl.batch_i32, torch.full((pad,), pl.B, dtype=torch.int32, device=dev)])
+        pl.mol_ptr = torch.cat([pl.mol_ptr, torch.tensor([N + pad], dtype=torch.int32, device=dev)])[:pl.B + 1]
+        pos_d = torch.cat([pos_d, torch.randn(pad, 3, device=dev)])
+        x1_full = torch.cat([x1_full, torch.randn(pad, 128)])
+        w_full = torch.cat([w, torch.randn(pad, 128)])
+        pl.P2_cap = pl.P2_cap + 100
+    x1d = x1_full.to(dev).requires_grad_(True)
+    pp = hip.pair_plan(pos_d, pl, cutoff)
+    assert int(pp.count[0]) == full // 2
+    out = hip.cfconv_pair(x1d, pd[0], pd[1], pd[2], pd[3], pp, gs.offset.to(dev), gs.coeff, cutoff)
+    out2, Wf = hip.cfconv_pair_forward(x1d.detach(), pp, pd[0].detach(), pd[1].detach(), pd[2].detach(), pd[3].detach(),
+                                       gs.offset.to(dev), gs.coeff, cutoff)
+    scale = float(ref.abs().max())
+    assert_close(out[:N], ref.detach(), 1e-4, 1e-4 * scale, "pair cfconv fwd")
+    assert torch.equal(out, out2), "bitwise reproducible"
+    if pad:
+        assert float(out[N:].abs().max()) == 0.0
+    # filter rows: pair (i < j) against the oracle's edge j -> i
+    key = {(int(a), int(c)): k for k, (a, c) in enumerate(zip(ei[0].tolist(), ei[1].tolist()))}
+    P2 = int(pp.count[0])
+    pi, pj, pdist = pp.pi[:P2].cpu().tolist(), pp.pj[:P2].cpu().tolist(), pp.pd[:P2].cpu()
+    rows = torch.zeros(P2, 128)
+    for k, (a, c) in enumerate(zip(pi, pj)):
+        assert a < c
+        e = key.get((c, a))
+        assert (e is None) == (float(pdist[k]) < 0), "pairs beyond the cutoff carry distance -1"
+        if e is not None:
+            rows[k] = Wf_ref[e].detach()
+    assert_close(Wf[:P2], rows, 1e-4, 1e-5, "pair filter rows")
+    (out * w_full.to(dev)).sum().backward()
+    assert_close(x1d.grad[:N], x1.grad, 1e-4, 1e-4 * float(x1.grad.abs().max()), "pair g_x1")
+    for name, a, r in zip(("gW1", "gb1", "gW2", "gb2"), pd, ps):
+        assert_close(a.grad, r.grad, 1e-3, 2e-4 * float(r.grad.abs().max()), f"pair {name}")
+
+
 def test_edge_geometry(dev):
     from moleculesde_amd import hip
     torch.manual_seed(6)
