@@ -23,6 +23,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define RS_KB 32                                  // k per block
 #define RS_PAD 4                                  // LDS row stride = Kpad + 4 floats (4 mod 32: see rs_lds_ld)
+#ifndef RS_STAGES
+#define RS_STAGES 3                               // register stages of the operand pipeline (rsa_mma)
+#endif
 
 __device__ __forceinline__ f32x4 rs_mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -79,7 +82,6 @@ __device__ __forceinline__ void rsa_mma(const float* __restrict__ As, int ld, co
   const unsigned off0 = ((unsigned)(8 * g) * (unsigned)ldb + (unsigned)(wcol + W0 * n)) * 4u;
   const unsigned off1 = ((unsigned)(8 * g) * (unsigned)ldb + (unsigned)(wcol + 16 * W0 + W1 * n)) * 4u;
   const unsigned rowb = (unsigned)ldb * 4u;          // bytes per k row (uniform)
-  float b0[8][T], b1[8][T];
   auto ld_seg = [&](unsigned voff, unsigned soff, float (&dst)[T], int first, int w) {
     if (w == 4) {
       const rs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
@@ -116,30 +118,42 @@ __device__ __forceinline__ void rsa_mma(const float* __restrict__ As, int ld, co
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[c][r] = rs_mfma(rs_f4(a[r][j >> 2], j & 3), b[j][c], acc[c][r]);
   };
-  // Software pipeline, two blocks per trip: the operands of block kb + 1 are requested BEFORE the MFMAs of block kb.  The
-  // scheduling barriers keep hipcc from sinking the requests down to their first use (it did: every load sat behind a
-  // vmcnt(0) next to its MFMA).  The block after the last one is clamped to the last (one redundant request at the end).
-  float4 a0[RT][2], a1[RT][2];
-  loadB(blk(0), b0);
+  // Software pipeline with NS register stages: the operands of block kb + NS - 1 are requested BEFORE the MFMAs of block
+  // kb, so a request has NS - 1 blocks of matrix work (8 T RT MFMAs each) to come back.  The scheduling barriers keep
+  // hipcc from sinking the requests down to their first use (it did: every load sat behind a vmcnt(0) next to its
+  // MFMA).  Blocks past the last one are clamped to the last (a few redundant requests at the very end).
+  constexpr int NS = RS_STAGES;
+  float bq[NS][8][T];
+  float4 aq[NS][RT][2];
+  const int last = nkb - 1;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) loadB(blk(min(s, last)), bq[s]);
   if (SYNC) {
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
-  readA(blk(0), a0);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) readA(blk(min(s, last)), aq[s]);
   int kb = 0;
-  for (; kb + 1 < nkb; kb += 2) {
-    loadB(blk(kb + 1), b1);
-    readA(blk(kb + 1), a1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    loadB(blk(min(kb + 2, nkb - 1)), b0);
-    readA(blk(min(kb + 2, nkb - 1)), a0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
+  for (; kb + NS <= nkb; kb += NS) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int nx = min(kb + s + NS - 1, last);
+      loadB(blk(nx), bq[(s + NS - 1) % NS]);
+      readA(blk(nx), aq[(s + NS - 1) % NS]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(aq[s], bq[s]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  if (kb < nkb) mfmas(a0, b0);                       // odd number of blocks: the last one is in (a0, b0)
+  // the remaining 0 .. NS - 1 blocks are already in flight: stage s holds block kb + s
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    if (kb + s < nkb) {
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(aq[s], bq[s]);
+    }
+  }
 }
 
 // Stage a strip of `rows` x K floats of a row-major matrix into LDS (zero beyond M / K) through `xf(v, k, row)`:
