@@ -184,6 +184,19 @@ int msde_gin_aggregate_bwd_x(const float* g, const float* x, const float* tab, c
  * tables are summed in a fixed order (deterministic, no atomics).  2*R*D*4 bytes must fit LDS (<= 64 KiB).
  * workspace: msde_gin_aggregate_bwd_tab_workspace_floats(N, E, D, R) floats. */
 long long msde_gin_aggregate_bwd_tab_workspace_floats(int N, int E, int D, int R);
+/* msde_gin_aggregate_fwd on the layer input h = max(z scale[c] + shift[c], 0 if relu): the outer BatchNorm (+ ReLU) of the
+ * previous GIN layer (molecule_gnn_model.py:176-182; scale / shift from msde_bn_fin_fwd) applied on the fly to the gathered
+ * rows; h itself is written to h_out.  D % 4 == 0. */
+int msde_gin_aggregate_bn_fwd(const float* z, const float* scale, const float* shift, int relu, const float* tab,
+                              const int* codes, const float* eps, const int* rowptr, const int* src, int N, int D,
+                              float* h_out, float* out, void* stream);
+/* msde_gin_aggregate_bwd_x that also emits the BatchNorm-backward partial sums of its result for the previous layer's outer
+ * BatchNorm: stats [ceil(N/16)][2][D] = per 16-row strip (sum g', sum g' (zprev - mean)), g' = g_x gated by x > 0 when
+ * relu; rows >= *m_valid contribute nothing (input of msde_bn_fin_bwd).  D % 4 == 0. */
+int msde_gin_aggregate_bwd_x_stats(const float* g, const float* x, const float* tab, const int* codes, const float* eps,
+                                   const int* rowptr_s, const int* perm_s, const int* dst, int N, const int* m_valid,
+                                   int D, const float* zprev, const float* mean, int relu, float* g_x, float* stats,
+                                   void* stream);
 /* With g_tab == g_eps == NULL the call only leaves msde_gin_aggregate_bwd_tab_slabs(N,E) partial tables
  * [slabs][R*D] followed by [slabs] eps partials in `workspace` (for msde_reduce_slabs_multi). */
 int msde_gin_aggregate_bwd_tab_slabs(int N, int E);

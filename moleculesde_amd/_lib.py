@@ -34,6 +34,8 @@ SIGNATURES = {
     "msde_embedding_sum_bwd": [P, P, P, I, I, I, P, P, P],
     "msde_gin_aggregate_fwd": [P, P, P, P, P, P, I, I, P, P],
     "msde_gin_aggregate_bwd_x": [P, P, P, P, P, P, P, P, I, I, P, P],
+    "msde_gin_aggregate_bn_fwd": [P, P, P, I, P, P, P, P, P, I, I, P, P, P],
+    "msde_gin_aggregate_bwd_x_stats": [P, P, P, P, P, P, P, P, I, P, I, P, P, I, P, P, P],
     "msde_gin_aggregate_bwd_tab_workspace_floats": [I, I, I, I],
     "msde_gin_aggregate_bwd_tab": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],
     "msde_rbf_cutoff_fwd": [P, P, I, I, P, F, F, P, P, P],

@@ -217,6 +217,10 @@ __device__ __forceinline__ void rs_epilogue(const msde_rs_desc& d, f32x4 (&acc)[
 //                     msde_bn_fin_bwd (c1 = mean g', c2 = mean g' xhat)
 // The transformed strip is optionally written back once (A_out, by the workgroup of column split 0): the weight gradient's
 // operand.  All 256 threads, 16-B pieces, coalesced along k; zero beyond M / K.
+// Every global load of a batch of rows is issued before the first result is used: written as a plain loop (run-time bounds,
+// one load -> transform -> store per trip) the strip cost 5 (K = 300) to 12 (K = 600) DEPENDENT memory round trips per
+// thread -- several microseconds in front of every product.  Wave w stages rows w, w + 4, ...; lanes cover the 16-B pieces
+// q = lane, lane + 64, lane + 128 of a row (K <= 768), two rows per batch.
 template <int MODE>
 __device__ __forceinline__ void rs_stage_mode(const msde_rs_desc& d, bool writer, float* __restrict__ As, int ld, int m0,
                                               int rows) {
@@ -224,34 +228,75 @@ __device__ __forceinline__ void rs_stage_mode(const msde_rs_desc& d, bool writer
   const int K = d.K, M = d.M, kq = rs_kpad(K) / 4;
   const bool relu = (d.flags & MSDE_RS_AXF_RELU) != 0;
   float* __restrict__ out = writer ? d.A_out : nullptr;
-  for (int r = wave; r < rows; r += 4) {
-    const int gm = m0 + r;
-    for (int q = lane; q < kq; q += 64) {
-      const int k = 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gm < M && k < K) {
-        v = *reinterpret_cast<const float4*>(d.A + (size_t)gm * d.lda + k);
-        if (MODE == MSDE_RS_AXF_AFFINE) {
-          const float4 sv = *reinterpret_cast<const float4*>(d.xf0 + k), tv = *reinterpret_cast<const float4*>(d.xf1 + k);
-          v = make_float4(fmaf(v.x, sv.x, tv.x), fmaf(v.y, sv.y, tv.y), fmaf(v.z, sv.z, tv.z), fmaf(v.w, sv.w, tv.w));
-          if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-        } else if (MODE == MSDE_RS_AXF_BNBWD) {
-          const float4 z = *reinterpret_cast<const float4*>(d.A2 + (size_t)gm * d.lda2 + k);
-          const float4 pv = *reinterpret_cast<const float4*>(d.xf0 + k), wv = *reinterpret_cast<const float4*>(d.xf1 + k);
-          const float4 uv = *reinterpret_cast<const float4*>(d.xf2 + k);
-          if (d.xf3) {
-            const float4 sv = *reinterpret_cast<const float4*>(d.xf3 + k), tv = *reinterpret_cast<const float4*>(d.xf4 + k);
-            v.x = fmaf(z.x, sv.x, tv.x) > 0.f ? v.x : 0.f;
-            v.y = fmaf(z.y, sv.y, tv.y) > 0.f ? v.y : 0.f;
-            v.z = fmaf(z.z, sv.z, tv.z) > 0.f ? v.z : 0.f;
-            v.w = fmaf(z.w, sv.w, tv.w) > 0.f ? v.w : 0.f;
-          }
-          v = make_float4(fmaf(pv.x, v.x, fmaf(wv.x, z.x, uv.x)), fmaf(pv.y, v.y, fmaf(wv.y, z.y, uv.y)),
-                          fmaf(pv.z, v.z, fmaf(wv.z, z.z, uv.z)), fmaf(pv.w, v.w, fmaf(wv.w, z.w, uv.w)));
-        }
-        if (MODE != MSDE_RS_AXF_NONE && out) *reinterpret_cast<float4*>(out + (size_t)gm * d.lda_out + k) = v;
+  constexpr int NQ = 3, NR = 2;
+  if (kq > 64 * NQ) {          // very long rows: simple loop
+    for (int r = wave; r < rows; r += 4) {
+      const int gm = m0 + r;
+      for (int q = lane; q < kq; q += 64) {
+        const int k = 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gm < M && k < K) v = *reinterpret_cast<const float4*>(d.A + (size_t)gm * d.lda + k);
+        *reinterpret_cast<float4*>(As + r * ld + k) = v;      // (transforms are not offered for K > 768)
       }
-      *reinterpret_cast<float4*>(As + r * ld + k) = v;
+    }
+    return;
+  }
+  // per-column vectors of the transform: once per lane
+  float4 x0[NQ], x1[NQ], x2[NQ], x3[NQ], x4[NQ];
+  const bool gate = MODE == MSDE_RS_AXF_BNBWD && d.xf3 != nullptr;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int k = 4 * (lane + 64 * j);
+    const bool in = k < K;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    x0[j] = (MODE != MSDE_RS_AXF_NONE && in) ? *reinterpret_cast<const float4*>(d.xf0 + k) : zero;
+    x1[j] = (MODE != MSDE_RS_AXF_NONE && in) ? *reinterpret_cast<const float4*>(d.xf1 + k) : zero;
+    x2[j] = (MODE == MSDE_RS_AXF_BNBWD && in) ? *reinterpret_cast<const float4*>(d.xf2 + k) : zero;
+    x3[j] = (gate && in) ? *reinterpret_cast<const float4*>(d.xf3 + k) : zero;
+    x4[j] = (gate && in) ? *reinterpret_cast<const float4*>(d.xf4 + k) : zero;
+  }
+  for (int rb = wave; rb < rows; rb += 4 * NR) {
+    float4 v[NR][NQ], z[NR][NQ];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int gm = m0 + rb + 4 * i;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int k = 4 * (lane + 64 * j);
+        const bool ok = rb + 4 * i < rows && gm < M && k < K;
+        v[i][j] = ok ? *reinterpret_cast<const float4*>(d.A + (size_t)gm * d.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == MSDE_RS_AXF_BNBWD)
+          z[i][j] = ok ? *reinterpret_cast<const float4*>(d.A2 + (size_t)gm * d.lda2 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = rb + 4 * i, gm = m0 + r;
+      if (r >= rows) continue;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int q = lane + 64 * j, k = 4 * q;
+        if (q >= kq) continue;
+        float4 a = v[i][j];
+        const bool ok = gm < M && k < K;
+        if (ok && MODE == MSDE_RS_AXF_AFFINE) {
+          a = make_float4(fmaf(a.x, x0[j].x, x1[j].x), fmaf(a.y, x0[j].y, x1[j].y), fmaf(a.z, x0[j].z, x1[j].z),
+                          fmaf(a.w, x0[j].w, x1[j].w));
+          if (relu) a = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+        } else if (ok && MODE == MSDE_RS_AXF_BNBWD) {
+          const float4 zz = z[i][j];
+          if (gate) {
+            a.x = fmaf(zz.x, x3[j].x, x4[j].x) > 0.f ? a.x : 0.f;
+            a.y = fmaf(zz.y, x3[j].y, x4[j].y) > 0.f ? a.y : 0.f;
+            a.z = fmaf(zz.z, x3[j].z, x4[j].z) > 0.f ? a.z : 0.f;
+            a.w = fmaf(zz.w, x3[j].w, x4[j].w) > 0.f ? a.w : 0.f;
+          }
+          a = make_float4(fmaf(x0[j].x, a.x, fmaf(x1[j].x, zz.x, x2[j].x)), fmaf(x0[j].y, a.y, fmaf(x1[j].y, zz.y, x2[j].y)),
+                          fmaf(x0[j].z, a.z, fmaf(x1[j].z, zz.z, x2[j].z)), fmaf(x0[j].w, a.w, fmaf(x1[j].w, zz.w, x2[j].w)));
+        }
+        if (MODE != MSDE_RS_AXF_NONE && out && ok) *reinterpret_cast<float4*>(out + (size_t)gm * d.lda_out + k) = a;
+        *reinterpret_cast<float4*>(As + r * ld + k) = a;
+      }
     }
   }
 }
@@ -527,6 +572,7 @@ extern "C" int msde_gemm_rs(const msde_rs_desc* desc, void* stream) {
   if (d.K % 4 || d.lda % 4 || !rs_al16(d.A)) return MSDE_EUNSUP;
   if ((size_t)d.K * (size_t)d.ldb >= (1u << 30)) return MSDE_EUNSUP;       // 32-bit element offsets of B
   if (d.epi == MSDE_EPI_DACT && d.act != MSDE_ACT_NONE && !d.R) return MSDE_EINVAL;
+  if (d.axf != MSDE_RS_AXF_NONE && d.K > 768) return MSDE_EUNSUP;          // transforms are staged with <= 3 pieces per lane
   if (d.axf == MSDE_RS_AXF_AFFINE && (!d.xf0 || !d.xf1 || !rs_al16(d.xf0) || !rs_al16(d.xf1))) return MSDE_EINVAL;
   if (d.axf == MSDE_RS_AXF_BNBWD && (!d.A2 || !d.xf0 || !d.xf1 || !d.xf2 || d.lda2 % 4 || !rs_al16(d.A2))) return MSDE_EINVAL;
   if (d.A_out && (d.lda_out % 4 || !rs_al16(d.A_out))) return MSDE_EINVAL;

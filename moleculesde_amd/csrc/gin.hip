@@ -88,6 +88,143 @@ __global__ void gin_aggregate_bwd_x_kernel(const float* __restrict__ g, const fl
   }
 }
 
+// ---- variants fused with the BatchNorm of the PREVIOUS layer (csrc/gemm_rs.hip; D % 4 == 0) ---------------------
+// Forward: the layer input is h = max(z scale[c] + shift[c], 0 if relu) of the previous layer's second product z (its
+// outer BatchNorm, molecule_gnn_model.py:176-182): applied on the fly to every gathered row and to the node's own row,
+// which is also written out (h_out) -- the separate BatchNorm-apply launch of the layer disappears.
+__global__ void __launch_bounds__(256)
+gin_aggregate_bn_fwd_kernel(const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+                            int relu, const float* __restrict__ tab, const int* __restrict__ codes,
+                            const float* __restrict__ eps, const int* __restrict__ rowptr, const int* __restrict__ src,
+                            int N, int cols, float* __restrict__ h_out, float* __restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= N) return;
+  const float4* Z = reinterpret_cast<const float4*>(z);
+  const float4* Tb = reinterpret_cast<const float4*>(tab);
+  const float ope = 1.f + eps[0];
+  const int s0 = rowptr[i], s1 = rowptr[i + 1];
+  for (int c = lane; c < cols; c += 64) {
+    const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+    auto hrow = [&](int j) {
+      float4 v = vfma(Z[(size_t)j * cols + c], sc, sh);
+      return relu ? vrelu(v) : v;
+    };
+    float4 acc = vzero4();
+    int e = s0;
+    for (; e + 1 < s1; e += 2) {
+      const int j0 = src[e], j1 = src[e + 1];
+      const int a0 = codes[3 * e], a1 = codes[3 * e + 1], a2 = codes[3 * e + 2];
+      const int b0 = codes[3 * e + 3], b1 = codes[3 * e + 4], b2 = codes[3 * e + 5];
+      const float4 x0 = hrow(j0), x1 = hrow(j1);
+      const float4 t0 = Tb[(size_t)a0 * cols + c], t1 = Tb[(size_t)a1 * cols + c], t2 = Tb[(size_t)a2 * cols + c];
+      const float4 u0 = Tb[(size_t)b0 * cols + c], u1 = Tb[(size_t)b1 * cols + c], u2 = Tb[(size_t)b2 * cols + c];
+      acc = vadd(acc, vrelu(vadd(x0, vadd(vadd(t0, t1), t2))));
+      acc = vadd(acc, vrelu(vadd(x1, vadd(vadd(u0, u1), u2))));
+    }
+    for (; e < s1; ++e) acc = vadd(acc, vrelu(vadd(hrow(src[e]), bond_emb<4>(Tb, codes, e, cols, c))));
+    const float4 hi = hrow(i);
+    reinterpret_cast<float4*>(h_out)[(size_t)i * cols + c] = hi;
+    reinterpret_cast<float4*>(out)[(size_t)i * cols + c] = vadd(vscale(hi, ope), acc);
+  }
+}
+
+// Backward w.r.t. the layer input + the BatchNorm-backward partial sums of that gradient for the previous layer's outer
+// BatchNorm: per 16-row strip and column, sum g' and sum g' (z - mean[c]) with g' = g_x gated by x > 0 when `relu` (x is
+// that BatchNorm's ReLU output) -- the [strips][2][D] format msde_bn_fin_bwd takes.  One workgroup = 16 rows.
+__global__ void __launch_bounds__(256)
+gin_aggregate_bwd_x_stats_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ tab,
+                                 const int* __restrict__ codes, const float* __restrict__ eps,
+                                 const int* __restrict__ rowptr_s, const int* __restrict__ perm_s,
+                                 const int* __restrict__ dst, int N, const int* __restrict__ m_valid, int cols,
+                                 const float* __restrict__ zprev, const float* __restrict__ mean, int relu,
+                                 float* __restrict__ g_x, float* __restrict__ stats) {
+  extern __shared__ float red[];                  // [3 groups][2][4 cols]
+  const int grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int mv = m_valid ? min(N, m_valid[0]) : N;
+  const float4* X = reinterpret_cast<const float4*>(x);
+  const float4* G = reinterpret_cast<const float4*>(g);
+  const float4* Tb = reinterpret_cast<const float4*>(tab);
+  const float4* Zp = reinterpret_cast<const float4*>(zprev);
+  const float ope = 1.f + eps[0];
+  const int D = cols * 4;
+  for (int c = lane, ci = 0; c < cols; c += 64, ++ci) {
+    const float4 mu = reinterpret_cast<const float4*>(mean)[c];
+    float4 sa = vzero4(), sb = vzero4();
+    for (int it = 0; it < 4; ++it) {
+      const int j = blockIdx.x * 16 + it * 4 + grp;
+      if (j >= N) continue;
+      const float4 xj = X[(size_t)j * cols + c];
+      float4 acc = vscale(G[(size_t)j * cols + c], ope);
+      const int s0 = rowptr_s[j], s1 = rowptr_s[j + 1];
+      int sidx = s0;
+      for (; sidx + 1 < s1; sidx += 2) {
+        const int e0 = perm_s[sidx], e1 = perm_s[sidx + 1];
+        const int d0 = dst[e0], d1 = dst[e1];
+        const int a0 = codes[3 * e0], a1 = codes[3 * e0 + 1], a2 = codes[3 * e0 + 2];
+        const int b0 = codes[3 * e1], b1 = codes[3 * e1 + 1], b2 = codes[3 * e1 + 2];
+        const float4 g0 = G[(size_t)d0 * cols + c], g1 = G[(size_t)d1 * cols + c];
+        const float4 t0 = Tb[(size_t)a0 * cols + c], t1 = Tb[(size_t)a1 * cols + c], t2 = Tb[(size_t)a2 * cols + c];
+        const float4 u0 = Tb[(size_t)b0 * cols + c], u1 = Tb[(size_t)b1 * cols + c], u2 = Tb[(size_t)b2 * cols + c];
+        acc = vadd(acc, vgate(g0, vadd(xj, vadd(vadd(t0, t1), t2))));
+        acc = vadd(acc, vgate(g1, vadd(xj, vadd(vadd(u0, u1), u2))));
+      }
+      for (; sidx < s1; ++sidx) {
+        const int e = perm_s[sidx];
+        acc = vadd(acc, vgate(G[(size_t)dst[e] * cols + c], vadd(xj, bond_emb<4>(Tb, codes, e, cols, c))));
+      }
+      reinterpret_cast<float4*>(g_x)[(size_t)j * cols + c] = acc;
+      if (j < mv) {
+        const float4 gp = relu ? vgate(acc, xj) : acc;
+        const float4 zz = Zp[(size_t)j * cols + c];
+        sa = vadd(sa, gp);
+        sb = vfma(gp, make_float4(zz.x - mu.x, zz.y - mu.y, zz.z - mu.z, zz.w - mu.w), sb);
+      }
+    }
+    // groups 1..3 hand their sums to group 0 (fixed order)
+    float* slot = red + ((size_t)(grp > 0 ? grp - 1 : 0) * 2) * D;
+    if (grp > 0) {
+      reinterpret_cast<float4*>(slot)[c] = sa;
+      reinterpret_cast<float4*>(slot + D)[c] = sb;
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        sa = vadd(sa, reinterpret_cast<const float4*>(red + (size_t)k * 2 * D)[c]);
+        sb = vadd(sb, reinterpret_cast<const float4*>(red + (size_t)k * 2 * D + D)[c]);
+      }
+      reinterpret_cast<float4*>(stats + (size_t)blockIdx.x * 2 * D)[c] = sa;
+      reinterpret_cast<float4*>(stats + (size_t)blockIdx.x * 2 * D + D)[c] = sb;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int msde_gin_aggregate_bn_fwd(const float* z, const float* scale, const float* shift, int relu, const float* tab,
+                                         const int* codes, const float* eps, const int* rowptr, const int* src, int N,
+                                         int D, float* h_out, float* out, void* stream) {
+  if (N < 0 || D <= 0 || D % 4 || !z || !scale || !shift || !tab || !eps || !rowptr || !h_out || !out) return MSDE_EINVAL;
+  if (N == 0) return 0;
+  MSDE_LAUNCH(gin_aggregate_bn_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), z, scale, shift, relu, tab, codes,
+              eps, rowptr, src, N, D / 4, h_out, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_gin_aggregate_bwd_x_stats(const float* g, const float* x, const float* tab, const int* codes,
+                                              const float* eps, const int* rowptr_s, const int* perm_s, const int* dst,
+                                              int N, const int* m_valid, int D, const float* zprev, const float* mean,
+                                              int relu, float* g_x, float* stats, void* stream) {
+  if (N < 0 || D <= 0 || D % 4 || !g || !x || !tab || !eps || !rowptr_s || !zprev || !mean || !g_x || !stats)
+    return MSDE_EINVAL;
+  if (N == 0) return 0;
+  MSDE_LAUNCH(gin_aggregate_bwd_x_stats_kernel, dim3((N + 15) / 16), dim3(256), (size_t)3 * 2 * D * sizeof(float),
+              as_stream(stream), g, x, tab, codes, eps, rowptr_s, perm_s, dst, N, m_valid, D / 4, zprev, mean, relu, g_x,
+              stats);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 // Bond-table and eps gradients, deterministic and free of global atomics.  Block b owns GT_EC consecutive
 // edges (canonical by-target order) and a slice of the nodes; thread t owns column t (+ blockDim, ...) of the
 // LDS copies of the table (for the ReLU gate x[src] + emb > 0) and of the block's partial gradient table, so

@@ -11,6 +11,7 @@ from . import nn as _nn
 
 import os as _os
 FUSE_GIN_LAYER = _os.environ.get("MSDE_FUSE_GIN", "1") != "0"     # A/B switch: BatchNorm folded into the GIN products
+FUSE_GIN_APPLY = _os.environ.get("MSDE_FUSE_GIN_APPLY", "1") != "0"   # ... and its apply into the next layer's aggregation
 
 
 class GINConv(nn.Module):
@@ -25,16 +26,16 @@ class GINConv(nn.Module):
         self.eps = nn.Parameter(torch.Tensor([0]))
         self.bond_encoder = _nn.EmbeddingList(bond_dims, emb_dim, "bond_embedding_list")
 
-    def forward(self, x, bond_plan, bond_codes, outer_bn=None):
+    def forward(self, x, bond_plan, bond_codes, outer_bn=None, link=None, defer_apply=False):
         """outer_bn: the layer's BatchNorm of GNN.batch_norms (molecule_gnn_model.py:176-182).  Given in training mode,
         the whole Linear -> BatchNorm -> ReLU -> Linear -> BatchNorm (-> ReLU) chain runs as hip.gin_mlp_bn (statistics
         and normalisation folded into the products) and the result already includes outer_bn."""
-        agg = hip.gin_aggregate(x, self.bond_encoder.table(), self.eps, bond_plan, bond_codes)
+        agg = hip.gin_aggregate(x, self.bond_encoder.table(), self.eps, bond_plan, bond_codes, link)
         if outer_bn is None:
             return self.mlp(agg)
         for bn in (self.mlp[1], outer_bn):
             _nn.count_batch(bn)
-        return hip.gin_mlp_bn(agg, self.mlp[0], self.mlp[1], self.mlp[3], outer_bn, outer_bn.fuse_relu)
+        return hip.gin_mlp_bn(agg, self.mlp[0], self.mlp[1], self.mlp[3], outer_bn, outer_bn.fuse_relu, defer_apply)
 
 
 class GNN(nn.Module):
@@ -88,13 +89,23 @@ class GNN(nn.Module):
             h.register_hook(lambda g_: (cb(), None)[1])
         h_list = [h]
         fused = FUSE_GIN_LAYER and self.training and h.is_cuda and h.size(1) % 4 == 0 and 0 < h.size(0) <= hip.RS_MAX_ROWS
+        # a layer output that only the next layer's aggregation reads (JK = last, no dropout) is never normalised by a launch
+        # of its own: the aggregation kernel applies the BatchNorm while it gathers
+        lazy_ok = fused and FUSE_GIN_APPLY and self.JK == "last" and self.drop_ratio == 0
+        link = None
         for layer in range(self.num_layer):
             if fused and _nn.bn_fusable(self.gnns[layer].mlp[1]) and _nn.bn_fusable(self.batch_norms[layer]):
-                h = self.gnns[layer](h_list[layer], pl.bond, pl.bond_codes, self.batch_norms[layer])
+                defer = lazy_ok and layer + 1 < self.num_layer
+                out = self.gnns[layer](h_list[layer], pl.bond, pl.bond_codes, self.batch_norms[layer], link, defer)
+                h, link = out if defer else (out, None)
             else:
+                if link is not None:           # the previous layer deferred its BatchNorm apply: do it now
+                    hip.bn_apply_link(h_list[layer], link)
+                    link = None
                 h = self.gnns[layer](h_list[layer], pl.bond, pl.bond_codes)
                 h = self.batch_norms[layer](h)             # ReLU fused for all but the last layer
-            h = F.dropout(h, self.drop_ratio, training=self.training)
+            if self.drop_ratio > 0:
+                h = F.dropout(h, self.drop_ratio, training=self.training)
             h_list.append(h)
 
         if self.JK == "concat":

@@ -442,29 +442,57 @@ def embedding_sum(tab, codes, list_ptr, list_nodes):
     return _EmbeddingSum.apply(tab, codes, list_ptr, list_nodes)
 
 
+# The aggregation backward can also emit the BatchNorm-backward partial sums of its result (msde_gin_aggregate_bwd_x_stats).
+# Measured slower than the separate 6 us column-statistics launch: strips of 16 rows leave 225 workgroups walking four
+# dependent gather chains each (27.7 us against 13.0 + 6.4; step 2.91 vs 2.86 ms), so it is off.
+GIN_BWD_STATS = _os_pair.environ.get("MSDE_GIN_BWD_STATS", "0") != "0"
+
+
+class BnLink:
+    """What a fused GIN layer hands to the NEXT layer's aggregation so that its outer BatchNorm (+ ReLU) is applied on the
+    fly there instead of by a launch of its own (hip._GinMlpBN with defer_apply): z = the second product, vec = scale |
+    shift | mean | rstd.  The next layer's aggregation backward leaves the BatchNorm-backward partial sums in `stats`."""
+
+    __slots__ = ("z", "vec", "relu", "stats")
+
+    def __init__(self, z, vec, relu):
+        self.z, self.vec, self.relu, self.stats = z, vec, bool(relu), None
+
+
 class _GinAggregate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, tab, eps, plan, codes):
+    def forward(ctx, x, tab, eps, plan, codes, link=None):
         x, tab, eps = _f32(x), _f32(tab), _f32(eps)
         N, D = x.shape
         out = torch.empty_like(x)
-        _lib.call("msde_gin_aggregate_fwd", _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr), _p(plan.src), N, D,
-                  _p(out), _stream())
+        if link is not None:
+            # x is allocated but NOT yet written: this kernel forms it from link.z and writes it
+            _lib.call("msde_gin_aggregate_bn_fwd", _p(link.z), _p(link.vec[0]), _p(link.vec[1]), int(link.relu), _p(tab),
+                      _p(codes), _p(eps), _p(plan.rowptr), _p(plan.src), N, D, _p(x), _p(out), _stream())
+        else:
+            _lib.call("msde_gin_aggregate_fwd", _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr), _p(plan.src), N, D,
+                      _p(out), _stream())
         ctx.save_for_backward(x, tab, eps, codes)
-        ctx.plan = plan
+        ctx.plan, ctx.link = plan, link
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, tab, eps, codes = ctx.saved_tensors
-        plan = ctx.plan
+        plan, link = ctx.plan, ctx.link
         g = _f32(g)
         N, D = x.shape
         R = tab.size(0)
         st = _stream()
         g_x = torch.empty_like(x)
-        _lib.call("msde_gin_aggregate_bwd_x", _p(g), _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr_s),
-                  _p(plan.perm_s), _p(plan.dst), N, D, _p(g_x), st)
+        if link is not None and GIN_BWD_STATS:
+            link.stats = torch.empty((N + 15) // 16, 2, D, dtype=torch.float32, device=x.device)
+            _lib.call("msde_gin_aggregate_bwd_x_stats", _p(g), _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr_s),
+                      _p(plan.perm_s), _p(plan.dst), N, _p(bound_tensor(N)), D, _p(link.z), _p(link.vec[2]), int(link.relu),
+                      _p(g_x), _p(link.stats), st)
+        else:
+            _lib.call("msde_gin_aggregate_bwd_x", _p(g), _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr_s),
+                      _p(plan.perm_s), _p(plan.dst), N, D, _p(g_x), st)
         g_tab = torch.empty_like(tab)
         g_eps = torch.empty(1, dtype=torch.float32, device=x.device)
         nfl = int(_lib.load().msde_gin_aggregate_bwd_tab_workspace_floats(N, plan.E, D, R))
@@ -488,12 +516,19 @@ class _GinAggregate(torch.autograd.Function):
             ws = _scratch(nfl, x.device)
             _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N,
                       plan.E, D, R, _p(g_tab), _p(g_eps), _p(ws), st)
-        return g_x, g_tab, g_eps, None, None
+        return g_x, g_tab, g_eps, None, None, None
 
 
-def gin_aggregate(x, tab, eps, plan, codes):
-    """(1+eps) x_i + sum_j relu(x_j + bond_emb(e_ji))  (molecule_gnn_model.py:22-29)."""
-    return _GinAggregate.apply(x, tab, eps, plan, codes)
+def bn_apply_link(h, link):
+    """Materialise a deferred BatchNorm output (see BnLink) with a launch of its own."""
+    M, D = link.z.shape
+    _lib.call("msde_affine_cols", _p(link.z), M, D, _p(link.vec[0]), _p(link.vec[1]), int(link.relu), _p(h), _stream())
+
+
+def gin_aggregate(x, tab, eps, plan, codes, link=None):
+    """(1+eps) x_i + sum_j relu(x_j + bond_emb(e_ji))  (molecule_gnn_model.py:22-29).  link: x is the not yet applied
+    BatchNorm output of the previous fused layer (BnLink)."""
+    return _GinAggregate.apply(x, tab, eps, plan, codes, link)
 
 
 class _CFConvAggregate(torch.autograd.Function):
@@ -2174,7 +2209,7 @@ class _GinMlpBN(torch.autograd.Function):
     gradient formed in the A load of the next one.  Forward 5 launches, backward 5 (+ the queued weight gradients)."""
 
     @staticmethod
-    def forward(ctx, agg, W1, b1, g1, be1, rm1, rv1, W2, b2, g2, be2, rm2, rv2, eps1, mom1, eps2, mom2, relu_out):
+    def forward(ctx, agg, W1, b1, g1, be1, rm1, rv1, W2, b2, g2, be2, rm2, rv2, eps1, mom1, eps2, mom2, relu_out, link_out):
         agg = _f32(agg)
         M, D = agg.shape
         H = W1.size(0)
@@ -2193,7 +2228,13 @@ class _GinMlpBN(torch.autograd.Function):
                 b_kmajor=True, N=D, K=H, fallback=False)
         v2 = _bn_fin_fwd(st2, s2, r2, M, D, g2, be2, eps2, mom2, rm2, rv2)
         h = torch.empty(M, D, dtype=torch.float32, device=dev)
-        _lib.call("msde_affine_cols", _p(z2), M, D, _p(v2[0]), _p(v2[1]), int(relu_out), _p(h), _stream())
+        if link_out is not None:
+            # the next layer's aggregation applies this BatchNorm while it gathers (and fills h): no launch here
+            link_out.append(BnLink(z2, v2, relu_out))
+            ctx.link = link_out[0]
+        else:
+            _lib.call("msde_affine_cols", _p(z2), M, D, _p(v2[0]), _p(v2[1]), int(relu_out), _p(h), _stream())
+            ctx.link = None
         ctx.save_for_backward(agg, z1, a1, z2, h, v1, v2, W1, W2, g1, g2)
         ctx.relu_out = bool(relu_out)
         ctx.deferrable = all(t.is_leaf or getattr(t, "_msde_leaf_like", False) for t in (W1, b1, W2, b2))
@@ -2209,10 +2250,14 @@ class _GinMlpBN(torch.autograd.Function):
         st = _stream()
         # BatchNorm 2 backward: partial sums of the incoming gradient (gated by the output ReLU), finished, and the input
         # gradient formed while the next product loads its A strip
-        sb = (M + 63) // 64
-        stb = torch.empty(sb, 2, D, dtype=torch.float32, device=dev)
-        _lib.call("msde_bn_bwd_colstats", _p(g), _p(z2), _p(h if ctx.relu_out else None), _p(v2[2]), M, _p(bound_tensor(M)), D,
-                  _p(stb), st)
+        if ctx.link is not None and ctx.link.stats is not None:
+            stb, ctx.link.stats = ctx.link.stats, None      # left by the next layer's aggregation backward
+            sb = stb.size(0)
+        else:
+            sb = (M + 63) // 64
+            stb = torch.empty(sb, 2, D, dtype=torch.float32, device=dev)
+            _lib.call("msde_bn_bwd_colstats", _p(g), _p(z2), _p(h if ctx.relu_out else None), _p(v2[2]), M,
+                      _p(bound_tensor(M)), D, _p(stb), st)
         pw2, gb2 = _bn_fin_bwd(stb, sb, M, D, g2, v2[2], v2[3])
         # g_a1 = dz2 W2, gated by the ReLU behind BatchNorm 1 (a1 > 0), with BatchNorm 1's partial sums
         sa, _ = rs_geometry(M, H, D)
@@ -2235,15 +2280,19 @@ class _GinMlpBN(torch.autograd.Function):
         gW2, gbias2 = weight_grad(dz2, a1, True, ctx.deferrable)
         gW1, gbias1 = weight_grad(dz1, agg, True, ctx.deferrable)
         return (g_agg, gW1, gbias1, gb1[0], gb1[1], None, None, gW2, gbias2, gb2[0], gb2[1], None, None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
-def gin_mlp_bn(agg, lin1, bn1, lin2, bn2, relu_out):
-    """mlp(agg) followed by the layer's outer BatchNorm (+ ReLU) -- see _GinMlpBN.  Modules give the parameters."""
-    return _GinMlpBN.apply(agg, lin1.weight, lin1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
-                           lin2.weight, lin2.bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
-                           bn1.eps, 0.1 if bn1.momentum is None else bn1.momentum, bn2.eps,
-                           0.1 if bn2.momentum is None else bn2.momentum, relu_out)
+def gin_mlp_bn(agg, lin1, bn1, lin2, bn2, relu_out, defer_apply=False):
+    """mlp(agg) followed by the layer's outer BatchNorm (+ ReLU) -- see _GinMlpBN.  Modules give the parameters.
+    defer_apply: returns (h, link) with h allocated but NOT yet written; the caller must pass (h, link) to the next
+    layer's hip.gin_aggregate, whose kernel applies the BatchNorm on the fly and fills h."""
+    box = [] if defer_apply else None
+    h = _GinMlpBN.apply(agg, lin1.weight, lin1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                        lin2.weight, lin2.bias, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var,
+                        bn1.eps, 0.1 if bn1.momentum is None else bn1.momentum, bn2.eps,
+                        0.1 if bn2.momentum is None else bn2.momentum, relu_out, box)
+    return (h, box[0]) if defer_apply else h
 
 
 class _SchNetTail(torch.autograd.Function):
