@@ -36,50 +36,76 @@ __device__ __forceinline__ float rs_dact(int act, float r) {
   }
 }
 
-// Epilogue of one wave: T tiles x RT row tiles of 16 x 16 accumulators.  C/D map of v_mfma_f32_16x16x4_f32: lane-column
-// i = lane & 15, row = 4 (lane >> 4) + e for element e; the column of lane-column i of tile c is rs_col<T>(wcol, c, i)
-// (interleaved inside a segment, gemm_rs.h).  Uniform switches are hoisted out of the element loops.
-template <int RT, int T>
-__device__ __forceinline__ void rs_epilogue(const msde_rs_desc& d, f32x4 (&acc)[T][RT], int wcol, int m0, int strip,
-                                            int strip_rows) {
-  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
-  const int M = d.M, N = d.N;
-  // 1. bias, pre-activation store
+// W consecutive floats: one 16-B / 8-B access when the buffer allows it (`vec`), else scalar
+template <int W> __device__ __forceinline__ void rs_ldw(const float* __restrict__ p, float (&o)[4], bool vec) {
+  if (W == 4 && vec) { const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+  else if (W == 2 && vec) { const float2 v = *reinterpret_cast<const float2*>(p); o[0] = v.x; o[1] = v.y; }
+  else {
 #pragma unroll
-  for (int c = 0; c < T; ++c) {
-    const int col = rs_col<T>(wcol, c, n);
-    const float bv = (d.bias && col < N) ? d.bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[c][r][e] += bv;
+    for (int t = 0; t < W; ++t) o[t] = p[t];
   }
-  if (d.Z) {
+}
+template <int W> __device__ __forceinline__ void rs_stw(float* __restrict__ p, const float (&o)[4], bool vec) {
+  if (W == 4 && vec) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  else if (W == 2 && vec) *reinterpret_cast<float2*>(p) = make_float2(o[0], o[1]);
+  else {
 #pragma unroll
-    for (int c = 0; c < T; ++c) {
-      const int col = rs_col<T>(wcol, c, n);
+    for (int t = 0; t < W; ++t) p[t] = o[t];
+  }
+}
+
+// One column segment of the epilogue: W interleaved tiles starting at tile F; the lane's W values of an output row are W
+// CONSECUTIVE columns, so bias, saved activations (R), residual, statistics input and the stores all move as vectors.
+// C/D map of v_mfma_f32_16x16x4_f32: lane-column i = lane & 15, row = 4 (lane >> 4) + e for element e.  Every uniform
+// choice (activation, derivative, residual, accumulate, statistics) is made ONCE, outside the element loops: a chain of
+// scalar branches per element cost the plain products a microsecond.
+template <int RT, int T, int W, int F>
+__device__ __forceinline__ void rs_epi_segment(const msde_rs_desc& d, f32x4 (&acc)[T][RT], int colb, int m0, int strip,
+                                               int strip_rows) {
+  const int lane = threadIdx.x & 63, g = lane >> 4;
+  const int M = d.M, N = d.N;
+  if (colb >= N) return;                          // (N % W == 0: a lane's W columns are all inside or all outside)
+  const bool vec = (d.flags & MSDE_RS_VEC_STORE) != 0;
+  const int row0 = m0 + 4 * g;                    // row of (r, e) = row0 + 16 r + e
+  // 1. bias
+  if (d.bias) {
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    rs_ldw<W>(d.bias + colb, bv, vec);
+#pragma unroll
+    for (int t = 0; t < W; ++t)
 #pragma unroll
       for (int r = 0; r < RT; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = m0 + r * 16 + 4 * g + e;
-          if (row < M && col < N) d.Z[(size_t)row * d.ldz + col] = acc[c][r][e];
-        }
-    }
+        for (int e = 0; e < 4; ++e) acc[F + t][r][e] += bv[t];
   }
-  // 2. activation / derivative
+  // 2. pre-activation store
+  if (d.Z) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = row0 + 16 * r + e;
+        if (row < M) {
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < W; ++t) v[t] = acc[F + t][r][e];
+          rs_stw<W>(d.Z + (size_t)row * d.ldz + colb, v, vec);
+        }
+      }
+  }
+  // 3. activation / derivative
   if (d.act != MSDE_ACT_NONE) {
     if (d.epi == MSDE_EPI_DACT) {
-#define RS_DACT(ACT_)                                                                                        \
-  case ACT_:                                                                                                 \
-    _Pragma("unroll") for (int c = 0; c < T; ++c) {                                                          \
-      const int col = rs_col<T>(wcol, c, n);                                                                 \
-      _Pragma("unroll") for (int r = 0; r < RT; ++r) _Pragma("unroll") for (int e = 0; e < 4; ++e) {         \
-        const int row = m0 + r * 16 + 4 * g + e;                                                             \
-        const float rv = (row < M && col < N) ? d.R[(size_t)row * d.ldr + col] : 0.f;                        \
-        acc[c][r][e] *= rs_dact(ACT_, rv);                                                                   \
-      }                                                                                                      \
-    }                                                                                                        \
+#define RS_DACT(ACT_)                                                                                          \
+  case ACT_:                                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r) _Pragma("unroll") for (int e = 0; e < 4; ++e) {             \
+      const int row = row0 + 16 * r + e;                                                                       \
+      if (row < M) {                                                                                           \
+        float rv[4];                                                                                           \
+        rs_ldw<W>(d.R + (size_t)row * d.ldr + colb, rv, vec);                                                  \
+        _Pragma("unroll") for (int t = 0; t < W; ++t) acc[F + t][r][e] *= rs_dact(ACT_, rv[t]);                \
+      }                                                                                                        \
+    }                                                                                                          \
     break;
       switch (d.act) {
         RS_DACT(MSDE_ACT_TANH) RS_DACT(MSDE_ACT_SILU) RS_DACT(MSDE_ACT_ELU) RS_DACT(MSDE_ACT_SSP) RS_DACT(MSDE_ACT_RELU)
@@ -88,10 +114,10 @@ __device__ __forceinline__ void rs_epilogue(const msde_rs_desc& d, f32x4 (&acc)[
       }
 #undef RS_DACT
     } else {
-#define RS_ACT(ACT_)                                                                                         \
-  case ACT_:                                                                                                 \
-    _Pragma("unroll") for (int c = 0; c < T; ++c) _Pragma("unroll") for (int r = 0; r < RT; ++r)             \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[c][r][e] = rs_act(ACT_, acc[c][r][e]);             \
+#define RS_ACT(ACT_)                                                                                           \
+  case ACT_:                                                                                                   \
+    _Pragma("unroll") for (int t = 0; t < W; ++t) _Pragma("unroll") for (int r = 0; r < RT; ++r)               \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[F + t][r][e] = rs_act(ACT_, acc[F + t][r][e]);       \
     break;
       switch (d.act) {
         RS_ACT(MSDE_ACT_TANH) RS_ACT(MSDE_ACT_SILU) RS_ACT(MSDE_ACT_ELU) RS_ACT(MSDE_ACT_SSP) RS_ACT(MSDE_ACT_RELU)
@@ -100,114 +126,115 @@ __device__ __forceinline__ void rs_epilogue(const msde_rs_desc& d, f32x4 (&acc)[
 #undef RS_ACT
     }
   }
-  // 3. residual, accumulate, store: a lane's W values of a segment are W consecutive floats of the output row
-  const bool accum = (d.flags & MSDE_GEMM_ACCUMULATE) != 0;
-  const bool vec = (d.flags & MSDE_RS_VEC_STORE) != 0;
-  constexpr int NSEG = RsSeg<T>::NSEG;
-#pragma unroll
-  for (int sg = 0; sg < NSEG; ++sg) {
-    constexpr int W0 = RsSeg<T>::W[0];
-    const int W = sg == 0 ? W0 : RsSeg<T>::W[1];
-    const int f = sg == 0 ? 0 : W0;                               // first tile of the segment
-    const int colb = wcol + (sg == 0 ? 0 : 16 * W0) + W * n;       // first of the lane's W columns
+  // 4. residual, accumulate, store
+  if (!d.Res && !(d.flags & MSDE_GEMM_ACCUMULATE)) {
 #pragma unroll
     for (int r = 0; r < RT; ++r)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int row = m0 + r * 16 + 4 * g + e;
-        if (row >= M) continue;
-        if (W == 4 && vec) {
-          if (colb < N) {
-            float4 v = make_float4(acc[f][r][e], acc[f + 1 < T ? f + 1 : f][r][e], acc[f + 2 < T ? f + 2 : f][r][e],
-                                   acc[f + 3 < T ? f + 3 : f][r][e]);
-            if (d.Res) {
-              const float4 q = *reinterpret_cast<const float4*>(d.Res + (size_t)row * d.ldres + colb);
-              v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-            }
-            float4* dst = reinterpret_cast<float4*>(d.C + (size_t)row * d.ldc + colb);
-            if (accum) { const float4 q = *dst; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-            *dst = v;
-            acc[f][r][e] = v.x;
-            if (f + 1 < T) acc[f + 1][r][e] = v.y;
-            if (f + 2 < T) acc[f + 2][r][e] = v.z;
-            if (f + 3 < T) acc[f + 3][r][e] = v.w;
-          }
-        } else if (W == 2 && vec) {
-          if (colb < N) {
-            float2 v = make_float2(acc[f][r][e], acc[f + 1 < T ? f + 1 : f][r][e]);
-            if (d.Res) {
-              const float2 q = *reinterpret_cast<const float2*>(d.Res + (size_t)row * d.ldres + colb);
-              v.x += q.x; v.y += q.y;
-            }
-            float2* dst = reinterpret_cast<float2*>(d.C + (size_t)row * d.ldc + colb);
-            if (accum) { const float2 q = *dst; v.x += q.x; v.y += q.y; }
-            *dst = v;
-            acc[f][r][e] = v.x;
-            if (f + 1 < T) acc[f + 1][r][e] = v.y;
-          }
-        } else {
+        const int row = row0 + 16 * r + e;
+        if (row < M) {
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            if (t < W && f + t < T && colb + t < N) {
-              float v = acc[f + t][r][e];
-              if (d.Res) v += d.Res[(size_t)row * d.ldres + colb + t];
-              float* dst = d.C + (size_t)row * d.ldc + colb + t;
-              if (accum) v += *dst;
-              *dst = v;
-              acc[f + t][r][e] = v;
-            }
+          for (int t = 0; t < W; ++t) v[t] = acc[F + t][r][e];
+          rs_stw<W>(d.C + (size_t)row * d.ldc + colb, v, vec);
+        }
+      }
+  } else {
+    const bool accum = (d.flags & MSDE_GEMM_ACCUMULATE) != 0;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = row0 + 16 * r + e;
+        if (row < M) {
+          float v[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < W; ++t) v[t] = acc[F + t][r][e];
+          if (d.Res) {
+            rs_ldw<W>(d.Res + (size_t)row * d.ldres + colb, q, vec);
+#pragma unroll
+            for (int t = 0; t < W; ++t) v[t] += q[t];
           }
+          float* dst = d.C + (size_t)row * d.ldc + colb;
+          if (accum) {
+            rs_ldw<W>(dst, q, vec);
+#pragma unroll
+            for (int t = 0; t < W; ++t) v[t] += q[t];
+          }
+          rs_stw<W>(dst, v, vec);
+#pragma unroll
+          for (int t = 0; t < W; ++t) acc[F + t][r][e] = v[t];
         }
       }
   }
-  // 4. per-strip column statistics of what was stored, over the VALID rows of the strip
-  if (d.stats) {
-    const int mv = d.m_valid ? min(M, d.m_valid[0]) : M;
+  if (!d.stats) return;
+  // 5. per-strip column statistics of what was stored, over the VALID rows of the strip
+  const int mv = d.m_valid ? min(M, d.m_valid[0]) : M;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (d.stats_mode == MSDE_RS_STATS_BNFWD) {        // mean, then squared deviations from it
     const int cnt = max(0, min(strip_rows, mv - m0));
-    float* __restrict__ out = d.stats + (size_t)strip * 2 * N;
 #pragma unroll
-    for (int c = 0; c < T; ++c) {
-      const int col = rs_col<T>(wcol, c, n);
-      float s0 = 0.f, s1 = 0.f;
-      if (d.stats_mode == MSDE_RS_STATS_BNFWD) {
+    for (int t = 0; t < W; ++t) {
+      float a = 0.f;
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) s0 += (m0 + r * 16 + 4 * g + e < mv) ? acc[c][r][e] : 0.f;
-        s0 += __shfl_xor(s0, 16, 64);
-        s0 += __shfl_xor(s0, 32, 64);
-        const float mean = cnt > 0 ? s0 / (float)cnt : 0.f;
+        for (int e = 0; e < 4; ++e) a += (row0 + 16 * r + e < mv) ? acc[F + t][r][e] : 0.f;
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      const float mean = cnt > 0 ? a / (float)cnt : 0.f;
+      float q = 0.f;
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+      for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float dv = acc[c][r][e] - mean;
-            s1 += (m0 + r * 16 + 4 * g + e < mv) ? dv * dv : 0.f;
-          }
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        s0 = mean;
-      } else {                                       // MSDE_RS_STATS_BNBWD: sum g, sum g (z - mean[col])
-        const float mu = col < N ? d.stats_mean[col] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const float dv = acc[F + t][r][e] - mean;
+          q += (row0 + 16 * r + e < mv) ? dv * dv : 0.f;
+        }
+      q += __shfl_xor(q, 16, 64);
+      q += __shfl_xor(q, 32, 64);
+      s0[t] = mean;
+      s1[t] = q;
+    }
+  } else {                                           // MSDE_RS_STATS_BNBWD: sum g, sum g (z - mean[col])
+    float mu[4] = {0.f, 0.f, 0.f, 0.f};
+    rs_ldw<W>(d.stats_mean + colb, mu, vec);
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+    for (int r = 0; r < RT; ++r)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = m0 + r * 16 + 4 * g + e;
-            if (row < mv && col < N) {
-              const float gv = acc[c][r][e];
-              s0 += gv;
-              s1 = fmaf(gv, d.stats_z[(size_t)row * d.ld_sz + col] - mu, s1);
-            }
-          }
-        s0 += __shfl_xor(s0, 16, 64);
-        s0 += __shfl_xor(s0, 32, 64);
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
+      for (int e = 0; e < 4; ++e) {
+        const int row = row0 + 16 * r + e;
+        if (row < mv) {
+          float zz[4];
+          rs_ldw<W>(d.stats_z + (size_t)row * d.ld_sz + colb, zz, vec);
+#pragma unroll
+          for (int t = 0; t < W; ++t) { s0[t] += acc[F + t][r][e]; s1[t] = fmaf(acc[F + t][r][e], zz[t] - mu[t], s1[t]); }
+        }
       }
-      if (g == 0 && col < N) { out[col] = s0; out[N + col] = s1; }
+#pragma unroll
+    for (int t = 0; t < W; ++t) {
+      s0[t] += __shfl_xor(s0[t], 16, 64);
+      s0[t] += __shfl_xor(s0[t], 32, 64);
+      s1[t] += __shfl_xor(s1[t], 16, 64);
+      s1[t] += __shfl_xor(s1[t], 32, 64);
     }
   }
+  if (g == 0) {
+    float* __restrict__ out = d.stats + (size_t)strip * 2 * N;
+    rs_stw<W>(out + colb, s0, vec);
+    rs_stw<W>(out + N + colb, s1, vec);
+  }
+}
+
+// Epilogue of one wave: T tiles x RT row tiles of 16 x 16 accumulators, segment by segment (gemm_rs.h: RsSeg).
+template <int RT, int T>
+__device__ __forceinline__ void rs_epilogue(const msde_rs_desc& d, f32x4 (&acc)[T][RT], int wcol, int m0, int strip,
+                                            int strip_rows) {
+  const int n = threadIdx.x & 15;
+  constexpr int W0 = RsSeg<T>::W[0], W1 = RsSeg<T>::W[1];
+  rs_epi_segment<RT, T, W0, 0>(d, acc, wcol + W0 * n, m0, strip, strip_rows);
+  if (RsSeg<T>::NSEG > 1) rs_epi_segment<RT, T, (W1 > 0 ? W1 : 1), (W1 > 0 ? W0 : 0)>(d, acc, wcol + 16 * W0 + W1 * n, m0, strip, strip_rows);
 }
 
 // ---- A transforms on load -----------------------------------------------------------------------------------------
@@ -587,7 +614,10 @@ extern "C" int msde_gemm_rs(const msde_rs_desc* desc, void* stream) {
   d.splits = S;
   d.rt = rt;
   d.flags &= ~MSDE_RS_VEC_STORE;
-  if (d.ldc % 4 == 0 && rs_al16(d.C) && (!d.Res || (d.ldres % 4 == 0 && rs_al16(d.Res)))) d.flags |= MSDE_RS_VEC_STORE;
+  auto rows_ok = [](const void* p, int ldx) { return !p || (ldx % 4 == 0 && rs_al16(p)); };
+  if (rows_ok(d.C, d.ldc) && rows_ok(d.Res, d.ldres) && rows_ok(d.R, d.ldr) && rows_ok(d.Z, d.ldz) &&
+      rows_ok(d.stats_z, d.ld_sz) && rows_ok(d.bias, 0) && rows_ok(d.stats_mean, 0) && rows_ok(d.stats, 0) && d.N % 4 == 0)
+    d.flags |= MSDE_RS_VEC_STORE;
   dim3 grid(((d.M + 16 * rt - 1) / (16 * rt)) * S);
   hipStream_t st = as_stream(stream);
 #define RSA_GO(T_) (rt == 2 ? rs_launch(gemm_rsa_kernel<2, T_>, grid, lds, st, d) : rs_launch(gemm_rsa_kernel<1, T_>, grid, lds, st, d))
