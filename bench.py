@@ -15,9 +15,12 @@ Headline (`value`): `--stream` (64) DISTINCT batches streamed through ONE captur
 collated arrays in, plans + extended graph built on the device).  Secondary keys under config.stream: the same blobs
 from pinned host memory (PCIe-inclusive) and the round-1 mode (4 resident batches, a graph each).
 
-Rank 0 prints ONE JSON line; `roofline` = the kernel with the largest share of the step's GPU time, timed live with
-HIP events at the step's launch geometry; `roofline_forward_schnet_sde2d3d` = the north-star forward figure;
-`cpu_baseline` = the oracle port timed on the host cores (N=1 only).
+Rank 0 prints ONE JSON line; `roofline` = the kernel with the largest share of the step's GPU time (round 3: the row-strip
+fp32-MFMA GEMM on the GIN layer's 3588 x 300 x 600 product), its duration measured INSIDE the captured step with device
+timestamps (both streams running), the stand-alone HIP-event timing kept under `standalone`;
+`roofline_forward_schnet_sde2d3d` = the north-star forward figure; `config4_sampler` / `config5_md17` = BASELINE.json
+configs[3] / configs[4] with the oracle's CPU time beside them; `cpu_baseline` = the oracle port of the pretrain step timed on
+the host cores (N=1 only).
 """
 import argparse
 import json
@@ -49,42 +52,25 @@ def _event_time_ms(fn, iters, stream):
     return start.elapsed_time(end) / iters
 
 
-def _radius(trainer, batch):
-    from moleculesde_amd import hip, plan as P
-    sch = trainer.models["model_3D"]
-    pl = P.get_plan(batch)
-    with torch.no_grad():
-        rplan, dist = hip.radius_plan(batch.positions, pl.batch_i32, pl.mol_ptr, sch.cutoff, pl.E_r_cap, 32)
-    return sch, rplan, dist, int(rplan.rowptr[-1]), batch.x.size(0)
-
-
-def _pmc_traffic(kernel, E, N, wgs=None):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r02_pmc_counters.json: separate
-    FETCH_SIZE / WRITE_SIZE passes of tools/prof_kernels.py, corrected as MI355X_MICROARCH.md prescribes), valid only for
-    the batch shape they were collected on; `wgs` selects the launch width (grid = workgroups x 256 threads)."""
+def _pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes (profiles/r03_pmc_counters.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) -- a recorded figure, not a
+    measurement of this run; None when the file does not hold the kernel."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_counters.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_counters.json")) as f:
             d = json.load(f)
-        if d.get("shape", {}).get("E_r") != E or d.get("shape", {}).get("N") != N:
-            return None
-        cands = {k: v for k, v in d.items() if k.startswith(kernel + "[grid=") and "traffic_bytes" in v}
-        if not cands:
-            return None
-        if wgs:
-            key = f"{kernel}[grid={int(wgs) * 256}]"
-            return cands[key]["traffic_bytes"] if key in cands else None
-        return cands[max(cands, key=lambda k: int(k.split("=")[1].rstrip("]")))]["traffic_bytes"]
+        v = d.get(kernel)
+        return v.get("traffic_bytes") if isinstance(v, dict) else None
     except Exception:
         return None
 
 
 def _rocprof_avg_us(kernel, full=False):
-    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of this same command
-    (profiles/r02_{default,full}_bench_kernel_stats.csv): launches inside the step (beside the other stream's kernels)
-    and the roofline loop's own, together.  None when the summary does not hold the kernel."""
+    """Average duration of `kernel` in the COMMITTED rocprofv3 --kernel-trace --stats summary of this same command
+    (profiles/r03_{default,full}_bench_kernel_stats.csv).  None when the summary does not hold the kernel."""
     import csv
     try:
-        path = os.path.join(ROOT, "profiles", "r02_%s_bench_kernel_stats.csv" % ("full" if full else "default"))
+        path = os.path.join(ROOT, "profiles", "r03_%s_bench_kernel_stats.csv" % ("full" if full else "default"))
         with open(path) as f:
             for r in csv.DictReader(f):
                 if kernel in r["Name"]:
@@ -94,109 +80,184 @@ def _rocprof_avg_us(kernel, full=False):
     return None
 
 
-def _step_widths(trainer):
-    """Workgroup counts the trainer gives the two wide CFConv kernels inside the step (pretrain.Trainer.losses:
-    narrowed while SchNet runs beside the GIN -> 2D->3D chain, full width with the 3D->2D head behind it)."""
-    from moleculesde_amd import pretrain
-    side = trainer.overlap_streams and not (trainer.args.SDE_coeff_generative_3Dto2D > 0)
-    return (pretrain.SIDE_CFCONV_FWD_WGS, pretrain.SIDE_CFCONV_BWD_WGS) if side else (None, None)
+def roofline_gemm(trainer, batch, dev, graph_replays=25):
+    """`roofline`: the kernel with the largest share of the step's GPU time -- gemm_rsa_kernel (csrc/gemm_rs.hip, the
+    row-strip fp32-MFMA GEMM: 22 % of the GPU time of the default step, profiles/r03_default_bench_kernel_stats.csv) -- on
+    its heaviest shape, the second product of a GIN layer: [N, 600] (BatchNorm + ReLU applied on load) x W^T [600, 300],
+    statistics of the following BatchNorm in the epilogue (molecule_gnn_model.py:17,176-182).  Algorithmic FLOPs per launch
+    = 2 N 300 600 (SURVEY §8d row 'GIN MLP').  `frac` is the IN-STEP figure: the launch's duration inside a captured
+    training step, both streams running, from device timestamps captured into the graph around it (median over replays);
+    `standalone` is the same launch alone between HIP events."""
+    from moleculesde_amd import hip
+    N = int(batch.x.size(0))
+    D, H = trainer.args.emb_dim, 2 * trainer.args.emb_dim
+    flops = 2.0 * N * D * H
+    out = {"kernel": "gemm_rsa_kernel<1, 5> (GIN layer, second product: BatchNorm+ReLU on load, statistics in the epilogue)",
+           "bound": "mfma", "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "flops_per_launch": flops,
+           "shape_MxNxK": [N, D, H], "launches_per_step_of_this_kernel": None}
+    # ---- stand-alone: the same fused launch between HIP events
+    with torch.no_grad():
+        z1 = torch.randn(N, H, device=dev)
+        Wt = torch.randn(H, D, device=dev) / H ** 0.5
+        sc, sh = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.1
+        b2 = torch.randn(D, device=dev)
+        a1, z2 = torch.empty(N, H, device=dev), torch.empty(N, D, device=dev)
+        strips, _ = hip.rs_geometry(N, D, H)
+        st = torch.empty(strips, 2, D, device=dev)
+        fn = lambda: hip.gemm_rs(z1, Wt, z2, bias=b2, axf="affine", xf=(sc, sh), relu=True, A_out=a1, stats=st,
+                                 stats_mode="bnfwd", b_kmajor=True, N=D, K=H, fallback=False)
+        ms = _event_time_ms(fn, 50, torch.cuda.current_stream())
+    tf = flops / (ms * 1e-3) / 1e12
+    out["standalone"] = {"avg_launch_us": round(ms * 1e3, 2), "achieved": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TF, 4)}
+    # ---- in-step: device stamps around the launch, captured into the step's graph
+    in_us = None
+    try:
+        b2_ = batch.clone() if hasattr(batch, "clone") else batch
+        from moleculesde_amd.geom3d import prepare_batch
+        if not getattr(b2_, "_msde_plan", None):
+            b2_ = prepare_batch(b2_, dev)
+        hip.enable_stamps(dev)
+        trainer.step(b2_)
+        trainer.capture(b2_)
+        vals = []
+        for _ in range(graph_replays):
+            trainer.step_graph(b2_)
+            torch.cuda.synchronize()
+            t = hip.read_stamps()
+            if "gin_gemm2_start" in t and "gin_gemm2_end" in t:
+                vals.append((t["gin_gemm2_end"] - t["gin_gemm2_start"]) / 100.0)      # 100 MHz counter -> us
+        if vals:
+            vals.sort()
+            in_us = vals[len(vals) // 2] - _stamp_overhead_us(dev)
+    except Exception as exc:
+        print(f"[bench] in-step GEMM timing failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+    finally:
+        hip.STAMPS = None
+    if in_us and in_us > 0:
+        tfi = flops / (in_us * 1e-6) / 1e12
+        out.update({"achieved": round(tfi, 2), "frac": round(tfi / FP32_MFMA_PEAK_TF, 4), "avg_launch_us": round(in_us, 2),
+                    "timing": "inside the captured step (device timestamps around the launch, median of %d replays, "
+                              "stamp overhead subtracted)" % len(vals)})
+    else:
+        out.update({"achieved": out["standalone"]["achieved"], "frac": out["standalone"]["frac"],
+                    "avg_launch_us": out["standalone"]["avg_launch_us"], "timing": "stand-alone (in-step timing unavailable)"})
+    out["rocprofv3_avg_launch_us_committed_profile"] = _rocprof_avg_us("gemm_rsa_kernel<1, 5>")
+    out["traffic"] = _pmc_traffic("gemm_rsa_kernel<1, 5>[3588x300x600]")
+    out["traffic_source"] = "profiles/r03_pmc_counters.json (committed FETCH_SIZE / WRITE_SIZE passes; not measured by this run)"
+    out["algorithmic_bytes_per_launch"] = (N * H + H * D + N * D + N * H) * 4      # z1 in, W, z2 out, a1 out
+    return out
 
 
-def roofline_fused_fwd(trainer, batch, iters=50, wgs=None):
-    """The fused CFConv forward (csrc/cfconv_fused.hip; 6 launches per step forward), fp32 matrix-core bound
-    (83 FLOP/B): algorithmic FLOPs per launch = E * 2 * (G*F + F*F) for the filter network (SURVEY §8d row 'SchNet
-    CFConv fused'); algorithmic bytes = E*8 + E*F*4 (gather) + weights + N*F*4 (+ E*F*4 filter rows out).
-    Timed on the raw C-ABI call with HIP events at the SAME workgroup count the step launches it with (`wgs`; None
-    = full width), so the figure is the kernel as the step runs it, minus cross-stream contention."""
+def _stamp_overhead_us(dev):
+    """Two back-to-back timestamp launches on one stream: the cost the stamp pair itself adds between its two reads."""
+    from moleculesde_amd import hip
+    g = torch.cuda.CUDAGraph()
+    hip.stamp("ovh_a"); hip.stamp("ovh_b")
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        hip.stamp("ovh_a")
+        hip.stamp("ovh_b")
+    v = []
+    for _ in range(20):
+        g.replay()
+        torch.cuda.synchronize()
+        t = hip.read_stamps()
+        v.append((t["ovh_b"] - t["ovh_a"]) / 100.0)
+    v.sort()
+    return v[len(v) // 2]
+
+
+def _pair_setup(trainer, batch):
+    from moleculesde_amd import hip, plan as P
+    sch = trainer.models["model_3D"]
+    pl = P.get_plan(batch)
+    with torch.no_grad():
+        pp = hip.pair_plan(batch.positions, pl, sch.cutoff)
+    return sch, pl, pp, int(pp.count[0]), int(batch.x.size(0))
+
+
+def roofline_pair_filter(trainer, batch, iters=50):
+    """CFConv filter network on unordered pairs (csrc/cfconv_pair.hip; 6 launches per forward): FLOPs per launch =
+    P * 2 * (G F + F F) over the P = E_r / 2 pairs -- HALF of the per-edge kernel of rounds 1-2 (2.25 GFLOP at E_r = 49 k),
+    which is the point: the fraction is reported against the work actually done AND against the per-edge figure."""
     from moleculesde_amd import hip, _lib
-    sch, rplan, dist, E, N = _radius(trainer, batch)
+    sch, pl, pp, P2, N = _pair_setup(trainer, batch)
     if sch.num_filters != 128:
         return None
     blk, de = sch.interactions[0], sch.distance_expansion
     G = sch.num_gaussians
     with torch.no_grad():
-        x1 = torch.randn(N, 128, device=batch.x.device)
-        W1T = blk.mlp[0].weight.detach()          # nn.Linear layouts, as the C ABI takes them
-        W2T = blk.mlp[2].weight.detach()
-        b1, b2 = blk.mlp[0].bias.detach(), blk.mlp[2].bias.detach()
-        agg = torch.empty(N, 128, device=batch.x.device)
-        Wf = torch.empty(rplan.E, 128, device=batch.x.device)
-        stream = torch.cuda.current_stream()
+        W1, b1, W2, b2 = (t.detach() for t in (blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias))
+        Wf = torch.empty(max(pp.P, 1), 128, device=batch.x.device)
         p, st = hip._p, hip._stream()
-        cpw = hip.FUSED_CHUNKS_PER_WG if wgs is None else max(1, -(-((rplan.E + 31) // 32) // int(wgs)))
-        fn = lambda: _lib.call("msde_cfconv_fused_fwd", p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst), p(W1T),
-                               p(b1), p(W2T), p(b2), p(de.offset), N, 128, G, rplan.E, float(de.coeff), float(sch.cutoff),
-                               cpw, p(agg), p(Wf), st)
-        ms = _event_time_ms(fn, iters, stream)
-    flops = E * 2.0 * (G * 128 + 128 * 128)
-    nbytes = E * 8 + E * 128 * 4 * 2 + (G * 128 + 128 * 128 + 256) * 4 + N * 128 * 4 + (N + 1) * 4
+        fn = lambda: _lib.call("msde_cfconv_pair_filter", p(pp.pd), p(pp.count), p(W1), p(b1), p(W2), p(b2), p(de.offset), 128, G,
+                               pp.P, float(de.coeff), float(sch.cutoff), 0, p(Wf), st)
+        ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
+    flops = P2 * 2.0 * (G * 128 + 128 * 128)
     tf = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "cfconv_fused_fwd_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF,
-            "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-            "traffic": _pmc_traffic("cfconv_fused_fwd_kernel", E, N, wgs), "flops_per_launch": flops,
-            "algorithmic_bytes_per_launch": nbytes, "hbm_frac_at_this_time": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N,
-            "workgroups": "full width" if wgs is None else int(wgs)}
+    return {"kernel": "cfconv_pair_filter_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "flops_per_launch": flops, "pairs": P2,
+            "frac_against_the_per_edge_flops_of_rounds_1_2": round(2 * tf / FP32_MFMA_PEAK_TF, 4),
+            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "timing": "stand-alone (HIP events)",
+            "rocprofv3_avg_launch_us_committed_profile": _rocprof_avg_us("cfconv_pair_filter_kernel"),
+            "algorithmic_bytes_per_launch": P2 * 4 + P2 * 128 * 4 + (G * 128 + 128 * 128 + 256) * 4}
 
 
-def roofline_fused_bwd(trainer, batch, iters=30, wgs=None):
-    """Second line: the recomputing weight-gradient kernel of the fused CFConv (cfconv_fused_bwd.hip),
-    FLOPs per launch = E * 2 * (G*F [recompute pre1] + F*F [g_W2] + F*F [W2^T g] + F*G [g_W1])."""
+def roofline_pair_bwd_w(trainer, batch, iters=30):
+    """Pair form of the recomputing weight-gradient kernel (cfconv_fused_bwd.hip, SYM): FLOPs per launch =
+    P * 2 * (2 G F + 2 F F) over unordered pairs (4.5 GFLOP per launch in the per-edge form of rounds 1-2)."""
     from moleculesde_amd import hip, _lib
-    sch, rplan, dist, E, N = _radius(trainer, batch)
+    sch, pl, pp, P2, N = _pair_setup(trainer, batch)
     if sch.num_filters != 128:
         return None
     blk, de = sch.interactions[0], sch.distance_expansion
     G = sch.num_gaussians
     with torch.no_grad():
         dev = batch.x.device
-        x1 = torch.randn(N, 128, device=dev)
-        g = torch.randn(N, 128, device=dev)
+        x1, g = torch.randn(N, 128, device=dev), torch.randn(N, 128, device=dev)
         W1, b1, W2 = blk.mlp[0].weight.detach(), blk.mlp[0].bias.detach(), blk.mlp[2].weight.detach()
-        gW1, gb1, gW2, gb2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2), torch.empty_like(b1)
-        mw = int(wgs or 0)
-        ws = hip._cf_workspace(rplan.E, G, dev, mw)
+        ws = hip._cf_workspace(pp.P, G, dev, 0)
         p, st = hip._p, hip._stream()
-        fn = lambda: _lib.call("msde_cfconv_fused_bwd_w", p(g), p(x1), p(dist), p(rplan.rowptr), p(rplan.src), p(rplan.dst),
-                               p(W1), p(b1), p(W2), p(de.offset), N, 128, G, rplan.E, float(de.coeff), float(sch.cutoff),
-                               mw, p(None), p(None), p(None), p(None), p(ws), st)      # slabs only: the kernel alone
+        fn = lambda: _lib.call("msde_cfconv_pair_bwd_w", p(g), p(x1), p(pp.pd), p(pp.count), p(pp.pi), p(pp.pj), p(W1), p(b1), p(W2),
+                               p(de.offset), N, 128, G, pp.P, float(de.coeff), float(sch.cutoff), 0, p(None), p(None), p(None),
+                               p(None), p(ws), st)
         ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
-    flops = E * 2.0 * (2 * G * 128 + 2 * 128 * 128)
+    flops = P2 * 2.0 * (2 * G * 128 + 2 * 128 * 128)
     tf = flops / (ms * 1e-3) / 1e12
-    full = trainer.args.SDE_coeff_generative_3Dto2D > 0
-    rp = _rocprof_avg_us("cfconv_fused_bwd_w_pipe_kernel", full)
-    return {"kernel": "cfconv_fused_bwd_w_pipe_kernel", "bound": "mfma", "achieved": round(tf, 2),
-            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
-            "rocprofv3_avg_launch_us_same_command": rp,
-            "frac_at_rocprofv3_avg": None if not rp else round(flops / (rp * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4),
-            "traffic": _pmc_traffic("cfconv_fused_bwd_w_pipe_kernel", E, N, wgs), "flops_per_launch": flops,
-            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "edges": E, "nodes": N,
-            "workgroups": "full width" if wgs is None else int(wgs)}
+    return {"kernel": "cfconv_fused_bwd_w_pipe_kernel<26, 0, true, true> (pair form)", "bound": "mfma", "achieved": round(tf, 2),
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "flops_per_launch": flops,
+            "frac_against_the_per_edge_flops_of_rounds_1_2": round(2 * tf / FP32_MFMA_PEAK_TF, 4), "pairs": P2,
+            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "timing": "stand-alone (HIP events)",
+            "rocprofv3_avg_launch_us_committed_profile": _rocprof_avg_us("cfconv_fused_bwd_w_pipe_kernel<26, 0, true, true>")}
 
 
 def roofline_hbm_kernel(trainer, batch, iters=50):
-    """HBM-bound message-passing kernel that the step really launches (6 x per backward pass): the input gradient
-    of the CFConv aggregation, g_x1[j] = sum_{e: src_e = j} g_agg[dst_e] * Wf[e]  (schnet.py:190,194-195 transposed;
-    `cfconv_aggregate_bwd_x_kernel`).  Algorithmic bytes per launch (SURVEY §8d convention): E*F*4 (filter rows) +
-    E*F*4 (gathered gradient rows) + E*8 (slot -> edge, edge -> target) + (N+1)*4 + N*F*4 (output)."""
+    """HBM-bound message-passing kernel of the step (12 launches: CFConv aggregation forward and its input gradient):
+    out[i] = sum_{j != i} x[j] * Wf[pair(i, j)] (schnet.py:190,194-195; csrc/cfconv_pair.hip).  Algorithmic bytes per launch
+    (SURVEY §8d convention, a gather counts E x row bytes): E F 4 (gathered x rows) + E F 4 (filter rows, each pair row read
+    by both of its atoms) + N F 4 (output) + index arrays, with E = 2 P ordered neighbours."""
     from moleculesde_amd import hip, _lib
-    sch, rplan, dist, E, N = _radius(trainer, batch)
+    sch, pl, pp, P2, N = _pair_setup(trainer, batch)
     Fd = sch.num_filters
+    if Fd != 128:
+        return None
     with torch.no_grad():
         dev = batch.x.device
-        g = torch.randn(N, Fd, device=dev)
-        Wf = torch.randn(rplan.E, Fd, device=dev)
+        x = torch.randn(N, Fd, device=dev)
+        Wf = torch.randn(max(pp.P, 1), Fd, device=dev)
         out = torch.empty(N, Fd, device=dev)
         p, st = hip._p, hip._stream()
-        fn = lambda: _lib.call("msde_cfconv_aggregate_bwd_x", p(g), p(Wf), p(None), p(rplan.rowptr_s), p(rplan.perm_s),
-                               p(rplan.dst), N, Fd, p(out), st)
+        fn = lambda: _lib.call("msde_cfconv_pair_aggregate", p(x), p(Wf), p(pp.batch_i32), p(pp.mol_ptr), p(pp.pair_ptr), N, pp.B,
+                               Fd, p(out), st)
         ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
-    nbytes = E * Fd * 4 * 2 + E * 8 + (N + 1) * 4 + N * Fd * 4
+    E = 2 * P2
+    nbytes = E * Fd * 4 * 2 + N * Fd * 4 + N * 4 + (pp.B + 1) * 8
     achieved = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "cfconv_aggregate_bwd_x_kernel", "bound": "hbm", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": _pmc_traffic("cfconv_aggregate_bwd_x_kernel", E, N), "bytes_per_launch": nbytes,
-            "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6}
+    return {"kernel": "cfconv_pair_aggregate_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("cfconv_pair_aggregate_kernel"),
+            "bytes_per_launch": nbytes, "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 12,
+            "timing": "stand-alone (HIP events)",
+            "rocprofv3_avg_launch_us_committed_profile": _rocprof_avg_us("cfconv_pair_aggregate_kernel")}
 
 
 def forward_algorithmic(st, H=300, F=128, G=51, D=300, C=32, L3=6):
@@ -239,9 +300,18 @@ def roofline_forward(trainer, batch, stats, iters=30):
     h2 = torch.randn(batch.x.size(0), trainer.args.emb_dim, device=dev, requires_grad=True)
     keep = []
 
+    side = trainer._side_stream
+
     def fwd():
-        _, h3 = sch(batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
+        # the two models are independent until the losses: SchNet runs on the trainer's second stream beside the 2D->3D
+        # model, exactly as in a training step (pretrain.Trainer.losses)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _, h3 = sch(batch.x[:, 0], batch.positions, batch.batch, return_latent=True)
         l23 = sde(h2, batch, anneal_power=0)["position"]
+        main.wait_stream(side)
+        h3.record_stream(main)
         keep[:] = [h3, l23]
 
     for _ in range(2):
@@ -263,7 +333,8 @@ def roofline_forward(trainer, batch, stats, iters=30):
     B = stats["B"]
     t = ms * 1e-3
     gbs, tf = nbytes / t / 1e9, flops / t / 1e12
-    return {"what": "SchNet + SDEModel2Dto3D_02 forward, training mode, bs %d (%s)" % (B, how), "ms": round(ms, 4),
+    return {"what": "SchNet + SDEModel2Dto3D_02 forward, training mode, bs %d (%s; SchNet on the second stream beside the "
+                    "2D->3D model, as in a training step)" % (B, how), "ms": round(ms, 4),
             "molecules_per_s_forward_only": round(B / t, 1),
             "algorithmic_MB": round(nbytes / 1e6, 2), "algorithmic_MB_per_molecule": round(nbytes / 1e6 / B, 4),
             "algorithmic_GFLOP": round(flops / 1e9, 3), "algorithmic_MFLOP_per_molecule": round(flops / 1e6 / B, 2),
@@ -305,6 +376,106 @@ def roofline_dense_head_node_mlp(batch, iters=20):
     return {"kernel": "gemm_ex_kernel x3 (node MLP 364->728->728->119 of the dense head, valid atoms only)", "bound": "mfma",
             "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
             "us_per_chain": round(ms * 1e3, 2), "rows": N, "flops": flops}
+
+
+def config4_sampler(dev, pc_steps=1000, cpu_steps=10):
+    """BASELINE.json configs[3]: 2D->3D VE reverse-SDE sampling (pretrain_MoleculeSDE_inference_2D_to_3D_VE_VP.py:92-138 as
+    intended): one 14-atom molecule x 10 replicas, `pc_steps` predictor-corrector iterations (2 score-network
+    calls each), one iteration captured as a hipGraph and replayed.  Beside it the oracle's models through the same loop on
+    the host cores, on a bounded sample of `cpu_steps` iterations."""
+    import numpy as np
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import sampler
+    from moleculesde_amd.batch import Batch
+    from moleculesde_amd.synthetic import make_molecule
+    torch.manual_seed(0)
+    mol = make_molecule(np.random.default_rng(0), 14)
+    cpu_b = Batch.from_data_list([mol] * 10)
+    b = G.prepare_batch(cpu_b.clone(), dev)
+    gnn = G.GNN(5, 300, JK="last", drop_ratio=0, gnn_type="GIN").to(dev).eval()
+    s23 = G.SDEModel2Dto3D_02(emb_dim=300, hidden_dim=32, beta_min=0.2, beta_max=1.0, num_diffusion_timesteps=1000,
+                              beta_schedule=None, SDE_type="VE", use_extend_graph=True).to(dev).eval()
+    with torch.no_grad():
+        rep = gnn(b.x, b.edge_index, b.edge_attr)
+    sampler.position_PC_generation(s23, rep, b, num_steps=20, use_graph=True)      # warm-up (workspaces, first capture)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pos = sampler.position_PC_generation(s23, rep, b, num_steps=pc_steps, use_graph=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"what": "2D->3D VE predictor-corrector sampling, 10 x 14 atoms, %d PC iterations (2 score calls each)" % pc_steps,
+           "seconds_per_trajectory_batch": round(dt, 3), "pc_iterations_per_s": round(pc_steps / dt, 1),
+           "finite": bool(torch.isfinite(pos).all()), "launch": "one PC iteration captured as a hipGraph, replayed"}
+    try:
+        from oracle import restate as R
+        torch.set_num_threads(min(_host_cores()[0], 16))
+        ognn = R.GNN(5, 300).eval()
+        o23 = R.SDEModel2Dto3D_02(emb_dim=300, hidden_dim=32, beta_schedule=None, beta_min=0.2, beta_max=1.0,
+                                  num_diffusion_timesteps=1000, SDE_type="VE", use_extend_graph=True).eval()
+        with torch.no_grad():
+            orep = ognn(cpu_b.x, cpu_b.edge_index, cpu_b.edge_attr)
+            sampler.position_PC_generation(o23, orep, cpu_b, num_steps=2, use_graph=False)
+            t0 = time.perf_counter()
+            sampler.position_PC_generation(o23, orep, cpu_b, num_steps=cpu_steps, use_graph=False)
+            dtc = time.perf_counter() - t0
+        out["cpu_oracle"] = {"pc_iterations_per_s": round(cpu_steps / dtc, 2), "sample": "%d PC iterations of the same loop on "
+                             "oracle/restate.py models, %d threads" % (cpu_steps, torch.get_num_threads()),
+                             "seconds_per_trajectory_batch_extrapolated": round(dtc / cpu_steps * pc_steps, 1)}
+    except Exception as exc:
+        out["cpu_oracle"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
+
+
+def config5_md17(dev, steps=20, cpu_steps=5):
+    """BASELINE.json configs[4]: MD17-aspirin-shaped force fine-tuning step (finetune_MD17.py:47-78): 21 atoms, batch 1,
+    SchNet(300, 128 filters, 6 interactions, 51 Gaussians, cutoff 10) + Linear head; energy -> forces by
+    autograd.grad(create_graph=True) -> L1 losses -> backward through the forces -> torch Adam.  Eager (latency bound:
+    ~40 small launches per interaction block and order of differentiation).  Beside it the oracle on the host cores."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.synthetic import make_md17_batch
+    kw = dict(hidden_channels=300, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10, readout="mean", node_class=119)
+    torch.manual_seed(0)
+    cpu_b = make_md17_batch(1, seed=3, n_atoms=21)
+    e_t, f_t = torch.randn(1, 1), torch.randn(cpu_b.x.size(0), 3)
+
+    def step(model, head, opt, b, et, ft):
+        pos = b.positions.clone().requires_grad_(True)
+        energy = head(model(b.x, pos, b.batch))
+        force = -torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=True, retain_graph=True)[0]
+        loss = (energy - et).abs().mean() + (force - ft).abs().mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    sch, head = G.SchNet(**kw).to(dev), torch.nn.Linear(300, 1).to(dev)
+    opt = torch.optim.Adam(list(sch.parameters()) + list(head.parameters()), lr=5e-4)
+    b = G.prepare_batch(cpu_b.clone(), dev)
+    for _ in range(3):
+        step(sch, head, opt, b, e_t.to(dev), f_t.to(dev))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(sch, head, opt, b, e_t.to(dev), f_t.to(dev))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"what": "MD17-aspirin-shaped SchNet force fine-tune step, 21 atoms, batch 1 (energy, forces with create_graph, "
+                   "backward through the forces, Adam)", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
+           "finite": bool(torch.isfinite(loss)), "launch": "eager"}
+    try:
+        from oracle import restate as R
+        torch.set_num_threads(min(_host_cores()[0], 16))
+        osch, ohead = R.SchNet(**kw), torch.nn.Linear(300, 1)
+        oopt = torch.optim.Adam(list(osch.parameters()) + list(ohead.parameters()), lr=5e-4)
+        step(osch, ohead, oopt, cpu_b, e_t, f_t)
+        t0 = time.perf_counter()
+        for _ in range(cpu_steps):
+            step(osch, ohead, oopt, cpu_b, e_t, f_t)
+        out["cpu_oracle"] = {"ms_per_step": round((time.perf_counter() - t0) / cpu_steps * 1e3, 1),
+                             "sample": "%d steps of oracle/restate.py SchNet, %d threads" % (cpu_steps, torch.get_num_threads())}
+    except Exception as exc:
+        out["cpu_oracle"] = {"error": f"{type(exc).__name__}: {exc}"}
+    return out
 
 
 def _host_cores():
@@ -395,6 +566,7 @@ def main():
                     help="distinct batches streamed through ONE captured graph (capacity bucket, device-built plans); "
                          "0 = the round-1 mode (one graph per resident batch)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_configs45", action="store_true", help="skip the configs[3] (sampler) / configs[4] (MD17) timings")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host (no hipGraph replay)")
     ap.add_argument("--debug_dp_path", action="store_true",
                     help="one GPU: initialise a 1-rank RCCL group and run the multi-GPU step structure "
@@ -411,6 +583,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if os.environ.get("MSDE_DP_BACKEND") == "gloo" and torch.cuda.device_count() <= local:
+        local = 0            # smoke mode: several gloo ranks share ONE GPU (DP step structure without RCCL)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     torch.manual_seed(0)
@@ -522,12 +696,10 @@ def main():
         # `roofline` = the kernel with the largest share of the step's GPU time (profiles/*_kernel_stats.csv):
         # cfconv_fused_bwd_w, timed at the workgroup count the step launches it with; the full-width figures are
         # kept as separate keys
-        wf, wb = _step_widths(trainer)
-        roof = roofline_fused_bwd(trainer, pool[0], wgs=wb)
-        roof["standalone_full_width"] = roofline_fused_bwd(trainer, pool[0]) if wb else None
-        roof_fwd = roofline_fused_fwd(trainer, pool[0], wgs=wf)
-        roof_fwd["standalone_full_width"] = roofline_fused_fwd(trainer, pool[0]) if wf else None
+        roof_filter = roofline_pair_filter(trainer, pool[0])
+        roof_bwd = roofline_pair_bwd_w(trainer, pool[0])
         roof_agg = roofline_hbm_kernel(trainer, pool[0])
+        roof = roofline_gemm(trainer, cpu_pool[0].clone(), device)
         roof_head = roofline_dense_head_node_mlp(pool[0])
         roof_forward = roofline_forward(trainer, pool[0], stats)
         out = {
@@ -544,11 +716,15 @@ def main():
                        "stream": stream_info, "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 3),
                        "loss_scalar": float(trainer.log["2Dto3D"]) / max(trainer.steps, 1)},
             "roofline": roof,
-            "roofline_cfconv_fused_fwd": roof_fwd,
+            "roofline_cfconv_pair_filter": roof_filter,
+            "roofline_cfconv_pair_bwd_w": roof_bwd,
             "roofline_hbm_message_passing": roof_agg,
             "roofline_forward_schnet_sde2d3d": roof_forward,
             "roofline_dense_head_node_mlp": roof_head,
         }
+        if world == 1 and not a.no_configs45:
+            out["config4_sampler"] = config4_sampler(device)
+            out["config5_md17"] = config5_md17(device)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch_size)
         print(json.dumps(out), flush=True)

@@ -27,17 +27,33 @@ def _round_up(v, q):
     return ((int(v) + q - 1) // q) * q
 
 
+PLAN_NMAX = 32           # atoms per molecule csrc/plan.hip builds (PL_NMAX: 32-bit neighbourhood masks)
+
+
+class BucketOverflow(RuntimeError):
+    """A batch does not fit the capacities of its bucket (or holds a molecule csrc/plan.hip cannot build)."""
+
+
 class Caps:
-    """Row capacities of a bucket.  Pairwise distinct multiples of 8 (the row-bound table is keyed by capacity)."""
+    """Row capacities of a bucket.  Pairwise distinct (the row-bound table is keyed by capacity) and different from every
+    other row count a step allocates (B, B * n_max, the `reserved` numbers): a tensor whose row count happened to equal a
+    capacity would be clamped to the bucket's valid rows."""
 
     __slots__ = ("B", "N", "E_b", "E_e", "E_r", "P", "n_max")
 
-    def __init__(self, B, N, E_b, E_e, E_r, P, n_max):
+    def __init__(self, B, N, E_b, E_e, E_r, P, n_max, reserved=()):
         self.B, self.n_max = int(B), int(n_max)
+        if self.n_max > PLAN_NMAX:
+            raise BucketOverflow(f"molecules of up to {self.n_max} atoms: the device-side plan builder takes <= {PLAN_NMAX} "
+                                 "(use the exact-size path: prepare_batch + Trainer.step)")
         # fine granularity: every padded row is processed by the row-wise kernels, so padding costs time one for one
         vals = [_round_up(N, 64), _round_up(E_b, 64) + 8, _round_up(E_e, 256) + 16, _round_up(E_r, 256) + 24,
                 _round_up(P, 256) + 40]
-        assert len(set(vals)) == 5
+        taken = {self.B, self.B * self.n_max, self.B + 1, self.B + 2} | {int(r) for r in reserved}
+        for i, q in enumerate((64, 64, 256, 256, 256)):
+            while vals[i] in taken or vals[i] in vals[:i]:
+                vals[i] += q
+        assert len(set(vals)) == 5 and not (set(vals) & taken)
         self.N, self.E_b, self.E_e, self.E_r, self.P = vals
 
     def fits(self, need):
@@ -79,6 +95,10 @@ def raw_sizes(b):
 def pack_raw(b, caps, pin=False):
     """Raw blob (int32, host) of a collated Batch for a bucket of capacities `caps`: exactly the arrays a loader's
     collate holds (no plan, no extended edges)."""
+    need = raw_sizes(b)
+    if not caps.fits(need) or need["n_max"] > PLAN_NMAX:
+        # an oversize field would silently overwrite the next field of the blob: refuse here, on the host, for free
+        raise BucketOverflow(f"batch {need} does not fit the bucket {caps.as_dict()}")
     lay = raw_layout(caps)
     blob = torch.zeros(lay["_total"], dtype=torch.int32)
     if pin:
@@ -178,6 +198,7 @@ class Bucket:
                   p(pl.atom_codes), p(pl.z_codes), p(pl.bond.rowptr), p(pl.bond.src), p(pl.bond.dst), p(pl.bond.rowptr_s),
                   p(pl.bond.perm_s), p(pl.bond_codes), p(pl.bond_type), p(self.ext_rows), p(self.ext_cnt), p(self.ext_ptr),
                   p(pl.ext.rowptr), p(pl.ext.src), p(pl.ext.dst), p(pl.ext.rowptr_s), p(pl.ext.perm_s), p(self.err), st)
+        # (msde_plan_build clears *err itself at the start of every build)
         def lists(st_):
             _lib.call("msde_plan_row_lists", p(pl.atom_codes), p(pl.N_dev), K_ATOM, pl.atom_R, p(self._cnt_scratch),
                       p(pl.atom_list_ptr), p(pl.atom_list_nodes), st_)
@@ -189,6 +210,23 @@ class Bucket:
             side_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side_stream):
                 lists(hip._stream())
+
+    def poll_overflow(self):
+        """Device-side overflow flag WITHOUT a synchronisation of the running step: returns the flag as it was when the
+        PREVIOUS poll's copy completed (one call late), and queues the next copy behind the work submitted so far.
+        csrc/plan.hip sets the flag when a molecule exceeds its limits or the batch exceeds a capacity (such rows are
+        then left inert: no out-of-bounds write)."""
+        if not hasattr(self, "_err_host"):
+            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._err_event = None
+        seen = False
+        if self._err_event is not None:
+            self._err_event.synchronize()          # a copy queued one step ago: done long before
+            seen = bool(int(self._err_host[0]))
+        self._err_host.copy_(self.err, non_blocking=True)
+        self._err_event = torch.cuda.Event()
+        self._err_event.record()
+        return seen
 
     def activate(self):
         """Declare the bucket's row bounds (process wide: one bucket is active at a time)."""

@@ -377,6 +377,14 @@ extern "C" int msde_gemm_ex(const msde_gemm_desc* desc, void* stream) {
   bool vec = vec_ok(d.A, d.a_gs, d.lda, d.K1) && vec_ok(d.B, d.b_gs, d.ldb, km ? d.N : d.K1);
   if (d.b_kblk_log2 > 0) vec = vec && (d.b_kblk_stride % 4 == 0);
   if (d.A2) vec = vec && vec_ok(d.A2, d.a_gs, d.lda2, d.K2) && vec_ok(d.B2, d.b_gs, d.ldb2, km ? d.N : d.K2);
+  // the fast staging path keeps per-thread BYTE offsets in 32 bits (relative to a tile base that already contains k0):
+  // operands whose extent reaches 4 GiB take the general path with 64-bit addressing
+  auto fits32 = [](long long rows, long long ld, long long extra) { return (rows * ld + extra) * 4 < (1LL << 32); };
+  if (vec) {
+    bool ok = fits32(d.M, d.lda, d.K1) && fits32(km ? d.K1 : d.N, d.ldb, km ? d.N : d.K1);
+    if (d.A2) ok = ok && fits32(d.M, d.lda2, d.K2) && fits32(km ? d.K2 : d.N, d.ldb2, km ? d.N : d.K2);
+    if (!ok) vec = false;
+  }
   // tile height: 128 rows when that still gives every CU >= 2 tiles, else 64 (skinny problems need the parallelism)
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.groups;
   static const int force_tm = getenv("MSDE_GEMM_TM") ? atoi(getenv("MSDE_GEMM_TM")) : 0;      // tuning knob

@@ -40,22 +40,34 @@ __device__ __forceinline__ int pl_block_exscan(int v, int* sh /* [1024/64 + 1] *
 }
 
 // sizes[]: 0 N, 1 E_b, 2 E_e, 3 P = sum n^2, 4 n_max, 5 sum n*min(n-1, max_nbr) (radius-graph edge bound)
+// *err: cleared here, set (by this kernel or the per-molecule ones) when a molecule exceeds PL_NMAX / PL_EMAX or the batch
+// exceeds a capacity.  The counts are SANITISED before anything is derived from them -- a molecule beyond the limits counts
+// as empty, prefix sums are clamped to the capacities -- so that mol_ptr / bond_ptr / pair_ptr stay monotone and inside the
+// buffers whatever the raw blob holds: every kernel that walks them (here and in the step) is memory safe; the flagged
+// batch computes garbage, which the caller learns from *err (bucket.Bucket.poll_overflow).
 __global__ void __launch_bounds__(1024)
-plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_bonds, int B, int max_nbr,
-                 int* __restrict__ mol_ptr /* [B+2] */, int* __restrict__ bond_ptr /* [B+1] */,
-                 int* __restrict__ pair_ptr /* [B+1] */, int* __restrict__ sizes) {
+plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_bonds, int B, int max_nbr, int N_cap,
+                 int Eb_cap, int* __restrict__ mol_ptr /* [B+2] */, int* __restrict__ bond_ptr /* [B+1] */,
+                 int* __restrict__ pair_ptr /* [B+1] */, int* __restrict__ sizes, int* __restrict__ err) {
   __shared__ int sh[20];
-  __shared__ int smax;
+  __shared__ int smax, sbad;
   const int t = threadIdx.x;
-  const int n = t < B ? mol_atoms[t] : 0, m = t < B ? mol_bonds[t] : 0;
-  if (t == 0) smax = 0;
+  int n = t < B ? mol_atoms[t] : 0, m = t < B ? mol_bonds[t] : 0;
+  if (t == 0) { smax = 0; sbad = 0; }
+  __syncthreads();
+  if (n < 0 || n > PL_NMAX || m < 0 || m > PL_EMAX) { n = 0; m = 0; atomicExch(&sbad, 1); }
   int tot;
   int ex = pl_block_exscan(n, sh, &tot);
-  if (t < B) mol_ptr[t] = ex;
-  if (t == 0) { mol_ptr[B] = tot; mol_ptr[B + 1] = tot; sizes[0] = tot; }
+  const int a0 = min(ex, N_cap), a1 = min(ex + n, N_cap);
+  if (ex + n > N_cap) atomicExch(&sbad, 1);
+  n = a1 - a0;                                      // atoms of this molecule that fit
+  if (n == 0) m = 0;                                // no atoms: its bonds have nothing to point at
+  if (t < B) mol_ptr[t] = a0;
+  if (t == 0) { const int v = min(tot, N_cap); mol_ptr[B] = v; mol_ptr[B + 1] = v; sizes[0] = v; }
   ex = pl_block_exscan(m, sh, &tot);
-  if (t < B) bond_ptr[t] = ex;
-  if (t == 0) { bond_ptr[B] = tot; sizes[1] = tot; }
+  if (ex + m > Eb_cap) { atomicExch(&sbad, 1); }
+  if (t < B) bond_ptr[t] = min(ex, Eb_cap);
+  if (t == 0) { const int v = min(tot, Eb_cap); bond_ptr[B] = v; sizes[1] = v; }
   ex = pl_block_exscan(n * n, sh, &tot);
   if (t < B) pair_ptr[t] = ex;
   if (t == 0) { pair_ptr[B] = tot; sizes[3] = tot; }
@@ -63,7 +75,7 @@ plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_
   if (t == 0) sizes[5] = tot;
   atomicMax(&smax, n);
   __syncthreads();
-  if (t == 0) sizes[4] = smax;
+  if (t == 0) { sizes[4] = smax; *err = sbad; }
 }
 
 // exclusive scan of cnt[0..n) (n <= 1024) -> ptr[0..n], total also to *total_out
@@ -87,15 +99,27 @@ plan_molecule_kernel(const int* __restrict__ x_raw, int K, const int* __restrict
                      int* __restrict__ batch_i32, int* __restrict__ atom_codes, int* __restrict__ z_codes,
                      int* __restrict__ rowptr, int* __restrict__ src, int* __restrict__ dst, int* __restrict__ rowptr_s,
                      int* __restrict__ perm_s, int* __restrict__ bond_codes, float* __restrict__ bond_type,
-                     unsigned* __restrict__ ext_rows, int* __restrict__ ext_cnt, int* __restrict__ err) {
+                     unsigned* __restrict__ ext_rows, int* __restrict__ ext_cnt, int* __restrict__ err, int B, int N_cap,
+                     int Eb_cap) {
   __shared__ short ls[PL_EMAX], ld[PL_EMAX];      // local source / target of the loader-order bonds
   __shared__ short cs[PL_EMAX];                   // local source of the canonical-order bonds
   __shared__ unsigned A[PL_NMAX], P[PL_NMAX];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0;
   const int e0 = bond_ptr[b], m = bond_ptr[b + 1] - e0;
-  if (n > PL_NMAX || m > PL_EMAX) {       // unsupported molecule: flag it, leave its rows to the tail fill
+  if (n > PL_NMAX || m > PL_EMAX || n < 0 || m < 0 || a0 + n > N_cap || e0 + m > Eb_cap) {
+    // unsupported molecule or a batch beyond the capacities: flag it and leave the rows that exist INERT (atoms of the empty
+    // molecule B with code 0, no bonds, edge slots -1) -- never the previous batch's contents, never a write past a buffer
     if (tid == 0) { atomicExch(err, 1); ext_cnt[b] = 0; }
+    for (int i = a0 + tid; i < min(a0 + max(n, 0), N_cap); i += 256) {
+      batch_i32[i] = B; z_codes[i] = 0; ext_rows[i] = 0u;
+      rowptr[i] = min(e0, Eb_cap); rowptr_s[i] = min(e0, Eb_cap);
+      for (int k = 0; k < K; ++k) atom_codes[(size_t)i * K + k] = 0;
+    }
+    for (int e = e0 + tid; e < min(e0 + max(m, 0), Eb_cap); e += 256) {
+      src[e] = -1; dst[e] = -1; perm_s[e] = e; bond_type[e] = 0.f;
+      bond_codes[3 * e] = 0; bond_codes[3 * e + 1] = 0; bond_codes[3 * e + 2] = 0;
+    }
     return;
   }
   for (int e = tid; e < n * K; e += 256) {
@@ -103,7 +127,16 @@ plan_molecule_kernel(const int* __restrict__ x_raw, int K, const int* __restrict
     atom_codes[(size_t)(a0 + i) * K + k] = x_raw[(size_t)(a0 + i) * K + k] + atom_off[k];
   }
   if (tid < n) { batch_i32[a0 + tid] = b; z_codes[a0 + tid] = x_raw[(size_t)(a0 + tid) * K]; A[tid] = 0u; }
-  for (int e = tid; e < m; e += 256) { ls[e] = (short)(bond_src[e0 + e] - a0); ld[e] = (short)(bond_dst[e0 + e] - a0); }
+  for (int e = tid; e < m; e += 256) {
+    int s_ = bond_src[e0 + e] - a0, d_ = bond_dst[e0 + e] - a0;
+    if (s_ < 0 || s_ >= n || d_ < 0 || d_ >= n) {   // an endpoint outside the molecule (inconsistent blob): keep the index valid
+      atomicExch(err, 1);
+      s_ = min(max(s_, 0), max(n - 1, 0));
+      d_ = min(max(d_, 0), max(n - 1, 0));
+    }
+    ls[e] = (short)s_;
+    ld[e] = (short)d_;
+  }
   __syncthreads();
   // canonical order: stable sort by target
   for (int e = tid; e < m; e += 256) {
@@ -158,12 +191,17 @@ plan_molecule_kernel(const int* __restrict__ x_raw, int K, const int* __restrict
 __global__ void __launch_bounds__(64)
 plan_ext_kernel(const unsigned* __restrict__ ext_rows, const int* __restrict__ mol_ptr, const int* __restrict__ ext_ptr,
                 int* __restrict__ rowptr, int* __restrict__ src, int* __restrict__ dst, int* __restrict__ rowptr_s,
-                int* __restrict__ perm_s) {
+                int* __restrict__ perm_s, int N_cap, int Ee_cap, int* __restrict__ err) {
   __shared__ unsigned R[PL_NMAX], Cc[PL_NMAX];
   __shared__ int rp[PL_NMAX + 1], rs[PL_NMAX + 1];
   const int b = blockIdx.x, t = threadIdx.x;
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, x0 = ext_ptr[b];
-  if (n > PL_NMAX) return;
+  if (n > PL_NMAX || n < 0 || a0 + n > N_cap || ext_ptr[b + 1] > Ee_cap) {
+    // (flagged molecules have no extended edges: only their row pointers are set, inside the buffer)
+    if (ext_ptr[b + 1] > Ee_cap && t == 0) atomicExch(err, 1);
+    if (n > 0 && t < min(n, PL_NMAX) && a0 + t < N_cap) { rowptr[a0 + t] = min(x0, Ee_cap); rowptr_s[a0 + t] = min(x0, Ee_cap); }
+    return;
+  }
   if (t < n) R[t] = ext_rows[a0 + t];
   __syncthreads();
   if (t < n) {
@@ -201,7 +239,7 @@ plan_tail_kernel(const int* __restrict__ sizes, int B, int N_cap, int Eb_cap, in
                  int* __restrict__ b_dst, int* __restrict__ b_rowptr_s, int* __restrict__ b_perm_s,
                  int* __restrict__ bond_codes, float* __restrict__ bond_type, int* __restrict__ e_rowptr,
                  int* __restrict__ e_src, int* __restrict__ e_dst, int* __restrict__ e_rowptr_s, int* __restrict__ e_perm_s) {
-  const int N = sizes[0], Eb = sizes[1], Ee = sizes[2];
+  const int N = min(sizes[0], N_cap), Eb = min(sizes[1], Eb_cap), Ee = min(sizes[2], Ee_cap);
   const int g = blockIdx.x * 256 + threadIdx.x, G = gridDim.x * 256;
   for (int i = N + g; i <= N_cap; i += G) {
     b_rowptr[i] = Eb; b_rowptr_s[i] = Eb; e_rowptr[i] = Ee; e_rowptr_s[i] = Ee;
@@ -269,17 +307,17 @@ extern "C" int msde_plan_build(const int* x_raw, int K, const int* atom_off, con
       !ext_cnt || !ext_ptr || !e_rowptr || !e_src || !e_dst || !e_rowptr_s || !e_perm_s || !err)
     return B > 1024 ? MSDE_EUNSUP : MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
-  MSDE_LAUNCH(plan_scan_kernel, dim3(1), dim3(1024), 0, st, mol_atoms, mol_bonds, B, max_nbr, mol_ptr, bond_ptr, pair_ptr,
-              sizes);
+  MSDE_LAUNCH(plan_scan_kernel, dim3(1), dim3(1024), 0, st, mol_atoms, mol_bonds, B, max_nbr, N_cap, Eb_cap, mol_ptr, bond_ptr,
+              pair_ptr, sizes, err);
   MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(plan_molecule_kernel, dim3(B), dim3(256), 0, st, x_raw, K, atom_off, bond_src, bond_dst, bond_attr, bond_off,
               (const int*)mol_ptr, (const int*)bond_ptr, batch_i32, atom_codes, z_codes, b_rowptr, b_src, b_dst, b_rowptr_s,
-              b_perm_s, bond_codes, bond_type, ext_rows, ext_cnt, err);
+              b_perm_s, bond_codes, bond_type, ext_rows, ext_cnt, err, B, N_cap, Eb_cap);
   MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(plan_scan_small_kernel, dim3(1), dim3(1024), 0, st, (const int*)ext_cnt, B, ext_ptr, sizes + 2);
   MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(plan_ext_kernel, dim3(B), dim3(64), 0, st, (const unsigned*)ext_rows, (const int*)mol_ptr,
-              (const int*)ext_ptr, e_rowptr, e_src, e_dst, e_rowptr_s, e_perm_s);
+              (const int*)ext_ptr, e_rowptr, e_src, e_dst, e_rowptr_s, e_perm_s, N_cap, Ee_cap, err);
   MSDE_CHECK_LAUNCH();
   int tail = (N_cap + Eb_cap + Ee_cap + 255) / 256;
   if (tail > 512) tail = 512;

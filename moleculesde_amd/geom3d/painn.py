@@ -204,5 +204,4 @@ class _OutDense(Dense):
     """Dense of the caller-side output head (create_output_layers): a plain module with its own forward."""
 
     def forward(self, input):
-        y = _nn.linear(input, self.weight, self.bias) if input.is_cuda else F.linear(input, self.weight, self.bias)
-        return self.activation(y)
+        return self.activation(_nn.linear(input, self.weight, self.bias))      # HIP only: _nn.linear refuses host tensors

@@ -1303,6 +1303,9 @@ class _SlabBatch:
         d, self.deferred = self.deferred, []
         for fn in d:
             fn(None)
+        # the closures hold the kernels' operands: kept until finish(), because they may be launched on ANOTHER stream than
+        # the one that allocated the operands (the caching allocator would hand their memory to that stream's next kernels)
+        self.launched.extend(d)
 
     def park(self):
         """Set the GEMMs queued so far aside (returned as an opaque group) instead of launching them: the caller launches
@@ -2224,8 +2227,10 @@ class _GinMlpBN(torch.autograd.Function):
         st2 = torch.empty(s2, 2, D, dtype=torch.float32, device=dev)
         a1 = torch.empty(M, H, dtype=torch.float32, device=dev)
         z2 = torch.empty(M, D, dtype=torch.float32, device=dev)
+        stamp("gin_gemm2_start")          # no-ops unless enable_stamps(): bench.py times this launch inside the captured step
         gemm_rs(z1, W2t, z2, bias=b2, axf="affine", xf=(v1[0], v1[1]), relu=True, A_out=a1, stats=st2, stats_mode="bnfwd",
                 b_kmajor=True, N=D, K=H, fallback=False)
+        stamp("gin_gemm2_end")
         v2 = _bn_fin_fwd(st2, s2, r2, M, D, g2, be2, eps2, mom2, rm2, rv2)
         h = torch.empty(M, D, dtype=torch.float32, device=dev)
         if link_out is not None:

@@ -557,8 +557,26 @@ class Trainer:
         return self.capture(bk.batch, pre=lambda: bk.build_plan_on_device(side))
 
     def step_bucket(self, bk, blob):
+        """One copy of the raw blob + one graph replay.  The device-side overflow flag of the PREVIOUS call is looked at
+        here (one step late: no synchronisation of the running step); blobs made by bucket.pack_raw were already checked
+        on the host, so the flag only fires for blobs packed some other way."""
+        if bk.poll_overflow():
+            from .bucket import BucketOverflow
+            raise BucketOverflow("the batch of the previous step_bucket() call did not fit the bucket "
+                                 f"{bk.caps.as_dict()}: its rows were left inert, that step is not a valid update")
         bk.load(blob)
         return self.step_graph(bk.batch)
+
+    def step_stream(self, bk, batch):
+        """One step on a collated HOST batch: through the bucket's captured graph when the batch fits its capacities,
+        otherwise the exact-size eager step (host plan) -- the fallback for a batch larger than anything the bucket was
+        sized for, or holding a molecule the device-side plan builder cannot take."""
+        from . import bucket as BK
+        need = BK.raw_sizes(batch)
+        if bk.caps.fits(need) and need["n_max"] <= BK.PLAN_NMAX:
+            return self.step_bucket(bk, BK.pack_raw(batch, bk.caps))
+        out, _ = self.step(prepare_batch(batch.clone(), self.device))
+        return out
 
     def state_dicts(self):
         """Checkpoint dictionary of pretrain_MoleculeSDE.py:78-88."""

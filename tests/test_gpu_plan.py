@@ -269,6 +269,150 @@ def test_one_graph_serves_different_batches(dev):
         hip.clear_row_bounds()
 
 
+def _capturable_noise(G, dev, seed=77):
+    """Position noise / time steps from fixed DEVICE tensors (padding independent, capturable); contrastive permutations
+    from the device kernel (a function of seed and call count)."""
+    class Noise(G.DeviceNoise):
+        def __init__(self):
+            super().__init__(seed=seed)
+            g = torch.Generator().manual_seed(5)
+            self.big = torch.randn(8192, 3, generator=g).to(dev)
+            self.ints = torch.randint(0, 1000, (4096,), generator=g).to(dev)
+
+        def randn_like(self, x):
+            assert x.dim() == 2 and x.size(1) == 3
+            return self.big[:x.size(0)].clone()
+
+        def randint(self, high, size, device):
+            return self.ints[:size[0]].clone()
+    return Noise()
+
+
+@pytest.mark.timeout(600)
+def test_oversized_batch_falls_back_and_overflow_is_flagged(dev):
+    """Hardening of the bucket path: (1) pack_raw refuses a batch that does not fit (host side, free); (2) Trainer.step_stream
+    sends such a batch through the exact-size eager step and the result equals a plain Trainer.step on it; (3) a blob
+    forced past the host check only sets the device-side flag -- no out-of-bounds write, the flagged rows inert -- and
+    step_bucket raises one call later without ever synchronising the running step; (4) Caps rejects molecules the
+    device-side plan builder cannot take and keeps clear of other row counts of the step."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import bucket as BK, hip, pretrain
+    from moleculesde_amd.synthetic import make_batch
+    args = pretrain.readme_args(emb_dim=64, SDE_coeff_generative_3Dto2D=0)
+    cand = sorted((make_batch(16, seed=s) for s in range(71, 79)), key=lambda q: BK.raw_sizes(q)["N"])
+    small, big = cand[:2], cand[-1]
+    top = max(BK.raw_sizes(q)["N"] for q in small)
+    # capacities sized for the small batches only (N rounded up to 64 must stay below the big batch)
+    need_s = [BK.raw_sizes(q) for q in small]
+    caps = BK.Caps.covering(need_s, n_max=24)
+    assert BK.raw_sizes(big)["N"] > caps.N or not caps.fits(BK.raw_sizes(big)), (BK.raw_sizes(big), caps.as_dict())
+    assert not caps.fits(BK.raw_sizes(big))
+    with pytest.raises(BK.BucketOverflow):
+        BK.pack_raw(big, caps)
+    with pytest.raises(BK.BucketOverflow):
+        BK.Caps(16, 100, 100, 100, 100, 100, 40)          # n_max beyond the plan builder
+    c2 = BK.Caps(16, 16 * 24 - 10, 100, 100, 100, 100, 24)
+    assert c2.N != 16 * 24 and len({c2.N, c2.E_b, c2.E_e, c2.E_r, c2.P}) == 5
+
+    def trainer():
+        torch.manual_seed(5)
+        t = pretrain.Trainer(args, dev)
+        t.overlap_streams = False
+        for m in t.models.values():
+            disable_dropout(m)
+        n = _capturable_noise(G, dev)
+        t.noise = n
+        t.models["SDE_2Dto3D_model"].noise = n
+        if "SDE_3Dto2D_model" in t.models:
+            t.models["SDE_3Dto2D_model"].noise = n
+        return t
+    fits = [b for b in small if caps.fits(BK.raw_sizes(b))]
+    assert fits
+    tr = trainer()
+    bk = tr.make_bucket(caps)
+    tr.capture_bucket(bk, BK.pack_raw(fits[0], caps).to(dev))
+    snap = (tr.opt.flat_p.clone(), tr.opt.m.clone(), tr.opt.v.clone(), tr.opt.step_dev.clone(), tr.step_counter.clone(),
+            {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in tr.models.items()})
+
+    calls0 = tr.noise.calls
+
+    def restore():
+        tr.opt.flat_p.copy_(snap[0]); tr.opt.m.copy_(snap[1]); tr.opt.v.copy_(snap[2]); tr.opt.step_dev.copy_(snap[3])
+        tr.step_counter.copy_(snap[4])
+        for k, m in tr.models.items():
+            m.load_state_dict(snap[5][k])
+        tr.noise.calls = calls0
+        hip.bump_weight_epoch()
+    tr.step_stream(bk, big)                               # does not fit -> exact-size eager step
+    torch.cuda.synchronize()
+    got = tr.opt.flat_p.clone()
+    restore()
+    tr.step(G.prepare_batch(big.clone(), dev))            # the plain exact-size step from the same state
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and torch.equal(got, tr.opt.flat_p), "fallback == exact-size step"
+    tr.step_stream(bk, fits[0])                           # and the bucket keeps working afterwards
+    torch.cuda.synchronize()
+    ok, _ = bk.check()
+    assert ok
+    # (3) a blob that lies about its sizes: more atoms than the capacity
+    blob = BK.pack_raw(fits[0], caps).clone()
+    o, n = bk.layout["mol_atoms"]
+    blob[o] = caps.N + 5                                  # first molecule claims more atoms than the bucket holds
+    guard = torch.full((4096,), 12345, dtype=torch.int32, device=dev)      # memory next to the bucket's buffers
+    tr.step_bucket(bk, blob.to(dev))
+    torch.cuda.synchronize()
+    assert int(bk.err.cpu()) == 1
+    assert bool((guard == 12345).all())
+    assert not bk.check()[0]
+    tr.step_bucket(bk, BK.pack_raw(fits[0], caps).to(dev))   # poll is one call late: this call only queues the copy ...
+    with pytest.raises(BK.BucketOverflow):
+        for _ in range(3):                                    # ... and one of the next calls reports the bad step
+            tr.step_bucket(bk, BK.pack_raw(fits[0], caps).to(dev))
+    hip.clear_row_bounds()
+
+
+@pytest.mark.timeout(600)
+def test_two_live_buckets(dev):
+    """Two buckets of different capacities, each with its own captured graph, used alternately: the row bounds a graph was
+    captured with stay its own (device pointers baked in at capture), so interleaving them gives the same parameters as
+    using each alone."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import bucket as BK, hip, pretrain
+    from moleculesde_amd.synthetic import make_batch
+    args = pretrain.readme_args(emb_dim=64, SDE_coeff_generative_3Dto2D=0)
+    A = [make_batch(12, seed=s) for s in (81, 82)]
+    Bb = [make_batch(24, seed=s) for s in (83, 84)]
+
+    def run(order):
+        torch.manual_seed(9)
+        tr = pretrain.Trainer(args, dev)
+        tr.overlap_streams = False
+        for m in tr.models.values():
+            disable_dropout(m)
+        n = _capturable_noise(G, dev)
+        tr.noise = n
+        tr.models["SDE_2Dto3D_model"].noise = n
+        ca, cb = BK.Caps.covering([BK.raw_sizes(b) for b in A], n_max=24), BK.Caps.covering([BK.raw_sizes(b) for b in Bb], n_max=24)
+        ba, bb = tr.make_bucket(ca), tr.make_bucket(cb)
+        blobs = {"a": [BK.pack_raw(b, ca).to(dev) for b in A], "b": [BK.pack_raw(b, cb).to(dev) for b in Bb]}
+        p0 = tr.opt.flat_p.clone()
+        tr.capture_bucket(ba, blobs["a"][0])
+        tr.capture_bucket(bb, blobs["b"][0])
+        # capture warm-up stepped the optimiser: back to a common starting point
+        tr.opt.flat_p.copy_(p0); tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_dev.zero_(); tr.step_counter.zero_()
+        hip.refresh_weight_t()
+        for which, i in order:
+            tr.step_bucket(ba if which == "a" else bb, blobs[which][i])
+        torch.cuda.synchronize()
+        assert ba.check()[0] and bb.check()[0]
+        hip.clear_row_bounds()
+        return tr.opt.flat_p.clone()
+    inter = run([("a", 0), ("b", 0), ("a", 1), ("b", 1)])
+    again = run([("a", 0), ("b", 0), ("a", 1), ("b", 1)])
+    assert torch.equal(inter, again), "same schedule, same parameters (bitwise)"
+    assert torch.isfinite(inter).all()
+
+
 def test_blob_feeder_prefetch(dev):
     """bucket.BlobFeeder: pinned blobs staged one step ahead on a copy stream arrive in the bucket intact and in order."""
     from moleculesde_amd import bucket as BK
