@@ -117,6 +117,7 @@ def roofline_gemm(trainer, batch, dev, graph_replays=25):
         if not getattr(b2_, "_msde_plan", None):
             b2_ = prepare_batch(b2_, dev)
         hip.enable_stamps(dev)
+        dp_was, trainer.dp_enabled = trainer.dp_enabled, False      # rank 0 alone: no collectives in this measurement
         trainer.step(b2_)
         trainer.capture(b2_)
         vals = []
@@ -133,6 +134,7 @@ def roofline_gemm(trainer, batch, dev, graph_replays=25):
         print(f"[bench] in-step GEMM timing failed ({type(exc).__name__}: {exc})", file=sys.stderr)
     finally:
         hip.STAMPS = None
+        trainer.dp_enabled = locals().get("dp_was", trainer.dp_enabled)
     if in_us and in_us > 0:
         tfi = flops / (in_us * 1e-6) / 1e12
         out.update({"achieved": round(tfi, 2), "frac": round(tfi / FP32_MFMA_PEAK_TF, 4), "avg_launch_us": round(in_us, 2),

@@ -1258,12 +1258,26 @@ class _SlabBatch:
                           torch.cuda.current_stream().cuda_stream if written else None))
 
     def queue_gemm(self, gY, X, M, N, K, has_bias, slab):
-        self.gemms.append((gY, X, M, N, K, has_bias, slab))
+        # the stream the operands were produced on rides along: a caller may flush one stream's GEMMs on that stream
+        # (launch_gemms(only_stream=...)) while the other stream is still in its backward chain
+        self.gemms.append((gY, X, M, N, K, has_bias, slab, torch.cuda.current_stream().cuda_stream))
 
-    def launch_gemms(self, max_wgs=0):
+    def launch_gemms(self, max_wgs=0, only_stream=None):
         """One grouped launch, on the current stream, for the weight-gradient GEMMs queued so far.  May be called
         several times per backward pass (each call takes the next rows of the problem table).  max_wgs > 0 limits the
-        launch to that many resident workgroups (a flush that runs beside the backward chain on another stream)."""
+        launch to that many resident workgroups (a flush that runs beside the backward chain on another stream);
+        only_stream: take only the GEMMs whose operands were produced on that stream (handle), leave the rest queued."""
+        if only_stream is not None:
+            mine = [t for t in self.gemms if t[7] == only_stream]
+            rest = [t for t in self.gemms if t[7] != only_stream]
+            if not mine:
+                return
+            self.gemms = mine
+            try:
+                self.launch_gemms(max_wgs)
+            finally:
+                self.gemms = rest + self.gemms
+            return
         if not self.gemms:
             return
         dev = self.gemms[0][0].device
@@ -1281,7 +1295,7 @@ class _SlabBatch:
         assert r0 + ng <= self.MAX_ROWS
         hp2 = host_ppre.numpy()
         total_b = 0
-        for r, (gY, X, M, N, K, hb, slab) in enumerate(self.gemms):
+        for r, (gY, X, M, N, K, hb, slab, _st) in enumerate(self.gemms):
             nb = lib.msde_linear_bwd_w_describe_ld(_p(gY), _row_stride(gY, N), _p(X), _row_stride(X, K), M, N, K, hb,
                                                    _p(slab), ctypes.c_void_p(host_prob[r0 + r].data_ptr()))
             if nb <= 0:
@@ -1393,11 +1407,12 @@ def begin_param_grad_batch(params=None):
     _SLABS.begin(params)
 
 
-def flush_wgrad_gemms(max_wgs=0):
+def flush_wgrad_gemms(max_wgs=0, only_stream=None):
     """Launch the weight-gradient GEMMs queued so far as one grouped kernel on the current stream (their slabs are
-    still summed by finish_param_grad_batch, whose stream must by then be ordered after this one)."""
+    still summed by finish_param_grad_batch, whose stream must by then be ordered after this one).  only_stream: only
+    those whose operands were produced on that stream."""
     if _SLABS.active:
-        _SLABS.launch_gemms(max_wgs)
+        _SLABS.launch_gemms(max_wgs, only_stream)
 
 
 def reduce_written_slabs():

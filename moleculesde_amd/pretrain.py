@@ -91,6 +91,8 @@ SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "256"))   # 256 
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
 GEOMETRY_ON_SIDE = os.environ.get("MSDE_GEOMETRY_ON_SIDE", "1") != "0"   # coordinate-only branch of the 2D->3D model at the head of the second stream.  Round 2 (SchNet the longer chain): 3.187 vs 3.151 ms, off; round 3 (pair CFConv: SchNet is the SHORTER chain): 2.86 vs 2.98 ms (tools/r03_ab5.sh), on
 EARLY_SLAB_REDUCE = os.environ.get("MSDE_EARLY_SLAB_REDUCE", "1") != "0"
+SIDE_WGRAD = os.environ.get("MSDE_SIDE_WGRAD", "0") != "0"   # second stream's weight gradients flushed on it, behind its backward: measured 2.865 vs 2.82 ms (tools/r03_ab8.sh: the GIN backward slows by more than the tail gains), off
+SIDE_WGRAD_WGS = int(os.environ.get("MSDE_SIDE_WGRAD_WGS", "0"))   # 0: full width
 SCHNET_AFTER_GIN = os.environ.get("MSDE_SCHNET_AFTER_GIN", "0") != "0"   # experiment: start SchNet when GIN's forward is done
 PLAN_LISTS_ON_SIDE = os.environ.get("MSDE_PLAN_LISTS_ON_SIDE", "1") != "0"   # bucket mode: embedding row lists off the main chain
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
@@ -298,7 +300,8 @@ class Trainer:
         if a.SDE_coeff_generative_2Dto3D > 0 and EARLY_GEOMETRY:
             m["SDE_2Dto3D_model"].begin(batch)
         elif (a.SDE_coeff_generative_2Dto3D > 0 and GEOMETRY_ON_SIDE and self.overlap_streams and not SCHNET_AFTER_GIN
-              and not getattr(self.noise, "replay", False)):
+              and not head_on_side and not getattr(self.noise, "replay", False)):
+            # (with the 3D->2D head behind SchNet the second stream is the longer one: 3.92 vs 4.03 ms without / with)
             # the coordinate-only branch of the 2D->3D model (noise, perturbation, frame / Fourier features, their MLPs:
             # ~10 launches forward, as many backward) depends on nothing the main chain computes: it runs at the head
             # of the second stream, in the slack SchNet leaves there; the model joins it by event
@@ -396,6 +399,14 @@ class Trainer:
                         early = hip.reduce_written_slabs()
                     if early:
                         torch.cuda.current_stream().wait_stream(self._side_stream)
+                if self.overlap_streams and SIDE_WGRAD:
+                    # the second stream's own weight gradients (SchNet, the coordinate branch of the 2D->3D model) as a grouped
+                    # launch ON that stream, right behind its backward: it finishes its chain earlier than the main stream
+                    # (round 3: pair CFConv), so these products run beside the GIN backward instead of at the tail
+                    with torch.cuda.stream(self._side_stream):
+                        hip.flush_wgrad_gemms(SIDE_WGRAD_WGS, only_stream=self._side_stream.cuda_stream)
+                    if not hip.have_deferred_leaf_kernels():
+                        torch.cuda.current_stream().wait_stream(self._side_stream)     # (joined below otherwise)
                 if self.overlap_streams and hip.have_deferred_leaf_kernels():
                     # leaf-only kernels of the backward pass (GIN bond-table gradients: 5 x 17 us that nothing downstream
                     # reads) run on the second stream BESIDE the grouped weight-gradient launch instead of inside the
