@@ -410,6 +410,30 @@ typedef struct msde_rs_desc {
 } msde_rs_desc;
 int msde_gemm_rs(const msde_rs_desc* desc, void* stream);
 int msde_gemm_rs_geometry(int M, int N, int K, int* strips, int* strip_rows);
+/* Up to MSDE_CHAIN_MAX chained products on strips of 16 rows that stay in LDS (csrc/gemm_rs.hip): stage s computes
+ * out_s = epilogue_s(in_s . W_s + bias_s) with in_0 = A [M, K_0] and in_s = out_{s-1} (K_s == N_{s-1}); epilogue as in
+ * msde_gemm_rs: act (MSDE_EPI_ACT) or multiplication by act'(dact[m,n]) (MSDE_EPI_DACT), then + res[m,n].  Every out_s is
+ * also written to memory.  W_s is read as [K_s][N_s] (row stride ldw): the transposed nn.Linear weight for a forward chain,
+ * the weight as stored for a chain of input gradients.  SchNet's node-level chains (schnet.py:163-167,97,189,118-120):
+ * CFConv.lin2 -> ShiftedSoftplus -> InteractionBlock.lin -> + residual -> the next block's CFConv.lin1.
+ * N_s <= 320, N_s % 4 == K_s % 4 == 0, K_0 <= 768, 16-byte aligned rows; otherwise MSDE_EUNSUP.  flags / ld_max: set by the
+ * library. */
+#define MSDE_CHAIN_MAX 4
+typedef struct msde_chain_stage {
+  const float* W;
+  const float* bias;
+  const float* res;
+  const float* dact;
+  float* out;
+  int N, K, ldw, ldres, lddact, ldout, act, epi, flags;
+} msde_chain_stage;
+typedef struct msde_chain_desc {
+  const float* A;
+  int lda, M, nstages, ld_max;
+  msde_chain_stage st[MSDE_CHAIN_MAX];
+} msde_chain_desc;
+int msde_gemm_chain(const msde_chain_desc* desc, void* stream);
+
 /* Finish the fused BatchNorm statistics (one small launch): forward -> scale = gamma rstd, shift = beta - mean scale (what
  * MSDE_RS_AXF_AFFINE of the consuming product applies), save_mean / save_rstd for the backward, running buffers updated
  * with `momentum` (unbiased variance), exactly as msde_bn_fwd.  Backward -> the three vectors of MSDE_RS_AXF_BNBWD and

@@ -363,6 +363,149 @@ gemm_rsa_kernel(const msde_rs_desc d) {
 }
 
 // ===================================================================================================================
+// Chained products: up to MSDE_CHAIN_MAX Linear layers applied to a strip of 16 rows without leaving the workgroup.  The
+// result strip of stage s (bias, activation or its derivative, residual -- the epilogue of the single product) is written to
+// memory (every intermediate of these chains is needed again: by the backward pass, or as the next operator's input) AND to
+// the other LDS strip, where it is the A operand of stage s + 1.  One launch instead of one per layer: no launch boundary,
+// no re-staging of the strip, no global round trip between the layers.  Used for SchNet's node-level chains
+// (schnet.py:163-167,97,189,118-120): lin2 -> ssp -> lin -> + residual -> next block's lin1, and their input gradients.
+// Per stage: N <= 320 (five 16-column tiles per wave), N % 4 == 0, K % 4 == 0, weights as [K][N].
+// ===================================================================================================================
+static inline bool rs_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int T, int NW>
+__device__ __forceinline__ void chain_stage(const msde_chain_desc& c, int s, const float* __restrict__ Ain, float* __restrict__ Aout,
+                                            int m0, bool last) {
+  const msde_chain_stage& q = c.st[s];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  const int wcol = wave * 16 * T;
+  const int ld_in = rs_lds_ld(q.K), ld_out = rs_lds_ld(q.N);
+  f32x4 acc[T][1];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  rsa_mma<1, T, false>(Ain, ld_in, q.W, q.ldw, q.N, q.K, wcol, acc, 0);
+  if (wcol < q.N) {
+    msde_rs_desc d;
+    d.M = c.M; d.N = q.N; d.K = q.K;
+    d.bias = q.bias; d.C = q.out; d.ldc = q.ldout; d.Z = nullptr; d.ldz = 0;
+    d.R = q.dact; d.ldr = q.lddact; d.Res = q.res; d.ldres = q.ldres;
+    d.act = q.act; d.epi = q.epi; d.flags = q.flags; d.stats = nullptr; d.stats_mode = 0; d.m_valid = nullptr;
+    d.stats_z = nullptr; d.stats_mean = nullptr; d.ld_sz = 0;
+    rs_epilogue<1, T>(d, acc, wcol, m0, 0, 16);
+    if (!last) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int col = rs_col<T>(wcol, t, n);
+        if (col < q.N) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Aout[(4 * g + e) * ld_out + col] = acc[t][0][e];
+        }
+      }
+    }
+  }
+  if (!last) {        // columns N .. Kpad(N) of the next stage's operand are zero
+    const int kp = rs_kpad(q.N);
+    for (int i = threadIdx.x; i < 16 * (kp - q.N); i += 64 * NW) {
+      const int r = i / (kp - q.N), cc = q.N + i % (kp - q.N);
+      Aout[r * ld_out + cc] = 0.f;
+    }
+  }
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1)
+gemm_chain_kernel(const msde_chain_desc c) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int m0 = blockIdx.x * 16;
+  float* buf[2] = {lds, lds + 16 * c.ld_max};
+  {   // stage 0 operand: the strip of A, all loads in flight at once (<= 3 pieces per lane and row, K <= 768)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int K = c.st[0].K, kq = rs_kpad(K) / 4, ld = rs_lds_ld(K);
+    constexpr int RW = 16 / NW;
+    float4 v[RW][3];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int gm = m0 + wave + NW * i, k = 4 * (lane + 64 * j);
+        v[i][j] = (gm < c.M && k < K) ? *reinterpret_cast<const float4*>(c.A + (size_t)gm * c.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int q = lane + 64 * j;
+        if (q < kq) *reinterpret_cast<float4*>(buf[0] + (wave + NW * i) * ld + 4 * q) = v[i][j];
+      }
+  }
+  __syncthreads();
+  for (int s = 0; s < c.nstages; ++s) {
+    const bool last = s + 1 == c.nstages;
+    const int T = (((c.st[s].N + 15) >> 4) + NW - 1) / NW;
+    const float* in = buf[s & 1];
+    float* out = buf[(s + 1) & 1];
+    if (NW == 4) {
+      switch (T) {
+        case 1: chain_stage<1, NW>(c, s, in, out, m0, last); break;
+        case 2: chain_stage<2, NW>(c, s, in, out, m0, last); break;
+        case 3: chain_stage<3, NW>(c, s, in, out, m0, last); break;
+        case 4: chain_stage<4, NW>(c, s, in, out, m0, last); break;
+        default: chain_stage<5, NW>(c, s, in, out, m0, last); break;
+      }
+    } else {
+      switch (T) {
+        case 1: chain_stage<1, NW>(c, s, in, out, m0, last); break;
+        case 2: chain_stage<2, NW>(c, s, in, out, m0, last); break;
+        default: chain_stage<3, NW>(c, s, in, out, m0, last); break;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int msde_gemm_chain(const msde_chain_desc* desc, void* stream) {
+  if (!desc) return MSDE_EINVAL;
+  msde_chain_desc c = *desc;
+  if (c.M < 0 || c.nstages < 1 || c.nstages > MSDE_CHAIN_MAX || !c.A) return MSDE_EINVAL;
+  if (c.M == 0) return 0;
+  if (c.lda % 4 || !rs_al16(c.A) || c.st[0].K > 768) return MSDE_EUNSUP;
+  int ld_max = 0;
+  for (int s = 0; s < c.nstages; ++s) {
+    msde_chain_stage& q = c.st[s];
+    if (!q.W || !q.out || q.N <= 0 || q.K <= 0) return MSDE_EINVAL;
+    if (q.N > 320 || q.N % 4 || q.K % 4 || q.ldw % 4 || !rs_al16(q.W)) return MSDE_EUNSUP;
+    if (s > 0 && q.K != c.st[s - 1].N) return MSDE_EINVAL;
+    if (q.epi == MSDE_EPI_DACT && q.act != MSDE_ACT_NONE && !q.dact) return MSDE_EINVAL;
+    if ((size_t)q.K * (size_t)q.ldw >= (1u << 30)) return MSDE_EUNSUP;
+    auto rows_ok = [](const void* p, int ldx) { return !p || (ldx % 4 == 0 && rs_al16(p)); };
+    q.flags = (rows_ok(q.out, q.ldout) && rows_ok(q.res, q.ldres) && rows_ok(q.dact, q.lddact) && rows_ok(q.bias, 0))
+                  ? MSDE_RS_VEC_STORE : 0;
+    ld_max = max(ld_max, max(rs_lds_ld(q.K), rs_lds_ld(q.N)));
+  }
+  c.ld_max = ld_max;
+  const size_t lds = (size_t)2 * 16 * ld_max * sizeof(float);
+  if (lds > 160 * 1024) return MSDE_EUNSUP;
+  hipStream_t st = as_stream(stream);
+  static const int waves = [] { const char* e = getenv("MSDE_CHAIN_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+  if (lds > 64 * 1024) {
+    static size_t granted = 0;
+    if (lds > granted) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_chain_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_chain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      granted = lds;
+    }
+  }
+  if (waves == 4) {
+    MSDE_LAUNCH(gemm_chain_kernel<4>, dim3((c.M + 15) / 16), dim3(256), lds, st, c);
+  } else {
+    MSDE_LAUNCH(gemm_chain_kernel<8>, dim3((c.M + 15) / 16), dim3(512), lds, st, c);
+  }
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ===================================================================================================================
 // finishing kernels of the fused BatchNorm: one launch of C / 16 workgroups; 16 lanes per column combine the per-strip
 // partials in a fixed order.
 // ===================================================================================================================
@@ -535,7 +678,6 @@ bn_bwd_colstats_kernel(const float* __restrict__ G, const float* __restrict__ Z,
 // ===================================================================================================================
 // host side
 // ===================================================================================================================
-static inline bool rs_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // geometry of the RSA kernel for (M, N, K): row tiles per strip (RT), tiles per wave (T), column splits (S = workgroups per
 // strip, each covering 64 T columns)

@@ -2353,6 +2353,132 @@ def schnet_tail(agg, h, lin2, lin):
     return _SchNetTail.apply(agg, h, lin2.weight, lin2.bias, lin.weight, lin.bias)
 
 
+def gemm_chain(A, stages):
+    """msde_gemm_chain (include/msde_hip.h): stages = [dict(W=[K][N] operand, N, K, out, bias=, act=, dact_from=, res=)];
+    stage s consumes the previous stage's result strip from LDS.  No autograd; raises where the kernel does not apply."""
+    d = _lib.ChainDesc()
+    d.A, d.lda, d.M, d.nstages = A.data_ptr(), _ld(A), A.size(0), len(stages)
+    for i, s in enumerate(stages):
+        q = d.st[i]
+        W = s["W"]
+        q.W, q.ldw, q.N, q.K = W.data_ptr(), W.stride(0), int(s["N"]), int(s["K"])
+        b = s.get("bias")
+        q.bias = b.data_ptr() if b is not None else None
+        q.out, q.ldout = s["out"].data_ptr(), _ld(s["out"])
+        q.act, q.epi = _lib.ACT[s.get("act")], _lib.EPI_ACT
+        r = s.get("dact_from")
+        if r is not None:
+            q.epi, q.dact, q.lddact = _lib.EPI_DACT, r.data_ptr(), _ld(r)
+        r = s.get("res")
+        if r is not None:
+            q.res, q.ldres = r.data_ptr(), _ld(r)
+    _lib.check(_lib.load().msde_gemm_chain(ctypes.byref(d), _stream()), "msde_gemm_chain")
+
+
+def chain_ok(M, dims):
+    """Layer widths msde_gemm_chain takes (dims[0] = input width)."""
+    return M > 0 and dims[0] <= 768 and all(x % 4 == 0 for x in dims) and all(x <= 320 for x in dims[1:])
+
+
+class _SchNetNodeChain(torch.autograd.Function):
+    """(h', x1') = (h + lin(ssp(lin2(agg))), lin1'(h')): the node-level tail of one SchNet interaction and the NEXT
+    interaction's CFConv.lin1 (schnet.py:163-167,97,189 and :160) as ONE chained-product launch -- the 16-row strip stays
+    in LDS between the three layers.  Backward: one launch again: g_h = g_x1' W1' + g_h' (the residual branch),
+    g_x = (g_h Wl) * ssp'(a), g_agg = g_x W2; the three weight gradients are queued."""
+
+    @staticmethod
+    def forward(ctx, agg, h, W2, b2, Wl, bl, Wn):
+        agg, h = _f32(agg), _f32(h)
+        M, F = agg.shape
+        Hd, Fn = W2.size(0), Wn.size(0)
+        dev = agg.device
+        a = torch.empty(M, Hd, dtype=torch.float32, device=dev)
+        hn = torch.empty(M, Hd, dtype=torch.float32, device=dev)
+        x1 = torch.empty(M, Fn, dtype=torch.float32, device=dev)
+        gemm_chain(agg, [dict(W=weight_t(W2), N=Hd, K=F, bias=b2, act="ssp", out=a),
+                         dict(W=weight_t(Wl), N=Hd, K=Hd, bias=bl, res=h, out=hn),
+                         dict(W=weight_t(Wn), N=Fn, K=Hd, out=x1)])
+        ctx.save_for_backward(agg, a, hn, W2, Wl, Wn)
+        ctx.deferrable = all(t.is_leaf for t in (W2, b2, Wl, bl, Wn))
+        return hn, x1
+
+    @staticmethod
+    def backward(ctx, g_hn, g_x1):
+        agg, a, hn, W2, Wl, Wn = ctx.saved_tensors
+        M, F = agg.shape
+        Hd = W2.size(0)
+        dev = agg.device
+        stages = []
+        if g_x1 is not None:
+            g_x1 = _f32(g_x1)
+            g_h = torch.empty(M, Hd, dtype=torch.float32, device=dev)
+            stages.append(dict(W=Wn, N=Hd, K=Wn.size(0), res=(_f32(g_hn) if g_hn is not None else None), out=g_h))
+            first = g_x1
+        else:
+            g_h = _f32(g_hn)
+            first = g_h
+        gx = torch.empty(M, Hd, dtype=torch.float32, device=dev)
+        stages.append(dict(W=Wl, N=Hd, K=Hd, act="sspo", dact_from=a, out=gx))
+        g_agg = torch.empty(M, F, dtype=torch.float32, device=dev)
+        stages.append(dict(W=W2, N=F, K=Hd, out=g_agg))
+        gemm_chain(first, stages)
+        gWn = weight_grad(g_x1, hn, False, ctx.deferrable)[0] if g_x1 is not None else None
+        gWl, gbl = weight_grad(g_h, a, True, ctx.deferrable)
+        gW2, gb2 = weight_grad(gx, agg, True, ctx.deferrable)
+        return g_agg, g_h, gW2, gb2, gWl, gbl, gWn
+
+
+class _SchNetHeadChain(torch.autograd.Function):
+    """lin2_h(ssp(lin1_h(h + lin(ssp(lin2(agg)))))): the last interaction's node-level tail and SchNet's output head
+    (schnet.py:163-167,97,189,118-120) as one chained-product launch of four layers; one launch in the backward."""
+
+    @staticmethod
+    def forward(ctx, agg, h, W2, b2, Wl, bl, W1h, b1h, W2h, b2h):
+        agg, h = _f32(agg), _f32(h)
+        M, F = agg.shape
+        Hd = W2.size(0)
+        dev = agg.device
+        a, h6, hh, out = (torch.empty(M, n, dtype=torch.float32, device=dev) for n in (Hd, Hd, W1h.size(0), W2h.size(0)))
+        gemm_chain(agg, [dict(W=weight_t(W2), N=Hd, K=F, bias=b2, act="ssp", out=a),
+                         dict(W=weight_t(Wl), N=Hd, K=Hd, bias=bl, res=h, out=h6),
+                         dict(W=weight_t(W1h), N=W1h.size(0), K=Hd, bias=b1h, act="ssp", out=hh),
+                         dict(W=weight_t(W2h), N=W2h.size(0), K=W1h.size(0), bias=b2h, out=out)])
+        ctx.save_for_backward(agg, a, h6, hh, W2, Wl, W1h, W2h)
+        ctx.deferrable = all(t.is_leaf for t in (W2, b2, Wl, bl, W1h, b1h, W2h, b2h))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        agg, a, h6, hh, W2, Wl, W1h, W2h = ctx.saved_tensors
+        g = _f32(g)
+        M, F = agg.shape
+        Hd = W2.size(0)
+        dev = agg.device
+        g_zh = torch.empty(M, W1h.size(0), dtype=torch.float32, device=dev)
+        g_h = torch.empty(M, Hd, dtype=torch.float32, device=dev)
+        gx = torch.empty(M, Hd, dtype=torch.float32, device=dev)
+        g_agg = torch.empty(M, F, dtype=torch.float32, device=dev)
+        gemm_chain(g, [dict(W=W2h, N=W2h.size(1), K=W2h.size(0), act="sspo", dact_from=hh, out=g_zh),
+                       dict(W=W1h, N=Hd, K=W1h.size(0), out=g_h),
+                       dict(W=Wl, N=Hd, K=Hd, act="sspo", dact_from=a, out=gx),
+                       dict(W=W2, N=F, K=Hd, out=g_agg)])
+        gW2h, gb2h = weight_grad(g, hh, True, ctx.deferrable)
+        gW1h, gb1h = weight_grad(g_zh, h6, True, ctx.deferrable)
+        gWl, gbl = weight_grad(g_h, a, True, ctx.deferrable)
+        gW2, gb2 = weight_grad(gx, agg, True, ctx.deferrable)
+        return g_agg, g_h, gW2, gb2, gWl, gbl, gW1h, gb1h, gW2h, gb2h
+
+
+def schnet_node_chain(agg, h, lin2, lin, next_lin1):
+    """(h + lin(ssp(lin2(agg))), next_lin1 of that) -- see _SchNetNodeChain."""
+    return _SchNetNodeChain.apply(agg, h, lin2.weight, lin2.bias, lin.weight, lin.bias, next_lin1.weight)
+
+
+def schnet_head_chain(agg, h, lin2, lin, head1, head2):
+    return _SchNetHeadChain.apply(agg, h, lin2.weight, lin2.bias, lin.weight, lin.bias, head1.weight, head1.bias,
+                                  head2.weight, head2.bias)
+
+
 # ---- diagnostics: device timestamps in stream order (tools/probes/step_timeline.py) ---------------------------
 STAMPS = None            # {"buf": int64[256] device tensor, "names": [..]} when enabled
 

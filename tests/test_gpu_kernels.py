@@ -1055,6 +1055,57 @@ def test_gemm_rs_epilogues(dev, act):
     assert_close(gpre, gpre_ref.double() + r2.double(), 1e-4, 1e-5, f"rs dact {act}")
 
 
+@pytest.mark.parametrize("M,F,Hd", [(3588, 128, 300), (1, 128, 300), (531, 16, 16), (40, 64, 320), (777, 128, 36)])
+def test_gemm_chain_schnet_node_layers(dev, M, F, Hd):
+    """msde_gemm_chain on SchNet's node-level chains: (h', x1') = (h + lin(ssp(lin2(agg))), lin1'(h')) and the four-layer
+    form with the output head, forward values and every gradient (inputs, weights, biases) against torch autograd in fp64
+    of the same fp32 inputs."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(M + Hd)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    agg, h = mk(M, F), mk(M, Hd)
+    W2, b2, Wl, bl = mk(Hd, F, sc=F ** -0.5), mk(Hd, sc=0.1), mk(Hd, Hd, sc=Hd ** -0.5), mk(Hd, sc=0.1)
+    Wn = mk(F, Hd, sc=Hd ** -0.5)
+    W1h, b1h, W2h, b2h = mk(Hd, Hd, sc=Hd ** -0.5), mk(Hd, sc=0.1), mk(Hd, Hd, sc=Hd ** -0.5), mk(Hd, sc=0.1)
+    g_hn, g_x1, g_out = mk(M, Hd), mk(M, F), mk(M, Hd)
+    ssp = lambda t: torch.nn.functional.softplus(t) - math.log(2.0)
+
+    def leaves(ts, dt, d):
+        return [t.to(d, dt).clone().requires_grad_(True) for t in ts]
+
+    # three layers
+    ref = leaves([agg, h, W2, b2, Wl, bl, Wn], torch.float64, "cpu")
+    a_, h_, W2_, b2_, Wl_, bl_, Wn_ = ref
+    hn_ref = h_ + ssp(a_ @ W2_.t() + b2_) @ Wl_.t() + bl_
+    x1_ref = hn_ref @ Wn_.t()
+    gref = torch.autograd.grad([hn_ref, x1_ref], ref, [g_hn.double(), g_x1.double()])
+    got = leaves([agg, h, W2, b2, Wl, bl, Wn], torch.float32, dev)
+    hn, x1 = hip._SchNetNodeChain.apply(*got)
+    assert_close(hn, hn_ref, 2e-5, 2e-5, "chain h'")
+    assert_close(x1, x1_ref, 2e-5, 2e-5, "chain x1'")
+    ggot = torch.autograd.grad([hn, x1], got, [g_hn.to(dev), g_x1.to(dev)])
+    for name, a, b in zip(("agg", "h", "W2", "b2", "Wl", "bl", "Wn"), ggot, gref):
+        assert_close(a, b, 2e-4, 2e-4 * max(1.0, float(b.abs().max())), "chain grad " + name)
+    # only the residual output used (g_x1 is None in the backward)
+    got = leaves([agg, h, W2, b2, Wl, bl, Wn], torch.float32, dev)
+    hn, x1 = hip._SchNetNodeChain.apply(*got)
+    ggot = torch.autograd.grad([hn], got[:6], [g_hn.to(dev)])
+    gref1 = torch.autograd.grad([h_ + ssp(a_ @ W2_.t() + b2_) @ Wl_.t() + bl_], ref[:6], [g_hn.double()])
+    for name, a, b in zip(("agg", "h", "W2", "b2", "Wl", "bl"), ggot, gref1):
+        assert_close(a, b, 2e-4, 2e-4 * max(1.0, float(b.abs().max())), "chain (residual only) grad " + name)
+    # four layers (output head)
+    ref = leaves([agg, h, W2, b2, Wl, bl, W1h, b1h, W2h, b2h], torch.float64, "cpu")
+    a_, h_, W2_, b2_, Wl_, bl_, W1h_, b1h_, W2h_, b2h_ = ref
+    out_ref = ssp((h_ + ssp(a_ @ W2_.t() + b2_) @ Wl_.t() + bl_) @ W1h_.t() + b1h_) @ W2h_.t() + b2h_
+    gref = torch.autograd.grad([out_ref], ref, [g_out.double()])
+    got = leaves([agg, h, W2, b2, Wl, bl, W1h, b1h, W2h, b2h], torch.float32, dev)
+    out = hip._SchNetHeadChain.apply(*got)
+    assert_close(out, out_ref, 3e-5, 3e-5, "head chain out")
+    ggot = torch.autograd.grad([out], got, [g_out.to(dev)])
+    for name, a, b in zip(("agg", "h", "W2", "b2", "Wl", "bl", "W1h", "b1h", "W2h", "b2h"), ggot, gref):
+        assert_close(a, b, 2e-4, 2e-4 * max(1.0, float(b.abs().max())), "head chain grad " + name)
+
+
 @pytest.mark.parametrize("M,C1,C2,relu,bound", [(3588, 600, 300, True, None), (3588, 300, 600, False, None),
                                                 (35186, 300, 32, True, None), (200, 64, 48, True, 150),
                                                 (3648, 600, 300, True, 3588)])
