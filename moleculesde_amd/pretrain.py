@@ -260,7 +260,9 @@ class Trainer:
             pl = _pl.get_plan(batch)
             rp, _ = hip.radius_plan(batch.positions, pl.batch_i32, pl.mol_ptr, m3.cutoff, pl.E_r_cap, 32)
             keep = rp.src >= 0                                    # host sync: PaiNN batches are not graph-captured
-            ei = torch.stack([rp.dst[keep], rp.src[keep]]).long()
+            # PyG radius_graph orientation: row 0 = source, row 1 = target (the 32-neighbour cap applies per TARGET);
+            # PaiNN aggregates at row 0 (painn.py:235), i.e. at the source, exactly as the reference does
+            ei = torch.stack([rp.src[keep], rp.dst[keep]]).long()
             batch.radius_edge_index = ei
         return m3(batch.x[:, 0], batch.positions, ei, batch.batch, return_latent=True)
 
