@@ -431,8 +431,9 @@ def config4_sampler(dev, pc_steps=1000, cpu_steps=10):
 def config5_md17(dev, steps=20, cpu_steps=5):
     """BASELINE.json configs[4]: MD17-aspirin-shaped force fine-tuning step (finetune_MD17.py:47-78): 21 atoms, batch 1,
     SchNet(300, 128 filters, 6 interactions, 51 Gaussians, cutoff 10) + Linear head; energy -> forces by
-    autograd.grad(create_graph=True) -> L1 losses -> backward through the forces -> torch Adam.  Eager (latency bound:
-    ~40 small launches per interaction block and order of differentiation).  Beside it the oracle on the host cores."""
+    autograd.grad(create_graph=True) -> L1 losses -> backward through the forces -> Adam, through
+    moleculesde_amd.finetune_md17.ForceTrainer: the whole step as ONE replayed hipGraph (`ms_per_step`) and launched from
+    the host (`eager_ms_per_step`: ~1500 tiny launches, latency bound).  Beside it the oracle on the host cores."""
     import moleculesde_amd.geom3d as G
     from moleculesde_amd.synthetic import make_md17_batch
     kw = dict(hidden_channels=300, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10, readout="mean", node_class=119)
@@ -450,20 +451,40 @@ def config5_md17(dev, steps=20, cpu_steps=5):
         opt.step()
         return loss
 
+    from moleculesde_amd.finetune_md17 import ForceTrainer
     sch, head = G.SchNet(**kw).to(dev), torch.nn.Linear(300, 1).to(dev)
-    opt = torch.optim.Adam(list(sch.parameters()) + list(head.parameters()), lr=5e-4)
     b = G.prepare_batch(cpu_b.clone(), dev)
+    ft = ForceTrainer(sch, head, lr=5e-4, energy_coeff=1.0, force_coeff=1.0)
+    et, ftg = e_t.to(dev).view(-1), f_t.to(dev)
     for _ in range(3):
-        step(sch, head, opt, b, e_t.to(dev), f_t.to(dev))
+        ft.step(b, et, ftg)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = step(sch, head, opt, b, e_t.to(dev), f_t.to(dev))
+        loss = ft.step(b, et, ftg)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    dt_eager = (time.perf_counter() - t0) / steps
     out = {"what": "MD17-aspirin-shaped SchNet force fine-tune step, 21 atoms, batch 1 (energy, forces with create_graph, "
-                   "backward through the forces, Adam)", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
-           "finite": bool(torch.isfinite(loss)), "launch": "eager"}
+                   "backward through the forces, Adam): moleculesde_amd.finetune_md17.ForceTrainer",
+           "steps": steps, "eager_ms_per_step": round(dt_eager * 1e3, 2)}
+    try:
+        ft.capture(b, et, ftg)
+        g = torch.Generator().manual_seed(1)
+        confs = [(cpu_b.positions + 0.05 * torch.randn(cpu_b.positions.shape, generator=g)).to(dev) for _ in range(8)]
+        for i in range(4):
+            ft.step_graph(confs[i % 8], et, ftg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(10 * steps):
+            loss = ft.step_graph(confs[i % 8], et, ftg)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (10 * steps)
+        out.update({"ms_per_step": round(dt * 1e3, 3), "launch": "ONE hipGraph for the whole step, replayed on 8 conformations "
+                    "(positions / energies / forces copied into static buffers)", "timed_steps": 10 * steps})
+    except Exception as exc:
+        print(f"[bench] MD17 capture failed ({type(exc).__name__}: {exc}); reporting eager", file=sys.stderr)
+        out.update({"ms_per_step": round(dt_eager * 1e3, 2), "launch": "eager"})
+    out["finite"] = bool(torch.isfinite(loss))
     try:
         from oracle import restate as R
         torch.set_num_threads(min(_host_cores()[0], 16))
@@ -569,6 +590,7 @@ def main():
                          "0 = the round-1 mode (one graph per resident batch)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_configs45", action="store_true", help="skip the configs[3] (sampler) / configs[4] (MD17) timings")
+    ap.add_argument("--no_pipeline", action="store_true", help="skip the two-bucket mode (plans of batch t+1 built beside step t)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host (no hipGraph replay)")
     ap.add_argument("--debug_dp_path", action="store_true",
                     help="one GPU: initialise a 1-rank RCCL group and run the multi-GPU step structure "
@@ -656,6 +678,29 @@ def main():
             assert ok
             launch = ("ONE hipGraph for all batches: %d distinct batches streamed as raw collated arrays (1 copy each), "
                       "plans + extend_graph built on the device inside the graph" % len(blobs))
+            dt_one_graph = dt
+            if not a.no_pipeline:
+                # two buckets used alternately: the plans of batch t+1 are built (plan graph, third stream) while the
+                # step of batch t runs -- the same work per batch, batch construction off the step's critical path
+                pipe = pretrain.BucketPipeline(trainer, caps, blobs[0])
+                state = {"i": 0}
+                pipe.submit(blobs[0])
+
+                def piped_step(_):
+                    state["i"] += 1
+                    pipe.submit(blobs[state["i"] % len(blobs)])
+                    return pipe.step()
+                for s in range(a.warmup):
+                    piped_step(None)
+                dt_pipe = timed(piped_step, blobs, a.steps)
+                pipe.step()                       # drain the batch submitted last
+                torch.cuda.synchronize()
+                assert pipe.check()
+                if dt_pipe < dt:
+                    dt = dt_pipe
+                    launch = ("two capacity buckets used alternately (one captured step graph + one plan graph each): %d "
+                              "distinct batches streamed as raw collated arrays (1 copy each); plans + extend_graph of "
+                              "batch t+1 built on the device beside the step of batch t" % len(blobs))
             pad = {k: round(getattr(caps, k) / max(n, 1), 3) for k, n in
                    (("N", sum(x["N"] for x in needs) / len(needs)), ("E_b", sum(x["E_b"] for x in needs) / len(needs)),
                     ("E_e", sum(x["E_e"] for x in needs) / len(needs)), ("P", sum(x["P"] for x in needs) / len(needs)))}
@@ -678,6 +723,8 @@ def main():
                            "ms_per_step_blobs_from_pinned_host": round(dt_h2d / a.steps * 1e3, 3),
                            "ms_per_step_blobs_from_pinned_host_prefetched": round(dt_fed / a.steps * 1e3, 3),
                            "ms_per_step_4_resident_batches_own_graphs": round(dt_pool / a.steps * 1e3, 3),
+                           "ms_per_step_one_graph_plan_inside": round(dt_one_graph / a.steps * 1e3, 3),
+                           "ms_per_step_two_buckets_plan_ahead": None if a.no_pipeline else round(dt_pipe / a.steps * 1e3, 3),
                            "host_prep_s_synthetic_generation_and_packing": round(host_prep_s, 2)}
         except Exception as exc:
             print(f"[bench] bucket mode failed ({type(exc).__name__}: {exc}); reporting the per-shape-graph mode",

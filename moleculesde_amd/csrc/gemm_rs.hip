@@ -486,7 +486,7 @@ extern "C" int msde_gemm_chain(const msde_chain_desc* desc, void* stream) {
   const size_t lds = (size_t)2 * 16 * ld_max * sizeof(float);
   if (lds > 160 * 1024) return MSDE_EUNSUP;
   hipStream_t st = as_stream(stream);
-  static const int waves = [] { const char* e = getenv("MSDE_CHAIN_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+  static const int waves = [] { const char* e = getenv("MSDE_CHAIN_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
   if (lds > 64 * 1024) {
     static size_t granted = 0;
     if (lds > granted) {

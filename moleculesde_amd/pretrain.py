@@ -554,7 +554,7 @@ class Trainer:
         from .bucket import Bucket
         return Bucket(caps, self.device)
 
-    def capture_bucket(self, bk, warm_blob, eager_steps=2):
+    def capture_bucket(self, bk, warm_blob, eager_steps=2, split_plan=False):
         """Warm up on one raw batch (sizes the workspaces), then capture {device-side plan construction + step} for
         the bucket's capacities.  Afterwards every batch that fits the capacities is `step_bucket(bk, blob)`: one
         copy of its raw blob + one graph replay, no per-batch host work."""
@@ -566,6 +566,13 @@ class Trainer:
             raise RuntimeError(f"batch does not fit the bucket: {sizes} vs {bk.caps.as_dict()}")
         for _ in range(eager_steps):
             self.step(bk.batch)
+        if split_plan:
+            # the plan construction as a graph of its own (BucketPipeline runs it for batch t+1 beside the step of batch t)
+            torch.cuda.synchronize()
+            bk.plan_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(bk.plan_graph, capture_error_mode="thread_local"):
+                bk.build_plan_on_device(None)
+            return self.capture(bk.batch)
         side = self._side_stream if (self.overlap_streams and PLAN_LISTS_ON_SIDE) else None
         return self.capture(bk.batch, pre=lambda: bk.build_plan_on_device(side))
 
@@ -597,6 +604,61 @@ class Trainer:
 
     def save(self, path):
         torch.save(self.state_dicts(), path)
+
+
+class BucketPipeline:
+    """Two buckets of the same capacities used alternately, so that batch construction leaves the step's critical path:
+    while the captured step of batch t runs, the raw blob of batch t+1 is copied into the OTHER bucket and its plans
+    (CSR views, extended graph, row lists: csrc/plan.hip) are built there by a captured plan graph on a third stream.  The
+    step graph of a bucket then starts with the encoders' first kernels instead of ~100 us of plan construction.
+        pipe = BucketPipeline(trainer, caps, warm_blob)
+        pipe.submit(blob_0)
+        for t in ...: pipe.submit(blob_{t+1}); loss = pipe.step()
+    Events both ways, no host synchronisation: a bucket is refilled only after the step that read it has finished."""
+
+    def __init__(self, trainer, caps, warm_blob):
+        self.tr = trainer
+        self.bks = [trainer.make_bucket(caps) for _ in range(2)]
+        for bk in self.bks:
+            trainer.capture_bucket(bk, warm_blob, split_plan=True)
+        self.stream = torch.cuda.Stream(device=trainer.device)
+        self.ready = [None, None]       # recorded on the plan stream: bucket i holds a built batch
+        self.done = [None, None]        # recorded on the compute stream: the step that read bucket i has finished
+        self.head = self.tail = 0       # batches submitted / stepped
+
+    def submit(self, blob):
+        assert self.head - self.tail < 2, "BucketPipeline: two batches are already waiting"
+        i = self.head & 1
+        bk = self.bks[i]
+        with torch.cuda.stream(self.stream):
+            if self.done[i] is not None:
+                self.stream.wait_event(self.done[i])
+            bk.load(blob)
+            bk.plan_graph.replay()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.ready[i] = ev
+        self.head += 1
+
+    def step(self):
+        assert self.tail < self.head, "BucketPipeline: nothing submitted"
+        i = self.tail & 1
+        bk = self.bks[i]
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.ready[i])
+        if bk.poll_overflow():
+            from .bucket import BucketOverflow
+            raise BucketOverflow(f"a batch did not fit the bucket {bk.caps.as_dict()}: its rows were left inert, that "
+                                 "step is not a valid update")
+        loss = self.tr.step_graph(bk.batch)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.done[i] = ev
+        self.tail += 1
+        return loss
+
+    def check(self):
+        return all(bk.check()[0] for bk in self.bks)
 
 
 def main(argv=None):

@@ -682,6 +682,60 @@ def test_md17_force_path_double_backward(dev, bs):
     assert_close(head.weight.grad, ohead.weight.grad, 1e-3, 1e-5, "head grad")
 
 
+@pytest.mark.timeout(600)
+def test_md17_force_trainer_graph_replay_matches_eager_and_oracle(dev):
+    """moleculesde_amd.finetune_md17.ForceTrainer (finetune_MD17.py:34-88): the whole force fine-tuning step -- energy,
+    forces with create_graph, L1 losses with the 0.05 / 0.95 coefficients, backward through the forces, Adam -- captured
+    as ONE hipGraph and replayed on new conformations gives the losses of the eager steps (same kernels: 1e-6) and of the
+    reference loop on the oracle with torch.optim.Adam (1e-3 relative, BASELINE north star)."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import hip
+    from moleculesde_amd.finetune_md17 import ForceTrainer
+    from moleculesde_amd.synthetic import make_md17_batch
+    kw = dict(hidden_channels=64, num_filters=32, num_interactions=3, num_gaussians=51, cutoff=10, readout="mean", node_class=119)
+    bs, steps = 2, 5
+    cpu_b = make_md17_batch(bs, seed=3, n_atoms=21)
+    g = torch.Generator().manual_seed(12)
+    confs = [cpu_b.positions + 0.05 * torch.randn(cpu_b.positions.shape, generator=g) for _ in range(steps)]
+    ys = [torch.randn(bs, generator=g) for _ in range(steps)]
+    fs = [torch.randn(cpu_b.x.size(0), 3, generator=g) for _ in range(steps)]
+
+    torch.manual_seed(7)
+    osch, ohead = R.SchNet(**kw), torch.nn.Linear(64, 1)
+    state, hstate = {k: v.clone() for k, v in osch.state_dict().items()}, {k: v.clone() for k, v in ohead.state_dict().items()}
+    oopt = torch.optim.Adam(list(osch.parameters()) + list(ohead.parameters()), lr=5e-4)
+    ref = []
+    for t in range(steps):          # the reference's loop, finetune_MD17.py:46-78
+        pos = confs[t].clone().requires_grad_(True)
+        e = ohead(osch(cpu_b.x, pos, cpu_b.batch)).squeeze(1)
+        f = -torch.autograd.grad(e, pos, grad_outputs=torch.ones_like(e), create_graph=True, retain_graph=True)[0]
+        loss = 0.05 * torch.nn.functional.l1_loss(e, ys[t]) + 0.95 * torch.nn.functional.l1_loss(f, fs[t])
+        oopt.zero_grad(); loss.backward(); oopt.step()
+        ref.append(float(loss))
+
+    def make():
+        sch, head = G.SchNet(**kw), torch.nn.Linear(64, 1)
+        sch.load_state_dict(state); head.load_state_dict(hstate)
+        return ForceTrainer(sch.to(dev), head.to(dev), lr=5e-4)
+    b = G.prepare_batch(cpu_b.clone(), dev)
+    ft = make()
+    eager = []
+    for t in range(steps):
+        b.positions = confs[t].to(dev)
+        eager.append(float(ft.step(b, ys[t].to(dev), fs[t].to(dev))))
+    ft = make()
+    p0 = ft.opt.flat_p.clone()
+    b.positions = confs[0].to(dev)
+    ft.capture(b, ys[0].to(dev), fs[0].to(dev))
+    ft.opt.flat_p.copy_(p0); ft.opt.m.zero_(); ft.opt.v.zero_(); ft.opt.step_dev.zero_()
+    hip.bump_weight_epoch()
+    replay = [float(ft.step_graph(confs[t].to(dev), ys[t].to(dev), fs[t].to(dev))) for t in range(steps)]
+    print("MD17 losses: oracle", ref, "eager", eager, "graph", replay)
+    for t in range(steps):
+        assert abs(replay[t] - eager[t]) <= 1e-6 * abs(eager[t]) + 1e-7, (t, replay[t], eager[t])
+        assert abs(eager[t] - ref[t]) <= 1e-3 * abs(ref[t]), (t, eager[t], ref[t])
+
+
 def test_md17_force_path_runs_on_library_kernels(dev):
     """§8 a18: energy -> forces (create_graph) -> backward through the forces launches the kernels of the closed
     twice-differentiable operator set (moleculesde_amd.dd) and no torch operator inside SchNet.  What remains on torch is
