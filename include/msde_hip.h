@@ -259,6 +259,14 @@ int msde_cfconv_fused_bwd_w_slabs(int E_cap, int max_workgroups);
 int msde_edge_geometry_fwd(const float* pos, const int* src, const int* dst, int E,
                            const float* Wd, const float* Wc, int C, float* feat_d, float* feat_i,
                            float* feat_j, float* angle, float* basis, void* stream);
+/* the same with strided outputs: feat_i / feat_j rows at stride feat_ld (>= 4C: e.g. the two halves of one [E, 2, 4C]
+ * buffer, so that a layer shared by both is ONE product over 2E rows); angle_ld >= 4: (pseudo_sin, pseudo_cos, 0, 0) is
+ * written to angle[e * angle_ld ..+3] and, when angle_zero_off > 0, four zeros to angle[e * angle_ld + angle_zero_off ..+3]
+ * -- column blocks of the buffer the `project` MLP reads (SDE_model_2D_to_3D.py:369-370), so no torch.cat. */
+int msde_edge_geometry_fwd_ld(const float* pos, const int* src, const int* dst, int E,
+                              const float* Wd, const float* Wc, int C, float* feat_d, float* feat_i,
+                              float* feat_j, int feat_ld, float* angle, int angle_ld, int angle_zero_off, float* basis,
+                              void* stream);
 /* PyG TransformerConv message+softmax+aggregate — equivariant_scorenetwork.py:18-24,35:
  * s[e,h] = q[dst]·(k[src]+ee[e]) / sqrt(Ch); alpha = softmax over in-edges of dst;
  * out[i] = sum_e dropout(alpha)[e,h] * (v[src]+ee[e]).  H*Ch == D <= 64.  alpha [E,H] is saved.
@@ -455,10 +463,14 @@ int msde_affine_cols(const float* X, int M, int C, const float* scale, const flo
  * fused ReLU; Y = the BatchNorm + ReLU output); rows >= *m_valid contribute nothing.  C % 4 == 0. */
 int msde_bn_bwd_colstats(const float* G, const float* Z, const float* Y, const float* mean, int M, const int* m_valid,
                          int C, float* stats, void* stream);
-/* dst_i [cols_i][rows_i] = src_i [rows_i][cols_i]^T for n contiguous fp32 matrices in one launch: the transposed weight
- * copies the forward products of msde_gemm_rs read (refreshed once per optimiser step).  table: n rows of 4 x int64
- * {src, dst, rows, cols} (device); prefix [n+1]: first 32 x 32 tile of each matrix, prefix[n] = total_tiles. */
+/* Re-laid-out copies of n fp32 blocks in one launch: the transposed weight copies the forward products of msde_gemm_rs read
+ * and the stacked / permuted operands of fused layers (refreshed once per optimiser step).  table: n rows of 8 x int64
+ * {src, dst, rows, cols, src_ld, dst_ld, mode, 0} (device); mode 0: dst[c * dst_ld + r] = src[r * src_ld + c] (transpose of
+ * the rows x cols block), mode 1: dst[r * dst_ld + c] = src[r * src_ld + c] (copy); prefix [n+1]: first 32 x 32 tile of each
+ * block, prefix[n] = total_tiles. */
 int msde_transpose_multi(const long long* table, const int* prefix, int n, int total_tiles, void* stream);
+/* the same for one block, no tables */
+int msde_relayout(const float* src, int src_ld, float* dst, int dst_ld, int rows, int cols, int mode, void* stream);
 /* the same for one matrix, no tables: dst [cols][rows] = src [rows][cols]^T */
 int msde_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 
@@ -616,9 +628,13 @@ int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void
 /* Batched weight gradients: msde_linear_bwd_w_partial runs only the split-M GEMM of msde_linear_bwd_w and
  * leaves slabs [splits][N*K] (+ bias partials [splits][N] when want_bias) in `slabs`
  * (msde_linear_bwd_w_workspace_bytes); splits = msde_linear_bwd_w_splits(M,N,K).  msde_reduce_slabs_multi then
- * sums the slabs of MANY layers in one launch: rows[r] = {slab address, splits, entries n (= stride between
- * splits), output address} as four int64; prefix[r] = 256-entry chunks before row r, prefix[count] =
- * total_chunks.  Fixed summation order (16 interleaved lanes over the splits), like msde_linear_bwd_w. */
+ * sums the slabs of MANY layers in one launch: rows[r] = MSDE_REDUCE_ROW (8) int64 {slab address, splits, entries n,
+ * output address, row_len, slab_ld, out_ld, split_stride}: entry (i / row_len, i % row_len) of split z is read at
+ * slabs[z * split_stride + r * slab_ld + c] and the sum written to out[r * out_ld + c] -- a flat row has row_len =
+ * slab_ld = out_ld = split_stride = n; a 2-D row sums a column block of the slabs into a column block of a wider
+ * gradient (a layer consumed as part of a stacked / permuted operand).  prefix[r] = chunks before row r
+ * (msde_reduce_slabs_chunks), prefix[count] = total_chunks.  Fixed summation order, like msde_linear_bwd_w. */
+#define MSDE_REDUCE_ROW 8
 int msde_linear_bwd_w_splits(int M, int N, int K);
 /* Grouped form: the split-M GEMMs of many layers in ONE launch (same tile code, bit-identical slabs).
  * msde_linear_bwd_w_describe fills one HOST row (12 int64) of the problem table for a layer and returns the

@@ -52,6 +52,7 @@ SIGNATURES = {
     "msde_cfconv_pair_aggregate": [P, P, P, P, P, I, I, I, P, P],
     "msde_cfconv_pair_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P, P, P, P, P],
     "msde_edge_geometry_fwd": [P, P, P, I, P, P, I, P, P, P, P, P, P],
+    "msde_edge_geometry_fwd_ld": [P, P, P, I, P, P, I, P, P, P, I, P, I, I, P, P],
     "msde_edge_attention_fwd": [P, P, P, P, I, P, I, P, P, I, I, I, F, ULL, P, P, P, P],
     "msde_edge_attention_bwd": [P, P, P, P, I, P, I, P, I, P, P, P, I, I, I, F, ULL, P, P, P, P, P, I, P],
     "msde_frame_mix_mean_fwd": [P, P, P, I, P, P],
@@ -74,6 +75,7 @@ SIGNATURES = {
     "msde_gemm_chain": [P, P],
     "msde_transpose_multi": [P, P, I, I, P],
     "msde_transpose": [P, P, I, I, P],
+    "msde_relayout": [P, I, P, I, I, I, I, P],
     "msde_affine_cols": [P, I, I, P, P, I, P, P],
     "msde_bn_bwd_colstats": [P, P, P, P, I, P, I, P, P],
     "msde_gemm_rs_geometry": [I, I, I, P, P],

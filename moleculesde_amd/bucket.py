@@ -51,9 +51,11 @@ class Caps:
                 _round_up(P, 256) + 40]
         taken = {self.B, self.B * self.n_max, self.B + 1, self.B + 2} | {int(r) for r in reserved}
         for i, q in enumerate((64, 64, 256, 256, 256)):
-            while vals[i] in taken or vals[i] in vals[:i]:
+            # (2 * E_e is a row count too: tensors with two rows per extended edge)
+            while vals[i] in taken or vals[i] in vals[:i] or (i > 2 and vals[i] == 2 * vals[2]) or \
+                    (i == 2 and 2 * vals[i] in taken | set(vals[:i])):
                 vals[i] += q
-        assert len(set(vals)) == 5 and not (set(vals) & taken)
+        assert len(set(vals + [2 * vals[2]])) == 6 and not (set(vals + [2 * vals[2]]) & taken)
         self.N, self.E_b, self.E_e, self.E_r, self.P = vals
 
     def fits(self, need):
@@ -231,8 +233,8 @@ class Bucket:
     def activate(self):
         """Declare the bucket's row bounds (process wide: one bucket is active at a time)."""
         c = self.caps
-        hip.set_row_bounds({c.N: self.sizes[0:1], c.E_b: self.sizes[1:2], c.E_e: self.sizes[2:3], c.P: self.sizes[3:4]},
-                           owner=self)
+        hip.set_row_bounds({c.N: self.sizes[0:1], c.E_b: self.sizes[1:2], c.E_e: self.sizes[2:3], c.P: self.sizes[3:4],
+                            2 * c.E_e: self.sizes[6:7]}, owner=self)
 
     def check(self):
         """Host-side validation (synchronises): the loaded batch fitted the capacities."""

@@ -774,59 +774,70 @@ extern "C" int msde_gemm_rs(const msde_rs_desc* desc, void* stream) {
 #undef RSA_GO
 }
 
-// ---- transposed weight copies (forward products read [K][N], gemm_rs.h): ONE launch for any number of matrices.
-// table rows (long long x 4): {src, dst, rows, cols}; prefix[i] = first 32 x 32 tile of matrix i, prefix[n] = total.
-__global__ void __launch_bounds__(256)
-transpose_multi_kernel(const long long* __restrict__ table, const int* __restrict__ prefix, int n) {
-  __shared__ float tile[32][33];
-  int lo = 0, hi = n - 1;                              // last matrix whose first tile is <= blockIdx.x
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const float* __restrict__ src = reinterpret_cast<const float*>(table[4 * lo]);
-  float* __restrict__ dst = reinterpret_cast<float*>(table[4 * lo + 1]);
-  const int rows = (int)table[4 * lo + 2], cols = (int)table[4 * lo + 3];
-  const int t = blockIdx.x - prefix[lo], tc = (cols + 31) >> 5;
+// ---- re-laid-out weight copies (forward products read [K][N], gemm_rs.h; stacked / permuted operands of fused layers):
+// ONE launch for any number of blocks.  table rows (long long x 8): {src, dst, rows, cols, src_ld, dst_ld, mode, 0} --
+// mode 0: dst[c * dst_ld + r] = src[r * src_ld + c] (transpose of a rows x cols block), mode 1: dst[r * dst_ld + c] =
+// src[r * src_ld + c] (copy of the block); prefix[i] = first 32 x 32 tile of block i, prefix[n] = total.
+__device__ __forceinline__ void relayout_tile(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
+                                              int src_ld, int dst_ld, int mode, int t, float (*tile)[33]) {
+  const int tc = (cols + 31) >> 5;
   const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+  if (mode == 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + y + 8 * k, c = c0 + x;
+      if (r < rows && c < cols) dst[(size_t)r * dst_ld + c] = src[(size_t)r * src_ld + c];
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = r0 + y + 8 * k, c = c0 + x;
-    tile[y + 8 * k][x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    tile[y + 8 * k][x] = (r < rows && c < cols) ? src[(size_t)r * src_ld + c] : 0.f;
   }
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = c0 + y + 8 * k, r = r0 + x;
-    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[x][y + 8 * k];
+    if (c < cols && r < rows) dst[(size_t)c * dst_ld + r] = tile[x][y + 8 * k];
   }
 }
 
 __global__ void __launch_bounds__(256)
-transpose_one_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+transpose_multi_kernel(const long long* __restrict__ table, const int* __restrict__ prefix, int n) {
   __shared__ float tile[32][33];
-  const int tc = (cols + 31) >> 5;
-  const int r0 = ((int)blockIdx.x / tc) * 32, c0 = ((int)blockIdx.x % tc) * 32;
-  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int r = r0 + y + 8 * k, c = c0 + x;
-    tile[y + 8 * k][x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  int lo = 0, hi = n - 1;                              // last block whose first tile is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = c0 + y + 8 * k, r = r0 + x;
-    if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[x][y + 8 * k];
-  }
+  const long long* e = table + 8 * (size_t)lo;
+  relayout_tile(reinterpret_cast<const float*>(e[0]), reinterpret_cast<float*>(e[1]), (int)e[2], (int)e[3], (int)e[4],
+                (int)e[5], (int)e[6], blockIdx.x - prefix[lo], tile);
+}
+
+__global__ void __launch_bounds__(256)
+transpose_one_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int src_ld, int dst_ld,
+                     int mode) {
+  __shared__ float tile[32][33];
+  relayout_tile(src, dst, rows, cols, src_ld, dst_ld, mode, blockIdx.x, tile);
+}
+
+extern "C" int msde_relayout(const float* src, int src_ld, float* dst, int dst_ld, int rows, int cols, int mode, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (!src || !dst || src_ld < cols || dst_ld < (mode == 1 ? cols : rows) || (mode != 0 && mode != 1)) return MSDE_EINVAL;
+  MSDE_LAUNCH(transpose_one_kernel, dim3(((rows + 31) / 32) * ((cols + 31) / 32)), dim3(256), 0, as_stream(stream), src, dst,
+              rows, cols, src_ld, dst_ld, mode);
+  MSDE_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int msde_transpose(const float* src, float* dst, int rows, int cols, void* stream) {
   if (rows <= 0 || cols <= 0) return 0;
   if (!src || !dst) return MSDE_EINVAL;
   MSDE_LAUNCH(transpose_one_kernel, dim3(((rows + 31) / 32) * ((cols + 31) / 32)), dim3(256), 0, as_stream(stream), src, dst,
-              rows, cols);
+              rows, cols, cols, rows, 0);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -526,8 +526,8 @@ extern "C" long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K) {
 }
 
 // Batched form of the slab reduction: the weight-gradient GEMMs of a whole backward pass only write their
-// slabs (msde_linear_bwd_w_partial) and ONE launch sums them all.  rows[r] = {slab address, splits, stride
-// between splits (= entries n), output address} as four int64; prefix[r] = number of chunks before row r
+// slabs (msde_linear_bwd_w_partial) and ONE launch sums them all.  rows[r] = {slab address, splits, entries n, output
+// address, row_len, slab_ld, out_ld, split_stride} as eight int64 (see below); prefix[r] = number of chunks before row r
 // (prefix[count] = grid size).  A chunk is 256 entries summed by 4 split lanes (lane ly takes the splits ly, ly+4, ...),
 // or -- rows with >= MSDE_REDUCE_LONG splits (per-workgroup slabs of the fused kernels: 256-512 of them) -- 64 entries
 // summed by 16 split lanes: the chain of dependent loads per thread is 4x shorter, which is what bounds those rows.
@@ -540,50 +540,64 @@ reduce_slabs_multi_kernel(const long long* __restrict__ rows, const int* __restr
     int mid = (lo + hi) >> 1;
     if (prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
   }
-  const long long* e = rows + (size_t)lo * 4;
+  const long long* e = rows + (size_t)lo * 8;
   const float* slabs = reinterpret_cast<const float*>(e[0]);
   const int splits = (int)e[1];
   const size_t n = (size_t)e[2];
   float* out = reinterpret_cast<float*>(e[3]);
+  // a row may be a 2-D block: n = nrows * row_len entries, entry (r, c) at slabs[z * split_stride + r * slab_ld + c] and
+  // out[r * out_ld + c] (a weight gradient whose columns are a block of a wider parameter); flat rows: row_len = n
+  const size_t row_len = (size_t)e[4], slab_ld = (size_t)e[5], out_ld = (size_t)e[6], sstride = (size_t)e[7];
   const int LY = splits >= MSDE_REDUCE_LONG ? 16 : 4, OXN = 256 / LY;
   const int ox = threadIdx.x % OXN, ly = threadIdx.x / OXN;
   const size_t i = (size_t)(blockIdx.x - prefix[lo]) * (4 * OXN) + 4 * ox;
-  const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const bool flat = row_len == n;
+  const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 &&
+                   (flat ? sstride % 4 == 0 : ((row_len | slab_ld | out_ld | sstride) % 4 == 0));
+  // offsets of the (up to) four entries this thread owns
+  size_t so[4], oo[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const size_t j = i + q;
+    if (flat) { so[q] = j; oo[q] = j; }
+    else { const size_t r = j / row_len, c = j - r * row_len; so[q] = r * slab_ld + c; oo[q] = r * out_ld + c; }
+  }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < n) {
     if (vec) {
+      const float* base = slabs + so[0];
       int z = ly;
       for (; z + 3 * LY < splits; z += 4 * LY) {       // four independent 16-byte loads in flight
-        float4 a = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i);
-        float4 b = *reinterpret_cast<const float4*>(slabs + (size_t)(z + LY) * n + i);
-        float4 c = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 2 * LY) * n + i);
-        float4 d = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 3 * LY) * n + i);
+        float4 a = *reinterpret_cast<const float4*>(base + (size_t)z * sstride);
+        float4 b = *reinterpret_cast<const float4*>(base + (size_t)(z + LY) * sstride);
+        float4 c = *reinterpret_cast<const float4*>(base + (size_t)(z + 2 * LY) * sstride);
+        float4 d = *reinterpret_cast<const float4*>(base + (size_t)(z + 3 * LY) * sstride);
         acc = vadd(vadd(vadd(vadd(acc, a), b), c), d);
       }
-      for (; z < splits; z += LY) acc = vadd(acc, *reinterpret_cast<const float4*>(slabs + (size_t)z * n + i));
+      for (; z < splits; z += LY) acc = vadd(acc, *reinterpret_cast<const float4*>(base + (size_t)z * sstride));
     } else {
       const bool h1 = i + 1 < n, h2 = i + 2 < n, h3 = i + 3 < n;
       int z = ly;
       for (; z + 3 * LY < splits; z += 4 * LY) {       // same order of additions as the tail loop, 4 rows in flight
-        const float* p0 = slabs + (size_t)z * n + i;
-        const float* p1 = slabs + (size_t)(z + LY) * n + i;
-        const float* p2 = slabs + (size_t)(z + 2 * LY) * n + i;
-        const float* p3 = slabs + (size_t)(z + 3 * LY) * n + i;
-        const float a0 = p0[0], a1 = p1[0], a2 = p2[0], a3 = p3[0];
-        const float b0 = h1 ? p0[1] : 0.f, b1 = h1 ? p1[1] : 0.f, b2 = h1 ? p2[1] : 0.f, b3 = h1 ? p3[1] : 0.f;
-        const float c0 = h2 ? p0[2] : 0.f, c1 = h2 ? p1[2] : 0.f, c2 = h2 ? p2[2] : 0.f, c3 = h2 ? p3[2] : 0.f;
-        const float d0 = h3 ? p0[3] : 0.f, d1 = h3 ? p1[3] : 0.f, d2 = h3 ? p2[3] : 0.f, d3 = h3 ? p3[3] : 0.f;
+        const float* p0 = slabs + (size_t)z * sstride;
+        const float* p1 = slabs + (size_t)(z + LY) * sstride;
+        const float* p2 = slabs + (size_t)(z + 2 * LY) * sstride;
+        const float* p3 = slabs + (size_t)(z + 3 * LY) * sstride;
+        const float a0 = p0[so[0]], a1 = p1[so[0]], a2 = p2[so[0]], a3 = p3[so[0]];
+        const float b0 = h1 ? p0[so[1]] : 0.f, b1 = h1 ? p1[so[1]] : 0.f, b2 = h1 ? p2[so[1]] : 0.f, b3 = h1 ? p3[so[1]] : 0.f;
+        const float c0 = h2 ? p0[so[2]] : 0.f, c1 = h2 ? p1[so[2]] : 0.f, c2 = h2 ? p2[so[2]] : 0.f, c3 = h2 ? p3[so[2]] : 0.f;
+        const float d0 = h3 ? p0[so[3]] : 0.f, d1 = h3 ? p1[so[3]] : 0.f, d2 = h3 ? p2[so[3]] : 0.f, d3 = h3 ? p3[so[3]] : 0.f;
         acc.x = (((acc.x + a0) + a1) + a2) + a3;
         acc.y = (((acc.y + b0) + b1) + b2) + b3;
         acc.z = (((acc.z + c0) + c1) + c2) + c3;
         acc.w = (((acc.w + d0) + d1) + d2) + d3;
       }
       for (; z < splits; z += LY) {
-        const float* p = slabs + (size_t)z * n + i;
-        acc.x += p[0];
-        if (h1) acc.y += p[1];
-        if (h2) acc.z += p[2];
-        if (h3) acc.w += p[3];
+        const float* p = slabs + (size_t)z * sstride;
+        acc.x += p[so[0]];
+        if (h1) acc.y += p[so[1]];
+        if (h2) acc.z += p[so[2]];
+        if (h3) acc.w += p[so[3]];
       }
     }
   }
@@ -593,12 +607,12 @@ reduce_slabs_multi_kernel(const long long* __restrict__ rows, const int* __restr
     float4 r = part[ox];
     for (int q = 1; q < LY; ++q) r = vadd(r, part[q * OXN + ox]);
     if (vec) {
-      *reinterpret_cast<float4*>(out + i) = r;
+      *reinterpret_cast<float4*>(out + oo[0]) = r;
     } else {
-      out[i] = r.x;
-      if (i + 1 < n) out[i + 1] = r.y;
-      if (i + 2 < n) out[i + 2] = r.z;
-      if (i + 3 < n) out[i + 3] = r.w;
+      out[oo[0]] = r.x;
+      if (i + 1 < n) out[oo[1]] = r.y;
+      if (i + 2 < n) out[oo[2]] = r.z;
+      if (i + 3 < n) out[oo[3]] = r.w;
     }
   }
 }

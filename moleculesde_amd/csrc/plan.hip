@@ -39,7 +39,8 @@ __device__ __forceinline__ int pl_block_exscan(int v, int* sh /* [1024/64 + 1] *
   return ex;
 }
 
-// sizes[]: 0 N, 1 E_b, 2 E_e, 3 P = sum n^2, 4 n_max, 5 sum n*min(n-1, max_nbr) (radius-graph edge bound)
+// sizes[]: 0 N, 1 E_b, 2 E_e, 3 P = sum n^2, 4 n_max, 5 sum n*min(n-1, max_nbr) (radius-graph edge bound), 6 2*E_e (valid
+// rows of tensors holding two rows per extended edge)
 // *err: cleared here, set (by this kernel or the per-molecule ones) when a molecule exceeds PL_NMAX / PL_EMAX or the batch
 // exceeds a capacity.  The counts are SANITISED before anything is derived from them -- a molecule beyond the limits counts
 // as empty, prefix sums are clamped to the capacities -- so that mol_ptr / bond_ptr / pair_ptr stay monotone and inside the
@@ -234,13 +235,14 @@ plan_ext_kernel(const unsigned* __restrict__ ext_rows, const int* __restrict__ m
 // padded tails: atoms [N, N_cap) belong to the empty molecule B with code 0; row pointers past N hold the edge totals;
 // edge slots past the totals hold src = dst = -1, perm_s = own index
 __global__ void __launch_bounds__(256)
-plan_tail_kernel(const int* __restrict__ sizes, int B, int N_cap, int Eb_cap, int Ee_cap, int K, int* __restrict__ batch_i32,
+plan_tail_kernel(int* __restrict__ sizes, int B, int N_cap, int Eb_cap, int Ee_cap, int K, int* __restrict__ batch_i32,
                  int* __restrict__ atom_codes, int* __restrict__ z_codes, int* __restrict__ b_rowptr, int* __restrict__ b_src,
                  int* __restrict__ b_dst, int* __restrict__ b_rowptr_s, int* __restrict__ b_perm_s,
                  int* __restrict__ bond_codes, float* __restrict__ bond_type, int* __restrict__ e_rowptr,
                  int* __restrict__ e_src, int* __restrict__ e_dst, int* __restrict__ e_rowptr_s, int* __restrict__ e_perm_s) {
   const int N = min(sizes[0], N_cap), Eb = min(sizes[1], Eb_cap), Ee = min(sizes[2], Ee_cap);
   const int g = blockIdx.x * 256 + threadIdx.x, G = gridDim.x * 256;
+  if (g == 0) sizes[6] = 2 * Ee;
   for (int i = N + g; i <= N_cap; i += G) {
     b_rowptr[i] = Eb; b_rowptr_s[i] = Eb; e_rowptr[i] = Ee; e_rowptr_s[i] = Ee;
     if (i < N_cap) {
@@ -321,7 +323,7 @@ extern "C" int msde_plan_build(const int* x_raw, int K, const int* atom_off, con
   MSDE_CHECK_LAUNCH();
   int tail = (N_cap + Eb_cap + Ee_cap + 255) / 256;
   if (tail > 512) tail = 512;
-  MSDE_LAUNCH(plan_tail_kernel, dim3(tail), dim3(256), 0, st, (const int*)sizes, B, N_cap, Eb_cap, Ee_cap, K, batch_i32,
+  MSDE_LAUNCH(plan_tail_kernel, dim3(tail), dim3(256), 0, st, sizes, B, N_cap, Eb_cap, Ee_cap, K, batch_i32,
               atom_codes, z_codes, b_rowptr, b_src, b_dst, b_rowptr_s, b_perm_s, bond_codes, bond_type, e_rowptr, e_src, e_dst,
               e_rowptr_s, e_perm_s);
   MSDE_CHECK_LAUNCH();

@@ -10,7 +10,8 @@ __global__ void edge_geometry_fwd_kernel(const float* __restrict__ pos, const in
                                          const int* __restrict__ dst, int E, const float* __restrict__ Wd,
                                          const float* __restrict__ Wc, int C, float* __restrict__ feat_d,
                                          float* __restrict__ feat_i, float* __restrict__ feat_j,
-                                         float* __restrict__ angle, float* __restrict__ basis) {
+                                         int feat_ld, float* __restrict__ angle, int angle_ld, int angle_zero_off,
+                                         float* __restrict__ basis) {
   const float PI_F = 3.14159265358979323846f;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)E * C) return;
@@ -42,8 +43,13 @@ __global__ void edge_geometry_fwd_kernel(const float* __restrict__ pos, const in
     float nj = sqrtf(cj0 * cj0 + cj1 * cj1 + cj2 * cj2);
     float pcos = mul / (ni + MSDE_EPS) / (nj + MSDE_EPS);
     float psin = sqrtf(1.f - pcos * pcos);
-    angle[2 * (size_t)e] = psin;
-    angle[2 * (size_t)e + 1] = pcos;
+    if (angle_ld >= 4) {
+      *reinterpret_cast<float4*>(angle + (size_t)angle_ld * e) = make_float4(psin, pcos, 0.f, 0.f);
+      if (angle_zero_off) *reinterpret_cast<float4*>(angle + (size_t)angle_ld * e + angle_zero_off) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      angle[2 * (size_t)e] = psin;
+      angle[2 * (size_t)e + 1] = pcos;
+    }
     float* b = basis + 9 * (size_t)e;
     b[0] = dx; b[1] = dy; b[2] = dz; b[3] = cx; b[4] = cy; b[5] = cz; b[6] = vx; b[7] = vy; b[8] = vz;
   }
@@ -53,25 +59,35 @@ __global__ void edge_geometry_fwd_kernel(const float* __restrict__ pos, const in
   float* fd = feat_d + (size_t)e * 2 * C;
   fd[c] = sinf(a);
   fd[C + c] = cosf(a);
-  float* fi = feat_i + (size_t)e * 4 * C;
-  float* fj = feat_j + (size_t)e * 4 * C;
+  float* fi = feat_i + (size_t)e * feat_ld;
+  float* fj = feat_j + (size_t)e * feat_ld;
   float a0 = ((ci0 * wc) * 2.f) * PI_F, a2 = ((ci2 * wc) * 2.f) * PI_F;
   fi[c] = sinf(a0); fi[C + c] = cosf(a0); fi[2 * C + c] = sinf(a2); fi[3 * C + c] = cosf(a2);
   float b0 = ((cj0 * wc) * 2.f) * PI_F, b2 = ((cj2 * wc) * 2.f) * PI_F;
   fj[c] = sinf(b0); fj[C + c] = cosf(b0); fj[2 * C + c] = sinf(b2); fj[3 * C + c] = cosf(b2);
 }
 
-extern "C" int msde_edge_geometry_fwd(const float* pos, const int* src, const int* dst, int E, const float* Wd,
-                                      const float* Wc, int C, float* feat_d, float* feat_i, float* feat_j,
-                                      float* angle, float* basis, void* stream) {
+extern "C" int msde_edge_geometry_fwd_ld(const float* pos, const int* src, const int* dst, int E, const float* Wd,
+                                         const float* Wc, int C, float* feat_d, float* feat_i, float* feat_j, int feat_ld,
+                                         float* angle, int angle_ld, int angle_zero_off, float* basis, void* stream) {
   if (E < 0 || C <= 0 || !pos || !src || !dst || !Wd || !Wc || !feat_d || !feat_i || !feat_j || !angle || !basis)
+    return MSDE_EINVAL;
+  if (feat_ld < 4 * C) return MSDE_EINVAL;
+  if (angle_ld != 2 && (angle_ld < 4 || angle_ld % 4 || angle_zero_off % 4 || angle_zero_off < 0 ||
+                        (reinterpret_cast<uintptr_t>(angle) & 15)))
     return MSDE_EINVAL;
   if (E == 0) return 0;
   size_t total = (size_t)E * C;
   MSDE_LAUNCH(edge_geometry_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
-                     pos, src, dst, E, Wd, Wc, C, feat_d, feat_i, feat_j, angle, basis);
+                     pos, src, dst, E, Wd, Wc, C, feat_d, feat_i, feat_j, feat_ld, angle, angle_ld, angle_zero_off, basis);
   MSDE_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int msde_edge_geometry_fwd(const float* pos, const int* src, const int* dst, int E, const float* Wd,
+                                      const float* Wc, int C, float* feat_d, float* feat_i, float* feat_j,
+                                      float* angle, float* basis, void* stream) {
+  return msde_edge_geometry_fwd_ld(pos, src, dst, E, Wd, Wc, C, feat_d, feat_i, feat_j, 4 * C, angle, 2, 0, basis, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -24,7 +24,10 @@ from . import nn as _nn
 from .sde import VESDE, VPSDE
 
 EPSILON = 1e-6
+import os as _os
 FUSE_GAT_TAIL = True     # csrc/gat_tail.hip for hidden size 32 (False: the kernel-per-stage path, used as a cross-check)
+FUSE_FRAME = _os.environ.get("MSDE_FUSE_FRAME", "1") != "0"              # hip._FrameMLP (False: coff_mlp twice + cat + project)
+FUSE_PAIR_LINEAR = _os.environ.get("MSDE_FUSE_PAIR_LINEAR", "1") != "0"  # hip._PairLinear (False: re-laid-out weight per step)
 
 
 class GaussianFourierProjection(nn.Module):
@@ -196,6 +199,17 @@ class SDEModel2Dto3D_02(nn.Module):
     def _geometry_branch(self, pos_perturbed, ep):
         """Everything that depends on coordinates only (frame, Fourier features, their MLPs)."""
         has_dist = hasattr(self, "input_mlp")
+        H = self.hidden_dim
+        if (FUSE_FRAME and H % 4 == 0 and pos_perturbed.is_cuda and len(self.project.layers) == 2
+                and self.project.activation_name == "silu" and not self.project.dropout and ep.E > 0):
+            # frame features stacked [feat_i; feat_j]: the shared coff_mlp runs once, project[0] reads its result and the
+            # pseudo-angle in place (no cat), SiLU in the product's epilogue -- hip._FrameMLP
+            feat_d, feat, X, basis = hip.edge_geometry_stacked(
+                pos_perturbed, ep, (self.dist_gaussian_fourier if has_dist else self.coff_gaussian_fourier).W,
+                self.coff_gaussian_fourier.W, H)
+            edge_attr_3D_invariant = self.input_mlp(feat_d) if has_dist else None
+            frame = hip.frame_mlp(feat, X, self.coff_mlp, self.project.layers[0], self.project.layers[1])
+            return edge_attr_3D_invariant, frame, basis
         feat_d, feat_i, feat_j, angle, basis = hip.edge_geometry(
             pos_perturbed, ep, (self.dist_gaussian_fourier if has_dist else self.coff_gaussian_fourier).W,
             self.coff_gaussian_fourier.W)
@@ -248,9 +262,12 @@ class SDEModel2Dto3D_02(nn.Module):
         # edge_2D_emb[0](cat(h[row], h[col])) == h[row] W[:, :D]^T + h[col] W[:, D:]^T + b
         # as ONE node-level GEMM with the two weight halves stacked ([W_row; W_col], one re-layout copy per step)
         lin0 = self.edge_2D_emb[0]
-        Wst = lin0.weight.view(D, 2, D).transpose(0, 1).reshape(2 * D, D)
-        bst = torch.cat([self._zero_bias, lin0.bias])          # the row half carries no bias
-        AB = _nn.linear(node_2D_repr, Wst, bst)
+        if FUSE_PAIR_LINEAR and torch.is_grad_enabled() and hip.pair_linear_ok(node_2D_repr, lin0):
+            AB = hip.pair_linear(node_2D_repr, lin0)          # stacked weight copy cached per optimiser step
+        else:
+            Wst = lin0.weight.view(D, 2, D).transpose(0, 1).reshape(2 * D, D)
+            bst = torch.cat([self._zero_bias, lin0.bias])          # the row half carries no bias
+            AB = _nn.linear(node_2D_repr, Wst, bst)
         pre = hip.pair_gather_add_cols(AB, ep)
         edge_attr_2D = self.edge_2D_emb[3](self.edge_2D_emb[2](self.edge_2D_emb[1](pre)))
         if side is not None:

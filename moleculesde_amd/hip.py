@@ -1190,11 +1190,11 @@ class _SlabBatch:
     def new_slot(self, device):
         """Pinned host image + device copy of the row / prefix tables (one per captured graph: the upload is a
         memcpy node that re-reads its host image at every replay)."""
-        host_rows = torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64).pin_memory()
+        host_rows = torch.zeros(self.MAX_ROWS, 8, dtype=torch.int64).pin_memory()
         host_pre = torch.zeros(self.MAX_ROWS + 64, dtype=torch.int32).pin_memory()
         host_prob = torch.zeros(self.MAX_ROWS, 16, dtype=torch.int64).pin_memory()      # MSDE_WGRAD_ROW
         host_ppre = torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32).pin_memory()
-        self.slot = (host_rows, host_pre, torch.zeros(self.MAX_ROWS, 4, dtype=torch.int64, device=device),
+        self.slot = (host_rows, host_pre, torch.zeros(self.MAX_ROWS, 8, dtype=torch.int64, device=device),
                      torch.zeros(self.MAX_ROWS + 64, dtype=torch.int32, device=device),
                      host_prob, host_ppre, torch.zeros(self.MAX_ROWS, 16, dtype=torch.int64, device=device),
                      torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device))
@@ -1248,14 +1248,16 @@ class _SlabBatch:
         self.used += nfloats
         return view
 
-    def add(self, slab_ptr, splits, n, out, written=False):
+    def add(self, slab_ptr, splits, n, out, written=False, block=None):
         # only the ADDRESS of the output is kept: an extra reference to the gradient tensor would make autograd's
         # AccumulateGrad clone it (it steals the buffer only when it holds the sole reference) -- a copy of the
         # not yet reduced buffer.  The leaf's .grad keeps the memory alive until the optimiser has used it.
         # written: the kernel that fills these slabs is already queued on the CURRENT stream (not a queued GEMM or a
         # deferred kernel), so reduce_written() may sum them on that stream before the end of the backward pass
+        # block = (row_len, slab_ld, out_ld, split_stride): the n = nrows * row_len entries are a column block of the
+        # slabs and go to a column block of `out` (include/msde_hip.h: msde_reduce_slabs_multi); None: flat
         self.rows.append((slab_ptr, splits, n, out.data_ptr(), out.device,
-                          torch.cuda.current_stream().cuda_stream if written else None))
+                          torch.cuda.current_stream().cuda_stream if written else None, block or (n, n, n, n)))
 
     def queue_gemm(self, gY, X, M, N, K, has_bias, slab):
         # the stream the operands were produced on rides along: a caller may flush one stream's GEMMs on that stream
@@ -1362,6 +1364,7 @@ class _SlabBatch:
         total = 0
         for r, row in enumerate(rows):
             hr[r0 + r, 0], hr[r0 + r, 1], hr[r0 + r, 2], hr[r0 + r, 3] = row[0], row[1], row[2], row[3]
+            hr[r0 + r, 4], hr[r0 + r, 5], hr[r0 + r, 6], hr[r0 + r, 7] = row[6]
             hp[q0 + r] = total
             total += (row[2] + 63) // 64 if row[1] >= _lib.REDUCE_LONG else (row[2] + 255) // 256
         hp[q0 + k] = total
@@ -1513,6 +1516,152 @@ def colsum(x):
     out = torch.empty(C, dtype=torch.float32, device=x.device)
     _lib.call("msde_colsum", _p(x), M, C, _p(out), _p(_bn_workspace(M, C, x.device)), _stream())
     return out
+
+
+def weight_grad_blocks(g2, x2, has_bias, blocks, deferrable=True):
+    """gW [N,K] = g2^T x2 whose COLUMN BLOCKS belong to wider / permuted parameter gradients: blocks = [(k0, kn, out,
+    out_col0)] sends columns k0 .. k0+kn to out[:, out_col0 .. +kn] (out [N, *] contiguous).  Returns the bias gradient
+    (or None).  Queued like weight_grad: the batched slab reduction writes the blocks in place (2-D reduce rows);
+    without an open parameter-gradient batch the product is formed on the spot and copied."""
+    M, N = g2.shape
+    K = x2.size(1)
+    use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
+    if _SLABS.active and deferrable and GROUPED_WGRAD and use_hip:
+        splits = _SPLITS.get((M, N, K))
+        if splits is None:
+            splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
+        slab = _SLABS.alloc(splits * (N * K + (N if has_bias else 0)), g2.device)
+        _SLABS.queue_gemm(g2, x2, M, N, K, int(has_bias), slab)
+        for k0, kn, out, c0 in blocks:
+            _SLABS.add(slab.data_ptr() + 4 * k0, splits, N * kn, out[:, c0:], block=(kn, K, out.size(1), N * K))
+        gb = None
+        if has_bias:
+            gb = torch.empty(N, dtype=torch.float32, device=g2.device)
+            _SLABS.add(slab.data_ptr() + 4 * splits * N * K, splits, N, gb)
+        return gb
+    gw, gb = weight_grad(g2, x2, has_bias, False)
+    for k0, kn, out, c0 in blocks:
+        out[:, c0:c0 + kn].copy_(gw[:, k0:k0 + kn])
+    return gb
+
+
+class _PairLinear(torch.autograd.Function):
+    """AB [M, 2D] = [h W[:, :D]^T | h W[:, D:]^T + b] for the Linear(2D, D) that the reference applies to cat(h[row], h[col])
+    of every edge (SDE_model_2D_to_3D.py:386-388: edge_2D_emb[0]): the product is linear in the two halves, so it is
+    formed ONCE PER NODE and the edge-level sum is a gather-add.  The weight is read through a cached stacked copy
+    (hip.weight_layout, refreshed with the transposed weights once per optimiser step: no per-step re-layout, no cat);
+    backward: two input-gradient products on the weight's column halves as stored, and two queued weight-gradient
+    problems whose results the batched reduction writes into the column halves of the [D, 2D] gradient."""
+
+    @staticmethod
+    def forward(ctx, h, W, b):
+        h = _f32(h)
+        M, D = h.shape
+        B = weight_layout("pair_linear", (W,), (D, 2 * D), [(W, 0, 0, D, D, 0, 0, True), (W, 0, D, D, D, 0, D, True)])
+        bst = weight_layout("pair_bias", (b,), (2 * D,), [(b, 0, 0, 1, D, 0, D, False)])
+        AB = torch.empty(M, 2 * D, dtype=torch.float32, device=h.device)
+        gemm_rs(h, B, AB, bias=bst, b_kmajor=True, N=2 * D, K=D, fallback=False)
+        ctx.save_for_backward(h, W)
+        ctx.deferrable = W.is_leaf and b.is_leaf
+        return AB
+
+    @staticmethod
+    def backward(ctx, g):
+        h, W = ctx.saved_tensors
+        g = _f32(g)
+        M, D = h.shape
+        g1, g2 = g[:, :D], g[:, D:]
+        gh = None
+        if ctx.needs_input_grad[0]:
+            gh = torch.empty(M, D, dtype=torch.float32, device=g.device)
+            gemm_rs(g1, W, gh, b_kmajor=True, N=D, K=D, fallback=False)
+            gemm_rs(g2, W[:, D:], gh, b_kmajor=True, N=D, K=D, accumulate=True, fallback=False)
+        gW = torch.empty(D, 2 * D, dtype=torch.float32, device=g.device)
+        weight_grad_blocks(g1, h, False, [(0, D, gW, 0)], ctx.deferrable)
+        gb = weight_grad_blocks(g2, h, True, [(0, D, gW, D)], ctx.deferrable)
+        return gh, gW, gb
+
+
+def pair_linear_ok(h, lin):
+    D = lin.weight.size(0)
+    return (h.is_cuda and h.dim() == 2 and lin.weight.size(1) == 2 * D and D % 4 == 0 and 0 < h.size(0) <= RS_MAX_ROWS
+            and lin.weight.is_leaf and lin.bias is not None and lin.bias.is_leaf and _LINEAR_MODE != "lib")
+
+
+def pair_linear(h, lin):
+    return _PairLinear.apply(h, lin.weight, lin.bias)
+
+
+class _FrameMLP(torch.autograd.Function):
+    """project(cat([angle, coff_mlp(feat_i), coff_mlp(feat_j)])) of SDE_model_2D_to_3D.py:366-370 without cat, without the
+    second application of the shared coff_mlp and without immediate weight-gradient launches:
+      * feat [2E, 4H] holds feat_i(e), feat_j(e) in rows 2e, 2e + 1 (msde_edge_geometry_fwd_ld writes them there): coff_mlp
+        is ONE product over 2E rows; its result goes to columns 0..H of X [2E, H + 4], whose columns H..H+4 the geometry
+        kernel has filled with (sin, cos, 0, 0) of the pseudo-angle (rows 2e) and zeros (rows 2e + 1);
+      * X seen as [E, 2H + 8] is then exactly project[0]'s input in another column order: one msde_gemm_ex launch against
+        a cached permuted, zero-padded copy of its weight ([W_i | W_angle 0 0 | W_j | 0 0 0 0], hip.weight_layout), SiLU
+        in the epilogue;
+      * backward: SiLU' in the epilogue of project[1]'s input-gradient product; ONE product gives the gradient of both
+        coff_mlp applications ([W_i | W_j] cached); the shared coff_mlp gets ONE queued weight-gradient problem over 2E
+        rows, project[0] one whose column blocks the batched reduction writes into the [H, 2H + 2] gradient.
+    feat / angle carry no gradient.  Valid rows of the 2E-row tensors: 2 x (valid extended edges), a
+    row bound of its own in a capacity bucket."""
+
+    @staticmethod
+    def forward(ctx, feat, X, Wc, bc, W1, b1, W2, b2):
+        E2, H = feat.size(0), Wc.size(0)
+        E = E2 // 2
+        dev = feat.device
+        gemm_ex(feat, Wc, X[:, :H], bias=bc)
+        W1p = weight_layout("frame_project", (W1,), (H, 2 * H + 8),
+                            [(W1, 0, 2, H, H, 0, 0, False), (W1, 0, 0, H, 2, 0, H, False), (W1, 0, H + 2, H, H, 0, H + 4, False)])
+        Z1 = torch.empty(E, H, dtype=torch.float32, device=dev)
+        h1 = torch.empty(E, H, dtype=torch.float32, device=dev)
+        gemm_ex(X.view(E, 2 * H + 8), W1p, h1, bias=b1, act="silu", Z=Z1)
+        out = torch.empty(E, W2.size(0), dtype=torch.float32, device=dev)
+        gemm_ex(h1, W2, out, bias=b2)
+        ctx.save_for_backward(feat, X, Z1, h1, Wc, W1, W2)
+        ctx.deferrable = all(t.is_leaf for t in (Wc, bc, W1, b1, W2, b2))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, X, Z1, h1, Wc, W1, W2 = ctx.saved_tensors
+        g = _f32(g)
+        E, H = Z1.shape
+        dev = g.device
+        gZ1 = torch.empty(E, H, dtype=torch.float32, device=dev)
+        gemm_ex(g, W2, gZ1, b_kmajor=True, act="silu", dact_from=Z1)
+        W1q = weight_layout("frame_project_ij", (W1,), (H, 2 * H), [(W1, 0, 2, H, 2 * H, 0, 0, False)])     # [W_i | W_j]
+        g_embed = torch.empty(2 * E, H, dtype=torch.float32, device=dev)
+        gemm_ex(gZ1, W1q, g_embed.view(E, 2 * H), b_kmajor=True)
+        gW2, gb2 = weight_grad(g, h1, True, ctx.deferrable)
+        gW1 = torch.empty(H, 2 * H + 2, dtype=torch.float32, device=dev)
+        gb1 = weight_grad_blocks(gZ1, X.view(E, 2 * H + 8), True,
+                                 [(0, H, gW1, 2), (H, 2, gW1, 0), (H + 4, H, gW1, H + 2)], ctx.deferrable)
+        gWc, gbc = weight_grad(g_embed, feat, True, ctx.deferrable)
+        return None, None, gWc, gbc, gW1, gb1, gW2, gb2
+
+
+def frame_mlp(feat, X, coff, l1, l2):
+    return _FrameMLP.apply(feat, X, coff.weight, coff.bias, l1.weight, l1.bias, l2.weight, l2.bias)
+
+
+def edge_geometry_stacked(pos, plan, Wd, Wc, H):
+    """hip.edge_geometry with the frame features laid out for hip.frame_mlp: returns (feat_d [E, 2C], feat [2E, 4C] with
+    feat_i(e) / feat_j(e) in rows 2e / 2e + 1, X [2E, H + 4] with (sin, cos, 0, 0) of the pseudo-angle in columns H.. of
+    rows 2e and zeros in those of rows 2e + 1, basis [E, 9])."""
+    pos = _f32(pos.detach())
+    E, C = plan.E, Wd.numel()
+    dev = pos.device
+    feat_d = torch.empty(E, 2 * C, dtype=torch.float32, device=dev)
+    feat = torch.empty(2 * E, 4 * C, dtype=torch.float32, device=dev)
+    X = torch.empty(2 * E, H + 4, dtype=torch.float32, device=dev)
+    basis = torch.empty(E, 9, dtype=torch.float32, device=dev)
+    _lib.call("msde_edge_geometry_fwd_ld", _p(pos), _p(plan.src), _p(plan.dst), E, _p(_f32(Wd.detach())),
+              _p(_f32(Wc.detach())), C, _p(feat_d), _p(feat), ctypes.c_void_p(feat.data_ptr() + 16 * C), 8 * C,
+              ctypes.c_void_p(X.data_ptr() + 4 * H), 2 * (H + 4), H + 4, _p(basis), _stream())
+    return feat_d, feat, X, basis
 
 
 class _Linear(torch.autograd.Function):
@@ -2037,19 +2186,44 @@ def bump_weight_epoch():
 
 
 def _transpose_into(entries):
-    """One msde_transpose_multi launch for `entries` (same device)."""
+    """Tables of one msde_transpose_multi launch for `entries` (same device): one table row per block."""
     dev = entries[0]["wt"].device
-    n = len(entries)
-    tab = torch.empty(n, 4, dtype=torch.int64)
+    blocks = [b for e in entries for b in e["blocks"]]
+    n = len(blocks)
+    tab = torch.zeros(n, 8, dtype=torch.int64)
     pre = torch.empty(n + 1, dtype=torch.int32)
     total = 0
-    for i, e in enumerate(entries):
-        r, c = e["shape"]
-        tab[i, 0], tab[i, 1], tab[i, 2], tab[i, 3] = e["src_ptr"], e["wt"].data_ptr(), r, c
+    for i, (src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode) in enumerate(blocks):
+        tab[i, 0], tab[i, 1], tab[i, 2], tab[i, 3], tab[i, 4], tab[i, 5], tab[i, 6] = src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode
         pre[i] = total
         total += ((r + 31) // 32) * ((c + 31) // 32)
     pre[n] = total
     return tab, pre, total, dev
+
+
+def _fill_entry(ent):
+    for src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode in ent["blocks"]:
+        _lib.call("msde_relayout", ctypes.c_void_p(src_ptr), src_ld, ctypes.c_void_p(dst_ptr), dst_ld, r, c, mode, _stream())
+
+
+def _cached_layout(key, src, make):
+    """Entry of the re-laid-out weight cache for the leaf parameters `src`; make() -> (buffer, blocks) on a miss.  The
+    buffer is refreshed (one msde_relayout per block on the current stream) when a source's version counter or the
+    parameter epoch moved; refresh_weight_t() does it for every entry in one launch."""
+    ent = _WT.get(key)
+    if ent is None:
+        def drop(_r, key=key):
+            _WT.pop(key, None)
+            _WT_TABLE.clear()
+        wt, blocks = make()
+        ent = {"wt": wt, "blocks": blocks, "refs": [_weakref.ref(p, drop) for p in src], "versions": None, "epoch": -1}
+        _WT[key] = ent
+        _WT_TABLE.clear()
+    versions = tuple(p._version for p in src)
+    if ent["versions"] != versions or ent["epoch"] != _WT_EPOCH:
+        _fill_entry(ent)
+        ent["versions"], ent["epoch"] = versions, _WT_EPOCH
+    return ent["wt"]
 
 
 def weight_t(w):
@@ -2064,25 +2238,38 @@ def weight_t(w):
         _lib.call("msde_transpose", _p(wc), _p(wt), int(w.size(0)), int(w.size(1)), _stream())
         return wt
     key = (tuple(id(p) for p in src), int(w.size(0)), int(w.size(1)), w.data_ptr())
-    ent = _WT.get(key)
-    if ent is None:
-        def drop(_r, key=key):
-            _WT.pop(key, None)
-            _WT_TABLE.clear()
-        ent = {"wt": torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device), "shape": (w.size(0), w.size(1)),
-               "src_ptr": w.data_ptr(), "refs": [_weakref.ref(p, drop) for p in src], "versions": None, "epoch": -1}
-        _WT[key] = ent
-        _WT_TABLE.clear()
-    versions = tuple(p._version for p in src)
-    if ent["versions"] != versions or ent["epoch"] != _WT_EPOCH:
-        _lib.call("msde_transpose", ctypes.c_void_p(ent["src_ptr"]), _p(ent["wt"]), ent["shape"][0], ent["shape"][1], _stream())
-        ent["versions"], ent["epoch"] = versions, _WT_EPOCH
-    return ent["wt"]
+
+    def make():
+        wt = torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device)
+        return wt, [(w.data_ptr(), wt.data_ptr(), int(w.size(0)), int(w.size(1)), int(w.size(1)), int(w.size(0)), 0)]
+    return _cached_layout(key, src, make)
+
+
+def weight_layout(tag, params, shape, blocks):
+    """A cached buffer of `shape` (zero-initialised once) assembled from blocks of the leaf parameters `params`:
+    blocks = [(param, row0, col0, rows, cols, dst_row0, dst_col0, transpose)] -- the rows x cols block of `param` at
+    (row0, col0) is copied (transpose False) to, or written transposed (True) at, (dst_row0, dst_col0) of the buffer.
+    Used for operands a fused layer reads in another arrangement than nn.Linear stores them (stacked halves, permuted /
+    zero-padded input columns, a bias behind a zero half); refreshed with the transposed weight copies -- once per
+    optimiser step, by the same launch."""
+    assert all(p.is_leaf and p.dim() in (1, 2) and p.is_contiguous() and p.dtype == torch.float32 for p in params)
+    key = (tag, tuple(id(p) for p in params), tuple(shape), tuple(p.data_ptr() for p in params))
+
+    def make():
+        buf = torch.zeros(*shape, dtype=torch.float32, device=params[0].device)
+        ld = int(shape[-1]) if len(shape) == 2 else int(shape[0])
+        out = []
+        for (p, r0, c0, rows, cols, dr, dc, tr) in blocks:
+            p_ld = int(p.size(1)) if p.dim() == 2 else int(p.size(0))
+            out.append((p.data_ptr() + 4 * (r0 * p_ld + c0), buf.data_ptr() + 4 * (dr * ld + dc), int(rows), int(cols), p_ld, ld,
+                        0 if tr else 1))
+        return buf, out
+    return _cached_layout(key, tuple(params), make)
 
 
 def refresh_weight_t():
-    """Re-transpose every known weight with one launch per device on the current stream and mark the copies fresh for the
-    current parameter epoch (the trainer calls this right after the optimiser step)."""
+    """Re-lay-out every known weight copy with one launch per device on the current stream and mark the copies fresh for
+    the current parameter epoch (the trainer calls this right after the optimiser step)."""
     if not _WT:
         return
     by_dev = {}
@@ -2092,10 +2279,10 @@ def refresh_weight_t():
         t = _WT_TABLE.get(dev)
         if t is None or t["n"] != len(entries):
             tab, pre, total, _ = _transpose_into(entries)
-            t = {"n": len(entries), "tab": tab.to(dev), "pre": pre.to(dev), "total": total}
+            t = {"n": len(entries), "rows": tab.size(0), "tab": tab.to(dev), "pre": pre.to(dev), "total": total}
             _WT_TABLE[dev] = t
             _retire([])            # tables are tiny and stay referenced from _WT_TABLE
-        _lib.call("msde_transpose_multi", _p(t["tab"]), _p(t["pre"]), t["n"], t["total"], _stream())
+        _lib.call("msde_transpose_multi", _p(t["tab"]), _p(t["pre"]), t["rows"], t["total"], _stream())
         for e in entries:
             e["versions"] = tuple(r()._version for r in e["refs"] if r() is not None)
             e["epoch"] = _WT_EPOCH
