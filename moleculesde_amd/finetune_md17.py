@@ -59,6 +59,7 @@ class ForceTrainer:
         self.opt.zero_grad()
         loss.backward()
         self.opt.step_from_grads()
+        hip.refresh_weight_t()             # re-laid-out weight copies (if any layer of the model reads one) follow the update
         return loss.detach()
 
     def step(self, batch, y=None, force=None):
@@ -98,5 +99,6 @@ class ForceTrainer:
         self._pos.copy_(positions, non_blocking=True)
         self._y.copy_(y.view(-1), non_blocking=True)
         self._f.copy_(force, non_blocking=True)
+        hip.sync_weight_copies()           # parameters edited from outside since the last step (load_state_dict, ...)
         self._graph.replay()
         return self._loss

@@ -2288,6 +2288,18 @@ def refresh_weight_t():
             e["epoch"] = _WT_EPOCH
 
 
+def sync_weight_copies():
+    """Call before REPLAYING a captured graph: a replay runs no Python, so it cannot notice that a parameter was changed
+    from outside the optimiser since the copies were refreshed (load_state_dict, an in-place edit: the autograd version
+    counters moved).  Host-side comparison of the counters (microseconds); on a mismatch every copy is refreshed with one
+    launch on the current stream, in front of the replay.  Returns True if it had to."""
+    for e in _WT.values():
+        if e["epoch"] != _WT_EPOCH or e["versions"] != tuple(r()._version for r in e["refs"] if r() is not None):
+            refresh_weight_t()
+            return True
+    return False
+
+
 def rs_forward_ok(M, N, K, w):
     """Shapes msde_gemm_rs takes for a forward product on weight w [N][K] (the rest goes to msde_gemm_ex)."""
     return K % 4 == 0 and N % 4 == 0 and w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32

@@ -537,6 +537,8 @@ class Trainer:
         """Replay the captured step; under DP the all-reduce and Adam run after the replay."""
         g, held, with_adam = self._graphs[id(batch)]
         assert held is batch
+        from . import hip as _hip
+        _hip.sync_weight_copies()          # parameters edited from outside since the last step (load_state_dict, ...)
         g.replay()
         for bn in self._bn_modules:
             bn.pending_batches += 1        # the captured forward does not run Python: count its BatchNorm calls here

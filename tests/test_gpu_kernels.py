@@ -811,6 +811,73 @@ def test_batched_slab_reduction_matches_immediate(dev):
             assert torch.equal(gb1, gb2)
 
 
+@pytest.mark.parametrize("E,H", [(35186, 32), (1000, 16), (3, 32)])
+def test_frame_mlp_and_pair_linear_fused_operators(dev, E, H):
+    """hip._FrameMLP (project(cat([angle, coff_mlp(feat_i), coff_mlp(feat_j)])), SDE_model_2D_to_3D.py:366-370) and
+    hip._PairLinear (edge_2D_emb[0] on cat(h[row], h[col]) as one per-node product, :386-388): values and every
+    parameter gradient against torch autograd in fp64 -- with the weight gradients formed on the spot, and queued in a
+    parameter-gradient batch (2-D rows of msde_reduce_slabs_multi write column blocks of the wider gradients); the cached
+    re-laid-out weight copies (hip.weight_layout) follow an in-place parameter update."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(E + H)
+    mk = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    feat_i, feat_j, angle = mk(E, 4 * H), mk(E, 4 * H), mk(E, 2)
+    Wc, bc = mk(H, 4 * H, sc=(4 * H) ** -0.5), mk(H, sc=0.1)
+    W1, b1 = mk(H, 2 * H + 2, sc=(2 * H) ** -0.5), mk(H, sc=0.1)
+    W2, b2 = mk(H, H, sc=H ** -0.5), mk(H, sc=0.1)
+    g_out = mk(E, H)
+
+    def ref_run(scale):
+        P = [t.double().clone().requires_grad_(True) for t in (Wc, bc, W1, b1, W2, b2)]
+        with torch.no_grad():
+            P[2].mul_(scale)
+        Wc_, bc_, W1_, b1_, W2_, b2_ = P
+        ei, ej = feat_i.double() @ Wc_.t() + bc_, feat_j.double() @ Wc_.t() + bc_
+        z = torch.cat([angle.double(), ei, ej], dim=1) @ W1_.t() + b1_
+        out = torch.nn.functional.silu(z) @ W2_.t() + b2_
+        return out, torch.autograd.grad(out, P, g_out.double())
+
+    feat = torch.stack([feat_i, feat_j], dim=1).reshape(2 * E, 4 * H).to(dev)
+    X = torch.full((2 * E, H + 4), float("nan"), device=dev)
+    X[0::2, H:H + 2] = angle.to(dev); X[0::2, H + 2:] = 0; X[1::2, H:] = 0
+    P = [t.to(dev).clone().requires_grad_(True) for t in (Wc, bc, W1, b1, W2, b2)]
+    for batched, scale in ((False, 1.0), (True, 1.0), (True, 0.5)):
+        if scale != 1.0:
+            with torch.no_grad():
+                P[2].mul_(scale)            # in-place update: the cached permuted copy of W1 must follow
+        out_ref, g_ref = ref_run(scale)
+        for p in P:
+            p.grad = None
+        if batched:
+            hip.begin_param_grad_batch(P)
+        out = hip._FrameMLP.apply(feat, X.clone(), *P)
+        out.backward(g_out.to(dev))
+        if batched:
+            hip.finish_param_grad_batch()
+        assert_close(out, out_ref, 2e-5, 2e-5, f"frame mlp out (batched={batched})")
+        for name, p, r in zip(("Wc", "bc", "W1", "b1", "W2", "b2"), P, g_ref):
+            assert_close(p.grad, r, 2e-4, 2e-4 * max(1.0, float(r.abs().max())), f"frame mlp grad {name} (batched={batched}, scale={scale})")
+    # pair linear
+    M, D = 777, 4 * H
+    h, W, b, gAB = mk(M, D), mk(D, 2 * D, sc=(2 * D) ** -0.5), mk(D, sc=0.1), mk(M, 2 * D)
+    R = [t.double().clone().requires_grad_(True) for t in (h, W, b)]
+    AB_ref = torch.cat([R[0] @ R[1][:, :D].t(), R[0] @ R[1][:, D:].t() + R[2]], dim=1)
+    g_ref = torch.autograd.grad(AB_ref, R, gAB.double())
+    Q = [t.to(dev).clone().requires_grad_(True) for t in (h, W, b)]
+    for batched in (False, True):
+        for q in Q:
+            q.grad = None
+        if batched:
+            hip.begin_param_grad_batch(Q[1:])
+        AB = hip._PairLinear.apply(*Q)
+        AB.backward(gAB.to(dev))
+        if batched:
+            hip.finish_param_grad_batch()
+        assert_close(AB, AB_ref, 2e-5, 2e-5, "pair linear out")
+        for name, q, r in zip(("h", "W", "b"), Q, g_ref):
+            assert_close(q.grad, r, 2e-4, 2e-4 * max(1.0, float(r.abs().max())), f"pair linear grad {name} (batched={batched})")
+
+
 @pytest.mark.parametrize("n", [1, 2, 37, 3588, 4096])
 def test_randperm_kernel(dev, n):
     """msde_randperm: always a permutation; reproducible for a (seed, counter); a new seed or counter value gives
