@@ -581,8 +581,8 @@ def cpu_baseline(bs=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch_size", type=int, default=256)
     ap.add_argument("--pool", type=int, default=4, help="distinct resident batches of the per-shape-graph mode")
     ap.add_argument("--stream", type=int, default=64,
@@ -644,14 +644,20 @@ def main():
     step_fn = trainer.step_graph if use_graph else trainer.step
 
     def timed(fn, items, steps):
-        dp.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for s in range(steps):
-            fn(items[s % len(items)])
-        dp.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        import gc
+        gc.collect()
+        gc.disable()            # a generation-2 collection of the interpreter (tens of ms with the captured graphs'
+        try:                    # autograd objects alive) inside a 30-step timing would be charged to the step
+            dp.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in range(steps):
+                fn(items[s % len(items)])
+            dp.barrier()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        finally:
+            gc.enable()
 
     dt_pool = timed(step_fn, pool, a.steps)
     dt, launch, stream_info = dt_pool, None, None
