@@ -226,12 +226,31 @@ def node_forward(cfg, XC, F, AC, T):
               ctypes.c_void_p(XC.data_ptr() + 4 * F), ld, hip._stream())
     w1, w2, nout = T[3].size(0), T[5].size(0), T[7].size(0)
     sv.Z1, sv.F1, sv.Z2, sv.F2 = (_empty(N, w, device=dev) for w in (w1, w1, w2, w2))
-    hip.gemm_ex(XC, T[3], sv.F1, bias=T[4], act="silu", Z=sv.Z1)
-    hip.gemm_ex(sv.F1, T[5], sv.F2, bias=T[6], act="silu", Z=sv.Z2)
     sv.OUT = _empty(N, XP_LD, device=dev)
-    hip.gemm_ex(sv.F2, T[7], sv.OUT[:, :nout], bias=T[8])
+    node_mlp_forward(XC, T[3], T[4], T[5], T[6], T[7], T[8], sv.Z1, sv.F1, sv.Z2, sv.F2, sv.OUT)
     sv.nout = nout
     return sv
+
+
+def _rs_ok(M, *tensors):
+    return 0 < M <= hip.RS_MAX_ROWS and all(t.is_leaf and t.is_contiguous() and t.dtype == torch.float32 for t in tensors)
+
+
+def node_mlp_forward(XC, W1, b1, W2, b2, W3, b3, Z1, F1, Z2, F2, OUT):
+    """NodeScoreNetwork_dense.final (invariant_scorenetwork_dense.py:126-127): 364 -> 728 -> 728 -> 119 with SiLU, bias + SiLU +
+    pre-activation store in the epilogues.  Layer 1 on msde_gemm_ex (64 x 64 tiles win at K = 364: 29.7 vs 33.3 us), layer 2
+    on the row-strip kernel (46 vs 51 us), the 119-wide output layer on the row-strip kernel against a cached transposed copy
+    of its weight padded to 120 columns (OUT has that row stride anyway): 12 us instead of 36 us for a 64-wide tile grid that
+    is 7 % full in its last column block."""
+    M, nout, w2 = XC.size(0), W3.size(0), W2.size(0)
+    hip.gemm_ex(XC, W1, F1, bias=b1, act="silu", Z=Z1)
+    hip.gemm_fwd(F1, W2, F2, bias=b2, act="silu", Z=Z2)
+    if _rs_ok(M, W3, b3) and w2 % 4 == 0 and nout <= XP_LD:
+        Wt = hip.weight_layout("dense_node_out_t", (W3,), (w2, XP_LD), [(W3, 0, 0, nout, w2, 0, 0, True)])
+        bp = hip.weight_layout("dense_node_out_b", (b3,), (XP_LD,), [(b3, 0, 0, 1, nout, 0, 0, False)])
+        hip.gemm_rs(F2, Wt, OUT, bias=bp, b_kmajor=True, N=XP_LD, K=w2, fallback=False)
+    else:
+        hip.gemm_ex(F2, W3, OUT[:, :nout], bias=b3)
 
 
 def node_backward(cfg, sv, XC, F, AC, T, gOUT):
@@ -244,10 +263,15 @@ def node_backward(cfg, sv, XC, F, AC, T, gOUT):
     go = gOUT[:, :nout]
     G[7], G[8] = wg(go, sv.F2, True)
     gZ2 = _empty(N, sv.Z2.size(1), device=dev)
-    hip.gemm_ex(go, T[7], gZ2, b_kmajor=True, act="silu", dact_from=sv.Z2)
+    if _rs_ok(N, T[7]) and sv.Z2.size(1) % 4 == 0 and gOUT.size(1) == XP_LD and nout <= XP_LD:
+        # K = 119 -> 120: the gradient's padding column is zero (dense_loss_bwd writes it), the weight's padding row too
+        Wp = hip.weight_layout("dense_node_out_pad", (T[7],), (XP_LD, T[7].size(1)), [(T[7], 0, 0, nout, T[7].size(1), 0, 0, False)])
+        hip.gemm_rs(gOUT, Wp, gZ2, b_kmajor=True, N=T[7].size(1), K=XP_LD, act="silu", dact_from=sv.Z2, fallback=False)
+    else:
+        hip.gemm_ex(go, T[7], gZ2, b_kmajor=True, act="silu", dact_from=sv.Z2)
     G[5], G[6] = wg(gZ2, sv.F1, True)
     gZ1 = _empty(N, sv.Z1.size(1), device=dev)
-    hip.gemm_ex(gZ2, T[5], gZ1, b_kmajor=True, act="silu", dact_from=sv.Z1)
+    hip.gemm_dgrad(gZ2, T[5], gZ1, act="silu", dact_from=sv.Z1)
     G[3], G[4] = wg(gZ1, XC, True)
     gXC = _empty(N, XC.size(1), device=dev)
     hip.gemm_ex(gZ1, T[3], gXC, b_kmajor=True)
