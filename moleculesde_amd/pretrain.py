@@ -91,6 +91,7 @@ SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "256"))   # 256 
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
 GEOMETRY_ON_SIDE = os.environ.get("MSDE_GEOMETRY_ON_SIDE", "1") != "0"   # coordinate-only branch of the 2D->3D model at the head of the second stream.  Round 2 (SchNet the longer chain): 3.187 vs 3.151 ms, off; round 3 (pair CFConv: SchNet is the SHORTER chain): 2.86 vs 2.98 ms, on (alternating A/B with tools/ab.sh)
 EARLY_SLAB_REDUCE = os.environ.get("MSDE_EARLY_SLAB_REDUCE", "1") != "0"
+CL_ON_SIDE = os.environ.get("MSDE_CL_ON_SIDE", "0") != "0"   # contrastive loss on the second stream behind SchNet (it idles there while the 2D->3D model runs): measured 2.83 vs 2.80 ms (its backward then sits in front of SchNet's on that stream), off
 SIDE_WGRAD = os.environ.get("MSDE_SIDE_WGRAD", "0") != "0"   # second stream's weight gradients flushed on it, behind its backward: measured 2.865 vs 2.82 ms (tools/ab.sh: the GIN backward slows by more than the tail gains), off
 SIDE_WGRAD_WGS = int(os.environ.get("MSDE_SIDE_WGRAD_WGS", "0"))   # 0: full width
 SCHNET_AFTER_GIN = os.environ.get("MSDE_SCHNET_AFTER_GIN", "0") != "0"   # experiment: start SchNet when GIN's forward is done
@@ -344,6 +345,22 @@ class Trainer:
             node_3D_repr, l32, _ = schnet_on_side()      # SchNet beside the 2D->3D model instead of beside GIN
         if stamps:
             node_2D_repr.register_hook(lambda g: _hip.stamp("gin_bwd_start"))
+        cl_done = None
+        if (CL_ON_SIDE and self.coeff_cl > 0 and self.overlap_streams and not SCHNET_AFTER_GIN and not head_on_side
+                and a.SDE_coeff_generative_2Dto3D > 0 and node_2D_repr.is_cuda):
+            # both encoders are done (SchNet first): the contrastive loss -- 2 launches forward, 1 backward -- runs on the second
+            # stream, which idles while the 2D->3D model works on the main one, instead of between that model's forward and
+            # backward where nothing else can run.  Joined by event: GIN's output must be complete, nothing later.
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side = self._side_stream
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                node_2D_repr.record_stream(side)
+                for t in negs:
+                    if t is not None:
+                        t.record_stream(side)
+                cl_done = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
         if a.SDE_coeff_generative_2Dto3D > 0:
             l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
             terms.append(l23); coeffs.append(a.SDE_coeff_generative_2Dto3D)
@@ -358,7 +375,12 @@ class Trainer:
                 l32[0].record_stream(main)
                 l32[1].record_stream(main)
         if self.coeff_cl > 0:
-            cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
+            if cl_done is not None:
+                cl, acc = cl_done
+                cl.record_stream(main)
+                acc.record_stream(main)
+            else:
+                cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
             terms.append(cl); coeffs.append(self.coeff_cl)
             parts["CL"], parts["CL_acc"] = cl.detach(), acc
         if want_32:
