@@ -688,6 +688,12 @@ int msde_randperm(int n, int count, unsigned long long seed, const unsigned long
 int msde_ve_perturb(const float* pos, const float* noise, const long long* draws, const int* batch, int N,
                     int B, int T, float eps, float sigma_min, float sigma_max, float* pos_out,
                     float* std_out, void* stream);
+/* the same with the draws made in the kernel: noise_out [N,3] ~ N(0,1) and one uniform integer time step per antithetic
+ * pair of molecules from the counter-based generator (seed [+ seed_dev[0]*FNV], index); replaces torch.randn_like +
+ * torch.randint (SDE_model_2D_to_3D.py:401-404) + msde_ve_perturb. */
+int msde_ve_perturb_rng(const float* pos, const int* batch, int N, int B, int T, float eps, float sigma_min,
+                        float sigma_max, unsigned long long seed, const unsigned long long* seed_dev,
+                        float* noise_out, float* pos_out, float* std_out, void* stream);
 /* VE position loss (SDE_model_2D_to_3D.py:425-432): loss[0] = mean_b mean_{i in b} sum_k (scores-noise)^2
  * [* std_i^anneal_power when anneal_power != 0]; mol_ws: B floats.  bwd: g_scores [N,3] from g_loss[0]. */
 int msde_ve_pos_loss_fwd(const float* scores, const float* noise, const float* std, float anneal_power,

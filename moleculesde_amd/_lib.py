@@ -125,6 +125,7 @@ SIGNATURES = {
     "msde_mul_add_bwd": [P, P, P, LL, P, P, P],
     "msde_randperm": [I, I, ULL, P, P, P],
     "msde_ve_perturb": [P, P, P, P, I, I, I, F, F, F, P, P, P],
+    "msde_ve_perturb_rng": [P, P, I, I, I, F, F, F, ULL, P, P, P, P, P],
     "msde_ve_pos_loss_fwd": [P, P, P, F, P, I, I, P, P, P],
     "msde_ve_pos_loss_bwd": [P, P, P, F, P, P, I, I, P, P, P],
     "msde_gat_tail_blocks": [I],

@@ -33,11 +33,7 @@ __device__ __forceinline__ float dh_elu(float z) { return z > 0.f ? z : __expf(z
 __device__ __forceinline__ float dh_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 __device__ __forceinline__ float dh_delu_y(float y) { return y > 0.f ? 1.f : y + 1.f; }
 
-__device__ __forceinline__ float dh_randn(unsigned long long seed, unsigned long long idx) {
-  float u1 = msde_uniform(seed, 2ull * idx), u2 = msde_uniform(seed, 2ull * idx + 1ull);
-  u1 = fmaxf(u1, 5.9604645e-8f);
-  return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
-}
+__device__ __forceinline__ float dh_randn(unsigned long long seed, unsigned long long idx) { return msde_randn(seed, idx); }
 
 // ================================================================================================ prepare
 __global__ void __launch_bounds__(256)

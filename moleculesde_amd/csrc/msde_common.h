@@ -106,6 +106,13 @@ __device__ __forceinline__ float msde_uniform(unsigned long long seed, unsigned 
   return (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 random bits -> [0,1)
 }
 
+// N(0,1) from two counter-based uniforms (Box-Muller); the same (seed, index) always gives the same draw
+__device__ __forceinline__ float msde_randn(unsigned long long seed, unsigned long long idx) {
+  float u1 = msde_uniform(seed, 2ull * idx), u2 = msde_uniform(seed, 2ull * idx + 1ull);
+  u1 = fmaxf(u1, 5.9604645e-8f);
+  return sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
 // launch a row kernel templated on the vector width; defines cols/tpr for the argument list
 #define LAUNCH_ROWS(KERNEL, ROWS, D, ...)                                                                          \
   if ((D) % 4 == 0) {                                                                                              \

@@ -168,6 +168,46 @@ extern "C" int msde_ve_perturb(const float* pos, const float* noise, const long 
   return 0;
 }
 
+// The same with the draws made in the kernel (counter-based generator: seed, device step counter, index): the position
+// noise N(0,1) per coordinate (written to noise_out: the loss needs it) and one uniform integer time step in [0, T) per
+// antithetic pair of molecules -- replaces torch.randn_like + torch.randint + msde_ve_perturb (3 launches -> 1).
+__global__ void __launch_bounds__(256)
+ve_perturb_rng_kernel(const float* __restrict__ pos, const int* __restrict__ batch, int N, int B, int T, float eps,
+                      float sigma_min, float sigma_ratio, unsigned long long seed,
+                      const unsigned long long* __restrict__ seed_dev, float* __restrict__ noise_out,
+                      float* __restrict__ pos_out, float* __restrict__ std_out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  if (seed_dev) seed += seed_dev[0] * 0x100000001B3ull;
+  int b = batch[i];
+  int H = B / 2 + 1;
+  const float u = msde_uniform(seed ^ 0x7157EEDC0FFEEull, (unsigned long long)(b < H ? b : b - H));
+  long long d0 = (long long)(u * (float)T);
+  if (d0 > T - 1) d0 = T - 1;
+  long long ts = b < H ? d0 : (long long)T - d0 - 1;
+  float t = (float)ts / (float)T;
+  t = t * (1.0f - eps) + eps;
+  float sd = sigma_min * powf(sigma_ratio, t);
+  std_out[i] = sd;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float z = msde_randn(seed, 3ull * (unsigned long long)i + c);
+    noise_out[3 * i + c] = z;
+    pos_out[3 * i + c] = pos[3 * i + c] + sd * z;
+  }
+}
+
+extern "C" int msde_ve_perturb_rng(const float* pos, const int* batch, int N, int B, int T, float eps, float sigma_min,
+                                   float sigma_max, unsigned long long seed, const unsigned long long* seed_dev,
+                                   float* noise_out, float* pos_out, float* std_out, void* stream) {
+  if (N < 0 || B <= 0 || T <= 0 || !pos || !batch || !noise_out || !pos_out || !std_out || sigma_min <= 0.f) return MSDE_EINVAL;
+  if (N == 0) return 0;
+  MSDE_LAUNCH(ve_perturb_rng_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), pos, batch, N, B, T, eps,
+              sigma_min, sigma_max / sigma_min, seed, seed_dev, noise_out, pos_out, std_out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 // Random permutation of 0..n-1 (torch.randperm for the contrastive negatives, examples/util.py:55) for n <= 4096:
 // out[i] = rank of key_i among n i.i.d. 64-bit keys (52 counter-based random bits: seed, device step counter,
 // index | 12 index bits, so keys are distinct).  The ranks of i.i.d. keys are a uniform random permutation.

@@ -236,6 +236,15 @@ class DeviceNoise:
             return hip.randperm(n, device, self.seed + 0x9E3779B1 * self.calls, self.seed_dev)
         return torch.randperm(n, device=device)
 
+    def draws_in_kernel(self):
+        """True when nothing overrides the position-noise / time-step draws: the VE perturbation kernel may then make them
+        itself (counter-based generator) instead of reading torch.randn_like / torch.randint results."""
+        return type(self).randn_like is DeviceNoise.randn_like and type(self).randint is DeviceNoise.randint
+
+    def next_seed(self):
+        self.calls += 1
+        return self.seed + 0x9E3779B1 * self.calls
+
     def rand(self, n, device):
         return torch.rand(n, device=device)
 

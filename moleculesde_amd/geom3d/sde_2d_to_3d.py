@@ -26,6 +26,7 @@ from .sde import VESDE, VPSDE
 EPSILON = 1e-6
 import os as _os
 FUSE_GAT_TAIL = True     # csrc/gat_tail.hip for hidden size 32 (False: the kernel-per-stage path, used as a cross-check)
+NOISE_IN_KERNEL = _os.environ.get("MSDE_NOISE_IN_KERNEL", "1") != "0"     # DeviceNoise: draws made by the VE perturbation kernel
 FUSE_FRAME = _os.environ.get("MSDE_FUSE_FRAME", "1") != "0"              # hip._FrameMLP (False: coff_mlp twice + cat + project)
 FUSE_PAIR_LINEAR = _os.environ.get("MSDE_FUSE_PAIR_LINEAR", "1") != "0"  # hip._PairLinear (False: re-laid-out weight per step)
 
@@ -240,6 +241,15 @@ class SDEModel2Dto3D_02(nn.Module):
         pl, ep = self._plan(data)
         B = data.num_graphs
         T = self.num_diffusion_timesteps
+        if (NOISE_IN_KERNEL and self.SDE_type == "VE" and pos.is_cuda and getattr(self.noise, "draws_in_kernel", None)
+                and self.noise.draws_in_kernel()):
+            # position noise and time steps drawn inside the perturbation kernel: one launch instead of three
+            pos_noise, pos_perturbed, std_pos = hip.ve_perturb_rng(
+                pos, pl.batch_i32, B, T, EPSILON, self.sde_pos.sigma_min, self.sde_pos.sigma_max, self.noise.next_seed(),
+                self.noise.seed_dev)
+            geo, side = self._launch_geometry(pos_perturbed, ep)
+            self._pending = (data, pos_noise, std_pos, pos_perturbed, geo, side)
+            return
         pos_noise = self.noise.randn_like(pos)
         draws = self.noise.randint(T, (B // 2 + 1,), pos.device)
         if self.SDE_type == "VE" and draws.dtype == torch.int64:

@@ -1977,6 +1977,18 @@ def ve_perturb(pos, noise, draws, batch_i32, B, T, eps, sigma_min, sigma_max):
     return out, std
 
 
+def ve_perturb_rng(pos, batch_i32, B, T, eps, sigma_min, sigma_max, seed, seed_dev=None):
+    """hip.ve_perturb with the draws made in the kernel (counter-based generator; seed_dev: device step counter mixed in
+    under hipGraph replay).  Returns (noise [N,3], pos + std * noise, std per atom)."""
+    pos = _f32(pos.detach())
+    N = pos.size(0)
+    noise, out = torch.empty_like(pos), torch.empty_like(pos)
+    std = torch.empty(N, dtype=torch.float32, device=pos.device)
+    _lib.call("msde_ve_perturb_rng", _p(pos), _p(batch_i32), N, int(B), int(T), float(eps), float(sigma_min), float(sigma_max),
+              int(seed) & 0xFFFFFFFFFFFFFFFF, _p(seed_dev), _p(noise), _p(out), _p(std), _stream())
+    return noise, out, std
+
+
 class _VEPosLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scores, noise, std, anneal_power, mol_ptr, batch_i32):

@@ -878,6 +878,37 @@ def test_frame_mlp_and_pair_linear_fused_operators(dev, E, H):
             assert_close(q.grad, r, 2e-4, 2e-4 * max(1.0, float(r.abs().max())), f"pair linear grad {name} (batched={batched})")
 
 
+def test_ve_perturb_rng_kernel(dev):
+    """msde_ve_perturb_rng: the VE perturbation (SDE_model_2D_to_3D.py:401-412) with the draws made in the kernel.  The
+    noise is N(0,1) (moments over 3 x 40k draws), pos_out = pos + std * noise, the time steps of molecule b and
+    b + H are antithetic (ts + ts' = T - 1 => std * std' is one constant), every molecule's atoms share one std,
+    reproducible for (seed, counter) and different for another counter value."""
+    from moleculesde_amd import hip
+    B, per, T = 256, 157, 1000
+    N = B * per
+    pos = torch.randn(N, 3, device=dev)
+    batch = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(per)
+    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+    smin, smax, eps = 0.1, 1.0, 1e-5
+    noise, out, std = hip.ve_perturb_rng(pos, batch, B, T, eps, smin, smax, 1234, ctr)
+    assert abs(float(noise.mean())) < 0.01 and abs(float(noise.var()) - 1.0) < 0.02
+    assert abs(float((noise ** 3).mean())) < 0.03 and abs(float((noise ** 4).mean()) - 3.0) < 0.1
+    assert_close(out, pos.double() + std.double()[:, None] * noise.double(), 1e-6, 1e-6, "pos + std * noise")     # (fused multiply-add in the kernel)
+    sm = std.view(B, per)
+    assert torch.equal(sm, sm[:, :1].expand(B, per))
+    H = B // 2 + 1
+    prod = sm[:B - H, 0].double() * sm[H:, 0].double()
+    want = smin * smin * (smax / smin) ** (((T - 1) / T) * (1 - eps) + 2 * eps)
+    assert_close(prod, torch.full_like(prod, want), 1e-5, 0, "antithetic time steps")
+    ts = torch.round(((torch.log(sm[:, 0].double() / smin) / math.log(smax / smin)) - eps) / (1 - eps) * T)
+    assert int(ts.min()) >= 0 and int(ts.max()) <= T - 1 and len(torch.unique(ts[:H])) > H // 2
+    again = hip.ve_perturb_rng(pos, batch, B, T, eps, smin, smax, 1234, ctr)
+    assert all(torch.equal(a, b) for a, b in zip((noise, out, std), again))
+    ctr.add_(1)
+    other = hip.ve_perturb_rng(pos, batch, B, T, eps, smin, smax, 1234, ctr)
+    assert not torch.equal(other[0], noise) and not torch.equal(other[2], std)
+
+
 @pytest.mark.parametrize("n", [1, 2, 37, 3588, 4096])
 def test_randperm_kernel(dev, n):
     """msde_randperm: always a permutation; reproducible for a (seed, counter); a new seed or counter value gives
