@@ -2228,7 +2228,8 @@ def _cached_layout(key, src, make):
             _WT.pop(key, None)
             _WT_TABLE.clear()
         wt, blocks = make()
-        ent = {"wt": wt, "blocks": blocks, "refs": [_weakref.ref(p, drop) for p in src], "versions": None, "epoch": -1}
+        ent = {"wt": wt, "blocks": blocks, "refs": [_weakref.ref(p, drop) for p in src], "versions": None, "epoch": -1,
+               "src_ptrs": tuple(p.data_ptr() for p in src)}
         _WT[key] = ent
         _WT_TABLE.clear()
     versions = tuple(p._version for p in src)
@@ -2284,6 +2285,16 @@ def refresh_weight_t():
     the current parameter epoch (the trainer calls this right after the optimiser step)."""
     if not _WT:
         return
+    # a parameter whose storage moved since its copy was made (an optimiser that re-points .data into a flat buffer, .to())
+    # has a new entry under its new address: the old one would read freed memory -- dropped here
+    moved = [k for k, e in _WT.items()
+             if any(r() is None or r().data_ptr() != q for r, q in zip(e["refs"], e["src_ptrs"]))]
+    for k in moved:
+        _WT.pop(k, None)
+    if moved:
+        _WT_TABLE.clear()
+        if not _WT:
+            return
     by_dev = {}
     for e in _WT.values():
         by_dev.setdefault(e["wt"].device, []).append(e)

@@ -878,6 +878,30 @@ def test_frame_mlp_and_pair_linear_fused_operators(dev, E, H):
             assert_close(q.grad, r, 2e-4, 2e-4 * max(1.0, float(r.abs().max())), f"pair linear grad {name} (batched={batched})")
 
 
+def test_weight_copies_follow_parameter_edits_and_moves(dev):
+    """The cached [K][N] copies the forward products read (hip.weight_t): an in-place edit (version counter), an update
+    through raw pointers (hip.bump_weight_epoch, what FlatAdam does) and a parameter whose storage is re-pointed (what
+    building a flat-buffer optimiser after a first forward does) are all seen by the next forward; the batched refresh
+    drops the copy of the old storage instead of reading it."""
+    from moleculesde_amd import hip
+    torch.manual_seed(3)
+    x = torch.randn(500, 64, device=dev)
+    lin = torch.nn.Linear(64, 48).to(dev)
+    ref = lambda: x.double() @ lin.weight.detach().double().t() + lin.bias.detach().double()
+    with torch.no_grad():
+        assert_close(hip.linear(x, lin.weight, lin.bias), ref(), 1e-5, 1e-5, "first forward")
+        lin.weight.mul_(0.5)                                        # version counter moves
+        assert_close(hip.linear(x, lin.weight, lin.bias), ref(), 1e-5, 1e-5, "after an in-place edit")
+        lin.weight.data.view(-1)[::7] += 1.0                        # .data edit: no version bump ...
+        hip.bump_weight_epoch()                                     # ... the optimiser's contract
+        assert_close(hip.linear(x, lin.weight, lin.bias), ref(), 1e-5, 1e-5, "after a raw-pointer update")
+        lin.weight.data = (lin.weight.data * 2.0).clone()           # storage re-pointed
+        hip.refresh_weight_t()                                      # must not touch the old storage's entry
+        assert_close(hip.linear(x, lin.weight, lin.bias), ref(), 1e-5, 1e-5, "after the storage moved")
+        hip.refresh_weight_t()
+        torch.cuda.synchronize()
+
+
 def test_ve_perturb_rng_kernel(dev):
     """msde_ve_perturb_rng: the VE perturbation (SDE_model_2D_to_3D.py:401-412) with the draws made in the kernel.  The
     noise is N(0,1) (moments over 3 x 40k draws), pos_out = pos + std * noise, the time steps of molecule b and
