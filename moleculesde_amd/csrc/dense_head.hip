@@ -180,6 +180,15 @@ struct EdgeLds {
   __host__ __device__ static int floats(int nm) {
     return 2 * nm * LQ + nm * nm * LA + 2 * nm * LV + nm * 17 * 2 + nm * 8 + ((W_END + 3) & ~3) + 8;
   }
+  // split forward: the node half (GCN + channel MLP) and the pair half (attention + pair MLP) of a molecule are two
+  // workgroups with their own, smaller LDS maps
+  __host__ __device__ static int floats_node(int nm) {
+    return nm * nm * LA + 2 * nm * LV + nm * 17 * 2 + nm * 8 + ((W_END + 3) & ~3) + 8;
+  }
+  __host__ __device__ static int floats_pair(int nm) { return 2 * nm * LQ + nm * nm * LA + ((W_END + 3) & ~3) + 8; }
+  __host__ __device__ static int floats_split(int nm) {
+    return floats_node(nm) > floats_pair(nm) ? floats_node(nm) : floats_pair(nm);
+  }
 };
 
 template <int C, int CO>
@@ -195,27 +204,33 @@ __device__ __forceinline__ void edge_load_weights(float* Wk, const msde_edge_lay
 }
 
 // stage Q | K, the adjacency channels and x W_c of one molecule; computes r[i] = clamp(deg_i, 1)^-1/2 per channel
+// (Qs == nullptr: no Q | K staging; Xv == nullptr: no x W_c staging and no r -- the two halves of the split forward)
 template <int C, int CO>
 __device__ __forceinline__ void edge_stage(float* Qs, float* Ks, float* Ad, float* Xv, float* Rn, const float* QK,
                                            const float* XV, const float* AC, int in_off, int a0, int n, int q0, int tid) {
   using L = EdgeLds<C, CO>;
   constexpr int W = 32 * C;
-  for (int e = tid; e < n * (W / 4); e += 256) {
-    const int i = e / (W / 4), c4 = (e - i * (W / 4)) * 4;
-    const float4 q = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + c4);
-    const float4 k = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + W + c4);
-    *reinterpret_cast<float4*>(Qs + i * L::LQ + c4) = q;
-    *reinterpret_cast<float4*>(Ks + i * L::LQ + c4) = k;
+  if (Qs) {
+    for (int e = tid; e < n * (W / 4); e += 256) {
+      const int i = e / (W / 4), c4 = (e - i * (W / 4)) * 4;
+      const float4 q = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + c4);
+      const float4 k = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + W + c4);
+      *reinterpret_cast<float4*>(Qs + i * L::LQ + c4) = q;
+      *reinterpret_cast<float4*>(Ks + i * L::LQ + c4) = k;
+    }
   }
   for (int e = tid; e < n * n * C; e += 256) {
     const int p = e / C, c = e - p * C;
     Ad[p * L::LA + c] = AC[(size_t)(q0 + p) * DH_AC + in_off + c];
   }
-  for (int e = tid; e < n * 16 * C; e += 256) {
-    const int i = e / (16 * C), f = e - i * 16 * C;
-    Xv[i * L::LV + f] = XV[(size_t)(a0 + i) * (16 * C) + f];
+  if (Xv) {
+    for (int e = tid; e < n * 16 * C; e += 256) {
+      const int i = e / (16 * C), f = e - i * 16 * C;
+      Xv[i * L::LV + f] = XV[(size_t)(a0 + i) * (16 * C) + f];
+    }
   }
   __syncthreads();
+  if (!Xv) return;
   // normalised adjacency of node_network_dense.py:66-74: diagonal := 1, deg = row sum clamped at 1
   for (int e = tid; e < n * C; e += 256) {
     const int i = e / C, c = e - i * C;
@@ -248,7 +263,10 @@ __device__ __forceinline__ float edge_att(const float* Qs, const float* Ks, int 
   return acc * 0.125f;
 }
 
-template <int C, int CO>
+// SPLIT: grid 2B -- workgroup 2b is the node half of molecule b (per-channel GCN, channel MLP, x_out), workgroup 2b + 1 its
+// pair half (attention, pair MLP, the layer's adjacency channels).  The halves share no intermediate, each needs about
+// half the LDS, so two workgroups fit a CU: two waves per SIMD instead of one walking five phases in a row.
+template <int C, int CO, int SPLIT = 0>
 __global__ void __launch_bounds__(256)
 dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restrict__ XV, float* __restrict__ AC, int in_off,
                             int out_off, const float* __restrict__ flags, const int* __restrict__ mol_ptr,
@@ -258,19 +276,21 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
   using L = EdgeLds<C, CO>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wk = lds;                    // weights first: 16-B aligned for the float4 broadcast reads
-  float* Qs = Wk + ((L::W_END + 3) & ~3);
-  float* Ks = Qs + nm * L::LQ;
-  float* Ad = Ks + nm * L::LQ;
-  float* Xv = Ad + nm * nm * L::LA;
+  const int part = SPLIT ? (int)(blockIdx.x & 1) : -1;      // 0: node half, 1: pair half, -1: both
+  float* Qs = part == 0 ? nullptr : Wk + ((L::W_END + 3) & ~3);
+  float* Ks = part == 0 ? nullptr : Qs + nm * L::LQ;
+  float* Ad = part == 0 ? Wk + ((L::W_END + 3) & ~3) : Ks + nm * L::LQ;
+  float* Xv = part == 1 ? nullptr : Ad + nm * nm * L::LA;
   float* Vc = Xv + nm * L::LV;
   float* Hm = Vc + nm * L::LV;        // [n][17]
   float* Tm = Hm + nm * 17;           // [n][17] scratch
   float* Rn = Tm + nm * 17;           // [n][C], C <= 8
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, tid = threadIdx.x;
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
   edge_load_weights<C, CO>(Wk, p, tid);
   edge_stage<C, CO>(Qs, Ks, Ad, Xv, Rn, QK, XV, AC, in_off, a0, n, q0, tid);
 
+  if (part != 1) {
   // ---- per-channel dense GCN: V_c = An_c (x W_c) + b_c; xcat[i][16c+f]
   for (int e = tid; e < n * 16 * C; e += 256) {
     const int i = e / (16 * C), cf = e - i * 16 * C, c = cf >> 4;
@@ -299,6 +319,8 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
     for (int k = 0; k < 16; ++k) s = fmaf(w[k], Hm[i * 17 + k], s);
     x_out[(size_t)(a0 + i) * 16 + o] = dh_tanh(s * flags[a0 + i]);
   }
+  }
+  if (part == 0) return;
   // ---- pairs: attention, pair MLP, symmetrise (= x2: inputs are symmetric, so mlp(i,j) == mlp(j,i)), mask
   for (int pp = tid; pp < n * n; pp += 256) {
     const int i = pp / n, j = pp - i * n;
@@ -618,6 +640,23 @@ extern "C" int msde_dense_edge_layer_fwd(const float* QK, const float* XV, float
   const int nm = n_max < 1 ? 1 : n_max;
   hipStream_t st = as_stream(stream);
   const msde_edge_layer_params p = *params;
+  static const bool want_split = [] { const char* e = getenv("MSDE_DENSE_SPLIT"); return !(e && atoi(e) == 0); }();
+#define EDGE_FWD_SPLIT(CC, CCO)                                                                                        \
+  if (C == CC && CO == CCO) {                                                                                          \
+    const int bytes = EdgeLds<CC, CCO>::floats_split(nm) * (int)sizeof(float);                                        \
+    if (want_split && 2 * bytes + 2048 <= 160 * 1024) {                                                                \
+      static bool s = false;                                                                                           \
+      if (!s) { hipFuncSetAttribute((const void*)dense_edge_layer_fwd_kernel<CC, CCO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); s = true; } \
+      MSDE_LAUNCH((dense_edge_layer_fwd_kernel<CC, CCO, 1>), dim3(2 * B), dim3(256), bytes, st, QK, XV, AC, in_off, out_off, \
+                  flags, mol_ptr, pair_ptr, p, nm, x_out, IN, H1, H2, xcat, Hmc);                                      \
+      MSDE_CHECK_LAUNCH();                                                                                             \
+      return 0;                                                                                                        \
+    }                                                                                                                  \
+  }
+  EDGE_FWD_SPLIT(2, 8)
+  EDGE_FWD_SPLIT(8, 8)
+  EDGE_FWD_SPLIT(8, 4)
+#undef EDGE_FWD_SPLIT
   EDGE_DISPATCH(dense_edge_layer_fwd_kernel, QK, XV, AC, in_off, out_off, flags, mol_ptr, pair_ptr, p, nm, x_out, IN, H1, H2,
                 xcat, Hmc);
   MSDE_CHECK_LAUNCH();
