@@ -86,8 +86,8 @@ def readme_args(**over):
 
 
 USE_FUSED_CL = True
-SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "256"))   # CFConv kernels beside the main chain:
-SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "256"))   # 256 = full width.  tools/ab.sh at the end of round 2, headline ms/step: 96: 3.13, 128: 3.065, 160: 3.04, 192: 3.065, 256: 3.085 -- at 160 the step is 1.4 % faster, but the kernel then occupies 62 % of the CUs: 89 us in the step = 0.32 of the chip's fp32 peak instead of 67 us = 0.43; --full: no difference
+SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "512"))   # CFConv kernels beside the main chain.  Round 3 (pair kernels; one box, 300-step runs, BWD = 160): 128: 2.825, 192: 2.803, 256: 2.766, 512: 2.736, 768: 2.740, 1024: 2.750 ms
+SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "176"))   # 256 = full width.  Round 3 (FWD = 256): 128: 2.768, 160: 2.757, 192: 2.755, 256: 2.783 ms -- the dominant kernel is now the row-strip GEMM of the MAIN chain, which gains what this kernel gives up.  Round 2:  tools/ab.sh at the end of round 2, headline ms/step: 96: 3.13, 128: 3.065, 160: 3.04, 192: 3.065, 256: 3.085 -- at 160 the step is 1.4 % faster, but the kernel then occupies 62 % of the CUs: 89 us in the step = 0.32 of the chip's fp32 peak instead of 67 us = 0.43; --full: no difference
 EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
 GEOMETRY_ON_SIDE = os.environ.get("MSDE_GEOMETRY_ON_SIDE", "1") != "0"   # coordinate-only branch of the 2D->3D model at the head of the second stream.  Round 2 (SchNet the longer chain): 3.187 vs 3.151 ms, off; round 3 (pair CFConv: SchNet is the SHORTER chain): 2.86 vs 2.98 ms, on (alternating A/B with tools/ab.sh)
 EARLY_SLAB_REDUCE = os.environ.get("MSDE_EARLY_SLAB_REDUCE", "1") != "0"
