@@ -119,6 +119,12 @@ int msde_dd_broadcast_rows(const float* b, int M, int K, float* y, void* stream)
 int msde_combine_losses(const float* a, const float* b, const float* c, const float* d, float ca, float cb, float cc,
                         float cd, float* out, void* stream);
 int msde_combine_losses_bwd(const float* g, float ca, float cb, float cc, float cd, float* out4, void* stream);
+/* msde_combine_losses with two riders in the same launch: seeds4[i] = c_i (= the backward's out4 for a unit upstream
+ * gradient: no backward launch then), and log_dst[k][0] += log_src[k][0] for k < n_log <= 5 (HOST arrays of device
+ * pointers): the per-term running sums of pretrain_MoleculeSDE.py:158-163. */
+int msde_combine_losses_ex(const float* a, const float* b, const float* c, const float* d, float ca, float cb, float cc,
+                           float cd, float* out, float* seeds4, const float* const* log_src, float* const* log_dst,
+                           int n_log, void* stream);
 
 /* Diagnostics: store the 100 MHz real-time counter into *slot, in stream order (capturable). */
 int msde_debug_stamp(long long* slot, void* stream);

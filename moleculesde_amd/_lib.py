@@ -106,6 +106,7 @@ SIGNATURES = {
     "msde_debug_stamp": [P, P],
     "msde_combine_losses": [P, P, P, P, F, F, F, F, P, P],
     "msde_combine_losses_bwd": [P, F, F, F, F, P, P],
+    "msde_combine_losses_ex": [P, P, P, P, F, F, F, F, P, P, P, P, I, P],
     "msde_set_row_bound": [I, P],
     "msde_clear_row_bounds": [],
     "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],

@@ -364,6 +364,33 @@ extern "C" int msde_combine_losses(const float* a, const float* b, const float* 
   MSDE_CHECK_LAUNCH();
   return 0;
 }
+// the same launch with two riders: seeds4[i] = c_i (the backward's result for a unit upstream gradient -- the trainer's case --
+// so that the backward pass needs no launch of its own), and up to five running sums log_dst[k] += *log_src[k] (the
+// per-term logs of pretrain_MoleculeSDE.py:158-163, one more launch at the end of every step otherwise)
+struct msde_combine_ex_args { const float* src[5]; float* dst[5]; };
+__global__ void combine_losses_ex_kernel(const float* a, const float* b, const float* c, const float* d, float ca, float cb,
+                                         float cc, float cd, float* out, float* seeds4, msde_combine_ex_args lg) {
+  float s = 0.f;
+  if (a) s = fmaf(ca, *a, s);
+  if (b) s = fmaf(cb, *b, s);
+  if (c) s = fmaf(cc, *c, s);
+  if (d) s = fmaf(cd, *d, s);
+  *out = s;
+  if (seeds4) { seeds4[0] = ca; seeds4[1] = cb; seeds4[2] = cc; seeds4[3] = cd; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    if (lg.src[k] && lg.dst[k]) *lg.dst[k] += *lg.src[k];
+}
+extern "C" int msde_combine_losses_ex(const float* a, const float* b, const float* c, const float* d, float ca, float cb,
+                                      float cc, float cd, float* out, float* seeds4, const float* const* log_src,
+                                      float* const* log_dst, int n_log, void* stream) {
+  if (!out || n_log < 0 || n_log > 5 || (n_log > 0 && (!log_src || !log_dst))) return MSDE_EINVAL;
+  msde_combine_ex_args lg;
+  for (int k = 0; k < 5; ++k) { lg.src[k] = k < n_log ? log_src[k] : nullptr; lg.dst[k] = k < n_log ? log_dst[k] : nullptr; }
+  MSDE_LAUNCH(combine_losses_ex_kernel, dim3(1), dim3(1), 0, as_stream(stream), a, b, c, d, ca, cb, cc, cd, out, seeds4, lg);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
 extern "C" int msde_combine_losses_bwd(const float* g, float ca, float cb, float cc, float cd, float* out4, void* stream) {
   if (!g || !out4) return MSDE_EINVAL;
   MSDE_LAUNCH(combine_losses_bwd_kernel, dim3(1), dim3(1), 0, as_stream(stream), g, ca, cb, cc, cd, out4);

@@ -6,6 +6,8 @@ stream; tensors must live on a HIP device -- there is no CPU path (a CPU tensor 
 """
 import ctypes
 
+import weakref as _weakref_unit
+
 import torch
 
 from . import _lib
@@ -2014,30 +2016,63 @@ class _VEPosLoss(torch.autograd.Function):
         return gs, None, None, None, None, None
 
 
+_UNIT_GRADS = {}          # data_ptr -> weakref of a LIVE tensor that holds the constant 1.0 (pretrain.Trainer._one_grad, the
+                          # d(loss)/d(loss) it passes to backward()): lets the loss composition skip its backward launch
+
+
+def register_unit_grad(t):
+    """t: a device scalar that holds 1.0 for as long as it lives and is passed to loss.backward(t)."""
+    _UNIT_GRADS[t.data_ptr()] = _weakref_unit.ref(t)
+
+
+def _is_unit_grad(g):
+    r = _UNIT_GRADS.get(g.data_ptr())
+    if r is None:
+        return False
+    if r() is None:                      # the registered tensor died: its address may belong to anything now
+        _UNIT_GRADS.pop(g.data_ptr(), None)
+        return False
+    return True
+
+
 class _CombineLosses(torch.autograd.Function):
-    """sum_i c_i * l_i over device scalars: one launch forward, one backward (csrc/pointwise.hip)."""
+    """sum_i c_i * l_i over device scalars: one launch forward (csrc/pointwise.hip), which also leaves the backward's result
+    for a unit upstream gradient and adds the logged terms to their running sums; the backward launches only when the
+    upstream gradient is something else than the trainer's constant one."""
 
     @staticmethod
-    def forward(ctx, coeffs, *terms):
+    def forward(ctx, coeffs, logs, *terms):
         assert 1 <= len(terms) <= 4 and len(coeffs) == len(terms)
         ts = [_f32(t).reshape(1) for t in terms]
         c = [float(x) for x in coeffs] + [0.0] * (4 - len(terms))
-        out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        dev = ts[0].device
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        seeds = torch.empty(4, dtype=torch.float32, device=dev)
         ptrs = [_p(t) for t in ts] + [_p(None)] * (4 - len(ts))
-        _lib.call("msde_combine_losses", *ptrs, *c, _p(out), _stream())
+        logs = list(logs or [])[:5]
+        n = len(logs)
+        src = (ctypes.c_void_p * 5)(*([t.data_ptr() for t, _ in logs] + [None] * (5 - n)))
+        dst = (ctypes.c_void_p * 5)(*([d.data_ptr() for _, d in logs] + [None] * (5 - n)))
+        _lib.call("msde_combine_losses_ex", *ptrs, *c, _p(out), _p(seeds), ctypes.cast(src, ctypes.c_void_p),
+                  ctypes.cast(dst, ctypes.c_void_p), n, _stream())
         ctx.c, ctx.n = c, len(terms)
+        ctx.seeds = seeds
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
-        g = _f32(g).reshape(1)
-        out4 = torch.empty(4, dtype=torch.float32, device=g.device)
-        _lib.call("msde_combine_losses_bwd", _p(g), *ctx.c, _p(out4), _stream())
-        return (None,) + tuple(out4[i] for i in range(ctx.n))
+        if _is_unit_grad(g):
+            out4 = ctx.seeds                 # g == 1: c_i * g was written by the forward launch
+        else:
+            g = _f32(g).reshape(1)
+            out4 = torch.empty(4, dtype=torch.float32, device=g.device)
+            _lib.call("msde_combine_losses_bwd", _p(g), *ctx.c, _p(out4), _stream())
+        return (None, None) + tuple(out4[i] for i in range(ctx.n))
 
 
-def combine_losses(coeffs, terms):
-    return _CombineLosses.apply(tuple(coeffs), *terms)
+def combine_losses(coeffs, terms, logs=None):
+    """logs: optional [(device scalar, running-sum device scalar)] added in the same launch (<= 5 pairs)."""
+    return _CombineLosses.apply(tuple(coeffs), logs, *terms)
 
 
 def ve_position_loss(scores, noise, std, anneal_power, mol_ptr, batch_i32):

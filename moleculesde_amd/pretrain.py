@@ -223,6 +223,9 @@ class Trainer:
         self.overlap_streams = True
         self._side_stream = torch.cuda.Stream(device=device)
         self._one_grad = torch.ones((), dtype=torch.float32, device=device)
+        if self._one_grad.is_cuda:
+            from . import hip as _hip0
+            _hip0.register_unit_grad(self._one_grad)      # the loss composition's backward needs no launch for it
         if EARLY_WGRAD_FLUSH:
             # when the 2D encoder's backward is through, launch the weight gradients queued so far (2D->3D model and
             # GIN) on the same stream: they run while the second stream still finishes SchNet's backward, and only
@@ -267,7 +270,7 @@ class Trainer:
             batch.radius_edge_index = ei
         return m3(batch.x[:, 0], batch.positions, ei, batch.batch, return_latent=True)
 
-    def losses(self, batch):
+    def losses(self, batch, log=False):
         """Loss composition of pretrain_MoleculeSDE.py:128-152.  The 3D encoder does not depend on the 2D
         branch (GIN -> 2D->3D score model) until the contrastive term, and most kernels of this 256-molecule
         step fill only part of the chip, so SchNet runs on a second HIP stream beside the 2D branch; autograd
@@ -392,7 +395,12 @@ class Trainer:
                 parts["3Dto2D"] = (_hip.combine_losses([0.5, 0.5], [l32[0].detach(), l32[1].detach()])
                                    if l32[0].is_cuda else (l32[0].detach() + l32[1].detach()) * 0.5)
         if terms and all(t.is_cuda for t in terms) and len(terms) <= 4:
-            loss = _hip.combine_losses(coeffs, terms)
+            logs = None
+            if log and not want_32 and len(parts) <= 5:
+                # the per-term running sums ride in the same launch (else: one more launch at the end of the step)
+                logs = [(parts[k].to(torch.float32) if parts[k].dtype != torch.float32 else parts[k], self.log[k]) for k in parts]
+                self._logged_by_launch = True
+            loss = _hip.combine_losses(coeffs, terms, logs)
         else:
             loss = 0
             for c_, t_ in zip(coeffs, terms):
@@ -401,6 +409,9 @@ class Trainer:
 
     def _log_parts(self, parts):
         keys = list(parts.keys())
+        if getattr(self, "_logged_by_launch", False):
+            self._logged_by_launch = False
+            return                     # already added by the loss composition's launch (losses(..., log=True))
         torch._foreach_add_([self.log[k] for k in keys], [parts[k].to(torch.float32) for k in keys])   # one launch
 
     def _backward(self, loss):
@@ -489,7 +500,7 @@ class Trainer:
     def step(self, batch):
         self._sync_bounds(batch)
         self.step_counter.add_(1)         # the device step counter re-seeds dropout / negatives once a capture set it
-        loss, parts = self.losses(batch)
+        loss, parts = self.losses(batch, log=True)
         self.opt.zero_grad()
         self._backward(loss)
         if self._use_dp():
@@ -507,7 +518,7 @@ class Trainer:
         from . import hip as _hip
         _hip.stamp("step_start")
         self.step_counter.add_(1)
-        loss, parts = self.losses(batch)
+        loss, parts = self.losses(batch, log=True)
         self.opt.zero_grad()
         self._backward(loss)
         if with_adam:
