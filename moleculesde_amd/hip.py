@@ -6,7 +6,7 @@ stream; tensors must live on a HIP device -- there is no CPU path (a CPU tensor 
 """
 import ctypes
 
-import weakref as _weakref_unit
+import weakref as _weakref
 
 import torch
 
@@ -2022,7 +2022,7 @@ _UNIT_GRADS = {}          # data_ptr -> weakref of a LIVE tensor that holds the 
 
 def register_unit_grad(t):
     """t: a device scalar that holds 1.0 for as long as it lives and is passed to loss.backward(t)."""
-    _UNIT_GRADS[t.data_ptr()] = _weakref_unit.ref(t)
+    _UNIT_GRADS[t.data_ptr()] = _weakref.ref(t)
 
 
 def _is_unit_grad(g):
@@ -2220,8 +2220,6 @@ def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=N
 #     bump_weight_epoch());
 #   * by ONE batched launch for all known weights (refresh_weight_t(), called by the trainer right after the optimiser
 #     step, inside the captured graph) -- then no forward of the next step launches a transpose.
-import weakref as _weakref
-
 _WT = {}                 # key -> entry dict(wt, refs, versions, epoch)
 _WT_EPOCH = 0
 _WT_TABLE = {}           # device -> dict(n, host/dev tables) of the batched refresh
