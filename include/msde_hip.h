@@ -210,6 +210,13 @@ int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab,
                                const int* src, const int* dst, int N, int E, int D, int R,
                                float* g_tab, float* g_eps, float* workspace, void* stream);
 
+/* the partial tables of `layers` <= 8 GIN layers over the SAME graph in ONE launch (g / x / tab / workspace: HOST arrays of
+ * device pointers, each workspace as for msde_gin_aggregate_bwd_tab with g_tab == g_eps == NULL): independent leaf work that
+ * would otherwise be `layers` launches in a row, each draining before the next starts. */
+int msde_gin_aggregate_bwd_tab_multi(const float* const* g, const float* const* x, const float* const* tab,
+                                     float* const* workspace, int layers, const int* codes, const int* src,
+                                     const int* dst, int N, int E, int D, int R, void* stream);
+
 /* ------------------------------------------------------------------ SchNet ----------------- */
 /* GaussianSmearing + cosine cutoff — schnet.py:186,205-207: rbf[e,g]=exp(coeff*(d-offset[g])^2),
  * C[e]=0.5(cos(d*pi/cutoff)+1); padded rows (e >= E_dev[0]) are zero. */

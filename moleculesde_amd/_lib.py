@@ -38,6 +38,7 @@ SIGNATURES = {
     "msde_gin_aggregate_bwd_x_stats": [P, P, P, P, P, P, P, P, I, P, I, P, P, I, P, P, P],
     "msde_gin_aggregate_bwd_tab_workspace_floats": [I, I, I, I],
     "msde_gin_aggregate_bwd_tab": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],
+    "msde_gin_aggregate_bwd_tab_multi": [P, P, P, P, I, P, P, P, I, I, I, I, P],
     "msde_rbf_cutoff_fwd": [P, P, I, I, P, F, F, P, P, P],
     "msde_cfconv_aggregate_fwd": [P, P, P, P, P, I, I, P, P],
     "msde_cfconv_aggregate_bwd_w": [P, P, P, P, P, I, I, I, P, P],

@@ -234,12 +234,23 @@ static inline int gt_ec() {           // edges per workgroup (MSDE_GT_EC: tuning
   static int v = [] { const char* e = getenv("MSDE_GT_EC"); int x = e ? atoi(e) : 16; return x < 4 ? 4 : x; }();
   return v;
 }
-__global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                             const float* __restrict__ tab, const int* __restrict__ codes,
+#define GT_MAX_LAYERS 8
+struct gt_layers {                  // the same kernel for up to GT_MAX_LAYERS layers of one graph in ONE launch
+  const float* g[GT_MAX_LAYERS];
+  const float* x[GT_MAX_LAYERS];
+  const float* tab[GT_MAX_LAYERS];
+  float* ws[GT_MAX_LAYERS];         // per layer: [nb][R*D] partial tables, then [nb] eps partials
+};
+__global__ void gin_aggregate_bwd_tab_kernel(const gt_layers L, int nb_per_layer, const int* __restrict__ codes,
                                              const int* __restrict__ src, const int* __restrict__ dst, int N, int E,
                                              const int* __restrict__ Ndev, const int* __restrict__ Edev,
-                                             int D, int R, int nodes_per_block, int GT_EC, float* __restrict__ slabs,
-                                             float* __restrict__ eps_part) {
+                                             int D, int R, int nodes_per_block, int GT_EC) {
+  const int layer = blockIdx.x / nb_per_layer, blk = blockIdx.x - layer * nb_per_layer;
+  const float* __restrict__ g = L.g[layer];
+  const float* __restrict__ x = L.x[layer];
+  const float* __restrict__ tab = L.tab[layer];
+  float* __restrict__ slabs = L.ws[layer];
+  float* __restrict__ eps_part = L.ws[layer] + (size_t)nb_per_layer * R * D;
   N = msde_true_rows(N, Ndev);      // row bounds: padded edges / atoms contribute nothing
   E = msde_true_rows(E, Edev);
   extern __shared__ float lds[];  // [R*D] table copy, [R*D] partial gradient, [blockDim/64] reduction scratch
@@ -248,7 +259,7 @@ __global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const 
   float* red = ltab + (size_t)R * D;
   for (int t = threadIdx.x; t < R * D; t += blockDim.x) { stab[t] = tab[t]; ltab[t] = 0.f; }
   __syncthreads();
-  const int e0 = blockIdx.x * GT_EC, e1 = min(e0 + GT_EC, E);
+  const int e0 = blk * GT_EC, e1 = min(e0 + GT_EC, E);
   for (int c = threadIdx.x; c < D; c += blockDim.x) {
     for (int eb = e0; eb < e1; eb += 4) {
       float xv[4], gv[4];
@@ -275,11 +286,11 @@ __global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const 
   }
   // eps partial: sum_i g[i].x[i] over this block's node slice
   float eacc = 0.f;
-  const int n0 = blockIdx.x * nodes_per_block, n1 = min(n0 + nodes_per_block, N);
+  const int n0 = blk * nodes_per_block, n1 = min(n0 + nodes_per_block, N);
   for (int i = n0; i < n1; ++i)
     for (int c = threadIdx.x; c < D; c += blockDim.x) eacc = fmaf(g[(size_t)i * D + c], x[(size_t)i * D + c], eacc);
   __syncthreads();
-  float* slab = slabs + (size_t)blockIdx.x * R * D;
+  float* slab = slabs + (size_t)blk * R * D;
   for (int t = threadIdx.x; t < R * D; t += blockDim.x) slab[t] = ltab[t];
   eacc = group_sum(eacc, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = eacc;
@@ -287,7 +298,7 @@ __global__ void gin_aggregate_bwd_tab_kernel(const float* __restrict__ g, const 
   if (threadIdx.x == 0) {
     float sum = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += red[w];
-    eps_part[blockIdx.x] = sum;
+    eps_part[blk] = sum;
   }
 }
 
@@ -321,6 +332,20 @@ extern "C" long long msde_gin_aggregate_bwd_tab_workspace_floats(int N, int E, i
   return (long long)gt_blocks(N, E) * ((long long)R * D + 1);
 }
 
+static int gt_launch(const gt_layers& L, int layers, const int* codes, const int* src, const int* dst, int N, int E, int D,
+                     int R, hipStream_t st) {
+  int threads = ((D + 63) / 64) * 64;
+  if (threads > 512) threads = 512;
+  size_t lds = (2 * (size_t)R * D + 8) * sizeof(float);
+  if (lds > 64 * 1024) return MSDE_EUNSUP;
+  int nb = gt_blocks(N, E);
+  int npb = (N + nb - 1) / nb;
+  MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3(nb * layers), dim3(threads), lds, st, L, nb, codes, src, dst, N, E,
+              msde_row_bound(N), msde_row_bound(E), D, R, npb, gt_ec());
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab, const int* codes,
                                           const int* src, const int* dst, int N, int E, int D, int R, float* g_tab,
                                           float* g_eps, float* workspace, void* stream) {
@@ -330,18 +355,29 @@ extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const 
     return MSDE_EINVAL;
   if (E > 0 && (!codes || !src || !dst)) return MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
-  int threads = ((D + 63) / 64) * 64;
-  if (threads > 512) threads = 512;
-  size_t lds = (2 * (size_t)R * D + 8) * sizeof(float);
-  if (lds > 64 * 1024) return MSDE_EUNSUP;
-  int nb = gt_blocks(N, E);
-  int npb = (N + nb - 1) / nb;
-  float* slabs = workspace;
-  float* eps_part = workspace + (size_t)nb * R * D;
-  MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3(nb), dim3(threads), lds, st, g, x, tab, codes, src, dst, N, E, msde_row_bound(N),
-              msde_row_bound(E), D, R, npb, gt_ec(),
-              slabs, eps_part);
-  MSDE_CHECK_LAUNCH();
+  gt_layers L = {};
+  L.g[0] = g; L.x[0] = x; L.tab[0] = tab; L.ws[0] = workspace;
+  int rc = gt_launch(L, 1, codes, src, dst, N, E, D, R, st);
+  if (rc) return rc;
   if (no_reduce) return 0;
-  return msde_reduce_slabs(slabs, nb, (size_t)R * D, g_tab, eps_part, 1, g_eps, st);
+  int nb = gt_blocks(N, E);
+  return msde_reduce_slabs(workspace, nb, (size_t)R * D, g_tab, workspace + (size_t)nb * R * D, 1, g_eps, st);
+}
+
+// the bond-table / eps partials of `layers` <= 8 GIN layers over the SAME graph (codes, src, dst) in one launch: the
+// layers' kernels are independent leaf work that the trainer runs beside the grouped weight-gradient launch, where five
+// launches in a row each wait for their last workgroups to find a free CU.  g / x / tab / workspace: HOST arrays of
+// `layers` device pointers; each workspace as for msde_gin_aggregate_bwd_tab with g_tab == g_eps == NULL.
+extern "C" int msde_gin_aggregate_bwd_tab_multi(const float* const* g, const float* const* x, const float* const* tab,
+                                                float* const* workspace, int layers, const int* codes, const int* src,
+                                                const int* dst, int N, int E, int D, int R, void* stream) {
+  if (layers < 1 || layers > GT_MAX_LAYERS || N < 0 || E < 0 || D <= 0 || R <= 0 || !g || !x || !tab || !workspace)
+    return MSDE_EINVAL;
+  if (E > 0 && (!codes || !src || !dst)) return MSDE_EINVAL;
+  gt_layers L = {};
+  for (int l = 0; l < layers; ++l) {
+    if (!g[l] || !x[l] || !tab[l] || !workspace[l]) return MSDE_EINVAL;
+    L.g[l] = g[l]; L.x[l] = x[l]; L.tab[l] = tab[l]; L.ws[l] = workspace[l];
+  }
+  return gt_launch(L, layers, codes, src, dst, N, E, D, R, as_stream(stream));
 }

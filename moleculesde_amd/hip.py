@@ -508,7 +508,9 @@ class _GinAggregate(torch.autograd.Function):
                           E_, D, R, _p(None), _p(None), _p(ws), st_ if st_ is not None else _stream())
             if DEFER_LEAF_KERNELS:
                 # a parameter gradient nothing in the backward chain reads: queued (operands kept alive) and launched by
-                # run_deferred_leaf_kernels() -- the trainer runs them beside the grouped weight-gradient launch
+                # run_deferred_leaf_kernels() -- the trainer runs them beside the grouped weight-gradient launch; the
+                # layers of one graph go out as ONE launch there (msde_gin_aggregate_bwd_tab_multi)
+                launch.gin_tab = (g, x, tab, codes, plan, ws, N, E_, D, R)
                 _SLABS.deferred.append(launch)
             else:
                 launch(st)
@@ -1319,8 +1321,22 @@ class _SlabBatch:
 
     def run_deferred(self):
         d, self.deferred = self.deferred, []
+        groups = {}
         for fn in d:
-            fn(None)
+            t = getattr(fn, "gin_tab", None)
+            if t is not None and GIN_TAB_MULTI:
+                groups.setdefault((t[3].data_ptr(), t[4].src.data_ptr(), t[6], t[7], t[8], t[9]), []).append(t)
+            else:
+                fn(None)
+        for ts in groups.values():
+            for i in range(0, len(ts), 8):
+                part = ts[i:i + 8]
+                n = len(part)
+                arr = lambda k: (ctypes.c_void_p * n)(*[t[k].data_ptr() for t in part])
+                _, _, _, codes, plan, _, N, E_, D, R = part[0]
+                _lib.call("msde_gin_aggregate_bwd_tab_multi", ctypes.cast(arr(0), ctypes.c_void_p), ctypes.cast(arr(1), ctypes.c_void_p),
+                          ctypes.cast(arr(2), ctypes.c_void_p), ctypes.cast(arr(5), ctypes.c_void_p), n, _p(codes), _p(plan.src),
+                          _p(plan.dst), N, E_, D, R, _stream())
         # the closures hold the kernels' operands: kept until finish(), because they may be launched on ANOTHER stream than
         # the one that allocated the operands (the caching allocator would hand their memory to that stream's next kernels)
         self.launched.extend(d)
@@ -1401,6 +1417,7 @@ class _SlabBatch:
 
 
 DEFER_LEAF_KERNELS = _os.environ.get("MSDE_DEFER_LEAF", "1") != "0"   # GIN bond-table gradients off the backward chain
+GIN_TAB_MULTI = _os.environ.get("MSDE_GIN_TAB_MULTI", "1") != "0"     # ... all layers of a graph in one launch
 WGRAD_LPT = _os.environ.get("MSDE_WGRAD_LPT", "1") != "0"            # grouped launch: problems with the longest workgroups first
 GROUPED_WGRAD = _os.environ.get("MSDE_GROUPED_WGRAD", "1") != "0"   # queued GEMMs -> one grouped launch at finish()
 _SLABS = _SlabBatch()
