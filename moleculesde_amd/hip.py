@@ -2392,7 +2392,7 @@ def rs_geometry(M, N, K):
 
 def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_kmajor=False, accumulate=False,
             axf=None, xf=(), relu=False, A2=None, A_out=None, stats=None, stats_mode=None, stats_z=None,
-            stats_mean=None, m_valid=None, N=None, K=None, rt=0, splits=0, fallback=True):
+            stats_mean=None, m_valid=None, N=None, K=None, rt=0, splits=0, fallback=True, t2=False):
     """out[M,N] = epilogue(xf(A) . B(^T) + bias) on msde_gemm_rs (see include/msde_hip.h: msde_rs_desc); no autograd.
     Returns `out`.  Shapes the row-strip kernels do not take (K % 4, unaligned operands) go to msde_gemm_ex when
     `fallback` and no fusion beyond bias / activation / derivative / accumulate is asked for; otherwise raises."""
@@ -2434,12 +2434,30 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
         m_valid = bound_tensor(M)
     d.m_valid = m_valid.data_ptr() if m_valid is not None else None
     d.rt, d.splits = int(rt), int(splits)
+    if t2:          # the 2-D tiled kernel (csrc/gemm_t2.hip): B is the [N][K] operand
+        _lib.check(_lib.load().msde_gemm_t2(ctypes.byref(d), _stream()), "msde_gemm_t2")
+        return out
     code = _lib.load().msde_gemm_rs(ctypes.byref(d), _stream())
     if code == -2 and fallback and axf is None and res is None and stats is None and A_out is None:
         return gemm_ex(A, B, out, bias=bias, act=act, Z=Z, dact_from=dact_from, b_kmajor=b_kmajor, accumulate=accumulate,
                        N=N, K=K)
     _lib.check(code, "msde_gemm_rs")
     return out
+
+
+_T2_MODE = _os.environ.get("MSDE_T2", "0")     # A/B switch while the 2-D tiled kernel is being evaluated in the step
+_T2_OK = {}
+
+
+def t2_ok(M, N, K):
+    """True when msde_gemm_t2 (csrc/gemm_t2.hip) takes this node-level product (and the switch is on)."""
+    if _T2_MODE == "0":
+        return False
+    key = (int(M), int(N), int(K))
+    v = _T2_OK.get(key)
+    if v is None:
+        v = _T2_OK[key] = bool(_lib.load().msde_gemm_t2_supported(*key))
+    return v
 
 
 RS_MAX_ROWS = 8192     # above this (edge-level operands) msde_gemm_ex's 64 x 64 tiles are faster than 16-row strips (tools/bench_gemm_rs.py)
@@ -2451,6 +2469,8 @@ def gemm_fwd(x, W, out, bias=None, act=None, Z=None, res=None):
     M, K = x.shape
     N = W.size(0)
     if 0 < M <= RS_MAX_ROWS and rs_forward_ok(M, N, K, W) and x.data_ptr() % 16 == 0 and _ld(x) % 4 == 0:
+        if t2_ok(M, N, K):        # 2-D tiles read the weight k-contiguous: as stored
+            return gemm_rs(x, W, out, bias=bias, act=act, Z=Z, res=res, N=N, K=K, t2=True)
         return gemm_rs(x, weight_t(W), out, bias=bias, act=act, Z=Z, res=res, b_kmajor=True, N=N, K=K, fallback=False)
     if res is not None:
         raise _lib.MsdeHipError("gemm_fwd: a residual needs the row-strip kernel (M <= %d, K %% 4 == N %% 4 == 0)" % RS_MAX_ROWS)
@@ -2463,6 +2483,8 @@ def gemm_dgrad(g, W, out, act=None, dact_from=None, res=None):
     K = W.size(1)
     if (0 < M <= RS_MAX_ROWS and N % 4 == 0 and K % 4 == 0 and W.is_contiguous() and g.data_ptr() % 16 == 0
             and _ld(g) % 4 == 0):
+        if t2_ok(M, K, N):        # ... for an input gradient that is the transposed copy [K][N]
+            return gemm_rs(g, weight_t(W), out, act=act, dact_from=dact_from, res=res, N=K, K=N, t2=True)
         return gemm_rs(g, W, out, act=act, dact_from=dact_from, res=res, b_kmajor=True, N=K, K=N, fallback=False)
     if act == "sspo":
         raise _lib.MsdeHipError("gemm_dgrad: 'sspo' needs the row-strip kernel")
