@@ -67,11 +67,14 @@ int msde_clear_row_bounds(void);
  * the bond graph as CSR by target (b_rowptr [N_cap+1], b_src, b_dst [Eb_cap]; canonical order = stable sort by target)
  * with its by-source view (b_rowptr_s, b_perm_s) and canonical-order bond_codes [Eb_cap][3] / bond_type [Eb_cap], the
  * extended graph the same way (e_*, Ee_cap), and scratch ext_rows [N_cap] / ext_cnt [B] / ext_ptr [B+1].  Padded tails:
- * see msde_set_row_bound.  *err is set to 1 if a molecule exceeds the limits. */
+ * see msde_set_row_bound.  *err is set to 1 if a molecule exceeds the limits or the batch one of the capacities N_cap,
+ * Eb_cap, Ee_cap, P_cap (atom pairs, sum n^2: rows of the dense head's pair arrays) or Er_cap (radius-edge bound sum
+ * n * min(n - 1, max_nbr): pair / edge buffers of the CFConv); the batch is then cut in front of the first molecule that
+ * does not fit (it and all later molecules count as empty), so every offset stays inside its buffer. */
 int msde_plan_build(const int* x_raw, int K, const int* atom_off, const int* bond_src, const int* bond_dst,
                     const int* bond_attr, const int* bond_off, const int* mol_atoms, const int* mol_bonds,
-                    int B, int N_cap, int Eb_cap, int Ee_cap, int max_nbr, int* mol_ptr, int* bond_ptr,
-                    int* pair_ptr, int* sizes, int* batch_i32, int* atom_codes, int* z_codes, int* b_rowptr,
+                    int B, int N_cap, int Eb_cap, int Ee_cap, int P_cap, int Er_cap, int max_nbr, int* mol_ptr,
+                    int* bond_ptr, int* pair_ptr, int* sizes, int* batch_i32, int* atom_codes, int* z_codes, int* b_rowptr,
                     int* b_src, int* b_dst, int* b_rowptr_s, int* b_perm_s, int* bond_codes, float* bond_type,
                     unsigned* ext_rows, int* ext_cnt, int* ext_ptr, int* e_rowptr, int* e_src, int* e_dst,
                     int* e_rowptr_s, int* e_perm_s, int* err, void* stream);
@@ -516,9 +519,10 @@ int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const float* g, i
  * 185-195): the filter network runs once per UNORDERED pair (csrc/cfconv_pair.hip).  Pairs of molecule m, local atoms
  * a < b of its n atoms: row pair_ptr[m] + a n - a (a + 1) / 2 + (b - a - 1); pair_ptr[B] = number of pairs.
  * msde_pair_build: pair_ptr [B+1], pi / pj [P_cap] (batch-global atom indices, pi < pj), pd [P_cap] = |p_i - p_j|, or -1
- * when d^2 >= r2 (no edge: its filter row is zero).  P_cap >= sum n (n - 1) / 2. */
+ * when d^2 >= r2 (no edge: its filter row is zero).  P_cap >= sum n (n - 1) / 2; a batch with more pairs is truncated
+ * (pair_ptr[B] = P_cap; the aggregation treats the missing pairs as absent) and *err (may be NULL) is set to 1. */
 int msde_pair_build(const float* pos, const int* mol_ptr, int B, float r2, int* pair_ptr, int* pi, int* pj, float* pd,
-                    int P_cap, void* stream);
+                    int P_cap, int* err, void* stream);
 /* Wf [P_cap, F] = (W2 ssp(W1 rbf(pd) + b1) + b2) * C(pd) for the first *count pairs (count = pair_ptr + B); F = 128,
  * G <= 64; W1 [F][G], W2 [F][F] as nn.Linear stores them.  blocks_per_wg <= 0: chosen by the library. */
 int msde_cfconv_pair_filter(const float* pd, const int* count, const float* W1, const float* b1, const float* W2,

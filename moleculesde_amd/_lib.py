@@ -48,7 +48,7 @@ SIGNATURES = {
     "msde_cfconv_fused_bwd_w_slabs": [I, I],
     "msde_gin_aggregate_bwd_tab_slabs": [I, I],
     "msde_cfconv_fused_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P, P, P, P, P],
-    "msde_pair_build": [P, P, I, F, P, P, P, P, I, P],
+    "msde_pair_build": [P, P, I, F, P, P, P, P, I, P, P],
     "msde_cfconv_pair_filter": [P, P, P, P, P, P, P, I, I, I, F, F, I, P, P],
     "msde_cfconv_pair_aggregate": [P, P, P, P, P, I, I, I, P, P],
     "msde_cfconv_pair_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P, P, P, P, P],
@@ -93,7 +93,7 @@ SIGNATURES = {
     "msde_dense_node_gcn_bwd": [P, I, P, I, P, P, P, P, I, I, P, P, P],
     "msde_dense_loss_fwd": [P, I, P, P, P, P, P, P, P, P, P, I, I, F, F, F, P, P, P, P, P, P],
     "msde_dense_loss_bwd": [P, P, P, P, P, I, P, P, P, P, P, I, I, F, F, F, P, P, P, P, P],
-    "msde_plan_build": [P, I, P, P, P, P, P, P, P, I, I, I, I, I] + [P] * 23 + [P],
+    "msde_plan_build": [P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I] + [P] * 23 + [P],
     "msde_plan_row_lists": [P, P, I, I, P, P, P, P],
     "msde_dd_unary": [P, P, LL, I, I, F, P, P],
     "msde_dd_rbf": [P, P, P, I, I, F, I, P, P],

@@ -148,6 +148,7 @@ class Bucket:
         self.ext_rows, self.ext_cnt, self.ext_ptr = i32(c.N), i32(c.B), i32(c.B + 1)
         pl = types.SimpleNamespace()
         pl.N, pl.B, pl.N_max, pl.max_nbr, pl.E_r_cap = c.N, c.B, c.n_max, MAX_NBR, c.E_r
+        pl.err_dev = self.err             # kernels that can detect a capacity overflow of their own raise the bucket's flag
         pl.mol_ptr = self.mol_ptr_full[:c.B + 1]
         pl.batch_i32 = i32(c.N)
         pl.atom_codes, pl.atom_R = i32(c.N, K_ATOM), sum(atom_dims)
@@ -196,7 +197,7 @@ class Bucket:
         c, pl, p, st = self.caps, self.plan, hip._p, hip._stream()
         _lib.call("msde_plan_build", p(self.x_raw), K_ATOM, p(self.atom_off), p(self.bond_src_raw), p(self.bond_dst_raw),
                   p(self.bond_attr_raw), p(self.bond_off), p(self.mol_atoms), p(self.mol_bonds), c.B, c.N, c.E_b, c.E_e,
-                  MAX_NBR, p(self.mol_ptr_full), p(self.bond_ptr), p(self.pair_ptr), p(self.sizes), p(pl.batch_i32),
+                  c.P, c.E_r, MAX_NBR, p(self.mol_ptr_full), p(self.bond_ptr), p(self.pair_ptr), p(self.sizes), p(pl.batch_i32),
                   p(pl.atom_codes), p(pl.z_codes), p(pl.bond.rowptr), p(pl.bond.src), p(pl.bond.dst), p(pl.bond.rowptr_s),
                   p(pl.bond.perm_s), p(pl.bond_codes), p(pl.bond_type), p(self.ext_rows), p(self.ext_cnt), p(self.ext_ptr),
                   p(pl.ext.rowptr), p(pl.ext.src), p(pl.ext.dst), p(pl.ext.rowptr_s), p(pl.ext.perm_s), p(self.err), st)

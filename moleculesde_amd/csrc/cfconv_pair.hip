@@ -29,7 +29,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // molecule's pairs, row-major over a < b
 __global__ void __launch_bounds__(256)
 pair_build_kernel(const float* __restrict__ pos, const int* __restrict__ mol_ptr, int B, float r2,
-                  int* __restrict__ pair_ptr, int* __restrict__ pi, int* __restrict__ pj, float* __restrict__ pd, int P_cap) {
+                  int* __restrict__ pair_ptr, int* __restrict__ pi, int* __restrict__ pj, float* __restrict__ pd, int P_cap,
+                  int* __restrict__ err) {
   __shared__ int part[256];
   const int m = blockIdx.x, tid = threadIdx.x;
   int s = 0;
@@ -49,6 +50,7 @@ pair_build_kernel(const float* __restrict__ pos, const int* __restrict__ mol_ptr
   if (tid == 0) {
     pair_ptr[m] = base;
     if (m == B - 1) pair_ptr[B] = min(base + cnt, P_cap);
+    if (base + cnt > P_cap && err) atomicExch(err, 1);     // the list is truncated: the batch is not a valid one
   }
   for (int idx = tid; idx < cnt; idx += 256) {
     // row a of the strict upper triangle starts at a n - a (a + 1) / 2: invert with a float root, then fix up
@@ -70,10 +72,11 @@ pair_build_kernel(const float* __restrict__ pos, const int* __restrict__ mol_ptr
 }
 
 extern "C" int msde_pair_build(const float* pos, const int* mol_ptr, int B, float r2, int* pair_ptr, int* pi, int* pj,
-                               float* pd, int P_cap, void* stream) {
+                               float* pd, int P_cap, int* err, void* stream) {
   if (B < 0 || P_cap < 0 || !pos || !mol_ptr || !pair_ptr || !pi || !pj || !pd) return MSDE_EINVAL;
   if (B == 0) return (int)hipMemsetAsync(pair_ptr, 0, sizeof(int), as_stream(stream));
-  MSDE_LAUNCH(pair_build_kernel, dim3(B), dim3(256), 0, as_stream(stream), pos, mol_ptr, B, r2, pair_ptr, pi, pj, pd, P_cap);
+  MSDE_LAUNCH(pair_build_kernel, dim3(B), dim3(256), 0, as_stream(stream), pos, mol_ptr, B, r2, pair_ptr, pi, pj, pd, P_cap,
+              err);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -275,6 +278,7 @@ cfconv_pair_aggregate_kernel(const float* __restrict__ x, const float* __restric
   if (m >= 0 && m < B) {
     const int a0 = mol_ptr[m], n = mol_ptr[m + 1] - a0, base = pair_ptr[m];
     const int a = i - a0;
+    const int cnt = pair_ptr[B];                // pairs actually listed (msde_pair_build truncates at its capacity)
     const float4* __restrict__ X = reinterpret_cast<const float4*>(x);
     const float4* __restrict__ W = reinterpret_cast<const float4*>(Wf);
     auto pid = [&](int b) {                     // pair of local atoms a and b != a
@@ -285,14 +289,17 @@ cfconv_pair_aggregate_kernel(const float* __restrict__ x, const float* __restric
     int k = h;
     for (; k + 2 < n - 1; k += 4) {
       const int b0 = k + (k >= a), b1 = k + 2 + (k + 2 >= a);
-      const float4 x0 = X[(size_t)(a0 + b0) * 32 + q], w0 = W[(size_t)pid(b0) * 32 + q];
-      const float4 x1 = X[(size_t)(a0 + b1) * 32 + q], w1 = W[(size_t)pid(b1) * 32 + q];
+      const int p0 = pid(b0), p1 = pid(b1);
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 x0 = X[(size_t)(a0 + b0) * 32 + q], w0 = p0 < cnt ? W[(size_t)p0 * 32 + q] : zero;
+      const float4 x1 = X[(size_t)(a0 + b1) * 32 + q], w1 = p1 < cnt ? W[(size_t)p1 * 32 + q] : zero;
       acc.x = fmaf(x0.x, w0.x, acc.x); acc.y = fmaf(x0.y, w0.y, acc.y); acc.z = fmaf(x0.z, w0.z, acc.z); acc.w = fmaf(x0.w, w0.w, acc.w);
       acc.x = fmaf(x1.x, w1.x, acc.x); acc.y = fmaf(x1.y, w1.y, acc.y); acc.z = fmaf(x1.z, w1.z, acc.z); acc.w = fmaf(x1.w, w1.w, acc.w);
     }
     for (; k < n - 1; k += 2) {
       const int b0 = k + (k >= a);
-      const float4 x0 = X[(size_t)(a0 + b0) * 32 + q], w0 = W[(size_t)pid(b0) * 32 + q];
+      const int p0 = pid(b0);
+      const float4 x0 = X[(size_t)(a0 + b0) * 32 + q], w0 = p0 < cnt ? W[(size_t)p0 * 32 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
       acc.x = fmaf(x0.x, w0.x, acc.x); acc.y = fmaf(x0.y, w0.y, acc.y); acc.z = fmaf(x0.z, w0.z, acc.z); acc.w = fmaf(x0.w, w0.w, acc.w);
     }
   }

@@ -147,10 +147,14 @@ gin_aggregate_bwd_x_stats_kernel(const float* __restrict__ g, const float* __res
   const float4* Zp = reinterpret_cast<const float4*>(zprev);
   const float ope = 1.f + eps[0];
   const int D = cols * 4;
-  for (int c = lane, ci = 0; c < cols; c += 64, ++ci) {
-    const float4 mu = reinterpret_cast<const float4*>(mean)[c];
+  // (the trip count is the same for every lane -- the barriers below are reached by all threads; lanes past the last column
+  // group only take part in them)
+  for (int cb = 0; cb < cols; cb += 64) {
+    const int c = cb + lane;
+    const bool act = c < cols;
+    const float4 mu = act ? reinterpret_cast<const float4*>(mean)[c] : vzero4();
     float4 sa = vzero4(), sb = vzero4();
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; act && it < 4; ++it) {
       const int j = blockIdx.x * 16 + it * 4 + grp;
       if (j >= N) continue;
       const float4 xj = X[(size_t)j * cols + c];
@@ -182,12 +186,12 @@ gin_aggregate_bwd_x_stats_kernel(const float* __restrict__ g, const float* __res
     }
     // groups 1..3 hand their sums to group 0 (fixed order)
     float* slot = red + ((size_t)(grp > 0 ? grp - 1 : 0) * 2) * D;
-    if (grp > 0) {
+    if (grp > 0 && act) {
       reinterpret_cast<float4*>(slot)[c] = sa;
       reinterpret_cast<float4*>(slot + D)[c] = sb;
     }
     __syncthreads();
-    if (grp == 0) {
+    if (grp == 0 && act) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         sa = vadd(sa, reinterpret_cast<const float4*>(red + (size_t)k * 2 * D)[c]);

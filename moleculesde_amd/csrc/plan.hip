@@ -42,38 +42,69 @@ __device__ __forceinline__ int pl_block_exscan(int v, int* sh /* [1024/64 + 1] *
 // sizes[]: 0 N, 1 E_b, 2 E_e, 3 P = sum n^2, 4 n_max, 5 sum n*min(n-1, max_nbr) (radius-graph edge bound), 6 2*E_e (valid
 // rows of tensors holding two rows per extended edge)
 // *err: cleared here, set (by this kernel or the per-molecule ones) when a molecule exceeds PL_NMAX / PL_EMAX or the batch
-// exceeds a capacity.  The counts are SANITISED before anything is derived from them -- a molecule beyond the limits counts
-// as empty, prefix sums are clamped to the capacities -- so that mol_ptr / bond_ptr / pair_ptr stay monotone and inside the
-// buffers whatever the raw blob holds: every kernel that walks them (here and in the step) is memory safe; the flagged
-// batch computes garbage, which the caller learns from *err (bucket.Bucket.poll_overflow).
+// exceeds a capacity.  The counts are SANITISED before anything is derived from them: a molecule beyond the limits counts as
+// empty, and the batch is CUT at the first molecule with which ANY running total -- atoms (N_cap), bonds (Eb_cap), atom
+// pairs sum n^2 (P_cap: the rows of the dense head's [P, *] arrays) or the radius-edge bound (Er_cap: the pair / edge
+// buffers of the CFConv) -- would pass its capacity: that molecule and every later one count as empty.  All prefix sums are
+// monotone, so the molecules that stay are a prefix of the batch and keep their offsets; mol_ptr / bond_ptr / pair_ptr stay
+// monotone and inside the buffers whatever the raw blob holds, and every kernel that walks them (here and in the step) is
+// memory safe.  The flagged batch is not a valid update, which the caller learns from *err (bucket.Bucket.poll_overflow).
 __global__ void __launch_bounds__(1024)
 plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_bonds, int B, int max_nbr, int N_cap,
-                 int Eb_cap, int* __restrict__ mol_ptr /* [B+2] */, int* __restrict__ bond_ptr /* [B+1] */,
+                 int Eb_cap, int P_cap, int Er_cap, int* __restrict__ mol_ptr /* [B+2] */, int* __restrict__ bond_ptr /* [B+1] */,
                  int* __restrict__ pair_ptr /* [B+1] */, int* __restrict__ sizes, int* __restrict__ err) {
   __shared__ int sh[20];
-  __shared__ int smax, sbad;
+  __shared__ int smax, sbad, scut;
   const int t = threadIdx.x;
   int n = t < B ? mol_atoms[t] : 0, m = t < B ? mol_bonds[t] : 0;
-  if (t == 0) { smax = 0; sbad = 0; }
+  if (t == 0) { smax = 0; sbad = 0; scut = B; }
   __syncthreads();
   if (n < 0 || n > PL_NMAX || m < 0 || m > PL_EMAX) { n = 0; m = 0; atomicExch(&sbad, 1); }
+  const int nr = n * min(max(n - 1, 0), max_nbr);
   int tot;
-  int ex = pl_block_exscan(n, sh, &tot);
-  const int a0 = min(ex, N_cap), a1 = min(ex + n, N_cap);
-  if (ex + n > N_cap) atomicExch(&sbad, 1);
-  n = a1 - a0;                                      // atoms of this molecule that fit
-  if (n == 0) m = 0;                                // no atoms: its bonds have nothing to point at
-  if (t < B) mol_ptr[t] = a0;
-  if (t == 0) { const int v = min(tot, N_cap); mol_ptr[B] = v; mol_ptr[B + 1] = v; sizes[0] = v; }
-  ex = pl_block_exscan(m, sh, &tot);
-  if (ex + m > Eb_cap) { atomicExch(&sbad, 1); }
-  if (t < B) bond_ptr[t] = min(ex, Eb_cap);
-  if (t == 0) { const int v = min(tot, Eb_cap); bond_ptr[B] = v; sizes[1] = v; }
-  ex = pl_block_exscan(n * n, sh, &tot);
-  if (t < B) pair_ptr[t] = ex;
-  if (t == 0) { pair_ptr[B] = tot; sizes[3] = tot; }
-  ex = pl_block_exscan(n * min(max(n - 1, 0), max_nbr), sh, &tot);
-  if (t == 0) sizes[5] = tot;
+  const int ex_n = pl_block_exscan(n, sh, &tot);
+  const int ex_m = pl_block_exscan(m, sh, &tot);
+  const int ex_p = pl_block_exscan(n * n, sh, &tot);
+  const int ex_r = pl_block_exscan(nr, sh, &tot);
+  if (t < B && (ex_n + n > N_cap || ex_m + m > Eb_cap || ex_p + n * n > P_cap || ex_r + nr > Er_cap)) {
+    atomicMin(&scut, t);
+    atomicExch(&sbad, 1);
+  }
+  __syncthreads();
+  const int cut = scut;
+  if (t == cut || (t == 0 && cut == B)) {          // totals = the offsets of the first molecule that was cut (or of the end)
+    const bool all = cut == B;
+    // (for cut == B thread 0 holds only ITS offsets: the totals of the whole batch come from one more scan below)
+    if (!all) {
+      mol_ptr[B] = ex_n; mol_ptr[B + 1] = ex_n; sizes[0] = ex_n;
+      bond_ptr[B] = ex_m; sizes[1] = ex_m;
+      pair_ptr[B] = ex_p; sizes[3] = ex_p;
+      sizes[5] = ex_r;
+    }
+  }
+  if (t >= cut) { n = 0; m = 0; }
+  // offsets: kept molecules keep theirs; cut ones collapse onto the cut molecule's (an empty range at the end of the valid rows)
+  __shared__ int cn, cm, cp;
+  if (t == cut) { cn = ex_n; cm = ex_m; cp = ex_p; }
+  __syncthreads();
+  if (t < B) {
+    mol_ptr[t] = t < cut ? ex_n : cn;
+    bond_ptr[t] = t < cut ? ex_m : cm;
+    pair_ptr[t] = t < cut ? ex_p : cp;
+  }
+  if (cut == B) {                                  // nothing cut: the block totals
+    int tn, tm, tp, tr;
+    pl_block_exscan(n, sh, &tn);
+    pl_block_exscan(m, sh, &tm);
+    pl_block_exscan(n * n, sh, &tp);
+    pl_block_exscan(nr, sh, &tr);
+    if (t == 0) {
+      mol_ptr[B] = tn; mol_ptr[B + 1] = tn; sizes[0] = tn;
+      bond_ptr[B] = tm; sizes[1] = tm;
+      pair_ptr[B] = tp; sizes[3] = tp;
+      sizes[5] = tr;
+    }
+  }
   atomicMax(&smax, n);
   __syncthreads();
   if (t == 0) { sizes[4] = smax; *err = sbad; }
@@ -298,19 +329,19 @@ plan_lists_fill_kernel(const int* __restrict__ codes, const int* __restrict__ n_
 
 extern "C" int msde_plan_build(const int* x_raw, int K, const int* atom_off, const int* bond_src, const int* bond_dst,
                                const int* bond_attr, const int* bond_off, const int* mol_atoms, const int* mol_bonds,
-                               int B, int N_cap, int Eb_cap, int Ee_cap, int max_nbr, int* mol_ptr, int* bond_ptr,
-                               int* pair_ptr, int* sizes, int* batch_i32, int* atom_codes, int* z_codes, int* b_rowptr,
+                               int B, int N_cap, int Eb_cap, int Ee_cap, int P_cap, int Er_cap, int max_nbr, int* mol_ptr,
+                               int* bond_ptr, int* pair_ptr, int* sizes, int* batch_i32, int* atom_codes, int* z_codes, int* b_rowptr,
                                int* b_src, int* b_dst, int* b_rowptr_s, int* b_perm_s, int* bond_codes, float* bond_type,
                                unsigned* ext_rows, int* ext_cnt, int* ext_ptr, int* e_rowptr, int* e_src, int* e_dst,
                                int* e_rowptr_s, int* e_perm_s, int* err, void* stream) {
-  if (B <= 0 || B > 1024 || K <= 0 || N_cap <= 0 || !x_raw || !atom_off || !bond_src || !bond_dst || !bond_attr ||
+  if (B <= 0 || B > 1024 || K <= 0 || N_cap <= 0 || P_cap < 0 || Er_cap < 0 || !x_raw || !atom_off || !bond_src || !bond_dst || !bond_attr ||
       !bond_off || !mol_atoms || !mol_bonds || !mol_ptr || !bond_ptr || !pair_ptr || !sizes || !batch_i32 || !atom_codes ||
       !z_codes || !b_rowptr || !b_src || !b_dst || !b_rowptr_s || !b_perm_s || !bond_codes || !bond_type || !ext_rows ||
       !ext_cnt || !ext_ptr || !e_rowptr || !e_src || !e_dst || !e_rowptr_s || !e_perm_s || !err)
     return B > 1024 ? MSDE_EUNSUP : MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
-  MSDE_LAUNCH(plan_scan_kernel, dim3(1), dim3(1024), 0, st, mol_atoms, mol_bonds, B, max_nbr, N_cap, Eb_cap, mol_ptr, bond_ptr,
-              pair_ptr, sizes, err);
+  MSDE_LAUNCH(plan_scan_kernel, dim3(1), dim3(1024), 0, st, mol_atoms, mol_bonds, B, max_nbr, N_cap, Eb_cap, P_cap, Er_cap, mol_ptr,
+              bond_ptr, pair_ptr, sizes, err);
   MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(plan_molecule_kernel, dim3(B), dim3(256), 0, st, x_raw, K, atom_off, bond_src, bond_dst, bond_attr, bond_off,
               (const int*)mol_ptr, (const int*)bond_ptr, batch_i32, atom_codes, z_codes, b_rowptr, b_src, b_dst, b_rowptr_s,

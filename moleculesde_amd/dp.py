@@ -44,6 +44,9 @@ def broadcast_flat(flat, src=0):
     """Make every replica start from rank `src`'s parameters."""
     if world_size() > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
         dist.broadcast(flat, src=src)
+        if flat.is_cuda:                  # parameters rewritten behind autograd's and the optimiser's back
+            from . import hip
+            hip.invalidate_weight_copies()
     return flat
 
 

@@ -59,7 +59,7 @@ class ForceTrainer:
         self.opt.zero_grad()
         loss.backward()
         self.opt.step_from_grads()
-        hip.refresh_weight_t()             # re-laid-out weight copies (if any layer of the model reads one) follow the update
+        self._refreshed = hip.refresh_weight_t()    # re-laid-out weight copies (if a layer reads one) follow the update
         return loss.detach()
 
     def step(self, batch, y=None, force=None):
@@ -91,6 +91,7 @@ class ForceTrainer:
         self.opt.use_eager_slot()
         hip.use_eager_param_grad_slot()
         self._graph = g
+        self._graph_wt_keys = self._refreshed          # the copies the captured refresh launch re-lays-out at every replay
         return g
 
     def step_graph(self, positions, y, force):
@@ -101,4 +102,5 @@ class ForceTrainer:
         self._f.copy_(force, non_blocking=True)
         hip.sync_weight_copies()           # parameters edited from outside since the last step (load_state_dict, ...)
         self._graph.replay()
+        hip.weight_copies_after_replay(self._graph_wt_keys)
         return self._loss

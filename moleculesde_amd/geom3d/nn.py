@@ -65,6 +65,10 @@ class BatchNorm1d(nn.BatchNorm1d):
         super().__init__(*a, **k)
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.flush_batches_tracked())
 
+    def _load_from_state_dict(self, *a, **k):
+        self._nbt_host = None             # the host mirror of num_batches_tracked (momentum=None mode) follows the buffer
+        return super()._load_from_state_dict(*a, **k)
+
     def flush_batches_tracked(self):
         if self.pending_batches and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(int(self.pending_batches))
@@ -82,7 +86,19 @@ class BatchNorm1d(nn.BatchNorm1d):
                     self.num_batches_tracked.add_(1)
                 elif not torch.cuda.is_current_stream_capturing():
                     self.pending_batches += 1          # replays of a captured step are counted by the trainer
-            momentum = 0.1 if self.momentum is None else self.momentum
+            momentum = self.momentum
+            if momentum is None:
+                # cumulative moving average (torch.nn.BatchNorm1d with momentum=None): factor 1 / batches seen.  The count
+                # lives on the device; a host mirror is read once and advanced with it (nothing else writes the buffer
+                # between forwards except load_state_dict, which resets the mirror below).  The factor changes per call,
+                # so this mode cannot be captured into a hipGraph.
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("BatchNorm1d(momentum=None) cannot run inside a captured step")
+                if getattr(self, "_nbt_host", None) is None or self.num_batches_tracked is None:
+                    self._nbt_host = int(self.num_batches_tracked) if self.num_batches_tracked is not None else 1
+                else:
+                    self._nbt_host += 1
+                momentum = 1.0 / max(self._nbt_host, 1)
             return hip.batch_norm_train(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
                                         self.running_var if self.track_running_stats else None, self.eps, momentum,
                                         self.fuse_relu)
@@ -94,7 +110,7 @@ class BatchNorm1d(nn.BatchNorm1d):
 def bn_fusable(bn):
     """Training-mode BatchNorm1d with running statistics and affine parameters: what the fused products implement."""
     return (isinstance(bn, BatchNorm1d) and bn.training and bn.track_running_stats and bn.affine and USE_HIP_LINEAR
-            and bn.running_mean is not None)
+            and bn.running_mean is not None and bn.momentum is not None)     # (momentum=None: a per-call factor, unfused)
 
 
 def count_batch(bn):

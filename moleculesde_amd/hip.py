@@ -308,7 +308,7 @@ def pair_plan(pos, pl, cutoff):
     pp.pj = torch.empty(n, dtype=torch.int32, device=dev)
     pp.pd = torch.empty(n, dtype=torch.float32, device=dev)
     _lib.call("msde_pair_build", _p(pos), _p(pl.mol_ptr), pp.B, float(cutoff) * float(cutoff), _p(pp.pair_ptr), _p(pp.pi),
-              _p(pp.pj), _p(pp.pd), pp.P, _stream())
+              _p(pp.pj), _p(pp.pd), pp.P, _p(getattr(pl, "err_dev", None)), _stream())
     pp.count = pp.pair_ptr[pp.B:]
     return pp
 
@@ -2268,6 +2268,24 @@ def _fill_entry(ent):
         _lib.call("msde_relayout", ctypes.c_void_p(src_ptr), src_ld, ctypes.c_void_p(dst_ptr), dst_ld, r, c, mode, _stream())
 
 
+def _clear_tables():
+    """Forget the eager refresh tables (the set of entries changed).  A captured graph never reads THESE tables -- a capture
+    builds its own, owned by the process for good (refresh_weight_t) -- but once anything was captured they are parked
+    instead of freed all the same."""
+    for t in _WT_TABLE.values():
+        _retire([t["tab"], t["pre"]])
+    _WT_TABLE.clear()
+
+
+def _drop_entry(key):
+    """Remove a cache entry (its parameter died or moved).  A captured graph may still write the entry's buffer at every
+    replay: parked, never handed back to the allocator, once a capture happened."""
+    ent = _WT.pop(key, None)
+    if ent is not None:
+        _retire([ent["wt"]])
+    _clear_tables()
+
+
 def _cached_layout(key, src, make):
     """Entry of the re-laid-out weight cache for the leaf parameters `src`; make() -> (buffer, blocks) on a miss.  The
     buffer is refreshed (one msde_relayout per block on the current stream) when a source's version counter or the
@@ -2275,13 +2293,12 @@ def _cached_layout(key, src, make):
     ent = _WT.get(key)
     if ent is None:
         def drop(_r, key=key):
-            _WT.pop(key, None)
-            _WT_TABLE.clear()
+            _drop_entry(key)
         wt, blocks = make()
         ent = {"wt": wt, "blocks": blocks, "refs": [_weakref.ref(p, drop) for p in src], "versions": None, "epoch": -1,
                "src_ptrs": tuple(p.data_ptr() for p in src)}
         _WT[key] = ent
-        _WT_TABLE.clear()
+        _clear_tables()
     versions = tuple(p._version for p in src)
     if ent["versions"] != versions or ent["epoch"] != _WT_EPOCH:
         _fill_entry(ent)
@@ -2294,7 +2311,9 @@ def weight_t(w):
     and free concatenation views of leaves are kept; anything else (a weight computed in the forward) is transposed
     on the spot."""
     src = getattr(w, "_msde_src", None) or (w,)
-    stable = not getattr(w, "_msde_volatile", False) and all(p.is_leaf for p in src)
+    # only PARAMETERS are cached (their storage lives as long as the model); any other leaf -- a weight computed under
+    # no_grad, a test tensor -- would leave an entry whose buffer a later capture bakes in and whose death frees it
+    stable = not getattr(w, "_msde_volatile", False) and all(isinstance(p, torch.nn.Parameter) for p in src)
     if not stable:
         wc = w if w.is_contiguous() else w.contiguous()
         wt = torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device)
@@ -2332,33 +2351,64 @@ def weight_layout(tag, params, shape, blocks):
 
 def refresh_weight_t():
     """Re-lay-out every known weight copy with one launch per device on the current stream and mark the copies fresh for
-    the current parameter epoch (the trainer calls this right after the optimiser step)."""
+    the current parameter epoch (the trainer calls this right after the optimiser step).  Returns the keys of the entries
+    it refreshed.  While a hipGraph is being captured, the table the launch reads and the buffers of the entries it names are
+    parked for the life of the process: entries that appear or disappear later build NEW eager tables (a table is never
+    edited in place), never touch the memory a captured launch reads or writes."""
     if not _WT:
-        return
+        return ()
     # a parameter whose storage moved since its copy was made (an optimiser that re-points .data into a flat buffer, .to())
     # has a new entry under its new address: the old one would read freed memory -- dropped here
     moved = [k for k, e in _WT.items()
              if any(r() is None or r().data_ptr() != q for r, q in zip(e["refs"], e["src_ptrs"]))]
     for k in moved:
-        _WT.pop(k, None)
-    if moved:
-        _WT_TABLE.clear()
-        if not _WT:
-            return
+        _drop_entry(k)
+    if not _WT:
+        return ()
+    capturing = torch.cuda.is_current_stream_capturing()
     by_dev = {}
-    for e in _WT.values():
-        by_dev.setdefault(e["wt"].device, []).append(e)
-    for dev, entries in by_dev.items():
+    for k, e in _WT.items():
+        by_dev.setdefault(e["wt"].device, []).append((k, e))
+    done = []
+    for dev, items in by_dev.items():
+        entries = [e for _, e in items]
         t = _WT_TABLE.get(dev)
         if t is None or t["n"] != len(entries):
+            if capturing:      # (a table upload is a host-to-device copy: not capturable)
+                raise _lib.MsdeHipError("refresh_weight_t inside a capture needs the tables of an eager step on the same "
+                                        "model first (Trainer.capture runs one)")
             tab, pre, total, _ = _transpose_into(entries)
             t = {"n": len(entries), "rows": tab.size(0), "tab": tab.to(dev), "pre": pre.to(dev), "total": total}
             _WT_TABLE[dev] = t
-            _retire([])            # tables are tiny and stay referenced from _WT_TABLE
+        if capturing:
+            # tables are never edited in place (a changed entry set builds new ones): parking this one and the buffers it
+            # names is all a replay needs
+            _KEEP_ALIVE.extend([t["tab"], t["pre"]] + [e["wt"] for e in entries])
         _lib.call("msde_transpose_multi", _p(t["tab"]), _p(t["pre"]), t["rows"], t["total"], _stream())
-        for e in entries:
+        for k, e in items:
             e["versions"] = tuple(r()._version for r in e["refs"] if r() is not None)
             e["epoch"] = _WT_EPOCH
+            done.append(k)
+    return tuple(done)
+
+
+def weight_copies_after_replay(keys):
+    """Call after REPLAYING a captured step whose optimiser update runs inside the graph: the parameters changed without
+    any Python running, the graph's own refresh launch re-laid-out the entries `keys` (what refresh_weight_t returned at
+    capture) -- those are fresh, every other entry (made later, e.g. by an eager step on another batch shape) is stale
+    and is refreshed lazily at its next use."""
+    bump_weight_epoch()
+    for k in keys:
+        e = _WT.get(k)
+        if e is not None:
+            e["versions"] = tuple(r()._version for r in e["refs"] if r() is not None)
+            e["epoch"] = _WT_EPOCH
+
+
+def invalidate_weight_copies():
+    """The parameters were rewritten through a path that moves neither the autograd version counters nor the optimiser
+    (p.data.copy_, a write into the flat parameter buffer, a broadcast): every re-laid-out copy is stale."""
+    bump_weight_epoch()
 
 
 def sync_weight_copies():
@@ -2373,6 +2423,21 @@ def sync_weight_copies():
     return False
 
 
+_T2_MODE = _os.environ.get("MSDE_T2", "1")     # "0": every node-level product on the row strips (A/B measurements)
+_T2_OK = {}
+
+
+def t2_ok(M, N, K):
+    """True when msde_gemm_t2 (csrc/gemm_t2.hip) takes this node-level product (and the switch is on)."""
+    if _T2_MODE == "0":
+        return False
+    key = (int(M), int(N), int(K))
+    v = _T2_OK.get(key)
+    if v is None:
+        v = _T2_OK[key] = bool(_lib.load().msde_gemm_t2_supported(*key))
+    return v
+
+
 def rs_forward_ok(M, N, K, w):
     """Shapes msde_gemm_rs takes for a forward product on weight w [N][K] (the rest goes to msde_gemm_ex)."""
     return K % 4 == 0 and N % 4 == 0 and w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32
@@ -2384,10 +2449,23 @@ def bound_tensor(rows):
 
 
 def rs_geometry(M, N, K):
-    """(strips, rows per strip) of the statistics partials msde_gemm_rs writes for this problem."""
+    """(strips, rows per strip) of the statistics partials the node-level product kernel writes for this problem (the 2-D
+    tiled kernel when it takes the shape, else the row strips)."""
     a, b = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.call("msde_gemm_rs_geometry", int(M), int(N), int(K), ctypes.byref(a), ctypes.byref(b))
+    _lib.call("msde_gemm_t2_geometry" if t2_ok(M, N, K) else "msde_gemm_rs_geometry", int(M), int(N), int(K), ctypes.byref(a),
+              ctypes.byref(b))
     return a.value, b.value
+
+
+def gemm_node(A, W, out, forward, N, K, **kw):
+    """A node-level product against the nn.Linear weight W [out][in]: forward (A W^T, N = out, K = in) or input gradient
+    (A W, N = in, K = out), with every fusion of gemm_rs (**kw), on whichever kernel takes the shape -- and the weight copy
+    that kernel reads: 2-D tiles read the reduction index contiguous ([N][K]: W as stored forward, its transposed copy
+    backward), row strips the other one."""
+    M = A.size(0)
+    if t2_ok(M, N, K):
+        return gemm_rs(A, W if forward else weight_t(W), out, N=N, K=K, t2=True, **kw)
+    return gemm_rs(A, weight_t(W) if forward else W, out, b_kmajor=True, N=N, K=K, fallback=False, **kw)
 
 
 def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_kmajor=False, accumulate=False,
@@ -2443,21 +2521,6 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
                        N=N, K=K)
     _lib.check(code, "msde_gemm_rs")
     return out
-
-
-_T2_MODE = _os.environ.get("MSDE_T2", "0")     # A/B switch while the 2-D tiled kernel is being evaluated in the step
-_T2_OK = {}
-
-
-def t2_ok(M, N, K):
-    """True when msde_gemm_t2 (csrc/gemm_t2.hip) takes this node-level product (and the switch is on)."""
-    if _T2_MODE == "0":
-        return False
-    key = (int(M), int(N), int(K))
-    v = _T2_OK.get(key)
-    if v is None:
-        v = _T2_OK[key] = bool(_lib.load().msde_gemm_t2_supported(*key))
-    return v
 
 
 RS_MAX_ROWS = 8192     # above this (edge-level operands) msde_gemm_ex's 64 x 64 tiles are faster than 16-row strips (tools/bench_gemm_rs.py)
@@ -2526,19 +2589,18 @@ class _GinMlpBN(torch.autograd.Function):
         M, D = agg.shape
         H = W1.size(0)
         dev = agg.device
-        W1t, W2t = weight_t(W1), weight_t(W2)
         s1, r1 = rs_geometry(M, H, D)
         st1 = torch.empty(s1, 2, H, dtype=torch.float32, device=dev)
         z1 = torch.empty(M, H, dtype=torch.float32, device=dev)
-        gemm_rs(agg, W1t, z1, bias=b1, stats=st1, stats_mode="bnfwd", b_kmajor=True, N=H, K=D, fallback=False)
+        gemm_node(agg, W1, z1, True, H, D, bias=b1, stats=st1, stats_mode="bnfwd")
         v1 = _bn_fin_fwd(st1, s1, r1, M, H, g1, be1, eps1, mom1, rm1, rv1)
         s2, r2 = rs_geometry(M, D, H)
         st2 = torch.empty(s2, 2, D, dtype=torch.float32, device=dev)
         a1 = torch.empty(M, H, dtype=torch.float32, device=dev)
         z2 = torch.empty(M, D, dtype=torch.float32, device=dev)
         stamp("gin_gemm2_start")          # no-ops unless enable_stamps(): bench.py times this launch inside the captured step
-        gemm_rs(z1, W2t, z2, bias=b2, axf="affine", xf=(v1[0], v1[1]), relu=True, A_out=a1, stats=st2, stats_mode="bnfwd",
-                b_kmajor=True, N=D, K=H, fallback=False)
+        gemm_node(z1, W2, z2, True, D, H, bias=b2, axf="affine", xf=(v1[0], v1[1]), relu=True, A_out=a1, stats=st2,
+                  stats_mode="bnfwd")
         stamp("gin_gemm2_end")
         v2 = _bn_fin_fwd(st2, s2, r2, M, D, g2, be2, eps2, mom2, rm2, rv2)
         h = torch.empty(M, D, dtype=torch.float32, device=dev)
@@ -2578,19 +2640,17 @@ class _GinMlpBN(torch.autograd.Function):
         sta = torch.empty(sa, 2, H, dtype=torch.float32, device=dev)
         dz2 = torch.empty(M, D, dtype=torch.float32, device=dev)
         ga1 = torch.empty(M, H, dtype=torch.float32, device=dev)
-        gemm_rs(g, W2, ga1, b_kmajor=True, N=H, K=D, axf="bnbwd",
-                xf=(pw2[0], pw2[1], pw2[2]) + ((v2[0], v2[1]) if ctx.relu_out else (None, None)), A2=z2, A_out=dz2,
-                act="relu", dact_from=a1, stats=sta, stats_mode="bnbwd", stats_z=z1, stats_mean=v1[2], fallback=False)
+        gemm_node(g, W2, ga1, False, H, D, axf="bnbwd",
+                  xf=(pw2[0], pw2[1], pw2[2]) + ((v2[0], v2[1]) if ctx.relu_out else (None, None)), A2=z2, A_out=dz2,
+                  act="relu", dact_from=a1, stats=sta, stats_mode="bnbwd", stats_z=z1, stats_mean=v1[2])
         pw1, gb1 = _bn_fin_bwd(sta, sa, M, H, g1, v1[2], v1[3])
         dz1 = torch.empty(M, H, dtype=torch.float32, device=dev)
         g_agg = torch.empty(M, D, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         if g_agg is not None:
-            gemm_rs(ga1, W1, g_agg, b_kmajor=True, N=D, K=H, axf="bnbwd", xf=(pw1[0], pw1[1], pw1[2]), A2=z1, A_out=dz1,
-                    fallback=False)
+            gemm_node(ga1, W1, g_agg, False, D, H, axf="bnbwd", xf=(pw1[0], pw1[1], pw1[2]), A2=z1, A_out=dz1)
         else:       # nothing upstream wants a gradient: only dz1 for the weight gradient (product result discarded)
             scratch = torch.empty(M, D, dtype=torch.float32, device=dev)
-            gemm_rs(ga1, W1, scratch, b_kmajor=True, N=D, K=H, axf="bnbwd", xf=(pw1[0], pw1[1], pw1[2]), A2=z1, A_out=dz1,
-                    fallback=False)
+            gemm_node(ga1, W1, scratch, False, D, H, axf="bnbwd", xf=(pw1[0], pw1[1], pw1[2]), A2=z1, A_out=dz1)
         gW2, gbias2 = weight_grad(dz2, a1, True, ctx.deferrable)
         gW1, gbias1 = weight_grad(dz1, agg, True, ctx.deferrable)
         return (g_agg, gW1, gbias1, gb1[0], gb1[1], None, None, gW2, gbias2, gb2[0], gb2[1], None, None,

@@ -243,6 +243,7 @@ class Trainer:
         self.adam_outside_graph = False   # True reproduces the multi-GPU structure (graph; all-reduce; Adam) on 1 GPU
         self._graph_pool = None
         self._graph_loss = {}
+        self._graph_wt_keys = {}
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=device)
 
     def _side_geometry(self, on):
@@ -485,7 +486,7 @@ class Trainer:
         """Right after an optimiser step: ONE launch re-transposes every weight the forward products read as [K][N]
         (hip.weight_t), so that no forward of the next step has to."""
         from . import hip as _hip
-        _hip.refresh_weight_t()
+        self._last_refreshed = _hip.refresh_weight_t()
 
     def _sync_bounds(self, batch):
         """Row bounds are process wide: a capacity-bucket batch needs its bucket's bounds, an exact-size batch none."""
@@ -563,6 +564,8 @@ class Trainer:
         # the captured batch is held strongly: its tensors' addresses are baked into the graph, and a live reference
         # keeps id(batch) from being recycled for a different batch
         self._graphs[key] = (g, batch, with_adam)
+        # the weight copies the captured refresh launch re-lays-out at every replay (hip.weight_copies_after_replay)
+        self._graph_wt_keys[key] = getattr(self, "_last_refreshed", ()) if with_adam else None
         self._graph_loss[key] = loss
         return g
 
@@ -573,6 +576,8 @@ class Trainer:
         from . import hip as _hip
         _hip.sync_weight_copies()          # parameters edited from outside since the last step (load_state_dict, ...)
         g.replay()
+        if self._graph_wt_keys.get(id(batch)) is not None:
+            _hip.weight_copies_after_replay(self._graph_wt_keys[id(batch)])
         for bn in self._bn_modules:
             bn.pending_batches += 1        # the captured forward does not run Python: count its BatchNorm calls here
         if not with_adam:

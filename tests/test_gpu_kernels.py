@@ -902,6 +902,43 @@ def test_weight_copies_follow_parameter_edits_and_moves(dev):
         torch.cuda.synchronize()
 
 
+def test_weight_copy_refresh_captured_in_a_graph_survives_later_entries(dev):
+    """a captured step holds the raw addresses of the refresh launch's tables and of every copy it writes.  Entries
+    that appear (another model's first forward) or die (a temporary module) after the capture rebuild the EAGER tables;
+    the captured launch keeps reading its own table and writing its own buffers, which are never handed back to the
+    allocator.  After the replay the copy of the captured entry is fresh, the later entry is marked stale."""
+    from moleculesde_amd import hip
+    torch.manual_seed(4)
+    lin_a = torch.nn.Linear(96, 80).to(dev)
+    with torch.no_grad():
+        wa = hip.weight_t(lin_a.weight)
+        assert torch.equal(wa, lin_a.weight.t())
+        hip.note_capture()
+        hip.refresh_weight_t()                                        # (eager: builds the tables a capture may not upload)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            keys = hip.refresh_weight_t()
+        assert len(keys) >= 1
+        lin_b = torch.nn.Linear(64, 48).to(dev)                       # a later entry: the eager tables are rebuilt
+        wb = hip.weight_t(lin_b.weight)
+        tmp = torch.nn.Linear(200, 120).to(dev)
+        hip.weight_t(tmp.weight)
+        del tmp                                                       # ... and one that dies: its buffer must not be reused
+        import gc
+        gc.collect()
+        junk = [torch.full((n,), float("nan"), device=dev) for n in (64, 512, 4096, 24000, 200 * 120)]   # grabs freed blocks
+        lin_a.weight.data.add_(1.0)                                   # an update Python does not see (what Adam in a graph does)
+        lin_b.weight.data.add_(2.0)
+        g.replay()
+        hip.weight_copies_after_replay(keys)
+        torch.cuda.synchronize()
+        assert torch.equal(wa, lin_a.weight.t()), "the captured refresh wrote the copy it was captured with"
+        assert all(bool(torch.isnan(j).all()) for j in junk), "a replay wrote into memory it no longer owns"
+        assert torch.equal(hip.weight_t(lin_b.weight), lin_b.weight.t()), "the later entry was marked stale and refreshed"
+        del wb
+
+
 def test_ve_perturb_rng_kernel(dev):
     """msde_ve_perturb_rng: the VE perturbation (SDE_model_2D_to_3D.py:401-412) with the draws made in the kernel.  The
     noise is N(0,1) (moments over 3 x 40k draws), pos_out = pos + std * noise, the time steps of molecule b and
@@ -1143,6 +1180,39 @@ def test_gemm_rs_plain(dev, M, N, K):
     assert torch.equal(out, out2), "gemm_rs must be bitwise reproducible"
 
 
+@pytest.mark.parametrize("M,N,K", [(3588, 300, 300), (3588, 600, 300), (3588, 300, 600), (3588, 128, 300), (3588, 300, 128),
+                                   (3588, 32, 300), (3588, 128, 32), (3588, 728, 364), (3588, 728, 728), (35186, 32, 300),
+                                   (35186, 300, 32), (777, 80, 64), (512, 176, 36), (9000, 128, 64), (3588, 256, 100),
+                                   (1030, 36, 4), (3588, 304, 16)])
+def test_gemm_t2_plain(dev, M, N, K):
+    """msde_gemm_t2 (2-D tiles, both operands through LDS by LDS-DMA): C = act(A W^T + bias) + res with the pre-activation
+    stored, against fp64 torch; [N][K] weights, row / column / K tails (K = 300: a 12-wide last K tile whose second k-half
+    is skipped; K = 36, 100, 4; odd and even tile counts), every tiles-per-workgroup variant, forced split counts.
+    NaN-filled outputs prove every element is written; two launches must agree bit for bit."""
+    from moleculesde_amd import hip, _lib
+    if not _lib.load().msde_gemm_t2_supported(M, N, K):
+        pytest.skip("shape not taken by msde_gemm_t2")
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    zr = A.double() @ W.double().t() + b.double()
+    ref = _act_ref("ssp")(zr) + res.double()
+    for splits in (0, 1, 3, 8):
+        ntiles = (N + 15) // 16
+        if splits > ntiles:
+            continue
+        out = torch.full((M, N), float("nan"), device=dev)
+        Z = torch.full((M, N), float("nan"), device=dev)
+        hip.gemm_rs(A, W, out, bias=b, act="ssp", Z=Z, res=res, t2=True, splits=splits)
+        assert_close(Z, zr, 1e-5, 2e-5, f"gemm_t2 pre-activation (splits {splits})")
+        assert_close(out, ref, 1e-5, 2e-5, f"gemm_t2 out (splits {splits})")
+        out2 = torch.full((M, N), float("nan"), device=dev)
+        hip.gemm_rs(A, W, out2, bias=b, act="ssp", res=res, t2=True, splits=splits)
+        assert torch.equal(out, out2), "gemm_t2 must be bitwise reproducible"
+
+
 @pytest.mark.parametrize("act", [None, "silu", "ssp", "relu", "tanh"])
 def test_gemm_rs_epilogues(dev, act):
     """Residual + accumulate into a column block of a wider buffer, and the input-gradient product through an activation
@@ -1228,10 +1298,12 @@ def test_gemm_chain_schnet_node_layers(dev, M, F, Hd):
         assert_close(a, b, 2e-4, 2e-4 * max(1.0, float(b.abs().max())), "head chain grad " + name)
 
 
+@pytest.mark.parametrize("t2", [False, True], ids=["strips", "tiles"])
 @pytest.mark.parametrize("M,C1,C2,relu,bound", [(3588, 600, 300, True, None), (3588, 300, 600, False, None),
                                                 (35186, 300, 32, True, None), (200, 64, 48, True, 150),
-                                                (3648, 600, 300, True, 3588)])
-def test_gemm_rs_fused_batchnorm_chain(dev, M, C1, C2, relu, bound):
+                                                (3648, 600, 300, True, 3588), (1350, 600, 300, True, None),
+                                                (1408, 300, 600, True, 1350), (700, 128, 64, False, None)])
+def test_gemm_rs_fused_batchnorm_chain(dev, M, C1, C2, relu, bound, t2):
     """x -> Linear(K0, C1) -> BatchNorm1d (training) -> [ReLU] -> Linear(C1, C2) with the statistics in the first product's
     epilogue, msde_bn_fin_fwd, and the BatchNorm apply (+ ReLU) in the second product's A load; then the backward:
     input-gradient product with the ReLU gate and the BatchNorm-backward partial sums in its epilogue, msde_bn_fin_bwd,
@@ -1240,6 +1312,18 @@ def test_gemm_rs_fused_batchnorm_chain(dev, M, C1, C2, relu, bound):
     from moleculesde_amd import hip, _lib
     import ctypes
     K0 = 128
+    if t2 and M < 512:
+        pytest.skip("msde_gemm_t2 takes M >= 512")
+
+    def prod(A, W, out, forward, **kw):          # W: nn.Linear layout [out][in]; both kernels, each with the layout it reads
+        if t2:
+            return hip.gemm_rs(A, W if forward else W.t().contiguous(), out, t2=True, **kw)
+        return hip.gemm_rs(A, W.t().contiguous() if forward else W, out, b_kmajor=True, fallback=False, **kw)
+
+    def geometry(M_, N_, K_):
+        a_, b_ = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.call("msde_gemm_t2_geometry" if t2 else "msde_gemm_rs_geometry", M_, N_, K_, ctypes.byref(a_), ctypes.byref(b_))
+        return a_.value, b_.value
     torch.manual_seed(M + C1)
     Mv = bound or M
     x = torch.randn(M, K0)
@@ -1266,19 +1350,20 @@ def test_gemm_rs_fused_batchnorm_chain(dev, M, C1, C2, relu, bound):
     st = hip._stream()
     p = hip._p
     # forward
-    strips, srows = hip.rs_geometry(M, C1, K0)
+    strips, srows = geometry(M, C1, K0)
     stats = torch.full((strips, 2, C1), float("nan"), device=dev)
     zd = torch.empty(M, C1, device=dev)
-    hip.gemm_rs(xd, W1d.t().contiguous(), zd, bias=b1d, stats=stats, stats_mode="bnfwd", m_valid=mvd, b_kmajor=True,
-                fallback=False)
+    prod(xd, W1d, zd, True, bias=b1d, stats=stats, stats_mode="bnfwd", m_valid=mvd)
     scale, shift, smean, srstd = (torch.empty(C1, device=dev) for _ in range(4))
     rm, rv = torch.zeros(C1, device=dev), torch.ones(C1, device=dev)
     _lib.call("msde_bn_fin_fwd", p(stats), strips, srows, M, p(mvd), C1, p(gd), p(bd), 1e-5, 0.1, p(rm), p(rv), p(scale),
               p(shift), p(smean), p(srstd), st)
     ad = torch.full((M, C1), float("nan"), device=dev)
     yd = torch.empty(M, C2, device=dev)
-    hip.gemm_rs(zd, W2d.t().contiguous(), yd, axf="affine", xf=(scale, shift), relu=relu, A_out=ad, m_valid=mvd,
-                b_kmajor=True, fallback=False)
+    prod(zd, W2d, yd, True, axf="affine", xf=(scale, shift), relu=relu, A_out=ad, m_valid=mvd)
+    yd2, ad2 = torch.full_like(yd, float("nan")), torch.full_like(ad, float("nan"))
+    prod(zd, W2d, yd2, True, axf="affine", xf=(scale, shift), relu=relu, A_out=ad2, m_valid=mvd)
+    assert torch.equal(yd, yd2) and torch.equal(ad, ad2), "fused BatchNorm-apply product must be bitwise reproducible"
     assert_close(smean, mu.detach(), 1e-5, 1e-5, "fused bn mean")
     assert_close(srstd, 1 / torch.sqrt(var.detach() + 1e-5), 1e-4, 1e-5, "fused bn rstd")
     assert_close(ad[:Mv], a.detach(), 1e-4, 2e-5, "fused bn apply (A_out)")
@@ -1287,17 +1372,20 @@ def test_gemm_rs_fused_batchnorm_chain(dev, M, C1, C2, relu, bound):
     assert_close(rm, 0.1 * mu.detach(), 1e-5, 1e-6, "running mean")
     assert_close(rv, 0.9 + 0.1 * unb, 1e-4, 1e-6, "running var")
     # backward: g_a = gy W2 gated by the ReLU, with the BatchNorm-backward partial sums
-    strips2, _ = hip.rs_geometry(M, C1, C2)
+    strips2, _ = geometry(M, C1, C2)
     stats2 = torch.full((strips2, 2, C1), float("nan"), device=dev)
     gad = torch.empty(M, C1, device=dev)
-    hip.gemm_rs(gyd, W2d, gad, b_kmajor=True, act="relu" if relu else None, dact_from=ad if relu else None, stats=stats2,
-                stats_mode="bnbwd", stats_z=zd, stats_mean=smean, m_valid=mvd, fallback=False)
+    prod(gyd, W2d, gad, False, act="relu" if relu else None, dact_from=ad if relu else None, stats=stats2,
+         stats_mode="bnbwd", stats_z=zd, stats_mean=smean, m_valid=mvd)
     pv, wv, uv, dgam, dbet = (torch.empty(C1, device=dev) for _ in range(5))
     _lib.call("msde_bn_fin_bwd", p(stats2), strips2, M, p(mvd), C1, p(gd), p(smean), p(srstd), p(pv), p(wv), p(uv), p(dgam),
               p(dbet), st)
     dzd = torch.full((M, C1), float("nan"), device=dev)
     gxd = torch.empty(M, K0, device=dev)
-    hip.gemm_rs(gad, W1d, gxd, b_kmajor=True, axf="bnbwd", xf=(pv, wv, uv), A2=zd, A_out=dzd, m_valid=mvd, fallback=False)
+    prod(gad, W1d, gxd, False, axf="bnbwd", xf=(pv, wv, uv), A2=zd, A_out=dzd, m_valid=mvd)
+    gxd2, dzd2 = torch.full_like(gxd, float("nan")), torch.full_like(dzd, float("nan"))
+    prod(gad, W1d, gxd2, False, axf="bnbwd", xf=(pv, wv, uv), A2=zd, A_out=dzd2, m_valid=mvd)
+    assert torch.equal(gxd, gxd2) and torch.equal(dzd, dzd2), "fused BatchNorm-backward product must be bitwise reproducible"
     # a pre-activation within rounding of the ReLU gate may fall on either side: compare away from it
     apre = (xhat * gr + br).detach()
     unsure = (apre.abs() <= 2e-5) if relu else torch.zeros_like(apre, dtype=torch.bool)

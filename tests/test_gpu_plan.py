@@ -369,7 +369,27 @@ def test_oversized_batch_falls_back_and_overflow_is_flagged(dev):
     assert int(bk.err.cpu()) == 1
     assert bool((guard == 12345).all())
     assert not bk.check()[0]
-    tr.step_bucket(bk, BK.pack_raw(fits[0], caps).to(dev))   # poll is one call late: this call only queues the copy ...
+    # (3b) a blob whose ATOMS fit but whose atom pairs (sum n^2: the rows of the dense head's [P, *] arrays, the CFConv's
+    # pair list) do not: few, large molecules.  The plan cuts the batch in front of the first molecule that does not fit,
+    # every derived size stays inside its capacity, and the flag is raised
+    blob2 = BK.pack_raw(fits[0], caps).clone()
+    k = min(caps.B, caps.N // 24)
+    assert k * 24 * 24 > caps.P, (k, caps.as_dict())
+    blob2[o:o + caps.B] = torch.tensor([24] * k + [0] * (caps.B - k), dtype=torch.int32)
+    try:
+        tr.step_bucket(bk, blob2.to(dev))
+    except BK.BucketOverflow:
+        tr.step_bucket(bk, blob2.to(dev))                     # (the poll of the previous bad step)
+    torch.cuda.synchronize()
+    sz = bk.sizes.cpu()
+    assert int(bk.err.cpu()) == 1
+    assert int(sz[0]) <= caps.N and int(sz[3]) <= caps.P and int(sz[5]) <= caps.E_r, (sz.tolist(), caps.as_dict())
+    assert int(bk.pair_ptr.cpu().max()) <= caps.P
+    assert bool((guard == 12345).all())
+    try:
+        tr.step_bucket(bk, BK.pack_raw(fits[0], caps).to(dev))   # poll is one call late: this call only queues the copy ...
+    except BK.BucketOverflow:
+        pass
     with pytest.raises(BK.BucketOverflow):
         for _ in range(3):                                    # ... and one of the next calls reports the bad step
             tr.step_bucket(bk, BK.pack_raw(fits[0], caps).to(dev))
