@@ -330,8 +330,10 @@ def cfconv_pair_forward(x1, pp, W1, b1, W2, b2, offset, coeff, cutoff):
     _lib.call("msde_cfconv_pair_filter", _p(pp.pd), _p(pp.count), _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)),
               _p(_f32(offset)), Fd, G, pp.P, float(coeff), float(cutoff), _pair_blocks_per_wg(pp.P), _p(Wf), st)
     agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
+    stamp("cf_agg_start")     # no-ops unless enable_stamps(): bench.py times this launch inside the captured step
     _lib.call("msde_cfconv_pair_aggregate", _p(x1), _p(Wf), _p(pp.batch_i32), _p(pp.mol_ptr), _p(pp.pair_ptr), N, pp.B, Fd,
               _p(agg), st)
+    stamp("cf_agg_end")
     return agg, Wf
 
 
