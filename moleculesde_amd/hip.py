@@ -2376,12 +2376,19 @@ def refresh_weight_t():
         entries = [e for _, e in items]
         t = _WT_TABLE.get(dev)
         if t is None or t["n"] != len(entries):
-            if capturing:      # (a table upload is a host-to-device copy: not capturable)
-                raise _lib.MsdeHipError("refresh_weight_t inside a capture needs the tables of an eager step on the same "
-                                        "model first (Trainer.capture runs one)")
             tab, pre, total, _ = _transpose_into(entries)
-            t = {"n": len(entries), "rows": tab.size(0), "tab": tab.to(dev), "pre": pre.to(dev), "total": total}
-            _WT_TABLE[dev] = t
+            if capturing:
+                # entries first made INSIDE this capture (a layer the warm-up steps did not reach: e.g. a loss term switched
+                # on since): a host-to-device copy is not capturable, so the table's upload is recorded and performed once
+                # after the capture (flush_table_uploads), like every other pointer table of a captured step
+                dtab = torch.empty(tab.shape, dtype=tab.dtype, device=dev)
+                dpre = torch.empty(pre.shape, dtype=pre.dtype, device=dev)
+                upload_table(dtab, tab)
+                upload_table(dpre, pre)
+                t = {"n": len(entries), "rows": tab.size(0), "tab": dtab, "pre": dpre, "total": total}
+            else:
+                t = {"n": len(entries), "rows": tab.size(0), "tab": tab.to(dev), "pre": pre.to(dev), "total": total}
+                _WT_TABLE[dev] = t
         if capturing:
             # tables are never edited in place (a changed entry set builds new ones): parking this one and the buffers it
             # names is all a replay needs

@@ -509,3 +509,50 @@ def test_blob_feeder_prefetch(dev):
         assert torch.equal(bk.raw.cpu(), pinned[t]), t
         ok, sizes = bk.check()
         assert ok and sizes["N"] == cpu[t].x.size(0)
+
+
+@pytest.mark.timeout(900)
+def test_stream_runner_matches_its_eager_twin_and_main_runs(dev, capsys):
+    """the product's own training loop (pretrain.main / train_epochs / StreamRunner -- the counterpart
+    of examples/pretrain_MoleculeSDE.py:106-175) drives the captured-graph + capacity-bucket + prefetch path.  (1) the
+    replayed loop and its eager twin (same bucket, same device-side plans, kernels launched from the host) give the same
+    per-epoch losses and the same parameters; (2) a contrastive skip epoch re-captures with the new coefficient; (3) main()
+    runs end to end and prints the reference's epoch report."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import pretrain
+    from moleculesde_amd.synthetic import make_batch
+    args = pretrain.readme_args(emb_dim=64, SDE_coeff_generative_3Dto2D=0, batch_size=12, epochs=2)
+    args.SDE_coeff_contrastive_skip_epochs = 1
+    args.output_model_dir = ""
+    cpu = [make_batch(12, seed=s) for s in range(201, 206)]
+    res = []
+    for replay in (True, False):
+        torch.manual_seed(11)
+        tr = pretrain.Trainer(args, dev)
+        for m in tr.models.values():
+            disable_dropout(m)
+        nz = _capturable_noise(G, dev, fixed_calls=True)          # the same draws whether a step is replayed or launched
+        tr.noise = nz
+        tr.models["SDE_2Dto3D_model"].noise = nz
+        runner = pretrain.StreamRunner(tr, cpu, n_max=24, replay=replay)
+        blobs = [runner.pack(b) for b in cpu]
+        assert all(b is not None for b in blobs)
+        hist = pretrain.train_epochs(args, tr, runner, lambda e: (blobs, 7), out=lambda *_: None)
+        torch.cuda.synchronize()
+        res.append((hist, tr.opt.flat_p.clone()))
+        from moleculesde_amd import hip
+        hip.clear_row_bounds()
+    (ha, pa), (hb, pb) = res
+    assert ha[0][0] == 0.0 and ha[1][0] > 0.0, "contrastive loss skipped in epoch 1, on in epoch 2"
+    for ea, eb in zip(ha, hb):
+        for x, y in zip(ea[:4], eb[:4]):
+            assert abs(x - y) <= 2e-5 * max(1.0, abs(y)), (ea, eb)
+    assert float((pa - pb).norm() / pb.norm()) < 1e-5
+    # (3) the command-line entry point, tiny configuration
+    out = pretrain.main(["--epochs", "1", "--steps_per_epoch", "5", "--batch_size", "8", "--emb_dim", "64", "--synthetic_pool", "3",
+                         "--SDE_2Dto3D_model", "SDEModel2Dto3D_02", "--CL_similarity_metric", "EBM_node_dot_prod",
+                         "--SDE_coeff_generative_3Dto2D", "0", "--dropout_ratio", "0"])
+    printed = capsys.readouterr().out
+    assert "epoch: 1" in printed and "SDE 2Dto3D Loss" in printed and len(out) == 1 and out[0][5] == 5
+    import math
+    assert all(math.isfinite(v) for v in out[0][:4])
