@@ -7,7 +7,9 @@ libmsde_hip.so -- csrc/dense_head.hip (per-molecule kernels) and csrc/gemm_ex.hi
 
 Layout (see csrc/dense_head.hip): atoms in batch order; pairs of molecule b at rows pair_ptr[b] + i*n_b + j.
   XC [N, F+64]   columns 0..F-1: x = embedding_3D(h) + embedding_X(perturbed one-hot) (:156); F..F+63: the four dense-GCN
-                 outputs of the node network -- i.e. exactly cat(x_list) of invariant_scorenetwork_dense.py:123-124
+                 outputs of the node network -- i.e. exactly cat(x_list) of invariant_scorenetwork_dense.py:123-124.
+                 SDEModel3Dto2D_node_adj_dense_02 (:326) concatenates the two embeddings instead: x is 2 F wide (XC
+                 [N, 2F+64]), the two embedding products write adjacent column blocks
   AC [P, 32]     columns 0-1 perturbed adjacency and its square, 2..29 the edge layers' outputs = the concatenation the
                  final pair MLP reads (:81-84)
 """
@@ -310,14 +312,23 @@ class _DenseHeadLosses(torch.autograd.Function):
                   _p(cfg.mol_ptr), _p(cfg.pair_ptr), _p(cfg.draws), _p(cfg.t_in), B, cfg.T, cfg.eps, cfg.sde_vp, cfg.p0,
                   cfg.p1, _p(cfg.noise_adj), _p(cfg.noise_x), cfg.nm_pad, cfg.seed, _p(cfg.seed_dev), cfg.ncls, cfg.n_max,
                   _p(AC), _p(z_adj), _p(flags), _p(mean_std), _p(px), _p(z_x), hip._stream())
-        XC = _empty(N, F + 64, device=dev)
-        # embedding_3D(h) + embedding_X(x) (:156).  Two launches, not one two-segment product: embedding_X's weight rows
-        # are 119 floats (not 16-byte aligned) and would put the big product on the scalar-load path too
-        hip.gemm_ex(h3, W3, XC[:, :F], bias=b3, bias2=bX)
-        hip.gemm_ex(px[:, :cfg.ncls], WX, XC[:, :F], accumulate=True)
+        # x = embedding_3D(h) + embedding_X(x) (:156), or for SDEModel3Dto2D_node_adj_dense_02 their CONCATENATION (:326): the
+        # second product then writes the next F columns of XC instead of accumulating into the first -- the score networks
+        # read a 2 F-wide x, nothing else changes.  FX = width of x.
+        concat = bool(getattr(cfg, "concat", False))
+        FX = 2 * F if concat else F
+        XC = _empty(N, FX + 64, device=dev)
+        # Two launches, not one two-segment product: embedding_X's weight rows are 119 floats (not 16-byte aligned) and would
+        # put the big product on the scalar-load path too
+        if concat:
+            hip.gemm_ex(h3, W3, XC[:, :F], bias=b3)
+            hip.gemm_ex(px[:, :cfg.ncls], WX, XC[:, F:FX], bias=bX)
+        else:
+            hip.gemm_ex(h3, W3, XC[:, :F], bias=b3, bias2=bX)
+            hip.gemm_ex(px[:, :cfg.ncls], WX, XC[:, :F], accumulate=True)
         chans, offs = cfg.chans, cfg.offs
-        se = edge_forward(cfg, XC[:, :F], AC, flags, chans, offs, TE)
-        sn = node_forward(cfg, XC, F, AC, TN)
+        se = edge_forward(cfg, XC[:, :FX], AC, flags, chans, offs, TE)
+        sn = node_forward(cfg, XC, FX, AC, TN)
         f2W, f2b = TE[-2], TE[-1]
         res_adj, res_x = _empty(P, device=dev), _empty(N, XP_LD, device=dev)
         part, out = _empty(B * 4, 2, device=dev), _empty(2, device=dev)      # MSDE_DENSE_LOSS_SPLITS partials per molecule
@@ -347,11 +358,14 @@ class _DenseHeadLosses(torch.autograd.Function):
         _lib.call("msde_dense_loss_bwd", _p(g_lx), _p(g_la), _p(res_adj), _p(res_x), _p(se.ZG2), se.ZG2.size(1), _p(TE[-2]), _p(flags),
                   _p(mean_std), _p(cfg.mol_ptr), _p(cfg.pair_ptr), B, cfg.ncls, cfg.anneal, cfg.scale_x, cfg.scale_adj,
                   _p(getattr(cfg, "nmax_dev", None)), _p(gS), _p(gZG2), _p(gOUT), hip._stream())
-        GN, gXC = node_backward(cfg, sn, XC, F, AC, TN, gOUT)
-        GE, _ = edge_backward(cfg, se, AC, flags, cfg.chans, cfg.offs, TE, gS, gZG2, gXC[:, :F], True)
-        gX = gXC[:, :F]
+        concat = bool(getattr(cfg, "concat", False))
+        FX = 2 * F if concat else F
+        GN, gXC = node_backward(cfg, sn, XC, FX, AC, TN, gOUT)
+        GE, _ = edge_backward(cfg, se, AC, flags, cfg.chans, cfg.offs, TE, gS, gZG2, gXC[:, :FX], True)
+        gX = gXC[:, :F]                                   # gradient of embedding_3D's output
+        gXx = gXC[:, F:FX] if concat else gX              # ... of embedding_X's (the same tensor when they were added)
         gW3, gb3 = hip.weight_grad(gX, h3, True)
-        gWX, gbX = hip.weight_grad(gX, px[:, :cfg.ncls], True)
+        gWX, gbX = hip.weight_grad(gXx, px[:, :cfg.ncls], True)
         g_h3 = None
         if ctx.needs_input_grad[1]:
             g_h3 = _empty(N, F, device=dev)

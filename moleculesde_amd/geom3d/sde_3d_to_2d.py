@@ -241,6 +241,7 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
             cfg.chans, cfg.offs = _dh.edge_net_shape(self.edge_score_network)
             dn._fused_cfg = cfg
         cfg.sde_vp = 1 if self.SDE_type == "VP" else 0
+        cfg.concat = bool(self.CONCAT_EMBEDDINGS)          # _02: embeddings concatenated (:326), 2 * dim3D-wide score networks
         cfg.p0, cfg.p1 = float(self.beta_min), float(self.beta_max)
         cfg.draws = cfg.t_in = cfg.noise_adj = cfg.noise_x = None
         cfg.nm_pad, cfg.seed, cfg.seed_dev = Nm, 0, None
@@ -279,7 +280,7 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
         device = node_3D_repr.device
         pl = _plan.get_plan(data)
         dn = _plan.dense_plan(pl, data)                                      # padded layout, built once per batch
-        if USE_FUSED_HEAD and not self.CONCAT_EMBEDDINGS and self.noise_on_one_hot and hasattr(pl, "bond_type") and \
+        if USE_FUSED_HEAD and self.noise_on_one_hot and hasattr(pl, "bond_type") and \
                 _dh.fused_supported(self.edge_score_network, self.node_score_network, dn.N_max):
             return self._forward_fused(node_3D_repr, data, reduce_mean, anneal_power, pl, dn)
         B, Nm, T = pl.B, dn.N_max, self.num_diffusion_timesteps
@@ -329,7 +330,8 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
 class SDEModel3Dto2D_node_adj_dense_02(SDEModel3Dto2D_node_adj_dense):
     """SDE_model_3D_to_2D_node_adj_dense.py:182-345: identical to the model above except that embedding_3D(h) and
     embedding_X(x) are CONCATENATED (:326) and both score networks take 2 * dim3D features (:223,233).  Same state_dict
-    keys.  Runs on the operator-by-operator kernel path (the single-node fused head covers the additive variant)."""
+    keys.  Runs on the same fused head (geom3d/dense_head.py): the second embedding product writes the next column block of the
+    node-feature buffer instead of accumulating into the first."""
     CONCAT_EMBEDDINGS = True
 
 

@@ -26,8 +26,10 @@ def main():
     E = 8
     b = make_batch(4, seed=11, sizes=[6, 3, 5, 4])
     torch.manual_seed(91)
-    m = mod.SDEModel3Dto2D_node_adj_dense_02(dim3D=E, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=8, nhid=8,
-                                             num_layers=3, emb_dim=E, num_linears=3, beta_min=0.1, beta_max=1.0,
+    # the score-network dimensions of every MoleculeSDE script (pretrain_MoleculeSDE.py:310-315: nhid = adim = 16, 4 layers,
+    # 3 linears, channels 2 | 8 | 8 | 8 -> 4): the configuration the fused head kernels implement, so the test runs THEM
+    m = mod.SDEModel3Dto2D_node_adj_dense_02(dim3D=E, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=16, nhid=16,
+                                             num_layers=4, emb_dim=E, num_linears=3, beta_min=0.1, beta_max=1.0,
                                              num_diffusion_timesteps=1000, SDE_type="VE", num_class_X=119,
                                              noise_on_one_hot=True)
     set_parameters(m, 4200)

@@ -483,8 +483,8 @@ def test_golden_f3_sde3d2d_02(dev):
     g = load_golden("f3_sde3d2d_02.npz")
     b = G.prepare_batch(batch_from(g), dev)
     E = g["h3"].shape[1]
-    m = G.SDEModel3Dto2D_node_adj_dense_02(dim3D=E, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=8, nhid=8,
-                                           num_layers=3, emb_dim=E, num_linears=3, beta_min=0.1, beta_max=1.0,
+    m = G.SDEModel3Dto2D_node_adj_dense_02(dim3D=E, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=16, nhid=16,
+                                           num_layers=4, emb_dim=E, num_linears=3, beta_min=0.1, beta_max=1.0,
                                            num_diffusion_timesteps=1000, SDE_type="VE", num_class_X=119,
                                            noise_on_one_hot=True)
     assert [k for k, _ in m.named_parameters()] == list(g["param_names"])
@@ -492,7 +492,10 @@ def test_golden_f3_sde3d2d_02(dev):
     m.to(dev).train()
     m.noise = G.CpuReplayNoise(int(g["seed"]))
     h3 = torch.from_numpy(g["h3"]).to(dev).requires_grad_(True)
+    from moleculesde_amd.geom3d import dense_head
+    calls = dense_head.FUSED_CALLS
     lx, la = m(h3, b, reduce_mean=True, continuous=True, train=True, anneal_power=0)
+    assert dense_head.FUSED_CALLS == calls + 1, "the fused head kernels (not the operator path) must have run"
     assert_close(lx, g["loss_x"], 1e-4, 1e-6, "loss_x")
     assert_close(la, g["loss_adj"], 1e-4, 1e-6, "loss_adj")
     (lx + la).backward()
@@ -993,15 +996,16 @@ def test_golden_dense_head_production_dims_genuine(dev, fused):
     _grads_close(node, sub(g, "node.grad."), 1e-3, 1e-4, "node net")
 
 
-def test_dense_head_launches_no_torch_operator(dev):
-    """zero ATen launches inside the head.  Every kernel of a fused forward + backward (device
+@pytest.mark.parametrize("variant", ["", "_02"])
+def test_dense_head_launches_no_torch_operator(dev, variant):
+    """zero ATen launches inside the head (r3: also for the concatenating variant _02).  Every kernel of a fused forward + backward (device
     noise) carries a name from libmsde_hip.so; nothing from at::native / rocBLAS / hipBLASLt / rocclr copy-fill."""
     import moleculesde_amd.geom3d as G
     from moleculesde_amd import hip, pretrain
     from moleculesde_amd.synthetic import make_batch
     from torch.profiler import profile, ProfilerActivity
     torch.manual_seed(3)
-    args = pretrain.readme_args(emb_dim=64)
+    args = pretrain.readme_args(emb_dim=64, SDE_3Dto2D_model="SDEModel3Dto2D_node_adj_dense" + variant)
     tr = pretrain.Trainer(args, dev)                      # FlatAdam lays the stacked parameters out back to back
     m = tr.models["SDE_3Dto2D_model"]
     m.noise = G.DeviceNoise(seed=11)
