@@ -44,15 +44,14 @@ int msde_radius_fill(const float* pos, const int* batch, const int* mol_ptr, int
                      void* stream);
 
 /* Row bounds: one captured hipGraph for batches of different sizes.  Tensors are allocated with row CAPACITIES (atoms,
- * bonds, extended edges, ... each padded to a distinct capacity); msde_set_row_bound(cap, dev_count) declares that every
- * tensor with exactly `cap` rows has only *dev_count valid leading rows.  Kernels that REDUCE over rows (BatchNorm
- * statistics, weight / bias gradients, column sums, the contrastive loss and its permutation, LayerNorm-parameter and
- * embedding-table gradients) then stop at the valid rows; row-wise kernels keep processing all `cap` rows (padded rows
- * hold finite values and zero gradients) and CSR walks never reach padded edges.  dev_count == NULL removes the bound.
- * The reference has no counterpart: PyG's collate rebuilds exact-size tensors on the host for every batch
- * (Geom3D/datasets/dataset_3D.py:114-122, App. A.8). */
-int msde_set_row_bound(int cap, const int* dev_count);
-int msde_clear_row_bounds(void);
+ * bonds, extended edges, ... padded); the TRUE row count of a batch stays on the device.  Every entry point that REDUCES
+ * over rows (BatchNorm statistics, weight / bias gradients, column sums, the contrastive loss and its permutation,
+ * LayerNorm-parameter and embedding / bond-table gradients, the statistics epilogues of msde_gemm_rs / msde_gemm_t2) takes
+ * the device address of that count as an explicit argument (`rows_dev`, `m_valid`, `n_dev` ...; NULL = all rows) and stops
+ * at the valid rows; row-wise kernels keep processing all rows (padded rows hold finite values and zero gradients) and CSR
+ * walks never reach padded edges.  The library keeps NO table and no other global mutable state: two buckets with equal
+ * capacities, or two threads, cannot interfere.  The reference has no counterpart: PyG's collate rebuilds exact-size
+ * tensors on the host for every batch (Geom3D/datasets/dataset_3D.py:114-122, App. A.8). */
 
 /* ------------------------------------------------------------------ batch construction on the GPU --- */
 /* Everything index-shaped a pretrain step needs, from the RAW collated arrays of a mini-batch, into buffers of fixed
@@ -67,7 +66,7 @@ int msde_clear_row_bounds(void);
  * the bond graph as CSR by target (b_rowptr [N_cap+1], b_src, b_dst [Eb_cap]; canonical order = stable sort by target)
  * with its by-source view (b_rowptr_s, b_perm_s) and canonical-order bond_codes [Eb_cap][3] / bond_type [Eb_cap], the
  * extended graph the same way (e_*, Ee_cap), and scratch ext_rows [N_cap] / ext_cnt [B] / ext_ptr [B+1].  Padded tails:
- * see msde_set_row_bound.  *err is set to 1 if a molecule exceeds the limits or the batch one of the capacities N_cap,
+ * see "Row bounds" above.  *err is set to 1 if a molecule exceeds the limits or the batch one of the capacities N_cap,
  * Eb_cap, Ee_cap, P_cap (atom pairs, sum n^2: rows of the dense head's pair arrays) or Er_cap (radius-edge bound sum
  * n * min(n - 1, max_nbr): pair / edge buffers of the CFConv); the batch is then cut in front of the first molecule that
  * does not fit (it and all later molecules count as empty), so every offset stays inside its buffer. */
@@ -211,14 +210,16 @@ int msde_gin_aggregate_bwd_x_stats(const float* g, const float* x, const float* 
 int msde_gin_aggregate_bwd_tab_slabs(int N, int E);
 int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab, const int* codes,
                                const int* src, const int* dst, int N, int E, int D, int R,
-                               float* g_tab, float* g_eps, float* workspace, void* stream);
+                               float* g_tab, float* g_eps, float* workspace, const int* n_dev, const int* e_dev,
+                               void* stream);
 
 /* the partial tables of `layers` <= 8 GIN layers over the SAME graph in ONE launch (g / x / tab / workspace: HOST arrays of
  * device pointers, each workspace as for msde_gin_aggregate_bwd_tab with g_tab == g_eps == NULL): independent leaf work that
  * would otherwise be `layers` launches in a row, each draining before the next starts. */
 int msde_gin_aggregate_bwd_tab_multi(const float* const* g, const float* const* x, const float* const* tab,
                                      float* const* workspace, int layers, const int* codes, const int* src,
-                                     const int* dst, int N, int E, int D, int R, void* stream);
+                                     const int* dst, int N, int E, int D, int R, const int* n_dev, const int* e_dev,
+                                     void* stream);
 
 /* ------------------------------------------------------------------ SchNet ----------------- */
 /* GaussianSmearing + cosine cutoff — schnet.py:186,205-207: rbf[e,g]=exp(coeff*(d-offset[g])^2),
@@ -334,7 +335,7 @@ int msde_linear_bwd_x(const float* gY, const float* W, int M, int N, int K, floa
  * `workspace` (msde_linear_bwd_w_workspace_bytes) that are summed in a fixed order: reproducible. */
 long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K);
 int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, float* gW, float* gb,
-                      float* workspace, void* stream);
+                      float* workspace, const int* rows_dev, void* stream);
 
 /* ------------------------------------------------------------------ general fused GEMM ------ */
 /* The dense products of the score networks with everything a library GEMM cannot fuse (csrc/gemm_ex.hip):
@@ -511,7 +512,7 @@ int msde_mlp_head_fwd(const float* Z, int ldz, const float* W, const float* b, i
                       void* stream);
 int msde_mlp_head_bwd_slabs(int E, int H);
 int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const float* g, int E, int H, int J, float* gZ, float* gWb,
-                      float* workspace, void* stream);
+                      float* workspace, const int* rows_dev, void* stream);
 
 /* ------------------------------------------------------------------ CFConv on unordered atom pairs -- */
 /* SchNet's interaction graph (schnet.py:91-93: radius_graph over the molecule, 32-neighbour cap) is symmetric whenever the
@@ -620,10 +621,10 @@ int msde_dense_loss_bwd(const float* g_lx, const float* g_la, const float* res_a
  * perm1/perm2: the two negative-sample permutations (torch.randperm).  out[0] = loss, out[1] = accuracy.
  * rows [N,3] (p, n1, n2 logits) and inv1/inv2 [N] (inverse permutations) feed the backward. */
 int msde_cl_ebm_fwd(const float* X, const float* Y, const int* perm1, const int* perm2, int N, int D,
-                    float invT, float* rows, int* inv1, int* inv2, float* out, void* stream);
+                    float invT, float* rows, int* inv1, int* inv2, float* out, const int* rows_dev, void* stream);
 int msde_cl_ebm_bwd(const float* X, const float* Y, const int* perm1, const int* perm2,
                     const int* inv1, const int* inv2, const float* rows, const float* g_loss, int N,
-                    int D, float invT, float* gX, float* gY, void* stream);
+                    int D, float invT, float* gX, float* gY, const int* rows_dev, void* stream);
 
 /* ------------------------------------------------------------------ normalisation ---------- */
 /* nn.BatchNorm1d in training mode over the rows of X[M,C], optional fused ReLU —
@@ -633,10 +634,10 @@ int msde_cl_ebm_bwd(const float* X, const float* Y, const int* perm1, const int*
 int msde_bn_workspace_floats(int M, int C);
 int msde_bn_fwd(const float* X, int M, int C, const float* gamma, const float* beta, float eps,
                 float momentum, float* running_mean, float* running_var, int relu, float* Y,
-                float* save_mean, float* save_rstd, float* workspace, void* stream);
+                float* save_mean, float* save_rstd, float* workspace, const int* rows_dev, void* stream);
 int msde_bn_bwd(const float* dY, const float* X, const float* save_mean, const float* save_rstd,
                 const float* gamma, const float* beta, int relu, int M, int C, float* dX,
-                float* dgamma, float* dbeta, float* workspace, void* stream);
+                float* dgamma, float* dbeta, float* workspace, const int* rows_dev, void* stream);
 
 /* y = res + LayerNorm(x) over rows of D floats (res may be NULL) — GATLayer, equivariant_scorenetwork.py:36,38.
  * mean/rstd [N] are saved for the backward.  D % 4 == 0, D <= 1024. */
@@ -651,7 +652,7 @@ int msde_res_layernorm_bwd(const float* g, const float* x, const float* gamma, c
 
 /* out[c] = sum_m X[m,c] (bias gradient of an nn.Linear when the vendor GEMM computes the weight
  * gradient); workspace: msde_bn_workspace_floats(M, C) floats; fixed summation order. */
-int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void* stream);
+int msde_colsum(const float* X, int M, int C, float* out, float* workspace, const int* rows_dev, void* stream);
 
 /* Batched weight gradients: msde_linear_bwd_w_partial runs only the split-M GEMM of msde_linear_bwd_w and
  * leaves slabs [splits][N*K] (+ bias partials [splits][N] when want_bias) in `slabs`
@@ -668,12 +669,12 @@ int msde_linear_bwd_w_splits(int M, int N, int K);
  * msde_linear_bwd_w_describe fills one HOST row (12 int64) of the problem table for a layer and returns the
  * number of workgroups it needs; prefix[p] = workgroups before problem p, prefix[count] = total_blocks. */
 int msde_linear_bwd_w_describe(const float* gY, const float* X, int M, int N, int K, int want_bias,
-                               float* slabs, long long* host_row);
+                               float* slabs, const int* rows_dev, long long* host_row);
 /* the same for operands that are column blocks of wider buffers: ldg / ldx = row strides of gY / X (floats).
  * Every table row is MSDE_WGRAD_ROW int64 wide. */
 #define MSDE_WGRAD_ROW 16
 int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const float* X, int ldx, int M, int N, int K,
-                                  int want_bias, float* slabs, long long* row);
+                                  int want_bias, float* slabs, const int* rows_dev, long long* row);
 int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
                               void* stream);
 /* the same launch limited to `max_workgroups` resident workgroups (0 = one per tile): each walks several tiles, so the
@@ -681,7 +682,7 @@ int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int cou
 int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* prefix, int count, int total_blocks,
                                  int max_workgroups, void* stream);
 int msde_linear_bwd_w_partial(const float* gY, const float* X, int M, int N, int K, int want_bias,
-                              float* slabs, void* stream);
+                              float* slabs, const int* rows_dev, void* stream);
 int msde_reduce_slabs_multi(const long long* rows, const int* prefix, int count, int total_chunks,
                             void* stream);
 /* chunks (= workgroups) a row of n entries x `splits` slabs takes in msde_reduce_slabs_multi's prefix table: 256
@@ -709,7 +710,7 @@ int msde_mul_add_bwd(const float* g, const float* a, const float* b, long long n
  * out[count][n] int32, `count` independent uniform shuffles in one launch (dual_CL draws two) from the
  * counter-based generator (seed [+ seed_dev[0]*FNV], permutation number, index). */
 int msde_randperm(int n, int count, unsigned long long seed, const unsigned long long* seed_dev, int* out,
-                  void* stream);
+                  const int* rows_dev, void* stream);
 /* VE perturbation (SDE_model_2D_to_3D.py:401-412, SDE_sparse.py VESDE.marginal_prob): draws [B/2+1] int64 in
  * [0,T); molecule b uses ts = draws[b] (b < B/2+1) or T - draws[b-(B/2+1)] - 1; t = ts/T*(1-eps)+eps;
  * std_out[i] = sigma_min (sigma_max/sigma_min)^t of atom i's molecule; pos_out = pos + std * noise. */
@@ -748,7 +749,7 @@ int msde_gat_tail_bwd(const float* g_out, const float* x, const float* y1, const
                       const float* ln2_g, const float* ln2_b, int N, int D, float eps1, float eps2,
                       float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
                       int silu_out, float* g_x, float* g_res, float* g_x2, float* a, float* g_h0,
-                      float* ln_part, void* stream);
+                      float* ln_part, const int* rows_dev, void* stream);
 
 /* ------------------------------------------------------------------ optimiser -------------- */
 /* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —

@@ -26,7 +26,7 @@ SIGNATURES = {
     "msde_pair_gather_cat": [P, I, P, I, P, P, I, I, I, P, P],
     "msde_mlp_head_fwd": [P, I, P, P, I, I, I, P, P],
     "msde_mlp_head_bwd_slabs": [I, I],
-    "msde_mlp_head_bwd": [P, I, P, P, I, I, I, P, P, P, P],
+    "msde_mlp_head_bwd": [P, I, P, P, I, I, I, P, P, P, P, P],
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
     "msde_radius_transpose": [P, P, P, P, I, I, P, P, P, P],
@@ -37,8 +37,8 @@ SIGNATURES = {
     "msde_gin_aggregate_bn_fwd": [P, P, P, I, P, P, P, P, P, I, I, P, P, P],
     "msde_gin_aggregate_bwd_x_stats": [P, P, P, P, P, P, P, P, I, P, I, P, P, I, P, P, P],
     "msde_gin_aggregate_bwd_tab_workspace_floats": [I, I, I, I],
-    "msde_gin_aggregate_bwd_tab": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],
-    "msde_gin_aggregate_bwd_tab_multi": [P, P, P, P, I, P, P, P, I, I, I, I, P],
+    "msde_gin_aggregate_bwd_tab": [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P, P],
+    "msde_gin_aggregate_bwd_tab_multi": [P, P, P, P, I, P, P, P, I, I, I, I, P, P, P],
     "msde_rbf_cutoff_fwd": [P, P, I, I, P, F, F, P, P, P],
     "msde_cfconv_aggregate_fwd": [P, P, P, P, P, I, I, P, P],
     "msde_cfconv_aggregate_bwd_w": [P, P, P, P, P, I, I, I, P, P],
@@ -63,14 +63,14 @@ SIGNATURES = {
     "msde_linear_bwd_x": [P, P, I, I, I, P, P],
     "msde_linear_bwd_w_workspace_bytes": [I, I, I],
     "msde_linear_bwd_w_splits": [I, I, I],
-    "msde_linear_bwd_w_describe": [P, P, I, I, I, I, P, P],
-    "msde_linear_bwd_w_describe_ld": [P, I, P, I, I, I, I, I, P, P],
+    "msde_linear_bwd_w_describe": [P, P, I, I, I, I, P, P, P],
+    "msde_linear_bwd_w_describe_ld": [P, I, P, I, I, I, I, I, P, P, P],
     "msde_linear_bwd_w_grouped": [P, P, I, I, P],
     "msde_linear_bwd_w_grouped_ex": [P, P, I, I, I, P],
-    "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P],
+    "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_reduce_slabs_chunks": [LL, I],
-    "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P],
+    "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P, P],
     "msde_gemm_ex": [P, P],
     "msde_gemm_rs": [P, P],
     "msde_gemm_chain": [P, P],
@@ -111,16 +111,14 @@ SIGNATURES = {
     "msde_combine_losses": [P, P, P, P, F, F, F, F, P, P],
     "msde_combine_losses_bwd": [P, F, F, F, F, P, P],
     "msde_combine_losses_ex": [P, P, P, P, F, F, F, F, P, P, P, P, I, P],
-    "msde_set_row_bound": [I, P],
-    "msde_clear_row_bounds": [],
-    "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P],
-    "msde_cl_ebm_bwd": [P, P, P, P, P, P, P, P, I, I, F, P, P, P],
+    "msde_cl_ebm_fwd": [P, P, P, P, I, I, F, P, P, P, P, P, P],
+    "msde_cl_ebm_bwd": [P, P, P, P, P, P, P, P, I, I, F, P, P, P, P],
     "msde_bn_workspace_floats": [I, I],
-    "msde_colsum": [P, I, I, P, P, P],
+    "msde_colsum": [P, I, I, P, P, P, P],
     "msde_res_layernorm_fwd": [P, P, P, P, I, I, F, P, P, P, P],
     "msde_res_layernorm_bwd": [P, P, P, P, P, I, I, P, P, P, P, P],
-    "msde_bn_fwd": [P, I, I, P, P, F, F, P, P, I, P, P, P, P, P],
-    "msde_bn_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P],
+    "msde_bn_fwd": [P, I, I, P, P, F, F, P, P, I, P, P, P, P, P, P],
+    "msde_bn_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P, P, P],
     "msde_adam_flat": [P, P, P, P, LL, P, P, P, I, F, F, F, F, F, P],
     "msde_ssp_fwd": [P, LL, P, P],
     "msde_ssp_bwd": [P, P, LL, P, P],
@@ -128,14 +126,14 @@ SIGNATURES = {
     "msde_silu_dropout_bwd": [P, P, LL, F, ULL, P, P, P],
     "msde_mul_add_fwd": [P, P, P, LL, P, P],
     "msde_mul_add_bwd": [P, P, P, LL, P, P, P],
-    "msde_randperm": [I, I, ULL, P, P, P],
+    "msde_randperm": [I, I, ULL, P, P, P, P],
     "msde_ve_perturb": [P, P, P, P, I, I, I, F, F, F, P, P, P],
     "msde_ve_perturb_rng": [P, P, I, I, I, F, F, F, ULL, P, P, P, P, P],
     "msde_ve_pos_loss_fwd": [P, P, P, F, P, I, I, P, P, P],
     "msde_ve_pos_loss_bwd": [P, P, P, F, P, P, I, I, P, P, P],
     "msde_gat_tail_blocks": [I],
     "msde_gat_tail_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P],
-    "msde_gat_tail_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P, P, P],
+    "msde_gat_tail_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P, P, P, P],
     "msde_chunk_elems": [],
     "msde_gather_chunks": [P, I, P, P],
     "msde_adam_chunks": [P, P, I, P, P, P, P, P, I, F, F, F, F, F, P],

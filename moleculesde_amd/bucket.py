@@ -231,11 +231,16 @@ class Bucket:
         self._err_event.record()
         return seen
 
-    def activate(self):
-        """Declare the bucket's row bounds (process wide: one bucket is active at a time)."""
+    def bounds_map(self):
+        """{row capacity: device count} of this bucket's tensors (hip.row_bounds): atoms, bonds, extended edges, atom pairs,
+        and the two-rows-per-extended-edge tensors of the 2D->3D model."""
         c = self.caps
-        hip.set_row_bounds({c.N: self.sizes[0:1], c.E_b: self.sizes[1:2], c.E_e: self.sizes[2:3], c.P: self.sizes[3:4],
-                            2 * c.E_e: self.sizes[6:7]}, owner=self)
+        return {c.N: self.sizes[0:1], c.E_b: self.sizes[1:2], c.E_e: self.sizes[2:3], c.P: self.sizes[3:4],
+                2 * c.E_e: self.sizes[6:7]}
+
+    def bounds(self):
+        """`with bucket.bounds():` -- the scope in which steps on this bucket's batch are launched or captured."""
+        return hip.row_bounds(self.bounds_map())
 
     def check(self):
         """Host-side validation (synchronises): the loaded batch fitted the capacities."""

@@ -113,9 +113,10 @@ __global__ void cl_bwd_kernel(const float* __restrict__ X, const float* __restri
 }
 
 extern "C" int msde_cl_ebm_fwd(const float* X, const float* Y, const int* perm1, const int* perm2, int N, int D,
-                               float invT, float* rows, int* inv1, int* inv2, float* out, void* stream) {
+                               float invT, float* rows, int* inv1, int* inv2, float* out, const int* rows_dev,
+                               void* stream) {
   if (N <= 0 || D <= 0 || !X || !Y || !perm1 || !perm2 || !rows || !inv1 || !inv2 || !out) return MSDE_EINVAL;
-  const int* ndev = msde_row_bound(N);
+  const int* ndev = rows_dev;
   LAUNCH_ROWS(cl_rows_kernel, N, D, X, Y, perm1, perm2, N, ndev, cols, tpr, invT, rows, inv1, inv2);
   MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(cl_reduce_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (const float*)rows, N, ndev, out);
@@ -125,10 +126,10 @@ extern "C" int msde_cl_ebm_fwd(const float* X, const float* Y, const int* perm1,
 
 extern "C" int msde_cl_ebm_bwd(const float* X, const float* Y, const int* perm1, const int* perm2, const int* inv1,
                                const int* inv2, const float* rows, const float* g_loss, int N, int D, float invT,
-                               float* gX, float* gY, void* stream) {
+                               float* gX, float* gY, const int* rows_dev, void* stream) {
   if (N <= 0 || D <= 0 || !X || !Y || !perm1 || !perm2 || !inv1 || !inv2 || !rows || !g_loss || !gX || !gY)
     return MSDE_EINVAL;
-  LAUNCH_ROWS(cl_bwd_kernel, N, D, X, Y, perm1, perm2, inv1, inv2, rows, g_loss, N, msde_row_bound(N), cols, tpr, invT,
+  LAUNCH_ROWS(cl_bwd_kernel, N, D, X, Y, perm1, perm2, inv1, inv2, rows, g_loss, N, rows_dev, cols, tpr, invT,
               gX, gY);
   MSDE_CHECK_LAUNCH();
   return 0;

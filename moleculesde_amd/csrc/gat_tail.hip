@@ -283,7 +283,8 @@ extern "C" int msde_gat_tail_bwd(const float* g_out, const float* x, const float
                                  const float* ln1_g, const float* W0, const float* W3, const float* ln2_g,
                                  const float* ln2_b, int N, int D, float eps1, float eps2, float p_drop,
                                  unsigned long long seed, const unsigned long long* seed_dev, int silu_out, float* g_x,
-                                 float* g_res, float* g_x2, float* a, float* g_h0, float* ln_part, void* stream) {
+                                 float* g_res, float* g_x2, float* a, float* g_h0, float* ln_part, const int* rows_dev,
+                                 void* stream) {
   if (N < 0 || !g_out || !x || !y1 || !h0 || !x2 || !ln1_g || !W0 || !W3 || !ln2_g || !ln2_b || !g_x || !g_res || !g_x2 ||
       !a || !g_h0 || !ln_part)
     return MSDE_EINVAL;
@@ -291,7 +292,7 @@ extern "C" int msde_gat_tail_bwd(const float* g_out, const float* x, const float
   if (D != 32) return MSDE_EUNSUP;
   if (N == 0) return 0;
   MSDE_LAUNCH(gat_tail_bwd_kernel<32>, dim3(msde_gat_tail_blocks(N)), dim3(GT_THREADS), 0, as_stream(stream), g_out, x, y1,
-              h0, x2, ln1_g, W0, W3, ln2_g, ln2_b, N, msde_row_bound(N), eps1, eps2, p_drop, seed, seed_dev, silu_out, g_x, g_res, g_x2,
+              h0, x2, ln1_g, W0, W3, ln2_g, ln2_b, N, rows_dev, eps1, eps2, p_drop, seed, seed_dev, silu_out, g_x, g_res, g_x2,
               a, g_h0,
               ln_part);
   MSDE_CHECK_LAUNCH();

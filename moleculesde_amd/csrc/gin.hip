@@ -337,7 +337,7 @@ extern "C" long long msde_gin_aggregate_bwd_tab_workspace_floats(int N, int E, i
 }
 
 static int gt_launch(const gt_layers& L, int layers, const int* codes, const int* src, const int* dst, int N, int E, int D,
-                     int R, hipStream_t st) {
+                     int R, const int* n_dev, const int* e_dev, hipStream_t st) {
   int threads = ((D + 63) / 64) * 64;
   if (threads > 512) threads = 512;
   size_t lds = (2 * (size_t)R * D + 8) * sizeof(float);
@@ -345,14 +345,15 @@ static int gt_launch(const gt_layers& L, int layers, const int* codes, const int
   int nb = gt_blocks(N, E);
   int npb = (N + nb - 1) / nb;
   MSDE_LAUNCH(gin_aggregate_bwd_tab_kernel, dim3(nb * layers), dim3(threads), lds, st, L, nb, codes, src, dst, N, E,
-              msde_row_bound(N), msde_row_bound(E), D, R, npb, gt_ec());
+              n_dev, e_dev, D, R, npb, gt_ec());
   MSDE_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const float* tab, const int* codes,
                                           const int* src, const int* dst, int N, int E, int D, int R, float* g_tab,
-                                          float* g_eps, float* workspace, void* stream) {
+                                          float* g_eps, float* workspace, const int* n_dev, const int* e_dev,
+                                          void* stream) {
   // g_tab == g_eps == NULL: leave the per-workgroup partial tables in `workspace` for a batched reduction
   const bool no_reduce = !g_tab && !g_eps;
   if (N < 0 || E < 0 || D <= 0 || R <= 0 || !g || !x || !tab || !workspace || (!no_reduce && (!g_tab || !g_eps)))
@@ -361,7 +362,7 @@ extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const 
   hipStream_t st = as_stream(stream);
   gt_layers L = {};
   L.g[0] = g; L.x[0] = x; L.tab[0] = tab; L.ws[0] = workspace;
-  int rc = gt_launch(L, 1, codes, src, dst, N, E, D, R, st);
+  int rc = gt_launch(L, 1, codes, src, dst, N, E, D, R, n_dev, e_dev, st);
   if (rc) return rc;
   if (no_reduce) return 0;
   int nb = gt_blocks(N, E);
@@ -374,7 +375,8 @@ extern "C" int msde_gin_aggregate_bwd_tab(const float* g, const float* x, const 
 // `layers` device pointers; each workspace as for msde_gin_aggregate_bwd_tab with g_tab == g_eps == NULL.
 extern "C" int msde_gin_aggregate_bwd_tab_multi(const float* const* g, const float* const* x, const float* const* tab,
                                                 float* const* workspace, int layers, const int* codes, const int* src,
-                                                const int* dst, int N, int E, int D, int R, void* stream) {
+                                                const int* dst, int N, int E, int D, int R, const int* n_dev,
+                                                const int* e_dev, void* stream) {
   if (layers < 1 || layers > GT_MAX_LAYERS || N < 0 || E < 0 || D <= 0 || R <= 0 || !g || !x || !tab || !workspace)
     return MSDE_EINVAL;
   if (E > 0 && (!codes || !src || !dst)) return MSDE_EINVAL;
@@ -383,5 +385,5 @@ extern "C" int msde_gin_aggregate_bwd_tab_multi(const float* const* g, const flo
     if (!g[l] || !x[l] || !tab[l] || !workspace[l]) return MSDE_EINVAL;
     L.g[l] = g[l]; L.x[l] = x[l]; L.tab[l] = tab[l]; L.ws[l] = workspace[l];
   }
-  return gt_launch(L, layers, codes, src, dst, N, E, D, R, as_stream(stream));
+  return gt_launch(L, layers, codes, src, dst, N, E, D, R, n_dev, e_dev, as_stream(stream));
 }

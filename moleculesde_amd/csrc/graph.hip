@@ -527,43 +527,6 @@ extern "C" int msde_abi_version(void) { return 1; }
 extern "C" const char* msde_target_arch(void) { return "gfx950"; }
 
 
-// ------------------------------------------------------------------------------------------------
-// Row bounds: see msde_common.h / include/msde_hip.h.  A small process-wide table, written by the host between steps
-// (the trainer sets it when it loads a batch bucket), read by the launchers.
-#define MSDE_MAX_BOUNDS 32
-static int g_bound_cap[MSDE_MAX_BOUNDS];
-static const int* g_bound_ptr[MSDE_MAX_BOUNDS];
-static int g_bound_n = 0;
-
-const int* msde_row_bound(int cap) {
-  for (int i = 0; i < g_bound_n; ++i)
-    if (g_bound_cap[i] == cap) return g_bound_ptr[i];
-  return nullptr;
-}
-
-extern "C" int msde_set_row_bound(int cap, const int* dev_count) {
-  if (cap <= 0) return MSDE_EINVAL;
-  for (int i = 0; i < g_bound_n; ++i)
-    if (g_bound_cap[i] == cap) {
-      if (dev_count) { g_bound_ptr[i] = dev_count; return 0; }
-      g_bound_cap[i] = g_bound_cap[g_bound_n - 1];
-      g_bound_ptr[i] = g_bound_ptr[g_bound_n - 1];
-      --g_bound_n;
-      return 0;
-    }
-  if (!dev_count) return 0;
-  if (g_bound_n >= MSDE_MAX_BOUNDS) return MSDE_EUNSUP;
-  g_bound_cap[g_bound_n] = cap;
-  g_bound_ptr[g_bound_n] = dev_count;
-  ++g_bound_n;
-  return 0;
-}
-
-extern "C" int msde_clear_row_bounds(void) {
-  g_bound_n = 0;
-  return 0;
-}
-
 // ---- diagnostics: a device timestamp on a stream (tools/probes/step_timeline.py).  One thread stores the 100 MHz
 // real-time counter; captured into the step's hipGraph it gives an undistorted timeline of the replay (rocprofv3's
 // kernel trace slows every dispatch and serialises the two queues of the step).

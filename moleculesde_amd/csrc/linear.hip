@@ -420,9 +420,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 template <int TM, int TN, bool A_KM, bool B_KM>
 static void launch_cfg(bool vec, dim3 grid, hipStream_t st, const float* A, const float* B, const float* bias, float* C,
-                       float* colsum_ws, int M, int N, int K, int lda, int ldb, int ldc, int k_per_split) {
-  // weight gradients reduce over the rows of both operands: honour a row bound on that extent
-  const int* kdev = (A_KM && B_KM) ? msde_row_bound(K) : nullptr;
+                       float* colsum_ws, int M, int N, int K, int lda, int ldb, int ldc, int k_per_split, const int* kdev) {
+  // (kdev: weight gradients reduce over the rows of both operands and honour a row bound on that extent)
   if (vec)
     MSDE_LAUNCH((gemm_f32_mfma_kernel<TM, TN, A_KM, B_KM, true>), grid, dim3(256), 0, st, A, B, bias, C, colsum_ws, M, N,
                 K, lda, ldb, ldc, k_per_split, kdev);
@@ -435,7 +434,8 @@ static void launch_cfg(bool vec, dim3 grid, hipStream_t st, const float* A, cons
 // whenever the dimension exceeds 64 (weight gradient: parallelism comes from the M split instead).
 template <bool A_KM, bool B_KM>
 static int launch_gemm(const float* A, const float* B, const float* bias, float* C, float* colsum_ws, int M, int N,
-                       int K, int lda, int ldb, int ldc, int splits, int k_per_split, bool big, hipStream_t st) {
+                       int K, int lda, int ldb, int ldc, int splits, int k_per_split, bool big, hipStream_t st,
+                       const int* kdev = nullptr) {
   // vector path: 16-B aligned bases, leading dimensions % 4, and the contiguous extent of each operand % 4
   bool vec = aligned16(A) && aligned16(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (k_per_split % 4 == 0);
   vec = vec && ((A_KM ? M : K) % 4 == 0) && ((B_KM ? N : K) % 4 == 0);
@@ -451,7 +451,7 @@ static int launch_gemm(const float* A, const float* B, const float* bias, float*
     else { tm = 1; tn = 1; }
   }
   dim3 grid((N + 64 * tn - 1) / (64 * tn), (M + 64 * tm - 1) / (64 * tm), splits);
-#define LG_ARGS vec, grid, st, A, B, bias, C, colsum_ws, M, N, K, lda, ldb, ldc, k_per_split
+#define LG_ARGS vec, grid, st, A, B, bias, C, colsum_ws, M, N, K, lda, ldb, ldc, k_per_split, kdev
   if (tm == 2 && tn == 2) launch_cfg<2, 2, A_KM, B_KM>(LG_ARGS);
   else if (tm == 2 && tn == 1) launch_cfg<2, 1, A_KM, B_KM>(LG_ARGS);
   else if (tm == 1 && tn == 2) launch_cfg<1, 2, A_KM, B_KM>(LG_ARGS);
@@ -634,12 +634,12 @@ extern "C" int msde_reduce_slabs_multi(const long long* rows, const int* prefix,
 // Fills one row of the grouped-GEMM problem table (host memory, 12 int64) and returns the number of workgroups
 // the problem needs (<= 0: error).  want_bias: the bias partials follow the weight slabs in `slabs`.
 extern "C" int msde_linear_bwd_w_describe(const float* gY, const float* X, int M, int N, int K, int want_bias,
-                                          float* slabs, long long* row) {
-  return msde_linear_bwd_w_describe_ld(gY, N, X, K, M, N, K, want_bias, slabs, row);
+                                          float* slabs, const int* rows_dev, long long* row) {
+  return msde_linear_bwd_w_describe_ld(gY, N, X, K, M, N, K, want_bias, slabs, rows_dev, row);
 }
 
 extern "C" int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const float* X, int ldx, int M, int N, int K,
-                                             int want_bias, float* slabs, long long* row) {
+                                             int want_bias, float* slabs, const int* rows_dev, long long* row) {
   if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs || !row || ldg < N || ldx < K) return MSDE_EINVAL;
   if (wgrad_big(M, N, K)) return MSDE_EUNSUP;        // the grouped kernel is built for 64 x 64 tiles
   int splits, kps;
@@ -647,7 +647,7 @@ extern "C" int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const flo
   int tx = (K + 63) / 64, ty = (N + 63) / 64;
   bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (kps % 4 == 0) && (ldg % 4 == 0) &&
              (ldx % 4 == 0);
-  row[12] = ldg; row[13] = ldx; row[14] = reinterpret_cast<long long>(msde_row_bound(M)); row[15] = 0;
+  row[12] = ldg; row[13] = ldx; row[14] = reinterpret_cast<long long>(rows_dev); row[15] = 0;
   row[0] = reinterpret_cast<long long>(gY);
   row[1] = reinterpret_cast<long long>(X);
   row[2] = reinterpret_cast<long long>(slabs);
@@ -682,17 +682,17 @@ extern "C" int msde_linear_bwd_w_splits(int M, int N, int K) {
 // GEMM half of msde_linear_bwd_w: slabs [splits][N*K] followed (when want_bias) by the bias partials
 // [splits][N]; sum them with msde_reduce_slabs_multi (or msde_linear_bwd_w does both).
 extern "C" int msde_linear_bwd_w_partial(const float* gY, const float* X, int M, int N, int K, int want_bias,
-                                         float* slabs, void* stream) {
+                                         float* slabs, const int* rows_dev, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs) return MSDE_EINVAL;
   int splits, k_per_split;
   wgrad_split_batched(M, N, K, &splits, &k_per_split);
   float* cs = want_bias ? slabs + (size_t)splits * N * K : nullptr;
   return launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, wgrad_big(M, N, K),
-                                 as_stream(stream));
+                                 as_stream(stream), rows_dev);
 }
 
 extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, int K, float* gW, float* gb,
-                                 float* workspace, void* stream) {
+                                 float* workspace, const int* rows_dev, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !gY || !X || !gW || !workspace) return MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
   int splits, k_per_split;
@@ -705,7 +705,7 @@ extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, 
     return (int)e;
   }
   // C[N,K] = A^T B with A = gY [M][N] (k-major, "M" of the product = N), B = X [M][K] (k-major)
-  int rc = launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, wgrad_big(M, N, K), st);
+  int rc = launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, wgrad_big(M, N, K), st, rows_dev);
   if (rc != 0) return rc;
   return msde_reduce_slabs(slabs, splits, (size_t)N * K, gW, cs, (size_t)N, gb, st);
 }

@@ -27,10 +27,10 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 int msde_reduce_slabs(const float* slabs, int splits, size_t n, float* out, const float* cs, size_t nb, float* outb,
                       hipStream_t st);
 
-// Row bounds (msde_set_row_bound, include/msde_hip.h): device address of the TRUE row count of tensors whose row
-// capacity is exactly `cap`, or nullptr.  Every kernel that reduces over rows clamps its row range with it, so one
-// captured hipGraph serves batches of different sizes padded to the same capacities.  (Defined in graph.hip.)
-const int* msde_row_bound(int cap);
+// Row bounds: kernels that REDUCE over rows take the device address of the TRUE row count of their operand (`rows_dev`,
+// NULL = all rows) and clamp their row range with it, so one captured hipGraph serves batches of different sizes padded to
+// the same capacities (include/msde_hip.h, "Row bounds").  The pointer is an explicit argument of every such entry point:
+// the library holds no table, no global state.
 __device__ __forceinline__ int msde_true_rows(int cap, const int* __restrict__ dev) {
   return dev ? min(cap, dev[0]) : cap;
 }

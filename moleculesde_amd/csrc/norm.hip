@@ -351,13 +351,13 @@ colsum_final_kernel(const float* __restrict__ ws, int splits, int C, float* __re
   if (ty == 0 && c < C) out[c] = ((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx];
 }
 
-extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* workspace, void* stream) {
+extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* workspace, const int* rows_dev, void* stream) {
   if (M < 0 || C <= 0 || !X || !out || !workspace) return MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
   if (M == 0) return (int)hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
   int splits, rows;
   bn_geometry(M, &splits, &rows);
-  MSDE_LAUNCH(colsum_partial_kernel, dim3((C + BN_COLS - 1) / BN_COLS, splits), dim3(256), 0, st, X, M, msde_row_bound(M), C, rows,
+  MSDE_LAUNCH(colsum_partial_kernel, dim3((C + BN_COLS - 1) / BN_COLS, splits), dim3(256), 0, st, X, M, rows_dev, C, rows,
               workspace);
   MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(colsum_final_kernel, dim3((C + BN_COLS - 1) / BN_COLS), dim3(256), 0, st, (const float*)workspace, splits, C,
@@ -376,19 +376,19 @@ extern "C" int msde_bn_workspace_floats(int M, int C) {
 
 extern "C" int msde_bn_fwd(const float* X, int M, int C, const float* gamma, const float* beta, float eps,
                            float momentum, float* running_mean, float* running_var, int relu, float* Y,
-                           float* save_mean, float* save_rstd, float* workspace, void* stream) {
+                           float* save_mean, float* save_rstd, float* workspace, const int* rows_dev, void* stream) {
   if (M <= 0 || C <= 0 || !X || !Y || !save_mean || !save_rstd || !workspace) return MSDE_EINVAL;
   int splits, rows;
   bn_geometry(M, &splits, &rows);
   dim3 grid((C + BN_COLS - 1) / BN_COLS, splits);
   const bool vec = (C % 4 == 0) && bn_aligned16(X) && bn_aligned16(Y);
   if (vec) {
-    MSDE_LAUNCH(bn_stats_partial_kernel<4>, grid, dim3(256), 0, as_stream(stream), X, M, msde_row_bound(M), C, rows, workspace);
+    MSDE_LAUNCH(bn_stats_partial_kernel<4>, grid, dim3(256), 0, as_stream(stream), X, M, rows_dev, C, rows, workspace);
     MSDE_CHECK_LAUNCH();
     MSDE_LAUNCH(bn_fwd_apply_kernel<4>, grid, dim3(256), 0, as_stream(stream), X, (const float*)workspace, M, C, splits,
                 rows, gamma, beta, eps, momentum, running_mean, running_var, relu, Y, save_mean, save_rstd);
   } else {
-    MSDE_LAUNCH(bn_stats_partial_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, M, msde_row_bound(M), C, rows, workspace);
+    MSDE_LAUNCH(bn_stats_partial_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, M, rows_dev, C, rows, workspace);
     MSDE_CHECK_LAUNCH();
     MSDE_LAUNCH(bn_fwd_apply_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, (const float*)workspace, M, C, splits,
                 rows, gamma, beta, eps, momentum, running_mean, running_var, relu, Y, save_mean, save_rstd);
@@ -399,7 +399,7 @@ extern "C" int msde_bn_fwd(const float* X, int M, int C, const float* gamma, con
 
 extern "C" int msde_bn_bwd(const float* dY, const float* X, const float* save_mean, const float* save_rstd,
                            const float* gamma, const float* beta, int relu, int M, int C, float* dX, float* dgamma,
-                           float* dbeta, float* workspace, void* stream) {
+                           float* dbeta, float* workspace, const int* rows_dev, void* stream) {
   if (M <= 0 || C <= 0 || !dY || !X || !save_mean || !save_rstd || !dX || !workspace) return MSDE_EINVAL;
   int splits, rows;
   bn_geometry(M, &splits, &rows);
@@ -407,16 +407,16 @@ extern "C" int msde_bn_bwd(const float* dY, const float* X, const float* save_me
   const bool vec = (C % 4 == 0) && bn_aligned16(X) && bn_aligned16(dY) && bn_aligned16(dX);
   if (vec) {
     MSDE_LAUNCH(bn_bwd_partial_kernel<4>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
-                relu, M, msde_row_bound(M), C, rows, workspace);
+                relu, M, rows_dev, C, rows, workspace);
     MSDE_CHECK_LAUNCH();
     MSDE_LAUNCH(bn_bwd_apply_kernel<4>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
-                relu, (const float*)workspace, M, msde_row_bound(M), C, splits, rows, dX, dgamma, dbeta);
+                relu, (const float*)workspace, M, rows_dev, C, splits, rows, dX, dgamma, dbeta);
   } else {
     MSDE_LAUNCH(bn_bwd_partial_kernel<1>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
-                relu, M, msde_row_bound(M), C, rows, workspace);
+                relu, M, rows_dev, C, rows, workspace);
     MSDE_CHECK_LAUNCH();
     MSDE_LAUNCH(bn_bwd_apply_kernel<1>, grid, dim3(256), 0, as_stream(stream), dY, X, save_mean, save_rstd, gamma, beta,
-                relu, (const float*)workspace, M, msde_row_bound(M), C, splits, rows, dX, dgamma, dbeta);
+                relu, (const float*)workspace, M, rows_dev, C, splits, rows, dX, dgamma, dbeta);
   }
   MSDE_CHECK_LAUNCH();
   return 0;

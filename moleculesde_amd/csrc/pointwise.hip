@@ -252,12 +252,12 @@ randperm_kernel(int n, const int* __restrict__ ndev, unsigned long long seed,
 }
 
 extern "C" int msde_randperm(int n, int count, unsigned long long seed, const unsigned long long* seed_dev, int* out,
-                             void* stream) {
+                             const int* rows_dev, void* stream) {
   if (n < 0 || count < 0 || !out) return MSDE_EINVAL;
   if (n > RP_MAX) return MSDE_EUNSUP;
   if (n == 0 || count == 0) return 0;
   MSDE_LAUNCH(randperm_kernel, dim3((n + RP_BLOCK / 4 - 1) / (RP_BLOCK / 4), count), dim3(RP_BLOCK), 0, as_stream(stream), n,
-              msde_row_bound(n), seed, seed_dev, out);
+              rows_dev, seed, seed_dev, out);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -530,7 +530,7 @@ extern "C" int msde_mlp_head_fwd(const float* Z, int ldz, const float* W, const 
 extern "C" int msde_mlp_head_bwd_slabs(int E, int H) { return mh_grid(E, pick_tpr(H / 4)); }
 
 extern "C" int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const float* g, int E, int H, int J, float* gZ,
-                                 float* gWb, float* workspace, void* stream) {
+                                 float* gWb, float* workspace, const int* rows_dev, void* stream) {
   if (E < 0 || !Z || !W || !g || !gZ || !workspace) return MSDE_EINVAL;
   if (!mh_ok(H, J, Z, ldz, W) || (reinterpret_cast<uintptr_t>(gZ) & 15)) return MSDE_EUNSUP;
   hipStream_t st = as_stream(stream);
@@ -541,7 +541,7 @@ extern "C" int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const 
   }
   const int lpr = pick_tpr(H / 4), nb = mh_grid(E, lpr);
   MSDE_LAUNCH(mlp_head_bwd_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4*>(Z), ldz / 4,
-              reinterpret_cast<const float4*>(W), g, E, msde_row_bound(E), H / 4, J, lpr, reinterpret_cast<float4*>(gZ),
+              reinterpret_cast<const float4*>(W), g, E, rows_dev, H / 4, J, lpr, reinterpret_cast<float4*>(gZ),
               workspace);
   MSDE_CHECK_LAUNCH();
   if (!gWb) return 0;                 // slabs stay in `workspace` for a batched reduction

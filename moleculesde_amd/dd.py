@@ -427,7 +427,7 @@ class _MMtn(torch.autograd.Function):
         assert x.size(0) == M
         y = _new(N, K, like=g)
         ws = hip._wgrad_workspace(M, N, K, g.device)
-        _call("msde_linear_bwd_w", _p(g), _p(x), M, N, K, _p(y), _p(None), _p(ws), _stream())
+        _call("msde_linear_bwd_w", _p(g), _p(x), M, N, K, _p(y), _p(None), _p(ws), _p(hip.bound_tensor(M)), _stream())
         ctx.save_for_backward(g, x)
         return y
 

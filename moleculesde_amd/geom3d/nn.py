@@ -19,7 +19,6 @@ def shifted_softplus(x):
 
 import os as _os
 FUSED_MLP = _os.environ.get("MSDE_FUSED_MLP", "1") != "0"     # Linear/SiLU/Linear chains as hip.mlp_fused (A/B switch)
-USE_HIP_LINEAR = True   # False routes dense layers to the vendor GEMM ON THE DEVICE (A/B measurements only)
 
 
 def _need_device(x):
@@ -37,14 +36,12 @@ class Linear(nn.Linear):
 
     def forward(self, x):
         _need_device(x)
-        if USE_HIP_LINEAR:
-            return hip.linear(x, self.weight, self.bias, offload=not self.shared)
-        return F.linear(x, self.weight, self.bias)
+        return hip.linear(x, self.weight, self.bias, offload=not self.shared)
 
     def fork(self, x):
         """(x, self(x)) for blocks that also feed x to a residual: see hip.linear_fork."""
         _need_device(x)
-        if USE_HIP_LINEAR and torch.is_grad_enabled() and x.requires_grad:
+        if torch.is_grad_enabled() and x.requires_grad:
             return hip.linear_fork(x, self.weight, self.bias, not self.shared)
         return x, self.forward(x)
 
@@ -76,7 +73,7 @@ class BatchNorm1d(nn.BatchNorm1d):
 
     def forward(self, x):
         _need_device(x)
-        if not (USE_HIP_LINEAR and x.dim() == 2):
+        if x.dim() != 2:                  # [N, C, L] inputs: not on the hot path, torch's own kernel
             y = super().forward(x)
             return F.relu(y) if self.fuse_relu else y
         if self.training or not self.track_running_stats:
@@ -109,7 +106,7 @@ class BatchNorm1d(nn.BatchNorm1d):
 
 def bn_fusable(bn):
     """Training-mode BatchNorm1d with running statistics and affine parameters: what the fused products implement."""
-    return (isinstance(bn, BatchNorm1d) and bn.training and bn.track_running_stats and bn.affine and USE_HIP_LINEAR
+    return (isinstance(bn, BatchNorm1d) and bn.training and bn.track_running_stats and bn.affine
             and bn.running_mean is not None and bn.momentum is not None)     # (momentum=None: a per-call factor, unfused)
 
 
@@ -126,14 +123,12 @@ def count_batch(bn):
 
 def linear(x, weight, bias=None):
     _need_device(x)
-    if USE_HIP_LINEAR:
-        return hip.linear(x, weight, bias)
-    return F.linear(x, weight, bias)
+    return hip.linear(x, weight, bias)
 
 
 def linear_fork(x, weight, bias=None):
     _need_device(x)
-    if USE_HIP_LINEAR and torch.is_grad_enabled() and x.requires_grad:
+    if torch.is_grad_enabled() and x.requires_grad:
         return hip.linear_fork(x, weight, bias)
     return x, linear(x, weight, bias)
 
@@ -161,7 +156,7 @@ class MultiLayerPerceptron(nn.Module):
             nn.init.constant_(layer.bias, 0.0)
 
     def forward(self, x):
-        if (FUSED_MLP and USE_HIP_LINEAR and len(self.layers) >= 2 and self.activation_name == "silu" and not self.dropout
+        if (FUSED_MLP and len(self.layers) >= 2 and self.activation_name == "silu" and not self.dropout
                 and x.is_cuda and x.dim() == 2 and all(d % 4 == 0 for d in self.dims) and not any(l.shared for l in self.layers)):
             # bias + SiLU in the GEMM epilogues, SiLU' in the epilogue of the next layer's input-gradient GEMM
             return hip.mlp_fused(x, [(l.weight, l.bias) for l in self.layers], "silu")

@@ -40,30 +40,36 @@ def _i32(t):
 
 
 # ------------------------------------------------------------------------------------------------
-# row bounds (include/msde_hip.h: msde_set_row_bound)
+# row bounds (include/msde_hip.h, "Row bounds"): the C library takes the device row count of an operand as an explicit
+# argument of every reducing kernel and keeps no table.  The operators of this module see plain tensors, so while a step on
+# a capacity bucket is being LAUNCHED (eagerly, or recorded into a hipGraph) the bucket's {row capacity: count tensor} map
+# is in scope here -- `with hip.row_bounds(bucket.bounds_map()):`, entered by Trainer.step / Trainer.capture for the batch
+# they are given and restored on exit -- and each operator hands the count of its operand's capacity to its kernel.  A
+# replayed graph needs nothing in scope: the pointers are part of the recorded launches.  (The scope is process wide, not
+# thread local: the backward functions, which look bounds up too, run on the autograd engine's thread.)
 # ------------------------------------------------------------------------------------------------
-_BOUNDS = {}
-_BOUNDS_OWNER = None      # the bucket whose bounds are set (moleculesde_amd.bucket.Bucket.activate)
+import contextlib as _contextlib
+
+_BOUNDS = {}              # the map in scope: {row capacity: int32 device tensor holding the valid row count}
 
 
-def set_row_bounds(bounds, owner=None):
-    """bounds: {row capacity: int32 device tensor holding the valid row count}.  Replaces the current set.  Kernels
-    that reduce over rows of a tensor with exactly `capacity` rows then stop at the valid rows (moleculesde_amd.bucket)."""
-    clear_row_bounds()
-    for cap, t in bounds.items():
+@_contextlib.contextmanager
+def row_bounds(bounds):
+    """Scope in which kernels reducing over rows of a tensor with exactly `capacity` rows stop at the valid rows."""
+    global _BOUNDS
+    for t in bounds.values():
         assert t.dtype == torch.int32 and t.is_cuda and t.numel() >= 1
-        _lib.call("msde_set_row_bound", int(cap), _p(t))
-        _BOUNDS[int(cap)] = t          # keeps the device scalar alive
-    global _BOUNDS_OWNER
-    _BOUNDS_OWNER = owner
+    prev, _BOUNDS = _BOUNDS, {int(c): t for c, t in bounds.items()}
+    try:
+        yield
+    finally:
+        _BOUNDS = prev
 
 
 def clear_row_bounds():
-    global _BOUNDS_OWNER
-    _BOUNDS_OWNER = None
-    if _BOUNDS:
-        _lib.call("msde_clear_row_bounds")
-        _BOUNDS.clear()
+    """(tests) leave every scope: exact-size tensors from here on."""
+    global _BOUNDS
+    _BOUNDS = {}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -507,7 +513,8 @@ class _GinAggregate(torch.autograd.Function):
 
             def launch(st_=None, g=g, x=x, tab=tab, codes=codes, plan=plan, ws=ws):
                 _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N,
-                          E_, D, R, _p(None), _p(None), _p(ws), st_ if st_ is not None else _stream())
+                          E_, D, R, _p(None), _p(None), _p(ws), _p(bound_tensor(N)), _p(bound_tensor(E_)),
+                          st_ if st_ is not None else _stream())
             if DEFER_LEAF_KERNELS:
                 # a parameter gradient nothing in the backward chain reads: queued (operands kept alive) and launched by
                 # run_deferred_leaf_kernels() -- the trainer runs them beside the grouped weight-gradient launch; the
@@ -521,7 +528,7 @@ class _GinAggregate(torch.autograd.Function):
         else:
             ws = _scratch(nfl, x.device)
             _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N,
-                      plan.E, D, R, _p(g_tab), _p(g_eps), _p(ws), st)
+                      plan.E, D, R, _p(g_tab), _p(g_eps), _p(ws), _p(bound_tensor(N)), _p(bound_tensor(plan.E)), st)
         return g_x, g_tab, g_eps, None, None, None
 
 
@@ -808,11 +815,13 @@ class _MlpFused(torch.autograd.Function):
             nslab = int(_lib.load().msde_mlp_head_bwd_slabs(E, H))
             if _SLABS.active and ctx.deferrable:
                 ws = _SLABS.alloc(nslab * gall.numel(), g.device)
-                _lib.call("msde_mlp_head_bwd", _p(Zp), _ld(Zp), _p(W), _p(g), E, H, J, _p(gz), _p(None), _p(ws), _stream())
+                _lib.call("msde_mlp_head_bwd", _p(Zp), _ld(Zp), _p(W), _p(g), E, H, J, _p(gz), _p(None), _p(ws), _p(bound_tensor(E)),
+                          _stream())
                 _SLABS.add(ws.data_ptr(), nslab, gall.numel(), gall, written=True)
             else:
                 ws = torch.empty(nslab * gall.numel(), dtype=torch.float32, device=g.device)
-                _lib.call("msde_mlp_head_bwd", _p(Zp), _ld(Zp), _p(W), _p(g), E, H, J, _p(gz), _p(gall), _p(ws), _stream())
+                _lib.call("msde_mlp_head_bwd", _p(Zp), _ld(Zp), _p(W), _p(g), E, H, J, _p(gz), _p(gall), _p(ws), _p(bound_tensor(E)),
+                          _stream())
             grads[2 * n - 2] = gall[:J * H].view(J, H)
             grads[2 * n - 1] = gall[J * H:J * H + J] if b is not None else None
             g, top = gz, n - 2
@@ -1131,7 +1140,8 @@ def _wgrad_workspace(M, N, K, device):
 #     M = 3588 whatever the layer size, 110-225 us at edge level); the split-M MFMA kernel + fixed-order
 #     slab reduce takes 9-33 us (tools/bench_wgrad.py, hipGraph-timed), fuses the bias gradient and is
 #     bitwise reproducible -> hand-written kernel for every layer.
-# MSDE_LINEAR=hip forces the round-1 kernels of csrc/linear.hip everywhere, =lib the vendor GEMM (A/B measurements only).
+# MSDE_LINEAR=hip forces the round-1 kernels of csrc/linear.hip everywhere (cross-checks); the vendor GEMM is not reachable
+# from the product (tools/bench_gemm*.py time it beside the kernels).
 import os as _os
 
 _LINEAR_MODE = _os.environ.get("MSDE_LINEAR", "auto")
@@ -1140,7 +1150,7 @@ WGRAD_HIP_MIN_ROWS = 64          # below this a split over M has nothing to spli
 
 def set_linear_mode(mode):
     global _LINEAR_MODE
-    assert mode in ("auto", "hip", "lib")
+    assert mode in ("auto", "hip")
     _LINEAR_MODE = mode
 
 
@@ -1305,7 +1315,7 @@ class _SlabBatch:
         total_b = 0
         for r, (gY, X, M, N, K, hb, slab, _st) in enumerate(self.gemms):
             nb = lib.msde_linear_bwd_w_describe_ld(_p(gY), _row_stride(gY, N), _p(X), _row_stride(X, K), M, N, K, hb,
-                                                   _p(slab), ctypes.c_void_p(host_prob[r0 + r].data_ptr()))
+                                                   _p(slab), _p(bound_tensor(M)), ctypes.c_void_p(host_prob[r0 + r].data_ptr()))
             if nb <= 0:
                 raise _lib.MsdeHipError(f"msde_linear_bwd_w_describe failed ({nb}) for {M}x{N}x{K}")
             hp2[q0 + r] = total_b
@@ -1338,7 +1348,7 @@ class _SlabBatch:
                 _, _, _, codes, plan, _, N, E_, D, R = part[0]
                 _lib.call("msde_gin_aggregate_bwd_tab_multi", ctypes.cast(arr(0), ctypes.c_void_p), ctypes.cast(arr(1), ctypes.c_void_p),
                           ctypes.cast(arr(2), ctypes.c_void_p), ctypes.cast(arr(5), ctypes.c_void_p), n, _p(codes), _p(plan.src),
-                          _p(plan.dst), N, E_, D, R, _stream())
+                          _p(plan.dst), N, E_, D, R, _p(bound_tensor(N)), _p(bound_tensor(E_)), _stream())
         # the closures hold the kernels' operands: kept until finish(), because they may be launched on ANOTHER stream than
         # the one that allocated the operands (the caching allocator would hand their memory to that stream's next kernels)
         self.launched.extend(d)
@@ -1492,41 +1502,31 @@ def _row_stride(t, cols):
 def weight_grad(g2, x2, has_bias, deferrable=True, out_w=None, out_b=None):
     """gW [N,K] = g2^T x2 and (has_bias) gb [N] = column sums of g2 for g2 [M,N], x2 [M,K]: the hand-written
     split-M kernel -- queued for the grouped launch + batched slab reduction when a parameter-gradient batch is
-    open and the results are `deferrable` -- or the vendor GEMM + column-sum kernels (MSDE_LINEAR=lib, tiny M).
+    open and the results are `deferrable` -- or the per-layer launch of the same kernel with its own slab reduction.
     Under the grouped launch the operands may be column blocks of wider buffers (unit column stride)."""
     M, N = g2.shape
     K = x2.size(1)
     if not (_SLABS.active and deferrable and GROUPED_WGRAD) or M < WGRAD_HIP_MIN_ROWS:
         g2, x2 = g2.contiguous(), x2.contiguous()          # only the grouped kernel takes row strides
     st = _stream()
-    use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
-    if use_hip:
-        # out_w / out_b: contiguous slices of a stacked gradient (several layers' weights consumed as one operand)
-        gw = out_w if out_w is not None else torch.empty(N, K, dtype=torch.float32, device=g2.device)
-        gb = (out_b if out_b is not None else torch.empty(N, dtype=torch.float32, device=g2.device)) if has_bias else None
-        if _SLABS.active and deferrable:
-            splits = _SPLITS.get((M, N, K))
-            if splits is None:
-                splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
-            slab = _SLABS.alloc(splits * (N * K + (N if has_bias else 0)), g2.device)
-            if GROUPED_WGRAD:
-                _SLABS.queue_gemm(g2, x2, M, N, K, int(has_bias), slab)
-            else:
-                _lib.call("msde_linear_bwd_w_partial", _p(g2), _p(x2), M, N, K, int(has_bias), _p(slab), st)
-            _SLABS.add(slab.data_ptr(), splits, N * K, gw)
-            if has_bias:
-                _SLABS.add(slab.data_ptr() + 4 * splits * N * K, splits, N, gb)
+    # out_w / out_b: contiguous slices of a stacked gradient (several layers' weights consumed as one operand)
+    gw = out_w if out_w is not None else torch.empty(N, K, dtype=torch.float32, device=g2.device)
+    gb = (out_b if out_b is not None else torch.empty(N, dtype=torch.float32, device=g2.device)) if has_bias else None
+    if _SLABS.active and deferrable:
+        splits = _SPLITS.get((M, N, K))
+        if splits is None:
+            splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
+        slab = _SLABS.alloc(splits * (N * K + (N if has_bias else 0)), g2.device)
+        if GROUPED_WGRAD:
+            _SLABS.queue_gemm(g2, x2, M, N, K, int(has_bias), slab)
         else:
-            ws = _wgrad_workspace(M, N, K, g2.device)
-            _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), st)
-    else:
-        gw = torch.mm(g2.t(), x2)
-        if out_w is not None:
-            gw = out_w.copy_(gw)
-        gb = None
+            _lib.call("msde_linear_bwd_w_partial", _p(g2), _p(x2), M, N, K, int(has_bias), _p(slab), _p(bound_tensor(M)), st)
+        _SLABS.add(slab.data_ptr(), splits, N * K, gw)
         if has_bias:
-            gb = out_b if out_b is not None else torch.empty(N, dtype=torch.float32, device=g2.device)
-            _lib.call("msde_colsum", _p(g2), M, N, _p(gb), _p(_bn_workspace(M, N, g2.device)), st)
+            _SLABS.add(slab.data_ptr() + 4 * splits * N * K, splits, N, gb)
+    else:
+        ws = _wgrad_workspace(M, N, K, g2.device)
+        _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), _p(bound_tensor(M)), st)
     return gw, gb
 
 
@@ -1535,7 +1535,7 @@ def colsum(x):
     x = _f32(x)
     M, C = x.shape
     out = torch.empty(C, dtype=torch.float32, device=x.device)
-    _lib.call("msde_colsum", _p(x), M, C, _p(out), _p(_bn_workspace(M, C, x.device)), _stream())
+    _lib.call("msde_colsum", _p(x), M, C, _p(out), _p(_bn_workspace(M, C, x.device)), _p(bound_tensor(M)), _stream())
     return out
 
 
@@ -1546,8 +1546,7 @@ def weight_grad_blocks(g2, x2, has_bias, blocks, deferrable=True):
     without an open parameter-gradient batch the product is formed on the spot and copied."""
     M, N = g2.shape
     K = x2.size(1)
-    use_hip = _LINEAR_MODE == "hip" or (_LINEAR_MODE == "auto" and M >= WGRAD_HIP_MIN_ROWS)
-    if _SLABS.active and deferrable and GROUPED_WGRAD and use_hip:
+    if _SLABS.active and deferrable and GROUPED_WGRAD:
         splits = _SPLITS.get((M, N, K))
         if splits is None:
             splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
@@ -1606,7 +1605,7 @@ class _PairLinear(torch.autograd.Function):
 def pair_linear_ok(h, lin):
     D = lin.weight.size(0)
     return (h.is_cuda and h.dim() == 2 and lin.weight.size(1) == 2 * D and D % 4 == 0 and 0 < h.size(0) <= RS_MAX_ROWS
-            and lin.weight.is_leaf and lin.bias is not None and lin.bias.is_leaf and _LINEAR_MODE != "lib")
+            and lin.weight.is_leaf and lin.bias is not None and lin.bias.is_leaf)
 
 
 def pair_linear(h, lin):
@@ -1697,8 +1696,6 @@ class _Linear(torch.autograd.Function):
             y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
             _lib.call("msde_linear_fwd", _p(x2), _p(w), _p(_f32(bias) if bias is not None else None), M, N, K, _p(y),
                       _stream())
-        elif _LINEAR_MODE == "lib":
-            y = torch.addmm(bias, x2, w.t()) if bias is not None else torch.mm(x2, w.t())
         else:
             y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
             if M > 0:
@@ -1725,9 +1722,6 @@ class _Linear(torch.autograd.Function):
                 _lib.call("msde_linear_bwd_x", _p(g2), _p(w), M, N, K, _p(gx), st)
                 if g_res is not None:
                     gx = gx + g_res.reshape(M, K)
-            elif _LINEAR_MODE == "lib":
-                # residual gradient folded into the GEMM (beta = 1): no separate add
-                gx = torch.addmm(_f32(g_res.reshape(M, K)), g2, w) if g_res is not None else torch.mm(g2, w)
             else:
                 gx = torch.empty(M, K, dtype=torch.float32, device=g2.device)
                 if M > 0:
@@ -1784,7 +1778,7 @@ class _ContrastiveEBM(torch.autograd.Function):
         inv2 = torch.empty(N, dtype=torch.int32, device=X.device)
         out = torch.empty(2, dtype=torch.float32, device=X.device)
         _lib.call("msde_cl_ebm_fwd", _p(X), _p(Y), _p(p1), _p(p2), N, D, 1.0 / float(T), _p(rows), _p(inv1), _p(inv2),
-                  _p(out), _stream())
+                  _p(out), _p(bound_tensor(N)), _stream())
         ctx.save_for_backward(X, Y, p1, p2, inv1, inv2, rows)
         ctx.invT = 1.0 / float(T)
         loss, acc = out[0], out[1]         # two outputs (a select on ONE output costs a zeros + copy in its backward)
@@ -1801,7 +1795,7 @@ class _ContrastiveEBM(torch.autograd.Function):
         gX, gY = torch.empty_like(X), torch.empty_like(Y)
         g = _f32(g_loss).reshape(1)        # d/d(loss); the accuracy carries no gradient
         _lib.call("msde_cl_ebm_bwd", _p(X), _p(Y), _p(p1), _p(p2), _p(inv1), _p(inv2), _p(rows), _p(g), N, D, ctx.invT,
-                  _p(gX), _p(gY), _stream())
+                  _p(gX), _p(gY), _p(bound_tensor(N)), _stream())
         return gX, gY, None, None, None
 
 
@@ -1838,7 +1832,7 @@ class _BatchNormTrain(torch.autograd.Function):
         rstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _bn_workspace(M, C, x.device)
         _lib.call("msde_bn_fwd", _p(x), M, C, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
-                  _p(running_var), int(relu), _p(y), _p(mean), _p(rstd), _p(ws), _stream())
+                  _p(running_var), int(relu), _p(y), _p(mean), _p(rstd), _p(ws), _p(bound_tensor(M)), _stream())
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.relu = int(relu)
         return y
@@ -1853,7 +1847,7 @@ class _BatchNormTrain(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if beta is not None else None
         ws = _bn_workspace(M, C, x.device)
         _lib.call("msde_bn_bwd", _p(g), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), ctx.relu, M, C, _p(dx), _p(dgamma),
-                  _p(dbeta), _p(ws), _stream())
+                  _p(dbeta), _p(ws), _p(bound_tensor(M)), _stream())
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
@@ -1982,7 +1976,7 @@ def randperm(n, device, seed, seed_dev=None, count=None):
     independent ones when `count` is given."""
     out = torch.empty((n,) if count is None else (count, n), dtype=torch.int32, device=device)
     _lib.call("msde_randperm", int(n), 1 if count is None else int(count), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(seed_dev),
-              _p(out), _stream())
+              _p(out), _p(bound_tensor(n)), _stream())
     return out
 
 
@@ -2130,7 +2124,7 @@ class _GatTail(torch.autograd.Function):
         part = _SLABS.alloc(nblk * 4 * D, x.device) if defer else torch.empty(nblk * 4 * D, dtype=torch.float32, device=x.device)
         _lib.call("msde_gat_tail_bwd", _p(g), _p(x), _p(y1), _p(h0), _p(x2), _p(g1), _p(W0), _p(W3), _p(g2), _p(b2), N, D,
                   eps1, eps2, p, seed, _p(seed_dev), silu_out, _p(g_x), _p(g_res), _p(g_x2), _p(a), _p(g_h0), _p(part),
-                  _stream())
+                  _p(bound_tensor(N)), _stream())
         ln = torch.empty(4 * D, dtype=torch.float32, device=x.device)      # [d ln2_g | d ln2_b | d ln1_g | d ln1_b]
         if defer:
             _SLABS.add(part.data_ptr(), nblk, 4 * D, ln)

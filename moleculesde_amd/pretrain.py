@@ -488,29 +488,25 @@ class Trainer:
         from . import hip as _hip
         self._last_refreshed = _hip.refresh_weight_t()
 
-    def _sync_bounds(self, batch):
-        """Row bounds are process wide: a capacity-bucket batch needs its bucket's bounds, an exact-size batch none."""
+    def _bounds(self, batch):
+        """The row-bound scope of a batch: its capacity bucket's counts, or none for an exact-size batch."""
         from . import hip as _hip
         bk = getattr(batch, "_bucket", None)
-        if bk is not None:
-            if _hip._BOUNDS_OWNER is not bk:
-                bk.activate()
-        elif _hip._BOUNDS:
-            _hip.clear_row_bounds()
+        return _hip.row_bounds(bk.bounds_map() if bk is not None else {})
 
     def step(self, batch):
-        self._sync_bounds(batch)
-        self.step_counter.add_(1)         # the device step counter re-seeds dropout / negatives once a capture set it
-        loss, parts = self.losses(batch, log=True)
-        self.opt.zero_grad()
-        self._backward(loss)
-        if self._use_dp():
-            self.opt.gather_grads()
-            self._allreduce_and_adam()
-        else:
-            self.opt.step_from_grads()
-            self._refresh_weights()
-        self._log_parts(parts)
+        with self._bounds(batch):         # (kernels reducing over rows stop at the bucket's valid rows)
+            self.step_counter.add_(1)     # the device step counter re-seeds dropout / negatives once a capture set it
+            loss, parts = self.losses(batch, log=True)
+            self.opt.zero_grad()
+            self._backward(loss)
+            if self._use_dp():
+                self.opt.gather_grads()
+                self._allreduce_and_adam()
+            else:
+                self.opt.step_from_grads()
+                self._refresh_weights()
+            self._log_parts(parts)
         self.steps += 1
         return loss.detach(), parts
 
@@ -539,7 +535,6 @@ class Trainer:
         key = id(batch)
         if key in self._graphs:
             return self._graphs[key][0]
-        self._sync_bounds(batch)
         with_adam = not self._use_dp() and not self.adam_outside_graph
         sd = self.step_counter.view(torch.int64)
         self.models["SDE_2Dto3D_model"].score_network.seed_dev = sd
@@ -554,7 +549,7 @@ class Trainer:
             self._graph_pool = torch.cuda.graph_pool_handle()
         # thread_local: other threads of the process (the RCCL watchdog under DP) may issue HIP calls
         # while this thread captures; they must not invalidate the capture
-        with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+        with self._bounds(batch), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             if pre is not None:
                 pre()
             loss = self._graph_body(batch, with_adam)
@@ -598,7 +593,6 @@ class Trainer:
         """Warm up on one raw batch (sizes the workspaces), then capture {device-side plan construction + step} for
         the bucket's capacities.  Afterwards every batch that fits the capacities is `step_bucket(bk, blob)`: one
         copy of its raw blob + one graph replay, no per-batch host work."""
-        bk.activate()
         bk.load(warm_blob)
         bk.build_plan_on_device()
         ok, sizes = bk.check()

@@ -157,11 +157,8 @@ def test_bucket_step_matches_exact_batch(dev, full):
     bk = BK.Bucket(caps, dev)
     bk.load(BK.pack_raw(cpu_b, caps))
     bk.build_plan_on_device()
-    bk.activate()
-    try:
+    with bk.bounds():
         parts_b, g_b, sd_b = run(bk.batch, caps.N)
-    finally:
-        hip.clear_row_bounds()
     for k in parts_e:
         assert abs(parts_b[k] - parts_e[k]) <= 2e-5 * abs(parts_e[k]) + 1e-7, (k, parts_b[k], parts_e[k])
     # per-parameter relative L2 error (different row capacities give different split geometries in the BatchNorm /

@@ -32,10 +32,10 @@ for M, N, K in SHAPES:
     gw = torch.empty(N, K, device=dev); gb = torch.empty(N, device=dev); y = torch.empty(M, N, device=dev)
     gx = torch.empty(M, K, device=dev)
     ws = hip._wgrad_workspace(M, N, K, dev); bws = hip._bn_workspace(M, N, dev)
-    def w_hip(): _lib.call("msde_linear_bwd_w", p(g), p(x), M, N, K, p(gw), p(gb), p(ws), hip._stream())
+    def w_hip(): _lib.call("msde_linear_bwd_w", p(g), p(x), M, N, K, p(gw), p(gb), p(ws), p(None), hip._stream())
     def w_lib():
         torch.mm(g.t(), x, out=gw)
-        _lib.call("msde_colsum", p(g), M, N, p(gb), p(bws), hip._stream())
+        _lib.call("msde_colsum", p(g), M, N, p(gb), p(bws), p(None), hip._stream())
     def f_hip(): _lib.call("msde_linear_fwd", p(x), p(w), p(b), M, N, K, p(y), hip._stream())
     def f_lib(): torch.addmm(b, x, w.t(), out=y)
     def d_hip(): _lib.call("msde_linear_bwd_x", p(g), p(w), M, N, K, p(gx), hip._stream())
