@@ -441,10 +441,10 @@ int msde_gemm_rs_geometry(int M, int N, int K, int* strips, int* strip_rows);
  * ldb (MSDE_GEMM_B_KMAJOR must NOT be set: nn.Linear's weight as stored for a forward product, its transposed copy for an
  * input-gradient product), and the statistics strips are always 16 rows (msde_gemm_t2_geometry).  axf: MSDE_RS_AXF_NONE,
  * MSDE_RS_AXF_AFFINE and MSDE_RS_AXF_BNBWD as in msde_gemm_rs (applied to the A fragments in registers).  msde_gemm_t2_supported:
- * 1 when the library would run (M, N, K) on this kernel (M >= 512, N >= 32, N % 4 == K % 4 == 0), else 0 -- callers pick the
- * weight copy to pass accordingly.  Operands below 2 GiB, 16-byte aligned rows; otherwise MSDE_EUNSUP. */
+ * 1 when the library would run (M, N, K) with transform `axf` on this kernel (M >= 512, N >= 32, N % 4 == K % 4 == 0, and
+ * a tiling that fills the chip in one round of workgroups), else 0 -- callers pick the weight copy to pass accordingly.  Operands below 2 GiB, 16-byte aligned rows; otherwise MSDE_EUNSUP. */
 int msde_gemm_t2(const msde_rs_desc* desc, void* stream);
-int msde_gemm_t2_supported(int M, int N, int K);
+int msde_gemm_t2_supported(int M, int N, int K, int axf);
 int msde_gemm_t2_geometry(int M, int N, int K, int* strips, int* strip_rows);
 /* Up to MSDE_CHAIN_MAX chained products on strips of 16 rows that stay in LDS (csrc/gemm_rs.hip): stage s computes
  * out_s = epilogue_s(in_s . W_s + bias_s) with in_0 = A [M, K_0] and in_s = out_{s-1} (K_s == N_{s-1}); epilogue as in

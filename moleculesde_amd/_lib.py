@@ -75,7 +75,7 @@ SIGNATURES = {
     "msde_gemm_rs": [P, P],
     "msde_gemm_chain": [P, P],
     "msde_gemm_t2": [P, P],
-    "msde_gemm_t2_supported": [I, I, I],
+    "msde_gemm_t2_supported": [I, I, I, I],
     "msde_gemm_t2_geometry": [I, I, I, P, P],
     "msde_transpose_multi": [P, P, I, I, P],
     "msde_transpose": [P, P, I, I, P],

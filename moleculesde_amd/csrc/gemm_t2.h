@@ -117,7 +117,7 @@ template <int RN, int AXF = 0, int ABL = 0>
 __global__ void __launch_bounds__(512)
 gemm_t2_kernel(const msde_rs_desc d) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char t2_smem[];
-  static_assert(RN >= 1 && RN <= 10, "geometry");
+  static_assert(RN >= 1 && RN <= 12, "geometry");
   constexpr int NBUF = 4;
   constexpr int BM = 64, BN = 16 * RN;
   constexpr int NA = AXF == MSDE_RS_AXF_BNBWD ? 2 : 1;          // row operands staged per stage: A (and z)
@@ -360,6 +360,20 @@ gemm_t2_kernel(const msde_rs_desc d) {
   if (h == 0) run_tiles(std::integral_constant<int, 0>{});
   else run_tiles(std::integral_constant<int, 1>{});
   T2_STAMP(2);
+  // The epilogue's share of the descriptor is read from the kernel-argument segment HERE, right behind the K loop (its barriers
+  // are memory clobbers, so these scalar loads cannot be hoisted above it; their latency passes under the exchange below): held in scalar registers from the kernel entry, its ~50 words pushed
+  // the K loop over the scalar register file (request operands of the LDS-DMA statements spilled: no longer uniform).
+  msde_rs_desc de;
+  {
+    typedef const __attribute__((address_space(4))) msde_rs_desc* kargp;
+    kargp kp = (kargp)__builtin_amdgcn_kernarg_segment_ptr();
+    de.bias = nullptr;                                           // (added above)
+    de.C = kp->C; de.Z = kp->Z; de.R = kp->R; de.Res = kp->Res; de.stats = kp->stats; de.stats_z = kp->stats_z;
+    de.stats_mean = kp->stats_mean; de.m_valid = kp->m_valid;
+    de.M = kp->M; de.N = kp->N; de.K = kp->K;
+    de.ldc = kp->ldc; de.ldz = kp->ldz; de.ldr = kp->ldr; de.ldres = kp->ldres; de.ld_sz = kp->ld_sz;
+    de.act = kp->act; de.epi = kp->epi; de.flags = kp->flags; de.stats_mode = kp->stats_mode;
+  }
   t2_wait_vm<0>();
   t2_barrier();                                                  // every wave is done with the ring: it becomes the exchange area
   // partial sums of the k-half 1 waves -> their k-half 0 partners (same rows), through LDS
@@ -377,20 +391,6 @@ gemm_t2_kernel(const msde_rs_desc d) {
       const float4 o = *reinterpret_cast<const float4*>(xb + t * 1024);
       acc[t][0][0] += o.x + bv[t]; acc[t][0][1] += o.y + bv[t]; acc[t][0][2] += o.z + bv[t]; acc[t][0][3] += o.w + bv[t];
     }
-  }
-  // The epilogue's share of the descriptor is read from the kernel-argument segment HERE (the barriers above are memory
-  // clobbers, so these scalar loads cannot be hoisted): held in scalar registers from the kernel entry, its ~50 words pushed
-  // the K loop over the scalar register file (request operands of the LDS-DMA statements spilled: no longer uniform).
-  msde_rs_desc de;
-  {
-    typedef const __attribute__((address_space(4))) msde_rs_desc* kargp;
-    kargp kp = (kargp)__builtin_amdgcn_kernarg_segment_ptr();
-    de.bias = nullptr;                                           // (added above)
-    de.C = kp->C; de.Z = kp->Z; de.R = kp->R; de.Res = kp->Res; de.stats = kp->stats; de.stats_z = kp->stats_z;
-    de.stats_mean = kp->stats_mean; de.m_valid = kp->m_valid;
-    de.M = kp->M; de.N = kp->N; de.K = kp->K;
-    de.ldc = kp->ldc; de.ldz = kp->ldz; de.ldr = kp->ldr; de.ldres = kp->ldres; de.ld_sz = kp->ld_sz;
-    de.act = kp->act; de.epi = kp->epi; de.flags = kp->flags; de.stats_mode = kp->stats_mode;
   }
   t2_epilogue<RN>(de, acc, n0, m0 + 16 * wr, rowblk * 4 + wr);
 #ifdef T2_TIMING
@@ -435,6 +435,7 @@ int t2_launch_rn(int rn, dim3 grid, size_t lds, hipStream_t st, const msde_rs_de
     T2_RN(T2_PROBE)
 #else
     T2_RN(1) T2_RN(2) T2_RN(3) T2_RN(4) T2_RN(5) T2_RN(6) T2_RN(8) T2_RN(10)
+    case 12: if constexpr (AXF == MSDE_RS_AXF_NONE) return t2_launch(gemm_t2_kernel<12, AXF>, grid, dim3(512), lds, st, d); else return MSDE_EUNSUP;
 #endif
     default: return MSDE_EUNSUP;
   }

@@ -14,31 +14,35 @@ struct t2_cfg { int rn, splits; };
 
 // geometry for (M, N, K): 64-row tiles x as many column splits as give every CU about one workgroup; `splits` != 0 forces
 // the split count (measurements).
-static const int T2_RN_OK[] = {1, 2, 3, 4, 5, 6, 8, 10};       // (12: hipcc runs out of scalar registers for the request operands)
-static bool t2_pick(int M, int N, int K, int splits, t2_cfg* c) {
+static const int T2_RN_OK[] = {1, 2, 3, 4, 5, 6, 8, 10, 12};   // (12: the plain kernel only -- with a transform it runs out of registers)
+static bool t2_pick(int M, int N, int K, int splits, int axf, t2_cfg* c) {
   if (M < 512 || N % 4 || K % 4 || N < 32) return false;
   const int ntiles = (N + 15) / 16;
   const int cus = msde_num_cus();
   const int rowblks = (M + 63) / 64;
+  const int rn_max = axf == MSDE_RS_AXF_NONE ? 12 : 10;
   int S = splits > 0 ? splits : (cus + rowblks / 2) / rowblks;
   if (S < 1) S = 1;
   if (S > ntiles) S = ntiles;
   int rn = (ntiles + S - 1) / S;
-  while (rn > 10) { ++S; rn = (ntiles + S - 1) / S; }
+  while (rn > rn_max) { ++S; rn = (ntiles + S - 1) / S; }
   for (int ok : T2_RN_OK) if (ok >= rn) { rn = ok; break; }
   S = (ntiles + rn - 1) / rn;
+  // a node-level operand (fewer row blocks than CUs) must fit the chip in ONE round of workgroups: a second, mostly empty
+  // round costs more than the row strips of msde_gemm_rs do (N = 728 with a transform: 57 x 5 workgroups)
+  if (splits <= 0 && rowblks <= cus && rowblks * S > cus + cus / 16) return false;
   c->rn = rn; c->splits = S;
   return true;
 }
 
-extern "C" int msde_gemm_t2_supported(int M, int N, int K) {
+extern "C" int msde_gemm_t2_supported(int M, int N, int K, int axf) {
   t2_cfg c;
-  return t2_pick(M, N, K, 0, &c) ? 1 : 0;
+  return t2_pick(M, N, K, 0, axf, &c) ? 1 : 0;
 }
 
 extern "C" int msde_gemm_t2_geometry(int M, int N, int K, int* strips, int* strip_rows) {
   t2_cfg c;
-  if (!strips || !strip_rows || !t2_pick(M, N, K, 0, &c)) return MSDE_EINVAL;
+  if (!strips || !strip_rows || !t2_pick(M, N, K, 0, MSDE_RS_AXF_BNBWD, &c)) return MSDE_EINVAL;
   *strip_rows = 16;
   *strips = ((M + 63) / 64) * 4;
   return 0;
@@ -68,7 +72,7 @@ extern "C" int msde_gemm_t2(const msde_rs_desc* desc, void* stream) {
   }
   if (d.A_out && (d.lda_out % 4 || !t2_al16(d.A_out))) return MSDE_EINVAL;
   t2_cfg c;
-  if (!t2_pick(d.M, d.N, d.K, d.splits, &c)) return MSDE_EUNSUP;
+  if (!t2_pick(d.M, d.N, d.K, d.splits, d.axf, &c)) return MSDE_EUNSUP;
   d.splits = c.splits;
 #ifndef T2_TIMING
   d.rt = 1;

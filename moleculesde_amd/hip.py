@@ -2430,11 +2430,14 @@ _T2_MODE = _os.environ.get("MSDE_T2", "1")     # "0": every node-level product o
 _T2_OK = {}
 
 
-def t2_ok(M, N, K):
-    """True when msde_gemm_t2 (csrc/gemm_t2.hip) takes this node-level product (and the switch is on)."""
+def t2_ok(M, N, K, axf=None):
+    """True when msde_gemm_t2 (csrc/gemm_t2.hip) takes this node-level product with the A transform `axf` (and the switch
+    is on).  The statistics geometry of a fused chain must not depend on the transform: callers that write BatchNorm
+    partials ask with the heaviest transform of their chain."""
     if _T2_MODE == "0":
         return False
-    key = (int(M), int(N), int(K))
+    code = {None: _lib.RS_AXF_NONE, "affine": _lib.RS_AXF_AFFINE, "bnbwd": _lib.RS_AXF_BNBWD}[axf]
+    key = (int(M), int(N), int(K), code)
     v = _T2_OK.get(key)
     if v is None:
         v = _T2_OK[key] = bool(_lib.load().msde_gemm_t2_supported(*key))
@@ -2455,8 +2458,8 @@ def rs_geometry(M, N, K):
     """(strips, rows per strip) of the statistics partials the node-level product kernel writes for this problem (the 2-D
     tiled kernel when it takes the shape, else the row strips)."""
     a, b = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.call("msde_gemm_t2_geometry" if t2_ok(M, N, K) else "msde_gemm_rs_geometry", int(M), int(N), int(K), ctypes.byref(a),
-              ctypes.byref(b))
+    _lib.call("msde_gemm_t2_geometry" if t2_ok(M, N, K, "bnbwd") else "msde_gemm_rs_geometry", int(M), int(N), int(K),
+              ctypes.byref(a), ctypes.byref(b))
     return a.value, b.value
 
 
@@ -2466,7 +2469,10 @@ def gemm_node(A, W, out, forward, N, K, **kw):
     that kernel reads: 2-D tiles read the reduction index contiguous ([N][K]: W as stored forward, its transposed copy
     backward), row strips the other one."""
     M = A.size(0)
-    if t2_ok(M, N, K):
+    # (one kernel family per chain: a product that writes or follows BatchNorm partials is asked with the heaviest transform,
+    # so that rs_geometry and every product of the chain agree on the strips)
+    fused = kw.get("stats") is not None or kw.get("axf") is not None
+    if t2_ok(M, N, K, "bnbwd" if fused else None):
         return gemm_rs(A, W if forward else weight_t(W), out, N=N, K=K, t2=True, **kw)
     return gemm_rs(A, weight_t(W) if forward else W, out, b_kmajor=True, N=N, K=K, fallback=False, **kw)
 

@@ -1190,7 +1190,7 @@ def test_gemm_t2_plain(dev, M, N, K):
     is skipped; K = 36, 100, 4; odd and even tile counts), every tiles-per-workgroup variant, forced split counts.
     NaN-filled outputs prove every element is written; two launches must agree bit for bit."""
     from moleculesde_amd import hip, _lib
-    if not _lib.load().msde_gemm_t2_supported(M, N, K):
+    if not _lib.load().msde_gemm_t2_supported(M, N, K, 0):
         pytest.skip("shape not taken by msde_gemm_t2")
     g = torch.Generator().manual_seed(M * 7 + N + K)
     A = torch.randn(M, K, generator=g).to(dev)
