@@ -493,12 +493,21 @@ int msde_bn_bwd_colstats(const float* G, const float* Z, const float* Y, const f
                          int C, float* stats, void* stream);
 /* Re-laid-out copies of n fp32 blocks in one launch: the transposed weight copies the forward products of msde_gemm_rs read
  * and the stacked / permuted operands of fused layers (refreshed once per optimiser step).  table: n rows of 8 x int64
- * {src, dst, rows, cols, src_ld, dst_ld, mode, 0} (device); mode 0: dst[c * dst_ld + r] = src[r * src_ld + c] (transpose of
- * the rows x cols block), mode 1: dst[r * dst_ld + c] = src[r * src_ld + c] (copy); prefix [n+1]: first 32 x 32 tile of each
- * block, prefix[n] = total_tiles. */
+ * {src, dst, rows, cols, src_ld, dst_ld, mode, plane_stride} (device); mode 0: dst[c * dst_ld + r] = src[r * src_ld + c]
+ * (transpose of the rows x cols block), mode 1: dst[r * dst_ld + c] = src[r * src_ld + c] (copy); modes 2 / 3 (the bf16x3
+ * experiment): the copy / the transpose split into three bf16 planes, dst16[plane * plane_stride + ...] (16-bit elements),
+ * value = hi + mid + lo exactly; prefix [n+1]: first 32 x 32 tile of each block, prefix[n] = total_tiles. */
 int msde_transpose_multi(const long long* table, const int* prefix, int n, int total_tiles, void* stream);
 /* the same for one block, no tables */
 int msde_relayout(const float* src, int src_ld, float* dst, int dst_ld, int rows, int cols, int mode, void* stream);
+/* one block split into three bf16 planes (modes 2 / 3 above), no tables */
+int msde_relayout_split(const float* src, int src_ld, void* dst16, int dst_ld, int rows, int cols, int transpose,
+                        long long plane_stride, void* stream);
+/* EXPERIMENT, off by default (csrc/gemm_t2b.hip): msde_gemm_t2 with both operands split into three bf16 terms on the bf16
+ * matrix pipe, fp32 accumulate -- six of the nine term products, i.e. fp32-level accuracy.  Same descriptor (MSDE_RS_AXF_NONE
+ * only) except the weight operand: B = three bf16 planes [3][N][ldb] of the [N][K] weight (msde_transpose_multi modes 2 / 3),
+ * ldb = row length in 16-bit elements, a multiple of 32 and >= K, zero beyond K.  Never the headline path. */
+int msde_gemm_t2b(const msde_rs_desc* desc, void* stream);
 /* the same for one matrix, no tables: dst [cols][rows] = src [rows][cols]^T */
 int msde_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 

@@ -75,6 +75,8 @@ SIGNATURES = {
     "msde_gemm_rs": [P, P],
     "msde_gemm_chain": [P, P],
     "msde_gemm_t2": [P, P],
+    "msde_gemm_t2b": [P, P],
+    "msde_relayout_split": [P, I, P, I, I, I, I, LL, P],
     "msde_gemm_t2_supported": [I, I, I, I],
     "msde_gemm_t2_geometry": [I, I, I, P, P],
     "msde_transpose_multi": [P, P, I, I, P],

@@ -565,12 +565,34 @@ extern "C" int msde_gemm_rs(const msde_rs_desc* desc, void* stream) {
 // ---- re-laid-out weight copies (forward products read [K][N], gemm_rs.h; stacked / permuted operands of fused layers):
 // ONE launch for any number of blocks.  table rows (long long x 8): {src, dst, rows, cols, src_ld, dst_ld, mode, 0} --
 // mode 0: dst[c * dst_ld + r] = src[r * src_ld + c] (transpose of a rows x cols block), mode 1: dst[r * dst_ld + c] =
-// src[r * src_ld + c] (copy of the block); prefix[i] = first 32 x 32 tile of block i, prefix[n] = total.
+// src[r * src_ld + c] (copy of the block); modes 2 / 3: the copy / the transpose split into three bf16 planes (word 7 of the
+// row = plane stride in elements; gemm_t2b.hip); prefix[i] = first 32 x 32 tile of block i, prefix[n] = total.
+// modes 2 / 3 (the bf16x3 experiment, csrc/gemm_t2b.hip): the block (mode 2) or its transpose (mode 3) split into three bf16
+// planes dst[plane * plane_stride + row * dst_ld + col] (16-bit elements): v = hi + mid + lo exactly, by truncation
+__device__ __forceinline__ void relayout_split_store(unsigned short* __restrict__ dst, size_t idx, long long plane_stride, float v) {
+  const unsigned h = __float_as_uint(v) & 0xFFFF0000u;
+  const float r = v - __uint_as_float(h);
+  const unsigned m = __float_as_uint(r) & 0xFFFF0000u;
+  const float q = r - __uint_as_float(m);
+  dst[idx] = (unsigned short)(h >> 16);
+  dst[idx + plane_stride] = (unsigned short)(m >> 16);
+  dst[idx + 2 * plane_stride] = (unsigned short)(__float_as_uint(q) >> 16);
+}
+
 __device__ __forceinline__ void relayout_tile(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
-                                              int src_ld, int dst_ld, int mode, int t, float (*tile)[33]) {
+                                              int src_ld, int dst_ld, int mode, int t, float (*tile)[33], long long plane_stride = 0) {
   const int tc = (cols + 31) >> 5;
   const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+  if (mode == 2) {
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + y + 8 * k, c = c0 + x;
+      if (r < rows && c < cols) relayout_split_store(d16, (size_t)r * dst_ld + c, plane_stride, src[(size_t)r * src_ld + c]);
+    }
+    return;
+  }
   if (mode == 1) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -588,7 +610,10 @@ __device__ __forceinline__ void relayout_tile(const float* __restrict__ src, flo
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = c0 + y + 8 * k, r = r0 + x;
-    if (c < cols && r < rows) dst[(size_t)c * dst_ld + r] = tile[x][y + 8 * k];
+    if (c < cols && r < rows) {
+      if (mode == 3) relayout_split_store(reinterpret_cast<unsigned short*>(dst), (size_t)c * dst_ld + r, plane_stride, tile[x][y + 8 * k]);
+      else dst[(size_t)c * dst_ld + r] = tile[x][y + 8 * k];
+    }
   }
 }
 
@@ -602,21 +627,33 @@ transpose_multi_kernel(const long long* __restrict__ table, const int* __restric
   }
   const long long* e = table + 8 * (size_t)lo;
   relayout_tile(reinterpret_cast<const float*>(e[0]), reinterpret_cast<float*>(e[1]), (int)e[2], (int)e[3], (int)e[4],
-                (int)e[5], (int)e[6], blockIdx.x - prefix[lo], tile);
+                (int)e[5], (int)e[6], blockIdx.x - prefix[lo], tile, e[7]);
 }
 
 __global__ void __launch_bounds__(256)
 transpose_one_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int src_ld, int dst_ld,
-                     int mode) {
+                     int mode, long long plane_stride) {
   __shared__ float tile[32][33];
-  relayout_tile(src, dst, rows, cols, src_ld, dst_ld, mode, blockIdx.x, tile);
+  relayout_tile(src, dst, rows, cols, src_ld, dst_ld, mode, blockIdx.x, tile, plane_stride);
 }
 
 extern "C" int msde_relayout(const float* src, int src_ld, float* dst, int dst_ld, int rows, int cols, int mode, void* stream) {
   if (rows <= 0 || cols <= 0) return 0;
-  if (!src || !dst || src_ld < cols || dst_ld < (mode == 1 ? cols : rows) || (mode != 0 && mode != 1)) return MSDE_EINVAL;
+  if (!src || !dst || src_ld < cols || (mode != 0 && mode != 1) || dst_ld < (mode == 1 ? cols : rows)) return MSDE_EINVAL;
   MSDE_LAUNCH(transpose_one_kernel, dim3(((rows + 31) / 32) * ((cols + 31) / 32)), dim3(256), 0, as_stream(stream), src, dst,
-              rows, cols, src_ld, dst_ld, mode);
+              rows, cols, src_ld, dst_ld, mode, 0LL);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// One block split into three bf16 planes (modes 2 / 3 of msde_transpose_multi): dst16[plane * plane_stride + r * dst_ld + c],
+// the block itself (transpose == 0) or its transpose.  The bf16x3 experiment (csrc/gemm_t2b.hip).
+extern "C" int msde_relayout_split(const float* src, int src_ld, void* dst16, int dst_ld, int rows, int cols, int transpose,
+                                   long long plane_stride, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  if (!src || !dst16 || src_ld < cols || dst_ld < (transpose ? rows : cols) || plane_stride <= 0) return MSDE_EINVAL;
+  MSDE_LAUNCH(transpose_one_kernel, dim3(((rows + 31) / 32) * ((cols + 31) / 32)), dim3(256), 0, as_stream(stream), src,
+              reinterpret_cast<float*>(dst16), rows, cols, src_ld, dst_ld, transpose ? 3 : 2, plane_stride);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -625,7 +662,7 @@ extern "C" int msde_transpose(const float* src, float* dst, int rows, int cols, 
   if (rows <= 0 || cols <= 0) return 0;
   if (!src || !dst) return MSDE_EINVAL;
   MSDE_LAUNCH(transpose_one_kernel, dim3(((rows + 31) / 32) * ((cols + 31) / 32)), dim3(256), 0, as_stream(stream), src, dst,
-              rows, cols, cols, rows, 0);
+              rows, cols, cols, rows, 0, 0LL);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -30,6 +30,7 @@
 #include <mutex>
 
 typedef int t2_i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int t2_u32x4 __attribute__((ext_vector_type(4)));
 #define T2_OOB 0x80000000u      // per-lane byte offset beyond any operand (< 2 GiB): the range check returns zeros
 
 __device__ __forceinline__ t2_i32x4 t2_rsrc(const void* p, unsigned bytes) {
@@ -260,6 +261,11 @@ gemm_t2_kernel(const msde_rs_desc d) {
   // the column split tile % splits
   const float lbound = (d.flags & MSDE_RS_AXF_RELU) ? 0.f : -3.0e38f;
   const int arow = m0 + 16 * wr + r;
+  // A_out through a buffer descriptor (zero records when there is no A_out: every store is dropped)
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+      d.A_out ? d.A_out : const_cast<float*>(d.A), 0,
+      (AXF != MSDE_RS_AXF_NONE && d.A_out) ? (int)(((size_t)(M - 1) * (size_t)d.lda_out + (size_t)K) * 4) : 0, 0x00020000);
+  const unsigned aout_row = arow < M ? (unsigned)arow * (unsigned)d.lda_out * 4u : T2_OOB;
   auto xform = [&](float4& a, const float4& z, const float4 (&x)[NV > 0 ? NV : 1], int tile, bool mine) __attribute__((always_inline)) {
     if (AXF == MSDE_RS_AXF_AFFINE) {
       a.x = fmaxf(fmaf(a.x, x[0].x, x[1].x), lbound); a.y = fmaxf(fmaf(a.y, x[0].y, x[1].y), lbound);
@@ -270,9 +276,15 @@ gemm_t2_kernel(const msde_rs_desc d) {
       a.x = fmaf(x[0].x, gx, fmaf(x[1].x, z.x, x[2].x)); a.y = fmaf(x[0].y, gy, fmaf(x[1].y, z.y, x[2].y));
       a.z = fmaf(x[0].z, gz, fmaf(x[1].z, z.z, x[2].z)); a.w = fmaf(x[0].w, gw, fmaf(x[1].w, z.w, x[2].w));
     }
-    if (AXF != MSDE_RS_AXF_NONE && d.A_out) {
+    if (AXF != MSDE_RS_AXF_NONE) {
+      // write-back WITHOUT control flow (a branch here splits every K-tile block into basic blocks, and hipcc then shuffles
+      // the accumulators between them: 1.5 register copies per MFMA measured): a buffer store whose per-lane offset is out
+      // of range for the lanes / tiles that do not write (the range check drops them)
       const int k = 32 * tile + 16 * h + 4 * q;
-      if (mine && arow < M && k < K) *reinterpret_cast<float4*>(d.A_out + (size_t)arow * d.lda_out + k) = a;
+      const unsigned off = (mine && k < K) ? aout_row + 4u * (unsigned)k : T2_OOB;
+      t2_u32x4 v;
+      v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y); v.z = __float_as_uint(a.z); v.w = __float_as_uint(a.w);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsO, off, 0, 0);
     }
   };
   const bool skip_last = h == 1 && K - (nt - 1) * 32 <= 16;     // this wave's half of the last tile lies beyond K

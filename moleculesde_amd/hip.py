@@ -1333,11 +1333,13 @@ class _SlabBatch:
 
     def run_deferred(self):
         d, self.deferred = self.deferred, []
-        groups = {}
+        groups, others = {}, []
         for fn in d:
             t = getattr(fn, "gin_tab", None)
             if t is not None and GIN_TAB_MULTI:
                 groups.setdefault((t[3].data_ptr(), t[4].src.data_ptr(), t[6], t[7], t[8], t[9]), []).append(t)
+            elif TAB_FIRST:
+                others.append(fn)
             else:
                 fn(None)
         for ts in groups.values():
@@ -1349,6 +1351,8 @@ class _SlabBatch:
                 _lib.call("msde_gin_aggregate_bwd_tab_multi", ctypes.cast(arr(0), ctypes.c_void_p), ctypes.cast(arr(1), ctypes.c_void_p),
                           ctypes.cast(arr(2), ctypes.c_void_p), ctypes.cast(arr(5), ctypes.c_void_p), n, _p(codes), _p(plan.src),
                           _p(plan.dst), N, E_, D, R, _p(bound_tensor(N)), _p(bound_tensor(E_)), _stream())
+        for fn in others:
+            fn(None)
         # the closures hold the kernels' operands: kept until finish(), because they may be launched on ANOTHER stream than
         # the one that allocated the operands (the caching allocator would hand their memory to that stream's next kernels)
         self.launched.extend(d)
@@ -1429,6 +1433,7 @@ class _SlabBatch:
 
 
 DEFER_LEAF_KERNELS = _os.environ.get("MSDE_DEFER_LEAF", "1") != "0"   # GIN bond-table gradients off the backward chain
+TAB_FIRST = _os.environ.get("MSDE_TAB_FIRST", "0") != "0"   # bond-table kernels ahead of the embedding-table ones at the tail
 GIN_TAB_MULTI = _os.environ.get("MSDE_GIN_TAB_MULTI", "1") != "0"     # ... all layers of a graph in one launch
 WGRAD_LPT = _os.environ.get("MSDE_WGRAD_LPT", "1") != "0"            # grouped launch: problems with the longest workgroups first
 GROUPED_WGRAD = _os.environ.get("MSDE_GROUPED_WGRAD", "1") != "0"   # queued GEMMs -> one grouped launch at finish()
@@ -2251,8 +2256,11 @@ def _transpose_into(entries):
     tab = torch.zeros(n, 8, dtype=torch.int64)
     pre = torch.empty(n + 1, dtype=torch.int32)
     total = 0
-    for i, (src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode) in enumerate(blocks):
+    for i, blk in enumerate(blocks):
+        src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode = blk[:7]
         tab[i, 0], tab[i, 1], tab[i, 2], tab[i, 3], tab[i, 4], tab[i, 5], tab[i, 6] = src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode
+        if len(blk) > 7:        # modes 2 / 3: plane stride of the three bf16 planes (elements)
+            tab[i, 7] = blk[7]
         pre[i] = total
         total += ((r + 31) // 32) * ((c + 31) // 32)
     pre[n] = total
@@ -2260,8 +2268,13 @@ def _transpose_into(entries):
 
 
 def _fill_entry(ent):
-    for src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode in ent["blocks"]:
-        _lib.call("msde_relayout", ctypes.c_void_p(src_ptr), src_ld, ctypes.c_void_p(dst_ptr), dst_ld, r, c, mode, _stream())
+    for blk in ent["blocks"]:
+        src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode = blk[:7]
+        if mode >= 2:
+            _lib.call("msde_relayout_split", ctypes.c_void_p(src_ptr), src_ld, ctypes.c_void_p(dst_ptr), dst_ld, r, c, mode - 2,
+                      blk[7], _stream())
+        else:
+            _lib.call("msde_relayout", ctypes.c_void_p(src_ptr), src_ld, ctypes.c_void_p(dst_ptr), dst_ld, r, c, mode, _stream())
 
 
 def _clear_tables():
@@ -2321,6 +2334,22 @@ def weight_t(w):
         wt = torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device)
         return wt, [(w.data_ptr(), wt.data_ptr(), int(w.size(0)), int(w.size(1)), int(w.size(1)), int(w.size(0)), 0)]
     return _cached_layout(key, src, make)
+
+
+def weight_planes(w, transposed):
+    """EXPERIMENT (MSDE_BF16X3, csrc/gemm_t2b.hip): the 2-D fp32 parameter w [N][K] -- or its transpose when `transposed` --
+    split into three bf16 planes [3][rows][ld] (ld = the row length rounded up to 32, zero beyond it), hi + mid + lo = w
+    exactly.  Cached and refreshed like weight_t.  Returns (int16 buffer, ld)."""
+    assert isinstance(w, torch.nn.Parameter) and w.dim() == 2 and w.is_contiguous()
+    rows, cols = (int(w.size(1)), int(w.size(0))) if transposed else (int(w.size(0)), int(w.size(1)))
+    ld = (cols + 31) // 32 * 32
+    key = ("bf16x3", bool(transposed), id(w), rows, cols, w.data_ptr())
+
+    def make():
+        buf = torch.zeros(3, rows, ld, dtype=torch.int16, device=w.device)
+        return buf, [(w.data_ptr(), buf.data_ptr(), int(w.size(0)), int(w.size(1)), int(w.size(1)), ld, 3 if transposed else 2,
+                      rows * ld)]
+    return _cached_layout(key, (w,), make), ld
 
 
 def weight_layout(tag, params, shape, blocks):
@@ -2428,6 +2457,10 @@ def sync_weight_copies():
 
 _T2_MODE = _os.environ.get("MSDE_T2", "1")     # "0": every node-level product on the row strips (A/B measurements)
 _T2_OK = {}
+# EXPERIMENT, never the default and never the headline (bench.py reports it under its own key): the plain node-level
+# products (gemm_fwd / gemm_dgrad on parameters) with both operands split into three bf16 terms (csrc/gemm_t2b.hip).
+_BF16X3 = _os.environ.get("MSDE_BF16X3", "0") == "1"
+_BF16X3_PARTS = set(_os.environ.get("MSDE_BF16X3_PARTS", "fwd,dgrad,node").split(","))     # (bisection of the experiment)
 
 
 def t2_ok(M, N, K, axf=None):
@@ -2473,13 +2506,17 @@ def gemm_node(A, W, out, forward, N, K, **kw):
     # so that rs_geometry and every product of the chain agree on the strips)
     fused = kw.get("stats") is not None or kw.get("axf") is not None
     if t2_ok(M, N, K, "bnbwd" if fused else None):
+        if (_BF16X3 and "node" in _BF16X3_PARTS and kw.get("axf") is None and kw.get("A_out") is None
+                and isinstance(W, torch.nn.Parameter)):
+            planes, ld = weight_planes(W, not forward)      # (same strips of statistics partials as the fp32 tiles)
+            return gemm_rs(A, planes, out, N=N, K=K, t2b_ld=ld, **kw)
         return gemm_rs(A, W if forward else weight_t(W), out, N=N, K=K, t2=True, **kw)
     return gemm_rs(A, weight_t(W) if forward else W, out, b_kmajor=True, N=N, K=K, fallback=False, **kw)
 
 
 def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_kmajor=False, accumulate=False,
             axf=None, xf=(), relu=False, A2=None, A_out=None, stats=None, stats_mode=None, stats_z=None,
-            stats_mean=None, m_valid=None, N=None, K=None, rt=0, splits=0, fallback=True, t2=False):
+            stats_mean=None, m_valid=None, N=None, K=None, rt=0, splits=0, fallback=True, t2=False, t2b_ld=0):
     """out[M,N] = epilogue(xf(A) . B(^T) + bias) on msde_gemm_rs (see include/msde_hip.h: msde_rs_desc); no autograd.
     Returns `out`.  Shapes the row-strip kernels do not take (K % 4, unaligned operands) go to msde_gemm_ex when
     `fallback` and no fusion beyond bias / activation / derivative / accumulate is asked for; otherwise raises."""
@@ -2491,6 +2528,8 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
     d.N = int(N)
     d.A, d.lda = A.data_ptr(), _ld(A)
     d.B, d.ldb = B.data_ptr(), (B.stride(0) if B.dim() == 2 else (d.N if b_kmajor else d.K))
+    if t2b_ld:
+        d.ldb = int(t2b_ld)
     d.bias = bias.data_ptr() if bias is not None else None
     d.C, d.ldc = out.data_ptr(), _ld(out)
     if Z is not None:
@@ -2521,6 +2560,9 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
         m_valid = bound_tensor(M)
     d.m_valid = m_valid.data_ptr() if m_valid is not None else None
     d.rt, d.splits = int(rt), int(splits)
+    if t2b_ld:      # EXPERIMENT: the bf16x3 kernel (csrc/gemm_t2b.hip): B = three bf16 planes of the [N][K] operand
+        _lib.check(_lib.load().msde_gemm_t2b(ctypes.byref(d), _stream()), "msde_gemm_t2b")
+        return out
     if t2:          # the 2-D tiled kernel (csrc/gemm_t2.hip): B is the [N][K] operand
         _lib.check(_lib.load().msde_gemm_t2(ctypes.byref(d), _stream()), "msde_gemm_t2")
         return out
@@ -2542,6 +2584,9 @@ def gemm_fwd(x, W, out, bias=None, act=None, Z=None, res=None):
     N = W.size(0)
     if 0 < M <= RS_MAX_ROWS and rs_forward_ok(M, N, K, W) and x.data_ptr() % 16 == 0 and _ld(x) % 4 == 0:
         if t2_ok(M, N, K):        # 2-D tiles read the weight k-contiguous: as stored
+            if _BF16X3 and "fwd" in _BF16X3_PARTS and isinstance(W, torch.nn.Parameter):
+                planes, ld = weight_planes(W, False)
+                return gemm_rs(x, planes, out, bias=bias, act=act, Z=Z, res=res, N=N, K=K, t2b_ld=ld)
             return gemm_rs(x, W, out, bias=bias, act=act, Z=Z, res=res, N=N, K=K, t2=True)
         return gemm_rs(x, weight_t(W), out, bias=bias, act=act, Z=Z, res=res, b_kmajor=True, N=N, K=K, fallback=False)
     if res is not None:
@@ -2556,6 +2601,9 @@ def gemm_dgrad(g, W, out, act=None, dact_from=None, res=None):
     if (0 < M <= RS_MAX_ROWS and N % 4 == 0 and K % 4 == 0 and W.is_contiguous() and g.data_ptr() % 16 == 0
             and _ld(g) % 4 == 0):
         if t2_ok(M, K, N):        # ... for an input gradient that is the transposed copy [K][N]
+            if _BF16X3 and "dgrad" in _BF16X3_PARTS and isinstance(W, torch.nn.Parameter):
+                planes, ld = weight_planes(W, True)
+                return gemm_rs(g, planes, out, act=act, dact_from=dact_from, res=res, N=K, K=N, t2b_ld=ld)
             return gemm_rs(g, weight_t(W), out, act=act, dact_from=dact_from, res=res, N=K, K=N, t2=True)
         return gemm_rs(g, W, out, act=act, dact_from=dact_from, res=res, b_kmajor=True, N=K, K=N, fallback=False)
     if act == "sspo":

@@ -96,6 +96,7 @@ for use_graph in (False, True):
             tr_dp.step(b); tr_1.step(b)
     torch.cuda.synchronize()
     d = rel(tr_dp.opt.flat_p, tr_1.opt.flat_p)
+    print(f"rank {rank} graph={use_graph} identical shards: distance {d:.2e}", flush=True)
     assert d < 1e-6, ("identical shards", use_graph, d)
     # every rank holds the same parameters
     mine = tr_dp.opt.flat_p.clone()

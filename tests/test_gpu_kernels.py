@@ -1213,6 +1213,51 @@ def test_gemm_t2_plain(dev, M, N, K):
         assert torch.equal(out, out2), "gemm_t2 must be bitwise reproducible"
 
 
+@pytest.mark.parametrize("M,N,K", [(3588, 300, 300), (3588, 600, 300), (3588, 300, 600), (3588, 128, 300), (3588, 32, 300),
+                                   (3588, 728, 364), (3588, 728, 728), (35186, 32, 300), (777, 80, 64), (512, 176, 36),
+                                   (1030, 36, 4), (3588, 304, 16), (3588, 256, 100)])
+def test_gemm_t2b_bf16x3_experiment(dev, M, N, K):
+    """The bf16x3 EXPERIMENT (csrc/gemm_t2b.hip, off unless MSDE_BF16X3=1): the three bf16 planes of a weight sum to it bit
+    for bit (copy and transpose modes), and the six-term product on the bf16 matrix pipe meets the SAME tolerances against
+    fp64 as the fp32 kernel (test_gemm_t2_plain), every split count, NaN-filled outputs, reproducible."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(M * 5 + N + K)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = torch.nn.Parameter((torch.randn(N, K, generator=g) / K ** 0.5).to(dev))
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    planes, ld = hip.weight_planes(W, False)
+    assert ld % 32 == 0 and ld >= K and tuple(planes.shape) == (3, N, ld)
+    as_f32 = (planes.to(torch.int32) << 16).view(torch.float32)
+    assert torch.equal(as_f32.sum(0)[:, :K], W.detach()), "hi + mid + lo must be the weight exactly"
+    assert not as_f32[:, :, K:].any()
+    pt, ldt = hip.weight_planes(W, True)
+    tf32 = (pt.to(torch.int32) << 16).view(torch.float32)
+    assert torch.equal(tf32.sum(0)[:, :N], W.detach().t())
+    zr = A.double() @ W.detach().double().t() + b.double()
+    ref = _act_ref("ssp")(zr) + res.double()
+    for splits in (0, 1, 3):
+        if splits > (N + 15) // 16:
+            continue
+        out = torch.full((M, N), float("nan"), device=dev)
+        Z = torch.full((M, N), float("nan"), device=dev)
+        hip.gemm_rs(A, planes, out, bias=b, act="ssp", Z=Z, res=res, N=N, K=K, t2b_ld=ld, splits=splits)
+        assert_close(Z, zr, 1e-5, 2e-5, f"gemm_t2b pre-activation (splits {splits})")
+        assert_close(out, ref, 1e-5, 2e-5, f"gemm_t2b out (splits {splits})")
+        out2 = torch.full((M, N), float("nan"), device=dev)
+        hip.gemm_rs(A, planes, out2, bias=b, act="ssp", res=res, N=N, K=K, t2b_ld=ld, splits=splits)
+        assert torch.equal(out, out2), "gemm_t2b must be bitwise reproducible"
+    # and it is no worse than the fp32 kernel: errors of both against fp64
+    if hip.t2_ok(M, N, K):
+        o32 = torch.empty(M, N, device=dev)
+        o3 = torch.empty(M, N, device=dev)
+        hip.gemm_rs(A, W.detach(), o32, bias=b, N=N, K=K, t2=True)
+        hip.gemm_rs(A, planes, o3, bias=b, N=N, K=K, t2b_ld=ld)
+        e32 = (o32.double() - zr).abs().max().item()
+        e3 = (o3.double() - zr).abs().max().item()
+        assert e3 <= 4 * e32 + 1e-7, (e3, e32)
+
+
 @pytest.mark.parametrize("act", [None, "silu", "ssp", "relu", "tanh"])
 def test_gemm_rs_epilogues(dev, act):
     """Residual + accumulate into a column block of a wider buffer, and the input-gradient product through an activation
