@@ -566,7 +566,8 @@ extern "C" int msde_gemm_rs(const msde_rs_desc* desc, void* stream) {
 // ONE launch for any number of blocks.  table rows (long long x 8): {src, dst, rows, cols, src_ld, dst_ld, mode, 0} --
 // mode 0: dst[c * dst_ld + r] = src[r * src_ld + c] (transpose of a rows x cols block), mode 1: dst[r * dst_ld + c] =
 // src[r * src_ld + c] (copy of the block); modes 2 / 3: the copy / the transpose split into three bf16 planes (word 7 of the
-// row = plane stride in elements; gemm_t2b.hip); prefix[i] = first 32 x 32 tile of block i, prefix[n] = total.
+// row = plane stride in elements; gemm_t2b.hip); prefix[i] = first tile of block i, prefix[n] = total.  A tile is 32 x 32
+// source elements (modes 0 / 1), 32 rows x 64 columns (mode 2) or 64 rows x 32 columns (mode 3).
 // modes 2 / 3 (the bf16x3 experiment, csrc/gemm_t2b.hip): the block (mode 2) or its transpose (mode 3) split into three bf16
 // planes dst[plane * plane_stride + row * dst_ld + col] (16-bit elements): v = hi + mid + lo exactly, by truncation
 __device__ __forceinline__ void relayout_split_store(unsigned short* __restrict__ dst, size_t idx, long long plane_stride, float v) {
@@ -581,18 +582,45 @@ __device__ __forceinline__ void relayout_split_store(unsigned short* __restrict_
 
 __device__ __forceinline__ void relayout_tile(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
                                               int src_ld, int dst_ld, int mode, int t, float (*tile)[33], long long plane_stride = 0) {
-  const int tc = (cols + 31) >> 5;
-  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
   const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
-  if (mode == 2) {
+  if (mode >= 2) {
+    // split modes: a workgroup owns WHOLE 128-byte lines of the 16-bit planes (64 destination columns: two 32 x 32
+    // sub-tiles) -- with 64-byte pieces two workgroups, usually on different XCDs, write the halves of one line
     unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+    if (mode == 2) {
+      const int tc = (cols + 63) >> 6;
+      const int r0 = (t / tc) * 32, c0 = (t % tc) * 64;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int r = r0 + y + 8 * k, c = c0 + x;
-      if (r < rows && c < cols) relayout_split_store(d16, (size_t)r * dst_ld + c, plane_stride, src[(size_t)r * src_ld + c]);
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int hcol = 0; hcol < 2; ++hcol) {
+          const int r = r0 + y + 8 * k, c = c0 + 32 * hcol + x;
+          if (r < rows && c < cols) relayout_split_store(d16, (size_t)r * dst_ld + c, plane_stride, src[(size_t)r * src_ld + c]);
+        }
+      return;
+    }
+    const int tc = (cols + 31) >> 5;
+    const int c0 = (t % tc) * 32;
+#pragma unroll
+    for (int hrow = 0; hrow < 2; ++hrow) {
+      const int r0 = (t / tc) * 64 + 32 * hrow;
+      if (hrow) __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + y + 8 * k, c = c0 + x;
+        tile[y + 8 * k][x] = (r < rows && c < cols) ? src[(size_t)r * src_ld + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + y + 8 * k, r = r0 + x;
+        if (c < cols && r < rows) relayout_split_store(d16, (size_t)c * dst_ld + r, plane_stride, tile[x][y + 8 * k]);
+      }
     }
     return;
   }
+  const int tc = (cols + 31) >> 5;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
   if (mode == 1) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -610,10 +638,7 @@ __device__ __forceinline__ void relayout_tile(const float* __restrict__ src, flo
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int c = c0 + y + 8 * k, r = r0 + x;
-    if (c < cols && r < rows) {
-      if (mode == 3) relayout_split_store(reinterpret_cast<unsigned short*>(dst), (size_t)c * dst_ld + r, plane_stride, tile[x][y + 8 * k]);
-      else dst[(size_t)c * dst_ld + r] = tile[x][y + 8 * k];
-    }
+    if (c < cols && r < rows) dst[(size_t)c * dst_ld + r] = tile[x][y + 8 * k];
   }
 }
 
@@ -652,7 +677,8 @@ extern "C" int msde_relayout_split(const float* src, int src_ld, void* dst16, in
                                    long long plane_stride, void* stream) {
   if (rows <= 0 || cols <= 0) return 0;
   if (!src || !dst16 || src_ld < cols || dst_ld < (transpose ? rows : cols) || plane_stride <= 0) return MSDE_EINVAL;
-  MSDE_LAUNCH(transpose_one_kernel, dim3(((rows + 31) / 32) * ((cols + 31) / 32)), dim3(256), 0, as_stream(stream), src,
+  const int tiles = transpose ? ((rows + 63) / 64) * ((cols + 31) / 32) : ((rows + 31) / 32) * ((cols + 63) / 64);
+  MSDE_LAUNCH(transpose_one_kernel, dim3(tiles), dim3(256), 0, as_stream(stream), src,
               reinterpret_cast<float*>(dst16), rows, cols, src_ld, dst_ld, transpose ? 3 : 2, plane_stride);
   MSDE_CHECK_LAUNCH();
   return 0;

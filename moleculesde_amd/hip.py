@@ -2262,7 +2262,9 @@ def _transpose_into(entries):
         if len(blk) > 7:        # modes 2 / 3: plane stride of the three bf16 planes (elements)
             tab[i, 7] = blk[7]
         pre[i] = total
-        total += ((r + 31) // 32) * ((c + 31) // 32)
+        # (tiles of a block: 32 x 32 source elements; the split modes take 32 x 64 / 64 x 32 -- whole 128-byte lines)
+        total += (((r + 31) // 32) * ((c + 63) // 64) if mode == 2 else ((r + 63) // 64) * ((c + 31) // 32) if mode == 3
+                  else ((r + 31) // 32) * ((c + 31) // 32))
     pre[n] = total
     return tab, pre, total, dev
 
@@ -2338,11 +2340,11 @@ def weight_t(w):
 
 def weight_planes(w, transposed):
     """EXPERIMENT (MSDE_BF16X3, csrc/gemm_t2b.hip): the 2-D fp32 parameter w [N][K] -- or its transpose when `transposed` --
-    split into three bf16 planes [3][rows][ld] (ld = the row length rounded up to 32, zero beyond it), hi + mid + lo = w
+    split into three bf16 planes [3][rows][ld] (ld = the row length rounded up to 64, zero beyond it), hi + mid + lo = w
     exactly.  Cached and refreshed like weight_t.  Returns (int16 buffer, ld)."""
     assert isinstance(w, torch.nn.Parameter) and w.dim() == 2 and w.is_contiguous()
     rows, cols = (int(w.size(1)), int(w.size(0))) if transposed else (int(w.size(0)), int(w.size(1)))
-    ld = (cols + 31) // 32 * 32
+    ld = (cols + 63) // 64 * 64           # 128-byte rows: a line of the planes is written by one workgroup of the refresh
     key = ("bf16x3", bool(transposed), id(w), rows, cols, w.data_ptr())
 
     def make():

@@ -221,6 +221,13 @@ class Trainer:
         # hipGraph mode: one captured graph per batch shape (forward + backward + gradient flattening
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self.overlap_streams = True
+        from . import hip as _hipx
+        if os.environ.get("MSDE_ONE_STREAM") == "1":      # (measurements: the single-stream step)
+            self.overlap_streams = False
+        if _hipx._BF16X3 and os.environ.get("MSDE_BF16X3_TWO_STREAMS") != "1":
+            # the bf16x3 EXPERIMENT (csrc/gemm_t2b.hip) is reproducible only when no other kernel shares the chip with it:
+            # beside it, kernels of the second stream returned values that differ from replay to replay
+            self.overlap_streams = False
         self._side_stream = torch.cuda.Stream(device=device)
         self._one_grad = torch.ones((), dtype=torch.float32, device=device)
         if self._one_grad.is_cuda:

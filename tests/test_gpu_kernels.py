@@ -1227,7 +1227,7 @@ def test_gemm_t2b_bf16x3_experiment(dev, M, N, K):
     b = torch.randn(N, generator=g).to(dev)
     res = torch.randn(M, N, generator=g).to(dev)
     planes, ld = hip.weight_planes(W, False)
-    assert ld % 32 == 0 and ld >= K and tuple(planes.shape) == (3, N, ld)
+    assert ld % 64 == 0 and ld >= K and tuple(planes.shape) == (3, N, ld)
     as_f32 = (planes.to(torch.int32) << 16).view(torch.float32)
     assert torch.equal(as_f32.sum(0)[:, :K], W.detach()), "hi + mid + lo must be the weight exactly"
     assert not as_f32[:, :, K:].any()

@@ -11,11 +11,11 @@ for w in $WHAT; do
 case $w in
 bench)
   timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; cut -c1-200 $O/bench_default.json
-  timeout 600 python bench.py --full --no_cpu_baseline --no_configs45 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"; cut -c1-200 $O/bench_full.json;;
+  timeout 600 python bench.py --full --no_cpu_baseline --no_configs45 --no_bf16x3 > $O/bench_full.json 2> $O/bench_full.err; echo "bench full rc=$?"; cut -c1-200 $O/bench_full.json;;
 prof)
   cd /tmp
-  timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof -o run -- python3 $R/bench.py --no_cpu_baseline --no_configs45 > $O/prof_bench.json 2> $O/prof.log; echo "prof rc=$?"
-  timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_full -o run -- python3 $R/bench.py --full --no_cpu_baseline --no_configs45 > $O/prof_full_bench.json 2> $O/prof_full.log; echo "prof full rc=$?"
+  timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof -o run -- python3 $R/bench.py --no_cpu_baseline --no_configs45 --no_bf16x3 > $O/prof_bench.json 2> $O/prof.log; echo "prof rc=$?"
+  timeout 600 rocprofv3 --output-format csv --kernel-trace --stats -d $O/prof_full -o run -- python3 $R/bench.py --full --no_cpu_baseline --no_configs45 --no_bf16x3 > $O/prof_full_bench.json 2> $O/prof_full.log; echo "prof full rc=$?"
   cd $R
   cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/default_bench_kernel_stats.csv
   cp $(find $O/prof_full -name "*kernel_stats.csv" | head -1) $O/full_bench_kernel_stats.csv;;
@@ -33,7 +33,7 @@ tl)
   timeout 300 python tools/probes/step_timeline.py --bucket > $O/step_timeline_device_stamps.txt 2>/dev/null; cat $O/step_timeline_device_stamps.txt;;
 trace)
   cd /tmp
-  timeout 600 rocprofv3 --output-format csv --kernel-trace -d $O/trace -o run -- python3 $R/bench.py --no_cpu_baseline --no_configs45 --steps 12 --warmup 6 > $O/trace_bench.json 2> $O/trace.log; echo "trace rc=$?"
+  timeout 600 rocprofv3 --output-format csv --kernel-trace -d $O/trace -o run -- python3 $R/bench.py --no_cpu_baseline --no_configs45 --no_bf16x3 --steps 12 --warmup 6 > $O/trace_bench.json 2> $O/trace.log; echo "trace rc=$?"
   cd $R
   python tools/trace_step.py $O/trace > $O/step_kernel_order_under_rocprof.txt 2>&1; head -6 $O/step_kernel_order_under_rocprof.txt
   rm -rf $O/trace;;
