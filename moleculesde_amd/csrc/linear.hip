@@ -53,7 +53,7 @@ template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>
 __device__ __forceinline__ void
 gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                    float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
-                   int ldc, int k_per_split, const int bid_x, const int bid_y, const int bid_z) {
+                   int ldc, int k_per_split, const int bid_x, const int bid_y, const int bid_z, const bool edge_fast = false) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
   // k-major LDS images.  An operand that is k-major in memory is copied with aligned 16-B stores (row
   // stride BM+4); one that is row-major is transposed on the way in with scalar stores, for which the
@@ -133,19 +133,23 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   // offset from a wave-uniform tile base (scalar arithmetic, `saddr + voffset` loads).  The general path costs ~12
   // vector instructions per float4, and on this chip vector instructions take issue slots from the fp32 MFMAs
   // (DESIGN 4.17): ~50 per K tile against 16 MFMAs.
+  // EDGE tiles of the output (m0 + BM > M or n0 + BN > N) take the same path: a float4 whose columns lie beyond the operand's
+  // width (a whole float4: widths are multiples of 4 here) is read from the operand's LAST float4 instead -- valid memory,
+  // wrong values, and they only ever reach accumulator rows / columns >= M / N, which the epilogue does not store (and the
+  // column sums, which it does not store either).  Rows of the reduction are what must be exact, and full K tiles are.
   constexpr bool FAST = A_KM && B_KM && VEC;
-  const bool interior = FAST && m0 + BM <= M && n0 + BN <= N;
+  const bool interior = FAST && (edge_fast ? (M >= 4 && N >= 4) : (m0 + BM <= M && n0 + BN <= N));
   unsigned oa[NA], ob[NB];
   if (FAST) {
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
-      const int idx = p * 256 + tid, kr = idx / (BM / 4), mq = (idx % (BM / 4)) * 4;
-      oa[p] = (unsigned)(((size_t)kr * lda + mq) * 4);
+      const int idx = p * 256 + tid, kr = idx / (BM / 4), mq = min((idx % (BM / 4)) * 4, M - 4 - m0);
+      oa[p] = (unsigned)(((long long)kr * lda + mq) * 4);
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
-      const int idx = p * 256 + tid, kr = idx / (BN / 4), nq = (idx % (BN / 4)) * 4;
-      ob[p] = (unsigned)(((size_t)kr * ldb + nq) * 4);
+      const int idx = p * 256 + tid, kr = idx / (BN / 4), nq = min((idx % (BN / 4)) * 4, N - 4 - n0);
+      ob[p] = (unsigned)(((long long)kr * ldb + nq) * 4);
     }
   }
   auto load_tile_fast = [&](float4 (&ra)[NA], float4 (&rb)[NB], int k0) {
@@ -199,6 +203,12 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   float csum = 0.f;  // column sum of A over k (weight-gradient mode: bias gradient), thread tid < BM
 
   const bool quadrant_live = !LG_SKIP_DEAD || ((m0 + wm * 32 * TM < M) && (n0 + wn * 32 * TN < N));
+  bool sub_live[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      sub_live[i][j] = (m0 + (wm * TM + i) * 32 < M) && (n0 + (wn * TN + j) * 32 < N);
   auto compute_tile = [&]() {
     if (TM == 1 && TN == 1) {
       // a wave whose 32 x 32 quadrant lies entirely outside the product (narrow layers: N or K <= 32 fill one or two
@@ -221,6 +231,8 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
       __builtin_amdgcn_s_setprio(0);
       }
     } else {
+    // (32 x 32 sub-tiles that lie entirely outside the product are skipped: a 300-wide dimension covers 10 of them, not 12)
+    __builtin_amdgcn_s_setprio(LG_PRIO);
 #pragma unroll
     for (int kk = 0; kk < LG_BK / 2; ++kk) {
       float af[TM], bf[TN];
@@ -232,8 +244,10 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          if (!LG_SKIP_DEAD || sub_live[i][j])
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
     }
     if (colsum_ws != nullptr && bid_x == 0) {
       if (BM == 64) {
@@ -334,8 +348,8 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
 // (ldg / ldx: row strides of gY / X -- operands may be column blocks of wider buffers);
 // prefix[p] = workgroups before problem p.  A workgroup finds its problem by binary search and then runs the very
 // same tile body as the per-layer kernel (64 x 64 tiles), so results are bit-identical to it.
-__global__ void __launch_bounds__(256)
-gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
+__device__ __forceinline__ void
+gemm_grouped_wgrad_body(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
                           int xcd_order) {
   // grid == total: one tile per workgroup.  grid < total (msde_linear_bwd_w_grouped_ex with a width limit): each
   // workgroup walks tiles blockIdx.x, + gridDim.x, ...: the launch then occupies at most gridDim.x workgroup slots, so it
@@ -366,11 +380,23 @@ gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __rest
     const int bx = local % tx, by = (local / tx) % ty, bz = local / (tx * ty);
     // product C[N][K] = gY^T X: "M" of the product = N, "N" = K, reduction = M (see msde_linear_bwd_w)
     if (e[11])
-      gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
+      gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz, e[15] != 0);
     else
       gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
     __syncthreads();                 // the next tile reuses the LDS stages
   }
+}
+
+__global__ void __launch_bounds__(256)
+gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
+                          int xcd_order) {
+  gemm_grouped_wgrad_body(probs, prefix, count, total, xcd_order);
+}
+// the same with the register budget of FOUR workgroups per CU (128 VGPRs; the default build takes 140: three)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+gemm_grouped_wgrad_occ4_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
+                               int xcd_order) {
+  gemm_grouped_wgrad_body(probs, prefix, count, total, xcd_order);
 }
 
 // out[i] = sum_z slabs[z][i] for the weight slabs (n entries) and, in the same launch, the bias-gradient
@@ -519,6 +545,16 @@ static inline void wgrad_split_for(int M, int N, int K, int target, int* splits,
   *splits = M > 0 ? (M + kps - 1) / kps : 1;
 }
 
+// Split plan of one problem of the grouped launch, a function of the SHAPE only (the caller sizes the slabs from it before
+// the operands' addresses are known).  Round 4 tried 128 x 128 tiles here for the node-level layers (2 x 2 sub-tiles per wave,
+// dead 32 x 32 sub-tiles skipped; half the operand traffic per FLOP and half the barriers): 2.78 against 2.73 ms per step --
+// the body then needs 216 VGPRs, two workgroups per CU, and the 64 x 64 tiles hide their load -> store -> barrier phases
+// behind six other workgroups instead.
+static inline bool wgrad_group_plan(int M, int N, int K, int* splits, int* k_per_split) {
+  wgrad_split_batched(M, N, K, splits, k_per_split);
+  return false;
+}
+
 extern "C" long long msde_linear_bwd_w_workspace_bytes(int M, int N, int K) {
   int splits, kps;
   wgrad_split(M, N, K, &splits, &kps);
@@ -641,13 +677,16 @@ extern "C" int msde_linear_bwd_w_describe(const float* gY, const float* X, int M
 extern "C" int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const float* X, int ldx, int M, int N, int K,
                                              int want_bias, float* slabs, const int* rows_dev, long long* row) {
   if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs || !row || ldg < N || ldx < K) return MSDE_EINVAL;
-  if (wgrad_big(M, N, K)) return MSDE_EUNSUP;        // the grouped kernel is built for 64 x 64 tiles
+  if (wgrad_big(M, N, K)) return MSDE_EUNSUP;
+  bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0);
   int splits, kps;
-  wgrad_split_batched(M, N, K, &splits, &kps);
+  wgrad_group_plan(M, N, K, &splits, &kps);
   int tx = (K + 63) / 64, ty = (N + 63) / 64;
-  bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (kps % 4 == 0) && (ldg % 4 == 0) &&
-             (ldx % 4 == 0);
-  row[12] = ldg; row[13] = ldx; row[14] = reinterpret_cast<long long>(rows_dev); row[15] = 0;
+  vec = vec && (kps % 4 == 0);
+  // (round 4, tools/ab_multi.sh on one box: edge tiles on the fast path 2.70-2.73 vs 2.69-2.72 ms, the 128-VGPR build
+  // MSDE_WGRAD_OCC4 2.70-2.71, register prefetch two / three tiles deep (-DLG_ST) 2.72 vs 2.71: none of them moves the step)
+  static const int relax = env_int("MSDE_WGRAD_EDGE_FAST", 0);
+  row[12] = ldg; row[13] = ldx; row[14] = reinterpret_cast<long long>(rows_dev); row[15] = relax;
   row[0] = reinterpret_cast<long long>(gY);
   row[1] = reinterpret_cast<long long>(X);
   row[2] = reinterpret_cast<long long>(slabs);
@@ -662,8 +701,13 @@ extern "C" int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* p
   if (count == 0 || total_blocks == 0) return 0;
   static const int xcd = env_int("MSDE_WGRAD_XCD", 1);
   const int grid = max_workgroups > 0 && max_workgroups < total_blocks ? max_workgroups : total_blocks;
-  MSDE_LAUNCH(gemm_grouped_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), probs, prefix, count, total_blocks,
-              grid == total_blocks ? xcd : 0);
+  static const int occ4 = env_int("MSDE_WGRAD_OCC4", 0);
+  if (occ4)
+    MSDE_LAUNCH(gemm_grouped_wgrad_occ4_kernel, dim3(grid), dim3(256), 0, as_stream(stream), probs, prefix, count, total_blocks,
+                grid == total_blocks ? xcd : 0);
+  else
+    MSDE_LAUNCH(gemm_grouped_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), probs, prefix, count, total_blocks,
+                grid == total_blocks ? xcd : 0);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -675,7 +719,7 @@ extern "C" int msde_linear_bwd_w_grouped(const long long* probs, const int* pref
 
 extern "C" int msde_linear_bwd_w_splits(int M, int N, int K) {
   int splits, kps;
-  wgrad_split_batched(M, N, K, &splits, &kps);
+  wgrad_group_plan(M, N, K, &splits, &kps);
   return splits;
 }
 
@@ -685,7 +729,7 @@ extern "C" int msde_linear_bwd_w_partial(const float* gY, const float* X, int M,
                                          float* slabs, const int* rows_dev, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !gY || !X || !slabs) return MSDE_EINVAL;
   int splits, k_per_split;
-  wgrad_split_batched(M, N, K, &splits, &k_per_split);
+  wgrad_group_plan(M, N, K, &splits, &k_per_split);       // (same splits as the grouped launch: the caller sized the slabs from them)
   float* cs = want_bias ? slabs + (size_t)splits * N * K : nullptr;
   return launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, wgrad_big(M, N, K),
                                  as_stream(stream), rows_dev);

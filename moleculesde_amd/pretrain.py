@@ -96,6 +96,7 @@ SIDE_WGRAD = os.environ.get("MSDE_SIDE_WGRAD", "0") != "0"   # second stream's w
 SIDE_WGRAD_WGS = int(os.environ.get("MSDE_SIDE_WGRAD_WGS", "0"))   # 0: full width
 SCHNET_AFTER_GIN = os.environ.get("MSDE_SCHNET_AFTER_GIN", "0") != "0"   # experiment: start SchNet when GIN's forward is done
 PLAN_LISTS_ON_SIDE = os.environ.get("MSDE_PLAN_LISTS_ON_SIDE", "1") != "0"   # bucket mode: embedding row lists off the main chain
+LEAF_SERIAL = os.environ.get("MSDE_LEAF_SERIAL", "0") != "0"   # (measurement, round 4) leaf kernels in front of the grouped launch on the same stream: 2.75 vs 2.72 ms; on a high-priority third stream: 6.2 ms
 BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
 GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
 EARLY_GEOMETRY = os.environ.get("MSDE_EARLY_GEO", "0") != "0"   # start the 2D->3D coordinate branch before the encoders (measured: 2% slower at bs256, so off)
@@ -238,7 +239,9 @@ class Trainer:
             # GIN) on the same stream: they run while the second stream still finishes SchNet's backward, and only
             # SchNet's own weight gradients are left for the tail of the step
             from . import hip as _hip4
-            self.models["model_2D"].on_input_grad = _hip4.flush_wgrad_gemms
+            wgs = int(os.environ.get("MSDE_EARLY_WGRAD_WGS", "0"))
+            self.models["model_2D"].on_input_grad = (lambda: _hip4.flush_wgrad_gemms(wgs, only_stream=(
+                torch.cuda.current_stream().cuda_stream if os.environ.get("MSDE_EARLY_WGRAD_OWN", "1") != "0" else None)))
         self._bn_modules = [mod for m_ in self.models.values() for mod in m_.modules() if isinstance(mod, _nn.BatchNorm1d)]
         # Measured on MI355X (tools/marginal_cost.py, hipGraph replay, bs 256): 1 stream 5.26 ms, SchNet beside the
         # 2D branch 4.55 ms, a third stream for the 2D->3D coordinate branch 4.73 ms, weight gradients on a fourth
@@ -455,11 +458,15 @@ class Trainer:
                     # reads) run on the second stream BESIDE the grouped weight-gradient launch instead of inside the
                     # backward chain.  Host order: everything of SchNet's backward is already queued on that stream.
                     main_, side_ = torch.cuda.current_stream(), self._side_stream
-                    side_.wait_stream(main_)
-                    with torch.cuda.stream(side_):
+                    if LEAF_SERIAL:
                         hip.run_deferred_leaf_kernels()
-                    hip.flush_wgrad_gemms()
-                    main_.wait_stream(side_)
+                        hip.flush_wgrad_gemms()
+                    else:
+                        side_.wait_stream(main_)
+                        with torch.cuda.stream(side_):
+                            hip.run_deferred_leaf_kernels()
+                        hip.flush_wgrad_gemms()
+                        main_.wait_stream(side_)
                 if hip.STAMPS is not None and self.overlap_streams:
                     with torch.cuda.stream(self._side_stream):
                         hip.stamp("bwd_side_end")
