@@ -149,6 +149,28 @@ int msde_segment_sum_rows2(const float* rows, int ldi, const int* rowptr, const 
  * SDE_model_2D_to_3D.py:346-347 (factored cat+Linear), equivariant_scorenetwork.py:154-155 */
 int msde_pair_gather_add(const float* A, const float* B, int ld, const int* src, const int* dst, int E,
                          int D, float* out, void* stream);
+/* edge_2D_emb of the 2D->3D model fused around the gather (SDE_model_2D_to_3D.py:35-40,264-271; hip._PairBnReluLinear):
+ * msde_pair_gather_add_stats = msde_pair_gather_add that also writes the BatchNorm statistics of its result per strip of
+ * msde_pair_strip() edges, stats[strip][2][D] in the MSDE_RS_STATS_BNFWD format over the valid edges (e < *e_valid, or E) -- finish with
+ * msde_bn_fin_fwd(stats, ceil(E / strip), strip, ...).  msde_segment_sum_rows_bn: out[i] = p * sum G[e] + w * sum Z[e] + n_i * u
+ * over node i's CSR segment (n_i edges; perm = edge ids or NULL): the segment sum of the BatchNorm input gradient
+ * p G + w Z + u (vectors of msde_bn_fin_bwd) without materialising it.  D % 4 == 0, 16-byte aligned; else MSDE_EUNSUP. */
+int msde_pair_gather_add_stats(const float* A, const float* B, int ld, const int* src, const int* dst, int E, int D,
+                               const int* e_valid, float* out, float* stats, void* stream);
+int msde_segment_sum_rows_bn(const float* G, const float* Z, int ld, const int* rowptr, const int* perm, int N, int D,
+                             const float* p, const float* w, const float* u, float* out, int ldo, void* stream);
+/* The backward half of the same fusion.  msde_pair_bn_dgrad_stats: GA[e] = (g[e] W) gated where scale z + shift <= 0
+ * (g [E, H], H = 16 or 32, row stride ldg; W [H][D] as nn.Linear stores the second Linear's weight; z = Z[e], the gathered
+ * sums) together with the strip sums (sum GA, sum GA (z - mean)) of MSDE_RS_STATS_BNBWD over strips of msde_pair_strip()
+ * edges -> msde_bn_fin_bwd.  msde_pair_bn_scatter: gAB [N, 2 D] = gradient of AB through dz = p GA + w z + u, one launch
+ * for both column blocks (by-source and by-target segments; sum z over a segment is rebuilt from AB's own rows). */
+int msde_pair_strip(void);
+int msde_pair_bn_dgrad_stats(const float* g, int ldg, const float* W, const float* Z, const float* scale, const float* shift,
+                             const float* mean, int E, int H, int D, const int* e_valid, float* GA, float* stats,
+                             void* stream);
+int msde_pair_bn_scatter(const float* GA, const float* AB, int D, const int* src, const int* dst, const int* rowptr_s,
+                         const int* perm_s, const int* rowptr, int N, const float* p, const float* w, const float* u,
+                         float* gAB, void* stream);
 /* out[e] = [X[src[e]] + X[dst[e]] | C[e]] ([E, D + D2], rows with src<0 zero): the gather writes the concatenation
  * cat([h_row + h_col, edge_attr]) that the basis MLP reads (equivariant_scorenetwork.py:154-157).  Row strides ldx,
  * ldc in floats; D, D2, ldx, ldc multiples of 4 and 16-byte aligned bases (else MSDE_EUNSUP). */

@@ -23,6 +23,11 @@ SIGNATURES = {
     "msde_segment_sum_rows": [P, I, P, P, I, I, F, P, I, P],
     "msde_segment_sum_rows2": [P, I, P, P, P, P, I, I, F, P, I, P],
     "msde_pair_gather_add": [P, P, I, P, P, I, I, P, P],
+    "msde_pair_gather_add_stats": [P, P, I, P, P, I, I, P, P, P, P],
+    "msde_segment_sum_rows_bn": [P, P, I, P, P, I, I, P, P, P, P, I, P],
+    "msde_pair_strip": [],
+    "msde_pair_bn_dgrad_stats": [P, I, P, P, P, P, P, I, I, I, P, P, P, P],
+    "msde_pair_bn_scatter": [P, P, I, P, P, P, P, P, I, P, P, P, P, P],
     "msde_pair_gather_cat": [P, I, P, I, P, P, I, I, I, P, P],
     "msde_mlp_head_fwd": [P, I, P, P, I, I, I, P, P],
     "msde_mlp_head_bwd_slabs": [I, I],

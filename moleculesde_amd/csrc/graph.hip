@@ -309,6 +309,335 @@ extern "C" int msde_pair_gather_add(const float* A, const float* B, int ld, cons
   return 0;
 }
 
+#define MSDE_PAIR_STRIP 128      // edges per statistics strip of the fused edge_2D_emb kernels (hip.PAIR_STRIP must agree)
+// ---- edge_2D_emb of the 2D->3D model (SDE_model_2D_to_3D.py:35-40,264-271: Linear(cat(h_row, h_col)) -> BatchNorm1d -> ReLU ->
+// Linear), fused around the gather (hip._PairBnReluLinear):
+//   forward   pre[e] = A[src_e] + B[dst_e] written ONCE together with its per-strip BatchNorm statistics (this kernel; the
+//             separate statistics pass re-read the 42 MB tensor), BatchNorm apply + ReLU in the A load of the second Linear;
+//   backward  the BatchNorm input gradient dz = p g + w z + u is linear in (g, z), so the two segment sums over a node's
+//             edges are taken of g and z themselves and combined per column afterwards (msde_segment_sum_rows_bn): dz is
+//             never materialised.
+// One workgroup per strip of SR edges: CL = D / 4 column lanes x RL = 512 / CL row lanes (450 of 512 threads at D = 300).
+// Statistics per strip and column in the MSDE_RS_STATS_BNFWD format (mean, sum of squared deviations) over the VALID edges
+// (e < *e_valid, or E), accumulated around the strip's first row (shifted sums: no cancellation for columns far from zero).
+__global__ void __launch_bounds__(512)
+pair_gather_add_stats_kernel(const float4* __restrict__ A, const float4* __restrict__ B, int ld4, const int* __restrict__ src,
+                             const int* __restrict__ dst, int E, const int* __restrict__ e_valid, int CL, int SR,
+                             float4* __restrict__ out, float* __restrict__ stats) {
+  __shared__ float4 p1[512], p2[512];
+  const int RL = 512 / CL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int e0 = blockIdx.x * SR;
+  const int ev = e_valid ? min(E, e_valid[0]) : E;
+  const bool active = rl < RL;
+  float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), s1 = sh, s2 = sh;
+  if (active && e0 < ev) {
+    const int j = src[e0], i = dst[e0];
+    if (j >= 0) sh = vadd(A[(size_t)j * ld4 + cl], B[(size_t)i * ld4 + cl]);
+  }
+  if (active) {
+    for (int r = rl; r < SR; r += 4 * RL) {        // four rows in flight per lane
+      float4 v[4];
+      int e[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        e[k] = e0 + r + k * RL;
+        const bool in = (r + k * RL < SR) && e[k] < E;
+        const int j = in ? src[e[k]] : -1, i = in ? dst[e[k]] : 0;
+        v[k] = j >= 0 ? vadd(A[(size_t)j * ld4 + cl], B[(size_t)i * ld4 + cl]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!in) e[k] = -1;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (e[k] < 0) continue;
+        out[(size_t)e[k] * CL + cl] = v[k];
+        if (e[k] < ev) {
+          const float4 d = make_float4(v[k].x - sh.x, v[k].y - sh.y, v[k].z - sh.z, v[k].w - sh.w);
+          s1 = vadd(s1, d);
+          s2.x = fmaf(d.x, d.x, s2.x); s2.y = fmaf(d.y, d.y, s2.y); s2.z = fmaf(d.z, d.z, s2.z); s2.w = fmaf(d.w, d.w, s2.w);
+        }
+      }
+    }
+  }
+  p1[threadIdx.x] = s1;
+  p2[threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0) {
+    for (int q = 1; q < RL; ++q) { s1 = vadd(s1, p1[q * CL + cl]); s2 = vadd(s2, p2[q * CL + cl]); }     // row lanes in order
+    const int n = max(0, min(SR, ev - e0));
+    const float inv = n > 0 ? 1.f / (float)n : 0.f;
+    float4 mean, m2;
+    mean.x = sh.x + s1.x * inv; mean.y = sh.y + s1.y * inv; mean.z = sh.z + s1.z * inv; mean.w = sh.w + s1.w * inv;
+    m2.x = fmaxf(s2.x - s1.x * s1.x * inv, 0.f); m2.y = fmaxf(s2.y - s1.y * s1.y * inv, 0.f);
+    m2.z = fmaxf(s2.z - s1.z * s1.z * inv, 0.f); m2.w = fmaxf(s2.w - s1.w * s1.w * inv, 0.f);
+    float4* st = reinterpret_cast<float4*>(stats + (size_t)blockIdx.x * 2 * (4 * CL));
+    st[cl] = mean;
+    st[CL + cl] = m2;
+  }
+}
+
+// out[e] = A[src_e] + B[dst_e] (rows of width D, row stride ld of A / B) and stats[strip][2][D] over strips of
+// MSDE_PAIR_STRIP edges (msde_bn_fin_fwd with that strip_rows).  D % 4 == 0, D <= 1024, 16-byte aligned operands.
+extern "C" int msde_pair_gather_add_stats(const float* A, const float* B, int ld, const int* src, const int* dst, int E,
+                                          int D, const int* e_valid, float* out, float* stats, void* stream) {
+  if (E < 0 || D <= 0 || !A || !B || !src || !dst || !out || !stats) return MSDE_EINVAL;
+  if (ld == 0) ld = D;
+  if (ld < D) return MSDE_EINVAL;
+  if (D % 4 || ld % 4 || D > 1024 ||
+      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(out) |
+        reinterpret_cast<uintptr_t>(stats)) & 15))
+    return MSDE_EUNSUP;
+  if (E == 0) return 0;
+  MSDE_LAUNCH(pair_gather_add_stats_kernel, dim3((E + MSDE_PAIR_STRIP - 1) / MSDE_PAIR_STRIP), dim3(512), 0, as_stream(stream),
+              reinterpret_cast<const float4*>(A), reinterpret_cast<const float4*>(B), ld / 4, src, dst, E, e_valid, D / 4,
+              MSDE_PAIR_STRIP, reinterpret_cast<float4*>(out), stats);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward half: GA[e] = (g[e] W) gated by the ReLU behind the BatchNorm (scale z + shift > 0, z = Z[e]: the sign the forward
+// product's A load saw), written once, with the BatchNorm-backward strip sums (sum GA, sum GA (z - mean)) of MSDE_RS_STATS_BNBWD
+// over strips of MSDE_PAIR_STRIP edges.  g [E, H] with H <= 32: the product is 32 multiply-adds per output, done on the
+// vector units from a register copy of W's column quad (the 2-D tiled product spends its time in a 300-column epilogue
+// when K = 32: 111 us against ~25 here).  Thread layout of pair_gather_add_stats_kernel.
+template <int H>
+__device__ __forceinline__ float4 pbd_row(const float* __restrict__ gr_, const float4 (&w)[H]) {
+  const float4* gr = reinterpret_cast<const float4*>(gr_);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < H / 4; ++q) {
+    const float4 gv = gr[q];
+    a.x = fmaf(gv.x, w[4 * q].x, a.x); a.y = fmaf(gv.x, w[4 * q].y, a.y); a.z = fmaf(gv.x, w[4 * q].z, a.z); a.w = fmaf(gv.x, w[4 * q].w, a.w);
+    a.x = fmaf(gv.y, w[4 * q + 1].x, a.x); a.y = fmaf(gv.y, w[4 * q + 1].y, a.y); a.z = fmaf(gv.y, w[4 * q + 1].z, a.z); a.w = fmaf(gv.y, w[4 * q + 1].w, a.w);
+    a.x = fmaf(gv.z, w[4 * q + 2].x, a.x); a.y = fmaf(gv.z, w[4 * q + 2].y, a.y); a.z = fmaf(gv.z, w[4 * q + 2].z, a.z); a.w = fmaf(gv.z, w[4 * q + 2].w, a.w);
+    a.x = fmaf(gv.w, w[4 * q + 3].x, a.x); a.y = fmaf(gv.w, w[4 * q + 3].y, a.y); a.z = fmaf(gv.w, w[4 * q + 3].z, a.z); a.w = fmaf(gv.w, w[4 * q + 3].w, a.w);
+  }
+  return a;
+}
+
+template <int H>
+__global__ void __launch_bounds__(512)
+pair_bn_dgrad_stats_kernel(const float* __restrict__ g, int ldg, const float4* __restrict__ W, const float4* __restrict__ Z,
+                           const float4* __restrict__ scale, const float4* __restrict__ shift, const float4* __restrict__ mean,
+                           int E, const int* __restrict__ e_valid, int CL, int SR, float4* __restrict__ GA,
+                           float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) float gs[];      // [SR][H] gradient rows of the strip
+  __shared__ float4 p1[512], p2[512];
+  const int RL = 512 / CL;
+  const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+  const int e0 = blockIdx.x * SR;
+  const int ev = e_valid ? min(E, e_valid[0]) : E;
+  const bool active = rl < RL;
+  for (int t = threadIdx.x; t < SR * (H / 4); t += 512) {
+    const int r = t / (H / 4), q = t - r * (H / 4);
+    const int e = e0 + r;
+    reinterpret_cast<float4*>(gs)[t] = e < E ? *reinterpret_cast<const float4*>(g + (size_t)e * ldg + 4 * q)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 w[H];
+  float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sf = sc, mu = sc;
+  if (active) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) w[h] = W[(size_t)h * CL + cl];
+    sc = scale[cl]; sf = shift[cl]; mu = mean[cl];
+  }
+  __syncthreads();
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  auto finish = [&](int e, float4 a, const float4& z) __attribute__((always_inline)) {
+    a.x = fmaf(z.x, sc.x, sf.x) > 0.f ? a.x : 0.f;
+    a.y = fmaf(z.y, sc.y, sf.y) > 0.f ? a.y : 0.f;
+    a.z = fmaf(z.z, sc.z, sf.z) > 0.f ? a.z : 0.f;
+    a.w = fmaf(z.w, sc.w, sf.w) > 0.f ? a.w : 0.f;
+    GA[(size_t)e * CL + cl] = a;
+    if (e < ev) {
+      s1 = vadd(s1, a);
+      s2.x = fmaf(a.x, z.x - mu.x, s2.x); s2.y = fmaf(a.y, z.y - mu.y, s2.y);
+      s2.z = fmaf(a.z, z.z - mu.z, s2.z); s2.w = fmaf(a.w, z.w - mu.w, s2.w);
+    }
+  };
+  if (active) {
+    // the z rows of this lane's next FOUR edges are requested before the 4 x 32 x 4 multiply-adds of the current four
+    const int nrows = min(SR, E - e0);
+    for (int r = rl; r < nrows; r += 4 * RL) {
+      float4 z[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rr = r + k * RL;
+        z[k] = rr < nrows ? Z[(size_t)(e0 + rr) * CL + cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rr = r + k * RL;
+        if (rr < nrows) finish(e0 + rr, pbd_row<H>(gs + rr * H, w), z[k]);
+      }
+    }
+  }
+  p1[threadIdx.x] = s1;
+  p2[threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0) {
+    for (int q = 1; q < RL; ++q) { s1 = vadd(s1, p1[q * CL + cl]); s2 = vadd(s2, p2[q * CL + cl]); }
+    float4* st = reinterpret_cast<float4*>(stats + (size_t)blockIdx.x * 2 * (4 * CL));
+    st[cl] = s1;
+    st[CL + cl] = s2;
+  }
+}
+
+extern "C" int msde_pair_bn_dgrad_stats(const float* g, int ldg, const float* W, const float* Z, const float* scale,
+                                        const float* shift, const float* mean, int E, int H, int D, const int* e_valid,
+                                        float* GA, float* stats, void* stream) {
+  if (E < 0 || H <= 0 || D <= 0 || !g || !W || !Z || !scale || !shift || !mean || !GA || !stats) return MSDE_EINVAL;
+  if (ldg <= 0) ldg = H;
+  if ((H != 16 && H != 32) || D % 4 || D > 1024 || ldg % 4 ||
+      ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Z) |
+        reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(mean) |
+        reinterpret_cast<uintptr_t>(GA) | reinterpret_cast<uintptr_t>(stats)) & 15))
+    return MSDE_EUNSUP;
+  if (E == 0) return 0;
+  const dim3 grid((E + MSDE_PAIR_STRIP - 1) / MSDE_PAIR_STRIP);
+  const size_t lds = (size_t)MSDE_PAIR_STRIP * H * sizeof(float);
+#define PBD_GO(H_) MSDE_LAUNCH(pair_bn_dgrad_stats_kernel<H_>, grid, dim3(512), lds, as_stream(stream), g, ldg,                     \
+                               reinterpret_cast<const float4*>(W), reinterpret_cast<const float4*>(Z),                             \
+                               reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(shift),                    \
+                               reinterpret_cast<const float4*>(mean), E, e_valid, D / 4, MSDE_PAIR_STRIP,                          \
+                               reinterpret_cast<float4*>(GA), stats)
+  if (H == 16) PBD_GO(16); else PBD_GO(32);
+#undef PBD_GO
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// Gradient of AB = [A | B] [N, 2 D] for pre[e] = A[src_e] + B[dst_e] through the BatchNorm input gradient dz = p GA + w z + u
+// (z = pre), ONE launch over 2 N rows: row j < N is node j's by-SOURCE segment (gradient of A[j]), row N + i node i's
+// by-TARGET segment (gradient of B[i]).  sum_e z[e] over a segment is taken from AB itself -- n A[j] + sum B[dst_e], or
+// sum A[src_e] + n B[i] -- whose rows stay in L2, instead of from the [E, D] tensor: only GA is streamed from memory.
+__global__ void __launch_bounds__(256)
+pair_bn_scatter_kernel(const float4* __restrict__ GA, const float4* __restrict__ AB, int ldab4,
+                       const int* __restrict__ src, const int* __restrict__ dst,
+                       const int* __restrict__ rowptr_s, const int* __restrict__ perm_s,
+                       const int* __restrict__ rowptr, int N, int cols, const float4* __restrict__ p,
+                       const float4* __restrict__ w, const float4* __restrict__ u, float4* __restrict__ out, int ldo4) {
+  // one column quad per thread, 256 / cols rows per workgroup (3 x 75 = 225 of 256 threads at D = 300)
+  const int rpb = 256 / cols;
+  const int c = threadIdx.x % cols, rw = threadIdx.x / cols;
+  const int row = blockIdx.x * rpb + rw;
+  if (rw >= rpb || row >= 2 * N) return;
+  const bool by_src = row < N;
+  const int i = by_src ? row : row - N;
+  const int* rp = by_src ? rowptr_s : rowptr;
+  const int s0 = rp[i], s1 = rp[i + 1];
+  const float cnt = (float)(s1 - s0);
+  const float4* other = AB + (by_src ? cols : 0);                         // B[.] / A[.] of the edge's other end
+  const int* oidx = by_src ? dst : src;
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), az = ag;
+  int s = s0;
+  for (; s + 3 < s1; s += 4) {
+    int e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = by_src ? perm_s[s + k] : s + k;
+    float4 gv[4], zv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gv[k] = GA[(size_t)e[k] * cols + c];
+      zv[k] = other[(size_t)oidx[e[k]] * ldab4 + c];
+    }
+    ag = vadd(vadd(vadd(vadd(ag, gv[0]), gv[1]), gv[2]), gv[3]);
+    az = vadd(vadd(vadd(vadd(az, zv[0]), zv[1]), zv[2]), zv[3]);
+  }
+  for (; s < s1; ++s) {
+    const int e = by_src ? perm_s[s] : s;
+    ag = vadd(ag, GA[(size_t)e * cols + c]);
+    az = vadd(az, other[(size_t)oidx[e] * ldab4 + c]);
+  }
+  const float4 o = AB[(size_t)i * ldab4 + (by_src ? 0 : cols) + c], pv = p[c], wv = w[c], uv = u[c];
+  float4 r;
+  r.x = fmaf(pv.x, ag.x, fmaf(wv.x, fmaf(cnt, o.x, az.x), cnt * uv.x));
+  r.y = fmaf(pv.y, ag.y, fmaf(wv.y, fmaf(cnt, o.y, az.y), cnt * uv.y));
+  r.z = fmaf(pv.z, ag.z, fmaf(wv.z, fmaf(cnt, o.z, az.z), cnt * uv.z));
+  r.w = fmaf(pv.w, ag.w, fmaf(wv.w, fmaf(cnt, o.w, az.w), cnt * uv.w));
+  out[(size_t)i * ldo4 + (by_src ? 0 : cols) + c] = r;
+}
+
+extern "C" int msde_pair_bn_scatter(const float* GA, const float* AB, int D, const int* src, const int* dst,
+                                    const int* rowptr_s, const int* perm_s, const int* rowptr, int N, const float* p,
+                                    const float* w, const float* u, float* gAB, void* stream) {
+  if (N < 0 || D <= 0 || !GA || !AB || !src || !dst || !rowptr_s || !perm_s || !rowptr || !p || !w || !u || !gAB)
+    return MSDE_EINVAL;
+  if (D % 4 || ((reinterpret_cast<uintptr_t>(GA) | reinterpret_cast<uintptr_t>(AB) | reinterpret_cast<uintptr_t>(gAB) |
+                 reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(u)) & 15))
+    return MSDE_EUNSUP;
+  if (N == 0) return 0;
+  if (D > 1024) return MSDE_EUNSUP;
+  const int cols = D / 4, rpb = 256 / cols;
+  MSDE_LAUNCH(pair_bn_scatter_kernel, dim3((2 * N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream),
+              reinterpret_cast<const float4*>(GA), reinterpret_cast<const float4*>(AB), 2 * cols, src, dst, rowptr_s, perm_s,
+              rowptr, N, cols, reinterpret_cast<const float4*>(p), reinterpret_cast<const float4*>(w),
+              reinterpret_cast<const float4*>(u), reinterpret_cast<float4*>(gAB), 2 * cols);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[i] = p * (sum_e G[e]) + w * (sum_e Z[e]) + count_i * u over the edges e of node i's CSR segment (perm: edge ids, or
+// the segment itself): the segment sum of the BatchNorm input gradient p G + w Z + u (vectors of msde_bn_fin_bwd) without
+// forming it.  Thread layout of segment_sum_rows_kernel (tpr column lanes per row, float4 columns).
+__global__ void segment_sum_rows_bn_kernel(const float4* __restrict__ G, const float4* __restrict__ Z, int ld4,
+                                           const int* __restrict__ rowptr, const int* __restrict__ perm, int N, int cols,
+                                           int tpr, const float4* __restrict__ p, const float4* __restrict__ w,
+                                           const float4* __restrict__ u, float4* __restrict__ out, int ldo4) {
+  const int rpb = blockDim.x / tpr;
+  const int i = blockIdx.x * rpb + threadIdx.x / tpr, lane = threadIdx.x % tpr;
+  if (i >= N) return;
+  const int s0 = rowptr[i], s1 = rowptr[i + 1];
+  const float cnt = (float)(s1 - s0);
+  for (int c = lane; c < cols; c += tpr) {
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), az = ag;
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {
+      const int e0 = perm ? perm[s] : s, e1 = perm ? perm[s + 1] : s + 1, e2 = perm ? perm[s + 2] : s + 2,
+                e3 = perm ? perm[s + 3] : s + 3;
+      const float4 g0 = G[(size_t)e0 * ld4 + c], g1 = G[(size_t)e1 * ld4 + c], g2 = G[(size_t)e2 * ld4 + c],
+                   g3 = G[(size_t)e3 * ld4 + c];
+      const float4 z0 = Z[(size_t)e0 * ld4 + c], z1 = Z[(size_t)e1 * ld4 + c], z2 = Z[(size_t)e2 * ld4 + c],
+                   z3 = Z[(size_t)e3 * ld4 + c];
+      ag = vadd(vadd(vadd(vadd(ag, g0), g1), g2), g3);
+      az = vadd(vadd(vadd(vadd(az, z0), z1), z2), z3);
+    }
+    for (; s < s1; ++s) {
+      const int e = perm ? perm[s] : s;
+      ag = vadd(ag, G[(size_t)e * ld4 + c]);
+      az = vadd(az, Z[(size_t)e * ld4 + c]);
+    }
+    const float4 pv = p[c], wv = w[c], uv = u[c];
+    float4 r;
+    r.x = fmaf(pv.x, ag.x, fmaf(wv.x, az.x, cnt * uv.x));
+    r.y = fmaf(pv.y, ag.y, fmaf(wv.y, az.y, cnt * uv.y));
+    r.z = fmaf(pv.z, ag.z, fmaf(wv.z, az.z, cnt * uv.z));
+    r.w = fmaf(pv.w, ag.w, fmaf(wv.w, az.w, cnt * uv.w));
+    out[(size_t)i * ldo4 + c] = r;
+  }
+}
+
+extern "C" int msde_segment_sum_rows_bn(const float* G, const float* Z, int ld, const int* rowptr, const int* perm, int N,
+                                        int D, const float* p, const float* w, const float* u, float* out, int ldo,
+                                        void* stream) {
+  if (N < 0 || D <= 0 || !G || !Z || !rowptr || !p || !w || !u || !out) return MSDE_EINVAL;
+  if (ld <= 0) ld = D;
+  if (ldo <= 0) ldo = D;
+  if (ld < D || ldo < D) return MSDE_EINVAL;
+  if (D % 4 || ld % 4 || ldo % 4 ||
+      ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(out) |
+        reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(u)) & 15))
+    return MSDE_EUNSUP;
+  if (N == 0) return 0;
+  const int cols = D / 4, tpr = pick_tpr(cols), rpb = 256 / tpr;
+  MSDE_LAUNCH(segment_sum_rows_bn_kernel, dim3((N + rpb - 1) / rpb), dim3(256), 0, as_stream(stream),
+              reinterpret_cast<const float4*>(G), reinterpret_cast<const float4*>(Z), ld / 4, rowptr, perm, N, cols, tpr,
+              reinterpret_cast<const float4*>(p), reinterpret_cast<const float4*>(w), reinterpret_cast<const float4*>(u),
+              reinterpret_cast<float4*>(out), ldo / 4);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 // out[e] = [X[src_e] + X[dst_e] | C[e]]: the concatenation the basis MLP of the 2D->3D score network reads
 // (equivariant_scorenetwork.py: cat([h_row + h_col, edge_attr])) written by the gather itself.  D, D2 in float4 units.
 __global__ void pair_gather_cat_kernel(const float4* __restrict__ X, int ldx, const float4* __restrict__ C, int ldc,
@@ -537,3 +866,5 @@ extern "C" int msde_debug_stamp(long long* slot, void* stream) {
   MSDE_CHECK_LAUNCH();
   return 0;
 }
+
+extern "C" int msde_pair_strip(void) { return MSDE_PAIR_STRIP; }

@@ -28,6 +28,7 @@ import os as _os
 FUSE_GAT_TAIL = True     # csrc/gat_tail.hip for hidden size 32 (False: the kernel-per-stage path, used as a cross-check)
 NOISE_IN_KERNEL = _os.environ.get("MSDE_NOISE_IN_KERNEL", "1") != "0"     # DeviceNoise: draws made by the VE perturbation kernel
 FUSE_FRAME = _os.environ.get("MSDE_FUSE_FRAME", "1") != "0"              # hip._FrameMLP (False: coff_mlp twice + cat + project)
+FUSE_EDGE_EMB = _os.environ.get("MSDE_FUSE_EDGE_EMB", "1") != "0"        # hip._PairBnReluLinear (False: gather-add, BatchNorm, Linear as separate ops)
 FUSE_PAIR_LINEAR = _os.environ.get("MSDE_FUSE_PAIR_LINEAR", "1") != "0"  # hip._PairLinear (False: re-laid-out weight per step)
 
 
@@ -278,8 +279,15 @@ class SDEModel2Dto3D_02(nn.Module):
             Wst = lin0.weight.view(D, 2, D).transpose(0, 1).reshape(2 * D, D)
             bst = torch.cat([self._zero_bias, lin0.bias])          # the row half carries no bias
             AB = _nn.linear(node_2D_repr, Wst, bst)
-        pre = hip.pair_gather_add_cols(AB, ep)
-        edge_attr_2D = self.edge_2D_emb[3](self.edge_2D_emb[2](self.edge_2D_emb[1](pre)))
+        bn, lin3 = self.edge_2D_emb[1], self.edge_2D_emb[3]
+        if (FUSE_EDGE_EMB and torch.is_grad_enabled() and _nn.bn_fusable(bn) and bn.fuse_relu
+                and hip.pair_bn_relu_linear_ok(AB, bn, lin3)):
+            # gather-add + BatchNorm statistics in one pass, BatchNorm + ReLU inside the second Linear (hip._PairBnReluLinear)
+            edge_attr_2D = hip.pair_bn_relu_linear(AB, ep, bn, lin3)
+            _nn.count_batch(bn)
+        else:
+            pre = hip.pair_gather_add_cols(AB, ep)
+            edge_attr_2D = lin3(self.edge_2D_emb[2](bn(pre)))
         if side is not None:
             main = torch.cuda.current_stream()
             main.wait_stream(side)

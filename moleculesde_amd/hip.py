@@ -2728,6 +2728,93 @@ def gin_mlp_bn(agg, lin1, bn1, lin2, bn2, relu_out, defer_apply=False):
     return (h, box[0]) if defer_apply else h
 
 
+class _PairBnReluLinear(torch.autograd.Function):
+    """edge_2D_emb of the 2D->3D model on the edges of the (extended) graph: Linear(cat(h_row, h_col)) -> BatchNorm1d ->
+    ReLU -> Linear (SDE_model_2D_to_3D.py:35-40,264-271), given AB = [h W_row^T | h W_col^T + b] from ONE node-level product
+    (hip.pair_linear).  Forward 3 launches: gather-add that also writes the BatchNorm strip statistics of its result, their
+    finish, the second Linear with BatchNorm apply + ReLU in its A load (the normalised tensor is written once, by that
+    product, for the weight gradient).  Backward 4 launches (+ the queued weight gradient): input gradient of the second
+    Linear gated by the ReLU with the BatchNorm-backward sums in its epilogue, their finish, and the two segment sums of the
+    gradient of AB taken of (g, z) and combined per column -- the BatchNorm input gradient is never materialised.  Replaces
+    gather-add, statistics, apply, product / product, partial sums, apply, two segment sums (9 launches, ~250 MB more traffic
+    at 35 k edges x 300)."""
+
+    @staticmethod
+    def forward(ctx, AB, plan, gamma, beta, rm, rv, eps, momentum, W2, b2):
+        AB = _f32(AB)
+        E, D = plan.E, AB.size(1) // 2
+        H = W2.size(0)
+        dev = AB.device
+        SR = pair_strip()
+        strips = (E + SR - 1) // SR
+        pre = torch.empty(E, D, dtype=torch.float32, device=dev)
+        st = torch.empty(strips, 2, D, dtype=torch.float32, device=dev)
+        _lib.call("msde_pair_gather_add_stats", _p(AB), AB.data_ptr() + 4 * D, 2 * D, _p(plan.src), _p(plan.dst), E, D,
+                  _p(bound_tensor(E)), _p(pre), _p(st), _stream())
+        v = _bn_fin_fwd(st, strips, SR, E, D, gamma, beta, eps, momentum, rm, rv)
+        y = torch.empty(E, D, dtype=torch.float32, device=dev)
+        out = torch.empty(E, H, dtype=torch.float32, device=dev)
+        gemm_node(pre, W2, out, True, H, D, bias=b2, axf="affine", xf=(v[0], v[1]), relu=True, A_out=y)
+        ctx.save_for_backward(pre, y, v, W2, gamma, AB)
+        ctx.plan = plan
+        ctx.deferrable = all(t.is_leaf or getattr(t, "_msde_leaf_like", False) for t in (W2, b2))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pre, y, v, W2, gamma, AB = ctx.saved_tensors
+        plan = ctx.plan
+        g = _f32(g)
+        E, D = pre.shape
+        H = W2.size(0)
+        dev = g.device
+        ga = torch.empty(E, D, dtype=torch.float32, device=dev)
+        if H in (16, 32) and W2.is_contiguous() and W2.data_ptr() % 16 == 0:
+            # K = H is tiny: the product, the ReLU gate and the BatchNorm-backward strip sums in one streaming kernel
+            SR = pair_strip()
+            sa = (E + SR - 1) // SR
+            sta = torch.empty(sa, 2, D, dtype=torch.float32, device=dev)
+            _lib.call("msde_pair_bn_dgrad_stats", _p(g), _ld(g), _p(W2), _p(pre), _p(v[0]), _p(v[1]), _p(v[2]), E, H, D,
+                      _p(bound_tensor(E)), _p(ga), _p(sta), _stream())
+        else:
+            sa, _ = rs_geometry(E, D, H)
+            sta = torch.empty(sa, 2, D, dtype=torch.float32, device=dev)
+            gemm_node(g, W2, ga, False, D, H, act="relu", dact_from=y, stats=sta, stats_mode="bnbwd", stats_z=pre,
+                      stats_mean=v[2])
+        pw, gb = _bn_fin_bwd(sta, sa, E, D, gamma, v[2], v[3])
+        g_AB = None
+        if ctx.needs_input_grad[0]:
+            g_AB = torch.empty(plan.N, 2 * D, dtype=torch.float32, device=dev)
+            _lib.call("msde_pair_bn_scatter", _p(ga), _p(AB), D, _p(plan.src), _p(plan.dst), _p(plan.rowptr_s), _p(plan.perm_s),
+                      _p(plan.rowptr), plan.N, _p(pw[0]), _p(pw[1]), _p(pw[2]), _p(g_AB), _stream())
+        gW2, gb2 = weight_grad(g, y, True, ctx.deferrable)
+        return g_AB, None, gb[0], gb[1], None, None, None, None, gW2, gb2
+
+
+_PAIR_STRIP = None
+
+
+def pair_strip():
+    global _PAIR_STRIP
+    if _PAIR_STRIP is None:
+        _PAIR_STRIP = int(_lib.load().msde_pair_strip())
+    return _PAIR_STRIP
+
+
+def pair_bn_relu_linear_ok(AB, bn, lin2):
+    D = AB.size(1) // 2
+    return (AB.is_cuda and AB.dtype == torch.float32 and AB.dim() == 2 and AB.size(1) == 2 * D and D % 4 == 0 and D <= 1024
+            and AB.is_contiguous() and AB.data_ptr() % 16 == 0
+            and lin2.weight.size(1) == D and lin2.weight.size(0) % 4 == 0 and lin2.bias is not None
+            and lin2.weight.is_contiguous() and bn.weight.data_ptr() % 16 == 0 and bn.bias.data_ptr() % 16 == 0)
+
+
+def pair_bn_relu_linear(AB, plan, bn, lin2):
+    """lin2(relu(bn(AB[src, :D] + AB[dst, D:]))) for a training-mode BatchNorm1d `bn` and nn.Linear `lin2`: _PairBnReluLinear."""
+    return _PairBnReluLinear.apply(AB, plan, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                                   lin2.weight, lin2.bias)
+
+
 class _SchNetTail(torch.autograd.Function):
     """h + lin(ssp(lin2(agg))) of a SchNet interaction (schnet.py:163-167,97,189; CFConv.lin2, InteractionBlock.act /
     lin, the residual of SchNet.forward) as two products: bias + shifted softplus in the first epilogue, bias + residual in

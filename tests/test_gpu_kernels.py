@@ -132,6 +132,55 @@ def test_pair_gather_add_backward(dev):
     assert_close(Bd.grad, Bm.grad, 1e-5, 1e-5, "gB")
 
 
+@pytest.mark.parametrize("B,D,H", [(8, 300, 32), (40, 300, 32), (40, 64, 64), (3, 32, 32)])
+def test_pair_bn_relu_linear_fused(dev, B, D, H):
+    """hip._PairBnReluLinear (edge_2D_emb of the 2D->3D model: gather-add -> BatchNorm1d(train) -> ReLU -> Linear around ONE
+    gather, SDE_model_2D_to_3D.py:35-40,264-271) against fp64 autograd: output, running statistics, and the gradients of AB,
+    the BatchNorm affine parameters and the second Linear; few edges (row-strip products) and > 512 edges (2-D tiles)."""
+    from moleculesde_amd import hip
+    from moleculesde_amd.geom3d import nn as mnn
+    torch.manual_seed(B * 7 + D)
+    b = _toy_graph(3, B)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    src, dst = pl.src.cpu().long(), pl.dst.cpu().long()
+    E = pl.E
+    AB = (torch.randn(N, 2 * D) * 1.5 + 0.3).double().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(D).double()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    lin = torch.nn.Linear(D, H).double()
+    R = torch.randn(E, H).double()
+    out_ref = lin(torch.relu(bn(AB[src, :D] + AB[dst, D:])))
+    (out_ref * R).sum().backward()
+    bnd = mnn.BatchNorm1d(D).to(dev)
+    bnd.fuse_relu = True
+    lind = mnn.Linear(D, H).to(dev)
+    with torch.no_grad():
+        bnd.weight.copy_(bn.weight.float()); bnd.bias.copy_(bn.bias.float())
+        lind.weight.copy_(lin.weight.float()); lind.bias.copy_(lin.bias.float())
+    ABd = AB.detach().float().to(dev).requires_grad_(True)
+    assert mnn.bn_fusable(bnd) and hip.pair_bn_relu_linear_ok(ABd, bnd, lind)
+    out = hip.pair_bn_relu_linear(ABd, pl, bnd, lind)
+    (out * R.float().to(dev)).sum().backward()
+    assert_close(out, out_ref, 2e-4, 2e-4, "out")
+    assert_close(bnd.running_mean, bn.running_mean, 1e-5, 1e-5, "running_mean")
+    assert_close(bnd.running_var, bn.running_var, 1e-4, 1e-5, "running_var")
+    sc = float(AB.grad.abs().max())
+    assert_close(ABd.grad, AB.grad, 2e-3, 2e-4 * sc, "g_AB")
+    assert_close(bnd.weight.grad, bn.weight.grad, 2e-3, 2e-4 * float(bn.weight.grad.abs().max()), "dgamma")
+    assert_close(bnd.bias.grad, bn.bias.grad, 2e-3, 2e-4 * float(bn.bias.grad.abs().max()), "dbeta")
+    assert_close(lind.weight.grad, lin.weight.grad, 2e-3, 2e-4 * float(lin.weight.grad.abs().max()), "gW2")
+    assert_close(lind.bias.grad, lin.bias.grad, 2e-3, 2e-4 * float(lin.bias.grad.abs().max()), "gb2")
+    # and the unfused operator chain of the same modules gives the same numbers
+    AB2 = AB.detach().float().to(dev).requires_grad_(True)
+    bn2 = mnn.BatchNorm1d(D).to(dev); bn2.fuse_relu = True
+    with torch.no_grad():
+        bn2.weight.copy_(bn.weight.float()); bn2.bias.copy_(bn.bias.float())
+    out2 = lind(bn2(hip.pair_gather_add_cols(AB2, pl)))
+    assert_close(out, out2, 1e-4, 1e-4, "fused vs operator chain")
+
+
 @pytest.mark.parametrize("J", [3, 32])
 def test_pair_gather_cat_and_fused_mlp(dev, J):
     """cat([h_row + h_col, edge_attr]) -> Linear -> SiLU -> Linear (equivariant_scorenetwork.py:154-157, 142-146): the
