@@ -85,7 +85,7 @@ class ForceTrainer:
         hip.new_param_grad_slot(self.device)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with hip.no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._loss = self._body(batch, self._pos, self._y, self._f)
         hip.flush_table_uploads()
         self.opt.use_eager_slot()

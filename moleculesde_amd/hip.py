@@ -1094,6 +1094,27 @@ def note_capture():
     _CAPTURED = True
 
 
+class no_gc:
+    """Wrap a hipGraph capture: the interpreter's cyclic garbage collector must not run inside it.  A collection that happens
+    to fall into a capture finalises whatever garbage earlier code left behind -- another trainer's captured graphs, tensors
+    of their memory pools -- and destroying a graph or releasing pool memory while a capture is under way aborts the process
+    (seen in the test suite: `Fatal Python error: Aborted ... Garbage-collecting` inside Trainer.capture).  Collect first,
+    then keep the collector off until the capture has ended."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 def _retire(bufs):
     if _CAPTURED:
         _KEEP_ALIVE.extend(b for b in bufs if b is not None)
@@ -2576,6 +2597,7 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
     return out
 
 
+T2_EDGE_LEVEL = _os.environ.get("MSDE_T2_EDGE", "0") != "0"     # edge-level Linear layers (M > RS_MAX_ROWS) on the 2-D tiles too: measured 2.71 vs 2.69 ms (gemm_ex wins at 35 k x 64..128), off
 RS_MAX_ROWS = 8192     # above this (edge-level operands) msde_gemm_ex's 64 x 64 tiles are faster than 16-row strips (tools/bench_gemm_rs.py)
 
 
@@ -2584,7 +2606,8 @@ def gemm_fwd(x, W, out, bias=None, act=None, Z=None, res=None):
     W for node-level operands, msde_gemm_ex otherwise.  No autograd."""
     M, K = x.shape
     N = W.size(0)
-    if 0 < M <= RS_MAX_ROWS and rs_forward_ok(M, N, K, W) and x.data_ptr() % 16 == 0 and _ld(x) % 4 == 0:
+    big_t2 = T2_EDGE_LEVEL and M > RS_MAX_ROWS and t2_ok(M, N, K)       # edge-level operands: 2-D tiles have no row limit
+    if (0 < M <= RS_MAX_ROWS or big_t2) and rs_forward_ok(M, N, K, W) and x.data_ptr() % 16 == 0 and _ld(x) % 4 == 0:
         if t2_ok(M, N, K):        # 2-D tiles read the weight k-contiguous: as stored
             if _BF16X3 and "fwd" in _BF16X3_PARTS and isinstance(W, torch.nn.Parameter):
                 planes, ld = weight_planes(W, False)
@@ -2600,7 +2623,8 @@ def gemm_dgrad(g, W, out, act=None, dact_from=None, res=None):
     """out = (g W) * act'(dact_from) (+ res) for an nn.Linear weight W [N][K] and g [M][N]: the input gradient."""
     M, N = g.shape
     K = W.size(1)
-    if (0 < M <= RS_MAX_ROWS and N % 4 == 0 and K % 4 == 0 and W.is_contiguous() and g.data_ptr() % 16 == 0
+    big_t2 = T2_EDGE_LEVEL and M > RS_MAX_ROWS and t2_ok(M, K, N)
+    if ((0 < M <= RS_MAX_ROWS or big_t2) and N % 4 == 0 and K % 4 == 0 and W.is_contiguous() and g.data_ptr() % 16 == 0
             and _ld(g) % 4 == 0):
         if t2_ok(M, K, N):        # ... for an input gradient that is the transposed copy [K][N]
             if _BF16X3 and "dgrad" in _BF16X3_PARTS and isinstance(W, torch.nn.Parameter):

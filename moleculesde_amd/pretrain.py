@@ -563,7 +563,7 @@ class Trainer:
             self._graph_pool = torch.cuda.graph_pool_handle()
         # thread_local: other threads of the process (the RCCL watchdog under DP) may issue HIP calls
         # while this thread captures; they must not invalidate the capture
-        with self._bounds(batch), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+        with _hip.no_gc(), self._bounds(batch), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             if pre is not None:
                 pre()
             loss = self._graph_body(batch, with_adam)
@@ -618,7 +618,8 @@ class Trainer:
             # the plan construction as a graph of its own (BucketPipeline runs it for batch t+1 beside the step of batch t)
             torch.cuda.synchronize()
             bk.plan_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(bk.plan_graph, capture_error_mode="thread_local"):
+            from . import hip as _hipg
+            with _hipg.no_gc(), torch.cuda.graph(bk.plan_graph, capture_error_mode="thread_local"):
                 bk.build_plan_on_device(None)
             return self.capture(bk.batch)
         side = self._side_stream if (self.overlap_streams and PLAN_LISTS_ON_SIDE) else None

@@ -4,6 +4,7 @@ shipped (missing import, undefined args, hard-coded `break` aft
 restates the algorithm:  for t in linspace(T, eps, N):  Langevin corrector -> reverse-diffusion
 predictor, each calling SDEModel2Dto3D_02.get_score on the replicated molecule batch."""
 import torch
+from . import hip as _hip_mod
 
 
 def predictor_update(sde, score_model, representation, data, pos, t, noise=None):
@@ -60,7 +61,7 @@ def position_PC_generation(score_model, representation, data, num_steps=1000, sn
         if use_graph and dev.type == "cuda" and graph is None and i == 2:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _hip_mod.no_gc(), torch.cuda.graph(graph):
                 one_step()                 # capture only records; the replay below executes iteration i
         if graph is not None:
             graph.replay()
