@@ -737,6 +737,16 @@ int msde_silu_dropout_bwd(const float* g, const float* x, long long n, float p, 
 int msde_mul_add_fwd(const float* a, const float* b, const float* c, long long n, float* out, void* stream);
 int msde_mul_add_bwd(const float* g, const float* a, const float* b, long long n, float* ga, float* gb,
                      void* stream);
+/* Predictor-corrector sampler arithmetic for ONE diffusion time shared by all n atoms (pretrain_MoleculeSDE_inference_2D_to_3D_VE_VP.py
+ * :191-212 LangevinCorrector.update_fn, :163-168 ReverseDiffusionPredictor.update_fn): `out` is the score network's raw output
+ * [n, 3] (score = -out / std), par = {std(t), G(t), alpha(t), fa(t)} on the device, fa = 1 + f(x)/x of the discretised
+ * forward SDE (VE: 1).  corrector: step = (snr mean|noise| / mean|score|)^2 2 alpha, x_mean = pos + step score,
+ * x = x_mean + sqrt(2 step) scale_eps noise (one workgroup, fixed-order reductions); predictor: x_mean = pos - ((fa - 1) pos -
+ * G^2 score), x = x_mean + G noise. */
+int msde_pc_corrector(const float* out, const float* pos, const float* noise, const float* par, int n, float snr,
+                      float scale_eps, float* x, float* x_mean, void* stream);
+int msde_pc_predictor(const float* out, const float* pos, const float* noise, const float* par, int n, float* x,
+                      float* x_mean, void* stream);
 /* torch.randperm(n) for the contrastive negatives (examples/util.py:55), n <= 4096 (else MSDE_EUNSUP):
  * out[count][n] int32, `count` independent uniform shuffles in one launch (dual_CL draws two) from the
  * counter-based generator (seed [+ seed_dev[0]*FNV], permutation number, index). */

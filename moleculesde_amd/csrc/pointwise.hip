@@ -547,3 +547,78 @@ extern "C" int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const 
   if (!gWb) return 0;                 // slabs stay in `workspace` for a batched reduction
   return msde_reduce_slabs(workspace, nb, n, gWb, nullptr, 0, nullptr, st);
 }
+
+// ---- predictor-corrector sampler arithmetic (pretrain_MoleculeSDE_inference_2D_to_3D_VE_VP.py:163-168 ReverseDiffusionPredictor,
+// :191-212 LangevinCorrector) for ONE diffusion time shared by every atom, as the sampler uses it: ~25 element-wise / reduction
+// operators per half iteration become one single-workgroup kernel each (n atoms x 3 coordinates; the loop is launch bound).
+// par = {std(t), G(t), alpha(t), fa(t)} on the DEVICE (a row of a table the caller computed once for all time steps with the
+// SDE's own formulas): score = -out / std; drift of the discretised forward SDE f(x) = (fa - 1) x (VE: fa = 1).
+__device__ __forceinline__ float pc_block_sum(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int k = 0; k < nw; ++k) t += red[k];            // every thread adds the wave partials in wave order
+  return t;
+}
+
+__global__ void __launch_bounds__(1024)
+pc_corrector_kernel(const float* __restrict__ out, const float* __restrict__ pos, const float* __restrict__ noise,
+                    const float* __restrict__ par, int n, float snr, float scale_eps, float* __restrict__ x,
+                    float* __restrict__ x_mean) {
+  __shared__ float red[16];
+  const float inv_std = 1.f / par[0], alpha = par[2];
+  float gs = 0.f, ns = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float g0 = -out[3 * i] * inv_std, g1 = -out[3 * i + 1] * inv_std, g2 = -out[3 * i + 2] * inv_std;
+    const float z0 = noise[3 * i], z1 = noise[3 * i + 1], z2 = noise[3 * i + 2];
+    gs += sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+    ns += sqrtf(z0 * z0 + z1 * z1 + z2 * z2);
+  }
+  const float gn = pc_block_sum(gs, red) / (float)n;
+  const float nn = pc_block_sum(ns, red) / (float)n;
+  const float r = snr * nn / gn;
+  const float step = r * r * 2.f * alpha;
+  const float ns2 = sqrtf(step * 2.f) * scale_eps;
+  for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {
+    const float g = -out[i] * inv_std;
+    const float m = fmaf(step, g, pos[i]);
+    x_mean[i] = m;
+    x[i] = fmaf(ns2, noise[i], m);
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+pc_predictor_kernel(const float* __restrict__ out, const float* __restrict__ pos, const float* __restrict__ noise,
+                    const float* __restrict__ par, int n, float* __restrict__ x, float* __restrict__ x_mean) {
+  const float inv_std = 1.f / par[0], G = par[1], fa = par[3];
+  const float g2 = G * G;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += gridDim.x * blockDim.x) {
+    const float score = -out[i] * inv_std;
+    const float p = pos[i];
+    const float m = p - ((fa - 1.f) * p - g2 * score);        // x - (f - G^2 score)
+    x_mean[i] = m;
+    x[i] = fmaf(G, noise[i], m);
+  }
+}
+
+extern "C" int msde_pc_corrector(const float* out, const float* pos, const float* noise, const float* par, int n, float snr,
+                                 float scale_eps, float* x, float* x_mean, void* stream) {
+  if (n <= 0 || !out || !pos || !noise || !par || !x || !x_mean) return MSDE_EINVAL;
+  MSDE_LAUNCH(pc_corrector_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, as_stream(stream), out, pos, noise, par, n, snr,
+              scale_eps, x, x_mean);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_pc_predictor(const float* out, const float* pos, const float* noise, const float* par, int n, float* x,
+                                 float* x_mean, void* stream) {
+  if (n <= 0 || !out || !pos || !noise || !par || !x || !x_mean) return MSDE_EINVAL;
+  const int blocks = (3 * n + 1023) / 1024;
+  MSDE_LAUNCH(pc_predictor_kernel, dim3(blocks > 256 ? 256 : blocks), dim3(1024), 0, as_stream(stream), out, pos, noise, par, n,
+              x, x_mean);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

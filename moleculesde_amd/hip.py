@@ -881,10 +881,36 @@ class _CatParams(torch.autograd.Function):
         return tuple(g.split(ctx.rows, 0))
 
 
+_CAT_CACHE = {}      # inference: concatenations of parameters that do NOT lie back to back (no FlatAdam laid them out)
+
+
 def cat_params(ws):
     ws = list(ws)
     if len(ws) == 1:
         return ws[0]
+    if not torch.is_grad_enabled() and all(isinstance(w, torch.nn.Parameter) for w in ws):
+        # Without autograd (sampling, evaluation) a real concatenation is made once per parameter version, not per call, and --
+        # being the same tensor every time -- its transposed copy is cached by weight_t like a parameter's (2 launches per
+        # stacked layer and score-network call otherwise: 16 of the sampler's ~140 launches per iteration).
+        key = tuple(id(w) for w in ws)
+        ver = tuple(w._version for w in ws) + (_WT_EPOCH,) + tuple(w.data_ptr() for w in ws)
+        hit = _CAT_CACHE.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        if not torch.cuda.is_current_stream_capturing():
+            if hit is not None and hit[1].data_ptr() != ws[0].data_ptr():
+                # parameters changed: refill the SAME buffer (the transposed copy cached for it stays addressed to it)
+                out = hit[1]
+                torch.cat([w.detach() for w in ws], 0, out=out)
+                _CAT_CACHE[key] = (ver, out, hit[2])
+                return out
+            out = _CatParams.apply(*ws)
+            out._msde_leaf_like = all(w.is_leaf for w in ws)
+            out._msde_src = tuple(ws)
+            out._msde_volatile = False            # the cached tensor is stable: the copy made from it may be cached too
+            refs = [_weakref.ref(w, lambda _r, key=key: _CAT_CACHE.pop(key, None)) for w in ws]
+            _CAT_CACHE[key] = (ver, out, refs)
+            return out
     out = _CatParams.apply(*ws)
     out._msde_leaf_like = all(w.is_leaf for w in ws)     # its gradient only gets split into views for the leaves
     out._msde_src = tuple(ws)                            # weight_t(): the copy is valid while these are unchanged

@@ -3,8 +3,12 @@ examples/pretrain_MoleculeSDE_inference_2D_to_3D_VE_VP.py:92-212.  The script it
 shipped (missing import, undefined args, hard-coded `break` after 11 steps); this
 restates the algorithm:  for t in linspace(T, eps, N):  Langevin corrector -> reverse-diffusion
 predictor, each calling SDEModel2Dto3D_02.get_score on the replicated molecule batch."""
+import os
 import torch
+from . import _lib
 from . import hip as _hip_mod
+
+FUSED_PC = os.environ.get("MSDE_FUSED_PC", "1") != "0"     # sampler arithmetic on msde_pc_corrector / msde_pc_predictor
 
 
 def predictor_update(sde, score_model, representation, data, pos, t, noise=None):
@@ -49,7 +53,35 @@ def position_PC_generation(score_model, representation, data, num_steps=1000, sn
     vec_t = torch.ones(n, device=dev)
     x_mean = pos.clone()
 
+    # Fused arithmetic (csrc/pointwise.hip: msde_pc_corrector / msde_pc_predictor): every atom shares the diffusion time, so
+    # std(t), G(t), alpha(t) and the drift factor are tabulated ONCE for all time steps with the SDE's own methods, and each
+    # half iteration is: score network -> one noise draw -> one kernel.  The operator-by-operator functions above stay the
+    # reference path (tests, n_corrector_steps > 1, CPU).
+    fused = (FUSED_PC and dev.type == "cuda" and n_corrector_steps == 1 and hasattr(score_model, "get_score_raw")
+             and pos.dtype == torch.float32)
+    if fused:
+        S = num_steps
+        ones = torch.ones(S, 1, device=dev)
+        std_all = sde.marGINal_prob(ones, timesteps)[1]
+        f_all, G_all = sde.discretize(ones, timesteps)
+        alpha_all = sde.corrector_alpha(timesteps) if hasattr(sde, "corrector_alpha") else torch.ones_like(timesteps)
+        par_all = torch.stack([std_all.float(), G_all.float(), alpha_all.float(), f_all[:, 0].float() + 1.0], 1).contiguous()
+        par = torch.zeros(4, device=dev)
+        xc = torch.empty_like(pos)
+        xm_c = torch.empty_like(pos)
+        stream = _hip_mod._stream
+
     def one_step():
+        if fused:
+            raw = score_model.get_score_raw(representation, data, pos).contiguous()
+            noise = torch.randn_like(pos)
+            _lib.call("msde_pc_corrector", _hip_mod._p(raw), _hip_mod._p(pos), _hip_mod._p(noise), _hip_mod._p(par), n, float(snr),
+                      float(scale_eps), _hip_mod._p(xc), _hip_mod._p(xm_c), stream())
+            raw2 = score_model.get_score_raw(representation, data, xc).contiguous()
+            noise2 = torch.randn_like(pos)
+            _lib.call("msde_pc_predictor", _hip_mod._p(raw2), _hip_mod._p(xc), _hip_mod._p(noise2), _hip_mod._p(par), n,
+                      _hip_mod._p(pos), _hip_mod._p(x_mean), stream())
+            return
         p, _ = corrector_update(sde, score_model, representation, data, pos, vec_t, snr, scale_eps, n_corrector_steps)
         p, m = predictor_update(sde, score_model, representation, data, p, vec_t)
         pos.copy_(p)
@@ -57,7 +89,10 @@ def position_PC_generation(score_model, representation, data, num_steps=1000, sn
 
     graph = None
     for i in range(num_steps):
-        vec_t.fill_(1.0).mul_(timesteps[i])
+        if fused:
+            par.copy_(par_all[i])
+        else:
+            vec_t.fill_(1.0).mul_(timesteps[i])
         if use_graph and dev.type == "cuda" and graph is None and i == 2:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
