@@ -749,6 +749,8 @@ extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, 
     return (int)e;
   }
   // C[N,K] = A^T B with A = gY [M][N] (k-major, "M" of the product = N), B = X [M][K] (k-major)
+  if (splits == 1)      // one split (few rows: a 21-atom MD17 step launches ~90 of these): the only slab IS the result
+    return launch_gemm<true, true>(gY, X, nullptr, gW, gb, N, K, M, N, K, K, 1, k_per_split, wgrad_big(M, N, K), st, rows_dev);
   int rc = launch_gemm<true, true>(gY, X, nullptr, slabs, cs, N, K, M, N, K, K, splits, k_per_split, wgrad_big(M, N, K), st, rows_dev);
   if (rc != 0) return rc;
   return msde_reduce_slabs(slabs, splits, (size_t)N * K, gW, cs, (size_t)N, gb, st);

@@ -357,6 +357,11 @@ extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* work
   if (M == 0) return (int)hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
   int splits, rows;
   bn_geometry(M, &splits, &rows);
+  if (splits == 1) {     // one split: its partial sums are the result (no second launch)
+    MSDE_LAUNCH(colsum_partial_kernel, dim3((C + BN_COLS - 1) / BN_COLS, 1), dim3(256), 0, st, X, M, rows_dev, C, rows, out);
+    MSDE_CHECK_LAUNCH();
+    return 0;
+  }
   MSDE_LAUNCH(colsum_partial_kernel, dim3((C + BN_COLS - 1) / BN_COLS, splits), dim3(256), 0, st, X, M, rows_dev, C, rows,
               workspace);
   MSDE_CHECK_LAUNCH();

@@ -370,6 +370,13 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         x, W = ctx.saved_tensors
         ni = ctx.needs_input_grad
+        if ctx.has_bias and ni[1] and ni[2] and not torch.is_grad_enabled():
+            # the LAST differentiation (nothing will differentiate this backward again): weight and bias gradient from one
+            # launch of the split-M kernel instead of mm_tn + colsum (two members of the closed set, two to three launches)
+            g2 = _f32(g)
+            CALLS["msde_linear_bwd_w"] = CALLS.get("msde_linear_bwd_w", 0) + 1
+            gW, gb = hip.weight_grad(g2, x, True, deferrable=False)
+            return (mm_nn(g, W) if ni[0] else None), gW, gb
         return (mm_nn(g, W) if ni[0] else None), (mm_tn(g, x) if ni[1] else None), \
             (colsum(g) if ctx.has_bias and ni[2] else None)
 
