@@ -297,31 +297,33 @@ extern "C" int msde_gemm_chain(const msde_chain_desc* desc, void* stream) {
 // finishing kernels of the fused BatchNorm: one launch of C / 16 workgroups; 16 lanes per column combine the per-strip
 // partials in a fixed order.
 // ===================================================================================================================
-// Both kernels: 16 lanes per column; lane l owns strips l, l + 16, ... (up to FIN_PER_LANE kept in registers: all loads are
+// Both kernels: LPC lanes per column; lane l owns strips l, l + LPC, ... (the first ones kept in registers: all loads are
 // issued before anything is summed), lane partials are combined by a fixed butterfly (bitwise reproducible).
-#define FIN_PER_LANE 16      // strips <= 256 in registers; beyond that the tail is walked in a loop
-__device__ __forceinline__ float fin_lane_sum16(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
+#define FIN_REGS 16           // partials of a lane kept in registers (LPC * FIN_REGS strips); beyond that the tail is walked in a loop
+template <int LPC>
+__device__ __forceinline__ float fin_lane_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < LPC; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
 // Forward: strip partials (mean_s, M2_s) with n_s valid rows ->  mean = sum n_s mean_s / n,  M2 = sum M2_s + n_s (mean_s -
-// mean)^2 (two passes over the partials, no division per strip).
+// mean)^2 (two passes over the partials, no division per strip).  LPC lanes per column (16: round 3; 64 = a wave per
+// column: a quarter of the dependent loads per lane, four times the workgroups -- the kernel is pure latency on the GIN chain).
+template <int LPC>
 __global__ void __launch_bounds__(256)
 bn_fin_fwd_kernel(const float* __restrict__ stats, int strips, int strip_rows, int M, const int* __restrict__ m_valid,
                   int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                   float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ scale,
                   float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  constexpr int PL = LPC == 16 ? FIN_REGS : 4;
   const int mv = m_valid ? min(M, m_valid[0]) : M;
-  const int l = threadIdx.x & 15, col = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & (LPC - 1), col = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
   const int cc = min(col, C - 1);
-  float pm[FIN_PER_LANE], pq[FIN_PER_LANE], pn[FIN_PER_LANE];
+  float pm[PL], pq[PL], pn[PL];
 #pragma unroll
-  for (int k = 0; k < FIN_PER_LANE; ++k) {
-    const int s = l + 16 * k;
+  for (int k = 0; k < PL; ++k) {
+    const int s = l + LPC * k;
     const bool ok = s < strips;
     const size_t o = (size_t)(ok ? s : 0) * 2 * C + cc;
     pm[k] = stats[o];
@@ -330,23 +332,23 @@ bn_fin_fwd_kernel(const float* __restrict__ stats, int strips, int strip_rows, i
   }
   float sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < FIN_PER_LANE; ++k) sum = fmaf(pn[k], pn[k] > 0.f ? pm[k] : 0.f, sum);
-  for (int s = l + 16 * FIN_PER_LANE; s < strips; s += 16) {
+  for (int k = 0; k < PL; ++k) sum = fmaf(pn[k], pn[k] > 0.f ? pm[k] : 0.f, sum);
+  for (int s = l + LPC * PL; s < strips; s += LPC) {
     const float n = (float)max(0, min(strip_rows, mv - s * strip_rows));
     if (n > 0.f) sum = fmaf(n, stats[(size_t)s * 2 * C + cc], sum);
   }
-  sum = fin_lane_sum16(sum);
+  sum = fin_lane_sum<LPC>(sum);
   const float n = (float)mv;
   const float mean = mv > 0 ? sum / n : 0.f;
   float m2 = 0.f;
 #pragma unroll
-  for (int k = 0; k < FIN_PER_LANE; ++k)
+  for (int k = 0; k < PL; ++k)
     if (pn[k] > 0.f) { const float dl = pm[k] - mean; m2 += pq[k] + pn[k] * dl * dl; }
-  for (int s = l + 16 * FIN_PER_LANE; s < strips; s += 16) {
+  for (int s = l + LPC * PL; s < strips; s += LPC) {
     const float ns = (float)max(0, min(strip_rows, mv - s * strip_rows));
     if (ns > 0.f) { const float dl = stats[(size_t)s * 2 * C + cc] - mean; m2 += stats[(size_t)s * 2 * C + C + cc] + ns * dl * dl; }
   }
-  m2 = fin_lane_sum16(m2);
+  m2 = fin_lane_sum<LPC>(m2);
   if (col < C && l == 0) {
     const float var = mv > 0 ? m2 / n : 0.f;
     const float rstd = rsqrtf(var + eps);
@@ -363,18 +365,20 @@ bn_fin_fwd_kernel(const float* __restrict__ stats, int strips, int strip_rows, i
   }
 }
 
+template <int LPC>
 __global__ void __launch_bounds__(256)
 bn_fin_bwd_kernel(const float* __restrict__ stats, int strips, int M, const int* __restrict__ m_valid, int C,
                   const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
                   float* __restrict__ p, float* __restrict__ w, float* __restrict__ u, float* __restrict__ dgamma,
                   float* __restrict__ dbeta) {
+  constexpr int PL = LPC == 16 ? FIN_REGS : 4;
   const int mv = m_valid ? min(M, m_valid[0]) : M;
-  const int l = threadIdx.x & 15, col = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & (LPC - 1), col = blockIdx.x * (256 / LPC) + threadIdx.x / LPC;
   const int cc = min(col, C - 1);
-  float pa[FIN_PER_LANE], pb[FIN_PER_LANE];
+  float pa[PL], pb[PL];
 #pragma unroll
-  for (int k = 0; k < FIN_PER_LANE; ++k) {
-    const int s = l + 16 * k;
+  for (int k = 0; k < PL; ++k) {
+    const int s = l + LPC * k;
     const bool ok = s < strips;
     const size_t o = (size_t)(ok ? s : 0) * 2 * C + cc;
     pa[k] = ok ? stats[o] : 0.f;
@@ -382,9 +386,9 @@ bn_fin_bwd_kernel(const float* __restrict__ stats, int strips, int M, const int*
   }
   float a = 0.f, b = 0.f;
 #pragma unroll
-  for (int k = 0; k < FIN_PER_LANE; ++k) { a += pa[k]; b += pb[k]; }
-  for (int s = l + 16 * FIN_PER_LANE; s < strips; s += 16) { a += stats[(size_t)s * 2 * C + cc]; b += stats[(size_t)s * 2 * C + C + cc]; }
-  const float ra = fin_lane_sum16(a), rb = fin_lane_sum16(b);
+  for (int k = 0; k < PL; ++k) { a += pa[k]; b += pb[k]; }
+  for (int s = l + LPC * PL; s < strips; s += LPC) { a += stats[(size_t)s * 2 * C + cc]; b += stats[(size_t)s * 2 * C + C + cc]; }
+  const float ra = fin_lane_sum<LPC>(a), rb = fin_lane_sum<LPC>(b);
   if (col < C && l == 0) {
     const float rs = rstd[col], mu = mean[col], gv = gamma ? gamma[col] : 1.f;
     const float sum_g = ra, sum_gx = rb * rs;          // sum g', sum g' xhat
@@ -706,8 +710,13 @@ extern "C" int msde_bn_fin_fwd(const float* stats, int strips, int strip_rows, i
                                float* running_var, float* scale, float* shift, float* save_mean, float* save_rstd,
                                void* stream) {
   if (!stats || strips <= 0 || strip_rows <= 0 || C <= 0 || !scale || !shift || !save_mean || !save_rstd) return MSDE_EINVAL;
-  MSDE_LAUNCH(bn_fin_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), stats, strips, strip_rows, M, m_valid,
-              C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+  static const int lpc = [] { const char* e = getenv("MSDE_FIN_LANES"); return e ? atoi(e) : 64; }();
+  if (lpc == 16)
+    MSDE_LAUNCH(bn_fin_fwd_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), stats, strips, strip_rows, M,
+                m_valid, C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+  else
+    MSDE_LAUNCH(bn_fin_fwd_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats, strips, strip_rows, M,
+                m_valid, C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
@@ -716,8 +725,13 @@ extern "C" int msde_bn_fin_bwd(const float* stats, int strips, int M, const int*
                                const float* mean, const float* rstd, float* p, float* w, float* u, float* dgamma,
                                float* dbeta, void* stream) {
   if (!stats || strips <= 0 || C <= 0 || !mean || !rstd || !p || !w || !u) return MSDE_EINVAL;
-  MSDE_LAUNCH(bn_fin_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), stats, strips, M, m_valid, C, gamma,
-              mean, rstd, p, w, u, dgamma, dbeta);
+  static const int lpc = [] { const char* e = getenv("MSDE_FIN_LANES"); return e ? atoi(e) : 64; }();
+  if (lpc == 16)
+    MSDE_LAUNCH(bn_fin_bwd_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), stats, strips, M, m_valid, C,
+                gamma, mean, rstd, p, w, u, dgamma, dbeta);
+  else
+    MSDE_LAUNCH(bn_fin_bwd_kernel<64>, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats, strips, M, m_valid, C,
+                gamma, mean, rstd, p, w, u, dgamma, dbeta);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
