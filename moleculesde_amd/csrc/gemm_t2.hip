@@ -28,9 +28,30 @@ static bool t2_pick(int M, int N, int K, int splits, int axf, t2_cfg* c) {
   while (rn > rn_max) { ++S; rn = (ntiles + S - 1) / S; }
   for (int ok : T2_RN_OK) if (ok >= rn) { rn = ok; break; }
   S = (ntiles + rn - 1) / rn;
+  // Wide outputs (N = 600: 10 column tiles per workgroup) on a node-level operand: HALF the tile width and two workgroups per
+  // CU instead (their rings fit the LDS twice when only one A operand is staged) -- one workgroup's prologue and epilogue
+  // then overlap the other's K loop (3588 x 600 x 300 alone: 22.5 -> 19.6 us; narrower outputs lose, tools/bench_gemm_t2.py
+  // --sweep).  MSDE_T2_SPLIT2=0 keeps one workgroup per CU.
+  static const int split2 = [] { const char* e = getenv("MSDE_T2_SPLIT2"); return e ? atoi(e) : 2; }();
+  bool two_per_cu = false;
+  static const int rn_cap = [] { const char* e = getenv("MSDE_T2_RNCAP"); return e ? atoi(e) : 0; }();     // (measurement knob)
+  if (rn_cap > 0 && splits <= 0 && rowblks <= cus && rn > rn_cap) {
+    int rn2 = rn_cap;
+    for (int ok : T2_RN_OK) if (ok >= rn2) { rn2 = ok; break; }
+    const int S2 = (ntiles + rn2 - 1) / rn2;
+    if (rowblks * S2 <= 2 * cus) { rn = rn2; S = S2; two_per_cu = true; }
+  }
+  if (split2 && splits <= 0 && rowblks <= cus && rn >= 8 && (axf != MSDE_RS_AXF_BNBWD || split2 == 2)) {
+    // the narrowest tile >= half the width whose workgroups still number <= 2 per CU
+    for (int ok : T2_RN_OK) {
+      if (ok < (rn + 1) / 2 || ok >= rn) continue;
+      const int S2 = (ntiles + ok - 1) / ok;
+      if (rowblks * S2 <= 2 * cus) { rn = ok; S = S2; two_per_cu = true; break; }
+    }
+  }
   // a node-level operand (fewer row blocks than CUs) must fit the chip in ONE round of workgroups: a second, mostly empty
   // round costs more than the row strips of msde_gemm_rs do (N = 728 with a transform: 57 x 5 workgroups)
-  if (splits <= 0 && rowblks <= cus && rowblks * S > cus + cus / 16) return false;
+  if (splits <= 0 && rowblks <= cus && !two_per_cu && rowblks * S > cus + cus / 16) return false;
   c->rn = rn; c->splits = S;
   return true;
 }
