@@ -544,6 +544,15 @@ int msde_mlp_head_fwd(const float* Z, int ldz, const float* W, const float* b, i
 int msde_mlp_head_bwd_slabs(int E, int H);
 int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const float* g, int E, int H, int J, float* gZ, float* gWb,
                       float* workspace, const int* rows_dev, void* stream);
+/* The head fused with the frame mix + mean that consumes it in the 2D->3D score network (equivariant_scorenetwork.py:142-166):
+ * out[i] = base[i] + mean over in-edges e of i of sum_j coff[e][j] basis[e][j][:], coff[e] = b + W silu(Z[e]) (3 outputs);
+ * rowptr = by-target CSR of the edges (in-edges of a node contiguous), mix [E, 3] = scratch.  Backward: as msde_mlp_head_bwd
+ * with the head's gradient formed from the NODE gradient gnode [N, 3] (dst [E] = target node of each edge); the slabs of the
+ * head's own weight / bias gradient stay in `workspace` (msde_mlp_head_bwd_slabs(E, H) of them) for a batched reduction. */
+int msde_mlp_head_mix_fwd(const float* Z, int ldz, const float* W, const float* b, int H, const float* basis,
+                          const int* rowptr, int N, const float* base, float* mix, float* out, void* stream);
+int msde_mlp_head_mix_bwd(const float* Z, int ldz, const float* W, const float* gnode, const float* basis, const int* dst,
+                          const int* rowptr, int E, int H, float* gZ, float* workspace, const int* rows_dev, void* stream);
 
 /* ------------------------------------------------------------------ CFConv on unordered atom pairs -- */
 /* SchNet's interaction graph (schnet.py:91-93: radius_graph over the molecule, 32-neighbour cap) is symmetric whenever the

@@ -32,6 +32,8 @@ SIGNATURES = {
     "msde_mlp_head_fwd": [P, I, P, P, I, I, I, P, P],
     "msde_mlp_head_bwd_slabs": [I, I],
     "msde_mlp_head_bwd": [P, I, P, P, I, I, I, P, P, P, P, P],
+    "msde_mlp_head_mix_fwd": [P, I, P, P, I, P, P, I, P, P, P, P],
+    "msde_mlp_head_mix_bwd": [P, I, P, P, P, P, P, I, I, P, P, P, P],
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
     "msde_radius_transpose": [P, P, P, P, I, I, P, P, P, P],

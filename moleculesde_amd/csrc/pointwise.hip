@@ -406,6 +406,7 @@ extern "C" int msde_combine_losses_bwd(const float* g, float ca, float cb, float
 // weight / bias gradient in registers -> one slab per workgroup (summed by msde_reduce_slabs[_multi], fixed order).
 #define MH_MAXJ 4
 #define MH_MAXWG 256
+#define FMX_LPN 8        // lanes per node of the mean over in-edges (= FM_LPN of sde2d3d.hip: same order of additions)
 // slab of one workgroup: [gW (J x H) | gb (J)] padded to whole float4 (the batched reduction then takes its vector path)
 __host__ __device__ __forceinline__ size_t mh_slab_floats(int J, int H) { return ((size_t)J * H + J + 3) & ~(size_t)3; }
 __device__ __forceinline__ float mh_sigmoid(float z) { return 1.f / (1.f + __expf(-z)); }
@@ -435,10 +436,14 @@ mlp_head_fwd_kernel(const float4* __restrict__ Z, int ldz4, const float4* __rest
   }
 }
 
-// H4 <= lpr here (one float4 column piece per lane): the per-lane weight-gradient accumulators stay in registers
+// H4 <= lpr here (one float4 column piece per lane): the per-lane weight-gradient accumulators stay in registers.
+// MIX (J = 3): the head's output went straight into the frame mix + mean over the in-edges of its target node
+// (mlp_head_mix_fwd_kernel), so its gradient is formed here from the NODE gradient: g[e][j] = (gnode[dst_e] / deg) . basis[e][j].
+template <bool MIX>
 __global__ void __launch_bounds__(256)
 mlp_head_bwd_kernel(const float4* __restrict__ Z, int ldz4, const float4* __restrict__ W, const float* __restrict__ g, int E,
-                    const int* __restrict__ Edev, int H4, int J, int lpr, float4* __restrict__ gZ, float* __restrict__ slabs) {
+                    const int* __restrict__ Edev, int H4, int J, int lpr, float4* __restrict__ gZ, float* __restrict__ slabs,
+                    const float* __restrict__ basis, const int* __restrict__ dst, const int* __restrict__ rowptr) {
   __shared__ float4 red[256 * MH_MAXJ];
   __shared__ float redb[64 * MH_MAXJ];
   const int Et = msde_true_rows(E, Edev);      // padded rows: zero gradient, no contribution to the weight gradient
@@ -459,10 +464,24 @@ mlp_head_bwd_kernel(const float4* __restrict__ Z, int ldz4, const float4* __rest
       const float4 z = Z[(size_t)e * ldz4 + lane];
       const float4 s = make_float4(mh_sigmoid(z.x), mh_sigmoid(z.y), mh_sigmoid(z.z), mh_sigmoid(z.w));
       const float4 a = make_float4(z.x * s.x, z.y * s.y, z.z * s.z, z.w * s.w);
+      float ge[MH_MAXJ] = {0.f, 0.f, 0.f, 0.f};
+      if (MIX) {
+        const int i = dst[e];
+        const float inv = 1.f / (float)max(rowptr[i + 1] - rowptr[i], 1);
+        const float gx = g[3 * i] * inv, gy = g[3 * i + 1] * inv, gz = g[3 * i + 2] * inv;
+        const float* b = basis + 9 * (size_t)e;
+        ge[0] = gx * b[0] + gy * b[1] + gz * b[2];
+        ge[1] = gx * b[3] + gy * b[4] + gz * b[5];
+        ge[2] = gx * b[6] + gy * b[7] + gz * b[8];
+      } else {
+#pragma unroll
+        for (int j = 0; j < MH_MAXJ; ++j)
+          if (j < J) ge[j] = g[(size_t)e * J + j];
+      }
 #pragma unroll
       for (int j = 0; j < MH_MAXJ; ++j)
         if (j < J) {
-          const float gj = g[(size_t)e * J + j];
+          const float gj = ge[j];
           t = make_float4(fmaf(gj, w[j].x, t.x), fmaf(gj, w[j].y, t.y), fmaf(gj, w[j].z, t.z), fmaf(gj, w[j].w, t.w));
           dw[j] = make_float4(fmaf(gj, a.x, dw[j].x), fmaf(gj, a.y, dw[j].y), fmaf(gj, a.z, dw[j].z), fmaf(gj, a.w, dw[j].w));
           db[j] += gj;
@@ -540,12 +559,98 @@ extern "C" int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const 
     return 0;
   }
   const int lpr = pick_tpr(H / 4), nb = mh_grid(E, lpr);
-  MSDE_LAUNCH(mlp_head_bwd_kernel, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4*>(Z), ldz / 4,
+  MSDE_LAUNCH(mlp_head_bwd_kernel<false>, dim3(nb), dim3(256), 0, st, reinterpret_cast<const float4*>(Z), ldz / 4,
               reinterpret_cast<const float4*>(W), g, E, rows_dev, H / 4, J, lpr, reinterpret_cast<float4*>(gZ),
-              workspace);
+              workspace, (const float*)nullptr, (const int*)nullptr, (const int*)nullptr);
   MSDE_CHECK_LAUNCH();
   if (!gWb) return 0;                 // slabs stay in `workspace` for a batched reduction
   return msde_reduce_slabs(workspace, nb, n, gWb, nullptr, 0, nullptr, st);
+}
+
+// ---- the same head fused with what consumes it in the 2D->3D score network (equivariant_scorenetwork.py:142-166): the three
+// outputs per edge are the coefficients of the edge's frame vectors, mixed and averaged over the in-edges of the target node
+// and added to the running sum of the earlier score layers.  Forward: one workgroup per MHX_NPW consecutive nodes -- their
+// in-edges are contiguous (by-target order); the per-edge mixed vectors go through `mix` [E, 3] (written and read by the
+// same workgroup), then 8 lanes per node add them in the order of frame_mix_mean_fwd_kernel.  coff itself is never stored:
+// the backward (mlp_head_bwd_kernel<true>) needs only the node gradient and the frame.
+#define MHX_NPW 4
+__global__ void __launch_bounds__(256)
+mlp_head_mix_fwd_kernel(const float4* __restrict__ Z, int ldz4, const float4* __restrict__ W, const float* __restrict__ b,
+                        int H4, int lpr, const float* __restrict__ basis, const int* __restrict__ rowptr, int N,
+                        const float* __restrict__ base, float* __restrict__ mix, float* __restrict__ out) {
+  const int rpb = 256 / lpr, group = threadIdx.x / lpr, lane = threadIdx.x % lpr;
+  const int n0 = blockIdx.x * MHX_NPW, n1 = min(n0 + MHX_NPW, N);
+  const int e0 = rowptr[n0], e1 = rowptr[n1];
+  const float b0 = b ? b[0] : 0.f, b1 = b ? b[1] : 0.f, b2 = b ? b[2] : 0.f;
+  for (int e = e0 + group; e < e1; e += rpb) {
+    float p[3] = {0.f, 0.f, 0.f};
+    for (int c = lane; c < H4; c += lpr) {
+      const float4 z = Z[(size_t)e * ldz4 + c];
+      const float4 a = make_float4(z.x * mh_sigmoid(z.x), z.y * mh_sigmoid(z.y), z.z * mh_sigmoid(z.z), z.w * mh_sigmoid(z.w));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float4 w = W[j * H4 + c];
+        p[j] += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+      }
+    }
+    const float c0 = group_sum(p[0], lpr) + b0, c1 = group_sum(p[1], lpr) + b1, c2 = group_sum(p[2], lpr) + b2;
+    if (lane == 0) {
+      const float* bs = basis + 9 * (size_t)e;
+      float* m = mix + 3 * (size_t)e;
+      m[0] = (c0 * bs[0] + c1 * bs[3]) + c2 * bs[6];
+      m[1] = (c0 * bs[1] + c1 * bs[4]) + c2 * bs[7];
+      m[2] = (c0 * bs[2] + c1 * bs[5]) + c2 * bs[8];
+    }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < MHX_NPW * FMX_LPN) {
+    const int i = n0 + t / FMX_LPN, l = t % FMX_LPN;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    int s0 = 0, s1 = 0;
+    if (i < n1) {
+      s0 = rowptr[i]; s1 = rowptr[i + 1];
+      for (int e = s0 + l; e < s1; e += FMX_LPN) {
+        const float* m = mix + 3 * (size_t)e;
+        ax += m[0]; ay += m[1]; az += m[2];
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < FMX_LPN; o <<= 1) { ax += __shfl_xor(ax, o); ay += __shfl_xor(ay, o); az += __shfl_xor(az, o); }
+    if (i < n1 && l == 0) {
+      const float inv = 1.f / (float)max(s1 - s0, 1);
+      const float bx = base ? base[3 * i] : 0.f, by = base ? base[3 * i + 1] : 0.f, bz = base ? base[3 * i + 2] : 0.f;
+      out[3 * i] = bx + ax * inv; out[3 * i + 1] = by + ay * inv; out[3 * i + 2] = bz + az * inv;
+    }
+  }
+}
+
+extern "C" int msde_mlp_head_mix_fwd(const float* Z, int ldz, const float* W, const float* b, int H, const float* basis,
+                                     const int* rowptr, int N, const float* base, float* mix, float* out, void* stream) {
+  if (N < 0 || !Z || !W || !basis || !rowptr || !mix || !out) return MSDE_EINVAL;
+  if (!mh_ok(H, 3, Z, ldz, W)) return MSDE_EUNSUP;
+  if (N == 0) return 0;
+  const int lpr = pick_tpr(H / 4);
+  MSDE_LAUNCH(mlp_head_mix_fwd_kernel, dim3((N + MHX_NPW - 1) / MHX_NPW), dim3(256), 0, as_stream(stream),
+              reinterpret_cast<const float4*>(Z), ldz / 4, reinterpret_cast<const float4*>(W), b, H / 4, lpr, basis, rowptr, N,
+              base, mix, out);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// gnode [N, 3]: gradient of the mixed output; dst [E]: target node of each edge (by-target order, = the CSR of rowptr)
+extern "C" int msde_mlp_head_mix_bwd(const float* Z, int ldz, const float* W, const float* gnode, const float* basis,
+                                     const int* dst, const int* rowptr, int E, int H, float* gZ, float* workspace,
+                                     const int* rows_dev, void* stream) {
+  if (E < 0 || !Z || !W || !gnode || !basis || !dst || !rowptr || !gZ || !workspace) return MSDE_EINVAL;
+  if (!mh_ok(H, 3, Z, ldz, W) || (reinterpret_cast<uintptr_t>(gZ) & 15)) return MSDE_EUNSUP;
+  if (E == 0) return 0;
+  const int lpr = pick_tpr(H / 4), nb = mh_grid(E, lpr);
+  MSDE_LAUNCH(mlp_head_bwd_kernel<true>, dim3(nb), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(Z),
+              ldz / 4, reinterpret_cast<const float4*>(W), gnode, E, rows_dev, H / 4, 3, lpr, reinterpret_cast<float4*>(gZ),
+              workspace, basis, dst, rowptr);
+  MSDE_CHECK_LAUNCH();
+  return 0;
 }
 
 // ---- predictor-corrector sampler arithmetic (pretrain_MoleculeSDE_inference_2D_to_3D_VE_VP.py:163-168 ReverseDiffusionPredictor,

@@ -29,6 +29,7 @@ FUSE_GAT_TAIL = True     # csrc/gat_tail.hip for hidden size 32 (False: the kern
 NOISE_IN_KERNEL = _os.environ.get("MSDE_NOISE_IN_KERNEL", "1") != "0"     # DeviceNoise: draws made by the VE perturbation kernel
 FUSE_FRAME = _os.environ.get("MSDE_FUSE_FRAME", "1") != "0"              # hip._FrameMLP (False: coff_mlp twice + cat + project)
 STATIC_FEATURE_CACHE = _os.environ.get("MSDE_STATIC_FEATURES", "1") != "0"   # inference: coordinate-independent inputs of the score network computed once per 2D representation
+FUSE_HEAD_MIX = _os.environ.get("MSDE_FUSE_HEAD_MIX", "1") != "0"        # hip._MlpHeadMix (False: hip.mlp_fused + hip.frame_mix_mean)
 FUSE_EDGE_EMB = _os.environ.get("MSDE_FUSE_EDGE_EMB", "1") != "0"        # hip._PairBnReluLinear (False: gather-add, BatchNorm, Linear as separate ops)
 FUSE_PAIR_LINEAR = _os.environ.get("MSDE_FUSE_PAIR_LINEAR", "1") != "0"  # hip._PairLinear (False: re-laid-out weight per step)
 
@@ -154,6 +155,10 @@ class EquivariantScoreNetwork(nn.Module):
             if _nn.FUSED_MLP and node_feature.size(1) % 4 == 0 and edge_attr.size(1) % 4 == 0:
                 # cat([h_row + h_col, edge_attr]) written by the gather; Linear -> SiLU -> Linear on gemm_ex epilogues
                 edge_feature = hip.pair_gather_cat(node_feature, edge_attr, plan)
+                if FUSE_HEAD_MIX and hip.mlp_head_mix_ok(edge_feature, mlp[0], mlp[2]):
+                    # head + frame mix + mean + running sum in one kernel; the coefficients are never stored
+                    gradient = hip.mlp_head_mix(edge_feature, mlp[0], mlp[2], basis, plan, gradient)
+                    continue
                 coff = hip.mlp_fused(edge_feature, [(mlp[0].weight, mlp[0].bias), (mlp[2].weight, mlp[2].bias)], "silu")
             else:
                 pair = hip.pair_gather_add(node_feature, node_feature, plan)        # h_row + h_col

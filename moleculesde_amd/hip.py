@@ -1055,6 +1055,76 @@ def frame_mix_mean(coff, basis, plan, base=None):
     return _FrameMixMean.apply(coff, basis, plan, base)
 
 
+class _MlpHeadMix(torch.autograd.Function):
+    """basis MLP of the 2D->3D score network and what consumes it, as one autograd node (equivariant_scorenetwork.py:142-166):
+    Linear(in, H) -> SiLU -> Linear(H, 3) on every edge, the three outputs mixed with the edge's frame vectors, averaged over
+    the in-edges of the target node and added to `base`.  Forward: the first Linear (pre-activation stored) + ONE kernel
+    (msde_mlp_head_mix_fwd) instead of head kernel + frame-mix kernel; the per-edge coefficients are never stored.  Backward:
+    msde_mlp_head_mix_bwd forms the head's gradient from the node gradient while it reads the pre-activations (instead of a
+    frame-mix backward kernel writing it first), then the first Linear's input gradient; weight gradients queued."""
+
+    @staticmethod
+    def forward(ctx, x, basis, plan, base, offload, W1, b1, W2, b2):
+        x = x if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1) else _f32(x)
+        E, H = x.size(0), W1.size(0)
+        dev = x.device
+        Z = torch.empty(E, H, dtype=torch.float32, device=dev)
+        gemm_fwd(x, W1, Z, bias=b1)
+        mix = torch.empty(E, 3, dtype=torch.float32, device=dev)
+        out = torch.empty(plan.N, 3, dtype=torch.float32, device=dev)
+        base = _f32(base) if base is not None else None
+        _lib.call("msde_mlp_head_mix_fwd", _p(Z), _ld(Z), _p(W2), _p(b2), H, _p(basis), _p(plan.rowptr), plan.N, _p(base),
+                  _p(mix), _p(out), _stream())
+        ctx.save_for_backward(x, Z, basis, W1, W2)
+        ctx.plan = plan
+        ctx.has_b2 = b2 is not None
+        ctx.deferrable = offload and all(t is None or t.is_leaf or getattr(t, "_msde_leaf_like", False) for t in (W1, b1, W2, b2))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Z, basis, W1, W2 = ctx.saved_tensors
+        plan = ctx.plan
+        g = g if (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()) else _f32(g)
+        E, H = Z.shape
+        dev = g.device
+        gz = torch.empty(E, H, dtype=torch.float32, device=dev)
+        gall = torch.empty((3 * H + 3 + 3) & ~3, dtype=torch.float32, device=dev)      # [gW2 | gb2], whole float4
+        nslab = int(_lib.load().msde_mlp_head_bwd_slabs(E, H))
+        if _SLABS.active and ctx.deferrable:
+            ws = _SLABS.alloc(nslab * gall.numel(), dev)
+            _lib.call("msde_mlp_head_mix_bwd", _p(Z), _ld(Z), _p(W2), _p(g), _p(basis), _p(plan.dst), _p(plan.rowptr), E, H,
+                      _p(gz), _p(ws), _p(bound_tensor(E)), _stream())
+            _SLABS.add(ws.data_ptr(), nslab, gall.numel(), gall, written=True)
+        else:       # (no batch open: the two-kernel form, whose head kernel reduces its own slabs)
+            g_coff = torch.empty(E, 3, dtype=torch.float32, device=dev)
+            _lib.call("msde_frame_mix_mean_bwd", _p(g), _p(basis), _p(plan.rowptr), plan.N, E, _p(g_coff), _stream())
+            ws = torch.empty(nslab * gall.numel(), dtype=torch.float32, device=dev)
+            _lib.call("msde_mlp_head_bwd", _p(Z), _ld(Z), _p(W2), _p(g_coff), E, H, 3, _p(gz), _p(gall), _p(ws),
+                      _p(bound_tensor(E)), _stream())
+        gW2 = gall[:3 * H].view(3, H)
+        gb2 = gall[3 * H:3 * H + 3] if ctx.has_b2 else None
+        gW1 = gb1 = None
+        if ctx.needs_input_grad[5] or ctx.needs_input_grad[6]:
+            gW1, gb1 = weight_grad(gz, x, True, ctx.deferrable)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(E, W1.size(1), dtype=torch.float32, device=dev)
+            gemm_dgrad(gz, W1, gx)
+        return gx, None, None, (g if ctx.needs_input_grad[3] else None), None, gW1, gb1, gW2, gb2
+
+
+def mlp_head_mix_ok(x, lin1, lin2):
+    H = lin1.weight.size(0)
+    return (x.is_cuda and x.dim() == 2 and lin2.weight.size(0) == 3 and lin2.weight.size(1) == H and H % 4 == 0 and H <= 256
+            and lin1.bias is not None and lin2.weight.is_contiguous() and lin2.weight.data_ptr() % 16 == 0)
+
+
+def mlp_head_mix(x, lin1, lin2, basis, plan, base=None, offload=True):
+    """base + mean over in-edges of (lin2(silu(lin1(x))) mixed with the frame vectors): _MlpHeadMix."""
+    return _MlpHeadMix.apply(x, basis, plan, base, offload, lin1.weight, lin1.bias, lin2.weight, lin2.bias)
+
+
 class _SegmentMean(torch.autograd.Function):
     """Per-molecule mean/sum of node rows (torch_scatter.scatter over the sorted `batch` vector)."""
 

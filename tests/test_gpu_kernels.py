@@ -181,6 +181,65 @@ def test_pair_bn_relu_linear_fused(dev, B, D, H):
     assert_close(out, out2, 1e-4, 1e-4, "fused vs operator chain")
 
 
+@pytest.mark.parametrize("B,with_base", [(6, True), (40, False)])
+def test_mlp_head_mix_fused(dev, B, with_base):
+    """hip._MlpHeadMix (basis MLP + frame mix + mean over in-edges + running sum, equivariant_scorenetwork.py:142-166, one
+    autograd node) against fp64 autograd and against the two-operator form (hip.mlp_fused + hip.frame_mix_mean): output and the
+    gradients of the input, of both Linear layers and of the running sum -- inside a parameter-gradient batch (queued slabs)
+    and outside one."""
+    from moleculesde_amd import hip
+    from moleculesde_amd.geom3d import nn as mnn
+    torch.manual_seed(B)
+    b = _toy_graph(4, B)
+    N = b.x.size(0)
+    pl = _plan_for(b.extended_edge_index, N, dev)
+    E = pl.E
+    dst = pl.dst.cpu().long()
+    x = torch.randn(E, 64).double().requires_grad_(True)
+    basis = torch.randn(E, 3, 3).double()
+    base = torch.randn(N, 3).double().requires_grad_(True) if with_base else None
+    l1, l2 = torch.nn.Linear(64, 128).double(), torch.nn.Linear(128, 3).double()
+    coff = l2(torch.nn.functional.silu(l1(x)))
+    mixed = (coff[:, :, None] * basis).sum(1)
+    deg = torch.zeros(N, dtype=torch.float64).index_add_(0, dst, torch.ones(E, dtype=torch.float64)).clamp(min=1)
+    ref = torch.zeros(N, 3, dtype=torch.float64).index_add_(0, dst, mixed) / deg[:, None]
+    if base is not None:
+        ref = ref + base
+    R = torch.randn(N, 3).double()
+    (ref * R).sum().backward()
+    for batched in (False, True):
+        d1, d2 = mnn.Linear(64, 128).to(dev), mnn.Linear(128, 3).to(dev)
+        with torch.no_grad():
+            d1.weight.copy_(l1.weight.float()); d1.bias.copy_(l1.bias.float())
+            d2.weight.copy_(l2.weight.float()); d2.bias.copy_(l2.bias.float())
+        xd = x.detach().float().to(dev).requires_grad_(True)
+        based = base.detach().float().to(dev).requires_grad_(True) if base is not None else None
+        bd = basis.float().to(dev).contiguous()
+        assert hip.mlp_head_mix_ok(xd, d1, d2)
+        if batched:
+            hip.begin_param_grad_batch([d1.weight, d1.bias, d2.weight, d2.bias])
+        try:
+            out = hip.mlp_head_mix(xd, d1, d2, bd.view(E, 9), pl, based)
+            (out * R.float().to(dev)).sum().backward()
+        finally:
+            if batched:
+                hip.flush_wgrad_gemms()
+                hip.finish_param_grad_batch()
+        assert_close(out, ref, 1e-4, 1e-4, "out")
+        assert_close(xd.grad, x.grad, 2e-3, 1e-5, "g_x")
+        assert_close(d1.weight.grad, l1.weight.grad, 2e-3, 2e-4 * float(l1.weight.grad.abs().max()), "gW1")
+        assert_close(d1.bias.grad, l1.bias.grad, 2e-3, 2e-4 * float(l1.bias.grad.abs().max()), "gb1")
+        assert_close(d2.weight.grad, l2.weight.grad, 2e-3, 2e-4 * float(l2.weight.grad.abs().max()), "gW2")
+        assert_close(d2.bias.grad, l2.bias.grad, 2e-3, 2e-4 * float(l2.bias.grad.abs().max()), "gb2")
+        if based is not None:
+            assert_close(based.grad, base.grad, 1e-6, 1e-6, "g_base")
+        # the two-operator form gives the same output (same order of additions; multiply-add contraction may differ)
+        with torch.no_grad():
+            c2 = hip.mlp_fused(xd.detach(), [(d1.weight, d1.bias), (d2.weight, d2.bias)], "silu")
+            o2 = hip.frame_mix_mean(c2, bd.view(E, 9), pl, based.detach() if based is not None else None)
+        assert_close(out.detach(), o2, 1e-6, 1e-6, "fused vs two-operator output")
+
+
 @pytest.mark.parametrize("J", [3, 32])
 def test_pair_gather_cat_and_fused_mlp(dev, J):
     """cat([h_row + h_col, edge_attr]) -> Linear -> SiLU -> Linear (equivariant_scorenetwork.py:154-157, 142-146): the
