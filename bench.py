@@ -126,6 +126,7 @@ def count_kernels_per_step(trainer, batch):
     libmsde_hip.so)."""
     try:
         from torch.profiler import profile, ProfilerActivity
+        trainer.dp_enabled = False          # rank 0 measures alone: no collective may be issued here (N > 1 would deadlock)
         trainer.step(batch)
         torch.cuda.synchronize()
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
@@ -874,6 +875,9 @@ def main():
     if rank == 0:
         print(f"[bench] {a.steps} steps in {dt:.3f}s", file=sys.stderr, flush=True)
         mols = world * a.batch_size * a.steps
+        # everything below is measured by rank 0 ALONE while the other ranks wait at the final barrier: the trainer must not
+        # issue collectives any more (found by the 2-rank smoke run: the kernel count's eager step hung in its all-reduce)
+        trainer.dp_enabled = False
         # `roofline` = the kernel with the largest share of the step's GPU time (profiles/*_kernel_stats.csv):
         # cfconv_fused_bwd_w, timed at the workgroup count the step launches it with; the full-width figures are
         # kept as separate keys
