@@ -96,8 +96,9 @@ def in_step_stamps(trainer, batch, dev, graph_replays=25):
         dp_was, trainer.dp_enabled = trainer.dp_enabled, False      # rank 0 alone: no collectives in this measurement
         trainer.step(b2_)
         trainer.capture(b2_)
-        pairs = {"gin_gemm2": ("gin_gemm2_start", "gin_gemm2_end"), "cf_agg": ("cf_agg_start", "cf_agg_end"),
-                 "tail": ("bwd_main_end", "step_end"), "step": ("step_start", "step_end")}
+        pairs = {"cf_agg": ("cf_agg_start", "cf_agg_end"), "tail": ("bwd_main_end", "step_end"), "step": ("step_start", "step_end")}
+        for k in range(8):        # the GIN layers' second product: one pair of stamps per layer
+            pairs["gin_gemm2#%d" % k] = ("gin_gemm2_start#%d" % k, "gin_gemm2_end#%d" % k)
         vals = {k: [] for k in pairs}
         for _ in range(graph_replays):
             trainer.step_graph(b2_)
@@ -110,7 +111,11 @@ def in_step_stamps(trainer, batch, dev, graph_replays=25):
         for k, v in vals.items():
             if v:
                 v.sort()
-                res[k] = v[len(v) // 2] - (ovh if k in ("gin_gemm2", "cf_agg") else 0.0)
+                res[k] = v[len(v) // 2] - (ovh if (k.startswith("gin_gemm2") or k == "cf_agg") else 0.0)
+        per_layer = [res[k] for k in sorted(res) if k.startswith("gin_gemm2#")]
+        if per_layer:             # mean over the layers of the per-layer medians (a single layer's figure depends on what the
+            res["gin_gemm2"] = sum(per_layer) / len(per_layer)      # second stream happens to run beside it)
+            res["gin_gemm2_per_layer"] = [round(x, 2) for x in per_layer]
         res["replays"] = graph_replays
     except Exception as exc:
         print(f"[bench] in-step timing failed ({type(exc).__name__}: {exc})", file=sys.stderr)
@@ -195,8 +200,10 @@ def roofline_gemm(trainer, batch, dev, in_step):
     if in_us and in_us > 0:
         tfi = flops / (in_us * 1e-6) / 1e12
         out.update({"achieved": round(tfi, 2), "frac": round(tfi / FP32_MFMA_PEAK_TF, 4), "avg_launch_us": round(in_us, 2),
-                    "timing": "inside the captured step (device timestamps around the launch, median of %d replays, "
-                              "stamp overhead subtracted)" % in_step.get("replays", 0)})
+                    "timing": "inside the captured step (device timestamps around the launch in each of the 5 GIN layers, "
+                              "median of %d replays per layer, mean over the layers, stamp overhead subtracted)"
+                              % in_step.get("replays", 0),
+                    "avg_launch_us_per_layer": in_step.get("gin_gemm2_per_layer")})
     else:
         out.update({"achieved": out["standalone"]["achieved"], "frac": out["standalone"]["frac"],
                     "avg_launch_us": out["standalone"]["avg_launch_us"], "timing": "stand-alone (in-step timing unavailable)"})

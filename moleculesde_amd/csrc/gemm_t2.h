@@ -28,6 +28,9 @@
 #include <type_traits>
 #include <map>
 #include <mutex>
+#ifndef T2_NBUF
+#define T2_NBUF 4          // stages of the LDS ring (3: measured, tools/ab_libs.sh)
+#endif
 
 typedef int t2_i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int t2_u32x4 __attribute__((ext_vector_type(4)));
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(512)
 gemm_t2_kernel(const msde_rs_desc d) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char t2_smem[];
   static_assert(RN >= 1 && RN <= 12, "geometry");
-  constexpr int NBUF = 4;
+  constexpr int NBUF = T2_NBUF;
   constexpr int BM = 64, BN = 16 * RN;
   constexpr int NA = AXF == MSDE_RS_AXF_BNBWD ? 2 : 1;          // row operands staged per stage: A (and z)
   constexpr int AP = BM / 8, BP = BN / 8, P = NA * AP + BP;     // 1 KiB pieces of the A (, z) / B tile of one stage
@@ -436,7 +439,7 @@ static int t2_launch(KERN kern, dim3 grid, dim3 block, size_t lds, hipStream_t s
 // bytes of dynamic LDS of gemm_t2_kernel<rn, axf> for a reduction length K
 static inline size_t t2_lds_bytes(int rn, int axf, int K) {
   const int na = axf == MSDE_RS_AXF_BNBWD ? 2 : 1, nv = axf == MSDE_RS_AXF_BNBWD ? 5 : (axf == MSDE_RS_AXF_AFFINE ? 2 : 0);
-  return (size_t)4 * ((size_t)(64 * na + 16 * rn) * 128 + 1024) + (size_t)nv * (size_t)((K + 31) / 32 * 32) * 4;
+  return (size_t)T2_NBUF * ((size_t)(64 * na + 16 * rn) * 128 + 1024) + (size_t)nv * (size_t)((K + 31) / 32 * 32) * 4;
 }
 
 template <int AXF>

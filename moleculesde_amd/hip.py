@@ -2777,10 +2777,10 @@ class _GinMlpBN(torch.autograd.Function):
         st2 = torch.empty(s2, 2, D, dtype=torch.float32, device=dev)
         a1 = torch.empty(M, H, dtype=torch.float32, device=dev)
         z2 = torch.empty(M, D, dtype=torch.float32, device=dev)
-        stamp("gin_gemm2_start")          # no-ops unless enable_stamps(): bench.py times this launch inside the captured step
+        stamp("gin_gemm2_start", seq=True)          # no-ops unless enable_stamps(): bench.py times this launch inside the captured step
         gemm_node(z1, W2, z2, True, D, H, bias=b2, axf="affine", xf=(v1[0], v1[1]), relu=True, A_out=a1, stats=st2,
                   stats_mode="bnfwd")
-        stamp("gin_gemm2_end")
+        stamp("gin_gemm2_end", seq=True)
         v2 = _bn_fin_fwd(st2, s2, r2, M, D, g2, be2, eps2, mom2, rm2, rv2)
         h = torch.empty(M, D, dtype=torch.float32, device=dev)
         if link_out is not None:
@@ -3108,10 +3108,18 @@ def enable_stamps(device):
     STAMPS = {"buf": torch.zeros(256, dtype=torch.int64, device=device), "names": []}
 
 
-def stamp(name):
-    """No-op unless enable_stamps() was called: one 1-thread launch on the current stream storing the real-time counter."""
+def stamp(name, seq=False):
+    """No-op unless enable_stamps() was called: one 1-thread launch on the current stream storing the real-time counter.
+    seq: a name that occurs several times per step (one per GIN layer) gets its own slot per occurrence, `name#k`, counted
+    from the step's "step_start" stamp."""
     if STAMPS is None:
         return
+    if name == "step_start":
+        STAMPS["seq"] = {}
+    if seq:
+        k = STAMPS.setdefault("seq", {}).get(name, 0)
+        STAMPS["seq"][name] = k + 1
+        name = "%s#%d" % (name, k)
     if name not in STAMPS["names"]:
         STAMPS["names"].append(name)
     i = STAMPS["names"].index(name)

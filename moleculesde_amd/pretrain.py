@@ -563,6 +563,7 @@ class Trainer:
             self._graph_pool = torch.cuda.graph_pool_handle()
         # thread_local: other threads of the process (the RCCL watchdog under DP) may issue HIP calls
         # while this thread captures; they must not invalidate the capture
+        # (round 4: capturing on a high-priority stream -- main chain over the second stream -- changes nothing: 2.575 vs 2.582 ms)
         with _hip.no_gc(), self._bounds(batch), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             if pre is not None:
                 pre()
