@@ -16,7 +16,10 @@
 // the two-stream step returned a different value in ONE register of 16 CONSECUTIVE LANES of one wave of a co-resident kernel
 // (seen in msde_dense_edge_layer_fwd, a plain VALU kernel, and in msde_gemm_rs) in roughly one replay in six.  Bisection
 // (tools/bf16x3_repro.py): the same kernel with its six bf16 matrix instructions removed (-DT2B_NO_MFMA) or replaced by six
-// v_mfma_f32_16x16x4_f32 (-DT2B_F32_MFMA) never does it; neither does the fp32 kernel of gemm_t2.h; allocating AGPRs
+// v_mfma_f32_16x16x4_f32 (-DT2B_F32_MFMA) never does it; neither does the fp32 kernel of gemm_t2.h; NOR DOES THIS KERNEL WITH EACH
+// K = 32 INSTRUCTION WRITTEN AS TWO v_mfma_f32_16x16x16_bf16 (-DT2B_K16: the gfx90a-era shape; same sums, tests green, 0 of 8
+// trials against 6 of 8) -- the effect belongs to v_mfma_f32_16x16x32_bf16, the K-doubled shape new in gfx950, as hipcc 7.2
+// emits it here; 32 idle issue cycles behind every one of them (-DT2B_NOPS) change nothing; allocating AGPRs
 // (-DT2B_TOUCH_AGPR) does not help; no out-of-bounds global write (tools/t2b_guard.py), no stray LDS write
 // (tools/t2b_canary.py), no kernel of the step reads LDS it did not write (tools/lds_poison_step.py).  Root cause not
 // established; the switch therefore forces the single-stream step (pretrain.Trainer), where results are reproducible.
@@ -218,15 +221,35 @@ gemm_t2b_kernel(const msde_rs_desc d) {
         x[2] += __builtin_bit_cast(float, __builtin_bit_cast(t2_u32x4, ah)[0] ^ __builtin_bit_cast(t2_u32x4, bl)[1]) * 1e-30f;
         rd_b(nstage, c, 0, fb[cur ^ 1][c][0]);
         rd_b(nstage, c, 1, fb[cur ^ 1][c][1]);
+#elif defined(T2B_K16)
+        {   // (debugging the co-residency finding: each K = 32 instruction as two of the gfx90a-era K = 16 bf16 shape -- the lane's
+            //  eight k values split 4 + 4 on both operands alike, so the sum is the same)
+          typedef short t2b_s4 __attribute__((ext_vector_type(4)));
+          auto lo4 = [](const t2b_bf16x8& v) { const t2_u32x4 u = __builtin_bit_cast(t2_u32x4, v); typedef unsigned u2 __attribute__((ext_vector_type(2))); const u2 w = {u[0], u[1]}; return __builtin_bit_cast(t2b_s4, w); };
+          auto hi4 = [](const t2b_bf16x8& v) { const t2_u32x4 u = __builtin_bit_cast(t2_u32x4, v); typedef unsigned u2 __attribute__((ext_vector_type(2))); const u2 w = {u[2], u[3]}; return __builtin_bit_cast(t2b_s4, w); };
+#define T2B_M16(A_, B_) x = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(lo4(A_), lo4(B_), x, 0, 0, 0); x = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi4(A_), hi4(B_), x, 0, 0, 0)
+          T2B_M16(al, bh); T2B_M16(ah, bl);
+          rd_b(nstage, c, 0, fb[cur ^ 1][c][0]);
+          T2B_M16(am, bm); T2B_M16(am, bh);
+          rd_b(nstage, c, 1, fb[cur ^ 1][c][1]);
+          T2B_M16(ah, bm); T2B_M16(ah, bh);
+#undef T2B_M16
+        }
 #else
-        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, x, 0, 0, 0);
+#ifdef T2B_NOPS       // (debugging the co-residency finding: idle issue cycles behind every bf16 matrix instruction)
+#define T2B_GAP() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+#else
+#define T2B_GAP()
+#endif
+        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, x, 0, 0, 0); T2B_GAP();
+        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, x, 0, 0, 0); T2B_GAP();
         rd_b(nstage, c, 0, fb[cur ^ 1][c][0]);
-        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, x, 0, 0, 0); T2B_GAP();
+        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, x, 0, 0, 0); T2B_GAP();
         rd_b(nstage, c, 1, fb[cur ^ 1][c][1]);
-        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, x, 0, 0, 0);
-        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, x, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, x, 0, 0, 0); T2B_GAP();
+        x = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, x, 0, 0, 0); T2B_GAP();
+#undef T2B_GAP
 #endif
         rd_b(nstage, c, 2, fb[cur ^ 1][c][2]);
         acc[c][0] = x;
