@@ -573,7 +573,7 @@ extern "C" int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const 
 // in-edges are contiguous (by-target order); the per-edge mixed vectors go through `mix` [E, 3] (written and read by the
 // same workgroup), then 8 lanes per node add them in the order of frame_mix_mean_fwd_kernel.  coff itself is never stored:
 // the backward (mlp_head_bwd_kernel<true>) needs only the node gradient and the frame.
-#define MHX_NPW 4
+#define MHX_NPW 2
 __global__ void __launch_bounds__(256)
 mlp_head_mix_fwd_kernel(const float4* __restrict__ Z, int ldz4, const float4* __restrict__ W, const float* __restrict__ b,
                         int H4, int lpr, const float* __restrict__ basis, const int* __restrict__ rowptr, int N,
@@ -582,15 +582,29 @@ mlp_head_mix_fwd_kernel(const float4* __restrict__ Z, int ldz4, const float4* __
   const int n0 = blockIdx.x * MHX_NPW, n1 = min(n0 + MHX_NPW, N);
   const int e0 = rowptr[n0], e1 = rowptr[n1];
   const float b0 = b ? b[0] : 0.f, b1 = b ? b[1] : 0.f, b2 = b ? b[2] : 0.f;
+  // (H4 <= lpr: one column piece per lane -- its three weight rows stay in registers for all edges of the workgroup)
+  const bool one = H4 <= lpr;
+  float4 w0 = vzero4(), w1 = vzero4(), w2 = vzero4();
+  if (one && lane < H4) { w0 = W[lane]; w1 = W[H4 + lane]; w2 = W[2 * H4 + lane]; }
   for (int e = e0 + group; e < e1; e += rpb) {
     float p[3] = {0.f, 0.f, 0.f};
-    for (int c = lane; c < H4; c += lpr) {
-      const float4 z = Z[(size_t)e * ldz4 + c];
-      const float4 a = make_float4(z.x * mh_sigmoid(z.x), z.y * mh_sigmoid(z.y), z.z * mh_sigmoid(z.z), z.w * mh_sigmoid(z.w));
+    if (one) {
+      if (lane < H4) {
+        const float4 z = Z[(size_t)e * ldz4 + lane];
+        const float4 a = make_float4(z.x * mh_sigmoid(z.x), z.y * mh_sigmoid(z.y), z.z * mh_sigmoid(z.z), z.w * mh_sigmoid(z.w));
+        p[0] = (a.x * w0.x + a.y * w0.y) + (a.z * w0.z + a.w * w0.w);
+        p[1] = (a.x * w1.x + a.y * w1.y) + (a.z * w1.z + a.w * w1.w);
+        p[2] = (a.x * w2.x + a.y * w2.y) + (a.z * w2.z + a.w * w2.w);
+      }
+    } else {
+      for (int c = lane; c < H4; c += lpr) {
+        const float4 z = Z[(size_t)e * ldz4 + c];
+        const float4 a = make_float4(z.x * mh_sigmoid(z.x), z.y * mh_sigmoid(z.y), z.z * mh_sigmoid(z.z), z.w * mh_sigmoid(z.w));
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float4 w = W[j * H4 + c];
-        p[j] += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+        for (int j = 0; j < 3; ++j) {
+          const float4 w = W[j * H4 + c];
+          p[j] += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+        }
       }
     }
     const float c0 = group_sum(p[0], lpr) + b0, c1 = group_sum(p[1], lpr) + b1, c2 = group_sum(p[2], lpr) + b2;
