@@ -903,6 +903,11 @@ def cat_params(ws):
                 out = hit[1]
                 torch.cat([w.detach() for w in ws], 0, out=out)
                 _CAT_CACHE[key] = (ver, out, hit[2])
+                # re-laid-out copies made FROM this buffer (weight_t keys end with its address) may have been "refreshed" from
+                # its old contents by a training step's batched refresh in between: stale whatever their bookkeeping says
+                for k_, e_ in _WT.items():
+                    if isinstance(k_, tuple) and k_ and k_[-1] == out.data_ptr():
+                        e_["versions"] = None
                 return out
             out = _CatParams.apply(*ws)
             out._msde_leaf_like = all(w.is_leaf for w in ws)

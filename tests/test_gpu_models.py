@@ -645,6 +645,41 @@ def test_sampler_graph_matches_eager(dev):
     assert_close(outs[1], outs[0], 1e-4, 1e-4, "graph vs eager sampler")
 
 
+def test_inference_caches_follow_parameter_updates(dev):
+    """The inference-time caches (concatenated parameters and their transposed copies, coordinate-independent score-network
+    inputs) must not survive a parameter update: get_score after training steps == get_score of a FRESH model loaded with
+    the same parameters (a training step's batched weight-copy refresh runs between the two evaluations)."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import pretrain
+    from moleculesde_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=0, emb_dim=64)
+    tr = pretrain.Trainer(args, dev)
+    b = G.prepare_batch(make_batch(8, seed=3), dev)
+    m = tr.models["SDE_2Dto3D_model"]
+    gnn = tr.models["model_2D"]
+
+    def score(model, enc):
+        model.eval(); enc.eval()
+        with torch.no_grad():
+            rep = enc(b.x, b.edge_index, b.edge_attr)
+            out = model.get_score(rep, b, b.positions, None, torch.full((b.x.size(0),), 0.5, device=dev))
+        model.train(); enc.train()
+        return out.clone()
+
+    s0 = score(m, gnn)
+    for _ in range(3):
+        tr.step(b)
+    s1 = score(m, gnn)
+    assert (s1 - s0).abs().max() > 0, "the parameters did not move"
+    args2 = pretrain.readme_args(SDE_coeff_generative_3Dto2D=0, emb_dim=64)
+    fresh = pretrain.build_models(args2, dev)
+    fresh["SDE_2Dto3D_model"].load_state_dict(m.state_dict())
+    fresh["model_2D"].load_state_dict(gnn.state_dict())
+    s2 = score(fresh["SDE_2Dto3D_model"], fresh["model_2D"])
+    assert_close(s1, s2, 1e-5, 1e-6, "get_score after training steps vs a fresh model with the same parameters")
+
+
 @pytest.mark.parametrize("sde_type", ["VE", "VP"])
 def test_sampler_fused_arithmetic_matches_operator_path(dev, sde_type):
     """msde_pc_corrector / msde_pc_predictor (one kernel per half iteration, diffusion-time scalars tabulated once) against
