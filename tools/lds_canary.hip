@@ -1,3 +1,5 @@
+// Build: hipcc --offload-arch=gfx950 -O2 -fPIC -shared tools/lds_canary.hip -o tools/_build/liblds_canary.so   (loaded by
+// tools/t2b_canary.py, tools/vgpr_canary.py, tools/lds_poison_step.py; investigation tools, not part of the product)
 // Debug tool: workgroups that fill their LDS with a pattern and keep checking it for `iters` rounds; a word that changes under
 // them (another workgroup's stray LDS write) is counted.  Run beside the kernel under suspicion (tools/t2b_canary.py).
 #include <hip/hip_runtime.h>
