@@ -474,7 +474,7 @@ def roofline_dense_head_node_mlp(batch, iters=20):
         ms = _event_time_ms(g.replay, iters, torch.cuda.current_stream())
     flops = 2.0 * N * (364 * 728 + 728 * 728 + 728 * 119)
     tf = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "gemm_ex_kernel + gemm_rsa_kernel x2 (node MLP 364->728->728->119 of the dense head, valid atoms only)", "bound": "mfma",
+    return {"kernel": "gemm_ex_kernel (364->728) + gemm_t2_kernel (728->728) + gemm_rsa_kernel (728->119): node MLP of the dense head, valid atoms only", "bound": "mfma",
             "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4),
             "us_per_chain": round(ms * 1e3, 2), "rows": N, "flops": flops}
 
