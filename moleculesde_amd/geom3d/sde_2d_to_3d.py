@@ -155,7 +155,7 @@ class EquivariantScoreNetwork(nn.Module):
             if _nn.FUSED_MLP and node_feature.size(1) % 4 == 0 and edge_attr.size(1) % 4 == 0:
                 # cat([h_row + h_col, edge_attr]) written by the gather; Linear -> SiLU -> Linear on gemm_ex epilogues
                 edge_feature = hip.pair_gather_cat(node_feature, edge_attr, plan)
-                if FUSE_HEAD_MIX and hip.mlp_head_mix_ok(edge_feature, mlp[0], mlp[2]):
+                if FUSE_HEAD_MIX and plan.E > 0 and hip.mlp_head_mix_ok(edge_feature, mlp[0], mlp[2]):
                     # head + frame mix + mean + running sum in one kernel; the coefficients are never stored
                     gradient = hip.mlp_head_mix(edge_feature, mlp[0], mlp[2], basis, plan, gradient)
                     continue
@@ -301,7 +301,7 @@ class SDEModel2Dto3D_02(nn.Module):
             bst = torch.cat([self._zero_bias, lin0.bias])          # the row half carries no bias
             AB = _nn.linear(node_2D_repr, Wst, bst)
         bn, lin3 = self.edge_2D_emb[1], self.edge_2D_emb[3]
-        if (FUSE_EDGE_EMB and torch.is_grad_enabled() and _nn.bn_fusable(bn) and bn.fuse_relu
+        if (FUSE_EDGE_EMB and torch.is_grad_enabled() and _nn.bn_fusable(bn) and bn.fuse_relu and ep.E > 0
                 and hip.pair_bn_relu_linear_ok(AB, bn, lin3)):
             # gather-add + BatchNorm statistics in one pass, BatchNorm + ReLU inside the second Linear (hip._PairBnReluLinear)
             out = hip.pair_bn_relu_linear(AB, ep, bn, lin3)
