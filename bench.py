@@ -709,6 +709,42 @@ def bf16x3_experiment(a):
             "status": "off by default, not the headline: beside this kernel on a second stream other kernels were not reproducible"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, argv, timeout=None):
+    """`bench.py --gpus N` without torchrun's environment: start `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same flags>` as a child process (never exec: SURVEY §8e / the pool's rule about processes that may have
+    initialised the GPU), relay its output, return its exit code.  N ranks need N devices unless MSDE_DP_BACKEND=gloo
+    (the functional smoke mode: several gloo ranks share one GPU) -- refusing here is better than a 1-GPU number
+    labelled N."""
+    import subprocess
+    have = torch.cuda.device_count()            # counts devices without creating a HIP context
+    if have < n and os.environ.get("MSDE_DP_BACKEND") != "gloo":
+        print(f"[bench] --gpus {n} but only {have} device(s) visible; set MSDE_DP_BACKEND=gloo for the one-GPU smoke "
+              f"mode of the DP step structure", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    try:
+        for line in child.stdout:               # rank 0's JSON line (and anything else the ranks print) passes through
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return child.wait(timeout=timeout)
+    except BaseException:
+        child.kill()
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -729,7 +765,36 @@ def main():
                          "(graph without Adam; all-reduce; Adam kernel)")
     ap.add_argument("--full", action="store_true",
                     help="configs[2] per-GPU work: add the 3D->2D dense head loss (default: configs[1])")
+    ap.add_argument("--census_only", action="store_true",
+                    help="launcher check: start the ranks, count them with one all-reduce, print the line's DP keys and exit "
+                         "(runs without a GPU under MSDE_DP_BACKEND=gloo: tests/test_host_logic.py)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched HIP yet (torch is imported, no device
+        # call made), and the ranks are CHILD processes -- this process only relays rank 0's JSON line and the exit code.
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+
+    if a.census_only:
+        from moleculesde_amd import dp
+        on_gpu = torch.cuda.device_count() > 0
+        rank, world, local = dp.init_from_env("cuda" if on_gpu else "cpu")
+        dev = torch.device("cuda", local if torch.cuda.device_count() > local else 0) if on_gpu else torch.device("cpu")
+        ones = torch.ones(1, device=dev)
+        mine = torch.tensor([dev.index if on_gpu else -1], device=dev, dtype=torch.int64)
+        got = [mine]
+        if world > 1:
+            torch.distributed.all_reduce(ones)
+            got = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(got, mine)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rccl_ranks_seen": int(ones.item()), "rank_devices": [int(g.item()) for g in got],
+                              "dp_backend": torch.distributed.get_backend() if world > 1 else None, "census_only": True}),
+                  flush=True)
+        dp.barrier()
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+        return
 
     from moleculesde_amd import _lib, dp, pretrain
     from moleculesde_amd.geom3d import prepare_batch
@@ -873,10 +938,21 @@ def main():
         finally:
             from moleculesde_amd import hip as _hip
             _hip.clear_row_bounds()
-    if world > 1:
+    ranks_seen, rank_devices, backend = 1, [int(device.index)], None
+    if world > 1 or torch.distributed.is_initialized():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+        # census: an all-reduce of ones says how many ranks really took part in the collectives, the gathered device
+        # indices say whether they sat on distinct GPUs (the one-GPU gloo smoke mode shows [0, 0, ...])
+        ones = torch.ones(1, device=device)
+        torch.distributed.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        mine = torch.tensor([device.index], device=device, dtype=torch.int64)
+        got = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size())]
+        torch.distributed.all_gather(got, mine)
+        rank_devices = [int(g.item()) for g in got]
+        backend = torch.distributed.get_backend()
 
     out = None
     if rank == 0:
@@ -901,6 +977,7 @@ def main():
             "value": round(mols / dt, 1), "unit": "molecules/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_ranks_seen": ranks_seen, "rank_devices": rank_devices, "dp_backend": backend,
             "config": {"workload": "PCQM4Mv2-shaped pretrain step: GIN5x300 + SchNet(6x128f,51g,rc10) + "
                                    "EBM_node_dot_prod contrastive + SDEModel2Dto3D_02 VE" + (" + SDEModel3Dto2D_node_adj_dense VE" if a.full else "") + "; fwd+bwd+Adam",
                        "molecules_per_gpu": a.batch_size, "global_batch": world * a.batch_size,

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import hip, plan as _plan
+from .. import escore as _escore, hip, plan as _plan
 from . import nn as _nn
 from .sde import VESDE, VPSDE
 
@@ -31,6 +31,7 @@ FUSE_FRAME = _os.environ.get("MSDE_FUSE_FRAME", "1") != "0"              # hip._
 STATIC_FEATURE_CACHE = _os.environ.get("MSDE_STATIC_FEATURES", "1") != "0"   # inference: coordinate-independent inputs of the score network computed once per 2D representation
 FUSE_HEAD_MIX = _os.environ.get("MSDE_FUSE_HEAD_MIX", "1") != "0"        # hip._MlpHeadMix (False: hip.mlp_fused + hip.frame_mix_mean)
 FUSE_EDGE_EMB = _os.environ.get("MSDE_FUSE_EDGE_EMB", "1") != "0"        # hip._PairBnReluLinear (False: gather-add, BatchNorm, Linear as separate ops)
+MOL_KERNEL = True       # EquivariantScoreNetwork as one launch, one workgroup per molecule (False: operator by operator, the cross-check)
 FUSE_PAIR_LINEAR = _os.environ.get("MSDE_FUSE_PAIR_LINEAR", "1") != "0"  # hip._PairLinear (False: re-laid-out weight per step)
 
 
@@ -134,15 +135,22 @@ class EquivariantScoreNetwork(nn.Module):
         # lin_edge of every GAT layer consumes the same edge features: one stacked weight, one GEMM
         return [[gnn.MHA.lin_edge.weight for layers in self.gnn_layers for gnn in layers]]
 
-    def forward(self, plan, node_attr, edge_attr, basis):
+    def forward(self, plan, node_attr, edge_attr, basis, pl=None):
+        """pl: the batch plan (atom ranges of the molecules) -- given, and the shapes allowing, the whole network is ONE launch
+        with one workgroup per molecule (moleculesde_amd/escore.py, csrc/escore_mol.hip); otherwise operator by operator."""
+        if self.seed_dev is None:
+            self._calls += 1     # eager: host-side call counter; graph mode: the device counter varies the mask
+        if MOL_KERNEL and node_attr.is_cuda and plan.E > 0 and _escore.supported(self, pl):
+            seed0 = (self._seed_base + self._calls) * 16
+            if not torch.is_grad_enabled():
+                return {"node_feature": None,
+                        "gradient": _escore.forward_nograd(self, plan, pl, node_attr, edge_attr, basis, seed0, self.seed_dev)}
         conv_input = node_attr
         gradient = None
         ee_all, shared, D = None, None, self.hidden_dim
         ee_all = _nn.linear(edge_attr, hip.cat_params(self.fusion_sets()[0]))       # [E, layers*D]
         shared = {}
         layer_no = 0
-        if self.seed_dev is None:
-            self._calls += 1     # eager: host-side call counter; graph mode: the device counter varies the mask
         for module_idx, gnn_layers in enumerate(self.gnn_layers):
             for conv_idx, gnn in enumerate(gnn_layers):
                 seed = (self._seed_base + self._calls) * 16 + module_idx * 4 + conv_idx
@@ -282,13 +290,15 @@ class SDEModel2Dto3D_02(nn.Module):
                hip._WT_EPOCH,
                tuple(t._version for m in (self.edge_2D_emb, self.node_emb) for t in list(m.parameters()) + list(m.buffers())))
         hit = getattr(self, "_static_cache", None)
-        if hit is not None and hit[0] == key:
+        # the entry PINS the representation and the plan it was computed from and is matched by identity: addresses and
+        # id()s alone are reused by the allocator / CPython once the previous molecule's objects die
+        if hit is not None and hit[0] == key and hit[3] is node_2D_repr and hit[4] is ep:
             return hit[1], hit[2]
         if torch.cuda.is_current_stream_capturing():
             return None            # (computed inside the capture like everything else; cached by the next eager call)
         edge_attr_2D = self._edge_2D(node_2D_repr, ep)
         node_attr = self.node_emb(node_2D_repr)
-        self._static_cache = (key, edge_attr_2D, node_attr)
+        self._static_cache = (key, edge_attr_2D, node_attr, node_2D_repr, ep)
         return edge_attr_2D, node_attr
 
     def _edge_2D(self, node_2D_repr, ep):
@@ -351,7 +361,7 @@ class SDEModel2Dto3D_02(nn.Module):
                     t.record_stream(cur)
 
         node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep, (geo, side))
-        scores = self.score_network(ep, node_attr, edge_attr, basis)["gradient"]
+        scores = self.score_network(ep, node_attr, edge_attr, basis, pl)["gradient"]
         # sum_k (score - noise)^2 [* std^anneal_power] -> scatter_mean over molecules -> mean: one kernel pair
         return {"position": hip.ve_position_loss(scores, pos_noise, std_pos, anneal_power, pl.mol_ptr, pl.batch_i32)}
 
@@ -361,12 +371,13 @@ class SDEModel2Dto3D_02(nn.Module):
         (msde_pc_corrector / msde_pc_predictor) apply the scaling themselves."""
         pl, ep = self._plan(data)
         node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep)
-        return self.score_network(ep, node_attr, edge_attr, basis)["gradient"]
+        return self.score_network(ep, node_attr, edge_attr, basis, pl)["gradient"]
 
+    @torch.no_grad()
     def get_score(self, node_2D_repr, data, pos_perturbed, sigma, t_pos):
         pl, ep = self._plan(data)
         node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep)
-        output = self.score_network(ep, node_attr, edge_attr, basis)["gradient"]
+        output = self.score_network(ep, node_attr, edge_attr, basis, pl)["gradient"]
         _, std_pos = self.sde_pos.marGINal_prob(pos_perturbed, t_pos)
         return -output / std_pos[:, None]
 

@@ -1,0 +1,129 @@
+"""EquivariantScoreNetwork on the one-workgroup-per-molecule kernels (csrc/escore_mol.hip, moleculesde_amd/escore.py)
+against (a) the oracle's CPU restatement of equivariant_scorenetwork.py:121-169 and (b) the operator-by-operator HIP path,
+which draws the identical dropout masks from the same seeds.  fp32; tolerances at each assert."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restate as R  # noqa: E402
+from helpers import assert_close  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from moleculesde_amd import _lib
+    _lib.load()
+    return torch.device("cuda", 0)
+
+
+def _case(dev, B, seed):
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import plan as P
+    from moleculesde_amd.geom3d import sde_2d_to_3d as M
+    from moleculesde_amd.synthetic import make_batch
+    torch.manual_seed(seed)
+    cpu_b = make_batch(B, seed)
+    dev_b = G.prepare_batch(cpu_b.clone(), dev)
+    pl = P.get_plan(dev_b)
+    ep = pl.ext
+    net = M.EquivariantScoreNetwork(32, hidden_coff_dim=128)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.normal_(1, 0.3)
+                m.bias.normal_(0, 0.3)
+    net = net.to(dev)
+    x = torch.randn(ep.N, 32)
+    ea_canon = torch.randn(ep.E, 32) * 0.7
+    basis = torch.randn(ep.E, 9)
+    return cpu_b, pl, ep, net, x, ea_canon, basis
+
+
+def _oracle(net, cpu_b, ep, x, ea_canon, basis):
+    o = R.EquivariantScoreNetwork(32, hidden_coff_dim=128)
+    o.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    o.eval()
+    perm = ep.perm_t.cpu()                              # canonical edge id -> position in the caller's edge_index
+    ei = cpu_b.extended_edge_index
+    ea = torch.empty_like(ea_canon)
+    bs = torch.empty_like(basis)
+    ea[perm] = ea_canon
+    bs[perm] = basis
+    return o, ei, ea, [bs[:, 0:3], bs[:, 3:6], bs[:, 6:9]]
+
+
+@pytest.mark.parametrize("B,seed", [(1, 3), (7, 5), (256, 0)])
+def test_escore_mol_forward_eval_vs_oracle_and_operator_path(dev, B, seed):
+    from moleculesde_amd.geom3d import sde_2d_to_3d as M
+    cpu_b, pl, ep, net, x, ea, basis = _case(dev, B, seed)
+    net.eval()
+    o, ei, ea_o, basis_o = _oracle(net, cpu_b, ep, x, ea, basis)
+    with torch.no_grad():
+        ref = o(ei, x, ea_o, basis_o)["gradient"]
+        xd, ed, bd = x.to(dev), ea.to(dev), basis.to(dev)
+        assert M.MOL_KERNEL
+        got = net(ep, xd, ed, bd, pl)["gradient"]
+        M.MOL_KERNEL = False
+        try:
+            ops = net(ep, xd, ed, bd, pl)["gradient"]
+        finally:
+            M.MOL_KERNEL = True
+    scale = float(ref.abs().max())
+    assert_close(got, ref, 1e-4, 2e-5 * scale, "escore mol kernel vs oracle")
+    assert_close(got, ops, 1e-5, 2e-6 * scale, "escore mol kernel vs operator path")
+    # bit-reproducible: every sum inside the kernel has a fixed order
+    with torch.no_grad():
+        again = net(ep, xd, ed, bd, pl)["gradient"]
+    assert torch.equal(got, again)
+
+
+def test_escore_mol_forward_dropout_masks_match_operator_path(dev):
+    from moleculesde_amd.geom3d import sde_2d_to_3d as M
+    cpu_b, pl, ep, net, x, ea, basis = _case(dev, 16, 11)
+    net.train()
+    xd, ed, bd = x.to(dev), ea.to(dev), basis.to(dev)
+    ctr = torch.full((1,), 9, dtype=torch.int64, device=dev)
+    outs = []
+    for seed_dev in (None, ctr):
+        net.seed_dev = seed_dev
+        pair = []
+        for mol in (True, False):
+            net._calls = 41
+            M.MOL_KERNEL = mol
+            try:
+                with torch.no_grad():
+                    pair.append(net(ep, xd, ed, bd, pl)["gradient"])
+            finally:
+                M.MOL_KERNEL = True
+        assert_close(pair[0], pair[1], 1e-5, 2e-6 * float(pair[1].abs().max()), "escore dropout: mol kernel vs operator path")
+        outs.append(pair[0])
+    net.seed_dev = None
+    assert not torch.allclose(outs[0], outs[1])         # the device counter changes the masks
+    net.eval()
+    with torch.no_grad():
+        clean = net(ep, xd, ed, bd, pl)["gradient"]
+    assert not torch.allclose(outs[0], clean)           # and dropout was really on
+
+
+def test_escore_mol_padded_rows_and_empty_molecules(dev):
+    """Capacity padding: atoms behind the last molecule get zero scores, an empty molecule in the middle is skipped."""
+    from moleculesde_amd import escore
+    cpu_b, pl, ep, net, x, ea, basis = _case(dev, 5, 21)
+    net.eval()
+    xd, ed, bd = x.to(dev), ea.to(dev), basis.to(dev)
+    with torch.no_grad():
+        ref = escore.forward_nograd(net, ep, pl, xd, ed, bd, 0, None)
+    import types
+    N, pad = ep.N, 7
+    mp = pl.mol_ptr.cpu().tolist()
+    mp2 = mp[:3] + [mp[2]] + mp[3:]                     # an empty molecule between molecules 1 and 2
+    pl2 = types.SimpleNamespace(mol_ptr=torch.tensor(mp2, dtype=torch.int32, device=dev), B=len(mp2) - 1, N_max=pl.N_max)
+    ep2 = types.SimpleNamespace(N=N + pad, E=ep.E, src=ep.src, dst=ep.dst,
+                                rowptr=torch.cat([ep.rowptr, ep.rowptr[-1:].expand(pad)]).contiguous())
+    x2 = torch.cat([xd, torch.full((pad, 32), float("nan"), device=dev)])
+    with torch.no_grad():
+        got = escore.forward_nograd(net, ep2, pl2, x2, ed, bd, 0, None)
+    assert torch.equal(got[:N], ref)
+    assert torch.equal(got[N:], torch.zeros(pad, 3, device=dev))

@@ -266,3 +266,23 @@ def test_data_parallel_gloo_world_size_2(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("OK") == 2
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun environment) must become a launcher of 2 rank processes, not a 1-rank run
+    labelled 2.  Runs here without a GPU: `--census_only` stops after the rank count, gloo backend."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MSDE_DP_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--census_only"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and len(j["rank_devices"]) == 2
+    # without the smoke backend and without 2 devices the launcher refuses instead of mislabelling a 1-GPU run
+    if torch.cuda.device_count() < 2:
+        env.pop("MSDE_DP_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--census_only"], env=env,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 2 and "device(s) visible" in r.stderr
