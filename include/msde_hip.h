@@ -805,22 +805,22 @@ int msde_gat_tail_bwd(const float* g_out, const float* x, const float* y1, const
 /* EquivariantScoreNetwork.forward (equivariant_scorenetwork.py:121-169; called from SDE_model_2D_to_3D.py:386-391 and
  * get_score :393-445) for hidden = 32, 8 heads, basis-MLP width 128 and molecules of <= 32 atoms: 4 GATLayers (:13-40),
  * 2 basis MLPs, frame mix and the mean over in-edges, ONE launch, one workgroup per molecule (csrc/escore_mol.hip).
- *   params: HOST array of 52 device pointers, nn.Linear layouts, field-major:
- *     [Wqkvs x4 ([128,32]: query|key|value|skip rows), bqkvs x4, Wedge x4 ([32,32]), ln1_g x4, ln1_b x4, W0 x4, b0 x4,
- *      W3 x4, b3 x4, ln2_g x4, ln2_b x4, basis W1 x2 ([128,64]), b1 x2, W2 x2 ([3,128]), b2 x2]
+ *   params: DEVICE array of 52 device pointers (the caller keeps it alive and current), nn.Linear layouts: per GAT layer
+ *     (x4) [Wqkvs ([128,32]: query|key|value|skip rows), bqkvs, Wedge ([32,32]), ln1_g, ln1_b, W0, b0, W3, b3, ln2_g, ln2_b],
+ *     then per basis MLP (x2) [W1 ([128,64]), b1, W2 ([3,128]), b2]
  *   x0 [N,32] node features, edge_attr [E,ld_ea] (by-target edge order), basis [E,9], mol_ptr [B+1] atom ranges,
  *   rowptr [N+1] / src [E] / dst [E] the by-target CSR of the (extended) edges.
  *   Dropout: attention weights (p_att) and feed-forward (p_ffn) masks are the counter masks of msde_edge_attention_fwd /
  *   msde_gat_tail_fwd with per-layer seeds seed0 + 4*block + conv (feed-forward: ^ 0x46464E), + seed_dev[0] * 0x100000001B3.
  *   out [N,3]: the score ("gradient"); rows behind mol_ptr[B] are zero-filled.
- *   saved / alpha_saved (both or neither): what msde_escore_mol_bwd needs -- msde_escore_mol_saved_floats(N) floats
- *   and 4*E*8 floats. */
+ *   saved (or NULL): what msde_escore_mol_bwd needs, msde_escore_mol_saved_floats(N) floats (per layer and atom: attention
+ *   output, y1, h0, x2, layer output, softmax max and 1/sum per head; everything per-edge is recomputed in the backward). */
 long long msde_escore_mol_saved_floats(int N);
 int msde_escore_mol_fwd(const void* const* params, const float* x0, const float* edge_attr, int ld_ea,
                         const float* basis, const int* mol_ptr, int B, const int* rowptr, const int* src,
                         const int* dst, int N, int E, int hidden, int heads, int hidden_coff, float p_att,
                         float p_ffn, unsigned long long seed0, const unsigned long long* seed_dev, float eps1,
-                        float eps2, float* out, float* saved, float* alpha_saved, void* stream);
+                        float eps2, float* out, float* saved, void* stream);
 
 /* ------------------------------------------------------------------ optimiser -------------- */
 /* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —

@@ -146,7 +146,7 @@ SIGNATURES = {
     "msde_gat_tail_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P],
     "msde_gat_tail_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P, P, P, P],
     "msde_escore_mol_saved_floats": [I],
-    "msde_escore_mol_fwd": [P, P, P, I, P, P, I, P, P, P, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P, P],
+    "msde_escore_mol_fwd": [P, P, P, I, P, P, I, P, P, P, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P],
     "msde_chunk_elems": [],
     "msde_gather_chunks": [P, I, P, P],
     "msde_adam_chunks": [P, P, I, P, P, P, P, P, I, F, F, F, F, F, P],

@@ -2,142 +2,135 @@
 // (equivariant_scorenetwork.py:13-40 GATLayer, :121-169 forward; SDE_model_2D_to_3D.py:386-391, :393-445 get_score).
 //
 // Every extended edge joins two atoms of one molecule (<= 32 atoms, <= 992 edges, hidden size 32), so a molecule's four
-// GAT layers, two basis MLPs and the frame mix never need data of another workgroup:
-//     per layer   qkvs = x Wqkvs^T + b                   [n, 128]   fp32 MFMA 16x16x4, A from LDS, B (weights) in registers
-//                 ee   = edge_attr Wedge^T               [E_m, 32]  fp32 MFMA, A straight from global, result in LDS
-//                 attention: one wave per target, lane = 8 * edge slot + head (the recipe of edge_attention_fwd_wave_kernel
-//                            reading LDS), softmax in registers, dropout from the counter mask of the operator path
-//                 tail: y1 = x + LN1(att); FFN; out = y1 + LN2(.) [+ SiLU]: 8 lanes per atom row (the recipe of gat_tail.hip)
-//     per block   Z = [h_src + h_dst | edge_attr] W1^T + b1  [E_m, 128]  fp32 MFMA, each wave owns 32 columns (weights resident
-//                 in registers for all edge tiles), SiLU, the 3-wide head as per-lane partial dots + a 16-lane reduction,
-//                 frame mix per edge, mean over the in-edges of each atom in edge order (fixed order: bit-reproducible)
+// GAT layers, two basis MLPs and the frame mix never need data of another workgroup.  The kernel is a LATENCY problem (four
+// waves walk ~30 dependent phases), so every phase is laid out to need no cross-lane traffic (ds_bpermute shuffles were
+// 60 % of the first version's 105 us for ten 14-atom molecules) and no global round trip (indices and edge features are
+// staged in LDS once, the weights of layer l + 1 are requested while layer l computes):
+//     per layer   qkvs = x Wqkvs^T + b                [n, 128]   fp32 MFMA 16x16x4, A from LDS, B (weights) in registers
+//                 ee   = edge_attr Wedge^T            [E_m, 32]  fp32 MFMA, result in LDS
+//                 attention: one LANE per (target, head) walking the target's in-edges -- scores, softmax statistics and
+//                            the weighted sum stay in the lane's registers; dropout from the counter mask of the operator path
+//                 tail: y1 = x + LN1(att) on 8 lanes per atom row (row sums by DPP), the two 32 x 32 feed-forward products
+//                       on MFMA (one 16 x 16 tile per wave), out = y1 + LN2(.) [+ SiLU]
+//     per block   Z^T = W1 [h_src + h_dst | edge_attr]^T + b1  [128, E_m]  fp32 MFMA, TRANSPOSED so that the 3-wide head
+//                 coff^T = W2 SiLU(Z^T) takes the accumulator tile as its B operand (no lane reduction); a wave takes every
+//                 fourth 16-edge tile with all 128 hidden rows (W1 resident in registers); frame mix per edge, mean over the
+//                 in-edges of each atom in edge order (fixed order: bit-reproducible)
 // The operator path (msde_edge_attention_*, msde_gat_tail_*, msde_mlp_head_mix_*, ~18 launches forward) stays as the
 // cross-check and for shapes this kernel does not take (hidden != 32, heads != 8, basis-MLP width != 128, > 32 atoms).
 // Dropout masks are functions of (seed, GLOBAL edge / element index) exactly as in those kernels, so both paths draw the
 // same masks from the same seed.
 //
-// Training: the forward stores, per layer, the rows the backward kernel cannot cheaply rebuild (attention output, y1, h0, x2,
-// the layer output: 5 x [N, 32]; the softmax weights [E, 8]); everything per-edge and 128 wide is recomputed there.
+// Training: the forward stores, per layer and atom, the rows the backward kernel does not rebuild (attention output, y1, h0,
+// x2, the layer output, the softmax statistics max / 1/sum per head: ES_SV floats); everything per-edge is recomputed there.
 #include "msde_common.h"
 
 #define ES_D 32
 #define ES_HC 128
 #define ES_NMAX 32
-#define ES_ECH 384            // edges per attention chunk (whole molecules of <= 20 atoms: one chunk)
+#define ES_ECH 192            // edges per attention chunk (a molecule of <= 14 atoms: one chunk)
 #define ES_LDX 36             // LDS row stride of the [., 32] tiles (16-byte aligned rows, conflict-free b128 fragments)
 #define ES_LDQ 132            // LDS row stride of qkvs [., 128]
 #define ES_LAYERS 4
-#define ES_SV 160             // saved floats per (layer, atom): att | y1 | h0 | x2 | out
+#define ES_SV 176             // saved floats per (layer, atom): att | y1 | h0 | x2 | out | softmax max[8] | 1/sum[8]
 #define ES_NPTR 52
+#define ES_EMAX (ES_NMAX * (ES_NMAX - 1))    // 992 edges at most
+#define ES_EAL 384                           // molecules of up to this many edges keep their edge features in LDS
 
 typedef float es_f4 __attribute__((ext_vector_type(4)));
 
-struct EsW {                  // device pointers, nn.Linear layouts ([out][in])
-  const float *Wqkvs[4], *bqkvs[4], *Wedge[4], *ln1g[4], *ln1b[4], *W0[4], *b0[4], *W3[4], *b3[4], *ln2g[4], *ln2b[4];
-  const float *bW1[2], *bb1[2], *bW2[2], *bb2[2];
+// Parameter table: ES_NPTR device pointers (nn.Linear layouts [out][in]) in DEVICE memory -- 11 per GAT layer (Wqkvs, bqkvs,
+// Wedge, ln1_g, ln1_b, W0, b0, W3, b3, ln2_g, ln2_b), then 4 per basis MLP (W1, b1, W2, b2); read with scalar loads at a
+// dynamic layer index (a by-value struct indexed by the layer went through scratch memory).
+struct EsW {
+  const float* const* __restrict__ p;
+  __device__ __forceinline__ const float* at(int field, int i) const { return p[i * 11 + field]; }
+  __device__ __forceinline__ const float* Wqkvs(int l) const { return at(0, l); }
+  __device__ __forceinline__ const float* bqkvs(int l) const { return at(1, l); }
+  __device__ __forceinline__ const float* Wedge(int l) const { return at(2, l); }
+  __device__ __forceinline__ const float* ln1g(int l) const { return at(3, l); }
+  __device__ __forceinline__ const float* ln1b(int l) const { return at(4, l); }
+  __device__ __forceinline__ const float* W0(int l) const { return at(5, l); }
+  __device__ __forceinline__ const float* b0(int l) const { return at(6, l); }
+  __device__ __forceinline__ const float* W3(int l) const { return at(7, l); }
+  __device__ __forceinline__ const float* b3(int l) const { return at(8, l); }
+  __device__ __forceinline__ const float* ln2g(int l) const { return at(9, l); }
+  __device__ __forceinline__ const float* ln2b(int l) const { return at(10, l); }
+  __device__ __forceinline__ const float* bW1(int m) const { return p[44 + 4 * m]; }
+  __device__ __forceinline__ const float* bb1(int m) const { return p[45 + 4 * m]; }
+  __device__ __forceinline__ const float* bW2(int m) const { return p[46 + 4 * m]; }
+  __device__ __forceinline__ const float* bb2(int m) const { return p[47 + 4 * m]; }
 };
 
 __device__ __forceinline__ es_f4 es_mfma(float a, float b, es_f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// 1 / (1 + 2^(-x log2 e)) on the transcendental unit (v_exp_f32, v_rcp_f32: ~1 ulp each, no range branches; x -> -inf gives
+// rcp(inf) = 0, x -> +inf gives 1)
 __device__ __forceinline__ float es_sigmoid(float x) {
-  float e = expf(-fabsf(x));
-  float r = 1.f / (1.f + e);
-  return x >= 0.f ? r : e * r;
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
+__device__ __forceinline__ float es_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ void es_ld8(const float* __restrict__ p, float (&v)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
-__device__ __forceinline__ float es_red8_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 8, 64)); v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float es_red8_sum(float v) {
-  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64);
-}
-__device__ __forceinline__ float es_red16_sum(float v) {      // over the 16 lanes that share lane >> 4
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v + __shfl_xor(v, 8, 64);
+__device__ __forceinline__ void es_ld16(const float* __restrict__ p, float (&v)[16]) {
+#pragma unroll
+  for (int t = 0; t < 16; t += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(p + t);
+    v[t] = a.x; v[t + 1] = a.y; v[t + 2] = a.z; v[t + 3] = a.w;
+  }
 }
 __device__ __forceinline__ float es_dot4(float4 a, float4 b, float4 c) {      // a . (b + c), channel order
   return ((a.x * (b.x + c.x) + a.y * (b.y + c.y)) + a.z * (b.z + c.z)) + a.w * (b.w + c.w);
 }
-
-// ---- the tail of a GAT layer on 8 lanes per atom row (4 columns per lane), as gat_tail.hip with GT_LPR = 8 --------------
-__device__ __forceinline__ float es_row_sum(float s) {
-  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); return s + __shfl_xor(s, 4);
+// sum over the 8 lanes of an atom row: xor 1, xor 2 (quad permutes), then the mirror image inside the half row -- three DPP
+// moves on the vector ALU instead of three ds_bpermute round trips
+template <int CTRL>
+__device__ __forceinline__ float es_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float es_row8_sum(float s) {
+  s += es_dpp<0xB1>(s);          // quad_perm [1,0,3,2]
+  s += es_dpp<0x4E>(s);          // quad_perm [2,3,0,1]
+  return s + es_dpp<0x141>(s);   // row_half_mirror: lane i <-> 7 - i of its group of 8
 }
 __device__ __forceinline__ void es_layernorm(const float (&v)[4], float eps, float& mu, float& rs) {
-  mu = es_row_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 32.f);
+  mu = es_row8_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.f / 32.f);
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) q = fmaf(v[k] - mu, v[k] - mu, q);
-  rs = rsqrtf(es_row_sum(q) * (1.f / 32.f) + eps);
-}
-__device__ __forceinline__ void es_gather(const float (&v)[4], float (&full)[32]) {
-  const int base = (threadIdx.x & 63) & ~7;
-#pragma unroll
-  for (int r = 0; r < 8; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) full[r * 4 + c] = __shfl(v[c], base + r);
-}
-// out[jj] = bias[4q + jj] + sum_k W[4q + jj][k] full[k]; Wp = permuted image [jj][q][k]
-__device__ __forceinline__ void es_matvec(const float* __restrict__ Wp, const float* __restrict__ bs, int q,
-                                          const float (&full)[32], float (&out)[4]) {
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    float acc = bs[q * 4 + jj];
-    const float* wr = Wp + (jj * 8 + q) * 32;
-#pragma unroll
-    for (int k = 0; k < 32; k += 4) {
-      const float4 w = *reinterpret_cast<const float4*>(wr + k);
-      acc = fmaf(w.x, full[k], acc); acc = fmaf(w.y, full[k + 1], acc);
-      acc = fmaf(w.z, full[k + 2], acc); acc = fmaf(w.w, full[k + 3], acc);
-    }
-    out[jj] = acc;
-  }
+  rs = rsqrtf(es_row8_sum(q) * (1.f / 32.f) + eps);
 }
 
-struct EsMol { int n0, n, e0, Em; };
+// Register-resident weights of one GAT layer (prefetched one layer ahead: the loads of layer l + 1 are in flight while
+// layer l computes -- with one wave per SIMD nothing else hides a global round trip).
+struct EsLayerRegs {
+  float wq[2][8], bq[2];        // B fragments of the wave's two column tiles of Wqkvs, their bias entries
+  float we[8];                  // B fragment of the wave's column tile of Wedge
+  float w0[8], w3[8];           // B fragments of the wave's column tile of the feed-forward weights
+  float prm;                    // this thread's entry of [ln1_g | ln1_b | b0 | b3 | ln2_g | ln2_b] (threads < 192)
+};
 
-// qkvs = xs Wqkvs^T + b into LDS (rows >= n hold the bias: finite, never read)
-__device__ __forceinline__ void es_qkvs(const float* __restrict__ Wq, const float* __restrict__ bq, const float* xs, float* qk,
-                                        int n, int wave, int lane) {
-  const int c = lane & 15, g = lane >> 4;
-  const int ntile = (n + 15) >> 4;
+__device__ __forceinline__ void es_load_layer(const EsW& W, int layer, int tid, EsLayerRegs& R) {
+  const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int cti = 0; cti < 2; ++cti) {
     const int col = 16 * (2 * wave + cti) + c;
-    float b[8];
-    es_ld8(Wq + (size_t)col * ES_D + 8 * g, b);
-    const float bias = bq[col];
-    for (int rt = 0; rt < ntile; ++rt) {
-      float a[8];
-      es_ld8(xs + (16 * rt + c) * ES_LDX + 8 * g, a);
-      es_f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc = es_mfma(a[t], b[t], acc);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) qk[(16 * rt + 4 * g + r) * ES_LDQ + col] = acc[r] + bias;
-    }
+    es_ld8(W.Wqkvs(layer) + (size_t)col * ES_D + 8 * g, R.wq[cti]);
+    R.bq[cti] = W.bqkvs(layer)[col];
   }
-}
-
-// ee[0 .. cn) = edge_attr[eg0 .. eg0 + cn) Wedge^T into LDS
-__device__ __forceinline__ void es_edge_proj(const float* __restrict__ We, const float* __restrict__ ea, int ld_ea, size_t eg0,
-                                             int cn, float* ee, int wave, int lane) {
-  const int c = lane & 15, g = lane >> 4, ct = wave & 1;
-  float b[8];
-  es_ld8(We + (size_t)(16 * ct + c) * ES_D + 8 * g, b);
-  const int ntile = (cn + 15) >> 4;
-  for (int rt = wave >> 1; rt < ntile; rt += 2) {
-    const int el = 16 * rt + c;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (el < cn) es_ld8(ea + (eg0 + el) * ld_ea + 8 * g, a);
-    es_f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc = es_mfma(a[t], b[t], acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ee[(16 * rt + 4 * g + r) * ES_LDX + 16 * ct + c] = acc[r];
+  const size_t frag = (size_t)(16 * (wave & 1) + c) * ES_D + 8 * g;
+  es_ld8(W.Wedge(layer) + frag, R.we);
+  es_ld8(W.W0(layer) + frag, R.w0);
+  es_ld8(W.W3(layer) + frag, R.w3);
+  R.prm = 0.f;
+  if (tid < 6 * ES_D) {
+    const int f = tid >> 5, k = tid & 31;
+    const float* src = f == 0 ? W.ln1g(layer) : f == 1 ? W.ln1b(layer) : f == 2 ? W.b0(layer) : f == 3 ? W.b3(layer)
+                       : f == 4 ? W.ln2g(layer) : W.ln2b(layer);
+    R.prm = src[k];
   }
 }
 
@@ -148,265 +141,375 @@ __device__ __forceinline__ int es_chunk_end(const int* rp, int t0, int n) {
   return t1;
 }
 
+#ifdef ES_TIMING            // tools/escore_phases.py: wall-clock stamps (100 MHz) of workgroup 0 at phase boundaries
+__device__ long long es_stamps[64];
+#define ES_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) es_stamps[i] = wall_clock64(); } while (0)
+extern "C" int msde_escore_debug_stamps(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(es_stamps), sizeof(long long) * 64);
+}
+#else
+#define ES_STAMP(i)
+#endif
+
 template <bool TRAIN>
 __global__ void __launch_bounds__(256)
 escore_mol_fwd_kernel(EsW W, const float* __restrict__ x0, const float* __restrict__ ea, int ld_ea,
                       const float* __restrict__ basis, const int* __restrict__ mol_ptr, int B, const int* __restrict__ rowptr,
                       const int* __restrict__ src, const int* __restrict__ dst, int N, float p_att, float p_ffn,
                       unsigned long long seed0, const unsigned long long* __restrict__ seed_dev, float eps1, float eps2,
-                      float* __restrict__ out, float* __restrict__ sv, float* __restrict__ alpha_sv, int E_total) {
-  __shared__ __attribute__((aligned(16))) float xs[ES_NMAX * ES_LDX];
-  __shared__ __attribute__((aligned(16))) float att[ES_NMAX * ES_LDX];
-  __shared__ __attribute__((aligned(16))) float qk[ES_NMAX * ES_LDQ];
-  __shared__ __attribute__((aligned(16))) float ee[ES_ECH * ES_LDX];       // basis phase: per-wave partial head sums
-  __shared__ __attribute__((aligned(16))) float al[ES_ECH * 8];            // basis phase: per-edge mixed vectors
-  __shared__ __attribute__((aligned(16))) float W0p[ES_D * ES_D], W3p[ES_D * ES_D];
+                      float* __restrict__ out, float* __restrict__ sv) {
+  __shared__ __attribute__((aligned(16))) float xs[ES_NMAX * ES_LDX];       // layer input; inside the tail: SiLU(h0) rows
+  __shared__ __attribute__((aligned(16))) float att[ES_NMAX * ES_LDX];      // attention output; inside the tail: y1 rows
+  __shared__ __attribute__((aligned(16))) float qk[ES_NMAX * ES_LDQ];       // q|k|v|skip; inside the tail: x2 rows
+  __shared__ __attribute__((aligned(16))) float eal[ES_EAL * ES_LDX];       // edge features of the molecule (Em <= ES_EAL)
+  __shared__ __attribute__((aligned(16))) float ee[ES_ECH * ES_LDX];        // basis phase: per-edge mixed vectors [Em][3]
+  __shared__ __attribute__((aligned(16))) float hw[ES_HC + 3 * ES_HC];      // basis phase: b1 | W2
   __shared__ float prm[6 * ES_D];
   __shared__ float gacc[ES_NMAX * 3];
   __shared__ int rp[ES_NMAX + 1];
-  __shared__ int srcl[ES_ECH];
+  __shared__ unsigned char sl[ES_EMAX + 16], dl[ES_EMAX + 16];              // molecule-local source / target of every edge
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  if ((int)blockIdx.x >= B) {
-    // rows behind the last molecule (capacity padding): finite outputs
+  ES_STAMP(0);
+  {
+    // rows behind the last molecule (capacity padding): finite outputs, one slice per workgroup
     const int nt = mol_ptr[B];
-    for (int t = nt * 3 + tid; t < N * 3; t += 256) out[t] = 0.f;
-    return;
+    for (int t = nt * 3 + (int)blockIdx.x * 256 + tid; t < N * 3; t += B * 256) out[t] = 0.f;
   }
   const int n0 = mol_ptr[blockIdx.x], n = min(mol_ptr[blockIdx.x + 1] - n0, ES_NMAX);
   if (n <= 0) return;
-  const int e0 = rowptr[n0], Em = rowptr[n0 + n] - e0;
-  unsigned long long sdev = seed_dev ? seed_dev[0] * 0x100000001B3ull : 0ull;
+  EsLayerRegs R;
+  es_load_layer(W, 0, tid, R);
+  const int e0 = rowptr[n0], Em = min(rowptr[n0 + n] - e0, ES_EMAX);
+  const bool ea_lds = Em <= ES_EAL;
+  const unsigned long long sdev = seed_dev ? seed_dev[0] * 0x100000001B3ull : 0ull;
   for (int t = tid; t <= n; t += 256) rp[t] = rowptr[n0 + t] - e0;
-  for (int t = tid; t < ES_NMAX * 8; t += 256) {          // xs <- node_attr rows (zero beyond n), one float4 per thread
-    const int row = t >> 3, q = t & 7;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < n) v = *reinterpret_cast<const float4*>(x0 + (size_t)(n0 + row) * ES_D + 4 * q);
-    *reinterpret_cast<float4*>(xs + row * ES_LDX + 4 * q) = v;
+  for (int t = tid; t < Em; t += 256) {
+    sl[t] = (unsigned char)(src[e0 + t] - n0);
+    dl[t] = (unsigned char)(dst[e0 + t] - n0);
+  }
+  {
+    const int q = tid & 7;
+    for (int row = tid >> 3; row < ES_NMAX; row += 32) {   // xs <- node_attr rows (zero beyond n)
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < n) v = *reinterpret_cast<const float4*>(x0 + (size_t)(n0 + row) * ES_D + 4 * q);
+      *reinterpret_cast<float4*>(xs + row * ES_LDX + 4 * q) = v;
+      *reinterpret_cast<float4*>(att + row * ES_LDX + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (ea_lds)
+      for (int row = tid >> 3; row < Em; row += 32)
+        *reinterpret_cast<float4*>(eal + row * ES_LDX + 4 * q) =
+            *reinterpret_cast<const float4*>(ea + ((size_t)e0 + row) * ld_ea + 4 * q);
   }
   if (tid < ES_NMAX * 3) gacc[tid] = 0.f;
-  __syncthreads();
+  const int c = lane & 15, g = lane >> 4;
 
+#pragma unroll 1
   for (int layer = 0; layer < ES_LAYERS; ++layer) {
     const int mi = layer >> 1, ci = layer & 1;
-    // tail weights of this layer -> LDS (read after two barriers)
-    for (int t = tid; t < ES_D * ES_D; t += 256) {
-      const int j = t >> 5, k = t & 31;
-      const int d = ((j & 3) * 8 + (j >> 2)) * ES_D + k;
-      W0p[d] = W.W0[layer][t]; W3p[d] = W.W3[layer][t];
+    if (tid < 6 * ES_D) prm[tid] = R.prm;              // (the previous layer's tail finished behind a barrier)
+    float wq[2][8], bq[2], we[8], w0[8], w3[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { wq[0][t] = R.wq[0][t]; wq[1][t] = R.wq[1][t]; we[t] = R.we[t]; w0[t] = R.w0[t]; w3[t] = R.w3[t]; }
+    bq[0] = R.bq[0]; bq[1] = R.bq[1];
+    __syncthreads();                                   // xs (first layer: + the staged inputs) visible
+    ES_STAMP(1 + 8 * layer);
+    if (layer + 1 < ES_LAYERS) es_load_layer(W, layer + 1, tid, R);      // in flight during this layer
+    // qkvs = xs Wqkvs^T + b (rows >= n hold the bias: finite, never read); the wave's two column tiles are independent chains
+    {
+      const int ntile = (n + 15) >> 4;
+      for (int rt = 0; rt < ntile; ++rt) {
+        float a[8];
+        es_ld8(xs + (16 * rt + c) * ES_LDX + 8 * g, a);
+        es_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { acc0 = es_mfma(a[t], wq[0][t], acc0); acc1 = es_mfma(a[t], wq[1][t], acc1); }
+        float* o = qk + (16 * rt + 4 * g) * ES_LDQ + 32 * wave + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[r * ES_LDQ] = acc0[r] + bq[0]; o[r * ES_LDQ + 16] = acc1[r] + bq[1]; }
+      }
     }
-    if (tid < ES_D) {
-      prm[tid] = W.ln1g[layer][tid]; prm[ES_D + tid] = W.ln1b[layer][tid]; prm[2 * ES_D + tid] = W.b0[layer][tid];
-      prm[3 * ES_D + tid] = W.b3[layer][tid]; prm[4 * ES_D + tid] = W.ln2g[layer][tid]; prm[5 * ES_D + tid] = W.ln2b[layer][tid];
-    }
-    es_qkvs(W.Wqkvs[layer], W.bqkvs[layer], xs, qk, n, wave, lane);
+    ES_STAMP(2 + 8 * layer);
     const unsigned long long seed_l = seed0 + (unsigned long long)(mi * 4 + ci);
     const unsigned long long seed_att = seed_l + sdev, seed_ffn = (seed_l ^ 0x46464Eull) + sdev;
     const float keep_att = p_att > 0.f ? 1.f / (1.f - p_att) : 1.f;
     for (int t0 = 0; t0 < n;) {
       const int t1 = es_chunk_end(rp, t0, n);
       const int ce0 = rp[t0], cn = rp[t1] - ce0;
-      es_edge_proj(W.Wedge[layer], ea, ld_ea, (size_t)e0 + ce0, cn, ee, wave, lane);
-      for (int t = tid; t < cn; t += 256) srcl[t] = src[e0 + ce0 + t] - n0;
-      __syncthreads();
+      // ee[0 .. cn) = edge_attr[ce0 .. ce0 + cn) Wedge^T: wave -> column tile wave & 1, row tiles wave >> 1, + 2, ...
+      // (two tiles per trip: independent MFMA chains)
       {
-        const int h = lane & 7, l = lane >> 3;
-        for (int i = t0 + wave; i < t1; i += 4) {
-          const float4 q4 = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + h * 4);
-          const int s0 = rp[i] - ce0, s1 = rp[i + 1] - ce0;
-          float m = -INFINITY;
-          for (int e = s0 + l; e < s1; e += 8) {
-            const float4 k4 = *reinterpret_cast<const float4*>(qk + srcl[e] * ES_LDQ + ES_D + h * 4);
-            const float4 e4 = *reinterpret_cast<const float4*>(ee + e * ES_LDX + h * 4);
-            const float sc = es_dot4(q4, k4, e4) * 0.5f;
-            al[e * 8 + h] = sc;
-            m = fmaxf(m, sc);
+        const int ct = wave & 1, ntile = (cn + 15) >> 4;
+        for (int rt = wave >> 1; rt < ntile; rt += 4) {
+          const int el0 = 16 * rt + c, el1 = el0 + 32;
+          float a0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (ea_lds) {
+            if (el0 < cn) es_ld8(eal + (ce0 + el0) * ES_LDX + 8 * g, a0);
+            if (el1 < cn) es_ld8(eal + (ce0 + el1) * ES_LDX + 8 * g, a1);
+          } else {
+            if (el0 < cn) es_ld8(ea + ((size_t)e0 + ce0 + el0) * ld_ea + 8 * g, a0);
+            if (el1 < cn) es_ld8(ea + ((size_t)e0 + ce0 + el1) * ld_ea + 8 * g, a1);
           }
-          m = es_red8_max(m);
-          float sum = 0.f;
-          for (int e = s0 + l; e < s1; e += 8) {
-            const float p = expf(al[e * 8 + h] - m);
-            al[e * 8 + h] = p;
-            sum += p;
-          }
-          sum = es_red8_sum(sum);
-          const float inv = 1.f / (sum + 1e-16f);
-          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int e = s0 + l; e < s1; e += 8) {
-            const float4 v4 = *reinterpret_cast<const float4*>(qk + srcl[e] * ES_LDQ + 2 * ES_D + h * 4);
-            const float4 e4 = *reinterpret_cast<const float4*>(ee + e * ES_LDX + h * 4);
-            float a = al[e * 8 + h] * inv;
-            const unsigned long long ge = (unsigned long long)(e0 + ce0 + e);
-            if (TRAIN) alpha_sv[((size_t)layer * E_total + ge) * 8 + h] = a;
-            if (p_att > 0.f) a = (msde_uniform(seed_att, ge * 8 + h) >= p_att) ? a * keep_att : 0.f;
-            acc.x = fmaf(a, v4.x + e4.x, acc.x); acc.y = fmaf(a, v4.y + e4.y, acc.y);
-            acc.z = fmaf(a, v4.z + e4.z, acc.z); acc.w = fmaf(a, v4.w + e4.w, acc.w);
-          }
-          acc.x = es_red8_sum(acc.x); acc.y = es_red8_sum(acc.y); acc.z = es_red8_sum(acc.z); acc.w = es_red8_sum(acc.w);
-          if (l == 0) {
-            const float4 s4 = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + 3 * ES_D + h * 4);   // + lin_skip(x_i)
-            acc.x += s4.x; acc.y += s4.y; acc.z += s4.z; acc.w += s4.w;
-            *reinterpret_cast<float4*>(att + i * ES_LDX + h * 4) = acc;
+          es_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 8; ++t) { acc0 = es_mfma(a0[t], we[t], acc0); acc1 = es_mfma(a1[t], we[t], acc1); }
+          float* o = ee + (16 * rt + 4 * g) * ES_LDX + 16 * ct + c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r * ES_LDX] = acc0[r];
+          if (rt + 2 < ntile) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[(32 + r) * ES_LDX] = acc1[r];
           }
         }
       }
       __syncthreads();
+      ES_STAMP(3 + 8 * layer);
+      // attention: lane = (target, head); two walks over the target's in-edges (maximum; exponentials, their sum and the
+      // weighted sum) -- scores are recomputed, not stored, and nothing crosses lanes
+      {
+        const int i = tid >> 3, h = tid & 7;
+        if (i >= t0 && i < t1) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + h * 4);
+          const int s0 = rp[i], s1 = rp[i + 1];
+          const float* kb = qk + ES_D + h * 4;
+          const float* eb = ee + h * 4 - ce0 * ES_LDX;
+          float m = -INFINITY;
+#pragma unroll 4
+          for (int e = s0; e < s1; ++e) {
+            const float4 k4 = *reinterpret_cast<const float4*>(kb + sl[e] * ES_LDQ);
+            const float4 e4 = *reinterpret_cast<const float4*>(eb + e * ES_LDX);
+            m = fmaxf(m, es_dot4(q4, k4, e4) * 0.5f);
+          }
+          float sum = 0.f;
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+          for (int e = s0; e < s1; ++e) {
+            const int j = sl[e];
+            const float4 k4 = *reinterpret_cast<const float4*>(kb + j * ES_LDQ);
+            const float4 v4 = *reinterpret_cast<const float4*>(kb + ES_D + j * ES_LDQ);
+            const float4 e4 = *reinterpret_cast<const float4*>(eb + e * ES_LDX);
+            float p = es_exp(es_dot4(q4, k4, e4) * 0.5f - m);
+            sum += p;
+            if (p_att > 0.f) p = (msde_uniform(seed_att, (unsigned long long)(e0 + e) * 8 + h) >= p_att) ? p * keep_att : 0.f;
+            acc.x = fmaf(p, v4.x + e4.x, acc.x); acc.y = fmaf(p, v4.y + e4.y, acc.y);
+            acc.z = fmaf(p, v4.z + e4.z, acc.z); acc.w = fmaf(p, v4.w + e4.w, acc.w);
+          }
+          const float inv = 1.f / (sum + 1e-16f);
+          const float4 s4 = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + 3 * ES_D + h * 4);   // + lin_skip(x_i)
+          *reinterpret_cast<float4*>(att + i * ES_LDX + h * 4) =
+              make_float4(fmaf(acc.x, inv, s4.x), fmaf(acc.y, inv, s4.y), fmaf(acc.z, inv, s4.z), fmaf(acc.w, inv, s4.w));
+          if (TRAIN) {
+            float* st = sv + ((size_t)layer * N + n0 + i) * ES_SV + 160;
+            st[h] = m; st[8 + h] = inv;
+          }
+        }
+      }
+      __syncthreads();
+      ES_STAMP(4 + 8 * layer);
       t0 = t1;
     }
-    // tail: 8 lanes per atom row
+    // basis-MLP weights of this block: requested before the tail so that they arrive under it.  The first Linear is split,
+    //   [h_src + h_dst | edge_attr] W1^T = P[src] + P[dst] + edge_attr W1[:, 32:]^T,   P = h W1[:, :32]^T  (per ATOM),
+    // which halves the per-edge product (K = 32) -- b1w: the edge half as A fragments, wp: the atom half as B fragments
+    float b1w[8][8], wp[2][8], pb1 = 0.f, pw2a = 0.f, pw2b = 0.f;
+    if (ci == 1) {
+#pragma unroll
+      for (int ht = 0; ht < 8; ++ht) es_ld8(W.bW1(mi) + (size_t)(16 * ht + c) * (2 * ES_D) + ES_D + 8 * g, b1w[ht]);
+#pragma unroll
+      for (int cti = 0; cti < 2; ++cti) es_ld8(W.bW1(mi) + (size_t)(32 * wave + 16 * cti + c) * (2 * ES_D) + 8 * g, wp[cti]);
+      if (tid < ES_HC) pb1 = W.bb1(mi)[tid];
+      pw2a = W.bW2(mi)[tid];
+      if (tid < ES_HC) pw2b = W.bW2(mi)[256 + tid];
+    }
+    // ---- tail -------------------------------------------------------------------------------------------------------------
+    const int row = tid >> 3, q = tid & 7;
+    const bool live = row < n;
+    float* svr = TRAIN ? sv + ((size_t)layer * N + n0 + (live ? row : 0)) * ES_SV : nullptr;
     {
-      const int row = tid >> 3, q = tid & 7;
-      const bool live = row < n;
-      const int rr = live ? row : 0;
-      const float scale = p_ffn > 0.f ? 1.f / (1.f - p_ffn) : 1.f;
-      float v[4], y1[4], h[4], full[32];
-      {
-        const float4 a = *reinterpret_cast<const float4*>(att + rr * ES_LDX + 4 * q);
-        const float4 r4 = *reinterpret_cast<const float4*>(xs + rr * ES_LDX + 4 * q);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; y1[0] = r4.x; y1[1] = r4.y; y1[2] = r4.z; y1[3] = r4.w;
-      }
-      float* svr = TRAIN ? sv + ((size_t)layer * N + n0 + rr) * ES_SV + 4 * q : nullptr;
-      if (TRAIN && live) *reinterpret_cast<float4*>(svr) = make_float4(v[0], v[1], v[2], v[3]);
+      // T1: y1 = x + LN1(att), in place over the attention rows (8 lanes per row, 4 columns per lane)
+      const float4 a4 = *reinterpret_cast<const float4*>(att + row * ES_LDX + 4 * q);
+      const float4 r4 = *reinterpret_cast<const float4*>(xs + row * ES_LDX + 4 * q);
+      float v[4] = {a4.x, a4.y, a4.z, a4.w}, y1[4] = {r4.x, r4.y, r4.z, r4.w};
       float mu, rs;
       es_layernorm(v, eps1, mu, rs);
 #pragma unroll
       for (int k = 0; k < 4; ++k) y1[k] += fmaf((v[k] - mu) * rs, prm[q * 4 + k], prm[ES_D + q * 4 + k]);
-      es_gather(y1, full);
-      es_matvec(W0p, prm + 2 * ES_D, q, full, h);
+      *reinterpret_cast<float4*>(att + row * ES_LDX + 4 * q) = make_float4(y1[0], y1[1], y1[2], y1[3]);
       if (TRAIN && live) {
-        *reinterpret_cast<float4*>(svr + 32) = make_float4(y1[0], y1[1], y1[2], y1[3]);
-        *reinterpret_cast<float4*>(svr + 64) = make_float4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<float4*>(svr + 4 * q) = a4;
+        *reinterpret_cast<float4*>(svr + 32 + 4 * q) = make_float4(y1[0], y1[1], y1[2], y1[3]);
       }
-      const unsigned long long off = (unsigned long long)(n0 + rr) * ES_D + q * 4;
+    }
+    __syncthreads();
+    const int trt = wave >> 1, tct = wave & 1;         // the wave's 16 x 16 tile of the two feed-forward products
+    const int tcol = 16 * tct + c;
+    {
+      // T2: h0 = y1 W0^T + b0; a = Dropout(SiLU(h0)) -> xs region
+      float a[8];
+      es_ld8(att + (16 * trt + c) * ES_LDX + 8 * g, a);
+      es_f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float s = h[j] * es_sigmoid(h[j]);
-        if (p_ffn > 0.f) s = msde_uniform(seed_ffn, off + j) >= p_ffn ? s * scale : 0.f;
-        h[j] = s;
+      for (int t = 0; t < 8; ++t) acc = es_mfma(a[t], w0[t], acc);
+      const float b0c = prm[2 * ES_D + tcol];
+      const float scale = p_ffn > 0.f ? 1.f / (1.f - p_ffn) : 1.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rw = 16 * trt + 4 * g + r;
+        const float h0 = acc[r] + b0c;
+        if (TRAIN && rw < n) sv[((size_t)layer * N + n0 + rw) * ES_SV + 64 + tcol] = h0;
+        float s = h0 * es_sigmoid(h0);
+        if (p_ffn > 0.f) s = msde_uniform(seed_ffn, (unsigned long long)(n0 + rw) * ES_D + tcol) >= p_ffn ? s * scale : 0.f;
+        xs[rw * ES_LDX + tcol] = s;
       }
-      es_gather(h, full);
-      es_matvec(W3p, prm + 3 * ES_D, q, full, v);      // v = x2
-      if (TRAIN && live) *reinterpret_cast<float4*>(svr + 96) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    {
+      // T3: x2 = a W3^T + b3 -> qk region (row stride ES_LDX)
+      float a[8];
+      es_ld8(xs + (16 * trt + c) * ES_LDX + 8 * g, a);
+      es_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc = es_mfma(a[t], w3[t], acc);
+      const float b3c = prm[3 * ES_D + tcol];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rw = 16 * trt + 4 * g + r;
+        const float x2 = acc[r] + b3c;
+        if (TRAIN && rw < n) sv[((size_t)layer * N + n0 + rw) * ES_SV + 96 + tcol] = x2;
+        qk[rw * ES_LDX + tcol] = x2;
+      }
+    }
+    __syncthreads();
+    {
+      // T4: out = y1 + LN2(x2) [-> SiLU between the two convolutions of a block, :142] -> xs (rows >= n: zero)
+      const float4 x4 = *reinterpret_cast<const float4*>(qk + row * ES_LDX + 4 * q);
+      const float4 y4 = *reinterpret_cast<const float4*>(att + row * ES_LDX + 4 * q);
+      float v[4] = {x4.x, x4.y, x4.z, x4.w}, y1[4] = {y4.x, y4.y, y4.z, y4.w};
+      float mu, rs;
       es_layernorm(v, eps2, mu, rs);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float o = y1[k] + fmaf((v[k] - mu) * rs, prm[4 * ES_D + q * 4 + k], prm[5 * ES_D + q * 4 + k]);
-        v[k] = ci == 0 ? o * es_sigmoid(o) : o;        // SiLU between the two convolutions of a block (:142)
+        v[k] = live ? (ci == 0 ? o * es_sigmoid(o) : o) : 0.f;
       }
-      if (live) {
-        *reinterpret_cast<float4*>(xs + row * ES_LDX + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
-        if (TRAIN) *reinterpret_cast<float4*>(svr + 128) = make_float4(v[0], v[1], v[2], v[3]);
-      }
+      *reinterpret_cast<float4*>(xs + row * ES_LDX + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+      if (TRAIN && live) *reinterpret_cast<float4*>(svr + 128 + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (ci == 1) {
+      if (tid < ES_HC) hw[tid] = pb1;
+      hw[ES_HC + tid] = pw2a;
+      if (tid < ES_HC) hw[ES_HC + 256 + tid] = pw2b;
     }
     __syncthreads();
+    ES_STAMP(5 + 8 * layer);
     if (ci == 1) {
-      // basis MLP of block mi on every edge + frame mix + mean over the in-edges of the target (:150-166)
-      const int c = lane & 15, g = lane >> 4;
-      float b[2][16], bias1[2], w2[2][3];
+      // basis MLP of block mi on every edge + frame mix + mean over the in-edges of the target (:150-166), transposed:
+      //   P[atom][hidden] = h W1[:, :32]^T + b1 / 2                              (qk region; as the q|k|v|skip product)
+      //   Z^T[16 ht + 4 g + r][edge c] = P[src] + P[dst] + sum_k W1[.][32 + k] edge_attr[edge][k]   (8 hidden tiles, 64 MFMAs)
+      //   coff^T[j][edge c] = sum_hidden W2[j][hidden] SiLU(Z^T)[hidden][edge]  (the Z^T tiles ARE the B operands: 32 MFMAs;
+      //   hidden index 16 ht + 4 g + r <-> MFMA (ht, r), k-group g on both operands)
+      {
+        const int ntile_n = (n + 15) >> 4;
+        const float hb0 = 0.5f * hw[32 * wave + c], hb1 = 0.5f * hw[32 * wave + 16 + c];
+        for (int rt = 0; rt < ntile_n; ++rt) {
+          float a[8];
+          es_ld8(xs + (16 * rt + c) * ES_LDX + 8 * g, a);
+          es_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int cti = 0; cti < 2; ++cti) {
-        const int col = 32 * wave + 16 * cti + c;
-        const float* wr = W.bW1[mi] + (size_t)col * (2 * ES_D) + 16 * g;
-        es_ld8(wr, *reinterpret_cast<float(*)[8]>(&b[cti][0]));
-        es_ld8(wr + 8, *reinterpret_cast<float(*)[8]>(&b[cti][8]));
-        bias1[cti] = W.bb1[mi][col];
+          for (int t = 0; t < 8; ++t) { acc0 = es_mfma(a[t], wp[0][t], acc0); acc1 = es_mfma(a[t], wp[1][t], acc1); }
+          float* o = qk + (16 * rt + 4 * g) * ES_LDQ + 32 * wave + c;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) w2[cti][k] = W.bW2[mi][k * ES_HC + col];
+          for (int r = 0; r < 4; ++r) { o[r * ES_LDQ] = acc0[r] + hb0; o[r * ES_LDQ + 16] = acc1[r] + hb1; }
+        }
       }
-      const int ntile = (Em + 15) >> 4, Ep = ntile * 16;
-      float* part = ee;                                 // [4 waves][Ep][3]
-      for (int rt = 0; rt < ntile; ++rt) {
+      __syncthreads();
+      const int ntile = (Em + 15) >> 4;
+      float* mix = ee;                                   // [Em][3]
+      const float b2j[3] = {W.bb2(mi)[0], W.bb2(mi)[1], W.bb2(mi)[2]};
+      for (int rt = wave; rt < ntile; rt += 4) {
         const int el = 16 * rt + c;
-        float a[16];
+        const bool on = el < Em;
+        float bs[9];
+        if (g == 0) {                                    // lanes that will hold the edge's three coefficients
+          const float* bp = basis + 9 * ((size_t)e0 + (on ? el : 0));
 #pragma unroll
-        for (int t = 0; t < 16; ++t) a[t] = 0.f;
-        if (el < Em) {
-          const size_t ge = (size_t)e0 + el;
-          if (g < 2) {
-            const float* pj = xs + (src[ge] - n0) * ES_LDX + 16 * g;
-            const float* pi = xs + (dst[ge] - n0) * ES_LDX + 16 * g;
+          for (int k = 0; k < 9; ++k) bs[k] = bp[k];
+        }
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* pj = qk + (on ? sl[el] : 0) * ES_LDQ + 4 * g;
+        const float* pi = qk + (on ? dl[el] : 0) * ES_LDQ + 4 * g;
+        if (on) {
+          if (ea_lds) es_ld8(eal + el * ES_LDX + 8 * g, a);
+          else es_ld8(ea + ((size_t)e0 + el) * ld_ea + 8 * g, a);
+        }
+        es_f4 acc[8];
 #pragma unroll
-            for (int t = 0; t < 16; t += 4) {
-              const float4 u = *reinterpret_cast<const float4*>(pj + t), w = *reinterpret_cast<const float4*>(pi + t);
-              a[t] = u.x + w.x; a[t + 1] = u.y + w.y; a[t + 2] = u.z + w.z; a[t + 3] = u.w + w.w;
-            }
-          } else {
-            const float* pe = ea + ge * ld_ea + 16 * (g - 2);
-            es_ld8(pe, *reinterpret_cast<float(*)[8]>(&a[0]));
-            es_ld8(pe + 8, *reinterpret_cast<float(*)[8]>(&a[8]));
+        for (int ht = 0; ht < 8; ++ht) {
+          const float4 u = *reinterpret_cast<const float4*>(pj + 16 * ht), w = *reinterpret_cast<const float4*>(pi + 16 * ht);
+          acc[ht] = es_f4{u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w};
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int ht = 0; ht < 8; ++ht) acc[ht] = es_mfma(b1w[ht][t], a[t], acc[ht]);
+        es_f4 cf = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ht = 0; ht < 8; ++ht) {
+          float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c < 3) w = *reinterpret_cast<const float4*>(hw + ES_HC + c * ES_HC + 16 * ht + 4 * g);
+          const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = acc[ht][r];
+            cf = es_mfma(wv[r], z * es_sigmoid(z), cf);
           }
         }
-        es_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 16; ++t) { acc0 = es_mfma(a[t], b[0][t], acc0); acc1 = es_mfma(a[t], b[1][t], acc1); }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float z0 = acc0[r] + bias1[0], z1 = acc1[r] + bias1[1];
-          const float a0 = z0 * es_sigmoid(z0), a1 = z1 * es_sigmoid(z1);
-          const float p0 = es_red16_sum(fmaf(a0, w2[0][0], a1 * w2[1][0]));
-          const float p1 = es_red16_sum(fmaf(a0, w2[0][1], a1 * w2[1][1]));
-          const float p2 = es_red16_sum(fmaf(a0, w2[0][2], a1 * w2[1][2]));
-          if (c == 0) {
-            float* pp = part + ((size_t)wave * Ep + 16 * rt + 4 * g + r) * 3;
-            pp[0] = p0; pp[1] = p1; pp[2] = p2;
-          }
+        if (g == 0 && on) {                              // rows 0..2 of the coefficient tile: registers 0..2 of lanes g == 0
+          const float c0 = cf[0] + b2j[0], c1 = cf[1] + b2j[1], c2 = cf[2] + b2j[2];
+          float* mo = mix + el * 3;                      // (c0 b_diff + c1 b_cross) + c2 b_vert, as written in the reference
+          mo[0] = (c0 * bs[0] + c1 * bs[3]) + c2 * bs[6];
+          mo[1] = (c0 * bs[1] + c1 * bs[4]) + c2 * bs[7];
+          mo[2] = (c0 * bs[2] + c1 * bs[5]) + c2 * bs[8];
         }
       }
       __syncthreads();
-      const float b20 = W.bb2[mi][0], b21 = W.bb2[mi][1], b22 = W.bb2[mi][2];
-      for (int e = tid; e < Em; e += 256) {
-        float cf[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          cf[k] = (((part[(size_t)e * 3 + k] + part[((size_t)Ep + e) * 3 + k]) + part[((size_t)2 * Ep + e) * 3 + k]) +
-                   part[((size_t)3 * Ep + e) * 3 + k]) + (k == 0 ? b20 : k == 1 ? b21 : b22);
-        const float* bs = basis + 9 * ((size_t)e0 + e);
-        al[e * 3] = (cf[0] * bs[0] + cf[1] * bs[3]) + cf[2] * bs[6];
-        al[e * 3 + 1] = (cf[0] * bs[1] + cf[1] * bs[4]) + cf[2] * bs[7];
-        al[e * 3 + 2] = (cf[0] * bs[2] + cf[1] * bs[5]) + cf[2] * bs[8];
-      }
-      __syncthreads();
+      ES_STAMP(6 + 8 * layer);
       if (tid < n * 3) {
         const int i = tid / 3, k = tid - 3 * i;
         const int s0 = rp[i], s1 = rp[i + 1];
         float s = 0.f;
-        for (int e = s0; e < s1; ++e) s += al[e * 3 + k];
+        for (int e = s0; e < s1; ++e) s += mix[e * 3 + k];
         gacc[tid] += s * (1.f / (float)max(s1 - s0, 1));
       }
       __syncthreads();
     }
   }
   if (tid < n * 3) out[(size_t)n0 * 3 + tid] = gacc[tid];
+  ES_STAMP(40);
 }
 
 extern "C" long long msde_escore_mol_saved_floats(int N) { return (long long)ES_LAYERS * (long long)N * ES_SV; }
 
-// params: HOST array of ES_NPTR device pointers in the order of struct EsW (per field: the 4 layers / the 2 blocks)
+// params: DEVICE array of ES_NPTR device pointers (4 x 11 layer pointers, 2 x 4 basis-MLP pointers; struct EsW)
 extern "C" int msde_escore_mol_fwd(const void* const* params, const float* x0, const float* edge_attr, int ld_ea,
                                    const float* basis, const int* mol_ptr, int B, const int* rowptr, const int* src,
                                    const int* dst, int N, int E, int hidden, int heads, int hidden_coff, float p_att,
                                    float p_ffn, unsigned long long seed0, const unsigned long long* seed_dev, float eps1,
-                                   float eps2, float* out, float* saved, float* alpha_saved, void* stream) {
+                                   float eps2, float* out, float* saved, void* stream) {
   if (!params || !x0 || !edge_attr || !basis || !mol_ptr || !rowptr || !src || !dst || !out || N < 0 || B < 0 || E < 0)
     return MSDE_EINVAL;
   if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC) return MSDE_EUNSUP;
   if (ld_ea < ES_D || ld_ea % 4 || (reinterpret_cast<uintptr_t>(edge_attr) & 15) || (reinterpret_cast<uintptr_t>(x0) & 15))
     return MSDE_EINVAL;
   if (p_att < 0.f || p_att >= 1.f || p_ffn < 0.f || p_ffn >= 1.f) return MSDE_EINVAL;
-  if ((saved == nullptr) != (alpha_saved == nullptr)) return MSDE_EINVAL;
   if (saved && (reinterpret_cast<uintptr_t>(saved) & 15)) return MSDE_EINVAL;
-  EsW W;
-  const float** wp = reinterpret_cast<const float**>(&W);
-  for (int i = 0; i < ES_NPTR; ++i) {
-    if (!params[i]) return MSDE_EINVAL;
-    wp[i] = static_cast<const float*>(params[i]);
-  }
+  EsW W{reinterpret_cast<const float* const*>(params)};
   if (N == 0 || B == 0) return 0;
   if (saved)
-    MSDE_LAUNCH(escore_mol_fwd_kernel<true>, dim3(B + 1), dim3(256), 0, as_stream(stream), W, x0, edge_attr, ld_ea, basis,
-                mol_ptr, B, rowptr, src, dst, N, p_att, p_ffn, seed0, seed_dev, eps1, eps2, out, saved, alpha_saved, E);
+    MSDE_LAUNCH(escore_mol_fwd_kernel<true>, dim3(B), dim3(256), 0, as_stream(stream), W, x0, edge_attr, ld_ea, basis,
+                mol_ptr, B, rowptr, src, dst, N, p_att, p_ffn, seed0, seed_dev, eps1, eps2, out, saved);
   else
-    MSDE_LAUNCH(escore_mol_fwd_kernel<false>, dim3(B + 1), dim3(256), 0, as_stream(stream), W, x0, edge_attr, ld_ea, basis,
-                mol_ptr, B, rowptr, src, dst, N, p_att, p_ffn, seed0, seed_dev, eps1, eps2, out, saved, alpha_saved, E);
+    MSDE_LAUNCH(escore_mol_fwd_kernel<false>, dim3(B), dim3(256), 0, as_stream(stream), W, x0, edge_attr, ld_ea, basis,
+                mol_ptr, B, rowptr, src, dst, N, p_att, p_ffn, seed0, seed_dev, eps1, eps2, out, saved);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

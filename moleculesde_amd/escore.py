@@ -12,7 +12,6 @@ import torch
 from . import _lib, hip
 
 NMAX = 32                 # ES_NMAX of csrc/escore_mol.hip
-_FIELDS = 11              # per-layer pointer fields of struct EsW
 
 
 def supported(net, pl):
@@ -27,27 +26,39 @@ def supported(net, pl):
 
 
 def param_tensors(net):
-    """The 52 tensors of struct EsW, field-major.  q|k|v|skip weights / biases are the (free, once FlatAdam laid them out
-    back to back) concatenations the operator path uses."""
-    layers = [g for blk in net.gnn_layers for g in blk]
-    per = [[] for _ in range(_FIELDS)]
-    for g in layers:
+    """The 52 tensors of the kernel's parameter table: 11 per GAT layer, then 4 per basis MLP (struct EsW).  q|k|v|skip
+    weights / biases are the (free, once FlatAdam laid them out back to back) concatenations the operator path uses."""
+    out = []
+    for g in (g for blk in net.gnn_layers for g in blk):
         Ws, bs = g.MHA.fusion_sets()
-        vals = (hip.cat_params(Ws), hip.cat_params(bs), g.MHA.lin_edge.weight, g.norm1.weight, g.norm1.bias, g.FFN[0].weight,
-                g.FFN[0].bias, g.FFN[3].weight, g.FFN[3].bias, g.norm2.weight, g.norm2.bias)
-        for f, v in zip(per, vals):
-            f.append(v)
-    out = [t for f in per for t in f]
-    for k in range(4):
-        out += [(m[0].weight, m[0].bias, m[2].weight, m[2].bias)[k] for m in net.basis_mlp_modules]
+        out += [hip.cat_params(Ws), hip.cat_params(bs), g.MHA.lin_edge.weight, g.norm1.weight, g.norm1.bias, g.FFN[0].weight,
+                g.FFN[0].bias, g.FFN[3].weight, g.FFN[3].bias, g.norm2.weight, g.norm2.bias]
+    for m in net.basis_mlp_modules:
+        out += [m[0].weight, m[0].bias, m[2].weight, m[2].bias]
     return out
 
 
-def _pointer_table(tensors):
+_TABLES = {}          # id(net) -> (addresses, device int64 tensor of the 52 pointers, the tensors themselves)
+
+
+def _pointer_table(net, tensors):
+    """Device array of the 52 parameter addresses.  Rebuilt only when an address changes (FlatAdam keeps them fixed), never
+    inside a hipGraph capture: an eager call of the same network must come first (the trainer's warm-up steps do)."""
+    addrs = tuple(t.data_ptr() for t in tensors)
+    hit = _TABLES.get(id(net))
+    if hit is not None and hit[0] == addrs and hit[1].device == tensors[0].device:
+        hit[2][:] = tensors                      # keep the views alive for as long as their addresses are in the table
+        return hit[1]
     for t in tensors:
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0):
             raise _lib.MsdeHipError("escore: parameters must be contiguous fp32 device tensors, 16-byte aligned")
-    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.MsdeHipError("escore: parameter table missing inside a capture (run one eager call first)")
+    tab = torch.tensor(addrs, dtype=torch.int64).to(tensors[0].device)
+    _TABLES[id(net)] = (addrs, tab, list(tensors))
+    import weakref
+    weakref.finalize(net, _TABLES.pop, id(net), None)
+    return tab
 
 
 def _cfg(net):
@@ -64,7 +75,7 @@ def forward_nograd(net, ep, pl, node_attr, edge_attr, basis, seed0, seed_dev):
     if not (ea.is_cuda and ea.dtype == torch.float32 and ea.stride(-1) == 1 and ea.stride(0) % 4 == 0 and ea.data_ptr() % 16 == 0):
         ea = hip._f32(ea)
     out = torch.empty(ep.N, 3, dtype=torch.float32, device=x0.device)
-    _lib.call("msde_escore_mol_fwd", _pointer_table(tens), hip._p(x0), hip._p(ea), ea.stride(0), hip._p(basis), hip._p(pl.mol_ptr),
+    _lib.call("msde_escore_mol_fwd", hip._p(_pointer_table(net, tens)), hip._p(x0), hip._p(ea), ea.stride(0), hip._p(basis), hip._p(pl.mol_ptr),
               int(pl.B), hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), ep.N, ep.E, 32, 8, 128, p_att, p_ffn,
-              int(seed0) & 0xFFFFFFFFFFFFFFFF, hip._p(seed_dev), eps1, eps2, hip._p(out), hip._p(None), hip._p(None), hip._stream())
+              int(seed0) & 0xFFFFFFFFFFFFFFFF, hip._p(seed_dev), eps1, eps2, hip._p(out), hip._p(None), hip._stream())
     return out
