@@ -822,6 +822,19 @@ int msde_escore_mol_fwd(const void* const* params, const float* x0, const float*
                         float p_ffn, unsigned long long seed0, const unsigned long long* seed_dev, float eps1,
                         float eps2, float* out, float* saved, void* stream);
 
+/* Backward of msde_escore_mol_fwd (same arguments; `saved` written by it).  rowptr_s [N+1] / perm_s [E]: the by-source view
+ * of the edges (slot -> by-target edge id).  g_out [N,3] -> g_x0 [N,32], g_edge_attr [E,ld_gea] (all rows written; rows behind
+ * the last molecule are zero) and B slabs of msde_escore_mol_slab_floats() floats: the weight gradients of every molecule in
+ * the order of `params` (4 x [128x32, 128, 32x32, 32, 32, 32x32, 32, 32x32, 32, 32, 32], 2 x [128x64, 128, 3x128, 3 + 1 pad]),
+ * to be summed over the B slabs (fixed order) by the caller -- the backward of equivariant_scorenetwork.py:121-169. */
+long long msde_escore_mol_slab_floats(void);
+int msde_escore_mol_bwd(const void* const* params, const float* x0, const float* edge_attr, int ld_ea,
+                        const float* basis, const int* mol_ptr, int B, const int* rowptr, const int* src,
+                        const int* dst, const int* rowptr_s, const int* perm_s, int N, int E, int hidden, int heads,
+                        int hidden_coff, float p_att, float p_ffn, unsigned long long seed0,
+                        const unsigned long long* seed_dev, float eps1, float eps2, const float* saved,
+                        const float* g_out, float* g_x0, float* g_edge_attr, int ld_gea, float* slabs, void* stream);
+
 /* ------------------------------------------------------------------ optimiser -------------- */
 /* torch.optim.Adam step over a flat parameter buffer with per-element lr via segment table —
  * examples/pretrain_MoleculeSDE.py:331-337,156.  seg_end[S] (exclusive ends), seg_lr[S].

@@ -79,3 +79,80 @@ def forward_nograd(net, ep, pl, node_attr, edge_attr, basis, seed0, seed_dev):
               int(pl.B), hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), ep.N, ep.E, 32, 8, 128, p_att, p_ffn,
               int(seed0) & 0xFFFFFFFFFFFFFFFF, hip._p(seed_dev), eps1, eps2, hip._p(out), hip._p(None), hip._stream())
     return out
+
+
+_LAYER_SHAPES = [(128, 32), (128,), (32, 32), (32,), (32,), (32, 32), (32,), (32, 32), (32,), (32,), (32,)]
+_BASIS_SHAPES = [(128, 64), (128,), (3, 128), (3,)]
+
+
+def _grad_views(gall):
+    """Views of the summed slab [ES_SLAB] in the order of param_tensors (layout: csrc/escore_mol.h)."""
+    out, off = [], 0
+    for shapes, reps, pad in ((_LAYER_SHAPES, 4, 0), (_BASIS_SHAPES, 2, 1)):
+        for _ in range(reps):
+            for shp in shapes:
+                n = 1
+                for d in shp:
+                    n *= d
+                out.append(gall[off:off + n].view(shp))
+                off += n
+            off += pad
+    assert off == gall.numel()
+    return out
+
+
+class _EScoreMol(torch.autograd.Function):
+    """EquivariantScoreNetwork.forward as ONE autograd node: msde_escore_mol_fwd / msde_escore_mol_bwd, one workgroup per
+    molecule each way.  Weight gradients leave the backward kernel as one slab per molecule and are summed by the batched slab
+    reduction of the step (hip._SLABS) or, outside a batch, right here."""
+
+    @staticmethod
+    def forward(ctx, node_attr, edge_attr, basis, net, ep, pl, seed0, seed_dev, *params):
+        p_att, p_ffn, eps1, eps2 = _cfg(net)
+        x0, ea = hip._f32(node_attr), edge_attr
+        if not (ea.is_cuda and ea.dtype == torch.float32 and ea.stride(-1) == 1 and ea.stride(0) % 4 == 0 and ea.data_ptr() % 16 == 0):
+            ea = hip._f32(ea)
+        basis = hip._f32(basis)
+        dev = x0.device
+        N, E, B = ep.N, ep.E, int(pl.B)
+        out = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        sv = torch.empty(int(_lib.load().msde_escore_mol_saved_floats(N)), dtype=torch.float32, device=dev)
+        tab = _pointer_table(net, list(params))
+        seed0 = int(seed0) & 0xFFFFFFFFFFFFFFFF
+        _lib.call("msde_escore_mol_fwd", hip._p(tab), hip._p(x0), hip._p(ea), ea.stride(0), hip._p(basis), hip._p(pl.mol_ptr), B,
+                  hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), N, E, 32, 8, 128, p_att, p_ffn, seed0, hip._p(seed_dev),
+                  eps1, eps2, hip._p(out), hip._p(sv), hip._stream())
+        ctx.save_for_backward(x0, ea, basis, sv, *params)
+        ctx.cfg = (net, ep, pl, seed0, seed_dev, p_att, p_ffn, eps1, eps2, tab)
+        ctx.deferrable = all(t.is_leaf or getattr(t, "_msde_leaf_like", False) for t in params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, ea, basis, sv = ctx.saved_tensors[:4]
+        net, ep, pl, seed0, seed_dev, p_att, p_ffn, eps1, eps2, tab = ctx.cfg
+        g = g if (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()) else hip._f32(g)
+        dev = g.device
+        N, E, B = ep.N, ep.E, int(pl.B)
+        nslab = int(_lib.load().msde_escore_mol_slab_floats())
+        g_x0 = torch.empty(N, 32, dtype=torch.float32, device=dev)
+        g_ea = torch.empty(E, 32, dtype=torch.float32, device=dev)
+        gall = torch.empty(nslab, dtype=torch.float32, device=dev)
+        defer = hip._SLABS.active and ctx.deferrable
+        ws = hip._SLABS.alloc(B * nslab, dev) if defer else torch.empty(B * nslab, dtype=torch.float32, device=dev)
+        _lib.call("msde_escore_mol_bwd", hip._p(tab), hip._p(x0), hip._p(ea), ea.stride(0), hip._p(basis), hip._p(pl.mol_ptr), B,
+                  hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), hip._p(ep.rowptr_s), hip._p(ep.perm_s), N, E, 32, 8, 128,
+                  p_att, p_ffn, seed0, hip._p(seed_dev), eps1, eps2, hip._p(sv), hip._p(g), hip._p(g_x0), hip._p(g_ea), 32,
+                  hip._p(ws), hip._stream())
+        if defer:
+            hip._SLABS.add(ws.data_ptr(), B, nslab, gall, written=True)
+        else:
+            torch.sum(ws.view(B, nslab), dim=0, out=gall)
+        return (g_x0, g_ea, None, None, None, None, None, None) + tuple(_grad_views(gall))
+
+
+def forward(net, ep, pl, node_attr, edge_attr, basis, seed0, seed_dev):
+    """The score [N, 3] of EquivariantScoreNetwork.forward, differentiable w.r.t. node_attr, edge_attr and all parameters."""
+    if not torch.is_grad_enabled():
+        return forward_nograd(net, ep, pl, node_attr, edge_attr, basis, seed0, seed_dev)
+    return _EScoreMol.apply(node_attr, edge_attr, basis, net, ep, pl, seed0, seed_dev, *param_tensors(net))

@@ -142,9 +142,8 @@ class EquivariantScoreNetwork(nn.Module):
             self._calls += 1     # eager: host-side call counter; graph mode: the device counter varies the mask
         if MOL_KERNEL and node_attr.is_cuda and plan.E > 0 and _escore.supported(self, pl):
             seed0 = (self._seed_base + self._calls) * 16
-            if not torch.is_grad_enabled():
-                return {"node_feature": None,
-                        "gradient": _escore.forward_nograd(self, plan, pl, node_attr, edge_attr, basis, seed0, self.seed_dev)}
+            return {"node_feature": None,
+                    "gradient": _escore.forward(self, plan, pl, node_attr, edge_attr, basis, seed0, self.seed_dev)}
         conv_input = node_attr
         gradient = None
         ee_all, shared, D = None, None, self.hidden_dim

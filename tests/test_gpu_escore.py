@@ -127,3 +127,55 @@ def test_escore_mol_padded_rows_and_empty_molecules(dev):
         got = escore.forward_nograd(net, ep2, pl2, x2, ed, bd, 0, None)
     assert torch.equal(got[:N], ref)
     assert torch.equal(got[N:], torch.zeros(pad, 3, device=dev))
+
+
+def _grads(net, ep, pl, xd, ed, bd, w, mol):
+    from moleculesde_amd.geom3d import sde_2d_to_3d as M
+    net.zero_grad(set_to_none=True)
+    x = xd.clone().requires_grad_(True)
+    e = ed.clone().requires_grad_(True)
+    M.MOL_KERNEL = mol
+    try:
+        out = net(ep, x, e, bd, pl)["gradient"]
+        (out * w).sum().backward()
+    finally:
+        M.MOL_KERNEL = True
+    return out.detach(), x.grad, e.grad, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("B,seed,train", [(1, 3, False), (7, 5, False), (40, 9, True), (256, 0, True)])
+def test_escore_mol_backward_vs_operator_path_and_oracle(dev, B, seed, train):
+    """All gradients of the one-launch backward (node features, edge features, every parameter) against the operator path
+    (same dropout masks when training) and, without dropout, against the oracle's autograd on the CPU."""
+    cpu_b, pl, ep, net, x, ea, basis = _case(dev, B, seed)
+    net.train(train)
+    xd, ed, bd = x.to(dev), ea.to(dev), basis.to(dev)
+    w = torch.randn(ep.N, 3)
+    wd = w.to(dev)
+    net._calls = 7
+    o1, gx1, ge1, gp1 = _grads(net, ep, pl, xd, ed, bd, wd, True)
+    net._calls = 7
+    o2, gx2, ge2, gp2 = _grads(net, ep, pl, xd, ed, bd, wd, False)
+    assert_close(o1, o2, 1e-5, 2e-6 * float(o2.abs().max()), "forward (training variant)")
+    assert_close(gx1, gx2, 1e-4, 2e-5 * float(gx2.abs().max()), "g node features")
+    assert_close(ge1, ge2, 1e-4, 2e-5 * float(ge2.abs().max()), "g edge features")
+    assert set(gp1) == set(gp2)
+    scale = max(float(v.abs().max()) for v in gp2.values())
+    for k in gp2:
+        assert_close(gp1[k], gp2[k], 1e-4, 2e-5 * scale, f"grad {k}")
+    if not train:
+        o, ei, ea_o, basis_o = _oracle(net, cpu_b, ep, x, ea, basis)
+        xo = x.clone().requires_grad_(True)
+        eo = ea_o.clone().requires_grad_(True)
+        (o(ei, xo, eo, basis_o)["gradient"] * w).sum().backward()
+        perm = ep.perm_t.cpu()
+        assert_close(gx1, xo.grad, 2e-4, 5e-5 * float(xo.grad.abs().max()), "g node features vs oracle")
+        assert_close(ge1, eo.grad[perm], 2e-4, 5e-5 * float(eo.grad.abs().max()), "g edge features vs oracle")
+        og = {k: p.grad for k, p in o.named_parameters() if p.grad is not None}
+        oscale = max(float(v.abs().max()) for v in og.values())
+        for k, v in og.items():
+            assert_close(gp1[k], v, 2e-4, 5e-5 * oscale, f"grad {k} vs oracle")
+    # bit-reproducible backward
+    net._calls = 7
+    _, gx3, ge3, gp3 = _grads(net, ep, pl, xd, ed, bd, wd, True)
+    assert torch.equal(gx1, gx3) and torch.equal(ge1, ge3) and all(torch.equal(gp1[k], gp3[k]) for k in gp1)
