@@ -805,9 +805,9 @@ int msde_gat_tail_bwd(const float* g_out, const float* x, const float* y1, const
 /* EquivariantScoreNetwork.forward (equivariant_scorenetwork.py:121-169; called from SDE_model_2D_to_3D.py:386-391 and
  * get_score :393-445) for hidden = 32, 8 heads, basis-MLP width 128 and molecules of <= 32 atoms: 4 GATLayers (:13-40),
  * 2 basis MLPs, frame mix and the mean over in-edges, ONE launch, one workgroup per molecule (csrc/escore_mol.hip).
- *   params: DEVICE array of 52 device pointers (the caller keeps it alive and current), nn.Linear layouts: per GAT layer
- *     (x4) [Wqkvs ([128,32]: query|key|value|skip rows), bqkvs, Wedge ([32,32]), ln1_g, ln1_b, W0, b0, W3, b3, ln2_g, ln2_b],
- *     then per basis MLP (x2) [W1 ([128,64]), b1, W2 ([3,128]), b2]
+ *   params: DEVICE array of 76 device pointers (the caller keeps it alive and current), nn.Linear layouts: per GAT layer
+ *     (x4) [lin_query, lin_key, lin_value, lin_skip weights ([32,32] each), their 4 biases, lin_edge weight ([32,32]), ln1_g,
+ *     ln1_b, W0, b0, W3, b3, ln2_g, ln2_b], then per basis MLP (x2) [W1 ([128,64]), b1, W2 ([3,128]), b2]
  *   x0 [N,32] node features, edge_attr [E,ld_ea] (by-target edge order), basis [E,9], mol_ptr [B+1] atom ranges,
  *   rowptr [N+1] / src [E] / dst [E] the by-target CSR of the (extended) edges.
  *   Dropout: attention weights (p_att) and feed-forward (p_ffn) masks are the counter masks of msde_edge_attention_fwd /
@@ -825,7 +825,7 @@ int msde_escore_mol_fwd(const void* const* params, const float* x0, const float*
 /* Backward of msde_escore_mol_fwd (same arguments; `saved` written by it).  rowptr_s [N+1] / perm_s [E]: the by-source view
  * of the edges (slot -> by-target edge id).  g_out [N,3] -> g_x0 [N,32], g_edge_attr [E,ld_gea] (all rows written; rows behind
  * the last molecule are zero) and B slabs of msde_escore_mol_slab_floats() floats: the weight gradients of every molecule in
- * the order of `params` (4 x [128x32, 128, 32x32, 32, 32, 32x32, 32, 32x32, 32, 32, 32], 2 x [128x64, 128, 3x128, 3 + 1 pad]),
+ * the order of `params` (4 x [4 x 32x32, 4 x 32, 32x32, 32, 32, 32x32, 32, 32x32, 32, 32, 32], 2 x [128x64, 128, 3x128, 3 + 1 pad]),
  * to be summed over the B slabs (fixed order) by the caller -- the backward of equivariant_scorenetwork.py:121-169. */
 long long msde_escore_mol_slab_floats(void);
 int msde_escore_mol_bwd(const void* const* params, const float* x0, const float* edge_attr, int ld_ea,

@@ -11,33 +11,35 @@
 #define ES_LDQ 132            // LDS row stride of qkvs [., 128]
 #define ES_LAYERS 4
 #define ES_SV 176             // saved floats per (layer, atom): att | y1 | h0 | x2 | out | softmax max[8] | 1/sum[8]
-#define ES_NPTR 52
+#define ES_NPTR 76
 #define ES_EMAX (ES_NMAX * (ES_NMAX - 1))    // 992 edges at most
 #define ES_EAL 384                           // molecules of up to this many edges keep their edge features in LDS
 
 typedef float es_f4 __attribute__((ext_vector_type(4)));
 
-// Parameter table: ES_NPTR device pointers (nn.Linear layouts [out][in]) in DEVICE memory -- 11 per GAT layer (Wqkvs, bqkvs,
-// Wedge, ln1_g, ln1_b, W0, b0, W3, b3, ln2_g, ln2_b), then 4 per basis MLP (W1, b1, W2, b2); read with scalar loads at a
-// dynamic layer index (a by-value struct indexed by the layer went through scratch memory).
+// Parameter table: ES_NPTR device pointers (nn.Linear layouts [out][in]) in DEVICE memory -- 17 per GAT layer (lin_query,
+// lin_key, lin_value, lin_skip weights [32,32]; their four biases; lin_edge weight; ln1_g, ln1_b, W0, b0, W3, b3, ln2_g, ln2_b),
+// then 4 per basis MLP (W1, b1, W2, b2): every entry is a PARAMETER (stable address), never a concatenation.  Read with scalar
+// loads at a dynamic layer index (a by-value struct indexed by the layer went through scratch memory).  q|k|v|skip form the
+// [128, 32] projection "Wqkvs" of the kernels: row `col` lives in block col >> 5.
 struct EsW {
   const float* const* __restrict__ p;
-  __device__ __forceinline__ const float* at(int field, int i) const { return p[i * 11 + field]; }
-  __device__ __forceinline__ const float* Wqkvs(int l) const { return at(0, l); }
-  __device__ __forceinline__ const float* bqkvs(int l) const { return at(1, l); }
-  __device__ __forceinline__ const float* Wedge(int l) const { return at(2, l); }
-  __device__ __forceinline__ const float* ln1g(int l) const { return at(3, l); }
-  __device__ __forceinline__ const float* ln1b(int l) const { return at(4, l); }
-  __device__ __forceinline__ const float* W0(int l) const { return at(5, l); }
-  __device__ __forceinline__ const float* b0(int l) const { return at(6, l); }
-  __device__ __forceinline__ const float* W3(int l) const { return at(7, l); }
-  __device__ __forceinline__ const float* b3(int l) const { return at(8, l); }
-  __device__ __forceinline__ const float* ln2g(int l) const { return at(9, l); }
-  __device__ __forceinline__ const float* ln2b(int l) const { return at(10, l); }
-  __device__ __forceinline__ const float* bW1(int m) const { return p[44 + 4 * m]; }
-  __device__ __forceinline__ const float* bb1(int m) const { return p[45 + 4 * m]; }
-  __device__ __forceinline__ const float* bW2(int m) const { return p[46 + 4 * m]; }
-  __device__ __forceinline__ const float* bb2(int m) const { return p[47 + 4 * m]; }
+  __device__ __forceinline__ const float* at(int field, int i) const { return p[i * 17 + field]; }
+  __device__ __forceinline__ const float* Wq(int l, int block) const { return at(block, l); }          // rows 32 block ..
+  __device__ __forceinline__ const float* bq(int l, int block) const { return at(4 + block, l); }
+  __device__ __forceinline__ const float* Wedge(int l) const { return at(8, l); }
+  __device__ __forceinline__ const float* ln1g(int l) const { return at(9, l); }
+  __device__ __forceinline__ const float* ln1b(int l) const { return at(10, l); }
+  __device__ __forceinline__ const float* W0(int l) const { return at(11, l); }
+  __device__ __forceinline__ const float* b0(int l) const { return at(12, l); }
+  __device__ __forceinline__ const float* W3(int l) const { return at(13, l); }
+  __device__ __forceinline__ const float* b3(int l) const { return at(14, l); }
+  __device__ __forceinline__ const float* ln2g(int l) const { return at(15, l); }
+  __device__ __forceinline__ const float* ln2b(int l) const { return at(16, l); }
+  __device__ __forceinline__ const float* bW1(int m) const { return p[68 + 4 * m]; }
+  __device__ __forceinline__ const float* bb1(int m) const { return p[69 + 4 * m]; }
+  __device__ __forceinline__ const float* bW2(int m) const { return p[70 + 4 * m]; }
+  __device__ __forceinline__ const float* bb2(int m) const { return p[71 + 4 * m]; }
 };
 
 __device__ __forceinline__ es_f4 es_mfma(float a, float b, es_f4 c) {
@@ -119,3 +121,10 @@ __device__ __forceinline__ float es_dsilu(float z, float s) { return s * (1.f + 
 #define ES_SL_W2 8320
 #define ES_SL_B2 8704
 #define ES_SLAB (4 * ES_SL_LAYER + 2 * ES_SL_BASIS)
+
+#ifdef ES_TIMING            // tools/escore_phases.py: wall-clock stamps (100 MHz) of workgroup 0 at phase boundaries
+static __device__ long long es_stamps[128];   // one array per translation unit (no relocatable device code)
+#define ES_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) es_stamps[i] = wall_clock64(); } while (0)
+#else
+#define ES_STAMP(i)
+#endif

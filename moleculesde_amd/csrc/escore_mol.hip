@@ -38,9 +38,9 @@ __device__ __forceinline__ void es_load_layer(const EsW& W, int layer, int tid, 
   const int wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int cti = 0; cti < 2; ++cti) {
-    const int col = 16 * (2 * wave + cti) + c;
-    es_ld8(W.Wqkvs(layer) + (size_t)col * ES_D + 8 * g, R.wq[cti]);
-    R.bq[cti] = W.bqkvs(layer)[col];
+    const int colb = 16 * cti + c;               // the wave's two column tiles are exactly block `wave` of q|k|v|skip
+    es_ld8(W.Wq(layer, wave) + (size_t)colb * ES_D + 8 * g, R.wq[cti]);
+    R.bq[cti] = W.bq(layer, wave)[colb];
   }
   const size_t frag = (size_t)(16 * (wave & 1) + c) * ES_D + 8 * g;
   es_ld8(W.Wedge(layer) + frag, R.we);
@@ -55,14 +55,11 @@ __device__ __forceinline__ void es_load_layer(const EsW& W, int layer, int tid, 
   }
 }
 
-#ifdef ES_TIMING            // tools/escore_phases.py: wall-clock stamps (100 MHz) of workgroup 0 at phase boundaries
-__device__ long long es_stamps[64];
-#define ES_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) es_stamps[i] = wall_clock64(); } while (0)
+
+#ifdef ES_TIMING
 extern "C" int msde_escore_debug_stamps(long long* host) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(es_stamps), sizeof(long long) * 64);
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(es_stamps), sizeof(long long) * 128);
 }
-#else
-#define ES_STAMP(i)
 #endif
 
 template <bool TRAIN>

@@ -26,6 +26,12 @@ __device__ __forceinline__ float eb_rows_sum(float v) {   // over the 8 atom row
   return v + __shfl_xor(v, 32, 64);
 }
 
+#ifdef ES_TIMING
+extern "C" int msde_escore_debug_stamps_bwd(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(es_stamps), sizeof(long long) * 128);
+}
+#endif
+
 __global__ void __launch_bounds__(256)
 escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restrict__ ea, int ld_ea,
                       const float* __restrict__ basis, const int* __restrict__ mol_ptr, int B, const int* __restrict__ rowptr,
@@ -92,6 +98,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
     else es_ld8(ea + ((size_t)e0 + e) * ld_ea + k0, a);
   };
   auto ea_at = [&](int e, int k) -> float { return ea_lds ? eal[e * ES_LDX + k] : ea[((size_t)e0 + e) * ld_ea + k]; };
+  ES_STAMP(64);
   bool gea_first = true;          // the first pass over g_edge_attr stores, the later ones accumulate
 
 #pragma unroll 1
@@ -120,6 +127,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
         }
       }
       __syncthreads();
+      ES_STAMP(65 + 14 * (3 - layer));
       {
         // P = H W1[:, :32]^T + b1 / 2 -> qk (as the forward); gb2 = sum over edges of gcoff (wave 0, fixed tree)
         float wp[2][8];
@@ -146,6 +154,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
         }
       }
       __syncthreads();
+      ES_STAMP(66 + 14 * (3 - layer));
       const int ntile = (Em + 15) >> 4;
       {
         // ---- sweep A: the wave's 32 hidden columns, all edge tiles ----
@@ -165,30 +174,44 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
 #pragma unroll
           for (int b_ = 0; b_ < 2; ++b_) { gW1bT[a_][b_] = es_f4{0.f, 0.f, 0.f, 0.f}; gPn[a_][b_] = es_f4{0.f, 0.f, 0.f, 0.f}; }
         }
+        // P as a B operand (atoms as the contraction index): Z's initial value P[src] + P[dst] is the product of the edge's
+        // incidence row with P -- eight more MFMAs per column tile instead of sixteen dependent LDS reads
+        float pfr[2][8];
+#pragma unroll
+        for (int cti = 0; cti < 2; ++cti)
+#pragma unroll
+          for (int t = 0; t < 8; ++t) pfr[cti][t] = qk[(8 * g + t) * ES_LDQ + 32 * wave + 16 * cti + c];
         for (int rt = 0; rt < ntile; ++rt) {
-          // Z rows of this tile for the wave's columns: A = edge_attr rows, B = W1[:, 32:] fragments, init = P[src] + P[dst]
+          // ---- every operand of the tile is requested first (none depends on a product) ----
           const int em = 16 * rt + c;
           float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (em < Em) ea_row8(em, 8 * g, a);
-          es_f4 z[2];
+          int sb_ = 255, db_ = 255;
+          if (em < Em) { ea_row8(em, 8 * g, a); sb_ = sl[em]; db_ = dl[em]; }
+          float eaT0[4], eaT1[4], gct[4], inc0[4], inc1[4];
           float4 gcr[4];
-          int sj[4], si[4];
           bool on[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int e = 16 * rt + 4 * g + r;
-            on[r] = e < Em;
-            sj[r] = on[r] ? sl[e] : 0; si[r] = on[r] ? dl[e] : 0;
-            gcr[r] = on[r] ? *reinterpret_cast<const float4*>(gc + 4 * e) : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int t = 0; t < 4; ++t) {
+            const int e = 16 * rt + 4 * g + t;
+            on[t] = e < Em;
+            const int ec = on[t] ? e : 0;
+            eaT0[t] = on[t] ? ea_at(ec, c) : 0.f;                     // edge_attr^T: kin = c
+            eaT1[t] = on[t] ? ea_at(ec, 16 + c) : 0.f;                //               kin = 16 + c
+            const int sje = on[t] ? sl[ec] : 255, sie = on[t] ? dl[ec] : 255;
+            inc0[t] = (float)(sje == c) + (float)(sie == c);
+            inc1[t] = (float)(sje == 16 + c) + (float)(sie == 16 + c);
+            gcr[t] = on[t] ? *reinterpret_cast<const float4*>(gc + 4 * ec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gct[t] = c == 0 ? gcr[t].x : c == 1 ? gcr[t].y : c == 2 ? gcr[t].z : 0.f;   // gcoff^T: k = c
           }
-#pragma unroll
-          for (int cti = 0; cti < 2; ++cti) {
-            const int hid = 32 * wave + 16 * cti + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) z[cti][r] = qk[sj[r] * ES_LDQ + hid] + qk[si[r] * ES_LDQ + hid];
-          }
+          // ---- Z rows of this tile for the wave's columns: [edge_attr | incidence] x [W1[:, 32:]^T ; P] ----
+          es_f4 z[2] = {es_f4{0.f, 0.f, 0.f, 0.f}, es_f4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int t = 0; t < 8; ++t) { z[0] = es_mfma(a[t], bz[0][t], z[0]); z[1] = es_mfma(a[t], bz[1][t], z[1]); }
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float inc = (float)(sb_ == 8 * g + t) + (float)(db_ == 8 * g + t);
+            z[0] = es_mfma(inc, pfr[0][t], z[0]); z[1] = es_mfma(inc, pfr[1][t], z[1]);
+          }
           es_f4 S[2], gZ[2];
 #pragma unroll
           for (int cti = 0; cti < 2; ++cti)
@@ -200,23 +223,16 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
               gZ[cti][r] = on[r] ? gS * es_dsilu(zz, s) : 0.f;
               gb1p[cti] += gZ[cti][r];
             }
-          // contraction over the tile's 16 edges (k = 4 g + t): A operands built per step t
+          // ---- contraction over the tile's 16 edges (k = 4 g + t) ----
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const int e = 16 * rt + 4 * g + t;
-            const bool ok = e < Em;
-            const int ec = ok ? e : 0;
-            const float ea0 = ok ? ea_at(ec, c) : 0.f, ea1 = ok ? ea_at(ec, 16 + c) : 0.f;       // edge_attr^T: kin = c, 16 + c
-            const int sje = ok ? sl[ec] : 255, sie = ok ? dl[ec] : 255;
-            const float inc0 = (float)(sje == c) + (float)(sie == c), inc1 = (float)(sje == 16 + c) + (float)(sie == 16 + c);
-            const float gct = (ok && c < 3) ? gc[4 * ec + c] : 0.f;                               // gcoff^T: k = c
 #pragma unroll
             for (int cti = 0; cti < 2; ++cti) {
-              gW1bT[0][cti] = es_mfma(ea0, gZ[cti][t], gW1bT[0][cti]);
-              gW1bT[1][cti] = es_mfma(ea1, gZ[cti][t], gW1bT[1][cti]);
-              gPn[0][cti] = es_mfma(inc0, gZ[cti][t], gPn[0][cti]);
-              gPn[1][cti] = es_mfma(inc1, gZ[cti][t], gPn[1][cti]);
-              gW2a[cti] = es_mfma(gct, S[cti][t], gW2a[cti]);
+              gW1bT[0][cti] = es_mfma(eaT0[t], gZ[cti][t], gW1bT[0][cti]);
+              gW1bT[1][cti] = es_mfma(eaT1[t], gZ[cti][t], gW1bT[1][cti]);
+              gPn[0][cti] = es_mfma(inc0[t], gZ[cti][t], gPn[0][cti]);
+              gPn[1][cti] = es_mfma(inc1[t], gZ[cti][t], gPn[1][cti]);
+              gW2a[cti] = es_mfma(gct[t], S[cti][t], gW2a[cti]);
             }
           }
         }
@@ -242,6 +258,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
         }
       }
       __syncthreads();
+      ES_STAMP(67 + 14 * (3 - layer));
       {
         // g_H += gP W1[:, :32]  (contraction over the 128 hidden columns): the wave's tile (atom tile wave >> 1, input tile wave & 1)
         const int trt = wave >> 1, tct = wave & 1;
@@ -266,11 +283,21 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
           for (int r = 0; r < 4; ++r) sb[(size_t)(16 * ht + 4 * g + r) * 64 + 16 * kt + c] = d[r];
         }
       }
+      ES_STAMP(68 + 14 * (3 - layer));
       {
         // ---- sweep B: every fourth edge tile, all 128 hidden rows: g_edge_attr^T = W1[:, 32:]^T gZ^T ----
         float b1w[8][8];
 #pragma unroll
         for (int ht = 0; ht < 8; ++ht) es_ld8(W1 + (size_t)(16 * ht + c) * (2 * ES_D) + ES_D + 8 * g, b1w[ht]);
+        // A operands of the second product, resident: W1[hid = 16 ht + 4 g + r][32 + kin], kin = c / 16 + c
+        float wga[8][4], wgb[8][4];
+#pragma unroll
+        for (int ht = 0; ht < 8; ++ht)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float* wr = W1 + (size_t)(16 * ht + 4 * g + r) * (2 * ES_D) + ES_D;
+            wga[ht][r] = wr[c]; wgb[ht][r] = wr[16 + c];
+          }
         for (int rt = wave; rt < ntile; rt += 4) {
           const int el = 16 * rt + c;
           const bool on = el < Em;
@@ -301,10 +328,8 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
               const float zz = acc[ht][r], s = es_sigmoid(zz);
               const float gS = (gce.x * w0v[r] + gce.y * w1v[r]) + gce.z * w2v[r];
               const float gz = gS * es_dsilu(zz, s);
-              // A operand: W1[hid = 16 ht + 4 g + r][32 + kin], kin = c (tile 0) / 16 + c (tile 1)
-              const float* wr = W1 + (size_t)(16 * ht + 4 * g + r) * (2 * ES_D) + ES_D;
-              o0 = es_mfma(wr[c], gz, o0);
-              o1 = es_mfma(wr[16 + c], gz, o1);
+              o0 = es_mfma(wga[ht][r], gz, o0);
+              o1 = es_mfma(wgb[ht][r], gz, o1);
             }
           }
           if (on) {
@@ -321,6 +346,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
         gea_first = false;
       }
       __syncthreads();
+      ES_STAMP(69 + 14 * (3 - layer));
     }
 
     // ================= GAT layer `layer`: backward ========================================================================
@@ -344,9 +370,9 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
     {
 #pragma unroll
       for (int cti = 0; cti < 2; ++cti) {
-        const int col = 16 * (2 * wave + cti) + c;
-        es_ld8(W.Wqkvs(layer) + (size_t)col * ES_D + 8 * g, wq[cti]);
-        bq[cti] = W.bqkvs(layer)[col];
+        const int colb = 16 * cti + c;
+        es_ld8(W.Wq(layer, wave) + (size_t)colb * ES_D + 8 * g, wq[cti]);
+        bq[cti] = W.bq(layer, wave)[colb];
       }
       es_ld8(W.Wedge(layer) + (size_t)(16 * tct + c) * ES_D + 8 * g, we);
 #pragma unroll
@@ -392,6 +418,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
       *reinterpret_cast<float4*>(t_e + row * ES_LDX + 4 * q) = y4;
     }
     __syncthreads();
+    ES_STAMP(70 + 14 * (3 - layer));
     {
       // T3': g_a = gx2 W3; through Dropout and SiLU -> g_h0 (t_c); the activation itself -> t_d
       float a[8];
@@ -442,6 +469,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
       }
     }
     __syncthreads();
+    ES_STAMP(71 + 14 * (3 - layer));
     {
       // T1': through y1 = X_l + LN1(att): residual gradient -> gx, g_att -> ga; LayerNorm-parameter gradients
       const float4 g4 = *reinterpret_cast<const float4*>(t_b + row * ES_LDX + 4 * q);
@@ -499,6 +527,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
     float sm = 0.f, sinv = 0.f;
     if (ai < n) { sm = svl[(size_t)ai * ES_SV + 160 + ah]; sinv = svl[(size_t)ai * ES_SV + 168 + ah]; }
     __syncthreads();                      // qk ready; lnp consumed (ee aliases the tail's scratch)
+    ES_STAMP(72 + 14 * (3 - layer));
     for (int t0 = 0; t0 < n;) {
       const int t1 = es_chunk_end(rp, t0, n);
       const int ce0 = rp[t0], cn = rp[t1] - ce0;
@@ -516,6 +545,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
         }
       }
       __syncthreads();
+      ES_STAMP(73 + 14 * (3 - layer));
       if (ai >= t0 && ai < t1) {
         // softmax backward of (target ai, head ah)
         const float4 q4 = *reinterpret_cast<const float4*>(qk + ai * ES_LDQ + ah * 4);
@@ -558,44 +588,17 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
         *reinterpret_cast<float4*>(gqk + ai * ES_LDQ + 3 * ES_D + ah * 4) = go;      // d out / d skip = 1
       }
       __syncthreads();
+      ES_STAMP(74 + 14 * (3 - layer));
       {
-        // gradient of the lin_edge rows of this chunk, rank one per head: gee[e][col] = gs[e][h] q[dst][col] + am[e][h] g_att[dst][col]
-        auto gee = [&](int e, int col) -> float {      // e: molecule-local edge inside the chunk
-          const int i = dl[e], h = col >> 2;
-          return gsb[(e - ce0) * 8 + h] * qk[i * ES_LDQ + col] + amb[(e - ce0) * 8 + h] * ga[i * ES_LDX + col];
-        };
-        const int ntile_c = (cn + 15) >> 4;
-        // gWedge[out][kin] += sum_e gee[e][out] edge_attr[e][kin]: the wave's tile (out tile trt, in tile tct), all tiles of the chunk
-        for (int rt = 0; rt < ntile_c; ++rt) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int el = 16 * rt + 4 * g + t;
-            const bool ok = el < cn;
-            const float av = ok ? gee(ce0 + el, 16 * trt + c) : 0.f;
-            const float bv = ok ? ea_at(ce0 + el, tcol) : 0.f;
-            gWe = es_mfma(av, bv, gWe);
-          }
-        }
-        // g_edge_attr[e][kin] += sum_out gee[e][out] Wedge[out][kin]: in tile tct, edge tiles trt, trt + 2, ...
-        for (int rt = trt; rt < ntile_c; rt += 2) {
-          const int el = 16 * rt + c;
-          es_f4 acc = {0.f, 0.f, 0.f, 0.f};
-          float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (el < cn) {                   // (operands only: the MFMAs below must run with every lane)
-            const int e = ce0 + el, i = dl[e];
-            const float4 qa = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + 8 * g), qb = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + 8 * g + 4);
-            const float4 ga_ = *reinterpret_cast<const float4*>(ga + i * ES_LDX + 8 * g), gb_ = *reinterpret_cast<const float4*>(ga + i * ES_LDX + 8 * g + 4);
-            const float gs0 = gsb[el * 8 + 2 * g], gs1 = gsb[el * 8 + 2 * g + 1], am0 = amb[el * 8 + 2 * g], am1 = amb[el * 8 + 2 * g + 1];
-            av[0] = gs0 * qa.x + am0 * ga_.x; av[1] = gs0 * qa.y + am0 * ga_.y; av[2] = gs0 * qa.z + am0 * ga_.z; av[3] = gs0 * qa.w + am0 * ga_.w;
-            av[4] = gs1 * qb.x + am1 * gb_.x; av[5] = gs1 * qb.y + am1 * gb_.y; av[6] = gs1 * qb.z + am1 * gb_.z; av[7] = gs1 * qb.w + am1 * gb_.w;
-          }
-#pragma unroll
-          for (int t = 0; t < 8; ++t) acc = es_mfma(av[t], wet[t], acc);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int er = 16 * rt + 4 * g + r;
-            if (er < cn) g_ea[((size_t)e0 + ce0 + er) * ld_gea + tcol] += acc[r];
-          }
+        // gradient of the lin_edge rows of this chunk, rank one per head, written OVER the lin_edge rows (no longer needed):
+        //   gee[e][col] = gs[e][h] q[dst][col] + am[e][h] g_att[dst][col]
+        for (int t = tid; t < cn * 8; t += 256) {
+          const int el = t >> 3, h = t & 7, i = dl[ce0 + el];
+          const float gs = gsb[el * 8 + h], am = amb[el * 8 + h];
+          const float4 qd = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + 4 * h);
+          const float4 gd = *reinterpret_cast<const float4*>(ga + i * ES_LDX + 4 * h);
+          *reinterpret_cast<float4*>(ee + el * ES_LDX + 4 * h) =
+              make_float4(gs * qd.x + am * gd.x, gs * qd.y + am * gd.y, gs * qd.z + am * gd.z, gs * qd.w + am * gd.w);
         }
         // key / value gradients: lane = (source atom ai, head ah) over its out-edges that lie in this chunk
         if (ai < n) {
@@ -613,6 +616,44 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
         }
       }
       __syncthreads();
+      {
+        const int ntile_c = (cn + 15) >> 4;
+        // gWedge[out][kin] += sum_e gee[e][out] edge_attr[e][kin]: the wave's tile (out tile trt, in tile tct), all tiles of the
+        // chunk, two independent accumulators
+        es_f4 gWe2 = {0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < ntile_c; rt += 2) {
+          float av0[4], bv0[4], av1[4], bv1[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int el0 = 16 * rt + 4 * g + t, el1 = el0 + 16;
+            const bool ok0 = el0 < cn, ok1 = el1 < cn;
+            av0[t] = ok0 ? ee[el0 * ES_LDX + 16 * trt + c] : 0.f;
+            bv0[t] = ok0 ? ea_at(ce0 + el0, tcol) : 0.f;
+            av1[t] = ok1 ? ee[el1 * ES_LDX + 16 * trt + c] : 0.f;
+            bv1[t] = ok1 ? ea_at(ce0 + el1, tcol) : 0.f;
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { gWe = es_mfma(av0[t], bv0[t], gWe); gWe2 = es_mfma(av1[t], bv1[t], gWe2); }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gWe[r] += gWe2[r];
+        // g_edge_attr[e][kin] += sum_out gee[e][out] Wedge[out][kin]: in tile tct, edge tiles trt, trt + 2, ...
+        for (int rt = trt; rt < ntile_c; rt += 2) {
+          const int el = 16 * rt + c;
+          float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (el < cn) es_ld8(ee + el * ES_LDX + 8 * g, av);
+          es_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 8; ++t) acc = es_mfma(av[t], wet[t], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int er = 16 * rt + 4 * g + r;
+            if (er < cn) g_ea[((size_t)e0 + ce0 + er) * ld_gea + tcol] += acc[r];
+          }
+        }
+      }
+      __syncthreads();
+      ES_STAMP(75 + 14 * (3 - layer));
       t0 = t1;
     }
     if (ai < n) {
@@ -625,13 +666,13 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
     {
       // through q|k|v|skip = X_l Wqkvs^T + b: gx += gqk Wqkvs (contraction over 128 columns), gWqkvs = gqk^T X_l, gb = column sums
       es_f4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float* Wq = W.Wqkvs(layer);
+      const float* Wq = W.Wq(layer, g);               // column 32 g + .. of q|k|v|skip = row .. of block g
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         float a[8], b[8];
         es_ld8(gqk + (16 * trt + c) * ES_LDQ + 32 * g + 8 * kk, a);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) b[t] = Wq[(size_t)(32 * g + 8 * kk + t) * ES_D + tcol];
+        for (int t = 0; t < 8; ++t) b[t] = Wq[(size_t)(8 * kk + t) * ES_D + tcol];
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc = es_mfma(a[t], b[t], acc);
       }
@@ -651,6 +692,7 @@ escore_mol_bwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
       }
     }
     __syncthreads();
+    ES_STAMP(76 + 14 * (3 - layer));
   }
   if (live) *reinterpret_cast<float4*>(g_x0 + (size_t)(n0 + row) * ES_D + 4 * q) = *reinterpret_cast<const float4*>(gx + row * ES_LDX + 4 * q);
 }

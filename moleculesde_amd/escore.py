@@ -26,23 +26,22 @@ def supported(net, pl):
 
 
 def param_tensors(net):
-    """The 52 tensors of the kernel's parameter table: 11 per GAT layer, then 4 per basis MLP (struct EsW).  q|k|v|skip
-    weights / biases are the (free, once FlatAdam laid them out back to back) concatenations the operator path uses."""
+    """The 76 parameters of the kernel's table: 17 per GAT layer, then 4 per basis MLP (struct EsW, csrc/escore_mol.h)."""
     out = []
     for g in (g for blk in net.gnn_layers for g in blk):
-        Ws, bs = g.MHA.fusion_sets()
-        out += [hip.cat_params(Ws), hip.cat_params(bs), g.MHA.lin_edge.weight, g.norm1.weight, g.norm1.bias, g.FFN[0].weight,
-                g.FFN[0].bias, g.FFN[3].weight, g.FFN[3].bias, g.norm2.weight, g.norm2.bias]
+        Ws, bs = g.MHA.fusion_sets()                 # [query, key, value, skip]
+        out += list(Ws) + list(bs) + [g.MHA.lin_edge.weight, g.norm1.weight, g.norm1.bias, g.FFN[0].weight, g.FFN[0].bias,
+                                      g.FFN[3].weight, g.FFN[3].bias, g.norm2.weight, g.norm2.bias]
     for m in net.basis_mlp_modules:
         out += [m[0].weight, m[0].bias, m[2].weight, m[2].bias]
     return out
 
 
-_TABLES = {}          # id(net) -> (addresses, device int64 tensor of the 52 pointers, the tensors themselves)
+_TABLES = {}          # id(net) -> (addresses, device int64 tensor of the 76 pointers, the tensors themselves)
 
 
 def _pointer_table(net, tensors):
-    """Device array of the 52 parameter addresses.  Rebuilt only when an address changes (FlatAdam keeps them fixed), never
+    """Device array of the 76 parameter addresses.  Rebuilt only when an address changes (FlatAdam keeps them fixed), never
     inside a hipGraph capture: an eager call of the same network must come first (the trainer's warm-up steps do)."""
     addrs = tuple(t.data_ptr() for t in tensors)
     hit = _TABLES.get(id(net))
@@ -81,7 +80,7 @@ def forward_nograd(net, ep, pl, node_attr, edge_attr, basis, seed0, seed_dev):
     return out
 
 
-_LAYER_SHAPES = [(128, 32), (128,), (32, 32), (32,), (32,), (32, 32), (32,), (32, 32), (32,), (32,), (32,)]
+_LAYER_SHAPES = [(32, 32)] * 4 + [(32,)] * 4 + [(32, 32), (32,), (32,), (32, 32), (32,), (32, 32), (32,), (32,), (32,)]
 _BASIS_SHAPES = [(128, 64), (128,), (3, 128), (3,)]
 
 
@@ -124,7 +123,7 @@ class _EScoreMol(torch.autograd.Function):
                   eps1, eps2, hip._p(out), hip._p(sv), hip._stream())
         ctx.save_for_backward(x0, ea, basis, sv, *params)
         ctx.cfg = (net, ep, pl, seed0, seed_dev, p_att, p_ffn, eps1, eps2, tab)
-        ctx.deferrable = all(t.is_leaf or getattr(t, "_msde_leaf_like", False) for t in params)
+        ctx.deferrable = all(t.is_leaf for t in params)
         return out
 
     @staticmethod

@@ -31,7 +31,11 @@ FUSE_FRAME = _os.environ.get("MSDE_FUSE_FRAME", "1") != "0"              # hip._
 STATIC_FEATURE_CACHE = _os.environ.get("MSDE_STATIC_FEATURES", "1") != "0"   # inference: coordinate-independent inputs of the score network computed once per 2D representation
 FUSE_HEAD_MIX = _os.environ.get("MSDE_FUSE_HEAD_MIX", "1") != "0"        # hip._MlpHeadMix (False: hip.mlp_fused + hip.frame_mix_mean)
 FUSE_EDGE_EMB = _os.environ.get("MSDE_FUSE_EDGE_EMB", "1") != "0"        # hip._PairBnReluLinear (False: gather-add, BatchNorm, Linear as separate ops)
-MOL_KERNEL = True       # EquivariantScoreNetwork as one launch, one workgroup per molecule (False: operator by operator, the cross-check)
+MOL_KERNEL = True       # EquivariantScoreNetwork without autograd (get_score, sampling, evaluation) as ONE launch, one workgroup per molecule (False: operator by operator, the cross-check)
+MOL_KERNEL_TRAIN = False    # ... and under autograd (forward + one-launch backward, moleculesde_amd/escore.py).  Off by default: beside
+                            # the second stream of the pretrain step the 256 single-wave-per-SIMD workgroups hold every CU for ~100 + ~340 us
+                            # and the step is 2.69 ms against 2.58 ms operator by operator (alternating A/B on one box);
+                            # `--score_kernel mol` of pretrain.py / the parity tests switch it on
 FUSE_PAIR_LINEAR = _os.environ.get("MSDE_FUSE_PAIR_LINEAR", "1") != "0"  # hip._PairLinear (False: re-laid-out weight per step)
 
 
@@ -130,6 +134,7 @@ class EquivariantScoreNetwork(nn.Module):
         self._seed_base = 0x5DE2D3D
         self._calls = 0
         self.seed_dev = None   # device uint64 step counter (set by the trainer for hipGraph replay)
+        self.mol_kernel_train = None   # None: the module default MOL_KERNEL_TRAIN; the trainer sets it from --score_kernel
 
     def fusion_sets(self):
         # lin_edge of every GAT layer consumes the same edge features: one stacked weight, one GEMM
@@ -140,7 +145,9 @@ class EquivariantScoreNetwork(nn.Module):
         with one workgroup per molecule (moleculesde_amd/escore.py, csrc/escore_mol.hip); otherwise operator by operator."""
         if self.seed_dev is None:
             self._calls += 1     # eager: host-side call counter; graph mode: the device counter varies the mask
-        if MOL_KERNEL and node_attr.is_cuda and plan.E > 0 and _escore.supported(self, pl):
+        train_mol = MOL_KERNEL_TRAIN if self.mol_kernel_train is None else self.mol_kernel_train
+        if ((train_mol if torch.is_grad_enabled() else MOL_KERNEL) and node_attr.is_cuda and plan.E > 0
+                and _escore.supported(self, pl)):
             seed0 = (self._seed_base + self._calls) * 16
             return {"node_feature": None,
                     "gradient": _escore.forward(self, plan, pl, node_attr, edge_attr, basis, seed0, self.seed_dev)}

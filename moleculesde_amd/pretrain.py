@@ -67,6 +67,9 @@ def add_hot_path_flags(parser):
     a("--SDE_anneal_power", type=float, default=0)
     a("--output_model_dir", type=str, default="")
     a("--verbose", dest="verbose", action="store_true")
+    # (not in examples/config.py) the 2D->3D score network under autograd: "ops" = operator by operator (default, the faster
+    # pretrain step), "mol" = one launch each way with one workgroup per molecule (moleculesde_amd/escore.py)
+    a("--score_kernel", type=str, default="ops", choices=["ops", "mol"])
     return parser
 
 
@@ -212,6 +215,7 @@ class Trainer:
         self.noise = noise or _nn.DeviceNoise(seed=0x5EED + 7919 * r)
         self.models["SDE_2Dto3D_model"].score_network._seed_base += 0x10001 * r
         self.models["SDE_2Dto3D_model"].noise = self.noise
+        self.models["SDE_2Dto3D_model"].score_network.mol_kernel_train = getattr(args, "score_kernel", "ops") == "mol"
         if "SDE_3Dto2D_model" in self.models:
             self.models["SDE_3Dto2D_model"].noise = self.noise
         self.coeff_cl = args.SDE_coeff_contrastive

@@ -52,3 +52,45 @@ mol = make_molecule(np.random.default_rng(0), 14)
 case("sampler 10x14", Batch.from_data_list([mol] * 10), False)
 case("batch 256", make_batch(256, 0), False)
 case("batch 256", make_batch(256, 0), True)
+
+
+def case_bwd(name, cpu_b):
+    """forward (training variant) + backward, graph-timed, mol kernels vs operator path"""
+    from moleculesde_amd import hip
+    b = G.prepare_batch(cpu_b.clone(), dev)
+    pl = P.get_plan(b)
+    ep = pl.ext
+    net = M.EquivariantScoreNetwork(32, hidden_coff_dim=128).to(dev).train()
+    x = torch.randn(ep.N, 32, device=dev, requires_grad=True)
+    ea = torch.randn(ep.E, 32, device=dev, requires_grad=True)
+    bs = torch.randn(ep.E, 9, device=dev)
+    w = torch.randn(ep.N, 3, device=dev)
+    res = {}
+    for mol in (True, False):
+        M.MOL_KERNEL_TRAIN = mol
+
+        def step():
+            net.zero_grad(set_to_none=True)
+            x.grad = None
+            ea.grad = None
+            hip.begin_param_grad_batch()
+            out = net(ep, x, ea, bs, pl)["gradient"]
+            (out * w).sum().backward()
+            hip.finish_param_grad_batch()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            hip.new_param_grad_slot(dev)
+            with torch.cuda.graph(g, stream=s):
+                step()
+        res[mol] = timeit(g.replay, 50)
+    M.MOL_KERNEL_TRAIN = False
+    print(f"{name}: fwd+bwd+weight-gradient reduction in a graph: mol kernels {res[True]:.1f} us, operator path {res[False]:.1f} us")
+
+
+case_bwd("batch 256", make_batch(256, 0))
+case_bwd("10x14", Batch.from_data_list([mol] * 10))
