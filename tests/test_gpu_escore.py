@@ -198,13 +198,15 @@ def test_trainer_score_kernel_mol_matches_ops(dev):
         bs = [G.prepare_batch(b.clone(), dev) for b in cpu]
         losses = [float(tr.step(b)[0]) for b in bs]
         tr.capture(bs[0])
-        losses.append(float(tr.step_graph(bs[0])[0]))
+        losses.append(float(tr.step_graph(bs[0])))
         torch.cuda.synchronize()
         res[kind] = (losses, tr.opt.flat_p.detach().clone())
     for a, b in zip(res["mol"][0], res["ops"][0]):
         assert abs(a - b) <= 2e-5 * abs(b), (res["mol"][0], res["ops"][0])
     pa, pb = res["mol"][1], res["ops"][1]
-    # Adam's normalised update turns rounding-level gradient differences of near-zero gradients into differences of up to ~lr
-    # per step; three steps at lr = 1e-3
-    assert float((pa - pb).abs().max()) <= 4e-3
-    assert float((pa - pb).abs().mean()) <= 2e-5
+    # Adam's normalised update turns the rounding noise of an analytically ZERO gradient (key biases under the softmax) into
+    # steps of +-lr, with either sign in either trainer: up to 2 lr per step, three steps at lr = 1e-3; everything else agrees
+    # to rounding, which the mean shows
+    d = (pa - pb).abs()
+    assert float(d.max()) <= 6.5e-3, float(d.max())
+    assert float(d.mean()) <= 2e-5, float(d.mean())
