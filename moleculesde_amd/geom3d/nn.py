@@ -66,6 +66,12 @@ class BatchNorm1d(nn.BatchNorm1d):
         self._nbt_host = None             # the host mirror of num_batches_tracked (momentum=None mode) follows the buffer
         return super()._load_from_state_dict(*a, **k)
 
+    def reset_running_stats(self):
+        # (also reached through reset_parameters): the cumulative average restarts at 1 / 1, as torch.nn.BatchNorm1d's does
+        self._nbt_host = None
+        self.pending_batches = 0
+        return super().reset_running_stats()
+
     def flush_batches_tracked(self):
         if self.pending_batches and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(int(self.pending_batches))
@@ -77,6 +83,9 @@ class BatchNorm1d(nn.BatchNorm1d):
             y = super().forward(x)
             return F.relu(y) if self.fuse_relu else y
         if self.training or not self.track_running_stats:
+            if self.momentum is None and torch.cuda.is_current_stream_capturing():
+                # (checked BEFORE the counter moves: a refused capture attempt must leave num_batches_tracked alone)
+                raise RuntimeError("BatchNorm1d(momentum=None) cannot run inside a captured step")
             if self.track_running_stats and self.num_batches_tracked is not None:
                 if self.momentum is None:
                     self.flush_batches_tracked()
@@ -89,8 +98,6 @@ class BatchNorm1d(nn.BatchNorm1d):
                 # lives on the device; a host mirror is read once and advanced with it (nothing else writes the buffer
                 # between forwards except load_state_dict, which resets the mirror below).  The factor changes per call,
                 # so this mode cannot be captured into a hipGraph.
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError("BatchNorm1d(momentum=None) cannot run inside a captured step")
                 if getattr(self, "_nbt_host", None) is None or self.num_batches_tracked is None:
                     self._nbt_host = int(self.num_batches_tracked) if self.num_batches_tracked is not None else 1
                 else:

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import hip, plan as _plan
+from .. import _lib, hip, plan as _plan
 from . import dense_head as _dh
 from . import nn as _nn
 from .sde import VESDE, VPSDE
@@ -280,9 +280,16 @@ class SDEModel3Dto2D_node_adj_dense(nn.Module):
         device = node_3D_repr.device
         pl = _plan.get_plan(data)
         dn = _plan.dense_plan(pl, data)                                      # padded layout, built once per batch
-        if USE_FUSED_HEAD and self.noise_on_one_hot and hasattr(pl, "bond_type") and \
-                _dh.fused_supported(self.edge_score_network, self.node_score_network, dn.N_max):
+        fused_ok = self.noise_on_one_hot and hasattr(pl, "bond_type") and \
+            _dh.fused_supported(self.edge_score_network, self.node_score_network, dn.N_max)
+        if USE_FUSED_HEAD and fused_ok:
             return self._forward_fused(node_3D_repr, data, reduce_mean, anneal_power, pl, dn)
+        if not getattr(self, "allow_operator_path", False) and USE_FUSED_HEAD:
+            # the operator path below runs its batched products on the vendor GEMM (torch.baddbmm / matmul): never silently
+            raise _lib.MsdeHipError(
+                "SDEModel3Dto2D_node_adj_dense: this configuration is outside the fused HIP head (nhid = adim = 16, num_linears = 3, "
+                "c_init = 2, 4 layers, <= 32 atoms per molecule, noise_on_one_hot, bond features) -- set "
+                "`model.allow_operator_path = True` to run it operator by operator (vendor batched GEMMs)")
         B, Nm, T = pl.B, dn.N_max, self.num_diffusion_timesteps
         if self.noise_mode == "discrete":
             t = self.noise.randint(T, (B // 2 + 1,), device)

@@ -2928,7 +2928,9 @@ def pair_strip():
 
 def pair_bn_relu_linear_ok(AB, bn, lin2):
     D = AB.size(1) // 2
-    return (AB.is_cuda and AB.dtype == torch.float32 and AB.dim() == 2 and AB.size(1) == 2 * D and D % 4 == 0 and D <= 1024
+    # D <= 768: the second Linear runs with an A transform, which msde_gemm_t2 / msde_gemm_rs take up to K = 768 (beyond that
+    # the launch would fail with MSDE_EUNSUP and the fused autograd node has no fallback: refuse here instead)
+    return (AB.is_cuda and AB.dtype == torch.float32 and AB.dim() == 2 and AB.size(1) == 2 * D and D % 4 == 0 and D <= 768
             and AB.is_contiguous() and AB.data_ptr() % 16 == 0
             and lin2.weight.size(1) == D and lin2.weight.size(0) % 4 == 0 and lin2.bias is not None
             and lin2.weight.is_contiguous() and bn.weight.data_ptr() % 16 == 0 and bn.bias.data_ptr() % 16 == 0)

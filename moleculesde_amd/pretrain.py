@@ -768,28 +768,40 @@ class StreamRunner:
         bk.build_plan_on_device(None)
         return self.tr.step(bk.batch)[0]
 
+    def prepare(self, batch, pin=True):
+        """(host batch, its pinned raw blob or None when it does not fit the bucket): what run() consumes -- the host batch stays
+        beside the blob so that a batch outside the capacities takes the exact-size eager step instead of being re-packed."""
+        return (batch, self.pack(batch, pin=pin))
+
     def run(self, items, steps=None):
-        """One pass over `items` (collated host batches, or blobs already packed with pack()); `steps`: stop after that many,
-        cycling over a list.  Returns the number of steps taken."""
+        """One pass over `items` -- collated host batches, (batch, blob-or-None) pairs from prepare(), or bare blobs already
+        packed with pack(); `steps`: stop after that many, cycling over a list.  Returns the number of steps taken."""
         seq = list(items) if not isinstance(items, (list, tuple)) else items
         n = len(seq) if steps is None else steps
         if n == 0:
             return 0
 
-        def blob_of(i):
+        def item_of(i):
             it = seq[i % len(seq)]
-            return it if torch.is_tensor(it) else self.pack(it)
-        nxt = blob_of(0)
-        if nxt is not None:
-            self.feeder.submit(nxt)
+            if torch.is_tensor(it):
+                return None, it                     # a bare blob (the caller vouches that it fits)
+            if isinstance(it, tuple) and len(it) == 2 and (it[1] is None or torch.is_tensor(it[1])):
+                return it                           # prepare()'s pair
+            if it is None:
+                raise ValueError("StreamRunner.run: a None item (a batch that did not fit, packed without its host batch): "
+                                 "pass prepare(batch) pairs or the host batches themselves")
+            return it, self.pack(it)
+        nxt = item_of(0)
+        if nxt[1] is not None:
+            self.feeder.submit(nxt[1])
         for i in range(n):
             cur = nxt
-            nxt = blob_of(i + 1) if i + 1 < n else None
-            if nxt is not None:
-                self.feeder.submit(nxt)            # crosses PCIe while step i runs
-            if cur is None:                        # does not fit: exact-size eager step on a host-built plan
+            nxt = item_of(i + 1) if i + 1 < n else (None, None)
+            if nxt[1] is not None:
+                self.feeder.submit(nxt[1])         # crosses PCIe while step i runs
+            if cur[1] is None:                     # does not fit: exact-size eager step on a host-built plan
                 self.fallbacks += 1
-                self.tr.step(prepare_batch(seq[i % len(seq)].clone(), self.tr.device))
+                self.tr.step(prepare_batch(cur[0].clone(), self.tr.device))
             else:
                 self.feeder.load_next()
                 self._step_loaded()
@@ -859,7 +871,7 @@ def main(argv=None):
                 return steps
         return train_epochs(args, trainer, _Eager(), lambda e: (pool, args.steps_per_epoch), rank)
     runner = StreamRunner(trainer, cpu_pool)
-    blobs = [runner.pack(b) for b in cpu_pool]
+    blobs = [runner.prepare(b) for b in cpu_pool]
     return train_epochs(args, trainer, runner, lambda e: (blobs, args.steps_per_epoch), rank)
 
 

@@ -467,12 +467,33 @@ def test_golden_toy_sde3d2d(dev):
     m.to(dev).train()
     m.noise = G.CpuReplayNoise(int(g["seed"]))
     h3 = torch.from_numpy(g["h3"]).to(dev).requires_grad_(True)
+    from moleculesde_amd.geom3d import dense_head
+    calls = dense_head.FUSED_CALLS
     lx, la = m(h3, b, reduce_mean=True, continuous=True, train=True, anneal_power=0)
+    assert dense_head.FUSED_CALLS == calls + 1, "the fused head kernels (not the operator path on vendor GEMMs) must have run"
     assert_close(lx, g["loss_x"], 1e-4, 1e-6, "loss_x")
     assert_close(la, g["loss_adj"], 1e-4, 1e-6, "loss_adj")
     (lx + la).backward()
     assert_close(h3.grad, g["grad_h3"], 1e-3, 1e-4 * float(np.abs(g["grad_h3"]).max()), "grad h3")
     _grads_close(m, sub(g, "grad."), 1e-3, 2e-4, "sde3d2d")
+
+
+def test_sde3d2d_outside_the_fused_head_raises_unless_allowed(dev):
+    """A head configuration the kernels do not cover (nhid = 8) must not drop to the operator path (vendor batched GEMMs)
+    silently: it raises, and runs operator by operator only with `allow_operator_path = True`."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd._lib import MsdeHipError
+    from moleculesde_amd.synthetic import make_batch
+    b = G.prepare_batch(make_batch(4, seed=2), dev)
+    m = G.SDEModel3Dto2D_node_adj_dense(dim3D=16, c_init=2, c_hid=8, c_final=4, num_heads=4, adim=16, nhid=8, num_layers=4,
+                                        emb_dim=16, num_linears=3, beta_min=0.1, beta_max=1.0, num_diffusion_timesteps=1000,
+                                        SDE_type="VE", num_class_X=119, noise_on_one_hot=True).to(dev).train()
+    h3 = torch.randn(b.x.size(0), 16, device=dev)
+    with pytest.raises(MsdeHipError, match="allow_operator_path"):
+        m(h3, b, reduce_mean=True, continuous=True, train=True, anneal_power=0)
+    m.allow_operator_path = True
+    lx, la = m(h3, b, reduce_mean=True, continuous=True, train=True, anneal_power=0)
+    assert torch.isfinite(lx) and torch.isfinite(la)
 
 
 def test_golden_f3_sde3d2d_02(dev):

@@ -553,3 +553,26 @@ def test_stream_runner_matches_its_eager_twin_and_main_runs(dev, capsys):
     assert "epoch: 1" in printed and "SDE 2Dto3D Loss" in printed and len(out) == 1 and out[0][5] == 5
     import math
     assert all(math.isfinite(v) for v in out[0][:4])
+
+
+def test_stream_runner_takes_the_exact_step_for_a_batch_outside_the_bucket(dev):
+    """a batch that does not fit the capacity bucket (here: more molecules than the bucket was built for) must
+    take the documented fallback -- the exact-size eager step on its own host-built plan -- not crash in pack(None)."""
+    from moleculesde_amd import hip, pretrain
+    from moleculesde_amd.synthetic import make_batch
+    args = pretrain.readme_args(emb_dim=64, SDE_coeff_generative_3Dto2D=0, batch_size=12)
+    torch.manual_seed(3)
+    tr = pretrain.Trainer(args, dev)
+    cpu = [make_batch(12, seed=s) for s in range(301, 304)]
+    big = make_batch(20, seed=399)
+    runner = pretrain.StreamRunner(tr, cpu, n_max=24)
+    items = [runner.prepare(b) for b in cpu[:2]] + [runner.prepare(big), runner.prepare(cpu[2])]
+    assert items[2][1] is None and all(it[1] is not None for it in (items[0], items[1], items[3]))
+    p0 = tr.opt.flat_p.clone()
+    assert runner.run(items) == 4 and runner.fallbacks == 1
+    assert runner.run([cpu[0], big]) == 2 and runner.fallbacks == 2          # bare host batches are packed on the fly
+    with pytest.raises(ValueError):
+        runner.run([None])
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.opt.flat_p).all() and not torch.equal(tr.opt.flat_p, p0)
+    hip.clear_row_bounds()
