@@ -677,38 +677,6 @@ def cpu_baseline(bs=256):
     return out
 
 
-def bf16x3_experiment(a):
-    """the node-level products with both operands split into three bf16 terms on the bf16 matrix pipe
-    (csrc/gemm_t2b.hip, MSDE_BF16X3=1) -- an EXPERIMENT reported under its own key, never the headline.  The switch forces the
-    single-stream step (beside this kernel, kernels of a second stream were not reproducible: DESIGN.md round 4), so the fp32
-    step is timed single-stream too, each in a child process running this file's one-graph mode."""
-    import subprocess
-
-    def child(env_extra):
-        env = dict(os.environ, MSDE_BENCH_CHILD="1", **env_extra)
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch_size",
-               str(a.batch_size), "--no_cpu_baseline", "--no_configs45", "--no_pipeline"] + (["--full"] if a.full else [])
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        for line in reversed(r.stdout.splitlines()):
-            if line.startswith("{"):
-                j = json.loads(line)
-                return {"value": j["value"], "ms_per_step": j["ms_per_step"]}
-        return {"error": (r.stderr or r.stdout)[-300:]}
-    try:
-        x3 = child({"MSDE_BF16X3": "1"})
-        f32 = child({"MSDE_ONE_STREAM": "1"})
-    except Exception as exc:
-        return {"error": f"{type(exc).__name__}: {exc}"}
-    return {"value_bf16x3": x3.get("value"), "ms_per_step_bf16x3": x3.get("ms_per_step"), "unit": "molecules/s",
-            "dtype": "f32 operands split into 3 bf16 terms each, 6 of the 9 partial products on v_mfma_f32_16x16x32_bf16, f32 accumulate",
-            "streams": 1, "value_f32_one_stream": f32.get("value"), "ms_per_step_f32_one_stream": f32.get("ms_per_step"),
-            "errors": [e for e in (x3.get("error"), f32.get("error")) if e] or None,
-            "scope": "plain node-level products on parameters (gemm_fwd / gemm_dgrad / the BatchNorm-statistics products without an A "
-                     "transform); every other kernel of the step is the fp32 one",
-            "accuracy": "tests/test_gpu_kernels.py::test_gemm_t2b_bf16x3_experiment: same tolerances against fp64 as the fp32 kernel",
-            "status": "off by default, not the headline: beside this kernel on a second stream other kernels were not reproducible"}
-
-
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -759,7 +727,7 @@ def main():
     ap.add_argument("--no_configs45", action="store_true", help="skip the configs[3] (sampler) / configs[4] (MD17) timings")
     ap.add_argument("--no_pipeline", action="store_true", help="skip the two-bucket mode (plans of batch t+1 built beside step t)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host (no hipGraph replay)")
-    ap.add_argument("--no_bf16x3", action="store_true", help="skip the bf16x3 experiment's two child runs")
+    ap.add_argument("--no_bf16x3", action="store_true", help="(accepted for old command lines; the bf16x3 experiment is gone)")
     ap.add_argument("--debug_dp_path", action="store_true",
                     help="one GPU: initialise a 1-rank RCCL group and run the multi-GPU step structure "
                          "(graph without Adam; all-reduce; Adam kernel)")
@@ -1003,8 +971,6 @@ def main():
             out["config5_md17"] = config5_md17(device)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch_size)
-        if world == 1 and not a.no_bf16x3 and not os.environ.get("MSDE_BENCH_CHILD") and use_graph:
-            out["bf16x3_experiment"] = bf16x3_experiment(a)
         print(json.dumps(out), flush=True)
     dp.barrier()
     if torch.distributed.is_initialized():

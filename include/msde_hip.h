@@ -468,30 +468,6 @@ int msde_gemm_rs_geometry(int M, int N, int K, int* strips, int* strip_rows);
 int msde_gemm_t2(const msde_rs_desc* desc, void* stream);
 int msde_gemm_t2_supported(int M, int N, int K, int axf);
 int msde_gemm_t2_geometry(int M, int N, int K, int* strips, int* strip_rows);
-/* Up to MSDE_CHAIN_MAX chained products on strips of 16 rows that stay in LDS (csrc/gemm_rs.hip): stage s computes
- * out_s = epilogue_s(in_s . W_s + bias_s) with in_0 = A [M, K_0] and in_s = out_{s-1} (K_s == N_{s-1}); epilogue as in
- * msde_gemm_rs: act (MSDE_EPI_ACT) or multiplication by act'(dact[m,n]) (MSDE_EPI_DACT), then + res[m,n].  Every out_s is
- * also written to memory.  W_s is read as [K_s][N_s] (row stride ldw): the transposed nn.Linear weight for a forward chain,
- * the weight as stored for a chain of input gradients.  SchNet's node-level chains (schnet.py:163-167,97,189,118-120):
- * CFConv.lin2 -> ShiftedSoftplus -> InteractionBlock.lin -> + residual -> the next block's CFConv.lin1.
- * N_s <= 320, N_s % 4 == K_s % 4 == 0, K_0 <= 768, 16-byte aligned rows; otherwise MSDE_EUNSUP.  flags / ld_max: set by the
- * library. */
-#define MSDE_CHAIN_MAX 4
-typedef struct msde_chain_stage {
-  const float* W;
-  const float* bias;
-  const float* res;
-  const float* dact;
-  float* out;
-  int N, K, ldw, ldres, lddact, ldout, act, epi, flags;
-} msde_chain_stage;
-typedef struct msde_chain_desc {
-  const float* A;
-  int lda, M, nstages, ld_max;
-  msde_chain_stage st[MSDE_CHAIN_MAX];
-} msde_chain_desc;
-int msde_gemm_chain(const msde_chain_desc* desc, void* stream);
-
 /* Finish the fused BatchNorm statistics (one small launch): forward -> scale = gamma rstd, shift = beta - mean scale (what
  * MSDE_RS_AXF_AFFINE of the consuming product applies), save_mean / save_rstd for the backward, running buffers updated
  * with `momentum` (unbiased variance), exactly as msde_bn_fwd.  Backward -> the three vectors of MSDE_RS_AXF_BNBWD and
@@ -516,20 +492,11 @@ int msde_bn_bwd_colstats(const float* G, const float* Z, const float* Y, const f
 /* Re-laid-out copies of n fp32 blocks in one launch: the transposed weight copies the forward products of msde_gemm_rs read
  * and the stacked / permuted operands of fused layers (refreshed once per optimiser step).  table: n rows of 8 x int64
  * {src, dst, rows, cols, src_ld, dst_ld, mode, plane_stride} (device); mode 0: dst[c * dst_ld + r] = src[r * src_ld + c]
- * (transpose of the rows x cols block), mode 1: dst[r * dst_ld + c] = src[r * src_ld + c] (copy); modes 2 / 3 (the bf16x3
- * experiment): the copy / the transpose split into three bf16 planes, dst16[plane * plane_stride + ...] (16-bit elements),
- * value = hi + mid + lo exactly; prefix [n+1]: first 32 x 32 tile of each block, prefix[n] = total_tiles. */
+ * (transpose of the rows x cols block), mode 1: dst[r * dst_ld + c] = src[r * src_ld + c] (copy); word 7 unused;
+ * prefix [n+1]: first 32 x 32 tile of each block, prefix[n] = total_tiles. */
 int msde_transpose_multi(const long long* table, const int* prefix, int n, int total_tiles, void* stream);
 /* the same for one block, no tables */
 int msde_relayout(const float* src, int src_ld, float* dst, int dst_ld, int rows, int cols, int mode, void* stream);
-/* one block split into three bf16 planes (modes 2 / 3 above), no tables */
-int msde_relayout_split(const float* src, int src_ld, void* dst16, int dst_ld, int rows, int cols, int transpose,
-                        long long plane_stride, void* stream);
-/* EXPERIMENT, off by default (csrc/gemm_t2b.hip): msde_gemm_t2 with both operands split into three bf16 terms on the bf16
- * matrix pipe, fp32 accumulate -- six of the nine term products, i.e. fp32-level accuracy.  Same descriptor (MSDE_RS_AXF_NONE
- * only) except the weight operand: B = three bf16 planes [3][N][ldb] of the [N][K] weight (msde_transpose_multi modes 2 / 3),
- * ldb = row length in 16-bit elements, a multiple of 32 and >= K, zero beyond K.  Never the headline path. */
-int msde_gemm_t2b(const msde_rs_desc* desc, void* stream);
 /* the same for one matrix, no tables: dst [cols][rows] = src [rows][cols]^T */
 int msde_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 

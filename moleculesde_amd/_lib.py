@@ -80,10 +80,7 @@ SIGNATURES = {
     "msde_linear_bwd_w": [P, P, I, I, I, P, P, P, P, P],
     "msde_gemm_ex": [P, P],
     "msde_gemm_rs": [P, P],
-    "msde_gemm_chain": [P, P],
     "msde_gemm_t2": [P, P],
-    "msde_gemm_t2b": [P, P],
-    "msde_relayout_split": [P, I, P, I, I, I, I, LL, P],
     "msde_gemm_t2_supported": [I, I, I, I],
     "msde_gemm_t2_geometry": [I, I, I, P, P],
     "msde_transpose_multi": [P, P, I, I, P],
@@ -179,17 +176,6 @@ class RsDesc(ctypes.Structure):
 
 RS_AXF_NONE, RS_AXF_AFFINE, RS_AXF_BNBWD, RS_AXF_RELU, RS_VEC_STORE = 0, 1, 2, 4, 8
 RS_STATS_BNFWD, RS_STATS_BNBWD = 1, 2
-
-
-class ChainStage(ctypes.Structure):
-    """msde_chain_stage of include/msde_hip.h."""
-    _fields_ = [("W", P), ("bias", P), ("res", P), ("dact", P), ("out", P),
-                ("N", I), ("K", I), ("ldw", I), ("ldres", I), ("lddact", I), ("ldout", I), ("act", I), ("epi", I), ("flags", I)]
-
-
-class ChainDesc(ctypes.Structure):
-    """msde_chain_desc of include/msde_hip.h."""
-    _fields_ = [("A", P), ("lda", I), ("M", I), ("nstages", I), ("ld_max", I), ("st", ChainStage * 4)]
 
 
 class EdgeLayerParams(ctypes.Structure):

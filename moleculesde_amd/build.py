@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libmsde_hip.so")
 SOURCES = ["graph.hip", "gin.hip", "schnet.hip", "cfconv_fused.hip", "cfconv_fused_bwd.hip", "cfconv_pair.hip",
-           "sde2d3d.hip", "linear.hip", "gemm_ex.hip", "gemm_rs.hip", "gemm_t2.hip", "gemm_t2_a1.hip", "gemm_t2_a2.hip", "gemm_t2b.hip", "dense_head.hip", "plan.hip", "dd.hip", "norm.hip",
+           "sde2d3d.hip", "linear.hip", "gemm_ex.hip", "gemm_rs.hip", "gemm_t2.hip", "gemm_t2_a1.hip", "gemm_t2_a2.hip", "dense_head.hip", "plan.hip", "dd.hip", "norm.hip",
            "contrastive.hip", "optim.hip", "pointwise.hip", "gat_tail.hip", "escore_mol.hip", "escore_mol_bwd.hip"]
 HEADERS = [os.path.join(CSRC, "msde_common.h"), os.path.join(CSRC, "gemm_rs.h"), os.path.join(CSRC, "gemm_rs_epi.h"), os.path.join(CSRC, "gemm_t2.h"), os.path.join(CSRC, "escore_mol.h"),
            os.path.join(HERE, "..", "include", "msde_hip.h")]

@@ -640,10 +640,7 @@ __global__ void cfconv_reduce_slabs_kernel(const float* __restrict__ slabs, int 
 // LDS-using kernels are concerned).  A caller that runs this kernel BESIDE latency-critical work on another stream
 // passes a smaller number: the kernel takes longer but leaves whole CUs to the other stream (measured on the
 // pretrain step: 128 workgroups instead of 256 = +6 % step throughput).
-static inline bool cb_pipe() {          // MSDE_CFBWD_PIPE=0: the unpipelined kernel (kept as the cross-check)
-  static int v = [] { const char* e = getenv("MSDE_CFBWD_PIPE"); return e ? atoi(e) : 1; }();
-  return v != 0;
-}
+static inline bool cb_pipe() { return true; }   // the software-pipelined kernel (round 2: 57 vs 76 us); the round-1 kernel below is no longer reachable
 static inline void cb_geometry(int E_cap, int max_wgs, int* nwg, int* cpw) {
   const int te = CB_TE;
   int chunks = (E_cap + te - 1) / te;
@@ -683,7 +680,7 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
   int nwg, cpw;
   cb_geometry(E_cap, max_workgroups, &nwg, &cpw);
   int kk1 = (G + 1) / 2;
-  static const int dbg = getenv("MSDE_CFBWD_DBG") ? atoi(getenv("MSDE_CFBWD_DBG")) : 0;   // diagnostics (tools/bench_cfconv_bwd.py)
+  const int dbg = 0;    // (phase-skipping diagnostics of round 2: compile-time only now)
   auto lds_bytes = [](int KK1) {
     return (size_t)(CB_F * CB_HS + CB_TE * (2 * KK1 + 1) + 64 + 2 * CB_TE * CB_HS + 4 * CB_TE) * sizeof(float);
   };
@@ -701,7 +698,7 @@ extern "C" int msde_cfconv_fused_bwd_w(const float* g_agg, const float* x1, cons
               W1, b1, W2, offset, N, G, coeff, cutoff, cpw, workspace, dbg)
   // W2 in registers (96 KB of LDS per workgroup) by default: the same speed alone (56.6 vs 57.4 us) and the step no longer
   // loses 1.8 % when the kernel runs at full width beside the main chain (0.7 %); MSDE_CFBWD_W2REG=0: W2 in LDS (158 KB)
-  static const int w2reg = getenv("MSDE_CFBWD_W2REG") ? atoi(getenv("MSDE_CFBWD_W2REG")) : 1;
+  constexpr int w2reg = 1;
   auto ldsp_bytes = [](int KK1) {
     return (size_t)((w2reg ? 0 : CB_F * CB_HS) + 2 * (CB_TE * (2 * KK1 + 1) + 64) + 2 * CB_TE * CB_HS + 8 * CB_TE + 64) *
            sizeof(float);

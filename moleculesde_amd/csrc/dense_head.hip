@@ -640,7 +640,7 @@ extern "C" int msde_dense_edge_layer_fwd(const float* QK, const float* XV, float
   const int nm = n_max < 1 ? 1 : n_max;
   hipStream_t st = as_stream(stream);
   const msde_edge_layer_params p = *params;
-  static const bool want_split = [] { const char* e = getenv("MSDE_DENSE_SPLIT"); return !(e && atoi(e) == 0); }();
+  const bool want_split = true;
 #define EDGE_FWD_SPLIT(CC, CCO)                                                                                        \
   if (C == CC && CO == CCO) {                                                                                          \
     const int bytes = EdgeLds<CC, CCO>::floats_split(nm) * (int)sizeof(float);                                        \

@@ -387,7 +387,7 @@ extern "C" int msde_gemm_ex(const msde_gemm_desc* desc, void* stream) {
   }
   // tile height: 128 rows when that still gives every CU >= 2 tiles, else 64 (skinny problems need the parallelism)
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.groups;
-  static const int force_tm = getenv("MSDE_GEMM_TM") ? atoi(getenv("MSDE_GEMM_TM")) : 0;      // tuning knob
+  const int force_tm = 0;      // (tile-height override of the round-2 sweeps: 0 = the rule below)
   const int tm = force_tm ? force_tm : (t128 >= 2L * msde_num_cus() ? 2 : 1);
   const int tiles = ((d.M + 64 * tm - 1) / (64 * tm)) * ((d.N + 63) / 64);
   const int grid_x = ((tiles + 7) / 8) * 8;       // whole multiples of 8: every XCD gets the same number of slots

@@ -32,9 +32,9 @@ static bool t2_pick(int M, int N, int K, int splits, int axf, t2_cfg* c) {
   // CU instead (their rings fit the LDS twice when only one A operand is staged) -- one workgroup's prologue and epilogue
   // then overlap the other's K loop (3588 x 600 x 300 alone: 22.5 -> 19.6 us; narrower outputs lose, tools/bench_gemm_t2.py
   // --sweep).  MSDE_T2_SPLIT2=0 keeps one workgroup per CU.
-  static const int split2 = [] { const char* e = getenv("MSDE_T2_SPLIT2"); return e ? atoi(e) : 2; }();
+  const int split2 = 2;
   bool two_per_cu = false;
-  static const int rn_cap = [] { const char* e = getenv("MSDE_T2_RNCAP"); return e ? atoi(e) : 0; }();     // (measurement knob)
+  const int rn_cap = 0;
   if (rn_cap > 0 && splits <= 0 && rowblks <= cus && rn > rn_cap) {
     int rn2 = rn_cap;
     for (int ok : T2_RN_OK) if (ok >= rn2) { rn2 = ok; break; }

@@ -227,9 +227,9 @@ __global__ void segment_sum_rows_kernel(const float* __restrict__ rows, const in
 }
 
 static inline int seg_epl(int N, int tpr) {     // edge lanes: fill the chip when N * tpr threads would not
-  static int force = [] { const char* e = getenv("MSDE_SEG_EPL"); return e ? atoi(e) : 0; }();
+  const int force = 0;
   if (force) return force * tpr <= 64 ? force : 1;
-  static int wide = [] { const char* e = getenv("MSDE_SEG_EPL_WIDE"); return e ? atoi(e) : 0; }();
+  const int wide = 0;
   if (tpr >= 32 && !wide) return 1;     // rows of >= 128 floats: half a wave per row already; edge lanes measured slower
   int epl = 1;
   while (epl < 4 && tpr * epl * 2 <= 64 && (long)N * tpr * epl < 256L * 1024) epl *= 2;

@@ -507,24 +507,18 @@ extern "C" int msde_linear_bwd_x(const float* gY, const float* W, int M, int N, 
 // splits of the reduction (M) that ~512 workgroups (two per CU) are in flight, at least 64 rows per split, at
 // most 512 splits.  MI355X, hipGraph-timed: 3588x300x300 23 us (vendor mm + colsum 39), 49090x128x128 32 us
 // (vendor 225).  MSDE_WGRAD_TILE / MSDE_WGRAD_WGS are tuning knobs for tools/bench_wgrad.py.
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
 static inline bool wgrad_big(int M, int N, int K) {
-  static int force = env_int("MSDE_WGRAD_TILE", 0);   // experiment knob: 64 / 128 forces the tile width
-  if (force == 128) return true;
-  return false;   // measured (tools/bench_wgrad.py): 64-wide tiles + ~512 workgroups win on every step shape
+  return false;   // measured (tools/bench_wgrad.py): 64-wide tiles + ~512 workgroups win on every step shape (128-wide: 2.78 vs 2.72 ms)
 }
 static inline void wgrad_split_for(int M, int N, int K, int target, int* splits, int* k_per_split);
 static inline void wgrad_split(int M, int N, int K, int* splits, int* k_per_split) {
-  static int target = env_int("MSDE_WGRAD_WGS", 512);
+  const int target = 512;
   wgrad_split_for(M, N, K, target, splits, k_per_split);
 }
 // the batched paths (msde_linear_bwd_w_partial / _describe + _grouped) share one launch among all layers, so a
 // layer needs far fewer workgroups of its own: fewer, longer splits = less prologue / slab traffic per FLOP
 static inline void wgrad_split_batched(int M, int N, int K, int* splits, int* k_per_split) {
-  static int target = env_int("MSDE_WGRAD_WGS_GROUPED", 64);
+  const int target = 64;
   wgrad_split_for(M, N, K, target, splits, k_per_split);
 }
 static inline void wgrad_split_for(int M, int N, int K, int target, int* splits, int* k_per_split) {
@@ -685,7 +679,7 @@ extern "C" int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const flo
   vec = vec && (kps % 4 == 0);
   // (round 4, tools/ab_multi.sh on one box: edge tiles on the fast path 2.70-2.73 vs 2.69-2.72 ms, the 128-VGPR build
   // MSDE_WGRAD_OCC4 2.70-2.71, register prefetch two / three tiles deep (-DLG_ST) 2.72 vs 2.71: none of them moves the step)
-  static const int relax = env_int("MSDE_WGRAD_EDGE_FAST", 0);
+  const int relax = 0;
   row[12] = ldg; row[13] = ldx; row[14] = reinterpret_cast<long long>(rows_dev); row[15] = relax;
   row[0] = reinterpret_cast<long long>(gY);
   row[1] = reinterpret_cast<long long>(X);
@@ -699,9 +693,9 @@ extern "C" int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* p
                                             int max_workgroups, void* stream) {
   if (count < 0 || total_blocks < 0 || (count > 0 && (!probs || !prefix))) return MSDE_EINVAL;
   if (count == 0 || total_blocks == 0) return 0;
-  static const int xcd = env_int("MSDE_WGRAD_XCD", 1);
+  const int xcd = 1;
   const int grid = max_workgroups > 0 && max_workgroups < total_blocks ? max_workgroups : total_blocks;
-  static const int occ4 = env_int("MSDE_WGRAD_OCC4", 0);
+  const int occ4 = 0;
   if (occ4)
     MSDE_LAUNCH(gemm_grouped_wgrad_occ4_kernel, dim3(grid), dim3(256), 0, as_stream(stream), probs, prefix, count, total_blocks,
                 grid == total_blocks ? xcd : 0);

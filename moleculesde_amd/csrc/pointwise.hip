@@ -525,7 +525,7 @@ static inline int mh_grid(int E, int lpr) {
   // workgroups of the backward kernel (= slabs of its weight gradient).  Each row group walks its rows one dependent load
   // chain at a time, so the kernel is bound by rows per group, not by bytes: 256 workgroups (17 rows per group at 35 k
   // edges) 20 us, 1024 (4-5 rows) -- see MSDE_MH_MAXWG
-  static const int maxwg = [] { const char* e = getenv("MSDE_MH_MAXWG"); int v = e ? atoi(e) : 1024; return v < 1 ? 1 : v; }();
+  const int maxwg = 1024;
   const int rpb = 256 / lpr;
   int nb = (E + rpb - 1) / rpb;
   if (nb > maxwg) nb = maxwg;

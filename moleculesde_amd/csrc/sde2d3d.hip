@@ -404,10 +404,7 @@ edge_attention_bwd_wave_kernel(const float* __restrict__ g_out, const float* __r
 }
 
 static inline bool ea_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-static inline bool ea_wave_path() {           // MSDE_EA_WAVE=0: the thread-per-(target, head) kernels (cross-check)
-  static int v = [] { const char* e = getenv("MSDE_EA_WAVE"); return e ? atoi(e) : 1; }();
-  return v != 0;
-}
+static inline bool ea_wave_path() { return true; }   // wave-per-target kernels for 8 heads x 4 channels; the thread-per-(target, head) kernels take every other shape
 
 extern "C" int msde_edge_attention_fwd(const float* q, const float* k, const float* v, const float* skip, int ld,
                                        const float* ee, int ld_ee,

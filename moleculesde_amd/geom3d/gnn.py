@@ -10,8 +10,8 @@ from . import nn as _nn
 
 
 import os as _os
-FUSE_GIN_LAYER = _os.environ.get("MSDE_FUSE_GIN", "1") != "0"     # A/B switch: BatchNorm folded into the GIN products
-FUSE_GIN_APPLY = _os.environ.get("MSDE_FUSE_GIN_APPLY", "1") != "0"   # ... and its apply into the next layer's aggregation
+FUSE_GIN_LAYER = True     # BatchNorm folded into the GIN products (False: separate BatchNorm launches, the cross-check)
+FUSE_GIN_APPLY = True     # ... and its apply into the next layer's aggregation
 
 
 class GINConv(nn.Module):
@@ -54,7 +54,6 @@ class GNN(nn.Module):
         self.batch_norms = nn.ModuleList([_nn.BatchNorm1d(emb_dim) for _ in range(num_layer)])
         for layer in range(num_layer - 1):
             self.batch_norms[layer].fuse_relu = True     # ReLU after every layer but the last (:178-182)
-        self.on_input_grad = None
 
     def _find_plan(self, x, edge_index, edge_attr, data=None):
         pl = None
@@ -82,11 +81,6 @@ class GNN(nn.Module):
             raise ValueError("unmatched number of arguments.")
 
         h = hip.embedding_sum(self.atom_encoder.table(), pl.atom_codes, pl.atom_list_ptr, pl.atom_list_nodes)
-        if self.on_input_grad is not None and h.requires_grad:
-            # trainer hook: fires when the gradient of the first activation is ready, i.e. every Linear / BatchNorm
-            # of the encoder has run its backward (only the embedding tables' own gradient is still to come)
-            cb = self.on_input_grad
-            h.register_hook(lambda g_: (cb(), None)[1])
         h_list = [h]
         fused = FUSE_GIN_LAYER and self.training and h.is_cuda and h.size(1) % 4 == 0 and 0 < h.size(0) <= hip.RS_MAX_ROWS
         # a layer output that only the next layer's aggregation reads (JK = last, no dropout) is never normalised by a launch

@@ -18,7 +18,7 @@ def shifted_softplus(x):
 
 
 import os as _os
-FUSED_MLP = _os.environ.get("MSDE_FUSED_MLP", "1") != "0"     # Linear/SiLU/Linear chains as hip.mlp_fused (A/B switch)
+FUSED_MLP = True     # Linear/SiLU/Linear chains as hip.mlp_fused (False: layer by layer, the cross-check)
 
 
 def _need_device(x):

@@ -19,9 +19,9 @@ from .. import hip, plan as _plan
 from . import nn as _nn
 
 
-import os as _os
-FUSE_TAIL = _os.environ.get("MSDE_FUSE_SCHNET_TAIL", "1") != "0"   # A/B switch: softplus / residual in GEMM epilogues
-CHAIN = _os.environ.get("MSDE_SCHNET_CHAIN", "0") != "0"           # one chained-product launch per interaction (measured: no gain, off)
+FUSE_TAIL = True     # softplus / residual in GEMM epilogues (False: layer by layer, the cross-check)
+# (Round 3's chained-product kernel -- lin2 -> ssp -> lin -> + residual -> the next lin1 as ONE launch on 16-row strips -- was
+# 28.8 us against 30.0 us for the three launches and 2.843 vs 2.807 ms in the step: removed, numbers in DESIGN.md section 4.22.)
 
 
 class GaussianSmearing(nn.Module):
@@ -126,10 +126,6 @@ class SchNet(nn.Module):
 
         Hd, Fl = self.hidden_channels, self.num_filters
         nb = len(self.interactions)
-        # node-level layers between two message-passing steps as ONE launch (lin2 -> ssp -> lin -> + residual -> the next
-        # block's lin1; after the last block: -> the output head), the row strip staying in LDS
-        chained = (FUSE_TAIL and CHAIN and nb > 0 and hip.chain_ok(h.size(0), [Fl, Hd, Hd, Fl])
-                   and all(hip.rs_forward_ok(h.size(0), Hd, Fl, b.conv.lin2.weight) for b in self.interactions))
         x1 = None
         for bi, blk in enumerate(self.interactions):
             if x1 is None:
@@ -152,12 +148,7 @@ class SchNet(nn.Module):
                 Wf = blk.mlp(rbf)
                 agg = hip.cfconv_aggregate(x1, Wf, C, rplan)
             x1 = None
-            if chained and bi + 1 < nb:
-                h_res, x1 = hip.schnet_node_chain(agg, h_res, blk.conv.lin2, blk.lin, self.interactions[bi + 1].conv.lin1)
-                h = h_res
-            elif chained:
-                h = hip.schnet_head_chain(agg, h_res, blk.conv.lin2, blk.lin, self.lin1, self.lin2)
-            elif FUSE_TAIL and hip.rs_forward_ok(h.size(0), Hd, Fl, blk.conv.lin2.weight) \
+            if FUSE_TAIL and hip.rs_forward_ok(h.size(0), Hd, Fl, blk.conv.lin2.weight) \
                     and Hd % 4 == 0 and 0 < h.size(0) <= hip.RS_MAX_ROWS:
                 # lin2 -> ssp -> lin -> + residual: two products with the pointwise stages in their epilogues
                 h = hip.schnet_tail(agg, h_res, blk.conv.lin2, blk.lin)
@@ -166,9 +157,7 @@ class SchNet(nn.Module):
                 x = blk.lin(hip.shifted_softplus(x))
                 h = h_res + x
 
-        if chained:
-            pass                    # the head ran with the last interaction
-        elif FUSE_TAIL and Hd % 4 == 0 and h.size(0) > 0:
+        if FUSE_TAIL and Hd % 4 == 0 and h.size(0) > 0:
             h = hip.mlp_fused(h, [(self.lin1.weight, self.lin1.bias), (self.lin2.weight, self.lin2.bias)], "ssp")
         else:
             h = self.lin2(hip.shifted_softplus(self.lin1(h)))

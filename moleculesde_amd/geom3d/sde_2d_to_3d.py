@@ -26,17 +26,17 @@ from .sde import VESDE, VPSDE
 EPSILON = 1e-6
 import os as _os
 FUSE_GAT_TAIL = True     # csrc/gat_tail.hip for hidden size 32 (False: the kernel-per-stage path, used as a cross-check)
-NOISE_IN_KERNEL = _os.environ.get("MSDE_NOISE_IN_KERNEL", "1") != "0"     # DeviceNoise: draws made by the VE perturbation kernel
-FUSE_FRAME = _os.environ.get("MSDE_FUSE_FRAME", "1") != "0"              # hip._FrameMLP (False: coff_mlp twice + cat + project)
-STATIC_FEATURE_CACHE = _os.environ.get("MSDE_STATIC_FEATURES", "1") != "0"   # inference: coordinate-independent inputs of the score network computed once per 2D representation
-FUSE_HEAD_MIX = _os.environ.get("MSDE_FUSE_HEAD_MIX", "1") != "0"        # hip._MlpHeadMix (False: hip.mlp_fused + hip.frame_mix_mean)
-FUSE_EDGE_EMB = _os.environ.get("MSDE_FUSE_EDGE_EMB", "1") != "0"        # hip._PairBnReluLinear (False: gather-add, BatchNorm, Linear as separate ops)
+NOISE_IN_KERNEL = True     # DeviceNoise: draws made by the VE perturbation kernel
+FUSE_FRAME = True          # hip._FrameMLP (False: coff_mlp twice + cat + project)
+STATIC_FEATURE_CACHE = True   # inference: coordinate-independent inputs of the score network computed once per 2D representation
+FUSE_HEAD_MIX = True       # hip._MlpHeadMix (False: hip.mlp_fused + hip.frame_mix_mean)
+FUSE_EDGE_EMB = True       # hip._PairBnReluLinear (False: gather-add, BatchNorm, Linear as separate ops)
 MOL_KERNEL = True       # EquivariantScoreNetwork without autograd (get_score, sampling, evaluation) as ONE launch, one workgroup per molecule (False: operator by operator, the cross-check)
 MOL_KERNEL_TRAIN = False    # ... and under autograd (forward + one-launch backward, moleculesde_amd/escore.py).  Off by default: beside
                             # the second stream of the pretrain step the 256 single-wave-per-SIMD workgroups hold every CU for ~100 + ~340 us
                             # and the step is 2.69 ms against 2.58 ms operator by operator (alternating A/B on one box);
                             # `--score_kernel mol` of pretrain.py / the parity tests switch it on
-FUSE_PAIR_LINEAR = _os.environ.get("MSDE_FUSE_PAIR_LINEAR", "1") != "0"  # hip._PairLinear (False: re-laid-out weight per step)
+FUSE_PAIR_LINEAR = True    # hip._PairLinear (False: re-laid-out weight per step)
 
 
 class GaussianFourierProjection(nn.Module):

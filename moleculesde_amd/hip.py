@@ -284,7 +284,7 @@ def cfconv_fused(x1, W1, b1, W2, b2, dist, plan, offset, coeff, cutoff):
 
 # ---- CFConv on unordered atom pairs (csrc/cfconv_pair.hip) -----------------------------------------------------
 import os as _os_pair
-CFCONV_PAIR = _os_pair.environ.get("MSDE_CFCONV_PAIR", "1") != "0"     # A/B switch: CFConv on unordered pairs
+CFCONV_PAIR = True     # CFConv on unordered pairs (False: the per-edge fused kernels, kept as the cross-check and for > 33 atoms)
 
 
 class PairPlan:
@@ -430,7 +430,7 @@ class _EmbeddingSum(torch.autograd.Function):
         g_tab = torch.empty(ctx.R, ctx.D, dtype=torch.float32, device=g.device)
         nfl = int(_lib.load().msde_embedding_sum_bwd_workspace_floats(ctx.R, ctx.D, EMB_BWD_SPLIT))
         R, D = ctx.R, ctx.D
-        if _SLABS.active and DEFER_LEAF_KERNELS:
+        if _SLABS.active:
             # the table gradient is a leaf gradient: queued like the GIN bond-table gradients (own workspace in the arena;
             # only the ADDRESS of g_tab is kept, see _SlabBatch.add)
             ws = _SLABS.alloc(nfl, g.device)
@@ -452,21 +452,20 @@ def embedding_sum(tab, codes, list_ptr, list_nodes):
     return _EmbeddingSum.apply(tab, codes, list_ptr, list_nodes)
 
 
-# The aggregation backward can also emit the BatchNorm-backward partial sums of its result (msde_gin_aggregate_bwd_x_stats).
-# Measured slower than the separate 6 us column-statistics launch: strips of 16 rows leave 225 workgroups walking four
-# dependent gather chains each (27.7 us against 13.0 + 6.4; step 2.91 vs 2.86 ms), so it is off.
-GIN_BWD_STATS = _os_pair.environ.get("MSDE_GIN_BWD_STATS", "0") != "0"
+# (Round 3 measurement, removed from the product: the aggregation backward emitting the BatchNorm-backward partial sums of its
+# result -- msde_gin_aggregate_bwd_x_stats, still in the library and in tests/test_gpu_kernels.py -- was 27.7 us against 13.0 +
+# 6.4 us for the separate column-statistics launch; step 2.91 vs 2.86 ms.)
 
 
 class BnLink:
     """What a fused GIN layer hands to the NEXT layer's aggregation so that its outer BatchNorm (+ ReLU) is applied on the
     fly there instead of by a launch of its own (hip._GinMlpBN with defer_apply): z = the second product, vec = scale |
-    shift | mean | rstd.  The next layer's aggregation backward leaves the BatchNorm-backward partial sums in `stats`."""
+    shift | mean | rstd."""
 
-    __slots__ = ("z", "vec", "relu", "stats")
+    __slots__ = ("z", "vec", "relu")
 
     def __init__(self, z, vec, relu):
-        self.z, self.vec, self.relu, self.stats = z, vec, bool(relu), None
+        self.z, self.vec, self.relu = z, vec, bool(relu)
 
 
 class _GinAggregate(torch.autograd.Function):
@@ -495,14 +494,8 @@ class _GinAggregate(torch.autograd.Function):
         R = tab.size(0)
         st = _stream()
         g_x = torch.empty_like(x)
-        if link is not None and GIN_BWD_STATS:
-            link.stats = torch.empty((N + 15) // 16, 2, D, dtype=torch.float32, device=x.device)
-            _lib.call("msde_gin_aggregate_bwd_x_stats", _p(g), _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr_s),
-                      _p(plan.perm_s), _p(plan.dst), N, _p(bound_tensor(N)), D, _p(link.z), _p(link.vec[2]), int(link.relu),
-                      _p(g_x), _p(link.stats), st)
-        else:
-            _lib.call("msde_gin_aggregate_bwd_x", _p(g), _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr_s),
-                      _p(plan.perm_s), _p(plan.dst), N, D, _p(g_x), st)
+        _lib.call("msde_gin_aggregate_bwd_x", _p(g), _p(x), _p(tab), _p(codes), _p(eps), _p(plan.rowptr_s),
+                  _p(plan.perm_s), _p(plan.dst), N, D, _p(g_x), st)
         g_tab = torch.empty_like(tab)
         g_eps = torch.empty(1, dtype=torch.float32, device=x.device)
         nfl = int(_lib.load().msde_gin_aggregate_bwd_tab_workspace_floats(N, plan.E, D, R))
@@ -515,14 +508,11 @@ class _GinAggregate(torch.autograd.Function):
                 _lib.call("msde_gin_aggregate_bwd_tab", _p(g), _p(x), _p(tab), _p(codes), _p(plan.src), _p(plan.dst), N,
                           E_, D, R, _p(None), _p(None), _p(ws), _p(bound_tensor(N)), _p(bound_tensor(E_)),
                           st_ if st_ is not None else _stream())
-            if DEFER_LEAF_KERNELS:
-                # a parameter gradient nothing in the backward chain reads: queued (operands kept alive) and launched by
-                # run_deferred_leaf_kernels() -- the trainer runs them beside the grouped weight-gradient launch; the
-                # layers of one graph go out as ONE launch there (msde_gin_aggregate_bwd_tab_multi)
-                launch.gin_tab = (g, x, tab, codes, plan, ws, N, E_, D, R)
-                _SLABS.deferred.append(launch)
-            else:
-                launch(st)
+            # a parameter gradient nothing in the backward chain reads: queued (operands kept alive) and launched by
+            # run_deferred_leaf_kernels() -- the trainer runs them beside the grouped weight-gradient launch; the
+            # layers of one graph go out as ONE launch there (msde_gin_aggregate_bwd_tab_multi)
+            launch.gin_tab = (g, x, tab, codes, plan, ws, N, E_, D, R)
+            _SLABS.deferred.append(launch)
             _SLABS.add(ws.data_ptr(), nslab, R * D, g_tab)
             _SLABS.add(ws.data_ptr() + 4 * nslab * R * D, nslab, 1, g_eps)
         else:
@@ -1262,11 +1252,10 @@ def _wgrad_workspace(M, N, K, device):
 #     M = 3588 whatever the layer size, 110-225 us at edge level); the split-M MFMA kernel + fixed-order
 #     slab reduce takes 9-33 us (tools/bench_wgrad.py, hipGraph-timed), fuses the bias gradient and is
 #     bitwise reproducible -> hand-written kernel for every layer.
-# MSDE_LINEAR=hip forces the round-1 kernels of csrc/linear.hip everywhere (cross-checks); the vendor GEMM is not reachable
-# from the product (tools/bench_gemm*.py time it beside the kernels).
+# The vendor GEMM is not reachable from the product (tools/bench_gemm*.py time it beside the kernels).
 import os as _os
 
-_LINEAR_MODE = _os.environ.get("MSDE_LINEAR", "auto")
+_LINEAR_MODE = "auto"            # set_linear_mode("hip"): the round-1 kernels of csrc/linear.hip everywhere (cross-check tests)
 WGRAD_HIP_MIN_ROWS = 64          # below this a split over M has nothing to split
 
 
@@ -1424,13 +1413,12 @@ class _SlabBatch:
         self._select_slot(dev)
         host_prob, host_ppre, dev_prob, dev_ppre = self.slot[4:]
         lib = _lib.load()
-        if WGRAD_LPT:
-            # longest workgroups first (rows per split = K tiles per workgroup): the launch ends with short workgroups
-            # instead of draining a few 100-us ones at partial occupancy
-            def rows_per_split(t):
-                sp = _SPLITS.get((t[2], t[3], t[4])) or int(lib.msde_linear_bwd_w_splits(t[2], t[3], t[4]))
-                return t[2] / max(sp, 1)
-            self.gemms.sort(key=rows_per_split, reverse=True)
+        # longest workgroups first (rows per split = K tiles per workgroup): the launch ends with short workgroups
+        # instead of draining a few 100-us ones at partial occupancy
+        def rows_per_split(t):
+            sp = _SPLITS.get((t[2], t[3], t[4])) or int(lib.msde_linear_bwd_w_splits(t[2], t[3], t[4]))
+            return t[2] / max(sp, 1)
+        self.gemms.sort(key=rows_per_split, reverse=True)
         r0, q0, ng = self.prob_used, self.pre_used, len(self.gemms)
         assert r0 + ng <= self.MAX_ROWS
         hp2 = host_ppre.numpy()
@@ -1455,13 +1443,11 @@ class _SlabBatch:
 
     def run_deferred(self):
         d, self.deferred = self.deferred, []
-        groups, others = {}, []
+        groups = {}
         for fn in d:
             t = getattr(fn, "gin_tab", None)
-            if t is not None and GIN_TAB_MULTI:
+            if t is not None:       # the GIN bond-table gradients of one graph: ONE launch for all layers (below)
                 groups.setdefault((t[3].data_ptr(), t[4].src.data_ptr(), t[6], t[7], t[8], t[9]), []).append(t)
-            elif TAB_FIRST:
-                others.append(fn)
             else:
                 fn(None)
         for ts in groups.values():
@@ -1473,8 +1459,6 @@ class _SlabBatch:
                 _lib.call("msde_gin_aggregate_bwd_tab_multi", ctypes.cast(arr(0), ctypes.c_void_p), ctypes.cast(arr(1), ctypes.c_void_p),
                           ctypes.cast(arr(2), ctypes.c_void_p), ctypes.cast(arr(5), ctypes.c_void_p), n, _p(codes), _p(plan.src),
                           _p(plan.dst), N, E_, D, R, _p(bound_tensor(N)), _p(bound_tensor(E_)), _stream())
-        for fn in others:
-            fn(None)
         # the closures hold the kernels' operands: kept until finish(), because they may be launched on ANOTHER stream than
         # the one that allocated the operands (the caching allocator would hand their memory to that stream's next kernels)
         self.launched.extend(d)
@@ -1554,11 +1538,6 @@ class _SlabBatch:
             self.new_slot(dev)
 
 
-DEFER_LEAF_KERNELS = _os.environ.get("MSDE_DEFER_LEAF", "1") != "0"   # GIN bond-table gradients off the backward chain
-TAB_FIRST = _os.environ.get("MSDE_TAB_FIRST", "0") != "0"   # bond-table kernels ahead of the embedding-table ones at the tail
-GIN_TAB_MULTI = _os.environ.get("MSDE_GIN_TAB_MULTI", "1") != "0"     # ... all layers of a graph in one launch
-WGRAD_LPT = _os.environ.get("MSDE_WGRAD_LPT", "1") != "0"            # grouped launch: problems with the longest workgroups first
-GROUPED_WGRAD = _os.environ.get("MSDE_GROUPED_WGRAD", "1") != "0"   # queued GEMMs -> one grouped launch at finish()
 _SLABS = _SlabBatch()
 _SPLITS = {}
 
@@ -1633,7 +1612,7 @@ def weight_grad(g2, x2, has_bias, deferrable=True, out_w=None, out_b=None):
     Under the grouped launch the operands may be column blocks of wider buffers (unit column stride)."""
     M, N = g2.shape
     K = x2.size(1)
-    if not (_SLABS.active and deferrable and GROUPED_WGRAD) or M < WGRAD_HIP_MIN_ROWS:
+    if not (_SLABS.active and deferrable) or M < WGRAD_HIP_MIN_ROWS:
         g2, x2 = g2.contiguous(), x2.contiguous()          # only the grouped kernel takes row strides
     st = _stream()
     # out_w / out_b: contiguous slices of a stacked gradient (several layers' weights consumed as one operand)
@@ -1644,10 +1623,7 @@ def weight_grad(g2, x2, has_bias, deferrable=True, out_w=None, out_b=None):
         if splits is None:
             splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
         slab = _SLABS.alloc(splits * (N * K + (N if has_bias else 0)), g2.device)
-        if GROUPED_WGRAD:
-            _SLABS.queue_gemm(g2, x2, M, N, K, int(has_bias), slab)
-        else:
-            _lib.call("msde_linear_bwd_w_partial", _p(g2), _p(x2), M, N, K, int(has_bias), _p(slab), _p(bound_tensor(M)), st)
+        _SLABS.queue_gemm(g2, x2, M, N, K, int(has_bias), slab)       # one grouped launch at the end of the backward pass
         _SLABS.add(slab.data_ptr(), splits, N * K, gw)
         if has_bias:
             _SLABS.add(slab.data_ptr() + 4 * splits * N * K, splits, N, gb)
@@ -1673,7 +1649,7 @@ def weight_grad_blocks(g2, x2, has_bias, blocks, deferrable=True):
     without an open parameter-gradient batch the product is formed on the spot and copied."""
     M, N = g2.shape
     K = x2.size(1)
-    if _SLABS.active and deferrable and GROUPED_WGRAD:
+    if _SLABS.active and deferrable:
         splits = _SPLITS.get((M, N, K))
         if splits is None:
             splits = _SPLITS[(M, N, K)] = int(_lib.load().msde_linear_bwd_w_splits(M, N, K))
@@ -2381,12 +2357,8 @@ def _transpose_into(entries):
     for i, blk in enumerate(blocks):
         src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode = blk[:7]
         tab[i, 0], tab[i, 1], tab[i, 2], tab[i, 3], tab[i, 4], tab[i, 5], tab[i, 6] = src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode
-        if len(blk) > 7:        # modes 2 / 3: plane stride of the three bf16 planes (elements)
-            tab[i, 7] = blk[7]
         pre[i] = total
-        # (tiles of a block: 32 x 32 source elements; the split modes take 32 x 64 / 64 x 32 -- whole 128-byte lines)
-        total += (((r + 31) // 32) * ((c + 63) // 64) if mode == 2 else ((r + 63) // 64) * ((c + 31) // 32) if mode == 3
-                  else ((r + 31) // 32) * ((c + 31) // 32))
+        total += ((r + 31) // 32) * ((c + 31) // 32)          # tiles of a block: 32 x 32 source elements
     pre[n] = total
     return tab, pre, total, dev
 
@@ -2394,11 +2366,7 @@ def _transpose_into(entries):
 def _fill_entry(ent):
     for blk in ent["blocks"]:
         src_ptr, dst_ptr, r, c, src_ld, dst_ld, mode = blk[:7]
-        if mode >= 2:
-            _lib.call("msde_relayout_split", ctypes.c_void_p(src_ptr), src_ld, ctypes.c_void_p(dst_ptr), dst_ld, r, c, mode - 2,
-                      blk[7], _stream())
-        else:
-            _lib.call("msde_relayout", ctypes.c_void_p(src_ptr), src_ld, ctypes.c_void_p(dst_ptr), dst_ld, r, c, mode, _stream())
+        _lib.call("msde_relayout", ctypes.c_void_p(src_ptr), src_ld, ctypes.c_void_p(dst_ptr), dst_ld, r, c, mode, _stream())
 
 
 def _clear_tables():
@@ -2458,22 +2426,6 @@ def weight_t(w):
         wt = torch.empty(w.size(1), w.size(0), dtype=torch.float32, device=w.device)
         return wt, [(w.data_ptr(), wt.data_ptr(), int(w.size(0)), int(w.size(1)), int(w.size(1)), int(w.size(0)), 0)]
     return _cached_layout(key, src, make)
-
-
-def weight_planes(w, transposed):
-    """EXPERIMENT (MSDE_BF16X3, csrc/gemm_t2b.hip): the 2-D fp32 parameter w [N][K] -- or its transpose when `transposed` --
-    split into three bf16 planes [3][rows][ld] (ld = the row length rounded up to 64, zero beyond it), hi + mid + lo = w
-    exactly.  Cached and refreshed like weight_t.  Returns (int16 buffer, ld)."""
-    assert isinstance(w, torch.nn.Parameter) and w.dim() == 2 and w.is_contiguous()
-    rows, cols = (int(w.size(1)), int(w.size(0))) if transposed else (int(w.size(0)), int(w.size(1)))
-    ld = (cols + 63) // 64 * 64           # 128-byte rows: a line of the planes is written by one workgroup of the refresh
-    key = ("bf16x3", bool(transposed), id(w), rows, cols, w.data_ptr())
-
-    def make():
-        buf = torch.zeros(3, rows, ld, dtype=torch.int16, device=w.device)
-        return buf, [(w.data_ptr(), buf.data_ptr(), int(w.size(0)), int(w.size(1)), int(w.size(1)), ld, 3 if transposed else 2,
-                      rows * ld)]
-    return _cached_layout(key, (w,), make), ld
 
 
 def weight_layout(tag, params, shape, blocks):
@@ -2579,12 +2531,11 @@ def sync_weight_copies():
     return False
 
 
-_T2_MODE = _os.environ.get("MSDE_T2", "1")     # "0": every node-level product on the row strips (A/B measurements)
+_T2_MODE = "1"     # "0" (tests, measurements): every node-level product on the row strips
 _T2_OK = {}
-# EXPERIMENT, never the default and never the headline (bench.py reports it under its own key): the plain node-level
-# products (gemm_fwd / gemm_dgrad on parameters) with both operands split into three bf16 terms (csrc/gemm_t2b.hip).
-_BF16X3 = _os.environ.get("MSDE_BF16X3", "0") == "1"
-_BF16X3_PARTS = set(_os.environ.get("MSDE_BF16X3_PARTS", "fwd,dgrad,node").split(","))     # (bisection of the experiment)
+# (Round 4's bf16x3 experiment -- both fp32 operands split into three bf16 terms, six products on v_mfma_f32_16x16x32_bf16 --
+# is out of the tree: 2.63 vs 2.71 ms two-stream, and kernels co-resident with it were not reproducible; numbers and the
+# bisection in DESIGN.md section 5.000.)
 
 
 def t2_ok(M, N, K, axf=None):
@@ -2630,17 +2581,13 @@ def gemm_node(A, W, out, forward, N, K, **kw):
     # so that rs_geometry and every product of the chain agree on the strips)
     fused = kw.get("stats") is not None or kw.get("axf") is not None
     if t2_ok(M, N, K, "bnbwd" if fused else None):
-        if (_BF16X3 and "node" in _BF16X3_PARTS and kw.get("axf") is None and kw.get("A_out") is None
-                and isinstance(W, torch.nn.Parameter)):
-            planes, ld = weight_planes(W, not forward)      # (same strips of statistics partials as the fp32 tiles)
-            return gemm_rs(A, planes, out, N=N, K=K, t2b_ld=ld, **kw)
         return gemm_rs(A, W if forward else weight_t(W), out, N=N, K=K, t2=True, **kw)
     return gemm_rs(A, weight_t(W) if forward else W, out, b_kmajor=True, N=N, K=K, fallback=False, **kw)
 
 
 def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_kmajor=False, accumulate=False,
             axf=None, xf=(), relu=False, A2=None, A_out=None, stats=None, stats_mode=None, stats_z=None,
-            stats_mean=None, m_valid=None, N=None, K=None, rt=0, splits=0, fallback=True, t2=False, t2b_ld=0):
+            stats_mean=None, m_valid=None, N=None, K=None, rt=0, splits=0, fallback=True, t2=False):
     """out[M,N] = epilogue(xf(A) . B(^T) + bias) on msde_gemm_rs (see include/msde_hip.h: msde_rs_desc); no autograd.
     Returns `out`.  Shapes the row-strip kernels do not take (K % 4, unaligned operands) go to msde_gemm_ex when
     `fallback` and no fusion beyond bias / activation / derivative / accumulate is asked for; otherwise raises."""
@@ -2652,8 +2599,6 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
     d.N = int(N)
     d.A, d.lda = A.data_ptr(), _ld(A)
     d.B, d.ldb = B.data_ptr(), (B.stride(0) if B.dim() == 2 else (d.N if b_kmajor else d.K))
-    if t2b_ld:
-        d.ldb = int(t2b_ld)
     d.bias = bias.data_ptr() if bias is not None else None
     d.C, d.ldc = out.data_ptr(), _ld(out)
     if Z is not None:
@@ -2684,9 +2629,6 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
         m_valid = bound_tensor(M)
     d.m_valid = m_valid.data_ptr() if m_valid is not None else None
     d.rt, d.splits = int(rt), int(splits)
-    if t2b_ld:      # EXPERIMENT: the bf16x3 kernel (csrc/gemm_t2b.hip): B = three bf16 planes of the [N][K] operand
-        _lib.check(_lib.load().msde_gemm_t2b(ctypes.byref(d), _stream()), "msde_gemm_t2b")
-        return out
     if t2:          # the 2-D tiled kernel (csrc/gemm_t2.hip): B is the [N][K] operand
         _lib.check(_lib.load().msde_gemm_t2(ctypes.byref(d), _stream()), "msde_gemm_t2")
         return out
@@ -2698,7 +2640,7 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
     return out
 
 
-T2_EDGE_LEVEL = _os.environ.get("MSDE_T2_EDGE", "0") != "0"     # edge-level Linear layers (M > RS_MAX_ROWS) on the 2-D tiles too: measured 2.71 vs 2.69 ms (gemm_ex wins at 35 k x 64..128), off
+# (edge-level Linear layers, M > RS_MAX_ROWS, on the 2-D tiles too: measured 2.71 vs 2.69 ms -- gemm_ex wins at 35 k x 64..128 -- removed)
 RS_MAX_ROWS = 8192     # above this (edge-level operands) msde_gemm_ex's 64 x 64 tiles are faster than 16-row strips (tools/bench_gemm_rs.py)
 
 
@@ -2707,12 +2649,8 @@ def gemm_fwd(x, W, out, bias=None, act=None, Z=None, res=None):
     W for node-level operands, msde_gemm_ex otherwise.  No autograd."""
     M, K = x.shape
     N = W.size(0)
-    big_t2 = T2_EDGE_LEVEL and M > RS_MAX_ROWS and t2_ok(M, N, K)       # edge-level operands: 2-D tiles have no row limit
-    if (0 < M <= RS_MAX_ROWS or big_t2) and rs_forward_ok(M, N, K, W) and x.data_ptr() % 16 == 0 and _ld(x) % 4 == 0:
+    if 0 < M <= RS_MAX_ROWS and rs_forward_ok(M, N, K, W) and x.data_ptr() % 16 == 0 and _ld(x) % 4 == 0:
         if t2_ok(M, N, K):        # 2-D tiles read the weight k-contiguous: as stored
-            if _BF16X3 and "fwd" in _BF16X3_PARTS and isinstance(W, torch.nn.Parameter):
-                planes, ld = weight_planes(W, False)
-                return gemm_rs(x, planes, out, bias=bias, act=act, Z=Z, res=res, N=N, K=K, t2b_ld=ld)
             return gemm_rs(x, W, out, bias=bias, act=act, Z=Z, res=res, N=N, K=K, t2=True)
         return gemm_rs(x, weight_t(W), out, bias=bias, act=act, Z=Z, res=res, b_kmajor=True, N=N, K=K, fallback=False)
     if res is not None:
@@ -2724,13 +2662,9 @@ def gemm_dgrad(g, W, out, act=None, dact_from=None, res=None):
     """out = (g W) * act'(dact_from) (+ res) for an nn.Linear weight W [N][K] and g [M][N]: the input gradient."""
     M, N = g.shape
     K = W.size(1)
-    big_t2 = T2_EDGE_LEVEL and M > RS_MAX_ROWS and t2_ok(M, K, N)
-    if ((0 < M <= RS_MAX_ROWS or big_t2) and N % 4 == 0 and K % 4 == 0 and W.is_contiguous() and g.data_ptr() % 16 == 0
+    if (0 < M <= RS_MAX_ROWS and N % 4 == 0 and K % 4 == 0 and W.is_contiguous() and g.data_ptr() % 16 == 0
             and _ld(g) % 4 == 0):
         if t2_ok(M, K, N):        # ... for an input gradient that is the transposed copy [K][N]
-            if _BF16X3 and "dgrad" in _BF16X3_PARTS and isinstance(W, torch.nn.Parameter):
-                planes, ld = weight_planes(W, True)
-                return gemm_rs(g, planes, out, act=act, dact_from=dact_from, res=res, N=K, K=N, t2b_ld=ld)
             return gemm_rs(g, weight_t(W), out, act=act, dact_from=dact_from, res=res, N=K, K=N, t2=True)
         return gemm_rs(g, W, out, act=act, dact_from=dact_from, res=res, b_kmajor=True, N=K, K=N, fallback=False)
     if act == "sspo":
@@ -2810,14 +2744,10 @@ class _GinMlpBN(torch.autograd.Function):
         st = _stream()
         # BatchNorm 2 backward: partial sums of the incoming gradient (gated by the output ReLU), finished, and the input
         # gradient formed while the next product loads its A strip
-        if ctx.link is not None and ctx.link.stats is not None:
-            stb, ctx.link.stats = ctx.link.stats, None      # left by the next layer's aggregation backward
-            sb = stb.size(0)
-        else:
-            sb = (M + 63) // 64
-            stb = torch.empty(sb, 2, D, dtype=torch.float32, device=dev)
-            _lib.call("msde_bn_bwd_colstats", _p(g), _p(z2), _p(h if ctx.relu_out else None), _p(v2[2]), M,
-                      _p(bound_tensor(M)), D, _p(stb), st)
+        sb = (M + 63) // 64
+        stb = torch.empty(sb, 2, D, dtype=torch.float32, device=dev)
+        _lib.call("msde_bn_bwd_colstats", _p(g), _p(z2), _p(h if ctx.relu_out else None), _p(v2[2]), M,
+                  _p(bound_tensor(M)), D, _p(stb), st)
         pw2, gb2 = _bn_fin_bwd(stb, sb, M, D, g2, v2[2], v2[3])
         # g_a1 = dz2 W2, gated by the ReLU behind BatchNorm 1 (a1 > 0), with BatchNorm 1's partial sums
         sa, _ = rs_geometry(M, H, D)
@@ -2978,136 +2908,6 @@ class _SchNetTail(torch.autograd.Function):
 
 def schnet_tail(agg, h, lin2, lin):
     return _SchNetTail.apply(agg, h, lin2.weight, lin2.bias, lin.weight, lin.bias)
-
-
-def gemm_chain(A, stages):
-    """msde_gemm_chain (include/msde_hip.h): stages = [dict(W=[K][N] operand, N, K, out, bias=, act=, dact_from=, res=)];
-    stage s consumes the previous stage's result strip from LDS.  No autograd; raises where the kernel does not apply."""
-    d = _lib.ChainDesc()
-    d.A, d.lda, d.M, d.nstages = A.data_ptr(), _ld(A), A.size(0), len(stages)
-    for i, s in enumerate(stages):
-        q = d.st[i]
-        W = s["W"]
-        q.W, q.ldw, q.N, q.K = W.data_ptr(), W.stride(0), int(s["N"]), int(s["K"])
-        b = s.get("bias")
-        q.bias = b.data_ptr() if b is not None else None
-        q.out, q.ldout = s["out"].data_ptr(), _ld(s["out"])
-        q.act, q.epi = _lib.ACT[s.get("act")], _lib.EPI_ACT
-        r = s.get("dact_from")
-        if r is not None:
-            q.epi, q.dact, q.lddact = _lib.EPI_DACT, r.data_ptr(), _ld(r)
-        r = s.get("res")
-        if r is not None:
-            q.res, q.ldres = r.data_ptr(), _ld(r)
-    _lib.check(_lib.load().msde_gemm_chain(ctypes.byref(d), _stream()), "msde_gemm_chain")
-
-
-def chain_ok(M, dims):
-    """Layer widths msde_gemm_chain takes (dims[0] = input width)."""
-    return M > 0 and dims[0] <= 768 and all(x % 4 == 0 for x in dims) and all(x <= 320 for x in dims[1:])
-
-
-class _SchNetNodeChain(torch.autograd.Function):
-    """(h', x1') = (h + lin(ssp(lin2(agg))), lin1'(h')): the node-level tail of one SchNet interaction and the NEXT
-    interaction's CFConv.lin1 (schnet.py:163-167,97,189 and :160) as ONE chained-product launch -- the 16-row strip stays
-    in LDS between the three layers.  Backward: one launch again: g_h = g_x1' W1' + g_h' (the residual branch),
-    g_x = (g_h Wl) * ssp'(a), g_agg = g_x W2; the three weight gradients are queued."""
-
-    @staticmethod
-    def forward(ctx, agg, h, W2, b2, Wl, bl, Wn):
-        agg, h = _f32(agg), _f32(h)
-        M, F = agg.shape
-        Hd, Fn = W2.size(0), Wn.size(0)
-        dev = agg.device
-        a = torch.empty(M, Hd, dtype=torch.float32, device=dev)
-        hn = torch.empty(M, Hd, dtype=torch.float32, device=dev)
-        x1 = torch.empty(M, Fn, dtype=torch.float32, device=dev)
-        gemm_chain(agg, [dict(W=weight_t(W2), N=Hd, K=F, bias=b2, act="ssp", out=a),
-                         dict(W=weight_t(Wl), N=Hd, K=Hd, bias=bl, res=h, out=hn),
-                         dict(W=weight_t(Wn), N=Fn, K=Hd, out=x1)])
-        ctx.save_for_backward(agg, a, hn, W2, Wl, Wn)
-        ctx.deferrable = all(t.is_leaf for t in (W2, b2, Wl, bl, Wn))
-        return hn, x1
-
-    @staticmethod
-    def backward(ctx, g_hn, g_x1):
-        agg, a, hn, W2, Wl, Wn = ctx.saved_tensors
-        M, F = agg.shape
-        Hd = W2.size(0)
-        dev = agg.device
-        stages = []
-        if g_x1 is not None:
-            g_x1 = _f32(g_x1)
-            g_h = torch.empty(M, Hd, dtype=torch.float32, device=dev)
-            stages.append(dict(W=Wn, N=Hd, K=Wn.size(0), res=(_f32(g_hn) if g_hn is not None else None), out=g_h))
-            first = g_x1
-        else:
-            g_h = _f32(g_hn)
-            first = g_h
-        gx = torch.empty(M, Hd, dtype=torch.float32, device=dev)
-        stages.append(dict(W=Wl, N=Hd, K=Hd, act="sspo", dact_from=a, out=gx))
-        g_agg = torch.empty(M, F, dtype=torch.float32, device=dev)
-        stages.append(dict(W=W2, N=F, K=Hd, out=g_agg))
-        gemm_chain(first, stages)
-        gWn = weight_grad(g_x1, hn, False, ctx.deferrable)[0] if g_x1 is not None else None
-        gWl, gbl = weight_grad(g_h, a, True, ctx.deferrable)
-        gW2, gb2 = weight_grad(gx, agg, True, ctx.deferrable)
-        return g_agg, g_h, gW2, gb2, gWl, gbl, gWn
-
-
-class _SchNetHeadChain(torch.autograd.Function):
-    """lin2_h(ssp(lin1_h(h + lin(ssp(lin2(agg)))))): the last interaction's node-level tail and SchNet's output head
-    (schnet.py:163-167,97,189,118-120) as one chained-product launch of four layers; one launch in the backward."""
-
-    @staticmethod
-    def forward(ctx, agg, h, W2, b2, Wl, bl, W1h, b1h, W2h, b2h):
-        agg, h = _f32(agg), _f32(h)
-        M, F = agg.shape
-        Hd = W2.size(0)
-        dev = agg.device
-        a, h6, hh, out = (torch.empty(M, n, dtype=torch.float32, device=dev) for n in (Hd, Hd, W1h.size(0), W2h.size(0)))
-        gemm_chain(agg, [dict(W=weight_t(W2), N=Hd, K=F, bias=b2, act="ssp", out=a),
-                         dict(W=weight_t(Wl), N=Hd, K=Hd, bias=bl, res=h, out=h6),
-                         dict(W=weight_t(W1h), N=W1h.size(0), K=Hd, bias=b1h, act="ssp", out=hh),
-                         dict(W=weight_t(W2h), N=W2h.size(0), K=W1h.size(0), bias=b2h, out=out)])
-        ctx.save_for_backward(agg, a, h6, hh, W2, Wl, W1h, W2h)
-        ctx.deferrable = all(t.is_leaf for t in (W2, b2, Wl, bl, W1h, b1h, W2h, b2h))
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        agg, a, h6, hh, W2, Wl, W1h, W2h = ctx.saved_tensors
-        g = _f32(g)
-        M, F = agg.shape
-        Hd = W2.size(0)
-        dev = agg.device
-        g_zh = torch.empty(M, W1h.size(0), dtype=torch.float32, device=dev)
-        g_h = torch.empty(M, Hd, dtype=torch.float32, device=dev)
-        gx = torch.empty(M, Hd, dtype=torch.float32, device=dev)
-        g_agg = torch.empty(M, F, dtype=torch.float32, device=dev)
-        gemm_chain(g, [dict(W=W2h, N=W2h.size(1), K=W2h.size(0), act="sspo", dact_from=hh, out=g_zh),
-                       dict(W=W1h, N=Hd, K=W1h.size(0), out=g_h),
-                       dict(W=Wl, N=Hd, K=Hd, act="sspo", dact_from=a, out=gx),
-                       dict(W=W2, N=F, K=Hd, out=g_agg)])
-        gW2h, gb2h = weight_grad(g, hh, True, ctx.deferrable)
-        gW1h, gb1h = weight_grad(g_zh, h6, True, ctx.deferrable)
-        gWl, gbl = weight_grad(g_h, a, True, ctx.deferrable)
-        gW2, gb2 = weight_grad(gx, agg, True, ctx.deferrable)
-        return g_agg, g_h, gW2, gb2, gWl, gbl, gW1h, gb1h, gW2h, gb2h
-
-
-def schnet_node_chain(agg, h, lin2, lin, next_lin1):
-    """(h + lin(ssp(lin2(agg))), next_lin1 of that) -- see _SchNetNodeChain."""
-    return _SchNetNodeChain.apply(agg, h, lin2.weight, lin2.bias, lin.weight, lin.bias, next_lin1.weight)
-
-
-def schnet_head_chain(agg, h, lin2, lin, head1, head2):
-    return _SchNetHeadChain.apply(agg, h, lin2.weight, lin2.bias, lin.weight, lin.bias, head1.weight, head1.bias,
-                                  head2.weight, head2.bias)
-
-
-# ---- diagnostics: device timestamps in stream order (tools/probes/step_timeline.py) ---------------------------
-STAMPS = None            # {"buf": int64[256] device tensor, "names": [..]} when enabled
 
 
 def enable_stamps(device):

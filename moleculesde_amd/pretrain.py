@@ -89,20 +89,14 @@ def readme_args(**over):
 
 
 USE_FUSED_CL = True
-SIDE_CFCONV_FWD_WGS = int(os.environ.get("MSDE_SIDE_CFFWD_WGS", "512"))   # CFConv kernels beside the main chain.  Round 3 (pair kernels; one box, 300-step runs, BWD = 160): 128: 2.825, 192: 2.803, 256: 2.766, 512: 2.736, 768: 2.740, 1024: 2.750 ms
-SIDE_CFCONV_BWD_WGS = int(os.environ.get("MSDE_SIDE_CFBWD_WGS", "176"))   # 256 = full width.  Round 3 (FWD = 256): 128: 2.768, 160: 2.757, 192: 2.755, 256: 2.783 ms -- the dominant kernel is now the row-strip GEMM of the MAIN chain, which gains what this kernel gives up.  Round 2:  tools/ab.sh at the end of round 2, headline ms/step: 96: 3.13, 128: 3.065, 160: 3.04, 192: 3.065, 256: 3.085 -- at 160 the step is 1.4 % faster, but the kernel then occupies 62 % of the CUs: 89 us in the step = 0.32 of the chip's fp32 peak instead of 67 us = 0.43; --full: no difference
-EARLY_WGRAD_FLUSH = os.environ.get("MSDE_EARLY_WGRAD_FLUSH", "0") != "0"   # measured 1.4 % slower: off
-GEOMETRY_ON_SIDE = os.environ.get("MSDE_GEOMETRY_ON_SIDE", "1") != "0"   # coordinate-only branch of the 2D->3D model at the head of the second stream.  Round 2 (SchNet the longer chain): 3.187 vs 3.151 ms, off; round 3 (pair CFConv: SchNet is the SHORTER chain): 2.86 vs 2.98 ms, on (alternating A/B with tools/ab.sh)
-EARLY_SLAB_REDUCE = os.environ.get("MSDE_EARLY_SLAB_REDUCE", "1") != "0"
-CL_ON_SIDE = os.environ.get("MSDE_CL_ON_SIDE", "0") != "0"   # contrastive loss on the second stream behind SchNet (it idles there while the 2D->3D model runs): measured 2.83 vs 2.80 ms (its backward then sits in front of SchNet's on that stream), off
-SIDE_WGRAD = os.environ.get("MSDE_SIDE_WGRAD", "0") != "0"   # second stream's weight gradients flushed on it, behind its backward: measured 2.865 vs 2.82 ms (tools/ab.sh: the GIN backward slows by more than the tail gains), off
-SIDE_WGRAD_WGS = int(os.environ.get("MSDE_SIDE_WGRAD_WGS", "0"))   # 0: full width
-SCHNET_AFTER_GIN = os.environ.get("MSDE_SCHNET_AFTER_GIN", "0") != "0"   # experiment: start SchNet when GIN's forward is done
-PLAN_LISTS_ON_SIDE = os.environ.get("MSDE_PLAN_LISTS_ON_SIDE", "1") != "0"   # bucket mode: embedding row lists off the main chain
-LEAF_SERIAL = os.environ.get("MSDE_LEAF_SERIAL", "0") != "0"   # (measurement, round 4) leaf kernels in front of the grouped launch on the same stream: 2.75 vs 2.72 ms; on a high-priority third stream: 6.2 ms
-BATCH_SLAB_REDUCE = os.environ.get("MSDE_BATCH_SLAB_REDUCE", "1") != "0"   # one reduction launch per backward pass
-GEOMETRY_STREAM = os.environ.get("MSDE_GEOMETRY_STREAM", "0") != "0"   # third stream for the coordinate branch
-EARLY_GEOMETRY = os.environ.get("MSDE_EARLY_GEO", "0") != "0"   # start the 2D->3D coordinate branch before the encoders (measured: 2% slower at bs256, so off)
+# Stream layout of the step, fixed by alternating A/B runs on one box (numbers: DESIGN.md rounds 2-4).  What lost is gone from
+# the code: weight gradients flushed early or on the second stream, the contrastive loss on the second stream, SchNet started
+# behind GIN, a third stream for the coordinate branch, leaf kernels in front of the grouped launch.
+SIDE_CFCONV_FWD_WGS = 512     # SchNet's CFConv kernels beside the main chain: forward 128: 2.825 ... 512: 2.736, 1024: 2.750 ms
+SIDE_CFCONV_BWD_WGS = 176     # weight gradient 128: 2.768, 160: 2.757, 192: 2.755, 256 (full width): 2.783 ms
+GEOMETRY_ON_SIDE = True       # coordinate-only branch of the 2D->3D model at the head of the second stream (2.86 vs 2.98 ms)
+EARLY_SLAB_REDUCE = True      # the second stream sums the CFConv slabs it wrote, in the shadow of the GIN backward
+PLAN_LISTS_ON_SIDE = True     # bucket mode: embedding row lists off the main chain
 
 _SDE_RANGES_2D3D = {"VE": ("VE", 0.2, 1.0), "VP": ("VP", 0.2, 1.0), "VE02": ("VE", 0.1, 10.0), "VP02": ("VP", 0.2, 30.0),
                     "VE03": ("VE", 0.1, 1000.0), "VP03": ("VP", 0.2, 1000.0)}
@@ -199,7 +193,7 @@ def dual_CL(X, Y, args, noise, neg_indices=(None, None)):
 class Trainer:
     """One object per rank: models, flat Adam, the step function of pretrain_MoleculeSDE.py:125-156."""
 
-    def __init__(self, args, device, noise=None):
+    def __init__(self, args, device, noise=None, overlap_streams=True):
         self.args, self.device = args, device
         self.models = build_models(args, device)
         self.opt = make_optimizer(args, self.models)
@@ -209,7 +203,7 @@ class Trainer:
         # the data.  (Parameters are already broadcast, so reseeding torch here does not desynchronise them.)
         r = dp.rank()
         self.dp_enabled = True            # False: ignore the process group (single-replica reference runs in DP tests)
-        self.dp_buckets = int(os.environ.get("MSDE_DP_BUCKETS", "1")) != 0
+        self.dp_buckets = True            # per-model all-reduce buckets, each followed by its Adam (False: one flat all-reduce)
         if r:
             torch.manual_seed(torch.initial_seed() + 7919 * r)
         self.noise = noise or _nn.DeviceNoise(seed=0x5EED + 7919 * r)
@@ -225,34 +219,17 @@ class Trainer:
             m.train()
         # hipGraph mode: one captured graph per batch shape (forward + backward + gradient flattening
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
-        self.overlap_streams = True
-        from . import hip as _hipx
-        if os.environ.get("MSDE_ONE_STREAM") == "1":      # (measurements: the single-stream step)
-            self.overlap_streams = False
-        if _hipx._BF16X3 and os.environ.get("MSDE_BF16X3_TWO_STREAMS") != "1":
-            # the bf16x3 EXPERIMENT (csrc/gemm_t2b.hip) is reproducible only when no other kernel shares the chip with it:
-            # beside it, kernels of the second stream returned values that differ from replay to replay
-            self.overlap_streams = False
+        self.overlap_streams = overlap_streams      # SchNet (and the coordinate branch) on a second HIP stream
         self._side_stream = torch.cuda.Stream(device=device)
         self._one_grad = torch.ones((), dtype=torch.float32, device=device)
         if self._one_grad.is_cuda:
             from . import hip as _hip0
             _hip0.register_unit_grad(self._one_grad)      # the loss composition's backward needs no launch for it
-        if EARLY_WGRAD_FLUSH:
-            # when the 2D encoder's backward is through, launch the weight gradients queued so far (2D->3D model and
-            # GIN) on the same stream: they run while the second stream still finishes SchNet's backward, and only
-            # SchNet's own weight gradients are left for the tail of the step
-            from . import hip as _hip4
-            wgs = int(os.environ.get("MSDE_EARLY_WGRAD_WGS", "0"))
-            self.models["model_2D"].on_input_grad = (lambda: _hip4.flush_wgrad_gemms(wgs, only_stream=(
-                torch.cuda.current_stream().cuda_stream if os.environ.get("MSDE_EARLY_WGRAD_OWN", "1") != "0" else None)))
         self._bn_modules = [mod for m_ in self.models.values() for mod in m_.modules() if isinstance(mod, _nn.BatchNorm1d)]
         # Measured on MI355X (tools/marginal_cost.py, hipGraph replay, bs 256): 1 stream 5.26 ms, SchNet beside the
         # 2D branch 4.55 ms, a third stream for the 2D->3D coordinate branch 4.73 ms, weight gradients on a fourth
         # 5.4 ms -- the step is a chain of small kernels and every extra queue / cross-stream event costs more
         # dispatch latency than it hides.  Two streams it is.
-        if GEOMETRY_STREAM:
-            self.models["SDE_2Dto3D_model"].side_stream = torch.cuda.Stream(device=device)
         self._graphs = {}
         self.adam_outside_graph = False   # True reproduces the multi-GPU structure (graph; all-reduce; Adam) on 1 GPU
         self._graph_pool = None
@@ -313,15 +290,12 @@ class Trainer:
         negs = (None, None)
         # device noise: the permutation kernel (20 us, read 1.2 ms later by the contrastive loss) runs at the head of the
         # SECOND stream instead of at the head of the main chain; host call order (= the reference's draw order) unchanged
-        negs_on_side = (self.coeff_cl > 0 and self.overlap_streams and not SCHNET_AFTER_GIN
-                        and not getattr(self.noise, "replay", False))
+        negs_on_side = self.coeff_cl > 0 and self.overlap_streams and not getattr(self.noise, "replay", False)
         if self.coeff_cl > 0 and not negs_on_side:
             n = batch.x.size(0)
             negs = self.noise.randperm_pair(n, batch.x.device)
-        if a.SDE_coeff_generative_2Dto3D > 0 and EARLY_GEOMETRY:
-            m["SDE_2Dto3D_model"].begin(batch)
-        elif (a.SDE_coeff_generative_2Dto3D > 0 and GEOMETRY_ON_SIDE and self.overlap_streams and not SCHNET_AFTER_GIN
-              and not head_on_side and not getattr(self.noise, "replay", False)):
+        if (a.SDE_coeff_generative_2Dto3D > 0 and GEOMETRY_ON_SIDE and self.overlap_streams
+                and not head_on_side and not getattr(self.noise, "replay", False)):
             # (with the 3D->2D head behind SchNet the second stream is the longer one: 3.92 vs 4.03 ms without / with)
             # the coordinate-only branch of the 2D->3D model (noise, perturbation, frame / Fourier features, their MLPs:
             # ~10 launches forward, as many backward) depends on nothing the main chain computes: it runs at the head
@@ -348,37 +322,19 @@ class Trainer:
                 if stamps:
                     rep.register_hook(lambda g: _hip.stamp("schnet_bwd_start"))
                 return rep, (head_32(rep) if head_on_side else None), ng
-        if self.overlap_streams and not SCHNET_AFTER_GIN:
+        if self.overlap_streams:
             node_3D_repr, l32, ng = schnet_on_side()
             if ng is not None:
                 negs = ng
                 for t in negs:
                     if t is not None:
                         t.record_stream(main)
-        elif not self.overlap_streams:
+        else:
             _, node_3D_repr = self._encode_3d(batch)
         node_2D_repr = m["model_2D"](batch.x, batch.edge_index, batch.edge_attr)
         _hip.stamp("gin_fwd_end")
-        if self.overlap_streams and SCHNET_AFTER_GIN:
-            node_3D_repr, l32, _ = schnet_on_side()      # SchNet beside the 2D->3D model instead of beside GIN
         if stamps:
             node_2D_repr.register_hook(lambda g: _hip.stamp("gin_bwd_start"))
-        cl_done = None
-        if (CL_ON_SIDE and self.coeff_cl > 0 and self.overlap_streams and not SCHNET_AFTER_GIN and not head_on_side
-                and a.SDE_coeff_generative_2Dto3D > 0 and node_2D_repr.is_cuda):
-            # both encoders are done (SchNet first): the contrastive loss -- 2 launches forward, 1 backward -- runs on the second
-            # stream, which idles while the 2D->3D model works on the main one, instead of between that model's forward and
-            # backward where nothing else can run.  Joined by event: GIN's output must be complete, nothing later.
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side = self._side_stream
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                node_2D_repr.record_stream(side)
-                for t in negs:
-                    if t is not None:
-                        t.record_stream(side)
-                cl_done = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
         if a.SDE_coeff_generative_2Dto3D > 0:
             l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
             terms.append(l23); coeffs.append(a.SDE_coeff_generative_2Dto3D)
@@ -393,12 +349,7 @@ class Trainer:
                 l32[0].record_stream(main)
                 l32[1].record_stream(main)
         if self.coeff_cl > 0:
-            if cl_done is not None:
-                cl, acc = cl_done
-                cl.record_stream(main)
-                acc.record_stream(main)
-            else:
-                cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
+            cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
             terms.append(cl); coeffs.append(self.coeff_cl)
             parts["CL"], parts["CL_acc"] = cl.detach(), acc
         if want_32:
@@ -434,9 +385,6 @@ class Trainer:
         from . import hip
         try:
             one = self._one_grad if loss.is_cuda else None     # preallocated d(loss)/d(loss): no fill launch per step
-            if not BATCH_SLAB_REDUCE:
-                loss.backward(one)
-                return
             hip.begin_param_grad_batch(self.opt.params)
             try:
                 hip.stamp("bwd_start")
@@ -449,28 +397,16 @@ class Trainer:
                         early = hip.reduce_written_slabs()
                     if early:
                         torch.cuda.current_stream().wait_stream(self._side_stream)
-                if self.overlap_streams and SIDE_WGRAD:
-                    # the second stream's own weight gradients (SchNet, the coordinate branch of the 2D->3D model) as a grouped
-                    # launch ON that stream, right behind its backward: it finishes its chain earlier than the main stream
-                    # (round 3: pair CFConv), so these products run beside the GIN backward instead of at the tail
-                    with torch.cuda.stream(self._side_stream):
-                        hip.flush_wgrad_gemms(SIDE_WGRAD_WGS, only_stream=self._side_stream.cuda_stream)
-                    if not hip.have_deferred_leaf_kernels():
-                        torch.cuda.current_stream().wait_stream(self._side_stream)     # (joined below otherwise)
                 if self.overlap_streams and hip.have_deferred_leaf_kernels():
                     # leaf-only kernels of the backward pass (GIN bond-table gradients: 5 x 17 us that nothing downstream
                     # reads) run on the second stream BESIDE the grouped weight-gradient launch instead of inside the
                     # backward chain.  Host order: everything of SchNet's backward is already queued on that stream.
                     main_, side_ = torch.cuda.current_stream(), self._side_stream
-                    if LEAF_SERIAL:
+                    side_.wait_stream(main_)
+                    with torch.cuda.stream(side_):
                         hip.run_deferred_leaf_kernels()
-                        hip.flush_wgrad_gemms()
-                    else:
-                        side_.wait_stream(main_)
-                        with torch.cuda.stream(side_):
-                            hip.run_deferred_leaf_kernels()
-                        hip.flush_wgrad_gemms()
-                        main_.wait_stream(side_)
+                    hip.flush_wgrad_gemms()
+                    main_.wait_stream(side_)
                 if hip.STAMPS is not None and self.overlap_streams:
                     with torch.cuda.stream(self._side_stream):
                         hip.stamp("bwd_side_end")

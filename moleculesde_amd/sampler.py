@@ -8,7 +8,7 @@ import torch
 from . import _lib
 from . import hip as _hip_mod
 
-FUSED_PC = os.environ.get("MSDE_FUSED_PC", "1") != "0"     # sampler arithmetic on msde_pc_corrector / msde_pc_predictor
+FUSED_PC = True     # sampler arithmetic on msde_pc_corrector / msde_pc_predictor (False: operator by operator, the reference path of the tests)
 
 
 def predictor_update(sde, score_model, representation, data, pos, t, noise=None):

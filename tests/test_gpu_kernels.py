@@ -1321,51 +1321,6 @@ def test_gemm_t2_plain(dev, M, N, K):
         assert torch.equal(out, out2), "gemm_t2 must be bitwise reproducible"
 
 
-@pytest.mark.parametrize("M,N,K", [(3588, 300, 300), (3588, 600, 300), (3588, 300, 600), (3588, 128, 300), (3588, 32, 300),
-                                   (3588, 728, 364), (3588, 728, 728), (35186, 32, 300), (777, 80, 64), (512, 176, 36),
-                                   (1030, 36, 4), (3588, 304, 16), (3588, 256, 100)])
-def test_gemm_t2b_bf16x3_experiment(dev, M, N, K):
-    """The bf16x3 EXPERIMENT (csrc/gemm_t2b.hip, off unless MSDE_BF16X3=1): the three bf16 planes of a weight sum to it bit
-    for bit (copy and transpose modes), and the six-term product on the bf16 matrix pipe meets the SAME tolerances against
-    fp64 as the fp32 kernel (test_gemm_t2_plain), every split count, NaN-filled outputs, reproducible."""
-    from moleculesde_amd import hip
-    g = torch.Generator().manual_seed(M * 5 + N + K)
-    A = torch.randn(M, K, generator=g).to(dev)
-    W = torch.nn.Parameter((torch.randn(N, K, generator=g) / K ** 0.5).to(dev))
-    b = torch.randn(N, generator=g).to(dev)
-    res = torch.randn(M, N, generator=g).to(dev)
-    planes, ld = hip.weight_planes(W, False)
-    assert ld % 64 == 0 and ld >= K and tuple(planes.shape) == (3, N, ld)
-    as_f32 = (planes.to(torch.int32) << 16).view(torch.float32)
-    assert torch.equal(as_f32.sum(0)[:, :K], W.detach()), "hi + mid + lo must be the weight exactly"
-    assert not as_f32[:, :, K:].any()
-    pt, ldt = hip.weight_planes(W, True)
-    tf32 = (pt.to(torch.int32) << 16).view(torch.float32)
-    assert torch.equal(tf32.sum(0)[:, :N], W.detach().t())
-    zr = A.double() @ W.detach().double().t() + b.double()
-    ref = _act_ref("ssp")(zr) + res.double()
-    for splits in (0, 1, 3):
-        if splits > (N + 15) // 16:
-            continue
-        out = torch.full((M, N), float("nan"), device=dev)
-        Z = torch.full((M, N), float("nan"), device=dev)
-        hip.gemm_rs(A, planes, out, bias=b, act="ssp", Z=Z, res=res, N=N, K=K, t2b_ld=ld, splits=splits)
-        assert_close(Z, zr, 1e-5, 2e-5, f"gemm_t2b pre-activation (splits {splits})")
-        assert_close(out, ref, 1e-5, 2e-5, f"gemm_t2b out (splits {splits})")
-        out2 = torch.full((M, N), float("nan"), device=dev)
-        hip.gemm_rs(A, planes, out2, bias=b, act="ssp", res=res, N=N, K=K, t2b_ld=ld, splits=splits)
-        assert torch.equal(out, out2), "gemm_t2b must be bitwise reproducible"
-    # and it is no worse than the fp32 kernel: errors of both against fp64
-    if hip.t2_ok(M, N, K):
-        o32 = torch.empty(M, N, device=dev)
-        o3 = torch.empty(M, N, device=dev)
-        hip.gemm_rs(A, W.detach(), o32, bias=b, N=N, K=K, t2=True)
-        hip.gemm_rs(A, planes, o3, bias=b, N=N, K=K, t2b_ld=ld)
-        e32 = (o32.double() - zr).abs().max().item()
-        e3 = (o3.double() - zr).abs().max().item()
-        assert e3 <= 4 * e32 + 1e-7, (e3, e32)
-
-
 @pytest.mark.parametrize("act", [None, "silu", "ssp", "relu", "tanh"])
 def test_gemm_rs_epilogues(dev, act):
     """Residual + accumulate into a column block of a wider buffer, and the input-gradient product through an activation
@@ -1398,57 +1353,6 @@ def test_gemm_rs_epilogues(dev, act):
     gpre = torch.empty(M, 64, device=dev)
     hip.gemm_rs(gO, Wb, gpre, b_kmajor=True, act=act, dact_from=saved if act else None, res=r2, fallback=False)
     assert_close(gpre, gpre_ref.double() + r2.double(), 1e-4, 1e-5, f"rs dact {act}")
-
-
-@pytest.mark.parametrize("M,F,Hd", [(3588, 128, 300), (1, 128, 300), (531, 16, 16), (40, 64, 320), (777, 128, 36)])
-def test_gemm_chain_schnet_node_layers(dev, M, F, Hd):
-    """msde_gemm_chain on SchNet's node-level chains: (h', x1') = (h + lin(ssp(lin2(agg))), lin1'(h')) and the four-layer
-    form with the output head, forward values and every gradient (inputs, weights, biases) against torch autograd in fp64
-    of the same fp32 inputs."""
-    from moleculesde_amd import hip
-    g = torch.Generator().manual_seed(M + Hd)
-    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
-    agg, h = mk(M, F), mk(M, Hd)
-    W2, b2, Wl, bl = mk(Hd, F, sc=F ** -0.5), mk(Hd, sc=0.1), mk(Hd, Hd, sc=Hd ** -0.5), mk(Hd, sc=0.1)
-    Wn = mk(F, Hd, sc=Hd ** -0.5)
-    W1h, b1h, W2h, b2h = mk(Hd, Hd, sc=Hd ** -0.5), mk(Hd, sc=0.1), mk(Hd, Hd, sc=Hd ** -0.5), mk(Hd, sc=0.1)
-    g_hn, g_x1, g_out = mk(M, Hd), mk(M, F), mk(M, Hd)
-    ssp = lambda t: torch.nn.functional.softplus(t) - math.log(2.0)
-
-    def leaves(ts, dt, d):
-        return [t.to(d, dt).clone().requires_grad_(True) for t in ts]
-
-    # three layers
-    ref = leaves([agg, h, W2, b2, Wl, bl, Wn], torch.float64, "cpu")
-    a_, h_, W2_, b2_, Wl_, bl_, Wn_ = ref
-    hn_ref = h_ + ssp(a_ @ W2_.t() + b2_) @ Wl_.t() + bl_
-    x1_ref = hn_ref @ Wn_.t()
-    gref = torch.autograd.grad([hn_ref, x1_ref], ref, [g_hn.double(), g_x1.double()])
-    got = leaves([agg, h, W2, b2, Wl, bl, Wn], torch.float32, dev)
-    hn, x1 = hip._SchNetNodeChain.apply(*got)
-    assert_close(hn, hn_ref, 2e-5, 2e-5, "chain h'")
-    assert_close(x1, x1_ref, 2e-5, 2e-5, "chain x1'")
-    ggot = torch.autograd.grad([hn, x1], got, [g_hn.to(dev), g_x1.to(dev)])
-    for name, a, b in zip(("agg", "h", "W2", "b2", "Wl", "bl", "Wn"), ggot, gref):
-        assert_close(a, b, 2e-4, 2e-4 * max(1.0, float(b.abs().max())), "chain grad " + name)
-    # only the residual output used (g_x1 is None in the backward)
-    got = leaves([agg, h, W2, b2, Wl, bl, Wn], torch.float32, dev)
-    hn, x1 = hip._SchNetNodeChain.apply(*got)
-    ggot = torch.autograd.grad([hn], got[:6], [g_hn.to(dev)])
-    gref1 = torch.autograd.grad([h_ + ssp(a_ @ W2_.t() + b2_) @ Wl_.t() + bl_], ref[:6], [g_hn.double()])
-    for name, a, b in zip(("agg", "h", "W2", "b2", "Wl", "bl"), ggot, gref1):
-        assert_close(a, b, 2e-4, 2e-4 * max(1.0, float(b.abs().max())), "chain (residual only) grad " + name)
-    # four layers (output head)
-    ref = leaves([agg, h, W2, b2, Wl, bl, W1h, b1h, W2h, b2h], torch.float64, "cpu")
-    a_, h_, W2_, b2_, Wl_, bl_, W1h_, b1h_, W2h_, b2h_ = ref
-    out_ref = ssp((h_ + ssp(a_ @ W2_.t() + b2_) @ Wl_.t() + bl_) @ W1h_.t() + b1h_) @ W2h_.t() + b2h_
-    gref = torch.autograd.grad([out_ref], ref, [g_out.double()])
-    got = leaves([agg, h, W2, b2, Wl, bl, W1h, b1h, W2h, b2h], torch.float32, dev)
-    out = hip._SchNetHeadChain.apply(*got)
-    assert_close(out, out_ref, 3e-5, 3e-5, "head chain out")
-    ggot = torch.autograd.grad([out], got, [g_out.to(dev)])
-    for name, a, b in zip(("agg", "h", "W2", "b2", "Wl", "bl", "W1h", "b1h", "W2h", "b2h"), ggot, gref):
-        assert_close(a, b, 2e-4, 2e-4 * max(1.0, float(b.abs().max())), "head chain grad " + name)
 
 
 @pytest.mark.parametrize("t2", [False, True], ids=["strips", "tiles"])

@@ -1,0 +1,45 @@
+"""Every cross-check constant of the product leaves a correct step: the model / plan parity tests are run once per non-default
+setting.  The constants are module attributes (no environment switches in the product any more); each setting runs in its own
+pytest process with the attribute flipped by the tiny plugin below (tools-only plumbing: SWEEP_SET="module:ATTR=value,...").
+usage: python tools/switch_sweep.py            (on the GPU box)"""
+import importlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SETTINGS = {
+    "nopair": "moleculesde_amd.hip:CFCONV_PAIR=False",
+    "nofusegin": "moleculesde_amd.geom3d.gnn:FUSE_GIN_LAYER=False",
+    "noapply": "moleculesde_amd.geom3d.gnn:FUSE_GIN_APPLY=False",
+    "noframe": "moleculesde_amd.geom3d.sde_2d_to_3d:FUSE_FRAME=False,moleculesde_amd.geom3d.sde_2d_to_3d:FUSE_PAIR_LINEAR=False,"
+               "moleculesde_amd.geom3d.sde_2d_to_3d:NOISE_IN_KERNEL=False",
+    "noedgeemb": "moleculesde_amd.geom3d.sde_2d_to_3d:FUSE_EDGE_EMB=False,moleculesde_amd.geom3d.sde_2d_to_3d:FUSE_HEAD_MIX=False",
+    "nogeoside": "moleculesde_amd.pretrain:GEOMETRY_ON_SIDE=False,moleculesde_amd.pretrain:EARLY_SLAB_REDUCE=False",
+    "strips": "moleculesde_amd.hip:_T2_MODE='0'",
+    "notail": "moleculesde_amd.geom3d.schnet:FUSE_TAIL=False,moleculesde_amd.geom3d.nn:FUSED_MLP=False",
+    "moltrain": "moleculesde_amd.geom3d.sde_2d_to_3d:MOL_KERNEL_TRAIN=True",
+}
+
+
+def pytest_configure(config):          # (loaded as a plugin: -p switch_sweep)
+    for item in filter(None, os.environ.get("SWEEP_SET", "").split(",")):
+        mod, rest = item.split(":")
+        attr, val = rest.split("=")
+        setattr(importlib.import_module(mod), attr, eval(val))
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(SETTINGS)
+    bad = []
+    for n in names:
+        env = dict(os.environ, SWEEP_SET=SETTINGS[n], PYTHONPATH=os.path.join(ROOT, "tools") + os.pathsep + ROOT)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-p", "switch_sweep", os.path.join(ROOT, "tests", "test_gpu_models.py"),
+                            os.path.join(ROOT, "tests", "test_gpu_plan.py"), "-q", "-x", "-m", "gpu"], env=env, cwd=ROOT,
+                           capture_output=True, text=True)
+        tail = (r.stdout.strip().splitlines() or ["?"])[-1]
+        print(f"{n:10s} {SETTINGS[n][:90]:90s} rc={r.returncode} {tail}", flush=True)
+        if r.returncode:
+            bad.append(n)
+            print(r.stdout[-3000:])
+    sys.exit(1 if bad else 0)
