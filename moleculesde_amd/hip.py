@@ -2910,6 +2910,10 @@ def schnet_tail(agg, h, lin2, lin):
     return _SchNetTail.apply(agg, h, lin2.weight, lin2.bias, lin.weight, lin.bias)
 
 
+# ---- diagnostics: device timestamps in stream order (tools/probes/step_timeline.py) ---------------------------
+STAMPS = None            # {"buf": int64[256] device tensor, "names": [..]} when enabled
+
+
 def enable_stamps(device):
     global STAMPS
     STAMPS = {"buf": torch.zeros(256, dtype=torch.int64, device=device), "names": []}
