@@ -285,27 +285,32 @@ bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ X, c
   if (c >= C) return;
   T mu, rs, g, b;
   bn_col_params<V>(mean, rstd, gamma, beta, c, mu, rs, g, b);
-  const float invM = 1.f / (float)msde_true_rows(M, Mdev);      // mean over the valid rows; dX is written for all rows
+  const int Mv = msde_true_rows(M, Mdev);
+  const float invM = 1.f / (float)Mv;      // mean over the valid rows; dX is written for all rows -- ZERO behind the row bound:
+  // a padded row has no loss gradient, but "d - mean(d) - xhat mean(d xhat)" is not zero for d = 0, and what flows on from it
+  // reaches reductions over rows further up (GIN's eps / bond-table gradients): found by test_bucket_step_matches_exact_batch
+  // with the unfused BatchNorm (2 % gradient error in the deep GIN layers)
   T kb, kg, grs = vmul(g, rs);
 #pragma unroll
   for (int k = 0; k < V; ++k) { vref(kb, k) = s_db[tx * V + k] * invM; vref(kg, k) = s_dg[tx * V + k] * invM; }
   const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, M);
-  auto one = [&](T x, T d) -> T {
+  auto one = [&](T x, T d, int row) -> T {
     T h;
     bn_dz_xhat<V>(x, d, mu, rs, g, b, relu, h);
     T o;
+    const float live = row < Mv ? 1.f : 0.f;
 #pragma unroll
-    for (int k = 0; k < V; ++k) vref(o, k) = vget(grs, k) * (vget(d, k) - vget(kb, k) - vget(h, k) * vget(kg, k));
+    for (int k = 0; k < V; ++k) vref(o, k) = live * (vget(grs, k) * (vget(d, k) - vget(kb, k) - vget(h, k) * vget(kg, k)));
     return o;
   };
   int r = r0 + ty;
   for (; r + RL < r1; r += 2 * RL) {
     T x0 = bn_ld<V>(X + (size_t)r * C + c), x1 = bn_ld<V>(X + (size_t)(r + RL) * C + c);
     T d0 = bn_ld<V>(dY + (size_t)r * C + c), d1 = bn_ld<V>(dY + (size_t)(r + RL) * C + c);
-    bn_st<V>(dX + (size_t)r * C + c, one(x0, d0));
-    bn_st<V>(dX + (size_t)(r + RL) * C + c, one(x1, d1));
+    bn_st<V>(dX + (size_t)r * C + c, one(x0, d0, r));
+    bn_st<V>(dX + (size_t)(r + RL) * C + c, one(x1, d1, r + RL));
   }
-  for (; r < r1; r += RL) bn_st<V>(dX + (size_t)r * C + c, one(bn_ld<V>(X + (size_t)r * C + c), bn_ld<V>(dY + (size_t)r * C + c)));
+  for (; r < r1; r += RL) bn_st<V>(dX + (size_t)r * C + c, one(bn_ld<V>(X + (size_t)r * C + c), bn_ld<V>(dY + (size_t)r * C + c), r));
 }
 
 static inline void bn_geometry(int M, int* splits, int* rows) {
