@@ -52,12 +52,12 @@ def _event_time_ms(fn, iters, stream):
     return start.elapsed_time(end) / iters
 
 
-def _pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes (profiles/r04_pmc_counters.json:
+def _pmc_traffic(kernel, rnd="r04"):
+    """HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes (profiles/<rnd>_pmc_counters.json:
     separate FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) -- a recorded figure, not a
     measurement of this run; None when the file does not hold the kernel."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_counters.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "%s_pmc_counters.json" % rnd)) as f:
             d = json.load(f)
         v = d.get(kernel)
         return v.get("traffic_bytes") if isinstance(v, dict) else None
@@ -65,12 +65,21 @@ def _pmc_traffic(kernel):
         return None
 
 
+def _profile(name):
+    """Newest committed profile of that name: profiles/r05_<name> if present, else the round-4 one."""
+    for rnd in ("r05", "r04"):
+        p = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r05_%s" % name)
+
+
 def _rocprof_avg_us(kernel, full=False):
     """Average duration of `kernel` in the COMMITTED rocprofv3 --kernel-trace --stats summary of this same command
     (profiles/r04_{default,full}_bench_kernel_stats.csv).  None when the summary does not hold the kernel."""
     import csv
     try:
-        path = os.path.join(ROOT, "profiles", "r04_%s_bench_kernel_stats.csv" % ("full" if full else "default"))
+        path = _profile("%s_bench_kernel_stats.csv" % ("full" if full else "default"))
         with open(path) as f:
             for r in csv.DictReader(f):
                 if kernel in r["Name"]:
@@ -125,6 +134,69 @@ def in_step_stamps(trainer, batch, dev, graph_replays=25):
     return res
 
 
+def in_step_family(trainer, batch, dev, graph_replays=15):
+    """The WHOLE gemm_t2 family inside a captured training step: device timestamps around every launch (hip.enable_stamps(...,
+    family=True): two one-thread stamp kernels per launch, both streams running), median over replays per launch, stamp
+    overhead subtracted; aggregated per (N, K, A transform) class and over the family.  FLOPs = 2 M N K of the rows the batch
+    really has.  The ~150 extra stamp launches lengthen the step they sit in (reported as `step_us_with_stamps`), so the
+    durations are those of the kernels themselves beside a somewhat slower neighbourhood, not a statement about the step."""
+    from moleculesde_amd import hip
+    from moleculesde_amd.geom3d import prepare_batch
+    try:
+        b2_ = batch.clone() if hasattr(batch, "clone") else batch
+        if not getattr(b2_, "_msde_plan", None):
+            b2_ = prepare_batch(b2_, dev)
+        hip.enable_stamps(dev, family=True)
+        dp_was, trainer.dp_enabled = trainer.dp_enabled, False
+        trainer.step(b2_)
+        trainer.capture(b2_)
+        shapes = list(hip.STAMPS["t2_shapes"])
+        n = len(shapes)
+        per = [[] for _ in range(n)]
+        steps = []
+        for _ in range(graph_replays):
+            trainer.step_graph(b2_)
+            torch.cuda.synchronize()
+            t = hip.read_stamps()
+            for k in range(n):
+                a, b = t.get("t2_start#%d" % k), t.get("t2_end#%d" % k)
+                if a is not None and b is not None:
+                    per[k].append((b - a) / 100.0)
+            if "step_start" in t and "step_end" in t:
+                steps.append((t["step_end"] - t["step_start"]) / 100.0)
+        ovh = _stamp_overhead_us(dev)
+        cls = {}
+        for (M, N, K, axf), v in zip(shapes, per):
+            if not v:
+                continue
+            v.sort()
+            us = max(v[len(v) // 2] - ovh, 0.1)
+            c = cls.setdefault((N, K, axf), {"launches": 0, "gflop": 0.0, "us": 0.0, "M": M})
+            c["launches"] += 1
+            c["gflop"] += 2.0 * M * N * K / 1e9
+            c["us"] += us
+        tot_f = sum(c["gflop"] for c in cls.values())
+        tot_us = sum(c["us"] for c in cls.values())
+        rows = []
+        for (N, K, axf), c in sorted(cls.items(), key=lambda kv: -kv[1]["us"]):
+            tf = c["gflop"] / c["us"] * 1e-3 if c["us"] else 0.0
+            rows.append({"N": N, "K": K, "a_transform": axf, "rows": c["M"], "launches_per_step": c["launches"],
+                         "gflop_per_step": round(c["gflop"], 3), "us_per_step_in_step": round(c["us"], 1),
+                         "achieved_tflops": round(tf * 1e3, 2), "frac": round(tf * 1e3 / FP32_MFMA_PEAK_TF, 4)})
+        steps.sort()
+        return {"launches_per_step": n, "gflop_per_step": round(tot_f, 2), "us_per_step_in_step": round(tot_us, 1),
+                "achieved": round(tot_f / tot_us * 1e3, 2) if tot_us else None,
+                "frac": round(tot_f / tot_us * 1e3 / FP32_MFMA_PEAK_TF, 4) if tot_us else None, "classes": rows,
+                "stamp_overhead_us": round(ovh, 2), "replays": graph_replays,
+                "step_us_with_stamps": round(steps[len(steps) // 2], 1) if steps else None}
+    except Exception as exc:
+        print(f"[bench] family timing failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+        return None
+    finally:
+        hip.STAMPS = None
+        trainer.dp_enabled = locals().get("dp_was", trainer.dp_enabled)
+
+
 def count_kernels_per_step(trainer, batch):
     """Kernel launches of one training step (what a replayed hipGraph holds, plus the pointer-table uploads an eager step
     makes and a replay does not): counted with torch.profiler on one eager step; (launches, launches that are not kernels of
@@ -151,7 +223,7 @@ def _rocprof_family(prefix, full=False):
     step}; the summary covers the whole bench run, so per-step figures divide by the calls of the once-per-step Adam kernel."""
     import csv
     try:
-        path = os.path.join(ROOT, "profiles", "r04_%s_bench_kernel_stats.csv" % ("full" if full else "default"))
+        path = _profile("%s_bench_kernel_stats.csv" % ("full" if full else "default"))
         rows = list(csv.DictReader(open(path)))
         steps = max((int(r["Calls"]) for r in rows if "adam_chunks" in r["Name"]), default=0)
         mine = [r for r in rows if prefix in r["Name"]]
@@ -166,22 +238,21 @@ def _rocprof_family(prefix, full=False):
         return None
 
 
-def roofline_gemm(trainer, batch, dev, in_step):
+def roofline_gemm(trainer, batch, dev, in_step, family):
     """`roofline`: the kernel FAMILY with the largest share of the step's GPU time -- gemm_t2_kernel (csrc/gemm_t2.h, the 2-D
-    tiled fp32-MFMA GEMM of the node-level products: ~32 % of the GPU time of the default step over its instantiations,
-    profiles/r04_default_bench_kernel_stats.csv) -- on its heaviest shape, the second product of a GIN layer: [N, 600]
-    (BatchNorm + ReLU applied to the A fragments) x W^T [600, 300], statistics of the following BatchNorm in the epilogue
-    (molecule_gnn_model.py:17,176-182).  Algorithmic FLOPs per launch = 2 N 300 600 (SURVEY §8d row 'GIN MLP').  `frac` is
-    the IN-STEP figure: the launch's duration inside a captured training step, both streams running, from device
-    timestamps captured into the graph around it (median over replays); `standalone` is the same launch alone between HIP
-    events."""
+    tiled fp32-MFMA GEMM of every node-level product: a third of the GPU time of the default step over its instantiations;
+    the dominant single instantiation by the committed rocprofv3 summary is the plain <5,0,0> one).  `achieved` / `frac` = the
+    FLOP-WEIGHTED figure of the whole family INSIDE the captured step: sum over its launches of 2 M N K divided by the sum of
+    their durations from device timestamps around every launch, both streams running (in_step_family); `classes` lists every
+    (N, K, A-transform) class with its own in-step figure.  `gin_second_product` keeps round 4's figure -- the <5,1>
+    instantiation on the second product of a GIN layer ([N, 600] with BatchNorm + ReLU on the A fragments x W^T [600, 300],
+    statistics in the epilogue, molecule_gnn_model.py:17,176-182), in the step and stand-alone between HIP events."""
     from moleculesde_amd import hip
     N = int(batch.x.size(0))
     D, H = trainer.args.emb_dim, 2 * trainer.args.emb_dim
     flops = 2.0 * N * D * H
-    out = {"kernel": "gemm_t2_kernel<5, 1> (GIN layer, second product: BatchNorm+ReLU on the A fragments, statistics in the "
-                     "epilogue)", "bound": "mfma", "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "flops_per_launch": flops,
-           "shape_MxNxK": [N, D, H]}
+    sub = {"kernel": "gemm_t2_kernel<5, 1> (GIN layer, second product: BatchNorm+ReLU on the A fragments, statistics in the "
+                     "epilogue)", "flops_per_launch": flops, "shape_MxNxK": [N, D, H]}
     # ---- stand-alone: the same fused launch between HIP events
     with torch.no_grad():
         z1 = torch.randn(N, H, device=dev)
@@ -195,25 +266,37 @@ def roofline_gemm(trainer, batch, dev, in_step):
                                    stats_mode="bnfwd")
         ms = _event_time_ms(fn, 50, torch.cuda.current_stream())
     tf = flops / (ms * 1e-3) / 1e12
-    out["standalone"] = {"avg_launch_us": round(ms * 1e3, 2), "achieved": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TF, 4)}
+    sub["standalone"] = {"avg_launch_us": round(ms * 1e3, 2), "achieved": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TF, 4)}
     in_us = in_step.get("gin_gemm2")
     if in_us and in_us > 0:
         tfi = flops / (in_us * 1e-6) / 1e12
-        out.update({"achieved": round(tfi, 2), "frac": round(tfi / FP32_MFMA_PEAK_TF, 4), "avg_launch_us": round(in_us, 2),
+        sub.update({"achieved": round(tfi, 2), "frac": round(tfi / FP32_MFMA_PEAK_TF, 4), "avg_launch_us": round(in_us, 2),
                     "timing": "inside the captured step (device timestamps around the launch in each of the 5 GIN layers, "
                               "median of %d replays per layer, mean over the layers, stamp overhead subtracted)"
                               % in_step.get("replays", 0),
                     "avg_launch_us_per_layer": in_step.get("gin_gemm2_per_layer")})
+    sub["traffic"] = _pmc_traffic("gemm_t2_kernel<5, 1>[3588x300x600]")
+    sub["traffic_source"] = "profiles/r04_pmc_counters.json (committed FETCH_SIZE / WRITE_SIZE passes; not measured by this run)"
+    sub["algorithmic_bytes_per_launch"] = (N * H + H * D + N * D + N * H) * 4      # z1 in, W, z2 out, a1 out
+    out = {"kernel": "gemm_t2_kernel<RN, AXF> family (every node-level product of the step), FLOP-weighted, in the step",
+           "bound": "mfma", "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s"}
+    if family and family.get("frac"):
+        out.update({"achieved": family["achieved"], "frac": family["frac"],
+                    "timing": "device timestamps around every launch of the family inside the captured two-stream step, median of "
+                              "%d replays per launch, stamp overhead (%.2f us) subtracted" % (family["replays"], family["stamp_overhead_us"]),
+                    "launches_per_step": family["launches_per_step"], "gflop_per_step": family["gflop_per_step"],
+                    "us_per_step_in_step": family["us_per_step_in_step"], "classes": family["classes"],
+                    "step_us_with_stamps": family["step_us_with_stamps"]})
     else:
-        out.update({"achieved": out["standalone"]["achieved"], "frac": out["standalone"]["frac"],
-                    "avg_launch_us": out["standalone"]["avg_launch_us"], "timing": "stand-alone (in-step timing unavailable)"})
-    # the whole family in the committed rocprofv3 summary of this command: launches and time per step over ALL shapes
+        out.update({"achieved": sub.get("achieved", sub["standalone"]["achieved"]), "frac": sub.get("frac", sub["standalone"]["frac"]),
+                    "timing": "family timing unavailable: the GIN second product alone"})
     fam = _rocprof_family("gemm_t2_kernel")
     if fam:
         out["family_in_committed_rocprofv3_summary"] = fam
-    out["traffic"] = _pmc_traffic("gemm_t2_kernel<5, 1>[3588x300x600]")
-    out["traffic_source"] = "profiles/r04_pmc_counters.json (committed FETCH_SIZE / WRITE_SIZE passes; not measured by this run)"
-    out["algorithmic_bytes_per_launch"] = (N * H + H * D + N * D + N * H) * 4      # z1 in, W, z2 out, a1 out
+    # counters of the dominant instantiations (separate --pmc passes, tools/gpu_r05_pmc.sh -> profiles/r05_pmc_counters.json)
+    out["traffic"] = _pmc_traffic("gemm_t2_kernel<5, 0>[3588x300x300]", "r05") or sub["traffic"]
+    out["traffic_source"] = "profiles/r05_pmc_counters.json (committed FETCH_SIZE / WRITE_SIZE passes of the plain N = K = 300 product; not measured by this run)"
+    out["gin_second_product"] = sub
     return out
 
 
@@ -936,7 +1019,8 @@ def main():
         roof_bwd = roofline_pair_bwd_w(trainer, pool[0])
         in_step = in_step_stamps(trainer, cpu_pool[0].clone(), device)
         roof_agg = roofline_hbm_kernel(trainer, pool[0], in_step)
-        roof = roofline_gemm(trainer, cpu_pool[0].clone(), device, in_step)
+        family = in_step_family(trainer, cpu_pool[0].clone(), device)
+        roof = roofline_gemm(trainer, cpu_pool[0].clone(), device, in_step, family)
         n_kern, n_foreign = count_kernels_per_step(trainer, pool[0])
         roof_head = roofline_dense_head_node_mlp(pool[0])
         roof_forward = roofline_forward(trainer, pool[0], stats)

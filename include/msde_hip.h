@@ -480,6 +480,13 @@ int msde_bn_fin_bwd(const float* stats, int strips, int M, const int* m_valid, i
                     const float* mean, const float* rstd, float* p, float* w, float* u, float* dgamma,
                     float* dbeta, void* stream);
 
+/* The BatchNorm input gradient as a pass of its own -- exactly what MSDE_RS_AXF_BNBWD applies to the A fragments:
+ * out[m,c] = p[c] g' + w[c] Z[m,c] + u[c], g' = G[m,c] gated to 0 where Z[m,c] xf3[c] + xf4[c] <= 0 (xf3, xf4 both or neither);
+ * rows behind *m_valid are written as 0.  The GIN layer's BatchNorm backward (molecule_gnn_model.py:17,176-182) in front of a
+ * PLAIN product.  C % 4 == 0, leading dimensions % 4 == 0. */
+int msde_bn_bwd_cols(const float* G, int ldg, const float* Z, int ldz, const float* p, const float* w, const float* u,
+                     const float* xf3, const float* xf4, int M, const int* m_valid, int C, float* out, int ldo,
+                     void* stream);
 /* Y = max(X * scale[c] + shift[c], 0 if relu) over rows (the BatchNorm apply for a tensor with several consumers: the GIN
  * layer output, molecule_gnn_model.py:176-182); C % 4 == 0. */
 int msde_affine_cols(const float* X, int M, int C, const float* scale, const float* shift, int relu, float* Y,

@@ -2630,7 +2630,13 @@ def gemm_rs(A, B, out, bias=None, act=None, Z=None, dact_from=None, res=None, b_
     d.m_valid = m_valid.data_ptr() if m_valid is not None else None
     d.rt, d.splits = int(rt), int(splits)
     if t2:          # the 2-D tiled kernel (csrc/gemm_t2.hip): B is the [N][K] operand
+        fam = STAMPS is not None and STAMPS.get("family")
+        if fam:         # bench.py: device timestamps around EVERY launch of the family inside the captured step
+            STAMPS["t2_shapes"].append((int(d.M), int(d.N), int(d.K), axf or "none"))
+            stamp("t2_start", seq=True)
         _lib.check(_lib.load().msde_gemm_t2(ctypes.byref(d), _stream()), "msde_gemm_t2")
+        if fam:
+            stamp("t2_end", seq=True)
         return out
     code = _lib.load().msde_gemm_rs(ctypes.byref(d), _stream())
     if code == -2 and fallback and axf is None and res is None and stats is None and A_out is None:
@@ -2694,6 +2700,9 @@ def _bn_fin_bwd(stats, strips, M, C, gamma, mean, rstd, need_affine_grads=True):
     return vec, gb
 
 
+BN_BWD_PASS = True     # GIN backward: BatchNorm input gradient as a streaming pass + plain product: 2.543 vs 2.587 ms (False: on the A fragments)
+
+
 class _GinMlpBN(torch.autograd.Function):
     """Linear(D, 2D) -> BatchNorm1d -> ReLU -> Linear(2D, D) -> BatchNorm1d (-> ReLU) of a GIN layer in training mode
     (molecule_gnn_model.py:17,28-29,176-182) on the row-strip GEMMs: batch statistics in the epilogue of the producing
@@ -2716,6 +2725,8 @@ class _GinMlpBN(torch.autograd.Function):
         st2 = torch.empty(s2, 2, D, dtype=torch.float32, device=dev)
         a1 = torch.empty(M, H, dtype=torch.float32, device=dev)
         z2 = torch.empty(M, D, dtype=torch.float32, device=dev)
+        # (round 5: the forward transform as a pass of its own + plain product is neither faster nor slower -- 2.549 vs 2.545 ms,
+        # one launch more; it stays on the A fragments.  The BACKWARD transform is the one that pays as a pass: BN_BWD_PASS.)
         stamp("gin_gemm2_start", seq=True)          # no-ops unless enable_stamps(): bench.py times this launch inside the captured step
         gemm_node(z1, W2, z2, True, D, H, bias=b2, axf="affine", xf=(v1[0], v1[1]), relu=True, A_out=a1, stats=st2,
                   stats_mode="bnfwd")
@@ -2754,13 +2765,26 @@ class _GinMlpBN(torch.autograd.Function):
         sta = torch.empty(sa, 2, H, dtype=torch.float32, device=dev)
         dz2 = torch.empty(M, D, dtype=torch.float32, device=dev)
         ga1 = torch.empty(M, H, dtype=torch.float32, device=dev)
-        gemm_node(g, W2, ga1, False, H, D, axf="bnbwd",
-                  xf=(pw2[0], pw2[1], pw2[2]) + ((v2[0], v2[1]) if ctx.relu_out else (None, None)), A2=z2, A_out=dz2,
-                  act="relu", dact_from=a1, stats=sta, stats_mode="bnbwd", stats_z=z1, stats_mean=v1[2])
+        rows = bound_tensor(M)
+        if BN_BWD_PASS:
+            # the BatchNorm input gradient as a streaming pass in front of a PLAIN product (see msde_bn_bwd_cols)
+            _lib.call("msde_bn_bwd_cols", _p(g), _ld(g), _p(z2), _ld(z2), _p(pw2[0]), _p(pw2[1]), _p(pw2[2]),
+                      _p(v2[0] if ctx.relu_out else None), _p(v2[1] if ctx.relu_out else None), M, _p(rows), D, _p(dz2), D, st)
+            gemm_node(dz2, W2, ga1, False, H, D, act="relu", dact_from=a1, stats=sta, stats_mode="bnbwd", stats_z=z1,
+                      stats_mean=v1[2])
+        else:
+            gemm_node(g, W2, ga1, False, H, D, axf="bnbwd",
+                      xf=(pw2[0], pw2[1], pw2[2]) + ((v2[0], v2[1]) if ctx.relu_out else (None, None)), A2=z2, A_out=dz2,
+                      act="relu", dact_from=a1, stats=sta, stats_mode="bnbwd", stats_z=z1, stats_mean=v1[2])
         pw1, gb1 = _bn_fin_bwd(sta, sa, M, H, g1, v1[2], v1[3])
         dz1 = torch.empty(M, H, dtype=torch.float32, device=dev)
         g_agg = torch.empty(M, D, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
-        if g_agg is not None:
+        if BN_BWD_PASS:
+            _lib.call("msde_bn_bwd_cols", _p(ga1), _ld(ga1), _p(z1), _ld(z1), _p(pw1[0]), _p(pw1[1]), _p(pw1[2]), _p(None), _p(None),
+                      M, _p(rows), H, _p(dz1), H, st)
+            if g_agg is not None:
+                gemm_node(dz1, W1, g_agg, False, D, H)
+        elif g_agg is not None:
             gemm_node(ga1, W1, g_agg, False, D, H, axf="bnbwd", xf=(pw1[0], pw1[1], pw1[2]), A2=z1, A_out=dz1)
         else:       # nothing upstream wants a gradient: only dz1 for the weight gradient (product result discarded)
             scratch = torch.empty(M, D, dtype=torch.float32, device=dev)
@@ -2914,9 +2938,11 @@ def schnet_tail(agg, h, lin2, lin):
 STAMPS = None            # {"buf": int64[256] device tensor, "names": [..]} when enabled
 
 
-def enable_stamps(device):
+def enable_stamps(device, family=False):
+    """family: also stamp around every msde_gemm_t2 launch (`t2_start#k` / `t2_end#k`; shapes in STAMPS["t2_shapes"], in launch
+    order since the last "step_start")."""
     global STAMPS
-    STAMPS = {"buf": torch.zeros(256, dtype=torch.int64, device=device), "names": []}
+    STAMPS = {"buf": torch.zeros(1024, dtype=torch.int64, device=device), "names": [], "family": bool(family), "t2_shapes": []}
 
 
 def stamp(name, seq=False):
@@ -2927,6 +2953,7 @@ def stamp(name, seq=False):
         return
     if name == "step_start":
         STAMPS["seq"] = {}
+        STAMPS["t2_shapes"] = []
     if seq:
         k = STAMPS.setdefault("seq", {}).get(name, 0)
         STAMPS["seq"][name] = k + 1
