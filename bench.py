@@ -179,10 +179,10 @@ def in_step_family(trainer, batch, dev, graph_replays=15):
         tot_us = sum(c["us"] for c in cls.values())
         rows = []
         for (N, K, axf), c in sorted(cls.items(), key=lambda kv: -kv[1]["us"]):
-            tf = c["gflop"] / c["us"] * 1e-3 if c["us"] else 0.0
+            tf = c["gflop"] / c["us"] * 1e3 if c["us"] else 0.0          # GFLOP per us = 1000 TFLOP/s
             rows.append({"N": N, "K": K, "a_transform": axf, "rows": c["M"], "launches_per_step": c["launches"],
                          "gflop_per_step": round(c["gflop"], 3), "us_per_step_in_step": round(c["us"], 1),
-                         "achieved_tflops": round(tf * 1e3, 2), "frac": round(tf * 1e3 / FP32_MFMA_PEAK_TF, 4)})
+                         "achieved_tflops": round(tf, 2), "frac": round(tf / FP32_MFMA_PEAK_TF, 4)})
         steps.sort()
         return {"launches_per_step": n, "gflop_per_step": round(tot_f, 2), "us_per_step_in_step": round(tot_us, 1),
                 "achieved": round(tot_f / tot_us * 1e3, 2) if tot_us else None,
@@ -816,6 +816,9 @@ def main():
                          "(graph without Adam; all-reduce; Adam kernel)")
     ap.add_argument("--full", action="store_true",
                     help="configs[2] per-GPU work: add the 3D->2D dense head loss (default: configs[1])")
+    ap.add_argument("--score_kernel", default="ops", choices=["ops", "mol"],
+                    help="2D->3D score network under autograd: operator by operator (default) or one launch each way with one "
+                         "workgroup per molecule (pretrain.py --score_kernel)")
     ap.add_argument("--census_only", action="store_true",
                     help="launcher check: start the ranks, count them with one all-reduce, print the line's DP keys and exit "
                          "(runs without a GPU under MSDE_DP_BACKEND=gloo: tests/test_host_logic.py)")
@@ -861,7 +864,7 @@ def main():
     torch.cuda.set_device(device)
     torch.manual_seed(0)
 
-    args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=1 if a.full else 0, batch_size=a.batch_size)
+    args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=1 if a.full else 0, batch_size=a.batch_size, score_kernel=a.score_kernel)
     trainer = pretrain.Trainer(args, device)
     trainer.adam_outside_graph = a.debug_dp_path
     cpu_pool = [make_batch(a.batch_size, seed=dp.shard_seed(s, rank)) for s in range(a.pool)]
