@@ -722,14 +722,17 @@ int msde_mul_add_bwd(const float* g, const float* a, const float* b, long long n
                      void* stream);
 /* Predictor-corrector sampler arithmetic for ONE diffusion time shared by all n atoms (pretrain_MoleculeSDE_inference_2D_to_3D_VE_VP.py
  * :191-212 LangevinCorrector.update_fn, :163-168 ReverseDiffusionPredictor.update_fn): `out` is the score network's raw output
- * [n, 3] (score = -out / std), par = {std(t), G(t), alpha(t), fa(t)} on the device, fa = 1 + f(x)/x of the discretised
- * forward SDE (VE: 1).  corrector: step = (snr mean|noise| / mean|score|)^2 2 alpha, x_mean = pos + step score,
+ * [n, 3] (score = -out / std); par [S][4] = {std(t), G(t), alpha(t), fa(t)} per time step on the device, fa = 1 + f(x)/x of the
+ * discretised forward SDE (VE: 1).  corrector: step = (snr mean|noise| / mean|score|)^2 2 alpha, x_mean = pos + step score,
  * x = x_mean + sqrt(2 step) scale_eps noise (one workgroup, fixed-order reductions); predictor: x_mean = pos - ((fa - 1) pos -
- * G^2 score), x = x_mean + G noise. */
-int msde_pc_corrector(const float* out, const float* pos, const float* noise, const float* par, int n, float snr,
-                      float scale_eps, float* x, float* x_mean, void* stream);
-int msde_pc_predictor(const float* out, const float* pos, const float* noise, const float* par, int n, float* x,
-                      float* x_mean, void* stream);
+ * G^2 score), x = x_mean + G noise.
+ * step (device int64, may be NULL = row 0): the iteration counter -- the corrector uses row step[0] and then advances it, the
+ * predictor of the same iteration uses row step[0] - 1: a captured iteration replays without any host work.
+ * noise [n, 3], or NULL: N(0,1) draws from the counter generator keyed by (seed, row, corrector / predictor, element). */
+int msde_pc_corrector(const float* out, const float* pos, const float* noise, const float* par, long long* step,
+                      unsigned long long seed, int n, float snr, float scale_eps, float* x, float* x_mean, void* stream);
+int msde_pc_predictor(const float* out, const float* pos, const float* noise, const float* par, const long long* step,
+                      unsigned long long seed, int n, float* x, float* x_mean, void* stream);
 /* torch.randperm(n) for the contrastive negatives (examples/util.py:55), n <= 4096 (else MSDE_EUNSUP):
  * out[count][n] int32, `count` independent uniform shuffles in one launch (dual_CL draws two) from the
  * counter-based generator (seed [+ seed_dev[0]*FNV], permutation number, index). */
@@ -795,6 +798,18 @@ int msde_escore_mol_fwd(const void* const* params, const float* x0, const float*
                         const int* dst, int N, int E, int hidden, int heads, int hidden_coff, float p_att,
                         float p_ffn, unsigned long long seed0, const unsigned long long* seed_dev, float eps1,
                         float eps2, float* out, float* saved, void* stream);
+
+/* get_score of SDEModel2Dto3D_01/_02 up to the division by -std (SDE_model_2D_to_3D.py:393-445; _01: :200-249) as ONE launch:
+ * the coordinate-dependent edge features (frame, Gaussian-Fourier features, input_mlp, coff_mlp, project,
+ * edge_attr = input_mlp(.) * edge_2D + project(.)) are built inside the kernel from `pos` [N,3] and the coordinate-INDEPENDENT
+ * rows edge_2D [E, ld_e2d] (edge_2D_emb of the node pairs, computed once per representation), then the score network runs as in
+ * msde_escore_mol_fwd in inference mode.  params: DEVICE array of 86 pointers = the 76 above, then dist_gaussian_fourier.W [32]
+ * (any valid pointer when has_dist = 0), coff_gaussian_fourier.W [32], input_mlp weight [32,64] / bias, coff_mlp weight [32,128]
+ * / bias, project[0] weight [32,66] / bias, project[1] weight [32,32] / bias.  has_dist = 0: the _01 model (no distance
+ * branch).  n_max: the largest molecule of the batch; MSDE_EUNSUP above 20 atoms (<= 384 extended edges stay in LDS). */
+int msde_escore_mol_score(const void* const* params, const float* x0, const float* pos, const float* edge_2D, int ld_e2d,
+                          int has_dist, const int* mol_ptr, int B, const int* rowptr, const int* src, const int* dst, int N, int E,
+                          int hidden, int heads, int hidden_coff, int n_max, float eps1, float eps2, float* out, void* stream);
 
 /* Backward of msde_escore_mol_fwd (same arguments; `saved` written by it).  rowptr_s [N+1] / perm_s [E]: the by-source view
  * of the edges (slot -> by-target edge id).  g_out [N,3] -> g_x0 [N,32], g_edge_attr [E,ld_gea] (all rows written; rows behind

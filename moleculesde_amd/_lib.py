@@ -133,8 +133,8 @@ SIGNATURES = {
     "msde_silu_dropout_bwd": [P, P, LL, F, ULL, P, P, P],
     "msde_mul_add_fwd": [P, P, P, LL, P, P],
     "msde_mul_add_bwd": [P, P, P, LL, P, P, P],
-    "msde_pc_corrector": [P, P, P, P, I, ctypes.c_float, ctypes.c_float, P, P, P],
-    "msde_pc_predictor": [P, P, P, P, I, P, P, P],
+    "msde_pc_corrector": [P, P, P, P, P, ULL, I, F, F, P, P, P],
+    "msde_pc_predictor": [P, P, P, P, P, ULL, I, P, P, P],
     "msde_randperm": [I, I, ULL, P, P, P, P],
     "msde_ve_perturb": [P, P, P, P, I, I, I, F, F, F, P, P, P],
     "msde_ve_perturb_rng": [P, P, I, I, I, F, F, F, ULL, P, P, P, P, P],
@@ -145,6 +145,7 @@ SIGNATURES = {
     "msde_gat_tail_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P, P, P, P],
     "msde_escore_mol_saved_floats": [I],
     "msde_escore_mol_fwd": [P, P, P, I, P, P, I, P, P, P, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P],
+    "msde_escore_mol_score": [P, P, P, P, I, I, P, I, P, P, P, I, I, I, I, I, I, F, F, P, P],
     "msde_escore_mol_slab_floats": [],
     "msde_escore_mol_bwd": [P, P, P, I, P, P, I, P, P, P, P, P, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P, P, I, P, P],
     "msde_chunk_elems": [],

@@ -683,35 +683,50 @@ __device__ __forceinline__ float pc_block_sum(float v, float* red) {
   return t;
 }
 
+// par_all [S][4] = {std(t), G(t), alpha(t), 1 + f(x)/x} for every time step, row = the device iteration counter: the corrector
+// (ONE workgroup) reads step[0] as its row and then advances it; the predictor of the same iteration reads step[0] - 1.  With
+// step == NULL both use row 0 of `par_all` (the caller refreshes it).  noise == NULL: N(0,1) draws from the counter generator,
+// (seed, row, element) -> the same draw wherever it is asked for (the corrector needs its noise twice).
+__device__ __forceinline__ float pc_draw(const float* __restrict__ noise, unsigned long long seed, long long row, int stream_id, int i, int n3) {
+  return noise ? noise[i] : msde_randn(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * row + stream_id), (unsigned long long)i);
+}
+
 __global__ void __launch_bounds__(1024)
 pc_corrector_kernel(const float* __restrict__ out, const float* __restrict__ pos, const float* __restrict__ noise,
-                    const float* __restrict__ par, int n, float snr, float scale_eps, float* __restrict__ x,
-                    float* __restrict__ x_mean) {
+                    const float* __restrict__ par_all, long long* __restrict__ step, unsigned long long seed, int n, float snr,
+                    float scale_eps, float* __restrict__ x, float* __restrict__ x_mean) {
   __shared__ float red[16];
+  const long long row = step ? step[0] : 0;
+  const float* par = par_all + 4 * row;
   const float inv_std = 1.f / par[0], alpha = par[2];
   float gs = 0.f, ns = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float g0 = -out[3 * i] * inv_std, g1 = -out[3 * i + 1] * inv_std, g2 = -out[3 * i + 2] * inv_std;
-    const float z0 = noise[3 * i], z1 = noise[3 * i + 1], z2 = noise[3 * i + 2];
+    const float z0 = pc_draw(noise, seed, row, 0, 3 * i, 3 * n), z1 = pc_draw(noise, seed, row, 0, 3 * i + 1, 3 * n),
+                z2 = pc_draw(noise, seed, row, 0, 3 * i + 2, 3 * n);
     gs += sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
     ns += sqrtf(z0 * z0 + z1 * z1 + z2 * z2);
   }
   const float gn = pc_block_sum(gs, red) / (float)n;
   const float nn = pc_block_sum(ns, red) / (float)n;
   const float r = snr * nn / gn;
-  const float step = r * r * 2.f * alpha;
-  const float ns2 = sqrtf(step * 2.f) * scale_eps;
+  const float stp = r * r * 2.f * alpha;
+  const float ns2 = sqrtf(stp * 2.f) * scale_eps;
   for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {
     const float g = -out[i] * inv_std;
-    const float m = fmaf(step, g, pos[i]);
+    const float m = fmaf(stp, g, pos[i]);
     x_mean[i] = m;
-    x[i] = fmaf(ns2, noise[i], m);
+    x[i] = fmaf(ns2, pc_draw(noise, seed, row, 0, i, 3 * n), m);
   }
+  if (step && threadIdx.x == 0) step[0] = row + 1;      // (every thread read `row` before the block sums' barriers)
 }
 
 __global__ void __launch_bounds__(1024)
 pc_predictor_kernel(const float* __restrict__ out, const float* __restrict__ pos, const float* __restrict__ noise,
-                    const float* __restrict__ par, int n, float* __restrict__ x, float* __restrict__ x_mean) {
+                    const float* __restrict__ par_all, const long long* __restrict__ step, unsigned long long seed, int n,
+                    float* __restrict__ x, float* __restrict__ x_mean) {
+  const long long row = step ? step[0] - 1 : 0;
+  const float* par = par_all + 4 * row;
   const float inv_std = 1.f / par[0], G = par[1], fa = par[3];
   const float g2 = G * G;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += gridDim.x * blockDim.x) {
@@ -719,25 +734,25 @@ pc_predictor_kernel(const float* __restrict__ out, const float* __restrict__ pos
     const float p = pos[i];
     const float m = p - ((fa - 1.f) * p - g2 * score);        // x - (f - G^2 score)
     x_mean[i] = m;
-    x[i] = fmaf(G, noise[i], m);
+    x[i] = fmaf(G, pc_draw(noise, seed, row, 1, i, 3 * n), m);
   }
 }
 
-extern "C" int msde_pc_corrector(const float* out, const float* pos, const float* noise, const float* par, int n, float snr,
-                                 float scale_eps, float* x, float* x_mean, void* stream) {
-  if (n <= 0 || !out || !pos || !noise || !par || !x || !x_mean) return MSDE_EINVAL;
-  MSDE_LAUNCH(pc_corrector_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, as_stream(stream), out, pos, noise, par, n, snr,
-              scale_eps, x, x_mean);
+extern "C" int msde_pc_corrector(const float* out, const float* pos, const float* noise, const float* par, long long* step,
+                                 unsigned long long seed, int n, float snr, float scale_eps, float* x, float* x_mean, void* stream) {
+  if (n <= 0 || !out || !pos || !par || !x || !x_mean) return MSDE_EINVAL;
+  MSDE_LAUNCH(pc_corrector_kernel, dim3(1), dim3(n >= 512 ? 1024 : 256), 0, as_stream(stream), out, pos, noise, par, step, seed, n,
+              snr, scale_eps, x, x_mean);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int msde_pc_predictor(const float* out, const float* pos, const float* noise, const float* par, int n, float* x,
-                                 float* x_mean, void* stream) {
-  if (n <= 0 || !out || !pos || !noise || !par || !x || !x_mean) return MSDE_EINVAL;
+extern "C" int msde_pc_predictor(const float* out, const float* pos, const float* noise, const float* par, const long long* step,
+                                 unsigned long long seed, int n, float* x, float* x_mean, void* stream) {
+  if (n <= 0 || !out || !pos || !par || !x || !x_mean) return MSDE_EINVAL;
   const int blocks = (3 * n + 1023) / 1024;
-  MSDE_LAUNCH(pc_predictor_kernel, dim3(blocks > 256 ? 256 : blocks), dim3(1024), 0, as_stream(stream), out, pos, noise, par, n,
-              x, x_mean);
+  MSDE_LAUNCH(pc_predictor_kernel, dim3(blocks > 256 ? 256 : blocks), dim3(1024), 0, as_stream(stream), out, pos, noise, par, step,
+              seed, n, x, x_mean);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -80,6 +80,52 @@ def forward_nograd(net, ep, pl, node_attr, edge_attr, basis, seed0, seed_dev):
     return out
 
 
+SCORE_NMAX = 20           # msde_escore_mol_score: <= 384 extended edges per molecule stay in LDS
+
+
+def score_supported(model, pl):
+    """The one-launch get_score: what `supported` asks of the score network, molecules of at most 20 atoms, and the
+    coordinate branch in the reference's shape (input_mlp one Linear, project Linear -> SiLU -> Linear, no dropout)."""
+    net = model.score_network
+    if not supported(net, pl) or pl.N_max > SCORE_NMAX or model.hidden_dim != 32:
+        return False
+    proj = model.project
+    if len(proj.layers) != 2 or proj.activation_name != "silu" or proj.dropout:
+        return False
+    if hasattr(model, "input_mlp") and len(model.input_mlp.layers) != 1:
+        return False
+    return True
+
+
+def score_param_tensors(model):
+    """The 86 parameters of msde_escore_mol_score's table (include/msde_hip.h)."""
+    has_dist = hasattr(model, "input_mlp")
+    cf = model.coff_gaussian_fourier.W
+    geo = [model.dist_gaussian_fourier.W if has_dist else cf, cf]
+    if has_dist:
+        geo += [model.input_mlp.layers[0].weight, model.input_mlp.layers[0].bias]
+    else:
+        geo += [model.coff_mlp.weight, model.coff_mlp.bias]          # placeholders: never read when has_dist = 0
+    geo += [model.coff_mlp.weight, model.coff_mlp.bias, model.project.layers[0].weight, model.project.layers[0].bias,
+            model.project.layers[1].weight, model.project.layers[1].bias]
+    return param_tensors(model.score_network) + geo
+
+
+def score_nograd(model, ep, pl, node_attr, edge_2D, pos):
+    """SDEModel2Dto3D_0x.get_score's network output [N, 3] (before the division by -std) in one launch."""
+    net = model.score_network
+    tens = score_param_tensors(model)
+    _, _, eps1, eps2 = _cfg(net)
+    x0, e2, pos = hip._f32(node_attr), edge_2D, hip._f32(pos)
+    if not (e2.is_cuda and e2.dtype == torch.float32 and e2.stride(-1) == 1 and e2.stride(0) % 4 == 0 and e2.data_ptr() % 16 == 0):
+        e2 = hip._f32(e2)
+    out = torch.empty(ep.N, 3, dtype=torch.float32, device=x0.device)
+    _lib.call("msde_escore_mol_score", hip._p(_pointer_table(model, tens)), hip._p(x0), hip._p(pos), hip._p(e2), e2.stride(0),
+              int(hasattr(model, "input_mlp")), hip._p(pl.mol_ptr), int(pl.B), hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst),
+              ep.N, ep.E, 32, 8, 128, int(pl.N_max), eps1, eps2, hip._p(out), hip._stream())
+    return out
+
+
 _LAYER_SHAPES = [(32, 32)] * 4 + [(32,)] * 4 + [(32, 32), (32,), (32,), (32, 32), (32,), (32, 32), (32,), (32,), (32,)]
 _BASIS_SHAPES = [(128, 64), (128,), (3, 128), (3,)]
 

@@ -38,13 +38,17 @@ def corrector_update(sde, score_model, representation, data, pos, t, snr, scale_
 
 @torch.no_grad()
 def position_PC_generation(score_model, representation, data, num_steps=1000, snr=0.16, scale_eps=0.7,
-                           n_corrector_steps=1, eps=1e-4, denoise=True, pos_init=None, use_graph=True):
+                           n_corrector_steps=1, eps=1e-4, denoise=True, pos_init=None, use_graph=True, noise_seed=None,
+                           torch_noise=False, iters_per_graph=1):
     """position_PC_generation (:92-138): returns the final coordinates [N, 3].
 
     The loop is latency bound (every iteration = 1 + n_corrector_steps score-network calls on a graph of
     ~10 x 14 atoms, ~150 small launches), so by default one iteration (corrector + predictor, noise drawn
-    inside) is captured into a hipGraph after two eager warm-up iterations and replayed; only the
-    per-atom time vector is refreshed from the host between replays."""
+    inside) is captured into a hipGraph after two eager warm-up iterations and replayed.  On the fused path (one shared
+    diffusion time, one corrector step) the replay needs nothing from the host: the iteration counter and the noise live in
+    the two update kernels (noise_seed: their seed; None = drawn from torch's generator), and iters_per_graph iterations
+    share one graph launch.  torch_noise=True: the noise comes
+    from torch.randn_like as in the operator path (parity tests: same generator state => same trajectory)."""
     sde = score_model.sde_pos
     n = representation.size(0)
     dev = representation.device
@@ -66,40 +70,57 @@ def position_PC_generation(score_model, representation, data, num_steps=1000, sn
         f_all, G_all = sde.discretize(ones, timesteps)
         alpha_all = sde.corrector_alpha(timesteps) if hasattr(sde, "corrector_alpha") else torch.ones_like(timesteps)
         par_all = torch.stack([std_all.float(), G_all.float(), alpha_all.float(), f_all[:, 0].float() + 1.0], 1).contiguous()
-        par = torch.zeros(4, device=dev)
+        # the iteration counter lives on the device (the corrector advances it) and both kernels draw their own noise from the
+        # counter generator: a replayed iteration needs no host work and no random-number operator (noise_seed: one per call)
+        it_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise_seed is None else int(noise_seed)
         xc = torch.empty_like(pos)
         xm_c = torch.empty_like(pos)
         stream = _hip_mod._stream
+        p_ = _hip_mod._p
 
     def one_step():
         if fused:
             raw = score_model.get_score_raw(representation, data, pos).contiguous()
-            noise = torch.randn_like(pos)
-            _lib.call("msde_pc_corrector", _hip_mod._p(raw), _hip_mod._p(pos), _hip_mod._p(noise), _hip_mod._p(par), n, float(snr),
-                      float(scale_eps), _hip_mod._p(xc), _hip_mod._p(xm_c), stream())
+            nz = torch.randn_like(pos) if torch_noise else None
+            _lib.call("msde_pc_corrector", p_(raw), p_(pos), p_(nz), p_(par_all), p_(it_dev), seed, n, float(snr), float(scale_eps),
+                      p_(xc), p_(xm_c), stream())
             raw2 = score_model.get_score_raw(representation, data, xc).contiguous()
-            noise2 = torch.randn_like(pos)
-            _lib.call("msde_pc_predictor", _hip_mod._p(raw2), _hip_mod._p(xc), _hip_mod._p(noise2), _hip_mod._p(par), n,
-                      _hip_mod._p(pos), _hip_mod._p(x_mean), stream())
+            nz2 = torch.randn_like(pos) if torch_noise else None
+            _lib.call("msde_pc_predictor", p_(raw2), p_(xc), p_(nz2), p_(par_all), p_(it_dev), seed, n, p_(pos), p_(x_mean), stream())
             return
         p, _ = corrector_update(sde, score_model, representation, data, pos, vec_t, snr, scale_eps, n_corrector_steps)
         p, m = predictor_update(sde, score_model, representation, data, p, vec_t)
         pos.copy_(p)
         x_mean.copy_(m)
 
-    graph = None
-    for i in range(num_steps):
-        if fused:
-            par.copy_(par_all[i])
-        else:
+    # Replay: on the fused path an iteration reads nothing from the host (counter and noise live on the device), so
+    # `iters_per_graph` consecutive iterations can share ONE hipGraph; the tail that does not fill a graph replays a
+    # one-iteration graph.  Measured (tools/sampler_slope.py): the loop is bound by the two score-network launches of an
+    # iteration, 165-169 us per iteration for 1, 5 and 25 iterations per graph -- so the default stays 1 (cheapest capture).
+    graph, graph_k, k_iters = None, None, 1
+    i = 0
+    while i < num_steps:
+        if not fused:
             vec_t.fill_(1.0).mul_(timesteps[i])
         if use_graph and dev.type == "cuda" and graph is None and i == 2:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with _hip_mod.no_gc(), torch.cuda.graph(graph):
+            with _hip_mod.no_gc(collect=False), torch.cuda.graph(graph):
                 one_step()                 # capture only records; the replay below executes iteration i
-        if graph is not None:
+            k_iters = max(1, min(int(iters_per_graph), num_steps - i)) if fused else 1
+            if k_iters > 1:
+                graph_k = torch.cuda.CUDAGraph()
+                with _hip_mod.no_gc(collect=False), torch.cuda.graph(graph_k):
+                    for _ in range(k_iters):
+                        one_step()
+        if graph_k is not None and num_steps - i >= k_iters:
+            graph_k.replay()
+            i += k_iters
+        elif graph is not None:
             graph.replay()
+            i += 1
         else:
             one_step()
+            i += 1
     return (x_mean if denoise else pos).clone()

@@ -210,3 +210,65 @@ def test_trainer_score_kernel_mol_matches_ops(dev):
     d = (pa - pb).abs()
     assert float(d.max()) <= 6.5e-3, float(d.max())
     assert float(d.mean()) <= 2e-5, float(d.mean())
+
+
+@pytest.mark.parametrize("cls,sizes", [("SDEModel2Dto3D_02", [12, 5, 20, 9, 1, 17]), ("SDEModel2Dto3D_01", [14] * 10),
+                                        ("SDEModel2Dto3D_02", [20] * 3 + [2])])
+def test_get_score_one_launch_matches_operator_path(dev, cls, sizes):
+    """msde_escore_mol_score (frame, Fourier features, input_mlp / coff_mlp / project and the score network in ONE launch,
+    SDE_model_2D_to_3D.py:393-445) against the same get_score on the separate geometry launches + msde_escore_mol_fwd and
+    against the plain operator path.  The in-kernel Fourier features use the hardware sin / cos on the phase in revolutions
+    (|error| ~1e-6 per feature): 2e-4 relative to the score's scale."""
+    import numpy as np
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import plan as P
+    from moleculesde_amd.batch import Batch
+    from moleculesde_amd.geom3d import sde_2d_to_3d as M
+    from moleculesde_amd.synthetic import make_molecule
+    torch.manual_seed(11)
+    rng = np.random.default_rng(5)
+    b = G.prepare_batch(Batch.from_data_list([make_molecule(rng, n) for n in sizes]), dev)
+    gnn = G.GNN(3, 32, gnn_type="GIN").to(dev).eval()
+    model = getattr(G, cls)(emb_dim=32, hidden_dim=32, beta_min=0.1, beta_max=1.0, num_diffusion_timesteps=1000,
+                            beta_schedule=None, SDE_type="VE", use_extend_graph=True).to(dev).eval()
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.LayerNorm):
+                m.weight.normal_(1, 0.3)
+                m.bias.normal_(0, 0.3)
+        rep = gnn(b.x, b.edge_index, b.edge_attr)
+    pl = P.get_plan(b)
+    assert pl.N_max <= 20
+    outs = {}
+    # coordinates at a small and a large diffusion time
+    poses = [(b.positions + scale * torch.randn_like(b.positions)).contiguous() for scale in (0.3, 6.0)]
+    keep = (M.MOL_KERNEL, M.MOL_KERNEL_SCORE)
+    try:
+        for name, mk, ms in (("one_launch", True, True), ("mol_fwd", True, False), ("ops", False, False)):
+            M.MOL_KERNEL, M.MOL_KERNEL_SCORE = mk, ms
+            outs[name] = [model.get_score_raw(rep, b, pos).clone() for pos in poses]
+    finally:
+        M.MOL_KERNEL, M.MOL_KERNEL_SCORE = keep
+    for i in range(2):
+        ref = outs["ops"][i]
+        assert torch.isfinite(ref).all()
+        assert_close(outs["mol_fwd"][i], ref, 2e-4, 2e-4 * float(ref.abs().max()), "mol fwd vs ops")
+        assert_close(outs["one_launch"][i], ref, 2e-4, 2e-4 * float(ref.abs().max()), "one-launch get_score vs ops")
+
+
+def test_get_score_one_launch_falls_back_above_20_atoms(dev):
+    import numpy as np
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import escore, plan as P
+    from moleculesde_amd.batch import Batch
+    from moleculesde_amd.synthetic import make_molecule
+    rng = np.random.default_rng(6)
+    b = G.prepare_batch(Batch.from_data_list([make_molecule(rng, n) for n in (8, 24)]), dev)
+    model = G.SDEModel2Dto3D_02(emb_dim=32, hidden_dim=32, beta_min=0.1, beta_max=1.0, num_diffusion_timesteps=1000,
+                                beta_schedule=None, SDE_type="VE", use_extend_graph=True).to(dev).eval()
+    assert not escore.score_supported(model, P.get_plan(b))
+    gnn = G.GNN(3, 32, gnn_type="GIN").to(dev).eval()
+    with torch.no_grad():
+        rep = gnn(b.x, b.edge_index, b.edge_attr)
+    out = model.get_score_raw(rep, b, b.positions)
+    assert out.shape == (32, 3) and torch.isfinite(out).all()

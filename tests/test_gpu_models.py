@@ -728,11 +728,33 @@ def test_sampler_fused_arithmetic_matches_operator_path(dev, sde_type):
             sampler.FUSED_PC = fused
             torch.manual_seed(7)
             torch.cuda.manual_seed(7)
-            outs.append(sampler.position_PC_generation(s23, rep, b, num_steps=10, pos_init=pos0, use_graph=False, denoise=False))
+            outs.append(sampler.position_PC_generation(s23, rep, b, num_steps=10, pos_init=pos0, use_graph=False, denoise=False,
+                                                       torch_noise=True))
     finally:
         sampler.FUSED_PC = keep
     assert torch.isfinite(outs[0]).all()
     assert_close(outs[1], outs[0], 1e-4, 1e-5, "fused vs operator sampler arithmetic (%s)" % sde_type)
+    # the production mode: iteration counter and noise inside the update kernels -- a trajectory is a function of its seed, and the
+    # replayed hipGraph (no host work between iterations) walks the same trajectory as the host-launched loop
+    kw = dict(num_steps=12, pos_init=pos0, denoise=False, noise_seed=1234)
+    e1 = sampler.position_PC_generation(s23, rep, b, use_graph=False, **kw)
+    e2 = sampler.position_PC_generation(s23, rep, b, use_graph=False, **kw)
+    g1 = sampler.position_PC_generation(s23, rep, b, use_graph=True, **kw)              # 10 iterations in one graph launch
+    g4 = sampler.position_PC_generation(s23, rep, b, use_graph=True, iters_per_graph=4, **kw)   # 2 x 4 + 2 single replays
+    assert torch.equal(g4, g1)
+    o1 = sampler.position_PC_generation(s23, rep, b, use_graph=False, **dict(kw, noise_seed=99))
+    assert torch.isfinite(e1).all() and torch.equal(e1, e2)
+    assert_close(g1, e1, 1e-5, 1e-6, "replayed vs host-launched trajectory")
+    assert not torch.allclose(o1, e1)
+    # the in-kernel draws are N(0,1): moments of what one predictor step adds (x - x_mean) / G over many atoms
+    from moleculesde_amd import _lib, hip
+    n = 20000
+    z = torch.zeros(n, 3, device=dev)
+    par = torch.tensor([[1.0, 1.0, 1.0, 1.0]], device=dev)
+    x, xm = torch.empty_like(z), torch.empty_like(z)
+    _lib.call("msde_pc_predictor", hip._p(z), hip._p(z), hip._p(None), hip._p(par), hip._p(None), 77, n, hip._p(x), hip._p(xm), hip._stream())
+    d = (x - xm).flatten()
+    assert abs(float(d.mean())) < 0.02 and abs(float(d.std()) - 1.0) < 0.02 and abs(float((d ** 4).mean()) - 3.0) < 0.15
 
 
 @pytest.mark.parametrize("bs", [1, 4])
