@@ -273,6 +273,7 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
         }
       }
     }
+    ES_STAMP(41);
   }
 
 #pragma unroll 1

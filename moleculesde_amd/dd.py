@@ -347,6 +347,25 @@ seg_reduce = _SegReduce.apply
 
 
 # ------------------------------------------------------------------------------------------------ dense
+PARAM_GRADS = True      # False inside positions_only(): this differentiation is w.r.t. the coordinates alone
+
+
+class positions_only:
+    """`with dd.positions_only(): force = -autograd.grad(energy, positions, create_graph=True)` -- the caller states that
+    this differentiation does not ask for parameter gradients (finetune_MD17.py:68).  ctx.needs_input_grad cannot tell: it
+    is fixed at forward time (every weight requires grad), so each Linear's backward would also form its weight / bias
+    gradient -- a GEMM, a slab reduction and a column sum per layer that the engine then drops."""
+
+    def __enter__(self):
+        global PARAM_GRADS
+        self._was, PARAM_GRADS = PARAM_GRADS, False
+
+    def __exit__(self, *exc):
+        global PARAM_GRADS
+        PARAM_GRADS = self._was
+        return False
+
+
 def _gemm(A, B, bias=None, b_kmajor=False):
     M = A.size(0)
     N = B.size(1) if b_kmajor else B.size(0)
@@ -364,18 +383,22 @@ class _Linear(torch.autograd.Function):
         x, W = _f32(x), _f32(W)
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
+        ctx.b_key = b.data_ptr() if (b is not None and b.is_leaf) else None
         return _gemm(x, W, bias=_f32(b) if b is not None else None)
 
     @staticmethod
     def backward(ctx, g):
         x, W = ctx.saved_tensors
         ni = ctx.needs_input_grad
-        if ctx.has_bias and ni[1] and ni[2] and not torch.is_grad_enabled():
-            # the LAST differentiation (nothing will differentiate this backward again): weight and bias gradient from one
-            # launch of the split-M kernel instead of mm_tn + colsum (two members of the closed set, two to three launches)
+        if not PARAM_GRADS:
+            return (mm_nn(g, W) if ni[0] else None), None, None
+        if ni[1] and not torch.is_grad_enabled() and (not ctx.has_bias or (ni[2] and ctx.b_key is not None)):
+            # the LAST differentiation (nothing will differentiate this backward again): weight and bias gradient from the
+            # split-M kernel instead of mm_tn + colsum (two members of the closed set, two to three launches) -- queued for
+            # the step's ONE grouped launch when the trainer has a parameter-gradient batch open (hip.weight_grad_leaf)
             g2 = _f32(g)
             CALLS["msde_linear_bwd_w"] = CALLS.get("msde_linear_bwd_w", 0) + 1
-            gW, gb = hip.weight_grad(g2, x, True, deferrable=False)
+            gW, gb = hip.weight_grad_leaf(g2, x, ctx.has_bias, W, ctx.b_key)
             return (mm_nn(g, W) if ni[0] else None), gW, gb
         return (mm_nn(g, W) if ni[0] else None), (mm_tn(g, x) if ni[1] else None), \
             (colsum(g) if ctx.has_bias and ni[2] else None)
@@ -398,6 +421,12 @@ class _MMnn(torch.autograd.Function):
     def backward(ctx, u):
         g, W = ctx.saved_tensors
         ni = ctx.needs_input_grad
+        if not PARAM_GRADS:
+            return (mm_nt(u, W) if ni[0] else None), None
+        if ni[1] and not torch.is_grad_enabled() and W.is_leaf:
+            # last differentiation, W a parameter: its second contribution (the force path) joins the grouped launch
+            CALLS["msde_linear_bwd_w"] = CALLS.get("msde_linear_bwd_w", 0) + 1
+            return (mm_nt(u, W) if ni[0] else None), hip.weight_grad_leaf(g, _f32(u), False, W)[0]
         return (mm_nt(u, W) if ni[0] else None), (mm_tn(g, u) if ni[1] else None)
 
 
@@ -417,7 +446,10 @@ class _MMnt(torch.autograd.Function):
     def backward(ctx, u):
         x, W = ctx.saved_tensors
         ni = ctx.needs_input_grad
-        return (mm_nn(u, W) if ni[0] else None), (mm_tn(u, x) if ni[1] else None)
+        if ni[1] and PARAM_GRADS and not torch.is_grad_enabled() and W.is_leaf:
+            CALLS["msde_linear_bwd_w"] = CALLS.get("msde_linear_bwd_w", 0) + 1
+            return (mm_nn(u, W) if ni[0] else None), hip.weight_grad_leaf(_f32(u), x, False, W)[0]
+        return (mm_nn(u, W) if ni[0] else None), (mm_tn(u, x) if ni[1] and PARAM_GRADS else None)
 
 
 mm_nt = _MMnt.apply

@@ -16,7 +16,7 @@ moleculesde_amd/dd.py (SchNet._forward_force_path, PaiNN.forward); there is no h
 """
 import torch
 
-from . import hip
+from . import dd, hip
 from .optim import FlatAdam
 
 
@@ -48,8 +48,9 @@ class ForceTrainer:
         if self.normalization is not None:
             e_mean, f_mean, n_atom = self.normalization
             energy = energy * f_mean + e_mean * n_atom
-        force = -torch.autograd.grad(energy, positions, grad_outputs=torch.ones_like(energy), create_graph=create_graph,
-                                     retain_graph=create_graph)[0]
+        with dd.positions_only():        # (no parameter gradients in this differentiation: skips ~30 unused weight-gradient GEMMs)
+            force = -torch.autograd.grad(energy, positions, grad_outputs=torch.ones_like(energy), create_graph=create_graph,
+                                         retain_graph=create_graph)[0]
         return energy, force
 
     def _body(self, batch, positions, y, force_t):
@@ -57,7 +58,13 @@ class ForceTrainer:
         energy, force = self.energy_and_force(batch, pos)
         loss = self.energy_coeff * (energy - y).abs().mean() + self.force_coeff * (force - force_t).abs().mean()
         self.opt.zero_grad()
-        loss.backward()
+        # the weight gradients of the whole step (two contributions per Linear: energy path and force path) as ONE grouped
+        # launch + ONE slab reduction behind the backward pass (hip.weight_grad_leaf) instead of ~170 per-layer launches
+        hip.begin_param_grad_batch(self.opt.params)
+        try:
+            loss.backward()
+        finally:
+            hip.finish_param_grad_batch()
         self.opt.step_from_grads()
         self._refreshed = hip.refresh_weight_t()    # re-laid-out weight copies (if a layer reads one) follow the update
         return loss.detach()

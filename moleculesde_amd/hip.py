@@ -1314,6 +1314,8 @@ class _SlabBatch:
         self.retired = []        # outgrown arenas still referenced by queued rows
         self.launched = []       # operands of GEMMs already launched in this backward pass (kept alive until finish)
         self.deferred = []       # leaf-only kernels queued by backward functions (run_deferred_leaf_kernels)
+        self.leaf_first = {}     # weight_grad_leaf: parameter address -> (address, entries) of its first queued gradient
+        self.leaf_more = []      # ... and the later contributions to the same parameter: (first address, tensor, level)
         self.slot = None
         self.slots = []          # slots 0..EAGER_SLOTS-1: the eager ring; one more per captured hipGraph
         self.events = []         # per slot: event recorded behind the last upload of its pinned host images
@@ -1365,6 +1367,7 @@ class _SlabBatch:
                                             "slab reduction needs zero_grad(set_to_none=True) before every backward")
         self.active = True
         self.used = 0
+        self.leaf_first, self.leaf_more = {}, []
         self.prob_used = self.pre_used = 0
         self.rows_used = self.rpre_used = 0
         self.rotated = False
@@ -1492,6 +1495,21 @@ class _SlabBatch:
             self._select_slot(rows[0][4])
             self.launch_gemms()      # the (still) queued weight-gradient GEMMs as one grouped launch
             self._reduce(rows)
+            # parameters with several queued contributions (weight_grad_leaf): first + later ones, one more pass of the same
+            # kernel per level -- a two-"slab" row whose slabs are the two gradient buffers themselves
+            level = 1
+            while True:
+                extra = [(first, t) for first, t, lv in self.leaf_more if lv == level]
+                if not extra:
+                    break
+                rows2 = []
+                for first, t in extra:
+                    lo, hi = min(first, t.data_ptr()), max(first, t.data_ptr())
+                    n = t.numel()
+                    rows2.append((lo, 2, n, first, t.device, None, (n, n, n, (hi - lo) // 4)))
+                self._reduce(rows2)
+                level += 1
+            self.leaf_more = []
         if not torch.cuda.is_current_stream_capturing():
             ev = self.events[self.slot_i] or torch.cuda.Event()
             ev.record()
@@ -1637,6 +1655,34 @@ def weight_grad(g2, x2, has_bias, deferrable=True, out_w=None, out_b=None):
         ws = _wgrad_workspace(M, N, K, g2.device)
         _lib.call("msde_linear_bwd_w", _p(g2), _p(x2), M, N, K, _p(gw), _p(gb), _p(ws), _p(bound_tensor(M)), st)
     return gw, gb
+
+
+def weight_grad_leaf(g2, x2, has_bias, W, b_key=None):
+    """weight_grad for a LEAF parameter W that may receive several contributions in one backward pass (the twice-
+    differentiated force path of finetune_MD17.py:68-78: every weight is used by the energy AND by d(energy)/d(positions)).
+    With a parameter-gradient batch open each contribution is a problem of the grouped launch; the FIRST one's result
+    tensors are returned (autograd's AccumulateGrad steals them), later ones return (None, None) and are added to the first
+    behind the batched slab reduction (_SlabBatch.finish) -- no per-layer GEMM, slab-reduction or add launch.  b_key: the
+    bias parameter's address (has_bias).  Without an open batch: the immediate per-layer launch."""
+    if not (_SLABS.active and W.is_leaf):
+        return weight_grad(g2, x2, has_bias, deferrable=False)
+    if not (g2.dtype == torch.float32 and x2.dtype == torch.float32 and g2.stride(-1) == 1 and x2.stride(-1) == 1):
+        g2, x2 = _f32(g2), _f32(x2)
+    keys = [W.data_ptr()] + ([b_key] if has_bias else [])
+    levels = [len([1 for f, _, _ in _SLABS.leaf_more if f == _SLABS.leaf_first[k][0]]) + 1 if k in _SLABS.leaf_first else 0
+              for k in keys]
+    gw, gb = weight_grad(g2, x2, has_bias, deferrable=True)
+    outs = []
+    for k, lv, t in zip(keys, levels, (gw, gb)):
+        if lv == 0:
+            _SLABS.leaf_first[k] = (t.data_ptr(), t.numel())
+            outs.append(t)
+        else:
+            first, n = _SLABS.leaf_first[k]
+            assert n == t.numel()
+            _SLABS.leaf_more.append((first, t, lv))       # (kept alive here until finish())
+            outs.append(None)
+    return outs[0], (outs[1] if has_bias else None)
 
 
 def colsum(x):
