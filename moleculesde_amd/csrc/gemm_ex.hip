@@ -358,6 +358,99 @@ gemm_ex_kernel(const msde_gemm_desc d) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ small problems
+// C[M,N] = A[M,K] . B (+ bias) for M <= 512 rows and K <= 512 (the MD17 force fine-tuning step: 21 atoms / 420 edges, ~130
+// products per step, finetune_MD17.py:47-78).  Such a product is a LATENCY chain, not a throughput problem: the tiled kernel
+// above walks K in 32-wide steps behind barriers with ONE 32 x 32 accumulator per wave (K = 300: 150 dependent 64-cycle
+// MFMAs + 10 load -> LDS -> barrier round trips, ~10 us).  Here a workgroup owns a 32 x 32 output tile, its four waves
+// split K, every wave requests ALL of its operand fragments at once straight into MFMA operand registers (no LDS staging: the
+// k order inside a 16-wide chunk is free as long as A and B agree, so lane group g takes k = 4g .. 4g+3 as one 16-byte
+// load), runs its v_mfma_f32_16x16x4_f32 on four independent accumulators, and the four partial tiles meet in LDS.
+typedef float gs_f4 __attribute__((ext_vector_type(4)));
+#define GS_CH 8                 // 16-wide K chunks per wave: K <= 4 * 8 * 16 = 512
+
+template <bool B_KM, bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_small_kernel(const msde_gemm_desc d) {
+  __shared__ float part[4][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+  const int tiles_n = (d.N + 31) >> 5;
+  const int m0 = ((int)blockIdx.x / tiles_n) * 32, n0 = ((int)blockIdx.x % tiles_n) * 32;
+  const int K = d.K1;
+  const int nchunk = (K + 15) >> 4, cpw = (nchunk + 3) >> 2;
+  const int c_lo = wave * cpw, c_hi = min(c_lo + cpw, nchunk);
+  // rows / columns past the edge repeat the last one: their results are never stored
+  const float* __restrict__ arow[2];
+  const float* __restrict__ brow[2];
+  int bcol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    arow[i] = d.A + (size_t)min(m0 + 16 * i + c, d.M - 1) * d.lda;
+    bcol[i] = min(n0 + 16 * i + c, d.N - 1);
+    brow[i] = d.B + (B_KM ? (size_t)bcol[i] : (size_t)bcol[i] * d.ldb);
+  }
+  auto ld_k = [&](const float* __restrict__ row, int k) -> float4 {          // 4 consecutive k of a k-contiguous row
+    if (VEC) return k < K ? *reinterpret_cast<const float4*>(row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return make_float4(k < K ? row[k] : 0.f, k + 1 < K ? row[k + 1] : 0.f, k + 2 < K ? row[k + 2] : 0.f, k + 3 < K ? row[k + 3] : 0.f);
+  };
+  float4 av[GS_CH][2], bv[GS_CH][2];
+#pragma unroll
+  for (int t = 0; t < GS_CH; ++t) {
+    const int k = 16 * (c_lo + t) + 4 * g;
+    if (c_lo + t < c_hi) {                                   // (uniform in the wave)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[t][i] = ld_k(arow[i], k);
+        if (!B_KM) {
+          bv[t][i] = ld_k(brow[i], k);
+        } else {
+          const float* __restrict__ bp = brow[i] + (size_t)k * d.ldb;
+          bv[t][i] = make_float4(k < K ? bp[0] : 0.f, k + 1 < K ? bp[d.ldb] : 0.f, k + 2 < K ? bp[2 * (size_t)d.ldb] : 0.f,
+                                 k + 3 < K ? bp[3 * (size_t)d.ldb] : 0.f);
+        }
+      }
+    }
+  }
+  gs_f4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = gs_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < GS_CH; ++t) {
+    if (c_lo + t < c_hi) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][i].x, bv[t][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][i].y, bv[t][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][i].z, bv[t][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][i].w, bv[t][j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // C/D map of the 16 x 16 MFMA: column = lane & 15, row = 4 (lane >> 4) + r
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][(16 * i + 4 * g + r) * 33 + 16 * j + c] = acc[i][j][r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * 256 + tid, row = idx >> 5, col = idx & 31;
+    const int gm = m0 + row, gn = n0 + col;
+    if (gm < d.M && gn < d.N) {
+      const int o = row * 33 + col;
+      float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+      if (d.bias) v += d.bias[gn];
+      d.C[(size_t)gm * d.ldc + gn] = v;
+    }
+  }
+}
+
 static inline bool gx_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int msde_gemm_ex(const msde_gemm_desc* desc, void* stream) {
@@ -384,6 +477,17 @@ extern "C" int msde_gemm_ex(const msde_gemm_desc* desc, void* stream) {
     bool ok = fits32(d.M, d.lda, d.K1) && fits32(km ? d.K1 : d.N, d.ldb, km ? d.N : d.K1);
     if (d.A2) ok = ok && fits32(d.M, d.lda2, d.K2) && fits32(km ? d.K2 : d.N, d.ldb2, km ? d.N : d.K2);
     if (!ok) vec = false;
+  }
+  if (d.M <= 512 && d.K1 <= 16 * 4 * GS_CH && d.groups == 1 && !d.A2 && d.act == MSDE_ACT_NONE && d.epi == MSDE_EPI_ACT &&
+      !d.rowscale && d.alpha == 1.f && !d.Z && !d.bias2 && d.b_kblk_log2 == 0 && !(d.flags & ~MSDE_GEMM_B_KMAJOR)) {
+    // a latency chain, not a throughput problem: the small-problem kernel (above)
+    const bool v4 = gx_al16(d.A) && d.lda % 4 == 0 && d.K1 % 4 == 0 && (km || (gx_al16(d.B) && d.ldb % 4 == 0));
+    dim3 grid(((d.M + 31) / 32) * ((d.N + 31) / 32));
+    hipStream_t st = as_stream(stream);
+    if (km) { if (v4) MSDE_LAUNCH((gemm_small_kernel<true, true>), grid, dim3(256), 0, st, d); else MSDE_LAUNCH((gemm_small_kernel<true, false>), grid, dim3(256), 0, st, d); }
+    else { if (v4) MSDE_LAUNCH((gemm_small_kernel<false, true>), grid, dim3(256), 0, st, d); else MSDE_LAUNCH((gemm_small_kernel<false, false>), grid, dim3(256), 0, st, d); }
+    MSDE_CHECK_LAUNCH();
+    return 0;
   }
   // tile height: 128 rows when that still gives every CU >= 2 tiles, else 64 (skinny problems need the parallelism)
   const long t128 = (long)((d.M + 127) / 128) * ((d.N + 63) / 64) * d.groups;

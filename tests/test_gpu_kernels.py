@@ -1200,6 +1200,32 @@ def test_gemm_ex_plain_and_kmajor(dev, M, N, K, km):
     assert_close(out, ref, 1e-5, 2e-5, "gemm_ex out")
 
 
+@pytest.mark.parametrize("M,N,K", [(21, 300, 300), (21, 128, 300), (420, 128, 51), (420, 128, 128), (420, 51, 128), (1, 1, 1),
+                                   (33, 35, 17), (512, 300, 512), (42, 1, 300), (7, 3, 16), (64, 64, 500)])
+@pytest.mark.parametrize("km", [False, True])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm_ex_small_problem_kernel(dev, M, N, K, km, bias):
+    """Plain products of <= 512 rows and K <= 512 (the MD17 step's ~130 per step, finetune_MD17.py:47-78) run on
+    gemm_small_kernel (four waves split K, operands straight into MFMA registers): against fp64 torch; both B layouts,
+    unaligned K / leading dimensions, edges of every kind, operands that are column blocks of wider buffers."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    wide = torch.randn(M, K + 8, generator=g).to(dev)
+    A = wide[:, 4:4 + K] if K % 4 == 0 else wide[:, 3:3 + K]          # row stride != K; aligned only in the first case
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    Bop = W.t().contiguous() if km else W
+    out_w = torch.full((M, N + 5), float("nan"), device=dev)
+    out = out_w[:, 2:2 + N]
+    hip.gemm_ex(A, Bop, out, bias=b, b_kmajor=km)
+    ref = A.double() @ W.double().t() + (b.double() if bias else 0.0)
+    assert_close(out, ref, 1e-5, 2e-5, "small-problem product")
+    assert torch.isnan(out_w[:, :2]).all() and torch.isnan(out_w[:, 2 + N:]).all(), "wrote outside its column block"
+    out2 = torch.empty(M, N, device=dev)
+    hip.gemm_ex(A, Bop, out2, bias=b, b_kmajor=km)
+    assert torch.equal(out2, out.contiguous()), "two runs differ"
+
+
 @pytest.mark.parametrize("act", [None, "tanh", "silu", "elu", "ssp", "relu"])
 def test_gemm_ex_two_segments_epilogues(dev, act):
     """Two K segments written into a column block of a wider buffer (ldc > N), row mask, alpha, accumulate; then the

@@ -879,7 +879,7 @@ def test_md17_force_path_runs_on_library_kernels(dev):
     assert dd.CALLS.get("msde_gemm_ex", 0) > 20 and dd.CALLS.get("msde_linear_bwd_w", 0) > 10, dd.CALLS
     assert dd.CALLS.get("msde_dd_rbf", 0) >= 3 and dd.CALLS.get("msde_dd_edge_scatter", 0) >= 1, dd.CALLS
     names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
-    ours = ("dd_", "gemm_ex", "gemm_f32_mfma", "wgrad", "reduce_slabs", "colsum", "cfconv_aggregate", "radius_", "scan",
+    ours = ("dd_", "gemm_ex", "gemm_small", "gemm_f32_mfma", "wgrad", "reduce_slabs", "colsum", "cfconv_aggregate", "radius_", "scan",
             "embedding_sum", "segment_sum", "transpose")
     foreign = sorted({n for n in names if not any(k in n for k in ours)})
     # allowed: the test's own clone / ones_like, and the autograd engine's gradient accumulation (a + b)
