@@ -90,6 +90,10 @@ int msde_plan_row_lists(const int* codes, const int* n_dev, int K, int R, int* c
  * painn_utils.py:150-154), 2: reciprocal, 3: SiLU (painn.py activation), 4: sqrt(x + p0) (painn.py:104);
  * order = derivative order 0..2.  mask (may be NULL): entries < 0 give 0. */
 int msde_dd_unary(const float* x, const int* mask, long long n, int kind, int order, float p0, float* y, void* stream);
+/* y = g * (g2 ? g2 : 1) * f^(order)(x) (same kinds): the backward of msde_dd_unary, and of itself, in one launch
+ * (moleculesde_amd/dd.py: _UnaryMul; autograd's chain rule for Softplus / cos in schnet.py:186,213-216). */
+int msde_dd_unary_mul(const float* g, const float* g2, const float* x, const int* mask, long long n, int kind, int order,
+                      float p0, float* y, void* stream);
 /* Gaussian smearing exp(coeff (d - mu_g)^2) (schnet.py:205-207) and its 1st / 2nd derivative in d: y [E][G];
  * rows with src[e] < 0 (src may be NULL) are zero. */
 int msde_dd_rbf(const float* d, const int* src, const float* mu, int E, int G, float coeff, int order, float* y,

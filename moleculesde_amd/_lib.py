@@ -103,6 +103,7 @@ SIGNATURES = {
     "msde_plan_build": [P, I, P, P, P, P, P, P, P, I, I, I, I, I, I, I] + [P] * 23 + [P],
     "msde_plan_row_lists": [P, P, I, I, P, P, P, P],
     "msde_dd_unary": [P, P, LL, I, I, F, P, P],
+    "msde_dd_unary_mul": [P, P, P, P, LL, I, I, F, P, P],
     "msde_dd_rbf": [P, P, P, I, I, F, I, P, P],
     "msde_dd_binary": [P, P, LL, I, F, P, P],
     "msde_dd_mul_rows": [P, P, I, I, P, P],

@@ -19,8 +19,9 @@ __device__ __forceinline__ float dd_sigmoid(float x) { return 1.f / (1.f + expf(
 // kind 0: shifted softplus, order 0..2; kind 1: cosine cutoff 0.5 (cos(pi d / rc) + 1) for d < rc, 0 beyond, order 0..2
 // (p0 = rc); kind 2: reciprocal (order ignored); kind 3: SiLU x sigmoid(x), order 0..2 (painn.py activation);
 // kind 4: sqrt(x + p0), order 0..2 (painn.py:104).  mask (optional int array): entries < 0 give 0.
+// m1, m2 (optional): y = m1 * m2 * f^(order)(x) -- the chain-rule products of the operator's own backward in the same launch
 __global__ void dd_unary_kernel(const float* __restrict__ x, const int* __restrict__ mask, long long n, int kind, int order,
-                                float p0, float* __restrict__ y) {
+                                float p0, const float* __restrict__ m1, const float* __restrict__ m2, float* __restrict__ y) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float v = x[i];
     float r;
@@ -40,6 +41,8 @@ __global__ void dd_unary_kernel(const float* __restrict__ x, const int* __restri
       const float q = sqrtf(v + p0);
       r = order == 0 ? q : order == 1 ? 0.5f / q : -0.25f / (q * (v + p0));
     }
+    if (m1) r *= m1[i];
+    if (m2) r *= m2[i];
     if (mask && mask[i] < 0) r = 0.f;
     y[i] = r;
   }
@@ -160,7 +163,17 @@ extern "C" int msde_dd_unary(const float* x, const int* mask, long long n, int k
                              void* stream) {
   if (n < 0 || !x || !y || kind < 0 || kind > 4 || order < 0 || order > 2) return MSDE_EINVAL;
   if (n == 0) return 0;
-  MSDE_LAUNCH(dd_unary_kernel, DD_GRID(n), dim3(256), 0, as_stream(stream), x, mask, n, kind, order, p0, y);
+  MSDE_LAUNCH(dd_unary_kernel, DD_GRID(n), dim3(256), 0, as_stream(stream), x, mask, n, kind, order, p0, (const float*)nullptr,
+              (const float*)nullptr, y);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+// y = g * (g2 ? g2 : 1) * f^(order)(x): what the backward of msde_dd_unary (and of this operator) computes, as one launch
+extern "C" int msde_dd_unary_mul(const float* g, const float* g2, const float* x, const int* mask, long long n, int kind,
+                                 int order, float p0, float* y, void* stream) {
+  if (n < 0 || !g || !x || !y || kind < 0 || kind > 4 || order < 0 || order > 2) return MSDE_EINVAL;
+  if (n == 0) return 0;
+  MSDE_LAUNCH(dd_unary_kernel, DD_GRID(n), dim3(256), 0, as_stream(stream), x, mask, n, kind, order, p0, g, g2, y);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

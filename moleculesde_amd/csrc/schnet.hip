@@ -54,7 +54,38 @@ __global__ void cfconv_aggregate_fwd_kernel(const float* __restrict__ x1, const 
   int s0 = rowptr[i], s1 = rowptr[i + 1];
   for (int c = lane; c < cols; c += tpr) {
     T acc = vzero<V>();
-    for (int e = s0; e < s1; ++e) {
+    int e = s0;
+    // batches of 8 edges: the indices, then all 16 rows in flight, accumulated in edge order (one edge at a time this loop is a
+    // chain of index -> row round trips: 12 us for the 20 in-edges of an MD17 atom)
+    for (; e + 7 < s1; e += 8) {
+      int j[8];
+      T w[8], x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) j[u] = src[e + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { w[u] = W[(size_t)(e + u) * cols + c]; x[u] = X[(size_t)j[u] * cols + c]; }
+      if (C) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = vscale(w[u], C[e + u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = vadd(acc, vmul(x[u], w[u]));
+    }
+    for (; e + 3 < s1; e += 4) {
+      int j[4];
+      T w[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) j[u] = src[e + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { w[u] = W[(size_t)(e + u) * cols + c]; x[u] = X[(size_t)j[u] * cols + c]; }
+      if (C) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = vscale(w[u], C[e + u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = vadd(acc, vmul(x[u], w[u]));
+    }
+    for (; e < s1; ++e) {
       // message = x_j * (nn(edge_attr) * C): keep the reference's rounding order (W*C first)
       T w = C ? vscale(W[(size_t)e * cols + c], C[e]) : W[(size_t)e * cols + c];
       acc = vadd(acc, vmul(X[(size_t)src[e] * cols + c], w));
@@ -79,7 +110,21 @@ __global__ void cfconv_aggregate_bwd_w_kernel(const float* __restrict__ g_agg, c
     int s0 = rowptr[i], s1 = rowptr[i + 1];
     for (int c = lane; c < cols; c += tpr) {
       T gi = G[(size_t)i * cols + c];
-      for (int e = s0; e < s1; ++e) {
+      int e = s0;
+      for (; e + 7 < s1; e += 8) {             // batches of 8 edges: indices, then the 8 rows in flight
+        int j[8];
+        T x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) j[u] = src[e + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = X[(size_t)j[u] * cols + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          T v = vmul(gi, x[u]);
+          O[(size_t)(e + u) * cols + c] = C ? vscale(v, C[e + u]) : v;
+        }
+      }
+      for (; e < s1; ++e) {
         T v = vmul(gi, X[(size_t)src[e] * cols + c]);
         O[(size_t)e * cols + c] = C ? vscale(v, C[e]) : v;
       }

@@ -52,7 +52,33 @@ class _Unary(torch.autograd.Function):
         kind, order, p0, mask = ctx.cfg
         if order >= 2:
             raise NotImplementedError("third derivative of a pointwise operator of the force path")
-        return mul(g, _Unary.apply(x, kind, order + 1, p0, mask)), None, None, None, None
+        return _UnaryMul.apply(g, None, x, kind, order + 1, p0, mask), None, None, None, None
+
+
+class _UnaryMul(torch.autograd.Function):
+    """y = g * (g2 ? g2 : 1) * f^(order)(x): the chain-rule product of _Unary's backward as ONE launch (msde_dd_unary_mul)
+    instead of a derivative launch and one or two product launches.  Closed: its own backward is two more of the same."""
+
+    @staticmethod
+    def forward(ctx, g, g2, x, kind, order, p0, mask):
+        g, x = _f32(g), _f32(x)
+        g2 = _f32(g2) if g2 is not None else None
+        assert g.shape == x.shape and (g2 is None or g2.shape == x.shape)
+        y = torch.empty_like(x)
+        _call("msde_dd_unary_mul", _p(g), _p(g2), _p(x), _p(mask), x.numel(), kind, order, float(p0), _p(y), _stream())
+        ctx.save_for_backward(g, x)
+        ctx.cfg = (kind, order, p0, mask, g2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, u):
+        g, x = ctx.saved_tensors
+        kind, order, p0, mask, three = ctx.cfg
+        if three or order >= 2:
+            raise NotImplementedError("third derivative of a pointwise operator of the force path")
+        ni = ctx.needs_input_grad
+        return (_UnaryMul.apply(u, None, x, kind, order, p0, mask) if ni[0] else None), None, \
+            (_UnaryMul.apply(u, g, x, kind, order + 1, p0, mask) if ni[2] else None), None, None, None, None
 
 
 def ssp(x):
