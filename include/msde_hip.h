@@ -803,17 +803,23 @@ int msde_escore_mol_fwd(const void* const* params, const float* x0, const float*
                         float p_ffn, unsigned long long seed0, const unsigned long long* seed_dev, float eps1,
                         float eps2, float* out, float* saved, void* stream);
 
-/* get_score of SDEModel2Dto3D_01/_02 up to the division by -std (SDE_model_2D_to_3D.py:393-445; _01: :200-249) as ONE launch:
- * the coordinate-dependent edge features (frame, Gaussian-Fourier features, input_mlp, coff_mlp, project,
- * edge_attr = input_mlp(.) * edge_2D + project(.)) are built inside the kernel from `pos` [N,3] and the coordinate-INDEPENDENT
+/* get_score of SDEModel2Dto3D_01/_02 up to the division by -std (SDE_model_2D_to_3D.py:393-445; _01: :200-249): the
+ * coordinate-dependent edge features (frame, Gaussian-Fourier features, input_mlp, coff_mlp, project,
+ * edge_attr = input_mlp(.) * edge_2D + project(.)) are built by the library from `pos` [N,3] and the coordinate-INDEPENDENT
  * rows edge_2D [E, ld_e2d] (edge_2D_emb of the node pairs, computed once per representation), then the score network runs as in
  * msde_escore_mol_fwd in inference mode.  params: DEVICE array of 86 pointers = the 76 above, then dist_gaussian_fourier.W [32]
  * (any valid pointer when has_dist = 0), coff_gaussian_fourier.W [32], input_mlp weight [32,64] / bias, coff_mlp weight [32,128]
  * / bias, project[0] weight [32,66] / bias, project[1] weight [32,32] / bias.  has_dist = 0: the _01 model (no distance
- * branch).  n_max: the largest molecule of the batch; MSDE_EUNSUP above 20 atoms (<= 384 extended edges stay in LDS). */
+ * branch).  n_max: the largest molecule of the batch.
+ *   scratch != NULL (msde_escore_mol_score_scratch_floats(E) floats, 16-byte aligned): TWO launches -- everything that depends
+ *     on an edge alone (edge features, lin_edge of the four layers, the edge half of both basis MLPs' first Linear) in a wide
+ *     launch, one wave per 16 edges; then one workgroup per molecule.  Molecules of <= 32 atoms.
+ *   scratch == NULL: ONE launch, the edge features built in the per-molecule kernel's prologue; MSDE_EUNSUP above 20 atoms. */
+long long msde_escore_mol_score_scratch_floats(int E);
 int msde_escore_mol_score(const void* const* params, const float* x0, const float* pos, const float* edge_2D, int ld_e2d,
                           int has_dist, const int* mol_ptr, int B, const int* rowptr, const int* src, const int* dst, int N, int E,
-                          int hidden, int heads, int hidden_coff, int n_max, float eps1, float eps2, float* out, void* stream);
+                          int hidden, int heads, int hidden_coff, int n_max, float eps1, float eps2, float* scratch, float* out,
+                          void* stream);
 
 /* Backward of msde_escore_mol_fwd (same arguments; `saved` written by it).  rowptr_s [N+1] / perm_s [E]: the by-source view
  * of the edges (slot -> by-target edge id).  g_out [N,3] -> g_x0 [N,32], g_edge_attr [E,ld_gea] (all rows written; rows behind

@@ -146,7 +146,8 @@ SIGNATURES = {
     "msde_gat_tail_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P, P, P, P],
     "msde_escore_mol_saved_floats": [I],
     "msde_escore_mol_fwd": [P, P, P, I, P, P, I, P, P, P, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P],
-    "msde_escore_mol_score": [P, P, P, P, I, I, P, I, P, P, P, I, I, I, I, I, I, F, F, P, P],
+    "msde_escore_mol_score": [P, P, P, P, I, I, P, I, P, P, P, I, I, I, I, I, I, F, F, P, P, P],
+    "msde_escore_mol_score_scratch_floats": [I],
     "msde_escore_mol_slab_floats": [],
     "msde_escore_mol_bwd": [P, P, P, I, P, P, I, P, P, P, P, P, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P, P, I, P, P],
     "msde_chunk_elems": [],
@@ -196,6 +197,7 @@ _RESTYPE = {"msde_target_arch": ctypes.c_char_p, "msde_linear_bwd_w_workspace_by
             "msde_embedding_sum_bwd_workspace_floats": ctypes.c_longlong,
             "msde_gin_aggregate_bwd_tab_workspace_floats": ctypes.c_longlong,
             "msde_reduce_slabs_chunks": ctypes.c_longlong, "msde_escore_mol_saved_floats": ctypes.c_longlong,
+            "msde_escore_mol_score_scratch_floats": ctypes.c_longlong,
             "msde_escore_mol_slab_floats": ctypes.c_longlong}
 
 _lib = None

@@ -73,7 +73,186 @@ struct EsGeo {
   int ld_e2d, has_dist;         // has_dist = 0: SDEModel2Dto3D_01 (no distance branch: edge_attr = edge_2D + frame)
 };
 
-template <bool TRAIN, bool GEO>
+
+// ---- get_score in two launches (inference) ---------------------------------------------------------------------------------
+// Everything of the score network that depends on an EDGE alone is hoisted out of the per-molecule latency chain into a wide
+// launch (one wave per 16 edges, any number of workgroups -- the sampler's ten molecules keep ten CUs busy, its 1 820 edges
+// fill 114 waves): the edge features (frame, Fourier features, input_mlp / coff_mlp / project, as in the GEO prologue below),
+// then lin_edge of all four GAT layers and the edge half of both basis MLPs' first Linear.  Row e of `pre` (ES_PRE_LD floats):
+//   [0, 128)    lin_edge_l(edge_attr), l = 0..3           (what the attention of layer l adds to k_j and v_j)
+//   [128, 384)  W1_m[:, 32:] edge_attr, m = 0, 1          (the edge part of the basis MLP's hidden layer, no bias)
+//   [384, 393)  the three frame vectors
+// The per-molecule kernel (PRE) then only copies / adds these rows.
+#define ES_PRE_LD 400
+#define ES_PRE_WLD 36          // row stride of the LDS copies of Wedge (4 x 32 rows) and W1[:, 32:] (2 x 128 rows)
+
+__global__ void __launch_bounds__(256)
+escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int* __restrict__ dst, int E,
+                       float* __restrict__ pre) {
+  __shared__ __attribute__((aligned(16))) float wl[(4 * ES_D + 2 * ES_HC) * ES_PRE_WLD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  {
+    // Wedge_l rows 32 l + o, then W1_m[:, 32:] rows 128 + 128 m + o: 384 rows of 32 floats
+    const int q = tid & 7;
+    for (int row = tid >> 3; row < 4 * ES_D + 2 * ES_HC; row += 32) {
+      const float* sp = row < 4 * ES_D ? W.Wedge(row >> 5) + (size_t)(row & 31) * ES_D
+                                       : W.bW1((row - 4 * ES_D) >> 7) + (size_t)((row - 4 * ES_D) & 127) * (2 * ES_D) + ES_D;
+      *reinterpret_cast<float4*>(wl + row * ES_PRE_WLD + 4 * q) = *reinterpret_cast<const float4*>(sp + 4 * q);
+    }
+  }
+  const float* Wd = W.p[76]; const float* Wc = W.p[77];
+  const float* Win = W.p[78]; const float* bin = W.p[79]; const float* Wcm = W.p[80]; const float* bcm = W.p[81];
+  const float* Wp0 = W.p[82]; const float* bp0 = W.p[83]; const float* Wp1 = W.p[84]; const float* bp1 = W.p[85];
+  float wdv[16], wcv0[16], wcv1[16], wi[2][16], wcmA[2][16], wcmB[2][16], wp0[2][16], wp1[2][8];
+  es_ld16(Wd + 16 * (g & 1), wdv);
+  es_ld16(Wc, wcv0);
+  es_ld16(Wc + 16, wcv1);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int rowo = 16 * nt + c;
+    es_ld16(Win + (size_t)rowo * 64 + 16 * g, wi[nt]);
+    es_ld16(Wcm + (size_t)rowo * 128 + 32 * g, wcmA[nt]);
+    es_ld16(Wcm + (size_t)rowo * 128 + 32 * g + 16, wcmB[nt]);
+#pragma unroll
+    for (int e_ = 0; e_ < 2; ++e_)
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wp0[nt][(e_ * 2 + ot) * 4 + r] = Wp0[(size_t)rowo * 66 + 2 + 32 * e_ + 16 * ot + 4 * g + r];
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wp1[nt][n2 * 4 + r] = Wp1[(size_t)rowo * 32 + 16 * n2 + 4 * g + r];
+  }
+  const int ntile = (E + 15) >> 4;
+  const int rt = (int)blockIdx.x * 4 + wave;
+  const int e = 16 * rt + c;
+  const bool on = rt < ntile && e < E;
+  const int r_ = on ? max(src[e], 0) : 0, q_ = on ? max(dst[e], 0) : 0;
+  const float prx = geo.pos[3 * r_], pry = geo.pos[3 * r_ + 1], prz = geo.pos[3 * r_ + 2];
+  const float pcx = geo.pos[3 * q_], pcy = geo.pos[3 * q_ + 1], pcz = geo.pos[3 * q_ + 2];
+  float4 e2v[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+    e2v[nt] = on ? *reinterpret_cast<const float4*>(geo.e2d + (size_t)e * geo.ld_e2d + 16 * nt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();                                     // wl staged (every wave arrives, also those without a tile)
+  if (rt >= ntile) return;
+  // coord2basis and the frame coordinates of both endpoints: as edge_geometry_fwd_kernel (csrc/sde2d3d.hip)
+  float dx = prx - pcx, dy = pry - pcy, dz = prz - pcz;
+  float cx = pry * pcz - prz * pcy, cy = prz * pcx - prx * pcz, cz = prx * pcy - pry * pcx;
+  const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float nrm = dist + 1e-6f;
+  dx /= nrm; dy /= nrm; dz /= nrm;
+  const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
+  cx /= cn; cy /= cn; cz /= cn;
+  const float vx = dy * cz - dz * cy, vy = dz * cx - dx * cz, vz = dx * cy - dy * cx;
+  const float ci0 = dx * prx + dy * pry + dz * prz, ci1 = fabsf(cx * prx + cy * pry + cz * prz), ci2 = vx * prx + vy * pry + vz * prz;
+  const float cj0 = dx * pcx + dy * pcy + dz * pcz, cj1 = fabsf(cx * pcx + cy * pcy + cz * pcz), cj2 = vx * pcx + vy * pcy + vz * pcz;
+  const float ni = sqrtf(ci0 * ci0 + ci1 * ci1 + ci2 * ci2), nj = sqrtf(cj0 * cj0 + cj1 * cj1 + cj2 * cj2);
+  const float pcos = (ci0 * cj0 + ci1 * cj1 + ci2 * cj2) / (ni + 1e-6f) / (nj + 1e-6f);
+  const float psin = sqrtf(1.f - pcos * pcos);
+  float* prow = pre + (size_t)(on ? e : 0) * ES_PRE_LD;
+  if (g == 0 && on) {
+    float* b = prow + 384;
+    b[0] = dx; b[1] = dy; b[2] = dz; b[3] = cx; b[4] = cy; b[5] = cz; b[6] = vx; b[7] = vy; b[8] = vz;
+  }
+  // Gaussian-Fourier features as B operands on the transcendental unit (argument in revolutions; cos x = sin(x + 1/4))
+  const float qshift = (g & 1) ? 0.25f : 0.f;
+  auto four = [&](float x, float w) -> float { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(x, w, qshift))); };
+  const int nrow = 4 * g;                              // accumulator rows of this lane: outputs 16 nt + 4 g + r
+  es_f4 accI[2], accEi[2], accEj[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bin + 16 * nt + nrow), b1 = *reinterpret_cast<const float4*>(bcm + 16 * nt + nrow);
+    accI[nt] = es_f4{b0.x, b0.y, b0.z, b0.w};
+    accEi[nt] = es_f4{b1.x, b1.y, b1.z, b1.w};
+    accEj[nt] = accEi[nt];
+  }
+  if (geo.has_dist) {
+    // feat_d[k], k = 16 g + t: sin(dist Wd[k]) for k < 32, cos(dist Wd[k - 32]) above
+    const float dshift = g >= 2 ? 0.25f : 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float f = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(dist, wdv[t], dshift)));
+      accI[0] = es_mfma(wi[0][t], f, accI[0]);
+      accI[1] = es_mfma(wi[1][t], f, accI[1]);
+    }
+  }
+  {
+    // feat_i[k], k = 32 g + t: [sin(ci0 Wc) | cos(ci0 Wc) | sin(ci2 Wc) | cos(ci2 Wc)]; feat_j likewise
+    const float xi = g < 2 ? ci0 : ci2, xj = g < 2 ? cj0 : cj2;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float fi = four(xi, wcv0[t]), fj = four(xj, wcv0[t]);
+      accEi[0] = es_mfma(wcmA[0][t], fi, accEi[0]); accEi[1] = es_mfma(wcmA[1][t], fi, accEi[1]);
+      accEj[0] = es_mfma(wcmA[0][t], fj, accEj[0]); accEj[1] = es_mfma(wcmA[1][t], fj, accEj[1]);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float fi = four(xi, wcv1[t]), fj = four(xj, wcv1[t]);
+      accEi[0] = es_mfma(wcmB[0][t], fi, accEi[0]); accEi[1] = es_mfma(wcmB[1][t], fi, accEi[1]);
+      accEj[0] = es_mfma(wcmB[0][t], fj, accEj[0]); accEj[1] = es_mfma(wcmB[1][t], fj, accEj[1]);
+    }
+  }
+  es_f4 accH[2], accF[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bp0 + 16 * nt + nrow);
+    float hb[4] = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* wr = Wp0 + (size_t)(16 * nt + nrow + r) * 66;
+      hb[r] += wr[0] * psin + wr[1] * pcos;
+    }
+    accH[nt] = es_f4{hb[0], hb[1], hb[2], hb[3]};
+  }
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        accH[nt] = es_mfma(wp0[nt][ot * 4 + r], accEi[ot][r], accH[nt]);
+        accH[nt] = es_mfma(wp0[nt][(2 + ot) * 4 + r], accEj[ot][r], accH[nt]);
+      }
+    }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bp1 + 16 * nt + nrow);
+    accF[nt] = es_f4{b0.x, b0.y, b0.z, b0.w};
+  }
+#pragma unroll
+  for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float hz = accH[n2][r];
+      const float hv = hz * es_sigmoid(hz);
+      accF[0] = es_mfma(wp1[0][n2 * 4 + r], hv, accF[0]);
+      accF[1] = es_mfma(wp1[1][n2 * 4 + r], hv, accF[1]);
+    }
+  // edge_attr^T tile: feature 16 nt + 4 g + r of edge c -- the B operand of everything below (k <-> (nt, r), group g)
+  es_f4 eaT[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const float e2[4] = {e2v[nt].x, e2v[nt].y, e2v[nt].z, e2v[nt].w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) eaT[nt][r] = geo.has_dist ? fmaf(accI[nt][r], e2[r], accF[nt][r]) : e2[r] + accF[nt][r];
+  }
+  // 24 output tiles of 16 features: 8 of lin_edge (4 layers x 2), 16 of the basis MLPs' edge halves; weights from LDS
+#pragma unroll 2
+  for (int ot = 0; ot < 24; ++ot) {
+    const float* wr = wl + (16 * ot + c) * ES_PRE_WLD + 4 * g;
+    const float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 16);
+    es_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = es_mfma(w0.x, eaT[0][0], acc); acc = es_mfma(w0.y, eaT[0][1], acc);
+    acc = es_mfma(w0.z, eaT[0][2], acc); acc = es_mfma(w0.w, eaT[0][3], acc);
+    acc = es_mfma(w1.x, eaT[1][0], acc); acc = es_mfma(w1.y, eaT[1][1], acc);
+    acc = es_mfma(w1.z, eaT[1][2], acc); acc = es_mfma(w1.w, eaT[1][3], acc);
+    if (on) *reinterpret_cast<float4*>(prow + 16 * ot + nrow) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+template <bool TRAIN, bool GEO, bool PRE = false>
 __global__ void __launch_bounds__(256)
 escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const float* __restrict__ ea, int ld_ea,
                       const float* __restrict__ basis, const int* __restrict__ mol_ptr, int B, const int* __restrict__ rowptr,
@@ -119,7 +298,7 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
       *reinterpret_cast<float4*>(xs + row * ES_LDX + 4 * q) = v;
       *reinterpret_cast<float4*>(att + row * ES_LDX + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (ea_lds && !GEO)
+    if (ea_lds && !GEO && !PRE)
       for (int row = tid >> 3; row < Em; row += 32)
         *reinterpret_cast<float4*>(eal + row * ES_LDX + 4 * q) =
             *reinterpret_cast<const float4*>(ea + ((size_t)e0 + row) * ld_ea + 4 * q);
@@ -276,6 +455,7 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
     ES_STAMP(41);
   }
 
+  int rp_first_chunk = 0;                              // PRE: edges of the first attention chunk (targets 0 .. es_chunk_end)
 #pragma unroll 1
   for (int layer = 0; layer < ES_LAYERS; ++layer) {
     const int mi = layer >> 1, ci = layer & 1;
@@ -284,7 +464,19 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
 #pragma unroll
     for (int t = 0; t < 8; ++t) { wq[0][t] = R.wq[0][t]; wq[1][t] = R.wq[1][t]; we[t] = R.we[t]; w0[t] = R.w0[t]; w3[t] = R.w3[t]; }
     bq[0] = R.bq[0]; bq[1] = R.bq[1];
+    // PRE: lin_edge(edge_attr) of this layer was computed by escore_edge_pre_kernel -- the rows of the first chunk are requested
+    // here and land in LDS behind the q|k|v|skip product
     __syncthreads();                                   // xs (first layer: + the staged inputs) visible
+    float4 pf[PRE ? ES_ECH / 32 : 1];
+    if (PRE) {
+      if (layer == 0) rp_first_chunk = rp[es_chunk_end(rp, 0, n)];
+#pragma unroll
+      for (int u = 0; u < ES_ECH / 32; ++u) {
+        const int el = (tid >> 3) + 32 * u;
+        pf[u] = el < rp_first_chunk ? *reinterpret_cast<const float4*>(ea + ((size_t)e0 + el) * ld_ea + ES_D * layer + 4 * (tid & 7))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     ES_STAMP(1 + 8 * layer);
     // qkvs = xs Wqkvs^T + b (rows >= n hold the bias: finite, never read); the wave's two column tiles are independent chains
     {
@@ -307,8 +499,10 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
     // which halves the per-edge product (K = 32) -- b1w: the edge half as A fragments, wp: the atom half as B fragments
     float b1w[8][8], wp[2][8], pb1 = 0.f, pw2a = 0.f, pw2b = 0.f;
     if (ci == 1) {
+      if (!PRE) {
 #pragma unroll
-      for (int ht = 0; ht < 8; ++ht) es_ld8(W.bW1(mi) + (size_t)(16 * ht + c) * (2 * ES_D) + ES_D + 8 * g, b1w[ht]);
+        for (int ht = 0; ht < 8; ++ht) es_ld8(W.bW1(mi) + (size_t)(16 * ht + c) * (2 * ES_D) + ES_D + 8 * g, b1w[ht]);
+      }
 #pragma unroll
       for (int cti = 0; cti < 2; ++cti) es_ld8(W.bW1(mi) + (size_t)(32 * wave + 16 * cti + c) * (2 * ES_D) + 8 * g, wp[cti]);
       if (tid < ES_HC) pb1 = W.bb1(mi)[tid];
@@ -323,7 +517,19 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
       const int ce0 = rp[t0], cn = rp[t1] - ce0;
       // ee[0 .. cn) = edge_attr[ce0 .. ce0 + cn) Wedge^T: wave -> column tile wave & 1, row tiles wave >> 1, + 2, ...
       // (two tiles per trip: independent MFMA chains)
-      {
+      if (PRE) {
+        if (t0 == 0) {
+#pragma unroll
+          for (int u = 0; u < ES_ECH / 32; ++u) {
+            const int el = (tid >> 3) + 32 * u;
+            if (el < cn) *reinterpret_cast<float4*>(ee + el * ES_LDX + 4 * (tid & 7)) = pf[u];
+          }
+        } else {
+          for (int el = tid >> 3; el < cn; el += 32)
+            *reinterpret_cast<float4*>(ee + el * ES_LDX + 4 * (tid & 7)) =
+                *reinterpret_cast<const float4*>(ea + ((size_t)e0 + ce0 + el) * ld_ea + ES_D * layer + 4 * (tid & 7));
+        }
+      } else {
         const int ct = wave & 1, ntile = (cn + 15) >> 4;
         for (int rt = wave >> 1; rt < ntile; rt += 4) {
           const int el0 = 16 * rt + c, el1 = el0 + 32;
@@ -503,27 +709,41 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
         const bool on = el < Em;
         float bs[9];
         if (g == 0) {                                    // lanes that will hold the edge's three coefficients
-          const float* bp = GEO ? bas + 9 * (on ? el : 0) : basis + 9 * ((size_t)e0 + (on ? el : 0));
+          const float* bp = PRE ? ea + ((size_t)e0 + (on ? el : 0)) * ld_ea + 384
+                                : GEO ? bas + 9 * (on ? el : 0) : basis + 9 * ((size_t)e0 + (on ? el : 0));
 #pragma unroll
           for (int k = 0; k < 9; ++k) bs[k] = bp[k];
         }
         float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* pj = qk + (on ? sl[el] : 0) * ES_LDQ + 4 * g;
         const float* pi = qk + (on ? dl[el] : 0) * ES_LDQ + 4 * g;
-        if (on) {
+        if (on && !PRE) {
           if (ea_lds) es_ld8(eal + el * ES_LDX + 8 * g, a);
           else es_ld8(ea + ((size_t)e0 + el) * ld_ea + 8 * g, a);
         }
         es_f4 acc[8];
+        if (PRE) {
+          // the edge half of the hidden layer comes precomputed: hidden 16 ht + 4 g + r of edge c = one float4 of its row
+          const float* zr = ea + ((size_t)e0 + (on ? el : 0)) * ld_ea + 4 * ES_D + ES_HC * mi + 4 * g;
+          float4 z4[8];
 #pragma unroll
-        for (int ht = 0; ht < 8; ++ht) {
-          const float4 u = *reinterpret_cast<const float4*>(pj + 16 * ht), w = *reinterpret_cast<const float4*>(pi + 16 * ht);
-          acc[ht] = es_f4{u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w};
+          for (int ht = 0; ht < 8; ++ht) z4[ht] = *reinterpret_cast<const float4*>(zr + 16 * ht);
+#pragma unroll
+          for (int ht = 0; ht < 8; ++ht) {
+            const float4 u = *reinterpret_cast<const float4*>(pj + 16 * ht), w = *reinterpret_cast<const float4*>(pi + 16 * ht);
+            acc[ht] = es_f4{(u.x + w.x) + z4[ht].x, (u.y + w.y) + z4[ht].y, (u.z + w.z) + z4[ht].z, (u.w + w.w) + z4[ht].w};
+          }
+        } else {
+#pragma unroll
+          for (int ht = 0; ht < 8; ++ht) {
+            const float4 u = *reinterpret_cast<const float4*>(pj + 16 * ht), w = *reinterpret_cast<const float4*>(pi + 16 * ht);
+            acc[ht] = es_f4{u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w};
+          }
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int ht = 0; ht < 8; ++ht) acc[ht] = es_mfma(b1w[ht][t], a[t], acc[ht]);
         }
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int ht = 0; ht < 8; ++ht) acc[ht] = es_mfma(b1w[ht][t], a[t], acc[ht]);
         es_f4 cf = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ht = 0; ht < 8; ++ht) {
@@ -594,16 +814,31 @@ extern "C" int msde_escore_mol_fwd(const void* const* params, const float* x0, c
 // the 76 of msde_escore_mol_fwd + [dist_gaussian_fourier.W (unused when has_dist = 0), coff_gaussian_fourier.W, input_mlp weight
 // [32,64] / bias, coff_mlp weight [32,128] / bias, project[0] weight [32,66] / bias, project[1] weight [32,32] / bias].
 // Molecules of at most 20 atoms (<= 384 extended edges: they stay in LDS).
+extern "C" long long msde_escore_mol_score_scratch_floats(int E) { return (long long)E * ES_PRE_LD; }
+
 extern "C" int msde_escore_mol_score(const void* const* params, const float* x0, const float* pos, const float* edge_2D,
                                      int ld_e2d, int has_dist, const int* mol_ptr, int B, const int* rowptr, const int* src,
                                      const int* dst, int N, int E, int hidden, int heads, int hidden_coff, int n_max, float eps1,
-                                     float eps2, float* out, void* stream) {
+                                     float eps2, float* scratch, float* out, void* stream) {
   if (!params || !x0 || !pos || !edge_2D || !mol_ptr || !rowptr || !src || !dst || !out || N < 0 || B < 0 || E < 0) return MSDE_EINVAL;
-  if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC || n_max > 20) return MSDE_EUNSUP;
+  if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC || n_max > (scratch ? ES_NMAX : 20)) return MSDE_EUNSUP;
   if (ld_e2d < ES_D || ld_e2d % 4 || (reinterpret_cast<uintptr_t>(edge_2D) & 15) || (reinterpret_cast<uintptr_t>(x0) & 15)) return MSDE_EINVAL;
+  if (scratch && (reinterpret_cast<uintptr_t>(scratch) & 15)) return MSDE_EINVAL;
   EsW W{reinterpret_cast<const float* const*>(params)};
   if (N == 0 || B == 0) return 0;
   const EsGeo geo{pos, edge_2D, ld_e2d, has_dist};
+  if (scratch) {
+    // two launches: everything per EDGE in a wide one (one wave per 16 edges), the per-molecule chain behind it
+    if (E > 0)
+      MSDE_LAUNCH(escore_edge_pre_kernel, dim3((unsigned)(((E + 15) / 16 + 3) / 4)), dim3(256), 0, as_stream(stream), W, geo, src, dst, E,
+                  scratch);
+    const EsGeo nogeo{nullptr, nullptr, 0, 0};
+    MSDE_LAUNCH((escore_mol_fwd_kernel<false, false, true>), dim3(B), dim3(256), 0, as_stream(stream), W, nogeo, x0,
+                (const float*)scratch, ES_PRE_LD, (const float*)nullptr, mol_ptr, B, rowptr, src, dst, N, 0.f, 0.f, 0ull,
+                (const unsigned long long*)nullptr, eps1, eps2, out, (float*)nullptr);
+    MSDE_CHECK_LAUNCH();
+    return 0;
+  }
   MSDE_LAUNCH((escore_mol_fwd_kernel<false, true>), dim3(B), dim3(256), 0, as_stream(stream), W, geo, x0, (const float*)nullptr, ES_D,
               (const float*)nullptr, mol_ptr, B, rowptr, src, dst, N, 0.f, 0.f, 0ull, (const unsigned long long*)nullptr, eps1, eps2, out,
               (float*)nullptr);
