@@ -811,10 +811,9 @@ int msde_escore_mol_fwd(const void* const* params, const float* x0, const float*
  * (any valid pointer when has_dist = 0), coff_gaussian_fourier.W [32], input_mlp weight [32,64] / bias, coff_mlp weight [32,128]
  * / bias, project[0] weight [32,66] / bias, project[1] weight [32,32] / bias.  has_dist = 0: the _01 model (no distance
  * branch).  n_max: the largest molecule of the batch.
- *   scratch != NULL (msde_escore_mol_score_scratch_floats(E) floats, 16-byte aligned): TWO launches -- everything that depends
- *     on an edge alone (edge features, lin_edge of the four layers, the edge half of both basis MLPs' first Linear) in a wide
- *     launch, one wave per 16 edges; then one workgroup per molecule.  Molecules of <= 32 atoms.
- *   scratch == NULL: ONE launch, the edge features built in the per-molecule kernel's prologue; MSDE_EUNSUP above 20 atoms. */
+ * scratch: msde_escore_mol_score_scratch_floats(E) floats, 16-byte aligned.  TWO launches: everything that depends on an edge
+ * alone (edge features, lin_edge of the four layers, the edge half of both basis MLPs' first Linear) in a wide launch, one wave
+ * per 16 edges, into `scratch`; then one workgroup per molecule.  Molecules of <= 32 atoms (MSDE_EUNSUP above). */
 long long msde_escore_mol_score_scratch_floats(int E);
 int msde_escore_mol_score(const void* const* params, const float* x0, const float* pos, const float* edge_2D, int ld_e2d,
                           int has_dist, const int* mol_ptr, int B, const int* rowptr, const int* src, const int* dst, int N, int E,

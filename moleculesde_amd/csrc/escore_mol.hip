@@ -62,11 +62,9 @@ extern "C" int msde_escore_debug_stamps(long long* host) {
 }
 #endif
 
-// GEO (inference, get_score): the edge features are not read but BUILT here from the perturbed coordinates -- per-edge SE(3)
-// frame, distance and frame coordinates, their Gaussian-Fourier features, input_mlp / coff_mlp / project and
-// edge_attr = input_mlp(.) * edge_2D + project(.) (SDE_model_2D_to_3D.py:342-369,423-432; the ~7 launches of
-// hip.edge_geometry_stacked / frame_mlp / mul_add) -- as a prologue over the molecule's edge tiles, everything TRANSPOSED
-// (lane = edge): the features of a lane's own edge are the B operand, each product's accumulator tile is the next one's.
+// Inputs of the edge features of get_score: per-edge SE(3) frame, distance and frame coordinates, their Gaussian-Fourier
+// features, input_mlp / coff_mlp / project and edge_attr = input_mlp(.) * edge_2D + project(.)
+// (SDE_model_2D_to_3D.py:342-369,423-432; the ~7 launches of hip.edge_geometry_stacked / frame_mlp / mul_add).
 struct EsGeo {
   const float* pos;             // [N, 3] perturbed coordinates
   const float* e2d;             // [E, ld] edge_2D_emb of the node pairs (coordinate independent, computed once per representation)
@@ -77,8 +75,8 @@ struct EsGeo {
 // ---- get_score in two launches (inference) ---------------------------------------------------------------------------------
 // Everything of the score network that depends on an EDGE alone is hoisted out of the per-molecule latency chain into a wide
 // launch (one wave per 16 edges, any number of workgroups -- the sampler's ten molecules keep ten CUs busy, its 1 820 edges
-// fill 114 waves): the edge features (frame, Fourier features, input_mlp / coff_mlp / project, as in the GEO prologue below),
-// then lin_edge of all four GAT layers and the edge half of both basis MLPs' first Linear.  Row e of `pre` (ES_PRE_LD floats):
+// fill 114 waves): the edge features (frame, Fourier features, input_mlp / coff_mlp / project), everything TRANSPOSED (lane =
+// edge: the features of a lane's own edge are the B operand, each product's accumulator tile is the next one's), then lin_edge of all four GAT layers and the edge half of both basis MLPs' first Linear.  Row e of `pre` (ES_PRE_LD floats):
 //   [0, 128)    lin_edge_l(edge_attr), l = 0..3           (what the attention of layer l adds to k_j and v_j)
 //   [128, 384)  W1_m[:, 32:] edge_attr, m = 0, 1          (the edge part of the basis MLP's hidden layer, no bias)
 //   [384, 393)  the three frame vectors
@@ -91,6 +89,7 @@ escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int*
                        float* __restrict__ pre) {
   __shared__ __attribute__((aligned(16))) float wl[(4 * ES_D + 2 * ES_HC) * ES_PRE_WLD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  ES_STAMP(50);
   {
     // Wedge_l rows 32 l + o, then W1_m[:, 32:] rows 128 + 128 m + o: 384 rows of 32 floats
     const int q = tid & 7;
@@ -135,7 +134,9 @@ escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int*
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
     e2v[nt] = on ? *reinterpret_cast<const float4*>(geo.e2d + (size_t)e * geo.ld_e2d + 16 * nt + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+  ES_STAMP(51);
   __syncthreads();                                     // wl staged (every wave arrives, also those without a tile)
+  ES_STAMP(52);
   if (rt >= ntile) return;
   // coord2basis and the frame coordinates of both endpoints: as edge_geometry_fwd_kernel (csrc/sde2d3d.hip)
   float dx = prx - pcx, dy = pry - pcy, dz = prz - pcz;
@@ -230,6 +231,7 @@ escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int*
       accF[0] = es_mfma(wp1[0][n2 * 4 + r], hv, accF[0]);
       accF[1] = es_mfma(wp1[1][n2 * 4 + r], hv, accF[1]);
     }
+  ES_STAMP(53);
   // edge_attr^T tile: feature 16 nt + 4 g + r of edge c -- the B operand of everything below (k <-> (nt, r), group g)
   es_f4 eaT[2];
 #pragma unroll
@@ -250,11 +252,12 @@ escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int*
     acc = es_mfma(w1.z, eaT[1][2], acc); acc = es_mfma(w1.w, eaT[1][3], acc);
     if (on) *reinterpret_cast<float4*>(prow + 16 * ot + nrow) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
+  ES_STAMP(54);
 }
 
-template <bool TRAIN, bool GEO, bool PRE = false>
+template <bool TRAIN, bool PRE = false>
 __global__ void __launch_bounds__(256)
-escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const float* __restrict__ ea, int ld_ea,
+escore_mol_fwd_kernel(EsW W, const float* __restrict__ x0, const float* __restrict__ ea, int ld_ea,
                       const float* __restrict__ basis, const int* __restrict__ mol_ptr, int B, const int* __restrict__ rowptr,
                       const int* __restrict__ src, const int* __restrict__ dst, int N, float p_att, float p_ffn,
                       unsigned long long seed0, const unsigned long long* __restrict__ seed_dev, float eps1, float eps2,
@@ -269,8 +272,6 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
   __shared__ float gacc[ES_NMAX * 3];
   __shared__ int rp[ES_NMAX + 1];
   __shared__ unsigned char sl[ES_EMAX + 16], dl[ES_EMAX + 16];              // molecule-local source / target of every edge
-  __shared__ float bas[GEO ? ES_EAL * 9 : 1];                               // GEO: the frame vectors of every edge
-  __shared__ float posl[GEO ? ES_NMAX * 3 : 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   ES_STAMP(0);
   {
@@ -282,7 +283,7 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
   if (n <= 0) return;
   EsLayerRegs R;
   es_load_layer(W, 0, tid, R);
-  const int e0 = rowptr[n0], Em = min(rowptr[n0 + n] - e0, GEO ? ES_EAL : ES_EMAX);
+  const int e0 = rowptr[n0], Em = min(rowptr[n0 + n] - e0, ES_EMAX);
   const bool ea_lds = Em <= ES_EAL;
   const unsigned long long sdev = seed_dev ? seed_dev[0] * 0x100000001B3ull : 0ull;
   for (int t = tid; t <= n; t += 256) rp[t] = rowptr[n0 + t] - e0;
@@ -298,163 +299,13 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
       *reinterpret_cast<float4*>(xs + row * ES_LDX + 4 * q) = v;
       *reinterpret_cast<float4*>(att + row * ES_LDX + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (ea_lds && !GEO && !PRE)
+    if (ea_lds && !PRE)
       for (int row = tid >> 3; row < Em; row += 32)
         *reinterpret_cast<float4*>(eal + row * ES_LDX + 4 * q) =
             *reinterpret_cast<const float4*>(ea + ((size_t)e0 + row) * ld_ea + 4 * q);
   }
   if (tid < ES_NMAX * 3) gacc[tid] = 0.f;
   const int c = lane & 15, g = lane >> 4;
-  if (GEO) {
-    if (tid < n * 3) posl[tid] = geo.pos[(size_t)n0 * 3 + tid];
-    // weights as A operands (lane m = output row c of a 16-row tile, k-group g); Fourier frequencies of the lane's k-group
-    const float* Wd = W.p[76]; const float* Wc = W.p[77];
-    const float* Win = W.p[78]; const float* bin = W.p[79]; const float* Wcm = W.p[80]; const float* bcm = W.p[81];
-    const float* Wp0 = W.p[82]; const float* bp0 = W.p[83]; const float* Wp1 = W.p[84]; const float* bp1 = W.p[85];
-    float wdv[16], wcv0[16], wcv1[16], wi[2][16], wcmA[2][16], wcmB[2][16], wp0[2][16], wp1[2][8];
-    es_ld16(Wd + 16 * (g & 1), wdv);
-    es_ld16(Wc, wcv0);
-    es_ld16(Wc + 16, wcv1);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int rowo = 16 * nt + c;
-      es_ld16(Win + (size_t)rowo * 64 + 16 * g, wi[nt]);
-      es_ld16(Wcm + (size_t)rowo * 128 + 32 * g, wcmA[nt]);
-      es_ld16(Wcm + (size_t)rowo * 128 + 32 * g + 16, wcmB[nt]);
-#pragma unroll
-      for (int e_ = 0; e_ < 2; ++e_)
-#pragma unroll
-        for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) wp0[nt][(e_ * 2 + ot) * 4 + r] = Wp0[(size_t)rowo * 66 + 2 + 32 * e_ + 16 * ot + 4 * g + r];
-#pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wp1[nt][n2 * 4 + r] = Wp1[(size_t)rowo * 32 + 16 * n2 + 4 * g + r];
-    }
-    __syncthreads();                                   // sl / dl / posl staged
-    const int ntile = (Em + 15) >> 4;
-    for (int rt = wave; rt < ntile; rt += 4) {
-      const int el = 16 * rt + c;
-      const bool on = el < Em;
-      const int r_ = on ? sl[el] : 0, q_ = on ? dl[el] : 0;
-      const float prx = posl[3 * r_], pry = posl[3 * r_ + 1], prz = posl[3 * r_ + 2];
-      const float pcx = posl[3 * q_], pcy = posl[3 * q_ + 1], pcz = posl[3 * q_ + 2];
-      // coord2basis and the frame coordinates of both endpoints: as edge_geometry_fwd_kernel (csrc/sde2d3d.hip)
-      float dx = prx - pcx, dy = pry - pcy, dz = prz - pcz;
-      float cx = pry * pcz - prz * pcy, cy = prz * pcx - prx * pcz, cz = prx * pcy - pry * pcx;
-      const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-      const float nrm = dist + 1e-6f;
-      dx /= nrm; dy /= nrm; dz /= nrm;
-      const float cn = sqrtf(cx * cx + cy * cy + cz * cz) + 1e-6f;
-      cx /= cn; cy /= cn; cz /= cn;
-      const float vx = dy * cz - dz * cy, vy = dz * cx - dx * cz, vz = dx * cy - dy * cx;
-      const float ci0 = dx * prx + dy * pry + dz * prz, ci1 = fabsf(cx * prx + cy * pry + cz * prz), ci2 = vx * prx + vy * pry + vz * prz;
-      const float cj0 = dx * pcx + dy * pcy + dz * pcz, cj1 = fabsf(cx * pcx + cy * pcy + cz * pcz), cj2 = vx * pcx + vy * pcy + vz * pcz;
-      const float ni = sqrtf(ci0 * ci0 + ci1 * ci1 + ci2 * ci2), nj = sqrtf(cj0 * cj0 + cj1 * cj1 + cj2 * cj2);
-      const float pcos = (ci0 * cj0 + ci1 * cj1 + ci2 * cj2) / (ni + 1e-6f) / (nj + 1e-6f);
-      const float psin = sqrtf(1.f - pcos * pcos);
-      if (g == 0 && on) {
-        float* b = bas + 9 * el;
-        b[0] = dx; b[1] = dy; b[2] = dz; b[3] = cx; b[4] = cy; b[5] = cz; b[6] = vx; b[7] = vy; b[8] = vz;
-      }
-      // Gaussian-Fourier features as B operands: sin / cos of (x W 2 pi) on the transcendental unit (argument in revolutions)
-      const bool use_cos = g & 1;
-      auto four = [&](float x, float w) -> float {
-        const float t = __builtin_amdgcn_fractf(x * w);
-        return use_cos ? __builtin_amdgcn_cosf(t) : __builtin_amdgcn_sinf(t);
-      };
-      const int nrow = 4 * g;                          // accumulator rows of this lane: outputs 16 nt + 4 g + r
-      es_f4 accI[2], accEi[2], accEj[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float4 b0 = *reinterpret_cast<const float4*>(bin + 16 * nt + nrow), b1 = *reinterpret_cast<const float4*>(bcm + 16 * nt + nrow);
-        accI[nt] = es_f4{b0.x, b0.y, b0.z, b0.w};
-        accEi[nt] = es_f4{b1.x, b1.y, b1.z, b1.w};
-        accEj[nt] = accEi[nt];
-      }
-      if (geo.has_dist) {
-        // feat_d[k], k = 16 g + t: sin(dist Wd[k]) for k < 32, cos(dist Wd[k - 32]) above (use_cos here means g >= 2)
-        const bool dcos = g >= 2;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const float ph = __builtin_amdgcn_fractf(dist * wdv[t]);
-          const float f = dcos ? __builtin_amdgcn_cosf(ph) : __builtin_amdgcn_sinf(ph);
-          accI[0] = es_mfma(wi[0][t], f, accI[0]);
-          accI[1] = es_mfma(wi[1][t], f, accI[1]);
-        }
-      }
-      {
-        // feat_i[k], k = 32 g + t: [sin(ci0 Wc) | cos(ci0 Wc) | sin(ci2 Wc) | cos(ci2 Wc)]; feat_j likewise
-        const float xi = g < 2 ? ci0 : ci2, xj = g < 2 ? cj0 : cj2;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const float fi = four(xi, wcv0[t]), fj = four(xj, wcv0[t]);
-          accEi[0] = es_mfma(wcmA[0][t], fi, accEi[0]); accEi[1] = es_mfma(wcmA[1][t], fi, accEi[1]);
-          accEj[0] = es_mfma(wcmA[0][t], fj, accEj[0]); accEj[1] = es_mfma(wcmA[1][t], fj, accEj[1]);
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const float fi = four(xi, wcv1[t]), fj = four(xj, wcv1[t]);
-          accEi[0] = es_mfma(wcmB[0][t], fi, accEi[0]); accEi[1] = es_mfma(wcmB[1][t], fi, accEi[1]);
-          accEj[0] = es_mfma(wcmB[0][t], fj, accEj[0]); accEj[1] = es_mfma(wcmB[1][t], fj, accEj[1]);
-        }
-      }
-      // project[0] on [pseudo_sin, pseudo_cos, embed_i, embed_j]: the two angle columns on the vector unit, the rest with the
-      // embedding tiles as B operands (k = 16 ot + 4 g + r <-> step (ot, r))
-      es_f4 accH[2], accF[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float4 b0 = *reinterpret_cast<const float4*>(bp0 + 16 * nt + nrow);
-        float hb[4] = {b0.x, b0.y, b0.z, b0.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* wr = Wp0 + (size_t)(16 * nt + nrow + r) * 66;
-          hb[r] += wr[0] * psin + wr[1] * pcos;
-        }
-        accH[nt] = es_f4{hb[0], hb[1], hb[2], hb[3]};
-      }
-#pragma unroll
-      for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            accH[nt] = es_mfma(wp0[nt][ot * 4 + r], accEi[ot][r], accH[nt]);
-            accH[nt] = es_mfma(wp0[nt][(2 + ot) * 4 + r], accEj[ot][r], accH[nt]);
-          }
-        }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const float4 b0 = *reinterpret_cast<const float4*>(bp1 + 16 * nt + nrow);
-        accF[nt] = es_f4{b0.x, b0.y, b0.z, b0.w};
-      }
-#pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float hz = accH[n2][r];
-          const float hv = hz * es_sigmoid(hz);
-          accF[0] = es_mfma(wp1[0][n2 * 4 + r], hv, accF[0]);
-          accF[1] = es_mfma(wp1[1][n2 * 4 + r], hv, accF[1]);
-        }
-      if (on) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const float4 e2 = *reinterpret_cast<const float4*>(geo.e2d + ((size_t)e0 + el) * geo.ld_e2d + 16 * nt + nrow);
-          float4 v;
-          if (geo.has_dist)
-            v = make_float4(fmaf(accI[nt][0], e2.x, accF[nt][0]), fmaf(accI[nt][1], e2.y, accF[nt][1]),
-                            fmaf(accI[nt][2], e2.z, accF[nt][2]), fmaf(accI[nt][3], e2.w, accF[nt][3]));
-          else
-            v = make_float4(e2.x + accF[nt][0], e2.y + accF[nt][1], e2.z + accF[nt][2], e2.w + accF[nt][3]);
-          *reinterpret_cast<float4*>(eal + el * ES_LDX + 16 * nt + nrow) = v;
-        }
-      }
-    }
-    ES_STAMP(41);
-  }
-
   int rp_first_chunk = 0;                              // PRE: edges of the first attention chunk (targets 0 .. es_chunk_end)
 #pragma unroll 1
   for (int layer = 0; layer < ES_LAYERS; ++layer) {
@@ -709,8 +560,7 @@ escore_mol_fwd_kernel(EsW W, EsGeo geo, const float* __restrict__ x0, const floa
         const bool on = el < Em;
         float bs[9];
         if (g == 0) {                                    // lanes that will hold the edge's three coefficients
-          const float* bp = PRE ? ea + ((size_t)e0 + (on ? el : 0)) * ld_ea + 384
-                                : GEO ? bas + 9 * (on ? el : 0) : basis + 9 * ((size_t)e0 + (on ? el : 0));
+          const float* bp = PRE ? ea + ((size_t)e0 + (on ? el : 0)) * ld_ea + 384 : basis + 9 * ((size_t)e0 + (on ? el : 0));
 #pragma unroll
           for (int k = 0; k < 9; ++k) bs[k] = bp[k];
         }
@@ -797,51 +647,41 @@ extern "C" int msde_escore_mol_fwd(const void* const* params, const float* x0, c
   if (saved && (reinterpret_cast<uintptr_t>(saved) & 15)) return MSDE_EINVAL;
   EsW W{reinterpret_cast<const float* const*>(params)};
   if (N == 0 || B == 0) return 0;
-  const EsGeo nogeo{nullptr, nullptr, 0, 0};
   if (saved)
-    MSDE_LAUNCH((escore_mol_fwd_kernel<true, false>), dim3(B), dim3(256), 0, as_stream(stream), W, nogeo, x0, edge_attr, ld_ea, basis,
+    MSDE_LAUNCH((escore_mol_fwd_kernel<true, false>), dim3(B), dim3(256), 0, as_stream(stream), W, x0, edge_attr, ld_ea, basis,
                 mol_ptr, B, rowptr, src, dst, N, p_att, p_ffn, seed0, seed_dev, eps1, eps2, out, saved);
   else
-    MSDE_LAUNCH((escore_mol_fwd_kernel<false, false>), dim3(B), dim3(256), 0, as_stream(stream), W, nogeo, x0, edge_attr, ld_ea, basis,
+    MSDE_LAUNCH((escore_mol_fwd_kernel<false, false>), dim3(B), dim3(256), 0, as_stream(stream), W, x0, edge_attr, ld_ea, basis,
                 mol_ptr, B, rowptr, src, dst, N, p_att, p_ffn, seed0, seed_dev, eps1, eps2, out, saved);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
 
-// get_score in one launch (SDE_model_2D_to_3D.py:393-445 up to the division by -std): the edge features are built inside the
-// kernel from the perturbed coordinates `pos` and the coordinate-independent `edge_2D` rows (template parameter GEO above), then
-// the score network runs as in msde_escore_mol_fwd (inference: no dropout, nothing saved).  params: DEVICE array of 86 pointers =
-// the 76 of msde_escore_mol_fwd + [dist_gaussian_fourier.W (unused when has_dist = 0), coff_gaussian_fourier.W, input_mlp weight
-// [32,64] / bias, coff_mlp weight [32,128] / bias, project[0] weight [32,66] / bias, project[1] weight [32,32] / bias].
-// Molecules of at most 20 atoms (<= 384 extended edges: they stay in LDS).
+// get_score up to the division by -std (SDE_model_2D_to_3D.py:393-445) in two launches: escore_edge_pre_kernel fills `scratch`
+// (msde_escore_mol_score_scratch_floats(E) floats), the per-molecule kernel (PRE) consumes it; inference: no dropout, nothing
+// saved.  params: DEVICE array of 86 pointers = the 76 of msde_escore_mol_fwd + [dist_gaussian_fourier.W (unused when has_dist =
+// 0), coff_gaussian_fourier.W, input_mlp weight [32,64] / bias, coff_mlp weight [32,128] / bias, project[0] weight [32,66] / bias,
+// project[1] weight [32,32] / bias].
 extern "C" long long msde_escore_mol_score_scratch_floats(int E) { return (long long)E * ES_PRE_LD; }
 
 extern "C" int msde_escore_mol_score(const void* const* params, const float* x0, const float* pos, const float* edge_2D,
                                      int ld_e2d, int has_dist, const int* mol_ptr, int B, const int* rowptr, const int* src,
                                      const int* dst, int N, int E, int hidden, int heads, int hidden_coff, int n_max, float eps1,
                                      float eps2, float* scratch, float* out, void* stream) {
-  if (!params || !x0 || !pos || !edge_2D || !mol_ptr || !rowptr || !src || !dst || !out || N < 0 || B < 0 || E < 0) return MSDE_EINVAL;
-  if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC || n_max > (scratch ? ES_NMAX : 20)) return MSDE_EUNSUP;
-  if (ld_e2d < ES_D || ld_e2d % 4 || (reinterpret_cast<uintptr_t>(edge_2D) & 15) || (reinterpret_cast<uintptr_t>(x0) & 15)) return MSDE_EINVAL;
-  if (scratch && (reinterpret_cast<uintptr_t>(scratch) & 15)) return MSDE_EINVAL;
+  if (!params || !x0 || !pos || !edge_2D || !mol_ptr || !rowptr || !src || !dst || !out || !scratch || N < 0 || B < 0 || E < 0)
+    return MSDE_EINVAL;
+  if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC || n_max > ES_NMAX) return MSDE_EUNSUP;
+  if (ld_e2d < ES_D || ld_e2d % 4 || ((reinterpret_cast<uintptr_t>(edge_2D) | reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(scratch)) & 15))
+    return MSDE_EINVAL;
   EsW W{reinterpret_cast<const float* const*>(params)};
   if (N == 0 || B == 0) return 0;
   const EsGeo geo{pos, edge_2D, ld_e2d, has_dist};
-  if (scratch) {
-    // two launches: everything per EDGE in a wide one (one wave per 16 edges), the per-molecule chain behind it
-    if (E > 0)
-      MSDE_LAUNCH(escore_edge_pre_kernel, dim3((unsigned)(((E + 15) / 16 + 3) / 4)), dim3(256), 0, as_stream(stream), W, geo, src, dst, E,
-                  scratch);
-    const EsGeo nogeo{nullptr, nullptr, 0, 0};
-    MSDE_LAUNCH((escore_mol_fwd_kernel<false, false, true>), dim3(B), dim3(256), 0, as_stream(stream), W, nogeo, x0,
-                (const float*)scratch, ES_PRE_LD, (const float*)nullptr, mol_ptr, B, rowptr, src, dst, N, 0.f, 0.f, 0ull,
-                (const unsigned long long*)nullptr, eps1, eps2, out, (float*)nullptr);
-    MSDE_CHECK_LAUNCH();
-    return 0;
-  }
-  MSDE_LAUNCH((escore_mol_fwd_kernel<false, true>), dim3(B), dim3(256), 0, as_stream(stream), W, geo, x0, (const float*)nullptr, ES_D,
-              (const float*)nullptr, mol_ptr, B, rowptr, src, dst, N, 0.f, 0.f, 0ull, (const unsigned long long*)nullptr, eps1, eps2, out,
-              (float*)nullptr);
+  if (E > 0)
+    MSDE_LAUNCH(escore_edge_pre_kernel, dim3((unsigned)(((E + 15) / 16 + 3) / 4)), dim3(256), 0, as_stream(stream), W, geo, src, dst, E,
+                scratch);
+  MSDE_LAUNCH((escore_mol_fwd_kernel<false, true>), dim3(B), dim3(256), 0, as_stream(stream), W, x0, (const float*)scratch, ES_PRE_LD,
+              (const float*)nullptr, mol_ptr, B, rowptr, src, dst, N, 0.f, 0.f, 0ull, (const unsigned long long*)nullptr, eps1, eps2,
+              out, (float*)nullptr);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

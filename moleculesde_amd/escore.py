@@ -80,15 +80,11 @@ def forward_nograd(net, ep, pl, node_attr, edge_attr, basis, seed0, seed_dev):
     return out
 
 
-SCORE_TWO_LAUNCHES = True  # msde_escore_mol_score: per-edge work in a wide launch + the per-molecule chain (False: one launch, <= 20 atoms)
-SCORE_NMAX = 20            # the one-launch form: <= 384 extended edges per molecule stay in LDS
-
-
 def score_supported(model, pl):
-    """msde_escore_mol_score: what `supported` asks of the score network (one-launch form: at most 20 atoms), and the
+    """msde_escore_mol_score: what `supported` asks of the score network (molecules of at most 32 atoms), and the
     coordinate branch in the reference's shape (input_mlp one Linear, project Linear -> SiLU -> Linear, no dropout)."""
     net = model.score_network
-    if not supported(net, pl) or pl.N_max > (NMAX if SCORE_TWO_LAUNCHES else SCORE_NMAX) or model.hidden_dim != 32:
+    if not supported(net, pl) or model.hidden_dim != 32:
         return False
     proj = model.project
     if len(proj.layers) != 2 or proj.activation_name != "silu" or proj.dropout:
@@ -113,7 +109,8 @@ def score_param_tensors(model):
 
 
 def score_nograd(model, ep, pl, node_attr, edge_2D, pos):
-    """SDEModel2Dto3D_0x.get_score's network output [N, 3] (before the division by -std) in one launch."""
+    """SDEModel2Dto3D_0x.get_score's network output [N, 3] (before the division by -std): two launches (per-edge work wide,
+    then one workgroup per molecule)."""
     net = model.score_network
     tens = score_param_tensors(model)
     _, _, eps1, eps2 = _cfg(net)
@@ -121,9 +118,7 @@ def score_nograd(model, ep, pl, node_attr, edge_2D, pos):
     if not (e2.is_cuda and e2.dtype == torch.float32 and e2.stride(-1) == 1 and e2.stride(0) % 4 == 0 and e2.data_ptr() % 16 == 0):
         e2 = hip._f32(e2)
     out = torch.empty(ep.N, 3, dtype=torch.float32, device=x0.device)
-    scratch = None
-    if SCORE_TWO_LAUNCHES:
-        scratch = torch.empty(int(_lib.load().msde_escore_mol_score_scratch_floats(ep.E)), dtype=torch.float32, device=x0.device)
+    scratch = torch.empty(int(_lib.load().msde_escore_mol_score_scratch_floats(ep.E)), dtype=torch.float32, device=x0.device)
     _lib.call("msde_escore_mol_score", hip._p(_pointer_table(model, tens)), hip._p(x0), hip._p(pos), hip._p(e2), e2.stride(0),
               int(hasattr(model, "input_mlp")), hip._p(pl.mol_ptr), int(pl.B), hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst),
               ep.N, ep.E, 32, 8, 128, int(pl.N_max), eps1, eps2, hip._p(scratch), hip._p(out), hip._stream())

@@ -32,7 +32,7 @@ STATIC_FEATURE_CACHE = True   # inference: coordinate-independent inputs of the 
 FUSE_HEAD_MIX = True       # hip._MlpHeadMix (False: hip.mlp_fused + hip.frame_mix_mean)
 FUSE_EDGE_EMB = True       # hip._PairBnReluLinear (False: gather-add, BatchNorm, Linear as separate ops)
 MOL_KERNEL = True       # EquivariantScoreNetwork without autograd (get_score, sampling, evaluation) as ONE launch, one workgroup per molecule (False: operator by operator, the cross-check)
-MOL_KERNEL_SCORE = True  # get_score on msde_escore_mol_score: the coordinate-dependent edge features are built INSIDE that launch (molecules of <= 20 atoms, cached 2D features)
+MOL_KERNEL_SCORE = True  # get_score on msde_escore_mol_score: edge features, lin_edge x 4 and the basis MLPs' edge halves in ONE wide launch, the per-molecule chain behind it (cached 2D features)
 MOL_KERNEL_TRAIN = False    # ... and under autograd (forward + one-launch backward, moleculesde_amd/escore.py).  Off by default: beside
                             # the second stream of the pretrain step the 256 single-wave-per-SIMD workgroups hold every CU for ~100 + ~340 us
                             # and the step is 2.69 ms against 2.58 ms operator by operator (alternating A/B on one box);
@@ -372,9 +372,10 @@ class SDEModel2Dto3D_02(nn.Module):
         # sum_k (score - noise)^2 [* std^anneal_power] -> scatter_mean over molecules -> mean: one kernel pair
         return {"position": hip.ve_position_loss(scores, pos_noise, std_pos, anneal_power, pl.mol_ptr, pl.batch_i32)}
 
-    def _score_one_launch(self, node_2D_repr, pos_perturbed, pl, ep):
-        """get_score's network evaluation as ONE launch (msde_escore_mol_score): frame / Fourier features / input_mlp /
-        coff_mlp / project are computed inside the score-network kernel from the coordinates and the CACHED 2D edge features.
+    def _score_fused(self, node_2D_repr, pos_perturbed, pl, ep):
+        """get_score's network evaluation as TWO launches (msde_escore_mol_score): frame / Fourier features / input_mlp /
+        coff_mlp / project, lin_edge of every layer and the edge halves of the basis MLPs from the coordinates and the CACHED 2D
+        edge features in a wide launch; the per-molecule chain behind it.
         None when the shapes do not allow it (the caller then runs operator by operator + msde_escore_mol_fwd)."""
         if not (MOL_KERNEL and MOL_KERNEL_SCORE and STATIC_FEATURE_CACHE and pos_perturbed.is_cuda and not self.training
                 and ep.E > 0 and _escore.score_supported(self, pl)):
@@ -390,7 +391,7 @@ class SDEModel2Dto3D_02(nn.Module):
         """The score network's output before the division by -std(t) (get_score = -this / std): the fused sampler kernels
         (msde_pc_corrector / msde_pc_predictor) apply the scaling themselves."""
         pl, ep = self._plan(data)
-        out = self._score_one_launch(node_2D_repr, pos_perturbed, pl, ep)
+        out = self._score_fused(node_2D_repr, pos_perturbed, pl, ep)
         if out is not None:
             return out
         node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep)
@@ -399,7 +400,7 @@ class SDEModel2Dto3D_02(nn.Module):
     @torch.no_grad()
     def get_score(self, node_2D_repr, data, pos_perturbed, sigma, t_pos):
         pl, ep = self._plan(data)
-        output = self._score_one_launch(node_2D_repr, pos_perturbed, pl, ep)
+        output = self._score_fused(node_2D_repr, pos_perturbed, pl, ep)
         if output is None:
             node_attr, edge_attr, basis = self._edge_and_node_features(node_2D_repr, pos_perturbed, ep)
             output = self.score_network(ep, node_attr, edge_attr, basis, pl)["gradient"]

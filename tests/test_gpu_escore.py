@@ -216,8 +216,8 @@ def test_trainer_score_kernel_mol_matches_ops(dev):
                                         ("SDEModel2Dto3D_02", [20] * 3 + [2]), ("SDEModel2Dto3D_02", [31, 3, 24, 16])])
 def test_get_score_fused_matches_operator_path(dev, cls, sizes):
     """msde_escore_mol_score -- two launches (per-edge work: frame, Fourier features, input_mlp / coff_mlp / project, lin_edge of
-    the four layers, the edge half of the basis MLPs, in a wide launch; then one workgroup per molecule) and the one-launch
-    form (<= 20 atoms), SDE_model_2D_to_3D.py:393-445 -- against the same get_score on the separate geometry launches +
+    the four layers, the edge half of the basis MLPs, in a wide launch; then one workgroup per molecule),
+    SDE_model_2D_to_3D.py:393-445 -- against the same get_score on the separate geometry launches +
     msde_escore_mol_fwd and against the plain operator path.  The in-kernel Fourier features use the hardware sin on the phase
     in revolutions (|error| ~1e-6 per feature): 2e-4 relative to the score's scale."""
     import numpy as np
@@ -242,18 +242,16 @@ def test_get_score_fused_matches_operator_path(dev, cls, sizes):
     outs = {}
     # coordinates at a small and a large diffusion time
     poses = [(b.positions + scale * torch.randn_like(b.positions)).contiguous() for scale in (0.3, 6.0)]
-    keep = (M.MOL_KERNEL, M.MOL_KERNEL_SCORE, escore.SCORE_TWO_LAUNCHES)
-    modes = [("two_launches", True, True, True), ("mol_fwd", True, False, True), ("ops", False, False, True)]
-    if pl.N_max <= 20:
-        modes.insert(1, ("one_launch", True, True, False))
+    keep = (M.MOL_KERNEL, M.MOL_KERNEL_SCORE)
+    modes = [("two_launches", True, True), ("mol_fwd", True, False), ("ops", False, False)]
     try:
-        for name, mk, ms, two in modes:
-            M.MOL_KERNEL, M.MOL_KERNEL_SCORE, escore.SCORE_TWO_LAUNCHES = mk, ms, two
+        for name, mk, ms in modes:
+            M.MOL_KERNEL, M.MOL_KERNEL_SCORE = mk, ms
             if ms:
                 assert escore.score_supported(model, pl)
             outs[name] = [model.get_score_raw(rep, b, pos).clone() for pos in poses]
     finally:
-        M.MOL_KERNEL, M.MOL_KERNEL_SCORE, escore.SCORE_TWO_LAUNCHES = keep
+        M.MOL_KERNEL, M.MOL_KERNEL_SCORE = keep
     for i in range(2):
         ref = outs["ops"][i]
         assert torch.isfinite(ref).all()
@@ -265,28 +263,19 @@ def test_get_score_fused_matches_operator_path(dev, cls, sizes):
 
 
 def test_get_score_fused_falls_back_when_unsupported(dev):
-    """Molecules above the kernels' sizes (32 atoms; 20 for the one-launch form) take the operator path."""
+    """Molecules above the kernels' size (32 atoms) take the operator path."""
     import numpy as np
     import moleculesde_amd.geom3d as G
     from moleculesde_amd import escore, plan as P
     from moleculesde_amd.batch import Batch
     from moleculesde_amd.synthetic import make_molecule
     rng = np.random.default_rng(6)
-    b = G.prepare_batch(Batch.from_data_list([make_molecule(rng, n) for n in (8, 24)]), dev)
+    b = G.prepare_batch(Batch.from_data_list([make_molecule(rng, n) for n in (8, 40)]), dev)
     model = G.SDEModel2Dto3D_02(emb_dim=32, hidden_dim=32, beta_min=0.1, beta_max=1.0, num_diffusion_timesteps=1000,
                                 beta_schedule=None, SDE_type="VE", use_extend_graph=True).to(dev).eval()
-    keep = escore.SCORE_TWO_LAUNCHES
-    try:
-        escore.SCORE_TWO_LAUNCHES = False
-        assert not escore.score_supported(model, P.get_plan(b))
-        gnn = G.GNN(3, 32, gnn_type="GIN").to(dev).eval()
-        with torch.no_grad():
-            rep = gnn(b.x, b.edge_index, b.edge_attr)
-        out = model.get_score_raw(rep, b, b.positions)
-        assert out.shape == (32, 3) and torch.isfinite(out).all()
-        escore.SCORE_TWO_LAUNCHES = True
-        assert escore.score_supported(model, P.get_plan(b))
-        b2 = G.prepare_batch(Batch.from_data_list([make_molecule(rng, n) for n in (8, 40)]), dev)
-        assert not escore.score_supported(model, P.get_plan(b2))
-    finally:
-        escore.SCORE_TWO_LAUNCHES = keep
+    assert not escore.score_supported(model, P.get_plan(b))
+    gnn = G.GNN(3, 32, gnn_type="GIN").to(dev).eval()
+    with torch.no_grad():
+        rep = gnn(b.x, b.edge_index, b.edge_attr)
+    out = model.get_score_raw(rep, b, b.positions)
+    assert out.shape == (48, 3) and torch.isfinite(out).all()

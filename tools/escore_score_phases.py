@@ -11,7 +11,8 @@ torch.manual_seed(0)
 lib = _lib.load()
 fn = lib.msde_escore_debug_stamps
 fn.argtypes = [ctypes.c_void_p]
-names = {0: "start", 40: "end", 41: "staging + geometry prologue"}
+names = {0: "start", 40: "end", 41: "staging + geometry prologue", 50: "A start", 51: "A weights requested, staged to LDS", 52: "A barrier",
+         53: "A edge features", 54: "A 24 output tiles stored"}
 for l in range(4):
     for k, nm in ((1, "layer regs + barrier"), (2, "qkvs"), (3, "edge proj"), (4, "attention"), (5, "tail"), (6, "basis mlp")):
         names[k + 8 * l] = f"L{l} {nm}"
@@ -27,8 +28,11 @@ with torch.no_grad():
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 128)()
 assert fn(buf) == 0
-idx = [i for i in sorted(names) if buf[i] > 0]
-t0 = prev = min(buf[i] for i in idx)
-for i in sorted(idx, key=lambda i: buf[i]):
-    print(f"{names[i]:34s} +{(buf[i] - prev) / 100:7.2f} us   t={(buf[i] - t0) / 100:7.2f}")
-    prev = buf[i]
+for lo, hi in ((50, 59), (0, 49)):
+    idx = [i for i in sorted(names) if buf[i] > 0 and lo <= i <= hi]
+    if not idx:
+        continue
+    t0 = prev = min(buf[i] for i in idx)
+    for i in sorted(idx, key=lambda i: buf[i]):
+        print(f"{names[i]:38s} +{(buf[i] - prev) / 100:7.2f} us   t={(buf[i] - t0) / 100:7.2f}")
+        prev = buf[i]
