@@ -737,6 +737,11 @@ int msde_pc_corrector(const float* out, const float* pos, const float* noise, co
                       unsigned long long seed, int n, float snr, float scale_eps, float* x, float* x_mean, void* stream);
 int msde_pc_predictor(const float* out, const float* pos, const float* noise, const float* par, const long long* step,
                       unsigned long long seed, int n, float* x, float* x_mean, void* stream);
+/* MD17 force fine-tuning losses (finetune_MD17.py:68-74): loss[0] = ce mean_b |E_b - y_b| + cf mean |fsign dE - f| over the n3 = 3 N
+ * force components (fsign = -1: forces are minus the coordinate gradient dE), and the seeds of the backward pass in the same
+ * launch: gE [B] = d loss / d E, gdE [n3] = d loss / d (dE) (|x|' = sign x, 0 at 0, as torch).  One workgroup, fixed order. */
+int msde_l1_energy_force_loss(const float* E, const float* y, int B, const float* dE, const float* f, int n3, float fsign, float ce,
+                              float cf, float* loss, float* gE, float* gdE, void* stream);
 /* torch.randperm(n) for the contrastive negatives (examples/util.py:55), n <= 4096 (else MSDE_EUNSUP):
  * out[count][n] int32, `count` independent uniform shuffles in one launch (dual_CL draws two) from the
  * counter-based generator (seed [+ seed_dev[0]*FNV], permutation number, index). */

@@ -136,6 +136,7 @@ SIGNATURES = {
     "msde_mul_add_bwd": [P, P, P, LL, P, P, P],
     "msde_pc_corrector": [P, P, P, P, P, ULL, I, F, F, P, P, P],
     "msde_pc_predictor": [P, P, P, P, P, ULL, I, P, P, P],
+    "msde_l1_energy_force_loss": [P, P, I, P, P, I, F, F, F, P, P, P, P],
     "msde_randperm": [I, I, ULL, P, P, P, P],
     "msde_ve_perturb": [P, P, P, P, I, I, I, F, F, F, P, P, P],
     "msde_ve_perturb_rng": [P, P, I, I, I, F, F, F, ULL, P, P, P, P, P],

@@ -756,3 +756,44 @@ extern "C" int msde_pc_predictor(const float* out, const float* pos, const float
   MSDE_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ MD17 losses
+// loss = ce mean_b |E_b - y_b| + cf mean_{i,k} |F_ik - f_ik| with F = fsign * dE (finetune_MD17.py:68-74: fsign = -1, the forces are
+// minus the coordinate gradient) and, in the same launch, d loss / d E and d loss / d (dE) -- the seeds of the backward pass
+// (torch's |.| differentiates to sign(.), sign(0) = 0).  One workgroup, fixed-order sums: bit-reproducible.
+__global__ void __launch_bounds__(1024)
+l1_energy_force_loss_kernel(const float* __restrict__ E, const float* __restrict__ y, int B, const float* __restrict__ dE,
+                            const float* __restrict__ f, int n3, float fsign, float ce, float cf, float* __restrict__ loss,
+                            float* __restrict__ gE, float* __restrict__ gdE) {
+  __shared__ float part[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float se = 0.f, sf = 0.f;
+  const float we = ce / (float)max(B, 1), wf = cf / (float)max(n3, 1);
+  for (int i = tid; i < B; i += 1024) {
+    const float r = E[i] - y[i];
+    se += fabsf(r);
+    gE[i] = we * (r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f));
+  }
+  for (int i = tid; i < n3; i += 1024) {
+    const float r = fsign * dE[i] - f[i];
+    sf += fabsf(r);
+    gdE[i] = wf * fsign * (r > 0.f ? 1.f : (r < 0.f ? -1.f : 0.f));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { se += __shfl_down(se, o, 64); sf += __shfl_down(sf, o, 64); }
+  if (lane == 0) { part[0][wave] = se; part[1][wave] = sf; }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < 16; ++w) { a += part[0][w]; b += part[1][w]; }
+    loss[0] = we * a + wf * b;
+  }
+}
+
+extern "C" int msde_l1_energy_force_loss(const float* E, const float* y, int B, const float* dE, const float* f, int n3, float fsign,
+                                         float ce, float cf, float* loss, float* gE, float* gdE, void* stream) {
+  if (B <= 0 || n3 <= 0 || !E || !y || !dE || !f || !loss || !gE || !gdE) return MSDE_EINVAL;
+  MSDE_LAUNCH(l1_energy_force_loss_kernel, dim3(1), dim3(1024), 0, as_stream(stream), E, y, B, dE, f, n3, fsign, ce, cf, loss, gE, gdE);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}

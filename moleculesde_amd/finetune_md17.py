@@ -16,7 +16,7 @@ moleculesde_amd/dd.py (SchNet._forward_force_path, PaiNN.forward); there is no h
 """
 import torch
 
-from . import dd, hip
+from . import _lib, dd, hip
 from .optim import FlatAdam
 
 
@@ -38,8 +38,9 @@ class ForceTrainer:
         self._graph = None
 
     # ---- one step, launched from the host ------------------------------------------------------------------------
-    def energy_and_force(self, batch, positions, create_graph=True):
-        """finetune_MD17.py:49-68 (train) / :107-127 (eval, create_graph=False)."""
+    def energy_and_force(self, batch, positions, create_graph=True, negate=True):
+        """finetune_MD17.py:49-68 (train) / :107-127 (eval, create_graph=False).  negate=False: returns d energy / d positions
+        (= -force) without the sign flip (the training step's loss kernel applies it)."""
         if self.is_painn:
             rep = self.model(batch.x, positions, batch.radius_edge_index, batch.batch)
         else:
@@ -49,20 +50,35 @@ class ForceTrainer:
             e_mean, f_mean, n_atom = self.normalization
             energy = energy * f_mean + e_mean * n_atom
         with dd.positions_only():        # (no parameter gradients in this differentiation: skips ~30 unused weight-gradient GEMMs)
-            force = -torch.autograd.grad(energy, positions, grad_outputs=torch.ones_like(energy), create_graph=create_graph,
-                                         retain_graph=create_graph)[0]
-        return energy, force
+            dE = torch.autograd.grad(energy, positions, grad_outputs=self._ones_like(energy), create_graph=create_graph,
+                                     retain_graph=create_graph)[0]
+        return energy, (-dE if negate else dE)
+
+    def _ones_like(self, energy):
+        """d energy / d energy, kept (no fill launch per step)."""
+        o = getattr(self, "_ones", None)
+        if o is None or o.shape != energy.shape or o.device != energy.device:
+            o = self._ones = torch.ones_like(energy)
+        return o
 
     def _body(self, batch, positions, y, force_t):
         pos = positions.detach().requires_grad_(True)
-        energy, force = self.energy_and_force(batch, pos)
-        loss = self.energy_coeff * (energy - y).abs().mean() + self.force_coeff * (force - force_t).abs().mean()
+        energy, dE = self.energy_and_force(batch, pos, negate=False)      # dE = d energy / d positions = -force
+        # both L1 losses AND their derivatives w.r.t. energy and dE from one launch (msde_l1_energy_force_loss): the backward
+        # pass starts from those instead of walking sub / abs / mean / mul / add / neg and their backward operators (~20 launches)
+        y, force_t = hip._f32(y), hip._f32(force_t)
+        e32, d32 = hip._f32(energy.detach()), hip._f32(dE.detach())
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        g_e, g_d = torch.empty_like(e32), torch.empty_like(d32)
+        _lib.call("msde_l1_energy_force_loss", hip._p(e32), hip._p(y), e32.numel(), hip._p(d32), hip._p(force_t), d32.numel(), -1.0,
+                  self.energy_coeff, self.force_coeff, hip._p(loss), hip._p(g_e), hip._p(g_d), hip._stream())
+        loss = loss[0]
         self.opt.zero_grad()
         # the weight gradients of the whole step (two contributions per Linear: energy path and force path) as ONE grouped
         # launch + ONE slab reduction behind the backward pass (hip.weight_grad_leaf) instead of ~170 per-layer launches
         hip.begin_param_grad_batch(self.opt.params)
         try:
-            loss.backward()
+            torch.autograd.backward([energy, dE], [g_e, g_d])
         finally:
             hip.finish_param_grad_batch()
         self.opt.step_from_grads()

@@ -1485,3 +1485,26 @@ def test_gemm_rs_fused_batchnorm_chain(dev, M, C1, C2, relu, bound, t2):
         assert_close(gxd[:Mv], xr.grad, 2e-3, 2e-5 * float(xr.grad.abs().max()) + 1e-6, "fused bn chain dx")
         gW1 = dzd[:Mv].double().cpu().t() @ x[:Mv].double()
         assert_close(gW1, W1r.grad, 2e-3, 2e-5 * float(W1r.grad.abs().max()) + 1e-6, "dz (A_out) -> gW1")
+
+
+@pytest.mark.parametrize("B,n3", [(1, 63), (4, 252), (37, 5000)])
+def test_l1_energy_force_loss(dev, B, n3):
+    """msde_l1_energy_force_loss (finetune_MD17.py:68-74: both L1 losses and the seeds of the backward pass in one launch)
+    against torch autograd on the same values, including exact zeros of the residual (sign(0) = 0)."""
+    from moleculesde_amd import _lib, hip
+    g = torch.Generator().manual_seed(B + n3)
+    E, y = torch.randn(B, generator=g).to(dev), torch.randn(B, generator=g).to(dev)
+    dE, f = torch.randn(n3, generator=g).to(dev), torch.randn(n3, generator=g).to(dev)
+    y[0] = E[0]
+    f[1] = -dE[1]
+    Er, dr = E.clone().requires_grad_(True), dE.clone().requires_grad_(True)
+    ref = 0.05 * (Er - y).abs().mean() + 0.95 * ((-dr) - f).abs().mean()
+    ge_ref, gd_ref = torch.autograd.grad(ref, [Er, dr])
+    loss = torch.empty(1, device=dev)
+    gE, gd = torch.empty_like(E), torch.empty_like(dE)
+    _lib.call("msde_l1_energy_force_loss", hip._p(E), hip._p(y), B, hip._p(dE), hip._p(f), n3, -1.0, 0.05, 0.95, hip._p(loss),
+              hip._p(gE), hip._p(gd), hip._stream())
+    assert_close(loss[0], ref.detach(), 1e-6, 1e-7, "loss")
+    assert_close(gE, ge_ref, 1e-6, 1e-9, "d loss / d energy")
+    assert_close(gd, gd_ref, 1e-6, 1e-9, "d loss / d (dE)")
+    assert float(gE[0]) == 0.0 and float(gd[1]) == 0.0
