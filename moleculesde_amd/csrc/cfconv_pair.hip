@@ -22,7 +22,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CP_F 128
 #define CP_TE 32
-#define CP_HS 129
+#define CP_HS 130             // row stride of the hidden tile: == 2 (mod 64), so the operand read of lane (row lcol, k-half lhalf) -- bank
+                              // 2 lcol + lhalf + 2 kk -- touches 64 distinct banks (129 put lane (l, 1) on the bank of lane (l + 1, 0): every
+                              // hidden-tile read was a 2-way conflict, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 30 % in round 4)
+#define CP_RS 66              // ... and of the smearing tile (>= 64 entries, same residue)
+// rows of the hidden tile are stored permuted (bits 2 and 4 swapped): the accumulator rows RW(i) and RW(i) + 4 that the two lane
+// halves write in one instruction then lie 16 rows = 32 banks apart instead of 4 rows = 8 banks
+__host__ __device__ constexpr int cp_rho(int r) { return (r & ~0x14) | ((r & 4) << 2) | ((r & 16) >> 2); }
 
 // ---- pair list ------------------------------------------------------------------------------------------------------
 // one workgroup per molecule: base = pairs of all earlier molecules (B <= a few thousand: summed on the spot), then the
@@ -98,7 +104,8 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
                           const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
                           const float* __restrict__ offset, int G, float coeff, float cutoff, int cpw,
                           float* __restrict__ Wf) {
-  constexpr int RS = 2 * KK1 + 1;
+  constexpr int RS = CP_RS;
+  static_assert(2 * KK1 <= 64, "smearing tile row");
   extern __shared__ float lds[];
   float* rbf_t = lds;                          // [32][RS]
   float* hid_t = rbf_t + CP_TE * RS;           // [32][129]
@@ -199,15 +206,16 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
   produce_load(p_begin);
   produce_math();
   constexpr auto RW = [](int i) constexpr { return (i & 3) + 8 * (i >> 2); };
-  float* const hw = hid_t + 4 * lhalf * CP_HS + col;
+  float* const hw = hid_t + 16 * lhalf * CP_HS + col;            // (row RW(i) + 4 lhalf -> cp_rho(RW(i)) + 16 lhalf)
   const float* const ra = rbf_t + lcol * RS + lhalf;
-  const float* const ha = hid_t + lcol * CP_HS + lhalf;
+  const float* const ha = hid_t + cp_rho(lcol) * CP_HS + lhalf;
 
   int buf = 0;
   for (int pc = p_begin; pc < p_end; pc += CP_TE, buf ^= 1) {
     const int ce = min(pc + CP_TE, p_end);
 #pragma unroll
-    for (int j = 0; j < NRW; ++j) rbf_t[(wave + 4 * j) * RS + rbf_g] = rv[j];
+    for (int j = 0; j < NRW; ++j)
+      if (lane < 2 * KK1) rbf_t[(wave + 4 * j) * RS + rbf_g] = rv[j];
     if (tid < CP_TE) c_s[buf * CP_TE + tid] = m_d >= 0.f ? 0.5f * (__cosf(m_d * (PI_F / cutoff)) + 1.0f) : 0.f;
     __syncthreads();   // B1
     const float* cb = c_s + buf * CP_TE + 4 * lhalf;
@@ -220,7 +228,7 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
 #pragma unroll
     for (int kk = 0; kk < KK1; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * kk], w1r[kk], acc, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hw[RW(i) * CP_HS] = cp_ssp(acc[i] + b1c);
+    for (int i = 0; i < 16; ++i) hw[cp_rho(RW(i)) * CP_HS] = cp_ssp(acc[i] + b1c);
     __syncthreads();   // B2
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -248,7 +256,7 @@ extern "C" int msde_cfconv_pair_filter(const float* pd, const int* count, const 
     blocks_per_wg = (blocks + resident - 1) / resident;
   }
   const int grid = (blocks + blocks_per_wg - 1) / blocks_per_wg;
-  auto lds_bytes = [](int KK1) { return (size_t)(CP_TE * (2 * KK1 + 1) + CP_TE * CP_HS + 2 * CP_TE) * sizeof(float); };
+  auto lds_bytes = [](int) { return (size_t)(CP_TE * CP_RS + CP_TE * CP_HS + 2 * CP_TE) * sizeof(float); };
   hipStream_t st = as_stream(stream);
 #define CP_LAUNCH(KK)                                                                                                  \
   MSDE_LAUNCH(cfconv_pair_filter_kernel<KK>, dim3(grid), dim3(256), lds_bytes(KK), st, pd, count, W1, b1, W2, b2, offset, G, \

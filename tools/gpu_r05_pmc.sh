@@ -5,7 +5,7 @@ O=$R/gpurun_out/r05pmc
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-for m in gemm step; do
+for m in ${MODES:-gemm step infer}; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 400 rocprofv3 --output-format csv --kernel-trace --pmc $c -d $O/pmc_${m}_$c -o run -- python3 $R/tools/prof_kernels_r05.py $m > $O/pmc_${m}_$c.log 2>&1; echo "pmc $m $c rc=$?"
   done

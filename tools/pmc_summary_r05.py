@@ -6,7 +6,10 @@ import csv, json, statistics, sys, collections
 KEYS = {"gemm_t2_kernel<5, 0": "gemm_t2_kernel<5, 0>[3588x300x300]", "gemm_t2_kernel<5, 2": "gemm_t2_kernel<5, 2>[3588x600x300 bnbwd]",
         "gemm_grouped_wgrad_kernel": "gemm_grouped_wgrad_kernel[--full step, 157 problems]",
         "dense_edge_layer_fwd": "dense_edge_layer_fwd", "dense_edge_layer_bwd": "dense_edge_layer_bwd",
-        "escore_mol_fwd_kernel": "escore_mol_fwd_kernel<true>", "escore_mol_bwd_kernel": "escore_mol_bwd_kernel"}
+        "escore_mol_fwd_kernel<true": "escore_mol_fwd_kernel<true>", "escore_mol_bwd_kernel": "escore_mol_bwd_kernel",
+        "escore_mol_fwd_kernel<false, true": "escore_mol_fwd_kernel<false, true>[sampler: 10 x 14 atoms]",
+        "escore_edge_pre_kernel": "escore_edge_pre_kernel[sampler: 1820 edges]", "gemm_small_kernel": "gemm_small_kernel[MD17 step]",
+        "cfconv_pair_filter_kernel": "cfconv_pair_filter_kernel", "cfconv_fused_bwd_w_pipe_kernel": "cfconv_fused_bwd_w_pipe_kernel"}
 vals = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
 for path in sys.argv[2:]:
     for r in csv.DictReader(open(path)):
