@@ -87,42 +87,50 @@ struct EsGeo {
 __global__ void __launch_bounds__(256)
 escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int* __restrict__ dst, int E,
                        float* __restrict__ pre) {
-  __shared__ __attribute__((aligned(16))) float wl[(4 * ES_D + 2 * ES_HC) * ES_PRE_WLD];
+  // every weight matrix goes through LDS once per workgroup (coalesced 16-byte / 8-byte loads; a lane's MFMA fragments are
+  // rows c of 16-row blocks: read straight from global they are ~200 strided loads per lane, 7 us of the first version's 20)
+  constexpr int S_IN = 68, S_CM = 132, S_P0 = 68, S_P1 = 36;
+  constexpr int O_IN = (4 * ES_D + 2 * ES_HC) * ES_PRE_WLD, O_CM = O_IN + ES_D * S_IN, O_P0 = O_CM + ES_D * S_CM,
+                O_P1 = O_P0 + ES_D * S_P0, O_END = O_P1 + ES_D * S_P1;
+  __shared__ __attribute__((aligned(16))) float wl[O_END];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
   ES_STAMP(50);
-  {
-    // Wedge_l rows 32 l + o, then W1_m[:, 32:] rows 128 + 128 m + o: 384 rows of 32 floats
-    const int q = tid & 7;
-    for (int row = tid >> 3; row < 4 * ES_D + 2 * ES_HC; row += 32) {
-      const float* sp = row < 4 * ES_D ? W.Wedge(row >> 5) + (size_t)(row & 31) * ES_D
-                                       : W.bW1((row - 4 * ES_D) >> 7) + (size_t)((row - 4 * ES_D) & 127) * (2 * ES_D) + ES_D;
-      *reinterpret_cast<float4*>(wl + row * ES_PRE_WLD + 4 * q) = *reinterpret_cast<const float4*>(sp + 4 * q);
-    }
-  }
   const float* Wd = W.p[76]; const float* Wc = W.p[77];
   const float* Win = W.p[78]; const float* bin = W.p[79]; const float* Wcm = W.p[80]; const float* bcm = W.p[81];
   const float* Wp0 = W.p[82]; const float* bp0 = W.p[83]; const float* Wp1 = W.p[84]; const float* bp1 = W.p[85];
-  float wdv[16], wcv0[16], wcv1[16], wi[2][16], wcmA[2][16], wcmB[2][16], wp0[2][16], wp1[2][8];
+  {
+    // Wedge_l rows 32 l + o, then W1_m[:, 32:] rows 128 + 128 m + o: 384 rows of 32 floats
+    // (one loop per matrix: its address is uniform -- a per-row choice of the matrix would load the pointer table per lane,
+    // a dependent round trip in front of every row)
+    const int q = tid & 7, r8 = tid >> 3;
+    float4 stg[4 + 2 * 4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) stg[l] = *reinterpret_cast<const float4*>(W.Wedge(l) + (size_t)r8 * ES_D + 4 * q);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        stg[4 + 4 * m + u] = *reinterpret_cast<const float4*>(W.bW1(m) + (size_t)(r8 + 32 * u) * (2 * ES_D) + ES_D + 4 * q);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) *reinterpret_cast<float4*>(wl + (32 * l + r8) * ES_PRE_WLD + 4 * q) = stg[l];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        *reinterpret_cast<float4*>(wl + (4 * ES_D + ES_HC * m + r8 + 32 * u) * ES_PRE_WLD + 4 * q) = stg[4 + 4 * m + u];
+    for (int t = tid; t < ES_D * 16; t += 256)       // input_mlp weight [32][64]
+      *reinterpret_cast<float4*>(wl + O_IN + (t >> 4) * S_IN + 4 * (t & 15)) = *reinterpret_cast<const float4*>(Win + (size_t)(t >> 4) * 64 + 4 * (t & 15));
+    for (int t = tid; t < ES_D * 32; t += 256)       // coff_mlp weight [32][128]
+      *reinterpret_cast<float4*>(wl + O_CM + (t >> 5) * S_CM + 4 * (t & 31)) = *reinterpret_cast<const float4*>(Wcm + (size_t)(t >> 5) * 128 + 4 * (t & 31));
+    for (int t = tid; t < ES_D * 32; t += 256)       // project[0] weight [32][66]: columns 2 .. 65 (rows are 8-byte aligned there)
+      *reinterpret_cast<float2*>(wl + O_P0 + (t >> 5) * S_P0 + 2 * (t & 31)) = *reinterpret_cast<const float2*>(Wp0 + (size_t)(t >> 5) * 66 + 2 + 2 * (t & 31));
+    for (int t = tid; t < ES_D * 8; t += 256)        // project[1] weight [32][32]
+      *reinterpret_cast<float4*>(wl + O_P1 + (t >> 3) * S_P1 + 4 * (t & 7)) = *reinterpret_cast<const float4*>(Wp1 + (size_t)(t >> 3) * 32 + 4 * (t & 7));
+  }
+  float wdv[16], wcv0[16], wcv1[16];
   es_ld16(Wd + 16 * (g & 1), wdv);
   es_ld16(Wc, wcv0);
   es_ld16(Wc + 16, wcv1);
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int rowo = 16 * nt + c;
-    es_ld16(Win + (size_t)rowo * 64 + 16 * g, wi[nt]);
-    es_ld16(Wcm + (size_t)rowo * 128 + 32 * g, wcmA[nt]);
-    es_ld16(Wcm + (size_t)rowo * 128 + 32 * g + 16, wcmB[nt]);
-#pragma unroll
-    for (int e_ = 0; e_ < 2; ++e_)
-#pragma unroll
-      for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wp0[nt][(e_ * 2 + ot) * 4 + r] = Wp0[(size_t)rowo * 66 + 2 + 32 * e_ + 16 * ot + 4 * g + r];
-#pragma unroll
-    for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wp1[nt][n2 * 4 + r] = Wp1[(size_t)rowo * 32 + 16 * n2 + 4 * g + r];
-  }
   const int ntile = (E + 15) >> 4;
   const int rt = (int)blockIdx.x * 4 + wave;
   const int e = 16 * rt + c;
@@ -172,6 +180,9 @@ escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int*
   if (geo.has_dist) {
     // feat_d[k], k = 16 g + t: sin(dist Wd[k]) for k < 32, cos(dist Wd[k - 32]) above
     const float dshift = g >= 2 ? 0.25f : 0.f;
+    float wi[2][16];
+    es_ld16(wl + O_IN + c * S_IN + 16 * g, wi[0]);
+    es_ld16(wl + O_IN + (16 + c) * S_IN + 16 * g, wi[1]);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const float f = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(fmaf(dist, wdv[t], dshift)));
@@ -182,6 +193,12 @@ escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int*
   {
     // feat_i[k], k = 32 g + t: [sin(ci0 Wc) | cos(ci0 Wc) | sin(ci2 Wc) | cos(ci2 Wc)]; feat_j likewise
     const float xi = g < 2 ? ci0 : ci2, xj = g < 2 ? cj0 : cj2;
+    float wcmA[2][16], wcmB[2][16];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      es_ld16(wl + O_CM + (16 * nt + c) * S_CM + 32 * g, wcmA[nt]);
+      es_ld16(wl + O_CM + (16 * nt + c) * S_CM + 32 * g + 16, wcmB[nt]);
+    }
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const float fi = four(xi, wcv0[t]), fj = four(xj, wcv0[t]);
@@ -206,6 +223,20 @@ escore_edge_pre_kernel(EsW W, EsGeo geo, const int* __restrict__ src, const int*
       hb[r] += wr[0] * psin + wr[1] * pcos;
     }
     accH[nt] = es_f4{hb[0], hb[1], hb[2], hb[3]};
+  }
+  float wp0[2][16], wp1[2][8];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {                   // q4 = 2 e_ + ot: column block 32 e_ + 16 ot + 4 g of project[0]
+      const float4 v = *reinterpret_cast<const float4*>(wl + O_P0 + (16 * nt + c) * S_P0 + 16 * q4 + 4 * g);
+      wp0[nt][4 * q4] = v.x; wp0[nt][4 * q4 + 1] = v.y; wp0[nt][4 * q4 + 2] = v.z; wp0[nt][4 * q4 + 3] = v.w;
+    }
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) {
+      const float4 v = *reinterpret_cast<const float4*>(wl + O_P1 + (16 * nt + c) * S_P1 + 16 * n2 + 4 * g);
+      wp1[nt][4 * n2] = v.x; wp1[nt][4 * n2 + 1] = v.y; wp1[nt][4 * n2 + 2] = v.z; wp1[nt][4 * n2 + 3] = v.w;
+    }
   }
 #pragma unroll
   for (int ot = 0; ot < 2; ++ot)
