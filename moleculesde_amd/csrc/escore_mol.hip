@@ -439,7 +439,49 @@ escore_mol_fwd_kernel(EsW W, const float* __restrict__ x0, const float* __restri
       ES_STAMP(3 + 8 * layer);
       // attention: lane = (target, head); two walks over the target's in-edges (maximum; exponentials, their sum and the
       // weighted sum) -- scores are recomputed, not stored, and nothing crosses lanes
-      {
+      if (!TRAIN && n <= 16 && t0 == 0 && t1 == n) {
+        // inference, molecules of <= 16 atoms whose edges fit ONE chunk: TWO lanes per (target, head) -- lane half z takes the in-edges of
+        // parity z, the halves meet by DPP (row_ror:8 inside the 16-lane row of a target) -- all 256 lanes busy instead of 8 n,
+        // half the serial walk.  (The sum over the edges is formed as (even edges) + (odd edges).)
+        const int i = tid >> 4, z = (tid >> 3) & 1, h = tid & 7;
+        const bool live_i = i < n;
+        const int ii = live_i ? i : 0;
+        const float4 q4 = *reinterpret_cast<const float4*>(qk + ii * ES_LDQ + h * 4);
+        const int s0 = rp[ii], s1 = live_i ? rp[ii + 1] : rp[ii];
+        const float* kb = qk + ES_D + h * 4;
+        const float* eb = ee + h * 4 - ce0 * ES_LDX;
+        float m = -INFINITY;
+#pragma unroll 4
+        for (int e = s0 + z; e < s1; e += 2) {
+          const float4 k4 = *reinterpret_cast<const float4*>(kb + sl[e] * ES_LDQ);
+          const float4 e4 = *reinterpret_cast<const float4*>(eb + e * ES_LDX);
+          m = fmaxf(m, es_dot4(q4, k4, e4) * 0.5f);
+        }
+        m = fmaxf(m, es_dpp<0x128>(m));                  // row_ror:8: the other half's maximum
+        float sum = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int e = s0 + z; e < s1; e += 2) {
+          const int j = sl[e];
+          const float4 k4 = *reinterpret_cast<const float4*>(kb + j * ES_LDQ);
+          const float4 v4 = *reinterpret_cast<const float4*>(kb + ES_D + j * ES_LDQ);
+          const float4 e4 = *reinterpret_cast<const float4*>(eb + e * ES_LDX);
+          float p = es_exp(es_dot4(q4, k4, e4) * 0.5f - m);
+          sum += p;
+          if (p_att > 0.f) p = (msde_uniform(seed_att, (unsigned long long)(e0 + e) * 8 + h) >= p_att) ? p * keep_att : 0.f;
+          acc.x = fmaf(p, v4.x + e4.x, acc.x); acc.y = fmaf(p, v4.y + e4.y, acc.y);
+          acc.z = fmaf(p, v4.z + e4.z, acc.z); acc.w = fmaf(p, v4.w + e4.w, acc.w);
+        }
+        // even half + odd half, in that order on both lanes
+        const float so = es_dpp<0x128>(sum), ax = es_dpp<0x128>(acc.x), ay = es_dpp<0x128>(acc.y), az = es_dpp<0x128>(acc.z),
+                    aw = es_dpp<0x128>(acc.w);
+        if (z == 0 && live_i) {
+          const float inv = 1.f / ((sum + so) + 1e-16f);
+          const float4 s4 = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + 3 * ES_D + h * 4);   // + lin_skip(x_i)
+          *reinterpret_cast<float4*>(att + i * ES_LDX + h * 4) =
+              make_float4(fmaf(acc.x + ax, inv, s4.x), fmaf(acc.y + ay, inv, s4.y), fmaf(acc.z + az, inv, s4.z), fmaf(acc.w + aw, inv, s4.w));
+        }
+      } else {
         const int i = tid >> 3, h = tid & 7;
         if (i >= t0 && i < t1) {
           const float4 q4 = *reinterpret_cast<const float4*>(qk + i * ES_LDQ + h * 4);
