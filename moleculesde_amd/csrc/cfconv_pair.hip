@@ -22,13 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CP_F 128
 #define CP_TE 32
-#define CP_HS 130             // row stride of the hidden tile: == 2 (mod 64), so the operand read of lane (row lcol, k-half lhalf) -- bank
-                              // 2 lcol + lhalf + 2 kk -- touches 64 distinct banks (129 put lane (l, 1) on the bank of lane (l + 1, 0): every
-                              // hidden-tile read was a 2-way conflict, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 30 % in round 4)
-#define CP_RS 66              // ... and of the smearing tile (>= 64 entries, same residue)
-// rows of the hidden tile are stored permuted (bits 2 and 4 swapped): the accumulator rows RW(i) and RW(i) + 4 that the two lane
-// halves write in one instruction then lie 16 rows = 32 banks apart instead of 4 rows = 8 banks
-__host__ __device__ constexpr int cp_rho(int r) { return (r & ~0x14) | ((r & 4) << 2) | ((r & 16) >> 2); }
+#define CP_HS 129             // odd row stride: ds_read_b32 / ds_write_b32 bank = (a / 4) % 32 per 32-lane half, so a lane-per-row access
+                              // (bank = row + const) and a lane-per-column access (bank = column + const) are both conflict free
 
 // ---- pair list ------------------------------------------------------------------------------------------------------
 // one workgroup per molecule: base = pairs of all earlier molecules (B <= a few thousand: summed on the spot), then the
@@ -104,8 +99,7 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
                           const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
                           const float* __restrict__ offset, int G, float coeff, float cutoff, int cpw,
                           float* __restrict__ Wf) {
-  constexpr int RS = CP_RS;
-  static_assert(2 * KK1 <= 64, "smearing tile row");
+  constexpr int RS = 2 * KK1 + 1;
   extern __shared__ float lds[];
   float* rbf_t = lds;                          // [32][RS]
   float* hid_t = rbf_t + CP_TE * RS;           // [32][129]
@@ -149,13 +143,17 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i4 = tid + 256 * j;
-        float* dd = stage + (i4 >> 5) * CP_HS + 4 * (i4 & 31);
-        dd[0] = v2[r][j].x; dd[1] = v2[r][j].y; dd[2] = v2[r][j].z; dd[3] = v2[r][j].w;
+        // (a staged row is stored column-permuted, column 4 c + k at position 32 k + c: the 32 lanes of a half then cover 32
+        // banks in each of the four store instructions -- at position 4 c + k they covered 8, a 4-way conflict on every staging
+        // store, which was the 30 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 4's counters; the loop itself is conflict free)
+        float* dd = stage + (i4 >> 5) * CP_HS + (i4 & 31);
+        dd[0] = v2[r][j].x; dd[32] = v2[r][j].y; dd[64] = v2[r][j].z; dd[96] = v2[r][j].w;
       }
       __syncthreads();
       if (wave == r) {
 #pragma unroll
-        for (int kk = 0; kk < CP_F / 2; ++kk) w2r[kk] = stage[lcol * CP_HS + 2 * kk + lhalf];
+        for (int kk = 0; kk < CP_F / 2; ++kk)          // column 2 kk + lhalf = 4 c + k sits at 32 k + c
+          w2r[kk] = stage[lcol * CP_HS + 32 * lhalf + 64 * (kk & 1) + (kk >> 1)];
       }
       __syncthreads();
     }
@@ -206,9 +204,9 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
   produce_load(p_begin);
   produce_math();
   constexpr auto RW = [](int i) constexpr { return (i & 3) + 8 * (i >> 2); };
-  float* const hw = hid_t + 16 * lhalf * CP_HS + col;            // (row RW(i) + 4 lhalf -> cp_rho(RW(i)) + 16 lhalf)
+  float* const hw = hid_t + 4 * lhalf * CP_HS + col;
   const float* const ra = rbf_t + lcol * RS + lhalf;
-  const float* const ha = hid_t + cp_rho(lcol) * CP_HS + lhalf;
+  const float* const ha = hid_t + lcol * CP_HS + lhalf;
 
   int buf = 0;
   for (int pc = p_begin; pc < p_end; pc += CP_TE, buf ^= 1) {
@@ -228,7 +226,7 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
 #pragma unroll
     for (int kk = 0; kk < KK1; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * kk], w1r[kk], acc, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hw[cp_rho(RW(i)) * CP_HS] = cp_ssp(acc[i] + b1c);
+    for (int i = 0; i < 16; ++i) hw[RW(i) * CP_HS] = cp_ssp(acc[i] + b1c);
     __syncthreads();   // B2
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -256,7 +254,7 @@ extern "C" int msde_cfconv_pair_filter(const float* pd, const int* count, const 
     blocks_per_wg = (blocks + resident - 1) / resident;
   }
   const int grid = (blocks + blocks_per_wg - 1) / blocks_per_wg;
-  auto lds_bytes = [](int) { return (size_t)(CP_TE * CP_RS + CP_TE * CP_HS + 2 * CP_TE) * sizeof(float); };
+  auto lds_bytes = [](int KK1) { return (size_t)(CP_TE * (2 * KK1 + 1) + CP_TE * CP_HS + 2 * CP_TE) * sizeof(float); };
   hipStream_t st = as_stream(stream);
 #define CP_LAUNCH(KK)                                                                                                  \
   MSDE_LAUNCH(cfconv_pair_filter_kernel<KK>, dim3(grid), dim3(256), lds_bytes(KK), st, pd, count, W1, b1, W2, b2, offset, G, \
