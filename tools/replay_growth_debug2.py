@@ -38,6 +38,18 @@ class Fixed(G.DeviceNoise):
         return self.perm[n]
 
 
+_retire0 = hip._retire
+
+
+def _retire_logged(bufs):
+    import traceback
+    fr = traceback.extract_stack(limit=3)[0]
+    print("   _retire:", [None if b is None else (tuple(b.shape), hex(b.data_ptr())) for b in bufs], "from", fr.name, fr.lineno, "captured", hip._CAPTURED, flush=True)
+    _retire0(bufs)
+
+
+if "logretire" in sys.argv:
+    hip._retire = _retire_logged
 small = G.prepare_batch(make_batch(8, seed=81), dev)
 big = G.prepare_batch(make_batch(96, seed=82), dev)
 res = []
@@ -49,10 +61,14 @@ for use_graph in (True, False):
     tr.models["SDE_2Dto3D_model"].noise = tr.noise
     names = [f"{mn}.{pn}" for mn, m in tr.models.items() for pn, p in m.named_parameters()]
     params = [p for m in tr.models.values() for p in m.parameters()]
+    print("run graph" if use_graph else "run eager", flush=True)
     tr.step(small)
     if use_graph:
+        print("  capture", flush=True)
         tr.capture(small)
+    print("  step(big)", flush=True)
     tr.step(big)
+    print("  first small step behind it", flush=True)
     if "dirty" in sys.argv:        # whatever the eager step handed back to the caching allocator now holds NaN
         torch.cuda.synchronize()
         xs = [torch.full((n,), float("nan"), device=dev) for n in (1 << 8, 1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24) for _ in range(24)]
