@@ -38,17 +38,19 @@ class Fixed(G.DeviceNoise):
         return self.perm[n]
 
 
-_retire0 = hip._retire
+from moleculesde_amd import slabs
+_retire0 = slabs._retire
 
 
 def _retire_logged(bufs):
     import traceback
     fr = traceback.extract_stack(limit=3)[0]
-    print("   _retire:", [None if b is None else (tuple(b.shape), hex(b.data_ptr())) for b in bufs], "from", fr.name, fr.lineno, "captured", hip._CAPTURED, flush=True)
+    print("   _retire:", [None if b is None else (tuple(b.shape), hex(b.data_ptr())) for b in bufs], "from", fr.name, fr.lineno, "captured", slabs._CAPTURED, flush=True)
     _retire0(bufs)
 
 
 if "logretire" in sys.argv:
+    slabs._retire = _retire_logged        # (hip.py's own callers go through its imported name: patch both)
     hip._retire = _retire_logged
 small = G.prepare_batch(make_batch(8, seed=81), dev)
 big = G.prepare_batch(make_batch(96, seed=82), dev)
