@@ -76,6 +76,8 @@ for use_graph in (True, False):
         xs = [torch.full((n,), float("nan"), device=dev) for n in (1 << 8, 1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24) for _ in range(24)]
         del xs
         torch.cuda.synchronize()
+    if "refresh" in sys.argv and use_graph:
+        hip.refresh_weight_t()
     (tr.step_graph if use_graph else tr.step)(small)
     torch.cuda.synchronize()
     res.append(([None if p.grad is None else p.grad.detach().clone() for p in params], tr.opt.flat_p.clone(), names))
