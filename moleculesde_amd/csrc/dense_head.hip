@@ -28,6 +28,16 @@
 #define DH_AC MSDE_DENSE_AC_LD     // 32: row stride of the pair channel buffer (30 channels used)
 #define DH_XP MSDE_DENSE_XP_LD     // 120: row stride of the atom-class buffers (119 classes)
 
+#ifdef DH_TIMING      // diagnostic build (tools/dense_edge_phases.py): wall-clock stamps of workgroups 0 (node half) and 1 (pair half)
+static __device__ long long dh_stamps[64];
+#define DH_STAMP(i) do { if (blockIdx.x < 2 && threadIdx.x == 0) dh_stamps[32 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+extern "C" int msde_dense_debug_stamps(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dh_stamps), sizeof(long long) * 64);
+}
+#else
+#define DH_STAMP(i)
+#endif
+
 // fast forms (v_exp_f32 / v_rcp_f32): absolute error ~1e-7, far inside the parity tolerance
 __device__ __forceinline__ float dh_elu(float z) { return z > 0.f ? z : __expf(z) - 1.f; }
 __device__ __forceinline__ float dh_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
@@ -286,29 +296,101 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
   float* Tm = Hm + nm * 17;           // [n][17] scratch
   float* Rn = Tm + nm * 17;           // [n][C], C <= 8
   const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, tid = threadIdx.x;
+  DH_STAMP(0);
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
   edge_load_weights<C, CO>(Wk, p, tid);
+  DH_STAMP(1);
   edge_stage<C, CO>(Qs, Ks, Ad, Xv, Rn, QK, XV, AC, in_off, a0, n, q0, tid);
+  DH_STAMP(2);
 
   if (part != 1) {
-  // ---- per-channel dense GCN: V_c = An_c (x W_c) + b_c; xcat[i][16c+f]
-  for (int e = tid; e < n * 16 * C; e += 256) {
-    const int i = e / (16 * C), cf = e - i * 16 * C, c = cf >> 4;
-    float s = Wk[L::B_V + cf];
-    for (int j = 0; j < n; ++j) s = fmaf(edge_an<C>(Ad, Rn, n, i, j, c), Xv[j * L::LV + cf], s);
-    Vc[i * L::LV + cf] = s;
-    xcat[(size_t)(a0 + i) * (16 * C) + cf] = s;
+  typedef float f4n __attribute__((ext_vector_type(4)));
+  const int nl = tid & 63, nw = tid >> 6, ncl = nl & 15, ng = nl >> 4;
+  const int nbk = (n + 15) >> 4;
+  // ---- per-channel dense GCN on the matrix cores: V_c = An_c (x W_c) + b_c; xcat[i][16c+f].  One (channel, 16-row block) item
+  // per wave and trip: A = An_c[i = lane & 15][j = 4 s + (lane >> 4)] formed on the fly (r_i a_ij r_j, a_ii = 1, zero beyond n),
+  // B = (x W_c)[j][f = lane & 15]; n / 4 MFMAs per item instead of n multiply-adds (and n evaluations of An) per output.
+  for (int it = nw; it < C * nbk; it += 4) {
+    const int c = it % C, ib = it / C;
+    const int ia = 16 * ib + ncl;
+    const float ri = ia < n ? Rn[ia * C + c] : 0.f;
+    f4n acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s4 = 0; s4 < 4 * nbk; ++s4) {
+      const int jb_ = 4 * s4 + ng;
+      float av = 0.f, bvv = 0.f;
+      if (jb_ < n) {
+        if (ia < n) av = (ia == jb_ ? 1.f : Ad[(ia * n + jb_) * L::LA + c]) * ri * Rn[jb_ * C + c];
+        bvv = Xv[jb_ * L::LV + 16 * c + ncl];
+      }
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv, acc, 0, 0, 0);
+    }
+    const float bcol = Wk[L::B_V + 16 * c + ncl];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * ib + 4 * ng + r;
+      if (i < n) {
+        const float v = acc[r] + bcol;
+        Vc[i * L::LV + 16 * c + ncl] = v;
+        xcat[(size_t)(a0 + i) * (16 * C) + 16 * c + ncl] = v;
+      }
+    }
   }
   __syncthreads();
-  // ---- channel MLP (multi_channel): 16C -> 16 (elu) -> 16, mask, tanh
-  for (int e = tid; e < n * 16; e += 256) {
-    const int i = e >> 4, o = e & 15;
-    float s = Wk[L::B_C0 + o];
-    const float* w = Wk + L::W_C0 + o * 16 * C;
-    for (int k = 0; k < 16 * C; ++k) s = fmaf(w[k], Vc[i * L::LV + k], s);
-    s = dh_elu(s);
-    Hm[i * 17 + o] = s;
-    Hmc[(size_t)(a0 + i) * 16 + o] = s;
+  DH_STAMP(3);
+  // ---- channel MLP (multi_channel): 16C -> 16 (elu) -> 16, mask, tanh.  First layer on the matrix cores: rows = atoms, the
+  // 16 C inputs are the reduction, cut into four quarters (one per wave), partial sums through LDS in wave order
+  {
+    float* part_ = Tm;                       // [4][n][17] would not fit Tm ([n][17]): the partials go to the (dead) Xv rows instead
+    part_ = Xv;                              // Xv [n][16C+1]: 4 x 16 floats per atom row needed, 16 C + 1 >= 64 for C >= 4
+    constexpr int KQ = 16 * C / 4;           // k range of a wave
+    static_assert(C == 2 || 16 * C + 1 >= 64, "partial rows");
+    for (int ib = 0; ib < nbk; ++ib) {
+      const int ia = 16 * ib + ncl;
+      f4n acc = {0.f, 0.f, 0.f, 0.f};
+      if (C >= 4) {
+#pragma unroll
+        for (int s4 = 0; s4 < KQ / 4; ++s4) {
+          const int k = KQ * nw + 4 * s4 + ng;
+          const float av = ia < n ? Vc[ia * L::LV + k] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wk[L::W_C0 + ncl * 16 * C + k], acc, 0, 0, 0);
+        }
+      } else if (nw == 0) {                  // C = 2: 32 inputs, one wave
+#pragma unroll
+        for (int s4 = 0; s4 < 16 * C / 4; ++s4) {
+          const int k = 4 * s4 + ng;
+          const float av = ia < n ? Vc[ia * L::LV + k] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wk[L::W_C0 + ncl * 16 * C + k], acc, 0, 0, 0);
+        }
+      }
+      if (C >= 4) {
+        __syncthreads();                     // (first trip: Xv no longer read by the GCN; later trips: previous block's sums done)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ib + 4 * ng + r;
+          if (i < n) part_[i * L::LV + 16 * nw + ncl] = acc[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * 16; e += 256) {
+          const int i = 16 * ib + (e >> 4), o = e & 15;
+          if (i < n) {
+            const float* pr = part_ + i * L::LV + o;
+            const float sum = dh_elu(((pr[0] + pr[16]) + pr[32]) + pr[48] + Wk[L::B_C0 + o]);
+            Hm[i * 17 + o] = sum;
+            Hmc[(size_t)(a0 + i) * 16 + o] = sum;
+          }
+        }
+      } else if (nw == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ib + 4 * ng + r;
+          if (i < n) {
+            const float sum = dh_elu(acc[r] + Wk[L::B_C0 + ncl]);
+            Hm[i * 17 + ncl] = sum;
+            Hmc[(size_t)(a0 + i) * 16 + ncl] = sum;
+          }
+        }
+      }
+    }
   }
   __syncthreads();
   for (int e = tid; e < n * 16; e += 256) {
@@ -319,63 +401,120 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
     for (int k = 0; k < 16; ++k) s = fmaf(w[k], Hm[i * 17 + k], s);
     x_out[(size_t)(a0 + i) * 16 + o] = dh_tanh(s * flags[a0 + i]);
   }
+  DH_STAMP(4);
   }
   if (part == 0) return;
-  // ---- pairs: attention, pair MLP, symmetrise (= x2: inputs are symmetric, so mlp(i,j) == mlp(j,i)), mask
-  for (int pp = tid; pp < n * n; pp += 256) {
-    const int i = pp / n, j = pp - i * n;
-    // the weights are loop invariant: without this opaque zero in their address the compiler hoists all ~640 LDS reads
-    // out of the pair loop into registers (and spills)
-    int zofs = 0;
-    asm volatile("" : "+v"(zofs));
-    const float* Wp = Wk + zofs;
-    float in[2 * C];
+  // ---- pairs on the matrix cores (v_mfma_f32_16x16x4_f32): attention, pair MLP, symmetrise (= x2: inputs are symmetric, so
+  // mlp(i,j) == mlp(j,i)), mask.
+  //   attention: S_{c,h}[i][j] = q_i[c,h,:] . k_j[c,h,:] is ONE MFMA per (16 x 16 block of atoms, channel, head chunk) -- the
+  //     4 dims of a chunk are the MFMA's k; T_c = mean_h tanh(S / 2) accumulates in the accumulator layout (4 rows i per lane,
+  //     column j = lane & 15), both directions of a pair from one product (the per-pair loop formed T_c[i][j] and T_c[j][i]
+  //     separately: twice the tanh's);
+  //   pair MLP, TRANSPOSED (lane = pair): in^T is the B operand, H1^T = W0 in^T, and each accumulator tile -- rows = features --
+  //     is the next product's B operand (contraction over its row index): 2C/4 + 4 + 4 MFMAs per 16 pairs instead of
+  //     16 (2C + 16 + CO) multiply-adds per pair with the weights broadcast from LDS.
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lane = tid & 63, wave = tid >> 6, cl = lane & 15, g4 = lane >> 4;
+  constexpr int LT = C + 1;
+  float* Tt = Qs;                          // T_c[i][j] overwrites the q rows once every wave is done with Q | K (below)
+  {
+    const int nb = (n + 15) >> 4, nitem = nb * nb * C;
+    constexpr int MAXI = (4 * C + 3) / 4;    // items (block, channel) per wave: <= 4 blocks
+    f4 tv[MAXI];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      in[c] = 0.5f * (edge_att<C>(Qs, Ks, i, j, c) + edge_att<C>(Qs, Ks, j, i, c));
-      in[C + c] = Ad[pp * L::LA + c];
-    }
-    float h1[16], h2[16];
+    for (int u = 0; u < MAXI; ++u) {
+      const int it = wave + 4 * u;
+      tv[u] = f4{0.f, 0.f, 0.f, 0.f};
+      if (it < nitem) {                       // (uniform in the wave)
+        const int c = it % C, blk = it / C, ib = blk / nb, jb = blk - ib * nb;
+        const float* qr = Qs + min(16 * ib + cl, n - 1) * L::LQ + 32 * c + g4;
+        const float* kr = Ks + min(16 * jb + cl, n - 1) * L::LQ + 32 * c + g4;
+        f4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
-      float s = Wp[L::B_M0 + o];
+        for (int h = 0; h < 8; ++h) {
+          const f4 sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[4 * h], kr[4 * h], f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-      for (int k = 0; k < 2 * C; k += 4) {
-        const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M0 + o * 2 * C + k]);
-        s = fmaf(w.w, in[k + 3], fmaf(w.z, in[k + 2], fmaf(w.y, in[k + 1], fmaf(w.x, in[k], s))));
+          for (int r = 0; r < 4; ++r) t[r] += dh_tanh(0.5f * sacc[r]);
+        }
+        tv[u] = t;
       }
-      h1[o] = dh_elu(s);
     }
+    DH_STAMP(5);
+    __syncthreads();                          // nobody reads Q | K any more
 #pragma unroll
-    for (int o = 0; o < 16; ++o) {
-      float s = Wp[L::B_M1 + o];
+    for (int u = 0; u < MAXI; ++u) {
+      const int it = wave + 4 * u;
+      if (it < nitem) {
+        const int c = it % C, blk = it / C, ib = blk / nb, jb = blk - ib * nb;
+        const int jj = 16 * jb + cl;
 #pragma unroll
-      for (int k = 0; k < 16; k += 4) {
-        const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M1 + o * 16 + k]);
-        s = fmaf(w.w, h1[k + 3], fmaf(w.z, h1[k + 2], fmaf(w.y, h1[k + 1], fmaf(w.x, h1[k], s))));
+        for (int r = 0; r < 4; ++r) {
+          const int ii = 16 * ib + 4 * g4 + r;
+          if (ii < n && jj < n) Tt[(ii * n + jj) * LT + c] = tv[u][r] * 0.125f;
+        }
       }
-      h2[o] = dh_elu(s);
     }
-    const float m = 2.f * flags[a0 + i] * flags[a0 + j];
-    float* acrow = AC + (size_t)(q0 + pp) * DH_AC + out_off;
-#pragma unroll
-    for (int o = 0; o < CO; ++o) {
-      float s = Wp[L::B_M2 + o];
-#pragma unroll
-      for (int k = 0; k < 16; k += 4) {
-        const float4 w = *reinterpret_cast<const float4*>(&Wp[L::W_M2 + o * 16 + k]);
-        s = fmaf(w.w, h2[k + 3], fmaf(w.z, h2[k + 2], fmaf(w.y, h2[k + 1], fmaf(w.x, h2[k], s))));
-      }
-      acrow[o] = s * m;
-    }
-    float* inrow = IN + (size_t)(q0 + pp) * (2 * C);
-#pragma unroll
-    for (int k = 0; k < 2 * C; ++k) inrow[k] = in[k];
-    float* h1row = H1 + (size_t)(q0 + pp) * 16;
-    float* h2row = H2 + (size_t)(q0 + pp) * 16;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { h1row[k] = h1[k]; h2row[k] = h2[k]; }
+    __syncthreads();
   }
+  {
+    DH_STAMP(6);
+    constexpr int KS = (2 * C) / 4;          // k steps of the first product: lane group g4 supplies input 4 s + g4 in step s
+    const int ntile = (n * n + 15) >> 4;
+    // weights as A operands (row = lane & 15): W0 [16][2C], W1 [16][16], W2 [CO][16] (rows >= CO: zero)
+    float w0[KS];
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_) w0[s_] = Wk[L::W_M0 + cl * 2 * C + 4 * s_ + g4];
+    const float4 w1 = *reinterpret_cast<const float4*>(&Wk[L::W_M1 + cl * 16 + 4 * g4]);
+    const float4 w2 = cl < CO ? *reinterpret_cast<const float4*>(&Wk[L::W_M2 + cl * 16 + 4 * g4]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 b0 = *reinterpret_cast<const float4*>(&Wk[L::B_M0 + 4 * g4]);
+    const float4 b1 = *reinterpret_cast<const float4*>(&Wk[L::B_M1 + 4 * g4]);
+    float b2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b2[r] = 4 * g4 + r < CO ? Wk[L::B_M2 + 4 * g4 + r] : 0.f;
+    for (int t = wave; t < ntile; t += 4) {
+      const int pp = 16 * t + cl;
+      const bool on = pp < n * n;
+      const int pc = on ? pp : 0;
+      const int i = pc / n, j = pc - i * n, ppT = j * n + i;
+      float inv[KS];
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_) {
+        const int k = 4 * s_ + g4;            // input index: k < C attention channel k, else adjacency channel k - C
+        inv[s_] = k < C ? 0.5f * (Tt[pc * LT + k] + Tt[ppT * LT + k]) : Ad[pc * L::LA + (k - C)];
+      }
+      f4 a1 = {b0.x, b0.y, b0.z, b0.w};
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[s_], inv[s_], a1, 0, 0, 0);
+      float h1v[4], h2v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1v[r] = dh_elu(a1[r]);
+      f4 a2 = {b1.x, b1.y, b1.z, b1.w};
+      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, h1v[0], a2, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, h1v[1], a2, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, h1v[2], a2, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, h1v[3], a2, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h2v[r] = dh_elu(a2[r]);
+      f4 a3 = {b2[0], b2[1], b2[2], b2[3]};
+      a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2.x, h2v[0], a3, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2.y, h2v[1], a3, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2.z, h2v[2], a3, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2.w, h2v[3], a3, 0, 0, 0);
+      if (on) {
+        const float m = 2.f * flags[a0 + i] * flags[a0 + j];
+        float* acrow = AC + (size_t)(q0 + pp) * DH_AC + out_off;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * g4 + r < CO) acrow[4 * g4 + r] = a3[r] * m;
+        float* inrow = IN + (size_t)(q0 + pp) * (2 * C);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) inrow[4 * s_ + g4] = inv[s_];
+        *reinterpret_cast<float4*>(H1 + (size_t)(q0 + pp) * 16 + 4 * g4) = make_float4(h1v[0], h1v[1], h1v[2], h1v[3]);
+        *reinterpret_cast<float4*>(H2 + (size_t)(q0 + pp) * 16 + 4 * g4) = make_float4(h2v[0], h2v[1], h2v[2], h2v[3]);
+      }
+    }
+  }
+  DH_STAMP(7);
 }
 
 // Backward of the layer.  Inputs: g_xout [N,16] (nullptr: x_out is unused -- last layer), gAC (gradient of the pair
