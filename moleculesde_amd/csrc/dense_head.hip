@@ -204,13 +204,28 @@ struct EdgeLds {
 template <int C, int CO>
 __device__ __forceinline__ void edge_load_weights(float* Wk, const msde_edge_layer_params& p, int tid) {
   using L = EdgeLds<C, CO>;
-  for (int e = tid; e < 16 * 2 * C; e += 256) Wk[L::W_M0 + e] = p.mW0[e];
-  for (int e = tid; e < 256; e += 256) { Wk[L::W_M1 + e] = p.mW1[e]; Wk[L::W_C1 + e] = p.cW1[e]; }
-  for (int e = tid; e < CO * 16; e += 256) Wk[L::W_M2 + e] = p.mW2[e];
-  for (int e = tid; e < 16 * 16 * C; e += 256) Wk[L::W_C0 + e] = p.cW0[e];
-  if (tid < 16) { Wk[L::B_M0 + tid] = p.mb0[tid]; Wk[L::B_M1 + tid] = p.mb1[tid]; Wk[L::B_C0 + tid] = p.cb0[tid]; Wk[L::B_C1 + tid] = p.cb1[tid]; }
-  if (tid < CO) Wk[L::B_M2 + tid] = p.mb2[tid];
-  for (int e = tid; e < 16 * C; e += 256) Wk[L::B_V + e] = p.bv[e];
+  // every load is issued before the first LDS store (fixed trip counts): one global round trip for the whole weight set instead
+  // of one per loop -- a workgroup's staging was half of its 12-16 us (tools/dense_edge_phases.py)
+  constexpr int NC0 = 16 * 16 * C / 256;            // 256 C floats of the channel MLP's first layer: C per thread
+  float rc0[NC0];
+#pragma unroll
+  for (int u = 0; u < NC0; ++u) rc0[u] = p.cW0[tid + 256 * u];
+  const float rm1 = p.mW1[tid], rc1 = p.cW1[tid];
+  const float rm0 = tid < 16 * 2 * C ? p.mW0[tid] : 0.f;
+  const float rm2 = tid < CO * 16 ? p.mW2[tid] : 0.f;
+  const float rbv = tid < 16 * C ? p.bv[tid] : 0.f;
+  float rb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tid < 16) { rb[0] = p.mb0[tid]; rb[1] = p.mb1[tid]; rb[2] = p.cb0[tid]; rb[3] = p.cb1[tid]; }
+  const float rb2 = tid < CO ? p.mb2[tid] : 0.f;
+#pragma unroll
+  for (int u = 0; u < NC0; ++u) Wk[L::W_C0 + tid + 256 * u] = rc0[u];
+  Wk[L::W_M1 + tid] = rm1;
+  Wk[L::W_C1 + tid] = rc1;
+  if (tid < 16 * 2 * C) Wk[L::W_M0 + tid] = rm0;
+  if (tid < CO * 16) Wk[L::W_M2 + tid] = rm2;
+  if (tid < 16 * C) Wk[L::B_V + tid] = rbv;
+  if (tid < 16) { Wk[L::B_M0 + tid] = rb[0]; Wk[L::B_M1 + tid] = rb[1]; Wk[L::B_C0 + tid] = rb[2]; Wk[L::B_C1 + tid] = rb[3]; }
+  if (tid < CO) Wk[L::B_M2 + tid] = rb2;
 }
 
 // stage Q | K, the adjacency channels and x W_c of one molecule; computes r[i] = clamp(deg_i, 1)^-1/2 per channel
@@ -220,23 +235,59 @@ __device__ __forceinline__ void edge_stage(float* Qs, float* Ks, float* Ad, floa
                                            const float* XV, const float* AC, int in_off, int a0, int n, int q0, int tid) {
   using L = EdgeLds<C, CO>;
   constexpr int W = 32 * C;
+  // (batches of four trips, loads first: with a run-time trip count the compiler emits load -> wait -> store per trip, a global
+  // round trip each)
   if (Qs) {
-    for (int e = tid; e < n * (W / 4); e += 256) {
-      const int i = e / (W / 4), c4 = (e - i * (W / 4)) * 4;
-      const float4 q = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + c4);
-      const float4 k = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + W + c4);
-      *reinterpret_cast<float4*>(Qs + i * L::LQ + c4) = q;
-      *reinterpret_cast<float4*>(Ks + i * L::LQ + c4) = k;
+    const int tot = n * (W / 4);
+    for (int e0 = tid; e0 < tot; e0 += 4 * 256) {
+      float4 q[4], k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + 256 * u, tot - 1), i = e / (W / 4), c4 = (e - i * (W / 4)) * 4;
+        q[u] = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + c4);
+        k[u] = *reinterpret_cast<const float4*>(QK + (size_t)(a0 + i) * (2 * W) + W + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < tot) {
+          const int i = e / (W / 4), c4 = (e - i * (W / 4)) * 4;
+          *reinterpret_cast<float4*>(Qs + i * L::LQ + c4) = q[u];
+          *reinterpret_cast<float4*>(Ks + i * L::LQ + c4) = k[u];
+        }
+      }
     }
   }
-  for (int e = tid; e < n * n * C; e += 256) {
-    const int p = e / C, c = e - p * C;
-    Ad[p * L::LA + c] = AC[(size_t)(q0 + p) * DH_AC + in_off + c];
+  {
+    const int tot = n * n * C;
+    for (int e0 = tid; e0 < tot; e0 += 4 * 256) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + 256 * u, tot - 1), p = e / C, c = e - p * C;
+        v[u] = AC[(size_t)(q0 + p) * DH_AC + in_off + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < tot) { const int p = e / C, c = e - p * C; Ad[p * L::LA + c] = v[u]; }
+      }
+    }
   }
   if (Xv) {
-    for (int e = tid; e < n * 16 * C; e += 256) {
-      const int i = e / (16 * C), f = e - i * 16 * C;
-      Xv[i * L::LV + f] = XV[(size_t)(a0 + i) * (16 * C) + f];
+    const int tot = n * 16 * C;
+    for (int e0 = tid; e0 < tot; e0 += 4 * 256) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + 256 * u, tot - 1);
+        v[u] = XV[(size_t)a0 * (16 * C) + e];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < tot) { const int i = e / (16 * C), f = e - i * 16 * C; Xv[i * L::LV + f] = v[u]; }
+      }
     }
   }
   __syncthreads();
