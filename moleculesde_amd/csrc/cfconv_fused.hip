@@ -317,8 +317,8 @@ extern "C" int msde_cfconv_fused_fwd(const float* x1, const float* dist, const i
   if (F != CF_F || G <= 0 || G > 64) return MSDE_EUNSUP;
   if (N == 0) return 0;
   hipStream_t st = as_stream(stream);
-  hipError_t me = hipMemsetAsync(agg, 0, (size_t)N * CF_F * sizeof(float), st);   // atomics target + isolated nodes
-  if (me != hipSuccess) return (int)me;
+  int ze = msde_zero_words(agg, (size_t)N * CF_F, st);   // atomics target + isolated nodes (a kernel, see msde_common.h)
+  if (ze) return ze;
   if (E_cap == 0) return 0;
   int kk1 = (G + 1) / 2;
   int chunks = (E_cap + CF_TE - 1) / CF_TE;

@@ -75,7 +75,7 @@ pair_build_kernel(const float* __restrict__ pos, const int* __restrict__ mol_ptr
 extern "C" int msde_pair_build(const float* pos, const int* mol_ptr, int B, float r2, int* pair_ptr, int* pi, int* pj,
                                float* pd, int P_cap, int* err, void* stream) {
   if (B < 0 || P_cap < 0 || !pos || !mol_ptr || !pair_ptr || !pi || !pj || !pd) return MSDE_EINVAL;
-  if (B == 0) return (int)hipMemsetAsync(pair_ptr, 0, sizeof(int), as_stream(stream));
+  if (B == 0) return msde_zero_words(pair_ptr, 1, as_stream(stream));
   MSDE_LAUNCH(pair_build_kernel, dim3(B), dim3(256), 0, as_stream(stream), pos, mol_ptr, B, r2, pair_ptr, pi, pj, pd, P_cap,
               err);
   MSDE_CHECK_LAUNCH();

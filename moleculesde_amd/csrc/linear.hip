@@ -487,6 +487,28 @@ static int launch_gemm(const float* A, const float* B, const float* bias, float*
   return e == hipSuccess ? 0 : (int)e;
 }
 
+// ---- zero fill as a kernel (msde_common.h: the library never records memset nodes) --------------------------------
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+__global__ void __launch_bounds__(256) zero_words4_kernel(uint4* __restrict__ p, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+int msde_zero_words(void* p, size_t n_words, hipStream_t st) {
+  if (n_words == 0) return 0;
+  if (!p || (reinterpret_cast<uintptr_t>(p) & 3)) return MSDE_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && n_words % 4 == 0) {
+    size_t n4 = n_words / 4, wg = (n4 + 255) / 256;
+    MSDE_LAUNCH(zero_words4_kernel, dim3((unsigned)(wg < 4096 ? wg : 4096)), dim3(256), 0, st, reinterpret_cast<uint4*>(p), n4);
+  } else {
+    size_t wg = (n_words + 255) / 256;
+    MSDE_LAUNCH(zero_words_kernel, dim3((unsigned)(wg < 4096 ? wg : 4096)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), n_words);
+  }
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int msde_linear_fwd(const float* X, const float* W, const float* bias, int M, int N, int K, float* Y,
                                void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || !X || !W || !Y) return MSDE_EINVAL;
@@ -738,9 +760,9 @@ extern "C" int msde_linear_bwd_w(const float* gY, const float* X, int M, int N, 
   float* slabs = workspace;
   float* cs = gb ? workspace + (size_t)splits * N * K : nullptr;
   if (M == 0) {
-    hipError_t e = hipMemsetAsync(gW, 0, (size_t)N * K * sizeof(float), st);
-    if (e == hipSuccess && gb) e = hipMemsetAsync(gb, 0, (size_t)N * sizeof(float), st);
-    return (int)e;
+    int e = msde_zero_words(gW, (size_t)N * K, st);
+    if (e == 0 && gb) e = msde_zero_words(gb, (size_t)N, st);
+    return e;
   }
   // C[N,K] = A^T B with A = gY [M][N] (k-major, "M" of the product = N), B = X [M][K] (k-major)
   if (splits == 1)      // one split (few rows: a 21-atom MD17 step launches ~90 of these): the only slab IS the result

@@ -27,6 +27,11 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 int msde_reduce_slabs(const float* slabs, int splits, size_t n, float* out, const float* cs, size_t nb, float* outb,
                       hipStream_t st);
 
+// p[0 .. n_words) := 0 as a KERNEL (defined in linear.hip).  The library never uses hipMemsetAsync: a memset NODE of a
+// captured step was observed not to take effect in the first replay that follows an eager step on the same stream
+// (tools/replay_growth_debug2.py is the 3-second reproduction), a kernel node is always executed.
+int msde_zero_words(void* p, size_t n_words, hipStream_t st);
+
 // Row bounds: kernels that REDUCE over rows take the device address of the TRUE row count of their operand (`rows_dev`,
 // NULL = all rows) and clamp their row range with it, so one captured hipGraph serves batches of different sizes padded to
 // the same capacities (include/msde_hip.h, "Row bounds").  The pointer is an explicit argument of every such entry point:

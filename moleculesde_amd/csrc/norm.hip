@@ -359,7 +359,7 @@ colsum_final_kernel(const float* __restrict__ ws, int splits, int C, float* __re
 extern "C" int msde_colsum(const float* X, int M, int C, float* out, float* workspace, const int* rows_dev, void* stream) {
   if (M < 0 || C <= 0 || !X || !out || !workspace) return MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (M == 0) return (int)hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st);
+  if (M == 0) return msde_zero_words(out, (size_t)C, st);
   int splits, rows;
   bn_geometry(M, &splits, &rows);
   if (splits == 1) {     // one split: its partial sums are the result (no second launch)

@@ -555,7 +555,7 @@ extern "C" int msde_mlp_head_bwd(const float* Z, int ldz, const float* W, const 
   hipStream_t st = as_stream(stream);
   const size_t n = mh_slab_floats(J, H);
   if (E == 0) {
-    if (gWb) { hipError_t e = hipMemsetAsync(gWb, 0, n * sizeof(float), st); if (e != hipSuccess) return (int)e; }
+    if (gWb) { int e = msde_zero_words(gWb, n, st); if (e) return e; }
     return 0;
   }
   const int lpr = pick_tpr(H / 4), nb = mh_grid(E, lpr);

@@ -49,6 +49,17 @@ def test_product_path_has_no_cpu_fallback():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
 
 
+def test_library_records_no_memset_nodes():
+    """The library zero-fills with a kernel (csrc/msde_common.h: msde_zero_words), never with hipMemsetAsync: the memset NODE in
+    front of the per-edge CFConv forward kernel did not take effect in the first replay of a captured step that followed an eager
+    step (round 5, tools/replay_growth_debug2.py), and its partial-tile atomics landed on stale data."""
+    csrc = os.path.join(ROOT, "moleculesde_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            code = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, f)).read())
+            assert "hipMemset" not in code, f
+
+
 def test_extend_graph_path_graph_known_answer():
     """dataset_3D.py:12-35 on a 7-node path: pairs within <= 4 bonds, no self loops, sorted."""
     from moleculesde_amd.batch import extend_graph_index

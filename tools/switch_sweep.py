@@ -36,12 +36,10 @@ def pytest_configure(config):          # (loaded as a plugin: -p switch_sweep)
 # itself differs from the fused one by 2 % in a few small gradients of the 48-molecule test configuration (eps, bond tables of the
 # middle layers: both within the oracle's tolerance in tests/test_gpu_models.py), and the comparison inherits that (round 5:
 # tools/unfused_bucket_debug.py; the same at the round-4 commit).  Excluded for that setting only.
-# nopair (the per-edge CFConv kernels as the cross-check): test_replay_after_workspaces_grew fails IN THE SUITE since the
-# BatchNorm-backward pass of round 5 (commit 40fcb44; 3e-4 between the graph and the eager sequence, GIN parameters only), and only
-# when test_golden_f3_variants_2d3d and test_eager_steps_with_gpu_far_behind_host ran before it in the same process
-# (tools/replay_growth_debug2.py reproduces it in 3 s; alone, or with either of BN_BWD_PASS / FUSE_GIN_APPLY off, it passes).
-# Root cause not found this round -- OPEN; the default (pair) path passes the same sequence.
-DESELECT = {"nofusegin": "not bucket_step_matches_exact_batch", "nopair": "not test_replay_after_workspaces_grew"}
+# (nopair used to exclude test_replay_after_workspaces_grew: the cause was the hipMemsetAsync in front of the per-edge CFConv
+# forward kernel -- as a memset NODE of the captured step it did not take effect in the first replay behind an eager step; the
+# library zero-fills with a kernel now (csrc/msde_common.h: msde_zero_words) and the setting runs the whole suite.)
+DESELECT = {"nofusegin": "not bucket_step_matches_exact_batch"}
 
 
 if __name__ == "__main__":
