@@ -186,7 +186,7 @@ def edge_backward(cfg, sv, AC, flags, chans, offs, T, gS, gZG2, gx0, gx0_accumul
         if node:
             G[b + 14], G[b + 15] = wg(GY, s.Hmc, True)
             G[b + 12], G[b + 13] = wg(GHm, s.xcat, True)
-            G[b + 5] = hip.colsum(GV)
+            G[b + 5] = hip.colsum_leaf(GV)
             gWv = _empty(C * F, 16, device=dev)
             for c in range(C):          # x W_c with W_c stored [in, out]: gW_c = x^T g(xW_c)
                 wg(s.x, gXV[:, 16 * c:16 * c + 16], False, out_w=gWv[c * F:(c + 1) * F])
@@ -282,7 +282,7 @@ def node_backward(cfg, sv, XC, F, AC, T, gOUT):
     _lib.call("msde_dense_node_gcn_bwd", ctypes.c_void_p(gXC.data_ptr() + 4 * F), gXC.stride(0),
               ctypes.c_void_p(XC.data_ptr() + 4 * F), ld, _p(AC), _p(cfg.mol_ptr), _p(cfg.pair_ptr), _p(T[1]), B, cfg.n_max,
               _p(GP), _p(MM), hip._stream())
-    G[2] = hip.colsum(GP)
+    G[2] = hip.colsum_leaf(GP)
     gWl = _empty(48, 16, device=dev)
     for l in range(1, 4):       # W_l stored [in, out]: gW_l = x_l^T (An^T g_pre_l)
         wg(XC[:, F + 16 * (l - 1):F + 16 * l], MM[:, 16 * l:16 * l + 16], False, out_w=gWl[16 * (l - 1):16 * l])

@@ -1150,7 +1150,7 @@ from .slabs import (_WS, _WS_BYTES, _KEEP_ALIVE, note_capture, no_gc, _retire, _
                     _wgrad_workspace, _PENDING_UPLOADS, upload_table, flush_table_uploads, _SlabBatch, _SLABS, _SPLITS,
                     begin_param_grad_batch, flush_wgrad_gemms, reduce_written_slabs, run_deferred_leaf_kernels,
                     have_deferred_leaf_kernels, park_wgrad_gemms, launch_wgrad_group, finish_param_grad_batch,
-                    new_param_grad_slot, use_eager_param_grad_slot, _row_stride, weight_grad, weight_grad_leaf, colsum,
+                    new_param_grad_slot, use_eager_param_grad_slot, _row_stride, weight_grad, weight_grad_leaf, colsum, colsum_leaf,
                     weight_grad_blocks, WGRAD_HIP_MIN_ROWS)
 
 

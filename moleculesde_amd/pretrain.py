@@ -92,6 +92,7 @@ USE_FUSED_CL = True
 # Stream layout of the step, fixed by alternating A/B runs on one box (numbers: DESIGN.md rounds 2-4).  What lost is gone from
 # the code: weight gradients flushed early or on the second stream, the contrastive loss on the second stream, SchNet started
 # behind GIN, a third stream for the coordinate branch, leaf kernels in front of the grouped launch.
+SPLIT_HEAD_ROOT = True          # the 3D->2D head's loss as a backward root of its own on the second stream (Trainer.losses)
 SIDE_CFCONV_FWD_WGS = 512     # SchNet's CFConv kernels beside the main chain: forward 128: 2.825 ... 512: 2.736, 1024: 2.750 ms
 SIDE_CFCONV_BWD_WGS = 176     # weight gradient 128: 2.768, 160: 2.757, 192: 2.755, 256 (full width): 2.783 ms
 GEOMETRY_ON_SIDE = True       # coordinate-only branch of the 2D->3D model at the head of the second stream (2.86 vs 2.98 ms)
@@ -262,7 +263,7 @@ class Trainer:
             batch.radius_edge_index = ei
         return m3(batch.x[:, 0], batch.positions, ei, batch.batch, return_latent=True)
 
-    def losses(self, batch, log=False):
+    def losses(self, batch, log=False, split_roots=False):
         """Loss composition of pretrain_MoleculeSDE.py:128-152.  The 3D encoder does not depend on the 2D
         branch (GIN -> 2D->3D score model) until the contrastive term, and most kernels of this 256-molecule
         step fill only part of the chip, so SchNet runs on a second HIP stream beside the 2D branch; autograd
@@ -275,6 +276,11 @@ class Trainer:
         # the 3D->2D head depends only on the SchNet output: it follows SchNet on the side stream unless the
         # noise source replays the reference's program order (its draws come last there)
         head_on_side = want_32 and self.overlap_streams and not getattr(self.noise, "replay", False)
+        # split_roots (the trainer's own steps): with the 3D->2D head behind SchNet on the second stream, its loss stays a
+        # backward ROOT OF ITS OWN on that stream -- the main stream joins SchNet's output only (an event recorded in front of
+        # the head), composes the 2D->3D and contrastive terms and starts ITS backward without waiting for the head's ~600 us
+        # forward; _backward() differentiates both roots in one pass.  Returned loss: (main root, head root).
+        split = bool(split_roots and head_on_side and SPLIT_HEAD_ROOT)
         if self.overlap_streams and not head_on_side:
             # SchNet alone on the second stream is the shorter chain: its wide kernels give way to the main chain
             # (with the 3D->2D head behind it the second stream is the critical one and keeps the full width)
@@ -321,9 +327,14 @@ class Trainer:
                 _hip.stamp("schnet_fwd_end")
                 if stamps:
                     rep.register_hook(lambda g: _hip.stamp("schnet_bwd_start"))
-                return rep, (head_32(rep) if head_on_side else None), ng
+                ev = None
+                if split:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                return rep, (head_32(rep) if head_on_side else None), ng, ev
+        rep_ready = None
         if self.overlap_streams:
-            node_3D_repr, l32, ng = schnet_on_side()
+            node_3D_repr, l32, ng, rep_ready = schnet_on_side()
             if ng is not None:
                 negs = ng
                 for t in negs:
@@ -343,16 +354,26 @@ class Trainer:
             if stamps:
                 l23.register_hook(lambda g: _hip.stamp("2d3d_bwd_start"))
         if self.overlap_streams:
-            main.wait_stream(self._side_stream)
+            if rep_ready is not None:
+                main.wait_event(rep_ready)         # SchNet's output; the head queued behind it keeps the second stream
+            else:
+                main.wait_stream(self._side_stream)
             node_3D_repr.record_stream(main)
-            if l32 is not None:
+            if l32 is not None and not split:
                 l32[0].record_stream(main)
                 l32[1].record_stream(main)
         if self.coeff_cl > 0:
             cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
             terms.append(cl); coeffs.append(self.coeff_cl)
             parts["CL"], parts["CL_acc"] = cl.detach(), acc
-        if want_32:
+        loss_head = None
+        if want_32 and split:
+            with torch.cuda.stream(self._side_stream):
+                c32 = 0.5 * a.SDE_coeff_generative_3Dto2D       # (loss_x + loss_adj) / 2 (pretrain_MoleculeSDE.py:148)
+                loss_head = _hip.combine_losses([c32, c32], [l32[0], l32[1]])
+                with torch.no_grad():
+                    parts["3Dto2D"] = _hip.combine_losses([0.5, 0.5], [l32[0].detach(), l32[1].detach()])
+        elif want_32:
             if l32 is None:
                 l32 = head_32(node_3D_repr)
             terms += [l32[0], l32[1]]                      # (loss_x + loss_adj) / 2 (pretrain_MoleculeSDE.py:148)
@@ -371,6 +392,8 @@ class Trainer:
             loss = 0
             for c_, t_ in zip(coeffs, terms):
                 loss = loss + t_ * c_
+        if loss_head is not None:
+            return (loss, loss_head), parts
         return loss, parts
 
     def _log_parts(self, parts):
@@ -384,11 +407,15 @@ class Trainer:
         """loss.backward() with the weight-gradient slab reductions of all layers batched into one launch."""
         from . import hip
         try:
-            one = self._one_grad if loss.is_cuda else None     # preallocated d(loss)/d(loss): no fill launch per step
+            roots = loss if isinstance(loss, tuple) else (loss,)
+            one = self._one_grad if roots[0].is_cuda else None     # preallocated d(loss)/d(loss): no fill launch per step
             hip.begin_param_grad_batch(self.opt.params)
             try:
                 hip.stamp("bwd_start")
-                loss.backward(one)
+                if len(roots) == 1:
+                    roots[0].backward(one)
+                else:        # (main root, head root on the second stream): one pass of the engine over both
+                    torch.autograd.backward(list(roots), [one] * len(roots))
                 hip.stamp("bwd_main_end")
                 if self.overlap_streams and EARLY_SLAB_REDUCE:
                     # the second stream finished its backward (SchNet) long before the main chain (GIN): it sums the
@@ -416,6 +443,13 @@ class Trainer:
                 hip.stamp("wgrad_end")
         finally:
             self._side_geometry(False)
+
+    @staticmethod
+    def _total(loss):
+        """The step's loss value from its backward roots (after the backward pass: the current stream is ordered behind both)."""
+        if isinstance(loss, tuple):
+            return loss[0].detach() + loss[1].detach()
+        return loss
 
     def _use_dp(self):
         return self.dp_enabled and (dp.world_size() > 1 or dp.FORCE_COLLECTIVES)
@@ -451,9 +485,10 @@ class Trainer:
     def step(self, batch):
         with self._bounds(batch):         # (kernels reducing over rows stop at the bucket's valid rows)
             self.step_counter.add_(1)     # the device step counter re-seeds dropout / negatives once a capture set it
-            loss, parts = self.losses(batch, log=True)
+            loss, parts = self.losses(batch, log=True, split_roots=True)
             self.opt.zero_grad()
             self._backward(loss)
+            loss = self._total(loss)
             if self._use_dp():
                 self.opt.gather_grads()
                 self._allreduce_and_adam()
@@ -469,9 +504,10 @@ class Trainer:
         from . import hip as _hip
         _hip.stamp("step_start")
         self.step_counter.add_(1)
-        loss, parts = self.losses(batch, log=True)
+        loss, parts = self.losses(batch, log=True, split_roots=True)
         self.opt.zero_grad()
         self._backward(loss)
+        loss = self._total(loss)
         if with_adam:
             self.opt.step_from_grads()
             self._refresh_weights()

@@ -535,6 +535,23 @@ def colsum(x):
     return out
 
 
+def colsum_leaf(x):
+    """colsum(x) as a PARAMETER gradient nothing in the backward chain reads (a bias gradient whose product has no weight
+    operand of its own): inside an open parameter-gradient batch the launch is queued with the deferred leaf kernels (they
+    run beside the grouped weight-gradient launch, off the backward chain) and only the result's address goes to autograd."""
+    if not _SLABS.active:
+        return colsum(x)
+    x = _f32(x)
+    M, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = _bn_workspace(M, C, x.device)
+
+    def launch(st_=None, x=x, out=out, ws=ws):
+        _lib.call("msde_colsum", _p(x), M, C, _p(out), _p(ws), _p(bound_tensor(M)), st_ if st_ is not None else _stream())
+    _SLABS.deferred.append(launch)
+    return out
+
+
 def weight_grad_blocks(g2, x2, has_bias, blocks, deferrable=True):
     """gW [N,K] = g2^T x2 whose COLUMN BLOCKS belong to wider / permuted parameter gradients: blocks = [(k0, kn, out,
     out_col0)] sends columns k0 .. k0+kn to out[:, out_col0 .. +kn] (out [N, *] contiguous).  Returns the bias gradient
