@@ -359,7 +359,7 @@ gemm_ex_kernel(const msde_gemm_desc d) {
 }
 
 // ------------------------------------------------------------------------------------------------ small problems
-// C[M,N] = A[M,K] . B (+ bias) for M <= 512 rows and K <= 512 (the MD17 force fine-tuning step: 21 atoms / 420 edges, ~130
+// C[M,N] = A[M,K] . B (+ bias) for M <= 512 rows (or N <= 32 columns and M <= 8192) and K <= 512 (the MD17 force fine-tuning step: 21 atoms / 420 edges, ~130
 // products per step, finetune_MD17.py:47-78).  Such a product is a LATENCY chain, not a throughput problem: the tiled kernel
 // above walks K in 32-wide steps behind barriers with ONE 32 x 32 accumulator per wave (K = 300: 150 dependent 64-cycle
 // MFMAs + 10 load -> LDS -> barrier round trips, ~10 us).  Here a workgroup owns a 32 x 32 output tile, its four waves
@@ -379,15 +379,18 @@ gemm_small_kernel(const msde_gemm_desc d) {
   const int K = d.K1;
   const int nchunk = (K + 15) >> 4, cpw = (nchunk + 3) >> 2;
   const int c_lo = wave * cpw, c_hi = min(c_lo + cpw, nchunk);
+  const int grp = blockIdx.y;                                  // grouped products: group strides as in the tiled kernel
+  const float* __restrict__ Ag = d.A + (size_t)grp * d.a_gs;
+  const float* __restrict__ Bg = d.B + (size_t)grp * d.b_gs;
   // rows / columns past the edge repeat the last one: their results are never stored
   const float* __restrict__ arow[2];
   const float* __restrict__ brow[2];
   int bcol[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    arow[i] = d.A + (size_t)min(m0 + 16 * i + c, d.M - 1) * d.lda;
+    arow[i] = Ag + (size_t)min(m0 + 16 * i + c, d.M - 1) * d.lda;
     bcol[i] = min(n0 + 16 * i + c, d.N - 1);
-    brow[i] = d.B + (B_KM ? (size_t)bcol[i] : (size_t)bcol[i] * d.ldb);
+    brow[i] = Bg + (B_KM ? (size_t)bcol[i] : (size_t)bcol[i] * d.ldb);
   }
   auto ld_k = [&](const float* __restrict__ row, int k) -> float4 {          // 4 consecutive k of a k-contiguous row
     if (VEC) return k < K ? *reinterpret_cast<const float4*>(row + k) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -438,6 +441,15 @@ gemm_small_kernel(const msde_gemm_desc d) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[wave][(16 * i + 4 * g + r) * 33 + 16 * j + c] = acc[i][j][r];
   __syncthreads();
+  // epilogue as in gx_epilogue (bias, pre-activation store, activation on a column range or the derivative of a saved
+  // one, row mask, alpha, accumulation); the activation is a run-time switch here -- one uniform branch per element of a
+  // kernel that is a latency chain anyway
+  const float* __restrict__ bias = d.bias ? d.bias + (size_t)grp * d.bias_gs : nullptr;
+  const float* __restrict__ bias2 = d.bias2 ? d.bias2 + (size_t)grp * d.bias_gs : nullptr;
+  float* __restrict__ Cg = d.C + (size_t)grp * d.c_gs;
+  float* __restrict__ Zg = d.Z ? d.Z + (size_t)grp * d.c_gs : nullptr;
+  const float* __restrict__ Rg = d.R ? d.R + (size_t)grp * d.r_gs : nullptr;
+  const bool dact = d.epi == MSDE_EPI_DACT, accum = (d.flags & MSDE_GEMM_ACCUMULATE) != 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = q * 256 + tid, row = idx >> 5, col = idx & 31;
@@ -445,8 +457,36 @@ gemm_small_kernel(const msde_gemm_desc d) {
     if (gm < d.M && gn < d.N) {
       const int o = row * 33 + col;
       float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
-      if (d.bias) v += d.bias[gn];
-      d.C[(size_t)gm * d.ldc + gn] = v;
+      v += (bias ? bias[gn] : 0.f) + (bias2 ? bias2[gn] : 0.f);
+      const bool act_here = d.act != MSDE_ACT_NONE && gn >= d.act_lo && gn < d.act_hi;
+      if (!dact) {
+        if (Zg) Zg[(size_t)gm * d.ldz + gn] = v;
+        if (act_here) {
+          switch (d.act) {
+            case MSDE_ACT_TANH: v = gx_act<MSDE_ACT_TANH>(v); break;
+            case MSDE_ACT_SILU: v = gx_act<MSDE_ACT_SILU>(v); break;
+            case MSDE_ACT_ELU: v = gx_act<MSDE_ACT_ELU>(v); break;
+            case MSDE_ACT_SSP: v = gx_act<MSDE_ACT_SSP>(v); break;
+            case MSDE_ACT_RELU: v = gx_act<MSDE_ACT_RELU>(v); break;
+            default: break;
+          }
+        }
+      } else if (act_here) {
+        const float r = Rg[(size_t)gm * d.ldr + gn];
+        switch (d.act) {
+          case MSDE_ACT_TANH: v *= gx_dact<MSDE_ACT_TANH>(r); break;
+          case MSDE_ACT_SILU: v *= gx_dact<MSDE_ACT_SILU>(r); break;
+          case MSDE_ACT_ELU: v *= gx_dact<MSDE_ACT_ELU>(r); break;
+          case MSDE_ACT_SSP: v *= gx_dact<MSDE_ACT_SSP>(r); break;
+          case MSDE_ACT_RELU: v *= gx_dact<MSDE_ACT_RELU>(r); break;
+          default: break;
+        }
+      }
+      if (d.rowscale) v *= d.rowscale[gm];
+      v *= d.alpha;
+      float* dst = Cg + (size_t)gm * d.ldc + gn;
+      if (accum) v += *dst;
+      *dst = v;
     }
   }
 }
@@ -478,11 +518,19 @@ extern "C" int msde_gemm_ex(const msde_gemm_desc* desc, void* stream) {
     if (d.A2) ok = ok && fits32(d.M, d.lda2, d.K2) && fits32(km ? d.K2 : d.N, d.ldb2, km ? d.N : d.K2);
     if (!ok) vec = false;
   }
-  if (d.M <= 512 && d.K1 <= 16 * 4 * GS_CH && d.groups == 1 && !d.A2 && d.act == MSDE_ACT_NONE && d.epi == MSDE_EPI_ACT &&
-      !d.rowscale && d.alpha == 1.f && !d.Z && !d.bias2 && d.b_kblk_log2 == 0 && !(d.flags & ~MSDE_GEMM_B_KMAJOR)) {
+  // ... and tall products with <= 128 output columns (per group) and N * K <= 48 K, every epilogue: the tiled kernel gives them
+  // M / 64 workgroups per column tile that each walk the whole K behind barriers (3588 x 16 x 364: 57 workgroups, 28 us
+  // against 5.0 us here; 3588 x 64 x 364: 13.1 vs 5.6; 3588 x 128 x 300: 7.6 us).  Wider outputs stay on the tiled kernels
+  // (3588 x 512 x 16: 7.0 vs 8.4 us here; N = K = 300: 11.7 vs 17.3 us)
+  const bool small_rows = d.M <= 512 && d.groups == 1 && d.act == MSDE_ACT_NONE && d.epi == MSDE_EPI_ACT && !d.rowscale &&
+                          d.alpha == 1.f && !d.Z && !d.bias2 && !(d.flags & ~MSDE_GEMM_B_KMAJOR);
+  const bool skinny = d.M <= 8192 && d.N <= 128 && (long long)d.N * d.K1 <= 49152;
+  if ((small_rows || skinny) && d.K1 <= 16 * 4 * GS_CH && !d.A2 && d.b_kblk_log2 == 0 &&
+      !(d.flags & ~(MSDE_GEMM_B_KMAJOR | MSDE_GEMM_ACCUMULATE))) {
     // a latency chain, not a throughput problem: the small-problem kernel (above)
-    const bool v4 = gx_al16(d.A) && d.lda % 4 == 0 && d.K1 % 4 == 0 && (km || (gx_al16(d.B) && d.ldb % 4 == 0));
-    dim3 grid(((d.M + 31) / 32) * ((d.N + 31) / 32));
+    const bool v4 = gx_al16(d.A) && d.lda % 4 == 0 && d.K1 % 4 == 0 && d.a_gs % 4 == 0 &&
+                    (km || (gx_al16(d.B) && d.ldb % 4 == 0 && d.b_gs % 4 == 0));
+    dim3 grid(((d.M + 31) / 32) * ((d.N + 31) / 32), d.groups);
     hipStream_t st = as_stream(stream);
     if (km) { if (v4) MSDE_LAUNCH((gemm_small_kernel<true, true>), grid, dim3(256), 0, st, d); else MSDE_LAUNCH((gemm_small_kernel<true, false>), grid, dim3(256), 0, st, d); }
     else { if (v4) MSDE_LAUNCH((gemm_small_kernel<false, true>), grid, dim3(256), 0, st, d); else MSDE_LAUNCH((gemm_small_kernel<false, false>), grid, dim3(256), 0, st, d); }

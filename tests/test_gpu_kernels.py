@@ -1201,11 +1201,13 @@ def test_gemm_ex_plain_and_kmajor(dev, M, N, K, km):
 
 
 @pytest.mark.parametrize("M,N,K", [(21, 300, 300), (21, 128, 300), (420, 128, 51), (420, 128, 128), (420, 51, 128), (1, 1, 1),
-                                   (33, 35, 17), (512, 300, 512), (42, 1, 300), (7, 3, 16), (64, 64, 500)])
+                                   (33, 35, 17), (512, 300, 512), (42, 1, 300), (7, 3, 16), (64, 64, 500),
+                                   (3588, 16, 364), (3588, 16, 512), (3712, 32, 128), (8192, 32, 300), (3588, 5, 119)])
 @pytest.mark.parametrize("km", [False, True])
 @pytest.mark.parametrize("bias", [False, True])
 def test_gemm_ex_small_problem_kernel(dev, M, N, K, km, bias):
-    """Plain products of <= 512 rows and K <= 512 (the MD17 step's ~130 per step, finetune_MD17.py:47-78) run on
+    """Plain products of <= 512 rows (or <= 32 output columns and <= 8192 rows: the dense head's skinny node-level products,
+    invariant_scorenetwork_dense.py:118-131) and K <= 512 (the MD17 step's ~130 per step, finetune_MD17.py:47-78) run on
     gemm_small_kernel (four waves split K, operands straight into MFMA registers): against fp64 torch; both B layouts,
     unaligned K / leading dimensions, edges of every kind, operands that are column blocks of wider buffers."""
     from moleculesde_amd import hip
@@ -1285,6 +1287,58 @@ def test_gemm_ex_groups(dev):
     hip.gemm_ex(x, Wv, xv, b_kmajor=True, groups=8, group_strides=dict(b=256, c=16), N=16, K=16)
     ref = torch.einsum("mk,gkn->mgn", x.double(), Wv.double()).reshape(M, 128)
     assert_close(xv, ref, 1e-5, 2e-5, "grouped k-major")
+
+
+@pytest.mark.parametrize("act", [None, "tanh", "silu", "elu", "ssp", "relu"])
+@pytest.mark.parametrize("km", [False, True])
+def test_gemm_ex_skinny_products_every_epilogue(dev, act, km):
+    """Tall products with N * K <= 48 K (the dense head's node-level products, edge_network_dense.py:33-82: 3 588 rows against
+    16 .. 512 columns) run on gemm_small_kernel with the tiled kernel's whole epilogue: bias + second bias, activation on a
+    column range with the pre-activation stored, the derivative of a saved activation, row mask, alpha, accumulation into a
+    column block of a wider buffer; grouped (block-diagonal) with the derivative -- each against fp64 torch."""
+    from moleculesde_amd import hip
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 3588, 364, 96
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    Bop = W.t().contiguous() if km else W
+    b1, b2 = torch.randn(N, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+    mask = (torch.rand(M, generator=g) > 0.2).float().to(dev)
+    # forward form: act on columns 16..80, pre-activation stored, written into a column block of a wider buffer
+    wide = torch.full((M, N + 8), float("nan"), device=dev)
+    Z = torch.full((M, N), float("nan"), device=dev)
+    hip.gemm_ex(A, Bop, wide[:, 4:4 + N], bias=b1, bias2=b2, act=act, act_cols=(16, 80), Z=Z, b_kmajor=km)
+    z = A.double() @ W.double().t() + b1.double() + b2.double()
+    ref = z.clone()
+    ref[:, 16:80] = _act_ref(act)(z[:, 16:80])
+    assert_close(Z, z, 1e-5, 2e-5, f"skinny {act}: pre-activation")
+    assert_close(wide[:, 4:4 + N], ref, 1e-5, 3e-5, f"skinny {act}: output")
+    assert torch.isnan(wide[:, :4]).all() and torch.isnan(wide[:, 4 + N:]).all(), "wrote outside its column block"
+    # backward form: derivative of the saved tensor (output for tanh / elu / relu, pre-activation for silu / ssp), row mask,
+    # alpha, accumulation
+    saved = (_act_ref(act)(z) if act in ("tanh", "elu", "relu") else z).float().contiguous()
+    gy = torch.randn(M, 32, generator=g).to(dev)
+    Wn = (torch.randn(32, N, generator=g) / 6).to(dev)          # next layer's weight [out, in]: gZ = (gy Wn) * act'(saved)
+    base = torch.randn(M, N, generator=g).to(dev)
+    acc = base.clone()
+    hip.gemm_ex(gy, Wn if km else Wn.t().contiguous(), acc, b_kmajor=km, act=act, dact_from=saved, rowscale=mask, alpha=0.5,
+                accumulate=True)
+    zz = z.clone().requires_grad_(True)
+    _act_ref(act)(zz).backward(gy.double() @ Wn.double())
+    assert_close(acc, base.double() + 0.5 * mask.double()[:, None] * zz.grad, 1e-5, 3e-5, f"skinny {act}: derivative form")
+    # grouped: 16 groups of [M, 32] x [32, 32] with the derivative of a saved tensor (func_q / func_k backward)
+    G = 16
+    gq = torch.randn(M, G * 32, generator=g).to(dev)
+    Wg = (torch.randn(G, 32, 32, generator=g) / 6).to(dev)
+    Hs = torch.tanh(torch.randn(M, G * 32, generator=g)).to(dev) if act in (None, "tanh") else torch.randn(M, G * 32, generator=g).to(dev)
+    out = torch.full((M, G * 32), float("nan"), device=dev)
+    hip.gemm_ex(gq, Wg if km else Wg.transpose(1, 2).contiguous(), out, b_kmajor=km, groups=G,
+                group_strides=dict(a=32, b=1024, c=32, r=32), N=32, K=32, act=act, dact_from=Hs)
+    lin = torch.einsum("mgn,gnk->mgk", gq.view(M, G, 32).double(), Wg.double()).reshape(M, G * 32)
+    dd_ = {None: lambda r: torch.ones_like(r), "tanh": lambda r: 1 - r * r, "relu": lambda r: (r > 0).double(),
+           "elu": lambda r: torch.where(r > 0, torch.ones_like(r), r + 1), "ssp": torch.sigmoid,
+           "silu": lambda r: torch.sigmoid(r) * (1 + r * (1 - torch.sigmoid(r)))}[act]
+    assert_close(out, lin * dd_(Hs.double()), 1e-5, 3e-5, f"skinny grouped {act}")
 
 
 # ---- row-strip GEMM family (csrc/gemm_rs.hip) ----------------------------------------------------------------------

@@ -1141,7 +1141,7 @@ def test_dense_head_launches_no_torch_operator(dev, variant):
         torch.cuda.synchronize()
     names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     assert len(names) > 30, names
-    ours = ("dense_", "gemm_ex", "gemm_rsa", "gemm_t2", "transpose_", "gemm_grouped_wgrad", "reduce_slabs", "colsum", "bn_")
+    ours = ("dense_", "gemm_ex", "gemm_small", "gemm_rsa", "gemm_t2", "transpose_", "gemm_grouped_wgrad", "reduce_slabs", "colsum", "bn_")
     foreign = [n for n in names if not any(k in n for k in ours)]
     # the two stack/ones_like glue ops of THIS TEST (outside the head) are the only operator kernels allowed
     foreign = [n for n in foreign if "CatArrayBatchedCopy" not in n and "FillFunctor" not in n and "Memcpy" not in n
