@@ -291,39 +291,76 @@ plan_tail_kernel(int* __restrict__ sizes, int B, int N_cap, int Eb_cap, int Ee_c
 
 // per-table-row item lists of the embedding backward (plan.py::_row_lists): items = flat entries f = i*K + k of
 // codes [N][K] (N from the device), list of row r = items with code r in ascending f, stored as the atom index i.
+// (both kernels: one workgroup per table row; a lane takes 4 consecutive entries per 16-byte load and keeps PL_U of them in
+// flight per trip -- the first versions walked the N * K entries 256 at a time with one 4-byte load per lane and trip, 126
+// dependent trips (count: 20 us) with three barriers each in the fill (61 us at the head of the second stream))
+#define PL_U 4
+__device__ __forceinline__ int4 pl_load4(const int* __restrict__ codes, int f, int total, int vec) {   // f % 4 == 0; vec: codes 16-B aligned
+  if (vec && f + 3 < total) return *reinterpret_cast<const int4*>(codes + f);
+  return make_int4(f < total ? codes[f] : -1, f + 1 < total ? codes[f + 1] : -1, f + 2 < total ? codes[f + 2] : -1,
+                   f + 3 < total ? codes[f + 3] : -1);
+}
+
 __global__ void __launch_bounds__(256)
-plan_lists_count_kernel(const int* __restrict__ codes, const int* __restrict__ n_dev, int K, int* __restrict__ cnt) {
+plan_lists_count_kernel(const int* __restrict__ codes, const int* __restrict__ n_dev, int K, int* __restrict__ cnt, int vec) {
   __shared__ int red[4];
   const int r = blockIdx.x, total = n_dev[0] * K;
   int c = 0;
-  for (int f = threadIdx.x; f < total; f += 256) c += codes[f] == r;
+  for (int f0 = 4 * threadIdx.x; f0 < total; f0 += 1024 * PL_U) {
+    int4 v[PL_U];
+#pragma unroll
+    for (int u = 0; u < PL_U; ++u) v[u] = pl_load4(codes, f0 + 1024 * u, total, vec);
+#pragma unroll
+    for (int u = 0; u < PL_U; ++u) c += (v[u].x == r) + (v[u].y == r) + (v[u].z == r) + (v[u].w == r);
+  }
   c = (int)group_sum((float)c, 64);      // exact: counts < 2^24
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) cnt[r] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// wave w takes the w-th contiguous quarter of the entries (a multiple of 256): it counts its hits, the four counts meet once
+// in LDS, and it then writes its part of the row's list on its own -- per block of 256 entries four ballots (one per
+// component of the lanes' int4) give every hit its rank in ascending f; no barrier in the loop
 __global__ void __launch_bounds__(256)
 plan_lists_fill_kernel(const int* __restrict__ codes, const int* __restrict__ n_dev, int K, const int* __restrict__ ptr,
-                       int* __restrict__ items) {
+                       int* __restrict__ items, int vec) {
   __shared__ int wcnt[4];
-  __shared__ int base;
   const int r = blockIdx.x, total = n_dev[0] * K;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) base = ptr[r];
+  const int per = ((total + 1023) / 1024) * 256;
+  const int lo = w * per, hi = min(lo + per, total);
+  int c = 0;
+  for (int f0 = lo + 4 * lane; f0 < hi; f0 += 256 * PL_U) {
+    int4 v[PL_U];
+#pragma unroll
+    for (int u = 0; u < PL_U; ++u) v[u] = pl_load4(codes, f0 + 256 * u, hi, vec);
+#pragma unroll
+    for (int u = 0; u < PL_U; ++u) c += (v[u].x == r) + (v[u].y == r) + (v[u].z == r) + (v[u].w == r);
+  }
+  c = (int)group_sum((float)c, 64);
+  if (lane == 0) wcnt[w] = c;
   __syncthreads();
-  for (int f0 = 0; f0 < total; f0 += 256) {
-    const int f = f0 + threadIdx.x;
-    const bool hit = f < total && codes[f] == r;
-    const unsigned long long mask = __ballot(hit);
-    if (lane == 0) wcnt[w] = __popcll(mask);
-    __syncthreads();
-    int off = base;
-    for (int k = 0; k < w; ++k) off += wcnt[k];
-    if (hit) items[off + __popcll(mask & ((1ull << lane) - 1ull))] = f / K;
-    __syncthreads();
-    if (threadIdx.x == 0) base += (wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]);
-    __syncthreads();
+  int off = ptr[r];
+  for (int k = 0; k < w; ++k) off += wcnt[k];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int b0 = lo; b0 < hi; b0 += 256 * PL_U) {                  // (uniform trip count: every lane takes part in the ballots)
+    int4 v[PL_U];
+#pragma unroll
+    for (int u = 0; u < PL_U; ++u) v[u] = pl_load4(codes, b0 + 256 * u + 4 * lane, hi, vec);
+#pragma unroll
+    for (int u = 0; u < PL_U; ++u) {
+      const int f = b0 + 256 * u + 4 * lane;
+      const bool h0 = v[u].x == r, h1 = v[u].y == r, h2 = v[u].z == r, h3 = v[u].w == r;
+      const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+      // hits of lower lanes (all four components) come first, then this lane's own components in order
+      int pos = off + __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below);
+      if (h0) items[pos++] = f / K;
+      if (h1) items[pos++] = (f + 1) / K;
+      if (h2) items[pos++] = (f + 2) / K;
+      if (h3) items[pos++] = (f + 3) / K;
+      off += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+    }
   }
 }
 
@@ -365,11 +402,12 @@ extern "C" int msde_plan_row_lists(const int* codes, const int* n_dev, int K, in
                                    void* stream) {
   if (K <= 0 || R <= 0 || R > 1024 || !codes || !n_dev || !cnt || !list_ptr || !items) return R > 1024 ? MSDE_EUNSUP : MSDE_EINVAL;
   hipStream_t st = as_stream(stream);
-  MSDE_LAUNCH(plan_lists_count_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, cnt);
+  const int vec = (reinterpret_cast<uintptr_t>(codes) & 15) == 0;
+  MSDE_LAUNCH(plan_lists_count_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, cnt, vec);
   MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(plan_scan_small_kernel, dim3(1), dim3(1024), 0, st, (const int*)cnt, R, list_ptr, (int*)nullptr);
   MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(plan_lists_fill_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, (const int*)list_ptr, items);
+  MSDE_LAUNCH(plan_lists_fill_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, (const int*)list_ptr, items, vec);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
