@@ -189,6 +189,10 @@ int msde_gather_rows(const float* X, const int* idx, int E, int D, float* out, v
  * Uses that edges stay inside a molecule and rows list sources in ascending order.  deg_s: N ints scratch. */
 int msde_radius_transpose(const int* batch, const int* mol_ptr, const int* rowptr, const int* src, int N,
                           int E_cap, int* deg_s, int* rowptr_s, int* perm_s, void* stream);
+/* The same view in ONE launch, one workgroup per molecule, for batches whose molecules have at most 64 atoms (n_max: the
+ * host's bound; larger: MSDE_EUNSUP -- use msde_radius_transpose).  Identical rowptr_s / perm_s.  mol_ptr [B+1]. */
+int msde_radius_transpose_mol(const int* mol_ptr, int B, int n_max, const int* rowptr, const int* src, int N, int E_cap,
+                              int* rowptr_s, int* perm_s, void* stream);
 
 /* ------------------------------------------------------------------ embeddings ------------- */
 /* ogb AtomEncoder/BondEncoder, nn.Embedding — molecule_gnn_model.py:171, schnet.py:89.

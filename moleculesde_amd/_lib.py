@@ -37,6 +37,7 @@ SIGNATURES = {
     "msde_gather_rows": [P, P, I, I, P, P],
     "msde_embedding_sum_fwd": [P, P, I, I, I, P, P],
     "msde_radius_transpose": [P, P, P, P, I, I, P, P, P, P],
+    "msde_radius_transpose_mol": [P, I, I, P, P, I, I, P, P, P],
     "msde_embedding_sum_bwd_workspace_floats": [I, I, I],
     "msde_embedding_sum_bwd": [P, P, P, I, I, I, P, P, P],
     "msde_gin_aggregate_fwd": [P, P, P, P, P, P, I, I, P, P],

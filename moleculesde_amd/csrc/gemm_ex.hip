@@ -441,15 +441,32 @@ gemm_small_kernel(const msde_gemm_desc d) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[wave][(16 * i + 4 * g + r) * 33 + 16 * j + c] = acc[i][j][r];
   __syncthreads();
-  // epilogue as in gx_epilogue (bias, pre-activation store, activation on a column range or the derivative of a saved
-  // one, row mask, alpha, accumulation); the activation is a run-time switch here -- one uniform branch per element of a
-  // kernel that is a latency chain anyway
+  // plain products (the MD17 chain's ~130 per step): bias and store, nothing else evaluated
+  const bool accum = (d.flags & MSDE_GEMM_ACCUMULATE) != 0;
+  if (d.groups == 1 && d.act == MSDE_ACT_NONE && d.epi == MSDE_EPI_ACT && !d.rowscale && d.alpha == 1.f && !d.Z && !d.bias2 &&
+      !accum) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = q * 256 + tid, row = idx >> 5, col = idx & 31;
+      const int gm = m0 + row, gn = n0 + col;
+      if (gm < d.M && gn < d.N) {
+        const int o = row * 33 + col;
+        float v = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+        if (d.bias) v += d.bias[gn];
+        d.C[(size_t)gm * d.ldc + gn] = v;
+      }
+    }
+    return;
+  }
+  // the tiled kernel's whole epilogue (gx_epilogue: biases, pre-activation store, activation on a column range or the
+  // derivative of a saved one, row mask, alpha, accumulation); the activation is a run-time switch here -- one uniform branch
+  // per element of a kernel that is a latency chain anyway
   const float* __restrict__ bias = d.bias ? d.bias + (size_t)grp * d.bias_gs : nullptr;
   const float* __restrict__ bias2 = d.bias2 ? d.bias2 + (size_t)grp * d.bias_gs : nullptr;
   float* __restrict__ Cg = d.C + (size_t)grp * d.c_gs;
   float* __restrict__ Zg = d.Z ? d.Z + (size_t)grp * d.c_gs : nullptr;
   const float* __restrict__ Rg = d.R ? d.R + (size_t)grp * d.r_gs : nullptr;
-  const bool dact = d.epi == MSDE_EPI_DACT, accum = (d.flags & MSDE_GEMM_ACCUMULATE) != 0;
+  const bool dact = d.epi == MSDE_EPI_DACT;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = q * 256 + tid, row = idx >> 5, col = idx & 31;

@@ -45,7 +45,13 @@ class ForceTrainer:
             rep = self.model(batch.x, positions, batch.radius_edge_index, batch.batch)
         else:
             rep = self.model(batch.x, positions, batch.batch)
-        energy = (self.head(rep) if self.head is not None else rep).squeeze(1)
+        if isinstance(self.head, torch.nn.Linear):
+            # nn.Linear(emb_dim, 1) (finetune_MD17.py:276-279) on the library's twice-differentiable Linear: its product, both
+            # input gradients and the weight gradients (queued into the step's grouped launch) instead of five vendor GEMM
+            # launches + a bias-gradient reduction
+            energy = dd.linear(rep, self.head.weight, self.head.bias).squeeze(1)
+        else:
+            energy = (self.head(rep) if self.head is not None else rep).squeeze(1)
         if self.normalization is not None:
             e_mean, f_mean, n_atom = self.normalization
             energy = energy * f_mean + e_mean * n_atom

@@ -120,7 +120,8 @@ class SchNet(nn.Module):
         if pairwise:
             pp = hip.pair_plan(pos, pl, self.cutoff)
         else:
-            rplan, dist = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors)
+            rplan, dist = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors,
+                                           n_max=getattr(pl, "N_max", None))
         if not fusable:
             rbf, C = hip.rbf_cutoff(dist, rplan.E_dev, de.offset, de.coeff, self.cutoff)
 
@@ -174,7 +175,8 @@ class SchNet(nn.Module):
         the second differentiation only launch library kernels.  The radius CSR comes from the radius kernels (indices
         carry no gradient) and the atom embedding, which does not depend on the positions, from the embedding kernel."""
         from .. import dd
-        rplan, _ = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors)
+        rplan, _ = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors,
+                                   n_max=getattr(pl, "N_max", None))
         dist = dd.row_norm(dd.edge_diff(pos, rplan), rplan)
         de = self.distance_expansion
         rbf = dd.rbf(dist, rplan.src, de.offset, de.coeff)

@@ -91,7 +91,10 @@ def build_csr(edge_index, num_nodes):
     return p
 
 
-def radius_plan(pos, batch_i32, mol_ptr_i32, cutoff, E_cap, max_nbr=32):
+RADIUS_TRANSPOSE_MOL_NMAX = 64      # msde_radius_transpose_mol: molecules of at most this many atoms (the host's bound n_max)
+
+
+def radius_plan(pos, batch_i32, mol_ptr_i32, cutoff, E_cap, max_nbr=32, n_max=None):
     """Radius graph as a by-target CSR emitted directly on the device (schnet.py:91-93).
     Returns (plan, dist[E_cap]).  No host synchronisation: E_cap is the host-side upper bound
     sum_m n_m * min(n_m - 1, max_nbr); the true edge count stays on the device (plan.E_dev)."""
@@ -112,8 +115,13 @@ def radius_plan(pos, batch_i32, mol_ptr_i32, cutoff, E_cap, max_nbr=32):
     # transposed view (by source): stable counting sort on the device, no torch.sort
     rowptr_s = torch.empty(N + 1, dtype=torch.int32, device=dev)
     perm_s = torch.empty(E_cap, dtype=torch.int32, device=dev)
-    _lib.call("msde_radius_transpose", _p(batch_i32), _p(mol_ptr_i32), _p(rowptr), _p(src), N, E_cap, _p(deg),
-              _p(rowptr_s), _p(perm_s), st)
+    B = int(mol_ptr_i32.numel()) - 1
+    if n_max is not None and 0 < int(n_max) <= RADIUS_TRANSPOSE_MOL_NMAX and B > 0:      # one launch, one workgroup per molecule
+        _lib.call("msde_radius_transpose_mol", _p(mol_ptr_i32), B, int(n_max), _p(rowptr), _p(src), N, E_cap, _p(rowptr_s),
+                  _p(perm_s), st)
+    else:
+        _lib.call("msde_radius_transpose", _p(batch_i32), _p(mol_ptr_i32), _p(rowptr), _p(src), N, E_cap, _p(deg),
+                  _p(rowptr_s), _p(perm_s), st)
     p = CsrPlan()
     p.N, p.E = N, E_cap
     p.rowptr, p.src, p.dst = rowptr, src, dst

@@ -255,7 +255,7 @@ class Trainer:
         if ei is None:
             from . import hip, plan as _pl
             pl = _pl.get_plan(batch)
-            rp, _ = hip.radius_plan(batch.positions, pl.batch_i32, pl.mol_ptr, m3.cutoff, pl.E_r_cap, 32)
+            rp, _ = hip.radius_plan(batch.positions, pl.batch_i32, pl.mol_ptr, m3.cutoff, pl.E_r_cap, 32, n_max=getattr(pl, "N_max", None))
             keep = rp.src >= 0                                    # host sync: PaiNN batches are not graph-captured
             # PyG radius_graph orientation: row 0 = source, row 1 = target (the 32-neighbour cap applies per TARGET);
             # PaiNN aggregates at row 0 (painn.py:235), i.e. at the source, exactly as the reference does

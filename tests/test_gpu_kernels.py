@@ -72,6 +72,10 @@ def _radius_check(dev, pos, batch, cutoff, max_nbr=32):
     assert torch.equal(s_sorted, torch.sort(ei[0], stable=True)[0])
     N = pos.size(0)
     assert torch.equal(rp.rowptr_s.cpu().long(), torch.searchsorted(s_sorted, torch.arange(N + 1)))
+    if 0 < pl.N_max <= hip.RADIUS_TRANSPOSE_MOL_NMAX:
+        # the one-launch form (one workgroup per molecule): identical tables, padded slots included
+        rp2, _ = hip.radius_plan(pos.to(dev), pl.batch_i32, pl.mol_ptr, cutoff, pl.E_r_cap, max_nbr, n_max=pl.N_max)
+        assert torch.equal(rp2.rowptr_s, rp.rowptr_s) and torch.equal(rp2.perm_s, rp.perm_s)
     return rp, dist
 
 
