@@ -100,6 +100,10 @@ int msde_dd_rbf(const float* d, const int* src, const float* mu, int E, int G, f
                 void* stream);
 /* op 0: y = alpha a b, 1: y = a + b, 2: y = alpha a (b unused) */
 int msde_dd_binary(const float* a, const float* b, long long n, int op, float alpha, float* y, void* stream);
+/* y = srcs[0] + ... + srcs[n-1] elementwise (n <= 8 device pointers in a HOST array, `count` floats each, summed in index
+ * order): the gradient autograd accumulates for a tensor with n consumers (finetune_MD17.py:68,76 -- the smeared distances and
+ * the cutoff feed all six interaction blocks, schnet.py:185-195) as one launch instead of n - 1 additions. */
+int msde_dd_sum_n(const float* const* srcs, int n, long long count, float* y, void* stream);
 /* y[e][k] = M[e][k] s[e]   and   y[e] = sum_k a[e][k] b[e][k] (fixed lane order) */
 int msde_dd_mul_rows(const float* M, const float* s, int E, int K, float* y, void* stream);
 int msde_dd_row_dot(const float* a, const float* b, int E, int K, float* y, void* stream);

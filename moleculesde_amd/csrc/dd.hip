@@ -68,6 +68,18 @@ __global__ void dd_binary_kernel(const float* __restrict__ a, const float* __res
     y[i] = op == 0 ? alpha * a[i] * b[i] : op == 1 ? a[i] + b[i] : alpha * a[i];
 }
 
+// y = x_0 + x_1 + ... + x_{n-1} (n <= 8, summed in index order): the gradient of a tensor with n consumers in ONE launch
+struct dd_ptrs8 { const float* p[8]; };
+__global__ void dd_sum_n_kernel(dd_ptrs8 s, int n, long long count, float* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    float v = s.p[0][i];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+      if (k < n) v += s.p[k][i];
+    y[i] = v;
+  }
+}
+
 __global__ void dd_mul_rows_kernel(const float* __restrict__ M, const float* __restrict__ s, int E, int K, float* __restrict__ y) {
   const long long n = (long long)E * K;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = M[i] * s[i / K];
@@ -189,6 +201,18 @@ extern "C" int msde_dd_binary(const float* a, const float* b, long long n, int o
   if (n < 0 || !a || !y || op < 0 || op > 2 || (op != 2 && !b)) return MSDE_EINVAL;
   if (n == 0) return 0;
   MSDE_LAUNCH(dd_binary_kernel, DD_GRID(n), dim3(256), 0, as_stream(stream), a, b, n, op, alpha, y);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_dd_sum_n(const float* const* srcs, int n, long long count, float* y, void* stream) {
+  if (!srcs || n < 1 || n > 8 || count < 0 || !y) return MSDE_EINVAL;
+  dd_ptrs8 s;
+  for (int k = 0; k < 8; ++k) {
+    s.p[k] = k < n ? srcs[k] : nullptr;
+    if (k < n && !s.p[k]) return MSDE_EINVAL;
+  }
+  if (count == 0) return 0;
+  MSDE_LAUNCH(dd_sum_n_kernel, DD_GRID(count), dim3(256), 0, as_stream(stream), s, n, count, y);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -154,6 +154,51 @@ class _Add(torch.autograd.Function):
 add = _Add.apply
 
 
+class _SumN(torch.autograd.Function):
+    """x_0 + ... + x_{n-1} (n <= 8) in one launch; its backward hands the same gradient to every addend (no launch)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        import ctypes
+        xs = [_f32(x) for x in xs]
+        y = torch.empty_like(xs[0])
+        arr = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        _call("msde_dd_sum_n", ctypes.cast(arr, ctypes.c_void_p), len(xs), y.numel(), _p(y), _stream())
+        ctx.n = len(xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.n
+
+
+def sum_n(xs):
+    xs = list(xs)
+    while len(xs) > 8:
+        xs = [_SumN.apply(*xs[:8])] + xs[8:]
+    return xs[0] if len(xs) == 1 else _SumN.apply(*xs)
+
+
+class _Fanout(torch.autograd.Function):
+    """n aliases of x for n consumers: their gradients come back to ONE node, which sums them with one launch (sum_n) instead of
+    the n - 1 additions autograd's accumulation would launch -- in the first differentiation and, since sum_n is a member
+    of the closed set, in the second."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.detach() for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        return (sum_n(gs) if gs else None), None
+
+
+def fanout(x, n):
+    return _Fanout.apply(x, n) if n > 1 else (x,)
+
+
 class _Scale(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, alpha):

@@ -183,8 +183,12 @@ class SchNet(nn.Module):
         C = dd.cosine_cutoff(dist, self.cutoff, rplan.src)
         ptr, nodes = _plan.z_lists(pl, self.node_class)
         h = hip.embedding_sum(self.embedding.weight, pl.z_codes, ptr, nodes)
-        for blk in self.interactions:
+        # the smeared distances and the cutoff feed every block: one node each collects the blocks' gradients (dd.fanout)
+        nb = len(self.interactions)
+        rbfs, Cs = dd.fanout(rbf, nb), dd.fanout(C, nb)
+        for bi, blk in enumerate(self.interactions):
             m0, m2 = blk.mlp[0], blk.mlp[2]
+            rbf, C = rbfs[bi], Cs[bi]
             Wf = dd.mul_rows(dd.linear(dd.ssp(dd.linear(rbf, m0.weight, m0.bias)), m2.weight, m2.bias), C)
             x1 = dd.mm_nt(h, blk.conv.lin1.weight)
             agg = dd.edge_aggregate(x1, Wf, rplan)
