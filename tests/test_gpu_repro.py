@@ -47,3 +47,36 @@ def test_captured_two_stream_step_replays_bit_identically(full):
         assert torch.equal(loss, loss0), f"replay {it}: loss {float(loss)} vs {float(loss0)}"
         bad = [n for n in first if not torch.equal(first[n], grads[n])]
         assert not bad, f"replay {it}: {len(bad)} gradients differ from replay 0, e.g. {bad[:5]}"
+
+
+def test_head_loss_as_its_own_backward_root_equals_one_root():
+    """configs[2]'s per-GPU step: the 3D->2D head's loss differentiated as a second root on the second stream
+    (pretrain.SPLIT_HEAD_ROOT, the main stream starts its backward without waiting for the head's forward) gives the same
+    update as the single composed loss of pretrain_MoleculeSDE.py:128-152 -- the same kernels on the same operands, and
+    SchNet's output gradient is a sum of two contributions either way: parameters and Adam moments bit-equal after three steps,
+    captured and replayed included."""
+    assert torch.cuda.is_available()
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd import pretrain
+    from moleculesde_amd.synthetic import make_batch
+    dev = torch.device("cuda", 0)
+    b = G.prepare_batch(make_batch(64, seed=23), dev)
+    runs = []
+    old = pretrain.SPLIT_HEAD_ROOT
+    try:
+        for split in (True, False):
+            pretrain.SPLIT_HEAD_ROOT = split
+            torch.manual_seed(0)
+            tr = pretrain.Trainer(pretrain.readme_args(SDE_coeff_generative_3Dto2D=1), dev)
+            assert tr.overlap_streams
+            losses = [tr.step(b)[0].clone() for _ in range(2)]
+            tr.capture(b)
+            losses.append(tr.step_graph(b).clone())
+            torch.cuda.synchronize()
+            runs.append((losses, tr.opt.flat_p.clone(), tr.opt.m.clone(), tr.opt.v.clone()))
+    finally:
+        pretrain.SPLIT_HEAD_ROOT = old
+    (l1, p1, m1, v1), (l0, p0, m0, v0) = runs
+    for a, c in zip(l1, l0):
+        assert abs(float(a) - float(c)) <= 1e-6 * abs(float(c)), (float(a), float(c))      # (total = main + head: one more addition)
+    assert torch.equal(p1, p0) and torch.equal(m1, m0) and torch.equal(v1, v0)
