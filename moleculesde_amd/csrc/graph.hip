@@ -184,10 +184,10 @@ radius_transpose_mol_kernel(const int* __restrict__ mol_ptr, int B, const int* _
   __shared__ int cnt[RT_NMAX + 1];
   const int m = blockIdx.x, tid = threadIdx.x;
   const int i0 = mol_ptr[m], i1 = mol_ptr[m + 1], n = i1 - i0;
-  if (m == 0) {      // padded slots keep their own index (never read through rowptr_s); the closing row pointer
-    const int E = rowptr[N];
+  if (m == 0) {      // padded slots keep their own index (never read through rowptr_s); the closing row pointer, and the
+    const int E = rowptr[N];                 // rows of atoms behind the last molecule (a capacity bucket's padding): empty
     for (int e = E + tid; e < E_cap; e += 256) perm_s[e] = e;
-    if (tid == 0) rowptr_s[N] = E;
+    for (int j = mol_ptr[B] + tid; j <= N; j += 256) rowptr_s[j] = E;
   }
   if (n <= 0 || n > RT_NMAX) return;          // (n > RT_NMAX: the host does not route such batches here)
   for (int idx = tid; idx < n * n; idx += 256) {

@@ -110,13 +110,16 @@ def _fixed_noise(G, dev):
     return FixedNoise()
 
 
-@pytest.mark.parametrize("full", [False, True])
-def test_bucket_step_matches_exact_batch(dev, full):
+@pytest.mark.parametrize("full,per_edge", [(False, False), (True, False), (False, True)], ids=["configs1", "full", "configs1_per_edge_cfconv"])
+def test_bucket_step_matches_exact_batch(dev, full, per_edge, monkeypatch):
     """Losses and every parameter gradient of one pretrain step: padded bucket + row bounds + device-built plan vs the
     exact-size batch with the host plan.  Contrastive permutation: identity on both sides is impossible (it is drawn
-    on the device), so the contrastive negatives come from a fixed permutation of the VALID atoms."""
+    on the device), so the contrastive negatives come from a fixed permutation of the VALID atoms.  per_edge: SchNet's CFConv
+    on the per-edge kernels (radius CSR + its by-source view built for the PADDED atom count) instead of the pair form."""
     import moleculesde_amd.geom3d as G
     from moleculesde_amd import bucket as BK, hip, pretrain
+    if per_edge:
+        monkeypatch.setattr(hip, "CFCONV_PAIR", False)
     from moleculesde_amd.synthetic import make_batch
     args = pretrain.readme_args(emb_dim=64, SDE_coeff_generative_3Dto2D=1 if full else 0)
     torch.manual_seed(21)
