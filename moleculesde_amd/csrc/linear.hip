@@ -565,7 +565,8 @@ static inline void wgrad_split_for(int M, int N, int K, int target, int* splits,
 // the operands' addresses are known).  Round 4 tried 128 x 128 tiles here for the node-level layers (2 x 2 sub-tiles per wave,
 // dead 32 x 32 sub-tiles skipped; half the operand traffic per FLOP and half the barriers): 2.78 against 2.73 ms per step --
 // the body then needs 216 VGPRs, two workgroups per CU, and the 64 x 64 tiles hide their load -> store -> barrier phases
-// behind six other workgroups instead.
+// behind six other workgroups instead.  Round 5: 128 x 64 tiles (25 % fewer operand bytes per FLOP, 176 VGPRs) for layers with
+// >= 128 outputs: 2.48-2.51 vs 2.50-2.51 ms, --full 3.39-3.40 vs 3.38-3.40 -- nothing; the launch is not bound by operand traffic.
 static inline bool wgrad_group_plan(int M, int N, int K, int* splits, int* k_per_split) {
   wgrad_split_batched(M, N, K, splits, k_per_split);
   return false;
