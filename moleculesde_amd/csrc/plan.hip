@@ -16,27 +16,31 @@
 #define PL_NMAX 32
 #define PL_EMAX 1024
 
-// inclusive block scan of up to 1024 ints held one per thread; returns the exclusive prefix, total in *total
-__device__ __forceinline__ int pl_block_exscan(int v, int* sh /* [1024/64 + 1] */, int* total) {
+// inclusive block scan of up to 1024 x 4 ints (four values per thread, one pass of shuffles and barriers); returns the exclusive
+// prefixes, totals in *total
+__device__ __forceinline__ int4 pl_block_exscan4(int4 v, int4* sh4 /* [1024/64 + 1] */, int4* total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int x = v;
+  int4 x = v;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    int y = __shfl_up(x, o, 64);
-    if (lane >= o) x += y;
+    const int ya = __shfl_up(x.x, o, 64), yb = __shfl_up(x.y, o, 64), yc = __shfl_up(x.z, o, 64), yd = __shfl_up(x.w, o, 64);
+    if (lane >= o) { x.x += ya; x.y += yb; x.z += yc; x.w += yd; }
   }
-  if (lane == 63) sh[w] = x;
+  if (lane == 63) sh4[w] = x;
   __syncthreads();
   if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { int t = sh[k]; sh[k] = acc; acc += t; }
-    sh[blockDim.x >> 6] = acc;
+    int4 acc = make_int4(0, 0, 0, 0);
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+      const int4 t = sh4[k];
+      sh4[k] = acc;
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    sh4[blockDim.x >> 6] = acc;
   }
   __syncthreads();
-  const int ex = sh[w] + x - v;
-  *total = sh[blockDim.x >> 6];
-  __syncthreads();
-  return ex;
+  const int4 b = sh4[w];
+  *total = sh4[blockDim.x >> 6];
+  return make_int4(b.x + x.x - v.x, b.y + x.y - v.y, b.z + x.z - v.z, b.w + x.w - v.w);
 }
 
 // sizes[]: 0 N, 1 E_b, 2 E_e, 3 P = sum n^2, 4 n_max, 5 sum n*min(n-1, max_nbr) (radius-graph edge bound), 6 2*E_e (valid
@@ -53,7 +57,7 @@ __global__ void __launch_bounds__(1024)
 plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_bonds, int B, int max_nbr, int N_cap,
                  int Eb_cap, int P_cap, int Er_cap, int* __restrict__ mol_ptr /* [B+2] */, int* __restrict__ bond_ptr /* [B+1] */,
                  int* __restrict__ pair_ptr /* [B+1] */, int* __restrict__ sizes, int* __restrict__ err) {
-  __shared__ int sh[20];
+  __shared__ int4 sh4[20];
   __shared__ int smax, sbad, scut;
   const int t = threadIdx.x;
   int n = t < B ? mol_atoms[t] : 0, m = t < B ? mol_bonds[t] : 0;
@@ -61,11 +65,11 @@ plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_
   __syncthreads();
   if (n < 0 || n > PL_NMAX || m < 0 || m > PL_EMAX) { n = 0; m = 0; atomicExch(&sbad, 1); }
   const int nr = n * min(max(n - 1, 0), max_nbr);
-  int tot;
-  const int ex_n = pl_block_exscan(n, sh, &tot);
-  const int ex_m = pl_block_exscan(m, sh, &tot);
-  const int ex_p = pl_block_exscan(n * n, sh, &tot);
-  const int ex_r = pl_block_exscan(nr, sh, &tot);
+  // the four running totals (atoms, bonds, atom pairs, radius-edge bound) in ONE block scan; its totals are the batch's when
+  // nothing is cut below (round 5: four scans + four more for the totals were 12.8 us at the head of every step)
+  int4 tot4;
+  const int4 ex4 = pl_block_exscan4(make_int4(n, m, n * n, nr), sh4, &tot4);
+  const int ex_n = ex4.x, ex_m = ex4.y, ex_p = ex4.z, ex_r = ex4.w;
   if (t < B && (ex_n + n > N_cap || ex_m + m > Eb_cap || ex_p + n * n > P_cap || ex_r + nr > Er_cap)) {
     atomicMin(&scut, t);
     atomicExch(&sbad, 1);
@@ -93,11 +97,7 @@ plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_
     pair_ptr[t] = t < cut ? ex_p : cp;
   }
   if (cut == B) {                                  // nothing cut: the block totals
-    int tn, tm, tp, tr;
-    pl_block_exscan(n, sh, &tn);
-    pl_block_exscan(m, sh, &tm);
-    pl_block_exscan(n * n, sh, &tp);
-    pl_block_exscan(nr, sh, &tr);
+    const int tn = tot4.x, tm = tot4.y, tp = tot4.z, tr = tot4.w;
     if (t == 0) {
       mol_ptr[B] = tn; mol_ptr[B + 1] = tn; sizes[0] = tn;
       bond_ptr[B] = tm; sizes[1] = tm;
@@ -110,16 +110,6 @@ plan_scan_kernel(const int* __restrict__ mol_atoms, const int* __restrict__ mol_
   if (t == 0) { sizes[4] = smax; *err = sbad; }
 }
 
-// exclusive scan of cnt[0..n) (n <= 1024) -> ptr[0..n], total also to *total_out
-__global__ void __launch_bounds__(1024)
-plan_scan_small_kernel(const int* __restrict__ cnt, int n, int* __restrict__ ptr, int* __restrict__ total_out) {
-  __shared__ int sh[20];
-  const int t = threadIdx.x;
-  int tot;
-  const int ex = pl_block_exscan(t < n ? cnt[t] : 0, sh, &tot);
-  if (t < n) ptr[t] = ex;
-  if (t == 0) { ptr[n] = tot; if (total_out) *total_out = tot; }
-}
 
 // One workgroup per molecule: atom arrays, bond CSR (by target, ties in loader order = torch.argsort(stable)) with its
 // by-source view, bond feature codes, and the <= 4-bond neighbourhood rows (bit masks) + their count.
@@ -221,16 +211,28 @@ plan_molecule_kernel(const int* __restrict__ x_raw, int K, const int* __restrict
 
 // extended edges (row = source r, col = target c, loader order = row major): CSR by target + by-source view
 __global__ void __launch_bounds__(64)
-plan_ext_kernel(const unsigned* __restrict__ ext_rows, const int* __restrict__ mol_ptr, const int* __restrict__ ext_ptr,
-                int* __restrict__ rowptr, int* __restrict__ src, int* __restrict__ dst, int* __restrict__ rowptr_s,
-                int* __restrict__ perm_s, int N_cap, int Ee_cap, int* __restrict__ err) {
+plan_ext_kernel(const unsigned* __restrict__ ext_rows, const int* __restrict__ mol_ptr, const int* __restrict__ ext_cnt, int B,
+                int* __restrict__ ext_ptr, int* __restrict__ total_out, int* __restrict__ rowptr, int* __restrict__ src,
+                int* __restrict__ dst, int* __restrict__ rowptr_s, int* __restrict__ perm_s, int N_cap, int Ee_cap,
+                int* __restrict__ err) {
   __shared__ unsigned R[PL_NMAX], Cc[PL_NMAX];
   __shared__ int rp[PL_NMAX + 1], rs[PL_NMAX + 1];
   const int b = blockIdx.x, t = threadIdx.x;
-  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, x0 = ext_ptr[b];
-  if (n > PL_NMAX || n < 0 || a0 + n > N_cap || ext_ptr[b + 1] > Ee_cap) {
+  // offset of the molecule's extended edges = the counts of the molecules in front of it, summed by this (one-wave) workgroup
+  // itself (B <= 1024 counts: 16 loads per lane at most) instead of by a scan launch between plan_molecule and this kernel
+  int x0 = 0;
+  for (int k = t; k < b; k += 64) x0 += ext_cnt[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x0 += __shfl_xor(x0, o, 64);
+  const int x1 = x0 + ext_cnt[b];
+  if (t == 0) {
+    ext_ptr[b] = x0;
+    if (b == B - 1) { ext_ptr[B] = x1; *total_out = x1; }
+  }
+  const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0;
+  if (n > PL_NMAX || n < 0 || a0 + n > N_cap || x1 > Ee_cap) {
     // (flagged molecules have no extended edges: only their row pointers are set, inside the buffer)
-    if (ext_ptr[b + 1] > Ee_cap && t == 0) atomicExch(err, 1);
+    if (x1 > Ee_cap && t == 0) atomicExch(err, 1);
     if (n > 0 && t < min(n, PL_NMAX) && a0 + t < N_cap) { rowptr[a0 + t] = min(x0, Ee_cap); rowptr_s[a0 + t] = min(x0, Ee_cap); }
     return;
   }
@@ -323,9 +325,10 @@ plan_lists_count_kernel(const int* __restrict__ codes, const int* __restrict__ n
 // in LDS, and it then writes its part of the row's list on its own -- per block of 256 entries four ballots (one per
 // component of the lanes' int4) give every hit its rank in ascending f; no barrier in the loop
 __global__ void __launch_bounds__(256)
-plan_lists_fill_kernel(const int* __restrict__ codes, const int* __restrict__ n_dev, int K, const int* __restrict__ ptr,
-                       int* __restrict__ items, int vec) {
+plan_lists_fill_kernel(const int* __restrict__ codes, const int* __restrict__ n_dev, int K, const int* __restrict__ cnt, int R,
+                       int* __restrict__ ptr, int* __restrict__ items, int vec) {
   __shared__ int wcnt[4];
+  __shared__ int wpre[4];
   const int r = blockIdx.x, total = n_dev[0] * K;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int per = ((total + 1023) / 1024) * 256;
@@ -339,9 +342,19 @@ plan_lists_fill_kernel(const int* __restrict__ codes, const int* __restrict__ n_
     for (int u = 0; u < PL_U; ++u) c += (v[u].x == r) + (v[u].y == r) + (v[u].z == r) + (v[u].w == r);
   }
   c = (int)group_sum((float)c, 64);
-  if (lane == 0) wcnt[w] = c;
+  // start of the row's list = the counts of the rows in front of it (R <= 1024), summed here instead of by a scan launch
+  // between the count and the fill; the row's own pointer (and the closing one) is written for the embedding backward
+  int pre = 0;
+  for (int k = threadIdx.x; k < r; k += 256) pre += cnt[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+  if (lane == 0) { wcnt[w] = c; wpre[w] = pre; }
   __syncthreads();
-  int off = ptr[r];
+  int off = (wpre[0] + wpre[1]) + (wpre[2] + wpre[3]);
+  if (threadIdx.x == 0) {
+    ptr[r] = off;
+    if (r == R - 1) ptr[R] = off + ((wcnt[0] + wcnt[1]) + (wcnt[2] + wcnt[3]));
+  }
   for (int k = 0; k < w; ++k) off += wcnt[k];
   const unsigned long long below = (1ull << lane) - 1ull;
   for (int b0 = lo; b0 < hi; b0 += 256 * PL_U) {                  // (uniform trip count: every lane takes part in the ballots)
@@ -384,10 +397,8 @@ extern "C" int msde_plan_build(const int* x_raw, int K, const int* atom_off, con
               (const int*)mol_ptr, (const int*)bond_ptr, batch_i32, atom_codes, z_codes, b_rowptr, b_src, b_dst, b_rowptr_s,
               b_perm_s, bond_codes, bond_type, ext_rows, ext_cnt, err, B, N_cap, Eb_cap);
   MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(plan_scan_small_kernel, dim3(1), dim3(1024), 0, st, (const int*)ext_cnt, B, ext_ptr, sizes + 2);
-  MSDE_CHECK_LAUNCH();
   MSDE_LAUNCH(plan_ext_kernel, dim3(B), dim3(64), 0, st, (const unsigned*)ext_rows, (const int*)mol_ptr,
-              (const int*)ext_ptr, e_rowptr, e_src, e_dst, e_rowptr_s, e_perm_s, N_cap, Ee_cap, err);
+              (const int*)ext_cnt, B, ext_ptr, sizes + 2, e_rowptr, e_src, e_dst, e_rowptr_s, e_perm_s, N_cap, Ee_cap, err);
   MSDE_CHECK_LAUNCH();
   int tail = (N_cap + Eb_cap + Ee_cap + 255) / 256;
   if (tail > 512) tail = 512;
@@ -405,9 +416,7 @@ extern "C" int msde_plan_row_lists(const int* codes, const int* n_dev, int K, in
   const int vec = (reinterpret_cast<uintptr_t>(codes) & 15) == 0;
   MSDE_LAUNCH(plan_lists_count_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, cnt, vec);
   MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(plan_scan_small_kernel, dim3(1), dim3(1024), 0, st, (const int*)cnt, R, list_ptr, (int*)nullptr);
-  MSDE_CHECK_LAUNCH();
-  MSDE_LAUNCH(plan_lists_fill_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, (const int*)list_ptr, items, vec);
+  MSDE_LAUNCH(plan_lists_fill_kernel, dim3(R), dim3(256), 0, st, codes, n_dev, K, (const int*)cnt, R, list_ptr, items, vec);
   MSDE_CHECK_LAUNCH();
   return 0;
 }
