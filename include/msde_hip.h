@@ -499,6 +499,13 @@ int msde_bn_fin_bwd(const float* stats, int strips, int M, const int* m_valid, i
 int msde_bn_bwd_cols(const float* G, int ldg, const float* Z, int ldz, const float* p, const float* w, const float* u,
                      const float* xf3, const float* xf4, int M, const int* m_valid, int C, float* out, int ldo,
                      void* stream);
+/* msde_bn_fin_bwd + msde_bn_bwd_cols as ONE launch (the finish no longer sits on the GIN backward chain as a launch of its own):
+ * every workgroup sums the strip partials `stats` [strips][2][C] of its 64 columns itself (fixed order), forms p | w | u as
+ * msde_bn_fin_bwd does and applies them to its rows; dgamma / dbeta (NULL: not wanted) are written once.  Same operand
+ * conventions as the two entry points it replaces. */
+int msde_bn_bwd_fin_cols(const float* stats, int strips, const float* gamma, const float* mean, const float* rstd,
+                         const float* G, int ldg, const float* Z, int ldz, const float* xf3, const float* xf4, int M,
+                         const int* m_valid, int C, float* out, int ldo, float* dgamma, float* dbeta, void* stream);
 /* Y = max(X * scale[c] + shift[c], 0 if relu) over rows (the BatchNorm apply for a tensor with several consumers: the GIN
  * layer output, molecule_gnn_model.py:176-182); C % 4 == 0. */
 int msde_affine_cols(const float* X, int M, int C, const float* scale, const float* shift, int relu, float* Y,

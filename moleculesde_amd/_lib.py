@@ -90,6 +90,7 @@ SIGNATURES = {
     "msde_affine_cols": [P, I, I, P, P, I, P, P],
     "msde_bn_bwd_colstats": [P, P, P, P, I, P, I, P, P],
     "msde_bn_bwd_cols": [P, I, P, I, P, P, P, P, P, I, P, I, P, I, P],
+    "msde_bn_bwd_fin_cols": [P, I, P, P, P, P, I, P, I, P, P, I, P, I, P, I, P, P, P],
     "msde_gemm_rs_geometry": [I, I, I, P, P],
     "msde_bn_fin_fwd": [P, I, I, I, P, I, P, P, F, F, P, P, P, P, P, P, P],
     "msde_bn_fin_bwd": [P, I, I, P, I, P, P, P, P, P, P, P, P, P],

@@ -311,6 +311,88 @@ bn_bwd_cols_kernel(const float* __restrict__ G, int ldg, const float* __restrict
   }
 }
 
+// bn_fin_bwd + bn_bwd_cols in ONE launch: a workgroup owns 64 columns x a chunk of rows; it first sums the strip partials of
+// ITS columns (strips x 2 x 64 values: thread = (column, strip quarter), the four quarters meet in LDS in a fixed order) into
+// p | w | u exactly as bn_fin_bwd does, then streams its rows.  The finish was a 5 us launch of its own on the GIN chain in
+// front of every column pass (ten per step); recomputing it per workgroup costs ~30 independent loads per thread.  The row
+// chunk 0 of a column block also writes dgamma / dbeta.  Fixed summation order (bit-reproducible), not the order of
+// bn_fin_bwd<64> (a wave per column).
+__global__ void __launch_bounds__(256)
+bn_bwd_fin_cols_kernel(const float* __restrict__ stats, int strips, const float* __restrict__ gamma, const float* __restrict__ mean,
+                       const float* __restrict__ rstd, const float* __restrict__ G, int ldg, const float* __restrict__ Z, int ldz,
+                       const float* __restrict__ xf3, const float* __restrict__ xf4, int M, const int* __restrict__ m_valid, int C,
+                       int rows_per_wg, float* __restrict__ out, int ldo, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float pa[4][64], pb[4][64];
+  __shared__ float vp[64], vw[64], vu[64];
+  const int mv = m_valid ? min(M, m_valid[0]) : M;
+  const int c0 = blockIdx.x * 64;
+  {
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int cc = min(c0 + cl, C - 1);
+    float a = 0.f, b = 0.f;
+    for (int s0 = q; s0 < strips; s0 += 16) {          // four strips of this quarter per trip: eight independent loads in flight
+      float xa[4], xb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sidx = s0 + 4 * k;
+        const bool ok = sidx < strips;
+        const size_t o = (size_t)(ok ? sidx : 0) * 2 * C + cc;
+        xa[k] = ok ? stats[o] : 0.f;
+        xb[k] = ok ? stats[o + C] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a += xa[k]; b += xb[k]; }
+    }
+    pa[q][cl] = a;
+    pb[q][cl] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cl = threadIdx.x, col = c0 + cl;
+    if (col < C) {
+      const float ra = ((pa[0][cl] + pa[1][cl]) + pa[2][cl]) + pa[3][cl];
+      const float rb = ((pb[0][cl] + pb[1][cl]) + pb[2][cl]) + pb[3][cl];
+      const float rs = rstd[col], mu = mean[col], gv = gamma ? gamma[col] : 1.f;
+      const float sum_g = ra, sum_gx = rb * rs;          // sum g', sum g' xhat
+      if (blockIdx.y == 0) {
+        if (dbeta) dbeta[col] = sum_g;
+        if (dgamma) dgamma[col] = sum_gx;
+      }
+      const float inv = mv > 0 ? 1.f / (float)mv : 0.f;
+      const float c1 = sum_g * inv, c2 = sum_gx * inv;
+      const float pp = gv * rs;
+      vp[cl] = pp;
+      vw[cl] = -pp * c2 * rs;
+      vu[cl] = pp * (c2 * rs * mu - c1);
+    } else {
+      vp[cl] = 0.f; vw[cl] = 0.f; vu[cl] = 0.f;
+    }
+  }
+  __syncthreads();
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = c0 + 4 * cq;
+  if (c >= C) return;
+  const float4 pp = *reinterpret_cast<const float4*>(&vp[4 * cq]), ww = *reinterpret_cast<const float4*>(&vw[4 * cq]),
+               uu = *reinterpret_cast<const float4*>(&vu[4 * cq]);
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga;
+  if (xf3) { ga = *reinterpret_cast<const float4*>(xf3 + c); gb = *reinterpret_cast<const float4*>(xf4 + c); }
+  const int r0 = blockIdx.y * rows_per_wg, r1 = min(r0 + rows_per_wg, M);
+  for (int m = r0 + rl; m < r1; m += 16) {
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < mv) {
+      float4 g = *reinterpret_cast<const float4*>(G + (size_t)m * ldg + c);
+      const float4 z = *reinterpret_cast<const float4*>(Z + (size_t)m * ldz + c);
+      if (xf3) {
+        g.x = fmaf(z.x, ga.x, gb.x) <= 0.f ? 0.f : g.x; g.y = fmaf(z.y, ga.y, gb.y) <= 0.f ? 0.f : g.y;
+        g.z = fmaf(z.z, ga.z, gb.z) <= 0.f ? 0.f : g.z; g.w = fmaf(z.w, ga.w, gb.w) <= 0.f ? 0.f : g.w;
+      }
+      y = make_float4(fmaf(pp.x, g.x, fmaf(ww.x, z.x, uu.x)), fmaf(pp.y, g.y, fmaf(ww.y, z.y, uu.y)),
+                      fmaf(pp.z, g.z, fmaf(ww.z, z.z, uu.z)), fmaf(pp.w, g.w, fmaf(ww.w, z.w, uu.w)));
+    }
+    *reinterpret_cast<float4*>(out + (size_t)m * ldo + c) = y;
+  }
+}
+
 // BatchNorm-backward partial sums of a gradient that does NOT come out of one of the products above (the gradient of the
 // GIN layer output): per 64-row strip and column, sum g' and sum g' (z - mean[c]) with g' = g gated by the fused ReLU
 // (y[m][c] > 0, y = the layer output) -- the [strips][2][C] format of MSDE_RS_STATS_BNBWD.  One workgroup per
@@ -586,6 +668,23 @@ extern "C" int msde_bn_bwd_cols(const float* G, int ldg, const float* Z, int ldz
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   MSDE_LAUNCH(bn_bwd_cols_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), G, ldg, Z, ldz, p, w, u, xf3, xf4, M, m_valid, C,
               out, ldo);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int msde_bn_bwd_fin_cols(const float* stats, int strips, const float* gamma, const float* mean, const float* rstd,
+                                    const float* G, int ldg, const float* Z, int ldz, const float* xf3, const float* xf4, int M,
+                                    const int* m_valid, int C, float* out, int ldo, float* dgamma, float* dbeta, void* stream) {
+  if (M <= 0 || C <= 0) return 0;
+  if (C % 4 || ldg % 4 || ldz % 4 || ldo % 4 || !stats || strips <= 0 || !mean || !rstd || !G || !Z || !out ||
+      ((xf3 == nullptr) != (xf4 == nullptr)))
+    return MSDE_EINVAL;
+  const int cb = (C + 63) / 64;
+  // row chunk: ~one resident round of workgroups per CU or more (C = 600: 10 column blocks x 128-row chunks; C = 300: 5 x 64)
+  const int rows_per_wg = (long)cb * ((M + 127) / 128) >= msde_num_cus() ? 128 : 64;
+  dim3 grid(cb, (M + rows_per_wg - 1) / rows_per_wg);
+  MSDE_LAUNCH(bn_bwd_fin_cols_kernel, grid, dim3(256), 0, as_stream(stream), stats, strips, gamma, mean, rstd, G, ldg, Z, ldz,
+              xf3, xf4, M, m_valid, C, rows_per_wg, out, ldo, dgamma, dbeta);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

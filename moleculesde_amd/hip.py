@@ -2021,6 +2021,17 @@ def _bn_fin_bwd(stats, strips, M, C, gamma, mean, rstd, need_affine_grads=True):
     return vec, gb
 
 
+BN_BWD_FUSED_FIN = True     # ... with the finish of the strip partials inside the pass (msde_bn_bwd_fin_cols): one launch, not two
+
+
+def _bn_bwd_fin_cols(stats, strips, M, C, gamma, mean, rstd, G, Z, xf3, xf4, out, rows):
+    """(dgamma | dbeta) [2, C]; out = the BatchNorm input gradient (see msde_bn_bwd_fin_cols)."""
+    gb = torch.empty(2, C, dtype=torch.float32, device=stats.device)
+    _lib.call("msde_bn_bwd_fin_cols", _p(stats), strips, _p(gamma), _p(mean), _p(rstd), _p(G), _ld(G), _p(Z), _ld(Z), _p(xf3),
+              _p(xf4), M, _p(rows), C, _p(out), _ld(out), _p(gb[0]), _p(gb[1]), _stream())
+    return gb
+
+
 BN_BWD_PASS = True     # GIN backward: BatchNorm input gradient as a streaming pass + plain product: 2.543 vs 2.587 ms (False: on the A fragments)
 
 
@@ -2080,7 +2091,9 @@ class _GinMlpBN(torch.autograd.Function):
         stb = torch.empty(sb, 2, D, dtype=torch.float32, device=dev)
         _lib.call("msde_bn_bwd_colstats", _p(g), _p(z2), _p(h if ctx.relu_out else None), _p(v2[2]), M,
                   _p(bound_tensor(M)), D, _p(stb), st)
-        pw2, gb2 = _bn_fin_bwd(stb, sb, M, D, g2, v2[2], v2[3])
+        fused_fin = BN_BWD_PASS and BN_BWD_FUSED_FIN
+        if not fused_fin:
+            pw2, gb2 = _bn_fin_bwd(stb, sb, M, D, g2, v2[2], v2[3])
         # g_a1 = dz2 W2, gated by the ReLU behind BatchNorm 1 (a1 > 0), with BatchNorm 1's partial sums
         sa, _ = rs_geometry(M, H, D)
         sta = torch.empty(sa, 2, H, dtype=torch.float32, device=dev)
@@ -2089,20 +2102,28 @@ class _GinMlpBN(torch.autograd.Function):
         rows = bound_tensor(M)
         if BN_BWD_PASS:
             # the BatchNorm input gradient as a streaming pass in front of a PLAIN product (see msde_bn_bwd_cols)
-            _lib.call("msde_bn_bwd_cols", _p(g), _ld(g), _p(z2), _ld(z2), _p(pw2[0]), _p(pw2[1]), _p(pw2[2]),
-                      _p(v2[0] if ctx.relu_out else None), _p(v2[1] if ctx.relu_out else None), M, _p(rows), D, _p(dz2), D, st)
+            if fused_fin:
+                gb2 = _bn_bwd_fin_cols(stb, sb, M, D, g2, v2[2], v2[3], g, z2, v2[0] if ctx.relu_out else None,
+                                       v2[1] if ctx.relu_out else None, dz2, rows)
+            else:
+                _lib.call("msde_bn_bwd_cols", _p(g), _ld(g), _p(z2), _ld(z2), _p(pw2[0]), _p(pw2[1]), _p(pw2[2]),
+                          _p(v2[0] if ctx.relu_out else None), _p(v2[1] if ctx.relu_out else None), M, _p(rows), D, _p(dz2), D, st)
             gemm_node(dz2, W2, ga1, False, H, D, act="relu", dact_from=a1, stats=sta, stats_mode="bnbwd", stats_z=z1,
                       stats_mean=v1[2])
         else:
             gemm_node(g, W2, ga1, False, H, D, axf="bnbwd",
                       xf=(pw2[0], pw2[1], pw2[2]) + ((v2[0], v2[1]) if ctx.relu_out else (None, None)), A2=z2, A_out=dz2,
                       act="relu", dact_from=a1, stats=sta, stats_mode="bnbwd", stats_z=z1, stats_mean=v1[2])
-        pw1, gb1 = _bn_fin_bwd(sta, sa, M, H, g1, v1[2], v1[3])
+        if not fused_fin:
+            pw1, gb1 = _bn_fin_bwd(sta, sa, M, H, g1, v1[2], v1[3])
         dz1 = torch.empty(M, H, dtype=torch.float32, device=dev)
         g_agg = torch.empty(M, D, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         if BN_BWD_PASS:
-            _lib.call("msde_bn_bwd_cols", _p(ga1), _ld(ga1), _p(z1), _ld(z1), _p(pw1[0]), _p(pw1[1]), _p(pw1[2]), _p(None), _p(None),
-                      M, _p(rows), H, _p(dz1), H, st)
+            if fused_fin:
+                gb1 = _bn_bwd_fin_cols(sta, sa, M, H, g1, v1[2], v1[3], ga1, z1, None, None, dz1, rows)
+            else:
+                _lib.call("msde_bn_bwd_cols", _p(ga1), _ld(ga1), _p(z1), _ld(z1), _p(pw1[0]), _p(pw1[1]), _p(pw1[2]), _p(None), _p(None),
+                          M, _p(rows), H, _p(dz1), H, st)
             if g_agg is not None:
                 gemm_node(dz1, W1, g_agg, False, D, H)
         elif g_agg is not None:

@@ -1566,3 +1566,36 @@ def test_l1_energy_force_loss(dev, B, n3):
     assert_close(gE, ge_ref, 1e-6, 1e-9, "d loss / d energy")
     assert_close(gd, gd_ref, 1e-6, 1e-9, "d loss / d (dE)")
     assert float(gE[0]) == 0.0 and float(gd[1]) == 0.0
+
+
+@pytest.mark.parametrize("M,C,strips,gate", [(3588, 600, 57, False), (3588, 300, 57, True), (3712, 300, 228, True), (100, 64, 2, False),
+                                             (1000, 20, 16, True)])
+def test_bn_bwd_fin_cols_matches_finish_plus_pass(dev, M, C, strips, gate):
+    """msde_bn_bwd_fin_cols (the BatchNorm-backward finish inside the column pass: one launch on the GIN backward chain,
+    molecule_gnn_model.py:17,176-182) against msde_bn_fin_bwd + msde_bn_bwd_cols: the input gradient, dgamma and dbeta -- same
+    formulas, another (fixed) summation order over the strips; rows behind the row bound are written as zero; two runs bit-equal."""
+    from moleculesde_amd import hip, _lib
+    g = torch.Generator().manual_seed(M + C + strips)
+    stats = torch.randn(strips, 2, C, generator=g).to(dev)
+    gamma, mean = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    rstd = (torch.rand(C, generator=g) + 0.5).to(dev)
+    Gw = torch.randn(M, C + 8, generator=g).to(dev)
+    G = Gw[:, 4:4 + C]                                    # a column block of a wider buffer (row stride != C)
+    Z = torch.randn(M, C, generator=g).to(dev)
+    xf3 = torch.randn(C, generator=g).to(dev) if gate else None
+    xf4 = torch.randn(C, generator=g).to(dev) if gate else None
+    mv = M - 37
+    with hip.row_bounds({M: torch.tensor([mv], dtype=torch.int32, device=dev)}):
+        rows = hip.bound_tensor(M)
+        pw, gb = hip._bn_fin_bwd(stats, strips, M, C, gamma, mean, rstd)
+        ref = torch.full((M, C), float("nan"), device=dev)
+        _lib.call("msde_bn_bwd_cols", hip._p(G), hip._ld(G), hip._p(Z), hip._ld(Z), hip._p(pw[0]), hip._p(pw[1]), hip._p(pw[2]),
+                  hip._p(xf3), hip._p(xf4), M, hip._p(rows), C, hip._p(ref), C, hip._stream())
+        out = torch.full((M, C), float("nan"), device=dev)
+        gb2 = hip._bn_bwd_fin_cols(stats, strips, M, C, gamma, mean, rstd, G, Z, xf3, xf4, out, rows)
+        out_b = torch.empty(M, C, device=dev)
+        gb3 = hip._bn_bwd_fin_cols(stats, strips, M, C, gamma, mean, rstd, G, Z, xf3, xf4, out_b, rows)
+    assert torch.isfinite(out).all() and float(out[mv:].abs().max()) == 0.0
+    assert_close(out, ref.double(), 2e-5, 2e-5, "fused finish + pass: input gradient")
+    assert_close(gb2, gb.double(), 2e-5, 2e-5, "fused finish + pass: dgamma / dbeta")
+    assert torch.equal(out, out_b) and torch.equal(gb2, gb3), "two runs differ"
