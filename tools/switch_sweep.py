@@ -21,6 +21,7 @@ SETTINGS = {
     "moltrain": "moleculesde_amd.geom3d.sde_2d_to_3d:MOL_KERNEL_TRAIN=True",
     "noscore2": "moleculesde_amd.geom3d.sde_2d_to_3d:MOL_KERNEL_SCORE=False",      # get_score: separate geometry launches + msde_escore_mol_fwd
     "nomol": "moleculesde_amd.geom3d.sde_2d_to_3d:MOL_KERNEL=False",   # ... and operator by operator
+    "nofusedfin": "moleculesde_amd.hip:BN_BWD_FUSED_FIN=False",          # BatchNorm-backward finish as a launch of its own again
     "nosplit": "moleculesde_amd.pretrain:SPLIT_HEAD_ROOT=False",       # the 3D->2D head's loss composed into the one root again
 }
 
