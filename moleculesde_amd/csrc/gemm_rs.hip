@@ -330,10 +330,10 @@ bn_bwd_fin_cols_kernel(const float* __restrict__ stats, int strips, const float*
     const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int cc = min(c0 + cl, C - 1);
     float a = 0.f, b = 0.f;
-    for (int s0 = q; s0 < strips; s0 += 16) {          // four strips of this quarter per trip: eight independent loads in flight
-      float xa[4], xb[4];
+    for (int s0 = q; s0 < strips; s0 += 64) {          // sixteen strips of this quarter per trip (all 57 strips of the GIN layers in
+      float xa[16], xb[16];                            // ONE trip): 32 independent loads in flight, then summed in strip order
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 16; ++k) {
         const int sidx = s0 + 4 * k;
         const bool ok = sidx < strips;
         const size_t o = (size_t)(ok ? sidx : 0) * 2 * C + cc;
@@ -341,7 +341,7 @@ bn_bwd_fin_cols_kernel(const float* __restrict__ stats, int strips, const float*
         xb[k] = ok ? stats[o + C] : 0.f;
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { a += xa[k]; b += xb[k]; }
+      for (int k = 0; k < 16; ++k) { a += xa[k]; b += xb[k]; }
     }
     pa[q][cl] = a;
     pb[q][cl] = b;
