@@ -1,6 +1,6 @@
 """Undistorted timeline of one hipGraph replay of the pretrain step: device timestamps (msde_debug_stamp, 100 MHz) captured
 into the graph at the phase boundaries of both streams.  Prints microseconds from the start of the replay, median over
-replays.  usage: python tools/probes/step_timeline.py [--bucket] [--full]"""
+replays.  usage: python tools/probes/step_timeline.py [--bucket] [--full] [--no_cl]"""
 import os, sys, torch, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from moleculesde_amd import pretrain, hip, bucket as BK
@@ -9,7 +9,8 @@ from moleculesde_amd.synthetic import make_batch
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 full = "--full" in sys.argv
-tr = pretrain.Trainer(pretrain.readme_args() if full else pretrain.readme_args(SDE_coeff_generative_3Dto2D=0), dev)
+kw = dict(SDE_coeff_contrastive=0) if "--no_cl" in sys.argv else {}      # --no_cl: the main chain alone (no SchNet, no contrastive term)
+tr = pretrain.Trainer(pretrain.readme_args(**kw) if full else pretrain.readme_args(SDE_coeff_generative_3Dto2D=0, **kw), dev)
 hip.enable_stamps(dev)
 cpu = [make_batch(256, seed=s) for s in range(4)]
 if "--bucket" in sys.argv:
