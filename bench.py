@@ -761,6 +761,78 @@ def cpu_baseline(bs=256):
     return out
 
 
+# Keys every `--gpus N` line carries beside the contract's own (tests/test_host_logic.py asserts them on the launcher path,
+# tools/dp2_gloo_smoke.sh on a real step): configs[2]'s full step timed by the same ranks, the pieces of a DP step, the
+# per-rank spread.
+DP_LINE_KEYS = ("config2_full", "dp_step_parts_us", "ms_per_step_per_rank", "rccl_ranks_seen", "rank_devices", "dp_backend")
+DP_PART_KEYS = ("graph_us", "allreduce_us", "adam_us", "allreduce_alone_us", "steps")
+
+
+def dp_step_parts(trainer, step_i, n=20):
+    """The pieces of a data-parallel step, from HIP events on the compute stream (median over `n` steps, this rank):
+    `graph_us` = the captured graph (plan, forward, backward, weight gradients, gradient flattening); `allreduce_us` = what the
+    compute stream WAITS for the bucketed collectives (they run on RCCL's stream; bucket k+1 is on the wire while bucket k's
+    Adam runs, so this is the exposed part); `adam_us` = the per-bucket optimiser launches; `allreduce_alone_us` = the same
+    bucketed collectives issued on an otherwise idle device.  Every rank runs this (collectives inside)."""
+    import statistics
+    from moleculesde_amd import dp
+    try:
+        for i in range(3):
+            step_i(i)
+        trainer.dp_timing = []
+        for i in range(n):
+            step_i(i)
+        torch.cuda.synchronize()
+        recs, trainer.dp_timing = trainer.dp_timing, None
+        g_us, ar_us, ad_us = [], [], []
+        for ev in recs:
+            if len(ev) < 4:
+                continue
+            g_us.append(ev[0].elapsed_time(ev[1]) * 1e3)
+            ar = ad = 0.0
+            for k in range(2, len(ev), 2):
+                ar += ev[k - 1].elapsed_time(ev[k]) * 1e3
+                ad += ev[k].elapsed_time(ev[k + 1]) * 1e3
+            ar_us.append(ar)
+            ad_us.append(ad)
+        alone = []
+        flat, ranges = trainer.opt.flat_g, trainer.opt.bucket_ranges
+        for _ in range(max(n // 2, 3)):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _, works, _ = dp.allreduce_buckets_async(flat, ranges)
+            for w in works:
+                if w is not None:
+                    w.wait()
+            e1.record()
+            e1.synchronize()
+            alone.append(e0.elapsed_time(e1) * 1e3)
+        flat.zero_()
+        med = lambda v: round(statistics.median(v), 1) if v else None
+        return {"graph_us": med(g_us), "allreduce_us": med(ar_us), "adam_us": med(ad_us), "allreduce_alone_us": med(alone),
+                "steps": len(g_us), "gradient_bytes": int(flat.numel() * 4),
+                "buckets_bytes": [int((b - a_) * 4) for a_, b in ranges],
+                "what": "HIP events on the compute stream, median per step on this rank: graph_us = the captured step graph, "
+                        "allreduce_us = what the compute stream waits for the per-model gradient buckets (exposed part; the next "
+                        "bucket is on the wire while a bucket's Adam runs), adam_us = the per-bucket Adam launches, "
+                        "allreduce_alone_us = the same collectives on an otherwise idle device"}
+    except Exception as exc:
+        trainer.dp_timing = None
+        print(f"[bench] DP step parts failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def gather_ranks(vec, device):
+    """Every rank's row of floats (None -> nan), as a list of lists on every rank."""
+    t = torch.tensor([float("nan") if v is None else float(v) for v in vec], device=device, dtype=torch.float64)
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return [t.tolist()]
+    got = [torch.zeros_like(t) for _ in range(torch.distributed.get_world_size())]
+    torch.distributed.all_gather(got, t)
+    return [g.tolist() for g in got]
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -820,6 +892,8 @@ def main():
     ap.add_argument("--score_kernel", default="ops", choices=["ops", "mol"],
                     help="2D->3D score network under autograd: operator by operator (default) or one launch each way with one "
                          "workgroup per molecule (pretrain.py --score_kernel)")
+    ap.add_argument("--no_config2", action="store_true",
+                    help="skip the second timing (configs[2]: the full step with the 3D->2D head, same ranks) behind the headline")
     ap.add_argument("--census_only", action="store_true",
                     help="launcher check: start the ranks, count them with one all-reduce, print the line's DP keys and exit "
                          "(runs without a GPU under MSDE_DP_BACKEND=gloo: tests/test_host_logic.py)")
@@ -844,7 +918,8 @@ def main():
             torch.distributed.all_gather(got, mine)
         if rank == 0:
             print(json.dumps({"n_gpus": world, "rccl_ranks_seen": int(ones.item()), "rank_devices": [int(g.item()) for g in got],
-                              "dp_backend": torch.distributed.get_backend() if world > 1 else None, "census_only": True}),
+                              "dp_backend": torch.distributed.get_backend() if world > 1 else None, "census_only": True,
+                              "dp_line_keys": list(DP_LINE_KEYS), "dp_part_keys": list(DP_PART_KEYS)}),
                   flush=True)
         dp.barrier()
         if torch.distributed.is_initialized():
@@ -895,6 +970,8 @@ def main():
             use_graph = False
     step_fn = trainer.step_graph if use_graph else trainer.step
 
+    local_s = {}                # this rank's own time of the last timed() call (its device drained, BEFORE the closing barrier)
+
     def timed(fn, items, steps):
         import gc
         gc.collect()
@@ -905,68 +982,86 @@ def main():
             t0 = time.perf_counter()
             for s in range(steps):
                 fn(items[s % len(items)])
+            if world > 1:       # the rank's own finishing time (the per-rank spread of the line); the barrier below then
+                torch.cuda.synchronize()          # waits for the slowest rank, which is what `value` is computed from
+                local_s["last"] = time.perf_counter() - t0
             dp.barrier()
             torch.cuda.synchronize()
-            return time.perf_counter() - t0
+            dt_ = time.perf_counter() - t0
+            local_s.setdefault("last", dt_)
+            if world == 1:
+                local_s["last"] = dt_
+            return dt_
         finally:
             gc.enable()
 
     dt_pool = timed(step_fn, pool, a.steps)
     dt, launch, stream_info = dt_pool, None, None
-    if a.stream > 0 and use_graph:
-        # headline mode: `--stream` DISTINCT batches, each fed as its raw collated arrays (one device-to-device copy of
-        # the resident blob), plans and the extended graph built on the device inside the ONE captured graph
+    dt_local = local_s.get("last", dt_pool)
+
+    def stream_modes(tr, full, pcie_variants=True):
+        """`--stream` DISTINCT batches, each fed as its raw collated arrays (one device-to-device copy of the resident blob),
+        plans and the extended graph built on the device inside the ONE captured graph of trainer `tr`; then the two-bucket
+        mode and (pcie_variants) the blobs from pinned host memory.  Which mode is the headline is a FIXED rule, not "the
+        faster one": configs[1] -> the one-graph mode, the full step (configs[2]'s per-GPU work) -> the two-bucket mode; both
+        times are reported either way.  Returns (seconds of the headline mode, this rank's own seconds, launch text, info,
+        (bucket, blobs))."""
         from moleculesde_amd import bucket as BK
         t0 = time.perf_counter()
         extra = [make_batch(a.batch_size, seed=dp.shard_seed(1000 + s, rank)) for s in range(max(a.stream - len(cpu_pool), 0))]
         stream_cpu = (cpu_pool + extra)[:a.stream]
         needs = [BK.raw_sizes(b) for b in stream_cpu]
         caps = BK.Caps.covering(needs)
-        bk = trainer.make_bucket(caps)
+        bk = tr.make_bucket(caps)
         blobs = [BK.pack_raw(b, caps).to(device) for b in stream_cpu]
         host_prep_s = time.perf_counter() - t0
-        try:
-            trainer.capture_bucket(bk, blobs[0])
-            for s in range(a.warmup):
-                trainer.step_bucket(bk, blobs[s % len(blobs)])
-            ok, _ = bk.check()
-            assert ok
-            dt = timed(lambda blob: trainer.step_bucket(bk, blob), blobs, a.steps)
-            ok, _ = bk.check()
-            assert ok
-            launch = ("ONE hipGraph for all batches: %d distinct batches streamed as raw collated arrays (1 copy each), "
-                      "plans + extend_graph built on the device inside the graph" % len(blobs))
-            dt_one_graph = dt
-            if not a.no_pipeline:
-                # two buckets used alternately: the plans of batch t+1 are built (plan graph, third stream) while the
-                # step of batch t runs -- the same work per batch, batch construction off the step's critical path
-                pipe = pretrain.BucketPipeline(trainer, caps, blobs[0])
-                state = {"i": 0}
-                pipe.submit(blobs[0])
+        tr.capture_bucket(bk, blobs[0])
+        for s in range(a.warmup):
+            tr.step_bucket(bk, blobs[s % len(blobs)])
+        ok, _ = bk.check()
+        assert ok
+        dt_ = timed(lambda blob: tr.step_bucket(bk, blob), blobs, a.steps)
+        dtl_ = local_s["last"]
+        ok, _ = bk.check()
+        assert ok
+        launch_ = ("ONE hipGraph for all batches: %d distinct batches streamed as raw collated arrays (1 copy each), "
+                   "plans + extend_graph built on the device inside the graph" % len(blobs))
+        dt_one_graph, dt_pipe = dt_, None
+        if not a.no_pipeline:
+            # two buckets used alternately: the plans of batch t+1 are built (plan graph, third stream) while the
+            # step of batch t runs -- the same work per batch, batch construction off the step's critical path
+            pipe = pretrain.BucketPipeline(tr, caps, blobs[0])
+            state = {"i": 0}
+            pipe.submit(blobs[0])
 
-                def piped_step(_):
-                    state["i"] += 1
-                    pipe.submit(blobs[state["i"] % len(blobs)])
-                    return pipe.step()
-                for s in range(a.warmup):
-                    piped_step(None)
-                dt_pipe = timed(piped_step, blobs, a.steps)
-                pipe.step()                       # drain the batch submitted last
-                torch.cuda.synchronize()
-                assert pipe.check()
-                # which mode is the headline is a FIXED rule, not "the faster one": configs[1] -> the one-graph mode, --full
-                # (configs[2]'s per-GPU work) -> the two-bucket mode; both times are printed under config.stream either way
-                if a.full:
-                    dt = dt_pipe
-                    launch = ("two capacity buckets used alternately (one captured step graph + one plan graph each): %d "
-                              "distinct batches streamed as raw collated arrays (1 copy each); plans + extend_graph of "
-                              "batch t+1 built on the device beside the step of batch t" % len(blobs))
-            pad = {k: round(getattr(caps, k) / max(n, 1), 3) for k, n in
-                   (("N", sum(x["N"] for x in needs) / len(needs)), ("E_b", sum(x["E_b"] for x in needs) / len(needs)),
-                    ("E_e", sum(x["E_e"] for x in needs) / len(needs)), ("P", sum(x["P"] for x in needs) / len(needs)))}
+            def piped_step(_):
+                state["i"] += 1
+                pipe.submit(blobs[state["i"] % len(blobs)])
+                return pipe.step()
+            for s in range(a.warmup):
+                piped_step(None)
+            dt_pipe = timed(piped_step, blobs, a.steps)
+            dtl_pipe = local_s["last"]
+            pipe.step()                       # drain the batch submitted last
+            torch.cuda.synchronize()
+            assert pipe.check()
+            if full:
+                dt_, dtl_ = dt_pipe, dtl_pipe
+                launch_ = ("two capacity buckets used alternately (one captured step graph + one plan graph each): %d "
+                           "distinct batches streamed as raw collated arrays (1 copy each); plans + extend_graph of "
+                           "batch t+1 built on the device beside the step of batch t" % len(blobs))
+        pad = {k: round(getattr(caps, k) / max(n, 1), 3) for k, n in
+               (("N", sum(x["N"] for x in needs) / len(needs)), ("E_b", sum(x["E_b"] for x in needs) / len(needs)),
+                ("E_e", sum(x["E_e"] for x in needs) / len(needs)), ("P", sum(x["P"] for x in needs) / len(needs)))}
+        info = {"distinct_batches": len(blobs), "capacities": caps.as_dict(), "capacity_over_mean_size": pad,
+                "raw_blob_bytes": int(blobs[0].numel() * 4),
+                "ms_per_step_one_graph_plan_inside": round(dt_one_graph / a.steps * 1e3, 3),
+                "ms_per_step_two_buckets_plan_ahead": None if dt_pipe is None else round(dt_pipe / a.steps * 1e3, 3),
+                "host_prep_s_synthetic_generation_and_packing": round(host_prep_s, 2)}
+        if pcie_variants:
             # PCIe-inclusive variant: the same blobs from pinned host memory
             pinned = [BK.pack_raw(b, caps, pin=True) for b in stream_cpu[:16]]
-            dt_h2d = timed(lambda blob: trainer.step_bucket(bk, blob), pinned, a.steps)
+            dt_h2d = timed(lambda blob: tr.step_bucket(bk, blob), pinned, a.steps)
             # ... and prefetched one step ahead (bucket.BlobFeeder: the blob of step t+1 crosses PCIe while step t runs)
             feeder = BK.BlobFeeder(bk)
             feeder.submit(pinned[0])
@@ -976,16 +1071,19 @@ def main():
                 state["i"] += 1
                 feeder.submit(pinned[state["i"] % len(pinned)])
                 feeder.load_next()
-                return trainer.step_graph(bk.batch)
+                return tr.step_graph(bk.batch)
             dt_fed = timed(fed_step, pinned, a.steps)
-            stream_info = {"distinct_batches": len(blobs), "capacities": caps.as_dict(), "capacity_over_mean_size": pad,
-                           "raw_blob_bytes": int(blobs[0].numel() * 4),
-                           "ms_per_step_blobs_from_pinned_host": round(dt_h2d / a.steps * 1e3, 3),
-                           "ms_per_step_blobs_from_pinned_host_prefetched": round(dt_fed / a.steps * 1e3, 3),
-                           "ms_per_step_4_resident_batches_own_graphs": round(dt_pool / a.steps * 1e3, 3),
-                           "ms_per_step_one_graph_plan_inside": round(dt_one_graph / a.steps * 1e3, 3),
-                           "ms_per_step_two_buckets_plan_ahead": None if a.no_pipeline else round(dt_pipe / a.steps * 1e3, 3),
-                           "host_prep_s_synthetic_generation_and_packing": round(host_prep_s, 2)}
+            info.update({"ms_per_step_blobs_from_pinned_host": round(dt_h2d / a.steps * 1e3, 3),
+                         "ms_per_step_blobs_from_pinned_host_prefetched": round(dt_fed / a.steps * 1e3, 3)})
+        return dt_, dtl_, launch_, info, (bk, blobs)
+
+    dp_parts = None
+    if a.stream > 0 and use_graph:
+        try:
+            dt, dt_local, launch, stream_info, (bk0, blobs0) = stream_modes(trainer, a.full)
+            stream_info["ms_per_step_4_resident_batches_own_graphs"] = round(dt_pool / a.steps * 1e3, 3)
+            if trainer._use_dp():
+                dp_parts = dp_step_parts(trainer, lambda i: trainer.step_bucket(bk0, blobs0[i % len(blobs0)]))
         except Exception as exc:
             print(f"[bench] bucket mode failed ({type(exc).__name__}: {exc}); reporting the per-shape-graph mode",
                   file=sys.stderr)
@@ -993,6 +1091,30 @@ def main():
         finally:
             from moleculesde_amd import hip as _hip
             _hip.clear_row_bounds()
+    if dp_parts is None and trainer._use_dp() and use_graph:
+        dp_parts = dp_step_parts(trainer, lambda i: trainer.step_graph(pool[i % len(pool)]))
+
+    # configs[2] (BASELINE.json: contrastive + 2D->3D + 3D->2D, 256 molecules per GPU, DP): the SAME ranks time the full step on
+    # a second Trainer right behind the headline, so that one `--gpus N` run measures both configurations
+    # (examples/pretrain_MoleculeSDE.py:135-156 is the loss composition the full step adds to).  Every rank takes part:
+    # the trainer's collectives and timed()'s barriers need all of them.
+    config2 = None
+    if not a.full and not a.no_config2 and a.stream > 0 and use_graph:
+        try:
+            args2 = pretrain.readme_args(SDE_coeff_generative_3Dto2D=1, batch_size=a.batch_size, score_kernel=a.score_kernel)
+            tr2 = pretrain.Trainer(args2, device)
+            tr2.adam_outside_graph = a.debug_dp_path
+            dt2, dtl2, launch2, info2, (bk2, blobs2) = stream_modes(tr2, True, pcie_variants=False)
+            parts2 = dp_step_parts(tr2, lambda i: tr2.step_bucket(bk2, blobs2[i % len(blobs2)])) if tr2._use_dp() else None
+            config2 = {"dt": dt2, "dt_local": dtl2, "launch": launch2, "stream": info2, "dp_step_parts_us": parts2}
+            del tr2
+        except Exception as exc:
+            print(f"[bench] configs[2] (full step) failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+            config2 = {"error": f"{type(exc).__name__}: {exc}"}
+        finally:
+            from moleculesde_amd import hip as _hip
+            _hip.clear_row_bounds()
+
     ranks_seen, rank_devices, backend = 1, [int(device.index)], None
     if world > 1 or torch.distributed.is_initialized():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -1008,6 +1130,27 @@ def main():
         torch.distributed.all_gather(got, mine)
         rank_devices = [int(g.item()) for g in got]
         backend = torch.distributed.get_backend()
+    # per-rank spread and the DP pieces of every rank (a slow 8-GPU number must explain itself): row r = rank r
+    c2_ok = isinstance(config2, dict) and "dt" in config2
+    pk = DP_PART_KEYS[:4]
+    row = [dt_local, config2["dt"] if c2_ok else None, config2["dt_local"] if c2_ok else None]
+    row += [(dp_parts or {}).get(k) for k in pk]
+    row += [((config2 or {}).get("dp_step_parts_us") or {}).get(k) for k in pk]
+    rows = gather_ranks(row, device)
+    nan_none = lambda v: None if v != v else v
+    if c2_ok:
+        config2["dt"] = max(r[1] for r in rows)          # max over ranks, like the headline
+
+    def spread(col, scale=1.0, nd=3):
+        v = [r[col] * scale for r in rows if r[col] == r[col]]
+        return None if not v else {"min": round(min(v), nd), "max": round(max(v), nd), "per_rank": [round(x, nd) for x in v]}
+
+    def parts_out(mine, first_col):
+        if not mine or "error" in mine:
+            return mine
+        o = dict(mine)
+        o["max_over_ranks"] = {k: (spread(first_col + i, 1.0, 1) or {}).get("max") for i, k in enumerate(pk)}
+        return o
 
     out = None
     if rank == 0:
@@ -1034,6 +1177,9 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks_seen": ranks_seen, "rank_devices": rank_devices, "dp_backend": backend,
+            "ms_per_step_per_rank": spread(0, 1e3 / a.steps),
+            "dp_step_parts_us": parts_out(dp_parts, 3),
+            "config2_full": None,
             "config": {"workload": "PCQM4Mv2-shaped pretrain step: GIN5x300 + SchNet(6x128f,51g,rc10) + "
                                    "EBM_node_dot_prod contrastive + SDEModel2Dto3D_02 VE" + (" + SDEModel3Dto2D_node_adj_dense VE" if a.full else "") + "; fwd+bwd+Adam",
                        "molecules_per_gpu": a.batch_size, "global_batch": world * a.batch_size,
@@ -1058,6 +1204,22 @@ def main():
             "roofline_forward_schnet_sde2d3d": roof_forward,
             "roofline_dense_head_node_mlp": roof_head,
         }
+        if c2_ok:
+            out["config2_full"] = {
+                "what": "BASELINE.json configs[2]: the FULL pretrain step (contrastive + 2D->3D + 3D->2D dense head, VE; "
+                        "examples/pretrain_MoleculeSDE.py:135-156), %d molecules per GPU, timed by the same %d rank(s) right behind "
+                        "the headline with the same barrier + synchronize bracket, max over ranks" % (a.batch_size, world),
+                "ms_per_step": round(config2["dt"] / a.steps * 1e3, 3),
+                "value": round(world * a.batch_size * a.steps / config2["dt"], 1), "unit": "molecules/s", "n_gpus": world,
+                "steps": a.steps, "launch": config2["launch"], "stream": config2["stream"],
+                "ms_per_step_per_rank": spread(2, 1e3 / a.steps),
+                "dp_step_parts_us": parts_out(config2.get("dp_step_parts_us"), 7)}
+        elif a.full:
+            out["config2_full"] = {"what": "this line's headline IS the full step (--full)", "ms_per_step": out["ms_per_step"],
+                                   "value": out["value"], "unit": "molecules/s", "n_gpus": world}
+        elif config2 is not None:
+            out["config2_full"] = config2              # {"error": ...}
+        assert all(k in out for k in DP_LINE_KEYS)
         if world == 1 and not a.no_configs45:
             out["config4_sampler"] = config4_sampler(device)
             out["config5_md17"] = config5_md17(device)

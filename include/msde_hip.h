@@ -710,6 +710,15 @@ int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const float* X, int 
                                   int want_bias, float* slabs, const int* rows_dev, long long* row);
 int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
                               void* stream);
+/* Round 6: the same launch in an XCD-aware UNIT order.  msde_linear_bwd_w_xcd_order (host tables in, host table out) assigns
+ * every (problem, split) unit -- all tiles over the same rows of gY and X -- to one of the 8 XCDs (workgroup i of a launch runs
+ * on XCD i % 8), longest first onto the least loaded, and writes order[slot] = tile in the natural numbering (-1: padding slot);
+ * returns the number of slots (<= cap, a multiple of 8).  msde_linear_bwd_w_grouped_units launches `slots` workgroups that
+ * look their tile up in the DEVICE copy of `order`: a unit's operand rows are fetched into one XCD's L2 once instead of once
+ * per tile (profiles/r05_pmc_counters.json -> profiles/r06_pmc_counters.json).  Same tile body, bit-identical slabs. */
+int msde_linear_bwd_w_xcd_order(const long long* probs_host, const int* prefix_host, int count, int* order_host, int cap);
+int msde_linear_bwd_w_grouped_units(const long long* probs, const int* prefix, int count, const int* order, int slots,
+                                    void* stream);
 /* the same launch limited to `max_workgroups` resident workgroups (0 = one per tile): each walks several tiles, so the
  * GEMMs can run beside a latency-critical kernel chain on another stream without occupying every CU. */
 int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* prefix, int count, int total_blocks,
@@ -814,12 +823,13 @@ int msde_gat_tail_bwd(const float* g_out, const float* x, const float* y1, const
  *   Dropout: attention weights (p_att) and feed-forward (p_ffn) masks are the counter masks of msde_edge_attention_fwd /
  *   msde_gat_tail_fwd with per-layer seeds seed0 + 4*block + conv (feed-forward: ^ 0x46464E), + seed_dev[0] * 0x100000001B3.
  *   out [N,3]: the score ("gradient"); rows behind mol_ptr[B] are zero-filled.
+ *   n_max: the largest molecule of the batch (atoms); > 32 -> MSDE_EUNSUP (a molecule's rows live in LDS; nothing is cut silently).
  *   saved (or NULL): what msde_escore_mol_bwd needs, msde_escore_mol_saved_floats(N) floats (per layer and atom: attention
  *   output, y1, h0, x2, layer output, softmax max and 1/sum per head; everything per-edge is recomputed in the backward). */
 long long msde_escore_mol_saved_floats(int N);
 int msde_escore_mol_fwd(const void* const* params, const float* x0, const float* edge_attr, int ld_ea,
                         const float* basis, const int* mol_ptr, int B, const int* rowptr, const int* src,
-                        const int* dst, int N, int E, int hidden, int heads, int hidden_coff, float p_att,
+                        const int* dst, int N, int E, int hidden, int heads, int hidden_coff, int n_max, float p_att,
                         float p_ffn, unsigned long long seed0, const unsigned long long* seed_dev, float eps1,
                         float eps2, float* out, float* saved, void* stream);
 
@@ -849,7 +859,7 @@ long long msde_escore_mol_slab_floats(void);
 int msde_escore_mol_bwd(const void* const* params, const float* x0, const float* edge_attr, int ld_ea,
                         const float* basis, const int* mol_ptr, int B, const int* rowptr, const int* src,
                         const int* dst, const int* rowptr_s, const int* perm_s, int N, int E, int hidden, int heads,
-                        int hidden_coff, float p_att, float p_ffn, unsigned long long seed0,
+                        int hidden_coff, int n_max, float p_att, float p_ffn, unsigned long long seed0,
                         const unsigned long long* seed_dev, float eps1, float eps2, const float* saved,
                         const float* g_out, float* g_x0, float* g_edge_attr, int ld_gea, float* slabs, void* stream);
 

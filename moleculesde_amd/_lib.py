@@ -75,6 +75,8 @@ SIGNATURES = {
     "msde_linear_bwd_w_describe_ld": [P, I, P, I, I, I, I, I, P, P, P],
     "msde_linear_bwd_w_grouped": [P, P, I, I, P],
     "msde_linear_bwd_w_grouped_ex": [P, P, I, I, I, P],
+    "msde_linear_bwd_w_xcd_order": [P, P, I, P, I],
+    "msde_linear_bwd_w_grouped_units": [P, P, I, P, I, P],
     "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_reduce_slabs_chunks": [LL, I],
@@ -149,11 +151,11 @@ SIGNATURES = {
     "msde_gat_tail_fwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P],
     "msde_gat_tail_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, F, F, F, ULL, P, I, P, P, P, P, P, P, P, P],
     "msde_escore_mol_saved_floats": [I],
-    "msde_escore_mol_fwd": [P, P, P, I, P, P, I, P, P, P, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P],
+    "msde_escore_mol_fwd": [P, P, P, I, P, P, I, P, P, P, I, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P],
     "msde_escore_mol_score": [P, P, P, P, I, I, P, I, P, P, P, I, I, I, I, I, I, F, F, P, P, P],
     "msde_escore_mol_score_scratch_floats": [I],
     "msde_escore_mol_slab_floats": [],
-    "msde_escore_mol_bwd": [P, P, P, I, P, P, I, P, P, P, P, P, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P, P, I, P, P],
+    "msde_escore_mol_bwd": [P, P, P, I, P, P, I, P, P, P, P, P, I, I, I, I, I, I, F, F, ULL, P, F, F, P, P, P, P, I, P, P],
     "msde_chunk_elems": [],
     "msde_gather_chunks": [P, I, P, P],
     "msde_adam_chunks": [P, P, I, P, P, P, P, P, I, F, F, F, F, F, P],

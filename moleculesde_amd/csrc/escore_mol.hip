@@ -708,12 +708,14 @@ extern "C" long long msde_escore_mol_saved_floats(int N) { return (long long)ES_
 // params: DEVICE array of ES_NPTR device pointers (4 x 11 layer pointers, 2 x 4 basis-MLP pointers; struct EsW)
 extern "C" int msde_escore_mol_fwd(const void* const* params, const float* x0, const float* edge_attr, int ld_ea,
                                    const float* basis, const int* mol_ptr, int B, const int* rowptr, const int* src,
-                                   const int* dst, int N, int E, int hidden, int heads, int hidden_coff, float p_att,
+                                   const int* dst, int N, int E, int hidden, int heads, int hidden_coff, int n_max, float p_att,
                                    float p_ffn, unsigned long long seed0, const unsigned long long* seed_dev, float eps1,
                                    float eps2, float* out, float* saved, void* stream) {
   if (!params || !x0 || !edge_attr || !basis || !mol_ptr || !rowptr || !src || !dst || !out || N < 0 || B < 0 || E < 0)
     return MSDE_EINVAL;
-  if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC) return MSDE_EUNSUP;
+  // n_max: the largest molecule of the batch, stated by the caller (the kernel holds a molecule's rows in LDS: a larger one
+  // would be silently cut to ES_NMAX atoms)
+  if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC || n_max > ES_NMAX) return MSDE_EUNSUP;
   if (ld_ea < ES_D || ld_ea % 4 || (reinterpret_cast<uintptr_t>(edge_attr) & 15) || (reinterpret_cast<uintptr_t>(x0) & 15))
     return MSDE_EINVAL;
   if (p_att < 0.f || p_att >= 1.f || p_ffn < 0.f || p_ffn >= 1.f) return MSDE_EINVAL;

@@ -700,13 +700,13 @@ extern "C" long long msde_escore_mol_slab_floats(void) { return ES_SLAB; }
 extern "C" int msde_escore_mol_bwd(const void* const* params, const float* x0, const float* edge_attr, int ld_ea,
                                    const float* basis, const int* mol_ptr, int B, const int* rowptr, const int* src,
                                    const int* dst, const int* rowptr_s, const int* perm_s, int N, int E, int hidden, int heads,
-                                   int hidden_coff, float p_att, float p_ffn, unsigned long long seed0,
+                                   int hidden_coff, int n_max, float p_att, float p_ffn, unsigned long long seed0,
                                    const unsigned long long* seed_dev, float eps1, float eps2, const float* saved,
                                    const float* g_out, float* g_x0, float* g_edge_attr, int ld_gea, float* slabs, void* stream) {
   if (!params || !x0 || !edge_attr || !basis || !mol_ptr || !rowptr || !src || !dst || !rowptr_s || !perm_s || !saved || !g_out ||
       !g_x0 || !g_edge_attr || !slabs || N < 0 || B < 0 || E < 0)
     return MSDE_EINVAL;
-  if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC) return MSDE_EUNSUP;
+  if (hidden != ES_D || heads != 8 || hidden_coff != ES_HC || n_max > ES_NMAX) return MSDE_EUNSUP;
   if (ld_ea < ES_D || ld_ea % 4 || ld_gea < ES_D || ld_gea % 4 || (reinterpret_cast<uintptr_t>(edge_attr) & 15) ||
       (reinterpret_cast<uintptr_t>(x0) & 15) || (reinterpret_cast<uintptr_t>(g_edge_attr) & 15) ||
       (reinterpret_cast<uintptr_t>(g_x0) & 15) || (reinterpret_cast<uintptr_t>(saved) & 15) || (reinterpret_cast<uintptr_t>(slabs) & 15))

@@ -463,13 +463,19 @@ class _Linear(torch.autograd.Function):
         ni = ctx.needs_input_grad
         if not PARAM_GRADS:
             return (mm_nn(g, W) if ni[0] else None), None, None
-        if ni[1] and not torch.is_grad_enabled() and (not ctx.has_bias or (ni[2] and ctx.b_key is not None)):
+        if ni[1] and not torch.is_grad_enabled():
             # the LAST differentiation (nothing will differentiate this backward again): weight and bias gradient from the
             # split-M kernel instead of mm_tn + colsum (two members of the closed set, two to three launches) -- queued for
-            # the step's ONE grouped launch when the trainer has a parameter-gradient batch open (hip.weight_grad_leaf)
+            # the step's ONE grouped launch when the trainer has a parameter-gradient batch open (hip.weight_grad_leaf).
+            # EVERY contribution to one leaf W must take this path (the force path's _MMnn / _MMnt do): a deferred buffer is
+            # filled only at finish_param_grad_batch(), so an immediate mm_tn result added to it by AccumulateGrad would be
+            # summed with unfilled memory.  A frozen or non-leaf bias only drops the BIAS half of the deferred problem.
             g2 = _f32(g)
             CALLS["msde_linear_bwd_w"] = CALLS.get("msde_linear_bwd_w", 0) + 1
-            gW, gb = hip.weight_grad_leaf(g2, x, ctx.has_bias, W, ctx.b_key)
+            fused_bias = ctx.has_bias and ni[2] and ctx.b_key is not None
+            gW, gb = hip.weight_grad_leaf(g2, x, fused_bias, W, ctx.b_key if fused_bias else None)
+            if ctx.has_bias and ni[2] and not fused_bias:
+                gb = colsum(g)              # a bias that is not a leaf parameter: its gradient flows on, formed right here
             return (mm_nn(g, W) if ni[0] else None), gW, gb
         return (mm_nn(g, W) if ni[0] else None), (mm_tn(g, x) if ni[1] else None), \
             (colsum(g) if ctx.has_bias and ni[2] else None)

@@ -75,7 +75,7 @@ def forward_nograd(net, ep, pl, node_attr, edge_attr, basis, seed0, seed_dev):
         ea = hip._f32(ea)
     out = torch.empty(ep.N, 3, dtype=torch.float32, device=x0.device)
     _lib.call("msde_escore_mol_fwd", hip._p(_pointer_table(net, tens)), hip._p(x0), hip._p(ea), ea.stride(0), hip._p(basis), hip._p(pl.mol_ptr),
-              int(pl.B), hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), ep.N, ep.E, 32, 8, 128, p_att, p_ffn,
+              int(pl.B), hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), ep.N, ep.E, 32, 8, 128, int(pl.N_max), p_att, p_ffn,
               int(seed0) & 0xFFFFFFFFFFFFFFFF, hip._p(seed_dev), eps1, eps2, hip._p(out), hip._p(None), hip._stream())
     return out
 
@@ -164,8 +164,8 @@ class _EScoreMol(torch.autograd.Function):
         tab = _pointer_table(net, list(params))
         seed0 = int(seed0) & 0xFFFFFFFFFFFFFFFF
         _lib.call("msde_escore_mol_fwd", hip._p(tab), hip._p(x0), hip._p(ea), ea.stride(0), hip._p(basis), hip._p(pl.mol_ptr), B,
-                  hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), N, E, 32, 8, 128, p_att, p_ffn, seed0, hip._p(seed_dev),
-                  eps1, eps2, hip._p(out), hip._p(sv), hip._stream())
+                  hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), N, E, 32, 8, 128, int(pl.N_max), p_att, p_ffn, seed0,
+                  hip._p(seed_dev), eps1, eps2, hip._p(out), hip._p(sv), hip._stream())
         ctx.save_for_backward(x0, ea, basis, sv, *params)
         ctx.cfg = (net, ep, pl, seed0, seed_dev, p_att, p_ffn, eps1, eps2, tab)
         ctx.deferrable = all(t.is_leaf for t in params)
@@ -186,7 +186,7 @@ class _EScoreMol(torch.autograd.Function):
         ws = hip._SLABS.alloc(B * nslab, dev) if defer else torch.empty(B * nslab, dtype=torch.float32, device=dev)
         _lib.call("msde_escore_mol_bwd", hip._p(tab), hip._p(x0), hip._p(ea), ea.stride(0), hip._p(basis), hip._p(pl.mol_ptr), B,
                   hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), hip._p(ep.rowptr_s), hip._p(ep.perm_s), N, E, 32, 8, 128,
-                  p_att, p_ffn, seed0, hip._p(seed_dev), eps1, eps2, hip._p(sv), hip._p(g), hip._p(g_x0), hip._p(g_ea), 32,
+                  int(pl.N_max), p_att, p_ffn, seed0, hip._p(seed_dev), eps1, eps2, hip._p(sv), hip._p(g), hip._p(g_x0), hip._p(g_ea), 32,
                   hip._p(ws), hip._stream())
         if defer:
             hip._SLABS.add(ws.data_ptr(), B, nslab, gall, written=True)

@@ -205,6 +205,8 @@ class Trainer:
         r = dp.rank()
         self.dp_enabled = True            # False: ignore the process group (single-replica reference runs in DP tests)
         self.dp_buckets = True            # per-model all-reduce buckets, each followed by its Adam (False: one flat all-reduce)
+        self.dp_timing = None             # a list: step_graph() appends the timing events of each DP step (bench.py)
+        self._tm_cur = None
         if r:
             torch.manual_seed(torch.initial_seed() + 7919 * r)
         self.noise = noise or _nn.DeviceNoise(seed=0x5EED + 7919 * r)
@@ -375,6 +377,10 @@ class Trainer:
                 loss_head = _hip.combine_losses([c32, c32], [l32[0], l32[1]])
                 with torch.no_grad():
                     parts["3Dto2D"] = _hip.combine_losses([0.5, 0.5], [l32[0].detach(), l32[1].detach()])
+            # allocated on the second stream, read on the main one (_total, the loss log): tell the allocator, and let
+            # _backward() join the streams explicitly instead of relying on the autograd engine's leaf-stream join
+            loss_head.record_stream(main)
+            parts["3Dto2D"].record_stream(main)
         elif want_32:
             if l32 is None:
                 l32 = head_32(node_3D_repr)
@@ -440,6 +446,10 @@ class Trainer:
                     with torch.cuda.stream(self._side_stream):
                         hip.stamp("bwd_side_end")
                     torch.cuda.current_stream().wait_stream(self._side_stream)
+                elif len(roots) > 1 and self.overlap_streams:
+                    # a root of its own on the second stream (the 3D->2D head's loss): the main stream reads its value in
+                    # _total() and in the loss log -- ordered behind the second stream here, not by engine internals
+                    torch.cuda.current_stream().wait_stream(self._side_stream)
             finally:
                 hip.finish_param_grad_batch()
                 hip.stamp("wgrad_end")
@@ -466,11 +476,22 @@ class Trainer:
             return
         order, works, scale = dp.allreduce_buckets_async(self.opt.flat_g, self.opt.bucket_ranges)
         self.opt.begin_bucket_step()
+        tm = self._tm_cur                 # bench.py (Trainer.dp_timing): events on the compute stream around each piece
         for i, w in zip(order, works):
             if w is not None:
                 w.wait()                  # stream wait: the host does not block
+            if tm is not None:
+                tm.append(self._timing_event())       # bucket i reduced (what the compute stream had to wait for)
             self.opt.step_bucket(i, grad_scale=scale)
+            if tm is not None:
+                tm.append(self._timing_event())       # bucket i's Adam done
         self._refresh_weights()
+
+    @staticmethod
+    def _timing_event():
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
 
     def _refresh_weights(self):
         """Right after an optimiser step: ONE launch re-transposes every weight the forward products read as [K][N]
@@ -563,14 +584,23 @@ class Trainer:
         assert held is batch
         from . import hip as _hip
         _hip.sync_weight_copies()          # parameters edited from outside since the last step (load_state_dict, ...)
+        timing = self.dp_timing is not None and not with_adam and self._use_dp() and self.dp_buckets
+        if timing:                         # [replay start, replay end, (bucket reduced, bucket's Adam done) x buckets]
+            self._tm_cur = [self._timing_event()]
+            self.dp_timing.append(self._tm_cur)
         g.replay()
+        if timing:
+            self._tm_cur.append(self._timing_event())
         if self._graph_wt_keys.get(id(batch)) is not None:
             _hip.weight_copies_after_replay(self._graph_wt_keys[id(batch)])
         for bn in self._bn_modules:
             bn.pending_batches += 1        # the captured forward does not run Python: count its BatchNorm calls here
         if not with_adam:
             if self._use_dp():
-                self._allreduce_and_adam()
+                try:
+                    self._allreduce_and_adam()
+                finally:
+                    self._tm_cur = None
             else:
                 self.opt.step()
                 self._refresh_weights()

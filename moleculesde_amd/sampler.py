@@ -73,7 +73,13 @@ def position_PC_generation(score_model, representation, data, num_steps=1000, sn
         # the iteration counter lives on the device (the corrector advances it) and both kernels draw their own noise from the
         # counter generator: a replayed iteration needs no host work and no random-number operator (noise_seed: one per call)
         it_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise_seed is None else int(noise_seed)
+        # default seed: ONE draw from the device's torch generator per call (so torch.manual_seed / torch.cuda.manual_seed
+        # govern the trajectory as they did when the noise came from torch.randn_like on the device; one host read per
+        # trajectory, outside the iteration loop); an explicit noise_seed is taken modulo 2^64
+        if noise_seed is not None:
+            seed = int(noise_seed) & 0xFFFFFFFFFFFFFFFF
+        else:       # (torch_noise: the kernels get their noise from torch.randn_like -- no draw, the generator is left alone)
+            seed = 0 if torch_noise else int(torch.randint(0, 2 ** 62, (1,), device=dev).item())
         xc = torch.empty_like(pos)
         xm_c = torch.empty_like(pos)
         stream = _hip_mod._stream

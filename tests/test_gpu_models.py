@@ -851,6 +851,42 @@ def test_md17_force_trainer_graph_replay_matches_eager_and_oracle(dev):
         assert abs(eager[t] - ref[t]) <= 1e-3 * abs(ref[t]), (t, eager[t], ref[t])
 
 
+def test_md17_force_trainer_frozen_biases(dev):
+    """ADVICE r5 (dd.py:466): with a frozen bias the energy-path weight gradient of a Linear used to fall through to the
+    immediate mm_tn while the force-path contributions to the same weight were deferred into the grouped launch --
+    AccumulateGrad then added a real tensor to an unfilled buffer.  Every contribution to one leaf weight now takes the
+    deferred path; the bias half alone is dropped.  One ForceTrainer step (open parameter-gradient batch) with all SchNet
+    biases frozen, weight gradients against the oracle's autograd."""
+    import moleculesde_amd.geom3d as G
+    from moleculesde_amd.finetune_md17 import ForceTrainer
+    from moleculesde_amd.synthetic import make_md17_batch
+    kw = dict(hidden_channels=64, num_filters=32, num_interactions=3, num_gaussians=51, cutoff=10, readout="mean", node_class=119)
+    torch.manual_seed(11)
+    osch, ohead = R.SchNet(**kw), torch.nn.Linear(64, 1)
+    sch, head = G.SchNet(**kw), torch.nn.Linear(64, 1)
+    sch.load_state_dict(osch.state_dict()); head.load_state_dict(ohead.state_dict())
+    for m in (osch, sch):
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.requires_grad_(False)
+    cpu_b = make_md17_batch(2, seed=3, n_atoms=21)
+    y, f_t = torch.randn(2), torch.randn(cpu_b.x.size(0), 3)
+    pos = cpu_b.positions.clone().requires_grad_(True)
+    e = ohead(osch(cpu_b.x, pos, cpu_b.batch)).squeeze(1)
+    f = -torch.autograd.grad(e, pos, grad_outputs=torch.ones_like(e), create_graph=True, retain_graph=True)[0]
+    lo = 0.05 * torch.nn.functional.l1_loss(e, y) + 0.95 * torch.nn.functional.l1_loss(f, f_t)
+    lo.backward()
+    ft = ForceTrainer(sch.to(dev), head.to(dev), lr=0.0)          # lr 0: the step leaves the parameters (and .grad) in place
+    b = G.prepare_batch(cpu_b.clone(), dev)
+    l = ft.step(b, y.to(dev), f_t.to(dev))
+    assert_close(l, lo.detach(), 1e-4, 1e-6, "loss")
+    frozen = [n for n, p in sch.named_parameters() if not p.requires_grad]
+    assert frozen and all(p.grad is None for n, p in sch.named_parameters() if not p.requires_grad)
+    gs = {n: p.grad for n, p in osch.named_parameters() if p.grad is not None}
+    assert gs
+    _grads_close(sch, gs, 2e-3, 2e-4, "SchNet double-backward grads, frozen biases")
+
+
 def test_md17_force_path_runs_on_library_kernels(dev):
     """§8 a18: energy -> forces (create_graph) -> backward through the forces launches the kernels of the closed
     twice-differentiable operator set (moleculesde_amd.dd) and no torch operator inside SchNet.  What remains on torch is

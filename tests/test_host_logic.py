@@ -291,6 +291,10 @@ def test_bench_gpus_n_starts_its_own_ranks():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["rccl_ranks_seen"] == 2 and len(j["rank_devices"]) == 2
+    # the keys a `--gpus N` line carries beside the contract's own (round 6: configs[2]'s full step timed by the same ranks,
+    # the pieces of a DP step, the per-rank spread); bench.main() asserts the same tuple on the line it prints
+    assert {"config2_full", "dp_step_parts_us", "ms_per_step_per_rank"} <= set(j["dp_line_keys"])
+    assert {"graph_us", "allreduce_us", "adam_us"} <= set(j["dp_part_keys"])
     # without the smoke backend and without 2 devices the launcher refuses instead of mislabelling a 1-GPU run
     if torch.cuda.device_count() < 2:
         env.pop("MSDE_DP_BACKEND")
