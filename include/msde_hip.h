@@ -710,15 +710,6 @@ int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const float* X, int 
                                   int want_bias, float* slabs, const int* rows_dev, long long* row);
 int msde_linear_bwd_w_grouped(const long long* probs, const int* prefix, int count, int total_blocks,
                               void* stream);
-/* Round 6: the same launch in an XCD-aware UNIT order.  msde_linear_bwd_w_xcd_order (host tables in, host table out) assigns
- * every (problem, split) unit -- all tiles over the same rows of gY and X -- to one of the 8 XCDs (workgroup i of a launch runs
- * on XCD i % 8), longest first onto the least loaded, and writes order[slot] = tile in the natural numbering (-1: padding slot);
- * returns the number of slots (<= cap, a multiple of 8).  msde_linear_bwd_w_grouped_units launches `slots` workgroups that
- * look their tile up in the DEVICE copy of `order`: a unit's operand rows are fetched into one XCD's L2 once instead of once
- * per tile (profiles/r05_pmc_counters.json -> profiles/r06_pmc_counters.json).  Same tile body, bit-identical slabs. */
-int msde_linear_bwd_w_xcd_order(const long long* probs_host, const int* prefix_host, int count, int* order_host, int cap);
-int msde_linear_bwd_w_grouped_units(const long long* probs, const int* prefix, int count, const int* order, int slots,
-                                    void* stream);
 /* the same launch limited to `max_workgroups` resident workgroups (0 = one per tile): each walks several tiles, so the
  * GEMMs can run beside a latency-critical kernel chain on another stream without occupying every CU. */
 int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* prefix, int count, int total_blocks,

@@ -75,8 +75,6 @@ SIGNATURES = {
     "msde_linear_bwd_w_describe_ld": [P, I, P, I, I, I, I, I, P, P, P],
     "msde_linear_bwd_w_grouped": [P, P, I, I, P],
     "msde_linear_bwd_w_grouped_ex": [P, P, I, I, I, P],
-    "msde_linear_bwd_w_xcd_order": [P, P, I, P, I],
-    "msde_linear_bwd_w_grouped_units": [P, P, I, P, I, P],
     "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_reduce_slabs_chunks": [LL, I],

@@ -14,8 +14,6 @@
 // MFMAs (register prefetch).  The split-M weight gradient writes per-split slabs that a second
 // kernel sums in a fixed order: bitwise reproducible, no float atomics.
 #include "msde_common.h"
-#include <algorithm>
-#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -352,18 +350,11 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
 // same tile body as the per-layer kernel (64 x 64 tiles), so results are bit-identical to it.
 __device__ __forceinline__ void
 gemm_grouped_wgrad_body(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
-                          int xcd_order, const int* __restrict__ order = nullptr) {
+                          int xcd_order) {
   // grid == total: one tile per workgroup.  grid < total (msde_linear_bwd_w_grouped_ex with a width limit): each
   // workgroup walks tiles blockIdx.x, + gridDim.x, ...: the launch then occupies at most gridDim.x workgroup slots, so it
   // can run BESIDE a latency-critical chain on another stream without taking every CU (same results, tile by tile).
-  for (int slot = blockIdx.x; slot < total; slot += gridDim.x) {
-    // order != nullptr (msde_linear_bwd_w_grouped_units): slot -> tile of the natural numbering (or -1: a padding slot), an
-    // order in which every XCD (slot % 8) works through whole (problem, split) units one after the other
-    int blk = slot;
-    if (order) {
-      blk = order[slot];
-      if (blk < 0) continue;
-    }
+  for (int blk = blockIdx.x; blk < total; blk += gridDim.x) {
     int lo = 0, hi = count;
     while (hi - lo > 1) {
       int mid = (lo + hi) >> 1;
@@ -382,7 +373,7 @@ gemm_grouped_wgrad_body(const long long* __restrict__ probs, const int* __restri
     // then split) are cut into 8 contiguous runs and residue class c = local % 8 (one XCD) takes run c: the tiles an
     // XCD works on share gY / X row blocks in ITS L2.  Every problem is still spread evenly over the 8 XCDs.
     int local = blk - prefix[lo];
-    if (xcd_order && !order) {
+    if (xcd_order) {
       const int np = prefix[lo + 1] - prefix[lo], q = np >> 3, r = np & 7, c = local & 7;
       local = c * q + min(c, r) + (local >> 3);
     }
@@ -400,11 +391,6 @@ __global__ void __launch_bounds__(256)
 gemm_grouped_wgrad_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
                           int xcd_order) {
   gemm_grouped_wgrad_body(probs, prefix, count, total, xcd_order);
-}
-__global__ void __launch_bounds__(256)
-gemm_grouped_wgrad_units_kernel(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
-                                const int* __restrict__ order) {
-  gemm_grouped_wgrad_body(probs, prefix, count, total, 0, order);
 }
 // the same with the register budget of FOUR workgroups per CU (128 VGPRs; the default build takes 140: three)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -581,27 +567,8 @@ static inline void wgrad_split_for(int M, int N, int K, int target, int* splits,
 // the body then needs 216 VGPRs, two workgroups per CU, and the 64 x 64 tiles hide their load -> store -> barrier phases
 // behind six other workgroups instead.  Round 5: 128 x 64 tiles (25 % fewer operand bytes per FLOP, 176 VGPRs) for layers with
 // >= 128 outputs: 2.48-2.51 vs 2.50-2.51 ms, --full 3.39-3.40 vs 3.38-3.40 -- nothing; the launch is not bound by operand traffic.
-// Round 6: the counters of the launch (profiles/r05_pmc_counters.json: 1.87 GB through the L2s for 0.5 GB of operands) say every
-// 64 x 64 tile streams its two operand strips from the fabric.  The launch order now keeps the tiles of one (problem, split)
-// UNIT on one XCD (msde_linear_bwd_w_xcd_order), so a unit's rows -- rows_per_split x (N + K) floats -- are fetched once into
-// that XCD's 4 MB L2 and re-read from there by the unit's other tiles; a split is cut so that its rows fit MSDE_WGRAD_L2_BUDGET.
-#ifndef MSDE_WGRAD_L2_BUDGET
-#define MSDE_WGRAD_L2_BUDGET (3 << 19)          // 1.5 MB of operand rows per unit: two units in flight per XCD stay inside 4 MB
-#endif
-#ifndef MSDE_WGRAD_UNITS
-#define MSDE_WGRAD_UNITS 1
-#endif
 static inline bool wgrad_group_plan(int M, int N, int K, int* splits, int* k_per_split) {
   wgrad_split_batched(M, N, K, splits, k_per_split);
-  if (MSDE_WGRAD_UNITS) {
-    long rows = (long)MSDE_WGRAD_L2_BUDGET / (4L * (N + K));
-    rows = rows / LG_BK * LG_BK;
-    if (rows < 256) rows = 256;                  // (a shorter split is all pipeline prologue and slab write)
-    if (*k_per_split > rows) {
-      *k_per_split = (int)rows;
-      *splits = (M + *k_per_split - 1) / *k_per_split;
-    }
-  }
   return false;
 }
 
@@ -758,52 +725,6 @@ extern "C" int msde_linear_bwd_w_grouped_ex(const long long* probs, const int* p
   else
     MSDE_LAUNCH(gemm_grouped_wgrad_kernel, dim3(grid), dim3(256), 0, as_stream(stream), probs, prefix, count, total_blocks,
                 grid == total_blocks ? xcd : 0);
-  MSDE_CHECK_LAUNCH();
-  return 0;
-}
-
-// Launch order of the grouped weight-gradient tiles, one XCD at a time.  The hardware hands workgroup i of a launch to XCD
-// i % 8; slot 8 k + c is therefore the k-th workgroup of XCD c.  A unit = one split of one problem (all tx * ty tiles over
-// the same rows of gY and X).  Units go to the XCD with the least work so far, longest first (work = tiles x K tiles per tile);
-// an XCD then walks its units one after the other, so the ~100 workgroups it has in flight belong to one or two units whose
-// operand rows sit in ITS L2.  order[slot] = tile in the natural numbering (prefix[p] + split * tx * ty + tile), -1 for the slots
-// that pad the shorter XCD lists.  Host tables in, host table out; returns the number of slots (a multiple of 8), < 0 on error.
-extern "C" int msde_linear_bwd_w_xcd_order(const long long* probs, const int* prefix, int count, int* order, int cap) {
-  if (count < 0 || (count > 0 && (!probs || !prefix)) || !order) return MSDE_EINVAL;
-  struct Unit { int first, tiles; long work; };
-  std::vector<Unit> units;
-  for (int p = 0; p < count; ++p) {
-    const long long* e = probs + (size_t)p * MSDE_WGRAD_ROW;
-    const int M = (int)e[4], splits = (int)e[7], kps = (int)e[8], tiles = (int)e[9] * (int)e[10];
-    if (prefix[p + 1] - prefix[p] != tiles * splits) return MSDE_EINVAL;
-    for (int z = 0; z < splits; ++z) {
-      const int rows = std::min(kps, M - z * kps);
-      units.push_back({prefix[p] + z * tiles, tiles, (long)tiles * ((rows + LG_BK - 1) / LG_BK + 2)});
-    }
-  }
-  std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.work > b.work; });
-  std::vector<int> lists[8];
-  long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (const Unit& u : units) {
-    int c = 0;
-    for (int x = 1; x < 8; ++x)
-      if (load[x] < load[c]) c = x;
-    for (int t = 0; t < u.tiles; ++t) lists[c].push_back(u.first + t);
-    load[c] += u.work;
-  }
-  size_t longest = 0;
-  for (int c = 0; c < 8; ++c) longest = std::max(longest, lists[c].size());
-  if ((long long)longest * 8 > cap) return MSDE_EINVAL;
-  for (size_t k = 0; k < longest; ++k)
-    for (int c = 0; c < 8; ++c) order[8 * k + c] = k < lists[c].size() ? lists[c][k] : -1;
-  return (int)(longest * 8);
-}
-
-extern "C" int msde_linear_bwd_w_grouped_units(const long long* probs, const int* prefix, int count, const int* order,
-                                               int slots, void* stream) {
-  if (count < 0 || slots < 0 || (count > 0 && (!probs || !prefix || !order))) return MSDE_EINVAL;
-  if (count == 0 || slots == 0) return 0;
-  MSDE_LAUNCH(gemm_grouped_wgrad_units_kernel, dim3(slots), dim3(256), 0, as_stream(stream), probs, prefix, count, slots, order);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

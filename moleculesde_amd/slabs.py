@@ -28,7 +28,6 @@ def _bn_workspace(M, C, device):
 
 
 WGRAD_HIP_MIN_ROWS = 64          # below this a split over M has nothing to split
-WGRAD_UNIT_ORDER = True          # grouped launch: every (problem, split) unit on ONE XCD (msde_linear_bwd_w_xcd_order); False: round-5 order
 
 _WS = {}          # per-device wgrad slab workspace, grown on demand (stream-ordered reuse)
 _WS_BYTES = {}    # (M, N, K) -> workspace bytes
@@ -145,7 +144,6 @@ def flush_table_uploads():
 
 class _SlabBatch:
     MAX_ROWS = 4096
-    MAX_ORDER = 1 << 16          # slots of the grouped launch's tile-order table (8 x the longest XCD list)
     EAGER_SLOTS = 3
 
     def __init__(self):
@@ -161,7 +159,6 @@ class _SlabBatch:
         self.leaf_more = []      # ... and the later contributions to the same parameter: (first address, tensor, level)
         self.slot = None
         self.slots = []          # slots 0..EAGER_SLOTS-1: the eager ring; one more per captured hipGraph
-        self.order_tabs = []     # per slot: (pinned host, device) tile-order table of the grouped launch
         self.events = []         # per slot: event recorded behind the last upload of its pinned host images
         self.slot_i = -1
         self.eager_i = 0
@@ -178,8 +175,6 @@ class _SlabBatch:
                      host_prob, host_ppre, torch.zeros(self.MAX_ROWS, 16, dtype=torch.int64, device=device),
                      torch.zeros(self.MAX_ROWS + 1, dtype=torch.int32, device=device))
         self.slots.append(self.slot)
-        self.order_tabs.append((torch.zeros(self.MAX_ORDER, dtype=torch.int32).pin_memory(),
-                                torch.zeros(self.MAX_ORDER, dtype=torch.int32, device=device)))
         self.events.append(None)
         self.slot_i = len(self.slots) - 1
 
@@ -214,7 +209,7 @@ class _SlabBatch:
         self.active = True
         self.used = 0
         self.leaf_first, self.leaf_more = {}, []
-        self.prob_used = self.pre_used = self.order_used = 0
+        self.prob_used = self.pre_used = 0
         self.rows_used = self.rpre_used = 0
         self.rotated = False
 
@@ -289,21 +284,8 @@ class _SlabBatch:
         upload_table(dev_prob[r0:r0 + ng], host_prob[r0:r0 + ng])
         upload_table(dev_ppre[q0:q0 + ng + 1], host_ppre[q0:q0 + ng + 1])
         self.prob_used, self.pre_used = r0 + ng, q0 + ng + 1
-        slots = -1
-        if WGRAD_UNIT_ORDER and not max_wgs:
-            host_ord, dev_ord = self.order_tabs[self.slot_i]
-            o0 = self.order_used
-            slots = int(lib.msde_linear_bwd_w_xcd_order(ctypes.c_void_p(host_prob[r0].data_ptr()),
-                                                        ctypes.c_void_p(host_ppre[q0:].data_ptr()), ng,
-                                                        ctypes.c_void_p(host_ord[o0:].data_ptr()), self.MAX_ORDER - o0))
-        if slots > 0:
-            upload_table(dev_ord[o0:o0 + slots], host_ord[o0:o0 + slots])
-            self.order_used = o0 + slots
-            _lib.call("msde_linear_bwd_w_grouped_units", ctypes.c_void_p(dev_prob[r0].data_ptr()),
-                      ctypes.c_void_p(dev_ppre[q0:].data_ptr()), ng, ctypes.c_void_p(dev_ord[o0:].data_ptr()), slots, _stream())
-        else:       # (a width-limited flush, or a launch too long for the order table: the round-5 order)
-            _lib.call("msde_linear_bwd_w_grouped_ex", ctypes.c_void_p(dev_prob[r0].data_ptr()),
-                      ctypes.c_void_p(dev_ppre[q0:].data_ptr()), ng, total_b, int(max_wgs), _stream())
+        _lib.call("msde_linear_bwd_w_grouped_ex", ctypes.c_void_p(dev_prob[r0].data_ptr()),
+                  ctypes.c_void_p(dev_ppre[q0:].data_ptr()), ng, total_b, int(max_wgs), _stream())
         # the operands stay referenced until finish(): a flush may run on ANOTHER stream than the one that allocated
         # them, and the caching allocator would otherwise hand their memory to the allocating stream's next kernels
         self.launched.extend(self.gemms)
