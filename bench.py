@@ -348,7 +348,21 @@ def roofline_pair_filter(trainer, batch, iters=50):
         ms = _event_time_ms(fn, iters, torch.cuda.current_stream())
     flops = P2 * 2.0 * (G * 128 + 128 * 128)
     tf = flops / (ms * 1e-3) / 1e12
+    multi = None
+    try:      # round 6: the rows of ALL interaction blocks from one launch (what the step runs: hip.cfconv_pair_filters)
+        nets = [(b_.mlp[0].weight.detach(), b_.mlp[0].bias.detach(), b_.mlp[2].weight.detach(), b_.mlp[2].bias.detach())
+                for b_ in sch.interactions]
+        with torch.no_grad():
+            ms_m = _event_time_ms(lambda: hip.cfconv_pair_filters(pp, nets, de.offset, de.coeff, sch.cutoff), iters,
+                                  torch.cuda.current_stream())
+        tf_m = flops * len(nets) / (ms_m * 1e-3) / 1e12
+        multi = {"kernel": "cfconv_pair_filter_multi_kernel", "blocks": len(nets), "avg_launch_us": round(ms_m * 1e3, 2),
+                 "us_per_interaction_block": round(ms_m * 1e3 / len(nets), 2), "achieved": round(tf_m, 2),
+                 "frac": round(tf_m / FP32_MFMA_PEAK_TF, 4), "timing": "stand-alone (HIP events), incl. the [L, P, 128] allocation"}
+    except Exception as exc:
+        multi = {"error": f"{type(exc).__name__}: {exc}"}
     return {"kernel": "cfconv_pair_filter_kernel", "bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TF,
+            "all_blocks_one_launch": multi,
             "unit": "TFLOP/s", "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "flops_per_launch": flops, "pairs": P2,
             "frac_against_the_per_edge_flops_of_rounds_1_2": round(2 * tf / FP32_MFMA_PEAK_TF, 4),
             "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": 6, "timing": "stand-alone (HIP events)",

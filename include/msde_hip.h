@@ -562,6 +562,14 @@ int msde_pair_build(const float* pos, const int* mol_ptr, int B, float r2, int* 
 int msde_cfconv_pair_filter(const float* pd, const int* count, const float* W1, const float* b1, const float* W2,
                             const float* b2, const float* offset, int F, int G, int P_cap, float coeff, float cutoff,
                             int blocks_per_wg, float* Wf, void* stream);
+/* The same for the filter networks of ALL L <= MSDE_CFCONV_MAX_LAYERS interaction blocks in ONE launch: the inputs of
+ * `W = self.mlp(edge_attr) * C` (schnet.py:141-145) are the same smeared distances for every block (schnet.py:96-104), so no
+ * block's filter rows depend on the layer chain.  W1 / b1 / W2 / b2 / Wf: HOST arrays of L device pointers (copied into the
+ * launch's arguments).  Results equal msde_cfconv_pair_filter's bit for bit. */
+#define MSDE_CFCONV_MAX_LAYERS 8
+int msde_cfconv_pair_filter_multi(const float* pd, const int* count, const float* const* W1, const float* const* b1,
+                                  const float* const* W2, const float* const* b2, const float* offset, int L, int F, int G,
+                                  int P_cap, float coeff, float cutoff, int blocks_per_wg, float* const* Wf, void* stream);
 /* out[i] = sum_{j != i in i's molecule} x[j] * Wf[pair(i, j)], ascending j (fixed order, no atomics): the CFConv message
  * aggregation with x = x1, and -- the pair set and Wf being symmetric -- its input gradient with x = g_agg. */
 int msde_cfconv_pair_aggregate(const float* x, const float* Wf, const int* batch, const int* mol_ptr, const int* pair_ptr,
@@ -573,6 +581,18 @@ int msde_cfconv_pair_bwd_w(const float* g_agg, const float* x1, const float* pd,
                            const int* pj, const float* W1, const float* b1, const float* W2, const float* offset, int N,
                            int F, int G, int P_cap, float coeff, float cutoff, int max_workgroups, float* gW1, float* gb1,
                            float* gW2, float* gb2, float* workspace, void* stream);
+/* The same for L <= MSDE_CFCONV_MAX_LAYERS interaction blocks in ONE launch (slabs only): the filter-network gradients of a
+ * block are parameter gradients, nothing in the backward chain of schnet.py:185-195 reads them, so the caller collects the
+ * blocks' (g_agg, x1) pairs while the chain runs and launches them together -- L x as many 64-pair chunks over the same
+ * workgroups, i.e. an even split (one block alone: 2.2 chunks per workgroup, rounded up to 3).  g_agg / x1 / W1 / b1 / W2 /
+ * slabs: HOST arrays of L device pointers; slabs[l]: msde_cfconv_pair_bwd_w_multi_slabs(P_cap, L, max_workgroups) slabs of
+ * F*F + F*G + 2F floats for block l (the whole launch runs L x that many workgroups, <= max_workgroups; 0: one per CU).
+ * Slab contents equal those of L msde_cfconv_pair_bwd_w calls with the same per-block workgroup count. */
+int msde_cfconv_pair_bwd_w_multi_slabs(int P_cap, int L, int max_workgroups);
+int msde_cfconv_pair_bwd_w_multi(const float* const* g_agg, const float* const* x1, const float* pd, const int* count,
+                                 const int* pi, const int* pj, const float* const* W1, const float* const* b1,
+                                 const float* const* W2, const float* offset, int L, int N, int F, int G, int P_cap,
+                                 float coeff, float cutoff, int max_workgroups, float* const* slabs, void* stream);
 
 /* ------------------------------------------------------------------ 3D->2D dense score head -- */
 /* SDEModel3Dto2D_node_adj_dense.forward (SDE_model_3D_to_2D_node_adj_dense.py:101-179) with its

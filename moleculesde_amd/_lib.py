@@ -58,6 +58,9 @@ SIGNATURES = {
     "msde_cfconv_fused_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P, P, P, P, P],
     "msde_pair_build": [P, P, I, F, P, P, P, P, I, P, P],
     "msde_cfconv_pair_filter": [P, P, P, P, P, P, P, I, I, I, F, F, I, P, P],
+    "msde_cfconv_pair_filter_multi": [P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P],
+    "msde_cfconv_pair_bwd_w_multi_slabs": [I, I, I],
+    "msde_cfconv_pair_bwd_w_multi": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, F, I, P, P],
     "msde_cfconv_pair_aggregate": [P, P, P, P, P, I, I, I, P, P],
     "msde_cfconv_pair_bwd_w": [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P, P, P, P, P, P],
     "msde_edge_geometry_fwd": [P, P, P, I, P, P, I, P, P, P, P, P, P],

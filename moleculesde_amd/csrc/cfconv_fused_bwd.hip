@@ -263,13 +263,15 @@ cfconv_fused_bwd_w_kernel(const float* __restrict__ g_agg, const float* __restri
 // SYM (csrc/cfconv_pair.hip): the rows are UNORDERED atom pairs {src, dst}; the filter gradient of a pair is the sum over
 // both directions, g_pre2 = (g_agg[dst] x1[src] + g_agg[src] x1[dst]) C(d), formed before the weight-gradient products --
 // half the rows, half the matrix-core work.  A negative distance marks a pair beyond the cutoff (C = 0).
+// (body: workgroup `wg` of one filter network's launch; the kernels below bind it to blockIdx.x of a one-layer launch or to
+// (layer, workgroup) of the all-layers launch)
 template <int KK1, int DBG, bool W2R = false, bool SYM = false>
-__global__ void __launch_bounds__(256, 1)
-cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
-                               const int* __restrict__ ecount, const int* __restrict__ src, const int* __restrict__ dst,
-                               const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
-                               const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
-                               float* __restrict__ slabs) {
+__device__ __forceinline__ void
+cfconv_bwd_w_pipe_body(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
+                       const int* __restrict__ ecount, const int* __restrict__ src, const int* __restrict__ dst,
+                       const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                       const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
+                       float* __restrict__ slabs, const int wg) {
   constexpr int dbg = DBG;                     // phase knock-outs for tools/bench_cfconv_bwd.py (0 in the product)
   constexpr int RS = 2 * KK1 + 1;
   constexpr int RBF_SZ = CB_TE * RS + 64;      // + slack: the gW1 product reads up to column 63 of the last row
@@ -291,7 +293,7 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
   const int col = wave * 32 + lcol;
 
   const int E = ecount[0];                     // rows: radius edges (rowptr[N]) or pairs
-  const int e_begin = min(blockIdx.x * cpw * CB_TE, E);
+  const int e_begin = min(wg * cpw * CB_TE, E);
   const int e_end = min(e_begin + cpw * CB_TE, E);
   const int nchunks = (e_end - e_begin + CB_TE - 1) / CB_TE;
 
@@ -590,7 +592,7 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
 
   // ---- write this workgroup's slab: [128*128 gW2][128*G gW1][128 gb1][128 gb2]
   const size_t slab_sz = (size_t)CB_F * CB_F + (size_t)CB_F * G + 2 * CB_F;
-  float* slab = slabs + (size_t)blockIdx.x * slab_sz;
+  float* slab = slabs + (size_t)wg * slab_sz;
   if (dbg & 128) { if (aW2[0][0] + aW1[0][0] + sb1 + sb2 == 12345.678f) slab[0] = 1.f; return; }
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -614,6 +616,41 @@ cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __r
     slab[(size_t)CB_F * CB_F + (size_t)CB_F * G + col] = sb1;
     slab[(size_t)CB_F * CB_F + (size_t)CB_F * G + CB_F + col] = sb2;
   }
+}
+
+template <int KK1, int DBG, bool W2R = false, bool SYM = false>
+__global__ void __launch_bounds__(256, 1)
+cfconv_fused_bwd_w_pipe_kernel(const float* __restrict__ g_agg, const float* __restrict__ x1, const float* __restrict__ dist,
+                               const int* __restrict__ ecount, const int* __restrict__ src, const int* __restrict__ dst,
+                               const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                               const float* __restrict__ offset, int N, int G, float coeff, float cutoff, int cpw,
+                               float* __restrict__ slabs) {
+  cfconv_bwd_w_pipe_body<KK1, DBG, W2R, SYM>(g_agg, x1, dist, ecount, src, dst, W1, b1, W2, offset, N, G, coeff, cutoff, cpw, slabs,
+                                             (int)blockIdx.x);
+}
+
+// Pair form for SEVERAL interaction blocks in one launch: the filter-network weight gradients of a block feed nothing in the
+// backward chain (they are parameter gradients: slabs for the batched reduction), so the blocks' launches -- 383 chunks of 64
+// pairs each at bs 256, 2.2 per workgroup at the width the step gives them: every workgroup rounds up to 3 -- are collected
+// and run as ONE launch of L x 383 chunks once the chain has produced the last block's gradient: 13 per workgroup, rounded to
+// 14.  Workgroup b serves layer b / wpl with the pair chunks (b % wpl) * cpw ...; per-layer slabs [wpl][slab].
+struct cb_multi_ptrs {
+  const float* g[MSDE_CFCONV_MAX_LAYERS];
+  const float* x1[MSDE_CFCONV_MAX_LAYERS];
+  const float* W1[MSDE_CFCONV_MAX_LAYERS];
+  const float* b1[MSDE_CFCONV_MAX_LAYERS];
+  const float* W2[MSDE_CFCONV_MAX_LAYERS];
+  float* slabs[MSDE_CFCONV_MAX_LAYERS];
+};
+
+template <int KK1>
+__global__ void __launch_bounds__(256, 1)
+cfconv_pair_bwd_w_multi_kernel(const cb_multi_ptrs m, const float* __restrict__ pd, const int* __restrict__ count,
+                               const int* __restrict__ pi, const int* __restrict__ pj, const float* __restrict__ offset, int N,
+                               int G, float coeff, float cutoff, int cpw, int wpl) {
+  const int l = blockIdx.x / wpl, wg = blockIdx.x - l * wpl;
+  cfconv_bwd_w_pipe_body<KK1, 0, true, true>(m.g[l], m.x1[l], pd, count, pj, pi, m.W1[l], m.b1[l], m.W2[l], offset, N, G, coeff,
+                                             cutoff, cpw, m.slabs[l], wg);
 }
 
 __global__ void cfconv_reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, size_t slab_sz, int G,
@@ -807,6 +844,68 @@ extern "C" int msde_cfconv_pair_bwd_w(const float* g_agg, const float* x1, const
   const int blocks = (int)((slab_sz + 255) / 256);
   MSDE_LAUNCH(cfconv_reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, nwg, slab_sz, G, gW2,
               gW1, gb1, gb2);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- all-layers pair form (cfconv_pair_bwd_w_multi_kernel above) -----------------------------------------------------------
+// geometry: L layers share `max_workgroups` persistent workgroups (0: one per CU): every layer gets the same number wpl, each
+// workgroup cpw chunks of 64 pairs of ITS layer
+static inline void cb_multi_geometry(int P_cap, int L, int max_wgs, int* wpl, int* cpw) {
+  const int chunks = (P_cap + CB_TE - 1) / CB_TE;
+  const int total = max_wgs > 0 ? max_wgs : msde_num_cus();
+  int w = total / (L > 0 ? L : 1);
+  if (w < 1) w = 1;
+  if (w > chunks) w = chunks;
+  if (w < 1) w = 1;
+  *cpw = (chunks + w - 1) / w;
+  if (*cpw < 1) *cpw = 1;
+  *wpl = (chunks + *cpw - 1) / *cpw;
+  if (*wpl < 1) *wpl = 1;
+}
+
+extern "C" int msde_cfconv_pair_bwd_w_multi_slabs(int P_cap, int L, int max_workgroups) {
+  int wpl, cpw;
+  cb_multi_geometry(P_cap, L, max_workgroups, &wpl, &cpw);
+  return wpl;
+}
+
+extern "C" int msde_cfconv_pair_bwd_w_multi(const float* const* g_agg, const float* const* x1, const float* pd, const int* count,
+                                            const int* pi, const int* pj, const float* const* W1, const float* const* b1,
+                                            const float* const* W2, const float* offset, int L, int N, int F, int G, int P_cap,
+                                            float coeff, float cutoff, int max_workgroups, float* const* slabs, void* stream) {
+  if (N < 0 || P_cap < 0 || L < 0 || !g_agg || !x1 || !pd || !count || !pi || !pj || !W1 || !b1 || !W2 || !offset || !slabs)
+    return MSDE_EINVAL;
+  const int kk1 = (G + 1) / 2;
+  if (F != CB_F || G <= 0 || kk1 > 26 || L > MSDE_CFCONV_MAX_LAYERS) return MSDE_EUNSUP;
+  if (L == 0) return 0;
+  cb_multi_ptrs m;
+  for (int l = 0; l < L; ++l) {
+    if (!g_agg[l] || !x1[l] || !W1[l] || !b1[l] || !W2[l] || !slabs[l]) return MSDE_EINVAL;
+    m.g[l] = g_agg[l]; m.x1[l] = x1[l]; m.W1[l] = W1[l]; m.b1[l] = b1[l]; m.W2[l] = W2[l]; m.slabs[l] = slabs[l];
+  }
+  int wpl, cpw;
+  cb_multi_geometry(P_cap, L, max_workgroups, &wpl, &cpw);
+  auto ldsp_bytes = [](int KK1) {
+    return (size_t)(2 * (CB_TE * (2 * KK1 + 1) + 64) + 2 * CB_TE * CB_HS + 8 * CB_TE + 64) * sizeof(float);
+  };
+  hipStream_t st = as_stream(stream);
+#define CBM_LAUNCH(KK)                                                                                                \
+  {                                                                                                                   \
+    static bool attr_done = false;                                                                                    \
+    if (!attr_done) {                                                                                                 \
+      hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfconv_pair_bwd_w_multi_kernel<KK>),         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp_bytes(KK));           \
+      if (ae != hipSuccess) return (int)ae;                                                                           \
+      attr_done = true;                                                                                               \
+    }                                                                                                                 \
+  }                                                                                                                   \
+  MSDE_LAUNCH(cfconv_pair_bwd_w_multi_kernel<KK>, dim3(wpl * L), dim3(256), ldsp_bytes(KK), st, m, pd, count, pi, pj, offset, N, \
+              G, coeff, cutoff, cpw, wpl)
+  if (kk1 == 26) { CBM_LAUNCH(26); }
+  else if (kk1 == 25) { CBM_LAUNCH(25); }
+  else { CBM_LAUNCH(24); }
+#undef CBM_LAUNCH
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -93,12 +93,12 @@ __device__ __forceinline__ float cp_ssp(float x) {
   return fmaf(__builtin_amdgcn_logf(1.f + e), 0.69314718055994531f, fmaxf(x, 0.f) - 0.69314718055994531f);
 }
 
+// body shared by the one-layer launch and the all-layers launch below: the pair blocks [p_begin, p_end) of ONE filter network
 template <int KK1>
-__global__ void __launch_bounds__(256, 2)
-cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ count, const float* __restrict__ W1,
-                          const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
-                          const float* __restrict__ offset, int G, float coeff, float cutoff, int cpw,
-                          float* __restrict__ Wf) {
+__device__ __forceinline__ void
+cp_filter_body(const float* __restrict__ pd, const int P, const float* __restrict__ W1, const float* __restrict__ b1,
+               const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ offset, int G,
+               float coeff, float cutoff, const int p_begin, int cpw, float* __restrict__ Wf) {
   constexpr int RS = 2 * KK1 + 1;
   extern __shared__ float lds[];
   float* rbf_t = lds;                          // [32][RS]
@@ -109,72 +109,32 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 31, lhalf = lane >> 5;
   const int col = wave * 32 + lcol;
-  const int P = count[0];
-  const int p_begin = blockIdx.x * cpw * CP_TE;
   if (p_begin >= P) return;
   const int p_end = min(p_begin + cpw * CP_TE, P);
 
-  // weights -> registers (B operands) from the nn.Linear layouts W1 [F][G], W2 [F][F], staged through LDS
+  // weights -> registers (B operands), straight from the nn.Linear layouts W1 [F][G], W2 [F][F].  The 32x32x2 MFMA sums its two
+  // k lanes (lane halves), so ANY pairing of reduction indices with (k step, lane half) gives the same product as long as the A
+  // operand uses the same pairing: lane half h takes the CONTIGUOUS reduction range [64 h, 64 h + 64) of layer 2 and
+  // [KK1 h, KK1 h + KK1) of layer 1.  A lane's B fragments are then 64 (26) consecutive floats of ONE weight row: sixteen
+  // 16-byte loads (26 scalar ones: a W1 row is G = 51 floats, not 16-byte aligned) and no LDS staging -- the round-3 prologue moved
+  // the same 90 KB per workgroup global -> registers -> LDS -> registers behind twelve barriers (23.9 -> 21.4 us per launch).
   float w1r[KK1], w2r[CP_F / 2];
   {
-    float* stage = hid_t;
-    const bool vec = (reinterpret_cast<uintptr_t>(W2) & 15) == 0;
-    float4 v2[4][4];
+    const float* w2p = W2 + (size_t)col * CP_F + 64 * lhalf;
+    if ((reinterpret_cast<uintptr_t>(W2) & 15) == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i4 = tid + 256 * j;
-        const float* srcp = W2 + (size_t)(32 * r + (i4 >> 5)) * CP_F + 4 * (i4 & 31);
-        v2[r][j] = vec ? *reinterpret_cast<const float4*>(srcp) : make_float4(srcp[0], srcp[1], srcp[2], srcp[3]);
+      for (int j = 0; j < CP_F / 8; ++j) {
+        const float4 v = reinterpret_cast<const float4*>(w2p)[j];
+        w2r[4 * j] = v.x; w2r[4 * j + 1] = v.y; w2r[4 * j + 2] = v.z; w2r[4 * j + 3] = v.w;
       }
-    constexpr int W1J = 64 * 64 / 256;
-    float v1[2][W1J];
-    const int half_n = 64 * G;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int j = 0; j < W1J; ++j) {
-        const int i = tid + 256 * j;
-        v1[r][j] = i < half_n ? W1[(size_t)r * half_n + i] : 0.f;
-      }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i4 = tid + 256 * j;
-        // (a staged row is stored column-permuted, column 4 c + k at position 32 k + c: the 32 lanes of a half then cover 32
-        // banks in each of the four store instructions -- at position 4 c + k they covered 8, a 4-way conflict on every staging
-        // store, which was the 30 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 4's counters; the loop itself is conflict free)
-        float* dd = stage + (i4 >> 5) * CP_HS + (i4 & 31);
-        dd[0] = v2[r][j].x; dd[32] = v2[r][j].y; dd[64] = v2[r][j].z; dd[96] = v2[r][j].w;
-      }
-      __syncthreads();
-      if (wave == r) {
-#pragma unroll
-        for (int kk = 0; kk < CP_F / 2; ++kk)          // column 2 kk + lhalf = 4 c + k sits at 32 k + c
-          w2r[kk] = stage[lcol * CP_HS + 32 * lhalf + 64 * (kk & 1) + (kk >> 1)];
-      }
-      __syncthreads();
+      for (int kk = 0; kk < CP_F / 2; ++kk) w2r[kk] = w2p[kk];
     }
+    const int g0 = KK1 * lhalf;
+    const float* w1p = W1 + (size_t)col * G + g0;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-      for (int j = 0; j < W1J; ++j) {
-        const int i = tid + 256 * j;
-        if (i < half_n) stage[i] = v1[r][j];
-      }
-      __syncthreads();
-      if ((wave >> 1) == r) {
-        const int lrow = (wave & 1) * 32 + lcol;
-#pragma unroll
-        for (int kk = 0; kk < KK1; ++kk) {
-          const int g = 2 * kk + lhalf;
-          w1r[kk] = g < G ? stage[lrow * G + g] : 0.f;
-        }
-      }
-      __syncthreads();
-    }
+    for (int kk = 0; kk < KK1; ++kk) w1r[kk] = g0 + kk < G ? w1p[kk] : 0.f;
   }
   const float b1c = b1[col], b2c = b2[col];
 
@@ -205,8 +165,8 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
   produce_math();
   constexpr auto RW = [](int i) constexpr { return (i & 3) + 8 * (i >> 2); };
   float* const hw = hid_t + 4 * lhalf * CP_HS + col;
-  const float* const ra = rbf_t + lcol * RS + lhalf;
-  const float* const ha = hid_t + lcol * CP_HS + lhalf;
+  const float* const ra = rbf_t + lcol * RS + KK1 * lhalf;      // A operands: row = pair, this half's reduction range (see above)
+  const float* const ha = hid_t + lcol * CP_HS + 64 * lhalf;
 
   int buf = 0;
   for (int pc = p_begin; pc < p_end; pc += CP_TE, buf ^= 1) {
@@ -224,14 +184,14 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < KK1; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[2 * kk], w1r[kk], acc, 0, 0, 0);
+    for (int kk = 0; kk < KK1; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk], w1r[kk], acc, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) hw[RW(i) * CP_HS] = cp_ssp(acc[i] + b1c);
     __syncthreads();   // B2
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < CP_F / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[2 * kk], w2r[kk], acc, 0, 0, 0);
+    for (int kk = 0; kk < CP_F / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ha[kk], w2r[kk], acc, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = RW(i) + 4 * lhalf;
@@ -239,6 +199,72 @@ cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ 
     }
     if (more) produce_math();
   }
+}
+
+template <int KK1>
+__global__ void __launch_bounds__(256, 2)
+cfconv_pair_filter_kernel(const float* __restrict__ pd, const int* __restrict__ count, const float* __restrict__ W1,
+                          const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                          const float* __restrict__ offset, int G, float coeff, float cutoff, int cpw,
+                          float* __restrict__ Wf) {
+  cp_filter_body<KK1>(pd, count[0], W1, b1, W2, b2, offset, G, coeff, cutoff, blockIdx.x * cpw * CP_TE, cpw, Wf);
+}
+
+// The filter rows of ALL interaction blocks in one launch.  Wf_l(d) depends on the pair distances and on block l's filter
+// network only -- not on the atom features -- so nothing in the layer chain has to wait for it (schnet.py:141-145 computes
+// W = self.mlp(edge_attr) * C inside every block; the inputs edge_attr / edge_weight are the same tensors for all blocks,
+// schnet.py:96-104).  Workgroup b serves layer b / wpl, pair blocks (b % wpl) * cpw ...: L x more blocks per launch than a
+// layer of its own, so the split over the CUs is even (one layer: 766 blocks, 2 or 4 per CU) and the SchNet forward chain is
+// four launches per block (lin1, aggregate, lin2 + ssp, lin + residual) instead of five.
+struct cp_multi_ptrs {
+  const float* W1[MSDE_CFCONV_MAX_LAYERS];
+  const float* b1[MSDE_CFCONV_MAX_LAYERS];
+  const float* W2[MSDE_CFCONV_MAX_LAYERS];
+  const float* b2[MSDE_CFCONV_MAX_LAYERS];
+  float* Wf[MSDE_CFCONV_MAX_LAYERS];
+};
+
+template <int KK1>
+__global__ void __launch_bounds__(256, 2)
+cfconv_pair_filter_multi_kernel(const float* __restrict__ pd, const int* __restrict__ count, const cp_multi_ptrs m,
+                                const float* __restrict__ offset, int G, float coeff, float cutoff, int cpw, int wpl) {
+  const int l = blockIdx.x / wpl, r = blockIdx.x - l * wpl;
+  cp_filter_body<KK1>(pd, count[0], m.W1[l], m.b1[l], m.W2[l], m.b2[l], offset, G, coeff, cutoff, r * cpw * CP_TE, cpw, m.Wf[l]);
+}
+
+extern "C" int msde_cfconv_pair_filter_multi(const float* pd, const int* count, const float* const* W1, const float* const* b1,
+                                             const float* const* W2, const float* const* b2, const float* offset, int L, int F,
+                                             int G, int P_cap, float coeff, float cutoff, int blocks_per_wg, float* const* Wf,
+                                             void* stream) {
+  if (P_cap < 0 || L < 0 || !pd || !count || !W1 || !b1 || !W2 || !b2 || !offset || !Wf) return MSDE_EINVAL;
+  if (F != CP_F || G <= 0 || G > 64 || L > MSDE_CFCONV_MAX_LAYERS) return MSDE_EUNSUP;
+  if (P_cap == 0 || L == 0) return 0;
+  cp_multi_ptrs m;
+  for (int l = 0; l < L; ++l) {
+    if (!W1[l] || !b1[l] || !W2[l] || !b2[l] || !Wf[l]) return MSDE_EINVAL;
+    m.W1[l] = W1[l]; m.b1[l] = b1[l]; m.W2[l] = W2[l]; m.b2[l] = b2[l]; m.Wf[l] = Wf[l];
+  }
+  const int kk1 = (G + 1) / 2;
+  const int blocks = (P_cap + CP_TE - 1) / CP_TE;
+  if (blocks_per_wg <= 0) {
+    // ~ three rounds of two workgroups per CU over the whole launch: short enough workgroups that the dispatcher evens the
+    // CUs out, long enough (>= 3 blocks) that the 90 KB weight prologue of a workgroup stays a small part of it
+    const long total = (long)blocks * L, slots = 6L * msde_num_cus();
+    blocks_per_wg = (int)((total + slots - 1) / slots);
+    if (blocks_per_wg < 3) blocks_per_wg = 3;
+  }
+  const int wpl = (blocks + blocks_per_wg - 1) / blocks_per_wg;
+  auto lds_bytes = [](int KK1) { return (size_t)(CP_TE * (2 * KK1 + 1) + CP_TE * CP_HS + 2 * CP_TE) * sizeof(float); };
+  hipStream_t st = as_stream(stream);
+#define CPM_LAUNCH(KK)                                                                                                 \
+  MSDE_LAUNCH(cfconv_pair_filter_multi_kernel<KK>, dim3(wpl * L), dim3(256), lds_bytes(KK), st, pd, count, m, offset, G, coeff, \
+              cutoff, blocks_per_wg, wpl)
+  if (kk1 == 26) { CPM_LAUNCH(26); }
+  else if (kk1 == 25) { CPM_LAUNCH(25); }
+  else { CPM_LAUNCH(32); }
+#undef CPM_LAUNCH
+  MSDE_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int msde_cfconv_pair_filter(const float* pd, const int* count, const float* W1, const float* b1, const float* W2,

@@ -117,8 +117,16 @@ class SchNet(nn.Module):
         # unordered pairs (half the filter-network work, no radius CSR at all); larger molecules keep the per-edge kernels
         pairwise = (fusable and hip.CFCONV_PAIR and self.use_pairs and self.num_gaussians <= 52
                     and pl.N_max <= self.max_num_neighbors + 1)
+        Wfs = bwd_batch = None
         if pairwise:
             pp = hip.pair_plan(pos, pl, self.cutoff)
+            if grad and hip.CFCONV_BWD_GROUP > 1:
+                bwd_batch = hip.CfBwdBatch(pp, de.offset, de.coeff, self.cutoff, len(self.interactions))
+            if hip.CFCONV_FILTER_MULTI and 0 < len(self.interactions) <= 8:
+                # W = mlp(rbf(d)) * C(d) of every block (schnet.py:141-145) needs the distances only: one launch for all blocks,
+                # in front of the layer chain (the chain is then lin1 -> aggregate -> lin2 -> lin per block)
+                Wfs = hip.cfconv_pair_filters(pp, [(b_.mlp[0].weight, b_.mlp[0].bias, b_.mlp[2].weight, b_.mlp[2].bias)
+                                                   for b_ in self.interactions], de.offset, de.coeff, self.cutoff)
         else:
             rplan, dist = hip.radius_plan(pos, pl.batch_i32, pl.mol_ptr, self.cutoff, pl.E_r_cap, self.max_num_neighbors,
                                            n_max=getattr(pl, "N_max", None))
@@ -135,10 +143,11 @@ class SchNet(nn.Module):
                 h_res, x1 = _nn.linear_fork(h, blk.conv.lin1.weight)
             if pairwise and grad:
                 agg = hip.cfconv_pair(x1, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias, pp,
-                                      de.offset, de.coeff, self.cutoff)
+                                      de.offset, de.coeff, self.cutoff, Wf=None if Wfs is None else Wfs[bi], bwd_batch=bwd_batch)
             elif pairwise:
                 agg, _ = hip.cfconv_pair_forward(x1, pp, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight,
-                                                 blk.mlp[2].bias, de.offset, de.coeff, self.cutoff)
+                                                 blk.mlp[2].bias, de.offset, de.coeff, self.cutoff,
+                                                 Wf=None if Wfs is None else Wfs[bi])
             elif fusable and grad:
                 agg = hip.cfconv_fused(x1, blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias,
                                        dist, rplan, de.offset, de.coeff, self.cutoff)

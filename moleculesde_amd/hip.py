@@ -311,15 +311,38 @@ def _pair_blocks_per_wg(P):
     return max(1, -(-blocks // int(CFCONV_FWD_WGS)))
 
 
-def cfconv_pair_forward(x1, pp, W1, b1, W2, b2, offset, coeff, cutoff):
-    """(agg, Wf): filter rows per unordered pair on the matrix cores, then the fixed-order aggregation."""
+CFCONV_FILTER_MULTI = True     # the filter rows of all interaction blocks in ONE launch at the head of SchNet's forward
+CFCONV_MULTI_BLOCKS_PER_WG = 0   # 0: chosen by the library (msde_cfconv_pair_filter_multi)
+
+
+def cfconv_pair_filters(pp, nets, offset, coeff, cutoff):
+    """Filter rows Wf_l [P, 128] of every interaction block l from ONE launch (msde_cfconv_pair_filter_multi): they depend on
+    the pair distances and on block l's filter network only, so the layer chain need not wait for them one block at a time.
+    nets: [(W1, b1, W2, b2)] per block (schnet.py:141-145).  Returns the list of Wf_l (views of one buffer)."""
+    import ctypes
+    L = len(nets)
+    Fd, G = nets[0][2].size(0), nets[0][0].size(1)
+    dev = pp.pd.device
+    buf = torch.empty(L, max(pp.P, 1), Fd, dtype=torch.float32, device=dev)
+    keep = [[_f32(t) for t in n] for n in nets]
+    arr = lambda k: ctypes.cast((ctypes.c_void_p * L)(*[n[k].data_ptr() for n in keep]), ctypes.c_void_p)
+    outs = ctypes.cast((ctypes.c_void_p * L)(*[buf[l].data_ptr() for l in range(L)]), ctypes.c_void_p)
+    _lib.call("msde_cfconv_pair_filter_multi", _p(pp.pd), _p(pp.count), arr(0), arr(1), arr(2), arr(3), _p(_f32(offset)), L, Fd, G,
+              pp.P, float(coeff), float(cutoff), int(CFCONV_MULTI_BLOCKS_PER_WG), outs, _stream())
+    return [buf[l] for l in range(L)]
+
+
+def cfconv_pair_forward(x1, pp, W1, b1, W2, b2, offset, coeff, cutoff, Wf=None):
+    """(agg, Wf): filter rows per unordered pair on the matrix cores (unless the caller already has them: Wf from
+    cfconv_pair_filters), then the fixed-order aggregation."""
     x1 = _f32(x1)
     N, Fd = x1.shape
     G = W1.size(1)
     st = _stream()
-    Wf = torch.empty(max(pp.P, 1), Fd, dtype=torch.float32, device=x1.device)
-    _lib.call("msde_cfconv_pair_filter", _p(pp.pd), _p(pp.count), _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)),
-              _p(_f32(offset)), Fd, G, pp.P, float(coeff), float(cutoff), _pair_blocks_per_wg(pp.P), _p(Wf), st)
+    if Wf is None:
+        Wf = torch.empty(max(pp.P, 1), Fd, dtype=torch.float32, device=x1.device)
+        _lib.call("msde_cfconv_pair_filter", _p(pp.pd), _p(pp.count), _p(_f32(W1)), _p(_f32(b1)), _p(_f32(W2)), _p(_f32(b2)),
+                  _p(_f32(offset)), Fd, G, pp.P, float(coeff), float(cutoff), _pair_blocks_per_wg(pp.P), _p(Wf), st)
     agg = torch.empty(N, Fd, dtype=torch.float32, device=x1.device)
     stamp("cf_agg_start")     # no-ops unless enable_stamps(): bench.py times this launch inside the captured step
     _lib.call("msde_cfconv_pair_aggregate", _p(x1), _p(Wf), _p(pp.batch_i32), _p(pp.mol_ptr), _p(pp.pair_ptr), N, pp.B, Fd,
@@ -328,17 +351,64 @@ def cfconv_pair_forward(x1, pp, W1, b1, W2, b2, offset, coeff, cutoff):
     return agg, Wf
 
 
+CFCONV_BWD_GROUP = 6     # interaction blocks per filter-weight-gradient launch inside a parameter-gradient batch (1: a launch per block)
+
+
+class CfBwdBatch:
+    """The filter-network weight gradients of SchNet's interaction blocks as ONE launch per `group` blocks
+    (msde_cfconv_pair_bwd_w_multi).  They are parameter gradients -- nothing in the backward chain reads them -- so each
+    block's backward only hands its (g_agg, x1, weights, result buffer) over; the launch goes out when `group` blocks have
+    reported (the chain runs from the last block to the first) or, at the latest, with the deferred leaf kernels of the
+    parameter-gradient batch (a backward pass that stops short of some block).  One object per SchNet forward."""
+
+    def __init__(self, pp, offset, coeff, cutoff, total, group=None):
+        self.pp, self.offset, self.coeff, self.cutoff = pp, offset, float(coeff), float(cutoff)
+        self.total, self.group = int(total), max(1, min(int(group or CFCONV_BWD_GROUP), 8))
+        self.pending, self.seen, self.hooked = [], 0, False
+
+    def usable(self):
+        return self.group > 1 and _SLABS.active
+
+    def add(self, g, x1, W1, b1, W2, gall):
+        self.pending.append((g, x1, W1, b1, W2, gall))
+        self.seen += 1
+        if not self.hooked:          # safety net: whatever is still pending when the backward pass ends goes out then
+            self.hooked = True
+            _SLABS.deferred.append(lambda st_=None: self.flush())
+        if len(self.pending) >= self.group or self.seen >= self.total:
+            self.flush()
+
+    def flush(self):
+        import ctypes
+        items, self.pending = self.pending, []
+        if not items:
+            return
+        pp, L = self.pp, len(items)
+        N, Fd = items[0][1].shape
+        G = items[0][2].size(1)
+        mw = int(CFCONV_BWD_WGS or 0)
+        nslab = int(_lib.load().msde_cfconv_pair_bwd_w_multi_slabs(pp.P, L, mw))
+        ws = [_SLABS.alloc(nslab * it[5].numel(), it[0].device) for it in items]
+        arr = lambda ts: ctypes.cast((ctypes.c_void_p * L)(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
+        _lib.call("msde_cfconv_pair_bwd_w_multi", arr([it[0] for it in items]), arr([it[1] for it in items]), _p(pp.pd), _p(pp.count),
+                  _p(pp.pi), _p(pp.pj), arr([it[2] for it in items]), arr([it[3] for it in items]), arr([it[4] for it in items]),
+                  _p(self.offset), L, N, Fd, G, pp.P, self.coeff, self.cutoff, mw, arr(ws), _stream())
+        for it, w in zip(items, ws):
+            _SLABS.add(w.data_ptr(), nslab, it[5].numel(), it[5], written=True)
+        _SLABS.launched.append(items)      # operands stay referenced until the batch is finished
+
+
 class _CFConvPair(torch.autograd.Function):
     """CFConv (schnet.py:141-145,185-195) on unordered pairs: forward = filter kernel + aggregation; backward = the same
     aggregation applied to the incoming gradient (input gradient) and the pair form of the recomputing weight-gradient
     kernel (both directions of a pair summed before its products)."""
 
     @staticmethod
-    def forward(ctx, x1, W1, b1, W2, b2, pp, offset, coeff, cutoff):
+    def forward(ctx, x1, W1, b1, W2, b2, pp, offset, coeff, cutoff, Wf_pre=None, bwd_batch=None):
         x1, W1, b1, W2, b2 = _f32(x1), _f32(W1), _f32(b1), _f32(W2), _f32(b2)
-        agg, Wf = cfconv_pair_forward(x1, pp, W1, b1, W2, b2, offset, coeff, cutoff)
+        agg, Wf = cfconv_pair_forward(x1, pp, W1, b1, W2, b2, offset, coeff, cutoff, Wf=Wf_pre)
         ctx.save_for_backward(x1, W1, b1, W2, Wf, offset)
-        ctx.pp, ctx.coeff, ctx.cutoff = pp, float(coeff), float(cutoff)
+        ctx.pp, ctx.coeff, ctx.cutoff, ctx.bwd_batch = pp, float(coeff), float(cutoff), bwd_batch
         return agg
 
     @staticmethod
@@ -362,7 +432,9 @@ class _CFConvPair(torch.autograd.Function):
         mw = int(CFCONV_BWD_WGS or 0)
         args = (_p(g), _p(x1), _p(pp.pd), _p(pp.count), _p(pp.pi), _p(pp.pj), _p(W1), _p(b1), _p(W2), _p(offset), N, Fd, G,
                 pp.P, ctx.coeff, ctx.cutoff, mw)
-        if _SLABS.active:
+        if ctx.bwd_batch is not None and ctx.bwd_batch.usable():
+            ctx.bwd_batch.add(g, x1, W1, b1, W2, gall)        # one launch for `group` blocks (CfBwdBatch)
+        elif _SLABS.active:
             nslab = int(_lib.load().msde_cfconv_fused_bwd_w_slabs(pp.P, mw))
             ws = _SLABS.alloc(nslab * gall.numel(), g.device)
             _lib.call("msde_cfconv_pair_bwd_w", *args, _p(None), _p(None), _p(None), _p(None), _p(ws), st)
@@ -370,11 +442,13 @@ class _CFConvPair(torch.autograd.Function):
         else:
             ws = _cf_workspace(pp.P, G, x1.device, mw)
             _lib.call("msde_cfconv_pair_bwd_w", *args, _p(gW1), _p(gb1), _p(gW2), _p(gb2), _p(ws), st)
-        return g_x1, gW1, gb1, gW2, gb2, None, None, None, None
+        return g_x1, gW1, gb1, gW2, gb2, None, None, None, None, None, None
 
 
-def cfconv_pair(x1, W1, b1, W2, b2, pp, offset, coeff, cutoff):
-    return _CFConvPair.apply(x1, W1, b1, W2, b2, pp, offset, coeff, cutoff)
+def cfconv_pair(x1, W1, b1, W2, b2, pp, offset, coeff, cutoff, Wf=None, bwd_batch=None):
+    """Wf: this block's filter rows when the caller computed them for all blocks at once (cfconv_pair_filters); bwd_batch: the
+    CfBwdBatch of this forward pass (the blocks' filter-weight gradients as one launch)."""
+    return _CFConvPair.apply(x1, W1, b1, W2, b2, pp, offset, coeff, cutoff, Wf, bwd_batch)
 
 
 def edge_geometry(pos, plan, Wd, Wc):

@@ -10,6 +10,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def record_parity(line):
+    """Achieved parity numbers of a GPU test run, kept: appended to gpurun_out/parity_numbers.txt (scratch that gpurun merges
+    back; the round's copy is committed as profiles/rNN_parity_numbers.txt) and printed."""
+    print(line)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_numbers.txt"), "a") as f:
+            f.write(line.rstrip("\n") + "\n")
+    except OSError:
+        pass
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name)) as z:
         return {k: z[k] for k in z.files}

@@ -476,6 +476,63 @@ def test_cfconv_pair_forward_and_backward(dev, G, cutoff, stretch, pad):
         assert_close(a.grad, r.grad, 1e-3, 2e-4 * float(r.grad.abs().max()), f"pair {name}")
 
 
+@pytest.mark.parametrize("L,group", [(3, 3), (6, 6), (5, 2)])
+def test_cfconv_pair_all_blocks_in_one_launch(dev, L, group):
+    """Round 6: the filter rows of ALL interaction blocks from one launch (msde_cfconv_pair_filter_multi: they depend on the
+    distances only, schnet.py:96-104,141-145) are the per-block launches' rows bit for bit, and the blocks' filter-network
+    weight gradients collected by hip.CfBwdBatch (msde_cfconv_pair_bwd_w_multi: one launch per `group` blocks inside a
+    parameter-gradient batch) equal the per-block launches' gradients (same kernels; the slab count per block differs, so the
+    sums agree to rounding) -- including a group that does not divide the number of blocks."""
+    from moleculesde_amd import hip, plan as P
+    torch.manual_seed(11)
+    b = _toy_graph(12, 40)
+    pl = P.plan_to(P.build_plan(b), dev)
+    N, G, cutoff = b.x.size(0), 51, 10.0
+    gs = R.GaussianSmearing(0.0, cutoff, G)
+    off = gs.offset.to(dev)
+    pp = hip.pair_plan(b.positions.to(dev), pl, cutoff)
+    nets = []
+    for _ in range(L):
+        blk = R.InteractionBlock(hidden_channels=64, num_gaussians=G, num_filters=128, cutoff=cutoff)
+        with torch.no_grad():
+            blk.mlp[0].bias.normal_(0, 0.1); blk.mlp[2].bias.normal_(0, 0.1)
+        nets.append([q.detach().to(dev) for q in (blk.mlp[0].weight, blk.mlp[0].bias, blk.mlp[2].weight, blk.mlp[2].bias)])
+    Wfs = hip.cfconv_pair_filters(pp, nets, off, gs.coeff, cutoff)
+    xs = [torch.randn(N, 128, device=dev) for _ in range(L)]
+    ws = [torch.randn(N, 128, device=dev) for _ in range(L)]
+    P2 = int(pp.count[0])
+    for l in range(L):
+        _, Wf1 = hip.cfconv_pair_forward(xs[l], pp, *nets[l], off, gs.coeff, cutoff)
+        assert torch.equal(Wfs[l][:P2], Wf1[:P2]), f"filter rows of block {l}"
+
+    def run(batched):
+        ps = [[q.clone().requires_grad_(True) for q in n] for n in nets]
+        x = [t.clone().requires_grad_(True) for t in xs]
+        bb = hip.CfBwdBatch(pp, off, gs.coeff, cutoff, L, group=group) if batched else None
+        outs = [hip.cfconv_pair(x[l], *ps[l], pp, off, gs.coeff, cutoff, Wf=Wfs[l] if batched else None, bwd_batch=bb)
+                for l in range(L)]
+        loss = sum((o * w).sum() for o, w in zip(outs, ws))
+        params = [q for n in ps for q in n]
+        if batched:
+            hip.begin_param_grad_batch(params)
+            try:
+                loss.backward()
+            finally:
+                hip.finish_param_grad_batch()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return outs, x, ps
+    o1, x1_, p1 = run(False)
+    o2, x2_, p2 = run(True)
+    for l in range(L):
+        assert torch.equal(o1[l], o2[l]), "aggregation on precomputed rows"
+        assert torch.equal(x1_[l].grad, x2_[l].grad), "input gradient"
+        for name, a, r in zip(("gW1", "gb1", "gW2", "gb2"), p2[l], p1[l]):
+            assert a.grad is not None and torch.isfinite(a.grad).all()
+            assert_close(a.grad, r.grad, 1e-4, 1e-5 * float(r.grad.abs().max()), f"block {l} {name} (batched launch)")
+
+
 def test_edge_geometry(dev):
     from moleculesde_amd import hip
     torch.manual_seed(6)

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import restate as R  # noqa: E402
-from helpers import assert_close, batch_from, disable_dropout, load_golden, sub  # noqa: E402
+from helpers import assert_close, batch_from, disable_dropout, load_golden, record_parity, sub  # noqa: E402
 
 TOY = dict(emb=16, filters=16, interactions=2, gaussians=51)
 
@@ -193,7 +193,9 @@ def test_bs256_forward_backward_vs_oracle(dev):
     Gradients: GIN's 10 ReLU+BatchNorm stages make a few gates flip under ANY fp32 re-association --
     the fp32 oracle itself differs from an fp64 run of the same oracle by ~8e-3 relative L2 on GIN
     gradients (measured in this test).  So gradients are judged against the fp64 oracle, and the HIP
-    path must be as accurate as the CPU fp32 path: err_hip <= max(3 x err_cpu32, 2e-3) per tensor."""
+    path is held to FIXED bars per model (round 6; before: max(3 x err_cpu32, 2e-3), which floated with the oracle's own
+    error): relative L2 against the fp64 oracle <= 6e-3 for GIN (measured 2.44e-3 on MI355X, the CPU fp32 oracle itself
+    2.25e-3: profiles/r06_parity_numbers.txt), <= 1e-4 for SchNet (measured 1.7e-6), <= 2e-3 for the 2D->3D model (3.1e-4)."""
     import copy
     import moleculesde_amd.geom3d as G
     from moleculesde_amd.synthetic import make_batch
@@ -233,11 +235,10 @@ def test_bs256_forward_backward_vs_oracle(dev):
                 den = max(den, 5e-2 * nmax)
             e_hip[n] = float((p.grad.double().cpu() - g64[n]).norm()) / den
             e_cpu[n] = float((g32[n].double() - g64[n]).norm()) / den
-        # which gates flip is erratic per tensor, so the yardstick is the model's worst CPU-fp32 tensor
-        bar = max(3.0 * max(e_cpu.values()), 2e-3)
+        bar = {"model_2D": 6e-3, "model_3D": 1e-4, "SDE_2Dto3D_model": 2e-3}[k]
         worst = max(e_hip, key=e_hip.get)
-        print(f"{k}: worst gradient rel-L2 vs fp64 oracle: hip {e_hip[worst]:.2e} ({worst}); "
-              f"cpu fp32 worst {max(e_cpu.values()):.2e}; bar {bar:.2e}")
+        record_parity(f"bs256 gradients, {k}: worst rel-L2 vs fp64 oracle: hip {e_hip[worst]:.2e} ({worst}); "
+                      f"cpu fp32 oracle worst {max(e_cpu.values()):.2e}; fixed bar {bar:.1e}")
         assert e_hip[worst] <= bar, f"{k}:{worst}: rel-L2 vs fp64 oracle {e_hip[worst]:.2e} > {bar:.2e}"
 
 
@@ -287,7 +288,8 @@ def test_loss_curve_vs_oracle(dev):
     got, ref, ref64 = np.array(got), np.array(ref), np.array(ref64)
     rel = np.abs(got - ref) / np.abs(ref)
     noise_floor = np.abs(ref - ref64) / np.abs(ref64)
-    print("loss curve rel err vs fp32 oracle:", rel.max(), " fp32-vs-fp64 oracle:", noise_floor.max())
+    record_parity("loss curve (10 Adam steps, bs 64, emb 300): rel err per step vs fp32 oracle " +
+                  " ".join("%.1e" % v for v in rel) + "; max %.2e; fp32-vs-fp64 oracle max %.2e" % (rel.max(), noise_floor.max()))
     assert rel[:3].max() <= 1e-3, rel                       # before the dynamics amplify rounding
     assert rel.max() <= max(1e-3, 3 * noise_floor.max()), (rel, noise_floor, got, ref)
 
