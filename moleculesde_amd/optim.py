@@ -70,6 +70,14 @@ class FlatAdam:
         for _ in range(self.EAGER_SLOTS):
             self.new_table_slot()
         self._slot, self._slot_i = self._slots[0], 0
+        # chunk-table rows of every param group (= data-parallel bucket): groups are laid out one after the other
+        self._bucket_chunk_rows, r, k = [], 0, 0
+        for end in seg_end:
+            r0 = r
+            while k < len(self.params) and self.offsets[k] < end:
+                r += self._chunks_per_param[k]
+                k += 1
+            self._bucket_chunk_rows.append((r0, r))
         self.seg_end = torch.tensor(seg_end, dtype=torch.int64, device=dev)
         self.seg_lr = torch.tensor(seg_lr, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -138,6 +146,36 @@ class FlatAdam:
         table, n = self._chunk_table()
         hip.gather_chunks(table, n, self.flat_g)
         return self.flat_g
+
+    def grad_table(self):
+        """The chunk table for the current .grad tensors (built and uploaded once per step): for gather_bucket()."""
+        return self._chunk_table()[0]
+
+    def gather_bucket(self, i, table):
+        """gather_grads() for bucket i (= param group i) only: its rows of `table` (grad_table()) into its range of the flat
+        gradient buffer -- the data-parallel tail flattens, reduces and applies bucket by bucket."""
+        r0, r1 = self._bucket_chunk_rows[i]
+        if r1 > r0:
+            hip.gather_chunks(table[r0:r1], r1 - r0, self.flat_g)
+
+    def grad_bucket_lookup(self):
+        """address -> bucket of the parameter whose .grad holds that address (None: no such parameter): how the batched
+        weight-gradient machinery learns which bucket a result belongs to (slabs.partition_param_grad_batch)."""
+        import bisect
+        iv = []
+        ends = [e for _, e in self.bucket_ranges]
+        for p, off in zip(self.params, self.offsets):
+            g = p.grad
+            if g is not None:
+                b = bisect.bisect_right(ends, off)
+                iv.append((g.data_ptr(), g.data_ptr() + 4 * g.numel(), b))
+        iv.sort()
+        starts = [t[0] for t in iv]
+
+        def look(addr):
+            i = bisect.bisect_right(starts, addr) - 1
+            return iv[i][2] if i >= 0 and addr < iv[i][1] else None
+        return look
 
     def step(self, grad_scale=1.0):
         """Adam on the flat gradient buffer: assumes gather_grads() (and, under DP, the all-reduce of

@@ -9,12 +9,13 @@ loss composition  CL*c1 + L_2Dto3D*c2 + 0.5(L_x + L_adj)*c3  (:135-152), same op
 """
 import argparse
 import os
+import sys
 import time
 
 import torch
 import torch.nn.functional as F
 
-from . import dp
+from . import dp, slabs
 from .geom3d import GNN, SchNet, SDEModel2Dto3D_01, SDEModel2Dto3D_02, prepare_batch
 from .geom3d import nn as _nn
 from .optim import FlatAdam
@@ -95,9 +96,20 @@ USE_FUSED_CL = True
 SPLIT_HEAD_ROOT = True          # the 3D->2D head's loss as a backward root of its own on the second stream (Trainer.losses)
 SIDE_CFCONV_FWD_WGS = 512     # SchNet's CFConv kernels beside the main chain: forward 128: 2.825 ... 512: 2.736, 1024: 2.750 ms
 SIDE_CFCONV_BWD_WGS = 176     # weight gradient 128: 2.768, 160: 2.757, 192: 2.755, 256 (full width): 2.783 ms
+SIDE_CFCONV_BWD_GROUP = 3     # SchNet alone on the second stream: its filter-weight gradients as two launches of three blocks
+                              # beside the GIN backward (2.476 vs 2.493 ms for one launch of six, 2.500 for six of one; with the
+                              # 3D->2D head behind SchNet the second stream is the long pole and ONE launch wins: 3.268 / 3.281 /
+                              # 3.318 / 3.430 ms for 6 / 3 / 2 / 1 blocks per launch -- profiles/r06_ab_cfconv_hoisted.txt)
 GEOMETRY_ON_SIDE = True       # coordinate-only branch of the 2D->3D model at the head of the second stream (2.86 vs 2.98 ms)
 EARLY_SLAB_REDUCE = True      # the second stream sums the CFConv slabs it wrote, in the shadow of the GIN backward
 PLAN_LISTS_ON_SIDE = True     # bucket mode: embedding row lists off the main chain
+# Data parallel: weight gradients, flattening and all-reduce bucket by bucket, so that a bucket's all-reduce travels behind the
+# next bucket's weight-gradient work (Trainer._dp_tail).  Built and parity-green (tests/test_gpu_dp.py runs it), OFF by default:
+# the per-bucket pieces cost the compute stream more than the collectives they hide -- 1-rank RCCL, one box, alternating:
+# 2.775 vs 2.573 ms per step (three grouped launches + three reductions + three flattening launches as graph pieces of their
+# own instead of one of each inside the step's graph, and the leaf kernels no longer run beside the grouped launch), against
+# an all-reduce of 14 MB that the ring estimate puts at ~0.2 ms on 8 GPUs (profiles/r06_dp_tail_overlap_ab.txt).
+DP_OVERLAP = False
 
 _SDE_RANGES_2D3D = {"VE": ("VE", 0.2, 1.0), "VP": ("VP", 0.2, 1.0), "VE02": ("VE", 0.1, 10.0), "VP02": ("VP", 0.2, 30.0),
                     "VE03": ("VE", 0.1, 1000.0), "VP03": ("VP", 0.2, 1000.0)}
@@ -238,6 +250,7 @@ class Trainer:
         self._graph_pool = None
         self._graph_loss = {}
         self._graph_wt_keys = {}
+        self._graph_tails = {}            # data-parallel overlap: the per-bucket tail graphs of a captured step
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=device)
 
     def _side_geometry(self, on):
@@ -246,6 +259,10 @@ class Trainer:
         from . import hip
         hip.CFCONV_FWD_WGS = SIDE_CFCONV_FWD_WGS if on else None
         hip.CFCONV_BWD_WGS = SIDE_CFCONV_BWD_WGS if on else None
+        if on:
+            self._bwd_group_was, hip.CFCONV_BWD_GROUP = hip.CFCONV_BWD_GROUP, min(hip.CFCONV_BWD_GROUP, SIDE_CFCONV_BWD_GROUP)
+        elif getattr(self, "_bwd_group_was", None) is not None:
+            hip.CFCONV_BWD_GROUP, self._bwd_group_was = self._bwd_group_was, None
 
     def _encode_3d(self, batch):
         """pretrain_MoleculeSDE.py:131-133: SchNet takes (z, pos, batch); PaiNN also the radius graph of the batch
@@ -411,8 +428,10 @@ class Trainer:
             return                     # already added by the loss composition's launch (losses(..., log=True))
         torch._foreach_add_([self.log[k] for k in keys], [parts[k].to(torch.float32) for k in keys])   # one launch
 
-    def _backward(self, loss):
-        """loss.backward() with the weight-gradient slab reductions of all layers batched into one launch."""
+    def _backward(self, loss, finish=True):
+        """loss.backward() with the weight-gradient slab reductions of all layers batched into one launch.  finish=False
+        (data-parallel tail, _dp_tail): the backward chains and the leaf kernels only -- the queued weight-gradient GEMMs and
+        the slab reduction are left to the caller, who runs them bucket by bucket (hip.partition_param_grad_batch ...)."""
         from . import hip
         try:
             roots = loss if isinstance(loss, tuple) else (loss,)
@@ -440,7 +459,8 @@ class Trainer:
                     side_.wait_stream(main_)
                     with torch.cuda.stream(side_):
                         hip.run_deferred_leaf_kernels()
-                    hip.flush_wgrad_gemms()
+                    if finish:
+                        hip.flush_wgrad_gemms()
                     main_.wait_stream(side_)
                 if hip.STAMPS is not None and self.overlap_streams:
                     with torch.cuda.stream(self._side_stream):
@@ -451,8 +471,9 @@ class Trainer:
                     # _total() and in the loss log -- ordered behind the second stream here, not by engine internals
                     torch.cuda.current_stream().wait_stream(self._side_stream)
             finally:
-                hip.finish_param_grad_batch()
-                hip.stamp("wgrad_end")
+                if finish or sys.exc_info()[0] is not None:
+                    hip.finish_param_grad_batch()
+                    hip.stamp("wgrad_end")
         finally:
             self._side_geometry(False)
 
@@ -493,6 +514,58 @@ class Trainer:
         ev.record()
         return ev
 
+    def _dp_order(self):
+        """Buckets (= models) in the order their gradients are finished and sent: largest message first, so that it has the
+        whole rest of the weight-gradient work to travel behind, smallest last (the one whose all-reduce nothing hides)."""
+        r = self.opt.bucket_ranges
+        return sorted(range(len(r)), key=lambda i: r[i][0] - r[i][1])
+
+    def _dp_finish_bucket(self, i, table):
+        """Bucket i's weight gradients (its problems of the grouped launch), their slab reduction, its rows of the flat
+        gradient buffer -- on the current stream; the bucket is then ready for its all-reduce."""
+        from . import hip
+        slabs.finish_param_grad_part(i)
+        self.opt.gather_bucket(i, table)
+
+    def _dp_tail(self, graphs=None):
+        """Data-parallel tail of a step (buckets overlapped with the backward work).  The step's weight gradients
+        are ONE grouped launch at the end of the backward pass; here that launch is cut by model (hip.partition_param_grad_
+        batch): bucket k's problems run, are summed and flattened, and its all-reduce is issued (RCCL's own stream) while
+        the compute stream goes on with bucket k + 1's problems; the Adam launches follow in the same order, each behind its
+        bucket's reduction.  Only the last (smallest) bucket's all-reduce has nothing to hide behind.  graphs: the captured
+        per-bucket pieces (replayed instead of launched)."""
+        from . import hip
+        order = self._dp_order()
+        ranges = self.opt.bucket_ranges
+        tm = self._tm_cur
+        works = []
+        if graphs is None:
+            slabs.partition_param_grad_batch(self.opt.grad_bucket_lookup(), len(ranges))
+            table = self.opt.grad_table()
+        for k, i in enumerate(order):
+            if graphs is None:
+                self._dp_finish_bucket(i, table)
+            else:
+                graphs[k].replay()
+            a, b = ranges[i]
+            _, w, scale = dp.allreduce_buckets_async(self.opt.flat_g, [(a, b)], order=[0])
+            works.append(w[0])
+        if graphs is None:
+            hip.finish_param_grad_batch()
+            hip.stamp("wgrad_end")
+        if tm is not None:
+            tm.append(self._timing_event())           # every bucket's work queued: end of the "graph" part
+        self.opt.begin_bucket_step()
+        for i, w in zip(order, works):
+            if w is not None:
+                w.wait()
+            if tm is not None:
+                tm.append(self._timing_event())
+            self.opt.step_bucket(i, grad_scale=1.0 / dp.world_size())
+            if tm is not None:
+                tm.append(self._timing_event())
+        self._refresh_weights()
+
     def _refresh_weights(self):
         """Right after an optimiser step: ONE launch re-transposes every weight the forward products read as [K][N]
         (hip.weight_t), so that no forward of the next step has to."""
@@ -510,9 +583,12 @@ class Trainer:
             self.step_counter.add_(1)     # the device step counter re-seeds dropout / negatives once a capture set it
             loss, parts = self.losses(batch, log=True, split_roots=True)
             self.opt.zero_grad()
-            self._backward(loss)
+            overlap = self._use_dp() and DP_OVERLAP and self.dp_buckets
+            self._backward(loss, finish=not overlap)
             loss = self._total(loss)
-            if self._use_dp():
+            if overlap:
+                self._dp_tail()
+            elif self._use_dp():
                 self.opt.gather_grads()
                 self._allreduce_and_adam()
             else:
@@ -523,18 +599,18 @@ class Trainer:
         return loss.detach(), parts
 
     # ---- hipGraph path ---------------------------------------------------------------------------
-    def _graph_body(self, batch, with_adam):
+    def _graph_body(self, batch, with_adam, finish=True):
         from . import hip as _hip
         _hip.stamp("step_start")
         self.step_counter.add_(1)
         loss, parts = self.losses(batch, log=True, split_roots=True)
         self.opt.zero_grad()
-        self._backward(loss)
+        self._backward(loss, finish=finish)
         loss = self._total(loss)
         if with_adam:
             self.opt.step_from_grads()
             self._refresh_weights()
-        else:
+        elif finish:
             self.opt.gather_grads()
         self._log_parts(parts)
         from . import hip as _hip
@@ -563,16 +639,35 @@ class Trainer:
         # thread_local: other threads of the process (the RCCL watchdog under DP) may issue HIP calls
         # while this thread captures; they must not invalidate the capture
         # (round 4: capturing on a high-priority stream -- main chain over the second stream -- changes nothing: 2.575 vs 2.582 ms)
+        overlap = (not with_adam) and self._use_dp() and DP_OVERLAP and self.dp_buckets
+        tail_graphs = None
         with _hip.no_gc(), self._bounds(batch), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             if pre is not None:
                 pre()
-            loss = self._graph_body(batch, with_adam)
+            loss = self._graph_body(batch, with_adam, finish=not overlap)
+        if overlap:
+            # the data-parallel tail as one more captured piece per bucket (weight gradients of the bucket, their slab
+            # reduction, its rows of the flat gradient buffer): step_graph() issues the bucket's all-reduce behind each piece
+            # (_dp_tail).  Same memory pool, replayed in capture order.
+            order = self._dp_order()
+            slabs.partition_param_grad_batch(self.opt.grad_bucket_lookup(), len(self.opt.bucket_ranges))
+            table = self.opt.grad_table()
+            tail_graphs = []
+            for k, i in enumerate(order):
+                gk = torch.cuda.CUDAGraph()
+                with _hip.no_gc(), self._bounds(batch), torch.cuda.graph(gk, pool=self._graph_pool, capture_error_mode="thread_local"):
+                    self._dp_finish_bucket(i, table)
+                    if k == len(order) - 1:
+                        _hip.finish_param_grad_batch()
+                        _hip.stamp("wgrad_end")
+                tail_graphs.append(gk)
         _hip.flush_table_uploads()      # the graph's pointer tables: uploaded once, not at every replay
         self.opt.use_eager_slot()
         _hip.use_eager_param_grad_slot()
         # the captured batch is held strongly: its tensors' addresses are baked into the graph, and a live reference
         # keeps id(batch) from being recycled for a different batch
         self._graphs[key] = (g, batch, with_adam)
+        self._graph_tails[key] = tail_graphs
         # the weight copies the captured refresh launch re-lays-out at every replay (hip.weight_copies_after_replay)
         self._graph_wt_keys[key] = getattr(self, "_last_refreshed", ()) if with_adam else None
         self._graph_loss[key] = loss
@@ -589,7 +684,8 @@ class Trainer:
             self._tm_cur = [self._timing_event()]
             self.dp_timing.append(self._tm_cur)
         g.replay()
-        if timing:
+        tails = self._graph_tails.get(id(batch))
+        if timing and tails is None:
             self._tm_cur.append(self._timing_event())
         if self._graph_wt_keys.get(id(batch)) is not None:
             _hip.weight_copies_after_replay(self._graph_wt_keys[id(batch)])
@@ -598,10 +694,15 @@ class Trainer:
         if not with_adam:
             if self._use_dp():
                 try:
-                    self._allreduce_and_adam()
+                    if tails is not None:
+                        self._dp_tail(graphs=tails)
+                    else:
+                        self._allreduce_and_adam()
                 finally:
                     self._tm_cur = None
             else:
+                for gk in tails or ():     # (captured under DP, replayed without it: the tail pieces still finish the gradients)
+                    gk.replay()
                 self.opt.step()
                 self._refresh_weights()
         self.steps += 1
@@ -750,6 +851,7 @@ class StreamRunner:
             # (the superseded graph is parked, not destroyed: freeing a graph of the shared memory pool while another capture
             # into that pool follows trips an allocator assertion in this torch build; it is a few hundred nodes)
             self._parked = getattr(self, "_parked", []) + [self.tr._graphs.pop(id(self.bk.batch), None)]
+            self._parked.append(self.tr._graph_tails.pop(id(self.bk.batch), None))
             self.tr._graph_loss.pop(id(self.bk.batch), None)
             self.tr._graph_wt_keys.pop(id(self.bk.batch), None)
             self.tr.capture(self.bk.batch, pre=lambda: self.bk.build_plan_on_device(

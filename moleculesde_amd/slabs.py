@@ -326,8 +326,48 @@ class _SlabBatch:
         finally:
             self.gemms = rest
 
+    def partition(self, bucket_of, nb):
+        """Data-parallel tail (pretrain.Trainer): cut what finish() would launch -- the queued weight-gradient
+        GEMMs and the slab rows still to be summed -- into `nb` parts by the gradient bucket (= model) their RESULT belongs
+        to, so that finish_part(b) can run bucket by bucket and bucket b's all-reduce travels while bucket b + 1's weight
+        gradients are computed.  bucket_of(address of a result) -> bucket or None (unknown: the last part).  Same kernels on the
+        same tiles and rows in another grouping: results are bit-identical to finish()."""
+        assert self.active and not self.leaf_more, "partitioned finish: no multi-contribution parameters (MD17 path)"
+        self.run_deferred()
+        rows, self.rows = self.rows, []
+        gemms, self.gemms = self.gemms, []
+        parts = [([], []) for _ in range(nb)]
+        where = []
+        for r in rows:
+            b = bucket_of(r[3])
+            b = nb - 1 if b is None else b
+            parts[b][1].append(r)
+            where.append((r[0], b))
+        where.sort()
+        import bisect
+        keys = [w[0] for w in where]
+        for t in gemms:
+            lo, hi = t[6].data_ptr(), t[6].data_ptr() + 4 * t[6].numel()
+            i = bisect.bisect_left(keys, lo)
+            b = where[i][1] if i < len(where) and where[i][0] < hi else nb - 1
+            parts[b][0].append(t)
+        self._parts = parts
+
+    def finish_part(self, b):
+        """One grouped launch + one slab reduction for part b of partition() (current stream)."""
+        gemms, rows = self._parts[b]
+        self._parts[b] = ([], [])
+        if rows:
+            self._select_slot(rows[0][4])
+        if gemms:
+            self.gemms = gemms
+            self.launch_gemms()
+        if rows:
+            self._reduce(rows)
+
     def finish(self):
         self.active = False
+        self._parts = None
         self.run_deferred()          # nobody ran them on another stream: here, before their slabs are summed
         rows = self.rows
         if not rows and not self.rotated:
@@ -444,6 +484,15 @@ def park_wgrad_gemms():
 def launch_wgrad_group(group, max_wgs=0):
     if group:
         _SLABS.launch_group(group, max_wgs)
+
+
+def partition_param_grad_batch(bucket_of, nb):
+    """See _SlabBatch.partition: then finish_param_grad_part(b) per bucket, finish_param_grad_batch() at the end."""
+    _SLABS.partition(bucket_of, nb)
+
+
+def finish_param_grad_part(b):
+    _SLABS.finish_part(b)
 
 
 def finish_param_grad_batch():

@@ -27,6 +27,8 @@ assert world == 2 and dist.get_backend() == "gloo"
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 FULL = len(sys.argv) > 2 and sys.argv[2] == "full"
+if len(sys.argv) > 2 and sys.argv[2] == "overlap":      # the bucket-wise tail (pretrain.DP_OVERLAP): off by default, kept green
+    pretrain.DP_OVERLAP = True
 args = pretrain.readme_args(SDE_coeff_generative_3Dto2D=1 if FULL else 0, emb_dim=64)
 
 

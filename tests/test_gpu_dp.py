@@ -12,12 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", ["configs1", "full"])
+@pytest.mark.parametrize("mode", ["configs1", "full", "overlap"])
 def test_trainer_step_two_ranks_one_gpu(mode):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541" if mode == "full" else "29540",
-           os.path.join(ROOT, "tests", "dp_gpu_worker.py"), ROOT] + (["full"] if mode == "full" else [])
+           "127.0.0.1", "--master-port", {"full": "29541", "overlap": "29542"}.get(mode, "29540"),
+           os.path.join(ROOT, "tests", "dp_gpu_worker.py"), ROOT] + ([mode] if mode != "configs1" else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
     assert r.stdout.count("RANK0DONE") == 1 and r.stdout.count("RANK1DONE") == 1, r.stdout[-2000:]

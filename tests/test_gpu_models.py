@@ -243,10 +243,13 @@ def test_bs256_forward_backward_vs_oracle(dev):
 
 
 def test_loss_curve_vs_oracle(dev):
-    """10 Adam steps (README learning rates) at bs 64 with replayed noise, product Trainer (flat HIP
-    Adam) vs oracle torch.optim.Adam: loss curve within 1e-3 relative (BASELINE.json target).  Training
-    dynamics amplify rounding, so the bar is max(1e-3, 3 x the fp32 oracle's own distance to an fp64
-    run of the same oracle)."""
+    """10 Adam steps (README learning rates) at bs 64, emb 300 with replayed noise, product Trainer (flat HIP Adam) vs
+    oracle torch.optim.Adam.  FIXED bars (round 6; before: max(1e-3, 3 x the oracle's own fp32-vs-fp64 distance), which
+    floated): the first three steps within 1e-3 relative (BASELINE.json's target; measured 3.5e-7 / 1.1e-4 / 1.5e-4), the
+    first five within 2e-3 (8.1e-4), all ten within 2e-2 (8.8e-3).  A flat 1e-3 over ten steps does NOT hold at this size and
+    is not a property of the kernels: the training dynamics amplify rounding, and the fp32 CPU oracle itself ends 5.3e-3 away
+    from an fp64 run of the same oracle (profiles/r06_parity_numbers.txt).  The reference-generated 20-step curve (bs 8,
+    tests/golden/losscurve.npz) IS held to a flat 1e-3: test_golden_losscurve_through_hip_trainer."""
     import copy
     import moleculesde_amd.geom3d as G
     from moleculesde_amd.synthetic import make_batch
@@ -291,7 +294,8 @@ def test_loss_curve_vs_oracle(dev):
     record_parity("loss curve (10 Adam steps, bs 64, emb 300): rel err per step vs fp32 oracle " +
                   " ".join("%.1e" % v for v in rel) + "; max %.2e; fp32-vs-fp64 oracle max %.2e" % (rel.max(), noise_floor.max()))
     assert rel[:3].max() <= 1e-3, rel                       # before the dynamics amplify rounding
-    assert rel.max() <= max(1e-3, 3 * noise_floor.max()), (rel, noise_floor, got, ref)
+    assert rel[:5].max() <= 2e-3, rel
+    assert rel.max() <= 2e-2, (rel, noise_floor, got, ref)
 
 
 # ------------------------------------------------------------------ properties at full size ------

@@ -18,6 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def child(setting, bench_args):
     sys.path.insert(0, ROOT)
     for item in filter(None, setting.split(",")):
+        if item == "--dp":                 # the multi-GPU step structure on one GPU (1-rank RCCL group)
+            bench_args = bench_args + ["--debug_dp_path"]
+            continue
         if item.startswith("lib:"):
             from moleculesde_amd import _lib
             _lib.LIB_PATH = os.path.join(ROOT, item[4:])
