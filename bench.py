@@ -106,6 +106,7 @@ def in_step_stamps(trainer, batch, dev, graph_replays=25):
         trainer.step(b2_)
         trainer.capture(b2_)
         pairs = {"cf_agg": ("cf_agg_start", "cf_agg_end"), "tail": ("bwd_main_end", "step_end"), "tail_both": ("bwd_side_end", "step_end"),
+                 "tail_chain": ("bwd_side_chain_end", "step_end"),
                  "step": ("step_start", "step_end")}
         for k in range(8):        # the GIN layers' second product: one pair of stamps per layer
             pairs["gin_gemm2#%d" % k] = ("gin_gemm2_start#%d" % k, "gin_gemm2_end#%d" % k)
@@ -1206,9 +1207,12 @@ def main():
             "tail_us_what": "end of the backward chain of the main stream -> end of Adam and of the weight-copy refresh, device "
                             "stamps inside the captured per-shape step (grouped weight gradients, slab reduction, Adam)",
             "tail_after_both_streams_us": None if in_step.get("tail_both") is None else round(in_step["tail_both"], 1),
-            "tail_after_both_streams_what": "end of the backward chain of the SECOND stream (SchNet; the longer one: the grouped "
-                                            "weight-gradient launch runs beside its last third) -> end of Adam and of the weight-copy "
-                                            "refresh: what is left serial behind both chains",
+            "tail_after_both_streams_what": "end of the SECOND stream's work of the backward pass INCLUDING its deferred leaf kernels "
+                                            "(embedding / bond-table gradients, which run beside the grouped weight-gradient launch) -> "
+                                            "end of Adam and of the weight-copy refresh",
+            "tail_after_side_chain_us": None if in_step.get("tail_chain") is None else round(in_step["tail_chain"], 1),
+            "tail_after_side_chain_what": "end of the second stream's backward CHAIN (SchNet's backward, before its leaf kernels) -> "
+                                          "end of the step: with tail_us, how serial the grouped launch + reduction + Adam are",
             "step_us_device_stamps": None if in_step.get("step") is None else round(in_step["step"], 1),
             "kernels_per_step": n_kern, "kernels_per_step_not_from_libmsde_hip": n_foreign,
             "roofline": roof,

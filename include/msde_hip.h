@@ -887,6 +887,9 @@ int msde_adam_flat(float* p, const float* g, float* m, float* v, long long n, co
  * straddle tensors.  msde_gather_chunks copies the gradients into the flat buffer (the message of the
  * data-parallel all-reduce); msde_adam_chunks is msde_adam_flat reading the gradients through the table. */
 int msde_chunk_elems(void);
+/* step_counter[0] += 1 (int64: seeds of the in-kernel noise / dropout masks of a replayed step) and optimiser_step[0] += 1
+ * (int32: the `step` of torch.optim.Adam, pretrain_MoleculeSDE.py:156) in one launch; either pointer may be NULL. */
+int msde_step_counters(long long* step_counter, int* optimiser_step, void* stream);
 int msde_gather_chunks(const long long* table, int n_chunks, float* flat, void* stream);
 int msde_adam_chunks(float* p, const long long* table, int n_chunks, float* m, float* v,
                      const int* step_dev, const long long* seg_end, const float* seg_lr, int S,

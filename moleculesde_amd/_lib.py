@@ -78,6 +78,7 @@ SIGNATURES = {
     "msde_linear_bwd_w_describe_ld": [P, I, P, I, I, I, I, I, P, P, P],
     "msde_linear_bwd_w_grouped": [P, P, I, I, P],
     "msde_linear_bwd_w_grouped_ex": [P, P, I, I, I, P],
+    "msde_step_counters": [P, P, P],
     "msde_linear_bwd_w_partial": [P, P, I, I, I, I, P, P, P],
     "msde_reduce_slabs_multi": [P, P, I, I, P],
     "msde_reduce_slabs_chunks": [LL, I],

@@ -116,6 +116,20 @@ adam_chunks_kernel(float* __restrict__ p, const long long* __restrict__ table, f
 
 extern "C" int msde_chunk_elems(void) { return MSDE_CHUNK; }
 
+// both device-side counters of a training step -- the step counter that re-seeds the in-kernel noise / dropout masks and the
+// optimiser's step count -- advanced by ONE one-thread launch at the head of the step (they were two elementwise-add launches of
+// the tensor library, the second one in the serial tail between the slab reduction and Adam)
+__global__ void step_counters_kernel(long long* __restrict__ a, int* __restrict__ b) {
+  if (a) a[0] += 1;
+  if (b) b[0] += 1;
+}
+extern "C" int msde_step_counters(long long* step_counter, int* optimiser_step, void* stream) {
+  if (!step_counter && !optimiser_step) return 0;
+  MSDE_LAUNCH(step_counters_kernel, dim3(1), dim3(1), 0, as_stream(stream), step_counter, optimiser_step);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int msde_gather_chunks(const long long* table, int n_chunks, float* flat, void* stream) {
   if (n_chunks < 0 || !table || !flat) return MSDE_EINVAL;
   if (n_chunks == 0) return 0;

@@ -200,10 +200,12 @@ class FlatAdam:
         hip.adam_flat(self.flat_p[a:b], self.flat_g[a:b], self.m[a:b], self.v[a:b], self.step_dev, seg_end, seg_lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)
 
-    def step_from_grads(self, grad_scale=1.0):
-        """Single-GPU step: Adam reads each parameter's .grad in place through the chunk table (no flattening)."""
+    def step_from_grads(self, grad_scale=1.0, bump=True):
+        """Single-GPU step: Adam reads each parameter's .grad in place through the chunk table (no flattening).  bump=False:
+        the caller already advanced step_dev for this step (pretrain.Trainer: with its own counter, at the head of the step)."""
         table, n = self._chunk_table()
-        self.step_dev.add_(1)
+        if bump:
+            self.step_dev.add_(1)
         hip.bump_weight_epoch()
         hip.adam_chunks(self.flat_p, table, n, self.m, self.v, self.step_dev, self.seg_end, self.seg_lr,
                         self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)

@@ -95,7 +95,8 @@ USE_FUSED_CL = True
 # behind GIN, a third stream for the coordinate branch, leaf kernels in front of the grouped launch.
 SPLIT_HEAD_ROOT = True          # the 3D->2D head's loss as a backward root of its own on the second stream (Trainer.losses)
 SIDE_CFCONV_FWD_WGS = 512     # SchNet's CFConv kernels beside the main chain: forward 128: 2.825 ... 512: 2.736, 1024: 2.750 ms
-SIDE_CFCONV_BWD_WGS = 176     # weight gradient 128: 2.768, 160: 2.757, 192: 2.755, 256 (full width): 2.783 ms
+SIDE_CFCONV_BWD_WGS = 224     # weight gradient (round 4, a launch per block) 128: 2.768, 160: 2.757, 192: 2.755, 256: 2.783 ms; round 6 (launches of
+                              # three blocks) 160: 2.473, 176: 2.476, 192: 2.471, 224: 2.469 ms -- flat within 0.3 %
 SIDE_CFCONV_BWD_GROUP = 3     # SchNet alone on the second stream: its filter-weight gradients as two launches of three blocks
                               # beside the GIN backward (2.476 vs 2.493 ms for one launch of six, 2.500 for six of one; with the
                               # 3D->2D head behind SchNet the second stream is the long pole and ONE launch wins: 3.268 / 3.281 /
@@ -444,6 +445,9 @@ class Trainer:
                 else:        # (main root, head root on the second stream): one pass of the engine over both
                     torch.autograd.backward(list(roots), [one] * len(roots))
                 hip.stamp("bwd_main_end")
+                if hip.STAMPS is not None and self.overlap_streams:
+                    with torch.cuda.stream(self._side_stream):
+                        hip.stamp("bwd_side_chain_end")     # the second stream's backward CHAIN (bwd_side_end: + its leaf kernels)
                 if self.overlap_streams and EARLY_SLAB_REDUCE:
                     # the second stream finished its backward (SchNet) long before the main chain (GIN): it sums the
                     # CFConv filter-gradient slabs (6 x 256 slabs, ~125 MB) it wrote, in the shadow of the GIN backward
@@ -580,10 +584,11 @@ class Trainer:
 
     def step(self, batch):
         with self._bounds(batch):         # (kernels reducing over rows stop at the bucket's valid rows)
-            self.step_counter.add_(1)     # the device step counter re-seeds dropout / negatives once a capture set it
+            overlap = self._use_dp() and DP_OVERLAP and self.dp_buckets
+            single = not self._use_dp()
+            self._bump_counters(single)   # the device step counter re-seeds dropout / negatives once a capture set it
             loss, parts = self.losses(batch, log=True, split_roots=True)
             self.opt.zero_grad()
-            overlap = self._use_dp() and DP_OVERLAP and self.dp_buckets
             self._backward(loss, finish=not overlap)
             loss = self._total(loss)
             if overlap:
@@ -592,23 +597,35 @@ class Trainer:
                 self.opt.gather_grads()
                 self._allreduce_and_adam()
             else:
-                self.opt.step_from_grads()
+                self.opt.step_from_grads(bump=False)
                 self._refresh_weights()
             self._log_parts(parts)
         self.steps += 1
         return loss.detach(), parts
 
+    def _bump_counters(self, with_optimiser):
+        """step_counter += 1 (and the optimiser's step count when this step applies Adam through step_from_grads) in one
+        launch at the head of the step instead of one elementwise add here and one in the serial tail in front of Adam."""
+        from . import _lib, hip as _hip
+        if self.step_counter.is_cuda:
+            _lib.call("msde_step_counters", _hip._p(self.step_counter), _hip._p(self.opt.step_dev if with_optimiser else None),
+                      _hip._stream())
+        else:
+            self.step_counter.add_(1)
+            if with_optimiser:
+                self.opt.step_dev.add_(1)
+
     # ---- hipGraph path ---------------------------------------------------------------------------
     def _graph_body(self, batch, with_adam, finish=True):
         from . import hip as _hip
         _hip.stamp("step_start")
-        self.step_counter.add_(1)
+        self._bump_counters(with_adam)
         loss, parts = self.losses(batch, log=True, split_roots=True)
         self.opt.zero_grad()
         self._backward(loss, finish=finish)
         loss = self._total(loss)
         if with_adam:
-            self.opt.step_from_grads()
+            self.opt.step_from_grads(bump=False)
             self._refresh_weights()
         elif finish:
             self.opt.gather_grads()
