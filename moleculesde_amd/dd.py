@@ -16,7 +16,7 @@ Third derivatives (the backward of an order-2 pointwise op) are not needed by a 
 """
 import torch
 
-from . import _lib, hip
+from . import _lib, hip, slabs
 
 _p, _f32, _stream = hip._p, hip._f32, hip._stream
 
@@ -466,14 +466,14 @@ class _Linear(torch.autograd.Function):
         if ni[1] and not torch.is_grad_enabled():
             # the LAST differentiation (nothing will differentiate this backward again): weight and bias gradient from the
             # split-M kernel instead of mm_tn + colsum (two members of the closed set, two to three launches) -- queued for
-            # the step's ONE grouped launch when the trainer has a parameter-gradient batch open (hip.weight_grad_leaf).
+            # the step's ONE grouped launch when the trainer has a parameter-gradient batch open (slabs.weight_grad_leaf).
             # EVERY contribution to one leaf W must take this path (the force path's _MMnn / _MMnt do): a deferred buffer is
             # filled only at finish_param_grad_batch(), so an immediate mm_tn result added to it by AccumulateGrad would be
             # summed with unfilled memory.  A frozen or non-leaf bias only drops the BIAS half of the deferred problem.
             g2 = _f32(g)
             CALLS["msde_linear_bwd_w"] = CALLS.get("msde_linear_bwd_w", 0) + 1
             fused_bias = ctx.has_bias and ni[2] and ctx.b_key is not None
-            gW, gb = hip.weight_grad_leaf(g2, x, fused_bias, W, ctx.b_key if fused_bias else None)
+            gW, gb = slabs.weight_grad_leaf(g2, x, fused_bias, W, ctx.b_key if fused_bias else None)
             if ctx.has_bias and ni[2] and not fused_bias:
                 gb = colsum(g)              # a bias that is not a leaf parameter: its gradient flows on, formed right here
             return (mm_nn(g, W) if ni[0] else None), gW, gb
@@ -503,7 +503,7 @@ class _MMnn(torch.autograd.Function):
         if ni[1] and not torch.is_grad_enabled() and W.is_leaf:
             # last differentiation, W a parameter: its second contribution (the force path) joins the grouped launch
             CALLS["msde_linear_bwd_w"] = CALLS.get("msde_linear_bwd_w", 0) + 1
-            return (mm_nt(u, W) if ni[0] else None), hip.weight_grad_leaf(g, _f32(u), False, W)[0]
+            return (mm_nt(u, W) if ni[0] else None), slabs.weight_grad_leaf(g, _f32(u), False, W)[0]
         return (mm_nt(u, W) if ni[0] else None), (mm_tn(g, u) if ni[1] else None)
 
 
@@ -525,7 +525,7 @@ class _MMnt(torch.autograd.Function):
         ni = ctx.needs_input_grad
         if ni[1] and PARAM_GRADS and not torch.is_grad_enabled() and W.is_leaf:
             CALLS["msde_linear_bwd_w"] = CALLS.get("msde_linear_bwd_w", 0) + 1
-            return (mm_nn(u, W) if ni[0] else None), hip.weight_grad_leaf(_f32(u), x, False, W)[0]
+            return (mm_nn(u, W) if ni[0] else None), slabs.weight_grad_leaf(_f32(u), x, False, W)[0]
         return (mm_nn(u, W) if ni[0] else None), (mm_tn(u, x) if ni[1] and PARAM_GRADS else None)
 
 
@@ -542,7 +542,7 @@ class _MMtn(torch.autograd.Function):
         K = x.size(1)
         assert x.size(0) == M
         y = _new(N, K, like=g)
-        ws = hip._wgrad_workspace(M, N, K, g.device)
+        ws = slabs._wgrad_workspace(M, N, K, g.device)
         _call("msde_linear_bwd_w", _p(g), _p(x), M, N, K, _p(y), _p(None), _p(ws), _p(hip.bound_tensor(M)), _stream())
         ctx.save_for_backward(g, x)
         return y
@@ -563,7 +563,7 @@ class _ColSum(torch.autograd.Function):
         g = _f32(g)
         ctx.M = g.size(0)
         CALLS["msde_colsum"] = CALLS.get("msde_colsum", 0) + 1
-        return hip.colsum(g)
+        return slabs.colsum(g)
 
     @staticmethod
     def backward(ctx, u):

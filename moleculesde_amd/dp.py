@@ -9,6 +9,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import wcache
+
 
 FORCE_COLLECTIVES = False    # debug: run the collectives even at world size 1 (exercises RCCL on one GPU)
 
@@ -45,8 +47,7 @@ def broadcast_flat(flat, src=0):
     if world_size() > 1 or (FORCE_COLLECTIVES and dist.is_initialized()):
         dist.broadcast(flat, src=src)
         if flat.is_cuda:                  # parameters rewritten behind autograd's and the optimiser's back
-            from . import hip
-            hip.invalidate_weight_copies()
+            wcache.invalidate_weight_copies()
     return flat
 
 

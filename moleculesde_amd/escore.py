@@ -9,7 +9,7 @@ import ctypes
 
 import torch
 
-from . import _lib, hip
+from . import _lib, hip, slabs
 
 NMAX = 32                 # ES_NMAX of csrc/escore_mol.hip
 
@@ -148,7 +148,7 @@ def _grad_views(gall):
 class _EScoreMol(torch.autograd.Function):
     """EquivariantScoreNetwork.forward as ONE autograd node: msde_escore_mol_fwd / msde_escore_mol_bwd, one workgroup per
     molecule each way.  Weight gradients leave the backward kernel as one slab per molecule and are summed by the batched slab
-    reduction of the step (hip._SLABS) or, outside a batch, right here."""
+    reduction of the step (slabs._SLABS) or, outside a batch, right here."""
 
     @staticmethod
     def forward(ctx, node_attr, edge_attr, basis, net, ep, pl, seed0, seed_dev, *params):
@@ -182,14 +182,14 @@ class _EScoreMol(torch.autograd.Function):
         g_x0 = torch.empty(N, 32, dtype=torch.float32, device=dev)
         g_ea = torch.empty(E, 32, dtype=torch.float32, device=dev)
         gall = torch.empty(nslab, dtype=torch.float32, device=dev)
-        defer = hip._SLABS.active and ctx.deferrable
-        ws = hip._SLABS.alloc(B * nslab, dev) if defer else torch.empty(B * nslab, dtype=torch.float32, device=dev)
+        defer = slabs._SLABS.active and ctx.deferrable
+        ws = slabs._SLABS.alloc(B * nslab, dev) if defer else torch.empty(B * nslab, dtype=torch.float32, device=dev)
         _lib.call("msde_escore_mol_bwd", hip._p(tab), hip._p(x0), hip._p(ea), ea.stride(0), hip._p(basis), hip._p(pl.mol_ptr), B,
                   hip._p(ep.rowptr), hip._p(ep.src), hip._p(ep.dst), hip._p(ep.rowptr_s), hip._p(ep.perm_s), N, E, 32, 8, 128,
                   int(pl.N_max), p_att, p_ffn, seed0, hip._p(seed_dev), eps1, eps2, hip._p(sv), hip._p(g), hip._p(g_x0), hip._p(g_ea), 32,
                   hip._p(ws), hip._stream())
         if defer:
-            hip._SLABS.add(ws.data_ptr(), B, nslab, gall, written=True)
+            slabs._SLABS.add(ws.data_ptr(), B, nslab, gall, written=True)
         else:
             torch.sum(ws.view(B, nslab), dim=0, out=gall)
         return (g_x0, g_ea, None, None, None, None, None, None) + tuple(_grad_views(gall))

@@ -16,7 +16,7 @@ moleculesde_amd/dd.py (SchNet._forward_force_path, PaiNN.forward); there is no h
 """
 import torch
 
-from . import _lib, dd, hip
+from . import _lib, dd, hip, slabs, wcache
 from .optim import FlatAdam
 
 
@@ -81,14 +81,14 @@ class ForceTrainer:
         loss = loss[0]
         self.opt.zero_grad()
         # the weight gradients of the whole step (two contributions per Linear: energy path and force path) as ONE grouped
-        # launch + ONE slab reduction behind the backward pass (hip.weight_grad_leaf) instead of ~170 per-layer launches
-        hip.begin_param_grad_batch(self.opt.params)
+        # launch + ONE slab reduction behind the backward pass (slabs.weight_grad_leaf) instead of ~170 per-layer launches
+        slabs.begin_param_grad_batch(self.opt.params)
         try:
             torch.autograd.backward([energy, dE], [g_e, g_d])
         finally:
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
         self.opt.step_from_grads()
-        self._refreshed = hip.refresh_weight_t()    # re-laid-out weight copies (if a layer reads one) follow the update
+        self._refreshed = wcache.refresh_weight_t()    # re-laid-out weight copies (if a layer reads one) follow the update
         return loss.detach()
 
     def step(self, batch, y=None, force=None):
@@ -111,14 +111,14 @@ class ForceTrainer:
         for _ in range(eager_steps):
             self._body(batch, self._pos, self._y, self._f)
         self.opt.new_table_slot()
-        hip.new_param_grad_slot(self.device)
+        slabs.new_param_grad_slot(self.device)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with hip.no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with slabs.no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._loss = self._body(batch, self._pos, self._y, self._f)
-        hip.flush_table_uploads()
+        slabs.flush_table_uploads()
         self.opt.use_eager_slot()
-        hip.use_eager_param_grad_slot()
+        slabs.use_eager_param_grad_slot()
         self._graph = g
         self._graph_wt_keys = self._refreshed          # the copies the captured refresh launch re-lays-out at every replay
         return g
@@ -129,7 +129,7 @@ class ForceTrainer:
         self._pos.copy_(positions, non_blocking=True)
         self._y.copy_(y.view(-1), non_blocking=True)
         self._f.copy_(force, non_blocking=True)
-        hip.sync_weight_copies()           # parameters edited from outside since the last step (load_state_dict, ...)
+        wcache.sync_weight_copies()           # parameters edited from outside since the last step (load_state_dict, ...)
         self._graph.replay()
-        hip.weight_copies_after_replay(self._graph_wt_keys)
+        wcache.weight_copies_after_replay(self._graph_wt_keys)
         return self._loss

@@ -18,7 +18,7 @@ import types
 
 import torch
 
-from .. import _lib, hip
+from .. import _lib, hip, slabs, wcache
 
 AC_LD, XP_LD = 32, 120
 _p = hip._p
@@ -151,7 +151,7 @@ def edge_backward(cfg, sv, AC, flags, chans, offs, T, gS, gZG2, gx0, gx0_accumul
     L = len(chans)
     f = T[16 * L:]
     G = [None] * len(T)
-    wg = hip.weight_grad
+    wg = slabs.weight_grad
     G[16 * L + 4], G[16 * L + 5] = wg(gS.view(P, 1), sv.G2, True)
     G[16 * L + 2], G[16 * L + 3] = wg(gZG2, sv.G1, True)
     gZG1 = _empty(P, sv.ZG1.size(1), device=dev)
@@ -186,7 +186,7 @@ def edge_backward(cfg, sv, AC, flags, chans, offs, T, gS, gZG2, gx0, gx0_accumul
         if node:
             G[b + 14], G[b + 15] = wg(GY, s.Hmc, True)
             G[b + 12], G[b + 13] = wg(GHm, s.xcat, True)
-            G[b + 5] = hip.colsum_leaf(GV)
+            G[b + 5] = slabs.colsum_leaf(GV)
             gWv = _empty(C * F, 16, device=dev)
             for c in range(C):          # x W_c with W_c stored [in, out]: gW_c = x^T g(xW_c)
                 wg(s.x, gXV[:, 16 * c:16 * c + 16], False, out_w=gWv[c * F:(c + 1) * F])
@@ -248,8 +248,8 @@ def node_mlp_forward(XC, W1, b1, W2, b2, W3, b3, Z1, F1, Z2, F2, OUT):
     hip.gemm_ex(XC, W1, F1, bias=b1, act="silu", Z=Z1)
     hip.gemm_fwd(F1, W2, F2, bias=b2, act="silu", Z=Z2)
     if _rs_ok(M, W3, b3) and w2 % 4 == 0 and nout <= XP_LD:
-        Wt = hip.weight_layout("dense_node_out_t", (W3,), (w2, XP_LD), [(W3, 0, 0, nout, w2, 0, 0, True)])
-        bp = hip.weight_layout("dense_node_out_b", (b3,), (XP_LD,), [(b3, 0, 0, 1, nout, 0, 0, False)])
+        Wt = wcache.weight_layout("dense_node_out_t", (W3,), (w2, XP_LD), [(W3, 0, 0, nout, w2, 0, 0, True)])
+        bp = wcache.weight_layout("dense_node_out_b", (b3,), (XP_LD,), [(b3, 0, 0, 1, nout, 0, 0, False)])
         hip.gemm_rs(F2, Wt, OUT, bias=bp, b_kmajor=True, N=XP_LD, K=w2, fallback=False)
     else:
         hip.gemm_ex(F2, W3, OUT[:, :nout], bias=b3)
@@ -260,14 +260,14 @@ def node_backward(cfg, sv, XC, F, AC, T, gOUT):
     first F columns are the gradient of x)."""
     dev, N, B = XC.device, cfg.N, cfg.B
     G = [None] * len(T)
-    wg = hip.weight_grad
+    wg = slabs.weight_grad
     nout = sv.nout
     go = gOUT[:, :nout]
     G[7], G[8] = wg(go, sv.F2, True)
     gZ2 = _empty(N, sv.Z2.size(1), device=dev)
     if _rs_ok(N, T[7]) and sv.Z2.size(1) % 4 == 0 and gOUT.size(1) == XP_LD and nout <= XP_LD:
         # K = 119 -> 120: the gradient's padding column is zero (dense_loss_bwd writes it), the weight's padding row too
-        Wp = hip.weight_layout("dense_node_out_pad", (T[7],), (XP_LD, T[7].size(1)), [(T[7], 0, 0, nout, T[7].size(1), 0, 0, False)])
+        Wp = wcache.weight_layout("dense_node_out_pad", (T[7],), (XP_LD, T[7].size(1)), [(T[7], 0, 0, nout, T[7].size(1), 0, 0, False)])
         hip.gemm_rs(gOUT, Wp, gZ2, b_kmajor=True, N=T[7].size(1), K=XP_LD, act="silu", dact_from=sv.Z2, fallback=False)
     else:
         hip.gemm_ex(go, T[7], gZ2, b_kmajor=True, act="silu", dact_from=sv.Z2)
@@ -282,7 +282,7 @@ def node_backward(cfg, sv, XC, F, AC, T, gOUT):
     _lib.call("msde_dense_node_gcn_bwd", ctypes.c_void_p(gXC.data_ptr() + 4 * F), gXC.stride(0),
               ctypes.c_void_p(XC.data_ptr() + 4 * F), ld, _p(AC), _p(cfg.mol_ptr), _p(cfg.pair_ptr), _p(T[1]), B, cfg.n_max,
               _p(GP), _p(MM), hip._stream())
-    G[2] = hip.colsum_leaf(GP)
+    G[2] = slabs.colsum_leaf(GP)
     gWl = _empty(48, 16, device=dev)
     for l in range(1, 4):       # W_l stored [in, out]: gW_l = x_l^T (An^T g_pre_l)
         wg(XC[:, F + 16 * (l - 1):F + 16 * l], MM[:, 16 * l:16 * l + 16], False, out_w=gWl[16 * (l - 1):16 * l])
@@ -364,8 +364,8 @@ class _DenseHeadLosses(torch.autograd.Function):
         GE, _ = edge_backward(cfg, se, AC, flags, cfg.chans, cfg.offs, TE, gS, gZG2, gXC[:, :FX], True)
         gX = gXC[:, :F]                                   # gradient of embedding_3D's output
         gXx = gXC[:, F:FX] if concat else gX              # ... of embedding_X's (the same tensor when they were added)
-        gW3, gb3 = hip.weight_grad(gX, h3, True)
-        gWX, gbX = hip.weight_grad(gXx, px[:, :cfg.ncls], True)
+        gW3, gb3 = slabs.weight_grad(gX, h3, True)
+        gWX, gbX = slabs.weight_grad(gXx, px[:, :cfg.ncls], True)
         g_h3 = None
         if ctx.needs_input_grad[1]:
             g_h3 = _empty(N, F, device=dev)

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import escore as _escore, hip, plan as _plan
+from .. import escore as _escore, hip, plan as _plan, wcache
 from . import nn as _nn
 from .sde import VESDE, VPSDE
 
@@ -294,7 +294,7 @@ class SDEModel2Dto3D_02(nn.Module):
         is computed once per (representation, graph, parameter epoch) and reused -- ~12 launches less per score call, and none
         of them inside a captured iteration."""
         key = (node_2D_repr.data_ptr(), node_2D_repr._version, tuple(node_2D_repr.shape), id(ep), ep.E, ep.N, ep.src.data_ptr(),
-               hip.weight_epoch(),
+               wcache.weight_epoch(),
                tuple(t._version for m in (self.edge_2D_emb, self.node_emb) for t in list(m.parameters()) + list(m.buffers())))
         hit = getattr(self, "_static_cache", None)
         # the entry PINS the representation and the plan it was computed from and is matched by identity: addresses and

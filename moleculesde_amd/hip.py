@@ -1227,13 +1227,9 @@ def segment_reduce(x, mol_ptr, batch_i32, mean=True):
 # ------------------------------------------------------------------------------------------------
 # dense layers
 # ------------------------------------------------------------------------------------------------
-# (capture lifetime, workspaces, batched weight gradients / slab reduction: moleculesde_amd/slabs.py -- re-exported here)
-from .slabs import (_WS, _WS_BYTES, _KEEP_ALIVE, note_capture, no_gc, _retire, _SCRATCH, EMB_BWD_SPLIT, _scratch, _ws_key,  # noqa: F401,E402
-                    _wgrad_workspace, _PENDING_UPLOADS, upload_table, flush_table_uploads, _SlabBatch, _SLABS, _SPLITS,
-                    begin_param_grad_batch, flush_wgrad_gemms, reduce_written_slabs, run_deferred_leaf_kernels,
-                    have_deferred_leaf_kernels, park_wgrad_gemms, launch_wgrad_group, finish_param_grad_batch,
-                    new_param_grad_slot, use_eager_param_grad_slot, _row_stride, weight_grad, weight_grad_leaf, colsum, colsum_leaf,
-                    weight_grad_blocks, WGRAD_HIP_MIN_ROWS)
+# (capture lifetime, workspaces, batched weight gradients / slab reduction: moleculesde_amd/slabs.py; what this module uses of it)
+from .slabs import (_retire, EMB_BWD_SPLIT, _scratch, _ws_key, _SlabBatch, _SLABS, run_deferred_leaf_kernels, _row_stride,  # noqa: E402
+                    weight_grad, weight_grad_blocks)
 
 
 
@@ -1919,10 +1915,8 @@ def gemm_ex(A, B, out, bias=None, A2=None, B2=None, act=None, act_cols=None, Z=N
 # ------------------------------------------------------------------------------------------------
 # row-strip GEMM family (csrc/gemm_rs.hip): the plain nn.Linear products and the BatchNorm fused around them
 # ------------------------------------------------------------------------------------------------
-# (re-laid-out weight copies: moleculesde_amd/wcache.py -- re-exported here)
-from .wcache import (_WT, _WT_TABLE, weight_epoch, bump_weight_epoch, _transpose_into, _fill_entry, _clear_tables, _drop_entry,  # noqa: F401,E402
-                     _cached_layout, weight_t, weight_layout, refresh_weight_t, weight_copies_after_replay, invalidate_weight_copies,
-                     sync_weight_copies)
+# (re-laid-out weight copies: moleculesde_amd/wcache.py; what this module uses of it)
+from .wcache import _WT, weight_epoch, weight_t, weight_layout  # noqa: E402
 
 
 _T2_MODE = "1"     # "0" (tests, measurements): every node-level product on the row strips

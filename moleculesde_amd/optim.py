@@ -12,7 +12,7 @@ receives a gradient, so the two coincide there.
 """
 import torch
 
-from . import hip
+from . import hip, slabs, wcache
 
 
 class FlatAdam:
@@ -133,7 +133,7 @@ class FlatAdam:
             else:
                 col[r:r + nc] = g.data_ptr() + self._chunk_bytes[:nc]
             r += nc
-        hip.upload_table(dev, host)        # recorded (not captured) while a hipGraph is being captured
+        slabs.upload_table(dev, host)        # recorded (not captured) while a hipGraph is being captured
         if not capturing and self.flat_p.is_cuda:
             ev = self._events[self._slot_i] or torch.cuda.Event()
             ev.record()
@@ -181,14 +181,14 @@ class FlatAdam:
         """Adam on the flat gradient buffer: assumes gather_grads() (and, under DP, the all-reduce of
         flat_g) already happened."""
         self.step_dev.add_(1)
-        hip.bump_weight_epoch()            # parameters change through raw pointers: transposed weight copies go stale
+        wcache.bump_weight_epoch()            # parameters change through raw pointers: transposed weight copies go stale
         hip.adam_flat(self.flat_p, self.flat_g, self.m, self.v, self.step_dev, self.seg_end, self.seg_lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)
 
     def begin_bucket_step(self):
         """Bucketed form of step(): call once, then step_bucket(i) for every bucket (any order, each once)."""
         self.step_dev.add_(1)
-        hip.bump_weight_epoch()
+        wcache.bump_weight_epoch()
 
     def step_bucket(self, i, grad_scale=1.0):
         """Adam on bucket i (= param group i) of the flat buffers only: lets the optimiser start on a bucket whose
@@ -206,6 +206,6 @@ class FlatAdam:
         table, n = self._chunk_table()
         if bump:
             self.step_dev.add_(1)
-        hip.bump_weight_epoch()
+        wcache.bump_weight_epoch()
         hip.adam_chunks(self.flat_p, table, n, self.m, self.v, self.step_dev, self.seg_end, self.seg_lr,
                         self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)

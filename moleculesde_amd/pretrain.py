@@ -15,7 +15,7 @@ import time
 import torch
 import torch.nn.functional as F
 
-from . import dp, slabs
+from . import dp, slabs, wcache
 from .geom3d import GNN, SchNet, SDEModel2Dto3D_01, SDEModel2Dto3D_02, prepare_batch
 from .geom3d import nn as _nn
 from .optim import FlatAdam
@@ -437,7 +437,7 @@ class Trainer:
         try:
             roots = loss if isinstance(loss, tuple) else (loss,)
             one = self._one_grad if roots[0].is_cuda else None     # preallocated d(loss)/d(loss): no fill launch per step
-            hip.begin_param_grad_batch(self.opt.params)
+            slabs.begin_param_grad_batch(self.opt.params)
             try:
                 hip.stamp("bwd_start")
                 if len(roots) == 1:
@@ -452,19 +452,19 @@ class Trainer:
                     # the second stream finished its backward (SchNet) long before the main chain (GIN): it sums the
                     # CFConv filter-gradient slabs (6 x 256 slabs, ~125 MB) it wrote, in the shadow of the GIN backward
                     with torch.cuda.stream(self._side_stream):
-                        early = hip.reduce_written_slabs()
+                        early = slabs.reduce_written_slabs()
                     if early:
                         torch.cuda.current_stream().wait_stream(self._side_stream)
-                if self.overlap_streams and hip.have_deferred_leaf_kernels():
+                if self.overlap_streams and slabs.have_deferred_leaf_kernels():
                     # leaf-only kernels of the backward pass (GIN bond-table gradients: 5 x 17 us that nothing downstream
                     # reads) run on the second stream BESIDE the grouped weight-gradient launch instead of inside the
                     # backward chain.  Host order: everything of SchNet's backward is already queued on that stream.
                     main_, side_ = torch.cuda.current_stream(), self._side_stream
                     side_.wait_stream(main_)
                     with torch.cuda.stream(side_):
-                        hip.run_deferred_leaf_kernels()
+                        slabs.run_deferred_leaf_kernels()
                     if finish:
-                        hip.flush_wgrad_gemms()
+                        slabs.flush_wgrad_gemms()
                     main_.wait_stream(side_)
                 if hip.STAMPS is not None and self.overlap_streams:
                     with torch.cuda.stream(self._side_stream):
@@ -476,7 +476,7 @@ class Trainer:
                     torch.cuda.current_stream().wait_stream(self._side_stream)
             finally:
                 if finish or sys.exc_info()[0] is not None:
-                    hip.finish_param_grad_batch()
+                    slabs.finish_param_grad_batch()
                     hip.stamp("wgrad_end")
         finally:
             self._side_geometry(False)
@@ -555,7 +555,7 @@ class Trainer:
             _, w, scale = dp.allreduce_buckets_async(self.opt.flat_g, [(a, b)], order=[0])
             works.append(w[0])
         if graphs is None:
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
             hip.stamp("wgrad_end")
         if tm is not None:
             tm.append(self._timing_event())           # every bucket's work queued: end of the "graph" part
@@ -572,9 +572,9 @@ class Trainer:
 
     def _refresh_weights(self):
         """Right after an optimiser step: ONE launch re-transposes every weight the forward products read as [K][N]
-        (hip.weight_t), so that no forward of the next step has to."""
+        (wcache.weight_t), so that no forward of the next step has to."""
         from . import hip as _hip
-        self._last_refreshed = _hip.refresh_weight_t()
+        self._last_refreshed = wcache.refresh_weight_t()
 
     def _bounds(self, batch):
         """The row-bound scope of a batch: its capacity bucket's counts, or none for an exact-size batch."""
@@ -648,7 +648,7 @@ class Trainer:
             self.noise.seed_dev = sd        # fresh contrastive negatives on every replay
         self.opt.new_table_slot()       # this graph's own (pinned) gradient chunk table
         from . import hip as _hip
-        _hip.new_param_grad_slot(batch.x.device)
+        slabs.new_param_grad_slot(batch.x.device)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         if self._graph_pool is None:
@@ -658,7 +658,7 @@ class Trainer:
         # (round 4: capturing on a high-priority stream -- main chain over the second stream -- changes nothing: 2.575 vs 2.582 ms)
         overlap = (not with_adam) and self._use_dp() and DP_OVERLAP and self.dp_buckets
         tail_graphs = None
-        with _hip.no_gc(), self._bounds(batch), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
+        with slabs.no_gc(), self._bounds(batch), torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             if pre is not None:
                 pre()
             loss = self._graph_body(batch, with_adam, finish=not overlap)
@@ -672,20 +672,20 @@ class Trainer:
             tail_graphs = []
             for k, i in enumerate(order):
                 gk = torch.cuda.CUDAGraph()
-                with _hip.no_gc(), self._bounds(batch), torch.cuda.graph(gk, pool=self._graph_pool, capture_error_mode="thread_local"):
+                with slabs.no_gc(), self._bounds(batch), torch.cuda.graph(gk, pool=self._graph_pool, capture_error_mode="thread_local"):
                     self._dp_finish_bucket(i, table)
                     if k == len(order) - 1:
-                        _hip.finish_param_grad_batch()
+                        slabs.finish_param_grad_batch()
                         _hip.stamp("wgrad_end")
                 tail_graphs.append(gk)
-        _hip.flush_table_uploads()      # the graph's pointer tables: uploaded once, not at every replay
+        slabs.flush_table_uploads()      # the graph's pointer tables: uploaded once, not at every replay
         self.opt.use_eager_slot()
-        _hip.use_eager_param_grad_slot()
+        slabs.use_eager_param_grad_slot()
         # the captured batch is held strongly: its tensors' addresses are baked into the graph, and a live reference
         # keeps id(batch) from being recycled for a different batch
         self._graphs[key] = (g, batch, with_adam)
         self._graph_tails[key] = tail_graphs
-        # the weight copies the captured refresh launch re-lays-out at every replay (hip.weight_copies_after_replay)
+        # the weight copies the captured refresh launch re-lays-out at every replay (wcache.weight_copies_after_replay)
         self._graph_wt_keys[key] = getattr(self, "_last_refreshed", ()) if with_adam else None
         self._graph_loss[key] = loss
         return g
@@ -695,7 +695,7 @@ class Trainer:
         g, held, with_adam = self._graphs[id(batch)]
         assert held is batch
         from . import hip as _hip
-        _hip.sync_weight_copies()          # parameters edited from outside since the last step (load_state_dict, ...)
+        wcache.sync_weight_copies()          # parameters edited from outside since the last step (load_state_dict, ...)
         timing = self.dp_timing is not None and not with_adam and self._use_dp() and self.dp_buckets
         if timing:                         # [replay start, replay end, (bucket reduced, bucket's Adam done) x buckets]
             self._tm_cur = [self._timing_event()]
@@ -705,7 +705,7 @@ class Trainer:
         if timing and tails is None:
             self._tm_cur.append(self._timing_event())
         if self._graph_wt_keys.get(id(batch)) is not None:
-            _hip.weight_copies_after_replay(self._graph_wt_keys[id(batch)])
+            wcache.weight_copies_after_replay(self._graph_wt_keys[id(batch)])
         for bn in self._bn_modules:
             bn.pending_batches += 1        # the captured forward does not run Python: count its BatchNorm calls here
         if not with_adam:
@@ -746,7 +746,7 @@ class Trainer:
             torch.cuda.synchronize()
             bk.plan_graph = torch.cuda.CUDAGraph()
             from . import hip as _hipg
-            with _hipg.no_gc(), torch.cuda.graph(bk.plan_graph, capture_error_mode="thread_local"):
+            with slabs.no_gc(), torch.cuda.graph(bk.plan_graph, capture_error_mode="thread_local"):
                 bk.build_plan_on_device(None)
             return self.capture(bk.batch)
         side = self._side_stream if (self.overlap_streams and PLAN_LISTS_ON_SIDE) else None

@@ -7,6 +7,7 @@ import os
 import torch
 from . import _lib
 from . import hip as _hip_mod
+from . import slabs
 
 FUSED_PC = True     # sampler arithmetic on msde_pc_corrector / msde_pc_predictor (False: operator by operator, the reference path of the tests)
 
@@ -112,12 +113,12 @@ def position_PC_generation(score_model, representation, data, num_steps=1000, sn
         if use_graph and dev.type == "cuda" and graph is None and i == 2:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with _hip_mod.no_gc(collect=False), torch.cuda.graph(graph):
+            with slabs.no_gc(collect=False), torch.cuda.graph(graph):
                 one_step()                 # capture only records; the replay below executes iteration i
             k_iters = max(1, min(int(iters_per_graph), num_steps - i)) if fused else 1
             if k_iters > 1:
                 graph_k = torch.cuda.CUDAGraph()
-                with _hip_mod.no_gc(collect=False), torch.cuda.graph(graph_k):
+                with slabs.no_gc(collect=False), torch.cuda.graph(graph_k):
                     for _ in range(k_iters):
                         one_step()
         if graph_k is not None and num_steps - i >= k_iters:

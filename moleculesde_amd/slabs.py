@@ -1,5 +1,6 @@
 """Capture lifetime, grow-on-demand workspaces and the batched weight-gradient / slab-reduction machinery of a training step
-(split out of hip.py in round 5; hip.py re-exports every name, so `hip.begin_param_grad_batch`, `hip._SLABS`, ... keep working).
+(split out of hip.py in round 5; round 6: callers import this module -- `slabs.begin_param_grad_batch`, `slabs._SLABS`, ... -- hip.py no
+longer re-exports it).
 
   * note_capture / _retire / _KEEP_ALIVE, no_gc: what a captured hipGraph needs to stay valid while eager steps go on;
   * _scratch / _wgrad_workspace / _ws_key: per-(device, stream) workspaces;

@@ -20,6 +20,7 @@ from helpers import disable_dropout  # noqa: E402
 from moleculesde_amd import dp, pretrain  # noqa: E402
 import moleculesde_amd.geom3d as G  # noqa: E402
 from moleculesde_amd.synthetic import make_batch  # noqa: E402
+from moleculesde_amd import wcache  # noqa: E402
 
 os.environ["MSDE_DP_BACKEND"] = "gloo"
 rank, world, local = dp.init_from_env("cuda")
@@ -113,7 +114,7 @@ for use_graph in (False, True):
         tr_dp.step(shards[rank])
         tr_dp.capture(shards[rank])
         # the warm-up step moved tr_dp: both restart from the reference's point.  This rewrites tr_dp's parameters from
-        # OUTSIDE the optimiser after the capture: the replay must still see them (hip.sync_weight_copies in step_graph
+        # OUTSIDE the optimiser after the capture: the replay must still see them (wcache.sync_weight_copies in step_graph
         # refreshes the cached re-laid-out weight copies the forward products read)
         same_params(tr_1, tr_dp)
         tr_dp.opt.m.zero_(); tr_dp.opt.v.zero_(); tr_dp.opt.step_dev.zero_()

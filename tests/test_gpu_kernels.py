@@ -5,6 +5,7 @@ import math
 
 import pytest
 import torch
+from moleculesde_amd import slabs, wcache  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -221,14 +222,14 @@ def test_mlp_head_mix_fused(dev, B, with_base):
         bd = basis.float().to(dev).contiguous()
         assert hip.mlp_head_mix_ok(xd, d1, d2)
         if batched:
-            hip.begin_param_grad_batch([d1.weight, d1.bias, d2.weight, d2.bias])
+            slabs.begin_param_grad_batch([d1.weight, d1.bias, d2.weight, d2.bias])
         try:
             out = hip.mlp_head_mix(xd, d1, d2, bd.view(E, 9), pl, based)
             (out * R.float().to(dev)).sum().backward()
         finally:
             if batched:
-                hip.flush_wgrad_gemms()
-                hip.finish_param_grad_batch()
+                slabs.flush_wgrad_gemms()
+                slabs.finish_param_grad_batch()
         assert_close(out, ref, 1e-4, 1e-4, "out")
         assert_close(xd.grad, x.grad, 2e-3, 1e-5, "g_x")
         assert_close(d1.weight.grad, l1.weight.grad, 2e-3, 2e-4 * float(l1.weight.grad.abs().max()), "gW1")
@@ -266,12 +267,12 @@ def test_pair_gather_cat_and_fused_mlp(dev, J):
         hd, ed = h.detach().to(dev).requires_grad_(True), ea.detach().to(dev).requires_grad_(True)
         ps = [p.detach().to(dev).requires_grad_(True) for p in (l0.weight, l0.bias, l1.weight, l1.bias)]
         if batched:
-            hip.begin_param_grad_batch(ps)
+            slabs.begin_param_grad_batch(ps)
         out = hip.mlp_fused(hip.pair_gather_cat(hd, ed, pl), [(ps[0], ps[1]), (ps[2], ps[3])], "silu")
         assert_close(out, ref, 2e-5, 2e-5, "fused basis MLP fwd")
         (out * w.to(dev)).sum().backward()
         if batched:
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
         assert_close(hd.grad, h.grad, 1e-4, 1e-4, "g h")
         assert_close(ed.grad, ea.grad, 1e-4, 1e-4, "g edge_attr")
         for got, want, name in zip(ps, (l0.weight, l0.bias, l1.weight, l1.bias), ("W0", "b0", "W1", "b1")):
@@ -514,11 +515,11 @@ def test_cfconv_pair_all_blocks_in_one_launch(dev, L, group):
         loss = sum((o * w).sum() for o, w in zip(outs, ws))
         params = [q for n in ps for q in n]
         if batched:
-            hip.begin_param_grad_batch(params)
+            slabs.begin_param_grad_batch(params)
             try:
                 loss.backward()
             finally:
-                hip.finish_param_grad_batch()
+                slabs.finish_param_grad_batch()
         else:
             loss.backward()
         torch.cuda.synchronize()
@@ -960,11 +961,11 @@ def test_batched_slab_reduction_matches_immediate(dev):
             if b is not None:
                 b.grad = None
         if batched:
-            hip.begin_param_grad_batch()
+            slabs.begin_param_grad_batch()
         for x, w, b, g in layers:
             hip.linear(x, w, b).backward(g)
         if batched:
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
         torch.cuda.synchronize()
         return [(w.grad.clone(), None if b is None else b.grad.clone()) for x, w, b, g in layers]
 
@@ -986,7 +987,7 @@ def test_frame_mlp_and_pair_linear_fused_operators(dev, E, H):
     hip._PairLinear (edge_2D_emb[0] on cat(h[row], h[col]) as one per-node product, :386-388): values and every
     parameter gradient against torch autograd in fp64 -- with the weight gradients formed on the spot, and queued in a
     parameter-gradient batch (2-D rows of msde_reduce_slabs_multi write column blocks of the wider gradients); the cached
-    re-laid-out weight copies (hip.weight_layout) follow an in-place parameter update."""
+    re-laid-out weight copies (wcache.weight_layout) follow an in-place parameter update."""
     from moleculesde_amd import hip
     g = torch.Generator().manual_seed(E + H)
     mk = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
@@ -1018,11 +1019,11 @@ def test_frame_mlp_and_pair_linear_fused_operators(dev, E, H):
         for p in P:
             p.grad = None
         if batched:
-            hip.begin_param_grad_batch(P)
+            slabs.begin_param_grad_batch(P)
         out = hip._FrameMLP.apply(feat, X.clone(), *P)
         out.backward(g_out.to(dev))
         if batched:
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
         assert_close(out, out_ref, 2e-5, 2e-5, f"frame mlp out (batched={batched})")
         for name, p, r in zip(("Wc", "bc", "W1", "b1", "W2", "b2"), P, g_ref):
             assert_close(p.grad, r, 2e-4, 2e-4 * max(1.0, float(r.abs().max())), f"frame mlp grad {name} (batched={batched}, scale={scale})")
@@ -1037,19 +1038,19 @@ def test_frame_mlp_and_pair_linear_fused_operators(dev, E, H):
         for q in Q:
             q.grad = None
         if batched:
-            hip.begin_param_grad_batch(Q[1:])
+            slabs.begin_param_grad_batch(Q[1:])
         AB = hip._PairLinear.apply(*Q)
         AB.backward(gAB.to(dev))
         if batched:
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
         assert_close(AB, AB_ref, 2e-5, 2e-5, "pair linear out")
         for name, q, r in zip(("h", "W", "b"), Q, g_ref):
             assert_close(q.grad, r, 2e-4, 2e-4 * max(1.0, float(r.abs().max())), f"pair linear grad {name} (batched={batched})")
 
 
 def test_weight_copies_follow_parameter_edits_and_moves(dev):
-    """The cached [K][N] copies the forward products read (hip.weight_t): an in-place edit (version counter), an update
-    through raw pointers (hip.bump_weight_epoch, what FlatAdam does) and a parameter whose storage is re-pointed (what
+    """The cached [K][N] copies the forward products read (wcache.weight_t): an in-place edit (version counter), an update
+    through raw pointers (wcache.bump_weight_epoch, what FlatAdam does) and a parameter whose storage is re-pointed (what
     building a flat-buffer optimiser after a first forward does) are all seen by the next forward; the batched refresh
     drops the copy of the old storage instead of reading it."""
     from moleculesde_amd import hip
@@ -1062,12 +1063,12 @@ def test_weight_copies_follow_parameter_edits_and_moves(dev):
         lin.weight.mul_(0.5)                                        # version counter moves
         assert_close(hip.linear(x, lin.weight, lin.bias), ref(), 1e-5, 1e-5, "after an in-place edit")
         lin.weight.data.view(-1)[::7] += 1.0                        # .data edit: no version bump ...
-        hip.bump_weight_epoch()                                     # ... the optimiser's contract
+        wcache.bump_weight_epoch()                                     # ... the optimiser's contract
         assert_close(hip.linear(x, lin.weight, lin.bias), ref(), 1e-5, 1e-5, "after a raw-pointer update")
         lin.weight.data = (lin.weight.data * 2.0).clone()           # storage re-pointed
-        hip.refresh_weight_t()                                      # must not touch the old storage's entry
+        wcache.refresh_weight_t()                                      # must not touch the old storage's entry
         assert_close(hip.linear(x, lin.weight, lin.bias), ref(), 1e-5, 1e-5, "after the storage moved")
-        hip.refresh_weight_t()
+        wcache.refresh_weight_t()
         torch.cuda.synchronize()
 
 
@@ -1080,19 +1081,19 @@ def test_weight_copy_refresh_captured_in_a_graph_survives_later_entries(dev):
     torch.manual_seed(4)
     lin_a = torch.nn.Linear(96, 80).to(dev)
     with torch.no_grad():
-        wa = hip.weight_t(lin_a.weight)
+        wa = wcache.weight_t(lin_a.weight)
         assert torch.equal(wa, lin_a.weight.t())
-        hip.note_capture()
-        hip.refresh_weight_t()                                        # (eager: builds the tables a capture may not upload)
+        slabs.note_capture()
+        wcache.refresh_weight_t()                                        # (eager: builds the tables a capture may not upload)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            keys = hip.refresh_weight_t()
+            keys = wcache.refresh_weight_t()
         assert len(keys) >= 1
         lin_b = torch.nn.Linear(64, 48).to(dev)                       # a later entry: the eager tables are rebuilt
-        wb = hip.weight_t(lin_b.weight)
+        wb = wcache.weight_t(lin_b.weight)
         tmp = torch.nn.Linear(200, 120).to(dev)
-        hip.weight_t(tmp.weight)
+        wcache.weight_t(tmp.weight)
         del tmp                                                       # ... and one that dies: its buffer must not be reused
         import gc
         gc.collect()
@@ -1100,11 +1101,11 @@ def test_weight_copy_refresh_captured_in_a_graph_survives_later_entries(dev):
         lin_a.weight.data.add_(1.0)                                   # an update Python does not see (what Adam in a graph does)
         lin_b.weight.data.add_(2.0)
         g.replay()
-        hip.weight_copies_after_replay(keys)
+        wcache.weight_copies_after_replay(keys)
         torch.cuda.synchronize()
         assert torch.equal(wa, lin_a.weight.t()), "the captured refresh wrote the copy it was captured with"
         assert all(bool(torch.isnan(j).all()) for j in junk), "a replay wrote into memory it no longer owns"
-        assert torch.equal(hip.weight_t(lin_b.weight), lin_b.weight.t()), "the later entry was marked stale and refreshed"
+        assert torch.equal(wcache.weight_t(lin_b.weight), lin_b.weight.t()), "the later entry was marked stale and refreshed"
         del wb
 
 

@@ -5,6 +5,7 @@
 import numpy as np
 import pytest
 import torch
+from moleculesde_amd import slabs, wcache  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -849,7 +850,7 @@ def test_md17_force_trainer_graph_replay_matches_eager_and_oracle(dev):
     b.positions = confs[0].to(dev)
     ft.capture(b, ys[0].to(dev), fs[0].to(dev))
     ft.opt.flat_p.copy_(p0); ft.opt.m.zero_(); ft.opt.v.zero_(); ft.opt.step_dev.zero_()
-    hip.bump_weight_epoch()
+    wcache.bump_weight_epoch()
     replay = [float(ft.step_graph(confs[t].to(dev), ys[t].to(dev), fs[t].to(dev))) for t in range(steps)]
     print("MD17 losses: oracle", ref, "eager", eager, "graph", replay)
     for t in range(steps):
@@ -1171,11 +1172,11 @@ def test_dense_head_launches_no_torch_operator(dev, variant):
         h3.grad = None
         lx, la = m(h3, b, reduce_mean=True, continuous=True, train=True, anneal_power=0)
         out = torch.stack([lx, la])
-        hip.begin_param_grad_batch(tr.opt.params)
+        slabs.begin_param_grad_batch(tr.opt.params)
         try:
             torch.autograd.backward(out, torch.ones_like(out))
         finally:
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
     run()
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:

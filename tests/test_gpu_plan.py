@@ -9,6 +9,7 @@
 import numpy as np
 import pytest
 import torch
+from moleculesde_amd import wcache  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -347,7 +348,7 @@ def test_oversized_batch_falls_back_and_overflow_is_flagged(dev):
         for k, m in tr.models.items():
             m.load_state_dict(snap[5][k])
         tr.noise.calls = calls0
-        hip.bump_weight_epoch()
+        wcache.bump_weight_epoch()
     tr.step_stream(bk, big)                               # does not fit -> exact-size eager step
     torch.cuda.synchronize()
     got = tr.opt.flat_p.clone()
@@ -425,7 +426,7 @@ def test_two_live_buckets(dev):
         tr.capture_bucket(bb, blobs["b"][0])
         # capture warm-up stepped the optimiser: back to a common starting point
         tr.opt.flat_p.copy_(p0); tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_dev.zero_(); tr.step_counter.zero_()
-        hip.refresh_weight_t()
+        wcache.refresh_weight_t()
         for which, i in order:
             tr.step_bucket(ba if which == "a" else bb, blobs[which][i])
         torch.cuda.synchronize()
@@ -466,7 +467,7 @@ def test_bucket_pipeline_matches_single_bucket(dev):
             bk = tr.make_bucket(caps)
             tr.capture_bucket(bk, blobs[0])
         tr.opt.flat_p.copy_(p0); tr.opt.m.zero_(); tr.opt.v.zero_(); tr.opt.step_dev.zero_(); tr.step_counter.zero_()
-        hip.refresh_weight_t()
+        wcache.refresh_weight_t()
         losses = []
         if piped:
             pipe.submit(blobs[0])

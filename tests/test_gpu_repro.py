@@ -8,6 +8,7 @@ This test is the check that caught it, pointed at the default fp32 step: configs
 Adam moments, step counters restored before every replay) -- every gradient must be bit-identical across the replays."""
 import pytest
 import torch
+from moleculesde_amd import wcache  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +37,7 @@ def test_captured_two_stream_step_replays_bit_identically(full):
         with torch.no_grad():
             for t, s0 in zip(state, snap):
                 t.copy_(s0)
-        hip.invalidate_weight_copies()             # parameters rewritten behind the optimiser's back
+        wcache.invalidate_weight_copies()             # parameters rewritten behind the optimiser's back
         loss = tr.step_graph(b)
         torch.cuda.synchronize()
         grads = {n: p.grad.clone() for n, p in params if p.grad is not None}

@@ -7,6 +7,7 @@ from moleculesde_amd import plan as P, escore
 from moleculesde_amd.geom3d import sde_2d_to_3d as M
 from moleculesde_amd.batch import Batch
 from moleculesde_amd.synthetic import make_batch, make_molecule
+from moleculesde_amd import slabs  # noqa: E402
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 
@@ -73,10 +74,10 @@ def case_bwd(name, cpu_b):
             net.zero_grad(set_to_none=True)
             x.grad = None
             ea.grad = None
-            hip.begin_param_grad_batch()
+            slabs.begin_param_grad_batch()
             out = net(ep, x, ea, bs, pl)["gradient"]
             (out * w).sum().backward()
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -84,7 +85,7 @@ def case_bwd(name, cpu_b):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            hip.new_param_grad_slot(dev)
+            slabs.new_param_grad_slot(dev)
             with torch.cuda.graph(g, stream=s):
                 step()
         res[mol] = timeit(g.replay, 50)

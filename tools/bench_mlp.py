@@ -7,6 +7,7 @@ import torch
 from moleculesde_amd import hip
 from moleculesde_amd.geom3d import prepare_batch, nn as _nn
 from moleculesde_amd.synthetic import make_batch
+from moleculesde_amd import slabs  # noqa: E402
 
 dev = torch.device("cuda", 0)
 b = prepare_batch(make_batch(256, seed=0), dev)
@@ -31,22 +32,22 @@ def fused():
 def step(fn):
     for p in (h, ea, l0.weight, l0.bias, l1.weight, l1.bias):
         p.grad = None
-    hip.begin_param_grad_batch()
+    slabs.begin_param_grad_batch()
     out = fn()
     out.backward(w)
-    hip.finish_param_grad_batch()
+    slabs.finish_param_grad_batch()
 
 
 for name, fn in (("operator chain", chain), ("fused", fused)):
     for _ in range(3):
         step(fn)
     torch.cuda.synchronize()
-    hip.new_param_grad_slot(dev)
+    slabs.new_param_grad_slot(dev)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         step(fn)
-    hip.flush_table_uploads()
-    hip.use_eager_param_grad_slot()
+    slabs.flush_table_uploads()
+    slabs.use_eager_param_grad_slot()
     for _ in range(5):
         g.replay()
     torch.cuda.synchronize()

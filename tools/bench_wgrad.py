@@ -3,6 +3,7 @@ kernel (+ fused bias grad) vs vendor mm (+ msde_colsum), and forward / dgrad, on
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from moleculesde_amd import hip, _lib
+from moleculesde_amd import slabs  # noqa: E402
 dev = torch.device("cuda", 0)
 SHAPES = [(3588, 300, 300), (3588, 600, 300), (3588, 300, 600), (3588, 128, 300), (3588, 300, 128), (3588, 32, 32),
           (3588, 128, 32), (3588, 32, 128), (3588, 32, 300), (35186, 32, 32), (35186, 128, 64), (35186, 64, 128),
@@ -31,7 +32,7 @@ for M, N, K in SHAPES:
     g = torch.randn(M, N, device=dev)
     gw = torch.empty(N, K, device=dev); gb = torch.empty(N, device=dev); y = torch.empty(M, N, device=dev)
     gx = torch.empty(M, K, device=dev)
-    ws = hip._wgrad_workspace(M, N, K, dev); bws = hip._bn_workspace(M, N, dev)
+    ws = slabs._wgrad_workspace(M, N, K, dev); bws = hip._bn_workspace(M, N, dev)
     def w_hip(): _lib.call("msde_linear_bwd_w", p(g), p(x), M, N, K, p(gw), p(gb), p(ws), p(None), hip._stream())
     def w_lib():
         torch.mm(g.t(), x, out=gw)

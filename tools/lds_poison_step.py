@@ -9,6 +9,7 @@ from helpers import disable_dropout
 from moleculesde_amd import pretrain, hip, _lib
 import moleculesde_amd.geom3d as G
 from moleculesde_amd.synthetic import make_batch
+from moleculesde_amd import wcache  # noqa: E402
 
 dev = torch.device("cuda", 0)
 tool = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "liblds_canary.so"))
@@ -82,7 +83,7 @@ def run(lo, hi, on):
     with torch.no_grad():
         for t, s0 in zip((tr.opt.flat_p, tr.opt.m, tr.opt.v, tr.opt.step_dev, tr.step_counter), snap):
             t.copy_(s0)
-    hip.invalidate_weight_copies()
+    wcache.invalidate_weight_copies()
     torch.manual_seed(11)
     STATE.update(on=on, idx=0, lo=lo, hi=hi, names=[])
     loss, _ = tr.step(b)

@@ -5,6 +5,7 @@ import moleculesde_amd.geom3d as G
 from moleculesde_amd import hip, dd
 from moleculesde_amd.synthetic import make_md17_batch
 from moleculesde_amd.finetune_md17 import ForceTrainer
+from moleculesde_amd import slabs  # noqa: E402
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 kw = dict(hidden_channels=300, num_filters=128, num_interactions=6, num_gaussians=51, cutoff=10, readout="mean", node_class=119)
@@ -28,12 +29,12 @@ def grads(defer, skip):
         force = -torch.autograd.grad(energy, pos, grad_outputs=torch.ones_like(energy), create_graph=True, retain_graph=True)[0]
     loss = (energy - et).abs().mean() + (force - ftg).abs().mean()
     if defer:
-        hip.begin_param_grad_batch(params)
+        slabs.begin_param_grad_batch(params)
     try:
         loss.backward()
     finally:
         if defer:
-            hip.finish_param_grad_batch()
+            slabs.finish_param_grad_batch()
     torch.cuda.synchronize()
     return [None if p.grad is None else p.grad.clone() for p in params]
 

@@ -7,15 +7,16 @@ os.environ["MSDE_OVERLAP_STREAMS"] = os.environ.get("MSDE_OVERLAP_STREAMS", "1")
 from moleculesde_amd import pretrain, hip
 from moleculesde_amd.geom3d import prepare_batch
 from moleculesde_amd.synthetic import make_batch
+from moleculesde_amd import slabs  # noqa: E402
 dev = torch.device("cuda", 0)
 tr = pretrain.Trainer(pretrain.readme_args(**({} if "--full" in sys.argv else {"SDE_coeff_generative_3Dto2D": 0})), dev)
 b = prepare_batch(make_batch(256, seed=0), dev)
 tr.step(b)
-orig = hip._SLABS.launch_gemms
+orig = slabs._SLABS.launch_gemms
 def spy(max_wgs=0):
     tot = 0
     rows = []
-    for (gY, X, M, N, K, hb, slab) in hip._SLABS.gemms:
+    for (gY, X, M, N, K, hb, slab) in slabs._SLABS.gemms:
         tot += 2.0 * M * N * K
         rows.append((M, N, K))
     import collections
@@ -32,7 +33,7 @@ def spy(max_wgs=0):
     us = e0.elapsed_time(e1) * 1e3
     print("grouped launch alone: %.1f us -> %.1f TFLOP/s (%.2f of the 157.3 peak)" % (us, tot / us / 1e6, tot / us / 1e6 / 157.3))
     return r
-hip._SLABS.launch_gemms = spy
+slabs._SLABS.launch_gemms = spy
 for _ in range(3):
     tr.step(b)
 torch.cuda.synchronize()

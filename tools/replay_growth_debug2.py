@@ -51,7 +51,7 @@ def _retire_logged(bufs):
 
 if "logretire" in sys.argv:
     slabs._retire = _retire_logged        # (hip.py's own callers go through its imported name: patch both)
-    hip._retire = _retire_logged
+    slabs._retire = _retire_logged
 from moleculesde_amd import pretrain as _pt
 _dual0 = _pt.dual_CL
 CLSTASH = []
@@ -146,7 +146,7 @@ for use_graph in (True, False):
         del xs
         torch.cuda.synchronize()
     if "refresh" in sys.argv and use_graph:
-        hip.refresh_weight_t()
+        wcache.refresh_weight_t()
     pre = [None if t is None else t.clone() for t in gstatic] if use_graph else None
     if use_graph and "tables" in sys.argv:
         cs = slabs._SLABS.slots[-1]          # the capture's slot: (host_rows, host_pre, dev_rows, dev_pre, host_prob, host_ppre, dev_prob, dev_ppre)
