@@ -506,7 +506,7 @@ def roofline_forward(trainer, batch, stats, iters=30):
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     try:
-        from moleculesde_amd.hip import no_gc
+        from moleculesde_amd.slabs import no_gc
         with no_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             fwd()
         run = g.replay

@@ -104,6 +104,10 @@ SIDE_CFCONV_BWD_GROUP = 3     # SchNet alone on the second stream: its filter-we
 GEOMETRY_ON_SIDE = True       # coordinate-only branch of the 2D->3D model at the head of the second stream (2.86 vs 2.98 ms)
 EARLY_SLAB_REDUCE = True      # the second stream sums the CFConv slabs it wrote, in the shadow of the GIN backward
 PLAN_LISTS_ON_SIDE = True     # bucket mode: embedding row lists off the main chain
+# (Round 6, measured and removed: with the filter-weight gradients batched the second stream's backward CHAIN ends ~320 us before the
+# main stream's in configs[1] (stamps: bwd_side_chain_end 1750 vs bwd_main_end 2070 us); launching the weight-gradient problems whose
+# operands the second stream produced THERE, as a grouped launch of their own beside the GIN backward, took 100 us off the tail
+# (435 -> 333 us) and put 84 us on the GIN backward: 2.476 vs 2.470 ms, --full 3.389 vs 3.268 -- profiles/r06_ab_side_wgrad_flush.txt)
 # Data parallel: weight gradients, flattening and all-reduce bucket by bucket, so that a bucket's all-reduce travels behind the
 # next bucket's weight-gradient work (Trainer._dp_tail).  Built and parity-green (tests/test_gpu_dp.py runs it), OFF by default:
 # the per-bucket pieces cost the compute stream more than the collectives they hide -- 1-rank RCCL, one box, alternating:
