@@ -52,7 +52,7 @@ def _event_time_ms(fn, iters, stream):
     return start.elapsed_time(end) / iters
 
 
-def _pmc_traffic(kernel, rnd="r04"):
+def _pmc_traffic(kernel, rnd="r06"):
     """HBM-side bytes per launch of `kernel` from the COMMITTED rocprofv3 --pmc passes (profiles/<rnd>_pmc_counters.json:
     separate FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes) -- a recorded figure, not a
     measurement of this run; None when the file does not hold the kernel."""
@@ -66,12 +66,12 @@ def _pmc_traffic(kernel, rnd="r04"):
 
 
 def _profile(name):
-    """Newest committed profile of that name: profiles/r05_<name> if present, else the round-4 one."""
-    for rnd in ("r05", "r04"):
+    """Newest committed profile of that name: profiles/r06_<name> if present, else the round-5 / round-4 one."""
+    for rnd in ("r06", "r05", "r04"):
         p = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))
         if os.path.exists(p):
             return p
-    return os.path.join(ROOT, "profiles", "r05_%s" % name)
+    return os.path.join(ROOT, "profiles", "r06_%s" % name)
 
 
 def _rocprof_avg_us(kernel, full=False):
@@ -277,7 +277,7 @@ def roofline_gemm(trainer, batch, dev, in_step, family):
                               "median of %d replays per layer, mean over the layers, stamp overhead subtracted)"
                               % in_step.get("replays", 0),
                     "avg_launch_us_per_layer": in_step.get("gin_gemm2_per_layer")})
-    sub["traffic"] = _pmc_traffic("gemm_t2_kernel<5, 1>[3588x300x600]")
+    sub["traffic"] = _pmc_traffic("gemm_t2_kernel<5, 1>[3588x300x600]", "r04")
     sub["traffic_source"] = "profiles/r04_pmc_counters.json (committed FETCH_SIZE / WRITE_SIZE passes; not measured by this run)"
     sub["algorithmic_bytes_per_launch"] = (N * H + H * D + N * D + N * H) * 4      # z1 in, W, z2 out, a1 out
     out = {"kernel": "gemm_t2_kernel<RN, AXF> family (every node-level product of the step), FLOP-weighted, in the step",
@@ -296,8 +296,8 @@ def roofline_gemm(trainer, batch, dev, in_step, family):
     if fam:
         out["family_in_committed_rocprofv3_summary"] = fam
     # counters of the dominant instantiations (separate --pmc passes, tools/gpu_r05_pmc.sh -> profiles/r05_pmc_counters.json)
-    out["traffic"] = _pmc_traffic("gemm_t2_kernel<5, 0>[3588x300x300]", "r05") or sub["traffic"]
-    out["traffic_source"] = "profiles/r05_pmc_counters.json (committed FETCH_SIZE / WRITE_SIZE passes of the plain N = K = 300 product; not measured by this run)"
+    out["traffic"] = _pmc_traffic("gemm_t2_kernel<5, 0>[3588x300x300]", "r06") or _pmc_traffic("gemm_t2_kernel<5, 0>[3588x300x300]", "r05") or sub["traffic"]
+    out["traffic_source"] = "profiles/r06_pmc_counters.json (committed FETCH_SIZE / WRITE_SIZE passes of the plain N = K = 300 product inside ten eager steps; not measured by this run)"
     out["gin_second_product"] = sub
     return out
 
