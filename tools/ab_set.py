@@ -1,7 +1,8 @@
 """Alternating A/B of module constants and / or library builds on the bench line, on ONE box, without editing any source.
 
     python tools/ab_set.py ROUNDS [--full] [--steps N] name1=SET1 name2=SET2 ...
-        SET = comma list of  package.module:ATTR=python-literal   and / or   lib:tools/_build/libmsde_x.so   (empty: defaults)
+        SET = comma list of  package.module:ATTR=python-literal,  lib:tools/_build/libmsde_x.so,  arg:<bench.py argument>,  --dp
+              (empty: defaults)
     e.g. python tools/ab_set.py 3 units= r5order=moleculesde_amd.slabs:WGRAD_UNIT_ORDER=False r5=lib:tools/_build/libmsde_r5split.so
 
 Each run is a child process (`--child`): it applies the setting after importing the modules, runs bench.main() with the
@@ -20,6 +21,9 @@ def child(setting, bench_args):
     for item in filter(None, setting.split(",")):
         if item == "--dp":                 # the multi-GPU step structure on one GPU (1-rank RCCL group)
             bench_args = bench_args + ["--debug_dp_path"]
+            continue
+        if item.startswith("arg:"):        # a bench.py argument, e.g. arg:--score_kernel,arg:mol
+            bench_args = bench_args + [item[4:]]
             continue
         if item.startswith("lib:"):
             from moleculesde_amd import _lib

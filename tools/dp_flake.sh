@@ -1,4 +1,7 @@
+#!/bin/bash
 # repeat the two-rank worker (tests/dp_gpu_worker.py, "full") and print the DP-vs-single distances.  usage: tools/dp_flake.sh N [ENV=V ...]
+set -uo pipefail
+: "${GRAFT_REPO_ROOT:?}"
 cd $GRAFT_REPO_ROOT
 N=$1; shift
 for i in $(seq 1 $N); do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes (separate runs per counter set; --kernel-trace only beside --pmc) for the dominant kernels
-R=${GRAFT_REPO_ROOT:-$(pwd)}
+: "${GRAFT_REPO_ROOT:?}"
+R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${ROUND:-r06}pmc
 mkdir -p $O
 export TMPDIR=/tmp

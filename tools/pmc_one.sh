@@ -1,4 +1,7 @@
+#!/bin/bash
 # PMC counters of ONE kernel (name substring) over a short bench run; prints per-counter medians.  usage: tools/pmc_one.sh <substr> [bench args]
+set -uo pipefail
+: "${GRAFT_REPO_ROOT:?}"
 K=$1; shift
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/pmc1
 for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAVES SQ_INST_CYCLES_VMEM"; do
