@@ -184,9 +184,33 @@ extern "C" int msde_dense_prepare(const int* rowptr, const int* src, const float
 template <int C, int CO>
 struct EdgeLds {
   static constexpr int LQ = 32 * C + 4, LA = C + 1, LV = 16 * C + 1;   // LQ: 16-B rows, bank offset 4 per row
+  // FORWARD kernel (round 6; ds_read_b32 banks over 32 banks per 32-lane half, MI355X_MICROARCH.md): its matrix-core operand
+  // reads walk ROWS of these arrays with the lane index, so the row strides are chosen = 2 (mod 32) -- 16 consecutive rows x 2
+  // k lanes then cover the 32 banks exactly once:
+  //   LQF          q | k rows (8-byte aligned: staged with 8-byte stores); with LQ = 4 (mod 32) rows r and r + 8 met on a bank
+  //   rowf(n)      row stride of the pair arrays Ad / Tt, indexed [i][j][channel] = i * rowf(n) + j * LA + channel instead of
+  //                (i n + j) LA: the TRANSPOSED reads (pair (j, i) beside (i, j); column i of the adjacency in the GCN) have
+  //                the lane index on i, i.e. stride n LA = 144 floats at n = 16: sixteen lanes on two banks
+  static constexpr int LQF = 32 * C + 2;
+  __host__ __device__ static int rowf(int n) { const int x = n * LA; return x + ((34 - (x & 31)) & 31); }
+  __host__ __device__ static int floats_node_f(int nm) {
+    return nm * rowf(nm) + 2 * nm * LV + nm * 17 * 2 + nm * 8 + ((W_END + 3) & ~3) + 8;
+  }
+  __host__ __device__ static int floats_pair_f(int nm) { return 2 * nm * LQF + nm * rowf(nm) + ((W_END + 3) & ~3) + 8; }
+  __host__ __device__ static int floats_split_f(int nm) {
+    return floats_node_f(nm) > floats_pair_f(nm) ? floats_node_f(nm) : floats_pair_f(nm);
+  }
+  __host__ __device__ static int floats_f(int nm) {
+    return 2 * nm * LQF + nm * rowf(nm) + 2 * nm * LV + nm * 17 * 2 + nm * 8 + ((W_END + 3) & ~3) + 8;
+  }
+  // channel-MLP weights with PADDED rows (round 6): its first layer is read as an MFMA B operand with the lane index on the
+  // OUTPUT row (16 rows x 2 k lanes per 32-lane half): at the natural stride 16 C = 0 (mod 32) all sixteen rows met on one
+  // bank (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the forward kernel: 54 %); stride = 2 (mod 32) spreads them over the 32
+  // banks.  The second layer is read one output row per lane: stride 17.
+  static constexpr int SC0 = 16 * C + 2, SC1 = 17;
   static constexpr int W_M0 = 0, B_M0 = W_M0 + 16 * 2 * C, W_M1 = B_M0 + 16, B_M1 = W_M1 + 256, W_M2 = B_M1 + 16,
-                       B_M2 = W_M2 + CO * 16, W_C0 = B_M2 + CO, B_C0 = W_C0 + 16 * 16 * C, W_C1 = B_C0 + 16,
-                       B_C1 = W_C1 + 256, B_V = B_C1 + 16, W_END = B_V + 16 * C;
+                       B_M2 = W_M2 + CO * 16, W_C0 = B_M2 + CO, B_C0 = W_C0 + 16 * SC0, W_C1 = B_C0 + 16,
+                       B_C1 = W_C1 + 16 * SC1, B_V = B_C1 + 16, W_END = B_V + 16 * C;
   __host__ __device__ static int floats(int nm) {
     return 2 * nm * LQ + nm * nm * LA + 2 * nm * LV + nm * 17 * 2 + nm * 8 + ((W_END + 3) & ~3) + 8;
   }
@@ -218,9 +242,12 @@ __device__ __forceinline__ void edge_load_weights(float* Wk, const msde_edge_lay
   if (tid < 16) { rb[0] = p.mb0[tid]; rb[1] = p.mb1[tid]; rb[2] = p.cb0[tid]; rb[3] = p.cb1[tid]; }
   const float rb2 = tid < CO ? p.mb2[tid] : 0.f;
 #pragma unroll
-  for (int u = 0; u < NC0; ++u) Wk[L::W_C0 + tid + 256 * u] = rc0[u];
+  for (int u = 0; u < NC0; ++u) {
+    const int e = tid + 256 * u, row = e / (16 * C);
+    Wk[L::W_C0 + row * L::SC0 + (e - row * 16 * C)] = rc0[u];
+  }
   Wk[L::W_M1 + tid] = rm1;
-  Wk[L::W_C1 + tid] = rc1;
+  Wk[L::W_C1 + (tid >> 4) * L::SC1 + (tid & 15)] = rc1;
   if (tid < 16 * 2 * C) Wk[L::W_M0 + tid] = rm0;
   if (tid < CO * 16) Wk[L::W_M2 + tid] = rm2;
   if (tid < 16 * C) Wk[L::B_V + tid] = rbv;
@@ -230,14 +257,40 @@ __device__ __forceinline__ void edge_load_weights(float* Wk, const msde_edge_lay
 
 // stage Q | K, the adjacency channels and x W_c of one molecule; computes r[i] = clamp(deg_i, 1)^-1/2 per channel
 // (Qs == nullptr: no Q | K staging; Xv == nullptr: no x W_c staging and no r -- the two halves of the split forward)
+// lq: row stride of Qs / Ks (L::LQ: 16-byte stores; L::LQF: 8-byte stores); arow: row stride of Ad (n * L::LA: pair-linear,
+// the backward kernel; L::rowf(n): the forward kernel)
 template <int C, int CO>
 __device__ __forceinline__ void edge_stage(float* Qs, float* Ks, float* Ad, float* Xv, float* Rn, const float* QK,
-                                           const float* XV, const float* AC, int in_off, int a0, int n, int q0, int tid) {
+                                           const float* XV, const float* AC, int in_off, int a0, int n, int q0, int tid,
+                                           const int lq = EdgeLds<C, CO>::LQ, const int arow = -1) {
   using L = EdgeLds<C, CO>;
   constexpr int W = 32 * C;
+  const int ar = arow < 0 ? n * L::LA : arow;
   // (batches of four trips, loads first: with a run-time trip count the compiler emits load -> wait -> store per trip, a global
   // round trip each)
-  if (Qs) {
+  if (Qs && (lq & 3) != 0) {
+    // 8-byte aligned rows (the forward kernel's LQF): 8-byte loads and stores, a lane group's 16 x 8 B contiguous in LDS (with
+    // 16-byte loads split into two 8-byte stores the stores of lanes k and k + 8 met on a bank)
+    const int tot = n * (W / 2);
+    for (int e0 = tid; e0 < tot; e0 += 4 * 256) {
+      float2 q[4], k[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + 256 * u, tot - 1), i = e / (W / 2), c2 = (e - i * (W / 2)) * 2;
+        q[u] = *reinterpret_cast<const float2*>(QK + (size_t)(a0 + i) * (2 * W) + c2);
+        k[u] = *reinterpret_cast<const float2*>(QK + (size_t)(a0 + i) * (2 * W) + W + c2);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + 256 * u;
+        if (e < tot) {
+          const int i = e / (W / 2), c2 = (e - i * (W / 2)) * 2;
+          *reinterpret_cast<float2*>(Qs + i * lq + c2) = q[u];
+          *reinterpret_cast<float2*>(Ks + i * lq + c2) = k[u];
+        }
+      }
+    }
+  } else if (Qs) {
     const int tot = n * (W / 4);
     for (int e0 = tid; e0 < tot; e0 += 4 * 256) {
       float4 q[4], k[4];
@@ -252,8 +305,8 @@ __device__ __forceinline__ void edge_stage(float* Qs, float* Ks, float* Ad, floa
         const int e = e0 + 256 * u;
         if (e < tot) {
           const int i = e / (W / 4), c4 = (e - i * (W / 4)) * 4;
-          *reinterpret_cast<float4*>(Qs + i * L::LQ + c4) = q[u];
-          *reinterpret_cast<float4*>(Ks + i * L::LQ + c4) = k[u];
+          *reinterpret_cast<float4*>(Qs + i * lq + c4) = q[u];
+          *reinterpret_cast<float4*>(Ks + i * lq + c4) = k[u];
         }
       }
     }
@@ -270,7 +323,7 @@ __device__ __forceinline__ void edge_stage(float* Qs, float* Ks, float* Ad, floa
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int e = e0 + 256 * u;
-        if (e < tot) { const int p = e / C, c = e - p * C; Ad[p * L::LA + c] = v[u]; }
+        if (e < tot) { const int p = e / C, c = e - p * C, i = p / n; Ad[i * ar + (p - i * n) * L::LA + c] = v[u]; }
       }
     }
   }
@@ -297,7 +350,7 @@ __device__ __forceinline__ void edge_stage(float* Qs, float* Ks, float* Ad, floa
     const int i = e / C, c = e - i * C;
     float s = 1.f;
     for (int j = 0; j < n; ++j)
-      if (j != i) s += Ad[(i * n + j) * L::LA + c];
+      if (j != i) s += Ad[i * ar + j * L::LA + c];
     Rn[i * C + c] = rsqrtf(fmaxf(s, 1.f));
   }
   __syncthreads();
@@ -339,9 +392,9 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
   float* Wk = lds;                    // weights first: 16-B aligned for the float4 broadcast reads
   const int part = SPLIT ? (int)(blockIdx.x & 1) : -1;      // 0: node half, 1: pair half, -1: both
   float* Qs = part == 0 ? nullptr : Wk + ((L::W_END + 3) & ~3);
-  float* Ks = part == 0 ? nullptr : Qs + nm * L::LQ;
-  float* Ad = part == 0 ? Wk + ((L::W_END + 3) & ~3) : Ks + nm * L::LQ;
-  float* Xv = part == 1 ? nullptr : Ad + nm * nm * L::LA;
+  float* Ks = part == 0 ? nullptr : Qs + nm * L::LQF;
+  float* Ad = part == 0 ? Wk + ((L::W_END + 3) & ~3) : Ks + nm * L::LQF;
+  float* Xv = part == 1 ? nullptr : Ad + nm * L::rowf(nm);
   float* Vc = Xv + nm * L::LV;
   float* Hm = Vc + nm * L::LV;        // [n][17]
   float* Tm = Hm + nm * 17;           // [n][17] scratch
@@ -349,9 +402,10 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
   const int b = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, tid = threadIdx.x;
   DH_STAMP(0);
   const int a0 = mol_ptr[b], n = mol_ptr[b + 1] - a0, q0 = pair_ptr[b];
+  const int AR = L::rowf(n);              // row stride of Ad and Tt ([i][j][channel]), = 2 (mod 32)
   edge_load_weights<C, CO>(Wk, p, tid);
   DH_STAMP(1);
-  edge_stage<C, CO>(Qs, Ks, Ad, Xv, Rn, QK, XV, AC, in_off, a0, n, q0, tid);
+  edge_stage<C, CO>(Qs, Ks, Ad, Xv, Rn, QK, XV, AC, in_off, a0, n, q0, tid, L::LQF, AR);
   DH_STAMP(2);
 
   if (part != 1) {
@@ -370,7 +424,7 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
       const int jb_ = 4 * s4 + ng;
       float av = 0.f, bvv = 0.f;
       if (jb_ < n) {
-        if (ia < n) av = (ia == jb_ ? 1.f : Ad[(ia * n + jb_) * L::LA + c]) * ri * Rn[jb_ * C + c];
+        if (ia < n) av = (ia == jb_ ? 1.f : Ad[ia * AR + jb_ * L::LA + c]) * ri * Rn[jb_ * C + c];
         bvv = Xv[jb_ * L::LV + 16 * c + ncl];
       }
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv, acc, 0, 0, 0);
@@ -403,14 +457,14 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
         for (int s4 = 0; s4 < KQ / 4; ++s4) {
           const int k = KQ * nw + 4 * s4 + ng;
           const float av = ia < n ? Vc[ia * L::LV + k] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wk[L::W_C0 + ncl * 16 * C + k], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wk[L::W_C0 + ncl * L::SC0 + k], acc, 0, 0, 0);
         }
       } else if (nw == 0) {                  // C = 2: 32 inputs, one wave
 #pragma unroll
         for (int s4 = 0; s4 < 16 * C / 4; ++s4) {
           const int k = 4 * s4 + ng;
           const float av = ia < n ? Vc[ia * L::LV + k] : 0.f;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wk[L::W_C0 + ncl * 16 * C + k], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wk[L::W_C0 + ncl * L::SC0 + k], acc, 0, 0, 0);
         }
       }
       if (C >= 4) {
@@ -447,7 +501,7 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
   for (int e = tid; e < n * 16; e += 256) {
     const int i = e >> 4, o = e & 15;
     float s = Wk[L::B_C1 + o];
-    const float* w = Wk + L::W_C1 + o * 16;
+    const float* w = Wk + L::W_C1 + o * L::SC1;
 #pragma unroll
     for (int k = 0; k < 16; ++k) s = fmaf(w[k], Hm[i * 17 + k], s);
     x_out[(size_t)(a0 + i) * 16 + o] = dh_tanh(s * flags[a0 + i]);
@@ -478,8 +532,8 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
       tv[u] = f4{0.f, 0.f, 0.f, 0.f};
       if (it < nitem) {                       // (uniform in the wave)
         const int c = it % C, blk = it / C, ib = blk / nb, jb = blk - ib * nb;
-        const float* qr = Qs + min(16 * ib + cl, n - 1) * L::LQ + 32 * c + g4;
-        const float* kr = Ks + min(16 * jb + cl, n - 1) * L::LQ + 32 * c + g4;
+        const float* qr = Qs + min(16 * ib + cl, n - 1) * L::LQF + 32 * c + g4;
+        const float* kr = Ks + min(16 * jb + cl, n - 1) * L::LQF + 32 * c + g4;
         f4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
@@ -501,7 +555,7 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ii = 16 * ib + 4 * g4 + r;
-          if (ii < n && jj < n) Tt[(ii * n + jj) * LT + c] = tv[u][r] * 0.125f;
+          if (ii < n && jj < n) Tt[ii * AR + jj * LT + c] = tv[u][r] * 0.125f;
         }
       }
     }
@@ -526,12 +580,12 @@ dense_edge_layer_fwd_kernel(const float* __restrict__ QK, const float* __restric
       const int pp = 16 * t + cl;
       const bool on = pp < n * n;
       const int pc = on ? pp : 0;
-      const int i = pc / n, j = pc - i * n, ppT = j * n + i;
+      const int i = pc / n, j = pc - i * n;
       float inv[KS];
 #pragma unroll
       for (int s_ = 0; s_ < KS; ++s_) {
         const int k = 4 * s_ + g4;            // input index: k < C attention channel k, else adjacency channel k - C
-        inv[s_] = k < C ? 0.5f * (Tt[pc * LT + k] + Tt[ppT * LT + k]) : Ad[pc * L::LA + (k - C)];
+        inv[s_] = k < C ? 0.5f * (Tt[i * AR + j * LT + k] + Tt[j * AR + i * LT + k]) : Ad[i * AR + j * L::LA + (k - C)];
       }
       f4 a1 = {b0.x, b0.y, b0.z, b0.w};
 #pragma unroll
@@ -614,7 +668,7 @@ dense_edge_layer_bwd_kernel(const float* __restrict__ QK, const float* __restric
       const int i = e >> 4, k = e & 15;
       float s = 0.f;
 #pragma unroll
-      for (int o = 0; o < 16; ++o) s = fmaf(Wk[L::W_C1 + o * 16 + k], Tm[i * 17 + o], s);
+      for (int o = 0; o < 16; ++o) s = fmaf(Wk[L::W_C1 + o * L::SC1 + k], Tm[i * 17 + o], s);
       s *= dh_delu_y(Hmc[(size_t)(a0 + i) * 16 + k]);
       Hm[i * 17 + k] = s;
       GHm[(size_t)(a0 + i) * 16 + k] = s;
@@ -624,7 +678,7 @@ dense_edge_layer_bwd_kernel(const float* __restrict__ QK, const float* __restric
       const int i = e / (16 * C), cf = e - i * 16 * C;
       float s = 0.f;
 #pragma unroll
-      for (int o = 0; o < 16; ++o) s = fmaf(Wk[L::W_C0 + o * 16 * C + cf], Hm[i * 17 + o], s);
+      for (int o = 0; o < 16; ++o) s = fmaf(Wk[L::W_C0 + o * L::SC0 + cf], Hm[i * 17 + o], s);
       Vc[i * L::LV + cf] = s;
       GV[(size_t)(a0 + i) * (16 * C) + cf] = s;
     }
@@ -833,7 +887,7 @@ extern "C" int msde_dense_edge_layer_fwd(const float* QK, const float* XV, float
   const bool want_split = true;
 #define EDGE_FWD_SPLIT(CC, CCO)                                                                                        \
   if (C == CC && CO == CCO) {                                                                                          \
-    const int bytes = EdgeLds<CC, CCO>::floats_split(nm) * (int)sizeof(float);                                        \
+    const int bytes = EdgeLds<CC, CCO>::floats_split_f(nm) * (int)sizeof(float);                                      \
     if (want_split && 2 * bytes + 2048 <= 160 * 1024) {                                                                \
       static bool s = false;                                                                                           \
       if (!s) { hipFuncSetAttribute((const void*)dense_edge_layer_fwd_kernel<CC, CCO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); s = true; } \
@@ -847,10 +901,23 @@ extern "C" int msde_dense_edge_layer_fwd(const float* QK, const float* XV, float
   EDGE_FWD_SPLIT(8, 8)
   EDGE_FWD_SPLIT(8, 4)
 #undef EDGE_FWD_SPLIT
-  EDGE_DISPATCH(dense_edge_layer_fwd_kernel, QK, XV, AC, in_off, out_off, flags, mol_ptr, pair_ptr, p, nm, x_out, IN, H1, H2,
-                xcat, Hmc);
-  MSDE_CHECK_LAUNCH();
-  return 0;
+  // one workgroup per molecule (both halves): the forward's own LDS map (EdgeLds::floats_f)
+#define EDGE_FWD_WHOLE(CC, CCO)                                                                                        \
+  if (C == CC && CO == CCO) {                                                                                          \
+    const int bytes = EdgeLds<CC, CCO>::floats_f(nm) * (int)sizeof(float);                                            \
+    if (bytes > 160 * 1024) return MSDE_EUNSUP;                                                                        \
+    static bool s = false;                                                                                             \
+    if (!s) { hipFuncSetAttribute((const void*)dense_edge_layer_fwd_kernel<CC, CCO, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); s = true; } \
+    MSDE_LAUNCH((dense_edge_layer_fwd_kernel<CC, CCO, 0>), dim3(B), dim3(256), bytes, st, QK, XV, AC, in_off, out_off, flags,  \
+                mol_ptr, pair_ptr, p, nm, x_out, IN, H1, H2, xcat, Hmc);                                               \
+    MSDE_CHECK_LAUNCH();                                                                                               \
+    return 0;                                                                                                          \
+  }
+  EDGE_FWD_WHOLE(2, 8)
+  EDGE_FWD_WHOLE(8, 8)
+  EDGE_FWD_WHOLE(8, 4)
+#undef EDGE_FWD_WHOLE
+  return MSDE_EUNSUP;
 }
 
 extern "C" int msde_dense_edge_layer_bwd(const float* QK, const float* XV, const float* AC, float* gAC, int in_off,
