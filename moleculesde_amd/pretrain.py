@@ -90,6 +90,21 @@ def readme_args(**over):
 
 
 USE_FUSED_CL = True
+_STREAMS = {}
+
+
+def shared_stream(device, name):
+    """One HIP stream per (device, role) for the whole process.  HIP maps streams onto a handful of hardware queues: a second
+    Trainer with streams of its own (bench.py times configs[2] behind configs[1] in one process) found its plan-ahead stream on
+    the queue of another of its streams -- the two-bucket mode ran 3 % slower as the second trainer of a process than as the
+    first (3.32 vs 3.22 ms).  Trainers of one process run one after the other, so they can share."""
+    key = (str(device), name)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 # Stream layout of the step, fixed by alternating A/B runs on one box (numbers: DESIGN.md rounds 2-4).  What lost is gone from
 # the code: weight gradients flushed early or on the second stream, the contrastive loss on the second stream, SchNet started
 # behind GIN, a third stream for the coordinate branch, leaf kernels in front of the grouped launch.
@@ -240,7 +255,7 @@ class Trainer:
         # hipGraph mode: one captured graph per batch shape (forward + backward + gradient flattening
         # [+ Adam when single-GPU]); a device-side step counter re-seeds the dropout masks per replay
         self.overlap_streams = overlap_streams      # SchNet (and the coordinate branch) on a second HIP stream
-        self._side_stream = torch.cuda.Stream(device=device)
+        self._side_stream = shared_stream(device, "side") if torch.device(device).type == "cuda" else None
         self._one_grad = torch.ones((), dtype=torch.float32, device=device)
         if self._one_grad.is_cuda:
             from . import hip as _hip0
@@ -801,7 +816,7 @@ class BucketPipeline:
         self.bks = [trainer.make_bucket(caps) for _ in range(2)]
         for bk in self.bks:
             trainer.capture_bucket(bk, warm_blob, split_plan=True)
-        self.stream = torch.cuda.Stream(device=trainer.device)
+        self.stream = shared_stream(trainer.device, "plan")
         self.ready = [None, None]       # recorded on the plan stream: bucket i holds a built batch
         self.done = [None, None]        # recorded on the compute stream: the step that read bucket i has finished
         self.head = self.tail = 0       # batches submitted / stepped
