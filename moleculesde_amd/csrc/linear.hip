@@ -49,6 +49,20 @@ __device__ __forceinline__ float lg_ldg1(const float* p) {
 #endif
 }
 
+// -DLG_PROBE (tools only, tools/bench_grouped_wgrad.py probe): s_memtime stamps around the phases of the interior K loop, summed
+// over the loop by wave 0 of every workgroup and added into lg_probe[] (read back with msde_debug_lg_probe)
+#ifdef LG_PROBE
+__device__ unsigned long long lg_probe[8];
+#define LG_T(x) __builtin_amdgcn_sched_barrier(0); const unsigned long long x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+extern "C" int msde_debug_lg_probe(unsigned long long* host8, int reset) {
+  if (host8 && hipMemcpyFromSymbol(host8, HIP_SYMBOL(lg_probe), sizeof(lg_probe)) != hipSuccess) return MSDE_EINVAL;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lg_probe), z, sizeof(z)) != hipSuccess) return MSDE_EINVAL; }
+  return 0;
+}
+#else
+#define LG_T(x)
+#endif
+
 template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>
 __device__ __forceinline__ void
 gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
@@ -209,6 +223,9 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
 #pragma unroll
     for (int j = 0; j < TN; ++j)
       sub_live[i][j] = (m0 + (wm * TM + i) * 32 < M) && (n0 + (wn * TN + j) * 32 < N);
+#ifdef LG_PROBE
+  unsigned long long pt4 = 0, pacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   auto compute_tile = [&]() {
     if (TM == 1 && TN == 1) {
       // a wave whose 32 x 32 quadrant lies entirely outside the product (narrow layers: N or K <= 32 fill one or two
@@ -224,6 +241,10 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
         bf[kk] = Bs[(2 * kk + lhalf) * LDB_S + wn * 32 + lcol];
       }
       __builtin_amdgcn_sched_barrier(0);
+#ifdef LG_PROBE
+      pt4 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       __builtin_amdgcn_s_setprio(LG_PRIO);          // the wave in its MFMA phase wins issue slots from waves staging tiles
 #pragma unroll
       for (int kk = 0; kk < LG_BK / 2; ++kk)
@@ -279,11 +300,19 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
       for (; t + 2 * ST <= nfull; t += ST) {
 #pragma unroll
         for (int s = 0; s < ST; ++s) {
+          LG_T(t0);
           __syncthreads();
+          LG_T(t1);
           store_tile(rsa[s], rsb[s]);
+          LG_T(t2);
           __syncthreads();
+          LG_T(t3);
           load_tile_fast(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
           compute_tile();
+          LG_T(t5);
+#ifdef LG_PROBE
+          pacc[0] += t1 - t0; pacc[1] += t2 - t1; pacc[2] += t3 - t2; pacc[3] += pt4 - t3; pacc[4] += t5 - pt4; pacc[5] += 1;
+#endif
         }
       }
     }
@@ -309,6 +338,10 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
     }
   }
 
+#ifdef LG_PROBE
+  if (tid == 0 && quadrant_live)
+    for (int i = 0; i < 6; ++i) atomicAdd(&lg_probe[i], pacc[i]);
+#endif
   // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   float* Cz = C + (size_t)bid_z * (size_t)M * ldc;  // split slabs (bid_z == 0 when unsplit)
 #pragma unroll
@@ -539,8 +572,14 @@ static inline void wgrad_split(int M, int N, int K, int* splits, int* k_per_spli
 }
 // the batched paths (msde_linear_bwd_w_partial / _describe + _grouped) share one launch among all layers, so a
 // layer needs far fewer workgroups of its own: fewer, longer splits = less prologue / slab traffic per FLOP
+#ifndef MSDE_WGRAD_TARGET
+#define MSDE_WGRAD_TARGET 64
+#endif
+#ifndef MSDE_WGRAD_MIN_ROWS
+#define MSDE_WGRAD_MIN_ROWS 256
+#endif
 static inline void wgrad_split_batched(int M, int N, int K, int* splits, int* k_per_split) {
-  const int target = 64;
+  const int target = MSDE_WGRAD_TARGET;
   wgrad_split_for(M, N, K, target, splits, k_per_split);
 }
 static inline void wgrad_split_for(int M, int N, int K, int target, int* splits, int* k_per_split) {
@@ -550,7 +589,7 @@ static inline void wgrad_split_for(int M, int N, int K, int target, int* splits,
   long want = (target + tiles - 1) / tiles;
   // at least 256 rows (8 K tiles) per split: a 64-row split spends its time in the pipeline prologue and the 16 KB
   // slab write, and the grouped launch has thousands of workgroups anyway (the dense head alone adds ~150 problems)
-  long maxs = (M + 255) / 256;
+  long maxs = (M + MSDE_WGRAD_MIN_ROWS - 1) / MSDE_WGRAD_MIN_ROWS;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want > 512) want = 512;

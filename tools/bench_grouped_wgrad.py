@@ -100,3 +100,17 @@ assert worst < 1e-4 and all(torch.isfinite(t[2]).all() for t in ops), worst
 for rep in range(3):
     us = gtime(natural)
     print("grouped launch %7.1f us  %6.1f TFLOP/s  %.3f of 157.3" % (us, gflop / us * 1e3, gflop / us * 1e3 / 157.3))
+if "probe" in sys.argv:          # a -DLG_PROBE build: cycles of wave 0 per interior K tile, by phase (average over all workgroups)
+    buf = (ctypes.c_ulonglong * 8)()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    raw.msde_debug_lg_probe(None, 1)
+    natural(); torch.cuda.synchronize()
+    raw.msde_debug_lg_probe(buf, 0)
+    v = [int(x) for x in buf]
+    tiles = max(v[5], 1)
+    names = ("barrier 1 (previous tile consumed)", "global-load wait + LDS stores issued", "barrier 2 (stores landed)",
+             "next loads + 32 LDS reads issued", "MFMA phase (first operand wait + 16 MFMAs issued)")
+    tot_c = sum(v[:5])
+    print("K tiles probed %d; cycles per K tile (s_memtime ticks = shader cycles): total %.0f (16 MFMAs = 1024)" % (tiles, tot_c / tiles))
+    for nm, c in zip(names, v[:5]):
+        print("  %-52s %7.0f  %4.1f %%" % (nm, c / tiles, 100.0 * c / tot_c))
