@@ -104,6 +104,10 @@ int msde_dd_binary(const float* a, const float* b, long long n, int op, float al
  * order): the gradient autograd accumulates for a tensor with n consumers (finetune_MD17.py:68,76 -- the smeared distances and
  * the cutoff feed all six interaction blocks, schnet.py:185-195) as one launch instead of n - 1 additions. */
 int msde_dd_sum_n(const float* const* srcs, int n, long long count, float* y, void* stream);
+/* The same for [rows][cols] operands with row strides lds[k] (host array; cols % 4 == 0, rows 16-byte aligned; y contiguous): a
+ * consumer's gradient that is a column block of a wider buffer -- the edge half of the basis MLP's input gradient
+ * (equivariant_scorenetwork.py:154-157: cat([h_row + h_col, edge_attr])) -- is summed where it lies. */
+int msde_dd_sum_rows_n(const float* const* srcs, const int* lds, int n, int rows, int cols, float* y, void* stream);
 /* y[e][k] = M[e][k] s[e]   and   y[e] = sum_k a[e][k] b[e][k] (fixed lane order) */
 int msde_dd_mul_rows(const float* M, const float* s, int E, int K, float* y, void* stream);
 int msde_dd_row_dot(const float* a, const float* b, int E, int K, float* y, void* stream);

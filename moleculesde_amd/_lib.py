@@ -113,6 +113,7 @@ SIGNATURES = {
     "msde_dd_rbf": [P, P, P, I, I, F, I, P, P],
     "msde_dd_binary": [P, P, LL, I, F, P, P],
     "msde_dd_sum_n": [P, I, LL, P, P],
+    "msde_dd_sum_rows_n": [P, P, I, I, I, P, P],
     "msde_dd_mul_rows": [P, P, I, I, P, P],
     "msde_dd_row_dot": [P, P, I, I, P, P],
     "msde_dd_edge_diff": [P, P, P, I, P, P],

@@ -80,6 +80,25 @@ __global__ void dd_sum_n_kernel(dd_ptrs8 s, int n, long long count, float* __res
   }
 }
 
+// the same for [rows][cols] operands with row strides of their own (a gradient that is a column block of a wider buffer: the edge
+// half of the basis MLP's input gradient, equivariant_scorenetwork.py:154-157); cols % 4 == 0, 16-byte aligned rows
+struct dd_lds8 { int ld[8]; };
+__global__ void dd_sum_rows_n_kernel(dd_ptrs8 s, dd_lds8 l, int n, int rows, int cols4, float* __restrict__ y) {
+  const long long count = (long long)rows * cols4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    const long long r = i / cols4;
+    const int c = (int)(i - r * cols4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(s.p[0] + r * l.ld[0] + c);
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+      if (k < n) {
+        const float4 w = *reinterpret_cast<const float4*>(s.p[k] + r * l.ld[k] + c);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+    *reinterpret_cast<float4*>(y + r * (long long)cols4 * 4 + c) = v;
+  }
+}
+
 __global__ void dd_mul_rows_kernel(const float* __restrict__ M, const float* __restrict__ s, int E, int K, float* __restrict__ y) {
   const long long n = (long long)E * K;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = M[i] * s[i / K];
@@ -213,6 +232,21 @@ extern "C" int msde_dd_sum_n(const float* const* srcs, int n, long long count, f
   }
   if (count == 0) return 0;
   MSDE_LAUNCH(dd_sum_n_kernel, DD_GRID(count), dim3(256), 0, as_stream(stream), s, n, count, y);
+  MSDE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int msde_dd_sum_rows_n(const float* const* srcs, const int* lds, int n, int rows, int cols, float* y, void* stream) {
+  if (!srcs || !lds || n < 1 || n > 8 || rows < 0 || cols <= 0 || cols % 4 || !y) return MSDE_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(y) & 15) != 0) return MSDE_EINVAL;
+  dd_ptrs8 s;
+  dd_lds8 l;
+  for (int k = 0; k < 8; ++k) {
+    s.p[k] = k < n ? srcs[k] : nullptr;
+    l.ld[k] = k < n ? lds[k] : 0;
+    if (k < n && (!s.p[k] || lds[k] < cols || lds[k] % 4 || (reinterpret_cast<uintptr_t>(s.p[k]) & 15) != 0)) return MSDE_EINVAL;
+  }
+  if (rows == 0) return 0;
+  MSDE_LAUNCH(dd_sum_rows_n_kernel, DD_GRID((long long)rows * (cols / 4)), dim3(256), 0, as_stream(stream), s, l, n, rows, cols / 4, y);
   MSDE_CHECK_LAUNCH();
   return 0;
 }

@@ -192,7 +192,32 @@ class _Fanout(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gs):
         gs = [g for g in gs if g is not None]
-        return (sum_n(gs) if gs else None), None
+        if not gs:
+            return None, None
+        if len(gs) > 1 and not torch.is_grad_enabled() and any(not g.is_contiguous() for g in gs):
+            y = _sum_rows_n(gs)           # column blocks of wider gradient buffers, summed where they lie
+            if y is not None:
+                return y, None
+        return sum_n(gs), None
+
+
+def _sum_rows_n(gs):
+    """g_0 + ... + g_{n-1} for 2-D fp32 device tensors with unit column stride and row strides of their own (one launch,
+    msde_dd_sum_rows_n); None when the operands do not qualify (the caller falls back to sum_n on contiguous copies)."""
+    import ctypes
+    g0 = gs[0]
+    if len(gs) > 8 or g0.dim() != 2 or g0.size(1) % 4:
+        return None
+    for g in gs:
+        if (not g.is_cuda or g.dtype != torch.float32 or g.shape != g0.shape or g.stride(1) != 1 or g.stride(0) % 4
+                or g.stride(0) < g.size(1) or g.data_ptr() % 16):
+            return None
+    y = torch.empty(g0.shape, dtype=torch.float32, device=g0.device)
+    arr = (ctypes.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+    lds = (ctypes.c_int * len(gs))(*[g.stride(0) for g in gs])
+    _call("msde_dd_sum_rows_n", ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(lds, ctypes.c_void_p), len(gs), g0.size(0),
+          g0.size(1), _p(y), _stream())
+    return y
 
 
 def fanout(x, n):

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import escore as _escore, hip, plan as _plan, wcache
+from .. import dd as _dd, escore as _escore, hip, plan as _plan, wcache
 from . import nn as _nn
 from .sde import VESDE, VPSDE
 
@@ -37,6 +37,7 @@ MOL_KERNEL_TRAIN = False    # ... and under autograd (forward + one-launch backw
                             # the second stream of the pretrain step the 256 single-wave-per-SIMD workgroups hold every CU for ~100 + ~340 us
                             # and the step is 2.69 ms against 2.58 ms operator by operator (alternating A/B on one box);
                             # `--score_kernel mol` of pretrain.py / the parity tests switch it on
+FANOUT_EDGE_ATTR = True    # the score network's edge features through ONE fan-out node (dd.fanout): their 3 consumers' gradients summed by one launch
 FUSE_PAIR_LINEAR = True    # hip._PairLinear (False: re-laid-out weight per step)
 
 
@@ -155,18 +156,25 @@ class EquivariantScoreNetwork(nn.Module):
         conv_input = node_attr
         gradient = None
         ee_all, shared, D = None, None, self.hidden_dim
-        ee_all = _nn.linear(edge_attr, hip.cat_params(self.fusion_sets()[0]))       # [E, layers*D]
+        # edge_attr has 1 + len(gnn_layers) consumers (the stacked lin_edge product, every basis MLP's input): one fan-out node
+        # whose backward sums their gradients -- two of them column blocks of wider buffers -- in ONE launch instead of one
+        # autograd addition per extra consumer on the backward chain
+        n_use = 1 + len(self.gnn_layers)
+        ea = (_dd.fanout(edge_attr, n_use) if (FANOUT_EDGE_ATTR and n_use > 2 and edge_attr.is_cuda and torch.is_grad_enabled()
+                                              and edge_attr.requires_grad) else (edge_attr,) * n_use)
+        ee_all = _nn.linear(ea[0], hip.cat_params(self.fusion_sets()[0]))       # [E, layers*D]
         shared = {}
         layer_no = 0
         for module_idx, gnn_layers in enumerate(self.gnn_layers):
             for conv_idx, gnn in enumerate(gnn_layers):
                 seed = (self._seed_base + self._calls) * 16 + module_idx * 4 + conv_idx
-                hidden = gnn(plan, conv_input, edge_attr, seed, self.seed_dev, ee_all, layer_no * D, shared,
+                hidden = gnn(plan, conv_input, ea[0], seed, self.seed_dev, ee_all, layer_no * D, shared,
                              silu_out=conv_idx < len(gnn_layers) - 1)
                 layer_no += 1
                 conv_input = hidden
             node_feature = hidden
             mlp = self.basis_mlp_modules[module_idx]
+            edge_attr = ea[1 + module_idx]
             if _nn.FUSED_MLP and node_feature.size(1) % 4 == 0 and edge_attr.size(1) % 4 == 0:
                 # cat([h_row + h_col, edge_attr]) written by the gather; Linear -> SiLU -> Linear on gemm_ex epilogues
                 edge_feature = hip.pair_gather_cat(node_feature, edge_attr, plan)
@@ -329,14 +337,16 @@ class SDEModel2Dto3D_02(nn.Module):
 
     def _edge_and_node_features(self, node_2D_repr, pos_perturbed, ep, started=None):
         D = self.emb_dim
+        # (a pair: the caller's fan-out aliases of the representation for the edge and the node branch, pretrain.Trainer.losses)
+        repr_edge, repr_node = node_2D_repr if isinstance(node_2D_repr, tuple) else (node_2D_repr, node_2D_repr)
         geo, side = started if started is not None else self._launch_geometry(pos_perturbed, ep)
         edge_attr_3D_invariant, edge_attr_3D_frame_invariant, basis = geo
         static = None
         if not self.training and not torch.is_grad_enabled() and STATIC_FEATURE_CACHE:
-            static = self._static_features(node_2D_repr, ep)
+            static = self._static_features(repr_node, ep)
         # edge_2D_emb[0](cat(h[row], h[col])) == h[row] W[:, :D]^T + h[col] W[:, D:]^T + b
         # as ONE node-level GEMM with the two weight halves stacked ([W_row; W_col], one re-layout copy per step): _edge_2D
-        edge_attr_2D = static[0] if static is not None else self._edge_2D(node_2D_repr, ep)
+        edge_attr_2D = static[0] if static is not None else self._edge_2D(repr_edge, ep)
         if side is not None:
             main = torch.cuda.current_stream()
             main.wait_stream(side)
@@ -347,7 +357,7 @@ class SDEModel2Dto3D_02(nn.Module):
             edge_attr = edge_attr_2D + edge_attr_3D_frame_invariant
         else:
             edge_attr = hip.mul_add(edge_attr_3D_invariant, edge_attr_2D, edge_attr_3D_frame_invariant)
-        node_attr = static[1] if static is not None else self.node_emb(node_2D_repr)
+        node_attr = static[1] if static is not None else self.node_emb(repr_node)
         return node_attr, edge_attr, basis
 
     def forward(self, node_2D_repr, data, anneal_power):

@@ -129,6 +129,7 @@ PLAN_LISTS_ON_SIDE = True     # bucket mode: embedding row lists off the main ch
 # 2.775 vs 2.573 ms per step (three grouped launches + three reductions + three flattening launches as graph pieces of their
 # own instead of one of each inside the step's graph, and the leaf kernels no longer run beside the grouped launch), against
 # an all-reduce of 14 MB that the ring estimate puts at ~0.2 ms on 8 GPUs (profiles/r06_dp_tail_overlap_ab.txt).
+FANOUT_2D_REPR = True       # the GIN output through one fan-out node for its three consumers (losses())
 DP_OVERLAP = False
 
 _SDE_RANGES_2D3D = {"VE": ("VE", 0.2, 1.0), "VP": ("VP", 0.2, 1.0), "VE02": ("VE", 0.1, 10.0), "VP02": ("VP", 0.2, 30.0),
@@ -387,8 +388,17 @@ class Trainer:
         _hip.stamp("gin_fwd_end")
         if stamps:
             node_2D_repr.register_hook(lambda g: _hip.stamp("gin_bwd_start"))
+        repr_cl = node_2D_repr
         if a.SDE_coeff_generative_2Dto3D > 0:
-            l23 = m["SDE_2Dto3D_model"](node_2D_repr, batch, anneal_power=a.SDE_anneal_power)["position"]
+            repr_23 = node_2D_repr
+            if (FANOUT_2D_REPR and self.coeff_cl > 0 and node_2D_repr.is_cuda and torch.is_grad_enabled()
+                    and node_2D_repr.requires_grad):
+                # three consumers (the contrastive loss, the 2D->3D model's node and edge embeddings): one fan-out node sums
+                # their gradients in ONE launch in front of the GIN backward instead of two autograd additions
+                from . import dd as _dd
+                repr_cl, r_edge, r_node = _dd.fanout(node_2D_repr, 3)
+                repr_23 = (r_edge, r_node)
+            l23 = m["SDE_2Dto3D_model"](repr_23, batch, anneal_power=a.SDE_anneal_power)["position"]
             terms.append(l23); coeffs.append(a.SDE_coeff_generative_2Dto3D)
             parts["2Dto3D"] = l23.detach()
             _hip.stamp("2d3d_fwd_end")
@@ -404,7 +414,7 @@ class Trainer:
                 l32[0].record_stream(main)
                 l32[1].record_stream(main)
         if self.coeff_cl > 0:
-            cl, acc = dual_CL(node_2D_repr, node_3D_repr, a, self.noise, negs)
+            cl, acc = dual_CL(repr_cl, node_3D_repr, a, self.noise, negs)
             terms.append(cl); coeffs.append(self.coeff_cl)
             parts["CL"], parts["CL_acc"] = cl.detach(), acc
         loss_head = None

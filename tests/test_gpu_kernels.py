@@ -1657,3 +1657,40 @@ def test_bn_bwd_fin_cols_matches_finish_plus_pass(dev, M, C, strips, gate):
     assert_close(out, ref.double(), 2e-5, 2e-5, "fused finish + pass: input gradient")
     assert_close(gb2, gb.double(), 2e-5, 2e-5, "fused finish + pass: dgamma / dbeta")
     assert torch.equal(out, out_b) and torch.equal(gb2, gb3), "two runs differ"
+
+
+def test_fanout_sums_column_blocks_in_one_launch(dev):
+    """dd.fanout: a tensor with n consumers gets ONE gradient kernel; consumers' gradients that are column blocks of wider
+    buffers (the edge half of the basis MLP's input gradient, equivariant_scorenetwork.py:154-157) are summed where they lie
+    (msde_dd_sum_rows_n).  Same additions in the same order as autograd's accumulation: bit-exact."""
+    from moleculesde_amd import dd
+    torch.manual_seed(21)
+    E, D = 1237, 32
+    x = torch.randn(E, D)
+    wide1, wide2, plain = torch.randn(E, 2 * D), torch.randn(E, D + 8), torch.randn(E, D)
+    ref = (wide1[:, D:] + wide2[:, 8:]) + plain                  # index order of the fan-out node
+    xd = x.to(dev).requires_grad_(True)
+    a, b, c = dd.fanout(xd, 3)
+    # consumers whose backward hands on views of wider buffers / a contiguous tensor
+    w1, w2, pl = wide1.to(dev), wide2.to(dev), plain.to(dev)
+    torch.autograd.backward([a, b, c], [w1[:, D:], w2[:, 8:], pl])
+    assert_close(xd.grad, ref, 0, 0, "fanout strided gradients")
+    # all contiguous: the flat kernel
+    xd2 = x.to(dev).requires_grad_(True)
+    a, b = dd.fanout(xd2, 2)
+    torch.autograd.backward([a, b], [pl, w1[:, :D].contiguous()])
+    assert_close(xd2.grad, plain + wide1[:, :D], 0, 0, "fanout contiguous gradients")
+    # a consumer that does not contribute
+    xd3 = x.to(dev).requires_grad_(True)
+    a, b, c = dd.fanout(xd3, 3)
+    (a * 2.0 + c).sum().backward()
+    assert_close(xd3.grad, torch.full((E, D), 3.0), 0, 0, "fanout with an unused alias")
+    # the C entry point refuses operands it cannot vectorise
+    import ctypes
+    from moleculesde_amd import _lib
+    lib = _lib.load()
+    arr = (ctypes.c_void_p * 2)(w1.data_ptr() + 4, pl.data_ptr())
+    lds = (ctypes.c_int * 2)(2 * D, D)
+    y = torch.empty(E, D, device=dev)
+    assert lib.msde_dd_sum_rows_n(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(lds, ctypes.c_void_p), 2, E, D,
+                                  ctypes.c_void_p(y.data_ptr()), None) != 0
