@@ -722,9 +722,14 @@ int msde_colsum(const float* X, int M, int C, float* out, float* workspace, cons
  * (msde_reduce_slabs_chunks), prefix[count] = total_chunks.  Fixed summation order, like msde_linear_bwd_w. */
 #define MSDE_REDUCE_ROW 8
 int msde_linear_bwd_w_splits(int M, int N, int K);
-/* Grouped form: the split-M GEMMs of many layers in ONE launch (same tile code, bit-identical slabs).
- * msde_linear_bwd_w_describe fills one HOST row (12 int64) of the problem table for a layer and returns the
- * number of workgroups it needs; prefix[p] = workgroups before problem p, prefix[count] = total_blocks. */
+/* Grouped form: the split-M GEMMs of many layers in ONE launch (same tile code and splits; slabs bit-identical to the
+ * per-layer kernel except for layers with N <= 32 AND K <= 32, see below).
+ * msde_linear_bwd_w_describe fills one HOST row of the problem table for a layer and returns the
+ * number of workgroups it needs; prefix[p] = workgroups before problem p, prefix[count] = total_blocks.
+ * The row also names the layer's TILE SHAPE (outputs are N x K): 64 x 64 (four waves, a 32 x 32 quadrant each); N <= 32 < 64 < K:
+ * 32 x 128, K <= 32 < 64 < N: 128 x 32 (the four waves side by side along the wide dimension; same summation order per output);
+ * N <= 32 and K <= 32: 32 x 32 with the four waves on the same outputs, each summing every fourth 32-row block of the rows,
+ * their partial sums added in wave order (fixed, but not the per-layer kernel's order). */
 int msde_linear_bwd_w_describe(const float* gY, const float* X, int M, int N, int K, int want_bias,
                                float* slabs, const int* rows_dev, long long* host_row);
 /* the same for operands that are column blocks of wider buffers: ldg / ldx = row strides of gY / X (floats).

@@ -18,6 +18,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LG_BK 32
+#ifndef MSDE_WGRAD_NARROW
+#define MSDE_WGRAD_NARROW 7      // bit mask of the narrow tile shapes in use (1: 32 x 128, 2: 128 x 32, 4: 32 x 32 with split K tiles); 0: 64 x 64 only
+#endif
 #ifndef LG_SKIP_DEAD
 #define LG_SKIP_DEAD 1
 #endif
@@ -63,12 +66,22 @@ extern "C" int msde_debug_lg_probe(unsigned long long* host8, int reset) {
 #define LG_T(x)
 #endif
 
-template <int TM, int TN, bool A_KM, bool B_KM, bool VEC>
+// WGM: waves along the M side of the tile (2: the 2 x 2 wave grid of the 64 TM x 64 TN tile; 1 / 4 with TM = TN = 1: the four waves
+// side by side, a 32 x 128 / 128 x 32 tile).  KS = 4 (TM = TN = 1, WGM = 1): a 32 x 32 tile whose four waves all work on the SAME
+// outputs, each on its quarter (32 rows) of a 128-row K tile; the four partial accumulators meet in LDS (wave order: fixed).
+// These are the weight-gradient shapes of products with a 32-wide (or narrower) side, where the 64 x 64 tile would leave half
+// (two narrow sides: three quarters) of its waves idle beside operand columns nobody reads (msde_linear_bwd_w_describe_ld).
+template <int TM, int TN, bool A_KM, bool B_KM, bool VEC, int WGM = 2, int KS = 1>
 __device__ __forceinline__ void
 gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                    float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
-                   int ldc, int k_per_split, const int bid_x, const int bid_y, const int bid_z, const bool edge_fast = false) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+                   int ldc, int k_per_split, const int bid_x, const int bid_y, const int bid_z, float* __restrict__ As,
+                   float* __restrict__ Bs, const bool edge_fast = false) {
+  constexpr int WGN = KS == 4 ? 1 : 4 / WGM;
+  constexpr int BM = 32 * (KS == 4 ? 1 : WGM) * TM, BN = 32 * WGN * TN;
+  constexpr int BK = LG_BK * KS;            // rows of a K tile
+  static_assert(KS == 1 || (KS == 4 && TM == 1 && TN == 1 && WGM == 1 && A_KM && B_KM), "k-split tiles: 32 x 32, k-major operands");
+  static_assert(WGM == 2 || (TM == 1 && TN == 1 && A_KM && B_KM), "side-by-side wave layouts: weight-gradient operands only");
   // k-major LDS images.  An operand that is k-major in memory is copied with aligned 16-B stores (row
   // stride BM+4); one that is row-major is transposed on the way in with scalar stores, for which the
   // stride BM+1 (== 1 mod 32) is the conflict-free one.  The MFMA operand reads (32 consecutive floats
@@ -78,19 +91,25 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   // (with stride 68 every read pair needed a v_add for its address -- 16 vector instructions per K tile that the fp32
   // MFMAs cannot hide, 4.17).  Conflict-free all the same: a half-wave reads 32 consecutive floats of one row, and a
   // 16-byte store instruction is served 8 lanes (= 32 consecutive floats) at a time.
-  constexpr int LDA_S = A_KM ? (BM == 64 ? 64 : BM + 4) : BM + 1, LDB_S = B_KM ? (BN == 64 ? 64 : BN + 4) : BN + 1;
-  __shared__ __attribute__((aligned(16))) float As[LG_BK * LDA_S];
-  __shared__ __attribute__((aligned(16))) float Bs[LG_BK * LDB_S];
+  // (As / Bs: the caller's LDS, LG_BK * LDA_S and LG_BK * LDB_S floats -- the grouped kernel shares one buffer among its tile shapes)
+  constexpr int LDA_S = A_KM ? (KS == 4 ? 32 : BM <= 64 ? 64 : (WGM == 2 ? BM + 4 : BM)) : BM + 1;
+  constexpr int LDB_S = B_KM ? (KS == 4 ? 32 : BN <= 64 ? 64 : (WGM == 2 ? BN + 4 : BN)) : BN + 1;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid_ = threadIdx.x;
+  // (opaque to the optimiser: inside the grouped kernel's tile loop the per-thread constants of EVERY tile shape -- staging offsets,
+  // LDS addresses -- would otherwise be hoisted in front of the loop and stay live together: 240 VGPRs instead of the widest shape's)
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63, wave = tid >> 6;
   const int lcol = lane & 31, lhalf = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = KS == 4 ? 0 : wave / WGN, wn = KS == 4 ? 0 : wave % WGN;
+  const int kq = KS == 4 ? wave * LG_BK : 0;        // first row of this wave's share of the K tile
   const int m0 = bid_y * BM, n0 = bid_x * BN;
   const int kb = bid_z * k_per_split;
   const int ke = max(min(K, kb + k_per_split), kb);      // K may be a device-side row bound below this split: no tiles
 
-  // staging registers: each thread moves (BM*BK/4)/256 = 2*TM float4 of A and 2*TN of B per tile
-  constexpr int NA = 2 * TM, NB = 2 * TN;
+  // staging registers: each thread moves (BM*BK/4)/256 float4 of A and (BN*BK/4)/256 of B per tile (2 TM and 2 TN on the 2 x 2 grid)
+  constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;
+  static_assert(NA >= 1 && NB >= 1, "tile too small for 256 threads");
   constexpr int ST = LG_ST;  // register prefetch depth: loads are issued ST tiles ahead of their MFMAs
   float4 rsa[ST][NA], rsb[ST][NB];
 
@@ -237,8 +256,8 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
       float af[LG_BK / 2], bf[LG_BK / 2];
 #pragma unroll
       for (int kk = 0; kk < LG_BK / 2; ++kk) {
-        af[kk] = As[(2 * kk + lhalf) * LDA_S + wm * 32 + lcol];
-        bf[kk] = Bs[(2 * kk + lhalf) * LDB_S + wn * 32 + lcol];
+        af[kk] = As[(kq + 2 * kk + lhalf) * LDA_S + wm * 32 + lcol];
+        bf[kk] = Bs[(kq + 2 * kk + lhalf) * LDB_S + wn * 32 + lcol];
       }
       __builtin_amdgcn_sched_barrier(0);
 #ifdef LG_PROBE
@@ -271,12 +290,14 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
     __builtin_amdgcn_s_setprio(0);
     }
     if (colsum_ws != nullptr && bid_x == 0) {
-      if (BM == 64) {
-        // all four waves share the column sums (wave q takes k rows 8q .. 8q+7 of column tid & 63): 8 additions per
-        // thread and K tile instead of 32 on wave 0 alone, whose MFMAs they would hold up (4.17)
-        const int c = tid & 63, q = tid >> 6;
+      if (A_KM && (BM == 64 || WGM != 2)) {
+        // all four waves share the column sums (BM = 64: wave q takes k rows 8q .. 8q+7 of column tid & 63): 8 additions per
+        // thread and K tile instead of 32 on wave 0 alone, whose MFMAs they would hold up (4.17); in general 256 / BM groups of
+        // threads, group q on rows q BK / groups .. of column tid % BM
+        constexpr int CG = 256 / BM;
+        const int c = tid % BM, q = tid / BM;
 #pragma unroll
-        for (int kr = 0; kr < LG_BK / 4; ++kr) csum += As[(q * (LG_BK / 4) + kr) * LDA_S + c];
+        for (int kr = 0; kr < BK / CG; ++kr) csum += As[(q * (BK / CG) + kr) * LDA_S + c];
       } else if (tid < BM) {
 #pragma unroll 8
         for (int kr = 0; kr < LG_BK; ++kr) csum += As[kr * LDA_S + tid];
@@ -287,16 +308,16 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
   // Software pipeline: the loads of tile t+ST are issued while tile t is multiplied.  Every load is
   // unconditional (tiles past the end are masked to zero by ld4), so the steady-state loop is branch
   // free and the compiler can retire each stage with a counted vmcnt instead of vmcnt(0).
-  const int ntiles = (ke - kb + LG_BK - 1) / LG_BK;
+  const int ntiles = (ke - kb + BK - 1) / BK;
   if (ntiles > 0) {
 #pragma unroll
-    for (int s = 0; s < ST; ++s) load_tile(rsa[s], rsb[s], kb + s * LG_BK);
+    for (int s = 0; s < ST; ++s) load_tile(rsa[s], rsb[s], kb + s * BK);
     int t = 0;
     if (FAST && interior) {
       // steady state of an interior tile: every tile requested here (t + s + ST) lies entirely inside [kb, ke), so the
       // loop body is straight-line code with clamp-free loads -- with a second (general) path inside the loop the
       // compiler's wait counters go to vmcnt(0) at the LDS stores, i.e. they wait for the loads just issued
-      const int nfull = (ke - kb) / LG_BK;
+      const int nfull = (ke - kb) / BK;
       for (; t + 2 * ST <= nfull; t += ST) {
 #pragma unroll
         for (int s = 0; s < ST; ++s) {
@@ -307,7 +328,7 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
           LG_T(t2);
           __syncthreads();
           LG_T(t3);
-          load_tile_fast(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
+          load_tile_fast(rsa[s], rsb[s], kb + (t + s + ST) * BK);
           compute_tile();
           LG_T(t5);
 #ifdef LG_PROBE
@@ -322,7 +343,7 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
         __syncthreads();                      // previous tile fully consumed
         store_tile(rsa[s], rsb[s]);
         __syncthreads();
-        load_tile(rsa[s], rsb[s], kb + (t + s + ST) * LG_BK);
+        load_tile(rsa[s], rsb[s], kb + (t + s + ST) * BK);
         compute_tile();
       }
     }
@@ -344,6 +365,22 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
 #endif
   // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   float* Cz = C + (size_t)bid_z * (size_t)M * ldc;  // split slabs (bid_z == 0 when unsplit)
+  if (KS == 4) {
+    // four partial accumulators of the same 32 x 32 outputs: red[wave][r][lane] in the A tile buffer (16 KB), then thread
+    // (lane, wave q) sums r = 4 q .. 4 q + 3 over the waves in wave order
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) As[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
+    __syncthreads();
+    const int gn = n0 + lcol;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * wave + j;
+      const float v = ((As[r * 64 + lane] + As[(16 + r) * 64 + lane]) + As[(32 + r) * 64 + lane]) + As[(48 + r) * 64 + lane];
+      const int gm = m0 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+      if (gm < M && gn < N) Cz[(size_t)gm * ldc + gn] = v;
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -356,12 +393,18 @@ gemm_f32_mfma_body(const float* __restrict__ A, const float* __restrict__ B, con
         if (gm < M && gn < N) Cz[(size_t)gm * ldc + gn] = acc[i][j][r] + bv;
       }
     }
+  }
   if (colsum_ws != nullptr && bid_x == 0) {
-    if (BM == 64) {                      // the four row-quarter partials of a column, added in quarter order
+    if (A_KM && (BM == 64 || WGM != 2)) {   // the row-group partials of a column (four quarters when BM = 64), added in group order
+      constexpr int CG = 256 / BM;
       __syncthreads();
-      As[tid] = csum;
+      Bs[tid] = csum;
       __syncthreads();
-      if (tid < 64) csum = ((As[tid] + As[64 + tid]) + As[128 + tid]) + As[192 + tid];
+      if (tid < BM) {
+        csum = Bs[tid];
+#pragma unroll
+        for (int q = 1; q < CG; ++q) csum += Bs[q * BM + tid];
+      }
     }
     if (tid < BM && m0 + tid < M) colsum_ws[(size_t)bid_z * M + m0 + tid] = csum;
   }
@@ -372,8 +415,12 @@ __global__ void __launch_bounds__(256)
 gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
                      float* __restrict__ C, float* __restrict__ colsum_ws, int M, int N, int K, int lda, int ldb,
                      int ldc, int k_per_split, const int* __restrict__ Kdev) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int LDA_S = A_KM ? (BM == 64 ? 64 : BM + 4) : BM + 1, LDB_S = B_KM ? (BN == 64 ? 64 : BN + 4) : BN + 1;
+  __shared__ __attribute__((aligned(16))) float As[LG_BK * LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[LG_BK * LDB_S];
   gemm_f32_mfma_body<TM, TN, A_KM, B_KM, VEC>(A, B, bias, C, colsum_ws, M, N, msde_true_rows(K, Kdev), lda, ldb, ldc,
-                                              k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
+                                              k_per_split, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 
 // Grouped weight gradients: ONE launch runs the split-M GEMMs of many layers.  probs[p] = 16 int64:
@@ -384,6 +431,8 @@ gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, c
 __device__ __forceinline__ void
 gemm_grouped_wgrad_body(const long long* __restrict__ probs, const int* __restrict__ prefix, int count, int total,
                           int xcd_order) {
+  // one LDS buffer for every tile shape: As = lds (<= 4096 floats), Bs = lds + 4096 (<= 4096 floats)
+  __shared__ __attribute__((aligned(16))) float lds[8192];
   // grid == total: one tile per workgroup.  grid < total (msde_linear_bwd_w_grouped_ex with a width limit): each
   // workgroup walks tiles blockIdx.x, + gridDim.x, ...: the launch then occupies at most gridDim.x workgroup slots, so it
   // can run BESIDE a latency-critical chain on another stream without taking every CU (same results, tile by tile).
@@ -412,10 +461,21 @@ gemm_grouped_wgrad_body(const long long* __restrict__ probs, const int* __restri
     }
     const int bx = local % tx, by = (local / tx) % ty, bz = local / (tx * ty);
     // product C[N][K] = gY^T X: "M" of the product = N, "N" = K, reduction = M (see msde_linear_bwd_w)
-    if (e[11])
-      gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz, e[15] != 0);
+    // e[15]: bit 0 = edge tiles on the fast path, bits 1.. = tile shape (msde_linear_bwd_w_describe_ld)
+    const int shape = (int)(e[15] >> 1);
+    float* As = lds;
+    float* Bs = lds + 4096;
+    if ((MSDE_WGRAD_NARROW & 1) && e[11] && shape == 1)          // 32 x 128: the four waves side by side along K
+      gemm_f32_mfma_body<1, 1, true, true, true, 1, 1>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz, As, Bs, true);
+    else if ((MSDE_WGRAD_NARROW & 2) && e[11] && shape == 2)     // 128 x 32
+      gemm_f32_mfma_body<1, 1, true, true, true, 4, 1>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz, As, Bs, true);
+    else if ((MSDE_WGRAD_NARROW & 4) && e[11] && shape == 3)     // 32 x 32, the 128 rows of a K tile split over the waves
+      gemm_f32_mfma_body<1, 1, true, true, true, 1, 4>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz, As, Bs, true);
+    else if (e[11])
+      gemm_f32_mfma_body<1, 1, true, true, true>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz, As, Bs,
+                                                 (e[15] & 1) != 0);
     else
-      gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz);
+      gemm_f32_mfma_body<1, 1, true, true, false>(gY, X, nullptr, slabs, cs, N, K, Mt, ldg, ldx, K, kps, bx, by, bz, As, Bs);
     __syncthreads();                 // the next tile reuses the LDS stages
   }
 }
@@ -578,8 +638,12 @@ static inline void wgrad_split(int M, int N, int K, int* splits, int* k_per_spli
 #ifndef MSDE_WGRAD_MIN_ROWS
 #define MSDE_WGRAD_MIN_ROWS 256
 #endif
+#ifndef MSDE_WGRAD_TARGET_KS
+#define MSDE_WGRAD_TARGET_KS 64
+#endif
 static inline void wgrad_split_batched(int M, int N, int K, int* splits, int* k_per_split) {
-  const int target = MSDE_WGRAD_TARGET;
+  // (a product that is narrow on both sides runs on the k-split tile, four times the rows per unit of time: fewer, longer splits)
+  const int target = (N <= 32 && K <= 32 && (MSDE_WGRAD_NARROW & 4)) ? MSDE_WGRAD_TARGET_KS : MSDE_WGRAD_TARGET;
   wgrad_split_for(M, N, K, target, splits, k_per_split);
 }
 static inline void wgrad_split_for(int M, int N, int K, int target, int* splits, int* k_per_split) {
@@ -737,12 +801,22 @@ extern "C" int msde_linear_bwd_w_describe_ld(const float* gY, int ldg, const flo
   bool vec = aligned16(gY) && aligned16(X) && (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldx % 4 == 0);
   int splits, kps;
   wgrad_group_plan(M, N, K, &splits, &kps);
-  int tx = (K + 63) / 64, ty = (N + 63) / 64;
   vec = vec && (kps % 4 == 0);
+  // tile shape (gemm_grouped_wgrad_body): outputs are N x K.  A 32-wide (or narrower) side leaves half of the 64 x 64 tile's waves
+  // idle -- 32 x 128 / 128 x 32 tiles put the four waves side by side along the wide dimension, and a product that is narrow on
+  // BOTH sides lets them split the rows of a 128-row K tile (wgrad_narrow_body).  Same splits as the 64 x 64 plan.
+  int shape = 0;
+  if (vec) {
+    if (N <= 32 && K <= 32) shape = (MSDE_WGRAD_NARROW & 4) ? 3 : 0;
+    else if (N <= 32 && K > 64) shape = (MSDE_WGRAD_NARROW & 1) ? 1 : 0;
+    else if (K <= 32 && N > 64) shape = (MSDE_WGRAD_NARROW & 2) ? 2 : 0;
+  }
+  const int bm = (shape == 1 || shape == 3) ? 32 : shape == 2 ? 128 : 64, bn = (shape == 2 || shape == 3) ? 32 : shape == 1 ? 128 : 64;
+  int tx = (K + bn - 1) / bn, ty = (N + bm - 1) / bm;
   // (round 4, tools/ab_multi.sh on one box: edge tiles on the fast path 2.70-2.73 vs 2.69-2.72 ms, the 128-VGPR build
   // MSDE_WGRAD_OCC4 2.70-2.71, register prefetch two / three tiles deep (-DLG_ST) 2.72 vs 2.71: none of them moves the step)
   const int relax = 0;
-  row[12] = ldg; row[13] = ldx; row[14] = reinterpret_cast<long long>(rows_dev); row[15] = relax;
+  row[12] = ldg; row[13] = ldx; row[14] = reinterpret_cast<long long>(rows_dev); row[15] = relax | (shape << 1);
   row[0] = reinterpret_cast<long long>(gY);
   row[1] = reinterpret_cast<long long>(X);
   row[2] = reinterpret_cast<long long>(slabs);

@@ -1694,3 +1694,40 @@ def test_fanout_sums_column_blocks_in_one_launch(dev):
     y = torch.empty(E, D, device=dev)
     assert lib.msde_dd_sum_rows_n(ctypes.cast(arr, ctypes.c_void_p), ctypes.cast(lds, ctypes.c_void_p), 2, E, D,
                                   ctypes.c_void_p(y.data_ptr()), None) != 0
+
+
+def test_grouped_wgrad_narrow_tile_shapes(dev):
+    """Weight / bias gradients of layers with a 32-wide (or narrower) side run on their own tile shapes inside the grouped launch
+    (32 x 128 and 128 x 32: the four waves side by side; 32 x 32 with the rows of a 128-row K tile split over the waves --
+    msde_linear_bwd_w_describe_ld): each against the fp64 product, row counts that are not multiples of the K tile, widths of 8 and
+    16 (columns beyond the operand read from its last float4, never stored), and bit-identical on a second run."""
+    from moleculesde_amd import hip
+    torch.manual_seed(33)
+    shapes = [(35186, 32, 300), (5000, 32, 128), (35186, 128, 32), (4099, 32, 72), (3588, 16, 364), (3588, 16, 16),
+              (52680, 16, 32), (1000, 32, 32), (333, 32, 32), (777, 8, 200), (2049, 300, 8), (3588, 32, 64)]
+    layers = []
+    for M, N, K in shapes:
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev, requires_grad=True)
+        b = torch.randn(N, device=dev, requires_grad=True)
+        g = torch.randn(M, N, device=dev)
+        layers.append((x, w, b, g))
+
+    def run():
+        for x, w, b, g in layers:
+            w.grad = b.grad = None
+        slabs.begin_param_grad_batch()
+        for x, w, b, g in layers:
+            hip.linear(x, w, b).backward(g)
+        slabs.finish_param_grad_batch()
+        torch.cuda.synchronize()
+        return [(w.grad.clone(), b.grad.clone()) for x, w, b, g in layers]
+
+    got, again = run(), run()
+    for (M, N, K), (x, w, b, g), (gw, gb), (gw2, gb2) in zip(shapes, layers, got, again):
+        ref = g.double().t() @ x.double()
+        refb = g.double().sum(0)
+        ew = float((gw.double() - ref).abs().max() / ref.abs().max())
+        eb = float((gb.double() - refb).abs().max() / refb.abs().max())
+        assert ew < 5e-6 and eb < 5e-6, (M, N, K, ew, eb)          # fp32 accumulation over <= 52 680 rows against fp64
+        assert torch.equal(gw, gw2) and torch.equal(gb, gb2), (M, N, K)
