@@ -13,6 +13,9 @@
 // writes are both bank-conflict free.  Next tile's global loads are issued before the current tile's
 // MFMAs (register prefetch).  The split-M weight gradient writes per-split slabs that a second
 // kernel sums in a fixed order: bitwise reproducible, no float atomics.
+// Round 6: inside the grouped weight-gradient launch a layer with a 32-wide (or narrower) side runs the same tile body with
+// another wave layout (template parameters WGM / KS: 32 x 128, 128 x 32, or 32 x 32 with the K tile's rows split over the
+// waves) instead of leaving two or three of the four waves idle -- see gemm_f32_mfma_body and msde_linear_bwd_w_describe_ld.
 #include "msde_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
