@@ -60,6 +60,33 @@ def test_library_records_no_memset_nodes():
             assert "hipMemset" not in code, f
 
 
+def test_grouped_wgrad_problem_rows_name_their_tile_shape():
+    """msde_linear_bwd_w_describe_ld is host code (it fills one row of the grouped launch's problem table): the tile shape it picks
+    for a layer -- outputs are N x K -- and the number of workgroups it reports follow the rule in include/msde_hip.h: 64 x 64;
+    N <= 32 < 64 < K: 32 x 128; K <= 32 < 64 < N: 128 x 32; both <= 32: 32 x 32 with the K tile split over the waves; operands off
+    the 16-byte vector path keep 64 x 64.  The splits are the shape-only plan of msde_linear_bwd_w_splits in every case."""
+    import ctypes
+    from moleculesde_amd import _lib
+    lib = _lib.load()
+    row = (ctypes.c_longlong * 16)()
+    base = 1 << 20                       # fake 16-byte aligned device addresses: nothing is dereferenced here
+    ptr = lambda off=0: ctypes.c_void_p(base + off)
+    ceil = lambda a, b: (a + b - 1) // b
+    cases = [(3588, 300, 600, 0), (35186, 32, 300, 1), (70372, 32, 128, 1), (35186, 128, 32, 2), (35186, 32, 72, 1),
+             (35186, 32, 64, 0), (35186, 32, 32, 3), (3588, 16, 364, 1), (3588, 16, 16, 3), (52680, 16, 32, 3), (2049, 300, 8, 2),
+             (52680, 60, 30, 0), (52680, 1, 60, 0)]
+    for M, N, K, shape in cases:
+        n = lib.msde_linear_bwd_w_describe_ld(ptr(), N, ptr(1 << 16), K, M, N, K, 1, ptr(1 << 18), None, row)
+        splits = lib.msde_linear_bwd_w_splits(M, N, K)
+        bm, bn = {0: (64, 64), 1: (32, 128), 2: (128, 32), 3: (32, 32)}[shape]
+        assert row[15] >> 1 == shape, (M, N, K, row[15])
+        assert (row[9], row[10], row[7]) == (ceil(K, bn), ceil(N, bm), splits), (M, N, K, list(row))
+        assert n == ceil(K, bn) * ceil(N, bm) * splits
+    # an operand that is not 16-byte aligned leaves the vector path: 64 x 64 whatever the widths
+    lib.msde_linear_bwd_w_describe_ld(ptr(4), 32, ptr(1 << 16), 300, 35186, 32, 300, 1, ptr(1 << 18), None, row)
+    assert row[15] >> 1 == 0 and row[11] == 0
+
+
 def test_extend_graph_path_graph_known_answer():
     """dataset_3D.py:12-35 on a 7-node path: pairs within <= 4 bonds, no self loops, sorted."""
     from moleculesde_amd.batch import extend_graph_index
