@@ -20,6 +20,10 @@ import torch
 
 from .. import _lib, hip, slabs, wcache
 
+# the C per-channel weight gradients of an edge layer's node branch as ONE product x^T gXV (False: C products with 16-wide operands);
+# --full 3.209 vs 3.211 ms (profiles/r06_ab_merge_channel_wgrad.txt): 16 problems fewer in the grouped launch, the same time
+MERGE_CHANNEL_WGRAD = True
+
 AC_LD, XP_LD = 32, 120
 _p = hip._p
 
@@ -188,8 +192,14 @@ def edge_backward(cfg, sv, AC, flags, chans, offs, T, gS, gZG2, gx0, gx0_accumul
             G[b + 12], G[b + 13] = wg(GHm, s.xcat, True)
             G[b + 5] = slabs.colsum_leaf(GV)
             gWv = _empty(C * F, 16, device=dev)
-            for c in range(C):          # x W_c with W_c stored [in, out]: gW_c = x^T g(xW_c)
-                wg(s.x, gXV[:, 16 * c:16 * c + 16], False, out_w=gWv[c * F:(c + 1) * F])
+            # x W_c with W_c stored [in, out]: gW_c = x^T g(xW_c) -- the C channels share x, and their g(xW_c) are adjacent column
+            # blocks of gXV: ONE product x^T gXV [F, 16 C] whose column block c is channel c's gradient (the slab reduction
+            # writes the blocks in place) instead of C products with 16-wide operands (half-used matrix-core tiles)
+            if MERGE_CHANNEL_WGRAD:
+                slabs.weight_grad_blocks(s.x, gXV, False, [(16 * c, 16, gWv[c * F:(c + 1) * F], 0) for c in range(C)])
+            else:
+                for c in range(C):
+                    wg(s.x, gXV[:, 16 * c:16 * c + 16], False, out_w=gWv[c * F:(c + 1) * F])
             G[b + 4] = gWv
         # second q/k layers (block diagonal) and the gradient of their tanh hidden layer
         gH = _empty(N, W2, device=dev)
